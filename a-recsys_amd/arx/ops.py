@@ -1,0 +1,309 @@
+"""Thin tensor-level wrappers over the C ABI (include/arx.h).
+
+torch tensors are used ONLY as device-memory holders: every function passes
+`tensor.data_ptr()` and explicit sizes to libarx.so; no torch arithmetic runs
+on the hot path.  All launches go to torch's current HIP stream so that
+torch.cuda events / torch.distributed (RCCL) order correctly against them.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+from ._lib import call
+
+KEY_NONE = 0x7FFFFFFF
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise ValueError("%s must be a device tensor (the HIP path has no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise ValueError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous() and t.dim() == 1:
+        raise ValueError("%s must be contiguous" % name)
+
+
+def _ld(t):
+    """leading dimension (elements) of a 2-D row-major tensor or view"""
+    if t.dim() == 1:
+        return t.shape[0]
+    if t.stride(-1) != 1:
+        raise ValueError("inner dimension must be contiguous")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+class Workspace(object):
+    """Grow-only device scratch buffer (caller-owned workspace of the C ABI)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        nbytes = int(nbytes)
+        if nbytes <= 0:
+            return 0, 0
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+        return self.buf.data_ptr(), self.buf.numel()
+
+
+def device_info():
+    import ctypes as C
+    cu, wave, lds = C.c_int(), C.c_int(), C.c_int()
+    arch = C.create_string_buffer(64)
+    call("arx_device_info", C.byref(cu), C.byref(wave), C.byref(lds), arch, 64)
+    return {"cu_count": cu.value, "wave_size": wave.value, "lds_bytes": lds.value,
+            "arch": arch.value.decode()}
+
+
+# ---- a4/a7 ---------------------------------------------------------------
+def csr_expand(vals, starts, lens, row_ids, capacity, ws, pad_token=KEY_NONE, pad_seg=-1,
+               seg_base=0, coef_scale=1.0, want_coef=False, out=None):
+    """batch_slice2 / batch_segids2 (mulhot_index.py:48-67) on device.
+
+    Returns (token_ids[capacity], segids[capacity], offsets[B+1], total[1], coef or None)."""
+    B = int(row_ids.shape[0]) if row_ids is not None else int(lens.shape[0])
+    dev = vals.device
+    for t, n in ((vals, 'vals'), (starts, 'starts'), (lens, 'lens'), (row_ids, 'row_ids')):
+        _chk(t, torch.int32, n)
+    if out is None:
+        tok = torch.empty(capacity, dtype=torch.int32, device=dev)
+        seg = torch.empty(capacity, dtype=torch.int32, device=dev)
+        offs = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        tot = torch.empty(1, dtype=torch.int32, device=dev)
+        coef = torch.empty(capacity, dtype=torch.float32, device=dev) if want_coef else None
+    else:
+        tok, seg, offs, tot, coef = out
+    wsp, wsn = ws.get(_lib.lib.arx_csr_expand_workspace_bytes(B))
+    call("arx_csr_expand", _p(vals), _p(starts), _p(lens), _p(row_ids), B, _p(tok), _p(seg),
+         int(capacity), _p(offs), _p(tot), int(pad_token), int(pad_seg), int(seg_base),
+         float(coef_scale), _p(coef), wsp, wsn, _stream())
+    return tok, seg, offs, tot, coef
+
+
+def sparse_site_onehot(cat_map, ids, row_base, coef, keys_out, src_out, coef_out):
+    call("arx_sparse_site_onehot", _p(cat_map), _p(ids), int(ids.shape[0]), int(row_base),
+         float(coef), _p(keys_out), _p(src_out), _p(coef_out), _stream())
+
+
+# ---- a5 ---------------------------------------------------------------------
+def gather_onehot(E, bias, cat_map, ids, out, scale=1.0, accumulate=False, bias_out=None):
+    _chk(E, torch.float32, 'E'); _chk(ids, torch.int32, 'ids'); _chk(out, torch.float32, 'out')
+    call("arx_gather_onehot_fwd", _p(E), _p(bias), _p(cat_map), _p(ids), int(ids.shape[0]),
+         int(E.shape[1]), float(scale), int(bool(accumulate)), _p(out), _ld(out), _p(bias_out),
+         _stream())
+    return out
+
+
+def gather_mulhot_mean(E, bias, vals, starts, lens, ids, out, scale=1.0, accumulate=False,
+                       bias_out=None):
+    _chk(E, torch.float32, 'E'); _chk(ids, torch.int32, 'ids'); _chk(out, torch.float32, 'out')
+    call("arx_gather_mulhot_mean_fwd", _p(E), _p(bias), _p(vals), _p(starts), _p(lens), _p(ids),
+         int(ids.shape[0]), int(E.shape[1]), float(scale), int(bool(accumulate)), _p(out),
+         _ld(out), _p(bias_out), _stream())
+    return out
+
+
+# ---- a9 -----------------------------------------------------------------------
+def dot_score(U, T, tbias, score):
+    call("arx_dot_score_fwd", _p(U), _ld(U), _p(T), _ld(T), _p(tbias), int(U.shape[0]),
+         int(U.shape[1]), _p(score), _stream())
+    return score
+
+
+def dot_score_bwd(U, T, dscore, dU, acc_dU, dT):
+    call("arx_dot_score_bwd", _p(U), _ld(U), _p(T), _ld(T), _p(dscore), int(U.shape[0]),
+         int(U.shape[1]), _p(dU), _ld(dU), int(bool(acc_dU)), _p(dT),
+         _ld(dT) if dT is not None else 0, _stream())
+
+
+# ---- a8 -----------------------------------------------------------------------
+def gemm(A, B, C, ws, transA=False, transB=False, alpha=1.0, beta=0.0, col_bias=None):
+    """C[M,N] = alpha * op(A) . op(B) + beta * C + col_bias  (fp32 MFMA)."""
+    M, N = int(C.shape[0]), int(C.shape[1])
+    K = int(A.shape[0] if transA else A.shape[1])
+    kb = int(B.shape[1] if transB else B.shape[0])
+    if K != kb:
+        raise ValueError("gemm: inner dimensions differ (%d vs %d)" % (K, kb))
+    wsp, wsn = ws.get(_lib.lib.arx_gemm_f32_workspace_bytes(M, N, K))
+    call("arx_gemm_f32", int(bool(transA)), int(bool(transB)), M, N, K, float(alpha), _p(A),
+         _ld(A), _p(B), _ld(B), float(beta), _p(C), _ld(C), _p(col_bias), wsp, wsn, _stream())
+    return C
+
+
+# ---- a14 ------------------------------------------------------------------------
+def pos_mask_scatter(user_ids, pos_ptr, pos_items, item2slot, mask, value):
+    call("arx_pos_mask_scatter", _p(user_ids), int(user_ids.shape[0]), _p(pos_ptr), _p(pos_items),
+         _p(item2slot), _p(mask), _ld(mask), int(value), _stream())
+
+
+def slot_map_set(item2slot, ids, clear=False):
+    call("arx_slot_map_set", _p(item2slot), _p(ids), int(ids.shape[0]), int(bool(clear)), _stream())
+
+
+# ---- a10-a12 -----------------------------------------------------------------------
+def loss_mw(logits, tscore, mask, batch_loss, dlogits, dtscore, gscale, row_w=None,
+            mask_rows=0):
+    B, S = int(logits.shape[0]), int(logits.shape[1])
+    call("arx_loss_mw_fwdbwd", _p(logits), _ld(logits), _p(tscore), _p(mask),
+         _ld(mask) if mask is not None else 0, int(mask_rows), float(gscale), _p(row_w), B, S,
+         _p(batch_loss), _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _p(dtscore),
+         _stream())
+
+
+def loss_warp(logits, target, mask, batch_loss, dlogits, gscale, row_w=None, mask_rows=0):
+    B, V = int(logits.shape[0]), int(logits.shape[1])
+    call("arx_loss_warp_fwdbwd", _p(logits), _ld(logits), _p(target), _p(mask),
+         _ld(mask) if mask is not None else 0, int(mask_rows), float(gscale), _p(row_w), B, V,
+         _p(batch_loss), _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _stream())
+
+
+def loss_ce(logits, target, batch_loss, dlogits, gscale, row_w=None):
+    B, V = int(logits.shape[0]), int(logits.shape[1])
+    call("arx_loss_ce_fwdbwd", _p(logits), _ld(logits), _p(target), float(gscale), _p(row_w), B, V,
+         _p(batch_loss), _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _stream())
+
+
+def loss_warp_eval(logits, target, mask, margin_rank, true_rank, mask_rows=0):
+    B, V = int(logits.shape[0]), int(logits.shape[1])
+    call("arx_loss_warp_eval", _p(logits), _ld(logits), _p(target), _p(mask),
+         _ld(mask) if mask is not None else 0, int(mask_rows), B, V, _p(margin_rank),
+         _p(true_rank), _stream())
+
+
+# ---- a17 ---------------------------------------------------------------------------
+def key_bits_for(nrows):
+    return max(1, int(math.ceil(math.log2(max(2, int(nrows))))))
+
+
+def sparse_adagrad(E, acc, bias, bias_acc, keys, src, coef, G, Gb, lr_dev, ws, gscale_dev=None,
+                   n=None):
+    n = int(keys.shape[0]) if n is None else int(n)
+    wsp, wsn = ws.get(_lib.lib.arx_sparse_adagrad_workspace_bytes(n))
+    call("arx_sparse_adagrad", _p(E), _p(acc), _p(bias), _p(bias_acc), int(E.shape[1]), _p(keys),
+         _p(src), _p(coef), n, _p(G), _ld(G), _p(Gb), _p(lr_dev), _p(gscale_dev),
+         key_bits_for(E.shape[0]), wsp, wsn, _stream())
+
+
+def adagrad_dense(w, acc, g, lr_dev, gscale_dev=None):
+    call("arx_adagrad_dense", _p(w), _p(acc), _p(g), int(w.numel()), _p(lr_dev), _p(gscale_dev),
+         _stream())
+
+
+def sq_norm_accum(x, out_accum, d=1, row_scale=None, n=None):
+    call("arx_sq_norm_accum", _p(x), int(x.numel() if n is None else n), int(d), _p(row_scale),
+         _p(out_accum), _stream())
+
+
+def clip_coef(sqnorm, max_norm, coef_out, gnorm_out=None):
+    call("arx_clip_coef", _p(sqnorm), float(max_norm), _p(coef_out), _p(gnorm_out), _stream())
+
+
+# ---- utilities -------------------------------------------------------------------------
+def fill_f32(t, v):
+    call("arx_fill_f32", _p(t), int(t.numel()), float(v), _stream())
+
+
+def fill_i32(t, v):
+    call("arx_fill_i32", _p(t), int(t.numel()), int(v), _stream())
+
+
+def fill_u8(t, v):
+    call("arx_fill_u8", _p(t), int(t.numel()), int(v), _stream())
+
+
+def axpby(a, x, b, y, n=None):
+    call("arx_axpby", float(a), _p(x), float(b), _p(y), int(y.numel() if n is None else n), _stream())
+
+
+def add_rows_bcast(a, x, b, y):
+    call("arx_add_rows_bcast", float(a), _p(x), _ld(x), int(x.shape[0]), float(b), _p(y), _ld(y),
+         int(y.shape[0]), int(y.shape[1]), _stream())
+
+
+def row_sum(x, out, accumulate=False):
+    call("arx_row_sum", _p(x), _ld(x), int(x.shape[0]), int(x.shape[1]), _p(out),
+         int(bool(accumulate)), _stream())
+
+
+def col_sum(x, out):
+    call("arx_col_sum", _p(x), _ld(x), int(x.shape[0]), int(x.shape[1]), _p(out), _stream())
+
+
+def sum_scaled(x, scale, out, n=None):
+    call("arx_sum_scaled", _p(x), int(x.numel() if n is None else n), float(scale), _p(out), _stream())
+
+
+def dropout_fwd(x, keep_prob, seed, y, keep_mask):
+    call("arx_dropout_fwd", _p(x), int(x.numel()), float(keep_prob), int(seed), _p(y),
+         _p(keep_mask), _stream())
+
+
+def dropout_bwd(dy, keep_mask, keep_prob, dx):
+    call("arx_dropout_bwd", _p(dy), _p(keep_mask), int(dy.numel()), float(keep_prob), _p(dx), _stream())
+
+
+def act_fwd(x, kind, y):
+    call("arx_act_fwd", _p(x), int(x.numel()), int(kind), _p(y), _stream())
+
+
+def act_bwd(y, dy, kind, dx):
+    call("arx_act_bwd", _p(y), _p(dy), int(y.numel()), int(kind), _p(dx), _stream())
+
+
+def topk(logits, k, values, indices):
+    call("arx_topk", _p(logits), _ld(logits), int(logits.shape[0]), int(logits.shape[1]), int(k),
+         _p(values), _p(indices), _stream())
+
+
+def lstm_fwd(x, W, b, L, B, din, h, forget_bias, hs, cs, gates):
+    call("arx_lstm_fwd", _p(x), _p(W), _p(b), int(L), int(B), int(din), int(h), float(forget_bias),
+         _p(hs), _p(cs), _p(gates), _stream())
+
+
+def lstm_bwd(W, hs, cs, gates, dhs, L, B, din, h, dz):
+    call("arx_lstm_bwd", _p(W), _p(hs), _p(cs), _p(gates), _p(dhs), int(L), int(B), int(din),
+         int(h), _p(dz), _stream())
+
+
+def seq_weights(w, L, B, out):
+    call("arx_seq_weights", _p(w), int(L), int(B), _p(out), _stream())
+
+
+class CapturedGraph(object):
+    """A hipGraph of one step (arx_capture_* in include/arx.h)."""
+
+    def __init__(self):
+        import ctypes as C
+        self._exec = C.c_void_p(0)
+
+    def begin(self):
+        call("arx_capture_begin", _stream())
+
+    def end(self):
+        import ctypes as C
+        call("arx_capture_end", _stream(), C.byref(self._exec))
+
+    def launch(self):
+        call("arx_graph_launch", self._exec, _stream())
+
+    def __del__(self):
+        try:
+            if self._exec:
+                _lib.lib.arx_graph_destroy(self._exec)
+        except Exception:
+            pass

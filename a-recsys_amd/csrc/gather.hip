@@ -1,0 +1,477 @@
+// gather.hip -- attribute-embedding lookups for gfx950 (HBM-bound kernels).
+//
+//  K1  arx_gather_mulhot_mean_fwd : CSR expand + row gather + segment-mean fused
+//  K2  arx_gather_onehot_fwd      : one-hot row gather (+bias)
+//  K5  arx_dot_score_fwd/bwd      : per-row dot product (target score)
+//      arx_csr_expand             : batch_slice2 / batch_segids2 (integer, bit-exact)
+//
+// Layout: a table row is d fp32 (d=128 -> 512 B).  A row is read by a
+// sub-group of LPR = pow2ceil(d/4) lanes, one float4 (16 B) per lane, so a
+// wave64 covers 64/LPR rows per instruction (2 rows at d=128) with fully
+// coalesced 16 B/lane accesses -- the coalescing sweet spot on CDNA4.
+#include "common.h"
+
+namespace arx {
+
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// ---------------------------------------------------------------------------
+// K2: one-hot gather
+// ---------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void k_gather_onehot(
+    const float* __restrict__ E, const float* __restrict__ bias,
+    const int32_t* __restrict__ cat_map, const int32_t* __restrict__ ids, int64_t B, int d,
+    float scale, int accumulate, float* __restrict__ out, int64_t ldo,
+    float* __restrict__ bias_out) {
+  constexpr int GPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % LPR;
+  const int gid = lane / LPR;
+  const int col = lig * 4;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave * GPW + gid; r < B; r += nwave * GPW) {
+    int id = ids[r];
+    int row = cat_map ? cat_map[id] : id;
+    if (col < d) {
+      float4 v = *reinterpret_cast<const float4*>(E + (int64_t)row * d + col);
+      float4* op = reinterpret_cast<float4*>(out + r * ldo + col);
+      float4 o = accumulate ? *op : make_float4(0.f, 0.f, 0.f, 0.f);
+      o.x += scale * v.x;
+      o.y += scale * v.y;
+      o.z += scale * v.z;
+      o.w += scale * v.w;
+      *op = o;
+    }
+    if (bias_out && lig == 0) {
+      float b = scale * bias[row];
+      bias_out[r] = accumulate ? bias_out[r] + b : b;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K1: multi-hot gather + segment-mean.  One LPR-lane sub-group per bag.  The
+// bag's token ids are fetched coalesced (lane j of the sub-group loads token
+// j), then broadcast with ds_bpermute so every lane issues the row loads of
+// up to 4 tokens back-to-back (4 x 16 B in flight per lane) before summing.
+// ---------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void k_gather_mulhot(
+    const float* __restrict__ E, const float* __restrict__ bias,
+    const int32_t* __restrict__ vals, const int32_t* __restrict__ starts,
+    const int32_t* __restrict__ lens, const int32_t* __restrict__ ids, int64_t B, int d,
+    float scale, int accumulate, float* __restrict__ out, int64_t ldo,
+    float* __restrict__ bias_out) {
+  constexpr int GPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % LPR;
+  const int gid = lane / LPR;
+  const int col = lig * 4;
+  const bool colok = col < d;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave * GPW + gid; r < B; r += nwave * GPW) {
+    const int id = ids[r];
+    const int st = starts[id];
+    const int len = lens[id];
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    float bacc = 0.f;
+    for (int j0 = 0; j0 < len; j0 += LPR) {
+      const int myj = j0 + lig;
+      const int mytok = (myj < len) ? vals[st + myj] : 0;
+      if (bias && myj < len) bacc += bias[mytok];
+      const int cnt = min(LPR, len - j0);
+      int t = 0;
+      for (; t + 4 <= cnt; t += 4) {
+        const int t0 = __shfl(mytok, t, LPR);
+        const int t1 = __shfl(mytok, t + 1, LPR);
+        const int t2 = __shfl(mytok, t + 2, LPR);
+        const int t3 = __shfl(mytok, t + 3, LPR);
+        if (colok) {
+          float4 v0 = *reinterpret_cast<const float4*>(E + (int64_t)t0 * d + col);
+          float4 v1 = *reinterpret_cast<const float4*>(E + (int64_t)t1 * d + col);
+          float4 v2 = *reinterpret_cast<const float4*>(E + (int64_t)t2 * d + col);
+          float4 v3 = *reinterpret_cast<const float4*>(E + (int64_t)t3 * d + col);
+          a0 = f4_add(a0, v0);
+          a1 = f4_add(a1, v1);
+          a2 = f4_add(a2, v2);
+          a3 = f4_add(a3, v3);
+        }
+      }
+      for (; t < cnt; ++t) {
+        const int t0 = __shfl(mytok, t, LPR);
+        if (colok) a0 = f4_add(a0, *reinterpret_cast<const float4*>(E + (int64_t)t0 * d + col));
+      }
+    }
+    a0 = f4_add(f4_add(a0, a1), f4_add(a2, a3));
+    const float flen = (float)len;
+    if (colok) {
+      float4* op = reinterpret_cast<float4*>(out + r * ldo + col);
+      float4 o = accumulate ? *op : make_float4(0.f, 0.f, 0.f, 0.f);
+      o.x += scale * (a0.x / flen);
+      o.y += scale * (a0.y / flen);
+      o.z += scale * (a0.z / flen);
+      o.w += scale * (a0.w / flen);
+      *op = o;
+    }
+    if (bias_out) {
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) bacc += __shfl_xor(bacc, o, LPR);
+      if (lig == 0) {
+        float b = scale * (bacc / flen);
+        bias_out[r] = accumulate ? bias_out[r] + b : b;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K5: dot score
+// ---------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void k_dot_fwd(const float* __restrict__ U, int64_t ldu,
+                                                 const float* __restrict__ T, int64_t ldt,
+                                                 const float* __restrict__ tbias, int64_t B,
+                                                 int d, float* __restrict__ score) {
+  constexpr int GPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % LPR;
+  const int gid = lane / LPR;
+  const int col = lig * 4;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave * GPW + gid; r < B; r += nwave * GPW) {
+    float s = 0.f;
+    if (col < d) {
+      float4 u = *reinterpret_cast<const float4*>(U + r * ldu + col);
+      float4 t = *reinterpret_cast<const float4*>(T + r * ldt + col);
+      s = u.x * t.x + u.y * t.y + u.z * t.z + u.w * t.w;
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, LPR);
+    if (lig == 0) score[r] = s + (tbias ? tbias[r] : 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dot_bwd(const float* __restrict__ U, int64_t ldu,
+                                                 const float* __restrict__ T, int64_t ldt,
+                                                 const float* __restrict__ ds, int64_t B, int d4,
+                                                 float* __restrict__ dU, int64_t lddu, int acc_dU,
+                                                 float* __restrict__ dT, int64_t lddt) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t total = B * d4;
+  for (; i < total; i += stride) {
+    const int64_t r = i / d4;
+    const int c = (int)(i % d4) * 4;
+    const float g = ds[r];
+    const float4 t = *reinterpret_cast<const float4*>(T + r * ldt + c);
+    float4* up = reinterpret_cast<float4*>(dU + r * lddu + c);
+    float4 o = acc_dU ? *up : make_float4(0.f, 0.f, 0.f, 0.f);
+    o.x += g * t.x;
+    o.y += g * t.y;
+    o.z += g * t.z;
+    o.w += g * t.w;
+    *up = o;
+    if (dT) {
+      const float4 u = *reinterpret_cast<const float4*>(U + r * ldu + c);
+      *reinterpret_cast<float4*>(dT + r * lddt + c) =
+          make_float4(g * u.x, g * u.y, g * u.z, g * u.w);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// csr_expand: three launches (block-local scan, scan of block totals, emit).
+// ---------------------------------------------------------------------------
+constexpr int kExpBlock = 256;
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int n = __shfl_up(v, o, 64);
+    if (lane >= o) v += n;
+  }
+  return v;
+}
+
+// returns exclusive prefix of v within the block, *block_total gets the sum
+__device__ __forceinline__ int block_excl_scan(int v, int* wsum /*[4]*/, int* block_total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = wave_incl_scan(v, lane);
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < w; ++i) base += wsum[i];
+  *block_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(kExpBlock) void k_expand_local(
+    const int32_t* __restrict__ lens, const int32_t* __restrict__ row_ids, int64_t B,
+    int32_t* __restrict__ offsets, int32_t* __restrict__ block_tot) {
+  __shared__ int wsum[4];
+  const int64_t r = blockIdx.x * (int64_t)kExpBlock + threadIdx.x;
+  int len = 0;
+  if (r < B) len = lens[row_ids ? row_ids[r] : (int32_t)r];
+  int tot;
+  int ex = block_excl_scan(len, wsum, &tot);
+  if (r < B) offsets[r] = ex;
+  if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kExpBlock) void k_expand_scan_blocks(
+    int32_t* __restrict__ block_tot, int nb, int32_t* __restrict__ offsets_B,
+    int32_t* __restrict__ total_out) {
+  __shared__ int wsum[4];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += kExpBlock) {
+    const int i = base + threadIdx.x;
+    int v = (i < nb) ? block_tot[i] : 0;
+    int tot;
+    int ex = block_excl_scan(v, wsum, &tot);
+    const int carry = carry_s;
+    if (i < nb) block_tot[i] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *offsets_B = carry_s;
+    if (total_out) *total_out = carry_s;
+  }
+}
+
+__global__ __launch_bounds__(kExpBlock) void k_expand_emit(
+    const int32_t* __restrict__ vals, const int32_t* __restrict__ starts,
+    const int32_t* __restrict__ lens, const int32_t* __restrict__ row_ids, int64_t B,
+    int32_t* __restrict__ offsets, const int32_t* __restrict__ block_base,
+    const int32_t* __restrict__ total_p, int32_t* __restrict__ token_ids,
+    int32_t* __restrict__ segids, int64_t capacity, int32_t pad_token, int32_t pad_seg,
+    int32_t seg_base, float coef_scale, float* __restrict__ coef_out) {
+  __shared__ int s_off[kExpBlock + 1];
+  __shared__ int s_start[kExpBlock];
+  __shared__ int s_len[kExpBlock];
+  const int64_t r = blockIdx.x * (int64_t)kExpBlock + threadIdx.x;
+  const int base = block_base[blockIdx.x];
+  int off = 0, len = 0, st = 0;
+  if (r < B) {
+    const int row = row_ids ? row_ids[r] : (int32_t)r;
+    len = lens[row];
+    st = starts[row];
+    off = offsets[r] + base;
+    offsets[r] = off;
+  }
+  s_off[threadIdx.x] = off - base;
+  s_start[threadIdx.x] = st;
+  s_len[threadIdx.x] = len;
+  const int64_t rem = B - blockIdx.x * (int64_t)kExpBlock;
+  const int nb_here = (int)(rem < kExpBlock ? rem : kExpBlock);
+  if (threadIdx.x == nb_here - 1) s_off[nb_here] = off - base + len;
+  if (nb_here == 0 && threadIdx.x == 0) s_off[0] = 0;
+  __syncthreads();
+  const int block_total = s_off[nb_here];
+  // token-parallel emit: binary search the bag of every output position
+  for (int p = threadIdx.x; p < block_total; p += kExpBlock) {
+    int lo = 0, hi = nb_here - 1;  // last bag with s_off[bag] <= p  (skipping empty bags)
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (s_off[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    const int64_t q = (int64_t)base + p;
+    if (q < capacity) {
+      token_ids[q] = vals[s_start[lo] + (p - s_off[lo])];
+      if (segids) segids[q] = seg_base + (int32_t)(blockIdx.x * (int64_t)kExpBlock + lo);
+      if (coef_out) coef_out[q] = coef_scale / (float)s_len[lo];
+    }
+  }
+  // pad tail [total, capacity)
+  const int total = *total_p;
+  const int64_t gtid = blockIdx.x * (int64_t)kExpBlock + threadIdx.x;
+  const int64_t gstride = (int64_t)gridDim.x * kExpBlock;
+  for (int64_t q = (int64_t)total + gtid; q < capacity; q += gstride) {
+    token_ids[q] = pad_token;
+    if (segids) segids[q] = pad_seg;
+    if (coef_out) coef_out[q] = 0.f;
+  }
+}
+
+__global__ void k_site_onehot(const int32_t* __restrict__ cat_map, const int32_t* __restrict__ ids,
+                              int64_t n, int32_t row_base, float coef,
+                              int32_t* __restrict__ keys_out, int32_t* __restrict__ src_out,
+                              float* __restrict__ coef_out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int id = ids[i];
+    keys_out[i] = cat_map ? cat_map[id] : id;
+    if (src_out) src_out[i] = row_base + (int32_t)i;
+    if (coef_out) coef_out[i] = coef;
+  }
+}
+
+static inline int grid_waves(int64_t nwaves) {
+  int64_t g = ceil_div(nwaves, 4);
+  int64_t cap = (int64_t)cu_count() * 8;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace arx
+
+using namespace arx;
+
+#define ARX_DISPATCH_LPR(lpr, CALL)                  \
+  switch (lpr) {                                     \
+    case 1: { constexpr int LPR = 1; CALL; } break;  \
+    case 2: { constexpr int LPR = 2; CALL; } break;  \
+    case 4: { constexpr int LPR = 4; CALL; } break;  \
+    case 8: { constexpr int LPR = 8; CALL; } break;  \
+    case 16: { constexpr int LPR = 16; CALL; } break;\
+    case 32: { constexpr int LPR = 32; CALL; } break;\
+    default: { constexpr int LPR = 64; CALL; } break;\
+  }
+
+static int check_d(const char* fn, int d) {
+  if (d <= 0 || d % 4 != 0 || d > 256) {
+    set_error("%s: embedding size d=%d unsupported (need d %% 4 == 0 and d <= 256)", fn, d);
+    return ARX_EUNSUPPORTED;
+  }
+  return ARX_OK;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" {
+
+int arx_gather_onehot_fwd(const float* E, const float* bias, const int32_t* cat_map,
+                          const int32_t* ids, int64_t B, int d, float scale, int accumulate,
+                          float* out, int64_t ldo, float* bias_out, void* stream) {
+  ARX_CHECK_ARG(E && ids && out, "arx_gather_onehot_fwd: null pointer");
+  ARX_CHECK_ARG((bias != nullptr) == (bias_out != nullptr) || bias_out == nullptr,
+                "arx_gather_onehot_fwd: bias_out requires bias");
+  ARX_CHECK_ARG(!(bias_out && !bias), "arx_gather_onehot_fwd: bias_out requires bias");
+  int rc = check_d("arx_gather_onehot_fwd", d);
+  if (rc) return rc;
+  ARX_CHECK_ARG(ldo % 4 == 0 && ldo >= d && aligned16(E) && aligned16(out),
+                "arx_gather_onehot_fwd: ldo %% 4 and 16-byte alignment required");
+  if (B <= 0) return ARX_OK;
+  const int lpr = lanes_per_row(d);
+  const int64_t nwaves = ceil_div(B, 64 / lpr);
+  ARX_DISPATCH_LPR(lpr, (k_gather_onehot<LPR><<<grid_waves(nwaves), 256, 0, as_stream(stream)>>>(
+                            E, bias, cat_map, ids, B, d, scale, accumulate, out, ldo,
+                            bias_out)));
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_gather_mulhot_mean_fwd(const float* E, const float* bias, const int32_t* vals,
+                               const int32_t* starts, const int32_t* lens, const int32_t* ids,
+                               int64_t B, int d, float scale, int accumulate, float* out,
+                               int64_t ldo, float* bias_out, void* stream) {
+  ARX_CHECK_ARG(E && vals && starts && lens && ids && out,
+                "arx_gather_mulhot_mean_fwd: null pointer");
+  ARX_CHECK_ARG(!(bias_out && !bias), "arx_gather_mulhot_mean_fwd: bias_out requires bias");
+  int rc = check_d("arx_gather_mulhot_mean_fwd", d);
+  if (rc) return rc;
+  ARX_CHECK_ARG(ldo % 4 == 0 && ldo >= d && aligned16(E) && aligned16(out),
+                "arx_gather_mulhot_mean_fwd: ldo %% 4 and 16-byte alignment required");
+  if (B <= 0) return ARX_OK;
+  const int lpr = lanes_per_row(d);
+  const int64_t nwaves = ceil_div(B, 64 / lpr);
+  const float* b = bias_out ? bias : nullptr;
+  ARX_DISPATCH_LPR(lpr, (k_gather_mulhot<LPR><<<grid_waves(nwaves), 256, 0, as_stream(stream)>>>(
+                            E, b, vals, starts, lens, ids, B, d, scale, accumulate, out, ldo,
+                            bias_out)));
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_dot_score_fwd(const float* U, int64_t ldu, const float* T, int64_t ldt,
+                      const float* tbias, int64_t B, int d, float* score, void* stream) {
+  ARX_CHECK_ARG(U && T && score, "arx_dot_score_fwd: null pointer");
+  int rc = check_d("arx_dot_score_fwd", d);
+  if (rc) return rc;
+  ARX_CHECK_ARG(ldu % 4 == 0 && ldt % 4 == 0 && aligned16(U) && aligned16(T),
+                "arx_dot_score_fwd: leading dims %% 4 and 16-byte alignment required");
+  if (B <= 0) return ARX_OK;
+  const int lpr = lanes_per_row(d);
+  const int64_t nwaves = ceil_div(B, 64 / lpr);
+  ARX_DISPATCH_LPR(lpr, (k_dot_fwd<LPR><<<grid_waves(nwaves), 256, 0, as_stream(stream)>>>(
+                            U, ldu, T, ldt, tbias, B, d, score)));
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_dot_score_bwd(const float* U, int64_t ldu, const float* T, int64_t ldt,
+                      const float* dscore, int64_t B, int d, float* dU, int64_t lddu,
+                      int acc_dU, float* dT, int64_t lddt, void* stream) {
+  ARX_CHECK_ARG(U && T && dscore && dU, "arx_dot_score_bwd: null pointer");
+  int rc = check_d("arx_dot_score_bwd", d);
+  if (rc) return rc;
+  ARX_CHECK_ARG(ldu % 4 == 0 && ldt % 4 == 0 && lddu % 4 == 0 && (!dT || lddt % 4 == 0),
+                "arx_dot_score_bwd: leading dims must be multiples of 4");
+  if (B <= 0) return ARX_OK;
+  int64_t total = B * (d / 4);
+  int64_t g = ceil_div(total, 256);
+  int64_t cap = (int64_t)cu_count() * 8;
+  if (g > cap) g = cap;
+  k_dot_bwd<<<(int)g, 256, 0, as_stream(stream)>>>(U, ldu, T, ldt, dscore, B, d / 4, dU, lddu,
+                                                   acc_dU, dT, lddt);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_sparse_site_onehot(const int32_t* cat_map, const int32_t* ids, int64_t n,
+                           int32_t row_base, float coef, int32_t* keys_out, int32_t* src_out,
+                           float* coef_out, void* stream) {
+  ARX_CHECK_ARG(ids && keys_out, "arx_sparse_site_onehot: null pointer");
+  if (n <= 0) return ARX_OK;
+  int64_t g = ceil_div(n, 256);
+  int64_t cap = (int64_t)cu_count() * 8;
+  if (g > cap) g = cap;
+  k_site_onehot<<<(int)g, 256, 0, as_stream(stream)>>>(cat_map, ids, n, row_base, coef, keys_out,
+                                                       src_out, coef_out);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+size_t arx_csr_expand_workspace_bytes(int64_t B) {
+  int64_t nb = ceil_div(B > 0 ? B : 1, kExpBlock);
+  return (size_t)(nb + 1) * sizeof(int32_t);
+}
+
+int arx_csr_expand(const int32_t* vals, const int32_t* starts, const int32_t* lens,
+                   const int32_t* row_ids, int64_t B, int32_t* token_ids, int32_t* segids,
+                   int64_t capacity, int32_t* offsets, int32_t* total_out, int32_t pad_token,
+                   int32_t pad_seg, int32_t seg_base, float coef_scale, float* coef_out,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  ARX_CHECK_ARG(vals && starts && lens && token_ids && offsets, "arx_csr_expand: null pointer");
+  ARX_CHECK_ARG(B >= 0 && capacity >= 0, "arx_csr_expand: negative size");
+  if (workspace_bytes < arx_csr_expand_workspace_bytes(B) || !workspace) {
+    set_error("arx_csr_expand: workspace too small (%zu < %zu)", workspace_bytes,
+              arx_csr_expand_workspace_bytes(B));
+    return ARX_EWORKSPACE;
+  }
+  hipStream_t s = as_stream(stream);
+  int32_t* block_tot = reinterpret_cast<int32_t*>(workspace);
+  const int nb = (int)ceil_div(B > 0 ? B : 1, kExpBlock);
+  k_expand_local<<<nb, kExpBlock, 0, s>>>(lens, row_ids, B, offsets, block_tot);
+  ARX_CHECK_LAUNCH();
+  k_expand_scan_blocks<<<1, kExpBlock, 0, s>>>(block_tot, nb, offsets + B, total_out);
+  ARX_CHECK_LAUNCH();
+  k_expand_emit<<<nb, kExpBlock, 0, s>>>(vals, starts, lens, row_ids, B, offsets, block_tot,
+                                         offsets + B, token_ids, segids, capacity, pad_token,
+                                         pad_seg, seg_base, coef_scale, coef_out);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+}  // extern "C"

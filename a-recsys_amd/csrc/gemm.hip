@@ -1,0 +1,315 @@
+// gemm.hip -- K4: fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// The scorer of A-RecSys (embed_attribute.py:171,188-193,205) in embedding-space
+// form is three small GEMMs per step: logits = U.I^T + b (NT), dU = dL.I (NN),
+// dI = dL^T.U (TN).  fp32 in / fp32 accumulate is required (parity 1e-4 against
+// the TF fp32 graph; gfx950 has no TF32).  The f32 MFMA runs at the fp32 vector
+// peak (157 TF, 64 cycles per 32x32x2), so feeding it from LDS is cheap; what
+// matters for these shapes is filling 256 CUs: 128x128 tiles when the output is
+// large, otherwise 64x64 tiles with deterministic split-K (partials in a caller
+// workspace, summed in a fixed order by a second kernel).
+//
+// LDS images (per operand, chosen by how the operand is stored in HBM):
+//   K-contiguous storage  ([rows][k]) : X[rows][BK+1]  -- odd stride => the MFMA
+//        operand read (32 rows at fixed k) hits 32 distinct banks;
+//   MN-contiguous storage ([k][rows]) : X[BK][rows+4]  -- the operand read is 32
+//        consecutive floats, conflict-free; stores are aligned ds_write_b128.
+#include "common.h"
+
+namespace arx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int ROWS, int BK, bool KC>
+struct LdsImg {
+  static constexpr int kStride = KC ? (BK + 1) : (ROWS + 4);
+  static constexpr int kSize = KC ? ROWS * (BK + 1) : BK * (ROWS + 4);
+  __device__ static __forceinline__ int idx(int r, int k) {
+    return KC ? r * kStride + k : k * kStride + r;
+  }
+};
+
+// Loads 4 consecutive floats from p (elements [0,4) valid where i < nvalid).
+__device__ __forceinline__ float4 load4_guard(const float* p, int nvalid, bool vec_ok) {
+  if (nvalid >= 4 && vec_ok) return *reinterpret_cast<const float4*>(p);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nvalid > 0) v.x = p[0];
+  if (nvalid > 1) v.y = p[1];
+  if (nvalid > 2) v.z = p[2];
+  if (nvalid > 3) v.w = p[3];
+  return v;
+}
+
+// Stage one operand tile (ROWS x BK) from HBM into registers.
+//   KC : element (r,k) at X[(r0+r)*ld + k0+k]   -> float4 along k
+//   !KC: element (r,k) at X[(k0+k)*ld + r0+r]   -> float4 along r
+template <int ROWS, int BK, bool KC, int NL>
+__device__ __forceinline__ void tile_load(const float* __restrict__ X, int64_t ld, int64_t r0,
+                                          int64_t R, int64_t k0, int64_t kend, bool vec_ok,
+                                          float4 (&reg)[NL]) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int f = threadIdx.x + i * 256;
+    if (KC) {
+      const int r = f / (BK / 4), kq = f % (BK / 4);
+      const int64_t gr = r0 + r, gk = k0 + kq * 4;
+      int nv = (gr < R) ? (int)min((int64_t)4, kend - gk) : 0;
+      reg[i] = (nv > 0) ? load4_guard(X + gr * ld + gk, nv, vec_ok) : make_float4(0, 0, 0, 0);
+    } else {
+      const int k = f / (ROWS / 4), rq = f % (ROWS / 4);
+      const int64_t gk = k0 + k, gr = r0 + rq * 4;
+      int nv = (gk < kend) ? (int)min((int64_t)4, R - gr) : 0;
+      reg[i] = (nv > 0) ? load4_guard(X + gk * ld + gr, nv, vec_ok) : make_float4(0, 0, 0, 0);
+    }
+  }
+}
+
+template <int ROWS, int BK, bool KC, int NL>
+__device__ __forceinline__ void tile_store(float* __restrict__ S, const float4 (&reg)[NL]) {
+  using Img = LdsImg<ROWS, BK, KC>;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int f = threadIdx.x + i * 256;
+    if (KC) {
+      const int r = f / (BK / 4), kq = f % (BK / 4);
+      float* p = S + Img::idx(r, kq * 4);
+      p[0] = reg[i].x;
+      p[1] = reg[i].y;
+      p[2] = reg[i].z;
+      p[3] = reg[i].w;
+    } else {
+      const int k = f / (ROWS / 4), rq = f % (ROWS / 4);
+      *reinterpret_cast<float4*>(S + Img::idx(rq * 4, k)) = reg[i];
+    }
+  }
+}
+
+// C (or split-K partial) = op(A).op(B) over this block's k range.
+template <int BM, int BN, int BK, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void k_gemm_f32(
+    int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
+    const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C, int64_t ldc,
+    const float* __restrict__ col_bias, float* __restrict__ partial, int64_t kchunk,
+    int vec_a, int vec_b, int tiles_n) {
+  constexpr int WM = 2, WN = 2;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int FM = TM / 32, FN = TN / 32;
+  constexpr int NLA = BM * BK / 4 / 256, NLB = BN * BK / 4 / 256;
+  static_assert(NLA >= 1 && NLB >= 1, "tile too small for 256 threads");
+  using ImgA = LdsImg<BM, BK, A_KC>;
+  using ImgB = LdsImg<BN, BK, B_KC>;
+  __shared__ __attribute__((aligned(16))) float sA[2][ImgA::kSize];
+  __shared__ __attribute__((aligned(16))) float sB[2][ImgB::kSize];
+
+  // XCD-aware tile order: consecutive blocks of one XCD (b % 8) walk tiles that
+  // share the same A row-panel, so the panel stays in that XCD's L2.
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kend = min(K, kbeg + kchunk);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 ra[NLA], rb[NLB];
+  const int64_t nt = (kend > kbeg) ? ceil_div(kend - kbeg, (int64_t)BK) : 0;
+  if (nt > 0) {
+    tile_load<BM, BK, A_KC, NLA>(A, lda, m0, M, kbeg, kend, vec_a, ra);
+    tile_load<BN, BK, B_KC, NLB>(B, ldb, n0, N, kbeg, kend, vec_b, rb);
+    tile_store<BM, BK, A_KC, NLA>(sA[0], ra);
+    tile_store<BN, BK, B_KC, NLB>(sB[0], rb);
+  }
+  __syncthreads();
+  for (int64_t t = 0; t < nt; ++t) {
+    const int cur = (int)(t & 1);
+    if (t + 1 < nt) {
+      const int64_t k0 = kbeg + (t + 1) * BK;
+      tile_load<BM, BK, A_KC, NLA>(A, lda, m0, M, k0, kend, vec_a, ra);
+      tile_load<BN, BK, B_KC, NLB>(B, ldb, n0, N, k0, kend, vec_b, rb);
+    }
+    const float* a_s = sA[cur];
+    const float* b_s = sB[cur];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float av[FM], bv[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) av[i] = a_s[ImgA::idx(wm * TM + i * 32 + l31, kk + lhi)];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bv[j] = b_s[ImgB::idx(wn * TN + j * 32 + l31, kk + lhi)];
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nt) {
+      tile_store<BM, BK, A_KC, NLA>(sA[cur ^ 1], ra);
+      tile_store<BN, BK, B_KC, NLB>(sB[cur ^ 1], rb);
+    }
+    __syncthreads();
+  }
+
+  // epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int64_t col = n0 + wn * TN + j * 32 + l31;
+      if (col >= N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = m0 + wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+        if (row >= M) continue;
+        float v = acc[i][j][e];
+        if (partial) {
+          partial[((int64_t)blockIdx.z * M + row) * N + col] = v;
+        } else {
+          v *= alpha;
+          if (beta != 0.f) v += beta * C[row * ldc + col];
+          if (col_bias) v += col_bias[col];
+          C[row * ldc + col] = v;
+        }
+      }
+    }
+}
+
+// fixed-order reduction of split-K partials + epilogue
+__global__ __launch_bounds__(256) void k_splitk_reduce(
+    const float* __restrict__ partial, int splits, int64_t M, int64_t N, float alpha, float beta,
+    float* __restrict__ C, int64_t ldc, const float* __restrict__ col_bias) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t total = M * N;
+  for (; i < total; i += stride) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * total + i];
+    const int64_t r = i / N, c = i % N;
+    float v = alpha * s;
+    if (beta != 0.f) v += beta * C[r * ldc + c];
+    if (col_bias) v += col_bias[c];
+    C[r * ldc + c] = v;
+  }
+}
+
+struct GemmPlan {
+  bool big;
+  int splits;
+  int64_t kchunk;
+};
+
+static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
+  GemmPlan p;
+  const int cus = cu_count();
+  const int64_t tiles_big = ceil_div(M, 128) * ceil_div(N, 128);
+  p.big = tiles_big * 4 >= (int64_t)cus * 3;
+  p.splits = 1;
+  p.kchunk = K > 0 ? K : 1;
+  if (!p.big) {
+    const int64_t tiles = ceil_div(M, 64) * ceil_div(N, 64);
+    int64_t want = ceil_div((int64_t)cus * 2, tiles);
+    int64_t maxs = K / 128;  // keep >= 128 of K per split
+    if (maxs < 1) maxs = 1;
+    int64_t s = want < maxs ? want : maxs;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    int64_t chunk = ceil_div(ceil_div(K, s), 16) * 16;
+    if (chunk < 16) chunk = 16;
+    p.kchunk = chunk;
+    p.splits = (int)ceil_div(K > 0 ? K : 1, chunk);
+  }
+  return p;
+}
+
+template <int BM, int BN>
+static int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                       const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+                       float* C, int64_t ldc, const float* col_bias, float* partial,
+                       const GemmPlan& p, hipStream_t s) {
+  constexpr int BK = 16;
+  const int tiles_m = (int)ceil_div(M, BM), tiles_n = (int)ceil_div(N, BN);
+  dim3 grid(tiles_m * tiles_n, 1, p.splits);
+  const int vec_a = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
+  const int vec_b = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
+  const bool akc = (transA == 0), bkc = (transB != 0);
+#define ARX_GEMM_LAUNCH(AKC, BKC)                                                         \
+  k_gemm_f32<BM, BN, BK, AKC, BKC><<<grid, 256, 0, s>>>(M, N, K, alpha, A, lda, B, ldb,   \
+                                                        beta, C, ldc, col_bias, partial,  \
+                                                        p.kchunk, vec_a, vec_b, tiles_n)
+  if (akc && bkc) ARX_GEMM_LAUNCH(true, true);
+  else if (akc && !bkc) ARX_GEMM_LAUNCH(true, false);
+  else if (!akc && bkc) ARX_GEMM_LAUNCH(false, true);
+  else ARX_GEMM_LAUNCH(false, false);
+#undef ARX_GEMM_LAUNCH
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+}  // namespace arx
+
+using namespace arx;
+
+extern "C" {
+
+size_t arx_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0) return 0;
+  GemmPlan p = plan_gemm(M, N, K);
+  if (p.splits <= 1) return 0;
+  return (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float);
+}
+
+int arx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                 const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                 int64_t ldc, const float* col_bias, void* workspace, size_t workspace_bytes,
+                 void* stream) {
+  ARX_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "arx_gemm_f32: negative dimension");
+  if (M == 0 || N == 0) return ARX_OK;
+  ARX_CHECK_ARG(A && B && C, "arx_gemm_f32: null pointer");
+  ARX_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
+                "arx_gemm_f32: leading dimension too small");
+  hipStream_t s = as_stream(stream);
+  GemmPlan p = plan_gemm(M, N, K);
+  float* partial = nullptr;
+  if (p.splits > 1) {
+    size_t need = (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float);
+    if (!workspace || workspace_bytes < need) {
+      set_error("arx_gemm_f32: workspace too small (%zu < %zu)", workspace_bytes, need);
+      return ARX_EWORKSPACE;
+    }
+    partial = reinterpret_cast<float*>(workspace);
+  }
+  int rc;
+  if (p.big)
+    rc = launch_gemm<128, 128>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
+                               col_bias, partial, p, s);
+  else
+    rc = launch_gemm<64, 64>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
+                             col_bias, partial, p, s);
+  if (rc) return rc;
+  if (partial) {
+    int64_t total = M * N;
+    int64_t g = ceil_div(total, 256);
+    int64_t cap = (int64_t)cu_count() * 8;
+    if (g > cap) g = cap;
+    k_splitk_reduce<<<(int)g, 256, 0, s>>>(partial, p.splits, M, N, alpha, beta, C, ldc,
+                                           col_bias);
+    ARX_CHECK_LAUNCH();
+  }
+  return ARX_OK;
+}
+
+}  // extern "C"

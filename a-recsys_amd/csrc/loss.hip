@@ -1,0 +1,244 @@
+// loss.hip -- K6: batch losses (forward + backward fused) and the positive mask.
+//
+//  mw / warp : embed_attribute.py:605-618, 641-649  log(1 + sum relu(mask*(x - t + 1)))
+//  ce        : embed_attribute.py:529-531           sparse softmax cross entropy
+//  mask      : embed_attribute.py:651-672, 721-745  scatter_update of a bool variable
+//
+// One 256-thread workgroup per batch row; a row of S=1024 logits is one float4
+// per thread.  The row is read twice (sum, then gradient); the second read hits
+// L2, and dlogits may overwrite logits in place.
+#include "common.h"
+
+namespace arx {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum over 256 threads, fixed order (deterministic)
+__device__ __forceinline__ float block_sum(float v, float* sh /*[4]*/) {
+  v = wsum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+  v = wmax(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+// MW and WARP share the body; WARP takes t from the target column and routes
+// dt back into it.
+template <bool WARP>
+__global__ __launch_bounds__(256) void k_loss_margin(
+    const float* __restrict__ logits, int64_t ldl, const float* __restrict__ tscore,
+    const int32_t* __restrict__ target, const uint8_t* __restrict__ mask, int64_t ldm,
+    int64_t mask_rows, float gscale, const float* __restrict__ row_w, int64_t W,
+    float* __restrict__ batch_loss,
+    float* dlogits, int64_t lddl, float* __restrict__ dtscore) {
+  __shared__ float sh[4];
+  const int64_t r = blockIdx.x;
+  const float* x = logits + r * ldl;
+  const uint8_t* m = mask ? mask + (r % mask_rows) * ldm : nullptr;
+  const int tcol = WARP ? target[r] : -1;
+  const float t = WARP ? x[tcol] : tscore[r];
+  float s = 0.f;
+  for (int64_t c = threadIdx.x; c < W; c += 256) {
+    const float v = x[c] - t + 1.f;
+    const bool keep = m ? (m[c] != 0) : true;
+    s += (keep && v > 0.f) ? v : 0.f;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0 && batch_loss) batch_loss[r] = logf(1.f + s);
+  if (!dlogits) return;
+  const float g = gscale * (row_w ? row_w[r] : 1.f) / (1.f + s);
+  float* dx = dlogits + r * lddl;
+  float cnt = 0.f;
+  for (int64_t c = threadIdx.x; c < W; c += 256) {
+    const float v = x[c] - t + 1.f;
+    const bool keep = m ? (m[c] != 0) : true;
+    const bool act = keep && v > 0.f;
+    cnt += act ? 1.f : 0.f;
+    dx[c] = act ? g : 0.f;
+  }
+  cnt = block_sum(cnt, sh);  // (contains the barrier that orders the writes above)
+  if (threadIdx.x == 0) {
+    const float dt = -g * cnt;
+    if (WARP) dx[tcol] += dt;
+    else if (dtscore) dtscore[r] = dt;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_loss_ce(
+    const float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ target,
+    float gscale, const float* __restrict__ row_w, int64_t V, float* __restrict__ batch_loss,
+    float* dlogits, int64_t lddl) {
+  __shared__ float sh[4];
+  const int64_t r = blockIdx.x;
+  const float* x = logits + r * ldl;
+  const int tcol = target[r];
+  const float xt = x[tcol];
+  float mx = -INFINITY;
+  for (int64_t c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, x[c]);
+  mx = block_max(mx, sh);
+  float se = 0.f;
+  for (int64_t c = threadIdx.x; c < V; c += 256) se += expf(x[c] - mx);
+  se = block_sum(se, sh);
+  if (threadIdx.x == 0 && batch_loss) batch_loss[r] = logf(se) + mx - xt;
+  if (!dlogits) return;
+  const float g = gscale * (row_w ? row_w[r] : 1.f);
+  const float inv = g / se;
+  float* dx = dlogits + r * lddl;
+  for (int64_t c = threadIdx.x; c < V; c += 256) {
+    const float p = expf(x[c] - mx) * inv;
+    dx[c] = (c == tcol) ? p - g : p;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_warp_eval(
+    const float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ target,
+    const uint8_t* __restrict__ mask, int64_t ldm, int64_t mask_rows, int64_t V,
+    float* __restrict__ margin_rank, int32_t* __restrict__ true_rank) {
+  __shared__ float sh[4];
+  const int64_t r = blockIdx.x;
+  const float* x = logits + r * ldl;
+  const uint8_t* m = mask ? mask + (r % mask_rows) * ldm : nullptr;
+  const float t = x[target[r]];
+  float s = 0.f, cnt = 0.f;
+  for (int64_t c = threadIdx.x; c < V; c += 256) {
+    const bool keep = m ? (m[c] != 0) : true;
+    const float v = x[c] - t;
+    if (keep && v + 1.f > 0.f) s += v + 1.f;
+    if (keep && v > 0.f) cnt += 1.f;
+  }
+  s = block_sum(s, sh);
+  cnt = block_sum(cnt, sh);
+  if (threadIdx.x == 0) {
+    margin_rank[r] = s;
+    true_rank[r] = (int32_t)cnt;
+  }
+}
+
+// one wave per batch row walks the row's positives
+__global__ __launch_bounds__(256) void k_pos_mask_scatter(
+    const int32_t* __restrict__ user_ids, int64_t B, const int32_t* __restrict__ pos_ptr,
+    const int32_t* __restrict__ pos_items, const int32_t* __restrict__ item2slot,
+    uint8_t* __restrict__ mask, int64_t ldm, uint8_t value) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < B; r += nwave) {
+    const int u = user_ids[r];
+    const int beg = pos_ptr[u], end = pos_ptr[u + 1];
+    for (int p = beg + lane; p < end; p += 64) {
+      const int j = item2slot[pos_items[p]];
+      if (j >= 0) mask[r * ldm + j] = value;
+    }
+  }
+}
+
+__global__ void k_slot_map_set(int32_t* __restrict__ map, const int32_t* __restrict__ ids,
+                               int64_t S, int clear) {
+  const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  if (clear) map[ids[s]] = -1;
+  else atomicMax(&map[ids[s]], (int32_t)s);  // duplicate ids: last slot wins (dict semantics)
+}
+
+}  // namespace arx
+
+using namespace arx;
+
+extern "C" {
+
+int arx_pos_mask_scatter(const int32_t* user_ids, int64_t B, const int32_t* pos_ptr,
+                         const int32_t* pos_items, const int32_t* item2slot, uint8_t* mask,
+                         int64_t ldm, int value, void* stream) {
+  ARX_CHECK_ARG(user_ids && pos_ptr && pos_items && item2slot && mask,
+                "arx_pos_mask_scatter: null pointer");
+  if (B <= 0) return ARX_OK;
+  int64_t g = ceil_div(B, 4);
+  int64_t cap = (int64_t)cu_count() * 8;
+  if (g > cap) g = cap;
+  k_pos_mask_scatter<<<(int)g, 256, 0, as_stream(stream)>>>(user_ids, B, pos_ptr, pos_items,
+                                                            item2slot, mask, ldm,
+                                                            (uint8_t)(value ? 1 : 0));
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_slot_map_set(int32_t* item2slot, const int32_t* ids, int64_t S, int clear,
+                     void* stream) {
+  ARX_CHECK_ARG(item2slot && ids, "arx_slot_map_set: null pointer");
+  if (S <= 0) return ARX_OK;
+  k_slot_map_set<<<(int)ceil_div(S, 256), 256, 0, as_stream(stream)>>>(item2slot, ids, S, clear);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_loss_mw_fwdbwd(const float* logits, int64_t ldl, const float* tscore,
+                       const uint8_t* mask, int64_t ldm, int64_t mask_rows, float gscale,
+                       const float* row_w,
+                       int64_t B, int64_t S, float* batch_loss, float* dlogits, int64_t lddl,
+                       float* dtscore, void* stream) {
+  ARX_CHECK_ARG(logits && tscore, "arx_loss_mw_fwdbwd: null pointer");
+  ARX_CHECK_ARG(B >= 0 && S >= 0, "arx_loss_mw_fwdbwd: negative size");
+  if (B == 0) return ARX_OK;
+  k_loss_margin<false><<<(int)B, 256, 0, as_stream(stream)>>>(
+      logits, ldl, tscore, nullptr, mask, ldm, mask_rows > 0 ? mask_rows : B, gscale, row_w, S,
+      batch_loss, dlogits, lddl, dtscore);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_loss_warp_fwdbwd(const float* logits, int64_t ldl, const int32_t* target,
+                         const uint8_t* mask, int64_t ldm, int64_t mask_rows, float gscale,
+                         const float* row_w,
+                         int64_t B, int64_t V, float* batch_loss, float* dlogits, int64_t lddl,
+                         void* stream) {
+  ARX_CHECK_ARG(logits && target, "arx_loss_warp_fwdbwd: null pointer");
+  ARX_CHECK_ARG(B >= 0 && V > 0, "arx_loss_warp_fwdbwd: bad size");
+  if (B == 0) return ARX_OK;
+  k_loss_margin<true><<<(int)B, 256, 0, as_stream(stream)>>>(
+      logits, ldl, nullptr, target, mask, ldm, mask_rows > 0 ? mask_rows : B, gscale, row_w, V,
+      batch_loss, dlogits, lddl, nullptr);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_loss_ce_fwdbwd(const float* logits, int64_t ldl, const int32_t* target, float gscale,
+                       const float* row_w, int64_t B, int64_t V, float* batch_loss,
+                       float* dlogits, int64_t lddl, void* stream) {
+  ARX_CHECK_ARG(logits && target, "arx_loss_ce_fwdbwd: null pointer");
+  ARX_CHECK_ARG(B >= 0 && V > 0, "arx_loss_ce_fwdbwd: bad size");
+  if (B == 0) return ARX_OK;
+  k_loss_ce<<<(int)B, 256, 0, as_stream(stream)>>>(logits, ldl, target, gscale, row_w, V,
+                                                   batch_loss, dlogits, lddl);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_loss_warp_eval(const float* logits, int64_t ldl, const int32_t* target,
+                       const uint8_t* mask, int64_t ldm, int64_t mask_rows, int64_t B, int64_t V,
+                       float* margin_rank, int32_t* true_rank, void* stream) {
+  ARX_CHECK_ARG(logits && target && margin_rank && true_rank, "arx_loss_warp_eval: null pointer");
+  if (B <= 0) return ARX_OK;
+  k_warp_eval<<<(int)B, 256, 0, as_stream(stream)>>>(logits, ldl, target, mask, ldm,
+                                                     mask_rows > 0 ? mask_rows : B, V,
+                                                     margin_rank, true_rank);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+}  // extern "C"

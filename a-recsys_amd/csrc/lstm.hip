@@ -1,0 +1,339 @@
+// lstm.hip -- K9: LSTM sequence encoder (lstm/seqModel.py:99-103,477).
+//
+// tf.contrib.rnn LSTMCell(h): z = [x_t, h_{t-1}] . W + b, split i,j,f,o;
+// c = sigmoid(f + forget_bias)*c_prev + sigmoid(i)*tanh(j); h = sigmoid(o)*tanh(c);
+// zero initial state; static_rnn runs all L steps (padding is masked by the
+// loss weights only).
+//
+// The recurrence is latency-bound (L dependent [B,(d+h)]x[(d+h),4h] products),
+// so ONE persistent launch walks all L steps: a workgroup owns 16 batch rows
+// (the M of v_mfma_f32_16x16x4_f32), its 4 waves own h/4 units each -- all four
+// gates of those units, so the cell update is register-local; h_{t-1} lives in
+// LDS (double-buffered, stride h+2 => conflict-free operand reads), c_{t-1} in
+// registers, x_{t+1} is prefetched into LDS while step t computes.  W streams
+// from L2 as the MFMA B operand (it is read-only and tiny: 128 KB at d=h=64).
+#include "common.h"
+
+namespace arx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+constexpr int kRows = 16;  // batch rows per workgroup (MFMA M)
+
+// TPG = 16-unit tiles per gate per wave = h / 64
+template <int TPG>
+__global__ __launch_bounds__(256) void k_lstm_fwd(
+    const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+    int64_t L, int64_t B, int din, int h, float forget_bias, float* __restrict__ hs,
+    float* __restrict__ cs, float* __restrict__ gates) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int SX = din + 2, SH = h + 2;
+  float* xbuf = smem;                         // [2][16][SX]
+  float* hbuf = smem + 2 * kRows * SX;        // [2][16][SH]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * kRows;
+  const int UPW = h / 4;                      // units per wave
+  const int ubase = wave * UPW;
+  const int H4 = 4 * h;
+
+  // zero h_{-1}, stage x_0
+  for (int i = threadIdx.x; i < kRows * SH; i += 256) hbuf[i] = 0.f;
+  for (int i = threadIdx.x; i < kRows * din; i += 256) {
+    const int r = i / din, c = i % din;
+    const int64_t gr = row0 + r;
+    xbuf[r * SX + c] = (gr < B) ? x[gr * din + c] : 0.f;
+  }
+  float cprev[TPG][4];
+#pragma unroll
+  for (int tp = 0; tp < TPG; ++tp)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cprev[tp][r] = 0.f;
+  __syncthreads();
+
+  for (int64_t t = 0; t < L; ++t) {
+    const int cur = (int)(t & 1), nxt = cur ^ 1;
+    const float* xb = xbuf + cur * kRows * SX;
+    const float* hb = hbuf + cur * kRows * SH;
+    // prefetch x_{t+1}
+    if (t + 1 < L) {
+      float* xn = xbuf + nxt * kRows * SX;
+      const float* xs = x + (t + 1) * B * din;
+      for (int i = threadIdx.x; i < kRows * din; i += 256) {
+        const int r = i / din, c = i % din;
+        const int64_t gr = row0 + r;
+        xn[r * SX + c] = (gr < B) ? xs[gr * din + c] : 0.f;
+      }
+    }
+    f32x4 acc[4][TPG];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int tp = 0; tp < TPG; ++tp) {
+        const float bv = bias[g * h + ubase + tp * 16 + l15];
+        acc[g][tp] = (f32x4){bv, bv, bv, bv};
+      }
+    // x part
+    for (int kk = 0; kk < din; kk += 4) {
+      const float a = xb[l15 * SX + kk + lq];
+      const float* wrow = W + (int64_t)(kk + lq) * H4 + ubase + l15;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int tp = 0; tp < TPG; ++tp)
+          acc[g][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[g * h + tp * 16], acc[g][tp], 0, 0, 0);
+    }
+    // h part
+    for (int kk = 0; kk < h; kk += 4) {
+      const float a = hb[l15 * SH + kk + lq];
+      const float* wrow = W + (int64_t)(din + kk + lq) * H4 + ubase + l15;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int tp = 0; tp < TPG; ++tp)
+          acc[g][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[g * h + tp * 16], acc[g][tp], 0, 0, 0);
+    }
+    // cell update; C/D map of 16x16: col = lane&15 (unit), row = (lane>>4)*4 + reg
+    float* hn = hbuf + nxt * kRows * SH;
+#pragma unroll
+    for (int tp = 0; tp < TPG; ++tp) {
+      const int unit = ubase + tp * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lrow = lq * 4 + r;
+        const int64_t gr = row0 + lrow;
+        const float gi = sigmoidf_(acc[0][tp][r]);
+        const float gj = tanhf(acc[1][tp][r]);
+        const float gf = sigmoidf_(acc[2][tp][r] + forget_bias);
+        const float go = sigmoidf_(acc[3][tp][r]);
+        const float c = gf * cprev[tp][r] + gi * gj;
+        const float hh = go * tanhf(c);
+        cprev[tp][r] = c;
+        hn[lrow * SH + unit] = hh;
+        if (gr < B) {
+          const int64_t o = (t * B + gr);
+          hs[o * h + unit] = hh;
+          cs[o * h + unit] = c;
+          float* gp = gates + o * H4 + unit;
+          gp[0] = gi;
+          gp[h] = gj;
+          gp[2 * h] = gf;
+          gp[3 * h] = go;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int TPG>
+__global__ __launch_bounds__(256) void k_lstm_bwd(
+    const float* __restrict__ W, const float* __restrict__ cs, const float* __restrict__ gates,
+    const float* __restrict__ dhs, int64_t L, int64_t B, int din, int h,
+    float* __restrict__ dz) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H4 = 4 * h, SZ = H4 + 2;
+  float* zbuf = smem;  // [16][SZ]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * kRows;
+  const int UPW = h / 4;
+  const int ubase = wave * UPW;
+  float dh_rec[TPG][4], dc[TPG][4];
+#pragma unroll
+  for (int tp = 0; tp < TPG; ++tp)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh_rec[tp][r] = dc[tp][r] = 0.f;
+
+  for (int64_t t = L - 1; t >= 0; --t) {
+#pragma unroll
+    for (int tp = 0; tp < TPG; ++tp) {
+      const int unit = ubase + tp * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lrow = lq * 4 + r;
+        const int64_t gr = row0 + lrow;
+        float zi = 0.f, zj = 0.f, zf = 0.f, zo = 0.f;
+        if (gr < B) {
+          const int64_t o = t * B + gr;
+          const float* gp = gates + o * H4 + unit;
+          const float gi = gp[0], gj = gp[h], gf = gp[2 * h], go = gp[3 * h];
+          const float c = cs[o * h + unit];
+          const float cp = (t > 0) ? cs[(o - B) * h + unit] : 0.f;
+          const float dh = dhs[o * h + unit] + dh_rec[tp][r];
+          const float tc = tanhf(c);
+          const float d_o = dh * tc;
+          const float dcc = dc[tp][r] + dh * go * (1.f - tc * tc);
+          zi = dcc * gj * gi * (1.f - gi);
+          zj = dcc * gi * (1.f - gj * gj);
+          zf = dcc * cp * gf * (1.f - gf);
+          zo = d_o * go * (1.f - go);
+          dc[tp][r] = dcc * gf;
+          float* zp = dz + o * H4 + unit;
+          zp[0] = zi;
+          zp[h] = zj;
+          zp[2 * h] = zf;
+          zp[3 * h] = zo;
+        }
+        float* zb = zbuf + lrow * SZ + unit;
+        zb[0] = zi;
+        zb[h] = zj;
+        zb[2 * h] = zf;
+        zb[3 * h] = zo;
+      }
+    }
+    __syncthreads();
+    if (t > 0) {
+      // dh_{t-1}[row, unit] = sum_k dz[row, k] * W[din + unit, k]
+      f32x4 acc[TPG];
+#pragma unroll
+      for (int tp = 0; tp < TPG; ++tp) acc[tp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kk = 0; kk < H4; kk += 4) {
+        const float a = zbuf[l15 * SZ + kk + lq];
+#pragma unroll
+        for (int tp = 0; tp < TPG; ++tp) {
+          const float b = W[(int64_t)(din + ubase + tp * 16 + l15) * H4 + kk + lq];
+          acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tp], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int tp = 0; tp < TPG; ++tp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh_rec[tp][r] = acc[tp][r];
+    }
+    __syncthreads();
+  }
+}
+
+// ---- generic fallback (any din, h): one workgroup per batch row -------------
+__global__ __launch_bounds__(256) void k_lstm_fwd_generic(
+    const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+    int64_t L, int64_t B, int din, int h, float forget_bias, float* __restrict__ hs,
+    float* __restrict__ cs, float* __restrict__ gates) {
+  extern __shared__ float smem[];
+  float* in = smem;            // [din + h]
+  float* z = smem + din + h;   // [4h]
+  float* cst = z + 4 * h;      // [h]
+  const int64_t b = blockIdx.x;
+  const int K = din + h, H4 = 4 * h;
+  for (int i = threadIdx.x; i < h; i += 256) { in[din + i] = 0.f; cst[i] = 0.f; }
+  for (int64_t t = 0; t < L; ++t) {
+    for (int i = threadIdx.x; i < din; i += 256) in[i] = x[(t * B + b) * din + i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < H4; c += 256) {
+      float s = bias[c];
+      for (int k = 0; k < K; ++k) s = fmaf(in[k], W[(int64_t)k * H4 + c], s);
+      z[c] = s;
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < h; u += 256) {
+      const float gi = sigmoidf_(z[u]), gj = tanhf(z[h + u]);
+      const float gf = sigmoidf_(z[2 * h + u] + forget_bias), go = sigmoidf_(z[3 * h + u]);
+      const float c = gf * cst[u] + gi * gj;
+      const float hh = go * tanhf(c);
+      cst[u] = c;
+      in[din + u] = hh;
+      const int64_t o = t * B + b;
+      hs[o * h + u] = hh;
+      cs[o * h + u] = c;
+      gates[o * H4 + u] = gi;
+      gates[o * H4 + h + u] = gj;
+      gates[o * H4 + 2 * h + u] = gf;
+      gates[o * H4 + 3 * h + u] = go;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lstm_bwd_generic(
+    const float* __restrict__ W, const float* __restrict__ cs, const float* __restrict__ gates,
+    const float* __restrict__ dhs, int64_t L, int64_t B, int din, int h,
+    float* __restrict__ dz) {
+  extern __shared__ float smem[];
+  float* z = smem;           // [4h]
+  float* dhr = smem + 4 * h; // [h]
+  float* dcs = dhr + h;      // [h]
+  const int64_t b = blockIdx.x;
+  const int H4 = 4 * h;
+  for (int i = threadIdx.x; i < h; i += 256) { dhr[i] = 0.f; dcs[i] = 0.f; }
+  __syncthreads();
+  for (int64_t t = L - 1; t >= 0; --t) {
+    const int64_t o = t * B + b;
+    for (int u = threadIdx.x; u < h; u += 256) {
+      const float gi = gates[o * H4 + u], gj = gates[o * H4 + h + u];
+      const float gf = gates[o * H4 + 2 * h + u], go = gates[o * H4 + 3 * h + u];
+      const float c = cs[o * h + u];
+      const float cp = (t > 0) ? cs[(o - B) * h + u] : 0.f;
+      const float dh = dhs[o * h + u] + dhr[u];
+      const float tc = tanhf(c);
+      const float dcc = dcs[u] + dh * go * (1.f - tc * tc);
+      const float zi = dcc * gj * gi * (1.f - gi), zj = dcc * gi * (1.f - gj * gj);
+      const float zf = dcc * cp * gf * (1.f - gf), zo = dh * tc * go * (1.f - go);
+      dcs[u] = dcc * gf;
+      z[u] = zi; z[h + u] = zj; z[2 * h + u] = zf; z[3 * h + u] = zo;
+      dz[o * H4 + u] = zi; dz[o * H4 + h + u] = zj;
+      dz[o * H4 + 2 * h + u] = zf; dz[o * H4 + 3 * h + u] = zo;
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < h; u += 256) {
+      float s = 0.f;
+      const float* wr = W + (int64_t)(din + u) * H4;
+      for (int k = 0; k < H4; ++k) s = fmaf(z[k], wr[k], s);
+      dhr[u] = s;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace arx
+
+using namespace arx;
+
+extern "C" {
+
+int arx_lstm_fwd(const float* x, const float* W, const float* b, int64_t L, int64_t B, int din,
+                 int h, float forget_bias, float* hs, float* cs, float* gates, void* stream) {
+  ARX_CHECK_ARG(x && W && b && hs && cs && gates, "arx_lstm_fwd: null pointer");
+  ARX_CHECK_ARG(L >= 0 && B >= 0 && din > 0 && h > 0, "arx_lstm_fwd: bad size");
+  if (L == 0 || B == 0) return ARX_OK;
+  hipStream_t s = as_stream(stream);
+  const bool mfma_ok = (h % 64 == 0) && (h <= 128) && (din % 4 == 0);
+  if (mfma_ok) {
+    const size_t lds = (size_t)(2 * kRows * (din + 2) + 2 * kRows * (h + 2)) * sizeof(float);
+    const int grid = (int)ceil_div(B, kRows);
+    if (h == 64) k_lstm_fwd<1><<<grid, 256, lds, s>>>(x, W, b, L, B, din, h, forget_bias, hs, cs, gates);
+    else k_lstm_fwd<2><<<grid, 256, lds, s>>>(x, W, b, L, B, din, h, forget_bias, hs, cs, gates);
+  } else {
+    const size_t lds = (size_t)(din + h + 4 * h + h) * sizeof(float);
+    ARX_CHECK_ARG(lds <= 160 * 1024, "arx_lstm_fwd: sizes exceed LDS");
+    k_lstm_fwd_generic<<<(int)B, 256, lds, s>>>(x, W, b, L, B, din, h, forget_bias, hs, cs, gates);
+  }
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_lstm_bwd(const float* W, const float* hs, const float* cs, const float* gates,
+                 const float* dhs, int64_t L, int64_t B, int din, int h, float* dz,
+                 void* stream) {
+  (void)hs;
+  ARX_CHECK_ARG(W && cs && gates && dhs && dz, "arx_lstm_bwd: null pointer");
+  ARX_CHECK_ARG(L >= 0 && B >= 0 && din > 0 && h > 0, "arx_lstm_bwd: bad size");
+  if (L == 0 || B == 0) return ARX_OK;
+  hipStream_t s = as_stream(stream);
+  const bool mfma_ok = (h % 64 == 0) && (h <= 128);
+  if (mfma_ok) {
+    const size_t lds = (size_t)(kRows * (4 * h + 2)) * sizeof(float);
+    const int grid = (int)ceil_div(B, kRows);
+    if (h == 64) k_lstm_bwd<1><<<grid, 256, lds, s>>>(W, cs, gates, dhs, L, B, din, h, dz);
+    else k_lstm_bwd<2><<<grid, 256, lds, s>>>(W, cs, gates, dhs, L, B, din, h, dz);
+  } else {
+    const size_t lds = (size_t)(4 * h + 2 * h) * sizeof(float);
+    k_lstm_bwd_generic<<<(int)B, 256, lds, s>>>(W, cs, gates, dhs, L, B, din, h, dz);
+  }
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+}  // extern "C"

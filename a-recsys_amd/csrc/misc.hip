@@ -1,0 +1,101 @@
+// misc.hip -- top-k over logits rows (recommend path) and sequence-loss weights.
+#include "common.h"
+
+namespace arx {
+
+// tf.nn.top_k(sorted=True) semantics: descending value, ties -> lower index.
+// One workgroup per row; k rounds of a block-wide arg-max over the row with the
+// previously selected (value, index) as an exclusive upper bound -- no scratch,
+// no mutation of the logits.  O(k*V) per row: adequate for the recommend path
+// at ML-1m scale; a radix-select version is the planned replacement.
+__global__ __launch_bounds__(256) void k_topk(const float* __restrict__ logits, int64_t ld,
+                                              int64_t V, int k, float* __restrict__ values,
+                                              int32_t* __restrict__ indices) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  __shared__ float bv;
+  __shared__ int bi;
+  const int64_t r = blockIdx.x;
+  const float* x = logits + r * ld;
+  float prev_v = INFINITY;
+  int prev_i = -1;
+  for (int j = 0; j < k; ++j) {
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int64_t c = threadIdx.x; c < V; c += 256) {
+      const float v = x[c];
+      // candidate must come strictly after (prev_v, prev_i) in (desc value, asc index) order
+      const bool after = (v < prev_v) || (v == prev_v && (int)c > prev_i);
+      if (after && (v > best || (v == best && (int)c < besti))) {
+        best = v;
+        besti = (int)c;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(besti, o, 64);
+      if (ov > best || (ov == best && oi < besti)) {
+        best = ov;
+        besti = oi;
+      }
+    }
+    if ((threadIdx.x & 63) == 0) {
+      sv[threadIdx.x >> 6] = best;
+      si[threadIdx.x >> 6] = besti;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float b = sv[0];
+      int bidx = si[0];
+      for (int w = 1; w < 4; ++w)
+        if (sv[w] > b || (sv[w] == b && si[w] < bidx)) {
+          b = sv[w];
+          bidx = si[w];
+        }
+      bv = b;
+      bi = bidx;
+      if (values) values[r * k + j] = b;
+      indices[r * k + j] = bidx;
+    }
+    __syncthreads();
+    prev_v = bv;
+    prev_i = bi;
+  }
+}
+
+__global__ void k_seq_weights(const float* __restrict__ w, int64_t L, int64_t B,
+                              float* __restrict__ out) {
+  const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float tot = 0.f;
+  for (int64_t t = 0; t < L; ++t) tot += w[t * B + b];  // add_n over time steps
+  tot += 1e-12f;
+  for (int64_t t = 0; t < L; ++t) out[t * B + b] = w[t * B + b] / tot;
+}
+
+}  // namespace arx
+
+using namespace arx;
+
+extern "C" {
+
+int arx_topk(const float* logits, int64_t ld, int64_t B, int64_t V, int k, float* values,
+             int32_t* indices, void* stream) {
+  ARX_CHECK_ARG(logits && indices, "arx_topk: null pointer");
+  ARX_CHECK_ARG(k > 0 && k <= V, "arx_topk: need 0 < k <= V");
+  if (B <= 0) return ARX_OK;
+  k_topk<<<(int)B, 256, 0, as_stream(stream)>>>(logits, ld, V, k, values, indices);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_seq_weights(const float* w, int64_t L, int64_t B, float* out, void* stream) {
+  ARX_CHECK_ARG(w && out, "arx_seq_weights: null pointer");
+  if (B <= 0 || L <= 0) return ARX_OK;
+  k_seq_weights<<<(int)ceil_div(B, 256), 256, 0, as_stream(stream)>>>(w, L, B, out);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,444 @@
+// optim.hip -- K7: embedding_lookup gradient scatter fused with sparse Adagrad,
+//              K8: dense Adagrad, squared norms, clip coefficient.
+//
+// Reference semantics (hmf_model.py:146-151, seqModel.py:173-182; TF-1.0
+// AdagradOptimizer): duplicate indices of an IndexedSlices gradient are summed
+// first, then every touched row gets ONE update
+//     acc += g^2 ;  w -= lr * g / sqrt(acc).
+// Rows that receive no gradient are untouched, which is why the reference's
+// dense update over the whole table can be restricted to the touched rows.
+//
+// Algorithm (deterministic -- no floating-point atomics):
+//   1. keys -> stable radix sort of (key, position)            [rocPRIM]
+//   2. pass A: one sub-group (LPR lanes, float4 each) per sorted position.
+//      A position is a piece LEADER if it starts a run of equal keys or is
+//      aligned to kPiece.  Leaders walk their piece (<= kPiece positions),
+//      summing coef*G[src] rows in sorted (= original) order.
+//        - head whose run ends inside the piece: apply Adagrad at once;
+//        - head whose run continues: push the head on a list (pass B);
+//        - aligned continuation piece: write the partial row to scratch.
+//   3. pass B: one workgroup per listed (long) run: its sub-groups sum the
+//      run's scratch partials (strided, fixed order) + the head piece, combine
+//      through LDS in a fixed order, apply Adagrad.
+// Zipf-heavy attribute tokens (thousands of duplicates) therefore cost
+// O(len / kPiece / 8) dependent loads instead of O(len).
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace arx {
+
+constexpr int kPiece = 64;          // positions per piece
+constexpr int kPassBBlocks = 512;   // persistent grid of pass B
+
+__device__ __forceinline__ float4 f4_fma(float c, float4 v, float4 a) {
+  return make_float4(fmaf(c, v.x, a.x), fmaf(c, v.y, a.y), fmaf(c, v.z, a.z), fmaf(c, v.w, a.w));
+}
+__device__ __forceinline__ float4 f4_add2(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+__global__ void k_prep_keys(const int32_t* __restrict__ keys, int64_t n, uint32_t sentinel,
+                            uint32_t* __restrict__ keys_tmp, uint32_t* __restrict__ pos,
+                            int32_t* __restrict__ list_count) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i == 0) *list_count = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int32_t k = keys[i];
+    keys_tmp[i] = (k == ARX_KEY_NONE || k < 0 || (uint32_t)k >= sentinel) ? sentinel : (uint32_t)k;
+    pos[i] = (uint32_t)i;
+  }
+}
+
+// Sum coef*G[src] over sorted positions [q, pend) that carry `key`, stopping at
+// the first different key.  Returns the number of positions consumed.
+template <int LPR>
+__device__ __forceinline__ int walk_piece(const uint32_t* __restrict__ sk,
+                                          const uint32_t* __restrict__ spos,
+                                          const int32_t* __restrict__ src,
+                                          const float* __restrict__ coef,
+                                          const float* __restrict__ G, int64_t ldg,
+                                          const float* __restrict__ Gb, uint32_t key, int64_t q,
+                                          int64_t pend, int col, bool colok, int lig, int gid,
+                                          float4& acc_out, float& gb_out) {
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  float gb = 0.f;
+  int consumed = 0;
+  for (int64_t q0 = q; q0 < pend; q0 += LPR) {
+    const int64_t p = q0 + lig;
+    const bool same = (p < pend) && (sk[p] == key);
+    unsigned long long bal = __ballot(same);
+    unsigned long long bits = bal;
+    if constexpr (LPR < 64) bits = (bal >> (gid * LPR)) & ((1ull << LPR) - 1ull);
+    // length of the leading run of 'same' lanes
+    int cnt = (~bits == 0ull) ? 64 : (int)__builtin_ctzll(~bits);
+    if (cnt > LPR) cnt = LPR;
+    int mysrc = 0;
+    float mycoef = 0.f;
+    if (lig < cnt) {
+      const uint32_t i = spos[p];
+      mysrc = src ? src[i] : (int32_t)i;
+      mycoef = coef ? coef[i] : 1.f;
+      if (Gb) gb = fmaf(mycoef, Gb[mysrc], gb);
+    }
+    int t = 0;
+    for (; t + 2 <= cnt; t += 2) {
+      const int s0 = __shfl(mysrc, t, LPR), s1 = __shfl(mysrc, t + 1, LPR);
+      const float c0 = __shfl(mycoef, t, LPR), c1 = __shfl(mycoef, t + 1, LPR);
+      if (colok) {
+        const float4 v0 = *reinterpret_cast<const float4*>(G + (int64_t)s0 * ldg + col);
+        const float4 v1 = *reinterpret_cast<const float4*>(G + (int64_t)s1 * ldg + col);
+        a0 = f4_fma(c0, v0, a0);
+        a1 = f4_fma(c1, v1, a1);
+      }
+    }
+    if (t < cnt) {
+      const int s0 = __shfl(mysrc, t, LPR);
+      const float c0 = __shfl(mycoef, t, LPR);
+      if (colok) a0 = f4_fma(c0, *reinterpret_cast<const float4*>(G + (int64_t)s0 * ldg + col), a0);
+    }
+    consumed += cnt;
+    if (cnt < LPR) break;
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) gb += __shfl_xor(gb, o, LPR);
+  acc_out = f4_add2(a0, a1);
+  gb_out = gb;
+  return consumed;
+}
+
+__device__ __forceinline__ void adagrad_row(float* __restrict__ E, float* __restrict__ acc,
+                                            float* __restrict__ bias, float* __restrict__ bias_acc,
+                                            int d, uint32_t row, int col, bool colok, int lig,
+                                            float4 g, float gb, float lr, float gs) {
+  if (colok) {
+    float4* wp = reinterpret_cast<float4*>(E + (int64_t)row * d + col);
+    float4* ap = reinterpret_cast<float4*>(acc + (int64_t)row * d + col);
+    float4 w = *wp, a = *ap;
+    g.x *= gs; g.y *= gs; g.z *= gs; g.w *= gs;
+    a.x += g.x * g.x; a.y += g.y * g.y; a.z += g.z * g.z; a.w += g.w * g.w;
+    w.x -= lr * g.x / sqrtf(a.x);
+    w.y -= lr * g.y / sqrtf(a.y);
+    w.z -= lr * g.z / sqrtf(a.z);
+    w.w -= lr * g.w / sqrtf(a.w);
+    *ap = a;
+    *wp = w;
+  }
+  if (bias && lig == 0) {
+    const float gg = gb * gs;
+    const float a = bias_acc[row] + gg * gg;
+    bias_acc[row] = a;
+    bias[row] -= lr * gg / sqrtf(a);
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_sparse_pass_a(
+    float* __restrict__ E, float* __restrict__ acc, float* __restrict__ bias,
+    float* __restrict__ bias_acc, int d, const uint32_t* __restrict__ sk,
+    const uint32_t* __restrict__ spos, const int32_t* __restrict__ src,
+    const float* __restrict__ coef, int64_t n, uint32_t sentinel, const float* __restrict__ G,
+    int64_t ldg, const float* __restrict__ Gb, const float* __restrict__ lr_dev,
+    const float* __restrict__ gscale_dev, float* __restrict__ scratch,
+    float* __restrict__ scratch_b, int32_t* __restrict__ list, int32_t* __restrict__ list_count) {
+  constexpr int GPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % LPR;
+  const int gid = lane / LPR;
+  const int col = lig * 4;
+  const bool colok = col < d;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t q = wave * GPW + gid;
+  if (q >= n) return;
+  const uint32_t key = sk[q];
+  if (key >= sentinel) return;
+  const bool head = (q == 0) || (sk[q - 1] != key);
+  const bool aligned = (q % kPiece) == 0;
+  if (!head && !aligned) return;
+  int64_t pend = (q / kPiece + 1) * kPiece;
+  if (pend > n) pend = n;
+  float4 g;
+  float gb;
+  const int consumed = walk_piece<LPR>(sk, spos, src, coef, G, ldg, Gb, key, q, pend, col, colok,
+                                       lig, gid, g, gb);
+  const int64_t e = q + consumed;
+  const bool continues = (e == pend) && (e < n) && (sk[e] == key);
+  if (head) {
+    if (!continues) {
+      adagrad_row(E, acc, bias, bias_acc, d, key, col, colok, lig, g, gb, *lr_dev,
+                  gscale_dev ? *gscale_dev : 1.f);
+    } else if (lig == 0) {
+      const int slot = atomicAdd(list_count, 1);
+      list[slot] = (int32_t)q;
+    }
+  } else {  // aligned continuation piece -> partial
+    const int64_t slot = q / kPiece;
+    if (colok) *reinterpret_cast<float4*>(scratch + slot * (int64_t)d + col) = g;
+    if (lig == 0) scratch_b[slot] = gb;
+  }
+}
+
+// pass B: one workgroup per long run.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_sparse_pass_b(
+    float* __restrict__ E, float* __restrict__ acc, float* __restrict__ bias,
+    float* __restrict__ bias_acc, int d, const uint32_t* __restrict__ sk,
+    const uint32_t* __restrict__ spos, const int32_t* __restrict__ src,
+    const float* __restrict__ coef, int64_t n, const float* __restrict__ G, int64_t ldg,
+    const float* __restrict__ Gb, const float* __restrict__ lr_dev,
+    const float* __restrict__ gscale_dev, const float* __restrict__ scratch,
+    const float* __restrict__ scratch_b, const int32_t* __restrict__ list,
+    const int32_t* __restrict__ list_count) {
+  constexpr int NSG = 256 / LPR;  // sub-groups per workgroup
+  __shared__ __attribute__((aligned(16))) float sh[NSG][LPR * 4];
+  __shared__ float shb[NSG];
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % LPR;
+  const int gid = lane / LPR;
+  const int sg = threadIdx.x / LPR;
+  const int col = lig * 4;
+  const bool colok = col < d;
+  const int count = *list_count;
+  for (int it = blockIdx.x; it < count; it += gridDim.x) {
+    const int64_t h = list[it];
+    const uint32_t key = sk[h];
+    const int64_t first = (h / kPiece + 1) * kPiece;  // first aligned continuation piece
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    float gb = 0.f;
+    if (sg == 0) {  // recompute the head piece [h, first)
+      walk_piece<LPR>(sk, spos, src, coef, G, ldg, Gb, key, h, first, col, colok, lig, gid, g, gb);
+    }
+    // aligned pieces first + k*kPiece while they still carry the key
+    // sub-group sg takes the aligned pieces sg, sg+NSG, ... (sorted => monotone stop)
+    for (int64_t a = first + (int64_t)sg * kPiece; a < n; a += (int64_t)NSG * kPiece) {
+      if (sk[a] != key) break;
+      const int64_t slot = a / kPiece;
+      if (colok) g = f4_add2(g, *reinterpret_cast<const float4*>(scratch + slot * (int64_t)d + col));
+      gb += scratch_b[slot];
+    }
+    __syncthreads();
+    if (colok) *reinterpret_cast<float4*>(&sh[sg][col]) = g;
+    if (lig == 0) shb[sg] = gb;
+    __syncthreads();
+    if (sg == 0) {
+      float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+      float tb = 0.f;
+      for (int k = 0; k < NSG; ++k) {
+        if (colok) tot = f4_add2(tot, *reinterpret_cast<const float4*>(&sh[k][col]));
+        tb += shb[k];
+      }
+      adagrad_row(E, acc, bias, bias_acc, d, key, col, colok, lig, tot, tb, *lr_dev,
+                  gscale_dev ? *gscale_dev : 1.f);
+    }
+  }
+}
+
+__global__ void k_adagrad_dense(float* __restrict__ w, float* __restrict__ acc,
+                                const float* __restrict__ g, int64_t n,
+                                const float* __restrict__ lr_dev,
+                                const float* __restrict__ gscale_dev) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float lr = *lr_dev;
+  const float gs = gscale_dev ? *gscale_dev : 1.f;
+  for (; i < n; i += stride) {
+    const float gg = g[i] * gs;
+    const float a = acc[i] + gg * gg;
+    acc[i] = a;
+    w[i] -= lr * gg / sqrtf(a);
+  }
+}
+
+// deterministic two-stage squared norm: per-block partials then one block.
+__global__ __launch_bounds__(256) void k_sq_norm_partial(const float* __restrict__ x, int64_t n,
+                                                         int d, const float* __restrict__ row_scale,
+                                                         float* __restrict__ part) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float v = x[i];
+    s += (row_scale ? row_scale[i / d] : 1.f) * v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ void k_sq_norm_final(const float* __restrict__ part, int nb, float* __restrict__ out) {
+  // single wave
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 64) s += part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) *out += s;
+}
+
+__global__ void k_clip_coef(const float* __restrict__ sq, float max_norm, float* __restrict__ coef,
+                            float* __restrict__ gnorm) {
+  const float nrm = sqrtf(*sq);
+  if (gnorm) *gnorm = nrm;
+  *coef = max_norm / fmaxf(nrm, max_norm);
+}
+
+constexpr int kNormBlocks = 256;
+static __device__ float g_norm_part[kNormBlocks];
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct SparseWs {
+  size_t off_keys_tmp, off_keys_out, off_pos_in, off_pos_out, off_list, off_count, off_scratch,
+      off_scratch_b, off_temp, temp_bytes, total;
+};
+
+static int sparse_ws_layout(int64_t n, int d, SparseWs* w) {
+  size_t temp = 0;
+  hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t*, uint32_t*,
+                                           const uint32_t*, uint32_t*>(
+      nullptr, temp, nullptr, nullptr, nullptr, nullptr, (unsigned int)(n > 0 ? n : 1), 0, 32,
+      (hipStream_t)0, false);
+  if (e != hipSuccess) return ARX_EHIP;
+  const size_t ni = align_up((size_t)(n > 0 ? n : 1) * 4, 256);
+  const size_t pieces = (size_t)(n / kPiece + 2);
+  size_t o = 0;
+  w->off_keys_tmp = o; o += ni;
+  w->off_keys_out = o; o += ni;
+  w->off_pos_in = o; o += ni;
+  w->off_pos_out = o; o += ni;
+  w->off_list = o; o += align_up(pieces * 4, 256);
+  w->off_count = o; o += 256;
+  w->off_scratch = o; o += align_up(pieces * (size_t)d * 4, 256);
+  w->off_scratch_b = o; o += align_up(pieces * 4, 256);
+  w->off_temp = o; o += align_up(temp, 256);
+  w->temp_bytes = temp;
+  w->total = o;
+  return ARX_OK;
+}
+
+}  // namespace arx
+
+using namespace arx;
+
+#define ARX_DISPATCH_LPR(lpr, CALL)                   \
+  switch (lpr) {                                      \
+    case 1: { constexpr int LPR = 1; CALL; } break;   \
+    case 2: { constexpr int LPR = 2; CALL; } break;   \
+    case 4: { constexpr int LPR = 4; CALL; } break;   \
+    case 8: { constexpr int LPR = 8; CALL; } break;   \
+    case 16: { constexpr int LPR = 16; CALL; } break; \
+    case 32: { constexpr int LPR = 32; CALL; } break; \
+    default: { constexpr int LPR = 64; CALL; } break; \
+  }
+
+extern "C" {
+
+size_t arx_sparse_adagrad_workspace_bytes(int64_t n) {
+  SparseWs w;
+  if (sparse_ws_layout(n, 256, &w) != ARX_OK) return 0;  // d <= 256 (largest supported row)
+  return w.total;
+}
+
+int arx_sparse_adagrad(float* E, float* acc, float* bias, float* bias_acc, int d,
+                       const int32_t* keys, const int32_t* src, const float* coef, int64_t n,
+                       const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
+                       const float* gscale_dev, int key_bits, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  ARX_CHECK_ARG(E && acc && keys && G && lr_dev, "arx_sparse_adagrad: null pointer");
+  ARX_CHECK_ARG((bias == nullptr) == (bias_acc == nullptr), "arx_sparse_adagrad: bias and bias_acc go together");
+  ARX_CHECK_ARG(!(bias && !Gb), "arx_sparse_adagrad: bias table given without Gb");
+  if (d <= 0 || d % 4 != 0 || d > 256) {
+    set_error("arx_sparse_adagrad: d=%d unsupported (d %% 4 == 0, d <= 256)", d);
+    return ARX_EUNSUPPORTED;
+  }
+  ARX_CHECK_ARG(ldg % 4 == 0 && ldg >= d, "arx_sparse_adagrad: ldg must be a multiple of 4 and >= d");
+  ARX_CHECK_ARG(n >= 0 && n < (int64_t)0x7fffffff, "arx_sparse_adagrad: bad n");
+  if (n == 0) return ARX_OK;
+  SparseWs w;
+  int rc = sparse_ws_layout(n, 256, &w);
+  if (rc) { set_error("arx_sparse_adagrad: rocprim temp-size query failed"); return rc; }
+  if (!workspace || workspace_bytes < w.total) {
+    set_error("arx_sparse_adagrad: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+    return ARX_EWORKSPACE;
+  }
+  if (key_bits <= 0 || key_bits > 30) key_bits = 30;
+  const uint32_t sentinel = 1u << key_bits;
+  hipStream_t s = as_stream(stream);
+  char* base = reinterpret_cast<char*>(workspace);
+  uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(base + w.off_keys_tmp);
+  uint32_t* keys_out = reinterpret_cast<uint32_t*>(base + w.off_keys_out);
+  uint32_t* pos_in = reinterpret_cast<uint32_t*>(base + w.off_pos_in);
+  uint32_t* pos_out = reinterpret_cast<uint32_t*>(base + w.off_pos_out);
+  int32_t* list = reinterpret_cast<int32_t*>(base + w.off_list);
+  int32_t* count = reinterpret_cast<int32_t*>(base + w.off_count);
+  float* scratch = reinterpret_cast<float*>(base + w.off_scratch);
+  float* scratch_b = reinterpret_cast<float*>(base + w.off_scratch_b);
+  void* temp = base + w.off_temp;
+  {
+    int64_t g = ceil_div(n, 256);
+    int64_t cap = (int64_t)cu_count() * 8;
+    if (g > cap) g = cap;
+    k_prep_keys<<<(int)g, 256, 0, s>>>(keys, n, sentinel, keys_tmp, pos_in, count);
+    ARX_CHECK_LAUNCH();
+  }
+  size_t temp_bytes = w.temp_bytes;
+  ARX_CHECK_HIP((rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t*, uint32_t*,
+                                           const uint32_t*, uint32_t*>(
+      temp, temp_bytes, keys_tmp, keys_out, pos_in, pos_out, (unsigned int)n, 0, key_bits + 1, s,
+      false)));
+  const int lpr = lanes_per_row(d);
+  const int64_t nwaves = ceil_div(n, 64 / lpr);
+  const int grid_a = (int)ceil_div(nwaves, 4);
+  const float* gb_in = bias ? Gb : nullptr;
+  ARX_DISPATCH_LPR(lpr, (k_sparse_pass_a<LPR><<<grid_a, 256, 0, s>>>(
+                            E, acc, bias, bias_acc, d, keys_out, pos_out, src, coef, n, sentinel,
+                            G, ldg, gb_in, lr_dev, gscale_dev, scratch, scratch_b, list, count)));
+  ARX_CHECK_LAUNCH();
+  ARX_DISPATCH_LPR(lpr, (k_sparse_pass_b<LPR><<<kPassBBlocks, 256, 0, s>>>(
+                            E, acc, bias, bias_acc, d, keys_out, pos_out, src, coef, n, G, ldg,
+                            gb_in, lr_dev, gscale_dev, scratch, scratch_b, list, count)));
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const float* lr_dev,
+                      const float* gscale_dev, void* stream) {
+  ARX_CHECK_ARG(w && acc && g && lr_dev, "arx_adagrad_dense: null pointer");
+  if (n <= 0) return ARX_OK;
+  int64_t gr = ceil_div(n, 256);
+  int64_t cap = (int64_t)cu_count() * 8;
+  if (gr > cap) gr = cap;
+  k_adagrad_dense<<<(int)gr, 256, 0, as_stream(stream)>>>(w, acc, g, n, lr_dev, gscale_dev);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_sq_norm_accum(const float* x, int64_t n, int d, const float* row_scale, float* out_accum,
+                      void* stream) {
+  ARX_CHECK_ARG(x && out_accum && d > 0, "arx_sq_norm_accum: bad argument");
+  if (n <= 0) return ARX_OK;
+  float* part = nullptr;
+  ARX_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&part), HIP_SYMBOL(g_norm_part)));
+  int nb = (int)ceil_div(n, 256);
+  if (nb > kNormBlocks) nb = kNormBlocks;
+  k_sq_norm_partial<<<nb, 256, 0, as_stream(stream)>>>(x, n, d, row_scale, part);
+  ARX_CHECK_LAUNCH();
+  k_sq_norm_final<<<1, 64, 0, as_stream(stream)>>>(part, nb, out_accum);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_clip_coef(const float* sqnorm_dev, float max_norm, float* coef_out, float* gnorm_out,
+                  void* stream) {
+  ARX_CHECK_ARG(sqnorm_dev && coef_out, "arx_clip_coef: null pointer");
+  k_clip_coef<<<1, 1, 0, as_stream(stream)>>>(sqnorm_dev, max_norm, coef_out, gnorm_out);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+}  // extern "C"

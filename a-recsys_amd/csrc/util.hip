@@ -1,0 +1,360 @@
+// util.hip -- error state, device facts, small elementwise kernels, HIP-graph capture.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace arx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+      n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+// ---- kernels ---------------------------------------------------------------
+template <typename T>
+__global__ void k_fill(T* __restrict__ p, int64_t n, T v) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+__global__ void k_axpby(float a, const float* __restrict__ x, float b, float* __restrict__ y,
+                        int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (b == 0.f) {
+    for (; i < n; i += stride) y[i] = a * x[i];
+  } else {
+    for (; i < n; i += stride) y[i] = a * x[i] + b * y[i];
+  }
+}
+
+// y[r, c] = a * x[r % xrows, c] + b * y[r, c]; one thread per float4
+__global__ void k_add_rows_bcast(float a, const float* __restrict__ x, int64_t ldx,
+                                 int64_t xrows, float b, float* __restrict__ y, int64_t ldy,
+                                 int64_t rows, int d4) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t total = rows * d4;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    int64_t r = i / d4;
+    int c = (int)(i % d4) * 4;
+    float4 xv = *reinterpret_cast<const float4*>(x + (r % xrows) * ldx + c);
+    float4* yp = reinterpret_cast<float4*>(y + r * ldy + c);
+    float4 yv = (b == 0.f) ? make_float4(0, 0, 0, 0) : *yp;
+    yv.x = a * xv.x + b * yv.x;
+    yv.y = a * xv.y + b * yv.y;
+    yv.z = a * xv.z + b * yv.z;
+    yv.w = a * xv.w + b * yv.w;
+    *yp = yv;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// one wave per row
+__global__ void k_row_sum(const float* __restrict__ x, int64_t ld, int64_t rows, int64_t cols,
+                          float* __restrict__ out, int accumulate) {
+  int lane = threadIdx.x & 63;
+  int64_t w = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = w; r < rows; r += nw) {
+    const float* p = x + r * ld;
+    float s = 0.f;
+    for (int64_t c = lane; c < cols; c += 64) s += p[c];
+    s = wave_sum(s);
+    if (lane == 0) out[r] = accumulate ? out[r] + s : s;
+  }
+}
+
+// column sums: block (64 x 4) handles 64 columns; deterministic two-stage
+__global__ void k_col_sum(const float* __restrict__ x, int64_t ld, int64_t rows, int64_t cols,
+                          float* __restrict__ out) {
+  __shared__ float part[4][64];
+  int cx = threadIdx.x & 63;
+  int ry = threadIdx.x >> 6;
+  int64_t c = blockIdx.x * 64 + cx;
+  float s = 0.f;
+  if (c < cols)
+    for (int64_t r = ry; r < rows; r += 4) s += x[r * ld + c];
+  part[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < cols) out[c] = part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
+}
+
+// single block deterministic sum
+__global__ void k_sum_scaled(const float* __restrict__ x, int64_t n, float scale,
+                             float* __restrict__ out) {
+  __shared__ float part[16];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+  s = wave_sum(s);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) part[w] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[i];
+    *out = t * scale;
+  }
+}
+
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {
+  // splitmix64 finaliser -> 32 bits; counter-based, order independent
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+
+__global__ void k_dropout_fwd(const float* __restrict__ x, int64_t n, float keep_prob,
+                              uint64_t seed, float* __restrict__ y,
+                              uint8_t* __restrict__ keep) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float inv = 1.f / keep_prob;
+  for (; i < n; i += stride) {
+    float u = (mix32(seed * 0x100000001b3ull + (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
+    uint8_t k = (u < keep_prob) ? 1 : 0;
+    if (keep) keep[i] = k;
+    y[i] = k ? x[i] * inv : 0.f;
+  }
+}
+
+__global__ void k_dropout_bwd(const float* __restrict__ dy, const uint8_t* __restrict__ keep,
+                              int64_t n, float keep_prob, float* __restrict__ dx) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float inv = 1.f / keep_prob;
+  for (; i < n; i += stride) dx[i] = keep[i] ? dy[i] * inv : 0.f;
+}
+
+__global__ void k_act_fwd(const float* __restrict__ x, int64_t n, int kind,
+                          float* __restrict__ y) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = kind == 0 ? fmaxf(x[i], 0.f) : tanhf(x[i]);
+}
+
+__global__ void k_act_bwd(const float* __restrict__ y, const float* __restrict__ dy, int64_t n,
+                          int kind, float* __restrict__ dx) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float yy = y[i];
+    dx[i] = dy[i] * (kind == 0 ? (yy > 0.f ? 1.f : 0.f) : (1.f - yy * yy));
+  }
+}
+
+__global__ void k_add_col_bias(float* __restrict__ y, int64_t ld, int64_t rows, int64_t cols,
+                               const float* __restrict__ b) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t total = rows * cols;
+  for (; i < total; i += stride) {
+    int64_t r = i / cols, c = i % cols;
+    y[r * ld + c] += b[c];
+  }
+}
+
+static inline int grid_for(int64_t n, int block) {
+  int64_t g = ceil_div(n, block);
+  int64_t cap = (int64_t)cu_count() * 8;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace arx
+
+using namespace arx;
+
+extern "C" {
+
+const char* arx_last_error(void) { return g_err; }
+
+int arx_version(void) { return 100; }
+
+int arx_device_info(int* cu, int* wave, int* lds_bytes, char* arch, int arch_len) {
+  int dev = 0;
+  ARX_CHECK_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  ARX_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+  if (cu) *cu = p.multiProcessorCount;
+  if (wave) *wave = p.warpSize;
+  if (lds_bytes) *lds_bytes = (int)p.sharedMemPerBlock;
+  if (arch && arch_len > 0) {
+    strncpy(arch, p.gcnArchName, arch_len - 1);
+    arch[arch_len - 1] = 0;
+  }
+  return ARX_OK;
+}
+
+int arx_fill_f32(float* p, int64_t n, float v, void* stream) {
+  ARX_CHECK_ARG(p || n == 0, "arx_fill_f32: null pointer");
+  if (n <= 0) return ARX_OK;
+  k_fill<float><<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(p, n, v);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_fill_i32(int32_t* p, int64_t n, int32_t v, void* stream) {
+  ARX_CHECK_ARG(p || n == 0, "arx_fill_i32: null pointer");
+  if (n <= 0) return ARX_OK;
+  k_fill<int32_t><<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(p, n, v);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_fill_u8(uint8_t* p, int64_t n, int v, void* stream) {
+  ARX_CHECK_ARG(p || n == 0, "arx_fill_u8: null pointer");
+  if (n <= 0) return ARX_OK;
+  ARX_CHECK_HIP(hipMemsetAsync(p, v, (size_t)n, as_stream(stream)));
+  return ARX_OK;
+}
+
+int arx_axpby(float a, const float* x, float b, float* y, int64_t n, void* stream) {
+  ARX_CHECK_ARG(x && y, "arx_axpby: null pointer");
+  if (n <= 0) return ARX_OK;
+  k_axpby<<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(a, x, b, y, n);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_add_rows_bcast(float a, const float* x, int64_t ldx, int64_t xrows, float b, float* y,
+                       int64_t ldy, int64_t rows, int d, void* stream) {
+  ARX_CHECK_ARG(x && y && xrows > 0, "arx_add_rows_bcast: bad argument");
+  ARX_CHECK_ARG(d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "arx_add_rows_bcast: d, ld must be multiples of 4");
+  if (rows <= 0) return ARX_OK;
+  k_add_rows_bcast<<<grid_for(rows * (d / 4), 256), 256, 0, as_stream(stream)>>>(
+      a, x, ldx, xrows, b, y, ldy, rows, d / 4);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_row_sum(const float* x, int64_t ld, int64_t rows, int64_t cols, float* out,
+                int accumulate, void* stream) {
+  ARX_CHECK_ARG(x && out, "arx_row_sum: null pointer");
+  if (rows <= 0) return ARX_OK;
+  k_row_sum<<<grid_for(rows * 64, 256), 256, 0, as_stream(stream)>>>(x, ld, rows, cols, out,
+                                                                      accumulate);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_col_sum(const float* x, int64_t ld, int64_t rows, int64_t cols, float* out,
+                void* stream) {
+  ARX_CHECK_ARG(x && out, "arx_col_sum: null pointer");
+  if (cols <= 0) return ARX_OK;
+  k_col_sum<<<(int)ceil_div(cols, 64), 256, 0, as_stream(stream)>>>(x, ld, rows, cols, out);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_sum_scaled(const float* x, int64_t n, float scale, float* out, void* stream) {
+  ARX_CHECK_ARG(x && out, "arx_sum_scaled: null pointer");
+  k_sum_scaled<<<1, 1024, 0, as_stream(stream)>>>(x, n, scale, out);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_dropout_fwd(const float* x, int64_t n, float keep_prob, uint64_t seed, float* y,
+                    uint8_t* keep_mask, void* stream) {
+  ARX_CHECK_ARG(x && y, "arx_dropout_fwd: null pointer");
+  ARX_CHECK_ARG(keep_prob > 0.f && keep_prob <= 1.f, "arx_dropout_fwd: keep_prob must be in (0,1]");
+  if (n <= 0) return ARX_OK;
+  k_dropout_fwd<<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(x, n, keep_prob, seed, y,
+                                                                 keep_mask);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_dropout_bwd(const float* dy, const uint8_t* keep_mask, int64_t n, float keep_prob,
+                    float* dx, void* stream) {
+  ARX_CHECK_ARG(dy && keep_mask && dx, "arx_dropout_bwd: null pointer");
+  if (n <= 0) return ARX_OK;
+  k_dropout_bwd<<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(dy, keep_mask, n, keep_prob,
+                                                                 dx);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_act_fwd(const float* x, int64_t n, int kind, float* y, void* stream) {
+  ARX_CHECK_ARG(x && y && (kind == 0 || kind == 1), "arx_act_fwd: bad argument");
+  if (n <= 0) return ARX_OK;
+  k_act_fwd<<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(x, n, kind, y);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_act_bwd(const float* y, const float* dy, int64_t n, int kind, float* dx, void* stream) {
+  ARX_CHECK_ARG(y && dy && dx && (kind == 0 || kind == 1), "arx_act_bwd: bad argument");
+  if (n <= 0) return ARX_OK;
+  k_act_bwd<<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(y, dy, n, kind, dx);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_add_col_bias(float* y, int64_t ld, int64_t rows, int64_t cols, const float* b,
+                     void* stream) {
+  ARX_CHECK_ARG(y && b, "arx_add_col_bias: null pointer");
+  if (rows * cols <= 0) return ARX_OK;
+  k_add_col_bias<<<grid_for(rows * cols, 256), 256, 0, as_stream(stream)>>>(y, ld, rows, cols, b);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+// ---- HIP graph capture -------------------------------------------------------
+int arx_capture_begin(void* stream) {
+  ARX_CHECK_HIP(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
+  return ARX_OK;
+}
+
+int arx_capture_end(void* stream, void** graph_exec_out) {
+  ARX_CHECK_ARG(graph_exec_out, "arx_capture_end: null out pointer");
+  hipGraph_t g = nullptr;
+  ARX_CHECK_HIP(hipStreamEndCapture(as_stream(stream), &g));
+  hipGraphExec_t e = nullptr;
+  hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (err != hipSuccess) {
+    set_error("hipGraphInstantiate failed: %s", hipGetErrorString(err));
+    return ARX_EHIP;
+  }
+  *graph_exec_out = (void*)e;
+  return ARX_OK;
+}
+
+int arx_graph_launch(void* graph_exec, void* stream) {
+  ARX_CHECK_ARG(graph_exec, "arx_graph_launch: null graph");
+  ARX_CHECK_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, as_stream(stream)));
+  return ARX_OK;
+}
+
+int arx_graph_destroy(void* graph_exec) {
+  if (graph_exec) ARX_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return ARX_OK;
+}
+
+}  // extern "C"

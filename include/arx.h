@@ -1,0 +1,243 @@
+/* arx.h -- C ABI of libarx.so: the MI355X (gfx950) hot path of A-RecSys.
+ *
+ * The reference (skywaLKer518/A-Recsys) has no FFI: its hot path is a TF-1.0
+ * op graph built by Python classes.  This header is the boundary a maintainer
+ * binds with ctypes; every entry point cites the reference
+ * call site(s) whose arithmetic it replaces (paths relative to the reference
+ * root).  Conventions:
+ *   - extern "C"; returns 0 (ARX_OK) or a negative ARX_E* code; the message for
+ *     the calling thread is available from arx_last_error().
+ *   - every buffer is a CALLER-OWNED DEVICE pointer (torch tensors are only the
+ *     holders); element counts are int64_t; table-row / token indices int32_t.
+ *   - row-major fp32 everywhere, explicit leading dimensions in elements.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *     no hidden allocation: scratch comes from a caller-sized workspace.
+ *   - no exceptions / C++ types cross the boundary.
+ */
+#ifndef ARX_H_
+#define ARX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARX_OK 0
+#define ARX_EINVAL (-1)       /* bad argument (null pointer, bad size, alignment) */
+#define ARX_EHIP (-2)         /* a HIP runtime call / launch failed */
+#define ARX_EWORKSPACE (-3)   /* workspace too small */
+#define ARX_EUNSUPPORTED (-4) /* shape outside the implemented envelope */
+
+#define ARX_KEY_NONE 0x7fffffff /* "no row": skipped by arx_sparse_adagrad */
+
+/* ---- library ---------------------------------------------------------- */
+const char* arx_last_error(void);
+int arx_version(void);
+/* device facts used by bench.py's roofline (CU count, wave size, arch name) */
+int arx_device_info(int* cu_count, int* wave_size, int* lds_bytes, char* arch, int arch_len);
+
+/* ---- a4 / a7: ragged CSR expansion (integer, bit-exact) ----------------
+ * attributes/mulhot_index.py:48-52 batch_slice2 and :62-67 batch_segids2, as
+ * used by embed_attribute.py:392-396 (batch lookup) and :331-347 (sampled-pool
+ * staging).  For r in [0,B): row = row_ids ? row_ids[r] : r,
+ *   offsets[r] = sum_{q<r} lens[row_q]            (offsets[B] = total)
+ *   token_ids[offsets[r]+j] = vals[starts[row]+j],  segids[offsets[r]+j] = r.
+ * Positions in [total, capacity) are filled with pad_token / pad_seg.
+ * *total_out (device int32) receives the packed length (embed_attribute.py:338,347).
+ * For the gradient scatter the same expansion also yields, per token, the
+ * gradient-source row and the 1/len factor of tf.div's gradient: segids are
+ * offset by seg_base and coef_out[q] = coef_scale / lens[row] (nullable).
+ * workspace: arx_csr_expand_workspace_bytes(B). */
+size_t arx_csr_expand_workspace_bytes(int64_t B);
+int arx_csr_expand(const int32_t* vals, const int32_t* starts, const int32_t* lens,
+                   const int32_t* row_ids, int64_t B,
+                   int32_t* token_ids, int32_t* segids, int64_t capacity,
+                   int32_t* offsets, int32_t* total_out,
+                   int32_t pad_token, int32_t pad_seg,
+                   int32_t seg_base, float coef_scale, float* coef_out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* One-hot twin of the above for the gradient scatter (a17): keys_out[i] =
+ * cat_map ? cat_map[ids[i]] : ids[i]; src_out[i] = row_base + i; coef_out[i] = coef. */
+int arx_sparse_site_onehot(const int32_t* cat_map, const int32_t* ids, int64_t n,
+                           int32_t row_base, float coef, int32_t* keys_out, int32_t* src_out,
+                           float* coef_out, void* stream);
+
+/* ---- a5: one-hot attribute gather --------------------------------------
+ * embed_attribute.py:371-381: rows = cat_map[ids]; E[rows] (+ bias[rows]).
+ * out[r, 0:d] = (accumulate ? out : 0) + scale * E[cat_map[ids[r]], :]
+ * bias_out[r] likewise from bias[Vf] (both nullable together).
+ * cat_map may be NULL (identity).  d % 4 == 0, d <= 1024. */
+int arx_gather_onehot_fwd(const float* E, const float* bias, const int32_t* cat_map,
+                          const int32_t* ids, int64_t B, int d, float scale, int accumulate,
+                          float* out, int64_t ldo, float* bias_out, void* stream);
+
+/* ---- a5: multi-hot gather + segment-mean (K1) ---------------------------
+ * embed_attribute.py:382-407 with mulhot_index.py:48-67 fused in:
+ *   bag(r) = vals[starts[id_r] : starts[id_r] + lens[id_r]]
+ *   out[r,:] = (accumulate ? out : 0) + scale * (sum_k E[bag_k,:]) / lens[id_r]
+ * bias_out[r] likewise (tf.div of unsorted_segment_sum by float length). */
+int arx_gather_mulhot_mean_fwd(const float* E, const float* bias, const int32_t* vals,
+                               const int32_t* starts, const int32_t* lens,
+                               const int32_t* ids, int64_t B, int d, float scale,
+                               int accumulate, float* out, int64_t ldo, float* bias_out,
+                               void* stream);
+
+/* ---- a9: target dot score ------------------------------------------------
+ * embed_attribute.py:219-220: score[r] = sum_d(U[r,:]*T[r,:]) + tbias[r]. */
+int arx_dot_score_fwd(const float* U, int64_t ldu, const float* T, int64_t ldt,
+                      const float* tbias, int64_t B, int d, float* score, void* stream);
+/* dU[r,:] = (acc_dU ? dU : 0) + ds[r]*T[r,:];  dT[r,:] = ds[r]*U[r,:] (dT nullable) */
+int arx_dot_score_bwd(const float* U, int64_t ldu, const float* T, int64_t ldt,
+                      const float* dscore, int64_t B, int d, float* dU, int64_t lddu,
+                      int acc_dU, float* dT, int64_t lddt, void* stream);
+
+/* ---- a8: scorer GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32) --------------
+ * embed_attribute.py:171,188-193,205 in embedding-space form:
+ *   C[M,N] = alpha * op(A)[M,K] . op(B)[K,N] + beta * C + col_bias[n]
+ * transA=0: A stored [M,K] (lda>=K); transA=1: A stored [K,M] (lda>=M).
+ * transB=0: B stored [K,N] (ldb>=N); transB=1: B stored [N,K] (ldb>=K).
+ * col_bias nullable.  Split-K (deterministic, workspace partials) is chosen
+ * internally; workspace >= arx_gemm_f32_workspace_bytes(M,N,K). */
+size_t arx_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int arx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                 const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+                 float* C, int64_t ldc, const float* col_bias,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a14: positive mask ---------------------------------------------------
+ * embed_attribute.py:651-672 (mask variable + scatter_update set/reset) and
+ * :721-745 (host index list).  For each batch row r and each positive item v
+ * of user_ids[r] (CSR pos_ptr/pos_items over users; users without positives
+ * have empty rows): j = item2slot[v]; if j >= 0: mask[r*ldm + j] = value.
+ * value=0 is set_mask, value=1 is reset_mask.  mask is uint8, 1 = keep. */
+int arx_pos_mask_scatter(const int32_t* user_ids, int64_t B, const int32_t* pos_ptr,
+                         const int32_t* pos_items, const int32_t* item2slot,
+                         uint8_t* mask, int64_t ldm, int value, void* stream);
+/* item -> pool-slot map maintenance for the sampled pool (the device twin of
+ * utils/prepare_train.py:12-16 item_sampled_id2idx): map[ids[s]] = s (or -1). */
+int arx_slot_map_set(int32_t* item2slot, const int32_t* ids, int64_t S, int clear, void* stream);
+
+/* ---- a10-a12: batch losses, forward + backward fused ---------------------
+ * d(total)/d(batch_loss[r]) = gscale * (row_w ? row_w[r] : 1).
+ * The mask row of logits row r is r % mask_rows (the LSTM path scores L*B
+ * time-major rows against one [B, S] mask, seqModel.py:489-493); mask NULL = all kept.
+ * dlogits may alias logits (in place) or be NULL (forward only).
+ * mw   : embed_attribute.py:641-649  log(1 + sum_s relu(mask*(x - t + 1)))
+ * warp : embed_attribute.py:605-618  same with t = logits[r,target[r]] over V
+ * ce   : embed_attribute.py:529-531  sparse softmax cross entropy           */
+int arx_loss_mw_fwdbwd(const float* logits, int64_t ldl, const float* tscore,
+                       const uint8_t* mask, int64_t ldm, int64_t mask_rows, float gscale,
+                       const float* row_w,
+                       int64_t B, int64_t S, float* batch_loss, float* dlogits, int64_t lddl,
+                       float* dtscore, void* stream);
+int arx_loss_warp_fwdbwd(const float* logits, int64_t ldl, const int32_t* target,
+                         const uint8_t* mask, int64_t ldm, int64_t mask_rows, float gscale,
+                         const float* row_w,
+                         int64_t B, int64_t V, float* batch_loss, float* dlogits, int64_t lddl,
+                         void* stream);
+int arx_loss_ce_fwdbwd(const float* logits, int64_t ldl, const int32_t* target, float gscale,
+                       const float* row_w, int64_t B, int64_t V, float* batch_loss,
+                       float* dlogits, int64_t lddl, void* stream);
+/* embed_attribute.py:620-639 warp_eval -> margin_rank[B] (float), true_rank[B] (int32) */
+int arx_loss_warp_eval(const float* logits, int64_t ldl, const int32_t* target,
+                       const uint8_t* mask, int64_t ldm, int64_t mask_rows, int64_t B, int64_t V,
+                       float* margin_rank, int32_t* true_rank, void* stream);
+
+/* ---- a17: embedding_lookup gradient scatter fused with sparse Adagrad (K7)
+ * hmf_model.py:146-151 / seqModel.py:173-182 restricted to the rows that
+ * receive gradient.  n contributions i: table row keys[i] (ARX_KEY_NONE =
+ * skip) receives coef[i] * G[src[i], 0:d] (and coef[i]*Gb[src[i]] for the
+ * bias table).  Duplicates are summed first (stable sort by key => fixed
+ * summation order), then ONE Adagrad application per unique row:
+ *   g *= *gscale_dev (nullable; clip_by_global_norm coefficient)
+ *   acc[row] += g^2 ; E[row] -= *lr_dev * g / sqrt(acc[row])
+ * src NULL => identity; coef NULL => 1.  bias/bias_acc/Gb nullable together.
+ * key_bits: number of significant key bits (0 => 31) to shorten the sort. */
+size_t arx_sparse_adagrad_workspace_bytes(int64_t n);
+int arx_sparse_adagrad(float* E, float* acc, float* bias, float* bias_acc, int d,
+                       const int32_t* keys, const int32_t* src, const float* coef, int64_t n,
+                       const float* G, int64_t ldg, const float* Gb,
+                       const float* lr_dev, const float* gscale_dev, int key_bits,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a16/a19: dense Adagrad, norms, clip ---------------------------------
+ * tf.train.AdagradOptimizer dense apply; tf.clip_by_global_norm
+ * (seqModel.py:180): coef = max_norm / max(sqrt(sq), max_norm). */
+int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const float* lr_dev,
+                      const float* gscale_dev, void* stream);
+/* *out_accum += sum_i w_i * x_i^2 with w_i = row_scale ? row_scale[i / d] : 1 */
+int arx_sq_norm_accum(const float* x, int64_t n, int d, const float* row_scale,
+                      float* out_accum, void* stream);
+int arx_clip_coef(const float* sqnorm_dev, float max_norm, float* coef_out, float* gnorm_out,
+                  void* stream);
+
+/* ---- small device utilities ------------------------------------------------ */
+int arx_fill_f32(float* p, int64_t n, float v, void* stream);
+int arx_fill_i32(int32_t* p, int64_t n, int32_t v, void* stream);
+int arx_fill_u8(uint8_t* p, int64_t n, int v, void* stream);
+/* y = a*x + b*y  (n elements) */
+int arx_axpby(float a, const float* x, float b, float* y, int64_t n, void* stream);
+/* y[r,0:d] = a*x[r % xrows, 0:d] + b*y[r,0:d]  (row broadcast, rows = n) */
+int arx_add_rows_bcast(float a, const float* x, int64_t ldx, int64_t xrows, float b, float* y,
+                       int64_t ldy, int64_t rows, int d, void* stream);
+/* out[r] = sum_c x[r*ld + c]  (rows x cols), out (+)= when accumulate */
+int arx_row_sum(const float* x, int64_t ld, int64_t rows, int64_t cols, float* out,
+                int accumulate, void* stream);
+/* out[c] = sum_r x[r*ld + c] * (row_w ? row_w[r] : 1) */
+int arx_col_sum(const float* x, int64_t ld, int64_t rows, int64_t cols, float* out,
+                void* stream);
+/* mean over rows: *out = scale * sum_i x[i] */
+int arx_sum_scaled(const float* x, int64_t n, float scale, float* out, void* stream);
+/* tf.nn.dropout (embed_attribute.py:236): y = x * keep_mask / keep_prob, counter RNG */
+int arx_dropout_fwd(const float* x, int64_t n, float keep_prob, uint64_t seed, float* y,
+                    uint8_t* keep_mask, void* stream);
+int arx_dropout_bwd(const float* dy, const uint8_t* keep_mask, int64_t n, float keep_prob,
+                    float* dx, void* stream);
+/* elementwise activation for the optional MLP (hmf_model.py:80-94): kind 0=relu 1=tanh */
+int arx_act_fwd(const float* x, int64_t n, int kind, float* y, void* stream);
+int arx_act_bwd(const float* y, const float* dy, int64_t n, int kind, float* dx, void* stream);
+/* y[r,c] += b[c] */
+int arx_add_col_bias(float* y, int64_t ld, int64_t rows, int64_t cols, const float* b,
+                     void* stream);
+
+/* ---- a16 (next): top-k over logits rows ------------------------------------
+ * hmf_model.py:154 tf.nn.top_k(logits, k, sorted=True): descending values,
+ * ties broken by lower index.  k <= 1024. */
+int arx_topk(const float* logits, int64_t ld, int64_t B, int64_t V, int k, float* values,
+             int32_t* indices, void* stream);
+
+/* ---- a19-a20: LSTM encoder (K9) ---------------------------------------------
+ * lstm/seqModel.py:99-103,477 -- tf.contrib.rnn LSTMCell(h), no peepholes,
+ * forget_bias=1, gate order i,j,f,o, zero initial state, static_rnn over L
+ * steps.  x: [L,B,din] time-major; W: [(din+h), 4h]; b: [4h].
+ * hs: [L,B,h] outputs; gates: [L,B,4h] post-activation (i, j=tanh, f, o) and
+ * cs: [L,B,h] cell states are saved for backward. */
+int arx_lstm_fwd(const float* x, const float* W, const float* b, int64_t L, int64_t B,
+                 int din, int h, float forget_bias, float* hs, float* cs, float* gates,
+                 void* stream);
+/* dhs: [L,B,h] upstream gradient of every output.  Produces dz [L,B,4h]
+ * (pre-activation gate gradients, BPTT through h and c).  dx, dW and db are
+ * then plain GEMMs / a column sum over dz that the caller issues
+ * (arx_gemm_f32 with W_x^T, [x;h_prev]^T . dz, arx_col_sum). */
+int arx_lstm_bwd(const float* W, const float* hs, const float* cs, const float* gates,
+                 const float* dhs, int64_t L, int64_t B, int din, int h, float* dz,
+                 void* stream);
+
+/* lstm/seqModel.py:551-567 sequence_loss_by_example: per-row loss weights
+ * out[t,b] = w[t,b] / (sum_t w[t,b] + 1e-12)  (w time-major [L,B]). */
+int arx_seq_weights(const float* w, int64_t L, int64_t B, float* out, void* stream);
+
+/* ---- HIP-graph capture of a whole step ---------------------------------------
+ * The per-step kernel sequence has static shapes and pointers, so the host
+ * captures it once and replays it (MI355X launch-bound regime at B=64). */
+int arx_capture_begin(void* stream);
+int arx_capture_end(void* stream, void** graph_exec_out);
+int arx_graph_launch(void* graph_exec, void* stream);
+int arx_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARX_H_ */

@@ -1,0 +1,466 @@
+"""Per-kernel parity: every C-ABI entry point against a numpy restatement of the
+TF op it replaces (oracle.ref_graph helpers / plain numpy), on seeded inputs.
+Integer outputs bit-exact; fp32 rtol 1e-4 (north_star tolerance)."""
+import numpy as np
+import pytest
+
+from oracle import ref_graph as rg
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+ATOL = 1e-5
+
+
+def _t(dev, a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _csr(rng, n_rows, vocab, max_len, zipf=False, min_len=1):
+    lens = rng.integers(min_len, max_len + 1, size=n_rows).astype(np.int32)
+    starts = np.zeros(n_rows + 1, dtype=np.int32)
+    starts[1:] = np.cumsum(lens)
+    if zipf:
+        p = 1.0 / np.arange(1, vocab + 1)
+        p /= p.sum()
+        vals = rng.choice(vocab, size=int(starts[-1]), p=p).astype(np.int32)
+    else:
+        vals = rng.integers(0, vocab, size=int(starts[-1])).astype(np.int32)
+    return vals, starts[:-1].copy(), lens
+
+
+@pytest.mark.parametrize("B,max_len", [(1, 1), (7, 5), (256, 64), (1000, 20), (5000, 8)])
+def test_csr_expand_bit_exact(dev, B, max_len):
+    from arx import ops
+    rng = np.random.default_rng(B)
+    n_rows = 3000
+    vals, starts, lens = _csr(rng, n_rows, 50000, max_len)
+    ids = rng.integers(0, n_rows, size=B).astype(np.int32)
+    exp_tok = rg.batch_slice2(vals, starts[ids], lens[ids])
+    exp_seg = rg.batch_segids2(lens[ids])
+    T = len(exp_tok)
+    cap = T + 37
+    ws = ops.Workspace(dev)
+    tok, seg, offs, tot, coef = ops.csr_expand(_t(dev, vals), _t(dev, starts), _t(dev, lens),
+                                               _t(dev, ids), cap, ws, pad_token=-7, pad_seg=-9,
+                                               seg_base=100, coef_scale=0.5, want_coef=True)
+    tok, seg, offs, tot, coef = [x.cpu().numpy() for x in (tok, seg, offs, tot, coef)]
+    assert int(tot[0]) == T
+    np.testing.assert_array_equal(tok[:T], exp_tok)
+    np.testing.assert_array_equal(seg[:T], exp_seg + 100)
+    np.testing.assert_array_equal(tok[T:], -7)
+    np.testing.assert_array_equal(seg[T:], -9)
+    np.testing.assert_array_equal(offs, np.concatenate([[0], np.cumsum(lens[ids])]))
+    np.testing.assert_allclose(coef[:T], 0.5 / lens[ids][exp_seg].astype(np.float32), rtol=1e-7)
+    assert np.all(coef[T:] == 0)
+
+
+def test_csr_expand_empty_and_zero_len(dev):
+    from arx import ops
+    import torch
+    ws = ops.Workspace(dev)
+    vals = _t(dev, np.arange(10, dtype=np.int32))
+    starts = _t(dev, np.array([0, 3, 3, 6], dtype=np.int32))
+    lens = _t(dev, np.array([3, 0, 3, 0], dtype=np.int32))
+    ids = _t(dev, np.array([1, 0, 3, 2, 1], dtype=np.int32))
+    tok, seg, offs, tot, _ = ops.csr_expand(vals, starts, lens, ids, 8, ws, pad_token=-1, pad_seg=-1)
+    assert int(tot.item()) == 6
+    np.testing.assert_array_equal(tok.cpu().numpy(), [0, 1, 2, 3, 4, 5, -1, -1])
+    np.testing.assert_array_equal(seg.cpu().numpy(), [1, 1, 1, 3, 3, 3, -1, -1])
+    empty = torch.empty(0, dtype=torch.int32, device=dev)
+    tok, seg, offs, tot, _ = ops.csr_expand(vals, starts, lens, empty, 4, ws, pad_token=-1, pad_seg=-1)
+    assert int(tot.item()) == 0 and int(offs[0].item()) == 0
+    np.testing.assert_array_equal(tok.cpu().numpy(), [-1] * 4)
+
+
+@pytest.mark.parametrize("d", [4, 20, 32, 64, 128, 256])
+def test_gather_onehot(dev, d):
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(d)
+    Vf, N, B = 1000, 700, 333
+    E = rng.standard_normal((Vf, d)).astype(np.float32)
+    bias = rng.standard_normal((Vf,)).astype(np.float32)
+    cmap = rng.integers(0, Vf, size=N).astype(np.int32)
+    ids = rng.integers(0, N, size=B).astype(np.int32)
+    out = torch.full((B, d), 3.0, dtype=torch.float32, device=dev)
+    bout = torch.full((B,), 2.0, dtype=torch.float32, device=dev)
+    ops.gather_onehot(_t(dev, E), _t(dev, bias), _t(dev, cmap), _t(dev, ids), out, scale=0.5,
+                      accumulate=True, bias_out=bout)
+    np.testing.assert_allclose(out.cpu().numpy(), 3.0 + 0.5 * E[cmap[ids]], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(bout.cpu().numpy(), 2.0 + 0.5 * bias[cmap[ids]], rtol=RTOL, atol=ATOL)
+    out2 = torch.empty((B, d), dtype=torch.float32, device=dev)
+    ops.gather_onehot(_t(dev, E), None, None, _t(dev, cmap[ids]), out2)
+    np.testing.assert_array_equal(out2.cpu().numpy(), E[cmap[ids]])
+
+
+@pytest.mark.parametrize("d,max_len,B", [(128, 64, 1000), (32, 18, 64), (64, 5, 257), (20, 3, 10),
+                                         (128, 200, 50)])
+def test_gather_mulhot_mean(dev, d, max_len, B):
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(d + max_len)
+    Vf, N = 5000, 2000
+    E = rng.standard_normal((Vf, d)).astype(np.float32)
+    bias = rng.standard_normal((Vf,)).astype(np.float32)
+    vals, starts, lens = _csr(rng, N, Vf, max_len, zipf=True)
+    ids = rng.integers(0, N, size=B).astype(np.int32)
+    tok = rg.batch_slice2(vals, starts[ids], lens[ids])
+    seg = rg.batch_segids2(lens[ids])
+    ref = rg.unsorted_segment_sum(E.astype(np.float64)[tok], seg, B) / lens[ids].reshape(-1, 1)
+    refb = rg.unsorted_segment_sum(bias.astype(np.float64)[tok].reshape(-1, 1), seg, B)[:, 0] / lens[ids]
+    out = torch.empty((B, d), dtype=torch.float32, device=dev)
+    bout = torch.empty((B,), dtype=torch.float32, device=dev)
+    ops.gather_mulhot_mean(_t(dev, E), _t(dev, bias), _t(dev, vals), _t(dev, starts), _t(dev, lens),
+                           _t(dev, ids), out, bias_out=bout)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(bout.cpu().numpy(), refb, rtol=RTOL, atol=ATOL)
+    # accumulate + scale into a strided (concat) destination
+    wide = torch.ones((B, d + 8), dtype=torch.float32, device=dev)
+    ops.gather_mulhot_mean(_t(dev, E), None, _t(dev, vals), _t(dev, starts), _t(dev, lens),
+                           _t(dev, ids), wide[:, 4:4 + d], scale=0.25, accumulate=True)
+    w = wide.cpu().numpy()
+    np.testing.assert_allclose(w[:, 4:4 + d], 1 + 0.25 * ref, rtol=RTOL, atol=ATOL)
+    assert np.all(w[:, :4] == 1) and np.all(w[:, 4 + d:] == 1)
+
+
+def test_dot_score(dev):
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(0)
+    for d in (32, 128):
+        B = 517
+        U = rng.standard_normal((B, d)).astype(np.float32)
+        T = rng.standard_normal((B, d)).astype(np.float32)
+        tb = rng.standard_normal((B,)).astype(np.float32)
+        s = torch.empty(B, dtype=torch.float32, device=dev)
+        ops.dot_score(_t(dev, U), _t(dev, T), _t(dev, tb), s)
+        np.testing.assert_allclose(s.cpu().numpy(), (U.astype(np.float64) * T).sum(1) + tb,
+                                   rtol=RTOL, atol=1e-4)
+        ds = rng.standard_normal((B,)).astype(np.float32)
+        dU = torch.ones((B, d), dtype=torch.float32, device=dev)
+        dT = torch.empty((B, d), dtype=torch.float32, device=dev)
+        ops.dot_score_bwd(_t(dev, U), _t(dev, T), _t(dev, ds), dU, True, dT)
+        np.testing.assert_allclose(dU.cpu().numpy(), 1 + ds[:, None] * T, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(dT.cpu().numpy(), ds[:, None] * U, rtol=RTOL, atol=ATOL)
+
+
+GEMM_CASES = [
+    # transA, transB, M, N, K
+    (False, True, 64, 1024, 32),      # C1-like logits
+    (False, True, 4096, 1024, 128),   # C2 logits (big tiles)
+    (False, False, 4096, 128, 1024),  # dU (split-K)
+    (True, False, 1024, 128, 4096),   # dI (split-K)
+    (False, True, 64, 3100, 32),      # C1 full logits
+    (True, False, 3100, 32, 64),      # C1 dI, N=32 < tile
+    (False, False, 64, 32, 3100),     # C1 dU, K not multiple of 16
+    (False, True, 33, 77, 19),        # ragged everything (scalar load path)
+    (True, True, 129, 65, 130),
+    (False, False, 3200, 64, 1024),   # LSTM dH
+]
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K", GEMM_CASES)
+def test_gemm_f32(dev, tA, tB, M, N, K):
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
+    Bm = rng.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    bias = rng.standard_normal((N,)).astype(np.float32)
+    opA = A.T if tA else A
+    opB = Bm.T if tB else Bm
+    ref = 0.5 * (opA.astype(np.float64) @ opB.astype(np.float64)) + 2.0 * C0 + bias
+    C = _t(dev, C0)
+    ws = ops.Workspace(dev)
+    ops.gemm(_t(dev, A), _t(dev, Bm), C, ws, transA=tA, transB=tB, alpha=0.5, beta=2.0,
+             col_bias=_t(dev, bias))
+    torch.cuda.synchronize()
+    scale = np.abs(opA).astype(np.float64) @ np.abs(opB).astype(np.float64)
+    err = np.abs(C.cpu().numpy() - ref)
+    assert np.all(err <= 2e-6 * scale + 1e-5), float((err / (scale + 1e-9)).max())
+    # transpose detection: asymmetric inputs already; also check plain alpha=1,beta=0
+    C2 = torch.empty((M, N), dtype=torch.float32, device=dev)
+    ops.gemm(_t(dev, A), _t(dev, Bm), C2, ws, transA=tA, transB=tB)
+    ref2 = opA.astype(np.float64) @ opB.astype(np.float64)
+    err2 = np.abs(C2.cpu().numpy() - ref2)
+    assert np.all(err2 <= 2e-6 * scale + 1e-5)
+
+
+def _mask(rng, B, W, p=0.05):
+    return (rng.random((B, W)) > p)
+
+
+@pytest.mark.parametrize("B,S", [(64, 1024), (5, 100), (33, 3100)])
+def test_loss_mw(dev, B, S):
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(B + S)
+    logits = rng.standard_normal((B, S)).astype(np.float32)
+    t = rng.standard_normal((B,)).astype(np.float32)
+    mask = _mask(rng, B, S)
+    e = rg.RefEmbeddingAttribute.__new__(rg.RefEmbeddingAttribute)
+    e.dt = np.dtype(np.float64)
+    bl, cache = e.compute_loss(logits.astype(np.float64), t.astype(np.float64), 'mw', mask)
+    dl, dt = e.compute_loss_bwd(cache, np.full(B, 1.0 / B))
+    L = _t(dev, logits)
+    out_l = torch.empty(B, dtype=torch.float32, device=dev)
+    out_dt = torch.empty(B, dtype=torch.float32, device=dev)
+    dlog = torch.empty((B, S), dtype=torch.float32, device=dev)
+    ops.loss_mw(L, _t(dev, t), _t(dev, mask.astype(np.uint8)), out_l, dlog, out_dt, 1.0 / B)
+    np.testing.assert_allclose(out_l.cpu().numpy(), bl, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(dlog.cpu().numpy(), dl, rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(out_dt.cpu().numpy(), dt, rtol=RTOL, atol=1e-7)
+    # in place + no mask + row weights
+    rw = rng.random(B).astype(np.float32)
+    bl2, cache2 = e.compute_loss(logits.astype(np.float64), t.astype(np.float64), 'mw',
+                                 np.ones((B, S), bool))
+    dl2, dt2 = e.compute_loss_bwd(cache2, rw.astype(np.float64) * 0.3)
+    ops.loss_mw(L, _t(dev, t), None, out_l, L, out_dt, 0.3, row_w=_t(dev, rw))
+    np.testing.assert_allclose(L.cpu().numpy(), dl2, rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(out_dt.cpu().numpy(), dt2, rtol=RTOL, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,V", [(64, 3100), (7, 50)])
+def test_loss_warp_and_ce(dev, B, V):
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(B * V)
+    logits = rng.standard_normal((B, V)).astype(np.float32)
+    tgt = rng.integers(0, V, size=B).astype(np.int32)
+    mask = _mask(rng, B, V)
+    mask[np.arange(B)[::2], tgt[::2]] = False     # half the targets masked (training case)
+    e = rg.RefEmbeddingAttribute.__new__(rg.RefEmbeddingAttribute)
+    e.dt = np.dtype(np.float64)
+    for loss in ('warp', 'ce'):
+        bl, cache = e.compute_loss(logits.astype(np.float64), tgt, loss, mask)
+        dl, _ = e.compute_loss_bwd(cache, np.full(B, 1.0 / B))
+        out_l = torch.empty(B, dtype=torch.float32, device=dev)
+        dlog = torch.empty((B, V), dtype=torch.float32, device=dev)
+        if loss == 'warp':
+            ops.loss_warp(_t(dev, logits), _t(dev, tgt), _t(dev, mask.astype(np.uint8)), out_l,
+                          dlog, 1.0 / B)
+        else:
+            ops.loss_ce(_t(dev, logits), _t(dev, tgt), out_l, dlog, 1.0 / B)
+        np.testing.assert_allclose(out_l.cpu().numpy(), bl, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(dlog.cpu().numpy(), dl, rtol=RTOL, atol=1e-7)
+    mr, tr = e.warp_eval(logits.astype(np.float64), tgt, mask)
+    o_mr = torch.empty(B, dtype=torch.float32, device=dev)
+    o_tr = torch.empty(B, dtype=torch.int32, device=dev)
+    ops.loss_warp_eval(_t(dev, logits), _t(dev, tgt), _t(dev, mask.astype(np.uint8)), o_mr, o_tr)
+    np.testing.assert_allclose(o_mr.cpu().numpy(), mr, rtol=RTOL, atol=1e-4)
+    np.testing.assert_array_equal(o_tr.cpu().numpy(), tr)
+
+
+def test_pos_mask_bit_exact(dev):
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(5)
+    Nu, Ni, S, B = 300, 2000, 128, 64
+    pos = {u: list(rng.choice(Ni, size=rng.integers(0, 30), replace=False)) for u in range(0, Nu, 2)}
+    ptr = np.zeros(Nu + 1, dtype=np.int32)
+    items = []
+    for u in range(Nu):
+        items.extend(pos.get(u, []))
+        ptr[u + 1] = len(items)
+    items = np.asarray(items, dtype=np.int32)
+    pool = rng.choice(Ni, size=S, replace=False).astype(np.int32)
+    id2idx = {int(v): i for i, v in enumerate(pool)}
+    users = rng.integers(0, Nu, size=B).astype(np.int32)
+    e = rg.RefEmbeddingAttribute.__new__(rg.RefEmbeddingAttribute)
+    e.n_sampled, e.logit_size, e.item_ind2logit_ind = S, Ni, None
+    e.pos_item_set, e.pos_item_set_eval = pos, pos
+    ref = e.mask(list(users), 'mw', id2idx)
+    m2s = torch.full((Ni,), -1, dtype=torch.int32, device=dev)
+    ops.slot_map_set(m2s, _t(dev, pool))
+    mask = torch.ones((B, S), dtype=torch.uint8, device=dev)
+    ops.pos_mask_scatter(_t(dev, users), _t(dev, ptr), _t(dev, items), m2s, mask, 0)
+    np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), ref)
+    ops.pos_mask_scatter(_t(dev, users), _t(dev, ptr), _t(dev, items), m2s, mask, 1)
+    assert bool(mask.all().item())
+    ops.slot_map_set(m2s, _t(dev, pool), clear=True)
+    assert bool((m2s == -1).all().item())
+
+
+def _ref_sparse_adagrad(E, acc, bias, bacc, keys, src, coef, G, Gb, lr, gs=1.0):
+    E, acc, bias, bacc = [x.astype(np.float64).copy() for x in (E, acc, bias, bacc)]
+    g = np.zeros_like(E)
+    gb = np.zeros_like(bias)
+    for k, s, c in zip(keys, src, coef):
+        if k == 0x7FFFFFFF:
+            continue
+        g[k] += c * G[s]
+        gb[k] += c * Gb[s]
+    g *= gs
+    gb *= gs
+    touched = np.zeros(E.shape[0], bool)
+    touched[keys[keys != 0x7FFFFFFF]] = True
+    acc[touched] += g[touched] ** 2
+    E[touched] -= lr * g[touched] / np.sqrt(acc[touched])
+    bacc[touched] += gb[touched] ** 2
+    bias[touched] -= lr * gb[touched] / np.sqrt(bacc[touched])
+    return E, acc, bias, bacc
+
+
+@pytest.mark.parametrize("d,n,Vf,hot", [(128, 5000, 300, 0), (128, 20000, 5000, 3000),
+                                        (32, 777, 50, 400), (64, 64, 1000, 0), (128, 130, 2, 0)])
+def test_sparse_adagrad(dev, d, n, Vf, hot):
+    """Duplicates summed first, one update per touched row; long runs (hot keys,
+    > kPiece duplicates) exercise the two-pass path."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(n + d)
+    E = rng.standard_normal((Vf, d)).astype(np.float32)
+    acc = np.full((Vf, d), 0.1, dtype=np.float32) + rng.random((Vf, d)).astype(np.float32)
+    bias = rng.standard_normal((Vf,)).astype(np.float32)
+    bacc = np.full((Vf,), 0.1, dtype=np.float32)
+    m = 97
+    G = rng.standard_normal((m, d)).astype(np.float32)
+    Gb = rng.standard_normal((m,)).astype(np.float32)
+    keys = rng.integers(0, Vf, size=n).astype(np.int32)
+    if hot:
+        keys[rng.choice(n, size=hot, replace=False)] = 1 % Vf
+        keys[rng.choice(n, size=hot // 4, replace=False)] = Vf - 1
+    keys[rng.choice(n, size=n // 10, replace=False)] = 0x7FFFFFFF
+    src = rng.integers(0, m, size=n).astype(np.int32)
+    coef = rng.random(n).astype(np.float32)
+    lr, gs = 0.3, 0.7
+    rE, racc, rb, rbacc = _ref_sparse_adagrad(E, acc, bias, bacc, keys, src, coef, G, Gb, lr, gs)
+    tE, tacc, tb, tbacc = _t(dev, E), _t(dev, acc), _t(dev, bias), _t(dev, bacc)
+    ws = ops.Workspace(dev)
+    lr_dev = torch.tensor([lr], dtype=torch.float32, device=dev)
+    gs_dev = torch.tensor([gs], dtype=torch.float32, device=dev)
+    ops.sparse_adagrad(tE, tacc, tb, tbacc, _t(dev, keys), _t(dev, src), _t(dev, coef), _t(dev, G),
+                       _t(dev, Gb), lr_dev, ws, gscale_dev=gs_dev)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(tacc.cpu().numpy(), racc, rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(tE.cpu().numpy(), rE, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(tbacc.cpu().numpy(), rbacc, rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(tb.cpu().numpy(), rb, rtol=2e-4, atol=2e-5)
+    # determinism: the same call on the same inputs is bit-identical
+    tE2, tacc2 = _t(dev, E), _t(dev, acc)
+    tb2, tbacc2 = _t(dev, bias), _t(dev, bacc)
+    ops.sparse_adagrad(tE2, tacc2, tb2, tbacc2, _t(dev, keys), _t(dev, src), _t(dev, coef),
+                       _t(dev, G), _t(dev, Gb), lr_dev, ws, gscale_dev=gs_dev)
+    assert torch.equal(tE, tE2) and torch.equal(tacc, tacc2)
+
+
+def test_dense_adagrad_norm_clip(dev):
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(1)
+    n = 100003
+    w = rng.standard_normal(n).astype(np.float32)
+    acc = np.full(n, 0.1, np.float32)
+    g = rng.standard_normal(n).astype(np.float32)
+    tw, ta = _t(dev, w), _t(dev, acc)
+    lr = torch.tensor([0.5], dtype=torch.float32, device=dev)
+    sq = torch.zeros(1, dtype=torch.float32, device=dev)
+    ops.sq_norm_accum(_t(dev, g), sq)
+    np.testing.assert_allclose(sq.item(), (g.astype(np.float64) ** 2).sum(), rtol=1e-5)
+    coef = torch.empty(1, dtype=torch.float32, device=dev)
+    gn = torch.empty(1, dtype=torch.float32, device=dev)
+    ops.clip_coef(sq, 5.0, coef, gn)
+    nrm = np.sqrt((g.astype(np.float64) ** 2).sum())
+    np.testing.assert_allclose(coef.item(), 5.0 / max(nrm, 5.0), rtol=1e-5)
+    np.testing.assert_allclose(gn.item(), nrm, rtol=1e-5)
+    ops.adagrad_dense(tw, ta, _t(dev, g), lr, gscale_dev=coef)
+    gg = g.astype(np.float64) * (5.0 / max(nrm, 5.0))
+    racc = acc + gg * gg
+    np.testing.assert_allclose(ta.cpu().numpy(), racc, rtol=RTOL)
+    np.testing.assert_allclose(tw.cpu().numpy(), w - 0.5 * gg / np.sqrt(racc), rtol=RTOL, atol=ATOL)
+
+
+def test_topk_matches_tf_order(dev):
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(2)
+    B, V, k = 9, 3100, 100
+    logits = rng.standard_normal((B, V)).astype(np.float32)
+    logits[:, 100:110] = logits[:, 99:100]       # ties -> lower index first
+    ref = np.argsort(-logits, axis=1, kind='stable')[:, :k]
+    vals = torch.empty((B, k), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, k), dtype=torch.int32, device=dev)
+    ops.topk(_t(dev, logits), k, vals, idx)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    np.testing.assert_array_equal(vals.cpu().numpy(), np.take_along_axis(logits, ref, 1))
+
+
+def test_small_utils(dev):
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((50, 64)).astype(np.float32)
+    y = rng.standard_normal((200, 64)).astype(np.float32)
+    ty = _t(dev, y)
+    ops.add_rows_bcast(0.5, _t(dev, x), 0.25, ty)
+    np.testing.assert_allclose(ty.cpu().numpy(), 0.5 * np.tile(x, (4, 1)) + 0.25 * y, rtol=1e-6)
+    rs = torch.empty(200, dtype=torch.float32, device=dev)
+    ops.row_sum(_t(dev, y), rs)
+    np.testing.assert_allclose(rs.cpu().numpy(), y.sum(1), rtol=1e-5, atol=1e-5)
+    cs = torch.empty(64, dtype=torch.float32, device=dev)
+    ops.col_sum(_t(dev, y), cs)
+    np.testing.assert_allclose(cs.cpu().numpy(), y.sum(0), rtol=1e-5, atol=1e-4)
+    s = torch.empty(1, dtype=torch.float32, device=dev)
+    ops.sum_scaled(_t(dev, y), 0.125, s)
+    np.testing.assert_allclose(s.item(), y.sum() * 0.125, rtol=1e-4, atol=1e-4)
+    w = np.array([[1, 1, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], dtype=np.float32)  # [L=4,B=3]
+    o = torch.empty((4, 3), dtype=torch.float32, device=dev)
+    ops.seq_weights(_t(dev, w), 4, 3, o)
+    np.testing.assert_allclose(o.cpu().numpy(), w / (w.sum(0) + 1e-12), rtol=1e-6)
+    # dropout: keep_prob=1 is the identity; keep_prob<1 keeps ~p and rescales
+    xd = _t(dev, y)
+    yd = torch.empty_like(xd)
+    km = torch.empty(xd.numel(), dtype=torch.uint8, device=dev)
+    ops.dropout_fwd(xd, 1.0, 7, yd, km)
+    assert torch.equal(xd, yd)
+    ops.dropout_fwd(xd, 0.5, 7, yd, km)
+    frac = km.float().mean().item()
+    assert 0.45 < frac < 0.55
+    kept = km.view_as(xd).bool()
+    np.testing.assert_allclose(yd[kept].cpu().numpy(), (xd[kept] * 2).cpu().numpy(), rtol=1e-6)
+    assert float(yd[~kept].abs().sum().item()) == 0.0
+
+
+@pytest.mark.parametrize("L,B,din,h", [(3, 5, 64, 64), (50, 64, 64, 64), (7, 33, 128, 128),
+                                       (4, 6, 20, 24), (5, 16, 32, 64)])
+def test_lstm_fwd_bwd(dev, L, B, din, h):
+    from arx import ops
+    import torch
+    from oracle import ref_lstm
+    rng = np.random.default_rng(L * B + h)
+    x = (rng.standard_normal((L, B, din)) * 0.5).astype(np.float32)
+    W = (rng.standard_normal((din + h, 4 * h)) * 0.2).astype(np.float32)
+    b = (rng.standard_normal((4 * h,)) * 0.1).astype(np.float32)
+    dhs = rng.standard_normal((L, B, h)).astype(np.float32)
+    r_hs, r_cs, r_g = ref_lstm.lstm_fwd(x.astype(np.float64), W.astype(np.float64),
+                                        b.astype(np.float64), 1.0)
+    r_dz, r_dx, r_dW, r_db = ref_lstm.lstm_bwd(x.astype(np.float64), W.astype(np.float64), r_hs,
+                                               r_cs, r_g, dhs.astype(np.float64))
+    hs = torch.empty((L, B, h), dtype=torch.float32, device=dev)
+    cs = torch.empty_like(hs)
+    gates = torch.empty((L, B, 4 * h), dtype=torch.float32, device=dev)
+    tW = _t(dev, W)
+    ops.lstm_fwd(_t(dev, x), tW, _t(dev, b), L, B, din, h, 1.0, hs, cs, gates)
+    np.testing.assert_allclose(hs.cpu().numpy(), r_hs, rtol=RTOL, atol=2e-5)
+    np.testing.assert_allclose(cs.cpu().numpy(), r_cs, rtol=RTOL, atol=2e-5)
+    np.testing.assert_allclose(gates.cpu().numpy(), r_g, rtol=RTOL, atol=2e-5)
+    dz = torch.empty((L, B, 4 * h), dtype=torch.float32, device=dev)
+    ops.lstm_bwd(tW, hs, cs, gates, _t(dev, dhs), L, B, din, h, dz)
+    np.testing.assert_allclose(dz.cpu().numpy(), r_dz, rtol=2e-4, atol=5e-5)
+    # dx / dW / db are GEMMs + a column sum over dz (what the model issues)
+    ws = ops.Workspace(dev)
+    dz2 = dz.view(L * B, 4 * h)
+    dx = torch.empty((L * B, din), dtype=torch.float32, device=dev)
+    ops.gemm(dz2, tW[:din], dx, ws, transB=True)
+    np.testing.assert_allclose(dx.cpu().numpy(), r_dx.reshape(L * B, din), rtol=2e-4, atol=1e-4)
+    dW = torch.zeros((din + h, 4 * h), dtype=torch.float32, device=dev)
+    ops.gemm(_t(dev, x).view(L * B, din), dz2, dW[:din], ws, transA=True)
+    if L > 1:
+        ops.gemm(hs.view(L * B, h)[:(L - 1) * B], dz2[B:], dW[din:], ws, transA=True)
+    np.testing.assert_allclose(dW.cpu().numpy(), r_dW, rtol=2e-4, atol=2e-4)
+    db = torch.empty(4 * h, dtype=torch.float32, device=dev)
+    ops.col_sum(dz2, db)
+    np.testing.assert_allclose(db.cpu().numpy(), r_db, rtol=2e-4, atol=2e-4)
