@@ -1,0 +1,541 @@
+"""Deferred op graph + executor that replaces the reference's TF-1.0 graph/session.
+
+The reference's classes build a symbolic graph in __init__ and feed it in
+step().  Here the same calls build a tiny graph of `Node`s; `Runtime.run`
+executes it eagerly as a fixed sequence of libarx.so kernel launches (forward,
+backward, optimiser) and -- because every buffer, shape and pointer is static --
+captures the whole step into ONE hipGraph that is replayed on later steps
+(MI355X: a step at B=64 is launch-bound, not bandwidth-bound).
+
+Only what the hot path needs is implemented; anything else
+raises NotImplementedError.  torch tensors are device-memory holders only.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+
+KEY_NONE = ops.KEY_NONE
+
+
+# --------------------------------------------------------------------------
+# parameters
+# --------------------------------------------------------------------------
+class Table(object):
+    """One attribute embedding table [Vf,d] (+ optional bias [Vf]) with its
+    Adagrad accumulators (TF initial_accumulator_value = 0.1)."""
+
+    def __init__(self, name, bias_name, E, bias, acc0=0.1):
+        self.name = name
+        self.bias_name = bias_name
+        self.E = E
+        self.acc = torch.full_like(E, acc0)
+        self.bias = bias
+        self.bias_acc = torch.full_like(bias, acc0) if bias is not None else None
+        self.sites = []      # SparseSite list (rebuilt per plan)
+
+
+class DenseParam(object):
+    def __init__(self, name, w, acc0=0.1):
+        self.name = name
+        self.w = w
+        self.acc = torch.full_like(w, acc0)
+        self.grad = torch.zeros_like(w)
+
+
+class SparseSite(object):
+    """One embedding_lookup call site whose gradient lands in `table`."""
+
+    def __init__(self, table, kind, ids_node, maps, n, max_len, coef, node):
+        self.table = table
+        self.kind = kind          # 'cat' | 'mulhot'
+        self.ids_node = ids_node
+        self.maps = maps          # cat: (cat_map,) ; mulhot: (vals, starts, lens)
+        self.n = n                # lookups (rows of the gradient source)
+        self.cap = n if kind == 'cat' else n * max_len
+        self.coef = coef
+        self.node = node          # EntityEmbed node owning G rows (arena slice)
+        self.col_off = 0          # column offset inside the node's grad (concat)
+        self.key_off = 0          # offset inside the table's key/src/coef buffers
+
+
+# --------------------------------------------------------------------------
+# nodes
+# --------------------------------------------------------------------------
+class Node(object):
+    requires_grad = False
+
+    def __init__(self, rt, shape, inputs=()):
+        self.rt = rt
+        self.shape = tuple(int(s) for s in shape)
+        self.inputs = tuple(inputs)
+        self.value = None
+        self.grad = None
+        self._grad_written = False
+        rt.nodes.append(self)
+
+    # allocation ------------------------------------------------------------
+    def alloc_value(self):
+        if self.value is None:
+            self.value = torch.empty(self.shape, dtype=torch.float32, device=self.rt.device)
+        return self.value
+
+    def alloc_grad(self):
+        if self.grad is None:
+            self.grad = torch.empty(self.shape, dtype=torch.float32, device=self.rt.device)
+        return self.grad
+
+    def grad_beta(self):
+        """0.0 for the first writer of this node's grad in a backward pass, 1.0 after."""
+        b = 1.0 if self._grad_written else 0.0
+        self._grad_written = True
+        return b
+
+    def forward(self, train):
+        raise NotImplementedError
+
+    def backward(self):
+        pass
+
+    def get_shape(self):
+        return self.shape
+
+
+class IdsInput(Node):
+    """int32 placeholder (embed_attribute.py:142-146 _placeholders)."""
+
+    def __init__(self, rt, n, name):
+        super().__init__(rt, (n,))
+        self.name = name
+        self.value = torch.zeros(n, dtype=torch.int32, device=rt.device)
+
+    def feed(self, arr):
+        if isinstance(arr, torch.Tensor):
+            src = arr.to(dtype=torch.int32)
+        else:
+            src = torch.from_numpy(np.ascontiguousarray(np.asarray(arr, dtype=np.int32)))
+        if src.numel() != self.value.numel():
+            raise ValueError("placeholder %s expects %d ids, got %d" % (self.name, self.value.numel(),
+                                                                          src.numel()))
+        self.value.copy_(src.reshape(self.value.shape), non_blocking=True)
+
+    def forward(self, train):
+        pass
+
+
+class FloatInput(Node):
+    def __init__(self, rt, shape, name):
+        super().__init__(rt, shape)
+        self.name = name
+        self.value = torch.zeros(self.shape, dtype=torch.float32, device=rt.device)
+
+    def feed(self, arr):
+        if isinstance(arr, torch.Tensor):
+            src = arr.to(dtype=torch.float32)
+        else:
+            src = torch.from_numpy(np.ascontiguousarray(np.asarray(arr, dtype=np.float32)))
+        self.value.copy_(src.reshape(self.value.shape), non_blocking=True)
+
+    def forward(self, train):
+        pass
+
+
+class Feature(object):
+    """Static description of one attribute feature of an entity."""
+
+    def __init__(self, kind, table, maps, max_len=1):
+        self.kind = kind          # 'cat' | 'mulhot'
+        self.table = table
+        self.maps = maps          # cat: (cat_map,) ; mulhot: (vals, starts, lens)
+        self.max_len = max_len
+        self.d = int(table.E.shape[1])
+
+
+class EntityEmbed(Node):
+    """embed_attribute.py:350-417 _get_embedded + the reduce_mean / concat the
+    callers apply (:219, :235, :415): value [n, D], optional bias [n].
+    mean:   value = out_scale * mean_f e_f(ids)          (D = d)
+    concat: value = [e_0 | e_1 | ...]                     (D = sum d_f)"""
+
+    requires_grad = True
+
+    def __init__(self, rt, ids_node, feats, with_bias, concat=False, out_scale=1.0,
+                 train_tables=True):
+        n = ids_node.shape[0]
+        self.feats = feats
+        self.concat = concat
+        D = sum(f.d for f in feats) if concat else feats[0].d
+        if not concat and any(f.d != D for f in feats):
+            raise ValueError("mean over features needs equal embedding sizes")
+        super().__init__(rt, (n, D), (ids_node,))
+        self.with_bias = with_bias
+        self.out_scale = float(out_scale)
+        if with_bias and (self.out_scale != 1.0 or concat):
+            raise NotImplementedError("bias is only produced for mean-combined lookups with out_scale 1")
+        self.bias_value = None
+        self.bias_grad = None
+        self.train_tables = train_tables
+        self.bias_grad_used = False
+
+    def alloc_value(self):
+        super().alloc_value()
+        if self.with_bias and self.bias_value is None:
+            self.bias_value = torch.empty(self.shape[0], dtype=torch.float32, device=self.rt.device)
+        return self.value
+
+    def forward(self, train):
+        out = self.alloc_value()
+        ids = self.inputs[0].value
+        F = len(self.feats)
+        col = 0
+        for k, f in enumerate(self.feats):
+            if self.concat:
+                dst, scale, acc = out[:, col:col + f.d], 1.0, False
+                col += f.d
+            else:
+                dst, scale, acc = out, self.out_scale / F, k > 0
+            # bias = mean over features of the per-feature bias (:412); it shares the
+            # 1/F scale of the mean-combined embedding, so it rides in the same launch.
+            bias = f.table.bias if self.with_bias else None
+            bout = self.bias_value if self.with_bias else None
+            if f.kind == 'cat':
+                ops.gather_onehot(f.table.E, bias, f.maps[0], ids, dst, scale=scale,
+                                  accumulate=acc, bias_out=bout)
+            else:
+                ops.gather_mulhot_mean(f.table.E, bias, f.maps[0], f.maps[1], f.maps[2], ids, dst,
+                                       scale=scale, accumulate=acc, bias_out=bout)
+
+    def sites(self):
+        """Sparse-gradient call sites of this lookup (one per feature)."""
+        res = []
+        F = len(self.feats)
+        col = 0
+        for f in self.feats:
+            coef = 1.0 if self.concat else self.out_scale / F
+            s = SparseSite(f.table, f.kind, self.inputs[0], f.maps, self.shape[0], f.max_len, coef, self)
+            s.col_off = col if self.concat else 0
+            s.bias_coef = 1.0 / F
+            if self.concat:
+                col += f.d
+            res.append(s)
+        return res
+
+
+class Prediction(Node):
+    """embed_attribute.py:148-206 get_prediction in embedding-space form:
+    logits[r, j] = latent_r . Ibar_j + bbar_j with (Ibar, bbar) = EntityEmbed of
+    the pool's items (mean over output features, output_feat 0/1)."""
+
+    requires_grad = True
+
+    def __init__(self, rt, latent, pool_embed):
+        super().__init__(rt, (latent.shape[0], pool_embed.shape[0]), (latent, pool_embed))
+
+    def forward(self, train):
+        latent, pool = self.inputs
+        ops.gemm(latent.value, pool.value, self.alloc_value(), self.rt.ws, transB=True,
+                 col_bias=pool.bias_value)
+
+    def backward(self):
+        latent, pool = self.inputs
+        dl = self.grad
+        if latent.requires_grad:
+            g = latent.alloc_grad()
+            ops.gemm(dl, pool.value, g, self.rt.ws, beta=latent.grad_beta())     # dU = dL . Ibar
+        if pool.train_tables:
+            gp = pool.alloc_grad()
+            ops.gemm(dl, latent.value, gp, self.rt.ws, transA=True, beta=pool.grad_beta())  # dIbar = dL^T . U
+            ops.col_sum(dl, pool.bias_grad)                                       # dbbar
+            pool.bias_grad_used = True
+
+
+class TargetScore(Node):
+    """embed_attribute.py:208-220 get_target_score."""
+
+    requires_grad = True
+
+    def __init__(self, rt, latent, target_embed):
+        super().__init__(rt, (latent.shape[0],), (latent, target_embed))
+
+    def forward(self, train):
+        latent, te = self.inputs
+        ops.dot_score(latent.value, te.value, te.bias_value, self.alloc_value())
+
+    def backward(self):
+        latent, te = self.inputs
+        ds = self.grad
+        g = latent.alloc_grad()
+        dT = te.alloc_grad() if te.train_tables else None
+        ops.dot_score_bwd(latent.value, te.value, ds, g, latent.grad_beta() != 0.0, dT)
+        if te.train_tables:
+            te.grad_beta()
+            ops.axpby(1.0, ds, 0.0, te.bias_grad)
+            te.bias_grad_used = True
+
+
+class BatchLoss(Node):
+    """embed_attribute.py:525-649 compute_loss ('ce', 'warp', 'mw'); forward and
+    backward are one fused kernel, so the downstream reduction tells this node
+    its d(total)/d(batch_loss) up front (gscale, row_w)."""
+
+    requires_grad = True
+
+    def __init__(self, rt, kind, logits, target, mask=None, mask_rows=0):
+        if kind not in ('ce', 'warp', 'mw', 'warp_eval'):
+            raise NotImplementedError("loss %r is not implemented on the HIP path" % kind)
+        super().__init__(rt, (logits.shape[0],), (logits, target))
+        self.kind = kind
+        self.mask = mask              # MaskState or None
+        self.mask_rows = mask_rows
+        self.gscale = 1.0
+        self.row_w = None             # FloatInput-like node
+        self.rank_value = None
+
+    def forward(self, train):
+        logits, target = self.inputs
+        bl = self.alloc_value()
+        dl = logits.alloc_grad() if train else None
+        if train:
+            logits.grad_beta()
+        m = self.mask.buf if self.mask is not None else None
+        rw = self.row_w.value if self.row_w is not None else None
+        if self.kind == 'mw':
+            dt = target.alloc_grad() if train else None
+            if train:
+                target.grad_beta()
+            ops.loss_mw(logits.value, target.value, m, bl, dl, dt, self.gscale, rw, self.mask_rows)
+        elif self.kind == 'warp':
+            ops.loss_warp(logits.value, target.value, m, bl, dl, self.gscale, rw, self.mask_rows)
+        elif self.kind == 'ce':
+            ops.loss_ce(logits.value, target.value, bl, dl, self.gscale, rw)
+        else:  # warp_eval -> [margin_rank, true_rank]
+            if self.rank_value is None:
+                self.rank_value = torch.empty(self.shape[0], dtype=torch.int32, device=self.rt.device)
+            ops.loss_warp_eval(logits.value, target.value, m, bl, self.rank_value, self.mask_rows)
+
+
+class MeanLoss(Node):
+    """hmf_model.py:140 tf.reduce_mean(batch_loss)."""
+
+    requires_grad = True
+
+    def __init__(self, rt, batch_loss):
+        super().__init__(rt, (1,), (batch_loss,))
+        batch_loss.gscale = 1.0 / batch_loss.shape[0]
+
+    def forward(self, train):
+        bl = self.inputs[0]
+        ops.sum_scaled(bl.value, 1.0 / bl.shape[0], self.alloc_value())
+
+
+class MaskState(object):
+    """embed_attribute.py:651-672: persistent bool mask [rows, W] (initially all
+    True) plus the set / reset scatter ops; positives come from a device CSR."""
+
+    def __init__(self, rt, rows, W, user_ids, slot_map_getter, pos_getter):
+        self.rt = rt
+        self.rows, self.W = rows, W
+        self._buf = None            # allocated on first use: [rows, V] can be GBs at V = 1M
+        self.user_ids = user_ids
+        self.slot_map_getter = slot_map_getter
+        self.pos_getter = pos_getter
+
+    @property
+    def buf(self):
+        if self._buf is None:
+            self._buf = torch.ones((self.rows, self.W), dtype=torch.uint8, device=self.rt.device)
+        return self._buf
+
+    def scatter(self, value):
+        ptr, items = self.pos_getter()
+        ops.pos_mask_scatter(self.user_ids.value, ptr, items, self.slot_map_getter(), self.buf, value)
+
+
+# --------------------------------------------------------------------------
+# runtime
+# --------------------------------------------------------------------------
+class Plan(object):
+    """A fixed kernel sequence (forward [+ backward + optimiser]) over the graph."""
+
+    def __init__(self, rt, fetch, train, masks=()):
+        self.rt = rt
+        self.fetch = fetch
+        self.train = train
+        self.masks = list(masks)
+        self.order = rt.topo(fetch)
+        self.graph = None
+        self.warm = 0
+        self.tables = []
+        self.arenas = []
+        if train:
+            self._plan_sparse()
+
+    # ---- sparse-gradient bookkeeping (static) ----
+    def _plan_sparse(self):
+        rt = self.rt
+        embeds = [n for n in self.order if isinstance(n, EntityEmbed) and n.train_tables]
+        # gradient arena: one buffer per row width so rows are contiguous
+        by_width = {}
+        for n in embeds:
+            by_width.setdefault(n.shape[1], []).append(n)
+        for D, nodes in by_width.items():
+            rows = sum(n.shape[0] for n in nodes)
+            arena = torch.zeros((rows, D), dtype=torch.float32, device=rt.device)
+            arena_b = torch.zeros((rows,), dtype=torch.float32, device=rt.device)
+            r0 = 0
+            for n in nodes:
+                n.grad = arena[r0:r0 + n.shape[0]]
+                n.bias_grad = arena_b[r0:r0 + n.shape[0]]
+                n.arena, n.arena_b, n.row0 = arena, arena_b, r0
+                r0 += n.shape[0]
+            self.arenas.append((arena, arena_b))
+        tables = {}
+        for n in embeds:
+            for s in n.sites():
+                tables.setdefault(id(s.table), (s.table, []))[1].append(s)
+        for table, sites in tables.values():
+            # all sites of a table must share one arena (same width) -- true for
+            # mean-combined features; concat slices keep the node's width too.
+            total = 0
+            for s in sites:
+                s.key_off = total
+                total += s.cap
+            bufs = {
+                'keys': torch.full((total,), KEY_NONE, dtype=torch.int32, device=rt.device),
+                'src': torch.zeros((total,), dtype=torch.int32, device=rt.device),
+                'coef': torch.zeros((total,), dtype=torch.float32, device=rt.device),
+                'offs': torch.zeros((max(s.n for s in sites) + 1,), dtype=torch.int32, device=rt.device),
+                'tot': torch.zeros((1,), dtype=torch.int32, device=rt.device),
+            }
+            widths = set(s.node.shape[1] for s in sites)
+            if len(widths) != 1:
+                raise NotImplementedError("a table used by lookups of different output widths")
+            self.tables.append((table, sites, bufs, total))
+
+    # ---- execution ----
+    def _execute(self):
+        rt = self.rt
+        for m in self.masks:
+            m.scatter(0)                                   # set_mask (hmf_model.py:209-210)
+        for n in self.order:
+            n._grad_written = False
+            if isinstance(n, EntityEmbed):
+                n.bias_grad_used = False
+        for n in self.order:
+            n.forward(self.train)
+        if self.train:
+            for n in reversed(self.order):
+                if n.requires_grad and n._grad_written:
+                    n.backward()
+            rt.pre_apply(self)
+            self._apply_sparse()
+            rt.apply_dense(self)
+        for m in self.masks:
+            m.scatter(1)                                   # reset_mask (:217-218)
+
+    def _apply_sparse(self):
+        rt = self.rt
+        for table, sites, bufs, total in self.tables:
+            live = False
+            for s in sites:
+                node = s.node
+                if not node._grad_written:
+                    # this lookup received no gradient this step: leave its keys at NONE
+                    ops.fill_i32(bufs['keys'][s.key_off:s.key_off + s.cap], KEY_NONE)
+                    continue
+                live = True
+                ks = bufs['keys'][s.key_off:s.key_off + s.cap]
+                ss = bufs['src'][s.key_off:s.key_off + s.cap]
+                cs = bufs['coef'][s.key_off:s.key_off + s.cap]
+                if s.kind == 'cat':
+                    ops.sparse_site_onehot(s.maps[0], s.ids_node.value, node.row0, s.coef, ks, ss, cs)
+                else:
+                    ops.csr_expand(s.maps[0], s.maps[1], s.maps[2], s.ids_node.value, s.cap, rt.ws,
+                                   pad_token=KEY_NONE, pad_seg=0, seg_base=node.row0,
+                                   coef_scale=s.coef, want_coef=True,
+                                   out=(ks, ss, bufs['offs'], bufs['tot'], cs))
+            if not live:
+                continue
+            node0 = sites[0].node
+            G = node0.arena[:, sites[0].col_off:] if sites[0].col_off else node0.arena
+            use_bias = table.bias is not None and any(s.node.bias_grad_used for s in sites)
+            ops.sparse_adagrad(table.E, table.acc, table.bias if use_bias else None,
+                               table.bias_acc if use_bias else None, bufs['keys'], bufs['src'],
+                               bufs['coef'], G, node0.arena_b if use_bias else None, rt.lr, rt.ws,
+                               gscale_dev=rt.clip_coef_dev, n=total)
+
+    def run(self):
+        rt = self.rt
+        if rt.use_graph and self.warm >= 1:
+            if self.graph is None:
+                g = ops.CapturedGraph()
+                side = torch.cuda.Stream(device=rt.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    g.begin()
+                    try:
+                        self._execute()
+                    finally:
+                        g.end()
+                torch.cuda.current_stream().wait_stream(side)
+                self.graph = g
+            self.graph.launch()
+        else:
+            self._execute()
+            self.warm += 1
+
+
+class Runtime(object):
+    def __init__(self, device=None, learning_rate=0.1, use_graph=True):
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("arx needs an AMD GPU: the hot path is HIP-only (no CPU fallback)")
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.ws = ops.Workspace(self.device)
+        self.nodes = []
+        self.tables = {}
+        self.dense = {}
+        self.lr = torch.tensor([float(learning_rate)], dtype=torch.float32, device=self.device)
+        self.lr_host = float(learning_rate)
+        self.clip_coef_dev = None
+        self.max_gradient_norm = None
+        self.use_graph = use_graph
+        self.global_step = 0
+        self.pre_apply_hooks = []
+
+    def set_learning_rate(self, v):
+        self.lr_host = float(v)
+        ops.fill_f32(self.lr, self.lr_host)
+
+    def topo(self, fetch):
+        seen, order = set(), []
+
+        def visit(n):
+            if id(n) in seen:
+                return
+            seen.add(id(n))
+            for i in n.inputs:
+                visit(i)
+            for extra in getattr(n, 'extra_inputs', ()):
+                visit(extra)
+            order.append(n)
+        for f in fetch:
+            visit(f)
+        return order
+
+    def pre_apply(self, plan):
+        for h in self.pre_apply_hooks:
+            h(plan)
+
+    def apply_dense(self, plan):
+        for p in self.dense.values():
+            if getattr(p, 'touched', False):
+                ops.adagrad_dense(p.w, p.acc, p.grad, self.lr, gscale_dev=self.clip_coef_dev)
+                p.touched = False
+
+    def upload(self, arr, dtype):
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(arr))).to(dtype)
+        return t.to(self.device)

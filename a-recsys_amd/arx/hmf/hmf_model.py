@@ -1,0 +1,295 @@
+"""LatentProductModel -- the reference's HMF model (hmf/hmf_model.py:19-274) on MI355X.
+
+Constructor / step / get_batch / get_permuted_batch keep the reference's
+signatures; `session`, `GPU`, `run_op`, `run_meta` are accepted and ignored.
+State (tables, Adagrad slots, mask, sampled pool) lives on the device and is
+owned by the model.  step() is forward + backward + Adagrad as ONE captured
+hipGraph replay of libarx.so kernels.
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import torch
+
+from .. import graph as G
+from .. import ops
+from ..attributes import embed_attribute
+from ..utils.checkpoint import Saver
+
+
+class _Var(object):
+    """Stand-in for the tf.Variable handles the runners read with .eval()."""
+
+    def __init__(self, getter):
+        self._getter = getter
+
+    def eval(self, session=None):
+        return self._getter()
+
+
+class _Op(object):
+    def __init__(self, fn):
+        self._fn = fn
+
+    def run(self, session=None):
+        return self._fn()
+
+    __call__ = run
+
+
+class MLP(G.Node):
+    """hmf_model.py:80-94: act(act(act(u).W1 + b1).W2 + b2), keep_prob == 1."""
+
+    requires_grad = True
+
+    def __init__(self, rt, x, params, kind):
+        self.w1, self.b1, self.w2, self.b2 = params
+        super().__init__(rt, (x.shape[0], self.w2.w.shape[1]), (x,))
+        self.kind = 0 if kind == 'relu' else 1
+        n, hdim = x.shape[0], self.w1.w.shape[1]
+        dev = rt.device
+        self.h0 = torch.empty(x.shape, dtype=torch.float32, device=dev)
+        self.h1 = torch.empty((n, hdim), dtype=torch.float32, device=dev)
+        self.d1 = torch.empty((n, hdim), dtype=torch.float32, device=dev)
+        self.d0 = torch.empty(x.shape, dtype=torch.float32, device=dev)
+
+    def forward(self, train):
+        x = self.inputs[0]
+        out = self.alloc_value()
+        ops.act_fwd(x.value, self.kind, self.h0)
+        ops.gemm(self.h0, self.w1.w, self.h1, self.rt.ws, col_bias=self.b1.w)
+        ops.act_fwd(self.h1, self.kind, self.h1)
+        ops.gemm(self.h1, self.w2.w, out, self.rt.ws, col_bias=self.b2.w)
+        ops.act_fwd(out, self.kind, out)
+
+    def backward(self):
+        x = self.inputs[0]
+        rt = self.rt
+        dz2 = self.grad
+        ops.act_bwd(self.value, dz2, self.kind, dz2)                    # through act(z2)
+        ops.gemm(self.h1, dz2, self.w2.grad, rt.ws, transA=True)
+        ops.col_sum(dz2, self.b2.grad)
+        ops.gemm(dz2, self.w2.w, self.d1, rt.ws, transB=True)
+        ops.act_bwd(self.h1, self.d1, self.kind, self.d1)
+        ops.gemm(self.h0, self.d1, self.w1.grad, rt.ws, transA=True)
+        ops.col_sum(self.d1, self.b1.grad)
+        ops.gemm(self.d1, self.w1.w, self.d0, rt.ws, transB=True)
+        ops.act_bwd(self.h0, self.d0, self.kind, self.d0)
+        g = x.alloc_grad()
+        ops.add_rows_bcast(1.0, self.d0, x.grad_beta(), g)
+        for p in (self.w1, self.b1, self.w2, self.b2):
+            p.touched = True
+
+
+class TopK(G.Node):
+    """hmf_model.py:154 tf.nn.top_k(logits, top_N_items, sorted=True)."""
+
+    def __init__(self, rt, logits, k):
+        super().__init__(rt, (logits.shape[0], k), (logits,))
+        self.k = k
+        self.indices = torch.empty((logits.shape[0], k), dtype=torch.int32, device=rt.device)
+
+    def forward(self, train):
+        ops.topk(self.inputs[0].value, self.k, self.alloc_value(), self.indices)
+
+
+class LatentProductModel(object):
+    def __init__(self, user_size, item_size, size, num_layers, batch_size, learning_rate,
+                 learning_rate_decay_factor, user_attributes=None, item_attributes=None,
+                 item_ind2logit_ind=None, logit_ind2item_ind=None, loss_function='ce', GPU=None,
+                 logit_size_test=None, nonlinear=None, dropout=1.0, n_sampled=None,
+                 indices_item=None, dtype='float32', top_N_items=100, hidden_size=500,
+                 loss_func='log', loss_exp_p=1.005, params=None, use_graph=True, seed=0):
+        self.user_size = user_size
+        self.item_size = item_size
+        self.top_N_items = top_N_items
+        if user_attributes is not None:
+            user_attributes.set_model_size(size)             # hmf_model.py:34-36
+            self.user_attributes = user_attributes
+        if item_attributes is not None:
+            item_attributes.set_model_size(size)
+            self.item_attributes = item_attributes
+        self.item_ind2logit_ind = item_ind2logit_ind
+        self.logit_ind2item_ind = logit_ind2item_ind
+        if logit_ind2item_ind is not None:
+            self.logit_size = len(logit_ind2item_ind)
+        self.indices_item = indices_item if indices_item is not None else range(self.logit_size)
+        self.logit_size_test = logit_size_test
+        self.nonlinear = nonlinear
+        self.loss_function = loss_function
+        self.n_sampled = n_sampled
+        self.batch_size = batch_size
+        self.dropout = dropout
+        self.dtype = dtype
+        self.data_length = None
+        self.train_permutation = None
+        self.start_index = None
+        if loss_function in ('bpr', 'bpr-hinge'):
+            raise NotImplementedError("bpr losses: the reference's pos/neg feeds are commented out "
+                                      "(embed_attribute.py:704-706); not on the hot path")
+        if loss_function in ('rs', 'rs-sig', 'rs-sig2', 'bbpr') or loss_func != 'log':
+            raise NotImplementedError("loss %s/%s is not implemented on the HIP path" %
+                                      (loss_function, loss_func))
+
+        self.rt = rt = G.Runtime(learning_rate=learning_rate, use_graph=use_graph)
+        self._lr_decay = learning_rate_decay_factor
+        self.learning_rate = _Var(lambda: rt.lr_host)
+        self.learning_rate_decay_op = _Op(lambda: rt.set_learning_rate(rt.lr_host * self._lr_decay))
+        self.global_step = _Var(lambda: rt.global_step)
+
+        mb = batch_size
+        # mapped item target (logit index) and raw item id target (hmf_model.py:69-70)
+        self.item_target = G.IdsInput(rt, mb, 'item')
+        self.item_id_target = G.IdsInput(rt, mb, 'item_id')
+
+        m = embed_attribute.EmbeddingAttribute(user_attributes, item_attributes, mb, self.n_sampled,
+                                               0, False, item_ind2logit_ind, logit_ind2item_ind,
+                                               params=params, runtime=rt, seed=seed)
+        self.att_emb = m
+        embedded_user, _ = m.get_batch_user(float(dropout), False)          # :78
+        if self.nonlinear in ('relu', 'tanh'):
+            if dropout != 1.0:
+                raise NotImplementedError("MLP with dropout < 1")
+            ps = []
+            for name, shape in (('w1', (size, hidden_size)), ('b1', (hidden_size,)),
+                                ('w2', (hidden_size, size)), ('b2', (size,))):
+                w = m._new_var(name, shape, params or {})
+                p = G.DenseParam(name, w)
+                rt.dense[name] = p
+                ps.append(p)
+            embedded_user, _ = m.get_batch_user(1.0, False)                  # :87
+            embedded_user = MLP(rt, embedded_user, ps, self.nonlinear)
+        self.embedded_user = embedded_user
+
+        loss = self.loss_function
+        self._plans = {}
+        self.set_mask, self.reset_mask = {}, {}
+        sampled_logits = target_score = None
+        if self.n_sampled is not None:
+            sampled_logits = m.get_prediction(embedded_user, 'sampled')       # :112
+            target_score = m.get_target_score(embedded_user, self.item_id_target)  # :115
+        logits = m.get_prediction(embedded_user)                              # :118
+        self.output = logits
+        batch_loss_eval = None
+        if loss in ('warp', 'ce'):
+            batch_loss = m.compute_loss(logits, self.item_target, loss)
+        elif loss == 'warp_eval':
+            batch_loss, _ = m.compute_loss(logits, self.item_target, loss)
+        elif loss == 'mw':
+            batch_loss = m.compute_loss(sampled_logits, target_score, loss)
+            batch_loss_eval = m.compute_loss(logits, self.item_target, 'warp')  # :130
+        else:
+            raise NotImplementedError("not implemented!")
+        if loss in ('warp', 'warp_eval', 'mw'):
+            self.set_mask, self.reset_mask = m.get_warp_mask()
+        self.batch_loss = batch_loss
+        self.loss = G.MeanLoss(rt, batch_loss)                                # :140
+        self.loss_eval = G.MeanLoss(rt, batch_loss_eval) if loss == 'mw' else self.loss  # :144
+        self.topk = TopK(rt, logits, min(self.top_N_items, self.logit_size))  # :154
+        self.indices = self.topk
+        self.saver = Saver(self)
+
+    # ------------------------------------------------------------------
+    def prepare_warp(self, pos_item_set, pos_item_set_eval):
+        self.att_emb.prepare_warp(pos_item_set, pos_item_set_eval)
+
+    def _plan(self, key):
+        if key in self._plans:
+            return self._plans[key]
+        rt, m = self.rt, self.att_emb
+        loss = self.loss_function
+        if key == 'train':
+            masks = [m.mask[loss]] if loss in m.mask else []
+            p = G.Plan(rt, [self.loss], True, masks)
+        elif key == 'eval':
+            l = 'warp' if loss == 'mw' else loss
+            masks = [m.mask[l]] if l in m.mask else []
+            p = G.Plan(rt, [self.loss_eval], False, masks)
+        elif key == 'recommend':
+            p = G.Plan(rt, [self.topk], False, [])
+        elif key == 'warp_eval':
+            p = G.Plan(rt, [self.batch_loss], False, [m.mask['warp_eval']])
+        else:
+            raise KeyError(key)
+        self._plans[key] = p
+        return p
+
+    def _feed(self, user_input, item_input, recommend, loss, item_sampled, item_sampled_id2idx,
+              forward_only):
+        m = self.att_emb
+        if not recommend:
+            if isinstance(item_input, torch.Tensor):
+                self.item_id_target.feed(item_input)
+                if self.loss_function != 'mw' or forward_only:
+                    m.target_mapping_device(self.item_id_target.value, self.item_target.value)
+            else:
+                if self.loss_function != 'mw' or forward_only:
+                    targets = m.target_mapping([item_input])                  # :173
+                    self.item_target.feed(targets[0])
+                self.item_id_target.feed(item_input)                          # :176
+        update_sampled, _, _ = m.add_input({}, user_input, item_input, item_sampled=item_sampled,
+                                           item_sampled_id2idx=item_sampled_id2idx,
+                                           forward_only=forward_only, recommend=recommend, loss=loss)
+        for op in update_sampled:                                             # :206-207
+            op()
+
+    def step_async(self, session, user_input, item_input, neg_item_input=None, item_sampled=None,
+                   item_sampled_id2idx=None, forward_only=False, recommend=False,
+                   recommend_new=False, loss=None, run_op=None, run_meta=None):
+        """step() without the device->host read of the result: returns the device
+        tensor holding it (loss scalar / top-k indices)."""
+        if loss is None:
+            loss = self.loss_function
+        self._feed(user_input, item_input, recommend, loss, item_sampled, item_sampled_id2idx,
+                   forward_only)
+        if recommend:
+            self._plan('recommend').run()
+            return self.topk.indices
+        if loss == 'warp_eval':
+            self._plan('warp_eval').run()
+            return [self.batch_loss.value, self.batch_loss.rank_value]
+        if forward_only:
+            self._plan('eval').run()
+            return self.loss_eval.value
+        self._plan('train').run()
+        self.rt.global_step += 1
+        return self.loss.value
+
+    def step(self, session, user_input, item_input, neg_item_input=None, item_sampled=None,
+             item_sampled_id2idx=None, forward_only=False, recommend=False, recommend_new=False,
+             loss=None, run_op=None, run_meta=None):
+        """hmf_model.py:162-228.  Returns: train -> mean loss (float); forward_only ->
+        loss_eval (float); recommend -> int32 [mb, top_N]; warp_eval -> [loss, rank]."""
+        out = self.step_async(session, user_input, item_input, neg_item_input, item_sampled,
+                              item_sampled_id2idx, forward_only, recommend, recommend_new, loss,
+                              run_op, run_meta)
+        if recommend:
+            return out.cpu().numpy()
+        if isinstance(out, list):
+            return [o.cpu().numpy() for o in out]
+        return float(out.item())
+
+    # ---- batch drawing (hmf_model.py:230-260) ----
+    def get_batch(self, data, loss='ce', hist=None):
+        batch_user_input, batch_item_input = [], []
+        for _ in range(self.batch_size):
+            u, i, _t = random.choice(data)
+            batch_user_input.append(u)
+            batch_item_input.append(i)
+        return batch_user_input, batch_item_input, []
+
+    def get_permuted_batch(self, data):
+        if self.data_length is None:
+            self.data_length = len(data)
+            self.start_index = 0
+            self.train_permutation = np.random.permutation(self.data_length)
+        if self.start_index + self.batch_size >= self.data_length:
+            self.start_index = 0
+            self.train_permutation = np.random.permutation(self.data_length)
+        idx = self.train_permutation[self.start_index:self.start_index + self.batch_size]
+        self.start_index += self.batch_size
+        users = [data[j][0] for j in idx]
+        items = [data[j][1] for j in idx]
+        return users, items, None

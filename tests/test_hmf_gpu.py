@@ -1,0 +1,161 @@
+"""Whole-step HMF parity: arx.hmf.hmf_model.LatentProductModel (HIP, through the
+C ABI) against oracle.ref_graph.RefLatentProductModel (numpy restatement of the
+reference graph in its own full-table form), identical (user, item, negatives)
+batches, N consecutive steps.  fp32 rtol 1e-4 on loss / logits / updated rows."""
+import numpy as np
+import pytest
+
+from oracle import ref_graph as rg
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 2e-6
+
+
+def _build(cfg, loss, d, B, S, seed, nonlinear='linear', use_graph=True):
+    from arx.utils.synthetic import SyntheticHMF
+    from arx.hmf.hmf_model import LatentProductModel
+    syn = SyntheticHMF(seed=seed, **cfg)
+    params = syn.glorot_params(d, seed=seed + 1, scale=0.5)
+    if nonlinear in ('relu', 'tanh'):
+        rng = np.random.default_rng(seed + 2)
+        params['w1'] = (rng.standard_normal((d, 48)) * 0.3).astype(np.float32)
+        params['b1'] = (rng.standard_normal((48,)) * 0.1).astype(np.float32)
+        params['w2'] = (rng.standard_normal((48, d)) * 0.3).astype(np.float32)
+        params['b2'] = (rng.standard_normal((d,)) * 0.1).astype(np.float32)
+    i2l = syn.item_ind2logit_ind_dict()
+    l2i = syn.logit_ind2item_ind
+    n_s = S if loss == 'mw' else None
+    model = LatentProductModel(syn.n_users, syn.n_items, d, 1, B, 0.5, 1.0, syn.u_attr, syn.i_attr,
+                               i2l, l2i, loss_function=loss, n_sampled=n_s, params=params,
+                               nonlinear=nonlinear, hidden_size=48, top_N_items=10,
+                               use_graph=use_graph)
+    ref = rg.RefLatentProductModel(d, B, 0.5, syn.u_attr, syn.i_attr, i2l, l2i, loss_function=loss,
+                                   n_sampled=n_s, params=params, dtype=np.float64, top_N_items=10,
+                                   nonlinear=nonlinear, hidden_size=48)
+    pos = syn.positives_dict()
+    if loss in ('mw', 'warp'):
+        model.prepare_warp(pos, pos)
+        ref.prepare_warp(pos, pos)
+    return syn, model, ref
+
+
+def _compare_state(model, ref, rtol=RTOL, atol=ATOL):
+    got = model.att_emb.get_params()
+    slots = model.att_emb.get_slots()
+    for name, val in got.items():
+        np.testing.assert_allclose(val, ref.att_emb.params[name], rtol=rtol, atol=atol, err_msg=name)
+        np.testing.assert_allclose(slots[name], ref.att_emb.slots[name], rtol=rtol, atol=atol,
+                                   err_msg=name + '/Adagrad')
+    for name, p in model.rt.dense.items():
+        np.testing.assert_allclose(p.w.cpu().numpy(), ref.att_emb.params[name], rtol=rtol, atol=atol,
+                                   err_msg=name)
+
+
+CFG_ID = dict(n_users=500, n_items=700, logit_size=600)
+CFG_HET = dict(n_users=500, n_items=700, logit_size=700, item_mulhot=True, mulhot_vocab=300,
+               avg_len=6, max_len=18)
+CFG_MIX = dict(n_users=400, n_items=600, logit_size=600, item_mulhot=True, user_mulhot=True,
+               mulhot_vocab=200, avg_len=5, max_len=12, item_id_feature=False)
+
+
+@pytest.mark.parametrize("cfg,loss,d,B,S", [
+    (CFG_ID, 'mw', 128, 64, 256),
+    (CFG_HET, 'mw', 128, 64, 256),
+    (CFG_MIX, 'mw', 32, 48, 128),
+    (CFG_ID, 'ce', 32, 64, None),
+    (CFG_HET, 'ce', 32, 64, None),
+    (CFG_HET, 'warp', 64, 32, None),
+])
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_hmf_steps_match_oracle(dev, cfg, loss, d, B, S, use_graph):
+    syn, model, ref = _build(cfg, loss, d, B, S, seed=3, use_graph=use_graph)
+    rng = np.random.default_rng(11)
+    for step in range(4):
+        users, items = syn.sample_batch(B, rng)
+        users[1] = users[0]                      # duplicate user rows in one batch
+        items[2] = items[3]
+        pool = id2idx = None
+        if loss == 'mw' and step % 2 == 0:       # resample cadence
+            pool = syn.sample_pool(S, rng)
+            pool[:4] = items[:4]                 # targets inside the pool -> masked
+            pool = np.unique(pool)
+            extra = np.setdiff1d(syn.item_population, pool)[:S - len(pool)]
+            pool = np.concatenate([pool, extra]).astype(np.int32)
+            id2idx = {int(v): i for i, v in enumerate(pool)}
+            last_id2idx = id2idx
+        l_ref = ref.step(list(users), list(items), pool, id2idx if id2idx else
+                         (last_id2idx if loss == 'mw' else None), loss=loss)
+        l_got = model.step(None, list(users), list(items), None, pool, id2idx, loss=loss)
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='step %d' % step)
+        _compare_state(model, ref)
+
+
+def test_c1_shape_ce_three_seeds(dev):
+    """C1: ML-1m shape (6040 users, 3883 items, V=3100, d=32, B=64, ce, lr=1)."""
+    cfg = dict(n_users=6040, n_items=3883, logit_size=3100)
+    for seed in (0, 1, 2):
+        syn, model, ref = _build(cfg, 'ce', 32, 64, None, seed=seed)
+        rng = np.random.default_rng(seed)
+        for step in range(3):
+            users, items = syn.sample_batch(64, rng)
+            l_ref = ref.step(list(users), list(items), loss='ce')
+            l_got = model.step(None, list(users), list(items), loss='ce')
+            np.testing.assert_allclose(l_got, l_ref, rtol=RTOL)
+        _compare_state(model, ref)
+
+
+def test_eval_recommend_and_logits(dev):
+    syn, model, ref = _build(CFG_HET, 'mw', 64, 32, 128, seed=5)
+    rng = np.random.default_rng(2)
+    users, items = syn.sample_batch(32, rng)
+    pool = syn.sample_pool(128, rng)
+    id2idx = {int(v): i for i, v in enumerate(pool)}
+    l_ref = ref.step(list(users), list(items), pool, id2idx, loss='mw')
+    l_got = model.step(None, list(users), list(items), None, pool, id2idx, loss='mw')
+    np.testing.assert_allclose(l_got, l_ref, rtol=RTOL)
+    # sampled logits of that step
+    np.testing.assert_allclose(model.batch_loss.inputs[0].value.cpu().numpy(), ref.last['logits'],
+                               rtol=RTOL, atol=1e-5)
+    # forward_only -> loss_eval ('warp' over the full vocabulary with the eval positives)
+    e_ref = ref.step(list(users), list(items), forward_only=True, loss='warp')
+    e_got = model.step(None, list(users), list(items), forward_only=True, loss='warp')
+    np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
+    # recommend -> top-N logit indices
+    r_ref = ref.step(list(users), None, recommend=True)
+    r_got = model.step(None, list(users), None, recommend=True)
+    np.testing.assert_array_equal(r_got, r_ref)
+
+
+@pytest.mark.parametrize("nonlinear", ['relu', 'tanh'])
+def test_mlp_variant(dev, nonlinear):
+    syn, model, ref = _build(CFG_ID, 'mw', 32, 32, 128, seed=7, nonlinear=nonlinear)
+    rng = np.random.default_rng(4)
+    pool = syn.sample_pool(128, rng)
+    id2idx = {int(v): i for i, v in enumerate(pool)}
+    for step in range(3):
+        users, items = syn.sample_batch(32, rng)
+        l_ref = ref.step(list(users), list(items), pool if step == 0 else None, id2idx, loss='mw')
+        l_got = model.step(None, list(users), list(items), None, pool if step == 0 else None, id2idx,
+                           loss='mw')
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL)
+    _compare_state(model, ref, rtol=2e-4, atol=1e-5)
+
+
+def test_checkpoint_roundtrip(dev, tmp_path):
+    syn, model, ref = _build(CFG_ID, 'mw', 32, 32, 128, seed=9)
+    rng = np.random.default_rng(1)
+    pool = syn.sample_pool(128, rng)
+    id2idx = {int(v): i for i, v in enumerate(pool)}
+    users, items = syn.sample_batch(32, rng)
+    model.step(None, list(users), list(items), None, pool, id2idx, loss='mw')
+    path = model.saver.save(None, str(tmp_path / 'best.ckpt'), global_step=0)
+    before = model.att_emb.get_params()
+    users2, items2 = syn.sample_batch(32, rng)
+    l2 = model.step(None, list(users2), list(items2), None, None, id2idx, loss='mw')
+    model.saver.restore(None, path)
+    after = model.att_emb.get_params()
+    for k in before:
+        np.testing.assert_array_equal(before[k], after[k])
+    l2b = model.step(None, list(users2), list(items2), None, None, id2idx, loss='mw')
+    assert l2 == l2b     # deterministic kernels: same state + same batch -> same loss bits
