@@ -8,6 +8,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch ships its own libamdhip64; load it FIRST so libarx.so binds to the same
+# HIP runtime instance (two runtimes in one process => "no ROCm-capable device").
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libarx.so")
 
@@ -59,7 +63,8 @@ PROTOTYPES = {
     "arx_axpby": (cint, [f32, f32p, f32, f32p, i64, vp]),
     "arx_add_rows_bcast": (cint, [f32, f32p, i64, i64, f32, f32p, i64, i64, cint, vp]),
     "arx_row_sum": (cint, [f32p, i64, i64, i64, f32p, cint, vp]),
-    "arx_col_sum": (cint, [f32p, i64, i64, i64, f32p, vp]),
+    "arx_col_sum_workspace_bytes": (sz, [i64, i64]),
+    "arx_col_sum": (cint, [f32p, i64, i64, i64, f32p, vp, sz, vp]),
     "arx_sum_scaled": (cint, [f32p, i64, f32, f32p, vp]),
     "arx_dropout_fwd": (cint, [f32p, i64, f32, u64, f32p, u8p, vp]),
     "arx_dropout_bwd": (cint, [f32p, u8p, i64, f32, f32p, vp]),
@@ -100,6 +105,7 @@ def _load():
 lib = _load()
 
 _NO_CHECK = ("arx_last_error", "arx_version", "arx_csr_expand_workspace_bytes",
+             "arx_col_sum_workspace_bytes",
              "arx_gemm_f32_workspace_bytes", "arx_sparse_adagrad_workspace_bytes")
 
 

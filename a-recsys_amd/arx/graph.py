@@ -247,7 +247,7 @@ class Prediction(Node):
         if pool.train_tables:
             gp = pool.alloc_grad()
             ops.gemm(dl, latent.value, gp, self.rt.ws, transA=True, beta=pool.grad_beta())  # dIbar = dL^T . U
-            ops.col_sum(dl, pool.bias_grad)                                       # dbbar
+            ops.col_sum(dl, pool.bias_grad, self.rt.ws)                                       # dbbar
             pool.bias_grad_used = True
 
 

@@ -70,11 +70,11 @@ class MLP(G.Node):
         dz2 = self.grad
         ops.act_bwd(self.value, dz2, self.kind, dz2)                    # through act(z2)
         ops.gemm(self.h1, dz2, self.w2.grad, rt.ws, transA=True)
-        ops.col_sum(dz2, self.b2.grad)
+        ops.col_sum(dz2, self.b2.grad, rt.ws)
         ops.gemm(dz2, self.w2.w, self.d1, rt.ws, transB=True)
         ops.act_bwd(self.h1, self.d1, self.kind, self.d1)
         ops.gemm(self.h0, self.d1, self.w1.grad, rt.ws, transA=True)
-        ops.col_sum(self.d1, self.b1.grad)
+        ops.col_sum(self.d1, self.b1.grad, rt.ws)
         ops.gemm(self.d1, self.w1.w, self.d0, rt.ws, transB=True)
         ops.act_bwd(self.h0, self.d0, self.kind, self.d0)
         g = x.alloc_grad()

@@ -240,8 +240,10 @@ def row_sum(x, out, accumulate=False):
          int(bool(accumulate)), _stream())
 
 
-def col_sum(x, out):
-    call("arx_col_sum", _p(x), _ld(x), int(x.shape[0]), int(x.shape[1]), _p(out), _stream())
+def col_sum(x, out, ws):
+    rows, cols = int(x.shape[0]), int(x.shape[1])
+    wsp, wsn = ws.get(_lib.lib.arx_col_sum_workspace_bytes(rows, cols))
+    call("arx_col_sum", _p(x), _ld(x), rows, cols, _p(out), wsp, wsn, _stream())
 
 
 def sum_scaled(x, scale, out, n=None):

@@ -14,6 +14,8 @@
 //        operand read (32 rows at fixed k) hits 32 distinct banks;
 //   MN-contiguous storage ([k][rows]) : X[BK][rows+4]  -- the operand read is 32
 //        consecutive floats, conflict-free; stores are aligned ds_write_b128.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace arx {
@@ -217,6 +219,9 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
   const int cus = cu_count();
   const int64_t tiles_big = ceil_div(M, 128) * ceil_div(N, 128);
   p.big = tiles_big * 4 >= (int64_t)cus * 3;
+  static const char* force = getenv("ARX_GEMM_FORCE");   // tuning aid: "big" | "small"
+  if (force && force[0] == 'b') p.big = true;
+  if (force && force[0] == 's') p.big = false;
   p.splits = 1;
   p.kchunk = K > 0 ? K : 1;
   if (!p.big) {

@@ -24,6 +24,7 @@
 // O(len / kPiece / 8) dependent loads instead of O(len).
 #include <cstring>
 #include <hip/hip_runtime.h>
+#include <rocprim/block/block_radix_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
@@ -50,6 +51,39 @@ __global__ void k_prep_keys(const int32_t* __restrict__ keys, int64_t n, uint32_
     const int32_t k = keys[i];
     keys_tmp[i] = (k == ARX_KEY_NONE || k < 0 || (uint32_t)k >= sentinel) ? sentinel : (uint32_t)k;
     pos[i] = (uint32_t)i;
+  }
+}
+
+// n <= 1024*IPT: key normalisation + stable (key, position) sort by ONE workgroup.
+template <int IPT>
+__global__ __launch_bounds__(1024) void k_small_sort(const int32_t* __restrict__ keys, int64_t n,
+                                                     uint32_t sentinel, int key_bits,
+                                                     uint32_t* __restrict__ sk,
+                                                     uint32_t* __restrict__ spos,
+                                                     int32_t* __restrict__ list_count) {
+  using Sort = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint32_t>;
+  __shared__ typename Sort::storage_type storage;
+  if (threadIdx.x == 0) *list_count = 0;
+  uint32_t k[IPT], v[IPT];
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int64_t idx = (int64_t)threadIdx.x * IPT + i;
+    uint32_t kk = sentinel;   // padding sorts behind every real entry (stable)
+    if (idx < n) {
+      const int32_t r = keys[idx];
+      kk = (r == ARX_KEY_NONE || r < 0 || (uint32_t)r >= sentinel) ? sentinel : (uint32_t)r;
+    }
+    k[i] = kk;
+    v[i] = (uint32_t)idx;
+  }
+  Sort().sort(k, v, storage, 0, key_bits + 1);
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int64_t idx = (int64_t)threadIdx.x * IPT + i;
+    if (idx < n) {
+      sk[idx] = k[i];
+      spos[idx] = v[i];
+    }
   }
 }
 
@@ -379,18 +413,28 @@ int arx_sparse_adagrad(float* E, float* acc, float* bias, float* bias_acc, int d
   float* scratch = reinterpret_cast<float*>(base + w.off_scratch);
   float* scratch_b = reinterpret_cast<float*>(base + w.off_scratch_b);
   void* temp = base + w.off_temp;
-  {
+  if (n <= 16384) {
+    // id-only batches (B + S keys): one workgroup sorts everything in LDS -- a
+    // single launch instead of the 5-6 of the device-wide radix sort.
+    if (n <= 4096)
+      k_small_sort<4><<<1, 1024, 0, s>>>(keys, n, sentinel, key_bits, keys_out, pos_out, count);
+    else if (n <= 8192)
+      k_small_sort<8><<<1, 1024, 0, s>>>(keys, n, sentinel, key_bits, keys_out, pos_out, count);
+    else
+      k_small_sort<16><<<1, 1024, 0, s>>>(keys, n, sentinel, key_bits, keys_out, pos_out, count);
+    ARX_CHECK_LAUNCH();
+  } else {
     int64_t g = ceil_div(n, 256);
     int64_t cap = (int64_t)cu_count() * 8;
     if (g > cap) g = cap;
     k_prep_keys<<<(int)g, 256, 0, s>>>(keys, n, sentinel, keys_tmp, pos_in, count);
     ARX_CHECK_LAUNCH();
+    size_t temp_bytes = w.temp_bytes;
+    ARX_CHECK_HIP((rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t*, uint32_t*,
+                                             const uint32_t*, uint32_t*>(
+        temp, temp_bytes, keys_tmp, keys_out, pos_in, pos_out, (unsigned int)n, 0, key_bits + 1,
+        s, false)));
   }
-  size_t temp_bytes = w.temp_bytes;
-  ARX_CHECK_HIP((rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t*, uint32_t*,
-                                           const uint32_t*, uint32_t*>(
-      temp, temp_bytes, keys_tmp, keys_out, pos_in, pos_out, (unsigned int)n, 0, key_bits + 1, s,
-      false)));
   const int lpr = lanes_per_row(d);
   const int64_t nwaves = ceil_div(n, 64 / lpr);
   const int grid_a = (int)ceil_div(nwaves, 4);

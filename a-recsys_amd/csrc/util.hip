@@ -87,19 +87,44 @@ __global__ void k_row_sum(const float* __restrict__ x, int64_t ld, int64_t rows,
   }
 }
 
-// column sums: block (64 x 4) handles 64 columns; deterministic two-stage
-__global__ void k_col_sum(const float* __restrict__ x, int64_t ld, int64_t rows, int64_t cols,
-                          float* __restrict__ out) {
+// column sums, deterministic two-stage: grid (cols/64, row chunks) -> partials
+// [chunks, cols] in the caller workspace -> fixed-order final add.  (A single
+// stage with cols/64 workgroups left 240 of 256 CUs idle at [4096 x 1024].)
+__global__ void k_col_sum_partial(const float* __restrict__ x, int64_t ld, int64_t rows,
+                                  int64_t cols, int64_t rows_per_chunk,
+                                  float* __restrict__ partial) {
   __shared__ float part[4][64];
-  int cx = threadIdx.x & 63;
-  int ry = threadIdx.x >> 6;
-  int64_t c = blockIdx.x * 64 + cx;
+  const int cx = threadIdx.x & 63;
+  const int ry = threadIdx.x >> 6;
+  const int64_t c = blockIdx.x * 64 + cx;
+  const int64_t r0 = blockIdx.y * rows_per_chunk;
+  const int64_t r1 = min(rows, r0 + rows_per_chunk);
   float s = 0.f;
   if (c < cols)
-    for (int64_t r = ry; r < rows; r += 4) s += x[r * ld + c];
+    for (int64_t r = r0 + ry; r < r1; r += 4) s += x[r * ld + c];
   part[ry][cx] = s;
   __syncthreads();
-  if (ry == 0 && c < cols) out[c] = part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
+  if (ry == 0 && c < cols)
+    partial[blockIdx.y * cols + c] = part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
+}
+
+__global__ void k_col_sum_final(const float* __restrict__ partial, int nchunk, int64_t cols,
+                                float* __restrict__ out) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += partial[(int64_t)k * cols + c];
+  out[c] = s;
+}
+
+static inline int col_sum_chunks(int64_t rows, int64_t cols) {
+  const int64_t colblocks = ceil_div(cols > 0 ? cols : 1, 64);
+  int64_t want = ceil_div(2048, colblocks);          // ~2048 workgroups in flight
+  int64_t maxc = ceil_div(rows > 0 ? rows : 1, 16);  // >= 16 rows per chunk
+  int64_t n = want < maxc ? want : maxc;
+  if (n < 1) n = 1;
+  if (n > 256) n = 256;
+  return (int)n;
 }
 
 // single block deterministic sum
@@ -263,11 +288,25 @@ int arx_row_sum(const float* x, int64_t ld, int64_t rows, int64_t cols, float* o
   return ARX_OK;
 }
 
+size_t arx_col_sum_workspace_bytes(int64_t rows, int64_t cols) {
+  return (size_t)col_sum_chunks(rows, cols) * (size_t)(cols > 0 ? cols : 1) * sizeof(float);
+}
+
 int arx_col_sum(const float* x, int64_t ld, int64_t rows, int64_t cols, float* out,
-                void* stream) {
+                void* workspace, size_t workspace_bytes, void* stream) {
   ARX_CHECK_ARG(x && out, "arx_col_sum: null pointer");
   if (cols <= 0) return ARX_OK;
-  k_col_sum<<<(int)ceil_div(cols, 64), 256, 0, as_stream(stream)>>>(x, ld, rows, cols, out);
+  const int nchunk = col_sum_chunks(rows, cols);
+  if (!workspace || workspace_bytes < arx_col_sum_workspace_bytes(rows, cols)) {
+    set_error("arx_col_sum: workspace too small");
+    return ARX_EWORKSPACE;
+  }
+  float* partial = reinterpret_cast<float*>(workspace);
+  const int64_t rpc = ceil_div(rows > 0 ? rows : 1, nchunk);
+  dim3 grid((unsigned)ceil_div(cols, 64), (unsigned)nchunk);
+  k_col_sum_partial<<<grid, 256, 0, as_stream(stream)>>>(x, ld, rows, cols, rpc, partial);
+  ARX_CHECK_LAUNCH();
+  k_col_sum_final<<<(int)ceil_div(cols, 256), 256, 0, as_stream(stream)>>>(partial, nchunk, cols, out);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

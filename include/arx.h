@@ -185,9 +185,10 @@ int arx_add_rows_bcast(float a, const float* x, int64_t ldx, int64_t xrows, floa
 /* out[r] = sum_c x[r*ld + c]  (rows x cols), out (+)= when accumulate */
 int arx_row_sum(const float* x, int64_t ld, int64_t rows, int64_t cols, float* out,
                 int accumulate, void* stream);
-/* out[c] = sum_r x[r*ld + c] * (row_w ? row_w[r] : 1) */
+/* out[c] = sum_r x[r*ld + c]; deterministic two-stage, partials in the workspace */
+size_t arx_col_sum_workspace_bytes(int64_t rows, int64_t cols);
 int arx_col_sum(const float* x, int64_t ld, int64_t rows, int64_t cols, float* out,
-                void* stream);
+                void* workspace, size_t workspace_bytes, void* stream);
 /* mean over rows: *out = scale * sum_i x[i] */
 int arx_sum_scaled(const float* x, int64_t n, float scale, float* out, void* stream);
 /* tf.nn.dropout (embed_attribute.py:236): y = x * keep_mask / keep_prob, counter RNG */

@@ -557,12 +557,30 @@ class RefEmbeddingAttribute(object):
 
     # ---- optimiser over a Grads container ----
     def apply_gradients(self, grads, lr, scale=1.0):
+        """opt.apply_gradients (hmf_model.py:150): a variable with a dense (matmul)
+        contribution gets the dense update over the whole table; a variable with
+        only IndexedSlices gets TF's sparse apply: duplicates summed per unique
+        row (_apply_sparse_duplicate_indices), then one update per touched row."""
+        lr = self.dt.type(lr)
         for name in grads.names():
             p = self.params[name]
-            g = grads.total(name, p.shape, self.dt)
-            if scale != 1.0:
-                g = g * self.dt.type(scale)
-            adagrad_apply(p, self.slots[name], g, self.dt.type(lr))
+            if name in grads.dense:
+                g = grads.total(name, p.shape, self.dt)
+                if scale != 1.0:
+                    g = g * self.dt.type(scale)
+                adagrad_apply(p, self.slots[name], g, lr)
+            else:
+                idx = np.concatenate([i for i, _ in grads.sparse[name]])
+                val = np.concatenate([v.reshape((len(i),) + p.shape[1:])
+                                      for i, v in grads.sparse[name]], 0)
+                uniq, inv = np.unique(idx, return_inverse=True)
+                summed = np.zeros((len(uniq),) + p.shape[1:], dtype=self.dt)
+                np.add.at(summed, inv, val)
+                if scale != 1.0:
+                    summed = summed * self.dt.type(scale)
+                acc = self.slots[name][uniq] + summed * summed
+                self.slots[name][uniq] = acc
+                p[uniq] -= lr * summed / np.sqrt(acc)
 
 
 # --------------------------------------------------------------------------

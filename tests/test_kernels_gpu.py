@@ -401,7 +401,7 @@ def test_small_utils(dev):
     ops.row_sum(_t(dev, y), rs)
     np.testing.assert_allclose(rs.cpu().numpy(), y.sum(1), rtol=1e-5, atol=1e-5)
     cs = torch.empty(64, dtype=torch.float32, device=dev)
-    ops.col_sum(_t(dev, y), cs)
+    ops.col_sum(_t(dev, y), cs, ops.Workspace(dev))
     np.testing.assert_allclose(cs.cpu().numpy(), y.sum(0), rtol=1e-5, atol=1e-4)
     s = torch.empty(1, dtype=torch.float32, device=dev)
     ops.sum_scaled(_t(dev, y), 0.125, s)
@@ -462,5 +462,5 @@ def test_lstm_fwd_bwd(dev, L, B, din, h):
         ops.gemm(hs.view(L * B, h)[:(L - 1) * B], dz2[B:], dW[din:], ws, transA=True)
     np.testing.assert_allclose(dW.cpu().numpy(), r_dW, rtol=2e-4, atol=2e-4)
     db = torch.empty(4 * h, dtype=torch.float32, device=dev)
-    ops.col_sum(dz2, db)
+    ops.col_sum(dz2, db, ws)
     np.testing.assert_allclose(db.cpu().numpy(), r_db, rtol=2e-4, atol=2e-4)
