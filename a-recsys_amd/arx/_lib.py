@@ -43,12 +43,18 @@ PROTOTYPES = {
     "arx_gemm_f32_workspace_bytes": (sz, [i64, i64, i64]),
     "arx_gemm_f32": (cint, [cint, cint, i64, i64, i64, f32, f32p, i64, f32p, i64, f32, f32p, i64,
                             f32p, vp, sz, vp]),
+    "arx_gemm_f32_rowsum": (cint, [cint, cint, i64, i64, i64, f32, f32p, i64, f32p, i64, f32, f32p,
+                                   i64, f32p, f32p, vp, sz, vp]),
     "arx_pos_mask_scatter": (cint, [i32p, i64, i32p, i32p, i32p, u8p, i64, cint, vp]),
     "arx_slot_map_set": (cint, [i32p, i32p, i64, cint, vp]),
     "arx_loss_mw_fwdbwd": (cint, [f32p, i64, f32p, u8p, i64, i64, f32, f32p, i64, i64, f32p, f32p,
                                   i64, f32p, vp]),
     "arx_loss_warp_fwdbwd": (cint, [f32p, i64, i32p, u8p, i64, i64, f32, f32p, i64, i64, f32p, f32p,
                                     i64, vp]),
+    "arx_loss_mw_fwdbwd_pos": (cint, [f32p, i64, f32p, i32p, i32p, i32p, i32p, i64, f32, f32p, i64,
+                                      i64, f32p, f32p, i64, f32p, vp]),
+    "arx_loss_warp_fwdbwd_pos": (cint, [f32p, i64, i32p, i32p, i32p, i32p, i32p, i64, f32, f32p,
+                                        i64, i64, f32p, f32p, i64, vp]),
     "arx_loss_ce_fwdbwd": (cint, [f32p, i64, i32p, f32, f32p, i64, i64, f32p, f32p, i64, vp]),
     "arx_loss_warp_eval": (cint, [f32p, i64, i32p, u8p, i64, i64, i64, i64, f32p, i32p, vp]),
     "arx_sparse_adagrad_workspace_bytes": (sz, [i64]),

@@ -246,8 +246,9 @@ class Prediction(Node):
             ops.gemm(dl, pool.value, g, self.rt.ws, beta=latent.grad_beta())     # dU = dL . Ibar
         if pool.train_tables:
             gp = pool.alloc_grad()
-            ops.gemm(dl, latent.value, gp, self.rt.ws, transA=True, beta=pool.grad_beta())  # dIbar = dL^T . U
-            ops.col_sum(dl, pool.bias_grad, self.rt.ws)                                       # dbbar
+            # dIbar = dL^T . U ; dbbar = rowsum(dL^T) rides in the same kernel
+            ops.gemm(dl, latent.value, gp, self.rt.ws, transA=True, beta=pool.grad_beta(),
+                     a_rowsum=pool.bias_grad)
             pool.bias_grad_used = True
 
 
@@ -263,6 +264,15 @@ class TargetScore(Node):
         latent, te = self.inputs
         ops.dot_score(latent.value, te.value, te.bias_value, self.alloc_value())
 
+    def alloc_grad(self):
+        # d(score)/d(bias) = 1: the bias-gradient rows of the target lookup ARE this
+        # node's gradient, so the loss kernel writes dt straight into that slice.
+        te = self.inputs[1]
+        if te.train_tables and te.bias_grad is not None:
+            self.grad = te.bias_grad
+            return self.grad
+        return super().alloc_grad()
+
     def backward(self):
         latent, te = self.inputs
         ds = self.grad
@@ -271,7 +281,8 @@ class TargetScore(Node):
         ops.dot_score_bwd(latent.value, te.value, ds, g, latent.grad_beta() != 0.0, dT)
         if te.train_tables:
             te.grad_beta()
-            ops.axpby(1.0, ds, 0.0, te.bias_grad)
+            if ds.data_ptr() != te.bias_grad.data_ptr():
+                ops.axpby(1.0, ds, 0.0, te.bias_grad)
             te.bias_grad_used = True
 
 
@@ -299,21 +310,39 @@ class BatchLoss(Node):
         dl = logits.alloc_grad() if train else None
         if train:
             logits.grad_beta()
-        m = self.mask.buf if self.mask is not None else None
+        ms = self.mask
+        fused = ms is not None and ms.fused
+        m = ms.buf if (ms is not None and not fused) else None
         rw = self.row_w.value if self.row_w is not None else None
+        if fused:
+            ptr, items = ms.pos_getter()
+            uid, i2s = ms.user_ids.value, ms.slot_map_getter()
         if self.kind == 'mw':
             dt = target.alloc_grad() if train else None
             if train:
                 target.grad_beta()
-            ops.loss_mw(logits.value, target.value, m, bl, dl, dt, self.gscale, rw, self.mask_rows)
+            if fused:
+                ops.loss_mw_pos(logits.value, target.value, uid, ptr, items, i2s, bl, dl, dt,
+                                self.gscale, rw, self.mask_rows)
+            else:
+                ops.loss_mw(logits.value, target.value, m, bl, dl, dt, self.gscale, rw, self.mask_rows)
         elif self.kind == 'warp':
-            ops.loss_warp(logits.value, target.value, m, bl, dl, self.gscale, rw, self.mask_rows)
+            if fused:
+                ops.loss_warp_pos(logits.value, target.value, uid, ptr, items, i2s, bl, dl,
+                                  self.gscale, rw, self.mask_rows)
+            else:
+                ops.loss_warp(logits.value, target.value, m, bl, dl, self.gscale, rw, self.mask_rows)
         elif self.kind == 'ce':
             ops.loss_ce(logits.value, target.value, bl, dl, self.gscale, rw)
         else:  # warp_eval -> [margin_rank, true_rank]
             if self.rank_value is None:
                 self.rank_value = torch.empty(self.shape[0], dtype=torch.int32, device=self.rt.device)
-            ops.loss_warp_eval(logits.value, target.value, m, bl, self.rank_value, self.mask_rows)
+            if fused:          # eval-only path: use the array form of the mask
+                ms.scatter(0)
+            ops.loss_warp_eval(logits.value, target.value, ms.buf if ms is not None else None, bl,
+                               self.rank_value, self.mask_rows)
+            if fused:
+                ms.scatter(1)
 
 
 class MeanLoss(Node):
@@ -325,9 +354,24 @@ class MeanLoss(Node):
         super().__init__(rt, (1,), (batch_loss,))
         batch_loss.gscale = 1.0 / batch_loss.shape[0]
 
+    lazy = False   # train plans set this: the scalar is reduced only when somebody reads it
+
     def forward(self, train):
+        if self.lazy and train:
+            self.alloc_value()      # Plan.run marks it stale after every (replayed) step
+            return
+        self.reduce_now()
+
+    def reduce_now(self):
         bl = self.inputs[0]
         ops.sum_scaled(bl.value, 1.0 / bl.shape[0], self.alloc_value())
+        self._stale = False
+
+    def read(self):
+        """Device scalar holding the mean loss of the last step."""
+        if getattr(self, '_stale', False):
+            self.reduce_now()
+        return self.value
 
 
 class MaskState(object):
@@ -338,6 +382,9 @@ class MaskState(object):
         self.rt = rt
         self.rows, self.W = rows, W
         self._buf = None            # allocated on first use: [rows, V] can be GBs at V = 1M
+        # fused: the loss kernel derives the mask bits itself (LDS, <= 2^20 columns), so
+        # the persistent array and its set/reset launches are not needed by the plans.
+        self.fused = W <= ops.POS_MASK_MAX_COLS
         self.user_ids = user_ids
         self.slot_map_getter = slot_map_getter
         self.pos_getter = pos_getter
@@ -418,7 +465,8 @@ class Plan(object):
     def _execute(self):
         rt = self.rt
         for m in self.masks:
-            m.scatter(0)                                   # set_mask (hmf_model.py:209-210)
+            if not m.fused:
+                m.scatter(0)                               # set_mask (hmf_model.py:209-210)
         for n in self.order:
             n._grad_written = False
             if isinstance(n, EntityEmbed):
@@ -433,7 +481,8 @@ class Plan(object):
             self._apply_sparse()
             rt.apply_dense(self)
         for m in self.masks:
-            m.scatter(1)                                   # reset_mask (:217-218)
+            if not m.fused:
+                m.scatter(1)                               # reset_mask (:217-218)
 
     def _apply_sparse(self):
         rt = self.rt
@@ -485,6 +534,10 @@ class Plan(object):
         else:
             self._execute()
             self.warm += 1
+        if self.train:
+            for n in self.fetch:
+                if isinstance(n, MeanLoss) and n.lazy:
+                    n._stale = True
 
 
 class Runtime(object):

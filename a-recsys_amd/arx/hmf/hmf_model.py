@@ -186,6 +186,7 @@ class LatentProductModel(object):
             self.set_mask, self.reset_mask = m.get_warp_mask()
         self.batch_loss = batch_loss
         self.loss = G.MeanLoss(rt, batch_loss)                                # :140
+        self.loss.lazy = True
         self.loss_eval = G.MeanLoss(rt, batch_loss_eval) if loss == 'mw' else self.loss  # :144
         self.topk = TopK(rt, logits, min(self.top_N_items, self.logit_size))  # :154
         self.indices = self.topk
@@ -238,8 +239,8 @@ class LatentProductModel(object):
     def step_async(self, session, user_input, item_input, neg_item_input=None, item_sampled=None,
                    item_sampled_id2idx=None, forward_only=False, recommend=False,
                    recommend_new=False, loss=None, run_op=None, run_meta=None):
-        """step() without the device->host read of the result: returns the device
-        tensor holding it (loss scalar / top-k indices)."""
+        """step() without the device->host read of the result: returns the MeanLoss
+        node (call .read() for the device scalar) / the top-k index tensor."""
         if loss is None:
             loss = self.loss_function
         self._feed(user_input, item_input, recommend, loss, item_sampled, item_sampled_id2idx,
@@ -252,10 +253,10 @@ class LatentProductModel(object):
             return [self.batch_loss.value, self.batch_loss.rank_value]
         if forward_only:
             self._plan('eval').run()
-            return self.loss_eval.value
+            return self.loss_eval
         self._plan('train').run()
         self.rt.global_step += 1
-        return self.loss.value
+        return self.loss
 
     def step(self, session, user_input, item_input, neg_item_input=None, item_sampled=None,
              item_sampled_id2idx=None, forward_only=False, recommend=False, recommend_new=False,
@@ -269,7 +270,7 @@ class LatentProductModel(object):
             return out.cpu().numpy()
         if isinstance(out, list):
             return [o.cpu().numpy() for o in out]
-        return float(out.item())
+        return float(out.read().item())
 
     # ---- batch drawing (hmf_model.py:230-260) ----
     def get_batch(self, data, loss='ce', hist=None):

@@ -132,16 +132,19 @@ def dot_score_bwd(U, T, dscore, dU, acc_dU, dT):
 
 
 # ---- a8 -----------------------------------------------------------------------
-def gemm(A, B, C, ws, transA=False, transB=False, alpha=1.0, beta=0.0, col_bias=None):
-    """C[M,N] = alpha * op(A) . op(B) + beta * C + col_bias  (fp32 MFMA)."""
+def gemm(A, B, C, ws, transA=False, transB=False, alpha=1.0, beta=0.0, col_bias=None,
+         a_rowsum=None):
+    """C[M,N] = alpha * op(A) . op(B) + beta * C + col_bias  (fp32 MFMA);
+    a_rowsum[m] = sum_k op(A)[m,k] when given."""
     M, N = int(C.shape[0]), int(C.shape[1])
     K = int(A.shape[0] if transA else A.shape[1])
     kb = int(B.shape[1] if transB else B.shape[0])
     if K != kb:
         raise ValueError("gemm: inner dimensions differ (%d vs %d)" % (K, kb))
     wsp, wsn = ws.get(_lib.lib.arx_gemm_f32_workspace_bytes(M, N, K))
-    call("arx_gemm_f32", int(bool(transA)), int(bool(transB)), M, N, K, float(alpha), _p(A),
-         _ld(A), _p(B), _ld(B), float(beta), _p(C), _ld(C), _p(col_bias), wsp, wsn, _stream())
+    call("arx_gemm_f32_rowsum", int(bool(transA)), int(bool(transB)), M, N, K, float(alpha), _p(A),
+         _ld(A), _p(B), _ld(B), float(beta), _p(C), _ld(C), _p(col_bias), _p(a_rowsum), wsp, wsn,
+         _stream())
     return C
 
 
@@ -169,6 +172,26 @@ def loss_warp(logits, target, mask, batch_loss, dlogits, gscale, row_w=None, mas
     B, V = int(logits.shape[0]), int(logits.shape[1])
     call("arx_loss_warp_fwdbwd", _p(logits), _ld(logits), _p(target), _p(mask),
          _ld(mask) if mask is not None else 0, int(mask_rows), float(gscale), _p(row_w), B, V,
+         _p(batch_loss), _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _stream())
+
+
+POS_MASK_MAX_COLS = 1 << 20
+
+
+def loss_mw_pos(logits, tscore, user_ids, pos_ptr, pos_items, item2slot, batch_loss, dlogits,
+                dtscore, gscale, row_w=None, mask_rows=0):
+    B, S = int(logits.shape[0]), int(logits.shape[1])
+    call("arx_loss_mw_fwdbwd_pos", _p(logits), _ld(logits), _p(tscore), _p(user_ids), _p(pos_ptr),
+         _p(pos_items), _p(item2slot), int(mask_rows), float(gscale), _p(row_w), B, S,
+         _p(batch_loss), _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _p(dtscore),
+         _stream())
+
+
+def loss_warp_pos(logits, target, user_ids, pos_ptr, pos_items, item2slot, batch_loss, dlogits,
+                  gscale, row_w=None, mask_rows=0):
+    B, V = int(logits.shape[0]), int(logits.shape[1])
+    call("arx_loss_warp_fwdbwd_pos", _p(logits), _ld(logits), _p(target), _p(user_ids), _p(pos_ptr),
+         _p(pos_items), _p(item2slot), int(mask_rows), float(gscale), _p(row_w), B, V,
          _p(batch_loss), _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _stream())
 
 

@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(
     int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C, int64_t ldc,
     const float* __restrict__ col_bias, float* __restrict__ partial, int64_t kchunk,
-    int vec_a, int vec_b, int tiles_n) {
+    int vec_a, int vec_b, int tiles_n, float* __restrict__ a_rowsum,
+    float* __restrict__ rowsum_partial) {
   constexpr int WM = 2, WN = 2;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int FM = TM / 32, FN = TN / 32;
@@ -128,6 +129,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  const bool want_rs = (a_rowsum != nullptr) && (tn == 0) && ((int)threadIdx.x < BM);
+  float rs = 0.f;
   float4 ra[NLA], rb[NLB];
   const int64_t nt = (kend > kbeg) ? ceil_div(kend - kbeg, (int64_t)BK) : 0;
   if (nt > 0) {
@@ -146,6 +149,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(
     }
     const float* a_s = sA[cur];
     const float* b_s = sB[cur];
+    if (want_rs) {   // sum_k op(A)[m,k] rides along: the tile is already in LDS
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk) rs += a_s[ImgA::idx(threadIdx.x, kk)];
+    }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float av[FM], bv[FN];
@@ -164,6 +171,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32(
       tile_store<BN, BK, B_KC, NLB>(sB[cur ^ 1], rb);
     }
     __syncthreads();
+  }
+
+  if (want_rs && m0 + threadIdx.x < M) {
+    if (rowsum_partial) rowsum_partial[(int64_t)blockIdx.z * M + m0 + threadIdx.x] = rs;
+    else a_rowsum[m0 + threadIdx.x] = rs;
   }
 
   // epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -193,10 +205,18 @@ __global__ __launch_bounds__(256) void k_gemm_f32(
 // fixed-order reduction of split-K partials + epilogue
 __global__ __launch_bounds__(256) void k_splitk_reduce(
     const float* __restrict__ partial, int splits, int64_t M, int64_t N, float alpha, float beta,
-    float* __restrict__ C, int64_t ldc, const float* __restrict__ col_bias) {
+    float* __restrict__ C, int64_t ldc, const float* __restrict__ col_bias,
+    const float* __restrict__ rowsum_partial, float* __restrict__ a_rowsum) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t total = M * N;
+  if (a_rowsum) {
+    for (int64_t m = i; m < M; m += stride) {
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += rowsum_partial[(int64_t)z * M + m];
+      a_rowsum[m] = s;
+    }
+  }
   for (; i < total; i += stride) {
     float s = 0.f;
     for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * total + i];
@@ -244,7 +264,7 @@ template <int BM, int BN>
 static int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                        const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
                        float* C, int64_t ldc, const float* col_bias, float* partial,
-                       const GemmPlan& p, hipStream_t s) {
+                       const GemmPlan& p, hipStream_t s, float* a_rowsum, float* rowsum_partial) {
   constexpr int BK = 16;
   const int tiles_m = (int)ceil_div(M, BM), tiles_n = (int)ceil_div(N, BN);
   dim3 grid(tiles_m * tiles_n, 1, p.splits);
@@ -254,7 +274,8 @@ static int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, 
 #define ARX_GEMM_LAUNCH(AKC, BKC)                                                         \
   k_gemm_f32<BM, BN, BK, AKC, BKC><<<grid, 256, 0, s>>>(M, N, K, alpha, A, lda, B, ldb,   \
                                                         beta, C, ldc, col_bias, partial,  \
-                                                        p.kchunk, vec_a, vec_b, tiles_n)
+                                                        p.kchunk, vec_a, vec_b, tiles_n,  \
+                                                        a_rowsum, rowsum_partial)
   if (akc && bkc) ARX_GEMM_LAUNCH(true, true);
   else if (akc && !bkc) ARX_GEMM_LAUNCH(true, false);
   else if (!akc && bkc) ARX_GEMM_LAUNCH(false, true);
@@ -274,13 +295,13 @@ size_t arx_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0) return 0;
   GemmPlan p = plan_gemm(M, N, K);
   if (p.splits <= 1) return 0;
-  return (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float);
+  return (size_t)p.splits * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
 }
 
-int arx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
-                 const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
-                 int64_t ldc, const float* col_bias, void* workspace, size_t workspace_bytes,
-                 void* stream) {
+int arx_gemm_f32_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                        const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+                        float* C, int64_t ldc, const float* col_bias, float* a_rowsum,
+                        void* workspace, size_t workspace_bytes, void* stream) {
   ARX_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "arx_gemm_f32: negative dimension");
   if (M == 0 || N == 0) return ARX_OK;
   ARX_CHECK_ARG(A && B && C, "arx_gemm_f32: null pointer");
@@ -289,21 +310,23 @@ int arx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float 
   hipStream_t s = as_stream(stream);
   GemmPlan p = plan_gemm(M, N, K);
   float* partial = nullptr;
+  float* rs_partial = nullptr;
   if (p.splits > 1) {
-    size_t need = (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float);
+    size_t need = arx_gemm_f32_workspace_bytes(M, N, K);
     if (!workspace || workspace_bytes < need) {
       set_error("arx_gemm_f32: workspace too small (%zu < %zu)", workspace_bytes, need);
       return ARX_EWORKSPACE;
     }
     partial = reinterpret_cast<float*>(workspace);
+    if (a_rowsum) rs_partial = partial + (size_t)p.splits * (size_t)M * (size_t)N;
   }
   int rc;
   if (p.big)
     rc = launch_gemm<128, 128>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
-                               col_bias, partial, p, s);
+                               col_bias, partial, p, s, a_rowsum, rs_partial);
   else
     rc = launch_gemm<64, 64>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
-                             col_bias, partial, p, s);
+                             col_bias, partial, p, s, a_rowsum, rs_partial);
   if (rc) return rc;
   if (partial) {
     int64_t total = M * N;
@@ -311,10 +334,18 @@ int arx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float 
     int64_t cap = (int64_t)cu_count() * 8;
     if (g > cap) g = cap;
     k_splitk_reduce<<<(int)g, 256, 0, s>>>(partial, p.splits, M, N, alpha, beta, C, ldc,
-                                           col_bias);
+                                           col_bias, rs_partial, a_rowsum);
     ARX_CHECK_LAUNCH();
   }
   return ARX_OK;
+}
+
+int arx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                 const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                 int64_t ldc, const float* col_bias, void* workspace, size_t workspace_bytes,
+                 void* stream) {
+  return arx_gemm_f32_rowsum(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
+                             col_bias, nullptr, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

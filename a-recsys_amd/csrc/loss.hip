@@ -40,23 +40,50 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 
 // MW and WARP share the body; WARP takes t from the target column and routes
 // dt back into it.
-template <bool WARP>
+// Positive mask built on the fly (embed_attribute.py:721-745 fused into the loss):
+// one bit per logit column in LDS, set for every positive item of the row's user
+// that has a slot in this pool.  Replaces the persistent [mb, W] bool variable and
+// its two scatter_update launches per step.
+struct PosMask {
+  const int32_t* user_ids;   // [mask_rows]
+  const int32_t* pos_ptr;    // CSR over users
+  const int32_t* pos_items;
+  const int32_t* item2slot;  // item -> column (or -1)
+};
+
+__device__ __forceinline__ void build_pos_bits(uint32_t* bits, int64_t W, const PosMask& pm,
+                                               int64_t mrow) {
+  const int nwords = (int)((W + 31) >> 5);
+  for (int i = threadIdx.x; i < nwords; i += 256) bits[i] = 0u;
+  __syncthreads();
+  const int u = pm.user_ids[mrow];
+  const int beg = pm.pos_ptr[u], end = pm.pos_ptr[u + 1];
+  for (int p = beg + threadIdx.x; p < end; p += 256) {
+    const int j = pm.item2slot[pm.pos_items[p]];
+    if (j >= 0 && j < W) atomicOr(&bits[j >> 5], 1u << (j & 31));
+  }
+  __syncthreads();
+}
+
+template <bool WARP, bool POS>
 __global__ __launch_bounds__(256) void k_loss_margin(
     const float* __restrict__ logits, int64_t ldl, const float* __restrict__ tscore,
     const int32_t* __restrict__ target, const uint8_t* __restrict__ mask, int64_t ldm,
     int64_t mask_rows, float gscale, const float* __restrict__ row_w, int64_t W,
     float* __restrict__ batch_loss,
-    float* dlogits, int64_t lddl, float* __restrict__ dtscore) {
+    float* dlogits, int64_t lddl, float* __restrict__ dtscore, PosMask pm) {
   __shared__ float sh[4];
+  extern __shared__ uint32_t bits[];
   const int64_t r = blockIdx.x;
   const float* x = logits + r * ldl;
-  const uint8_t* m = mask ? mask + (r % mask_rows) * ldm : nullptr;
+  const uint8_t* m = (!POS && mask) ? mask + (r % mask_rows) * ldm : nullptr;
+  if (POS) build_pos_bits(bits, W, pm, r % mask_rows);
   const int tcol = WARP ? target[r] : -1;
   const float t = WARP ? x[tcol] : tscore[r];
   float s = 0.f;
   for (int64_t c = threadIdx.x; c < W; c += 256) {
     const float v = x[c] - t + 1.f;
-    const bool keep = m ? (m[c] != 0) : true;
+    const bool keep = POS ? !((bits[c >> 5] >> (c & 31)) & 1u) : (m ? (m[c] != 0) : true);
     s += (keep && v > 0.f) ? v : 0.f;
   }
   s = block_sum(s, sh);
@@ -67,7 +94,7 @@ __global__ __launch_bounds__(256) void k_loss_margin(
   float cnt = 0.f;
   for (int64_t c = threadIdx.x; c < W; c += 256) {
     const float v = x[c] - t + 1.f;
-    const bool keep = m ? (m[c] != 0) : true;
+    const bool keep = POS ? !((bits[c >> 5] >> (c & 31)) & 1u) : (m ? (m[c] != 0) : true);
     const bool act = keep && v > 0.f;
     cnt += act ? 1.f : 0.f;
     dx[c] = act ? g : 0.f;
@@ -195,9 +222,9 @@ int arx_loss_mw_fwdbwd(const float* logits, int64_t ldl, const float* tscore,
   ARX_CHECK_ARG(logits && tscore, "arx_loss_mw_fwdbwd: null pointer");
   ARX_CHECK_ARG(B >= 0 && S >= 0, "arx_loss_mw_fwdbwd: negative size");
   if (B == 0) return ARX_OK;
-  k_loss_margin<false><<<(int)B, 256, 0, as_stream(stream)>>>(
+  k_loss_margin<false, false><<<(int)B, 256, 0, as_stream(stream)>>>(
       logits, ldl, tscore, nullptr, mask, ldm, mask_rows > 0 ? mask_rows : B, gscale, row_w, S,
-      batch_loss, dlogits, lddl, dtscore);
+      batch_loss, dlogits, lddl, dtscore, PosMask{});
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
@@ -210,9 +237,59 @@ int arx_loss_warp_fwdbwd(const float* logits, int64_t ldl, const int32_t* target
   ARX_CHECK_ARG(logits && target, "arx_loss_warp_fwdbwd: null pointer");
   ARX_CHECK_ARG(B >= 0 && V > 0, "arx_loss_warp_fwdbwd: bad size");
   if (B == 0) return ARX_OK;
-  k_loss_margin<true><<<(int)B, 256, 0, as_stream(stream)>>>(
+  k_loss_margin<true, false><<<(int)B, 256, 0, as_stream(stream)>>>(
       logits, ldl, nullptr, target, mask, ldm, mask_rows > 0 ? mask_rows : B, gscale, row_w, V,
-      batch_loss, dlogits, lddl, nullptr);
+      batch_loss, dlogits, lddl, nullptr, PosMask{});
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+#define ARX_POS_LDS_MAX_COLS (1 << 20)   /* 128 KB of mask bits in LDS */
+
+int arx_loss_mw_fwdbwd_pos(const float* logits, int64_t ldl, const float* tscore,
+                           const int32_t* user_ids, const int32_t* pos_ptr,
+                           const int32_t* pos_items, const int32_t* item2slot, int64_t mask_rows,
+                           float gscale, const float* row_w, int64_t B, int64_t S,
+                           float* batch_loss, float* dlogits, int64_t lddl, float* dtscore,
+                           void* stream) {
+  ARX_CHECK_ARG(logits && tscore && user_ids && pos_ptr && pos_items && item2slot,
+                "arx_loss_mw_fwdbwd_pos: null pointer");
+  ARX_CHECK_ARG(B >= 0 && S >= 0, "arx_loss_mw_fwdbwd_pos: negative size");
+  if (S > ARX_POS_LDS_MAX_COLS) {
+    set_error("arx_loss_mw_fwdbwd_pos: %lld columns exceed the LDS mask (use the mask-array form)", (long long)S);
+    return ARX_EUNSUPPORTED;
+  }
+  if (B == 0) return ARX_OK;
+  const size_t lds = (size_t)((S + 31) / 32) * 4;
+  k_loss_margin<false, true><<<(int)B, 256, lds, as_stream(stream)>>>(
+      logits, ldl, tscore, nullptr, nullptr, 0, mask_rows > 0 ? mask_rows : B, gscale, row_w, S,
+      batch_loss, dlogits, lddl, dtscore, PosMask{user_ids, pos_ptr, pos_items, item2slot});
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_loss_warp_fwdbwd_pos(const float* logits, int64_t ldl, const int32_t* target,
+                             const int32_t* user_ids, const int32_t* pos_ptr,
+                             const int32_t* pos_items, const int32_t* item2slot,
+                             int64_t mask_rows, float gscale, const float* row_w, int64_t B,
+                             int64_t V, float* batch_loss, float* dlogits, int64_t lddl,
+                             void* stream) {
+  ARX_CHECK_ARG(logits && target && user_ids && pos_ptr && pos_items && item2slot,
+                "arx_loss_warp_fwdbwd_pos: null pointer");
+  ARX_CHECK_ARG(B >= 0 && V > 0, "arx_loss_warp_fwdbwd_pos: bad size");
+  if (V > ARX_POS_LDS_MAX_COLS) {
+    set_error("arx_loss_warp_fwdbwd_pos: %lld columns exceed the LDS mask (use the mask-array form)", (long long)V);
+    return ARX_EUNSUPPORTED;
+  }
+  if (B == 0) return ARX_OK;
+  const size_t lds = (size_t)((V + 31) / 32) * 4;
+  auto kern = k_loss_margin<true, true>;
+  if (lds > 48 * 1024)
+    ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  kern<<<(int)B, 256, lds, as_stream(stream)>>>(
+      logits, ldl, nullptr, target, nullptr, 0, mask_rows > 0 ? mask_rows : B, gscale, row_w, V,
+      batch_loss, dlogits, lddl, nullptr, PosMask{user_ids, pos_ptr, pos_items, item2slot});
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

@@ -32,7 +32,7 @@
 namespace arx {
 
 constexpr int kPiece = 64;          // positions per piece
-constexpr int kPassBBlocks = 512;   // persistent grid of pass B
+constexpr int kPassBBlocks = 128;   // persistent grid of pass B
 
 __device__ __forceinline__ float4 f4_fma(float c, float4 v, float4 a) {
   return make_float4(fmaf(c, v.x, a.x), fmaf(c, v.y, a.y), fmaf(c, v.z, a.z), fmaf(c, v.w, a.w));
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(1024) void k_small_sort(const int32_t* __restrict__
                                                      uint32_t* __restrict__ sk,
                                                      uint32_t* __restrict__ spos,
                                                      int32_t* __restrict__ list_count) {
-  using Sort = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint32_t>;
+  using Sort = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint32_t, 1, 1, 8>;
   __shared__ typename Sort::storage_type storage;
   if (threadIdx.x == 0) *list_count = 0;
   uint32_t k[IPT], v[IPT];

@@ -108,22 +108,28 @@ __global__ void k_col_sum_partial(const float* __restrict__ x, int64_t ld, int64
     partial[blockIdx.y * cols + c] = part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
 }
 
+// 256 threads = 64 columns x 4 partial-row lanes, fixed-order combine through LDS
 __global__ void k_col_sum_final(const float* __restrict__ partial, int nchunk, int64_t cols,
                                 float* __restrict__ out) {
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float part[4][64];
+  const int cx = threadIdx.x & 63;
+  const int ry = threadIdx.x >> 6;
+  const int64_t c = blockIdx.x * 64 + cx;
   float s = 0.f;
-  for (int k = 0; k < nchunk; ++k) s += partial[(int64_t)k * cols + c];
-  out[c] = s;
+  if (c < cols)
+    for (int k = ry; k < nchunk; k += 4) s += partial[(int64_t)k * cols + c];
+  part[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < cols) out[c] = part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
 }
 
 static inline int col_sum_chunks(int64_t rows, int64_t cols) {
   const int64_t colblocks = ceil_div(cols > 0 ? cols : 1, 64);
-  int64_t want = ceil_div(2048, colblocks);          // ~2048 workgroups in flight
+  int64_t want = ceil_div(1024, colblocks);          // ~1024 workgroups in flight
   int64_t maxc = ceil_div(rows > 0 ? rows : 1, 16);  // >= 16 rows per chunk
   int64_t n = want < maxc ? want : maxc;
   if (n < 1) n = 1;
-  if (n > 256) n = 256;
+  if (n > 64) n = 64;
   return (int)n;
 }
 
@@ -306,7 +312,7 @@ int arx_col_sum(const float* x, int64_t ld, int64_t rows, int64_t cols, float* o
   dim3 grid((unsigned)ceil_div(cols, 64), (unsigned)nchunk);
   k_col_sum_partial<<<grid, 256, 0, as_stream(stream)>>>(x, ld, rows, cols, rpc, partial);
   ARX_CHECK_LAUNCH();
-  k_col_sum_final<<<(int)ceil_div(cols, 256), 256, 0, as_stream(stream)>>>(partial, nchunk, cols, out);
+  k_col_sum_final<<<(int)ceil_div(cols, 64), 256, 0, as_stream(stream)>>>(partial, nchunk, cols, out);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

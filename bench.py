@@ -228,7 +228,7 @@ def main():
     torch.cuda.synchronize()
     wall = time.time() - t0
     ev_ms = e0.elapsed_time(e1)
-    final_loss = float(model.loss.value.item())
+    final_loss = float(model.loss.read().item())
     ms_per_step = 1e3 * wall / args.steps
 
     kr = kernel_rooflines(model, args)

@@ -105,6 +105,13 @@ int arx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float 
                  const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
                  float* C, int64_t ldc, const float* col_bias,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* Same, and additionally a_rowsum[m] = sum_k op(A)[m,k] (nullable).  With
+ * op(A) = dlogits^T this is the item-bias gradient (embed_attribute.py:171 `+ bias`
+ * back-propagated), produced by the dI GEMM for free instead of a separate pass. */
+int arx_gemm_f32_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                        const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+                        float* C, int64_t ldc, const float* col_bias, float* a_rowsum,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- a14: positive mask ---------------------------------------------------
  * embed_attribute.py:651-672 (mask variable + scatter_update set/reset) and
@@ -137,6 +144,22 @@ int arx_loss_warp_fwdbwd(const float* logits, int64_t ldl, const int32_t* target
                          const float* row_w,
                          int64_t B, int64_t V, float* batch_loss, float* dlogits, int64_t lddl,
                          void* stream);
+/* mw / warp with the positive mask built inside the kernel (embed_attribute.py:
+ * 721-745 + 651-672 fused): column j of row r is masked iff some positive item v
+ * of user_ids[r % mask_rows] has item2slot[v] == j.  No [mb, W] mask array is
+ * materialised (the reference's is mb*V bools).  W <= 2^20 columns (LDS bits). */
+int arx_loss_mw_fwdbwd_pos(const float* logits, int64_t ldl, const float* tscore,
+                           const int32_t* user_ids, const int32_t* pos_ptr,
+                           const int32_t* pos_items, const int32_t* item2slot, int64_t mask_rows,
+                           float gscale, const float* row_w, int64_t B, int64_t S,
+                           float* batch_loss, float* dlogits, int64_t lddl, float* dtscore,
+                           void* stream);
+int arx_loss_warp_fwdbwd_pos(const float* logits, int64_t ldl, const int32_t* target,
+                             const int32_t* user_ids, const int32_t* pos_ptr,
+                             const int32_t* pos_items, const int32_t* item2slot,
+                             int64_t mask_rows, float gscale, const float* row_w, int64_t B,
+                             int64_t V, float* batch_loss, float* dlogits, int64_t lddl,
+                             void* stream);
 int arx_loss_ce_fwdbwd(const float* logits, int64_t ldl, const int32_t* target, float gscale,
                        const float* row_w, int64_t B, int64_t V, float* batch_loss,
                        float* dlogits, int64_t lddl, void* stream);

@@ -464,3 +464,57 @@ def test_lstm_fwd_bwd(dev, L, B, din, h):
     db = torch.empty(4 * h, dtype=torch.float32, device=dev)
     ops.col_sum(dz2, db, ws)
     np.testing.assert_allclose(db.cpu().numpy(), r_db, rtol=2e-4, atol=2e-4)
+
+
+def test_loss_pos_variants_equal_mask_array(dev):
+    """mw / warp with the mask derived in-kernel from the positives CSR must be
+    bit-identical to the mask-array form fed by arx_pos_mask_scatter."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(8)
+    Nu, Ni, B = 200, 5000, 48
+    for W, kind in ((1024, 'mw'), (5000, 'warp'), (70000, 'warp')):
+        Ni2 = max(Ni, W)
+        ptr = np.zeros(Nu + 1, dtype=np.int32)
+        cnt = rng.integers(0, 40, size=Nu)
+        ptr[1:] = np.cumsum(cnt)
+        items = rng.integers(0, Ni2, size=int(ptr[-1])).astype(np.int32)
+        i2s = np.full(Ni2, -1, dtype=np.int32)
+        sel = rng.choice(Ni2, size=min(W, Ni2), replace=False)
+        i2s[sel] = rng.permutation(len(sel)).astype(np.int32)
+        users = rng.integers(0, Nu, size=B).astype(np.int32)
+        logits = rng.standard_normal((B, W)).astype(np.float32)
+        t = rng.standard_normal((B,)).astype(np.float32)
+        tgt = rng.integers(0, W, size=B).astype(np.int32)
+        mask = torch.ones((B, W), dtype=torch.uint8, device=dev)
+        d = [_t(dev, x) for x in (users, ptr, items, i2s)]
+        ops.pos_mask_scatter(d[0], d[1], d[2], d[3], mask, 0)
+        L = _t(dev, logits)
+        bl_a = torch.empty(B, dtype=torch.float32, device=dev); bl_b = torch.empty_like(bl_a)
+        dl_a = torch.empty_like(L); dl_b = torch.empty_like(L)
+        dt_a = torch.empty_like(bl_a); dt_b = torch.empty_like(bl_a)
+        if kind == 'mw':
+            ops.loss_mw(L, _t(dev, t), mask, bl_a, dl_a, dt_a, 0.1)
+            ops.loss_mw_pos(L, _t(dev, t), d[0], d[1], d[2], d[3], bl_b, dl_b, dt_b, 0.1)
+            assert torch.equal(dt_a, dt_b)
+        else:
+            ops.loss_warp(L, _t(dev, tgt), mask, bl_a, dl_a, 0.1)
+            ops.loss_warp_pos(L, _t(dev, tgt), d[0], d[1], d[2], d[3], bl_b, dl_b, 0.1)
+        assert torch.equal(bl_a, bl_b) and torch.equal(dl_a, dl_b)
+        assert int((mask == 0).sum().item()) > 0
+
+
+@pytest.mark.parametrize("tA,M,N,K", [(True, 1024, 128, 4096), (True, 300, 32, 64),
+                                      (False, 200, 64, 1000)])
+def test_gemm_rowsum(dev, tA, M, N, K):
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(M + K)
+    A = rng.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
+    Bm = rng.standard_normal((K, N)).astype(np.float32)
+    opA = A.T if tA else A
+    C = torch.empty((M, N), dtype=torch.float32, device=dev)
+    rs = torch.full((M,), 7.0, dtype=torch.float32, device=dev)
+    ops.gemm(_t(dev, A), _t(dev, Bm), C, ops.Workspace(dev), transA=tA, a_rowsum=rs)
+    np.testing.assert_allclose(rs.cpu().numpy(), opA.astype(np.float64).sum(1), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(C.cpu().numpy(), opA.astype(np.float64) @ Bm, rtol=1e-4, atol=1e-3)
