@@ -45,6 +45,10 @@ PROTOTYPES = {
                             f32p, vp, sz, vp]),
     "arx_gemm_f32_rowsum": (cint, [cint, cint, i64, i64, i64, f32, f32p, i64, f32p, i64, f32, f32p,
                                    i64, f32p, f32p, vp, sz, vp]),
+    "arx_gemm_f32_steps_tn": (cint, [i64, i64, i64, i64, f32p, i64, f32p, i64, f32p, f32p, f32, f32p,
+                                     i64, f32p, vp]),
+    "arx_dot_scaled": (cint, [f32p, f32p, i64, f32, f32p, vp]),
+    "arx_inv_len_scale": (cint, [i32p, i32p, i64, f32, f32p, vp]),
     "arx_pos_mask_scatter": (cint, [i32p, i64, i32p, i32p, i32p, u8p, i64, cint, vp]),
     "arx_slot_map_set": (cint, [i32p, i32p, i64, cint, vp]),
     "arx_loss_mw_fwdbwd": (cint, [f32p, i64, f32p, u8p, i64, i64, f32, f32p, i64, i64, f32p, f32p,

@@ -1,0 +1,480 @@
+"""SeqModel -- the reference's LSTM sequence recommender (lstm/seqModel.py:24-604) on MI355X.
+
+Same constructor / step / get_batch signatures.  What differs from the TF graph:
+  * every time step is batched: ONE lookup launch gathers all L*mb input items,
+    ONE persistent kernel runs the L LSTM steps, ONE GEMM scores all L*mb outputs
+    against the (shared) pool, ONE fused kernel evaluates the loss of every step --
+    the reference unrolls L copies of each op (seqModel.py:477-493);
+  * tf.clip_by_global_norm (seqModel.py:180) is reproduced including TF-1.0's
+    aggregation rule (a matmul'd table contributes one dense gradient PER unrolled
+    step, IndexedSlices contribute their un-merged values) -- see _clip_hook;
+  * evaluating an 'mw' model (`forward_only`) uses the 'warp' loss over the full
+    vocabulary, as hmf_model.py:130 does: the reference's own losses_full graph
+    for 'mw' (seqModel.py:510) mixes a [mb, n_sampled] mask with [mb, V] logits
+    and cannot be built unless n_sampled == V.
+Not implemented (raise): num_layers > 1, dropout < 1, use_concat=True,
+withAdagrad=False, beam search (dead code in the reference).
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import torch
+
+from .. import graph as G
+from .. import ops
+from ..attributes.embed_attribute import ZeroEmbed
+from ..hmf.hmf_model import _Op, _Var
+from ..utils.checkpoint import Saver
+
+
+class IdsView(G.Node):
+    """First n entries of an int placeholder (bucket shorter than the longest)."""
+
+    def __init__(self, rt, parent, n, name):
+        super().__init__(rt, (n,), (parent,))
+        self.name = name
+        self.value = parent.value[:n]
+
+    def forward(self, train):
+        pass
+
+
+class SeqInputMean(G.Node):
+    """seqModel.py:148-156: x_t = reduce_mean([user_embed, reduce_mean(item_embed_t)]).
+    `item_half` already holds 0.5*mean_f(item) for all L*mb rows; the user half is
+    broadcast-added in place."""
+
+    requires_grad = True
+
+    def __init__(self, rt, item_half, user, L, B):
+        super().__init__(rt, item_half.shape, (item_half, user))
+        self.L, self.B = L, B
+        self._tmp = None
+
+    def forward(self, train):
+        item_half, user = self.inputs
+        self.value = item_half.value
+        if not isinstance(user, ZeroEmbed):
+            ops.add_rows_bcast(0.5, user.value, 1.0, self.value)
+
+    def alloc_grad(self):
+        self.grad = self.inputs[0].alloc_grad()
+        return self.grad
+
+    def grad_beta(self):
+        self._grad_written = True
+        return self.inputs[0].grad_beta()
+
+    def backward(self):
+        item_half, user = self.inputs
+        if not user.requires_grad:
+            return
+        d = self.shape[1]
+        if self._tmp is None:
+            self._tmp = torch.empty((self.B, d), dtype=torch.float32, device=self.rt.device)
+        ops.col_sum(self.grad.view(self.L, self.B * d), self._tmp.view(-1), self.rt.ws)
+        ops.add_rows_bcast(0.5, self._tmp, user.grad_beta(), user.alloc_grad())
+
+
+class LSTM(G.Node):
+    """seqModel.py:99-103,477: LSTMCell(size) under static_rnn from the zero state."""
+
+    requires_grad = True
+
+    def __init__(self, rt, x, W, b, L, B):
+        h = W.w.shape[1] // 4
+        super().__init__(rt, (L * B, h), (x,))
+        self.W, self.b, self.L, self.B, self.h = W, b, L, B, h
+        self.din = x.shape[1]
+        dev = rt.device
+        self.cs = torch.empty((L * B, h), dtype=torch.float32, device=dev)
+        self.gates = torch.empty((L * B, 4 * h), dtype=torch.float32, device=dev)
+        self.dz = None
+
+    def forward(self, train):
+        x = self.inputs[0]
+        ops.lstm_fwd(x.value, self.W.w, self.b.w, self.L, self.B, self.din, self.h, 1.0,
+                     self.alloc_value(), self.cs, self.gates)
+
+    def backward(self):
+        x = self.inputs[0]
+        rt, L, B, din, h = self.rt, self.L, self.B, self.din, self.h
+        if self.dz is None:
+            self.dz = torch.empty((L * B, 4 * h), dtype=torch.float32, device=rt.device)
+        dz = self.dz
+        ops.lstm_bwd(self.W.w, self.value, self.cs, self.gates, self.grad, L, B, din, h, dz)
+        if x.requires_grad:
+            ops.gemm(dz, self.W.w[:din], x.alloc_grad(), rt.ws, transB=True, beta=x.grad_beta())
+        ops.gemm(x.value, dz, self.W.grad[:din], rt.ws, transA=True)
+        if L > 1:
+            ops.gemm(self.value[:(L - 1) * B], dz[B:], self.W.grad[din:], rt.ws, transA=True)
+        else:
+            ops.fill_f32(self.W.grad[din:], 0.0)
+        ops.col_sum(dz, self.b.grad, rt.ws)
+        self.W.touched = self.b.touched = True
+
+
+class SeqPrediction(G.Prediction):
+    """get_prediction applied to every LSTM output (seqModel.py:480-493).  Backward
+    keeps the per-step pool gradients (the dense gradient each unrolled matmul
+    produces) because clip_by_global_norm needs their separate norms."""
+
+    def __init__(self, rt, latent, pool_embed, L, B):
+        super().__init__(rt, latent, pool_embed)
+        self.L, self.B = L, B
+        self.C_steps = None
+
+    def backward(self):
+        latent, pool = self.inputs
+        dl = self.grad
+        S, d = pool.shape
+        if latent.requires_grad:
+            ops.gemm(dl, pool.value, latent.alloc_grad(), self.rt.ws, beta=latent.grad_beta())
+        if pool.train_tables:
+            if self.C_steps is None:
+                dev = self.rt.device
+                self.C_steps = torch.empty((self.L, S, d), dtype=torch.float32, device=dev)
+                self.rs_steps = torch.empty((self.L, S), dtype=torch.float32, device=dev)
+            gp = pool.alloc_grad()
+            ops.gemm_steps_tn(dl, latent.value, self.C_steps, self.rs_steps, self.L, self.B,
+                              C_sum=gp, beta=pool.grad_beta(), rowsum_sum=pool.bias_grad)
+            pool.bias_grad_used = True
+
+
+class SeqWeights(G.Node):
+    """seqModel.py:561-567: w_t / (sum_t w_t + 1e-12) per example (time-major rows)."""
+
+    def __init__(self, rt, w, L, B):
+        super().__init__(rt, (L * B,), (w,))
+        self.L, self.B = L, B
+
+    def forward(self, train):
+        ops.seq_weights(self.inputs[0].value, self.L, self.B, self.alloc_value())
+
+
+class SeqLoss(G.Node):
+    """seqModel.py:571-604 sequence_loss(average_across_timesteps, not across batch)."""
+
+    requires_grad = True
+
+    def __init__(self, rt, batch_loss, wn):
+        super().__init__(rt, (1,), (batch_loss, wn))
+        batch_loss.gscale = 1.0
+        batch_loss.row_w = wn
+        batch_loss.extra_inputs = (wn,)
+
+    def forward(self, train):
+        bl, wn = self.inputs
+        ops.dot_scaled(bl.value, wn.value, 1.0, self.alloc_value())
+
+    def read(self):
+        return self.value
+
+
+class SeqModel(object):
+    def __init__(self, buckets, size, num_layers, max_gradient_norm, batch_size, learning_rate,
+                 learning_rate_decay_factor, embeddingAttribute, withAdagrad=True, num_samples=512,
+                 forward_only=False, dropoutRate=1.0, START_ID=0, loss="ce", devices="",
+                 run_options=None, run_metadata=None, use_concat=True, output_feat=1,
+                 no_input_item_feature=False, no_user_id=True, topk_n=30, dtype='float32',
+                 params=None):
+        if num_layers != 1:
+            raise NotImplementedError("MultiRNNCell with num_layers != 1")
+        if float(dropoutRate) != 1.0:
+            raise NotImplementedError("DropoutWrapper with keep_prob < 1 (parity runs use 1.0)")
+        if use_concat:
+            raise NotImplementedError("use_concat=True (w_input_user / w_input_item projection)")
+        if not withAdagrad:
+            raise NotImplementedError("GradientDescentOptimizer")
+        if loss not in ('ce', 'warp', 'mw'):
+            raise NotImplementedError("loss %r" % loss)
+        self.embeddingAttribute = m = embeddingAttribute
+        self.att_emb = m
+        self.rt = rt = m.rt
+        self.buckets = list(buckets)
+        self.START_ID = START_ID
+        self.PAD_ID = START_ID
+        self.USER_PAD_ID = 0
+        self.batch_size = B = batch_size
+        self.loss = loss
+        self.devices = devices
+        self.output_feat = output_feat
+        self.no_input_item_feature = no_input_item_feature
+        self.no_user_id = no_user_id
+        self.topk_n = topk_n
+        self.size = size
+        self.max_gradient_norm = float(max_gradient_norm)
+        if B % 16 != 0:
+            raise NotImplementedError("batch_size must be a multiple of 16 (per-step GEMM tiles)")
+        Lmax = self.buckets[-1]
+        if m.input_steps < Lmax:
+            raise ValueError("EmbeddingAttribute was built with input_steps < longest bucket")
+
+        rt.set_learning_rate(learning_rate)
+        self._lr_decay = learning_rate_decay_factor
+        self.learning_rate = _Var(lambda: rt.lr_host)
+        self.learning_rate_decay_op = _Op(lambda: rt.set_learning_rate(rt.lr_host * self._lr_decay))
+        self.global_step = _Var(lambda: rt.global_step)
+        self.dropoutRate = _Var(lambda: 1.0)
+
+        # feeds (seqModel.py:118-124): time-major [L*mb]
+        self.target_ids_all = G.IdsInput(rt, Lmax * B, 'target_id_all')
+        self.targets_all = G.IdsInput(rt, Lmax * B, 'target_all')
+        self.weights_all = G.FloatInput(rt, (Lmax * B,), 'target_weight_all')
+
+        # LSTM weights: TF names of static_rnn(MultiRNNCell([LSTMCell])) variables
+        params = params or {}
+        din = size
+        wname, bname = 'rnn/multi_rnn_cell/cell_0/lstm_cell/weights', 'rnn/multi_rnn_cell/cell_0/lstm_cell/biases'
+        if 'lstm_w' in params:
+            W = rt.upload(np.asarray(params['lstm_w'], dtype=np.float32), torch.float32)
+        else:
+            W = m._new_var(wname, (din + size, 4 * size), params)
+        if 'lstm_b' in params:
+            b = rt.upload(np.asarray(params['lstm_b'], dtype=np.float32), torch.float32)
+        else:
+            b = torch.zeros(4 * size, dtype=torch.float32, device=rt.device)    # zero-init biases
+        self.W = G.DenseParam(wname, W.contiguous())
+        self.b = G.DenseParam(bname, b.contiguous())
+        rt.dense[wname] = self.W
+        rt.dense[bname] = self.b
+
+        rt.clip_coef_dev = torch.ones(1, dtype=torch.float32, device=rt.device)
+        self._sq = torch.zeros(1, dtype=torch.float32, device=rt.device)
+        self._gnorm = torch.zeros(1, dtype=torch.float32, device=rt.device)
+        rt.pre_apply_hooks.append(self._clip_hook)
+
+        self.user_embed, _ = m.get_batch_user(1.0, concat=False, no_id=no_user_id)   # :148
+        self._bk = {}
+        self._pool_scale = {}
+        self.saver = Saver(self)
+        self.gradient_norms = _Var(lambda: float(self._gnorm.item()))
+
+    # ------------------------------------------------------------- graph per bucket
+    def _bucket(self, bucket_id):
+        if bucket_id in self._bk:
+            return self._bk[bucket_id]
+        m, rt, B = self.att_emb, self.rt, self.batch_size
+        L = self.buckets[bucket_id]
+        n = L * B
+        Lmax = self.buckets[-1]
+
+        def view(node, name):
+            return node if L == Lmax else IdsView(rt, node, n, name)
+
+        ids_in = view(m.input_all, 'item_input_%d' % L)
+        feats = m._select_feats(m.item_feats, m.item_attributes, no_attribute=self.no_input_item_feature)
+        item_half = G.EntityEmbed(rt, ids_in, feats, with_bias=False, out_scale=0.5)   # :150-154
+        x = SeqInputMean(rt, item_half, self.user_embed, L, B)                           # :155
+        hs = LSTM(rt, x, self.W, self.b, L, B)                                           # :477
+        wn = SeqWeights(rt, self.weights_all if L == Lmax else _FloatView(rt, self.weights_all, n), L, B)
+        tid = view(self.target_ids_all, 'target_id_%d' % L)
+        tgt = view(self.targets_all, 'target_%d' % L)
+        bk = {'L': L}
+        if self.loss == 'mw':
+            logits = SeqPrediction(rt, hs, m._pool_embed('sampled', self.output_feat), L, B)  # :492
+            tscore = m.get_target_score(hs, tid)                                            # :493
+            bl = m.compute_loss(logits, tscore, 'mw')
+        else:
+            logits = SeqPrediction(rt, hs, m._pool_embed('full', self.output_feat), L, B)   # :484
+            bl = m.compute_loss(logits, tgt, self.loss)
+        bk['train'] = SeqLoss(rt, bl, wn)
+        bk['train_logits'] = logits
+        # losses_full (:510): full-vocabulary loss for evaluation
+        if self.loss == 'mw':
+            wn2 = SeqWeights(rt, wn.inputs[0], L, B)
+            full = G.Prediction(rt, hs, m._pool_embed('full', self.output_feat))
+            bl_full = m.compute_loss(full, tgt, 'warp')
+            bk['eval'] = SeqLoss(rt, bl_full, wn2)
+        else:
+            bk['eval'] = bk['train']
+        bk['plans'] = {}
+        self._bk[bucket_id] = bk
+        return bk
+
+    def _plan(self, bucket_id, key):
+        bk = self._bucket(bucket_id)
+        if key not in bk['plans']:
+            m = self.att_emb
+            if key == 'train':
+                masks = [m.mask[self.loss]] if self.loss in m.mask else []
+                bk['plans'][key] = G.Plan(self.rt, [bk['train']], True, masks)
+            else:
+                l = 'warp' if self.loss == 'mw' else self.loss
+                masks = [m.mask[l]] if l in m.mask else []
+                bk['plans'][key] = G.Plan(self.rt, [bk['eval']], False, masks)
+        return bk['plans'][key]
+
+    # ------------------------------------------------ clip_by_global_norm (:180)
+    def _row_scale(self, node, for_bias=False, subset=None, tag='all'):
+        """Per-row weight of ||grad row||^2 in the IndexedSlices norm of one lookup:
+        sum over (a subset of) its features of coef^2 (one-hot) or coef^2/len (bag)."""
+        feats = node.feats if subset is None else subset
+        key = (id(node), for_bias, tag)
+        cache = self.__dict__.setdefault('_rs_cache', {})
+        F = len(node.feats)
+        coef = (1.0 / F) if for_bias else node.out_scale / F
+        static = all(f.kind == 'cat' for f in feats)
+        if key in cache and static:
+            return cache[key]
+        n = node.shape[0]
+        dev = self.rt.device
+        if key not in cache:
+            cache[key] = torch.empty(n, dtype=torch.float32, device=dev)
+            cache[(key, 'tmp')] = torch.empty(n, dtype=torch.float32, device=dev)
+        out, tmp = cache[key], cache[(key, 'tmp')]
+        ncat = sum(1 for f in feats if f.kind == 'cat')
+        ops.fill_f32(out, ncat * coef * coef)
+        for f in feats:
+            if f.kind == 'mulhot':
+                ops.inv_len_scale(f.maps[2], node.inputs[0].value, coef * coef, tmp)
+                ops.axpby(1.0, tmp, 1.0, out)
+        return out
+
+    def _tiled(self, rs, L, tag):
+        S = rs.shape[0]
+        if S % 4 != 0:
+            raise NotImplementedError("pool size must be a multiple of 4")
+        cache = self._rs_cache
+        key = ('tile', tag)
+        if key not in cache:
+            cache[key] = torch.empty(L * S, dtype=torch.float32, device=self.rt.device)
+        ops.add_rows_bcast(1.0, rs.view(1, S), 0.0, cache[key].view(L, S))
+        return cache[key]
+
+    def _clip_hook(self, plan):
+        """tf.clip_by_global_norm over tf.gradients' aggregated list (seqModel.py:179-180).
+        TF-1.0 aggregates per variable: all-dense contributions are add_n'ed (norm of the
+        sum); if ANY contribution is an IndexedSlices (an embedding_lookup of the same
+        variable) everything is concatenated as IndexedSlices and the norm runs over the
+        un-merged values -- i.e. each unrolled step's dense matmul gradient separately."""
+        rt = self.rt
+        sq = self._sq
+        ops.fill_f32(sq, 0.0)
+        for p in rt.dense.values():
+            if getattr(p, 'touched', False):
+                ops.sq_norm_accum(p.grad, sq)
+        seq_pools = {}
+        for n in plan.order:
+            if isinstance(n, SeqPrediction) and n.inputs[1].train_tables and n._grad_written:
+                seq_pools[id(n.inputs[1])] = n
+        sites_of = {id(t): sites for t, sites, _, _ in plan.tables}
+        for n in plan.order:
+            if not (isinstance(n, G.EntityEmbed) and n.train_tables and n._grad_written):
+                continue
+            if id(n) in seq_pools:
+                sp = seq_pools[id(n)]
+                L, S, d = sp.C_steps.shape
+                for for_bias in (False, True):
+                    per_step, merged = [], []
+                    for f in n.feats:
+                        others = [s for s in sites_of.get(id(f.table), []) if s.node is not n]
+                        if for_bias:
+                            others = [s for s in others if s.node.with_bias]
+                        (per_step if others else merged).append(f)
+                    steps_buf = sp.rs_steps if for_bias else sp.C_steps
+                    sum_buf = n.bias_grad if for_bias else n.grad
+                    dd = 1 if for_bias else d
+                    if per_step:
+                        rs = self._row_scale(n, True, per_step, 'ps%d' % for_bias)
+                        ops.sq_norm_accum(steps_buf, sq, d=dd,
+                                          row_scale=self._tiled(rs, L, (id(n), for_bias)))
+                    if merged:
+                        rs = self._row_scale(n, True, merged, 'mg%d' % for_bias)
+                        ops.sq_norm_accum(sum_buf, sq, d=dd, row_scale=rs, n=S * dd)
+            else:
+                ops.sq_norm_accum(n.grad, sq, d=n.shape[1], row_scale=self._row_scale(n), n=n.grad.numel())
+                if n.bias_grad_used:
+                    ops.sq_norm_accum(n.bias_grad, sq, d=1, row_scale=self._row_scale(n, True))
+        ops.clip_coef(sq, self.max_gradient_norm, rt.clip_coef_dev, self._gnorm)
+
+    # ---------------------------------------------------------------------- step
+    def _feed(self, user_input, item_inputs, targets, target_weights, L, item_sampled,
+              item_sampled_id2idx, forward_only):
+        m, B = self.att_emb, self.batch_size
+
+        def flat_i(x):
+            if isinstance(x, torch.Tensor):
+                return x.reshape(-1)
+            return np.asarray(x, dtype=np.int32)[:L].reshape(-1)
+
+        n = L * B
+        t = flat_i(targets)
+        self.target_ids_all.value[:n].copy_(t if isinstance(t, torch.Tensor) else
+                                            torch.from_numpy(np.ascontiguousarray(t)), non_blocking=True)
+        if self.loss != 'mw' or forward_only:
+            m.target_mapping_device(self.target_ids_all.value[:n], self.targets_all.value[:n])
+        w = target_weights
+        if not isinstance(w, torch.Tensor):
+            w = torch.from_numpy(np.ascontiguousarray(np.asarray(w, dtype=np.float32)[:L].reshape(-1)))
+        self.weights_all.value[:n].copy_(w.reshape(-1), non_blocking=True)
+        it = flat_i(item_inputs)
+        m.input_all.value[:n].copy_(it if isinstance(it, torch.Tensor) else
+                                    torch.from_numpy(np.ascontiguousarray(it)), non_blocking=True)
+        update_sampled, _, _ = m.add_input({}, user_input, None, item_sampled=item_sampled,
+                                           item_sampled_id2idx=item_sampled_id2idx,
+                                           forward_only=forward_only, recommend=False, loss=self.loss)
+        for op in update_sampled:
+            op()
+
+    def step_async(self, session, user_input, item_inputs, targets, target_weights, bucket_id,
+                   item_sampled=None, item_sampled_id2idx=None, forward_only=False, recommend=False):
+        L = self.buckets[bucket_id]
+        self._feed(user_input, item_inputs, targets, target_weights, L, item_sampled,
+                   item_sampled_id2idx, forward_only)
+        if forward_only:
+            self._plan(bucket_id, 'eval').run()
+            return self._bucket(bucket_id)['eval']
+        self._plan(bucket_id, 'train').run()
+        self.rt.global_step += 1
+        return self._bucket(bucket_id)['train']
+
+    def step(self, session, user_input, item_inputs, targets, target_weights, bucket_id,
+             item_sampled=None, item_sampled_id2idx=None, forward_only=False, recommend=False):
+        """seqModel.py:289-324 -> summed sequence loss of the batch (float)."""
+        node = self.step_async(session, user_input, item_inputs, targets, target_weights, bucket_id,
+                               item_sampled, item_sampled_id2idx, forward_only, recommend)
+        return float(node.read().item())
+
+    def step_recommend(self, session, user_input, item_inputs, positions, bucket_id):
+        raise NotImplementedError("step_recommend: planned with the streaming full-vocabulary "
+                                  "scorer + top-k (SURVEY 8f #3)")
+
+    # ---------------------------------------------------- get_batch (:356-404)
+    def get_batch(self, data_set, bucket_id, start_id=None):
+        length = self.buckets[bucket_id]
+        users, item_inputs, item_outputs, weights = [], [], [], []
+        for i in range(self.batch_size):
+            if start_id is None:
+                user, item_seq = random.choice(data_set[bucket_id])
+            elif start_id + i < len(data_set[bucket_id]):
+                user, item_seq = data_set[bucket_id][start_id + i]
+            else:
+                user, item_seq = self.USER_PAD_ID, []
+            pad_seq = [self.PAD_ID] * (length - len(item_seq))
+            if len(item_seq) == 0:
+                item_input_seq = [self.START_ID] + pad_seq[1:]
+            else:
+                item_input_seq = [self.START_ID] + item_seq[:-1] + pad_seq
+            users.append(user)
+            item_inputs.append(item_input_seq)
+            item_outputs.append(item_seq + pad_seq)
+            weights.append([1.0] * len(item_seq) + [0.0] * len(pad_seq))
+
+        def batch_major(l):
+            return [[l[j][i] for j in range(self.batch_size)] for i in range(len(l[0]))]
+
+        finished = (start_id is not None and start_id + self.batch_size >= len(data_set[bucket_id]))
+        return (users, batch_major(item_inputs), batch_major(item_outputs), batch_major(weights),
+                finished)
+
+
+class _FloatView(G.Node):
+    def __init__(self, rt, parent, n):
+        super().__init__(rt, (n,), (parent,))
+        self.value = parent.value[:n]
+
+    def forward(self, train):
+        pass

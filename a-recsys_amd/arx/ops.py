@@ -148,6 +148,23 @@ def gemm(A, B, C, ws, transA=False, transB=False, alpha=1.0, beta=0.0, col_bias=
     return C
 
 
+def gemm_steps_tn(A, B, C_steps, rowsum_steps, steps, Kb, C_sum=None, beta=0.0, rowsum_sum=None):
+    """C_steps[t] = A_t^T . B_t for every time step t (rows t*Kb..), plus the sums."""
+    M, N = int(C_steps.shape[1]), int(C_steps.shape[2])
+    call("arx_gemm_f32_steps_tn", int(steps), M, N, int(Kb), _p(A), _ld(A), _p(B), _ld(B),
+         _p(C_steps), _p(rowsum_steps), float(beta), _p(C_sum),
+         _ld(C_sum) if C_sum is not None else 0, _p(rowsum_sum), _stream())
+
+
+def dot_scaled(x, y, scale, out, n=None):
+    call("arx_dot_scaled", _p(x), _p(y), int(x.numel() if n is None else n), float(scale), _p(out),
+         _stream())
+
+
+def inv_len_scale(lens, ids, c, out):
+    call("arx_inv_len_scale", _p(lens), _p(ids), int(out.numel()), float(c), _p(out), _stream())
+
+
 # ---- a14 ------------------------------------------------------------------------
 def pos_mask_scatter(user_ids, pos_ptr, pos_items, item2slot, mask, value):
     call("arx_pos_mask_scatter", _p(user_ids), int(user_ids.shape[0]), _p(pos_ptr), _p(pos_items),

@@ -340,6 +340,37 @@ int arx_gemm_f32_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K,
   return ARX_OK;
 }
 
+int arx_gemm_f32_steps_tn(int64_t steps, int64_t M, int64_t N, int64_t Kb, const float* A,
+                          int64_t lda, const float* B, int64_t ldb, float* C_steps,
+                          float* rowsum_steps, float beta, float* C_sum, int64_t ldc,
+                          float* rowsum_sum, void* stream) {
+  ARX_CHECK_ARG(steps > 0 && M > 0 && N > 0 && Kb > 0, "arx_gemm_f32_steps_tn: bad size");
+  ARX_CHECK_ARG(A && B && C_steps, "arx_gemm_f32_steps_tn: null pointer");
+  ARX_CHECK_ARG(Kb % 16 == 0, "arx_gemm_f32_steps_tn: rows per step must be a multiple of 16");
+  ARX_CHECK_ARG(lda >= M && ldb >= N, "arx_gemm_f32_steps_tn: leading dimension too small");
+  ARX_CHECK_ARG(!(rowsum_sum && !rowsum_steps), "arx_gemm_f32_steps_tn: rowsum_sum needs rowsum_steps");
+  hipStream_t s = as_stream(stream);
+  GemmPlan p;
+  p.big = false;
+  p.splits = (int)steps;
+  p.kchunk = Kb;
+  int rc = launch_gemm<64, 64>(1, 0, M, N, steps * Kb, 1.f, A, lda, B, ldb, 0.f, C_steps, N,
+                               nullptr, C_steps, p, s, rowsum_steps ? rowsum_steps : nullptr,
+                               rowsum_steps);
+  if (rc) return rc;
+  if (C_sum) {
+    ARX_CHECK_ARG(ldc >= N, "arx_gemm_f32_steps_tn: ldc too small");
+    int64_t total = M * N;
+    int64_t g = ceil_div(total, 256);
+    int64_t cap = (int64_t)cu_count() * 8;
+    if (g > cap) g = cap;
+    k_splitk_reduce<<<(int)g, 256, 0, s>>>(C_steps, (int)steps, M, N, 1.f, beta, C_sum, ldc,
+                                           nullptr, rowsum_steps, rowsum_sum);
+    ARX_CHECK_LAUNCH();
+  }
+  return ARX_OK;
+}
+
 int arx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                  const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
                  int64_t ldc, const float* col_bias, void* workspace, size_t workspace_bytes,

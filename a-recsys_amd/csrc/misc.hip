@@ -74,6 +74,30 @@ __global__ void k_seq_weights(const float* __restrict__ w, int64_t L, int64_t B,
   for (int64_t t = 0; t < L; ++t) out[t * B + b] = w[t * B + b] / tot;
 }
 
+// single workgroup, fixed order: *out = scale * sum_i x[i]*y[i]
+__global__ __launch_bounds__(1024) void k_dot_scaled(const float* __restrict__ x,
+                                                      const float* __restrict__ y, int64_t n,
+                                                      float scale, float* __restrict__ out) {
+  __shared__ float part[16];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += x[i] * y[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 16; ++i) t += part[i];
+    *out = t * scale;
+  }
+}
+
+__global__ void k_inv_len_scale(const int32_t* __restrict__ lens, const int32_t* __restrict__ ids,
+                                int64_t n, float c, float* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = c / (float)lens[ids ? ids[i] : (int32_t)i];
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -86,6 +110,23 @@ int arx_topk(const float* logits, int64_t ld, int64_t B, int64_t V, int k, float
   ARX_CHECK_ARG(k > 0 && k <= V, "arx_topk: need 0 < k <= V");
   if (B <= 0) return ARX_OK;
   k_topk<<<(int)B, 256, 0, as_stream(stream)>>>(logits, ld, V, k, values, indices);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_dot_scaled(const float* x, const float* y, int64_t n, float scale, float* out,
+                   void* stream) {
+  ARX_CHECK_ARG(x && y && out, "arx_dot_scaled: null pointer");
+  k_dot_scaled<<<1, 1024, 0, as_stream(stream)>>>(x, y, n, scale, out);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_inv_len_scale(const int32_t* lens, const int32_t* ids, int64_t n, float c, float* out,
+                      void* stream) {
+  ARX_CHECK_ARG(lens && out, "arx_inv_len_scale: null pointer");
+  if (n <= 0) return ARX_OK;
+  k_inv_len_scale<<<(int)ceil_div(n, 256), 256, 0, as_stream(stream)>>>(lens, ids, n, c, out);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

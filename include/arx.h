@@ -113,6 +113,17 @@ int arx_gemm_f32_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K,
                         float* C, int64_t ldc, const float* col_bias, float* a_rowsum,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* Per-time-step TN products for the LSTM path (seqModel.py:480-493 scores every
+ * step against the same pool): for t in [0,steps): C_steps[t] = A_t^T . B_t with
+ * A_t = A[t*Kb:(t+1)*Kb, 0:M], B_t = B[t*Kb:(t+1)*Kb, 0:N]; rowsum_steps[t][m] =
+ * sum_k A_t[k,m].  Optionally C_sum = beta*C_sum + sum_t C_steps[t] (fixed order) and
+ * rowsum_sum likewise.  The per-step products are what tf.clip_by_global_norm
+ * sees for a matmul'd table (one dense gradient per unrolled step). */
+int arx_gemm_f32_steps_tn(int64_t steps, int64_t M, int64_t N, int64_t Kb, const float* A,
+                          int64_t lda, const float* B, int64_t ldb, float* C_steps,
+                          float* rowsum_steps, float beta, float* C_sum, int64_t ldc,
+                          float* rowsum_sum, void* stream);
+
 /* ---- a14: positive mask ---------------------------------------------------
  * embed_attribute.py:651-672 (mask variable + scatter_update set/reset) and
  * :721-745 (host index list).  For each batch row r and each positive item v
@@ -249,6 +260,14 @@ int arx_lstm_bwd(const float* W, const float* hs, const float* cs, const float* 
                  const float* dhs, int64_t L, int64_t B, int din, int h, float* dz,
                  void* stream);
 
+/* *out = scale * sum_i x[i]*y[i] (single workgroup, fixed order): the weighted
+ * sum of sequence_loss (seqModel.py:561-563,596). */
+int arx_dot_scaled(const float* x, const float* y, int64_t n, float scale, float* out,
+                   void* stream);
+/* out[i] = c / lens[ids ? ids[i] : i] : per-bag factor of tf.div's gradient, used to
+ * weight squared norms of multi-hot lookup gradients (seqModel.py:180). */
+int arx_inv_len_scale(const int32_t* lens, const int32_t* ids, int64_t n, float c, float* out,
+                      void* stream);
 /* lstm/seqModel.py:551-567 sequence_loss_by_example: per-row loss weights
  * out[t,b] = w[t,b] / (sum_t w[t,b] + 1e-12)  (w time-major [L,B]). */
 int arx_seq_weights(const float* w, int64_t L, int64_t B, float* out, void* stream);

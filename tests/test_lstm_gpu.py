@@ -1,0 +1,122 @@
+"""LSTM sequence model parity (config C4 shape, scaled down): arx.lstm.seqModel.SeqModel
+on the HIP path vs oracle.ref_lstm.RefSeqModel (numpy restatement of
+lstm/seqModel.py incl. TF-1.0 clip_by_global_norm aggregation), same batches."""
+import numpy as np
+import pytest
+
+from oracle import ref_graph as rg
+from oracle import ref_lstm
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False):
+    from arx.attributes.embed_attribute import EmbeddingAttribute
+    from arx.lstm.seqModel import SeqModel
+    from arx.utils.synthetic import SyntheticHMF
+    syn = SyntheticHMF(seed=seed, **cfg)
+    syn.u_attr.set_model_size(size)
+    syn.i_attr.set_model_size(size)
+    params = syn.glorot_params(size, seed=seed + 1, scale=0.4)
+    rng = np.random.default_rng(seed + 2)
+    params['lstm_w'] = (rng.standard_normal((2 * size, 4 * size)) * 0.15).astype(np.float32)
+    params['lstm_b'] = (rng.standard_normal((4 * size,)) * 0.05).astype(np.float32)
+    i2l = syn.item_ind2logit_ind_dict()
+    START = syn.n_items
+    i2l[START] = 0                                   # lstm/run.py:277
+    l2i = syn.logit_ind2item_ind
+    n_s = S if loss == 'mw' else None
+    emb = EmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i, params=params)
+    model = SeqModel([L], size, 1, clip, B, 0.5, 0.83, emb, loss=loss, use_concat=False,
+                     no_user_id=no_user_id, START_ID=START, params=params)
+    remb = rg.RefEmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i,
+                                    params={k: v for k, v in params.items() if not k.startswith('lstm')},
+                                    dtype=np.float64)
+    ref = ref_lstm.RefSeqModel(L, size, clip, B, 0.5, remb, loss=loss, no_user_id=no_user_id,
+                               params=params)
+    pos = syn.positives_dict()
+    emb.prepare_warp(pos, pos)
+    remb.prepare_warp(pos, pos)
+    return syn, emb, model, remb, ref
+
+
+def _batch(syn, rng, L, B):
+    users = rng.integers(0, syn.n_users, size=B).astype(np.int32)
+    tg = np.stack([syn.sample_batch(B, rng)[1] for _ in range(L)], 0)          # [L,B] targets
+    inp = np.concatenate([np.full((1, B), syn.n_items, dtype=np.int32), tg[:-1]], 0)   # START then shifted
+    lens = rng.integers(1, L + 1, size=B)
+    w = (np.arange(L)[:, None] < lens[None, :]).astype(np.float32)
+    return users, inp, tg, w
+
+
+def _compare(emb, model, remb, ref, rtol=RTOL, atol=3e-6):
+    got = emb.get_params()
+    for k, v in got.items():
+        np.testing.assert_allclose(v, remb.params[k], rtol=rtol, atol=atol, err_msg=k)
+    np.testing.assert_allclose(model.W.w.cpu().numpy(), ref.W, rtol=rtol, atol=atol, err_msg='lstm_w')
+    np.testing.assert_allclose(model.b.w.cpu().numpy(), ref.b, rtol=rtol, atol=atol, err_msg='lstm_b')
+
+
+CFG_ID = dict(n_users=300, n_items=500, logit_size=500)
+CFG_HET = dict(n_users=300, n_items=500, logit_size=500, item_mulhot=True, mulhot_vocab=150,
+               avg_len=5, max_len=12)
+
+
+@pytest.mark.parametrize("cfg,size,B,L,S,clip", [
+    (CFG_ID, 64, 16, 5, 128, 5.0),       # MFMA LSTM kernel, clipping active
+    (CFG_ID, 32, 16, 4, 64, 0.5),        # generic LSTM kernel, hard clipping
+    (CFG_HET, 64, 32, 6, 128, 1e9),      # multi-hot item attributes, no clipping
+])
+def test_seq_mw_steps_match_oracle(dev, cfg, size, B, L, S, clip):
+    syn, emb, model, remb, ref = _build(cfg, 'mw', size, B, L, S, clip, seed=4)
+    rng = np.random.default_rng(7)
+    pool = syn.sample_pool(S, rng)
+    id2idx = {int(v): i for i, v in enumerate(pool)}
+    for step in range(3):
+        users, inp, tg, w = _batch(syn, rng, L, B)
+        if step == 0:
+            pool[:3] = tg[0, :3]
+            pool = np.unique(pool)
+            pool = np.concatenate([pool, np.setdiff1d(syn.item_population, pool)[:S - len(pool)]]).astype(np.int32)
+            id2idx = {int(v): i for i, v in enumerate(pool)}
+        ps = pool if step == 0 else None
+        l_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), ps, id2idx)
+        l_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, ps, id2idx)
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='loss step %d' % step)
+        if clip < 1e8:
+            np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL,
+                                       err_msg='global norm step %d' % step)
+        _compare(emb, model, remb, ref)
+
+
+def test_seq_ce_and_eval(dev):
+    syn, emb, model, remb, ref = _build(CFG_ID, 'ce', 64, 16, 4, None, 5.0, seed=6)
+    rng = np.random.default_rng(3)
+    for step in range(2):
+        users, inp, tg, w = _batch(syn, rng, 4, 16)
+        l_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist())
+        l_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0)
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL)
+        np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL)
+    _compare(emb, model, remb, ref)
+    users, inp, tg, w = _batch(syn, rng, 4, 16)
+    e_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), forward_only=True)
+    e_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, forward_only=True)
+    np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
+
+
+def test_seq_no_user_id_and_mw_eval(dev):
+    syn, emb, model, remb, ref = _build(CFG_ID, 'mw', 64, 16, 4, 64, 5.0, seed=8, no_user_id=True)
+    rng = np.random.default_rng(5)
+    pool = syn.sample_pool(64, rng)
+    id2idx = {int(v): i for i, v in enumerate(pool)}
+    users, inp, tg, w = _batch(syn, rng, 4, 16)
+    l_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), pool, id2idx)
+    l_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, pool, id2idx)
+    np.testing.assert_allclose(l_got, l_ref, rtol=RTOL)
+    _compare(emb, model, remb, ref)
+    e_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), forward_only=True)
+    e_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, forward_only=True)
+    np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
