@@ -100,6 +100,16 @@ def sparse_site_onehot(cat_map, ids, row_base, coef, keys_out, src_out, coef_out
          float(coef), _p(keys_out), _p(src_out), _p(coef_out), _stream())
 
 
+def shard_route(ids, world, rank, zero_row, rows_out, keys_out):
+    call("arx_shard_route", _p(ids), int(ids.shape[0]), int(world), int(rank), int(zero_row),
+         _p(rows_out), _p(keys_out), _stream())
+
+
+def copy_2d(src, dst):
+    call("arx_copy_2d", _p(src), _ld(src), _p(dst), _ld(dst), int(src.shape[0]), int(src.shape[1]),
+         _stream())
+
+
 # ---- a5 ---------------------------------------------------------------------
 def gather_onehot(E, bias, cat_map, ids, out, scale=1.0, accumulate=False, bias_out=None):
     _chk(E, torch.float32, 'E'); _chk(ids, torch.int32, 'ids'); _chk(out, torch.float32, 'out')

@@ -316,6 +316,33 @@ __global__ void k_site_onehot(const int32_t* __restrict__ cat_map, const int32_t
   }
 }
 
+// row-sharded table routing (mod-N striping): owner = id % world, local row = id / world
+__global__ void k_shard_route(const int32_t* __restrict__ ids, int64_t n, int world, int rank,
+                              int32_t zero_row, int32_t* __restrict__ rows_out,
+                              int32_t* __restrict__ keys_out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int id = ids[i];
+    const bool own = (id % world) == rank;
+    if (rows_out) rows_out[i] = own ? id / world : zero_row;
+    if (keys_out) keys_out[i] = own ? id / world : ARX_KEY_NONE;
+  }
+}
+
+// dst[r, 0:cols] = src[r, 0:cols] with independent leading dimensions (float4 per thread)
+__global__ void k_copy_2d(const float* __restrict__ src, int64_t lds, float* __restrict__ dst,
+                          int64_t ldd, int64_t rows, int c4) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t total = rows * c4;
+  for (; i < total; i += stride) {
+    const int64_t r = i / c4;
+    const int c = (int)(i % c4) * 4;
+    *reinterpret_cast<float4*>(dst + r * ldd + c) = *reinterpret_cast<const float4*>(src + r * lds + c);
+  }
+}
+
 static inline int grid_waves(int64_t nwaves) {
   int64_t g = ceil_div(nwaves, 4);
   int64_t cap = (int64_t)cu_count() * 8;
@@ -439,6 +466,31 @@ int arx_sparse_site_onehot(const int32_t* cat_map, const int32_t* ids, int64_t n
   if (g > cap) g = cap;
   k_site_onehot<<<(int)g, 256, 0, as_stream(stream)>>>(cat_map, ids, n, row_base, coef, keys_out,
                                                        src_out, coef_out);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_shard_route(const int32_t* ids, int64_t n, int world, int rank, int32_t zero_row,
+                    int32_t* rows_out, int32_t* keys_out, void* stream) {
+  ARX_CHECK_ARG(ids && world > 0 && rank >= 0 && rank < world, "arx_shard_route: bad argument");
+  if (n <= 0) return ARX_OK;
+  int64_t g = ceil_div(n, 256);
+  int64_t cap = (int64_t)cu_count() * 8;
+  if (g > cap) g = cap;
+  k_shard_route<<<(int)g, 256, 0, as_stream(stream)>>>(ids, n, world, rank, zero_row, rows_out, keys_out);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_copy_2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows,
+                int64_t cols, void* stream) {
+  ARX_CHECK_ARG(src && dst, "arx_copy_2d: null pointer");
+  ARX_CHECK_ARG(cols % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0, "arx_copy_2d: cols/ld must be multiples of 4");
+  if (rows <= 0 || cols <= 0) return ARX_OK;
+  int64_t g = ceil_div(rows * (cols / 4), 256);
+  int64_t cap = (int64_t)cu_count() * 8;
+  if (g > cap) g = cap;
+  k_copy_2d<<<(int)g, 256, 0, as_stream(stream)>>>(src, lds, dst, ldd, rows, (int)(cols / 4));
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

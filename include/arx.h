@@ -64,6 +64,16 @@ int arx_sparse_site_onehot(const int32_t* cat_map, const int32_t* ids, int64_t n
                            int32_t row_base, float coef, int32_t* keys_out, int32_t* src_out,
                            float* coef_out, void* stream);
 
+/* Row-sharded item table: table rows are striped over the
+ * ranks, owner = id % world, local row = id / world.  rows_out[i] = local row if
+ * this rank owns ids[i] else zero_row (an all-zero padding row of the shard);
+ * keys_out[i] = local row or ARX_KEY_NONE (so non-owned lookups get no update). */
+int arx_shard_route(const int32_t* ids, int64_t n, int world, int rank, int32_t zero_row,
+                    int32_t* rows_out, int32_t* keys_out, void* stream);
+/* strided 2-D copy (packs / unpacks the all-to-all blocks of the sharded scorer) */
+int arx_copy_2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows,
+                int64_t cols, void* stream);
+
 /* ---- a5: one-hot attribute gather --------------------------------------
  * embed_attribute.py:371-381: rows = cat_map[ids]; E[rows] (+ bias[rows]).
  * out[r, 0:d] = (accumulate ? out : 0) + scale * E[cat_map[ids[r]], :]

@@ -1,0 +1,107 @@
+"""TEST DOUBLE: numpy implementation of the compute-stage interface of
+arx.dist.ShardedHMF (the product backend is HipBackend / libarx.so).  It lets the
+world_size-2 gloo tests check the sharding + exchange logic on CPU against the
+single-process oracle.  Lives in tests/ on purpose: the package has no CPU path."""
+import numpy as np
+
+KEY_NONE = 0x7FFFFFFF
+
+
+def _n(t):
+    return t.numpy()
+
+
+class NumpyBackend(object):
+    def gather_rows(self, E, bias, rows, out, bias_out):
+        r = _n(rows).astype(np.int64)
+        _n(out)[...] = _n(E)[r]
+        if bias_out is not None:
+            _n(bias_out)[...] = _n(bias)[r]
+
+    def gemm(self, A, B, C, transA=False, transB=False, beta=0.0, col_bias=None, a_rowsum=None):
+        a = _n(A).astype(np.float64)
+        b = _n(B).astype(np.float64)
+        a = a.T if transA else a
+        b = b.T if transB else b
+        c = a @ b
+        if beta != 0.0:
+            c = c + beta * _n(C)
+        if col_bias is not None:
+            c = c + _n(col_bias)[None, :]
+        _n(C)[...] = c.astype(np.float32)
+        if a_rowsum is not None:
+            _n(a_rowsum)[...] = a.sum(1).astype(np.float32)
+
+    def dot_score(self, U, T, tb, out):
+        _n(out)[...] = ((_n(U).astype(np.float64) * _n(T)).sum(1) + _n(tb)).astype(np.float32)
+
+    def dot_score_bwd(self, U, T, ds, dU, acc, dT):
+        g = _n(ds)[:, None]
+        if acc:
+            _n(dU)[...] += g * _n(T)
+        else:
+            _n(dU)[...] = g * _n(T)
+        if dT is not None:
+            _n(dT)[...] = g * _n(U)
+
+    def copy_2d(self, src, dst):
+        dst.copy_(src)
+
+    def shard_route(self, ids, world, rank, zero_row, rows_out, keys_out):
+        i = _n(ids).astype(np.int64)
+        own = (i % world) == rank
+        if rows_out is not None:
+            _n(rows_out)[...] = np.where(own, i // world, zero_row).astype(np.int32)
+        if keys_out is not None:
+            _n(keys_out)[...] = np.where(own, i // world, KEY_NONE).astype(np.int32)
+
+    def loss_mw_pos(self, logits, t, urows, ptr, items, i2s, bl, dl, dt, gscale):
+        x = _n(logits).astype(np.float64)
+        tt = _n(t).astype(np.float64)
+        B, S = x.shape
+        mask = np.ones((B, S), dtype=bool)
+        p, it, m = _n(ptr), _n(items), _n(i2s)
+        for r, u in enumerate(_n(urows)):
+            for v in it[p[u]:p[u + 1]]:
+                j = m[v]
+                if j >= 0:
+                    mask[r, j] = False
+        v = x - tt[:, None] + 1
+        act = mask & (v > 0)
+        s = np.where(act, v, 0).sum(1)
+        _n(bl)[...] = np.log(1 + s)
+        g = gscale / (1 + s)
+        d = act * g[:, None]
+        _n(dl)[...] = d
+        _n(dt)[...] = -d.sum(1)
+
+    def sum_scaled(self, x, scale, out):
+        _n(out)[...] = _n(x).astype(np.float64).sum() * scale
+
+    def sparse_adagrad(self, E, acc, bias, bias_acc, keys, G, Gb, lr):
+        k = _n(keys).astype(np.int64)
+        ok = k != KEY_NONE
+        e, a = _n(E), _n(acc)
+        g = np.zeros(e.shape, dtype=np.float64)
+        np.add.at(g, k[ok], _n(G)[ok].astype(np.float64))
+        rows = np.unique(k[ok])
+        lrv = float(_n(lr)[0])
+        a[rows] = a[rows] + g[rows] ** 2
+        e[rows] = e[rows] - lrv * g[rows] / np.sqrt(a[rows])
+        if bias is not None:
+            b, ba = _n(bias), _n(bias_acc)
+            gb = np.zeros(b.shape, dtype=np.float64)
+            np.add.at(gb, k[ok], _n(Gb)[ok].astype(np.float64))
+            ba[rows] = ba[rows] + gb[rows] ** 2
+            b[rows] = b[rows] - lrv * gb[rows] / np.sqrt(ba[rows])
+
+    def slot_map_set(self, m, ids, clear):
+        i = _n(ids).astype(np.int64)
+        if clear:
+            _n(m)[i] = -1
+        else:
+            for s, v in enumerate(i):
+                _n(m)[v] = s
+
+    def copy_i32(self, src, dst):
+        dst.copy_(src)

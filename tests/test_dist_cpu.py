@@ -1,0 +1,92 @@
+"""world_size-2 gloo test of the row-sharded HMF step (arx.dist.ShardedHMF):
+the exchange / routing logic with a numpy compute double must reproduce the
+single-process oracle step on the global batch (loss and updated tables)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "a-recsys_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arx.dist import ShardedHMF
+    from arx.utils.synthetic import SyntheticHMF
+    from numpy_backend import NumpyBackend
+    from oracle import ref_graph as rg
+
+    n_users, n_items, d, B_loc, S = 60, 90, 16, 8, 16
+    syn = SyntheticHMF(n_users=n_users, n_items=n_items, seed=1, permute_logits=False, n_pos=6)
+    params = syn.glorot_params(d, seed=2, scale=0.5)
+    tables = {'user': params['userembed_cat_0'][2:], 'item': params['itemembed_cat_0'][2:],
+              'item_bias': params['item_bias_cat_0'][2:]}
+    model = ShardedHMF(n_users, n_items, d, B_loc, S, 0.5, rank, world, 'cpu',
+                       backend=NumpyBackend(), tables=tables)
+    # positives CSR over this rank's local user rows (global item ids)
+    own_users = np.arange(rank, n_users, world)
+    ptr = np.zeros(len(own_users) + 2, dtype=np.int32)
+    items = []
+    for k, u in enumerate(own_users):
+        its = syn.pos_items[syn.pos_ptr[u]:syn.pos_ptr[u + 1]]
+        items.extend(its.tolist())
+        ptr[k + 1] = len(items)
+    ptr[-1] = ptr[-2]
+    model.set_positives(ptr, np.asarray(items, dtype=np.int32))
+
+    B = B_loc * world
+    i2l = syn.item_ind2logit_ind_dict()
+    ref = rg.RefLatentProductModel(d, B, 0.5, syn.u_attr, syn.i_attr, i2l, syn.logit_ind2item_ind,
+                                   loss_function='mw', n_sampled=S, params=params, dtype=np.float64)
+    pos = syn.positives_dict()
+    ref.prepare_warp(pos, pos)
+    rng = np.random.default_rng(5)          # identical stream on both ranks
+    for step in range(4):
+        pool = None
+        if step % 2 == 0:                   # stratified pool: S/world items per owner, owner-major
+            blocks = []
+            for g in range(world):
+                cand = np.arange(g, n_items, world)
+                blocks.append(rng.choice(cand, size=S // world, replace=False))
+            pool = np.concatenate(blocks).astype(np.int32)
+            id2idx = {int(v): i for i, v in enumerate(pool)}
+            model.set_pool(pool)
+        gu, gi = [], []
+        for g in range(world):              # every rank draws users it owns
+            lu = rng.integers(0, len(np.arange(g, n_users, world)), size=B_loc)
+            users = lu * world + g
+            k = rng.integers(0, syn.n_pos, size=B_loc)
+            gu.append(users)
+            gi.append(syn.pos_items[syn.pos_ptr[users] + k])
+        gu[0][1] = gu[0][0]                 # duplicate user / target rows
+        gi[1][2] = gi[1][3]
+        if step == 0:
+            gi[0][0] = pool[S // world]     # a target that is also a pool slot (owned by rank 1)
+        l_ref = ref.step(np.concatenate(gu).tolist(), np.concatenate(gi).tolist(), pool, id2idx,
+                         loss='mw')
+        model.step(gu[rank].astype(np.int32), gi[rank].astype(np.int32))
+        l_got = float(model.read_loss().item())
+        assert abs(l_got - l_ref) <= 1e-5 * abs(l_ref), (step, l_got, l_ref)
+    got = model.gather_global_tables()
+    np.testing.assert_allclose(got['user'], ref.att_emb.params['userembed_cat_0'][2:], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got['item'], ref.att_emb.params['itemembed_cat_0'][2:], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got['item_bias'], ref.att_emb.params['item_bias_cat_0'][2:, 0],
+                               rtol=1e-4, atol=1e-6)
+    with open(os.path.join(out_dir, "ok%d" % rank), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+def test_sharded_step_matches_oracle_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 400)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
