@@ -1,0 +1,342 @@
+"""CPU suite (no GPU): pins the oracle and the host helpers.
+
+ 1. golden vectors produced by the REAL reference helpers (tests/golden/make_golden.py)
+    pin arx.utils.prepare_train / eval_metrics / Attributes;
+ 2. hand-computed known-answer cases pin the oracle's op restatements;
+ 3. an independent torch-autograd restatement (embedding-space form, written with a
+    different code shape) pins the oracle's analytic backward + Adagrad;
+ 4. libarx.so loads and exports every symbol include/arx.h declares.
+"""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_graph as rg
+from oracle import ref_lstm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_helpers.json")))
+
+
+# ---------------------------------------------------------------- 1. goldens
+def test_item_frequency_matches_reference_golden():
+    from arx.utils import prepare_train as pt
+    data_tr = [tuple(x) for x in GOLD["item_frequency"]["data_tr"]]
+    for case in GOLD["item_frequency"]["cases"]:
+        pop, p = pt.item_frequency(data_tr, case["power"])
+        assert sorted(pop) == sorted(case["item_population"])
+        got = dict(zip(pop, p))
+        exp = dict(zip(case["item_population"], case["p_item"]))
+        for k in exp:
+            assert got[k] == pytest.approx(exp[k], rel=1e-12)
+
+
+def test_positive_items_matches_reference_golden():
+    from arx.utils import prepare_train as pt
+    data_tr = [tuple(x) for x in GOLD["item_frequency"]["data_tr"]]
+    data_va = [tuple(x) for x in GOLD["positive_items"]["data_va"]]
+    pos, pos_va = pt.positive_items(data_tr, data_va)
+    assert {str(k): sorted(v) for k, v in pos.items()} == GOLD["positive_items"]["train"]
+    assert {str(k): sorted(v) for k, v in pos_va.items()} == GOLD["positive_items"]["valid"]
+
+
+def test_sample_items_bit_exact_with_reference_stream():
+    """np.random's legacy stream is frozen: same seed => same draws as the reference."""
+    from arx.utils import prepare_train as pt
+    data_tr = [tuple(x) for x in GOLD["item_frequency"]["data_tr"]]
+    ref_pop = GOLD["item_frequency"]["cases"][0]["item_population"]
+    ref_p = GOLD["item_frequency"]["cases"][0]["p_item"]
+    for s in GOLD["sample_items"]:
+        np.random.seed(s["seed"])
+        if "uniform_over" in s:
+            got, id2idx = pt.sample_items(list(range(s["uniform_over"])), s["n"])
+        else:
+            got, id2idx = pt.sample_items(ref_pop, s["n"], ref_p)
+        assert [int(x) for x in got] == s["sampled"]
+        assert {str(int(k)): int(v) for k, v in id2idx.items()} == s["id2idx"]
+
+
+def test_attributes_container_matches_reference_golden():
+    from arx.attributes.attribute import Attributes
+    g = GOLD["attributes"]
+    a = Attributes(2, [[2, 3, 1], [4, 2, 1]], 1, [[5, 6, 7, 1]], [2], [[0, 2, 3, 4]], [[2, 1, 1]],
+                   [5, 6], [9])
+    a.set_model_size(12)
+    assert {"cat": a._embedding_size_list_cat, "mulhot": a._embedding_size_list_mulhot} == g["after_int"]
+    a.set_model_size([3, 4])
+    a.set_model_size([7], 1)
+    assert {"cat": a._embedding_size_list_cat, "mulhot": a._embedding_size_list_mulhot} == g["after_lists"]
+    a.set_target_prediction([[1]], [[2]], [[3]], [[4.0]])
+    assert [a.full_cat_tr, a.full_values_tr, a.full_segids_tr, a.full_lengths_tr] == g["full"]
+    assert (a.num_features_cat, a.num_features_mulhot) == (g["num_features_cat"], g["num_features_mulhot"])
+    with pytest.raises(ValueError):
+        a.set_model_size("x")
+
+
+def test_eval_metrics_matches_reference_golden():
+    from arx.utils import eval_metrics as em
+    R = {int(k): v for k, v in GOLD["eval_metrics"]["R"].items()}
+    T = {int(k): v for k, v in GOLD["eval_metrics"]["T"].items()}
+    res = em.metrics(R, T)
+    for k, v in GOLD["eval_metrics"]["result"].items():
+        np.testing.assert_allclose(res[k], v, rtol=1e-12)
+
+
+# ------------------------------------------------------- 2. known answers
+def test_batch_slice_and_segids_known_answer():
+    vals = np.array([10, 11, 12, 13, 14, 15, 16], dtype=np.int32)
+    np.testing.assert_array_equal(rg.batch_slice2(vals, [4, 0, 2], [2, 3, 1]), [14, 15, 10, 11, 12, 12])
+    np.testing.assert_array_equal(rg.batch_segids2([2, 3, 1]), [0, 0, 1, 1, 1, 2])
+    assert rg.batch_slice2(vals, [], []).shape == (0,)
+    np.testing.assert_array_equal(rg.unsorted_segment_sum(np.array([[1.], [2.], [4.]]), [1, 1, 0], 3),
+                                  [[4.], [3.], [0.]])
+
+
+def _tiny_attrs():
+    from arx.attributes.attribute import Attributes
+    # 2 users (+START), 3 items (+START); item: one id feature + one 2-token-vocab bag
+    ua = Attributes(1, [np.array([2, 3, 1])], 0, [], None, [], [], [4], [])
+    ia = Attributes(1, [np.array([2, 3, 4, 1])], 1, [np.array([2, 3, 2, 3, 3, 1])], None,
+                    [np.array([0, 2, 3, 5, 6])], [np.array([2, 1, 2, 1])], [5], [4])
+    ua.set_model_size(2)
+    ia.set_model_size(2)
+    ia.set_target_prediction([np.array([2, 3, 4])], [np.array([2, 3, 2, 3, 3])],
+                             [np.array([0, 0, 1, 2, 2])], [np.array([[2.], [1.], [2.]])])
+    return ua, ia
+
+
+def test_scorer_and_mw_loss_known_answer():
+    """2-d embeddings with exactly representable values, checked by hand."""
+    ua, ia = _tiny_attrs()
+    P = {
+        'userembed_cat_0': np.array([[0, 0], [0, 0], [1, 0], [0, 2]], float),
+        'itemembed_cat_0': np.array([[0, 0], [0, 0], [1, 1], [2, 0], [0, 4]], float),
+        'item_bias_cat_0': np.array([[0], [0], [0.5], [0], [1]], float),
+        'itemembed_mulhot_0': np.array([[0, 0], [0, 0], [2, 0], [0, 2]], float),
+        'item_bias_mulhot_0': np.array([[0], [0], [1], [0]], float),
+    }
+    e = rg.RefEmbeddingAttribute(ua, ia, 2, 2, 0, False, {0: 0, 1: 1, 2: 2}, [0, 1, 2], params=P,
+                                 dtype=np.float64)
+    u, _ = e.get_batch_user([0, 1])
+    np.testing.assert_array_equal(u, [[1, 0], [0, 2]])
+    logits, _ = e.get_prediction(u, 'full')
+    # item0: id row [1,1] b .5 ; bag {2,3} mean [1,1] b .5 -> feature scores for u0=[1,0]: 1.5, 1.5
+    # item1: id row [2,0] b 0 ; bag {2} -> [2,0] b 1 -> u0: 2, 3 -> 2.5
+    # item2: id row [0,4] b 1 ; bag {3,3} -> [0,2] b 0 -> u0: 1, 0 -> .5 ; u1=[0,2]: 9, 4 -> 6.5
+    np.testing.assert_allclose(logits, [[1.5, 2.5, 0.5], [2.5, 0.5, 6.5]])
+    e.update_sampled([2, 0])
+    sl, _ = e.get_prediction(u, 'sampled')
+    np.testing.assert_allclose(sl, [[0.5, 1.5], [6.5, 2.5]])
+    t, _ = e.get_target_score(u, [1, 2])
+    np.testing.assert_allclose(t, [2.5, 6.5])
+    mask = np.array([[True, True], [False, True]])
+    bl, c = e.compute_loss(sl, t, 'mw', mask)
+    # row0: relu(.5-2.5+1)=0, relu(1.5-2.5+1)=0 -> log1 = 0 ; row1: masked, relu(2.5-6.5+1)=0 -> 0
+    np.testing.assert_allclose(bl, [0, 0])
+    bl2, c2 = e.compute_loss(sl, np.array([0.0, 7.0]), 'mw', mask)
+    np.testing.assert_allclose(bl2, [np.log(1 + 1.5 + 2.5), 0.0])
+    d, dt = e.compute_loss_bwd(c2, np.array([1.0, 1.0]))
+    np.testing.assert_allclose(d, [[0.2, 0.2], [0, 0]])
+    np.testing.assert_allclose(dt, [-0.4, 0])
+    # ce / warp on the full logits
+    ce, _ = e.compute_loss(logits, [1, 2], 'ce')
+    np.testing.assert_allclose(ce, [np.log(np.exp([1.5, 2.5, .5]).sum()) - 2.5,
+                                    np.log(np.exp([2.5, .5, 6.5]).sum()) - 6.5])
+    w, _ = e.compute_loss(logits, [1, 2], 'warp', np.array([[True, False, True], [True, True, False]]))
+    np.testing.assert_allclose(w, [np.log(1 + 0 + 0), np.log(1 + 0 + 0)])
+
+
+def test_adagrad_known_answer():
+    p, a = np.array([1.0, 2.0]), np.array([0.1, 0.1])
+    rg.adagrad_apply(p, a, np.array([0.3, 0.0]), 0.5)
+    np.testing.assert_allclose(a, [0.19, 0.1])
+    np.testing.assert_allclose(p, [1.0 - 0.5 * 0.3 / np.sqrt(0.19), 2.0])
+
+
+def test_mask_indices_follow_reference_feed_logic():
+    ua, ia = _tiny_attrs()
+    e = rg.RefEmbeddingAttribute(ua, ia, 3, 4, 0, False, {0: 2, 1: 0, 2: 1}, [1, 2, 0], params={})
+    e.prepare_warp({0: [0, 2], 1: [1]}, {0: [1]})
+    idx, V = e.mask_indices([1, 0, 5], 'mw', {2: 3, 1: 0})
+    assert V == 4 and idx == [0, 4 + 3]              # user1: item1->slot0 ; user0: item2->slot3 ; user5 absent
+    idx, V = e.mask_indices([0, 1], 'warp')
+    assert V == 3 and idx == [2, 1, 3 + 0]
+    idx, _ = e.mask_indices([0], 'warp', forward_only=True)
+    assert idx == [0]
+
+
+# ------------------------------------------------ 3. torch autograd witness
+def _torch_hmf_loss(P, syn_maps, users, items, pool, mask, loss, targets, B):
+    """Embedding-space HMF forward in torch (independent of ref_graph's code shape)."""
+    ucat, icat, ivals, istarts, ilens = syn_maps
+
+    def item_embed(ids):
+        feats, biases = [], []
+        if icat is not None:
+            rows = torch.as_tensor(icat[ids]).long()
+            feats.append(P['itemembed_cat_0'][rows])
+            biases.append(P['item_bias_cat_0'][rows, 0])
+        if ivals is not None:
+            es, bs = [], []
+            for i in ids:
+                tok = torch.as_tensor(ivals[istarts[i]:istarts[i] + ilens[i]]).long()
+                es.append(P['itemembed_mulhot_0'][tok].mean(0))
+                bs.append(P['item_bias_mulhot_0'][tok, 0].mean())
+            feats.append(torch.stack(es))
+            biases.append(torch.stack(bs))
+        return torch.stack(feats).mean(0), torch.stack(biases).mean(0)
+
+    u = P['userembed_cat_0'][torch.as_tensor(ucat[users]).long()]
+    Ip, bp = item_embed(pool)
+    logits = u @ Ip.T + bp
+    m = torch.as_tensor(mask)
+    if loss == 'mw':
+        It, bt = item_embed(items)
+        t = (u * It).sum(1) + bt
+        bl = torch.log(1 + (torch.relu(logits - t[:, None] + 1) * m).sum(1))
+    elif loss == 'warp':
+        t = logits[torch.arange(B), torch.as_tensor(targets).long()]
+        bl = torch.log(1 + (torch.relu(logits - t[:, None] + 1) * m).sum(1))
+    else:
+        bl = torch.nn.functional.cross_entropy(logits, torch.as_tensor(targets).long(), reduction='none')
+    return bl.mean()
+
+
+@pytest.mark.parametrize("loss,mulhot,id_feature", [('mw', False, True), ('mw', True, True),
+                                                    ('mw', True, False), ('ce', True, True),
+                                                    ('warp', True, True)])
+def test_oracle_step_equals_torch_autograd_plus_adagrad(loss, mulhot, id_feature):
+    from arx.utils.synthetic import SyntheticHMF
+    d, B, S = 8, 12, 16
+    syn = SyntheticHMF(n_users=40, n_items=50, logit_size=50, item_mulhot=mulhot, mulhot_vocab=20,
+                       avg_len=3, max_len=6, seed=3, item_id_feature=id_feature, n_pos=5)
+    params = syn.glorot_params(d, seed=4, scale=0.5)
+    i2l = syn.item_ind2logit_ind_dict()
+    ref = rg.RefLatentProductModel(d, B, 0.7, syn.u_attr, syn.i_attr, i2l, syn.logit_ind2item_ind,
+                                   loss_function=loss, n_sampled=S if loss == 'mw' else None,
+                                   params=params, dtype=np.float64)
+    pos = syn.positives_dict()
+    ref.prepare_warp(pos, pos)
+    rng = np.random.default_rng(0)
+    users, items = syn.sample_batch(B, rng)
+    users[1] = users[0]
+    pool = syn.sample_pool(S, rng)
+    pool[0] = items[0]
+    pool = np.unique(pool)
+    pool = np.concatenate([pool, np.setdiff1d(syn.item_population, pool)[:S - len(pool)]])
+    id2idx = {int(v): i for i, v in enumerate(pool)}
+    P = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
+    ia = syn.i_attr
+    maps = (np.asarray(syn.u_attr.features_cat[0]),
+            np.asarray(ia.features_cat[0]) if id_feature else None,
+            np.asarray(ia.features_mulhot[0]) if mulhot else None,
+            np.asarray(ia.mulhot_starts[0]) if mulhot else None,
+            np.asarray(ia.mulhot_lengths[0]) if mulhot else None)
+    if loss == 'mw':
+        mask = ref.att_emb.mask(list(users), 'mw', id2idx)
+        cols = pool
+        targets = None
+    else:
+        cols = np.asarray(syn.logit_ind2item_ind)
+        targets = [i2l[int(v)] for v in items]
+        mask = np.ones((B, len(cols)), bool) if loss == 'ce' else ref.att_emb.mask(list(users), 'warp')
+    L = _torch_hmf_loss(P, maps, users, items, cols, mask, loss, targets, B)
+    L.backward()
+    l_ref = ref.step(list(users), list(items), pool if loss == 'mw' else None, id2idx, loss=loss)
+    assert float(L) == pytest.approx(float(l_ref), rel=1e-10)
+    for name, t in P.items():
+        g = t.grad.numpy() if t.grad is not None else np.zeros(t.shape)
+        acc = 0.1 + g * g
+        exp = params[name].astype(np.float64) - 0.7 * g / np.sqrt(acc)
+        np.testing.assert_allclose(ref.att_emb.params[name], exp, rtol=1e-9, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(ref.att_emb.slots[name], acc, rtol=1e-9, atol=1e-12, err_msg=name)
+
+
+def test_oracle_lstm_equals_torch_autograd():
+    rng = np.random.default_rng(1)
+    L, B, din, h = 4, 3, 5, 6
+    x = rng.standard_normal((L, B, din))
+    W = rng.standard_normal((din + h, 4 * h)) * 0.3
+    b = rng.standard_normal(4 * h) * 0.1
+    dhs = rng.standard_normal((L, B, h))
+    hs, cs, gates = ref_lstm.lstm_fwd(x, W, b, 1.0)
+    dz, dx, dW, db = ref_lstm.lstm_bwd(x, W, hs, cs, gates, dhs)
+    tx = torch.tensor(x, requires_grad=True)
+    tW = torch.tensor(W, requires_grad=True)
+    tb = torch.tensor(b, requires_grad=True)
+    hp, cp, outs = torch.zeros(B, h, dtype=torch.float64), torch.zeros(B, h, dtype=torch.float64), []
+    for t in range(L):
+        z = torch.cat([tx[t], hp], 1) @ tW + tb
+        i, j, f, o = z.split(h, 1)
+        cp = torch.sigmoid(f + 1.0) * cp + torch.sigmoid(i) * torch.tanh(j)
+        hp = torch.sigmoid(o) * torch.tanh(cp)
+        outs.append(hp)
+    H = torch.stack(outs)
+    np.testing.assert_allclose(H.detach().numpy(), hs, rtol=1e-12)
+    (H * torch.tensor(dhs)).sum().backward()
+    np.testing.assert_allclose(tx.grad.numpy(), dx, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(tW.grad.numpy(), dW, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(tb.grad.numpy(), db, rtol=1e-9, atol=1e-12)
+
+
+def test_clip_norm_aggregation_rule():
+    """tf.gradients aggregation (gradients_impl._AggregatedGrads): all-dense => add_n;
+    any IndexedSlices => concatenation, norm over un-merged values."""
+    g = rg.Grads()
+    g.add_dense('a', np.array([[3.0, 0.0]]))
+    g.add_dense('a', np.array([[0.0, 4.0]]))
+    assert g.sq_norm_unmerged('a') == pytest.approx(25.0)          # ||[3,4]||^2
+    g.add_sparse('a', [0], np.array([[1.0, 0.0]]))
+    assert g.sq_norm_unmerged('a') == pytest.approx(9 + 16 + 1)    # concatenated, un-merged
+    g.add_sparse('b', [2, 2], np.array([[1.0], [1.0]]))
+    assert g.sq_norm_unmerged('b') == pytest.approx(2.0)           # duplicates NOT merged
+    np.testing.assert_allclose(g.total('b', (3, 1), np.float64), [[0], [0], [2.0]])
+
+
+# ------------------------------------------------------------ 4. the C ABI
+def test_library_exports_every_symbol_of_arx_h():
+    from arx import _lib
+    hdr = open(os.path.join(ROOT, "include", "arx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(arx_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 45
+    missing = [n for n in sorted(names) if not hasattr(_lib.lib, n)]
+    assert not missing, "not exported by libarx.so: %s" % missing
+    unbound = [n for n in sorted(names) if n not in _lib.PROTOTYPES]
+    assert not unbound, "declared in arx.h but not bound in arx/_lib.py: %s" % unbound
+    extra = [n for n in _lib.PROTOTYPES if n not in names]
+    assert not extra, "bound but not declared in arx.h: %s" % extra
+    assert _lib.lib.arx_version() >= 100
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from arx import graph
+    with pytest.raises(RuntimeError):
+        graph.Runtime()
+
+
+def test_synthetic_layout_follows_reference_preprocessing():
+    from arx.utils.synthetic import SyntheticHMF
+    syn = SyntheticHMF(n_users=30, n_items=40, logit_size=25, item_mulhot=True, mulhot_vocab=12,
+                       avg_len=3, max_len=5, seed=2)
+    ia = syn.i_attr
+    cat = np.asarray(ia.features_cat[0])
+    assert len(cat) == 41 and cat[-1] == 1                         # START row (preprocess.py:198)
+    starts, lens, vals = map(np.asarray, (ia.mulhot_starts[0], ia.mulhot_lengths[0], ia.features_mulhot[0]))
+    assert len(starts) == 42 and len(lens) == 41 and len(vals) == lens.sum()
+    np.testing.assert_array_equal(starts[1:], np.cumsum(lens))
+    assert lens.min() >= 1 and vals[-1] == 1 and lens[-1] == 1     # trailing START bag (:223-226)
+    l2i = syn.logit_ind2item_ind
+    np.testing.assert_array_equal(np.asarray(ia.full_cat_tr[0]), cat[l2i])
+    seg = np.asarray(ia.full_segids_tr[0])
+    assert np.all(np.diff(seg) >= 0) and seg[-1] == len(l2i) - 1   # sorted segids (:302-323)
+    fl = np.asarray(ia.full_lengths_tr[0]).reshape(-1)
+    np.testing.assert_array_equal(fl, lens[l2i])
+    exp_vals = np.concatenate([vals[starts[i]:starts[i] + lens[i]] for i in l2i])
+    np.testing.assert_array_equal(np.asarray(ia.full_values_tr[0]), exp_vals)
