@@ -455,6 +455,7 @@ class Plan(object):
                 'coef': torch.zeros((total,), dtype=torch.float32, device=rt.device),
                 'offs': torch.zeros((max(s.n for s in sites) + 1,), dtype=torch.int32, device=rt.device),
                 'tot': torch.zeros((1,), dtype=torch.int32, device=rt.device),
+                'hot': torch.zeros((total // 16 + 4,), dtype=torch.int32, device=rt.device),
             }
             widths = set(s.node.shape[1] for s in sites)
             if len(widths) != 1:
@@ -487,6 +488,31 @@ class Plan(object):
     def _apply_sparse(self):
         rt = self.rt
         for table, sites, bufs, total in self.tables:
+            live_sites = [s for s in sites if s.node._grad_written]
+            if not live_sites:
+                continue
+            n_live = sum(s.n for s in live_sites)
+            if all(s.kind == 'cat' and s.col_off == 0 for s in live_sites) and n_live <= 65536 \
+                    and len(live_sites) <= 8 and not rt.force_sort_path:
+                # one-hot lookups, few contributions: sort-free fast path (optim_cat.hip)
+                key = tuple(id(s) for s in live_sites)
+                if bufs.get('cat_key') != key:
+                    bufs['cat_key'] = key
+                    bufs['cat_args'] = ops.CatSiteArgs(
+                        [(s.maps[0], None, s.ids_node.value, s.node.row0, s.coef) for s in live_sites])
+                if getattr(table, 'aux_first', None) is None:
+                    table.aux_first = torch.full((table.E.shape[0],), 2 ** 31 - 1, dtype=torch.int32,
+                                                 device=rt.device)
+                    table.aux_cnt = torch.zeros((table.E.shape[0],), dtype=torch.int32, device=rt.device)
+                node0 = live_sites[0].node
+                use_bias = table.bias is not None and any(s.node.bias_grad_used for s in live_sites)
+                ops.sparse_adagrad_cat(table.E, table.acc, table.bias if use_bias else None,
+                                       table.bias_acc if use_bias else None, bufs['cat_args'],
+                                       node0.arena, node0.arena_b if use_bias else None, rt.lr,
+                                       table.aux_first, table.aux_cnt, bufs['hot'], bufs['keys'],
+                                       bufs['src'], bufs['coef'], rt.ws, gscale_dev=rt.clip_coef_dev,
+                                       mode=rt.cat_mode)
+                continue
             live = False
             for s in sites:
                 node = s.node
@@ -558,6 +584,9 @@ class Runtime(object):
         self.use_graph = use_graph
         self.global_step = 0
         self.pre_apply_hooks = []
+        import os as _os
+        self.force_sort_path = bool(_os.environ.get('ARX_FORCE_SORT'))
+        self.cat_mode = 1 if _os.environ.get('ARX_CAT_ATOMIC') else 0
 
     def set_learning_rate(self, v):
         self.lr_host = float(v)

@@ -249,6 +249,34 @@ def sparse_adagrad(E, acc, bias, bias_acc, keys, src, coef, G, Gb, lr_dev, ws, g
          key_bits_for(E.shape[0]), wsp, wsn, _stream())
 
 
+class CatSiteArgs(object):
+    """Host-side descriptor arrays of arx_sparse_adagrad_cat, built once per plan."""
+
+    def __init__(self, sites):
+        import ctypes as C
+        n = len(sites)
+        self.n = n
+        self.total = sum(int(s[2].shape[0]) for s in sites)
+        self.cat_map = (C.c_void_p * n)(*[_p(s[0]) or None for s in sites])
+        self.ids = (C.c_void_p * n)(*[_p(s[2]) for s in sites])
+        self.count = (C.c_int64 * n)(*[int(s[2].shape[0]) for s in sites])
+        self.row_base = (C.c_int32 * n)(*[int(s[3]) for s in sites])
+        self.coef = (C.c_float * n)(*[float(s[4]) for s in sites])
+        self._keep = sites
+
+
+def sparse_adagrad_cat(E, acc, bias, bias_acc, site_args, G, Gb, lr_dev, aux_first, aux_cnt,
+                       aux_hot, keys_buf, src_buf, coef_buf, ws, gscale_dev=None, mode=0):
+    """sites: list of (cat_map|None, _, ids, row_base, coef) packed in CatSiteArgs.
+    mode 0: fused keygen + LDS sort + Adagrad passes (n <= 16384) else atomic election."""
+    wsp, wsn = ws.get(_lib.lib.arx_sparse_adagrad_workspace_bytes(site_args.total))
+    call("arx_sparse_adagrad_cat", _p(E), _p(acc), _p(bias), _p(bias_acc), int(E.shape[0]),
+         int(E.shape[1]), site_args.n, site_args.cat_map, site_args.ids, site_args.count,
+         site_args.row_base, site_args.coef, _p(G), _ld(G), _p(Gb), _p(lr_dev), _p(gscale_dev),
+         _p(aux_first), _p(aux_cnt), _p(aux_hot), int(aux_hot.numel()), _p(keys_buf), _p(src_buf),
+         _p(coef_buf), int(mode), wsp, wsn, _stream())
+
+
 def adagrad_dense(w, acc, g, lr_dev, gscale_dev=None):
     call("arx_adagrad_dense", _p(w), _p(acc), _p(g), int(w.numel()), _p(lr_dev), _p(gscale_dev),
          _stream())

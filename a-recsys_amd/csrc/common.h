@@ -56,4 +56,26 @@ static inline int lanes_per_row(int d) {
 // number of CUs of the current device (cached)
 int cu_count();
 
+// One-hot lookup sites of a table (arx_sparse_adagrad_cat): site s contributes, for
+// j < offs[s+1]-offs[s], key = cat_map[s] ? cat_map[s][ids[s][j]] : ids[s][j], gradient
+// row row_base[s] + j, factor coef[s].
+constexpr int kMaxSites = 8;
+struct CatSites {
+  int nsites;
+  int64_t offs[kMaxSites + 1];
+  const int32_t* cat_map[kMaxSites];
+  const int32_t* ids[kMaxSites];
+  int32_t row_base[kMaxSites];
+  float coef[kMaxSites];
+};
+
+// optim.hip: key generation + single-workgroup sort + the two Adagrad passes
+// (n <= 16384 contributions); returns ARX_* codes.
+int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_acc,
+                                int64_t table_rows, int d, const CatSites& st, const float* G,
+                                int64_t ldg, const float* Gb, const float* lr_dev,
+                                const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
+                                float* coef_buf, void* workspace, size_t workspace_bytes,
+                                hipStream_t s);
+
 }  // namespace arx

@@ -22,6 +22,7 @@
 //      through LDS in a fixed order, apply Adagrad.
 // Zipf-heavy attribute tokens (thousands of duplicates) therefore cost
 // O(len / kPiece / 8) dependent loads instead of O(len).
+#include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/block/block_radix_sort.hpp>
@@ -54,6 +55,104 @@ __global__ void k_prep_keys(const int32_t* __restrict__ keys, int64_t n, uint32_
   }
 }
 
+// Stable rank sort for n <= 16384 keys, chip-wide in ONE launch: every workgroup keeps
+// the whole (normalised) key list in LDS (<= 64 KB); TPE lanes share one element and
+// count, each over a slice of the list, how many (key, index) pairs precede it; the
+// count IS the element's sorted position.  O(n^2 / CUs) integer compares with
+// ds_read_b128 -- a few microseconds at n = 5k -- instead of several dependent radix
+// passes by a single workgroup (15-27 us measured).
+template <int TPE>
+__global__ __launch_bounds__(256) void k_rank_sort(const int32_t* __restrict__ keys, int64_t n,
+                                                   uint32_t sentinel, uint32_t* __restrict__ sk,
+                                                   uint32_t* __restrict__ spos,
+                                                   int32_t* __restrict__ list_count) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t skeys[];
+  const int n4 = (int)((n + 3) & ~(int64_t)3);
+  // stage the key list: 8 independent loads in flight per thread (the loop is otherwise a
+  // chain of ~1 us L2 round trips: 22 us measured at n = 5k with one load per iteration)
+  for (int base = 0; base < n4; base += 256 * 8) {
+    int32_t r[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256 + threadIdx.x;
+      r[u] = (i < n) ? keys[i] : -2;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256 + threadIdx.x;
+      if (i < n4) {
+        uint32_t kk = 0xffffffffu;          // padding: greater than every real key
+        if (i < n)
+          kk = (r[u] == ARX_KEY_NONE || r[u] < 0 || (uint32_t)r[u] >= sentinel) ? sentinel
+                                                                                : (uint32_t)r[u];
+        skeys[i] = kk;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *list_count = 0;
+  __syncthreads();
+  constexpr int EPB = 256 / TPE;
+  const int e = blockIdx.x * EPB + threadIdx.x / TPE;
+  const int part = threadIdx.x % TPE;
+  const uint32_t ki = (e < n) ? skeys[e] : 0u;
+  int chunk = ((n4 / 4 + TPE - 1) / TPE) * 4;
+  if ((chunk & 63) == 0) chunk += 4;      // slices 256 B apart would all hit one LDS bank row
+  const int jb = min(n4, part * chunk);
+  const int je = min(n4, jb + chunk);
+  int cnt = 0;
+  for (int j = jb; j < je; j += 4) {
+    const uint4 v = *reinterpret_cast<const uint4*>(&skeys[j]);
+    cnt += (v.x < ki) || (v.x == ki && j < e);
+    cnt += (v.y < ki) || (v.y == ki && j + 1 < e);
+    cnt += (v.z < ki) || (v.z == ki && j + 2 < e);
+    cnt += (v.w < ki) || (v.w == ki && j + 3 < e);
+  }
+#pragma unroll
+  for (int o = TPE / 2; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, TPE);
+  if (part == 0 && e < n) {
+    sk[cnt] = ki;
+    spos[cnt] = (uint32_t)e;
+  }
+}
+
+static inline int launch_rank_sort(const int32_t* keys, int64_t n, uint32_t sentinel, uint32_t* sk,
+                                   uint32_t* spos, int32_t* count, hipStream_t s) {
+  static const int tpe = getenv("ARX_RANK_TPE") ? atoi(getenv("ARX_RANK_TPE")) : 16;
+  const size_t lds = (size_t)((n + 3) & ~(int64_t)3) * sizeof(uint32_t);
+  if (tpe == 32)
+    k_rank_sort<32><<<(int)ceil_div(n, 8), 256, lds, s>>>(keys, n, sentinel, sk, spos, count);
+  else if (tpe == 16)
+    k_rank_sort<16><<<(int)ceil_div(n, 16), 256, lds, s>>>(keys, n, sentinel, sk, spos, count);
+  else if (tpe == 4)
+    k_rank_sort<4><<<(int)ceil_div(n, 64), 256, lds, s>>>(keys, n, sentinel, sk, spos, count);
+  else
+    k_rank_sort<8><<<(int)ceil_div(n, 32), 256, lds, s>>>(keys, n, sentinel, sk, spos, count);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+// multi-site key generation (wide launch; the gathers are latency-bound)
+__global__ __launch_bounds__(256) void k_site_keys(CatSites st, int64_t table_rows,
+                                                   int32_t* __restrict__ keys,
+                                                   int32_t* __restrict__ src,
+                                                   float* __restrict__ coef) {
+  const int64_t n = st.offs[st.nsites];
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxSites; ++q)
+      if (q < st.nsites && i >= st.offs[q]) s = q;
+    const int64_t j = i - st.offs[s];
+    const int id = st.ids[s][j];
+    const int key = st.cat_map[s] ? st.cat_map[s][id] : id;
+    keys[i] = (key < 0 || key >= table_rows) ? ARX_KEY_NONE : key;
+    src[i] = st.row_base[s] + (int32_t)j;
+    coef[i] = st.coef[s];
+  }
+}
+
 // n <= 1024*IPT: key normalisation + stable (key, position) sort by ONE workgroup.
 template <int IPT>
 __global__ __launch_bounds__(1024) void k_small_sort(const int32_t* __restrict__ keys, int64_t n,
@@ -72,6 +171,52 @@ __global__ __launch_bounds__(1024) void k_small_sort(const int32_t* __restrict__
     if (idx < n) {
       const int32_t r = keys[idx];
       kk = (r == ARX_KEY_NONE || r < 0 || (uint32_t)r >= sentinel) ? sentinel : (uint32_t)r;
+    }
+    k[i] = kk;
+    v[i] = (uint32_t)idx;
+  }
+  Sort().sort(k, v, storage, 0, key_bits + 1);
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int64_t idx = (int64_t)threadIdx.x * IPT + i;
+    if (idx < n) {
+      sk[idx] = k[i];
+      spos[idx] = v[i];
+    }
+  }
+}
+
+// Same, with the key generation of up to 8 one-hot lookup sites folded in: the
+// workgroup gathers key = cat_map[id] itself and also emits the gradient-source row
+// and coefficient of every contribution (what arx_sparse_site_onehot would write).
+template <int IPT>
+__global__ __launch_bounds__(1024) void k_small_sort_sites(CatSites st, int64_t table_rows,
+                                                           uint32_t sentinel, int key_bits,
+                                                           uint32_t* __restrict__ sk,
+                                                           uint32_t* __restrict__ spos,
+                                                           int32_t* __restrict__ src_buf,
+                                                           float* __restrict__ coef_buf,
+                                                           int32_t* __restrict__ list_count) {
+  using Sort = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint32_t, 1, 1, 8>;
+  __shared__ typename Sort::storage_type storage;
+  if (threadIdx.x == 0) *list_count = 0;
+  const int64_t n = st.offs[st.nsites];
+  uint32_t k[IPT], v[IPT];
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int64_t idx = (int64_t)threadIdx.x * IPT + i;
+    uint32_t kk = sentinel;
+    if (idx < n) {
+      int s = 0;
+#pragma unroll
+      for (int q = 1; q < kMaxSites; ++q)
+        if (q < st.nsites && idx >= st.offs[q]) s = q;
+      const int64_t j = idx - st.offs[s];
+      const int id = st.ids[s][j];
+      const int key = st.cat_map[s] ? st.cat_map[s][id] : id;
+      kk = (key < 0 || key >= table_rows || (uint32_t)key >= sentinel) ? sentinel : (uint32_t)key;
+      src_buf[idx] = st.row_base[s] + (int32_t)j;
+      coef_buf[idx] = st.coef[s];
     }
     k[i] = kk;
     v[i] = (uint32_t)idx;
@@ -370,6 +515,77 @@ using namespace arx;
     default: { constexpr int LPR = 64; CALL; } break; \
   }
 
+namespace arx {
+
+int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_acc,
+                                int64_t table_rows, int d, const CatSites& st, const float* G,
+                                int64_t ldg, const float* Gb, const float* lr_dev,
+                                const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
+                                float* coef_buf, void* workspace, size_t workspace_bytes,
+                                hipStream_t s) {
+  (void)keys_buf;
+  const int64_t n = st.offs[st.nsites];
+  if (n == 0) return ARX_OK;
+  if (n > 16384) {
+    set_error("sparse_adagrad_sites_sorted: n=%lld > 16384", (long long)n);
+    return ARX_EUNSUPPORTED;
+  }
+  SparseWs w;
+  int rc = sparse_ws_layout(n, 256, &w);
+  if (rc) { set_error("arx_sparse_adagrad_cat: workspace layout failed"); return rc; }
+  if (!workspace || workspace_bytes < w.total) {
+    set_error("arx_sparse_adagrad_cat: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+    return ARX_EWORKSPACE;
+  }
+  int key_bits = 1;
+  while ((1ll << key_bits) < table_rows && key_bits < 30) ++key_bits;
+  const uint32_t sentinel = 1u << key_bits;
+  char* base = reinterpret_cast<char*>(workspace);
+  uint32_t* keys_out = reinterpret_cast<uint32_t*>(base + w.off_keys_out);
+  uint32_t* pos_out = reinterpret_cast<uint32_t*>(base + w.off_pos_out);
+  int32_t* list = reinterpret_cast<int32_t*>(base + w.off_list);
+  int32_t* count = reinterpret_cast<int32_t*>(base + w.off_count);
+  float* scratch = reinterpret_cast<float*>(base + w.off_scratch);
+  float* scratch_b = reinterpret_cast<float*>(base + w.off_scratch_b);
+  {
+    int64_t g = ceil_div(n, 256);
+    k_site_keys<<<(int)g, 256, 0, s>>>(st, table_rows, keys_buf, src_buf, coef_buf);
+    ARX_CHECK_LAUNCH();
+  }
+  rc = launch_rank_sort(keys_buf, n, sentinel, keys_out, pos_out, count, s);
+  if (rc) return rc;
+  const int lpr = lanes_per_row(d);
+  const int64_t nwaves = ceil_div(n, 64 / lpr);
+  const int grid_a = (int)ceil_div(nwaves, 4);
+  const float* gb_in = bias ? Gb : nullptr;
+#define ARX_LPR_CASE(L)                                                                          \
+  case L:                                                                                        \
+    k_sparse_pass_a<L><<<grid_a, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, pos_out,      \
+                                              src_buf, coef_buf, n, sentinel, G, ldg, gb_in,     \
+                                              lr_dev, gscale_dev, scratch, scratch_b, list,      \
+                                              count);                                            \
+    k_sparse_pass_b<L><<<kPassBBlocks, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, pos_out, \
+                                                    src_buf, coef_buf, n, G, ldg, gb_in, lr_dev, \
+                                                    gscale_dev, scratch, scratch_b, list, count); \
+    break;
+  switch (lpr) {
+    ARX_LPR_CASE(1) ARX_LPR_CASE(2) ARX_LPR_CASE(4) ARX_LPR_CASE(8) ARX_LPR_CASE(16)
+    ARX_LPR_CASE(32)
+    default:
+      k_sparse_pass_a<64><<<grid_a, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, pos_out,
+                                                 src_buf, coef_buf, n, sentinel, G, ldg, gb_in,
+                                                 lr_dev, gscale_dev, scratch, scratch_b, list, count);
+      k_sparse_pass_b<64><<<kPassBBlocks, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, pos_out,
+                                                       src_buf, coef_buf, n, G, ldg, gb_in, lr_dev,
+                                                       gscale_dev, scratch, scratch_b, list, count);
+  }
+#undef ARX_LPR_CASE
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+}  // namespace arx
+
 extern "C" {
 
 size_t arx_sparse_adagrad_workspace_bytes(int64_t n) {
@@ -416,13 +632,19 @@ int arx_sparse_adagrad(float* E, float* acc, float* bias, float* bias_acc, int d
   if (n <= 16384) {
     // id-only batches (B + S keys): one workgroup sorts everything in LDS -- a
     // single launch instead of the 5-6 of the device-wide radix sort.
-    if (n <= 4096)
-      k_small_sort<4><<<1, 1024, 0, s>>>(keys, n, sentinel, key_bits, keys_out, pos_out, count);
-    else if (n <= 8192)
-      k_small_sort<8><<<1, 1024, 0, s>>>(keys, n, sentinel, key_bits, keys_out, pos_out, count);
-    else
-      k_small_sort<16><<<1, 1024, 0, s>>>(keys, n, sentinel, key_bits, keys_out, pos_out, count);
-    ARX_CHECK_LAUNCH();
+    static const bool use_block_sort = getenv("ARX_BLOCK_SORT") != nullptr;   // A/B aid
+    if (!use_block_sort) {
+      rc = launch_rank_sort(keys, n, sentinel, keys_out, pos_out, count, s);
+      if (rc) return rc;
+    } else {
+      if (n <= 4096)
+        k_small_sort<4><<<1, 1024, 0, s>>>(keys, n, sentinel, key_bits, keys_out, pos_out, count);
+      else if (n <= 8192)
+        k_small_sort<8><<<1, 1024, 0, s>>>(keys, n, sentinel, key_bits, keys_out, pos_out, count);
+      else
+        k_small_sort<16><<<1, 1024, 0, s>>>(keys, n, sentinel, key_bits, keys_out, pos_out, count);
+      ARX_CHECK_LAUNCH();
+    }
   } else {
     int64_t g = ceil_div(n, 256);
     int64_t cap = (int64_t)cu_count() * 8;

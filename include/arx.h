@@ -206,6 +206,32 @@ int arx_sparse_adagrad(float* E, float* acc, float* bias, float* bias_acc, int d
                        const float* lr_dev, const float* gscale_dev, int key_bits,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Fast path of the above for one-hot lookups with few contributions (id-only batches:
+ * n = sum(site_n) <= ~64 k).  The lookup sites are described directly -- site s
+ * contributes, for j < site_n[s]: key = site_cat_map[s] ? site_cat_map[s][ids[j]] : ids[j],
+ * gradient row G[site_row_base[s] + j] (and Gb[...]), factor site_coef[s] -- so no
+ * separate key-generation launches and no sort: integer atomics elect the first
+ * contribution of every row as its leader, which sums its duplicates in
+ * contribution order (bit-deterministic) and applies Adagrad once.
+ * Rows with more than 16 duplicates ("hot", e.g. Zipf-popular targets) are summed by
+ * a whole workgroup each in a third launch.
+ * aux_first / aux_cnt: caller-owned int32[table_rows], initialised to INT_MAX / 0
+ * once; aux_hot: int32[aux_hot_len >= 3] zero-initialised once (hot-row list, sized
+ * n/16 + 2); the kernels leave all three clean.  keys/src/coef_buf: [n].
+ * mode 0 (default): for n <= 16384 the key generation is folded into a
+ * single-workgroup LDS radix sort followed by the two Adagrad passes of
+ * arx_sparse_adagrad (workspace >= arx_sparse_adagrad_workspace_bytes(n)) -- 3
+ * launches, no atomics; larger n and mode 1 use the atomic leader election above. */
+int arx_sparse_adagrad_cat(float* E, float* acc, float* bias, float* bias_acc, int64_t table_rows,
+                           int d, int nsites, const int32_t* const* site_cat_map,
+                           const int32_t* const* site_ids, const int64_t* site_n,
+                           const int32_t* site_row_base, const float* site_coef,
+                           const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
+                           const float* gscale_dev, int32_t* aux_first, int32_t* aux_cnt,
+                           int32_t* aux_hot, int64_t aux_hot_len, int32_t* keys_buf,
+                           int32_t* src_buf, float* coef_buf, int mode, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* ---- a16/a19: dense Adagrad, norms, clip ---------------------------------
  * tf.train.AdagradOptimizer dense apply; tf.clip_by_global_norm
  * (seqModel.py:180): coef = max_norm / max(sqrt(sq), max_norm). */

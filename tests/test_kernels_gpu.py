@@ -518,3 +518,62 @@ def test_gemm_rowsum(dev, tA, M, N, K):
     ops.gemm(_t(dev, A), _t(dev, Bm), C, ops.Workspace(dev), transA=tA, a_rowsum=rs)
     np.testing.assert_allclose(rs.cpu().numpy(), opA.astype(np.float64).sum(1), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(C.cpu().numpy(), opA.astype(np.float64) @ Bm, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("d,Vf,ns", [(128, 5000, (4096, 1024)), (32, 40, (300, 17, 64)), (64, 100000, (64,))])
+def test_sparse_adagrad_cat_fast_path(dev, d, Vf, ns):
+    """Sort-free one-hot path == reference semantics (duplicates summed, one update per
+    row), bit-deterministic, leaves its aux arrays clean."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(d + Vf)
+    E = rng.standard_normal((Vf, d)).astype(np.float32)
+    acc = (0.1 + rng.random((Vf, d))).astype(np.float32)
+    bias = rng.standard_normal((Vf,)).astype(np.float32)
+    bacc = np.full((Vf,), 0.1, dtype=np.float32)
+    N = 3 * Vf
+    sites, keys, src, coef = [], [], [], []
+    base = 0
+    m = sum(ns)
+    G = rng.standard_normal((m, d)).astype(np.float32)
+    Gb = rng.standard_normal((m,)).astype(np.float32)
+    for k, n in enumerate(ns):
+        cmap = rng.integers(0, Vf, size=N).astype(np.int32) if k % 2 == 0 else None
+        hi = N if cmap is not None else Vf
+        ids = rng.integers(0, hi, size=n).astype(np.int32)
+        if n > 40:
+            ids[rng.choice(n, size=n // 3, replace=False)] = ids[0]       # a hot row
+        c = float(rng.random() + 0.5)
+        sites.append((_t(dev, cmap) if cmap is not None else None, None, _t(dev, ids), base, c))
+        keys.append(cmap[ids] if cmap is not None else ids)
+        src.append(base + np.arange(n))
+        coef.append(np.full(n, c, dtype=np.float32))
+        base += n
+    keys, src, coef = np.concatenate(keys), np.concatenate(src).astype(np.int32), np.concatenate(coef)
+    rE, racc, rb, rbacc = _ref_sparse_adagrad(E, acc, bias, bacc, keys, src, coef, G, Gb, 0.3, 0.7)
+    lr = torch.tensor([0.3], dtype=torch.float32, device=dev)
+    gs = torch.tensor([0.7], dtype=torch.float32, device=dev)
+    first = torch.full((Vf,), 2 ** 31 - 1, dtype=torch.int32, device=dev)
+    cnt = torch.zeros((Vf,), dtype=torch.int32, device=dev)
+    args = ops.CatSiteArgs(sites)
+    hot = torch.zeros(m // 16 + 4, dtype=torch.int32, device=dev)
+    outs = []
+    ws = ops.Workspace(dev)
+    for rep in range(4):                     # mode 1 (atomic election) twice, mode 0 (fused sort) twice
+        mode = 1 if rep < 2 else 0
+        tE, tacc, tb, tbacc = _t(dev, E), _t(dev, acc), _t(dev, bias), _t(dev, bacc)
+        kb = torch.empty(m, dtype=torch.int32, device=dev)
+        sb = torch.empty(m, dtype=torch.int32, device=dev)
+        cb = torch.empty(m, dtype=torch.float32, device=dev)
+        ops.sparse_adagrad_cat(tE, tacc, tb, tbacc, args, _t(dev, G), _t(dev, Gb), lr, first, cnt,
+                               hot, kb, sb, cb, ws, gscale_dev=gs, mode=mode)
+        torch.cuda.synchronize()
+        outs.append((tE, tacc, tb))
+        assert int((first != 2 ** 31 - 1).sum().item()) == 0 and int(cnt.abs().sum().item()) == 0
+        assert int(hot[:2].abs().sum().item()) == 0
+    for o in (outs[0], outs[2]):
+        np.testing.assert_allclose(o[1].cpu().numpy(), racc, rtol=2e-4, atol=1e-5)
+        np.testing.assert_allclose(o[0].cpu().numpy(), rE, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(o[2].cpu().numpy(), rb, rtol=2e-4, atol=2e-5)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[2][0], outs[3][0]) and torch.equal(outs[2][1], outs[3][1])
