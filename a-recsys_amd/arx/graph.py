@@ -246,9 +246,13 @@ class Prediction(Node):
             ops.gemm(dl, pool.value, g, self.rt.ws, beta=latent.grad_beta())     # dU = dL . Ibar
         if pool.train_tables:
             gp = pool.alloc_grad()
-            # dIbar = dL^T . U ; dbbar = rowsum(dL^T) rides in the same kernel
-            ops.gemm(dl, latent.value, gp, self.rt.ws, transA=True, beta=pool.grad_beta(),
+            beta = pool.grad_beta()
+            # dIbar = dL^T . U ; dbbar = rowsum(dL^T) rides in the same kernel.  Independent
+            # of the dU GEMM above: runs on a side branch, joined before the optimiser.
+            tok = self.rt.fork(0)
+            ops.gemm(dl, latent.value, gp, self.rt.ws, transA=True, beta=beta,
                      a_rowsum=pool.bias_grad)
+            self.rt._pending.append(self.rt.end_fork(tok))
             pool.bias_grad_used = True
 
 
@@ -472,12 +476,29 @@ class Plan(object):
             n._grad_written = False
             if isinstance(n, EntityEmbed):
                 n.bias_grad_used = False
-        for n in self.order:
+        # lookups whose ids are placeholders are independent of each other: fork them
+        roots = [n for n in self.order if isinstance(n, EntityEmbed) and type(n.inputs[0]).__name__ in
+                 ('IdsInput', 'IdsView')]
+        toks = []
+        for k, n in enumerate(roots[1:]):
+            t = rt.fork(k)
             n.forward(self.train)
+            toks.append(rt.end_fork(t))
+        for n in self.order:
+            if n in roots[1:]:
+                continue
+            n.forward(self.train)
+            if roots and n is roots[0]:
+                for t in toks:
+                    rt.join(t)
         if self.train:
+            rt._pending = []
             for n in reversed(self.order):
                 if n.requires_grad and n._grad_written:
                     n.backward()
+            for t in rt._pending:
+                rt.join(t)
+            rt._pending = []
             rt.pre_apply(self)
             self._apply_sparse()
             rt.apply_dense(self)
@@ -487,7 +508,18 @@ class Plan(object):
 
     def _apply_sparse(self):
         rt = self.rt
-        for table, sites, bufs, total in self.tables:
+        toks = []
+        for ti, entry in enumerate(self.tables):
+            tok = rt.fork(ti) if ti > 0 else None          # tables are independent
+            self._apply_one(entry)
+            if tok is not None:
+                toks.append(rt.end_fork(tok))
+        for t in toks:
+            rt.join(t)
+
+    def _apply_one(self, entry):
+        rt = self.rt
+        for table, sites, bufs, total in (entry,):
             live_sites = [s for s in sites if s.node._grad_written]
             if not live_sites:
                 continue
@@ -587,6 +619,49 @@ class Runtime(object):
         import os as _os
         self.force_sort_path = bool(_os.environ.get('ARX_FORCE_SORT'))
         self.cat_mode = 1 if _os.environ.get('ARX_CAT_ATOMIC') else 0
+        # fork/join branches inside the captured graph measured SLOWER on ROCm 7.2 (250 us vs
+        # 187 us per C2 step: cross-stream graph edges cost more than the overlap buys at
+        # these kernel sizes) -- opt-in only.
+        self.use_streams = bool(_os.environ.get('ARX_STREAMS'))
+        self._side = None
+        self._side_ws = None
+        self._pending = []
+
+    # ---- fork/join onto side streams: independent branches of a step (the lookups of
+    # different entities, the dU / dI GEMMs, the per-table sparse updates) run
+    # concurrently; captured into the hipGraph the forks become parallel graph edges.
+    def fork(self, k):
+        """Start side branch k: returns a token for join().  Work issued until the
+        matching end_fork() goes to side stream k with its own workspace."""
+        if not self.use_streams:
+            return None
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+            self._side_ws = [ops.Workspace(self.device) for _ in range(3)]
+        k = k % len(self._side)
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._side[k].wait_event(ev)
+        ctx = torch.cuda.stream(self._side[k])
+        ctx.__enter__()
+        tok = {'k': k, 'ctx': ctx, 'ws': self.ws, 'main': main}
+        self.ws = self._side_ws[k]
+        return tok
+
+    def end_fork(self, tok):
+        if tok is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self._side[tok['k']])
+        tok['ctx'].__exit__(None, None, None)
+        self.ws = tok['ws']
+        tok['done'] = ev
+        return tok
+
+    def join(self, tok):
+        if tok is not None:
+            torch.cuda.current_stream().wait_event(tok['done'])
 
     def set_learning_rate(self, v):
         self.lr_host = float(v)

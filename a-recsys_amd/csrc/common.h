@@ -75,7 +75,7 @@ int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_a
                                 int64_t table_rows, int d, const CatSites& st, const float* G,
                                 int64_t ldg, const float* Gb, const float* lr_dev,
                                 const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
-                                float* coef_buf, void* workspace, size_t workspace_bytes,
-                                hipStream_t s);
+                                float* coef_buf, int32_t* aux_cnt, void* workspace,
+                                size_t workspace_bytes, hipStream_t s);
 
 }  // namespace arx

@@ -16,6 +16,8 @@
 //        consecutive floats, conflict-free; stores are aligned ds_write_b128.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace arx {
@@ -45,14 +47,25 @@ __device__ __forceinline__ float4 load4_guard(const float* p, int nvalid, bool v
 // Stage one operand tile (ROWS x BK) from HBM into registers.
 //   KC : element (r,k) at X[(r0+r)*ld + k0+k]   -> float4 along k
 //   !KC: element (r,k) at X[(k0+k)*ld + r0+r]   -> float4 along r
-template <int ROWS, int BK, bool KC, int NL>
+template <int ROWS, int BK, bool KC, int NL, bool FAST>
 __device__ __forceinline__ void tile_load(const float* __restrict__ X, int64_t ld, int64_t r0,
                                           int64_t R, int64_t k0, int64_t kend, bool vec_ok,
                                           float4 (&reg)[NL]) {
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const int f = threadIdx.x + i * 256;
-    if (KC) {
+    if (FAST) {
+      // interior tile, aligned: plain 16-B loads with no select on the result, so the
+      // compiler can leave them in flight across the MFMA block (the guarded form forces
+      // s_waitcnt vmcnt(0) right behind the loads: 3-4x slower, measured)
+      if (KC) {
+        const int r = f / (BK / 4), kq = f % (BK / 4);
+        reg[i] = *reinterpret_cast<const float4*>(X + (r0 + r) * ld + k0 + kq * 4);
+      } else {
+        const int k = f / (ROWS / 4), rq = f % (ROWS / 4);
+        reg[i] = *reinterpret_cast<const float4*>(X + (k0 + k) * ld + r0 + rq * 4);
+      }
+    } else if (KC) {
       const int r = f / (BK / 4), kq = f % (BK / 4);
       const int64_t gr = r0 + r, gk = k0 + kq * 4;
       int nv = (gr < R) ? (int)min((int64_t)4, kend - gk) : 0;
@@ -131,11 +144,15 @@ __global__ __launch_bounds__(256) void k_gemm_f32(
 
   const bool want_rs = (a_rowsum != nullptr) && (tn == 0) && ((int)threadIdx.x < BM);
   float rs = 0.f;
-  float4 ra[NLA], rb[NLB];
   const int64_t nt = (kend > kbeg) ? ceil_div(kend - kbeg, (int64_t)BK) : 0;
+  const bool fast = vec_a && vec_b && (m0 + BM <= M) && (n0 + BN <= N) &&
+                    (kend > kbeg) && ((kend - kbeg) % BK == 0);
+  auto mainloop = [&](auto fast_c) {
+  constexpr bool FAST = decltype(fast_c)::value;
+  float4 ra[NLA], rb[NLB];
   if (nt > 0) {
-    tile_load<BM, BK, A_KC, NLA>(A, lda, m0, M, kbeg, kend, vec_a, ra);
-    tile_load<BN, BK, B_KC, NLB>(B, ldb, n0, N, kbeg, kend, vec_b, rb);
+    tile_load<BM, BK, A_KC, NLA, FAST>(A, lda, m0, M, kbeg, kend, vec_a, ra);
+    tile_load<BN, BK, B_KC, NLB, FAST>(B, ldb, n0, N, kbeg, kend, vec_b, rb);
     tile_store<BM, BK, A_KC, NLA>(sA[0], ra);
     tile_store<BN, BK, B_KC, NLB>(sB[0], rb);
   }
@@ -144,8 +161,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(
     const int cur = (int)(t & 1);
     if (t + 1 < nt) {
       const int64_t k0 = kbeg + (t + 1) * BK;
-      tile_load<BM, BK, A_KC, NLA>(A, lda, m0, M, k0, kend, vec_a, ra);
-      tile_load<BN, BK, B_KC, NLB>(B, ldb, n0, N, k0, kend, vec_b, rb);
+      tile_load<BM, BK, A_KC, NLA, FAST>(A, lda, m0, M, k0, kend, vec_a, ra);
+      tile_load<BN, BK, B_KC, NLB, FAST>(B, ldb, n0, N, k0, kend, vec_b, rb);
     }
     const float* a_s = sA[cur];
     const float* b_s = sB[cur];
@@ -172,6 +189,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32(
     }
     __syncthreads();
   }
+  };
+  if (fast) mainloop(std::true_type{});
+  else mainloop(std::false_type{});
 
   if (want_rs && m0 + threadIdx.x < M) {
     if (rowsum_partial) rowsum_partial[(int64_t)blockIdx.z * M + m0 + threadIdx.x] = rs;
@@ -252,20 +272,19 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     int64_t s = want < maxs ? want : maxs;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
-    int64_t chunk = ceil_div(ceil_div(K, s), 16) * 16;
-    if (chunk < 16) chunk = 16;
+    int64_t chunk = ceil_div(ceil_div(K, s), 64) * 64;
+    if (chunk < 64) chunk = 64;
     p.kchunk = chunk;
     p.splits = (int)ceil_div(K > 0 ? K : 1, chunk);
   }
   return p;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 static int launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                        const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
                        float* C, int64_t ldc, const float* col_bias, float* partial,
                        const GemmPlan& p, hipStream_t s, float* a_rowsum, float* rowsum_partial) {
-  constexpr int BK = 16;
   const int tiles_m = (int)ceil_div(M, BM), tiles_n = (int)ceil_div(N, BN);
   dim3 grid(tiles_m * tiles_n, 1, p.splits);
   const int vec_a = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
@@ -321,12 +340,20 @@ int arx_gemm_f32_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K,
     if (a_rowsum) rs_partial = partial + (size_t)p.splits * (size_t)M * (size_t)N;
   }
   int rc;
-  if (p.big)
-    rc = launch_gemm<128, 128>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
-                               col_bias, partial, p, s, a_rowsum, rs_partial);
-  else
-    rc = launch_gemm<64, 64>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
-                             col_bias, partial, p, s, a_rowsum, rs_partial);
+  static const int bk_big = getenv("ARX_GEMM_BK_BIG") ? atoi(getenv("ARX_GEMM_BK_BIG")) : 16;
+  static const int bk_small = getenv("ARX_GEMM_BK_SMALL") ? atoi(getenv("ARX_GEMM_BK_SMALL")) : 16;
+#define ARX_GO(BM_, BN_, BK_)                                                                   \
+  rc = launch_gemm<BM_, BN_, BK_>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
+                                  col_bias, partial, p, s, a_rowsum, rs_partial)
+  if (p.big) {
+    if (bk_big == 32) ARX_GO(128, 128, 32);
+    else ARX_GO(128, 128, 16);
+  } else {
+    if (bk_small == 64) ARX_GO(64, 64, 64);
+    else if (bk_small == 32) ARX_GO(64, 64, 32);
+    else ARX_GO(64, 64, 16);
+  }
+#undef ARX_GO
   if (rc) return rc;
   if (partial) {
     int64_t total = M * N;
@@ -354,7 +381,7 @@ int arx_gemm_f32_steps_tn(int64_t steps, int64_t M, int64_t N, int64_t Kb, const
   p.big = false;
   p.splits = (int)steps;
   p.kchunk = Kb;
-  int rc = launch_gemm<64, 64>(1, 0, M, N, steps * Kb, 1.f, A, lda, B, ldb, 0.f, C_steps, N,
+  int rc = launch_gemm<64, 64, 16>(1, 0, M, N, steps * Kb, 1.f, A, lda, B, ldb, 0.f, C_steps, N,
                                nullptr, C_steps, p, s, rowsum_steps ? rowsum_steps : nullptr,
                                rowsum_steps);
   if (rc) return rc;

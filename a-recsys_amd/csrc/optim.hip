@@ -65,7 +65,11 @@ template <int TPE>
 __global__ __launch_bounds__(256) void k_rank_sort(const int32_t* __restrict__ keys, int64_t n,
                                                    uint32_t sentinel, uint32_t* __restrict__ sk,
                                                    uint32_t* __restrict__ spos,
-                                                   int32_t* __restrict__ list_count) {
+                                                   int32_t* __restrict__ list_count,
+                                                   const int32_t* __restrict__ src_in,
+                                                   const float* __restrict__ coef_in,
+                                                   int32_t* __restrict__ ssrc,
+                                                   float* __restrict__ scoef) {
   extern __shared__ __attribute__((aligned(16))) uint32_t skeys[];
   const int n4 = (int)((n + 3) & ~(int64_t)3);
   // stage the key list: 8 independent loads in flight per thread (the loop is otherwise a
@@ -112,21 +116,31 @@ __global__ __launch_bounds__(256) void k_rank_sort(const int32_t* __restrict__ k
   if (part == 0 && e < n) {
     sk[cnt] = ki;
     spos[cnt] = (uint32_t)e;
+    if (ssrc) {   // gradient-source row and coefficient in sorted order: one hop less in the apply pass
+      ssrc[cnt] = src_in ? src_in[e] : e;
+      scoef[cnt] = coef_in ? coef_in[e] : 1.f;
+    }
   }
 }
 
 static inline int launch_rank_sort(const int32_t* keys, int64_t n, uint32_t sentinel, uint32_t* sk,
-                                   uint32_t* spos, int32_t* count, hipStream_t s) {
+                                   uint32_t* spos, int32_t* count, hipStream_t s,
+                                   const int32_t* src_in = nullptr, const float* coef_in = nullptr,
+                                   int32_t* ssrc = nullptr, float* scoef = nullptr) {
   static const int tpe = getenv("ARX_RANK_TPE") ? atoi(getenv("ARX_RANK_TPE")) : 16;
   const size_t lds = (size_t)((n + 3) & ~(int64_t)3) * sizeof(uint32_t);
   if (tpe == 32)
-    k_rank_sort<32><<<(int)ceil_div(n, 8), 256, lds, s>>>(keys, n, sentinel, sk, spos, count);
+    k_rank_sort<32><<<(int)ceil_div(n, 8), 256, lds, s>>>(keys, n, sentinel, sk, spos, count, src_in,
+                                                              coef_in, ssrc, scoef);
   else if (tpe == 16)
-    k_rank_sort<16><<<(int)ceil_div(n, 16), 256, lds, s>>>(keys, n, sentinel, sk, spos, count);
+    k_rank_sort<16><<<(int)ceil_div(n, 16), 256, lds, s>>>(keys, n, sentinel, sk, spos, count, src_in,
+                                                              coef_in, ssrc, scoef);
   else if (tpe == 4)
-    k_rank_sort<4><<<(int)ceil_div(n, 64), 256, lds, s>>>(keys, n, sentinel, sk, spos, count);
+    k_rank_sort<4><<<(int)ceil_div(n, 64), 256, lds, s>>>(keys, n, sentinel, sk, spos, count, src_in,
+                                                              coef_in, ssrc, scoef);
   else
-    k_rank_sort<8><<<(int)ceil_div(n, 32), 256, lds, s>>>(keys, n, sentinel, sk, spos, count);
+    k_rank_sort<8><<<(int)ceil_div(n, 32), 256, lds, s>>>(keys, n, sentinel, sk, spos, count, src_in,
+                                                              coef_in, ssrc, scoef);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
@@ -258,7 +272,7 @@ __device__ __forceinline__ int walk_piece(const uint32_t* __restrict__ sk,
     int mysrc = 0;
     float mycoef = 0.f;
     if (lig < cnt) {
-      const uint32_t i = spos[p];
+      const uint32_t i = spos ? spos[p] : (uint32_t)p;   // null: src/coef already in sorted order
       mysrc = src ? src[i] : (int32_t)i;
       mycoef = coef ? coef[i] : 1.f;
       if (Gb) gb = fmaf(mycoef, Gb[mysrc], gb);
@@ -415,6 +429,94 @@ __global__ __launch_bounds__(256) void k_sparse_pass_b(
   }
 }
 
+// Small-n variant without the second launch: multi-piece runs are finished by their LAST
+// arriving piece (ticket on a per-table-row counter).  Every piece of such a run writes
+// its partial row, releases (agent scope), and adds 1 to cnt[key]; the head adds
+// 1 + (kBig - T) with T = pieces of the run (binary search over the aligned positions), so
+// the arrival that makes the counter reach kBig knows all T partials are published: it
+// acquires, sums them in piece order (fixed order => deterministic) and applies Adagrad.
+constexpr int kBig = 1 << 30;
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_sparse_onepass(
+    float* __restrict__ E, float* __restrict__ acc, float* __restrict__ bias,
+    float* __restrict__ bias_acc, int d, const uint32_t* __restrict__ sk,
+    const int32_t* __restrict__ ssrc, const float* __restrict__ scoef, int64_t n, uint32_t sentinel,
+    const float* __restrict__ G, int64_t ldg, const float* __restrict__ Gb,
+    const float* __restrict__ lr_dev, const float* __restrict__ gscale_dev,
+    float* __restrict__ scratch, float* __restrict__ scratch_b, float* __restrict__ scratch_h,
+    float* __restrict__ scratch_hb, int32_t* __restrict__ cnt) {
+  constexpr int GPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % LPR;
+  const int gid = lane / LPR;
+  const int col = lig * 4;
+  const bool colok = col < d;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t q = wave * GPW + gid;
+  if (q >= n) return;
+  const uint32_t key = sk[q];
+  if (key >= sentinel) return;
+  const bool head = (q == 0) || (sk[q - 1] != key);
+  const bool aligned = (q % kPiece) == 0;
+  if (!head && !aligned) return;
+  int64_t pend = (q / kPiece + 1) * kPiece;
+  if (pend > n) pend = n;
+  float4 g;
+  float gb;
+  const int consumed = walk_piece<LPR>(sk, nullptr, ssrc, scoef, G, ldg, Gb, key, q, pend, col, colok,
+                                       lig, gid, g, gb);
+  const int64_t e = q + consumed;
+  const bool continues = (e == pend) && (e < n) && (sk[e] == key);
+  const float lr = *lr_dev;
+  const float gs = gscale_dev ? *gscale_dev : 1.f;
+  if (head && !continues) {
+    adagrad_row(E, acc, bias, bias_acc, d, key, col, colok, lig, g, gb, lr, gs);
+    return;
+  }
+  // ---- piece of a multi-piece run ----
+  const int64_t slot = q / kPiece;
+  float* prow = (head ? scratch_h : scratch) + slot * (int64_t)d;
+  if (colok) *reinterpret_cast<float4*>(prow + col) = g;
+  if (lig == 0) (head ? scratch_hb : scratch_b)[slot] = gb;
+  __threadfence();                                   // release the partial (agent scope)
+  int inc = 1;
+  if (head) {
+    const int64_t first = (q / kPiece + 1) * kPiece;
+    int64_t lo = 0, hi = (n - 1 - first) / kPiece;   // sk[first + lo*kPiece] == key (continues)
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (sk[first + mid * kPiece] == key) lo = mid; else hi = mid - 1;
+    }
+    inc = 1 + (kBig - (int)(lo + 2));                // T = head piece + (lo + 1) aligned pieces
+  }
+  int old = 0;
+  if (lig == 0) old = atomicAdd(&cnt[key], inc);
+  old = __shfl(old, 0, LPR);
+  if (old + inc != kBig) return;
+  __threadfence();                                   // acquire: drop stale L1 lines
+  int64_t h = q;
+  if (!head) {                                       // lower bound of key in sk[0..q]
+    int64_t lo = 0, hi = q;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (sk[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    h = lo;
+  }
+  const int64_t ch = h / kPiece;
+  float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (colok) tot = *reinterpret_cast<const float4*>(scratch_h + ch * (int64_t)d + col);
+  float tb = scratch_hb[ch];
+  for (int64_t a = (ch + 1) * kPiece; a < n && sk[a] == key; a += kPiece) {
+    const int64_t sl = a / kPiece;
+    if (colok) tot = f4_add2(tot, *reinterpret_cast<const float4*>(scratch + sl * (int64_t)d + col));
+    tb += scratch_b[sl];
+  }
+  adagrad_row(E, acc, bias, bias_acc, d, key, col, colok, lig, tot, tb, lr, gs);
+  if (lig == 0) cnt[key] = 0;
+}
+
 __global__ void k_adagrad_dense(float* __restrict__ w, float* __restrict__ acc,
                                 const float* __restrict__ g, int64_t n,
                                 const float* __restrict__ lr_dev,
@@ -473,7 +575,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct SparseWs {
   size_t off_keys_tmp, off_keys_out, off_pos_in, off_pos_out, off_list, off_count, off_scratch,
-      off_scratch_b, off_temp, temp_bytes, total;
+      off_scratch_b, off_scratch_h, off_scratch_hb, off_ssrc, off_scoef, off_temp, temp_bytes, total;
 };
 
 static int sparse_ws_layout(int64_t n, int d, SparseWs* w) {
@@ -494,6 +596,10 @@ static int sparse_ws_layout(int64_t n, int d, SparseWs* w) {
   w->off_count = o; o += 256;
   w->off_scratch = o; o += align_up(pieces * (size_t)d * 4, 256);
   w->off_scratch_b = o; o += align_up(pieces * 4, 256);
+  w->off_scratch_h = o; o += align_up(pieces * (size_t)d * 4, 256);
+  w->off_scratch_hb = o; o += align_up(pieces * 4, 256);
+  w->off_ssrc = o; o += ni;
+  w->off_scoef = o; o += ni;
   w->off_temp = o; o += align_up(temp, 256);
   w->temp_bytes = temp;
   w->total = o;
@@ -521,9 +627,8 @@ int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_a
                                 int64_t table_rows, int d, const CatSites& st, const float* G,
                                 int64_t ldg, const float* Gb, const float* lr_dev,
                                 const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
-                                float* coef_buf, void* workspace, size_t workspace_bytes,
-                                hipStream_t s) {
-  (void)keys_buf;
+                                float* coef_buf, int32_t* aux_cnt, void* workspace,
+                                size_t workspace_bytes, hipStream_t s) {
   const int64_t n = st.offs[st.nsites];
   if (n == 0) return ARX_OK;
   if (n > 16384) {
@@ -552,32 +657,31 @@ int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_a
     k_site_keys<<<(int)g, 256, 0, s>>>(st, table_rows, keys_buf, src_buf, coef_buf);
     ARX_CHECK_LAUNCH();
   }
-  rc = launch_rank_sort(keys_buf, n, sentinel, keys_out, pos_out, count, s);
+  int32_t* ssrc = reinterpret_cast<int32_t*>(base + w.off_ssrc);
+  float* scoef = reinterpret_cast<float*>(base + w.off_scoef);
+  float* scratch_h = reinterpret_cast<float*>(base + w.off_scratch_h);
+  float* scratch_hb = reinterpret_cast<float*>(base + w.off_scratch_hb);
+  rc = launch_rank_sort(keys_buf, n, sentinel, keys_out, pos_out, count, s, src_buf, coef_buf, ssrc,
+                        scoef);
   if (rc) return rc;
   const int lpr = lanes_per_row(d);
   const int64_t nwaves = ceil_div(n, 64 / lpr);
   const int grid_a = (int)ceil_div(nwaves, 4);
   const float* gb_in = bias ? Gb : nullptr;
-#define ARX_LPR_CASE(L)                                                                          \
-  case L:                                                                                        \
-    k_sparse_pass_a<L><<<grid_a, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, pos_out,      \
-                                              src_buf, coef_buf, n, sentinel, G, ldg, gb_in,     \
-                                              lr_dev, gscale_dev, scratch, scratch_b, list,      \
-                                              count);                                            \
-    k_sparse_pass_b<L><<<kPassBBlocks, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, pos_out, \
-                                                    src_buf, coef_buf, n, G, ldg, gb_in, lr_dev, \
-                                                    gscale_dev, scratch, scratch_b, list, count); \
+  (void)list;
+#define ARX_LPR_CASE(L)                                                                            \
+  case L:                                                                                          \
+    k_sparse_onepass<L><<<grid_a, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, ssrc, scoef, n, \
+                                               sentinel, G, ldg, gb_in, lr_dev, gscale_dev, scratch, \
+                                               scratch_b, scratch_h, scratch_hb, aux_cnt);         \
     break;
   switch (lpr) {
     ARX_LPR_CASE(1) ARX_LPR_CASE(2) ARX_LPR_CASE(4) ARX_LPR_CASE(8) ARX_LPR_CASE(16)
     ARX_LPR_CASE(32)
     default:
-      k_sparse_pass_a<64><<<grid_a, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, pos_out,
-                                                 src_buf, coef_buf, n, sentinel, G, ldg, gb_in,
-                                                 lr_dev, gscale_dev, scratch, scratch_b, list, count);
-      k_sparse_pass_b<64><<<kPassBBlocks, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, pos_out,
-                                                       src_buf, coef_buf, n, G, ldg, gb_in, lr_dev,
-                                                       gscale_dev, scratch, scratch_b, list, count);
+      k_sparse_onepass<64><<<grid_a, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, ssrc, scoef, n,
+                                                  sentinel, G, ldg, gb_in, lr_dev, gscale_dev, scratch,
+                                                  scratch_b, scratch_h, scratch_hb, aux_cnt);
   }
 #undef ARX_LPR_CASE
   ARX_CHECK_LAUNCH();

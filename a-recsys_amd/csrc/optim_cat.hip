@@ -310,8 +310,8 @@ int arx_sparse_adagrad_cat(float* E, float* acc, float* bias, float* bias_acc, i
   hipStream_t s = as_stream(stream);
   if (mode == 0 && n <= 16384)   // default: fused key generation + LDS sort + the two passes
     return sparse_adagrad_sites_sorted(E, acc, bias, bias_acc, table_rows, d, st, G, ldg, Gb,
-                                       lr_dev, gscale_dev, keys_buf, src_buf, coef_buf, workspace,
-                                       workspace_bytes, s);
+                                       lr_dev, gscale_dev, keys_buf, src_buf, coef_buf, aux_cnt,
+                                       workspace, workspace_bytes, s);
   {
     int64_t g = ceil_div(n, 256);
     int64_t cap = (int64_t)cu_count() * 8;

@@ -1,0 +1,20 @@
+import sys, os
+sys.path.insert(0, '/root/repo/a-recsys_amd'); sys.path.insert(0, '/root/repo')
+import torch
+from arx import ops
+dev = torch.device('cuda:0')
+ws = ops.Workspace(dev)
+def t(fn, it=100):
+    for _ in range(5): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(it): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / it * 1e3
+B, S, d = 4096, 1024, 128
+U = torch.randn(B, d, device=dev); I = torch.randn(S, d, device=dev); L = torch.empty(B, S, device=dev)
+dL = torch.randn(B, S, device=dev); dU = torch.empty(B, d, device=dev); dI = torch.empty(S, d, device=dev)
+tag = 'big=%s small=%s force=%s' % (os.environ.get('ARX_GEMM_BK_BIG'), os.environ.get('ARX_GEMM_BK_SMALL'), os.environ.get('ARX_GEMM_FORCE'))
+print(tag, 'logits %.1f us' % t(lambda: ops.gemm(U, I, L, ws, transB=True)),
+      'dU %.1f us' % t(lambda: ops.gemm(dL, I, dU, ws)),
+      'dI %.1f us' % t(lambda: ops.gemm(dL, U, dI, ws, transA=True)))
