@@ -66,6 +66,8 @@ PROTOTYPES = {
     "arx_sparse_adagrad_workspace_bytes": (sz, [i64]),
     "arx_sparse_adagrad": (cint, [f32p, f32p, f32p, f32p, cint, i32p, i32p, f32p, i64, f32p, i64,
                                   f32p, f32p, f32p, cint, vp, sz, vp]),
+    "arx_sparse_adagrad_ticket": (cint, [f32p, f32p, f32p, f32p, cint, i32p, i32p, f32p, i64, f32p,
+                                         i64, f32p, f32p, f32p, cint, i32p, vp, sz, vp]),
     "arx_sparse_adagrad_cat": (cint, [f32p, f32p, f32p, f32p, i64, cint, cint, C.POINTER(vp),
                                       C.POINTER(vp), C.POINTER(i64), C.POINTER(i32),
                                       C.POINTER(f32), f32p, i64, f32p, f32p, f32p, i32p, i32p,

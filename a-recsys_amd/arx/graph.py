@@ -524,7 +524,7 @@ class Plan(object):
             if not live_sites:
                 continue
             n_live = sum(s.n for s in live_sites)
-            if all(s.kind == 'cat' and s.col_off == 0 for s in live_sites) and n_live <= 65536 \
+            if all(s.kind == 'cat' and s.col_off == 0 for s in live_sites) and n_live <= (1 << 22) \
                     and len(live_sites) <= 8 and not rt.force_sort_path:
                 # one-hot lookups, few contributions: sort-free fast path (optim_cat.hip)
                 key = tuple(id(s) for s in live_sites)
@@ -571,7 +571,8 @@ class Plan(object):
             ops.sparse_adagrad(table.E, table.acc, table.bias if use_bias else None,
                                table.bias_acc if use_bias else None, bufs['keys'], bufs['src'],
                                bufs['coef'], G, node0.arena_b if use_bias else None, rt.lr, rt.ws,
-                               gscale_dev=rt.clip_coef_dev, n=total)
+                               gscale_dev=rt.clip_coef_dev, n=total)   # two-pass apply: multi-hot tokens
+            # are Zipf-hot (runs of hundreds of pieces), where the one-launch ticket serialises
 
     def run(self):
         rt = self.rt

@@ -241,12 +241,13 @@ def key_bits_for(nrows):
 
 
 def sparse_adagrad(E, acc, bias, bias_acc, keys, src, coef, G, Gb, lr_dev, ws, gscale_dev=None,
-                   n=None):
+                   n=None, aux_cnt=None):
+    """aux_cnt (int32[table rows], zeros): enables the one-launch apply (ticket)."""
     n = int(keys.shape[0]) if n is None else int(n)
     wsp, wsn = ws.get(_lib.lib.arx_sparse_adagrad_workspace_bytes(n))
-    call("arx_sparse_adagrad", _p(E), _p(acc), _p(bias), _p(bias_acc), int(E.shape[1]), _p(keys),
-         _p(src), _p(coef), n, _p(G), _ld(G), _p(Gb), _p(lr_dev), _p(gscale_dev),
-         key_bits_for(E.shape[0]), wsp, wsn, _stream())
+    call("arx_sparse_adagrad_ticket", _p(E), _p(acc), _p(bias), _p(bias_acc), int(E.shape[1]),
+         _p(keys), _p(src), _p(coef), n, _p(G), _ld(G), _p(Gb), _p(lr_dev), _p(gscale_dev),
+         key_bits_for(E.shape[0]), _p(aux_cnt), wsp, wsn, _stream())
 
 
 class CatSiteArgs(object):

@@ -33,6 +33,14 @@
 namespace arx {
 
 constexpr int kPiece = 64;          // positions per piece
+constexpr int kRankSortMax = 8192;
+// rocPRIM 4.2's onesweep path resets its ordered-block-id counter on gfx942/gfx950 with a
+// BLOCKING hipMemset (ordered_block_id.hpp reset_from_host): it is not captured into a
+// hipGraph, so a replayed graph reads a stale counter and the kernel walks off its
+// lookback array (seen as a GPU segfault), and in eager mode it serialises the host.
+// Pin the merge-sort path (pure kernel launches) for every n above our own LDS rank sort.
+using RsConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                            rocprim::default_config, (size_t)1 << 31>;
 constexpr int kPassBBlocks = 128;   // persistent grid of pass B
 
 __device__ __forceinline__ float4 f4_fma(float c, float4 v, float4 a) {
@@ -142,6 +150,254 @@ static inline int launch_rank_sort(const int32_t* keys, int64_t n, uint32_t sent
     k_rank_sort<8><<<(int)ceil_div(n, 32), 256, lds, s>>>(keys, n, sentinel, sk, spos, count, src_in,
                                                               coef_in, ssrc, scoef);
   ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Device-wide stable LSD radix sort of (key, position) for n > kRankSortMax, written for
+// hipGraph replay: kernel launches only (rocPRIM's onesweep resets a counter with a
+// blocking hipMemset -- see RsConfig -- and its merge sort takes 17 launches, ~90 us, at
+// n = 100k).  <= 256 blocks, each owning one contiguous slice of ipb items (4 wave-
+// contiguous quarters), 2-3 passes of <= 10 bits, two launches per pass:
+//   k_rs_hist     per-block digit histogram -> hist[blk][bin]
+//   k_rs_scatter  every block derives its global bases from hist itself (the scan over
+//                 <= 256 blocks is cheaper inline than a third launch), counts digits per
+//                 wave, then ranks: lanes with equal digits find each other with one
+//                 ballot per digit bit, the lowest such lane bumps the wave's running
+//                 counter in LDS.  Stable by construction (block < wave < round < lane).
+// The first pass reads the caller's raw int32 keys (normalising out-of-range ones to the
+// sentinel) and the last pass also emits src/coef in sorted order, so neither a prep nor
+// a gather launch is needed.
+constexpr int kRsThreads = 256;
+constexpr int kRsMaxBlocks = 256;
+constexpr int kRsMaxBits = 10;
+constexpr int kRsMaxBins = 1 << kRsMaxBits;
+
+__device__ __forceinline__ uint32_t norm_key(int32_t k, uint32_t sentinel) {
+  return (k == ARX_KEY_NONE || k < 0 || (uint32_t)k >= sentinel) ? sentinel : (uint32_t)k;
+}
+
+template <bool RAW>
+__global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__ keys_in, int64_t n,
+                                                        uint32_t sentinel, int shift, int bits,
+                                                        int64_t ipb, int32_t* __restrict__ hist,
+                                                        int32_t* __restrict__ list_count) {
+  __shared__ int h[kRsMaxBins];
+  const int bins = 1 << bits;
+  for (int b = threadIdx.x; b < bins; b += kRsThreads) h[b] = 0;
+  if (list_count && blockIdx.x == 0 && threadIdx.x == 0) *list_count = 0;
+  __syncthreads();
+  const int64_t base = blockIdx.x * ipb;
+  const int64_t end = min(n, base + ipb);
+  const uint32_t mask = (uint32_t)bins - 1u;
+  for (int64_t i = base + threadIdx.x; i < end; i += kRsThreads) {
+    uint32_t k;
+    if constexpr (RAW) k = norm_key(reinterpret_cast<const int32_t*>(keys_in)[i], sentinel);
+    else k = reinterpret_cast<const uint32_t*>(keys_in)[i];
+    atomicAdd(&h[(k >> shift) & mask], 1);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += kRsThreads) hist[(int64_t)blockIdx.x * bins + b] = h[b];
+}
+
+template <bool RAW, bool LAST>
+__global__ __launch_bounds__(kRsThreads) void k_rs_scatter(
+    const void* __restrict__ keys_in, const uint32_t* __restrict__ pos_in, int64_t n,
+    uint32_t sentinel, int shift, int bits, int64_t ipb, const int32_t* __restrict__ hist, int nblk,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ pos_out,
+    const int32_t* __restrict__ src, const float* __restrict__ coef, int32_t* __restrict__ ssrc,
+    float* __restrict__ scoef) {
+  constexpr int NW = kRsThreads / 64;
+  __shared__ int wcnt[NW][kRsMaxBins];
+  __shared__ int gbase[kRsMaxBins];
+  __shared__ int stot[kRsMaxBins];
+  __shared__ int wsum[NW];
+  const int bins = 1 << bits;
+  const uint32_t mask = (uint32_t)bins - 1u;
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  // ---- global bases: below[b] = sum over earlier blocks, tot[b] = sum over all blocks ----
+  for (int b = threadIdx.x; b < bins; b += kRsThreads) {
+    int tot = 0, below = 0;
+    int blk = 0;
+    for (; blk + 8 <= nblk; blk += 8) {
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = hist[(int64_t)(blk + u) * bins + b];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        tot += v[u];
+        if (blk + u < (int)blockIdx.x) below += v[u];
+      }
+    }
+    for (; blk < nblk; ++blk) {
+      const int v = hist[(int64_t)blk * bins + b];
+      tot += v;
+      if (blk < (int)blockIdx.x) below += v;
+    }
+    gbase[b] = below;
+    stot[b] = tot;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) wcnt[ww][b] = 0;
+  }
+  __syncthreads();
+  // exclusive scan of stot over the bins (thread t owns a contiguous chunk)
+  {
+    const int per = (bins + kRsThreads - 1) / kRsThreads;   // 1..4
+    const int b0 = threadIdx.x * per;
+    int s = 0;
+    for (int u = 0; u < per; ++u)
+      if (b0 + u < bins) s += stot[b0 + u];
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int ww = 0; ww < w; ++ww) woff += wsum[ww];
+    int run = woff + incl - s;
+    for (int u = 0; u < per; ++u)
+      if (b0 + u < bins) {
+        const int t = stot[b0 + u];
+        gbase[b0 + u] += run;
+        run += t;
+      }
+  }
+  // ---- phase 1: per-wave digit counts over the wave's contiguous quarter ----
+  const int64_t base = blockIdx.x * ipb;
+  const int64_t end = min(n, base + ipb);
+  const int64_t ipw = ipb / NW;
+  const int64_t wb = base + w * ipw;
+  const int64_t we = min(end, wb + ipw);
+  for (int64_t i = wb + lane; i < we; i += 64) {
+    uint32_t k;
+    if constexpr (RAW) k = norm_key(reinterpret_cast<const int32_t*>(keys_in)[i], sentinel);
+    else k = reinterpret_cast<const uint32_t*>(keys_in)[i];
+    atomicAdd(&wcnt[w][(k >> shift) & mask], 1);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += kRsThreads) {
+    int run = gbase[b];
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) {
+      const int c = wcnt[ww][b];
+      wcnt[ww][b] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: stable rank + scatter ----
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int64_t i0 = wb; i0 < we; i0 += 64) {
+    const int64_t i = i0 + lane;
+    const bool valid = i < we;
+    uint32_t k = 0, p = 0;
+    if (valid) {
+      if constexpr (RAW) {
+        k = norm_key(reinterpret_cast<const int32_t*>(keys_in)[i], sentinel);
+        p = (uint32_t)i;
+      } else {
+        k = reinterpret_cast<const uint32_t*>(keys_in)[i];
+        p = pos_in[i];
+      }
+    }
+    const uint32_t dgt = (k >> shift) & mask;
+    unsigned long long peers = __ballot(valid);
+    for (int bit = 0; bit < bits; ++bit) {
+      const bool one = (dgt >> bit) & 1u;
+      const unsigned long long bb = __ballot(one);
+      peers &= one ? bb : ~bb;
+    }
+    if (valid) {
+      const int rank_in = __popcll(peers & lt);
+      const int old = wcnt[w][dgt];
+      if (rank_in == 0) wcnt[w][dgt] = old + __popcll(peers);
+      const int64_t dst = (int64_t)old + rank_in;
+      keys_out[dst] = k;
+      pos_out[dst] = p;
+      if constexpr (LAST) {
+        if (ssrc) {
+          ssrc[dst] = src ? src[p] : (int32_t)p;
+          scoef[dst] = coef ? coef[p] : 1.f;
+        }
+      }
+    }
+  }
+}
+
+struct RsPlan {
+  int nblk, passes, bits[4], shift[4];
+  int64_t ipb;
+};
+
+static inline RsPlan rs_plan(int64_t n, int total_bits) {
+  RsPlan p;
+  if (total_bits < 1) total_bits = 1;
+  p.passes = (total_bits + kRsMaxBits - 1) / kRsMaxBits;
+  const int r = (total_bits + p.passes - 1) / p.passes;
+  int sh = 0;
+  for (int i = 0; i < p.passes; ++i) {
+    p.bits[i] = (total_bits - sh) < r ? (total_bits - sh) : r;
+    p.shift[i] = sh;
+    sh += p.bits[i];
+  }
+  int64_t nblk = ceil_div(n, 2048);
+  if (nblk > kRsMaxBlocks) nblk = kRsMaxBlocks;
+  if (nblk < 1) nblk = 1;
+  p.ipb = ceil_div(ceil_div(n, nblk), kRsThreads) * kRsThreads;
+  p.nblk = (int)ceil_div(n, p.ipb);
+  return p;
+}
+
+// Sorted keys/positions land in keys_out/pos_out (keys_tmp/pos_tmp: ping-pong buffers of
+// n entries; hist: kRsMaxBlocks*kRsMaxBins ints).  ssrc/scoef (optional) receive
+// src[pos]/coef[pos] in sorted order.
+static inline int launch_radix_sort(const int32_t* keys_raw, int64_t n, uint32_t sentinel,
+                                    int total_bits, uint32_t* keys_tmp, uint32_t* keys_out,
+                                    uint32_t* pos_tmp, uint32_t* pos_out, int32_t* hist,
+                                    int32_t* list_count, const int32_t* src, const float* coef,
+                                    int32_t* ssrc, float* scoef, hipStream_t s) {
+  const RsPlan p = rs_plan(n, total_bits);
+  // the last pass must write keys_out/pos_out: passes alternate backwards from there
+  const void* in_k = keys_raw;
+  const uint32_t* in_p = nullptr;
+  for (int i = 0; i < p.passes; ++i) {
+    const bool last = (i == p.passes - 1);
+    const bool to_out = ((p.passes - 1 - i) % 2) == 0;
+    uint32_t* out_k = to_out ? keys_out : keys_tmp;
+    uint32_t* out_p = to_out ? pos_out : pos_tmp;
+    if (i == 0) {
+      k_rs_hist<true><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, sentinel, p.shift[i], p.bits[i], p.ipb,
+                                                    hist, list_count);
+      ARX_CHECK_LAUNCH();
+      if (last)
+        k_rs_scatter<true, true><<<p.nblk, kRsThreads, 0, s>>>(
+            in_k, in_p, n, sentinel, p.shift[i], p.bits[i], p.ipb, hist, p.nblk, out_k, out_p, src,
+            coef, ssrc, scoef);
+      else
+        k_rs_scatter<true, false><<<p.nblk, kRsThreads, 0, s>>>(
+            in_k, in_p, n, sentinel, p.shift[i], p.bits[i], p.ipb, hist, p.nblk, out_k, out_p, src,
+            coef, ssrc, scoef);
+    } else {
+      k_rs_hist<false><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, sentinel, p.shift[i], p.bits[i],
+                                                     p.ipb, hist, nullptr);
+      ARX_CHECK_LAUNCH();
+      if (last)
+        k_rs_scatter<false, true><<<p.nblk, kRsThreads, 0, s>>>(
+            in_k, in_p, n, sentinel, p.shift[i], p.bits[i], p.ipb, hist, p.nblk, out_k, out_p, src,
+            coef, ssrc, scoef);
+      else
+        k_rs_scatter<false, false><<<p.nblk, kRsThreads, 0, s>>>(
+            in_k, in_p, n, sentinel, p.shift[i], p.bits[i], p.ipb, hist, p.nblk, out_k, out_p, src,
+            coef, ssrc, scoef);
+    }
+    ARX_CHECK_LAUNCH();
+    in_k = out_k;
+    in_p = out_p;
+  }
   return ARX_OK;
 }
 
@@ -441,6 +697,7 @@ template <int LPR>
 __global__ __launch_bounds__(256) void k_sparse_onepass(
     float* __restrict__ E, float* __restrict__ acc, float* __restrict__ bias,
     float* __restrict__ bias_acc, int d, const uint32_t* __restrict__ sk,
+    const uint32_t* __restrict__ spos /* null: ssrc/scoef already sorted */,
     const int32_t* __restrict__ ssrc, const float* __restrict__ scoef, int64_t n, uint32_t sentinel,
     const float* __restrict__ G, int64_t ldg, const float* __restrict__ Gb,
     const float* __restrict__ lr_dev, const float* __restrict__ gscale_dev,
@@ -464,7 +721,7 @@ __global__ __launch_bounds__(256) void k_sparse_onepass(
   if (pend > n) pend = n;
   float4 g;
   float gb;
-  const int consumed = walk_piece<LPR>(sk, nullptr, ssrc, scoef, G, ldg, Gb, key, q, pend, col, colok,
+  const int consumed = walk_piece<LPR>(sk, spos, ssrc, scoef, G, ldg, Gb, key, q, pend, col, colok,
                                        lig, gid, g, gb);
   const int64_t e = q + consumed;
   const bool continues = (e == pend) && (e < n) && (sk[e] == key);
@@ -508,10 +765,33 @@ __global__ __launch_bounds__(256) void k_sparse_onepass(
   float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
   if (colok) tot = *reinterpret_cast<const float4*>(scratch_h + ch * (int64_t)d + col);
   float tb = scratch_hb[ch];
-  for (int64_t a = (ch + 1) * kPiece; a < n && sk[a] == key; a += kPiece) {
-    const int64_t sl = a / kPiece;
-    if (colok) tot = f4_add2(tot, *reinterpret_cast<const float4*>(scratch + sl * (int64_t)d + col));
-    tb += scratch_b[sl];
+  // 8 partials per round trip (a serial walk is one ~1.5 us L2 round trip per piece: a hot
+  // row with hundreds of pieces stalled the whole launch); rows past the run's end are
+  // loaded speculatively (in-bounds scratch) and dropped.  Fixed order => deterministic.
+  bool more = true;
+  for (int64_t a = (ch + 1) * kPiece; more && a < n; a += 8 * kPiece) {
+    float4 v[8];
+    float vb[8];
+    bool ok[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t aa = a + (int64_t)u * kPiece;
+      const bool in = aa < n;
+      ok[u] = in && sk[aa] == key;
+      const int64_t sl = in ? aa / kPiece : ch;
+      v[u] = colok ? *reinterpret_cast<const float4*>(scratch + sl * (int64_t)d + col)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      vb[u] = scratch_b[sl];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (ok[u]) {
+        tot = f4_add2(tot, v[u]);
+        tb += vb[u];
+      } else {
+        more = false;
+      }
+    }
   }
   adagrad_row(E, acc, bias, bias_acc, d, key, col, colok, lig, tot, tb, lr, gs);
   if (lig == 0) cnt[key] = 0;
@@ -571,16 +851,21 @@ __global__ void k_clip_coef(const float* __restrict__ sq, float max_norm, float*
 constexpr int kNormBlocks = 256;
 static __device__ float g_norm_part[kNormBlocks];
 
+static bool use_rocprim_sort() {
+  static const bool v = getenv("ARX_ROCPRIM_SORT") != nullptr;   // A/B aid
+  return v;
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct SparseWs {
   size_t off_keys_tmp, off_keys_out, off_pos_in, off_pos_out, off_list, off_count, off_scratch,
-      off_scratch_b, off_scratch_h, off_scratch_hb, off_ssrc, off_scoef, off_temp, temp_bytes, total;
+      off_scratch_b, off_scratch_h, off_scratch_hb, off_ssrc, off_scoef, off_hist, off_temp, temp_bytes, total;
 };
 
 static int sparse_ws_layout(int64_t n, int d, SparseWs* w) {
   size_t temp = 0;
-  hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t*, uint32_t*,
+  hipError_t e = rocprim::radix_sort_pairs<RsConfig, const uint32_t*, uint32_t*,
                                            const uint32_t*, uint32_t*>(
       nullptr, temp, nullptr, nullptr, nullptr, nullptr, (unsigned int)(n > 0 ? n : 1), 0, 32,
       (hipStream_t)0, false);
@@ -600,6 +885,7 @@ static int sparse_ws_layout(int64_t n, int d, SparseWs* w) {
   w->off_scratch_hb = o; o += align_up(pieces * 4, 256);
   w->off_ssrc = o; o += ni;
   w->off_scoef = o; o += ni;
+  w->off_hist = o; o += (size_t)kRsMaxBlocks * kRsMaxBins * 4;
   w->off_temp = o; o += align_up(temp, 256);
   w->temp_bytes = temp;
   w->total = o;
@@ -631,10 +917,6 @@ int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_a
                                 size_t workspace_bytes, hipStream_t s) {
   const int64_t n = st.offs[st.nsites];
   if (n == 0) return ARX_OK;
-  if (n > 16384) {
-    set_error("sparse_adagrad_sites_sorted: n=%lld > 16384", (long long)n);
-    return ARX_EUNSUPPORTED;
-  }
   SparseWs w;
   int rc = sparse_ws_layout(n, 256, &w);
   if (rc) { set_error("arx_sparse_adagrad_cat: workspace layout failed"); return rc; }
@@ -661,9 +943,37 @@ int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_a
   float* scoef = reinterpret_cast<float*>(base + w.off_scoef);
   float* scratch_h = reinterpret_cast<float*>(base + w.off_scratch_h);
   float* scratch_hb = reinterpret_cast<float*>(base + w.off_scratch_hb);
-  rc = launch_rank_sort(keys_buf, n, sentinel, keys_out, pos_out, count, s, src_buf, coef_buf, ssrc,
-                        scoef);
-  if (rc) return rc;
+  const uint32_t* spos_arg = nullptr;
+  const int32_t* src_arg = ssrc;
+  const float* coef_arg = scoef;
+  if (n <= kRankSortMax) {
+    rc = launch_rank_sort(keys_buf, n, sentinel, keys_out, pos_out, count, s, src_buf, coef_buf,
+                          ssrc, scoef);
+    if (rc) return rc;
+  } else if (!use_rocprim_sort()) {   // own LSD radix sort: src/coef come out in sorted order too
+    rc = launch_radix_sort(keys_buf, n, sentinel, key_bits + 1,
+                           reinterpret_cast<uint32_t*>(base + w.off_keys_tmp), keys_out,
+                           reinterpret_cast<uint32_t*>(base + w.off_pos_in), pos_out,
+                           reinterpret_cast<int32_t*>(base + w.off_hist), count, src_buf, coef_buf,
+                           ssrc, scoef, s);
+    if (rc) return rc;
+  } else {   // rocPRIM merge sort (A/B aid); the apply pass follows the position indirection
+    uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(base + w.off_keys_tmp);
+    uint32_t* pos_in = reinterpret_cast<uint32_t*>(base + w.off_pos_in);
+    int64_t g = ceil_div(n, 256);
+    int64_t cap = (int64_t)cu_count() * 8;
+    if (g > cap) g = cap;
+    k_prep_keys<<<(int)g, 256, 0, s>>>(keys_buf, n, sentinel, keys_tmp, pos_in, count);
+    ARX_CHECK_LAUNCH();
+    size_t temp_bytes = w.temp_bytes;
+    ARX_CHECK_HIP((rocprim::radix_sort_pairs<RsConfig, const uint32_t*, uint32_t*,
+                                             const uint32_t*, uint32_t*>(
+        base + w.off_temp, temp_bytes, keys_tmp, keys_out, pos_in, pos_out, (unsigned int)n, 0,
+        key_bits + 1, s, false)));
+    spos_arg = pos_out;
+    src_arg = src_buf;
+    coef_arg = coef_buf;
+  }
   const int lpr = lanes_per_row(d);
   const int64_t nwaves = ceil_div(n, 64 / lpr);
   const int grid_a = (int)ceil_div(nwaves, 4);
@@ -671,17 +981,19 @@ int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_a
   (void)list;
 #define ARX_LPR_CASE(L)                                                                            \
   case L:                                                                                          \
-    k_sparse_onepass<L><<<grid_a, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, ssrc, scoef, n, \
-                                               sentinel, G, ldg, gb_in, lr_dev, gscale_dev, scratch, \
-                                               scratch_b, scratch_h, scratch_hb, aux_cnt);         \
+    k_sparse_onepass<L><<<grid_a, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, spos_arg,      \
+                                               src_arg, coef_arg, n, sentinel, G, ldg, gb_in,      \
+                                               lr_dev, gscale_dev, scratch, scratch_b, scratch_h,  \
+                                               scratch_hb, aux_cnt);                               \
     break;
   switch (lpr) {
     ARX_LPR_CASE(1) ARX_LPR_CASE(2) ARX_LPR_CASE(4) ARX_LPR_CASE(8) ARX_LPR_CASE(16)
     ARX_LPR_CASE(32)
     default:
-      k_sparse_onepass<64><<<grid_a, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, ssrc, scoef, n,
-                                                  sentinel, G, ldg, gb_in, lr_dev, gscale_dev, scratch,
-                                                  scratch_b, scratch_h, scratch_hb, aux_cnt);
+      k_sparse_onepass<64><<<grid_a, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, spos_arg,
+                                                  src_arg, coef_arg, n, sentinel, G, ldg, gb_in,
+                                                  lr_dev, gscale_dev, scratch, scratch_b, scratch_h,
+                                                  scratch_hb, aux_cnt);
   }
 #undef ARX_LPR_CASE
   ARX_CHECK_LAUNCH();
@@ -703,6 +1015,15 @@ int arx_sparse_adagrad(float* E, float* acc, float* bias, float* bias_acc, int d
                        const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
                        const float* gscale_dev, int key_bits, void* workspace,
                        size_t workspace_bytes, void* stream) {
+  return arx_sparse_adagrad_ticket(E, acc, bias, bias_acc, d, keys, src, coef, n, G, ldg, Gb, lr_dev,
+                                   gscale_dev, key_bits, nullptr, workspace, workspace_bytes, stream);
+}
+
+int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc, int d,
+                              const int32_t* keys, const int32_t* src, const float* coef, int64_t n,
+                              const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
+                              const float* gscale_dev, int key_bits, int32_t* aux_cnt,
+                              void* workspace, size_t workspace_bytes, void* stream) {
   ARX_CHECK_ARG(E && acc && keys && G && lr_dev, "arx_sparse_adagrad: null pointer");
   ARX_CHECK_ARG((bias == nullptr) == (bias_acc == nullptr), "arx_sparse_adagrad: bias and bias_acc go together");
   ARX_CHECK_ARG(!(bias && !Gb), "arx_sparse_adagrad: bias table given without Gb");
@@ -733,7 +1054,8 @@ int arx_sparse_adagrad(float* E, float* acc, float* bias, float* bias_acc, int d
   float* scratch = reinterpret_cast<float*>(base + w.off_scratch);
   float* scratch_b = reinterpret_cast<float*>(base + w.off_scratch_b);
   void* temp = base + w.off_temp;
-  if (n <= 16384) {
+  const uint32_t* spos_arg = pos_out;
+  if (n <= kRankSortMax) {
     // id-only batches (B + S keys): one workgroup sorts everything in LDS -- a
     // single launch instead of the 5-6 of the device-wide radix sort.
     static const bool use_block_sort = getenv("ARX_BLOCK_SORT") != nullptr;   // A/B aid
@@ -749,14 +1071,25 @@ int arx_sparse_adagrad(float* E, float* acc, float* bias, float* bias_acc, int d
         k_small_sort<16><<<1, 1024, 0, s>>>(keys, n, sentinel, key_bits, keys_out, pos_out, count);
       ARX_CHECK_LAUNCH();
     }
-  } else {
+  } else if (!use_rocprim_sort()) {
+    // own LSD radix sort; src/coef are emitted in sorted order (one hop less per contribution)
+    int32_t* ssrc = reinterpret_cast<int32_t*>(base + w.off_ssrc);
+    float* scoef = reinterpret_cast<float*>(base + w.off_scoef);
+    rc = launch_radix_sort(keys, n, sentinel, key_bits + 1, keys_tmp, keys_out, pos_in, pos_out,
+                           reinterpret_cast<int32_t*>(base + w.off_hist), count, src, coef, ssrc,
+                           scoef, s);
+    if (rc) return rc;
+    spos_arg = nullptr;
+    src = ssrc;
+    coef = scoef;
+  } else {   // rocPRIM merge sort (A/B aid)
     int64_t g = ceil_div(n, 256);
     int64_t cap = (int64_t)cu_count() * 8;
     if (g > cap) g = cap;
     k_prep_keys<<<(int)g, 256, 0, s>>>(keys, n, sentinel, keys_tmp, pos_in, count);
     ARX_CHECK_LAUNCH();
     size_t temp_bytes = w.temp_bytes;
-    ARX_CHECK_HIP((rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t*, uint32_t*,
+    ARX_CHECK_HIP((rocprim::radix_sort_pairs<RsConfig, const uint32_t*, uint32_t*,
                                              const uint32_t*, uint32_t*>(
         temp, temp_bytes, keys_tmp, keys_out, pos_in, pos_out, (unsigned int)n, 0, key_bits + 1,
         s, false)));
@@ -765,12 +1098,22 @@ int arx_sparse_adagrad(float* E, float* acc, float* bias, float* bias_acc, int d
   const int64_t nwaves = ceil_div(n, 64 / lpr);
   const int grid_a = (int)ceil_div(nwaves, 4);
   const float* gb_in = bias ? Gb : nullptr;
+  if (aux_cnt) {   // one launch: multi-piece runs are finished by their last-arriving piece
+    float* scratch_h = reinterpret_cast<float*>(base + w.off_scratch_h);
+    float* scratch_hb = reinterpret_cast<float*>(base + w.off_scratch_hb);
+    ARX_DISPATCH_LPR(lpr, (k_sparse_onepass<LPR><<<grid_a, 256, 0, s>>>(
+                              E, acc, bias, bias_acc, d, keys_out, spos_arg, src, coef, n, sentinel, G,
+                              ldg, gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h,
+                              scratch_hb, aux_cnt)));
+    ARX_CHECK_LAUNCH();
+    return ARX_OK;
+  }
   ARX_DISPATCH_LPR(lpr, (k_sparse_pass_a<LPR><<<grid_a, 256, 0, s>>>(
-                            E, acc, bias, bias_acc, d, keys_out, pos_out, src, coef, n, sentinel,
+                            E, acc, bias, bias_acc, d, keys_out, spos_arg, src, coef, n, sentinel,
                             G, ldg, gb_in, lr_dev, gscale_dev, scratch, scratch_b, list, count)));
   ARX_CHECK_LAUNCH();
   ARX_DISPATCH_LPR(lpr, (k_sparse_pass_b<LPR><<<kPassBBlocks, 256, 0, s>>>(
-                            E, acc, bias, bias_acc, d, keys_out, pos_out, src, coef, n, G, ldg,
+                            E, acc, bias, bias_acc, d, keys_out, spos_arg, src, coef, n, G, ldg,
                             gb_in, lr_dev, gscale_dev, scratch, scratch_b, list, count)));
   ARX_CHECK_LAUNCH();
   return ARX_OK;

@@ -308,7 +308,7 @@ int arx_sparse_adagrad_cat(float* E, float* acc, float* bias, float* bias_acc, i
   if (n == 0) return ARX_OK;
   ARX_CHECK_ARG(n < (int64_t)INT_MAX, "arx_sparse_adagrad_cat: too many contributions");
   hipStream_t s = as_stream(stream);
-  if (mode == 0 && n <= 16384)   // default: fused key generation + LDS sort + the two passes
+  if (mode == 0)   // default: key generation + sort (LDS rank sort or device radix) + one-pass apply
     return sparse_adagrad_sites_sorted(E, acc, bias, bias_acc, table_rows, d, st, G, ldg, Gb,
                                        lr_dev, gscale_dev, keys_buf, src_buf, coef_buf, aux_cnt,
                                        workspace, workspace_bytes, s);

@@ -206,6 +206,16 @@ int arx_sparse_adagrad(float* E, float* acc, float* bias, float* bias_acc, int d
                        const float* lr_dev, const float* gscale_dev, int key_bits,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same with a per-table-row ticket counter (aux_cnt: caller-owned int32[table rows],
+ * zero-initialised once, left clean): long runs of duplicates are then completed by
+ * their last-arriving piece inside the same launch instead of a second pass.
+ * aux_cnt == NULL behaves exactly like arx_sparse_adagrad. */
+int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc, int d,
+                              const int32_t* keys, const int32_t* src, const float* coef, int64_t n,
+                              const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
+                              const float* gscale_dev, int key_bits, int32_t* aux_cnt,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* Fast path of the above for one-hot lookups with few contributions (id-only batches:
  * n = sum(site_n) <= ~64 k).  The lookup sites are described directly -- site s
  * contributes, for j < site_n[s]: key = site_cat_map[s] ? site_cat_map[s][ids[j]] : ids[j],

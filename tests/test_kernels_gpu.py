@@ -305,7 +305,11 @@ def _ref_sparse_adagrad(E, acc, bias, bacc, keys, src, coef, G, Gb, lr, gs=1.0):
 
 
 @pytest.mark.parametrize("d,n,Vf,hot", [(128, 5000, 300, 0), (128, 20000, 5000, 3000),
-                                        (32, 777, 50, 400), (64, 64, 1000, 0), (128, 130, 2, 0)])
+                                        (32, 777, 50, 400), (64, 64, 1000, 0), (128, 130, 2, 0),
+                                        # n > 8192: device-wide LSD radix sort (2 / 3 passes,
+                                        # 256 sort blocks with multi-round slices)
+                                        (4, 70000, 2100000, 500), (32, 600000, 40000, 20000),
+                                        (16, 9000, 1, 0)])
 def test_sparse_adagrad(dev, d, n, Vf, hot):
     """Duplicates summed first, one update per touched row; long runs (hot keys,
     > kPiece duplicates) exercise the two-pass path."""
@@ -577,3 +581,41 @@ def test_sparse_adagrad_cat_fast_path(dev, d, Vf, ns):
         np.testing.assert_allclose(o[2].cpu().numpy(), rb, rtol=2e-4, atol=2e-5)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[2][0], outs[3][0]) and torch.equal(outs[2][1], outs[3][1])
+
+
+@pytest.mark.parametrize("n,Vf", [(60000, 3000), (20000, 50)])
+def test_sparse_adagrad_ticket_large_n(dev, n, Vf):
+    """Device radix-sort path (n > 8192) with the one-launch ticket apply: Zipf-heavy keys
+    (runs of thousands of duplicates spanning many pieces) == reference, deterministic."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(n)
+    d = 128
+    E = rng.standard_normal((Vf, d)).astype(np.float32)
+    acc = (0.1 + rng.random((Vf, d))).astype(np.float32)
+    bias = rng.standard_normal((Vf,)).astype(np.float32)
+    bacc = np.full((Vf,), 0.1, dtype=np.float32)
+    m = 400
+    G = rng.standard_normal((m, d)).astype(np.float32)
+    Gb = rng.standard_normal((m,)).astype(np.float32)
+    p = 1.0 / np.arange(1, Vf + 1)
+    keys = rng.choice(Vf, size=n, p=p / p.sum()).astype(np.int32)
+    keys[rng.choice(n, size=n // 5, replace=False)] = 0x7FFFFFFF
+    src = rng.integers(0, m, size=n).astype(np.int32)
+    coef = rng.random(n).astype(np.float32)
+    rE, racc, rb, rbacc = _ref_sparse_adagrad(E, acc, bias, bacc, keys, src, coef, G, Gb, 0.3, 1.0)
+    lr = torch.tensor([0.3], dtype=torch.float32, device=dev)
+    cnt = torch.zeros((Vf,), dtype=torch.int32, device=dev)
+    ws = ops.Workspace(dev)
+    outs = []
+    for rep in range(2):
+        tE, tacc, tb, tbacc = _t(dev, E), _t(dev, acc), _t(dev, bias), _t(dev, bacc)
+        ops.sparse_adagrad(tE, tacc, tb, tbacc, _t(dev, keys), _t(dev, src), _t(dev, coef), _t(dev, G),
+                           _t(dev, Gb), lr, ws, aux_cnt=cnt)
+        torch.cuda.synchronize()
+        assert int(cnt.abs().sum().item()) == 0
+        outs.append((tE, tacc, tb))
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), racc, rtol=3e-4, atol=1e-4)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), rE, rtol=3e-4, atol=1e-4)
+    np.testing.assert_allclose(outs[0][2].cpu().numpy(), rb, rtol=3e-4, atol=1e-4)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
