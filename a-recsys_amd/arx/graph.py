@@ -571,8 +571,15 @@ class Plan(object):
             ops.sparse_adagrad(table.E, table.acc, table.bias if use_bias else None,
                                table.bias_acc if use_bias else None, bufs['keys'], bufs['src'],
                                bufs['coef'], G, node0.arena_b if use_bias else None, rt.lr, rt.ws,
-                               gscale_dev=rt.clip_coef_dev, n=total)   # two-pass apply: multi-hot tokens
-            # are Zipf-hot (runs of hundreds of pieces), where the one-launch ticket serialises
+                               gscale_dev=rt.clip_coef_dev, n=total, aux_cnt=self._aux_cnt(table))
+
+    def _aux_cnt(self, table):
+        """Per-row arrival counters of the window apply (zero between launches)."""
+        if getattr(table, 'aux_cnt', None) is None:
+            table.aux_first = torch.full((table.E.shape[0],), 2 ** 31 - 1, dtype=torch.int32,
+                                         device=self.rt.device)
+            table.aux_cnt = torch.zeros((table.E.shape[0],), dtype=torch.int32, device=self.rt.device)
+        return table.aux_cnt
 
     def run(self):
         rt = self.rt

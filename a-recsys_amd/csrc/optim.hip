@@ -54,7 +54,7 @@ __global__ void k_prep_keys(const int32_t* __restrict__ keys, int64_t n, uint32_
                             uint32_t* __restrict__ keys_tmp, uint32_t* __restrict__ pos,
                             int32_t* __restrict__ list_count) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i == 0) *list_count = 0;
+  if (i == 0) { list_count[0] = 0; list_count[1] = 0; }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     const int32_t k = keys[i];
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_rank_sort(const int32_t* __restrict__ k
       }
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *list_count = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { list_count[0] = 0; list_count[1] = 0; }
   __syncthreads();
   constexpr int EPB = 256 / TPE;
   const int e = blockIdx.x * EPB + threadIdx.x / TPE;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__
   __shared__ int h[kRsMaxBins];
   const int bins = 1 << bits;
   for (int b = threadIdx.x; b < bins; b += kRsThreads) h[b] = 0;
-  if (list_count && blockIdx.x == 0 && threadIdx.x == 0) *list_count = 0;
+  if (list_count && blockIdx.x == 0 && threadIdx.x == 0) { list_count[0] = 0; list_count[1] = 0; }
   __syncthreads();
   const int64_t base = blockIdx.x * ipb;
   const int64_t end = min(n, base + ipb);
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(1024) void k_small_sort(const int32_t* __restrict__
                                                      int32_t* __restrict__ list_count) {
   using Sort = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint32_t, 1, 1, 8>;
   __shared__ typename Sort::storage_type storage;
-  if (threadIdx.x == 0) *list_count = 0;
+  if (threadIdx.x == 0) { list_count[0] = 0; list_count[1] = 0; }
   uint32_t k[IPT], v[IPT];
 #pragma unroll
   for (int i = 0; i < IPT; ++i) {
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(1024) void k_small_sort_sites(CatSites st, int64_t 
                                                            int32_t* __restrict__ list_count) {
   using Sort = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint32_t, 1, 1, 8>;
   __shared__ typename Sort::storage_type storage;
-  if (threadIdx.x == 0) *list_count = 0;
+  if (threadIdx.x == 0) { list_count[0] = 0; list_count[1] = 0; }
   const int64_t n = st.offs[st.nsites];
   uint32_t k[IPT], v[IPT];
 #pragma unroll
@@ -584,103 +584,277 @@ __device__ __forceinline__ void adagrad_row(float* __restrict__ E, float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Window apply (replaces the position-per-sub-group passes): one WAVE owns 64 consecutive
+// sorted positions (= one piece).  Keys, gradient-source rows and coefficients of the
+// window are staged with three coalesced loads; run boundaries come from one ballot, so
+// the per-run walk needs no further key loads and issues its gradient rows 8 at a time.
+// The wave's 64/LPR sub-groups take the window's runs round-robin.
+//   complete run (starts and ends inside the window)      -> Adagrad at once
+//   open-left piece (run started in an earlier window)    -> partial row to scratch[slot]
+//   head piece whose run continues past the window        -> partial row to scratch_h[slot]
+// Multi-piece runs are finished
+//   * with `cnt` (per-table-row counter, zero on entry and exit) and <= 17 pieces: by the
+//     LAST arriving piece (ticket: every piece adds 1, the head adds 1 + kBig - T);
+//   * otherwise by k_sparse_long (second launch, one workgroup per listed run): the
+//     Zipf-hot rows with hundreds of pieces, summed by 32 sub-groups in parallel.
+// Partials are always summed head first, then in ascending piece order => bit-reproducible.
+constexpr int kBig = 1 << 30;
+constexpr int kShortMaxAligned = 16;    // runs with more aligned pieces get a whole workgroup
+
 template <int LPR>
-__global__ __launch_bounds__(256) void k_sparse_pass_a(
+__global__ __launch_bounds__(256) void k_sparse_win(
     float* __restrict__ E, float* __restrict__ acc, float* __restrict__ bias,
     float* __restrict__ bias_acc, int d, const uint32_t* __restrict__ sk,
-    const uint32_t* __restrict__ spos, const int32_t* __restrict__ src,
-    const float* __restrict__ coef, int64_t n, uint32_t sentinel, const float* __restrict__ G,
+    const uint32_t* __restrict__ spos, const int32_t* __restrict__ ssrc,
+    const float* __restrict__ scoef, int64_t n, uint32_t sentinel, const float* __restrict__ G,
     int64_t ldg, const float* __restrict__ Gb, const float* __restrict__ lr_dev,
     const float* __restrict__ gscale_dev, float* __restrict__ scratch,
-    float* __restrict__ scratch_b, int32_t* __restrict__ list, int32_t* __restrict__ list_count) {
-  constexpr int GPW = 64 / LPR;
+    float* __restrict__ scratch_b, float* __restrict__ scratch_h, float* __restrict__ scratch_hb,
+    int32_t* __restrict__ list_long, int32_t* __restrict__ list_short,
+    int32_t* __restrict__ list_count) {
+  constexpr int NSG = 64 / LPR;
+  __shared__ int s_src[4][64];
+  __shared__ float s_coef[4][64];
+  __shared__ uint32_t s_key[4][64];
   const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
   const int lig = lane % LPR;
-  const int gid = lane / LPR;
+  const int g = lane / LPR;
   const int col = lig * 4;
   const bool colok = col < d;
-  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  const int64_t q = wave * GPW + gid;
-  if (q >= n) return;
-  const uint32_t key = sk[q];
-  if (key >= sentinel) return;
-  const bool head = (q == 0) || (sk[q - 1] != key);
-  const bool aligned = (q % kPiece) == 0;
-  if (!head && !aligned) return;
-  int64_t pend = (q / kPiece + 1) * kPiece;
-  if (pend > n) pend = n;
-  float4 g;
-  float gb;
-  const int consumed = walk_piece<LPR>(sk, spos, src, coef, G, ldg, Gb, key, q, pend, col, colok,
-                                       lig, gid, g, gb);
-  const int64_t e = q + consumed;
-  const bool continues = (e == pend) && (e < n) && (sk[e] == key);
-  if (head) {
-    if (!continues) {
-      adagrad_row(E, acc, bias, bias_acc, d, key, col, colok, lig, g, gb, *lr_dev,
-                  gscale_dev ? *gscale_dev : 1.f);
-    } else if (lig == 0) {
-      const int slot = atomicAdd(list_count, 1);
-      list[slot] = (int32_t)q;
+  const int64_t w0 = ((int64_t)blockIdx.x * 4 + wv) * 64;
+  if (w0 >= n) return;                       // whole wave (no workgroup barrier below)
+  const int64_t p = w0 + lane;
+  const bool inb = p < n;
+  const uint32_t key = inb ? sk[p] : 0xffffffffu;
+  const uint32_t prev = (inb && p > 0) ? sk[p - 1] : 0xffffffffu;
+  const uint32_t knext = (w0 + 64 < n) ? sk[w0 + 64] : 0xffffffffu;
+  const bool valid = inb && key < sentinel;
+  const bool head = valid && (p == 0 || prev != key);
+  {
+    int sv = 0;
+    float cv = 0.f;
+    if (valid) {
+      const uint32_t i = spos ? spos[p] : (uint32_t)p;
+      sv = ssrc ? ssrc[i] : (int32_t)i;
+      cv = scoef ? scoef[i] : 1.f;
     }
-  } else {  // aligned continuation piece -> partial
-    const int64_t slot = q / kPiece;
-    if (colok) *reinterpret_cast<float4*>(scratch + slot * (int64_t)d + col) = g;
-    if (lig == 0) scratch_b[slot] = gb;
+    s_src[wv][lane] = sv;
+    s_coef[wv][lane] = cv;
+    s_key[wv][lane] = key;
+  }
+  const unsigned long long V = __ballot(valid);
+  const unsigned long long H = __ballot(head);
+  const unsigned long long L = H | (V & 1ull);            // leaders: heads + the window's first position
+  const int nvalid = __popcll(V);                          // valid positions are a prefix
+  const float lr = *lr_dev;
+  const float gs = gscale_dev ? *gscale_dev : 1.f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  unsigned long long m = L;
+  for (int k = 0; k < g && m; ++k) m &= m - 1;             // sub-group g starts at the g-th leader
+  while (m) {
+    const int i = __builtin_ctzll(m);
+    const unsigned long long rest = (i == 63) ? 0ull : (L & ~((2ull << i) - 1ull));
+    const int e = rest ? __builtin_ctzll(rest) : nvalid;
+    const int rows = e - i;
+    const uint32_t rkey = s_key[wv][i];
+    const bool is_head = (H >> i) & 1ull;
+    const bool continues = (e == 64) && (knext == rkey);
+    const bool complete = is_head && !continues;
+    // the table row is known up front: its loads fly with the gradient rows
+    float4 wrow = make_float4(0.f, 0.f, 0.f, 0.f), arow = wrow;
+    if (complete && colok) {
+      wrow = *reinterpret_cast<const float4*>(E + (int64_t)rkey * d + col);
+      arow = *reinterpret_cast<const float4*>(acc + (int64_t)rkey * d + col);
+    }
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < rows; t += 8) {
+      float4 v[8];
+      float c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool ok = t + u < rows;
+        const int idx = i + (ok ? t + u : 0);
+        const int s = s_src[wv][idx];
+        c[u] = ok ? s_coef[wv][idx] : 0.f;
+        v[u] = (ok && colok) ? *reinterpret_cast<const float4*>(G + (int64_t)s * ldg + col)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a = f4_fma(c[u], v[u], a);
+    }
+    float gb = 0.f;
+    if (Gb) {
+      for (int t = lig; t < rows; t += LPR) gb = fmaf(s_coef[wv][i + t], Gb[s_src[wv][i + t]], gb);
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) gb += __shfl_xor(gb, o, LPR);
+    }
+    if (complete) {
+      if (colok) {
+        float4 gg = make_float4(a.x * gs, a.y * gs, a.z * gs, a.w * gs);
+        arow.x += gg.x * gg.x; arow.y += gg.y * gg.y; arow.z += gg.z * gg.z; arow.w += gg.w * gg.w;
+        wrow.x -= lr * gg.x / sqrtf(arow.x);
+        wrow.y -= lr * gg.y / sqrtf(arow.y);
+        wrow.z -= lr * gg.z / sqrtf(arow.z);
+        wrow.w -= lr * gg.w / sqrtf(arow.w);
+        *reinterpret_cast<float4*>(acc + (int64_t)rkey * d + col) = arow;
+        *reinterpret_cast<float4*>(E + (int64_t)rkey * d + col) = wrow;
+      }
+      if (bias && lig == 0) {
+        const float gg = gb * gs;
+        const float ba = bias_acc[rkey] + gg * gg;
+        bias_acc[rkey] = ba;
+        bias[rkey] -= lr * gg / sqrtf(ba);
+      }
+    } else {
+      // ---- piece of a multi-piece run ----
+      const int64_t slot = w0 / 64;
+      const int64_t q = w0 + i;
+      float* prow = (is_head ? scratch_h : scratch) + slot * (int64_t)d;
+      if (colok) *reinterpret_cast<float4*>(prow + col) = a;
+      if (lig == 0) (is_head ? scratch_hb : scratch_b)[slot] = gb;
+      if (is_head) {
+        // aligned pieces that follow: probe 16 window starts per round trip; runs with at
+        // most kShortMaxAligned of them go to the short list (one sub-group each in
+        // k_sparse_finish), Zipf-hot ones to the long list (one workgroup each)
+        const int64_t first = w0 + 64;
+        int na = 0;
+        bool stop = false;
+        while (!stop) {
+          int mc = 0;
+          bool all = true;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int64_t aa = first + (int64_t)(na + j) * 64;
+            const bool same = (aa < n) && (sk[aa] == rkey);
+            if (all && same) ++mc; else all = false;
+          }
+          na += mc;
+          stop = (mc < 16) || (na > kShortMaxAligned);
+        }
+        if (lig == 0) {
+          if (na > kShortMaxAligned) {
+            const int sl = atomicAdd(&list_count[0], 1);
+            list_long[sl] = (int32_t)q;
+          } else {
+            const int sl = atomicAdd(&list_count[1], 1);
+            list_short[2 * sl] = (int32_t)q;
+            list_short[2 * sl + 1] = na;
+          }
+        }
+      }
+    }
+    for (int k = 0; k < NSG && m; ++k) m &= m - 1;         // next leader of this sub-group
   }
 }
 
-// pass B: one workgroup per long run.
+// Second launch of the window apply: finishes the multi-piece runs.
+//   blocks [0, nlong_blocks): one workgroup (1024 threads = 1024/LPR sub-groups) per LONG
+//     run: the sub-groups sum the aligned partials in parallel (4 rows in flight each) and
+//     combine through LDS in a fixed order -- a Zipf-hot token with 2000 pieces costs ~16
+//     dependent round trips instead of 2000;
+//   remaining blocks: one SUB-GROUP per SHORT run (head partial + <= 16 aligned partials,
+//     two round trips), grid-stride over the short list.
 template <int LPR>
-__global__ __launch_bounds__(256) void k_sparse_pass_b(
+__global__ __launch_bounds__(1024) void k_sparse_finish(
     float* __restrict__ E, float* __restrict__ acc, float* __restrict__ bias,
-    float* __restrict__ bias_acc, int d, const uint32_t* __restrict__ sk,
-    const uint32_t* __restrict__ spos, const int32_t* __restrict__ src,
-    const float* __restrict__ coef, int64_t n, const float* __restrict__ G, int64_t ldg,
-    const float* __restrict__ Gb, const float* __restrict__ lr_dev,
-    const float* __restrict__ gscale_dev, const float* __restrict__ scratch,
-    const float* __restrict__ scratch_b, const int32_t* __restrict__ list,
-    const int32_t* __restrict__ list_count) {
-  constexpr int NSG = 256 / LPR;  // sub-groups per workgroup
+    float* __restrict__ bias_acc, int d, const uint32_t* __restrict__ sk, int64_t n,
+    const float* __restrict__ lr_dev, const float* __restrict__ gscale_dev,
+    const float* __restrict__ scratch, const float* __restrict__ scratch_b,
+    const float* __restrict__ scratch_h, const float* __restrict__ scratch_hb,
+    const int32_t* __restrict__ list_long, const int32_t* __restrict__ list_short,
+    const int32_t* __restrict__ list_count, int nlong_blocks) {
+  constexpr int NSG = 1024 / LPR;
   __shared__ __attribute__((aligned(16))) float sh[NSG][LPR * 4];
   __shared__ float shb[NSG];
-  const int lane = threadIdx.x & 63;
-  const int lig = lane % LPR;
-  const int gid = lane / LPR;
+  const int lig = threadIdx.x % LPR;
   const int sg = threadIdx.x / LPR;
   const int col = lig * 4;
   const bool colok = col < d;
-  const int count = *list_count;
-  for (int it = blockIdx.x; it < count; it += gridDim.x) {
-    const int64_t h = list[it];
-    const uint32_t key = sk[h];
-    const int64_t first = (h / kPiece + 1) * kPiece;  // first aligned continuation piece
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    float gb = 0.f;
-    if (sg == 0) {  // recompute the head piece [h, first)
-      walk_piece<LPR>(sk, spos, src, coef, G, ldg, Gb, key, h, first, col, colok, lig, gid, g, gb);
+  const float lr = *lr_dev;
+  const float gs = gscale_dev ? *gscale_dev : 1.f;
+  if ((int)blockIdx.x >= nlong_blocks) {
+    // ---- short runs: one sub-group each ----
+    const int count = list_count[1];
+    const int64_t nsg_total = (int64_t)(gridDim.x - nlong_blocks) * NSG;
+    for (int64_t it = (int64_t)(blockIdx.x - nlong_blocks) * NSG + sg; it < count; it += nsg_total) {
+      const int64_t h = list_short[2 * it];
+      const int na = list_short[2 * it + 1];
+      const uint32_t key = sk[h];
+      const int64_t hslot = h / 64;
+      float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (colok) tot = *reinterpret_cast<const float4*>(scratch_h + hslot * (int64_t)d + col);
+      float tb = scratch_hb[hslot];
+      for (int j0 = 0; j0 < na; j0 += 8) {
+        float4 v[8];
+        float vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t sl = hslot + 1 + ((j0 + u < na) ? j0 + u : 0);
+          v[u] = colok ? *reinterpret_cast<const float4*>(scratch + sl * (int64_t)d + col)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+          vb[u] = scratch_b[sl];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j0 + u < na) {
+            tot = f4_add2(tot, v[u]);
+            tb += vb[u];
+          }
+      }
+      adagrad_row(E, acc, bias, bias_acc, d, key, col, colok, lig, tot, tb, lr, gs);
     }
-    // aligned pieces first + k*kPiece while they still carry the key
-    // sub-group sg takes the aligned pieces sg, sg+NSG, ... (sorted => monotone stop)
-    for (int64_t a = first + (int64_t)sg * kPiece; a < n; a += (int64_t)NSG * kPiece) {
-      if (sk[a] != key) break;
-      const int64_t slot = a / kPiece;
-      if (colok) g = f4_add2(g, *reinterpret_cast<const float4*>(scratch + slot * (int64_t)d + col));
-      gb += scratch_b[slot];
+    return;
+  }
+  // ---- long runs: one workgroup each ----
+  const int count = list_count[0];
+  for (int it = blockIdx.x; it < count; it += nlong_blocks) {
+    const int64_t h = list_long[it];
+    const uint32_t key = sk[h];
+    const int64_t hslot = h / 64;
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    float tb = 0.f;
+    bool more = true;
+    for (int64_t j0 = sg; more; j0 += (int64_t)NSG * 4) {
+      float4 v[4];
+      float vb[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t aa = (hslot + 1 + j0 + (int64_t)u * NSG) * 64;
+        const bool in = aa < n;
+        ok[u] = in && sk[aa] == key;
+        const int64_t sl = in ? aa / 64 : hslot;
+        v[u] = colok ? *reinterpret_cast<const float4*>(scratch + sl * (int64_t)d + col)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        vb[u] = scratch_b[sl];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (ok[u]) {
+          tot = f4_add2(tot, v[u]);
+          tb += vb[u];
+        } else {
+          more = false;
+        }
+      }
     }
     __syncthreads();
-    if (colok) *reinterpret_cast<float4*>(&sh[sg][col]) = g;
-    if (lig == 0) shb[sg] = gb;
+    if (colok) *reinterpret_cast<float4*>(&sh[sg][col]) = tot;
+    if (lig == 0) shb[sg] = tb;
     __syncthreads();
     if (sg == 0) {
-      float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
-      float tb = 0.f;
+      float4 t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (colok) t2 = *reinterpret_cast<const float4*>(scratch_h + hslot * (int64_t)d + col);
+      float t2b = scratch_hb[hslot];
       for (int k = 0; k < NSG; ++k) {
-        if (colok) tot = f4_add2(tot, *reinterpret_cast<const float4*>(&sh[k][col]));
-        tb += shb[k];
+        if (colok) t2 = f4_add2(t2, *reinterpret_cast<const float4*>(&sh[k][col]));
+        t2b += shb[k];
       }
-      adagrad_row(E, acc, bias, bias_acc, d, key, col, colok, lig, tot, tb, *lr_dev,
-                  gscale_dev ? *gscale_dev : 1.f);
+      adagrad_row(E, acc, bias, bias_acc, d, key, col, colok, lig, t2, t2b, lr, gs);
     }
   }
 }
@@ -691,7 +865,6 @@ __global__ __launch_bounds__(256) void k_sparse_pass_b(
 // 1 + (kBig - T) with T = pieces of the run (binary search over the aligned positions), so
 // the arrival that makes the counter reach kBig knows all T partials are published: it
 // acquires, sums them in piece order (fixed order => deterministic) and applies Adagrad.
-constexpr int kBig = 1 << 30;
 
 template <int LPR>
 __global__ __launch_bounds__(256) void k_sparse_onepass(
@@ -877,7 +1050,7 @@ static int sparse_ws_layout(int64_t n, int d, SparseWs* w) {
   w->off_keys_out = o; o += ni;
   w->off_pos_in = o; o += ni;
   w->off_pos_out = o; o += ni;
-  w->off_list = o; o += align_up(pieces * 4, 256);
+  w->off_list = o; o += align_up(pieces * 4 * 3, 256);   // long list + (position, pieces) pairs of the short list
   w->off_count = o; o += 256;
   w->off_scratch = o; o += align_up(pieces * (size_t)d * 4, 256);
   w->off_scratch_b = o; o += align_up(pieces * 4, 256);
@@ -906,6 +1079,55 @@ using namespace arx;
     case 32: { constexpr int LPR = 32; CALL; } break; \
     default: { constexpr int LPR = 64; CALL; } break; \
   }
+
+
+namespace arx {
+
+// window apply (+ the long-run launch when runs can exceed the ticket's reach)
+static int launch_apply(float* E, float* acc, float* bias, float* bias_acc, int d,
+                        const uint32_t* sk, const uint32_t* spos, const int32_t* ssrc,
+                        const float* scoef, int64_t n, uint32_t sentinel, const float* G, int64_t ldg,
+                        const float* gb_in, const float* lr_dev, const float* gscale_dev,
+                        float* scratch, float* scratch_b, float* scratch_h, float* scratch_hb,
+                        int32_t* cnt, int32_t* list, int32_t* count, hipStream_t s) {
+  const int lpr = lanes_per_row(d);
+  if (cnt != nullptr && n <= kRankSortMax) {
+    // small batches (single-launch LDS rank sort regime): one sub-group per sorted position --
+    // mostly-unique one-hot ids need the parallelism (80 windows would leave the chip idle);
+    // every multi-piece run is finished by its last arriver, no second launch.
+    const int64_t nwaves = ceil_div(n, 64 / lpr);
+    const int grid_a = (int)ceil_div(nwaves, 4);
+    ARX_DISPATCH_LPR(lpr, (k_sparse_onepass<LPR><<<grid_a, 256, 0, s>>>(
+                              E, acc, bias, bias_acc, d, sk, spos, ssrc, scoef, n, sentinel, G, ldg,
+                              gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h, scratch_hb,
+                              cnt)));
+    ARX_CHECK_LAUNCH();
+    return ARX_OK;
+  }
+  const int grid = (int)ceil_div(ceil_div(n, 64), 4);
+  int32_t* list_long = list;                       // <= n/64/17 entries
+  int32_t* list_short = list + (n / 64 / (kShortMaxAligned + 1) + 2);   // pairs, <= n/64 entries
+  ARX_DISPATCH_LPR(lpr, (k_sparse_win<LPR><<<grid, 256, 0, s>>>(
+                            E, acc, bias, bias_acc, d, sk, spos, ssrc, scoef, n, sentinel, G, ldg,
+                            gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h, scratch_hb,
+                            list_long, list_short, count)));
+  ARX_CHECK_LAUNCH();
+  {
+    int64_t nlong = ceil_div(n, 64 * (int64_t)(kShortMaxAligned + 2));      // upper bound of long runs
+    if (nlong > kPassBBlocks) nlong = kPassBBlocks;
+    const int nsg = 1024 / lpr;
+    int64_t nshort = ceil_div(ceil_div(n, 64), nsg);                         // upper bound of short runs
+    const int64_t cap = (int64_t)cu_count() * 2;
+    if (nshort > cap) nshort = cap;
+    ARX_DISPATCH_LPR(lpr, (k_sparse_finish<LPR><<<(int)(nlong + nshort), 1024, 0, s>>>(
+                              E, acc, bias, bias_acc, d, sk, n, lr_dev, gscale_dev, scratch, scratch_b,
+                              scratch_h, scratch_hb, list_long, list_short, count, (int)nlong)));
+    ARX_CHECK_LAUNCH();
+  }
+  return ARX_OK;
+}
+
+}  // namespace arx
 
 namespace arx {
 
@@ -974,30 +1196,10 @@ int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_a
     src_arg = src_buf;
     coef_arg = coef_buf;
   }
-  const int lpr = lanes_per_row(d);
-  const int64_t nwaves = ceil_div(n, 64 / lpr);
-  const int grid_a = (int)ceil_div(nwaves, 4);
   const float* gb_in = bias ? Gb : nullptr;
-  (void)list;
-#define ARX_LPR_CASE(L)                                                                            \
-  case L:                                                                                          \
-    k_sparse_onepass<L><<<grid_a, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, spos_arg,      \
-                                               src_arg, coef_arg, n, sentinel, G, ldg, gb_in,      \
-                                               lr_dev, gscale_dev, scratch, scratch_b, scratch_h,  \
-                                               scratch_hb, aux_cnt);                               \
-    break;
-  switch (lpr) {
-    ARX_LPR_CASE(1) ARX_LPR_CASE(2) ARX_LPR_CASE(4) ARX_LPR_CASE(8) ARX_LPR_CASE(16)
-    ARX_LPR_CASE(32)
-    default:
-      k_sparse_onepass<64><<<grid_a, 256, 0, s>>>(E, acc, bias, bias_acc, d, keys_out, spos_arg,
-                                                  src_arg, coef_arg, n, sentinel, G, ldg, gb_in,
-                                                  lr_dev, gscale_dev, scratch, scratch_b, scratch_h,
-                                                  scratch_hb, aux_cnt);
-  }
-#undef ARX_LPR_CASE
-  ARX_CHECK_LAUNCH();
-  return ARX_OK;
+  return launch_apply(E, acc, bias, bias_acc, d, keys_out, spos_arg, src_arg, coef_arg, n, sentinel, G,
+                      ldg, gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h, scratch_hb,
+                      aux_cnt, list, count, s);
 }
 
 }  // namespace arx
@@ -1094,29 +1296,11 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
         temp, temp_bytes, keys_tmp, keys_out, pos_in, pos_out, (unsigned int)n, 0, key_bits + 1,
         s, false)));
   }
-  const int lpr = lanes_per_row(d);
-  const int64_t nwaves = ceil_div(n, 64 / lpr);
-  const int grid_a = (int)ceil_div(nwaves, 4);
   const float* gb_in = bias ? Gb : nullptr;
-  if (aux_cnt) {   // one launch: multi-piece runs are finished by their last-arriving piece
-    float* scratch_h = reinterpret_cast<float*>(base + w.off_scratch_h);
-    float* scratch_hb = reinterpret_cast<float*>(base + w.off_scratch_hb);
-    ARX_DISPATCH_LPR(lpr, (k_sparse_onepass<LPR><<<grid_a, 256, 0, s>>>(
-                              E, acc, bias, bias_acc, d, keys_out, spos_arg, src, coef, n, sentinel, G,
-                              ldg, gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h,
-                              scratch_hb, aux_cnt)));
-    ARX_CHECK_LAUNCH();
-    return ARX_OK;
-  }
-  ARX_DISPATCH_LPR(lpr, (k_sparse_pass_a<LPR><<<grid_a, 256, 0, s>>>(
-                            E, acc, bias, bias_acc, d, keys_out, spos_arg, src, coef, n, sentinel,
-                            G, ldg, gb_in, lr_dev, gscale_dev, scratch, scratch_b, list, count)));
-  ARX_CHECK_LAUNCH();
-  ARX_DISPATCH_LPR(lpr, (k_sparse_pass_b<LPR><<<kPassBBlocks, 256, 0, s>>>(
-                            E, acc, bias, bias_acc, d, keys_out, spos_arg, src, coef, n, G, ldg,
-                            gb_in, lr_dev, gscale_dev, scratch, scratch_b, list, count)));
-  ARX_CHECK_LAUNCH();
-  return ARX_OK;
+  return launch_apply(E, acc, bias, bias_acc, d, keys_out, spos_arg, src, coef, n, sentinel, G, ldg,
+                      gb_in, lr_dev, gscale_dev, scratch, scratch_b,
+                      reinterpret_cast<float*>(base + w.off_scratch_h),
+                      reinterpret_cast<float*>(base + w.off_scratch_hb), aux_cnt, list, count, s);
 }
 
 int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const float* lr_dev,

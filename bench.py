@@ -120,7 +120,8 @@ def kernel_rooflines(model, args):
         t = _evt_time_ms(lambda: ops.sparse_adagrad(
             table.E, table.acc, table.bias if use_bias else None,
             table.bias_acc if use_bias else None, bufs['keys'], bufs['src'], bufs['coef'],
-            node0.arena, node0.arena_b if use_bias else None, rt.lr, rt.ws, n=total), 50)
+            node0.arena, node0.arena_b if use_bias else None, rt.lr, rt.ws, n=total,
+            aux_cnt=getattr(table, 'aux_cnt', None)), 50)
         table.E.copy_(snap[0])
         table.acc.copy_(snap[1])
         res['scatter_adagrad_%s' % table.name] = dict(ms=t, bytes=by, gbs=by / t / 1e6, unique_rows=uniq,
