@@ -78,4 +78,14 @@ int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_a
                                 float* coef_buf, int32_t* aux_cnt, void* workspace,
                                 size_t workspace_bytes, hipStream_t s);
 
+// radix_sort.hip: graph-safe stable LSD sort of (key, src, coef) triples, n > 8192.
+// keys_raw: caller keys (ARX_KEY_NONE / out-of-range -> sentinel); src_raw/coef_raw may be
+// null (identity / 1.0).  *_tmp: ping-pong buffers of n entries; hist: radix_sort_hist_bytes().
+// list_count (optional): two ints zeroed by the first launch.
+size_t radix_sort_hist_bytes();
+int launch_radix_sort(const int32_t* keys_raw, const int32_t* src_raw, const float* coef_raw, int64_t n,
+                      uint32_t sentinel, int total_bits, uint32_t* keys_tmp, uint32_t* keys_out,
+                      int32_t* src_tmp, int32_t* src_out, float* coef_tmp, float* coef_out,
+                      int32_t* hist, int32_t* list_count, hipStream_t s);
+
 }  // namespace arx

@@ -153,254 +153,6 @@ static inline int launch_rank_sort(const int32_t* keys, int64_t n, uint32_t sent
   return ARX_OK;
 }
 
-// ---------------------------------------------------------------------------------------
-// Device-wide stable LSD radix sort of (key, position) for n > kRankSortMax, written for
-// hipGraph replay: kernel launches only (rocPRIM's onesweep resets a counter with a
-// blocking hipMemset -- see RsConfig -- and its merge sort takes 17 launches, ~90 us, at
-// n = 100k).  <= 256 blocks, each owning one contiguous slice of ipb items (4 wave-
-// contiguous quarters), 2-3 passes of <= 10 bits, two launches per pass:
-//   k_rs_hist     per-block digit histogram -> hist[blk][bin]
-//   k_rs_scatter  every block derives its global bases from hist itself (the scan over
-//                 <= 256 blocks is cheaper inline than a third launch), counts digits per
-//                 wave, then ranks: lanes with equal digits find each other with one
-//                 ballot per digit bit, the lowest such lane bumps the wave's running
-//                 counter in LDS.  Stable by construction (block < wave < round < lane).
-// The first pass reads the caller's raw int32 keys (normalising out-of-range ones to the
-// sentinel) and the last pass also emits src/coef in sorted order, so neither a prep nor
-// a gather launch is needed.
-constexpr int kRsThreads = 256;
-constexpr int kRsMaxBlocks = 256;
-constexpr int kRsMaxBits = 10;
-constexpr int kRsMaxBins = 1 << kRsMaxBits;
-
-__device__ __forceinline__ uint32_t norm_key(int32_t k, uint32_t sentinel) {
-  return (k == ARX_KEY_NONE || k < 0 || (uint32_t)k >= sentinel) ? sentinel : (uint32_t)k;
-}
-
-template <bool RAW>
-__global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__ keys_in, int64_t n,
-                                                        uint32_t sentinel, int shift, int bits,
-                                                        int64_t ipb, int32_t* __restrict__ hist,
-                                                        int32_t* __restrict__ list_count) {
-  __shared__ int h[kRsMaxBins];
-  const int bins = 1 << bits;
-  for (int b = threadIdx.x; b < bins; b += kRsThreads) h[b] = 0;
-  if (list_count && blockIdx.x == 0 && threadIdx.x == 0) { list_count[0] = 0; list_count[1] = 0; }
-  __syncthreads();
-  const int64_t base = blockIdx.x * ipb;
-  const int64_t end = min(n, base + ipb);
-  const uint32_t mask = (uint32_t)bins - 1u;
-  for (int64_t i = base + threadIdx.x; i < end; i += kRsThreads) {
-    uint32_t k;
-    if constexpr (RAW) k = norm_key(reinterpret_cast<const int32_t*>(keys_in)[i], sentinel);
-    else k = reinterpret_cast<const uint32_t*>(keys_in)[i];
-    atomicAdd(&h[(k >> shift) & mask], 1);
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < bins; b += kRsThreads) hist[(int64_t)blockIdx.x * bins + b] = h[b];
-}
-
-template <bool RAW, bool LAST>
-__global__ __launch_bounds__(kRsThreads) void k_rs_scatter(
-    const void* __restrict__ keys_in, const uint32_t* __restrict__ pos_in, int64_t n,
-    uint32_t sentinel, int shift, int bits, int64_t ipb, const int32_t* __restrict__ hist, int nblk,
-    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ pos_out,
-    const int32_t* __restrict__ src, const float* __restrict__ coef, int32_t* __restrict__ ssrc,
-    float* __restrict__ scoef) {
-  constexpr int NW = kRsThreads / 64;
-  __shared__ int wcnt[NW][kRsMaxBins];
-  __shared__ int gbase[kRsMaxBins];
-  __shared__ int stot[kRsMaxBins];
-  __shared__ int wsum[NW];
-  const int bins = 1 << bits;
-  const uint32_t mask = (uint32_t)bins - 1u;
-  const int lane = threadIdx.x & 63;
-  const int w = threadIdx.x >> 6;
-  // ---- global bases: below[b] = sum over earlier blocks, tot[b] = sum over all blocks ----
-  for (int b = threadIdx.x; b < bins; b += kRsThreads) {
-    int tot = 0, below = 0;
-    int blk = 0;
-    for (; blk + 8 <= nblk; blk += 8) {
-      int v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = hist[(int64_t)(blk + u) * bins + b];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        tot += v[u];
-        if (blk + u < (int)blockIdx.x) below += v[u];
-      }
-    }
-    for (; blk < nblk; ++blk) {
-      const int v = hist[(int64_t)blk * bins + b];
-      tot += v;
-      if (blk < (int)blockIdx.x) below += v;
-    }
-    gbase[b] = below;
-    stot[b] = tot;
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) wcnt[ww][b] = 0;
-  }
-  __syncthreads();
-  // exclusive scan of stot over the bins (thread t owns a contiguous chunk)
-  {
-    const int per = (bins + kRsThreads - 1) / kRsThreads;   // 1..4
-    const int b0 = threadIdx.x * per;
-    int s = 0;
-    for (int u = 0; u < per; ++u)
-      if (b0 + u < bins) s += stot[b0 + u];
-    int incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) wsum[w] = incl;
-    __syncthreads();
-    int woff = 0;
-    for (int ww = 0; ww < w; ++ww) woff += wsum[ww];
-    int run = woff + incl - s;
-    for (int u = 0; u < per; ++u)
-      if (b0 + u < bins) {
-        const int t = stot[b0 + u];
-        gbase[b0 + u] += run;
-        run += t;
-      }
-  }
-  // ---- phase 1: per-wave digit counts over the wave's contiguous quarter ----
-  const int64_t base = blockIdx.x * ipb;
-  const int64_t end = min(n, base + ipb);
-  const int64_t ipw = ipb / NW;
-  const int64_t wb = base + w * ipw;
-  const int64_t we = min(end, wb + ipw);
-  for (int64_t i = wb + lane; i < we; i += 64) {
-    uint32_t k;
-    if constexpr (RAW) k = norm_key(reinterpret_cast<const int32_t*>(keys_in)[i], sentinel);
-    else k = reinterpret_cast<const uint32_t*>(keys_in)[i];
-    atomicAdd(&wcnt[w][(k >> shift) & mask], 1);
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < bins; b += kRsThreads) {
-    int run = gbase[b];
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) {
-      const int c = wcnt[ww][b];
-      wcnt[ww][b] = run;
-      run += c;
-    }
-  }
-  __syncthreads();
-  // ---- phase 2: stable rank + scatter ----
-  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (int64_t i0 = wb; i0 < we; i0 += 64) {
-    const int64_t i = i0 + lane;
-    const bool valid = i < we;
-    uint32_t k = 0, p = 0;
-    if (valid) {
-      if constexpr (RAW) {
-        k = norm_key(reinterpret_cast<const int32_t*>(keys_in)[i], sentinel);
-        p = (uint32_t)i;
-      } else {
-        k = reinterpret_cast<const uint32_t*>(keys_in)[i];
-        p = pos_in[i];
-      }
-    }
-    const uint32_t dgt = (k >> shift) & mask;
-    unsigned long long peers = __ballot(valid);
-    for (int bit = 0; bit < bits; ++bit) {
-      const bool one = (dgt >> bit) & 1u;
-      const unsigned long long bb = __ballot(one);
-      peers &= one ? bb : ~bb;
-    }
-    if (valid) {
-      const int rank_in = __popcll(peers & lt);
-      const int old = wcnt[w][dgt];
-      if (rank_in == 0) wcnt[w][dgt] = old + __popcll(peers);
-      const int64_t dst = (int64_t)old + rank_in;
-      keys_out[dst] = k;
-      pos_out[dst] = p;
-      if constexpr (LAST) {
-        if (ssrc) {
-          ssrc[dst] = src ? src[p] : (int32_t)p;
-          scoef[dst] = coef ? coef[p] : 1.f;
-        }
-      }
-    }
-  }
-}
-
-struct RsPlan {
-  int nblk, passes, bits[4], shift[4];
-  int64_t ipb;
-};
-
-static inline RsPlan rs_plan(int64_t n, int total_bits) {
-  RsPlan p;
-  if (total_bits < 1) total_bits = 1;
-  p.passes = (total_bits + kRsMaxBits - 1) / kRsMaxBits;
-  const int r = (total_bits + p.passes - 1) / p.passes;
-  int sh = 0;
-  for (int i = 0; i < p.passes; ++i) {
-    p.bits[i] = (total_bits - sh) < r ? (total_bits - sh) : r;
-    p.shift[i] = sh;
-    sh += p.bits[i];
-  }
-  int64_t nblk = ceil_div(n, 2048);
-  if (nblk > kRsMaxBlocks) nblk = kRsMaxBlocks;
-  if (nblk < 1) nblk = 1;
-  p.ipb = ceil_div(ceil_div(n, nblk), kRsThreads) * kRsThreads;
-  p.nblk = (int)ceil_div(n, p.ipb);
-  return p;
-}
-
-// Sorted keys/positions land in keys_out/pos_out (keys_tmp/pos_tmp: ping-pong buffers of
-// n entries; hist: kRsMaxBlocks*kRsMaxBins ints).  ssrc/scoef (optional) receive
-// src[pos]/coef[pos] in sorted order.
-static inline int launch_radix_sort(const int32_t* keys_raw, int64_t n, uint32_t sentinel,
-                                    int total_bits, uint32_t* keys_tmp, uint32_t* keys_out,
-                                    uint32_t* pos_tmp, uint32_t* pos_out, int32_t* hist,
-                                    int32_t* list_count, const int32_t* src, const float* coef,
-                                    int32_t* ssrc, float* scoef, hipStream_t s) {
-  const RsPlan p = rs_plan(n, total_bits);
-  // the last pass must write keys_out/pos_out: passes alternate backwards from there
-  const void* in_k = keys_raw;
-  const uint32_t* in_p = nullptr;
-  for (int i = 0; i < p.passes; ++i) {
-    const bool last = (i == p.passes - 1);
-    const bool to_out = ((p.passes - 1 - i) % 2) == 0;
-    uint32_t* out_k = to_out ? keys_out : keys_tmp;
-    uint32_t* out_p = to_out ? pos_out : pos_tmp;
-    if (i == 0) {
-      k_rs_hist<true><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, sentinel, p.shift[i], p.bits[i], p.ipb,
-                                                    hist, list_count);
-      ARX_CHECK_LAUNCH();
-      if (last)
-        k_rs_scatter<true, true><<<p.nblk, kRsThreads, 0, s>>>(
-            in_k, in_p, n, sentinel, p.shift[i], p.bits[i], p.ipb, hist, p.nblk, out_k, out_p, src,
-            coef, ssrc, scoef);
-      else
-        k_rs_scatter<true, false><<<p.nblk, kRsThreads, 0, s>>>(
-            in_k, in_p, n, sentinel, p.shift[i], p.bits[i], p.ipb, hist, p.nblk, out_k, out_p, src,
-            coef, ssrc, scoef);
-    } else {
-      k_rs_hist<false><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, sentinel, p.shift[i], p.bits[i],
-                                                     p.ipb, hist, nullptr);
-      ARX_CHECK_LAUNCH();
-      if (last)
-        k_rs_scatter<false, true><<<p.nblk, kRsThreads, 0, s>>>(
-            in_k, in_p, n, sentinel, p.shift[i], p.bits[i], p.ipb, hist, p.nblk, out_k, out_p, src,
-            coef, ssrc, scoef);
-      else
-        k_rs_scatter<false, false><<<p.nblk, kRsThreads, 0, s>>>(
-            in_k, in_p, n, sentinel, p.shift[i], p.bits[i], p.ipb, hist, p.nblk, out_k, out_p, src,
-            coef, ssrc, scoef);
-    }
-    ARX_CHECK_LAUNCH();
-    in_k = out_k;
-    in_p = out_p;
-  }
-  return ARX_OK;
-}
-
 // multi-site key generation (wide launch; the gathers are latency-bound)
 __global__ __launch_bounds__(256) void k_site_keys(CatSites st, int64_t table_rows,
                                                    int32_t* __restrict__ keys,
@@ -602,8 +354,8 @@ __device__ __forceinline__ void adagrad_row(float* __restrict__ E, float* __rest
 constexpr int kBig = 1 << 30;
 constexpr int kShortMaxAligned = 16;    // runs with more aligned pieces get a whole workgroup
 
-template <int LPR>
-__global__ __launch_bounds__(256) void k_sparse_win(
+template <int LPR, int WPW>
+__global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
     float* __restrict__ E, float* __restrict__ acc, float* __restrict__ bias,
     float* __restrict__ bias_acc, int d, const uint32_t* __restrict__ sk,
     const uint32_t* __restrict__ spos, const int32_t* __restrict__ ssrc,
@@ -614,16 +366,22 @@ __global__ __launch_bounds__(256) void k_sparse_win(
     int32_t* __restrict__ list_long, int32_t* __restrict__ list_short,
     int32_t* __restrict__ list_count) {
   constexpr int NSG = 64 / LPR;
-  __shared__ int s_src[4][64];
-  __shared__ float s_coef[4][64];
-  __shared__ uint32_t s_key[4][64];
+  constexpr int NWV = (WPW > 4) ? WPW : 4;    // waves per workgroup
+  __shared__ int s_src[NWV][64];
+  __shared__ float s_coef[NWV][64];
+  __shared__ uint32_t s_key[NWV][64];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int lig = lane % LPR;
   const int g = lane / LPR;
   const int col = lig * 4;
   const bool colok = col < d;
-  const int64_t w0 = ((int64_t)blockIdx.x * 4 + wv) * 64;
+  // WPW == 1: every wave owns a window (long runs: few leaders per window).
+  // WPW  > 1: the workgroup's WPW waves share ONE window and split its leaders (one-hot
+  //           ids: up to 64 single-row runs per window, a lone wave would walk them serially).
+  const int64_t w0 = (WPW == 1) ? ((int64_t)blockIdx.x * 4 + wv) * 64 : (int64_t)blockIdx.x * 64;
+  const int sgi = (WPW == 1) ? g : wv * NSG + g;          // this sub-group's first leader
+  constexpr int kStride = (WPW == 1) ? NSG : WPW * NSG;   // leaders taken per round
   if (w0 >= n) return;                       // whole wave (no workgroup barrier below)
   const int64_t p = w0 + lane;
   const bool inb = p < n;
@@ -654,7 +412,7 @@ __global__ __launch_bounds__(256) void k_sparse_win(
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   unsigned long long m = L;
-  for (int k = 0; k < g && m; ++k) m &= m - 1;             // sub-group g starts at the g-th leader
+  for (int k = 0; k < sgi && m; ++k) m &= m - 1;           // this sub-group starts at its sgi-th leader
   while (m) {
     const int i = __builtin_ctzll(m);
     const unsigned long long rest = (i == 63) ? 0ull : (L & ~((2ull << i) - 1ull));
@@ -747,7 +505,7 @@ __global__ __launch_bounds__(256) void k_sparse_win(
         }
       }
     }
-    for (int k = 0; k < NSG && m; ++k) m &= m - 1;         // next leader of this sub-group
+    for (int k = 0; k < kStride && m; ++k) m &= m - 1;     // next leader of this sub-group
   }
 }
 
@@ -1058,7 +816,7 @@ static int sparse_ws_layout(int64_t n, int d, SparseWs* w) {
   w->off_scratch_hb = o; o += align_up(pieces * 4, 256);
   w->off_ssrc = o; o += ni;
   w->off_scoef = o; o += ni;
-  w->off_hist = o; o += (size_t)kRsMaxBlocks * kRsMaxBins * 4;
+  w->off_hist = o; o += radix_sort_hist_bytes();
   w->off_temp = o; o += align_up(temp, 256);
   w->temp_bytes = temp;
   w->total = o;
@@ -1089,7 +847,8 @@ static int launch_apply(float* E, float* acc, float* bias, float* bias_acc, int 
                         const float* scoef, int64_t n, uint32_t sentinel, const float* G, int64_t ldg,
                         const float* gb_in, const float* lr_dev, const float* gscale_dev,
                         float* scratch, float* scratch_b, float* scratch_h, float* scratch_hb,
-                        int32_t* cnt, int32_t* list, int32_t* count, hipStream_t s) {
+                        int32_t* cnt, int32_t* list, int32_t* count, bool short_runs,
+                        hipStream_t s) {
   const int lpr = lanes_per_row(d);
   if (cnt != nullptr && n <= kRankSortMax) {
     // small batches (single-launch LDS rank sort regime): one sub-group per sorted position --
@@ -1107,10 +866,18 @@ static int launch_apply(float* E, float* acc, float* bias, float* bias_acc, int 
   const int grid = (int)ceil_div(ceil_div(n, 64), 4);
   int32_t* list_long = list;                       // <= n/64/17 entries
   int32_t* list_short = list + (n / 64 / (kShortMaxAligned + 1) + 2);   // pairs, <= n/64 entries
-  ARX_DISPATCH_LPR(lpr, (k_sparse_win<LPR><<<grid, 256, 0, s>>>(
-                            E, acc, bias, bias_acc, d, sk, spos, ssrc, scoef, n, sentinel, G, ldg,
-                            gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h, scratch_hb,
-                            list_long, list_short, count)));
+  if (short_runs) {   // one-hot ids: 8 waves share each window
+    const int grid8 = (int)ceil_div(n, 64);
+    ARX_DISPATCH_LPR(lpr, (k_sparse_win<LPR, 8><<<grid8, 512, 0, s>>>(
+                              E, acc, bias, bias_acc, d, sk, spos, ssrc, scoef, n, sentinel, G, ldg,
+                              gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h, scratch_hb,
+                              list_long, list_short, count)));
+  } else {
+    ARX_DISPATCH_LPR(lpr, (k_sparse_win<LPR, 1><<<grid, 256, 0, s>>>(
+                              E, acc, bias, bias_acc, d, sk, spos, ssrc, scoef, n, sentinel, G, ldg,
+                              gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h, scratch_hb,
+                              list_long, list_short, count)));
+  }
   ARX_CHECK_LAUNCH();
   {
     int64_t nlong = ceil_div(n, 64 * (int64_t)(kShortMaxAligned + 2));      // upper bound of long runs
@@ -1173,11 +940,11 @@ int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_a
                           ssrc, scoef);
     if (rc) return rc;
   } else if (!use_rocprim_sort()) {   // own LSD radix sort: src/coef come out in sorted order too
-    rc = launch_radix_sort(keys_buf, n, sentinel, key_bits + 1,
+    rc = launch_radix_sort(keys_buf, src_buf, coef_buf, n, sentinel, key_bits + 1,
                            reinterpret_cast<uint32_t*>(base + w.off_keys_tmp), keys_out,
-                           reinterpret_cast<uint32_t*>(base + w.off_pos_in), pos_out,
-                           reinterpret_cast<int32_t*>(base + w.off_hist), count, src_buf, coef_buf,
-                           ssrc, scoef, s);
+                           reinterpret_cast<int32_t*>(base + w.off_pos_in), ssrc,
+                           reinterpret_cast<float*>(base + w.off_pos_out), scoef,
+                           reinterpret_cast<int32_t*>(base + w.off_hist), count, s);
     if (rc) return rc;
   } else {   // rocPRIM merge sort (A/B aid); the apply pass follows the position indirection
     uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(base + w.off_keys_tmp);
@@ -1199,7 +966,7 @@ int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_a
   const float* gb_in = bias ? Gb : nullptr;
   return launch_apply(E, acc, bias, bias_acc, d, keys_out, spos_arg, src_arg, coef_arg, n, sentinel, G,
                       ldg, gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h, scratch_hb,
-                      aux_cnt, list, count, s);
+                      aux_cnt, list, count, /*short_runs=*/true, s);
 }
 
 }  // namespace arx
@@ -1277,9 +1044,10 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
     // own LSD radix sort; src/coef are emitted in sorted order (one hop less per contribution)
     int32_t* ssrc = reinterpret_cast<int32_t*>(base + w.off_ssrc);
     float* scoef = reinterpret_cast<float*>(base + w.off_scoef);
-    rc = launch_radix_sort(keys, n, sentinel, key_bits + 1, keys_tmp, keys_out, pos_in, pos_out,
-                           reinterpret_cast<int32_t*>(base + w.off_hist), count, src, coef, ssrc,
-                           scoef, s);
+    rc = launch_radix_sort(keys, src, coef, n, sentinel, key_bits + 1, keys_tmp, keys_out,
+                           reinterpret_cast<int32_t*>(pos_in), ssrc,
+                           reinterpret_cast<float*>(pos_out), scoef,
+                           reinterpret_cast<int32_t*>(base + w.off_hist), count, s);
     if (rc) return rc;
     spos_arg = nullptr;
     src = ssrc;
@@ -1300,7 +1068,8 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
   return launch_apply(E, acc, bias, bias_acc, d, keys_out, spos_arg, src, coef, n, sentinel, G, ldg,
                       gb_in, lr_dev, gscale_dev, scratch, scratch_b,
                       reinterpret_cast<float*>(base + w.off_scratch_h),
-                      reinterpret_cast<float*>(base + w.off_scratch_hb), aux_cnt, list, count, s);
+                      reinterpret_cast<float*>(base + w.off_scratch_hb), aux_cnt, list, count,
+                      /*short_runs=*/false, s);
 }
 
 int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const float* lr_dev,

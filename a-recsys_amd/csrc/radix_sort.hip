@@ -1,0 +1,293 @@
+// radix_sort.hip -- device-wide stable LSD radix sort of (key, src, coef) triples for K7
+// (sparse Adagrad) when the batch exceeds the single-launch LDS rank sort (n > 8192).
+//
+// Written for hipGraph replay: kernel launches only.  rocPRIM 4.2's onesweep resets its
+// ordered-block-id counter on gfx942/gfx950 with a BLOCKING hipMemset
+// (rocprim/device/detail/ordered_block_id.hpp, reset_from_host) -- not captured, so a
+// replayed graph walks off the lookback array -- and its merge sort takes 17 launches
+// (~90 us) at n = 100k.
+//
+// Layout: <= 256 blocks, each owning one contiguous slice of ipb items split into four
+// wave-contiguous quarters; 2-3 passes of <= 10 bits; three launches per pass:
+//   k_rs_hist     per-WAVE digit histogram -> hist[blk*4 + wave][bin]
+//   k_rs_scan     exclusive scan down every histogram column (<= 1024 rows), in place
+//   k_rs_scatter  wave start offset = bin base + its scanned row; lanes with equal digits
+//                 find each other with one ballot per digit bit and the lowest such lane
+//                 bumps the wave's running counter in LDS.  Stable by construction
+//                 (block < wave < round < lane).
+// (An inline scan in the scatter kernel was measured first: 16 dependent batches of loads
+// per block at 256 blocks, ~16 us per pass -- the extra launch is cheaper.)
+// The first pass reads the caller's raw int32 keys (out-of-range ones become the
+// sentinel) and raw src/coef; the payload travels with the key (coalesced 12 B per item
+// per pass instead of two random 4-byte gathers -- 64 B sectors each -- at the end).
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace arx {
+
+namespace {
+
+constexpr int kRsThreads = 256;
+constexpr int kRsMaxBlocks = 256;
+constexpr int kRsMaxBits = 10;
+constexpr int kRsMaxBins = 1 << kRsMaxBits;
+
+__device__ __forceinline__ uint32_t norm_key(int32_t k, uint32_t sentinel) {
+  return (k == ARX_KEY_NONE || k < 0 || (uint32_t)k >= sentinel) ? sentinel : (uint32_t)k;
+}
+
+template <bool RAW>
+__device__ __forceinline__ uint32_t load_key(const void* keys_in, int64_t i, uint32_t sentinel) {
+  if constexpr (RAW) return norm_key(reinterpret_cast<const int32_t*>(keys_in)[i], sentinel);
+  else return reinterpret_cast<const uint32_t*>(keys_in)[i];
+}
+
+constexpr int kRsWaves = kRsThreads / 64;
+
+// per-WAVE digit histograms: hist[(blk * 4 + wave)][bin] over the wave's contiguous quarter
+template <bool RAW>
+__global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__ keys_in, int64_t n,
+                                                        uint32_t sentinel, int shift, int bits,
+                                                        int64_t ipb, int32_t* __restrict__ hist,
+                                                        int32_t* __restrict__ list_count) {
+  __shared__ int h[kRsWaves][kRsMaxBins];
+  const int bins = 1 << bits;
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  for (int b = lane; b < bins; b += 64) h[w][b] = 0;
+  if (list_count && blockIdx.x == 0 && threadIdx.x == 0) {
+    list_count[0] = 0;
+    list_count[1] = 0;
+  }
+  const int64_t base = blockIdx.x * ipb;
+  const int64_t end = min(n, base + ipb);
+  const int64_t ipw = ipb / kRsWaves;
+  const int64_t wb = base + w * ipw;
+  const int64_t we = min(end, wb + ipw);
+  const uint32_t mask = (uint32_t)bins - 1u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int64_t i0 = wb + lane; i0 < we; i0 += 8 * 64) {
+    uint32_t k[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {      // 8 loads in flight: the loop is a chain of L2 round trips otherwise
+      const int64_t i = i0 + u * 64;
+      k[u] = (i < we) ? load_key<RAW>(keys_in, i, sentinel) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * 64 < we) atomicAdd(&h[w][(k[u] >> shift) & mask], 1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int32_t* row = hist + ((int64_t)blockIdx.x * kRsWaves + w) * bins;
+  for (int b = lane; b < bins; b += 64) row[b] = h[w][b];
+}
+
+// Exclusive scan over the rows (waves, in sort order) of each histogram column, in place;
+// column totals to tot[].  One workgroup per 4 columns (int4), thread r <-> row r.
+__global__ __launch_bounds__(1024) void k_rs_scan(int32_t* __restrict__ hist, int nrows, int bins,
+                                                  int32_t* __restrict__ tot) {
+  __shared__ int4 wsum[16];
+  const int r = threadIdx.x;
+  const int lane = r & 63;
+  const int w = r >> 6;
+  int4* cell = reinterpret_cast<int4*>(hist + (int64_t)r * bins) + blockIdx.x;
+  int4 v = make_int4(0, 0, 0, 0);
+  if (r < nrows) v = *cell;
+  int4 incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int tx = __shfl_up(incl.x, o, 64), ty = __shfl_up(incl.y, o, 64);
+    const int tz = __shfl_up(incl.z, o, 64), tw = __shfl_up(incl.w, o, 64);
+    if (lane >= o) { incl.x += tx; incl.y += ty; incl.z += tz; incl.w += tw; }
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int4 off = make_int4(0, 0, 0, 0);
+  for (int ww = 0; ww < w; ++ww) {
+    off.x += wsum[ww].x; off.y += wsum[ww].y; off.z += wsum[ww].z; off.w += wsum[ww].w;
+  }
+  if (r < nrows)
+    *cell = make_int4(off.x + incl.x - v.x, off.y + incl.y - v.y, off.z + incl.z - v.z,
+                      off.w + incl.w - v.w);
+  if (r == nrows - 1)
+    reinterpret_cast<int4*>(tot)[blockIdx.x] =
+        make_int4(off.x + incl.x, off.y + incl.y, off.z + incl.z, off.w + incl.w);
+}
+
+template <bool RAW>
+__global__ __launch_bounds__(kRsThreads) void k_rs_scatter(
+    const void* __restrict__ keys_in, const int32_t* __restrict__ src_in,
+    const float* __restrict__ coef_in, int64_t n, uint32_t sentinel, int shift, int bits,
+    int64_t ipb, const int32_t* __restrict__ hist, const int32_t* __restrict__ tot,
+    uint32_t* __restrict__ keys_out, int32_t* __restrict__ src_out, float* __restrict__ coef_out) {
+  constexpr int NW = kRsWaves;
+  __shared__ int wcnt[NW][kRsMaxBins];
+  __shared__ int gbase[kRsMaxBins];
+  __shared__ int wsum[NW];
+  const int bins = 1 << bits;
+  const uint32_t mask = (uint32_t)bins - 1u;
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  // ---- bin bases: exclusive scan of the column totals (thread t owns a contiguous chunk);
+  // this wave's starting offsets: bin base + rows before it (k_rs_scan)
+  {
+    const int per = (bins + kRsThreads - 1) / kRsThreads;   // 1..4
+    const int b0 = threadIdx.x * per;
+    int tv[4];
+    int s = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      tv[u] = (u < per && b0 + u < bins) ? tot[b0 + u] : 0;
+      s += tv[u];
+    }
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int ww = 0; ww < w; ++ww) woff += wsum[ww];
+    int run = woff + incl - s;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u < per && b0 + u < bins) {
+        gbase[b0 + u] = run;
+        run += tv[u];
+      }
+  }
+  __syncthreads();
+  {
+    const int32_t* row = hist + ((int64_t)blockIdx.x * NW + w) * bins;
+    for (int b = lane; b < bins; b += 64) wcnt[w][b] = gbase[b] + row[b];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // ---- stable rank + scatter over the wave's contiguous quarter, 4 rounds of loads in flight
+  const int64_t base = blockIdx.x * ipb;
+  const int64_t end = min(n, base + ipb);
+  const int64_t ipw = ipb / NW;
+  const int64_t wb = base + w * ipw;
+  const int64_t we = min(end, wb + ipw);
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int64_t i0 = wb; i0 < we; i0 += 4 * 64) {
+    uint32_t k[4];
+    int32_t sv[4];
+    float cv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * 64 + lane;
+      const bool valid = i < we;
+      k[u] = valid ? load_key<RAW>(keys_in, i, sentinel) : 0u;
+      if constexpr (RAW) {
+        sv[u] = (valid && src_in) ? src_in[i] : (int32_t)i;
+        cv[u] = (valid && coef_in) ? coef_in[i] : 1.f;
+      } else {
+        sv[u] = valid ? src_in[i] : 0;
+        cv[u] = valid ? coef_in[i] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * 64 + lane;
+      const bool valid = i < we;
+      if (i0 + u * 64 >= we) break;                 // wave-uniform
+      const uint32_t dgt = (k[u] >> shift) & mask;
+      unsigned long long peers = __ballot(valid);
+      for (int bit = 0; bit < bits; ++bit) {
+        const bool one = (dgt >> bit) & 1u;
+        const unsigned long long bb = __ballot(one);
+        peers &= one ? bb : ~bb;
+      }
+      if (valid) {
+        const int rank_in = __popcll(peers & lt);
+        const int old = wcnt[w][dgt];
+        if (rank_in == 0) wcnt[w][dgt] = old + __popcll(peers);
+        const int64_t dst = (int64_t)old + rank_in;
+        keys_out[dst] = k[u];
+        src_out[dst] = sv[u];
+        coef_out[dst] = cv[u];
+      }
+    }
+  }
+}
+
+struct RsPlan {
+  int nblk, passes, bits[4], shift[4];
+  int64_t ipb;
+};
+
+RsPlan rs_plan(int64_t n, int total_bits) {
+  RsPlan p;
+  if (total_bits < 2) total_bits = 2;
+  p.passes = (total_bits + kRsMaxBits - 1) / kRsMaxBits;
+  const int r = (total_bits + p.passes - 1) / p.passes;
+  int sh = 0;
+  for (int i = 0; i < p.passes; ++i) {
+    p.bits[i] = (total_bits - sh) < r ? (total_bits - sh) : r;
+    p.shift[i] = sh;
+    sh += p.bits[i];
+  }
+  int64_t nblk = ceil_div(n, 1024);   // one 4-round batch per wave at small n (latency-bound there)
+  if (nblk > kRsMaxBlocks) nblk = kRsMaxBlocks;
+  if (nblk < 1) nblk = 1;
+  p.ipb = ceil_div(ceil_div(n, nblk), kRsThreads) * kRsThreads;
+  p.nblk = (int)ceil_div(n, p.ipb);
+  return p;
+}
+
+}  // namespace
+
+size_t radix_sort_hist_bytes() {   // per-wave rows + the column totals
+  return (size_t)(kRsMaxBlocks * kRsWaves + 1) * kRsMaxBins * sizeof(int32_t);
+}
+
+int launch_radix_sort(const int32_t* keys_raw, const int32_t* src_raw, const float* coef_raw, int64_t n,
+                      uint32_t sentinel, int total_bits, uint32_t* keys_tmp, uint32_t* keys_out,
+                      int32_t* src_tmp, int32_t* src_out, float* coef_tmp, float* coef_out,
+                      int32_t* hist, int32_t* list_count, hipStream_t s) {
+  const RsPlan p = rs_plan(n, total_bits);
+  const void* in_k = keys_raw;
+  const int32_t* in_s = src_raw;
+  const float* in_c = coef_raw;
+  for (int i = 0; i < p.passes; ++i) {
+    // the last pass must write the *_out buffers: passes alternate backwards from there
+    const bool to_out = ((p.passes - 1 - i) % 2) == 0;
+    uint32_t* out_k = to_out ? keys_out : keys_tmp;
+    int32_t* out_s = to_out ? src_out : src_tmp;
+    float* out_c = to_out ? coef_out : coef_tmp;
+    int32_t* tot = hist + (int64_t)kRsMaxBlocks * kRsWaves * kRsMaxBins;
+    const int bins = 1 << p.bits[i];
+    if (i == 0)
+      k_rs_hist<true><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, sentinel, p.shift[i], p.bits[i], p.ipb,
+                                                    hist, list_count);
+    else
+      k_rs_hist<false><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, sentinel, p.shift[i], p.bits[i],
+                                                     p.ipb, hist, nullptr);
+    ARX_CHECK_LAUNCH();
+    k_rs_scan<<<bins / 4, 1024, 0, s>>>(hist, p.nblk * kRsWaves, bins, tot);
+    ARX_CHECK_LAUNCH();
+    if (i == 0)
+      k_rs_scatter<true><<<p.nblk, kRsThreads, 0, s>>>(in_k, in_s, in_c, n, sentinel, p.shift[i],
+                                                       p.bits[i], p.ipb, hist, tot, out_k, out_s,
+                                                       out_c);
+    else
+      k_rs_scatter<false><<<p.nblk, kRsThreads, 0, s>>>(in_k, in_s, in_c, n, sentinel, p.shift[i],
+                                                        p.bits[i], p.ipb, hist, tot, out_k, out_s,
+                                                        out_c);
+    ARX_CHECK_LAUNCH();
+    in_k = out_k;
+    in_s = out_s;
+    in_c = out_c;
+  }
+  return ARX_OK;
+}
+
+}  // namespace arx

@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4096, help="interactions per step per GPU")
+    ap.add_argument("--batch", type=int, default=16384,
+                    help="interactions per step per GPU (SURVEY 8(d) C2 throughput batches: 4096, 16384)")
     ap.add_argument("--n-items", type=int, default=1000000)
     ap.add_argument("--n-users", type=int, default=1000000)
     ap.add_argument("--dim", type=int, default=128)
