@@ -78,6 +78,12 @@ int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_a
                                 float* coef_buf, int32_t* aux_cnt, void* workspace,
                                 size_t workspace_bytes, hipStream_t s);
 
+// gemm_nt.hip: logits GEMM with the A operand register-resident (K in {32,64,128});
+// ARX_EUNSUPPORTED for any other shape / alignment.
+int gemm_nt_smallk(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                   const float* B, int64_t ldb, float* C, int64_t ldc, const float* col_bias,
+                   hipStream_t s);
+
 // radix_sort.hip: graph-safe stable LSD sort of (key, src, coef) triples, n > 8192.
 // keys_raw: caller keys (ARX_KEY_NONE / out-of-range -> sentinel); src_raw/coef_raw may be
 // null (identity / 1.0).  *_tmp: ping-pong buffers of n entries; hist: radix_sort_hist_bytes().

@@ -327,6 +327,13 @@ int arx_gemm_f32_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K,
   ARX_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
                 "arx_gemm_f32: leading dimension too small");
   hipStream_t s = as_stream(stream);
+  if (!transA && transB && beta == 0.f && !a_rowsum) {   // the scorer shape: K = embedding width
+    static const bool old_nt = getenv("ARX_GEMM_NT_OLD") != nullptr;   // A/B aid
+    if (!old_nt) {
+      const int rc_nt = gemm_nt_smallk(M, N, K, alpha, A, lda, B, ldb, C, ldc, col_bias, s);
+      if (rc_nt != ARX_EUNSUPPORTED) return rc_nt;
+    }
+  }
   GemmPlan p = plan_gemm(M, N, K);
   float* partial = nullptr;
   float* rs_partial = nullptr;

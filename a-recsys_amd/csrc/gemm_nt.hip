@@ -1,0 +1,207 @@
+// gemm_nt.hip -- the scorer GEMM  logits[M,N] = U[M,K] . I[N,K]^T + b[N]  for K = d <= 128
+// (embed_attribute.py:171,188-193: tf.matmul(user, item_pool, transpose_b=True) + bias).
+//
+// K is the embedding width (32..128), so a generic K-loop kernel spends most of its time
+// in prologue / epilogue: at M=16384, N=1024, K=128 the tiled kernel in gemm.hip reaches
+// 59 TF (37% of the fp32 MFMA peak).  Here the whole K extent of the A operand lives in
+// REGISTERS for the lifetime of a workgroup:
+//   * a workgroup owns 128 rows of U (4 waves x 32 rows) and a range of item-pool tiles;
+//   * each lane keeps its row's K/2 values in K/8 float4 registers, laid out so that one
+//     16-byte LDS read of the B operand feeds four v_mfma_f32_32x32x2_f32 (the k index a
+//     lane supplies is arbitrary as long as A and B agree: lane l holds k = 8s + 4*(l/32) + j
+//     for MFMA j of step s);
+//   * pool tiles (64 items x K) stream into a double-buffered LDS image by LDS-DMA
+//     (global_load_lds_dwordx4: no staging registers, no ds_write pass, and -- unlike
+//     register-staged loads, which hipcc drained with s_waitcnt vmcnt(0) AHEAD of the MFMA
+//     block because the accumulators wanted the same registers -- the copy of tile t+1
+//     stays in flight while tile t is multiplied);
+//   * the DMA writes lane-linear (wave base + 16 B x lane), so the image is unpadded and
+//     bank conflicts are avoided by an XOR swizzle applied to the SOURCE chunk index and
+//     again on the ds_read_b128 side: 16 B chunk c of pool row r lives at slot c ^ swz(r);
+//   * 64 KB of LDS and ~200 VGPRs => two workgroups per CU.
+#include "common.h"
+
+namespace arx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kNtBM = 128;   // rows per workgroup
+constexpr int kNtBN = 64;    // pool rows (output columns) per tile
+
+template <int KT>
+__device__ __forceinline__ int nt_swz(int r) {
+  // chunks per row: 32 (K=128), 16 (K=64): 16 consecutive rows must hit 16 distinct 16-B
+  // slots of the 256-B bank row; 8 (K=32): rows are 128 B, pairs of rows share a bank row.
+  return (KT >= 64) ? (r & 15) : ((r >> 1) & 7);
+}
+
+template <int KT>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
+    int64_t M, int64_t N, const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+    int64_t ldb, float alpha, float* __restrict__ C, int64_t ldc,
+    const float* __restrict__ col_bias, int tiles_per_block, int nsplit) {
+  constexpr int NS = KT / 8;                  // steps of 4 MFMAs
+  constexpr int CPR = KT / 4;                 // 16-B chunks per pool row
+  constexpr int NLB = kNtBN * CPR / 256;      // DMA pieces per thread per tile
+  static_assert(NLB >= 1, "tile too small");
+  // two separate arrays (not sB[2][..]): the compiler must see that the DMA destination and
+  // the buffer being read never alias, or it drains the DMA (vmcnt(0)) before the first ds_read
+  __shared__ __attribute__((aligned(1024))) float sB0[kNtBN * KT];
+  __shared__ __attribute__((aligned(1024))) float sB1[kNtBN * KT];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  // XCD-aware order: the nsplit blocks that share one A panel get consecutive ids on one XCD
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x;
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int panel = bid / nsplit, part = bid % nsplit;
+  const int64_t m0 = (int64_t)panel * kNtBM;
+  const int64_t tiles_n = ceil_div(N, (int64_t)kNtBN);
+  const int64_t t_beg = (int64_t)part * tiles_per_block;
+  const int64_t t_end = min(tiles_n, t_beg + tiles_per_block);
+  if (t_beg >= t_end) return;
+
+  // LDS-DMA of one pool tile: piece f = threadIdx.x + 256 i lands at chunk f of the image;
+  // it fetches chunk (f % CPR) ^ swz(row) of pool row n0 + f / CPR (rows past N clamped:
+  // their columns are never stored).
+  auto dma_b = [&](int64_t t, float* img) {
+    const int64_t n0 = t * kNtBN;
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      const int f = threadIdx.x + i * 256;
+      const int r = f / CPR, slot = f % CPR;
+      const int c = slot ^ nt_swz<KT>(r);
+      const int64_t gr = min(n0 + r, N - 1);
+      const float* src = B + gr * ldb + c * 4;
+      float* dst = img + (f - lane) * 4;           // wave-uniform base; HW adds 16 B x lane
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  dma_b(t_beg, sB0);
+
+  // ---- A operand: this lane's row, k = 8s + 4*lhi + {0..3} ----
+  float4 a[NS];
+  {
+    const int64_t row = m0 + wave * 32 + l31;
+    const bool ok = row < M;
+    const float* ap = A + (ok ? row : 0) * lda + 4 * lhi;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a[s] = *reinterpret_cast<const float4*>(ap + 8 * s);
+    if (!ok) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) a[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // bias of the first tile (later ones are fetched one tile ahead, behind the DMA issue)
+  float bias0 = 0.f, bias1 = 0.f;
+  if (col_bias) {
+    const int64_t c0 = min(t_beg * kNtBN + l31, N - 1), c1 = min(t_beg * kNtBN + 32 + l31, N - 1);
+    bias0 = col_bias[c0];
+    bias1 = col_bias[c1];
+  }
+  __syncthreads();
+
+  // read-side swizzle: chunk 2s + lhi of pool row (l31 [+32]); swz(l31) == swz(l31 + 32)
+  const int sw = nt_swz<KT>(l31);
+  auto tile = [&](int64_t t, const float* cur_img, float* nxt_img) {
+    float nb0 = 0.f, nb1 = 0.f;
+    if (t + 1 < t_end) {
+      if (col_bias) {
+        const int64_t c0 = min((t + 1) * kNtBN + l31, N - 1);
+        const int64_t c1 = min((t + 1) * kNtBN + 32 + l31, N - 1);
+        nb0 = col_bias[c0];
+        nb1 = col_bias[c1];
+      }
+      dma_b(t + 1, nxt_img);
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      acc0[e] = 0.f;
+      acc1[e] = 0.f;
+    }
+    const float* b0p = cur_img + l31 * KT;
+    const float* b1p = b0p + 32 * KT;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int off = ((2 * s + lhi) ^ sw) * 4;
+      const float4 b0 = *reinterpret_cast<const float4*>(b0p + off);
+      const float4 b1 = *reinterpret_cast<const float4*>(b1p + off);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].x, b0.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].x, b1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].y, b0.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].y, b1.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].z, b0.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].z, b1.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].w, b0.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].w, b1.w, acc1, 0, 0, 0);
+    }
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const int64_t n0 = t * kNtBN;
+    const int64_t rbase = m0 + wave * 32 + 4 * lhi;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = n0 + j * 32 + l31;
+      if (col < N) {
+        const float bias = (j == 0) ? bias0 : bias1;
+        float* cp = C + rbase * ldc + col;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ro = (e & 3) + 8 * (e >> 2);
+          if (rbase + ro < M) cp[(int64_t)ro * ldc] = alpha * (j == 0 ? acc0[e] : acc1[e]) + bias;
+        }
+      }
+    }
+    bias0 = nb0;
+    bias1 = nb1;
+    __syncthreads();          // tile t+1 landed (vmcnt(0) rides on the barrier); buffer cur free
+  };
+  for (int64_t t = t_beg; t < t_end; t += 2) {
+    tile(t, sB0, sB1);
+    if (t + 1 < t_end) tile(t + 1, sB1, sB0);
+  }
+}
+
+}  // namespace
+
+// Returns ARX_EUNSUPPORTED when the shape is not this kernel's (caller falls back to the
+// tiled kernel): K in {32, 64, 128}, 16-byte aligned operands.
+int gemm_nt_smallk(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                   const float* B, int64_t ldb, float* C, int64_t ldc, const float* col_bias,
+                   hipStream_t s) {
+  if (!(K == 32 || K == 64 || K == 128)) return ARX_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) ||
+      (lda % 4) || (ldb % 4))
+    return ARX_EUNSUPPORTED;
+  const int64_t panels = ceil_div(M, (int64_t)kNtBM);
+  const int64_t tiles_n = ceil_div(N, (int64_t)kNtBN);
+  // enough workgroups for two per CU; each keeps >= 1 tile
+  int64_t nsplit = ceil_div((int64_t)cu_count() * 2, panels);
+  if (nsplit > tiles_n) nsplit = tiles_n;
+  if (nsplit < 1) nsplit = 1;
+  const int64_t tpb = ceil_div(tiles_n, nsplit);
+  nsplit = ceil_div(tiles_n, tpb);
+  const int64_t grid = panels * nsplit;
+  if (grid > 0x7fffffff) return ARX_EUNSUPPORTED;
+  if (K == 128)
+    k_gemm_nt_areg<128><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, alpha, C, ldc, col_bias,
+                                                   (int)tpb, (int)nsplit);
+  else if (K == 64)
+    k_gemm_nt_areg<64><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, alpha, C, ldc, col_bias,
+                                                  (int)tpb, (int)nsplit);
+  else
+    k_gemm_nt_areg<32><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, alpha, C, ldc, col_bias,
+                                                  (int)tpb, (int)nsplit);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+}  // namespace arx

@@ -189,6 +189,26 @@ def test_gemm_f32(dev, tA, tB, M, N, K):
     assert np.all(err2 <= 2e-6 * scale + 1e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(16384, 1024, 128), (300, 1000, 64), (129, 65, 32), (1, 1, 128),
+                                   (4096, 70, 128)])
+def test_gemm_nt_scorer_shape(dev, M, N, K):
+    """logits = U.I^T + b with K = embedding width: the register-resident-A kernel
+    (gemm_nt.hip), ragged M / N, bias and alpha in the epilogue."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = rng.standard_normal((N, K)).astype(np.float32)
+    bias = rng.standard_normal((N,)).astype(np.float32)
+    C = torch.full((M, N), 7.0, dtype=torch.float32, device=dev)
+    ops.gemm(_t(dev, A), _t(dev, Bm), C, ops.Workspace(dev), transB=True, alpha=0.25,
+             col_bias=_t(dev, bias))
+    ref = 0.25 * (A.astype(np.float64) @ Bm.astype(np.float64).T) + bias
+    scale = np.abs(A).astype(np.float64) @ np.abs(Bm).astype(np.float64).T
+    err = np.abs(C.cpu().numpy() - ref)
+    assert np.all(err <= 2e-6 * scale + 1e-5), float((err / (scale + 1e-9)).max())
+
+
 def _mask(rng, B, W, p=0.05):
     return (rng.random((B, W)) > p)
 
