@@ -30,7 +30,8 @@ namespace {
 
 constexpr int kRsThreads = 256;
 constexpr int kRsMaxBlocks = 256;
-constexpr int kRsMaxBits = 10;
+constexpr int kRsMaxBits = 11;    // 2 passes cover 22 key bits (a 1M-row table + the sentinel bit)
+constexpr int kRsPer = (1 << kRsMaxBits) / 256;   // bins per thread in the bin-base scan
 constexpr int kRsMaxBins = 1 << kRsMaxBits;
 
 __device__ __forceinline__ uint32_t norm_key(int32_t k, uint32_t sentinel) {
@@ -135,12 +136,12 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(
   // ---- bin bases: exclusive scan of the column totals (thread t owns a contiguous chunk);
   // this wave's starting offsets: bin base + rows before it (k_rs_scan)
   {
-    const int per = (bins + kRsThreads - 1) / kRsThreads;   // 1..4
+    const int per = (bins + kRsThreads - 1) / kRsThreads;   // 1..kRsPer
     const int b0 = threadIdx.x * per;
-    int tv[4];
+    int tv[kRsPer];
     int s = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kRsPer; ++u) {
       tv[u] = (u < per && b0 + u < bins) ? tot[b0 + u] : 0;
       s += tv[u];
     }
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(
     for (int ww = 0; ww < w; ++ww) woff += wsum[ww];
     int run = woff + incl - s;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < kRsPer; ++u)
       if (u < per && b0 + u < bins) {
         gbase[b0 + u] = run;
         run += tv[u];

@@ -247,9 +247,18 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
+            # PMC passes (FETCH_SIZE / WRITE_SIZE, tools/profile.sh) of this workload: HBM-side
+            # bytes per launch of the kernels behind the two roofline entries
             tr = json.load(open(pmc))
-            roofline["traffic"] = tr.get(dom)
-            roofline_hbm["traffic"] = tr.get(hb)
+            want = "c%d_b%d" % (3 if args.mulhot else 2, B)
+            tags = sorted(k for k in tr if want in k)
+            if tags:
+                ent = tr[tags[-1]]
+                roofline["traffic"] = (ent.get(dom) or {}).get("traffic_bytes")
+                roofline["traffic_source"] = "profiles/pmc_traffic.json:%s" % tags[-1]
+                hb_key = {"gather": "gather_mulhot" if args.mulhot else "gather_onehot",
+                          "scatter": "sparse_apply_window"}.get(hb.split("_")[0])
+                roofline_hbm["traffic"] = (ent.get(hb_key) or {}).get("traffic_bytes")
         except Exception:
             pass
 
