@@ -84,6 +84,15 @@ int gemm_nt_smallk(int64_t M, int64_t N, int64_t K, float alpha, const float* A,
                    const float* B, int64_t ldb, float* C, int64_t ldc, const float* col_bias,
                    hipStream_t s);
 
+// gemm_dma.hip: NN / TN GEMMs with N <= 128 (dU, dI): LDS-DMA streamed operands, dL read once.
+bool gemm_dma_supported(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,
+                        int64_t lda, const float* B, int64_t ldb);
+void gemm_dma_plan(int64_t M, int64_t N, int64_t K, int* bm, int* splits, int64_t* kchunk);
+int gemm_dma_launch(int transA, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
+                    int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc,
+                    const float* col_bias, float* partial, int bm, int splits, int64_t kchunk,
+                    float* a_rowsum, float* rowsum_partial, hipStream_t s);
+
 // radix_sort.hip: graph-safe stable LSD sort of (key, src, coef) triples, n > 8192.
 // keys_raw: caller keys (ARX_KEY_NONE / out-of-range -> sentinel); src_raw/coef_raw may be
 // null (identity / 1.0).  *_tmp: ping-pong buffers of n entries; hist: radix_sort_hist_bytes().

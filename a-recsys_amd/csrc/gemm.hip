@@ -313,8 +313,18 @@ extern "C" {
 size_t arx_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0) return 0;
   GemmPlan p = plan_gemm(M, N, K);
-  if (p.splits <= 1) return 0;
-  return (size_t)p.splits * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
+  size_t need = 0;
+  if (p.splits > 1) need = (size_t)p.splits * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
+  if (N <= 128 && K % 32 == 0) {   // the DMA kernels (gemm_dma.hip) plan their own split-K
+    int bm, sp;
+    int64_t kc;
+    gemm_dma_plan(M, N, K, &bm, &sp, &kc);
+    if (sp > 1) {
+      const size_t nd = (size_t)sp * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
+      if (nd > need) need = nd;
+    }
+  }
+  return need;
 }
 
 int arx_gemm_f32_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
@@ -333,6 +343,35 @@ int arx_gemm_f32_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K,
       const int rc_nt = gemm_nt_smallk(M, N, K, alpha, A, lda, B, ldb, C, ldc, col_bias, s);
       if (rc_nt != ARX_EUNSUPPORTED) return rc_nt;
     }
+  }
+  static const bool old_bwd = getenv("ARX_GEMM_DMA_OFF") != nullptr;   // A/B aid
+  if (!old_bwd && gemm_dma_supported(transA, transB, M, N, K, A, lda, B, ldb)) {
+    int bm, sp;
+    int64_t kc;
+    gemm_dma_plan(M, N, K, &bm, &sp, &kc);
+    float* part = nullptr;
+    float* rsp = nullptr;
+    if (sp > 1) {
+      const size_t need = (size_t)sp * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
+      if (!workspace || workspace_bytes < need) {
+        set_error("arx_gemm_f32: workspace too small (%zu < %zu)", workspace_bytes, need);
+        return ARX_EWORKSPACE;
+      }
+      part = reinterpret_cast<float*>(workspace);
+      if (a_rowsum) rsp = part + (size_t)sp * (size_t)M * (size_t)N;
+    }
+    int rc_d = gemm_dma_launch(transA, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, col_bias, part,
+                               bm, sp, kc, a_rowsum, rsp, s);
+    if (rc_d) return rc_d;
+    if (part) {
+      int64_t g = ceil_div(M * N, 256);
+      int64_t cap = (int64_t)cu_count() * 8;
+      if (g > cap) g = cap;
+      k_splitk_reduce<<<(int)g, 256, 0, s>>>(part, sp, M, N, alpha, beta, C, ldc, col_bias, rsp,
+                                             a_rowsum);
+      ARX_CHECK_LAUNCH();
+    }
+    return ARX_OK;
   }
   GemmPlan p = plan_gemm(M, N, K);
   float* partial = nullptr;

@@ -11,10 +11,10 @@ def t(fn, it=100):
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it * 1e3
-B, S, d = 4096, 1024, 128
+B, S, d = int(os.environ.get('GB_B', 4096)), 1024, 128
 U = torch.randn(B, d, device=dev); I = torch.randn(S, d, device=dev); L = torch.empty(B, S, device=dev)
 dL = torch.randn(B, S, device=dev); dU = torch.empty(B, d, device=dev); dI = torch.empty(S, d, device=dev)
-tag = 'big=%s small=%s force=%s' % (os.environ.get('ARX_GEMM_BK_BIG'), os.environ.get('ARX_GEMM_BK_SMALL'), os.environ.get('ARX_GEMM_FORCE'))
+tag = 'B=%d bm=%s splits=%s' % (B, os.environ.get('ARX_DMA_BM'), os.environ.get('ARX_DMA_SPLITS'))
 print(tag, 'logits %.1f us' % t(lambda: ops.gemm(U, I, L, ws, transB=True)),
       'dU %.1f us' % t(lambda: ops.gemm(dL, I, dU, ws)),
       'dI %.1f us' % t(lambda: ops.gemm(dL, U, dI, ws, transA=True)))
