@@ -7,6 +7,8 @@
 // One 256-thread workgroup per batch row; a row of S=1024 logits is one float4
 // per thread.  The row is read twice (sum, then gradient); the second read hits
 // L2, and dlogits may overwrite logits in place.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace arx {
@@ -105,6 +107,149 @@ __global__ __launch_bounds__(256) void k_loss_margin(
     if (WARP) dx[tcol] += dt;
     else if (dtscore) dtscore[r] = dt;
   }
+}
+
+// Sampled-pool rows (W <= 2048, e.g. S = 1024 negatives): ONE WAVE per row, the row lives
+// in registers (NV float4 per lane), read once; reductions are wave shuffles (no workgroup
+// barrier).  The workgroup-per-row kernel above is bound by the positives chain
+// (user -> pos_ptr -> pos_items -> item2slot: four dependent loads, ~5 us per row with
+// only 8 rows resident per CU: 48 us at B=16384 for 134 MB = 2.8 TB/s); with a wave per row
+// 32 rows per CU are in flight and the chain overlaps the row load.
+// Same arithmetic, same summation order per lane is NOT kept (lane-strided float4 instead
+// of thread-strided scalars): results agree to fp32 rounding, deterministic run to run.
+template <bool WARP, bool POS, int NV>
+__global__ __launch_bounds__(256) void k_loss_margin_wave(
+    const float* __restrict__ logits, int64_t ldl, const float* __restrict__ tscore,
+    const int32_t* __restrict__ target, const uint8_t* __restrict__ mask, int64_t ldm,
+    int64_t mask_rows, float gscale, const float* __restrict__ row_w, int64_t B, int64_t W,
+    float* __restrict__ batch_loss, float* dlogits, int64_t lddl, float* __restrict__ dtscore,
+    PosMask pm) {
+  __shared__ uint32_t bits_all[4][NV * 8];           // NV*256 columns -> NV*8 words per wave
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+  if (r >= B) return;                                 // whole wave (no workgroup barrier below)
+  uint32_t* bits = bits_all[wv];
+  const float* x = logits + r * ldl;
+  float4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int64_t c = (int64_t)i * 256 + lane * 4;
+    v[i] = (c + 3 < W) ? *reinterpret_cast<const float4*>(x + c)
+                       : make_float4(c < W ? x[c] : 0.f, c + 1 < W ? x[c + 1] : 0.f,
+                                     c + 2 < W ? x[c + 2] : 0.f, 0.f);
+  }
+  // keep bits of this lane's columns: bit (4*i + e) <-> column i*256 + lane*4 + e
+  uint32_t keep = 0u;
+  const int64_t mrow = r % mask_rows;
+  if (POS) {
+    if (lane < NV * 8) bits[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int u = pm.user_ids[mrow];
+    const int beg = pm.pos_ptr[u], end = pm.pos_ptr[u + 1];
+    for (int p = beg + lane; p < end; p += 64) {
+      const int j = pm.item2slot[pm.pos_items[p]];
+      if (j >= 0 && j < W) atomicOr(&bits[j >> 5], 1u << (j & 31));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = i * 256 + lane * 4;                // 4 columns inside one 32-bit word
+      const uint32_t nib = (bits[c >> 5] >> (c & 31)) & 0xFu;
+      keep |= ((~nib) & 0xFu) << (4 * i);
+    }
+  } else if (mask) {
+    const uint8_t* m = mask + mrow * ldm;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int64_t c = (int64_t)i * 256 + lane * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < W && m[c + e] != 0) keep |= 1u << (4 * i + e);
+    }
+  } else {
+    keep = 0xFFFFFFFFu;
+  }
+  const int tcol = WARP ? target[r] : -1;
+  const float t = WARP ? x[tcol] : tscore[r];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int64_t c = (int64_t)i * 256 + lane * 4;
+    const float e0 = v[i].x - t + 1.f, e1 = v[i].y - t + 1.f, e2 = v[i].z - t + 1.f,
+                e3 = v[i].w - t + 1.f;
+    s += (((keep >> (4 * i)) & 1u) && c < W && e0 > 0.f) ? e0 : 0.f;
+    s += (((keep >> (4 * i + 1)) & 1u) && c + 1 < W && e1 > 0.f) ? e1 : 0.f;
+    s += (((keep >> (4 * i + 2)) & 1u) && c + 2 < W && e2 > 0.f) ? e2 : 0.f;
+    s += (((keep >> (4 * i + 3)) & 1u) && c + 3 < W && e3 > 0.f) ? e3 : 0.f;
+  }
+  s = wsum(s);
+  if (lane == 0 && batch_loss) batch_loss[r] = logf(1.f + s);
+  if (!dlogits) return;
+  const float g = gscale * (row_w ? row_w[r] : 1.f) / (1.f + s);
+  float* dx = dlogits + r * lddl;
+  float cnt = 0.f;
+  float4 d[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int64_t c = (int64_t)i * 256 + lane * 4;
+    const bool a0 = ((keep >> (4 * i)) & 1u) && c < W && (v[i].x - t + 1.f > 0.f);
+    const bool a1 = ((keep >> (4 * i + 1)) & 1u) && c + 1 < W && (v[i].y - t + 1.f > 0.f);
+    const bool a2 = ((keep >> (4 * i + 2)) & 1u) && c + 2 < W && (v[i].z - t + 1.f > 0.f);
+    const bool a3 = ((keep >> (4 * i + 3)) & 1u) && c + 3 < W && (v[i].w - t + 1.f > 0.f);
+    cnt += (a0 ? 1.f : 0.f) + (a1 ? 1.f : 0.f) + (a2 ? 1.f : 0.f) + (a3 ? 1.f : 0.f);
+    d[i] = make_float4(a0 ? g : 0.f, a1 ? g : 0.f, a2 ? g : 0.f, a3 ? g : 0.f);
+  }
+  cnt = wsum(cnt);
+  const float dt = -g * cnt;
+  if (WARP) {     // the target column's owner folds dt in before the row is stored
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = i * 256 + lane * 4;
+      if (tcol >= c && tcol < c + 4) {
+        const int e = tcol - c;
+        if (e == 0) d[i].x += dt; else if (e == 1) d[i].y += dt; else if (e == 2) d[i].z += dt; else d[i].w += dt;
+      }
+    }
+  } else if (lane == 0 && dtscore) {
+    dtscore[r] = dt;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int64_t c = (int64_t)i * 256 + lane * 4;
+    if (c + 3 < W) {
+      *reinterpret_cast<float4*>(dx + c) = d[i];
+    } else {
+      if (c < W) dx[c] = d[i].x;
+      if (c + 1 < W) dx[c + 1] = d[i].y;
+      if (c + 2 < W) dx[c + 2] = d[i].z;
+    }
+  }
+}
+
+// launch helper: true if the wave-per-row kernel took the call
+template <bool WARP, bool POS>
+static bool launch_margin_wave(const float* logits, int64_t ldl, const float* tscore,
+                               const int32_t* target, const uint8_t* mask, int64_t ldm,
+                               int64_t mask_rows, float gscale, const float* row_w, int64_t B,
+                               int64_t W, float* batch_loss, float* dlogits, int64_t lddl,
+                               float* dtscore, PosMask pm, hipStream_t s) {
+  static const bool off = getenv("ARX_LOSS_WAVE_OFF") != nullptr;   // A/B aid
+  if (off || W > 2048 || (ldl % 4) || (dlogits && (lddl % 4)) ||
+      (reinterpret_cast<uintptr_t>(logits) & 15) || (reinterpret_cast<uintptr_t>(dlogits) & 15))
+    return false;
+  const int grid = (int)ceil_div(B, 4);
+  if (W <= 1024)
+    k_loss_margin_wave<WARP, POS, 4><<<grid, 256, 0, s>>>(logits, ldl, tscore, target, mask, ldm,
+                                                          mask_rows, gscale, row_w, B, W, batch_loss,
+                                                          dlogits, lddl, dtscore, pm);
+  else
+    k_loss_margin_wave<WARP, POS, 8><<<grid, 256, 0, s>>>(logits, ldl, tscore, target, mask, ldm,
+                                                          mask_rows, gscale, row_w, B, W, batch_loss,
+                                                          dlogits, lddl, dtscore, pm);
+  return true;
 }
 
 __global__ __launch_bounds__(256) void k_loss_ce(
@@ -222,6 +367,13 @@ int arx_loss_mw_fwdbwd(const float* logits, int64_t ldl, const float* tscore,
   ARX_CHECK_ARG(logits && tscore, "arx_loss_mw_fwdbwd: null pointer");
   ARX_CHECK_ARG(B >= 0 && S >= 0, "arx_loss_mw_fwdbwd: negative size");
   if (B == 0) return ARX_OK;
+  if (launch_margin_wave<false, false>(logits, ldl, tscore, nullptr, mask, ldm,
+                                       mask_rows > 0 ? mask_rows : B, gscale, row_w, B, S,
+                                       batch_loss, dlogits, lddl, dtscore, PosMask{},
+                                       as_stream(stream))) {
+    ARX_CHECK_LAUNCH();
+    return ARX_OK;
+  }
   k_loss_margin<false, false><<<(int)B, 256, 0, as_stream(stream)>>>(
       logits, ldl, tscore, nullptr, mask, ldm, mask_rows > 0 ? mask_rows : B, gscale, row_w, S,
       batch_loss, dlogits, lddl, dtscore, PosMask{});
@@ -237,6 +389,13 @@ int arx_loss_warp_fwdbwd(const float* logits, int64_t ldl, const int32_t* target
   ARX_CHECK_ARG(logits && target, "arx_loss_warp_fwdbwd: null pointer");
   ARX_CHECK_ARG(B >= 0 && V > 0, "arx_loss_warp_fwdbwd: bad size");
   if (B == 0) return ARX_OK;
+  if (launch_margin_wave<true, false>(logits, ldl, nullptr, target, mask, ldm,
+                                      mask_rows > 0 ? mask_rows : B, gscale, row_w, B, V,
+                                      batch_loss, dlogits, lddl, nullptr, PosMask{},
+                                      as_stream(stream))) {
+    ARX_CHECK_LAUNCH();
+    return ARX_OK;
+  }
   k_loss_margin<true, false><<<(int)B, 256, 0, as_stream(stream)>>>(
       logits, ldl, nullptr, target, mask, ldm, mask_rows > 0 ? mask_rows : B, gscale, row_w, V,
       batch_loss, dlogits, lddl, nullptr, PosMask{});
@@ -260,6 +419,14 @@ int arx_loss_mw_fwdbwd_pos(const float* logits, int64_t ldl, const float* tscore
     return ARX_EUNSUPPORTED;
   }
   if (B == 0) return ARX_OK;
+  if (launch_margin_wave<false, true>(logits, ldl, tscore, nullptr, nullptr, 0,
+                                      mask_rows > 0 ? mask_rows : B, gscale, row_w, B, S,
+                                      batch_loss, dlogits, lddl, dtscore,
+                                      PosMask{user_ids, pos_ptr, pos_items, item2slot},
+                                      as_stream(stream))) {
+    ARX_CHECK_LAUNCH();
+    return ARX_OK;
+  }
   const size_t lds = (size_t)((S + 31) / 32) * 4;
   k_loss_margin<false, true><<<(int)B, 256, lds, as_stream(stream)>>>(
       logits, ldl, tscore, nullptr, nullptr, 0, mask_rows > 0 ? mask_rows : B, gscale, row_w, S,
@@ -282,6 +449,14 @@ int arx_loss_warp_fwdbwd_pos(const float* logits, int64_t ldl, const int32_t* ta
     return ARX_EUNSUPPORTED;
   }
   if (B == 0) return ARX_OK;
+  if (launch_margin_wave<true, true>(logits, ldl, nullptr, target, nullptr, 0,
+                                     mask_rows > 0 ? mask_rows : B, gscale, row_w, B, V,
+                                     batch_loss, dlogits, lddl, nullptr,
+                                     PosMask{user_ids, pos_ptr, pos_items, item2slot},
+                                     as_stream(stream))) {
+    ARX_CHECK_LAUNCH();
+    return ARX_OK;
+  }
   const size_t lds = (size_t)((V + 31) / 32) * 4;
   auto kern = k_loss_margin<true, true>;
   if (lds > 48 * 1024)
