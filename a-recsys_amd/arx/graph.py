@@ -506,16 +506,84 @@ class Plan(object):
             if not m.fused:
                 m.scatter(1)                               # reset_mask (:217-218)
 
-    def _apply_sparse(self):
+    def _cat_eligible(self, entry):
         rt = self.rt
+        table, sites, bufs, total = entry
+        live = [s for s in sites if s.node._grad_written]
+        if not live or rt.force_sort_path or rt.cat_mode != 0:
+            return None
+        if not all(s.kind == 'cat' and s.col_off == 0 for s in live):
+            return None
+        if sum(s.n for s in live) > (1 << 22):
+            return None
+        return live
+
+    def _apply_sparse(self):
+        """One K7 pass per table -- except that one-hot tables of equal width that read the
+        same gradient arena share ONE pass (arx_sparse_adagrad_cat_multi): their kernel chains
+        are launch-bound, and parallel hipGraph branches did not overlap them (measured)."""
+        rt = self.rt
+        fused = []
+        if not rt.no_multi:
+            cand = []
+            for entry in self.tables:
+                live = self._cat_eligible(entry)
+                if live is not None:
+                    cand.append((entry, live))
+            if len(cand) >= 2:
+                e0, l0 = cand[0]
+                d0, arena0 = e0[0].E.shape[1], l0[0].node.arena
+                group = [(e, l) for e, l in cand
+                         if e[0].E.shape[1] == d0 and all(x.node.arena is arena0 for x in l)
+                         and all(x.node.arena_b is l0[0].node.arena_b for x in l)]
+                rows_bits = max(int(e[0].E.shape[0] - 1).bit_length() for e, _ in group) if group else 0
+                # below the LDS rank-sort limit a table's own chain is already 3 launches; fusing
+                # would push the union into the 8-launch radix path (measured slower at B=4096)
+                big = any(sum(x.n for x in l) > 8192 for _, l in group)
+                if (big and 2 <= len(group) <= 4 and sum(len(l) for _, l in group) <= 8
+                        and rows_bits + 2 <= 30):
+                    fused = group
+        if fused:
+            self._apply_multi(fused)
+        done = set(id(e) for e, _ in fused)
         toks = []
         for ti, entry in enumerate(self.tables):
-            tok = rt.fork(ti) if ti > 0 else None          # tables are independent
+            if id(entry) in done:
+                continue
+            tok = rt.fork(ti, 'tables') if ti > 0 else None          # tables are independent
             self._apply_one(entry)
             if tok is not None:
                 toks.append(rt.end_fork(tok))
         for t in toks:
             rt.join(t)
+
+    def _apply_multi(self, group):
+        rt = self.rt
+        key = tuple(id(x) for _, l in group for x in l) + tuple(
+            bool(e[0].bias is not None and any(x.node.bias_grad_used for x in l)) for e, l in group)
+        cache = self.__dict__.setdefault('_multi_cache', {})
+        ent = cache.get(key)
+        if ent is None:
+            tables, sites = [], []
+            for ti, (e, l) in enumerate(group):
+                table = e[0]
+                use_bias = table.bias is not None and any(x.node.bias_grad_used for x in l)
+                tables.append((table.E, table.acc, table.bias if use_bias else None,
+                               table.bias_acc if use_bias else None, self._aux_cnt(table)))
+                for x in l:
+                    sites.append((ti, x.maps[0], x.ids_node.value, x.node.row0, x.coef))
+            args = ops.MultiCatArgs(tables, sites)
+            n = args.total
+            ent = dict(args=args,
+                       keys=torch.empty(n, dtype=torch.int32, device=rt.device),
+                       src=torch.empty(n, dtype=torch.int32, device=rt.device),
+                       coef=torch.empty(n, dtype=torch.float32, device=rt.device),
+                       any_bias=any(t[2] is not None for t in tables))
+            cache[key] = ent
+        node0 = group[0][1][0].node
+        ops.sparse_adagrad_cat_multi(ent['args'], node0.arena, node0.arena_b if ent['any_bias'] else None,
+                                     rt.lr, ent['keys'], ent['src'], ent['coef'], rt.ws,
+                                     gscale_dev=rt.clip_coef_dev)
 
     def _apply_one(self, entry):
         rt = self.rt
@@ -627,10 +695,11 @@ class Runtime(object):
         import os as _os
         self.force_sort_path = bool(_os.environ.get('ARX_FORCE_SORT'))
         self.cat_mode = 1 if _os.environ.get('ARX_CAT_ATOMIC') else 0
+        self.no_multi = bool(_os.environ.get('ARX_NO_MULTI'))      # A/B aid: one K7 pass per table
         # fork/join branches inside the captured graph measured SLOWER on ROCm 7.2 (250 us vs
         # 187 us per C2 step: cross-stream graph edges cost more than the overlap buys at
         # these kernel sizes) -- opt-in only.
-        self.use_streams = bool(_os.environ.get('ARX_STREAMS'))
+        self.use_streams = _os.environ.get('ARX_STREAMS') or False    # '1': all branches, 'tables': K7 only
         self._side = None
         self._side_ws = None
         self._pending = []
@@ -638,10 +707,10 @@ class Runtime(object):
     # ---- fork/join onto side streams: independent branches of a step (the lookups of
     # different entities, the dU / dI GEMMs, the per-table sparse updates) run
     # concurrently; captured into the hipGraph the forks become parallel graph edges.
-    def fork(self, k):
+    def fork(self, k, kind='other'):
         """Start side branch k: returns a token for join().  Work issued until the
         matching end_fork() goes to side stream k with its own workspace."""
-        if not self.use_streams:
+        if not self.use_streams or (self.use_streams == 'tables' and kind != 'tables'):
             return None
         if self._side is None:
             self._side = [torch.cuda.Stream(device=self.device) for _ in range(3)]

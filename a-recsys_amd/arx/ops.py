@@ -278,6 +278,40 @@ def sparse_adagrad_cat(E, acc, bias, bias_acc, site_args, G, Gb, lr_dev, aux_fir
          _p(coef_buf), int(mode), wsp, wsn, _stream())
 
 
+class MultiCatArgs(object):
+    """Host-side descriptor arrays of arx_sparse_adagrad_cat_multi, built once per plan.
+    tables: list of (E, acc, bias|None, bias_acc|None, aux_cnt|None);
+    sites: list of (table_index, cat_map|None, ids, row_base, coef)."""
+
+    def __init__(self, tables, sites):
+        import ctypes as C
+        nt, ns = len(tables), len(sites)
+        self.nt, self.ns = nt, ns
+        self.d = int(tables[0][0].shape[1])
+        self.total = sum(int(s[2].shape[0]) for s in sites)
+        self.E = (C.c_void_p * nt)(*[_p(t[0]) for t in tables])
+        self.acc = (C.c_void_p * nt)(*[_p(t[1]) for t in tables])
+        self.bias = (C.c_void_p * nt)(*[_p(t[2]) or None for t in tables])
+        self.bias_acc = (C.c_void_p * nt)(*[_p(t[3]) or None for t in tables])
+        self.rows = (C.c_int64 * nt)(*[int(t[0].shape[0]) for t in tables])
+        self.cnt = (C.c_void_p * nt)(*[_p(t[4]) or None for t in tables])
+        self.site_table = (C.c_int32 * ns)(*[int(s[0]) for s in sites])
+        self.cat_map = (C.c_void_p * ns)(*[_p(s[1]) or None for s in sites])
+        self.ids = (C.c_void_p * ns)(*[_p(s[2]) for s in sites])
+        self.count = (C.c_int64 * ns)(*[int(s[2].shape[0]) for s in sites])
+        self.row_base = (C.c_int32 * ns)(*[int(s[3]) for s in sites])
+        self.coef = (C.c_float * ns)(*[float(s[4]) for s in sites])
+        self._keep = (tables, sites)
+
+
+def sparse_adagrad_cat_multi(args, G, Gb, lr_dev, keys_buf, src_buf, coef_buf, ws, gscale_dev=None):
+    wsp, wsn = ws.get(_lib.lib.arx_sparse_adagrad_workspace_bytes(args.total))
+    call("arx_sparse_adagrad_cat_multi", args.nt, args.E, args.acc, args.bias, args.bias_acc,
+         args.rows, args.cnt, args.d, args.ns, args.site_table, args.cat_map, args.ids, args.count,
+         args.row_base, args.coef, _p(G), _ld(G), _p(Gb), _p(lr_dev), _p(gscale_dev), _p(keys_buf),
+         _p(src_buf), _p(coef_buf), wsp, wsn, _stream())
+
+
 def adagrad_dense(w, acc, g, lr_dev, gscale_dev=None):
     call("arx_adagrad_dense", _p(w), _p(acc), _p(g), int(w.numel()), _p(lr_dev), _p(gscale_dev),
          _stream())

@@ -60,6 +60,7 @@ int cu_count();
 // j < offs[s+1]-offs[s], key = cat_map[s] ? cat_map[s][ids[s][j]] : ids[s][j], gradient
 // row row_base[s] + j, factor coef[s].
 constexpr int kMaxSites = 8;
+constexpr int kMaxTables = 4;
 struct CatSites {
   int nsites;
   int64_t offs[kMaxSites + 1];
@@ -67,16 +68,30 @@ struct CatSites {
   const int32_t* ids[kMaxSites];
   int32_t row_base[kMaxSites];
   float coef[kMaxSites];
+  int32_t table[kMaxSites];        // which table of the TableSet the site updates
+  int64_t rows[kMaxTables];        // rows of each table (key validation)
+  int kb;                          // sort key = (table << kb) | row
+};
+
+// Tables updated by ONE sparse-Adagrad pass.  Several tables of equal width share a sort and
+// an apply launch (the per-table kernel chains are launch-bound: 12 launches of ~5 us per
+// table at B=16384): the sort key carries the table index above the row bits.
+struct TableSet {
+  float* E[kMaxTables];
+  float* acc[kMaxTables];
+  float* bias[kMaxTables];         // null: table without bias
+  float* bias_acc[kMaxTables];
+  int32_t* cnt[kMaxTables];        // per-row arrival counters (ticket apply), may be null
+  int kb;                          // row bits of the key
 };
 
 // optim.hip: key generation + single-workgroup sort + the two Adagrad passes
 // (n <= 16384 contributions); returns ARX_* codes.
-int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_acc,
-                                int64_t table_rows, int d, const CatSites& st, const float* G,
-                                int64_t ldg, const float* Gb, const float* lr_dev,
+int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const CatSites& st,
+                                const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
                                 const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
-                                float* coef_buf, int32_t* aux_cnt, void* workspace,
-                                size_t workspace_bytes, hipStream_t s);
+                                float* coef_buf, void* workspace, size_t workspace_bytes,
+                                hipStream_t s);
 
 // gemm_nt.hip: logits GEMM with the A operand register-resident (K in {32,64,128});
 // ARX_EUNSUPPORTED for any other shape / alignment.

@@ -154,8 +154,7 @@ static inline int launch_rank_sort(const int32_t* keys, int64_t n, uint32_t sent
 }
 
 // multi-site key generation (wide launch; the gathers are latency-bound)
-__global__ __launch_bounds__(256) void k_site_keys(CatSites st, int64_t table_rows,
-                                                   int32_t* __restrict__ keys,
+__global__ __launch_bounds__(256) void k_site_keys(CatSites st, int32_t* __restrict__ keys,
                                                    int32_t* __restrict__ src,
                                                    float* __restrict__ coef) {
   const int64_t n = st.offs[st.nsites];
@@ -169,7 +168,9 @@ __global__ __launch_bounds__(256) void k_site_keys(CatSites st, int64_t table_ro
     const int64_t j = i - st.offs[s];
     const int id = st.ids[s][j];
     const int key = st.cat_map[s] ? st.cat_map[s][id] : id;
-    keys[i] = (key < 0 || key >= table_rows) ? ARX_KEY_NONE : key;
+    const int tb = st.table[s];
+    const int64_t rows = tb == 0 ? st.rows[0] : tb == 1 ? st.rows[1] : tb == 2 ? st.rows[2] : st.rows[3];
+    keys[i] = (key < 0 || key >= rows) ? ARX_KEY_NONE : ((tb << st.kb) | key);
     src[i] = st.row_base[s] + (int32_t)j;
     coef[i] = st.coef[s];
   }
@@ -193,52 +194,6 @@ __global__ __launch_bounds__(1024) void k_small_sort(const int32_t* __restrict__
     if (idx < n) {
       const int32_t r = keys[idx];
       kk = (r == ARX_KEY_NONE || r < 0 || (uint32_t)r >= sentinel) ? sentinel : (uint32_t)r;
-    }
-    k[i] = kk;
-    v[i] = (uint32_t)idx;
-  }
-  Sort().sort(k, v, storage, 0, key_bits + 1);
-#pragma unroll
-  for (int i = 0; i < IPT; ++i) {
-    const int64_t idx = (int64_t)threadIdx.x * IPT + i;
-    if (idx < n) {
-      sk[idx] = k[i];
-      spos[idx] = v[i];
-    }
-  }
-}
-
-// Same, with the key generation of up to 8 one-hot lookup sites folded in: the
-// workgroup gathers key = cat_map[id] itself and also emits the gradient-source row
-// and coefficient of every contribution (what arx_sparse_site_onehot would write).
-template <int IPT>
-__global__ __launch_bounds__(1024) void k_small_sort_sites(CatSites st, int64_t table_rows,
-                                                           uint32_t sentinel, int key_bits,
-                                                           uint32_t* __restrict__ sk,
-                                                           uint32_t* __restrict__ spos,
-                                                           int32_t* __restrict__ src_buf,
-                                                           float* __restrict__ coef_buf,
-                                                           int32_t* __restrict__ list_count) {
-  using Sort = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint32_t, 1, 1, 8>;
-  __shared__ typename Sort::storage_type storage;
-  if (threadIdx.x == 0) { list_count[0] = 0; list_count[1] = 0; }
-  const int64_t n = st.offs[st.nsites];
-  uint32_t k[IPT], v[IPT];
-#pragma unroll
-  for (int i = 0; i < IPT; ++i) {
-    const int64_t idx = (int64_t)threadIdx.x * IPT + i;
-    uint32_t kk = sentinel;
-    if (idx < n) {
-      int s = 0;
-#pragma unroll
-      for (int q = 1; q < kMaxSites; ++q)
-        if (q < st.nsites && idx >= st.offs[q]) s = q;
-      const int64_t j = idx - st.offs[s];
-      const int id = st.ids[s][j];
-      const int key = st.cat_map[s] ? st.cat_map[s][id] : id;
-      kk = (key < 0 || key >= table_rows || (uint32_t)key >= sentinel) ? sentinel : (uint32_t)key;
-      src_buf[idx] = st.row_base[s] + (int32_t)j;
-      coef_buf[idx] = st.coef[s];
     }
     k[i] = kk;
     v[i] = (uint32_t)idx;
@@ -311,6 +266,38 @@ __device__ __forceinline__ int walk_piece(const uint32_t* __restrict__ sk,
   return consumed;
 }
 
+struct TabRow {
+  float* E;
+  float* acc;
+  float* bias;
+  float* bias_acc;
+  int32_t* cnt;
+  uint32_t row;
+};
+// key = (table << kb) | row  ->  that table's pointers (selects, not a runtime-indexed
+// kernel-argument array: that would go through scratch)
+template <bool MT>
+__device__ __forceinline__ TabRow tab_of(const TableSet& ts, uint32_t key) {
+  TabRow r;
+  if (!MT) {   // single table: wave-uniform pointers straight from the kernel arguments
+    r.row = key;
+    r.E = ts.E[0];
+    r.acc = ts.acc[0];
+    r.bias = ts.bias[0];
+    r.bias_acc = ts.bias_acc[0];
+    r.cnt = ts.cnt[0];
+    return r;
+  }
+  const uint32_t t = key >> ts.kb;
+  r.row = key & ((1u << ts.kb) - 1u);
+  r.E = t == 0 ? ts.E[0] : t == 1 ? ts.E[1] : t == 2 ? ts.E[2] : ts.E[3];
+  r.acc = t == 0 ? ts.acc[0] : t == 1 ? ts.acc[1] : t == 2 ? ts.acc[2] : ts.acc[3];
+  r.bias = t == 0 ? ts.bias[0] : t == 1 ? ts.bias[1] : t == 2 ? ts.bias[2] : ts.bias[3];
+  r.bias_acc = t == 0 ? ts.bias_acc[0] : t == 1 ? ts.bias_acc[1] : t == 2 ? ts.bias_acc[2] : ts.bias_acc[3];
+  r.cnt = t == 0 ? ts.cnt[0] : t == 1 ? ts.cnt[1] : t == 2 ? ts.cnt[2] : ts.cnt[3];
+  return r;
+}
+
 __device__ __forceinline__ void adagrad_row(float* __restrict__ E, float* __restrict__ acc,
                                             float* __restrict__ bias, float* __restrict__ bias_acc,
                                             int d, uint32_t row, int col, bool colok, int lig,
@@ -354,10 +341,9 @@ __device__ __forceinline__ void adagrad_row(float* __restrict__ E, float* __rest
 constexpr int kBig = 1 << 30;
 constexpr int kShortMaxAligned = 16;    // runs with more aligned pieces get a whole workgroup
 
-template <int LPR, int WPW>
+template <int LPR, int WPW, bool MT>
 __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
-    float* __restrict__ E, float* __restrict__ acc, float* __restrict__ bias,
-    float* __restrict__ bias_acc, int d, const uint32_t* __restrict__ sk,
+    TableSet ts, int d, const uint32_t* __restrict__ sk,
     const uint32_t* __restrict__ spos, const int32_t* __restrict__ ssrc,
     const float* __restrict__ scoef, int64_t n, uint32_t sentinel, const float* __restrict__ G,
     int64_t ldg, const float* __restrict__ Gb, const float* __restrict__ lr_dev,
@@ -419,14 +405,20 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
     const int e = rest ? __builtin_ctzll(rest) : nvalid;
     const int rows = e - i;
     const uint32_t rkey = s_key[wv][i];
+    const TabRow T = tab_of<MT>(ts, rkey);
+    float* __restrict__ E = T.E;
+    float* __restrict__ acc = T.acc;
+    float* __restrict__ bias = T.bias;
+    float* __restrict__ bias_acc = T.bias_acc;
+    const uint32_t rrow = T.row;
     const bool is_head = (H >> i) & 1ull;
     const bool continues = (e == 64) && (knext == rkey);
     const bool complete = is_head && !continues;
     // the table row is known up front: its loads fly with the gradient rows
     float4 wrow = make_float4(0.f, 0.f, 0.f, 0.f), arow = wrow;
     if (complete && colok) {
-      wrow = *reinterpret_cast<const float4*>(E + (int64_t)rkey * d + col);
-      arow = *reinterpret_cast<const float4*>(acc + (int64_t)rkey * d + col);
+      wrow = *reinterpret_cast<const float4*>(E + (int64_t)rrow * d + col);
+      arow = *reinterpret_cast<const float4*>(acc + (int64_t)rrow * d + col);
     }
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int t = 0; t < rows; t += 8) {
@@ -458,14 +450,14 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
         wrow.y -= lr * gg.y / sqrtf(arow.y);
         wrow.z -= lr * gg.z / sqrtf(arow.z);
         wrow.w -= lr * gg.w / sqrtf(arow.w);
-        *reinterpret_cast<float4*>(acc + (int64_t)rkey * d + col) = arow;
-        *reinterpret_cast<float4*>(E + (int64_t)rkey * d + col) = wrow;
+        *reinterpret_cast<float4*>(acc + (int64_t)rrow * d + col) = arow;
+        *reinterpret_cast<float4*>(E + (int64_t)rrow * d + col) = wrow;
       }
       if (bias && lig == 0) {
         const float gg = gb * gs;
-        const float ba = bias_acc[rkey] + gg * gg;
-        bias_acc[rkey] = ba;
-        bias[rkey] -= lr * gg / sqrtf(ba);
+        const float ba = bias_acc[rrow] + gg * gg;
+        bias_acc[rrow] = ba;
+        bias[rrow] -= lr * gg / sqrtf(ba);
       }
     } else {
       // ---- piece of a multi-piece run ----
@@ -516,10 +508,9 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
 //     dependent round trips instead of 2000;
 //   remaining blocks: one SUB-GROUP per SHORT run (head partial + <= 16 aligned partials,
 //     two round trips), grid-stride over the short list.
-template <int LPR>
+template <int LPR, bool MT>
 __global__ __launch_bounds__(1024) void k_sparse_finish(
-    float* __restrict__ E, float* __restrict__ acc, float* __restrict__ bias,
-    float* __restrict__ bias_acc, int d, const uint32_t* __restrict__ sk, int64_t n,
+    TableSet ts, int d, const uint32_t* __restrict__ sk, int64_t n,
     const float* __restrict__ lr_dev, const float* __restrict__ gscale_dev,
     const float* __restrict__ scratch, const float* __restrict__ scratch_b,
     const float* __restrict__ scratch_h, const float* __restrict__ scratch_hb,
@@ -563,7 +554,10 @@ __global__ __launch_bounds__(1024) void k_sparse_finish(
             tb += vb[u];
           }
       }
-      adagrad_row(E, acc, bias, bias_acc, d, key, col, colok, lig, tot, tb, lr, gs);
+      {
+        const TabRow T = tab_of<MT>(ts, key);
+        adagrad_row(T.E, T.acc, T.bias, T.bias_acc, d, T.row, col, colok, lig, tot, tb, lr, gs);
+      }
     }
     return;
   }
@@ -612,7 +606,10 @@ __global__ __launch_bounds__(1024) void k_sparse_finish(
         if (colok) t2 = f4_add2(t2, *reinterpret_cast<const float4*>(&sh[k][col]));
         t2b += shb[k];
       }
-      adagrad_row(E, acc, bias, bias_acc, d, key, col, colok, lig, t2, t2b, lr, gs);
+      {
+        const TabRow T = tab_of<MT>(ts, key);
+        adagrad_row(T.E, T.acc, T.bias, T.bias_acc, d, T.row, col, colok, lig, t2, t2b, lr, gs);
+      }
     }
   }
 }
@@ -624,16 +621,15 @@ __global__ __launch_bounds__(1024) void k_sparse_finish(
 // the arrival that makes the counter reach kBig knows all T partials are published: it
 // acquires, sums them in piece order (fixed order => deterministic) and applies Adagrad.
 
-template <int LPR>
+template <int LPR, bool MT>
 __global__ __launch_bounds__(256) void k_sparse_onepass(
-    float* __restrict__ E, float* __restrict__ acc, float* __restrict__ bias,
-    float* __restrict__ bias_acc, int d, const uint32_t* __restrict__ sk,
+    TableSet ts, int d, const uint32_t* __restrict__ sk,
     const uint32_t* __restrict__ spos /* null: ssrc/scoef already sorted */,
     const int32_t* __restrict__ ssrc, const float* __restrict__ scoef, int64_t n, uint32_t sentinel,
     const float* __restrict__ G, int64_t ldg, const float* __restrict__ Gb,
     const float* __restrict__ lr_dev, const float* __restrict__ gscale_dev,
     float* __restrict__ scratch, float* __restrict__ scratch_b, float* __restrict__ scratch_h,
-    float* __restrict__ scratch_hb, int32_t* __restrict__ cnt) {
+    float* __restrict__ scratch_hb) {
   constexpr int GPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int lig = lane % LPR;
@@ -658,8 +654,10 @@ __global__ __launch_bounds__(256) void k_sparse_onepass(
   const bool continues = (e == pend) && (e < n) && (sk[e] == key);
   const float lr = *lr_dev;
   const float gs = gscale_dev ? *gscale_dev : 1.f;
+  const TabRow T = tab_of<MT>(ts, key);
+  int32_t* __restrict__ cnt = T.cnt;
   if (head && !continues) {
-    adagrad_row(E, acc, bias, bias_acc, d, key, col, colok, lig, g, gb, lr, gs);
+    adagrad_row(T.E, T.acc, T.bias, T.bias_acc, d, T.row, col, colok, lig, g, gb, lr, gs);
     return;
   }
   // ---- piece of a multi-piece run ----
@@ -679,7 +677,7 @@ __global__ __launch_bounds__(256) void k_sparse_onepass(
     inc = 1 + (kBig - (int)(lo + 2));                // T = head piece + (lo + 1) aligned pieces
   }
   int old = 0;
-  if (lig == 0) old = atomicAdd(&cnt[key], inc);
+  if (lig == 0) old = atomicAdd(&cnt[T.row], inc);
   old = __shfl(old, 0, LPR);
   if (old + inc != kBig) return;
   __threadfence();                                   // acquire: drop stale L1 lines
@@ -724,8 +722,8 @@ __global__ __launch_bounds__(256) void k_sparse_onepass(
       }
     }
   }
-  adagrad_row(E, acc, bias, bias_acc, d, key, col, colok, lig, tot, tb, lr, gs);
-  if (lig == 0) cnt[key] = 0;
+  adagrad_row(T.E, T.acc, T.bias, T.bias_acc, d, T.row, col, colok, lig, tot, tb, lr, gs);
+  if (lig == 0) cnt[T.row] = 0;
 }
 
 __global__ void k_adagrad_dense(float* __restrict__ w, float* __restrict__ acc,
@@ -842,13 +840,13 @@ using namespace arx;
 namespace arx {
 
 // window apply (+ the long-run launch when runs can exceed the ticket's reach)
-static int launch_apply(float* E, float* acc, float* bias, float* bias_acc, int d,
-                        const uint32_t* sk, const uint32_t* spos, const int32_t* ssrc,
+static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uint32_t* spos, const int32_t* ssrc,
                         const float* scoef, int64_t n, uint32_t sentinel, const float* G, int64_t ldg,
                         const float* gb_in, const float* lr_dev, const float* gscale_dev,
                         float* scratch, float* scratch_b, float* scratch_h, float* scratch_hb,
-                        int32_t* cnt, int32_t* list, int32_t* count, bool short_runs,
+                        int32_t* list, int32_t* count, bool short_runs, bool multi,
                         hipStream_t s) {
+  const int32_t* cnt = ts.cnt[0];
   const int lpr = lanes_per_row(d);
   if (cnt != nullptr && n <= kRankSortMax) {
     // small batches (single-launch LDS rank sort regime): one sub-group per sorted position --
@@ -856,28 +854,33 @@ static int launch_apply(float* E, float* acc, float* bias, float* bias_acc, int 
     // every multi-piece run is finished by its last arriver, no second launch.
     const int64_t nwaves = ceil_div(n, 64 / lpr);
     const int grid_a = (int)ceil_div(nwaves, 4);
-    ARX_DISPATCH_LPR(lpr, (k_sparse_onepass<LPR><<<grid_a, 256, 0, s>>>(
-                              E, acc, bias, bias_acc, d, sk, spos, ssrc, scoef, n, sentinel, G, ldg,
-                              gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h, scratch_hb,
-                              cnt)));
+    if (multi) {
+      ARX_DISPATCH_LPR(lpr, (k_sparse_onepass<LPR, true><<<grid_a, 256, 0, s>>>(
+                                ts, d, sk, spos, ssrc, scoef, n, sentinel, G, ldg,
+                                gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h, scratch_hb)));
+    } else {
+      ARX_DISPATCH_LPR(lpr, (k_sparse_onepass<LPR, false><<<grid_a, 256, 0, s>>>(
+                                ts, d, sk, spos, ssrc, scoef, n, sentinel, G, ldg,
+                                gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h, scratch_hb)));
+    }
     ARX_CHECK_LAUNCH();
     return ARX_OK;
   }
   const int grid = (int)ceil_div(ceil_div(n, 64), 4);
   int32_t* list_long = list;                       // <= n/64/17 entries
   int32_t* list_short = list + (n / 64 / (kShortMaxAligned + 1) + 2);   // pairs, <= n/64 entries
+  const int grid8 = (int)ceil_div(n, 64);
+#define ARX_WIN_GO(WPW_, MT_, GRID_, THREADS_)                                                      \
+  ARX_DISPATCH_LPR(lpr, (k_sparse_win<LPR, WPW_, MT_><<<GRID_, THREADS_, 0, s>>>(                   \
+                            ts, d, sk, spos, ssrc, scoef, n, sentinel, G, ldg, gb_in, lr_dev,       \
+                            gscale_dev, scratch, scratch_b, scratch_h, scratch_hb, list_long,       \
+                            list_short, count)))
   if (short_runs) {   // one-hot ids: 8 waves share each window
-    const int grid8 = (int)ceil_div(n, 64);
-    ARX_DISPATCH_LPR(lpr, (k_sparse_win<LPR, 8><<<grid8, 512, 0, s>>>(
-                              E, acc, bias, bias_acc, d, sk, spos, ssrc, scoef, n, sentinel, G, ldg,
-                              gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h, scratch_hb,
-                              list_long, list_short, count)));
+    if (multi) { ARX_WIN_GO(8, true, grid8, 512); } else { ARX_WIN_GO(8, false, grid8, 512); }
   } else {
-    ARX_DISPATCH_LPR(lpr, (k_sparse_win<LPR, 1><<<grid, 256, 0, s>>>(
-                              E, acc, bias, bias_acc, d, sk, spos, ssrc, scoef, n, sentinel, G, ldg,
-                              gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h, scratch_hb,
-                              list_long, list_short, count)));
+    if (multi) { ARX_WIN_GO(1, true, grid, 256); } else { ARX_WIN_GO(1, false, grid, 256); }
   }
+#undef ARX_WIN_GO
   ARX_CHECK_LAUNCH();
   {
     int64_t nlong = ceil_div(n, 64 * (int64_t)(kShortMaxAligned + 2));      // upper bound of long runs
@@ -886,9 +889,15 @@ static int launch_apply(float* E, float* acc, float* bias, float* bias_acc, int 
     int64_t nshort = ceil_div(ceil_div(n, 64), nsg);                         // upper bound of short runs
     const int64_t cap = (int64_t)cu_count() * 2;
     if (nshort > cap) nshort = cap;
-    ARX_DISPATCH_LPR(lpr, (k_sparse_finish<LPR><<<(int)(nlong + nshort), 1024, 0, s>>>(
-                              E, acc, bias, bias_acc, d, sk, n, lr_dev, gscale_dev, scratch, scratch_b,
-                              scratch_h, scratch_hb, list_long, list_short, count, (int)nlong)));
+    if (multi) {
+      ARX_DISPATCH_LPR(lpr, (k_sparse_finish<LPR, true><<<(int)(nlong + nshort), 1024, 0, s>>>(
+                                ts, d, sk, n, lr_dev, gscale_dev, scratch, scratch_b,
+                                scratch_h, scratch_hb, list_long, list_short, count, (int)nlong)));
+    } else {
+      ARX_DISPATCH_LPR(lpr, (k_sparse_finish<LPR, false><<<(int)(nlong + nshort), 1024, 0, s>>>(
+                                ts, d, sk, n, lr_dev, gscale_dev, scratch, scratch_b,
+                                scratch_h, scratch_hb, list_long, list_short, count, (int)nlong)));
+    }
     ARX_CHECK_LAUNCH();
   }
   return ARX_OK;
@@ -898,12 +907,11 @@ static int launch_apply(float* E, float* acc, float* bias, float* bias_acc, int 
 
 namespace arx {
 
-int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_acc,
-                                int64_t table_rows, int d, const CatSites& st, const float* G,
-                                int64_t ldg, const float* Gb, const float* lr_dev,
+int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const CatSites& st,
+                                const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
                                 const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
-                                float* coef_buf, int32_t* aux_cnt, void* workspace,
-                                size_t workspace_bytes, hipStream_t s) {
+                                float* coef_buf, void* workspace, size_t workspace_bytes,
+                                hipStream_t s) {
   const int64_t n = st.offs[st.nsites];
   if (n == 0) return ARX_OK;
   SparseWs w;
@@ -913,8 +921,13 @@ int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_a
     set_error("arx_sparse_adagrad_cat: workspace too small (%zu < %zu)", workspace_bytes, w.total);
     return ARX_EWORKSPACE;
   }
-  int key_bits = 1;
-  while ((1ll << key_bits) < table_rows && key_bits < 30) ++key_bits;
+  int tbits = 0;                              // key = (table << kb) | row, sentinel above both
+  while ((1 << tbits) < ntables) ++tbits;
+  const int key_bits = ts.kb + tbits;
+  if (key_bits > 30) {
+    set_error("arx_sparse_adagrad_cat: %d key bits (rows + tables) exceed 30", key_bits);
+    return ARX_EUNSUPPORTED;
+  }
   const uint32_t sentinel = 1u << key_bits;
   char* base = reinterpret_cast<char*>(workspace);
   uint32_t* keys_out = reinterpret_cast<uint32_t*>(base + w.off_keys_out);
@@ -925,7 +938,7 @@ int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_a
   float* scratch_b = reinterpret_cast<float*>(base + w.off_scratch_b);
   {
     int64_t g = ceil_div(n, 256);
-    k_site_keys<<<(int)g, 256, 0, s>>>(st, table_rows, keys_buf, src_buf, coef_buf);
+    k_site_keys<<<(int)g, 256, 0, s>>>(st, keys_buf, src_buf, coef_buf);
     ARX_CHECK_LAUNCH();
   }
   int32_t* ssrc = reinterpret_cast<int32_t*>(base + w.off_ssrc);
@@ -963,10 +976,12 @@ int sparse_adagrad_sites_sorted(float* E, float* acc, float* bias, float* bias_a
     src_arg = src_buf;
     coef_arg = coef_buf;
   }
-  const float* gb_in = bias ? Gb : nullptr;
-  return launch_apply(E, acc, bias, bias_acc, d, keys_out, spos_arg, src_arg, coef_arg, n, sentinel, G,
-                      ldg, gb_in, lr_dev, gscale_dev, scratch, scratch_b, scratch_h, scratch_hb,
-                      aux_cnt, list, count, /*short_runs=*/true, s);
+  bool any_bias = false;
+  for (int t = 0; t < ntables; ++t) any_bias = any_bias || ts.bias[t] != nullptr;
+  const float* gb_in = any_bias ? Gb : nullptr;
+  return launch_apply(ts, d, keys_out, spos_arg, src_arg, coef_arg, n, sentinel, G, ldg, gb_in, lr_dev,
+                      gscale_dev, scratch, scratch_b, scratch_h, scratch_hb, list, count,
+                      /*short_runs=*/true, /*multi=*/ntables > 1, s);
 }
 
 }  // namespace arx
@@ -1065,11 +1080,18 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
         s, false)));
   }
   const float* gb_in = bias ? Gb : nullptr;
-  return launch_apply(E, acc, bias, bias_acc, d, keys_out, spos_arg, src, coef, n, sentinel, G, ldg,
-                      gb_in, lr_dev, gscale_dev, scratch, scratch_b,
+  TableSet ts = {};
+  ts.E[0] = E;
+  ts.acc[0] = acc;
+  ts.bias[0] = bias;
+  ts.bias_acc[0] = bias_acc;
+  ts.cnt[0] = aux_cnt;
+  ts.kb = key_bits;                            // single table: key >> kb == 0 for every real key
+  return launch_apply(ts, d, keys_out, spos_arg, src, coef, n, sentinel, G, ldg, gb_in, lr_dev,
+                      gscale_dev, scratch, scratch_b,
                       reinterpret_cast<float*>(base + w.off_scratch_h),
-                      reinterpret_cast<float*>(base + w.off_scratch_hb), aux_cnt, list, count,
-                      /*short_runs=*/false, s);
+                      reinterpret_cast<float*>(base + w.off_scratch_hb), list, count,
+                      /*short_runs=*/false, /*multi=*/false, s);
 }
 
 int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const float* lr_dev,

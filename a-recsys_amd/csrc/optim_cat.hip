@@ -308,10 +308,22 @@ int arx_sparse_adagrad_cat(float* E, float* acc, float* bias, float* bias_acc, i
   if (n == 0) return ARX_OK;
   ARX_CHECK_ARG(n < (int64_t)INT_MAX, "arx_sparse_adagrad_cat: too many contributions");
   hipStream_t s = as_stream(stream);
-  if (mode == 0)   // default: key generation + sort (LDS rank sort or device radix) + one-pass apply
-    return sparse_adagrad_sites_sorted(E, acc, bias, bias_acc, table_rows, d, st, G, ldg, Gb,
-                                       lr_dev, gscale_dev, keys_buf, src_buf, coef_buf, aux_cnt,
-                                       workspace, workspace_bytes, s);
+  if (mode == 0) {   // default: key generation + sort (LDS rank sort or device radix) + apply
+    TableSet ts = {};
+    ts.E[0] = E;
+    ts.acc[0] = acc;
+    ts.bias[0] = bias;
+    ts.bias_acc[0] = bias_acc;
+    ts.cnt[0] = aux_cnt;
+    int kb = 1;
+    while ((1ll << kb) < table_rows && kb < 30) ++kb;
+    ts.kb = kb;
+    st.kb = kb;
+    for (int q = 0; q < kMaxSites; ++q) st.table[q] = 0;
+    for (int q = 0; q < kMaxTables; ++q) st.rows[q] = table_rows;
+    return sparse_adagrad_sites_sorted(ts, 1, d, st, G, ldg, Gb, lr_dev, gscale_dev, keys_buf, src_buf,
+                                       coef_buf, workspace, workspace_bytes, s);
+  }
   {
     int64_t g = ceil_div(n, 256);
     int64_t cap = (int64_t)cu_count() * 8;
@@ -333,6 +345,74 @@ int arx_sparse_adagrad_cat(float* E, float* acc, float* bias, float* bias_acc, i
                             lr_dev, gscale_dev, aux_first, aux_cnt, aux_hot, (int)(aux_hot_len - 2))));
   ARX_CHECK_LAUNCH();
   return ARX_OK;
+}
+
+
+int arx_sparse_adagrad_cat_multi(int ntables, float* const* E, float* const* acc, float* const* bias,
+                                 float* const* bias_acc, const int64_t* table_rows,
+                                 int32_t* const* aux_cnt, int d, int nsites,
+                                 const int32_t* site_table, const int32_t* const* site_cat_map,
+                                 const int32_t* const* site_ids, const int64_t* site_n,
+                                 const int32_t* site_row_base, const float* site_coef, const float* G,
+                                 int64_t ldg, const float* Gb, const float* lr_dev,
+                                 const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
+                                 float* coef_buf, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  ARX_CHECK_ARG(ntables >= 1 && ntables <= kMaxTables, "arx_sparse_adagrad_cat_multi: 1..4 tables");
+  ARX_CHECK_ARG(nsites > 0 && nsites <= kMaxSites, "arx_sparse_adagrad_cat_multi: 1..8 lookup sites");
+  ARX_CHECK_ARG(E && acc && bias && bias_acc && table_rows && aux_cnt && site_table && site_cat_map &&
+                    site_ids && site_n && site_row_base && site_coef && G && lr_dev && keys_buf &&
+                    src_buf && coef_buf,
+                "arx_sparse_adagrad_cat_multi: null pointer");
+  if (d <= 0 || d % 4 != 0 || d > 256) {
+    set_error("arx_sparse_adagrad_cat_multi: d=%d unsupported (d %% 4 == 0, d <= 256)", d);
+    return ARX_EUNSUPPORTED;
+  }
+  ARX_CHECK_ARG(ldg % 4 == 0 && ldg >= d, "arx_sparse_adagrad_cat_multi: bad ldg");
+  TableSet ts = {};
+  CatSites st;
+  int kb = 1;
+  bool all_cnt = true, any_cnt = false;
+  for (int t = 0; t < kMaxTables; ++t) {
+    const bool live = t < ntables;
+    if (live) {
+      ARX_CHECK_ARG(E[t] && acc[t] && table_rows[t] > 0, "arx_sparse_adagrad_cat_multi: bad table");
+      ARX_CHECK_ARG((bias[t] == nullptr) == (bias_acc[t] == nullptr),
+                    "arx_sparse_adagrad_cat_multi: bias/bias_acc");
+      ARX_CHECK_ARG(!(bias[t] && !Gb), "arx_sparse_adagrad_cat_multi: bias table given without Gb");
+      while ((1ll << kb) < table_rows[t] && kb < 30) ++kb;
+      all_cnt = all_cnt && aux_cnt[t] != nullptr;
+      any_cnt = any_cnt || aux_cnt[t] != nullptr;
+    }
+    ts.E[t] = live ? E[t] : nullptr;
+    ts.acc[t] = live ? acc[t] : nullptr;
+    ts.bias[t] = live ? bias[t] : nullptr;
+    ts.bias_acc[t] = live ? bias_acc[t] : nullptr;
+    ts.cnt[t] = live ? aux_cnt[t] : nullptr;
+    st.rows[t] = live ? table_rows[t] : 0;
+  }
+  ARX_CHECK_ARG(all_cnt || !any_cnt, "arx_sparse_adagrad_cat_multi: aux_cnt for all tables or none");
+  ts.kb = kb;
+  st.kb = kb;
+  st.nsites = nsites;
+  st.offs[0] = 0;
+  for (int q = 0; q < kMaxSites; ++q) {
+    const bool live = q < nsites;
+    st.cat_map[q] = live ? site_cat_map[q] : nullptr;
+    st.ids[q] = live ? site_ids[q] : nullptr;
+    st.row_base[q] = live ? site_row_base[q] : 0;
+    st.coef[q] = live ? site_coef[q] : 0.f;
+    st.table[q] = live ? site_table[q] : 0;
+    st.offs[q + 1] = st.offs[q] + (live ? site_n[q] : 0);
+    if (live)
+      ARX_CHECK_ARG(site_ids[q] && site_n[q] >= 0 && site_table[q] >= 0 && site_table[q] < ntables,
+                    "arx_sparse_adagrad_cat_multi: bad site");
+  }
+  const int64_t n = st.offs[nsites];
+  if (n == 0) return ARX_OK;
+  ARX_CHECK_ARG(n < (int64_t)INT_MAX, "arx_sparse_adagrad_cat_multi: too many contributions");
+  return sparse_adagrad_sites_sorted(ts, ntables, d, st, G, ldg, Gb, lr_dev, gscale_dev, keys_buf,
+                                     src_buf, coef_buf, workspace, workspace_bytes, as_stream(stream));
 }
 
 }  // extern "C"

@@ -242,6 +242,25 @@ int arx_sparse_adagrad_cat(float* E, float* acc, float* bias, float* bias_acc, i
                            int32_t* src_buf, float* coef_buf, int mode, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* Several one-hot tables of equal width d in ONE pass (hmf_model.py:146-151 applies one
+ * Adagrad op per variable; the per-table kernel chains are launch-bound, so the tables
+ * share the key generation, the sort and the apply launches: the sort key carries the
+ * table index above the row bits).  Table t: E[t], acc[t], bias[t]/bias_acc[t] (NULL: no
+ * bias), table_rows[t], aux_cnt[t] (int32[table_rows[t]] zeros, for all tables or none).
+ * Site s updates table site_table[s]; the other site arrays as in arx_sparse_adagrad_cat.
+ * ntables <= 4, nsites <= 8, rows + table bits <= 30.
+ * workspace >= arx_sparse_adagrad_workspace_bytes(sum(site_n)). */
+int arx_sparse_adagrad_cat_multi(int ntables, float* const* E, float* const* acc, float* const* bias,
+                                 float* const* bias_acc, const int64_t* table_rows,
+                                 int32_t* const* aux_cnt, int d, int nsites,
+                                 const int32_t* site_table, const int32_t* const* site_cat_map,
+                                 const int32_t* const* site_ids, const int64_t* site_n,
+                                 const int32_t* site_row_base, const float* site_coef, const float* G,
+                                 int64_t ldg, const float* Gb, const float* lr_dev,
+                                 const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
+                                 float* coef_buf, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+
 /* ---- a16/a19: dense Adagrad, norms, clip ---------------------------------
  * tf.train.AdagradOptimizer dense apply; tf.clip_by_global_norm
  * (seqModel.py:180): coef = max_norm / max(sqrt(sq), max_norm). */

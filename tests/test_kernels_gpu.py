@@ -639,3 +639,83 @@ def test_sparse_adagrad_ticket_large_n(dev, n, Vf):
     np.testing.assert_allclose(outs[0][0].cpu().numpy(), rE, rtol=3e-4, atol=1e-4)
     np.testing.assert_allclose(outs[0][2].cpu().numpy(), rb, rtol=3e-4, atol=1e-4)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("d,rows,ns", [(128, (5000, 7000), (4096, 1024, 4096)),
+                                       (32, (40, 1000, 17), (300, 64, 50, 2000)),
+                                       (64, (100000, 300000), (20000, 30000))])
+def test_sparse_adagrad_cat_multi(dev, d, rows, ns):
+    """Several one-hot tables in one pass (table index in the sort key) == one reference
+    update per table; deterministic; counters left clean.  Small n: LDS rank sort + ticket
+    apply; large n: radix sort + window apply."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(d + sum(ns))
+    nt = len(rows)
+    m = sum(ns)
+    G = rng.standard_normal((m, d)).astype(np.float32)
+    Gb = rng.standard_normal((m,)).astype(np.float32)
+    tabs = []
+    for t, V in enumerate(rows):
+        E = rng.standard_normal((V, d)).astype(np.float32)
+        acc = (0.1 + rng.random((V, d))).astype(np.float32)
+        has_bias = (t != 1)
+        bias = rng.standard_normal((V,)).astype(np.float32)
+        bacc = np.full((V,), 0.1, dtype=np.float32)
+        tabs.append(dict(E=E, acc=acc, bias=bias, bacc=bacc, has_bias=has_bias, keys=[], src=[], coef=[]))
+    sites = []
+    base = 0
+    for k, n in enumerate(ns):
+        t = k % nt
+        V = rows[t]
+        N = 3 * V
+        cmap = rng.integers(-1, V, size=N).astype(np.int32) if k % 2 == 0 else None   # -1: dropped
+        ids = rng.integers(0, N if cmap is not None else V, size=n).astype(np.int32)
+        if n > 40:
+            ids[rng.choice(n, size=n // 3, replace=False)] = ids[0]       # a hot row
+        c = float(rng.random() + 0.5)
+        sites.append((t, cmap, ids, base, c))
+        key = cmap[ids] if cmap is not None else ids
+        tabs[t]['keys'].append(np.where(key < 0, 0x7FFFFFFF, key))
+        tabs[t]['src'].append(base + np.arange(n))
+        tabs[t]['coef'].append(np.full(n, c, dtype=np.float32))
+        base += n
+    refs = []
+    for tb in tabs:
+        keys = np.concatenate(tb['keys']) if tb['keys'] else np.zeros(0, np.int64)
+        src = np.concatenate(tb['src']).astype(np.int32) if tb['src'] else np.zeros(0, np.int32)
+        coef = np.concatenate(tb['coef']) if tb['coef'] else np.zeros(0, np.float32)
+        rE, racc, rb, rbacc = _ref_sparse_adagrad(tb['E'], tb['acc'], tb['bias'], tb['bacc'],
+                                                  keys.astype(np.int64), src, coef, G, Gb, 0.3, 0.7)
+        if not tb['has_bias']:
+            rb, rbacc = tb['bias'], tb['bacc']
+        refs.append((rE, racc, rb, rbacc))
+    lr = torch.tensor([0.3], dtype=torch.float32, device=dev)
+    gs = torch.tensor([0.7], dtype=torch.float32, device=dev)
+    outs = []
+    ws = ops.Workspace(dev)
+    for rep in range(2):
+        dtab = []
+        for tb in tabs:
+            cnt = torch.zeros((tb['E'].shape[0],), dtype=torch.int32, device=dev)
+            dtab.append((_t(dev, tb['E']), _t(dev, tb['acc']),
+                         _t(dev, tb['bias']) if tb['has_bias'] else None,
+                         _t(dev, tb['bacc']) if tb['has_bias'] else None, cnt))
+        dsites = [(t, _t(dev, cmap) if cmap is not None else None, _t(dev, ids), b, c)
+                  for (t, cmap, ids, b, c) in sites]
+        args = ops.MultiCatArgs(dtab, dsites)
+        kb = torch.empty(m, dtype=torch.int32, device=dev)
+        sb = torch.empty(m, dtype=torch.int32, device=dev)
+        cb = torch.empty(m, dtype=torch.float32, device=dev)
+        ops.sparse_adagrad_cat_multi(args, _t(dev, G), _t(dev, Gb), lr, kb, sb, cb, ws, gscale_dev=gs)
+        torch.cuda.synchronize()
+        for tt in dtab:
+            assert int(tt[4].abs().sum().item()) == 0
+        outs.append(dtab)
+    for t in range(nt):
+        rE, racc, rb, rbacc = refs[t]
+        np.testing.assert_allclose(outs[0][t][1].cpu().numpy(), racc, rtol=2e-4, atol=1e-5)
+        np.testing.assert_allclose(outs[0][t][0].cpu().numpy(), rE, rtol=2e-4, atol=2e-5)
+        if tabs[t]['has_bias']:
+            np.testing.assert_allclose(outs[0][t][2].cpu().numpy(), rb, rtol=2e-4, atol=2e-5)
+        assert torch.equal(outs[0][t][0], outs[1][t][0]) and torch.equal(outs[0][t][1], outs[1][t][1])
