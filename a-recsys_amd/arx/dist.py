@@ -6,22 +6,24 @@ ranks (owner = item % world); the user table is striped the same way and every
 rank trains on interactions of ITS users (pure data parallelism on that side).
 One step with B = world * B_loc interactions and a pool of S shared negatives
 (S/world owned by each rank) is algebraically the single-process step of
-hmf_model.py on the global batch; the exchanges are
+hmf_model.py on the global batch.  Exchanges per step and rank (SURVEY 8e's
+"gather the pool rows" alternative -- the [B, S] logits never cross xGMI):
 
-  all_gather   U_loc [B_loc,d]  -> U [B,d]            user latents
-  (local)      P_g = U . I_g^T + b_g   [B, S/world]    partial negative logits
-  all_to_all   P_g -> logits_loc [B_loc, S]            <- the negative-sample logits
-  reduce_scatter target scores t_g [B] -> t_loc [B_loc] (owner computes u_r . I[target_r])
-  (local)      WMRB loss fwd+bwd on [B_loc, S]
-  all_to_all   dlogits back to the owners  -> dP_g [B, S/world]
-  all_gather   dt_loc -> dt [B]
-  (local)      dI_g = dP_g^T . U (+ targets) -> scatter + sparse Adagrad on the shard
-  reduce_scatter dU partials [B,d] -> dU_loc [B_loc,d] -> Adagrad on the user shard
+  all_gather      owned pool rows [S/N, d+4] -> pool [S, d+4]        (0.5 MB at S=1024, d=128)
+  all_to_all(v)   target item ids  -> their owners                   (4 B per interaction)
+  all_to_all(v)   target rows [*, d+4] back                          (B_loc rows, (N-1)/N cross)
+  (local)         logits = U_loc . pool^T + b, WMRB loss, dU, user-shard Adagrad
+  reduce_scatter  pool gradient partials [S, d+4] -> owner blocks    (0.5 MB)
+  all_to_all(v)   target-row gradients -> owners                     (B_loc rows)
+  (local)         item-shard scatter + Adagrad (pool block + received target gradients)
 
-No table gradient ever crosses xGMI.  All exchanges are all-to-all shaped, so
-every one of the 7 links of a GPU is used concurrently; there is no ring
-all-reduce on the path (the dense LSTM weights of the sequence model would use
-one, 128 KB, latency-bound).
+(column d of the packed rows carries the bias / bias gradient.)  Per rank ~2 x B_loc x (d+4) x 4
+bytes move per step instead of 2 x B x S x 4 / N for an all-to-all of the logits (16.5 MB vs
+134 MB at B_loc=16384, S=1024).  The variable-size exchanges need per-destination counts: they
+are a property of the batch (owner = item % N), computed by the data loader on the host
+(`prepare_route`), which also orders the batch by owner so the device never permutes rows.
+No table gradient ever crosses xGMI and there is no ring all-reduce on the path (the dense
+LSTM weights of the sequence model would use one, 128 KB, latency-bound).
 
 The compute stages go through a `backend` object; the product backend is
 HipBackend (libarx.so).  tests/ injects a numpy backend to check the sharded
@@ -74,6 +76,39 @@ class HipBackend(object):
 
     def sparse_adagrad(self, E, acc, bias, bias_acc, keys, G, Gb, lr):
         self.ops.sparse_adagrad(E, acc, bias, bias_acc, keys, None, None, G, Gb, lr, self.ws)
+
+    def sparse_adagrad_multi(self, tables, sites, G, Gb, lr):
+        """tables: [(E, acc, bias|None, bias_acc|None)]; sites: [(table, local_rows, row_base)]:
+        one fused pass (arx_sparse_adagrad_cat_multi)."""
+        ops = self.ops
+        key = tuple((t, r.data_ptr(), int(r.shape[0]), b) for t, r, b in sites)
+        cache = self.__dict__.setdefault('_multi', {})
+        ent = cache.get(key)
+        if ent is None:
+            if len(cache) > 64:
+                cache.clear()
+            dev = G.device
+            cnts = self.__dict__.setdefault('_cnt', {})
+            tabs = []
+            for E, acc, bias, bacc in tables:
+                c = cnts.get(E.data_ptr())
+                if c is None:
+                    c = cnts[E.data_ptr()] = torch.zeros((E.shape[0],), dtype=torch.int32, device=dev)
+                tabs.append((E, acc, bias, bacc, c))
+            args = ops.MultiCatArgs(tabs, [(t, None, r, b, 1.0) for t, r, b in sites])
+            n = max(args.total, 1)
+            bufs = self.__dict__.get('_multi_bufs')
+            if bufs is None or bufs[0].shape[0] < n:
+                bufs = self._multi_bufs = (torch.empty(n, dtype=torch.int32, device=dev),
+                                           torch.empty(n, dtype=torch.int32, device=dev),
+                                           torch.empty(n, dtype=torch.float32, device=dev))
+            ent = cache[key] = args
+        kb, sb, cb = self._multi_bufs
+        if kb.shape[0] < ent.total:
+            self._multi_bufs = kb, sb, cb = (torch.empty(ent.total, dtype=torch.int32, device=G.device),
+                                             torch.empty(ent.total, dtype=torch.int32, device=G.device),
+                                             torch.empty(ent.total, dtype=torch.float32, device=G.device))
+        ops.sparse_adagrad_cat_multi(ent, G, Gb, lr, kb, sb, cb, self.ws)
 
     def slot_map_set(self, m, ids, clear):
         self.ops.slot_map_set(m, ids, clear=clear)
@@ -129,33 +164,47 @@ class ShardedHMF(object):
         self.Ab_item = torch.full_like(self.b_item, acc0)
         self.lr = torch.tensor([float(learning_rate)], dtype=f32, device=dev)
 
-        B, Sg, W = self.B, self.Sg, world
+        Sg, W = self.Sg, world
+        dp = d + 4                                          # packed row: d values + bias (+ pad)
+        self.dp = dp
         z = lambda *s: torch.zeros(s, dtype=f32, device=dev)
         zi = lambda *s: torch.zeros(s, dtype=i32, device=dev)
-        self.users_in, self.items_in = zi(B_loc), zi(B_loc)
         self.urows = zi(B_loc)
-        self.U_loc, self.U = z(B_loc, d), z(B, d)
-        self.tg_all, self.tg_rows, self.tg_keys = zi(B), zi(B), zi(B)
+        self.U_loc = z(B_loc, d)
         self.pool_ids = zi(S)                               # owner-major global ids
         self.pool_rows = zi(Sg)                             # local rows of the owned block
         self.pool_old = None
         self.item2slot = torch.full((n_items + 1,), -1, dtype=i32, device=dev)
-        self.I_g, self.b_g = z(Sg, d), z(Sg)
-        self.P_g = z(B, Sg)                                 # partial logits, rank-major rows
-        self.blk = z(W, B_loc, Sg)                          # all-to-all landing / staging
+        self.I_pack, self.b_g = z(Sg, dp), z(Sg)            # owned pool rows | bias in column d
+        self.I_all, self.b_all = z(S, dp), z(S)             # gathered pool
         self.logits = z(B_loc, S)
-        self.T_g, self.tb_g, self.t_g = z(B, d), z(B), z(B)
-        self.t_loc, self.dt_loc, self.dt = z(B_loc), z(B_loc), z(B)
-        self.bl, self.loss_part, self.loss = z(B_loc), z(1), z(1)
+        self.T_pack, self.tb = z(B_loc, dp), z(B_loc)       # target rows as received back
+        self.t_loc, self.dt_loc = z(B_loc), z(B_loc)
+        self.bl, self.loss = z(B_loc), z(1)
         self.dlogits = z(B_loc, S)
-        self.dP_g = z(B, Sg)
-        self.G_item = z(Sg + B, d)                          # [dI_g ; dT_g]
-        self.Gb_item = z(Sg + B)
-        self.keys_item = torch.full((Sg + B,), 0x7FFFFFFF, dtype=i32, device=dev)
-        self.dU, self.dU_loc = z(B, d), z(B_loc, d)
+        self.dI_all, self.gb_all = z(S, dp), z(S)           # pool-gradient partials (all columns)
+        self.dT_pack = z(B_loc, dp)                         # target-row gradients to send
+        self.cap_r = 0                                      # capacity for received target rows
+        self._alloc_recv(B_loc)
         self.pos_ptr = zi(nu + 2)
         self.pos_items = zi(1)
         self.steps = 0
+
+    def _alloc_recv(self, cap):
+        """Buffers that scale with R = target rows this rank owns in a batch.  The gradient
+        arena holds [dU_loc (B_loc) ; dI_g (Sg) ; received dT (R)] so that both tables are
+        updated by ONE fused sparse-Adagrad pass."""
+        if cap <= self.cap_r:
+            return
+        dev, f32, i32 = self.device, torch.float32, torch.int32
+        B_loc, Sg, dp = self.B_loc, self.Sg, self.dp
+        self.cap_r = cap
+        self.recv_ids = torch.zeros((cap,), dtype=i32, device=dev)
+        self.recv_rows = torch.zeros((cap,), dtype=i32, device=dev)
+        self.T_send = torch.zeros((cap, dp), dtype=f32, device=dev)
+        self.tb_send = torch.zeros((cap,), dtype=f32, device=dev)
+        self.arena = torch.zeros((B_loc + Sg + cap, dp), dtype=f32, device=dev)
+        self.arena_b = torch.zeros((B_loc + Sg + cap,), dtype=f32, device=dev)
 
     # ------------------------------------------------------------------ state
     def set_positives(self, ptr_local, items_global):
@@ -184,52 +233,85 @@ class ShardedHMF(object):
         mine = self.pool_ids[self.rank * self.Sg:(self.rank + 1) * self.Sg]
         be.shard_route(mine, self.world, self.rank, self.zero_row, self.pool_rows, None)
 
+    # ------------------------------------------------------------------ route
+    def prepare_route(self, users, items):
+        """Data-loader side of a batch (host): orders the interactions by the owner of their
+        target item and returns what the variable-size exchanges need.  One tiny all_to_all
+        of the per-destination counts (not on the step path)."""
+        W = self.world
+        u = users.cpu().numpy() if isinstance(users, torch.Tensor) else np.asarray(users)
+        it = items.cpu().numpy() if isinstance(items, torch.Tensor) else np.asarray(items)
+        u = u.astype(np.int32)
+        it = it.astype(np.int32)
+        owner = it % W
+        perm = np.argsort(owner, kind='stable')
+        send = np.bincount(owner, minlength=W).astype(np.int64)
+        st = torch.from_numpy(send).to(self.device)
+        rt = torch.empty_like(st)
+        dist.all_to_all_single(rt, st, group=self.group)
+        recv = [int(v) for v in rt.cpu().tolist()]
+        route = {'users': torch.from_numpy(np.ascontiguousarray(u[perm])).to(self.device),
+                 'items': torch.from_numpy(np.ascontiguousarray(it[perm])).to(self.device),
+                 'send': [int(v) for v in send.tolist()], 'recv': recv, 'R': int(sum(recv))}
+        self._alloc_recv(route['R'])
+        return route
+
     # ------------------------------------------------------------------- step
-    def step(self, users, items):
+    def step(self, users, items=None):
+        """One training step.  `users` is either a route from prepare_route() (the fast way:
+        nothing but kernels and collectives on the step path) or a users array with `items`
+        (routed here on the host)."""
+        route = users if isinstance(users, dict) else self.prepare_route(users, items)
         be, W, r = self.be, self.world, self.rank
-        B, B_loc, S, Sg, d = self.B, self.B_loc, self.S, self.Sg, self.d
+        B, B_loc, S, Sg, d, dp = self.B, self.B_loc, self.S, self.Sg, self.d, self.dp
         grp = self.group
-        be.copy_i32(users.to(self.device, torch.int32) if isinstance(users, torch.Tensor) else
-                    torch.as_tensor(np.asarray(users, dtype=np.int32)).to(self.device), self.users_in)
-        be.copy_i32(items.to(self.device, torch.int32) if isinstance(items, torch.Tensor) else
-                    torch.as_tensor(np.asarray(items, dtype=np.int32)).to(self.device), self.items_in)
-        # user side: local rows (all owned), gather, all_gather
-        be.shard_route(self.users_in, W, r, 0, self.urows, None)
+        send, recv, R = route['send'], route['recv'], route['R']
+        users_in, items_in = route['users'], route['items']
+        arena, arena_b = self.arena, self.arena_b
+        # ---- forward ----
+        be.shard_route(users_in, W, r, 0, self.urows, None)            # all owned: local rows
         be.gather_rows(self.E_user, None, self.urows, self.U_loc, None)
-        dist.all_gather_into_tensor(self.U, self.U_loc, group=grp)
-        dist.all_gather_into_tensor(self.tg_all, self.items_in, group=grp)
-        # owned pool block -> partial logits for ALL rows
-        be.gather_rows(self.E_item, self.b_item, self.pool_rows, self.I_g, self.b_g)
-        be.gemm(self.U, self.I_g, self.P_g, transB=True, col_bias=self.b_g)
-        # all_to_all: rank-major row blocks of P_g -> owner-major column blocks
-        dist.all_to_all_single(self.blk.view(-1), self.P_g.view(-1), group=grp)
-        for g in range(W):
-            be.copy_2d(self.blk[g], self.logits[:, g * Sg:(g + 1) * Sg])
-        # targets: the owner scores u_r . I[target_r] + b, everybody else contributes 0
-        be.shard_route(self.tg_all, W, r, self.zero_row, self.tg_rows, self.tg_keys)
-        be.gather_rows(self.E_item, self.b_item, self.tg_rows, self.T_g, self.tb_g)
-        be.dot_score(self.U, self.T_g, self.tb_g, self.t_g)
-        dist.reduce_scatter_tensor(self.t_loc, self.t_g, op=dist.ReduceOp.SUM, group=grp)
+        be.gather_rows(self.E_item, self.b_item, self.pool_rows, self.I_pack[:, :d], self.b_g)
+        self.I_pack[:, d].copy_(self.b_g)
+        dist.all_gather_into_tensor(self.I_all, self.I_pack, group=grp)
+        self.b_all.copy_(self.I_all[:, d])
+        be.gemm(self.U_loc, self.I_all[:, :d], self.logits, transB=True, col_bias=self.b_all)
+        # target rows: ids to their owners, packed rows back
+        recv_ids = self.recv_ids[:R]
+        dist.all_to_all_single(recv_ids, items_in, output_split_sizes=recv, input_split_sizes=send,
+                               group=grp)
+        recv_rows = self.recv_rows[:R]
+        T_send = self.T_send[:R]
+        if R > 0:
+            be.shard_route(recv_ids, W, r, self.zero_row, recv_rows, None)
+            be.gather_rows(self.E_item, self.b_item, recv_rows, T_send[:, :d], self.tb_send[:R])
+            T_send[:, d].copy_(self.tb_send[:R])
+        dist.all_to_all_single(self.T_pack, T_send, output_split_sizes=send, input_split_sizes=recv,
+                               group=grp)
+        self.tb.copy_(self.T_pack[:, d])
+        be.dot_score(self.U_loc, self.T_pack[:, :d], self.tb, self.t_loc)
         # loss (global mean => gscale = 1/B)
         be.loss_mw_pos(self.logits, self.t_loc, self.urows, self.pos_ptr, self.pos_items,
                        self.item2slot, self.bl, self.dlogits, self.dt_loc, 1.0 / B)
-        # backward exchanges
-        for g in range(W):
-            be.copy_2d(self.dlogits[:, g * Sg:(g + 1) * Sg], self.blk[g])
-        dist.all_to_all_single(self.dP_g.view(-1), self.blk.view(-1), group=grp)
-        dist.all_gather_into_tensor(self.dt, self.dt_loc, group=grp)
-        # dU partial = dP_g . I_g + dt * T_g ; dT_g = dt * U
-        be.gemm(self.dP_g, self.I_g, self.dU)
-        be.dot_score_bwd(self.U, self.T_g, self.dt, self.dU, True, self.G_item[Sg:])
-        # dI_g = dP_g^T . U, bias gradient = row sums
-        be.gemm(self.dP_g, self.U, self.G_item[:Sg], transA=True, a_rowsum=self.Gb_item[:Sg])
-        be.copy_i32(self.dt, self.Gb_item[Sg:])
-        be.copy_i32(self.pool_rows, self.keys_item[:Sg])
-        be.copy_i32(self.tg_keys, self.keys_item[Sg:])
-        be.sparse_adagrad(self.E_item, self.A_item, self.b_item, self.Ab_item, self.keys_item,
-                          self.G_item, self.Gb_item, self.lr)
-        dist.reduce_scatter_tensor(self.dU_loc, self.dU, op=dist.ReduceOp.SUM, group=grp)
-        be.sparse_adagrad(self.E_user, self.A_user, None, None, self.urows, self.dU_loc, None, self.lr)
+        # ---- backward ----
+        dU = arena[:B_loc, :d]
+        be.gemm(self.dlogits, self.I_all[:, :d], dU)                     # dU = dL . pool
+        be.dot_score_bwd(self.U_loc, self.T_pack[:, :d], self.dt_loc, dU, True, self.dT_pack[:, :d])
+        self.dT_pack[:, d].copy_(self.dt_loc)
+        # pool gradient partials (+ bias gradient = row sums) -> owners
+        be.gemm(self.dlogits, self.U_loc, self.dI_all[:, :d], transA=True, a_rowsum=self.gb_all)
+        self.dI_all[:, d].copy_(self.gb_all)
+        dist.reduce_scatter_tensor(arena[B_loc:B_loc + Sg], self.dI_all, op=dist.ReduceOp.SUM, group=grp)
+        dist.all_to_all_single(arena[B_loc + Sg:B_loc + Sg + R], self.dT_pack,
+                               output_split_sizes=recv, input_split_sizes=send, group=grp)
+        arena_b[B_loc:B_loc + Sg + R].copy_(arena[B_loc:B_loc + Sg + R, d])
+        # one fused scatter + Adagrad pass over both shards
+        sites = [(0, self.urows, 0), (1, self.pool_rows, B_loc)]
+        if R > 0:
+            sites.append((1, recv_rows, B_loc + Sg))
+        be.sparse_adagrad_multi([(self.E_user, self.A_user, None, None),
+                                 (self.E_item, self.A_item, self.b_item, self.Ab_item)],
+                                sites, arena[:, :d], arena_b, self.lr)
         self.steps += 1
 
     def read_loss(self):
@@ -295,7 +377,7 @@ def bench_main(args, world, rank, local_rank):
         k = torch.randint(0, n_pos, (B_loc,), device=dev, generator=gen)
         users = (lu * world + rank).to(torch.int32)
         items = pos_items[(lu * n_pos + k)]
-        batches.append((users, items))
+        batches.append(model.prepare_route(users, items))      # data-loader side: order by owner
     # stratified shared pools, identical on every rank
     pg = torch.Generator(device=dev)
     pg.manual_seed(4242)
@@ -317,8 +399,7 @@ def bench_main(args, world, rank, local_rank):
         for k in range(k0, k1):
             if k % args.n_resample == 0:
                 model.set_pool(pools[k // args.n_resample])
-            u, i = batches[k % nb]
-            model.step(u, i)
+            model.step(batches[k % nb])
 
     run(0, args.warmup)
     torch.cuda.synchronize()
@@ -344,8 +425,8 @@ def bench_main(args, world, rank, local_rank):
             "data": "synthetic",
             "config": {"workload": "C5-style: synthetic %d-item/%d-user HMF, dim %d, id-only, WMRB 'mw', item "
                                    "and user tables row-sharded over %d GPUs (owner = id %% N), %d shared "
-                                   "negatives/step (S/N per owner), RCCL all_gather(U) + all_to_all(logits, "
-                                   "dlogits) + reduce_scatter(t, dU); B_loc=%d per GPU"
+                                   "negatives/step (S/N per owner), RCCL all_gather(pool rows) + all_to_all(target "
+                                   "rows, target grads) + reduce_scatter(pool grads); B_loc=%d per GPU"
                                    % (args.n_items, args.n_users, d, world, S, B_loc),
                        "batch_per_gpu": B_loc, "global_batch": B, "n_sampled": S, "dim": d,
                        "parallelism": "row-sharded tables x dp%d" % world,
@@ -353,5 +434,15 @@ def bench_main(args, world, rank, local_rank):
                        "final_loss": loss, "setup_s": setup_s},
             "roofline": None, "cpu_baseline": None,
         }
-        print(json.dumps(out))
     dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio: flush it out first so that the JSON
+        # line is the LAST line on stdout
+        import ctypes
+        import sys
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)

@@ -95,6 +95,33 @@ class NumpyBackend(object):
             ba[rows] = ba[rows] + gb[rows] ** 2
             b[rows] = b[rows] - lrv * gb[rows] / np.sqrt(ba[rows])
 
+    def sparse_adagrad_multi(self, tables, sites, G, Gb, lr):
+        """tables: [(E, acc, bias|None, bias_acc|None)]; sites: [(table, local_rows, row_base)]."""
+        g_all, gb_all = _n(G).astype(np.float64), _n(Gb).astype(np.float64)
+        lrv = float(_n(lr)[0])
+        for t, (E, acc, bias, bacc) in enumerate(tables):
+            e, a = _n(E), _n(acc)
+            g = np.zeros(e.shape, dtype=np.float64)
+            gb = np.zeros(e.shape[0], dtype=np.float64)
+            touched = []
+            for tt, rows, base in sites:
+                if tt != t:
+                    continue
+                k = _n(rows).astype(np.int64)
+                src = base + np.arange(len(k))
+                np.add.at(g, k, g_all[src][:, :e.shape[1]])
+                np.add.at(gb, k, gb_all[src])
+                touched.append(k)
+            if not touched:
+                continue
+            rows = np.unique(np.concatenate(touched))
+            a[rows] = a[rows] + g[rows] ** 2
+            e[rows] = e[rows] - lrv * g[rows] / np.sqrt(a[rows])
+            if bias is not None:
+                b, ba = _n(bias), _n(bacc)
+                ba[rows] = ba[rows] + gb[rows] ** 2
+                b[rows] = b[rows] - lrv * gb[rows] / np.sqrt(ba[rows])
+
     def slot_map_set(self, m, ids, clear):
         i = _n(ids).astype(np.int64)
         if clear:
