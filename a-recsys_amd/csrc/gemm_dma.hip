@@ -26,7 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int kBK = 32;
-constexpr int kBN = 128;
+constexpr int kBNMax = 128;
 
 // LDS-DMA piece issued from inline asm: hipcc's waitcnt pass loses its per-buffer LDS-DMA
 // tracking at the loop header and drains vmcnt(0) before the first ds_read of every loop
@@ -45,7 +45,7 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) 
       : "memory");
 }
 
-template <bool A_KC, int BM>
+template <bool A_KC, int BM, int kBN>
 __global__ __launch_bounds__(256, 2) void k_gemm_dma(
     int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C, int64_t ldc,
@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
     float* __restrict__ a_rowsum, float* __restrict__ rowsum_partial) {
   constexpr int FM = BM / 64;                 // A fragments per wave (wave covers BM/2 rows)
   constexpr int NPA = BM * kBK / 4 / 256;     // DMA pieces per thread, A tile
-  constexpr int NPB = kBK * kBN / 4 / 256;    // = 4
+  constexpr int NPB = kBK * kBN / 4 / 256;    // 4 (BN=128) or 2 (BN=64)
+  constexpr int FN = kBN / 64;                // B fragments per wave (wave covers BN/2 columns)
   // BM=64: three LDS stages (72 KB): two tiles of DMA in flight behind the one being
   // multiplied -- one tile of MFMA work is ~0.85 us, shorter than an HBM round trip.
   // BM=128: two stages (64 KB) so that two workgroups still fit a CU.
@@ -98,11 +99,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
     }
   };
 
-  f32x16 acc[FM][2];
+  f32x16 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   // row sums of op(A) ride along in registers: every lane already holds its row's elements
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
     if (t + PD < nt) dma(t + PD, nA, nB);
 #pragma unroll
     for (int s = 0; s < kBK / 8; ++s) {
-      float av[FM][4], bv[2][4];
+      float av[FM][4], bv[FN][4];
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         const int r = wm * (BM / 2) + i * 32 + l31;
@@ -135,16 +136,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
         for (int i = 0; i < FM; ++i) rsl[i] += (av[i][0] + av[i][1]) + (av[i][2] + av[i][3]);
       }
 #pragma unroll
-      for (int jn = 0; jn < 2; ++jn)
+      for (int jn = 0; jn < FN; ++jn)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          bv[jn][j] = cB[(8 * s + 4 * lhi + j) * kBN + wn * 64 + jn * 32 + l31];
+          bv[jn][j] = cB[(8 * s + 4 * lhi + j) * kBN + wn * (kBN / 2) + jn * 32 + l31];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int jn = 0; jn < 2; ++jn)
+          for (int jn = 0; jn < FN; ++jn)
             acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j], bv[jn][j], acc[i][jn], 0, 0, 0);
     }
     // this wave's pieces of tile t+1 have landed once at most the NP pieces of tile t+2 are
@@ -194,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn) {
-      const int64_t col = wn * 64 + jn * 32 + l31;
+    for (int jn = 0; jn < FN; ++jn) {
+      const int64_t col = wn * (kBN / 2) + jn * 32 + l31;
       if (col >= N) continue;
       const float bias = (col_bias && !partial) ? col_bias[col] : 0.f;
 #pragma unroll
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
 bool gemm_dma_supported(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,
                         int64_t lda, const float* B, int64_t ldb) {
   if (transB) return false;
-  if (N <= 64 || N > kBN || (N % 4) || M < 64 || (M % 4) || K < 64 || (K % kBK)) return false;   // N <= 64: half the tile would be padding
+  if (N <= 32 || N > kBNMax || (N % 4) || M < 64 || (M % 4) || K < 64 || (K % kBK)) return false;   // N <= 32: half the 64-wide tile would be padding
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) ||
       (lda % 4) || (ldb % 4))
     return false;
@@ -270,15 +271,16 @@ int gemm_dma_launch(int transA, int64_t M, int64_t N, int64_t K, float alpha, co
   dim3 grid((unsigned)ceil_div(M, (int64_t)bm), 1, (unsigned)splits);
   float* part = splits > 1 ? partial : nullptr;
   float* rsp = splits > 1 ? rowsum_partial : nullptr;
-#define ARX_DMA_GO(AKC, BM_)                                                                   \
-  k_gemm_dma<AKC, BM_><<<grid, 256, 0, s>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,      \
-                                            col_bias, part, kchunk, a_rowsum, rsp)
+#define ARX_DMA_GO(AKC, BM_, BN_)                                                              \
+  k_gemm_dma<AKC, BM_, BN_><<<grid, 256, 0, s>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
+                                                 col_bias, part, kchunk, a_rowsum, rsp)
+  const bool narrow = N <= 64;                   // LSTM / d=64 shapes: 64-column tile
   if (!transA) {
-    if (bm == 128) ARX_DMA_GO(true, 128);
-    else ARX_DMA_GO(true, 64);
+    if (bm == 128) { if (narrow) ARX_DMA_GO(true, 128, 64); else ARX_DMA_GO(true, 128, 128); }
+    else { if (narrow) ARX_DMA_GO(true, 64, 64); else ARX_DMA_GO(true, 64, 128); }
   } else {
-    if (bm == 128) ARX_DMA_GO(false, 128);
-    else ARX_DMA_GO(false, 64);
+    if (bm == 128) { if (narrow) ARX_DMA_GO(false, 128, 64); else ARX_DMA_GO(false, 128, 128); }
+    else { if (narrow) ARX_DMA_GO(false, 64, 64); else ARX_DMA_GO(false, 64, 128); }
   }
 #undef ARX_DMA_GO
   ARX_CHECK_LAUNCH();
