@@ -12,6 +12,8 @@
 // LDS (double-buffered, stride h+2 => conflict-free operand reads), c_{t-1} in
 // registers, x_{t+1} is prefetched into LDS while step t computes.  W streams
 // from L2 as the MFMA B operand (it is read-only and tiny: 128 KB at d=h=64).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace arx {
@@ -207,6 +209,197 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(
   }
 }
 
+// ---- d = h = 64 (config C4): W register-resident --------------------------------------
+// The streaming kernels above re-read their W slice from L2 every time step (4 dependent-ish
+// global loads per k-step in a rolled loop: ~8 us per step measured, 8 TF).  At h = 64 a
+// wave's slice is (din + h) x 64 gate columns = 32 KB = 128 VGPRs per lane, so it is loaded
+// ONCE and the step is 32 LDS operand reads + 128 back-to-back MFMAs; bias lives in
+// registers too.  Backward: W_h^T slice = 64 VGPRs; the next step's gates / cells / dh are
+// prefetched into registers while the current step's dh GEMM runs.
+template <int DIN>
+__global__ __launch_bounds__(256, 1) void k_lstm_fwd_wreg(
+    const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+    int64_t L, int64_t B, float forget_bias, float* __restrict__ hs, float* __restrict__ cs,
+    float* __restrict__ gates) {
+  constexpr int H = 64, H4 = 256, SX = DIN + 2, SH = H + 2;
+  constexpr int NKX = DIN / 4, NKH = H / 4;
+  __shared__ __attribute__((aligned(16))) float xbuf[2][kRows * SX];
+  __shared__ __attribute__((aligned(16))) float hbuf[2][kRows * SH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * kRows;
+  const int ubase = wave * 16;
+  // W slice: k = 4*ks + lq, columns g*64 + ubase + l15
+  float wx[NKX][4], wh[NKH][4], bv[4];
+#pragma unroll
+  for (int ks = 0; ks < NKX; ++ks)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) wx[ks][g] = W[(int64_t)(4 * ks + lq) * H4 + g * H + ubase + l15];
+#pragma unroll
+  for (int ks = 0; ks < NKH; ++ks)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) wh[ks][g] = W[(int64_t)(DIN + 4 * ks + lq) * H4 + g * H + ubase + l15];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bv[g] = bias[g * H + ubase + l15];
+  for (int i = threadIdx.x; i < kRows * SH; i += 256) hbuf[0][i] = 0.f;
+  for (int i = threadIdx.x; i < kRows * DIN; i += 256) {
+    const int r = i / DIN, c = i % DIN;
+    const int64_t gr = row0 + r;
+    xbuf[0][r * SX + c] = (gr < B) ? x[gr * DIN + c] : 0.f;
+  }
+  float cprev[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  for (int64_t t = 0; t < L; ++t) {
+    const int cur = (int)(t & 1), nxt = cur ^ 1;
+    const float* xb = xbuf[cur];
+    const float* hb = hbuf[cur];
+    float xn[kRows * DIN / 256];                 // x_{t+1}: loads fly under the MFMAs
+    if (t + 1 < L) {
+      const float* xs = x + (t + 1) * B * DIN;
+#pragma unroll
+      for (int q = 0; q < kRows * DIN / 256; ++q) {
+        const int i = threadIdx.x + q * 256;
+        const int64_t gr = row0 + i / DIN;
+        xn[q] = xs[min(gr, B - 1) * DIN + i % DIN];
+      }
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = (f32x4){bv[g], bv[g], bv[g], bv[g]};
+#pragma unroll
+    for (int ks = 0; ks < NKX; ++ks) {
+      const float a = xb[l15 * SX + 4 * ks + lq];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wx[ks][g], acc[g], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < NKH; ++ks) {
+      const float a = hb[l15 * SH + 4 * ks + lq];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wh[ks][g], acc[g], 0, 0, 0);
+    }
+    // cell update; C/D map of 16x16: col = lane&15 (unit), row = (lane>>4)*4 + reg
+    float* hn = hbuf[nxt];
+    const int unit = ubase + l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lrow = lq * 4 + r;
+      const int64_t gr = row0 + lrow;
+      const float gi = sigmoidf_(acc[0][r]);
+      const float gj = tanhf(acc[1][r]);
+      const float gf = sigmoidf_(acc[2][r] + forget_bias);
+      const float go = sigmoidf_(acc[3][r]);
+      const float c = gf * cprev[r] + gi * gj;
+      const float hh = go * tanhf(c);
+      cprev[r] = c;
+      hn[lrow * SH + unit] = hh;
+      if (gr < B) {
+        const int64_t o = (t * B + gr);
+        hs[o * H + unit] = hh;
+        cs[o * H + unit] = c;
+        float* gp = gates + o * H4 + unit;
+        gp[0] = gi;
+        gp[H] = gj;
+        gp[2 * H] = gf;
+        gp[3 * H] = go;
+      }
+    }
+    if (t + 1 < L) {
+      float* xw = xbuf[nxt];
+#pragma unroll
+      for (int q = 0; q < kRows * DIN / 256; ++q) {
+        const int i = threadIdx.x + q * 256;
+        const int64_t gr = row0 + i / DIN;
+        xw[(i / DIN) * SX + i % DIN] = (gr < B) ? xn[q] : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int DIN>
+__global__ __launch_bounds__(256, 1) void k_lstm_bwd_wreg(
+    const float* __restrict__ W, const float* __restrict__ cs, const float* __restrict__ gates,
+    const float* __restrict__ dhs, int64_t L, int64_t B, float* __restrict__ dz) {
+  constexpr int H = 64, H4 = 256, SZ = H4 + 2, NK = H4 / 4;
+  __shared__ __attribute__((aligned(16))) float zbuf[kRows * SZ];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * kRows;
+  const int unit = wave * 16 + l15;
+  // W_h^T slice: B operand element (k = 4*ks + lq, unit) = W[DIN + unit][k]
+  float wt[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) wt[ks] = W[(int64_t)(DIN + unit) * H4 + 4 * ks + lq];
+  float dh_rec[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
+  // step-t inputs of this lane's 4 rows: gates (4), c, c_prev, dh
+  float pg[4][4], pc[4], pcp[4], pdh[4];
+  auto prefetch = [&](int64_t t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t gr = min(row0 + lq * 4 + r, B - 1);
+      const int64_t o = t * B + gr;
+      const float* gp = gates + o * H4 + unit;
+      pg[r][0] = gp[0];
+      pg[r][1] = gp[H];
+      pg[r][2] = gp[2 * H];
+      pg[r][3] = gp[3 * H];
+      pc[r] = cs[o * H + unit];
+      pcp[r] = (t > 0) ? cs[(o - B) * H + unit] : 0.f;
+      pdh[r] = dhs[o * H + unit];
+    }
+  };
+  if (L > 0) prefetch(L - 1);
+  for (int64_t t = L - 1; t >= 0; --t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lrow = lq * 4 + r;
+      const int64_t gr = row0 + lrow;
+      float zi = 0.f, zj = 0.f, zf = 0.f, zo = 0.f;
+      if (gr < B) {
+        const float gi = pg[r][0], gj = pg[r][1], gf = pg[r][2], go = pg[r][3];
+        const float dh = pdh[r] + dh_rec[r];
+        const float tc = tanhf(pc[r]);
+        const float d_o = dh * tc;
+        const float dcc = dc[r] + dh * go * (1.f - tc * tc);
+        zi = dcc * gj * gi * (1.f - gi);
+        zj = dcc * gi * (1.f - gj * gj);
+        zf = dcc * pcp[r] * gf * (1.f - gf);
+        zo = d_o * go * (1.f - go);
+        dc[r] = dcc * gf;
+        float* zp = dz + (t * B + gr) * H4 + unit;
+        zp[0] = zi;
+        zp[H] = zj;
+        zp[2 * H] = zf;
+        zp[3 * H] = zo;
+      }
+      float* zb = zbuf + lrow * SZ + unit;
+      zb[0] = zi;
+      zb[H] = zj;
+      zb[2 * H] = zf;
+      zb[3 * H] = zo;
+    }
+    __syncthreads();
+    if (t > 0) {
+      prefetch(t - 1);                          // in flight under the dh GEMM
+      // dh_{t-1}[row, unit] = sum_k dz[row, k] * W[DIN + unit, k]
+      f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;   // two chains: MFMA latency
+#pragma unroll
+      for (int ks = 0; ks < NK; ks += 2) {
+        const float a0 = zbuf[l15 * SZ + 4 * ks + lq];
+        const float a1 = zbuf[l15 * SZ + 4 * (ks + 1) + lq];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wt[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wt[ks + 1], acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh_rec[r] = acc0[r] + acc1[r];
+    }
+    __syncthreads();
+  }
+}
+
 // ---- generic fallback (any din, h): one workgroup per batch row -------------
 __global__ __launch_bounds__(256) void k_lstm_fwd_generic(
     const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
@@ -300,7 +493,11 @@ int arx_lstm_fwd(const float* x, const float* W, const float* b, int64_t L, int6
   if (L == 0 || B == 0) return ARX_OK;
   hipStream_t s = as_stream(stream);
   const bool mfma_ok = (h % 64 == 0) && (h <= 128) && (din % 4 == 0);
-  if (mfma_ok) {
+  static const bool wreg_off = getenv("ARX_LSTM_WREG_OFF") != nullptr;   // A/B aid
+  if (h == 64 && din == 64 && !wreg_off) {
+    k_lstm_fwd_wreg<64><<<(int)ceil_div(B, kRows), 256, 0, s>>>(x, W, b, L, B, forget_bias, hs, cs,
+                                                                   gates);
+  } else if (mfma_ok) {
     const size_t lds = (size_t)(2 * kRows * (din + 2) + 2 * kRows * (h + 2)) * sizeof(float);
     const int grid = (int)ceil_div(B, kRows);
     if (h == 64) k_lstm_fwd<1><<<grid, 256, lds, s>>>(x, W, b, L, B, din, h, forget_bias, hs, cs, gates);
@@ -323,7 +520,10 @@ int arx_lstm_bwd(const float* W, const float* hs, const float* cs, const float* 
   if (L == 0 || B == 0) return ARX_OK;
   hipStream_t s = as_stream(stream);
   const bool mfma_ok = (h % 64 == 0) && (h <= 128);
-  if (mfma_ok) {
+  static const bool wreg_off = getenv("ARX_LSTM_WREG_OFF") != nullptr;   // A/B aid
+  if (h == 64 && din == 64 && !wreg_off) {
+    k_lstm_bwd_wreg<64><<<(int)ceil_div(B, kRows), 256, 0, s>>>(W, cs, gates, dhs, L, B, dz);
+  } else if (mfma_ok) {
     const size_t lds = (size_t)(kRows * (4 * h + 2)) * sizeof(float);
     const int grid = (int)ceil_div(B, kRows);
     if (h == 64) k_lstm_bwd<1><<<grid, 256, lds, s>>>(W, cs, gates, dhs, L, B, din, h, dz);
