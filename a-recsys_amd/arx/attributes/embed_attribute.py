@@ -395,8 +395,9 @@ class EmbeddingAttribute(object):
 
     def compute_loss(self, logits, item_target, loss='ce', true_rank=False, loss_func='log',
                      exp_p=1.005, device='/gpu:0'):
-        """embed_attribute.py:525-549.  Implemented on device: 'ce', 'warp', 'mw',
-        'warp_eval'; the rs*/bbpr/bpr family is not on the north-star path."""
+        """embed_attribute.py:525-549.  Implemented on device: 'ce', 'warp', 'mw', 'warp_eval',
+        'rs', 'rs-sig', 'rs-sig2', 'bbpr' (loss_func log/exp/poly/poly2/linear/square); 'mce' has no
+        branch in the reference and bpr* needs feeds the reference commented out."""
         if loss not in ['ce', 'mce', 'warp', 'warp_eval', 'rs', 'rs-sig', 'rs-sig2', 'mw', 'bbpr',
                         'bpr', 'bpr-hinge']:
             raise ValueError("unknown loss %r" % loss)
@@ -408,6 +409,10 @@ class EmbeddingAttribute(object):
             if loss == 'warp_eval':
                 return [node, node]
             return node
+        if loss in ('rs', 'rs-sig', 'rs-sig2', 'bbpr'):                   # :532-547, :551-603
+            ms = self._mask_state(loss, logits.shape[0])
+            return G.BatchLoss(self.rt, loss, logits, item_target, mask=ms, mask_rows=self.batch_size,
+                               loss_func=loss_func, exp_p=exp_p)
         raise NotImplementedError('Error: not implemented other loss!!')   # :548
 
     def get_warp_mask(self, device='/gpu:0'):

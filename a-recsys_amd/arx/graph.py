@@ -297,9 +297,12 @@ class BatchLoss(Node):
 
     requires_grad = True
 
-    def __init__(self, rt, kind, logits, target, mask=None, mask_rows=0):
-        if kind not in ('ce', 'warp', 'mw', 'warp_eval'):
+    def __init__(self, rt, kind, logits, target, mask=None, mask_rows=0, loss_func='log', exp_p=1.005):
+        if kind not in ('ce', 'warp', 'mw', 'warp_eval', 'rs', 'rs-sig', 'rs-sig2', 'bbpr'):
             raise NotImplementedError("loss %r is not implemented on the HIP path" % kind)
+        if loss_func not in ops.RS_FUNCS:
+            raise ValueError("unknown loss_func %r" % (loss_func,))
+        self.loss_func, self.exp_p = loss_func, float(exp_p)
         super().__init__(rt, (logits.shape[0],), (logits, target))
         self.kind = kind
         self.mask = mask              # MaskState or None
@@ -338,6 +341,10 @@ class BatchLoss(Node):
                 ops.loss_warp(logits.value, target.value, m, bl, dl, self.gscale, rw, self.mask_rows)
         elif self.kind == 'ce':
             ops.loss_ce(logits.value, target.value, bl, dl, self.gscale, rw)
+        elif self.kind in ops.RS_KINDS:               # embed_attribute.py:551-603
+            ops.loss_rs(logits.value, target.value, self.kind, self.loss_func, self.exp_p, bl, dl,
+                        self.gscale, mask=m, pos=(uid, ptr, items, i2s) if fused else None, row_w=rw,
+                        mask_rows=self.mask_rows)
         else:  # warp_eval -> [margin_rank, true_rank]
             if self.rank_value is None:
                 self.rank_value = torch.empty(self.shape[0], dtype=torch.int32, device=self.rt.device)

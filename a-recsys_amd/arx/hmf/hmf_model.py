@@ -129,9 +129,7 @@ class LatentProductModel(object):
         if loss_function in ('bpr', 'bpr-hinge'):
             raise NotImplementedError("bpr losses: the reference's pos/neg feeds are commented out "
                                       "(embed_attribute.py:704-706); not on the hot path")
-        if loss_function in ('rs', 'rs-sig', 'rs-sig2', 'bbpr') or loss_func != 'log':
-            raise NotImplementedError("loss %s/%s is not implemented on the HIP path" %
-                                      (loss_function, loss_func))
+        self.loss_func, self.loss_exp_p = loss_func, loss_exp_p
 
         self.rt = rt = G.Runtime(learning_rate=learning_rate, use_graph=use_graph)
         self._lr_decay = learning_rate_decay_factor
@@ -173,8 +171,9 @@ class LatentProductModel(object):
         logits = m.get_prediction(embedded_user)                              # :118
         self.output = logits
         batch_loss_eval = None
-        if loss in ('warp', 'ce'):
-            batch_loss = m.compute_loss(logits, self.item_target, loss)
+        if loss in ('warp', 'ce', 'rs', 'rs-sig', 'rs-sig2', 'bbpr'):            # :121-122
+            batch_loss = m.compute_loss(logits, self.item_target, loss, loss_func=self.loss_func,
+                                        exp_p=self.loss_exp_p)
         elif loss == 'warp_eval':
             batch_loss, _ = m.compute_loss(logits, self.item_target, loss)
         elif loss == 'mw':
@@ -182,7 +181,7 @@ class LatentProductModel(object):
             batch_loss_eval = m.compute_loss(logits, self.item_target, 'warp')  # :130
         else:
             raise NotImplementedError("not implemented!")
-        if loss in ('warp', 'warp_eval', 'mw'):
+        if loss in ('warp', 'warp_eval', 'mw', 'rs', 'rs-sig', 'rs-sig2', 'bbpr'):   # :137
             self.set_mask, self.reset_mask = m.get_warp_mask()
         self.batch_loss = batch_loss
         self.loss = G.MeanLoss(rt, batch_loss)                                # :140

@@ -222,6 +222,22 @@ def loss_warp_pos(logits, target, user_ids, pos_ptr, pos_items, item2slot, batch
          _p(batch_loss), _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _stream())
 
 
+RS_KINDS = {'rs': 0, 'rs-sig': 1, 'rs-sig2': 2, 'bbpr': 3}
+RS_FUNCS = {'log': 0, 'exp': 1, 'poly': 2, 'poly2': 3, 'linear': 4, 'square': 5}
+
+
+def loss_rs(logits, target, kind, loss_func, exp_p, batch_loss, dlogits, gscale, mask=None,
+            pos=None, row_w=None, mask_rows=0):
+    """rs / rs-sig / rs-sig2 / bbpr over full logits.  pos = (user_ids, pos_ptr, pos_items,
+    item2slot) builds the mask on the fly; else `mask` (uint8 [rows, V]) or no mask."""
+    B, V = int(logits.shape[0]), int(logits.shape[1])
+    uid, ptr, items, i2s = pos if pos is not None else (None, None, None, None)
+    call("arx_loss_rs_fwdbwd", _p(logits), _ld(logits), _p(target), _p(mask),
+         _ld(mask) if mask is not None else 0, _p(uid), _p(ptr), _p(items), _p(i2s), int(mask_rows),
+         RS_KINDS[kind], RS_FUNCS[loss_func], float(exp_p), float(gscale), _p(row_w), B, V,
+         _p(batch_loss), _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _stream())
+
+
 def loss_ce(logits, target, batch_loss, dlogits, gscale, row_w=None):
     B, V = int(logits.shape[0]), int(logits.shape[1])
     call("arx_loss_ce_fwdbwd", _p(logits), _ld(logits), _p(target), float(gscale), _p(row_w), B, V,

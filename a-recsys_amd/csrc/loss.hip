@@ -252,6 +252,81 @@ static bool launch_margin_wave(const float* logits, int64_t ldl, const float* ts
   return true;
 }
 
+
+// rs / rs-sig / rs-sig2 / bbpr (embed_attribute.py:551-603): pairwise margin or sigmoid errors
+// over the full vocabulary, masked, summed, then a scalar transform (loss_func).
+//   kind 0 rs      err = relu(x - t + 1)
+//   kind 1 rs-sig  err = 2*sigmoid(masked relu(x - t + 1)) - 1
+//   kind 2 rs-sig2 err = sigmoid(x - t)
+//   kind 3 bbpr    err = sigmoid(x - t), loss = sum (no transform)
+//   loss_func 0 log(1+s) | 1 1 - p^-s | 2 s^p | 3 (1+s)^p | 4 s | 5 s^2
+// One workgroup per row, two passes (the second hits L2); the target column receives
+// -(sum of the row's gradient) like the warp loss.
+__device__ __forceinline__ void rs_err(int kind, float x, float t, bool keep, float& em, float& dem) {
+  float err, derr;
+  if (kind <= 1) {
+    const float pre = x - t + 1.f;
+    err = fmaxf(pre, 0.f);
+    derr = pre > 0.f ? 1.f : 0.f;
+  } else {
+    err = 1.f / (1.f + __expf(-(x - t)));
+    derr = err * (1.f - err);
+  }
+  em = keep ? err : 0.f;
+  dem = keep ? derr : 0.f;
+  if (kind == 1) {
+    const float sg = 1.f / (1.f + __expf(-em));
+    dem = dem * 2.f * sg * (1.f - sg);
+    em = 2.f * sg - 1.f;
+  }
+}
+
+template <bool POS>
+__global__ __launch_bounds__(256) void k_loss_rs(
+    const float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ target,
+    const uint8_t* __restrict__ mask, int64_t ldm, int64_t mask_rows, int kind, int loss_func,
+    float exp_p, float gscale, const float* __restrict__ row_w, int64_t W,
+    float* __restrict__ batch_loss, float* dlogits, int64_t lddl, PosMask pm) {
+  __shared__ float sh[4];
+  extern __shared__ uint32_t bits[];
+  const int64_t r = blockIdx.x;
+  const float* x = logits + r * ldl;
+  const uint8_t* m = (!POS && mask) ? mask + (r % mask_rows) * ldm : nullptr;
+  if (POS) build_pos_bits(bits, W, pm, r % mask_rows);
+  const int tcol = target[r];
+  const float t = x[tcol];
+  float s = 0.f;
+  for (int64_t c = threadIdx.x; c < W; c += 256) {
+    const bool keep = POS ? !((bits[c >> 5] >> (c & 31)) & 1u) : (m ? (m[c] != 0) : true);
+    float em, dem;
+    rs_err(kind, x[c], t, keep, em, dem);
+    s += em;
+  }
+  s = block_sum(s, sh);
+  float l, dl;
+  if (kind == 3 || loss_func == 4) { l = s; dl = 1.f; }
+  else if (loss_func == 0) { l = logf(1.f + s); dl = 1.f / (1.f + s); }
+  else if (loss_func == 1) { const float q = powf(exp_p, -s); l = 1.f - q; dl = logf(exp_p) * q; }
+  else if (loss_func == 2) { l = powf(s, exp_p); dl = exp_p * powf(s, exp_p - 1.f); }
+  else if (loss_func == 3) { l = powf(1.f + s, exp_p); dl = exp_p * powf(1.f + s, exp_p - 1.f); }
+  else { l = s * s; dl = 2.f * s; }
+  if (threadIdx.x == 0 && batch_loss) batch_loss[r] = l;
+  if (!dlogits) return;
+  const float g = gscale * (row_w ? row_w[r] : 1.f) * dl;
+  float* dx = dlogits + r * lddl;
+  float tot = 0.f;
+  for (int64_t c = threadIdx.x; c < W; c += 256) {
+    const bool keep = POS ? !((bits[c >> 5] >> (c & 31)) & 1u) : (m ? (m[c] != 0) : true);
+    float em, dem;
+    rs_err(kind, x[c], t, keep, em, dem);
+    const float d = dem * g;
+    tot += d;
+    dx[c] = d;
+  }
+  tot = block_sum(tot, sh);   // (contains the barrier that orders the writes above)
+  if (threadIdx.x == 0) dx[tcol] += -tot;
+}
+
 __global__ __launch_bounds__(256) void k_loss_ce(
     const float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ target,
     float gscale, const float* __restrict__ row_w, int64_t V, float* __restrict__ batch_loss,
@@ -465,6 +540,41 @@ int arx_loss_warp_fwdbwd_pos(const float* logits, int64_t ldl, const int32_t* ta
   kern<<<(int)B, 256, lds, as_stream(stream)>>>(
       logits, ldl, nullptr, target, nullptr, 0, mask_rows > 0 ? mask_rows : B, gscale, row_w, V,
       batch_loss, dlogits, lddl, nullptr, PosMask{user_ids, pos_ptr, pos_items, item2slot});
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_loss_rs_fwdbwd(const float* logits, int64_t ldl, const int32_t* target, const uint8_t* mask,
+                       int64_t ldm, const int32_t* user_ids, const int32_t* pos_ptr,
+                       const int32_t* pos_items, const int32_t* item2slot, int64_t mask_rows,
+                       int kind, int loss_func, float exp_p, float gscale, const float* row_w,
+                       int64_t B, int64_t V, float* batch_loss, float* dlogits, int64_t lddl,
+                       void* stream) {
+  ARX_CHECK_ARG(logits && target, "arx_loss_rs_fwdbwd: null pointer");
+  ARX_CHECK_ARG(B >= 0 && V > 0, "arx_loss_rs_fwdbwd: bad size");
+  ARX_CHECK_ARG(kind >= 0 && kind <= 3 && loss_func >= 0 && loss_func <= 5,
+                "arx_loss_rs_fwdbwd: kind in 0..3 (rs, rs-sig, rs-sig2, bbpr), loss_func in 0..5");
+  if (B == 0) return ARX_OK;
+  const int64_t mr = mask_rows > 0 ? mask_rows : B;
+  if (user_ids) {
+    ARX_CHECK_ARG(pos_ptr && pos_items && item2slot, "arx_loss_rs_fwdbwd: incomplete positives CSR");
+    if (V > ARX_POS_LDS_MAX_COLS) {
+      set_error("arx_loss_rs_fwdbwd: %lld columns exceed the LDS mask (use the mask-array form)", (long long)V);
+      return ARX_EUNSUPPORTED;
+    }
+    const size_t lds = (size_t)((V + 31) / 32) * 4;
+    auto kern = k_loss_rs<true>;
+    if (lds > 48 * 1024)
+      ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<(int)B, 256, lds, as_stream(stream)>>>(logits, ldl, target, nullptr, 0, mr, kind, loss_func,
+                                                  exp_p, gscale, row_w, V, batch_loss, dlogits, lddl,
+                                                  PosMask{user_ids, pos_ptr, pos_items, item2slot});
+  } else {
+    k_loss_rs<false><<<(int)B, 256, 0, as_stream(stream)>>>(logits, ldl, target, mask, ldm, mr, kind,
+                                                            loss_func, exp_p, gscale, row_w, V,
+                                                            batch_loss, dlogits, lddl, PosMask{});
+  }
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

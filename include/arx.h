@@ -165,6 +165,20 @@ int arx_loss_warp_fwdbwd(const float* logits, int64_t ldl, const int32_t* target
                          const float* row_w,
                          int64_t B, int64_t V, float* batch_loss, float* dlogits, int64_t lddl,
                          void* stream);
+/* rs / rs-sig / rs-sig2 / bbpr losses (embed_attribute.py:551-603 _compute_rs_loss) over full
+ * logits [B, V], forward + backward fused.  kind: 0 rs, 1 rs-sig, 2 rs-sig2, 3 bbpr;
+ * loss_func (hmf_model.py loss_func): 0 log, 1 exp, 2 poly, 3 poly2, 4 linear, 5 square, with
+ * exponent/base exp_p (default 1.005).  The mask is either the byte array `mask` [mask_rows, ldm]
+ * (0 = masked out; NULL = keep all) or, when user_ids != NULL, built on the fly in LDS from the
+ * positives CSR (as in arx_loss_warp_fwdbwd_pos).  The target column receives minus the row sum
+ * of the gradient.  dlogits may be NULL (forward only). */
+int arx_loss_rs_fwdbwd(const float* logits, int64_t ldl, const int32_t* target, const uint8_t* mask,
+                       int64_t ldm, const int32_t* user_ids, const int32_t* pos_ptr,
+                       const int32_t* pos_items, const int32_t* item2slot, int64_t mask_rows,
+                       int kind, int loss_func, float exp_p, float gscale, const float* row_w,
+                       int64_t B, int64_t V, float* batch_loss, float* dlogits, int64_t lddl,
+                       void* stream);
+
 /* mw / warp with the positive mask built inside the kernel (embed_attribute.py:
  * 721-745 + 651-672 fused): column j of row r is masked iff some positive item v
  * of user_ids[r % mask_rows] has item2slot[v] == j.  No [mb, W] mask array is

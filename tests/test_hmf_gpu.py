@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-4, 2e-6
 
 
-def _build(cfg, loss, d, B, S, seed, nonlinear='linear', use_graph=True):
+def _build(cfg, loss, d, B, S, seed, nonlinear='linear', use_graph=True, loss_func='log', exp_p=1.005):
     from arx.utils.synthetic import SyntheticHMF
     from arx.hmf.hmf_model import LatentProductModel
     syn = SyntheticHMF(seed=seed, **cfg)
@@ -29,12 +29,13 @@ def _build(cfg, loss, d, B, S, seed, nonlinear='linear', use_graph=True):
     model = LatentProductModel(syn.n_users, syn.n_items, d, 1, B, 0.5, 1.0, syn.u_attr, syn.i_attr,
                                i2l, l2i, loss_function=loss, n_sampled=n_s, params=params,
                                nonlinear=nonlinear, hidden_size=48, top_N_items=10,
-                               use_graph=use_graph)
+                               use_graph=use_graph, loss_func=loss_func, loss_exp_p=exp_p)
     ref = rg.RefLatentProductModel(d, B, 0.5, syn.u_attr, syn.i_attr, i2l, l2i, loss_function=loss,
                                    n_sampled=n_s, params=params, dtype=np.float64, top_N_items=10,
-                                   nonlinear=nonlinear, hidden_size=48)
+                                   nonlinear=nonlinear, hidden_size=48, loss_func=loss_func,
+                                   loss_exp_p=exp_p)
     pos = syn.positives_dict()
-    if loss in ('mw', 'warp'):
+    if loss in ('mw', 'warp', 'rs', 'rs-sig', 'rs-sig2', 'bbpr'):
         model.prepare_warp(pos, pos)
         ref.prepare_warp(pos, pos)
     return syn, model, ref
@@ -89,6 +90,31 @@ def test_hmf_steps_match_oracle(dev, cfg, loss, d, B, S, use_graph):
         l_got = model.step(None, list(users), list(items), None, pool, id2idx, loss=loss)
         np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='step %d' % step)
         _compare_state(model, ref)
+
+
+@pytest.mark.parametrize("loss,loss_func,exp_p", [
+    ('rs', 'log', 1.005), ('rs', 'exp', 1.3), ('rs', 'poly2', 0.7), ('rs', 'square', 1.005),
+    ('rs-sig', 'log', 1.005), ('rs-sig', 'linear', 1.005), ('rs-sig2', 'poly', 1.2),
+    ('bbpr', 'log', 1.005),
+])
+def test_hmf_rs_family_matches_oracle(dev, loss, loss_func, exp_p):
+    """a13: rs / rs-sig / rs-sig2 / bbpr with every loss_func transform
+    (embed_attribute.py:551-603), whole step vs the oracle, multi-hot item attributes."""
+    syn, model, ref = _build(CFG_HET, loss, 32, 48, None, seed=9, loss_func=loss_func, exp_p=exp_p)
+    rng = np.random.default_rng(3)
+    # 'square' multiplies the gradient by 2s (s ~ 1e2): after one Adagrad step at lr 0.5 every
+    # touched weight has jumped by ~0.5 and the hinge activations flip chaotically between fp32
+    # and fp64 -- one step is the meaningful comparison there.
+    for step in range(1 if loss_func == 'square' else 3):
+        users, items = syn.sample_batch(48, rng)
+        users[1] = users[0]
+        l_ref = ref.step(list(users), list(items), loss=loss)
+        l_got = model.step(None, list(users), list(items), loss=loss)
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='step %d' % step)
+        _compare_state(model, ref, rtol=2e-4 if loss_func == 'square' else RTOL, atol=2e-5)
+    e_ref = ref.step(list(users), list(items), forward_only=True, loss=loss)
+    e_got = model.step(None, list(users), list(items), forward_only=True, loss=loss)
+    np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
 
 
 def test_c1_shape_ce_three_seeds(dev):
