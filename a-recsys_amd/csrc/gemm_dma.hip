@@ -70,8 +70,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  // (M tile, K split) of this block.  Blocks are dealt round-robin to the 8 XCDs (linear id %
+  // 8); with split-K the M tiles of one K chunk all read the same B rows (dI: the U rows of the
+  // chunk, re-read by every M tile -- PMC showed 134 MB fetched for 75 MB algorithmic), so they
+  // are re-indexed to sit on ONE XCD and share those rows through its L2.
+  int bx = blockIdx.x, bz = blockIdx.z;
+  {
+    const int nx = gridDim.x, nz = gridDim.z;
+    if (nz > 1 && nz % 8 == 0) {
+      const int lin = bx + nx * bz;
+      const int xcd = lin & 7, slot = lin >> 3;      // slot < nx * nz / 8
+      bz = xcd * (nz / 8) + slot / nx;
+      bx = slot % nx;
+    }
+  }
+  const int64_t m0 = (int64_t)bx * BM;
+  const int64_t kbeg = (int64_t)bz * kchunk;
   const int64_t kend = min(K, kbeg + kchunk);
   const int64_t nt = (kend - kbeg) / kBK;      // K % 32 == 0 and kchunk % 32 == 0 (host)
 
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
       const float tot = rsl[i] + __shfl_xor(rsl[i], 32, 64);     // the two k halves of the row
       const int64_t row = m0 + wm * (BM / 2) + i * 32 + l31;
       if (wn == 0 && lhi == 0 && row < M) {
-        if (rowsum_partial) rowsum_partial[(int64_t)blockIdx.z * M + row] = tot;
+        if (rowsum_partial) rowsum_partial[(int64_t)bz * M + row] = tot;
         else a_rowsum[row] = tot;
       }
     }
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
         if (row >= M) continue;
         float v = acc[i][jn][e];
         if (partial) {
-          partial[((int64_t)blockIdx.z * M + row) * N + col] = v;
+          partial[((int64_t)bz * M + row) * N + col] = v;
         } else {
           v *= alpha;
           if (beta != 0.f) v += beta * C[row * ldc + col];

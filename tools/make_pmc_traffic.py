@@ -18,8 +18,9 @@ CAL_BYTES = 256 * 2 ** 20
 # bench.py kernel name -> substrings of the device kernels that implement it
 MAP = {
     'gemm_logits_nt': ['k_gemm_nt_areg'],
-    'gemm_dU_nn': ['k_gemm_f32<64, 64, 16, true, false>', 'k_gemm_f32<128, 128, 16, true, false>'],
-    'gemm_dI_tn': ['k_gemm_f32<64, 64, 16, false, false>', 'k_gemm_f32<128, 128, 16, false, false>'],
+    'gemm_dU_nn': ['k_gemm_dma<true', 'k_gemm_f32<64, 64, 16, true, false>', 'k_gemm_f32<128, 128, 16, true, false>'],
+    'gemm_dI_tn': ['k_gemm_dma<false', 'k_gemm_f32<64, 64, 16, false, false>', 'k_gemm_f32<128, 128, 16, false, false>'],
+    'splitk_reduce': ['k_splitk_reduce'],
     'loss_mw': ['k_loss_margin'],
     'gather_onehot': ['k_gather_onehot'],
     'gather_mulhot': ['k_gather_mulhot'],
