@@ -44,11 +44,13 @@ def main():
     batches = [(torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev)) for u, i in host]
     # parity of the first steps (same batches, both start from `params`)
     rel = 0.0
+    pairs = []
     for k in range(3):
         u, i = host[k]
         l_ref = float(ref.step(list(u), list(i), loss='ce'))
         l_got = float(model.step(None, list(u), list(i), loss='ce'))
         rel = max(rel, abs(l_got - l_ref) / abs(l_ref))
+        pairs.append((l_got, l_ref))
     for k in range(50):
         model.step_async(None, *batches[k % 64], loss='ce')
     torch.cuda.synchronize()
@@ -72,7 +74,7 @@ def main():
         "gpu_interactions_per_s": B * args.steps / gpu_wall, "gpu_us_per_step": 1e6 * gpu_wall / args.steps,
         "cpu_restatement_interactions_per_s": B * args.cpu_steps / cpu_wall,
         "cpu_ms_per_step": 1e3 * cpu_wall / args.cpu_steps, "cpu_threads": int(th),
-        "loss_rel_err_first3_steps_vs_fp32_restatement": rel}))
+        "loss_rel_err_first3_steps_vs_fp32_restatement": rel, "losses_gpu_vs_cpu": pairs}))
 
 
 if __name__ == "__main__":
