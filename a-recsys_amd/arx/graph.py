@@ -513,46 +513,54 @@ class Plan(object):
             if not m.fused:
                 m.scatter(1)                               # reset_mask (:217-218)
 
-    def _cat_eligible(self, entry):
+    def _fusable(self, entry):
+        """(one-hot sites, multi-hot sites) of a table that can join the fused K7 pass."""
         rt = self.rt
         table, sites, bufs, total = entry
         live = [s for s in sites if s.node._grad_written]
         if not live or rt.force_sort_path or rt.cat_mode != 0:
             return None
-        if not all(s.kind == 'cat' and s.col_off == 0 for s in live):
+        if any(s.col_off != 0 for s in live):
             return None
-        if sum(s.n for s in live) > (1 << 22):
-            return None
-        return live
+        return [s for s in live if s.kind == 'cat'], [s for s in live if s.kind != 'cat']
 
     def _apply_sparse(self):
-        """One K7 pass per table -- except that one-hot tables of equal width that read the
-        same gradient arena share ONE pass (arx_sparse_adagrad_cat_multi): their kernel chains
-        are launch-bound, and parallel hipGraph branches did not overlap them (measured)."""
+        """One K7 pass per table -- except that tables of equal width that read the same
+        gradient arena share ONE pass (arx_sparse_adagrad_cat_multi: the sort key carries the
+        table index; multi-hot lookups join as pre-expanded segments): the kernel chains are
+        launch-bound, and parallel hipGraph branches did not overlap them (measured)."""
         rt = self.rt
         fused = []
         if not rt.no_multi:
             cand = []
             for entry in self.tables:
-                live = self._cat_eligible(entry)
-                if live is not None:
-                    cand.append((entry, live))
+                f = self._fusable(entry)
+                if f is not None:
+                    cand.append((entry, f[0], f[1]))
             if len(cand) >= 2:
-                e0, l0 = cand[0]
-                d0, arena0 = e0[0].E.shape[1], l0[0].node.arena
-                group = [(e, l) for e, l in cand
-                         if e[0].E.shape[1] == d0 and all(x.node.arena is arena0 for x in l)
-                         and all(x.node.arena_b is l0[0].node.arena_b for x in l)]
-                rows_bits = max(int(e[0].E.shape[0] - 1).bit_length() for e, _ in group) if group else 0
+                e0, c0, m0 = cand[0]
+                n0 = (c0 + m0)[0].node
+                d0 = e0[0].E.shape[1]
+                group = [(e, c, m) for e, c, m in cand
+                         if e[0].E.shape[1] == d0 and all(x.node.arena is n0.arena for x in c + m)
+                         and all(x.node.arena_b is n0.arena_b for x in c + m)]
+                # multi-hot segments are padded to their worst-case capacity: past ~0.5 M entries
+                # the shared sort/apply pays more for the pads than the saved launches (measured:
+                # C3 B=16384 fused 627 us vs 543 us) -- then only the one-hot tables share a pass
+                if sum(x.cap for _, c, m in group for x in c + m) > (1 << 19):
+                    group = [(e, c, m) for e, c, m in group if not m]
+                rows_bits = max(int(e[0].E.shape[0] - 1).bit_length() for e, _, _ in group) if group else 0
+                n_tot = sum(x.cap for _, c, m in group for x in c + m)
                 # below the LDS rank-sort limit a table's own chain is already 3 launches; fusing
                 # would push the union into the 8-launch radix path (measured slower at B=4096)
-                big = any(sum(x.n for x in l) > 8192 for _, l in group)
-                if (big and 2 <= len(group) <= 4 and sum(len(l) for _, l in group) <= 8
-                        and rows_bits + 2 <= 30):
+                big = any(sum(x.cap for x in c + m) > 8192 for _, c, m in group)
+                if (big and 2 <= len(group) <= 4 and sum(len(c) for _, c, _ in group) <= 8
+                        and sum(len(m) for _, _, m in group) <= 8 and rows_bits + 2 <= 30
+                        and n_tot <= (1 << 22)):
                     fused = group
         if fused:
             self._apply_multi(fused)
-        done = set(id(e) for e, _ in fused)
+        done = set(id(e) for e, _, _ in fused)
         toks = []
         for ti, entry in enumerate(self.tables):
             if id(entry) in done:
@@ -566,29 +574,42 @@ class Plan(object):
 
     def _apply_multi(self, group):
         rt = self.rt
-        key = tuple(id(x) for _, l in group for x in l) + tuple(
-            bool(e[0].bias is not None and any(x.node.bias_grad_used for x in l)) for e, l in group)
+        key = tuple(id(x) for _, c, m in group for x in c + m) + tuple(
+            bool(e[0].bias is not None and any(x.node.bias_grad_used for x in c + m)) for e, c, m in group)
         cache = self.__dict__.setdefault('_multi_cache', {})
         ent = cache.get(key)
         if ent is None:
-            tables, sites = [], []
-            for ti, (e, l) in enumerate(group):
+            tables, sites, extra, xsites = [], [], [], []
+            for ti, (e, c, m) in enumerate(group):
                 table = e[0]
-                use_bias = table.bias is not None and any(x.node.bias_grad_used for x in l)
+                use_bias = table.bias is not None and any(x.node.bias_grad_used for x in c + m)
                 tables.append((table.E, table.acc, table.bias if use_bias else None,
                                table.bias_acc if use_bias else None, self._aux_cnt(table)))
-                for x in l:
+                for x in c:
                     sites.append((ti, x.maps[0], x.ids_node.value, x.node.row0, x.coef))
-            args = ops.MultiCatArgs(tables, sites)
+                for x in m:
+                    extra.append((ti, x.cap))
+                    xsites.append(x)
+            args = ops.MultiCatArgs(tables, sites, extra)
             n = args.total
-            ent = dict(args=args,
-                       keys=torch.empty(n, dtype=torch.int32, device=rt.device),
-                       src=torch.empty(n, dtype=torch.int32, device=rt.device),
-                       coef=torch.empty(n, dtype=torch.float32, device=rt.device),
+            dev = rt.device
+            ent = dict(args=args, xsites=xsites,
+                       keys=torch.empty(n, dtype=torch.int32, device=dev),
+                       src=torch.empty(n, dtype=torch.int32, device=dev),
+                       coef=torch.empty(n, dtype=torch.float32, device=dev),
+                       offs=[torch.zeros((x.n + 1,), dtype=torch.int32, device=dev) for x in xsites],
+                       tot=torch.zeros((1,), dtype=torch.int32, device=dev),
                        any_bias=any(t[2] is not None for t in tables))
             cache[key] = ent
-        node0 = group[0][1][0].node
-        ops.sparse_adagrad_cat_multi(ent['args'], node0.arena, node0.arena_b if ent['any_bias'] else None,
+        args = ent['args']
+        for x, off, offs in zip(ent['xsites'], args.extra_off, ent['offs']):   # multi-hot lookups
+            ops.csr_expand(x.maps[0], x.maps[1], x.maps[2], x.ids_node.value, x.cap, rt.ws,
+                           pad_token=KEY_NONE, pad_seg=0, seg_base=x.node.row0, coef_scale=x.coef,
+                           want_coef=True,
+                           out=(ent['keys'][off:off + x.cap], ent['src'][off:off + x.cap], offs,
+                                ent['tot'], ent['coef'][off:off + x.cap]))
+        node0 = (group[0][1] + group[0][2])[0].node
+        ops.sparse_adagrad_cat_multi(args, node0.arena, node0.arena_b if ent['any_bias'] else None,
                                      rt.lr, ent['keys'], ent['src'], ent['coef'], rt.ws,
                                      gscale_dev=rt.clip_coef_dev)
 

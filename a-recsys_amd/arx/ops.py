@@ -299,24 +299,36 @@ class MultiCatArgs(object):
     tables: list of (E, acc, bias|None, bias_acc|None, aux_cnt|None);
     sites: list of (table_index, cat_map|None, ids, row_base, coef)."""
 
-    def __init__(self, tables, sites):
+    def __init__(self, tables, sites, extra=()):
+        """extra: [(table_index, n)] pre-expanded segments (arx_csr_expand output) that follow
+        the one-hot contributions in keys_buf / src_buf / coef_buf."""
         import ctypes as C
         nt, ns = len(tables), len(sites)
         self.nt, self.ns = nt, ns
         self.d = int(tables[0][0].shape[1])
-        self.total = sum(int(s[2].shape[0]) for s in sites)
+        self.n_cat = sum(int(s[2].shape[0]) for s in sites)
+        self.nx = len(extra)
+        self.extra_n = (C.c_int64 * max(self.nx, 1))(*[int(e[1]) for e in extra])
+        self.extra_table = (C.c_int32 * max(self.nx, 1))(*[int(e[0]) for e in extra])
+        self.extra_off = []
+        off = self.n_cat
+        for e in extra:
+            self.extra_off.append(off)
+            off += int(e[1])
+        self.total = off
         self.E = (C.c_void_p * nt)(*[_p(t[0]) for t in tables])
         self.acc = (C.c_void_p * nt)(*[_p(t[1]) for t in tables])
         self.bias = (C.c_void_p * nt)(*[_p(t[2]) or None for t in tables])
         self.bias_acc = (C.c_void_p * nt)(*[_p(t[3]) or None for t in tables])
         self.rows = (C.c_int64 * nt)(*[int(t[0].shape[0]) for t in tables])
         self.cnt = (C.c_void_p * nt)(*[_p(t[4]) or None for t in tables])
-        self.site_table = (C.c_int32 * ns)(*[int(s[0]) for s in sites])
-        self.cat_map = (C.c_void_p * ns)(*[_p(s[1]) or None for s in sites])
-        self.ids = (C.c_void_p * ns)(*[_p(s[2]) for s in sites])
-        self.count = (C.c_int64 * ns)(*[int(s[2].shape[0]) for s in sites])
-        self.row_base = (C.c_int32 * ns)(*[int(s[3]) for s in sites])
-        self.coef = (C.c_float * ns)(*[float(s[4]) for s in sites])
+        m = max(ns, 1)
+        self.site_table = (C.c_int32 * m)(*[int(s[0]) for s in sites])
+        self.cat_map = (C.c_void_p * m)(*[_p(s[1]) or None for s in sites])
+        self.ids = (C.c_void_p * m)(*[_p(s[2]) for s in sites])
+        self.count = (C.c_int64 * m)(*[int(s[2].shape[0]) for s in sites])
+        self.row_base = (C.c_int32 * m)(*[int(s[3]) for s in sites])
+        self.coef = (C.c_float * m)(*[float(s[4]) for s in sites])
         self._keep = (tables, sites)
 
 
@@ -325,7 +337,7 @@ def sparse_adagrad_cat_multi(args, G, Gb, lr_dev, keys_buf, src_buf, coef_buf, w
     call("arx_sparse_adagrad_cat_multi", args.nt, args.E, args.acc, args.bias, args.bias_acc,
          args.rows, args.cnt, args.d, args.ns, args.site_table, args.cat_map, args.ids, args.count,
          args.row_base, args.coef, _p(G), _ld(G), _p(Gb), _p(lr_dev), _p(gscale_dev), _p(keys_buf),
-         _p(src_buf), _p(coef_buf), wsp, wsn, _stream())
+         _p(src_buf), _p(coef_buf), args.nx, args.extra_n, args.extra_table, wsp, wsn, _stream())
 
 
 def adagrad_dense(w, acc, g, lr_dev, gscale_dev=None):

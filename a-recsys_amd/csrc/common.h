@@ -71,6 +71,12 @@ struct CatSites {
   int32_t table[kMaxSites];        // which table of the TableSet the site updates
   int64_t rows[kMaxTables];        // rows of each table (key validation)
   int kb;                          // sort key = (table << kb) | row
+  // pre-expanded contributions behind the one-hot ones (multi-hot sites: arx_csr_expand wrote
+  // table-local keys, source rows and coefficients at keys_buf[offs[nsites] + xoffs[e] ...));
+  // k_site_keys only adds the table prefix
+  int nextra;
+  int64_t xoffs[kMaxSites + 1];
+  int32_t xtable[kMaxSites];
 };
 
 // Tables updated by ONE sparse-Adagrad pass.  Several tables of equal width share a sort and

@@ -319,6 +319,8 @@ int arx_sparse_adagrad_cat(float* E, float* acc, float* bias, float* bias_acc, i
     while ((1ll << kb) < table_rows && kb < 30) ++kb;
     ts.kb = kb;
     st.kb = kb;
+    st.nextra = 0;
+    st.xoffs[0] = 0;
     for (int q = 0; q < kMaxSites; ++q) st.table[q] = 0;
     for (int q = 0; q < kMaxTables; ++q) st.rows[q] = table_rows;
     return sparse_adagrad_sites_sorted(ts, 1, d, st, G, ldg, Gb, lr_dev, gscale_dev, keys_buf, src_buf,
@@ -356,10 +358,14 @@ int arx_sparse_adagrad_cat_multi(int ntables, float* const* E, float* const* acc
                                  const int32_t* site_row_base, const float* site_coef, const float* G,
                                  int64_t ldg, const float* Gb, const float* lr_dev,
                                  const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
-                                 float* coef_buf, void* workspace, size_t workspace_bytes,
-                                 void* stream) {
+                                 float* coef_buf, int nextra, const int64_t* extra_n,
+                                 const int32_t* extra_table, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
   ARX_CHECK_ARG(ntables >= 1 && ntables <= kMaxTables, "arx_sparse_adagrad_cat_multi: 1..4 tables");
-  ARX_CHECK_ARG(nsites > 0 && nsites <= kMaxSites, "arx_sparse_adagrad_cat_multi: 1..8 lookup sites");
+  ARX_CHECK_ARG(nsites >= 0 && nsites <= kMaxSites && nextra >= 0 && nextra <= kMaxSites &&
+                    nsites + nextra > 0,
+                "arx_sparse_adagrad_cat_multi: 0..8 one-hot sites, 0..8 pre-expanded segments");
+  ARX_CHECK_ARG(nextra == 0 || (extra_n && extra_table), "arx_sparse_adagrad_cat_multi: extra arrays");
   ARX_CHECK_ARG(E && acc && bias && bias_acc && table_rows && aux_cnt && site_table && site_cat_map &&
                     site_ids && site_n && site_row_base && site_coef && G && lr_dev && keys_buf &&
                     src_buf && coef_buf,
@@ -408,7 +414,17 @@ int arx_sparse_adagrad_cat_multi(int ntables, float* const* E, float* const* acc
       ARX_CHECK_ARG(site_ids[q] && site_n[q] >= 0 && site_table[q] >= 0 && site_table[q] < ntables,
                     "arx_sparse_adagrad_cat_multi: bad site");
   }
-  const int64_t n = st.offs[nsites];
+  st.nextra = nextra;
+  st.xoffs[0] = 0;
+  for (int q = 0; q < kMaxSites; ++q) {
+    const bool live = q < nextra;
+    st.xtable[q] = live ? extra_table[q] : 0;
+    st.xoffs[q + 1] = st.xoffs[q] + (live ? extra_n[q] : 0);
+    if (live)
+      ARX_CHECK_ARG(extra_n[q] >= 0 && extra_table[q] >= 0 && extra_table[q] < ntables,
+                    "arx_sparse_adagrad_cat_multi: bad pre-expanded segment");
+  }
+  const int64_t n = st.offs[nsites] + st.xoffs[nextra];
   if (n == 0) return ARX_OK;
   ARX_CHECK_ARG(n < (int64_t)INT_MAX, "arx_sparse_adagrad_cat_multi: too many contributions");
   return sparse_adagrad_sites_sorted(ts, ntables, d, st, G, ldg, Gb, lr_dev, gscale_dev, keys_buf,

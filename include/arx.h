@@ -262,8 +262,12 @@ int arx_sparse_adagrad_cat(float* E, float* acc, float* bias, float* bias_acc, i
  * table index above the row bits).  Table t: E[t], acc[t], bias[t]/bias_acc[t] (NULL: no
  * bias), table_rows[t], aux_cnt[t] (int32[table_rows[t]] zeros, for all tables or none).
  * Site s updates table site_table[s]; the other site arrays as in arx_sparse_adagrad_cat.
- * ntables <= 4, nsites <= 8, rows + table bits <= 30.
- * workspace >= arx_sparse_adagrad_workspace_bytes(sum(site_n)). */
+ * Multi-hot lookups join the same pass as pre-expanded segments: the caller runs
+ * arx_csr_expand into keys_buf / src_buf / coef_buf BEHIND the one-hot contributions (segment
+ * e occupies extra_n[e] entries starting at sum(site_n) + sum(extra_n[:e]), table-local token
+ * keys, padded with ARX_KEY_NONE) and names the table of each segment in extra_table[e].
+ * ntables <= 4, nsites <= 8, nextra <= 8, rows + table bits <= 30.
+ * workspace >= arx_sparse_adagrad_workspace_bytes(sum(site_n) + sum(extra_n)). */
 int arx_sparse_adagrad_cat_multi(int ntables, float* const* E, float* const* acc, float* const* bias,
                                  float* const* bias_acc, const int64_t* table_rows,
                                  int32_t* const* aux_cnt, int d, int nsites,
@@ -272,8 +276,9 @@ int arx_sparse_adagrad_cat_multi(int ntables, float* const* E, float* const* acc
                                  const int32_t* site_row_base, const float* site_coef, const float* G,
                                  int64_t ldg, const float* Gb, const float* lr_dev,
                                  const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
-                                 float* coef_buf, void* workspace, size_t workspace_bytes,
-                                 void* stream);
+                                 float* coef_buf, int nextra, const int64_t* extra_n,
+                                 const int32_t* extra_table, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 
 /* ---- a16/a19: dense Adagrad, norms, clip ---------------------------------
  * tf.train.AdagradOptimizer dense apply; tf.clip_by_global_norm

@@ -641,6 +641,58 @@ def test_sparse_adagrad_ticket_large_n(dev, n, Vf):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_sparse_adagrad_cat_multi_with_multihot_segments(dev):
+    """One fused pass over a one-hot table and a multi-hot token table: the multi-hot lookups
+    arrive as arx_csr_expand output (table-local token keys, ARX_KEY_NONE pads) behind the
+    one-hot contributions; result == one reference update per table."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(5)
+    d, V0, V1, B, n_rows = 64, 3000, 500, 900, 1200
+    G = rng.standard_normal((2 * B, d)).astype(np.float32)
+    Gb = rng.standard_normal((2 * B,)).astype(np.float32)
+    E0 = rng.standard_normal((V0, d)).astype(np.float32)
+    A0 = (0.1 + rng.random((V0, d))).astype(np.float32)
+    E1 = rng.standard_normal((V1, d)).astype(np.float32)
+    A1 = (0.1 + rng.random((V1, d))).astype(np.float32)
+    b1 = rng.standard_normal((V1,)).astype(np.float32)
+    ba1 = np.full((V1,), 0.1, dtype=np.float32)
+    ids0 = rng.integers(0, V0, size=B).astype(np.int32)                    # one-hot site, G rows [0, B)
+    vals, starts, lens = _csr(rng, n_rows, V1, 12, zipf=True)              # multi-hot site, G rows [B, 2B)
+    bag = rng.integers(0, n_rows, size=B).astype(np.int32)
+    tok = rg.batch_slice2(vals, starts[bag], lens[bag])
+    seg = rg.batch_segids2(lens[bag])
+    coef1 = (0.5 / lens[bag][seg]).astype(np.float32)
+    r0 = _ref_sparse_adagrad(E0, A0, np.zeros(V0, np.float32), np.full(V0, 0.1, np.float32),
+                             ids0.astype(np.int64), np.arange(B, dtype=np.int32),
+                             np.ones(B, np.float32), G, Gb, 0.3, 1.0)
+    r1 = _ref_sparse_adagrad(E1, A1, b1, ba1, tok.astype(np.int64), (B + seg).astype(np.int32), coef1,
+                             G, Gb, 0.3, 1.0)
+    cap = B * 12
+    t0 = (_t(dev, E0), _t(dev, A0), None, None, torch.zeros(V0, dtype=torch.int32, device=dev))
+    t1 = (_t(dev, E1), _t(dev, A1), _t(dev, b1), _t(dev, ba1), torch.zeros(V1, dtype=torch.int32, device=dev))
+    args = ops.MultiCatArgs([t0, t1], [(0, None, _t(dev, ids0), 0, 1.0)], extra=[(1, cap)])
+    kb = torch.empty(args.total, dtype=torch.int32, device=dev)
+    sb = torch.empty(args.total, dtype=torch.int32, device=dev)
+    cb = torch.empty(args.total, dtype=torch.float32, device=dev)
+    ws = ops.Workspace(dev)
+    off = args.extra_off[0]
+    offs = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    tot = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.csr_expand(_t(dev, vals), _t(dev, starts), _t(dev, lens), _t(dev, bag), cap, ws,
+                   pad_token=ops.KEY_NONE, pad_seg=0, seg_base=B, coef_scale=0.5, want_coef=True,
+                   out=(kb[off:off + cap], sb[off:off + cap], offs, tot, cb[off:off + cap]))
+    lr = torch.tensor([0.3], dtype=torch.float32, device=dev)
+    ops.sparse_adagrad_cat_multi(args, _t(dev, G), _t(dev, Gb), lr, kb, sb, cb, ws)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(t0[0].cpu().numpy(), r0[0], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(t0[1].cpu().numpy(), r0[1], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(t1[0].cpu().numpy(), r1[0], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(t1[1].cpu().numpy(), r1[1], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(t1[2].cpu().numpy(), r1[2], rtol=2e-4, atol=2e-5)
+    assert int(t0[4].abs().sum().item()) == 0 and int(t1[4].abs().sum().item()) == 0
+
+
 @pytest.mark.parametrize("d,rows,ns", [(128, (5000, 7000), (4096, 1024, 4096)),
                                        (32, (40, 1000, 17), (300, 64, 50, 2000)),
                                        (64, (100000, 300000), (20000, 30000))])
