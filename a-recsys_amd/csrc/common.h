@@ -118,10 +118,13 @@ int gemm_dma_launch(int transA, int64_t M, int64_t N, int64_t K, float alpha, co
 // keys_raw: caller keys (ARX_KEY_NONE / out-of-range -> sentinel); src_raw/coef_raw may be
 // null (identity / 1.0).  *_tmp: ping-pong buffers of n entries; hist: radix_sort_hist_bytes().
 // list_count (optional): two ints zeroed by the first launch.
+// n_live (optional, device int32): the first pass drops sentinel entries (pads, invalid keys)
+// and writes the number of survivors here; later passes -- and the caller's apply kernels --
+// work on that many entries (the grids stay sized for n).
 size_t radix_sort_hist_bytes();
 int launch_radix_sort(const int32_t* keys_raw, const int32_t* src_raw, const float* coef_raw, int64_t n,
                       uint32_t sentinel, int total_bits, uint32_t* keys_tmp, uint32_t* keys_out,
                       int32_t* src_tmp, int32_t* src_out, float* coef_tmp, float* coef_out,
-                      int32_t* hist, int32_t* list_count, hipStream_t s);
+                      int32_t* hist, int32_t* list_count, int32_t* n_live, hipStream_t s);
 
 }  // namespace arx

@@ -358,7 +358,8 @@ template <int LPR, int WPW, bool MT>
 __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
     TableSet ts, int d, const uint32_t* __restrict__ sk,
     const uint32_t* __restrict__ spos, const int32_t* __restrict__ ssrc,
-    const float* __restrict__ scoef, int64_t n, uint32_t sentinel, const float* __restrict__ G,
+    const float* __restrict__ scoef, int64_t n_host, const int32_t* __restrict__ n_dev,
+    uint32_t sentinel, const float* __restrict__ G,
     int64_t ldg, const float* __restrict__ Gb, const float* __restrict__ lr_dev,
     const float* __restrict__ gscale_dev, float* __restrict__ scratch,
     float* __restrict__ scratch_b, float* __restrict__ scratch_h, float* __restrict__ scratch_hb,
@@ -366,6 +367,9 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
     int32_t* __restrict__ list_count) {
   constexpr int NSG = 64 / LPR;
   constexpr int NWV = (WPW > 4) ? WPW : 4;    // waves per workgroup
+  // n_dev: entries that survived the radix sort's first pass (pads dropped); the grid is sized
+  // for the padded capacity and surplus windows leave at once
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   __shared__ int s_src[NWV][64];
   __shared__ float s_coef[NWV][64];
   __shared__ uint32_t s_key[NWV][64];
@@ -523,8 +527,8 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
 //     two round trips), grid-stride over the short list.
 template <int LPR, bool MT>
 __global__ __launch_bounds__(1024) void k_sparse_finish(
-    TableSet ts, int d, const uint32_t* __restrict__ sk, int64_t n,
-    const float* __restrict__ lr_dev, const float* __restrict__ gscale_dev,
+    TableSet ts, int d, const uint32_t* __restrict__ sk, int64_t n_host,
+    const int32_t* __restrict__ n_dev, const float* __restrict__ lr_dev, const float* __restrict__ gscale_dev,
     const float* __restrict__ scratch, const float* __restrict__ scratch_b,
     const float* __restrict__ scratch_h, const float* __restrict__ scratch_hb,
     const int32_t* __restrict__ list_long, const int32_t* __restrict__ list_short,
@@ -532,6 +536,7 @@ __global__ __launch_bounds__(1024) void k_sparse_finish(
   constexpr int NSG = 1024 / LPR;
   __shared__ __attribute__((aligned(16))) float sh[NSG][LPR * 4];
   __shared__ float shb[NSG];
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   const int lig = threadIdx.x % LPR;
   const int sg = threadIdx.x / LPR;
   const int col = lig * 4;
@@ -858,7 +863,7 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
                         const float* gb_in, const float* lr_dev, const float* gscale_dev,
                         float* scratch, float* scratch_b, float* scratch_h, float* scratch_hb,
                         int32_t* list, int32_t* count, bool short_runs, bool multi,
-                        hipStream_t s) {
+                        const int32_t* n_dev, hipStream_t s) {
   const int32_t* cnt = ts.cnt[0];
   const int lpr = lanes_per_row(d);
   if (cnt != nullptr && n <= kRankSortMax) {
@@ -885,7 +890,7 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
   const int grid8 = (int)ceil_div(n, 64);
 #define ARX_WIN_GO(WPW_, MT_, GRID_, THREADS_)                                                      \
   ARX_DISPATCH_LPR(lpr, (k_sparse_win<LPR, WPW_, MT_><<<GRID_, THREADS_, 0, s>>>(                   \
-                            ts, d, sk, spos, ssrc, scoef, n, sentinel, G, ldg, gb_in, lr_dev,       \
+                            ts, d, sk, spos, ssrc, scoef, n, n_dev, sentinel, G, ldg, gb_in, lr_dev, \
                             gscale_dev, scratch, scratch_b, scratch_h, scratch_hb, list_long,       \
                             list_short, count)))
   if (short_runs) {   // one-hot ids: 8 waves share each window
@@ -904,11 +909,11 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
     if (nshort > cap) nshort = cap;
     if (multi) {
       ARX_DISPATCH_LPR(lpr, (k_sparse_finish<LPR, true><<<(int)(nlong + nshort), 1024, 0, s>>>(
-                                ts, d, sk, n, lr_dev, gscale_dev, scratch, scratch_b,
+                                ts, d, sk, n, n_dev, lr_dev, gscale_dev, scratch, scratch_b,
                                 scratch_h, scratch_hb, list_long, list_short, count, (int)nlong)));
     } else {
       ARX_DISPATCH_LPR(lpr, (k_sparse_finish<LPR, false><<<(int)(nlong + nshort), 1024, 0, s>>>(
-                                ts, d, sk, n, lr_dev, gscale_dev, scratch, scratch_b,
+                                ts, d, sk, n, n_dev, lr_dev, gscale_dev, scratch, scratch_b,
                                 scratch_h, scratch_hb, list_long, list_short, count, (int)nlong)));
     }
     ARX_CHECK_LAUNCH();
@@ -961,6 +966,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   const uint32_t* spos_arg = nullptr;
   const int32_t* src_arg = ssrc;
   const float* coef_arg = scoef;
+  const int32_t* n_dev = nullptr;      // live-entry count of the radix sort (pads dropped)
   if (n <= kRankSortMax) {
     rc = launch_rank_sort(keys_buf, n, sentinel, keys_out, pos_out, count, s, src_buf, coef_buf,
                           ssrc, scoef);
@@ -970,8 +976,9 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
                            reinterpret_cast<uint32_t*>(base + w.off_keys_tmp), keys_out,
                            reinterpret_cast<int32_t*>(base + w.off_pos_in), ssrc,
                            reinterpret_cast<float*>(base + w.off_pos_out), scoef,
-                           reinterpret_cast<int32_t*>(base + w.off_hist), count, s);
+                           reinterpret_cast<int32_t*>(base + w.off_hist), count, count + 2, s);
     if (rc) return rc;
+    n_dev = count + 2;
   } else {   // rocPRIM merge sort (A/B aid); the apply pass follows the position indirection
     uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(base + w.off_keys_tmp);
     uint32_t* pos_in = reinterpret_cast<uint32_t*>(base + w.off_pos_in);
@@ -994,7 +1001,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   const float* gb_in = any_bias ? Gb : nullptr;
   return launch_apply(ts, d, keys_out, spos_arg, src_arg, coef_arg, n, sentinel, G, ldg, gb_in, lr_dev,
                       gscale_dev, scratch, scratch_b, scratch_h, scratch_hb, list, count,
-                      /*short_runs=*/(ntables > 1 || n <= (1 << 19)), /*multi=*/ntables > 1, s);   // fused passes mix unique-heavy one-hot ids in: 8 waves per window
+                      /*short_runs=*/(ntables > 1 || n <= (1 << 19)), /*multi=*/ntables > 1, n_dev, s);   // fused passes mix unique-heavy one-hot ids in: 8 waves per window
 }
 
 }  // namespace arx
@@ -1052,6 +1059,7 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
   float* scratch_b = reinterpret_cast<float*>(base + w.off_scratch_b);
   void* temp = base + w.off_temp;
   const uint32_t* spos_arg = pos_out;
+  const int32_t* n_dev = nullptr;      // live-entry count of the radix sort (pads dropped)
   if (n <= kRankSortMax) {
     // id-only batches (B + S keys): one workgroup sorts everything in LDS -- a
     // single launch instead of the 5-6 of the device-wide radix sort.
@@ -1075,8 +1083,9 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
     rc = launch_radix_sort(keys, src, coef, n, sentinel, key_bits + 1, keys_tmp, keys_out,
                            reinterpret_cast<int32_t*>(pos_in), ssrc,
                            reinterpret_cast<float*>(pos_out), scoef,
-                           reinterpret_cast<int32_t*>(base + w.off_hist), count, s);
+                           reinterpret_cast<int32_t*>(base + w.off_hist), count, count + 2, s);
     if (rc) return rc;
+    n_dev = count + 2;
     spos_arg = nullptr;
     src = ssrc;
     coef = scoef;
@@ -1104,7 +1113,7 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
                       gscale_dev, scratch, scratch_b,
                       reinterpret_cast<float*>(base + w.off_scratch_h),
                       reinterpret_cast<float*>(base + w.off_scratch_hb), list, count,
-                      /*short_runs=*/n <= (1 << 19)   /* 8 waves per window measured faster up to ~0.5 M contributions (mulhot100k 92 -> 73 us), slower at 1.3 M */, /*multi=*/false, s);
+                      /*short_runs=*/n <= (1 << 19)   /* 8 waves per window measured faster up to ~0.5 M contributions (mulhot100k 92 -> 73 us), slower at 1.3 M */, /*multi=*/false, n_dev, s);
 }
 
 int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const float* lr_dev,

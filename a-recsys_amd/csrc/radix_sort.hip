@@ -48,10 +48,14 @@ constexpr int kRsWaves = kRsThreads / 64;
 
 // per-WAVE digit histograms: hist[(blk * 4 + wave)][bin] over the wave's contiguous quarter
 template <bool RAW>
-__global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__ keys_in, int64_t n,
+__global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__ keys_in, int64_t n_host,
+                                                        const int32_t* __restrict__ n_dev,
                                                         uint32_t sentinel, int shift, int bits,
                                                         int64_t ipb, int32_t* __restrict__ hist,
                                                         int32_t* __restrict__ list_count) {
+  // n_dev: live entries after the first pass dropped the sentinels (device-side count; the
+  // grid is still sized for the padded capacity, surplus blocks write zero rows)
+  const int64_t n = (!RAW && n_dev) ? (int64_t)*n_dev : n_host;
   __shared__ int h[kRsWaves][kRsMaxBins];
   const int bins = 1 << bits;
   const int lane = threadIdx.x & 63;
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-      if (i0 + u * 64 < we) atomicAdd(&h[w][(k[u] >> shift) & mask], 1);
+      if (i0 + u * 64 < we && !(RAW && k[u] >= sentinel))   // pads / dropped keys are not sorted at all
+        atomicAdd(&h[w][(k[u] >> shift) & mask], 1);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -122,9 +127,11 @@ __global__ __launch_bounds__(1024) void k_rs_scan(int32_t* __restrict__ hist, in
 template <bool RAW>
 __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(
     const void* __restrict__ keys_in, const int32_t* __restrict__ src_in,
-    const float* __restrict__ coef_in, int64_t n, uint32_t sentinel, int shift, int bits,
-    int64_t ipb, const int32_t* __restrict__ hist, const int32_t* __restrict__ tot,
-    uint32_t* __restrict__ keys_out, int32_t* __restrict__ src_out, float* __restrict__ coef_out) {
+    const float* __restrict__ coef_in, int64_t n_host, int32_t* __restrict__ n_live,
+    uint32_t sentinel, int shift, int bits, int64_t ipb, const int32_t* __restrict__ hist,
+    const int32_t* __restrict__ tot, uint32_t* __restrict__ keys_out, int32_t* __restrict__ src_out,
+    float* __restrict__ coef_out) {
+  const int64_t n = (!RAW && n_live) ? (int64_t)*n_live : n_host;
   constexpr int NW = kRsWaves;
   __shared__ int wcnt[NW][kRsMaxBins];
   __shared__ int gbase[kRsMaxBins];
@@ -162,6 +169,8 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(
         gbase[b0 + u] = run;
         run += tv[u];
       }
+    // first pass: the grand total = entries that survive (sentinels dropped)
+    if (RAW && n_live && blockIdx.x == 0 && threadIdx.x == kRsThreads - 1) *n_live = run;
   }
   __syncthreads();
   {
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t i = i0 + u * 64 + lane;
-      const bool valid = i < we;
+      const bool valid = (i < we) && !(RAW && k[u] >= sentinel);
       if (i0 + u * 64 >= we) break;                 // wave-uniform
       const uint32_t dgt = (k[u] >> shift) & mask;
       unsigned long long peers = __ballot(valid);
@@ -253,7 +262,7 @@ size_t radix_sort_hist_bytes() {   // per-wave rows + the column totals
 int launch_radix_sort(const int32_t* keys_raw, const int32_t* src_raw, const float* coef_raw, int64_t n,
                       uint32_t sentinel, int total_bits, uint32_t* keys_tmp, uint32_t* keys_out,
                       int32_t* src_tmp, int32_t* src_out, float* coef_tmp, float* coef_out,
-                      int32_t* hist, int32_t* list_count, hipStream_t s) {
+                      int32_t* hist, int32_t* list_count, int32_t* n_live, hipStream_t s) {
   const RsPlan p = rs_plan(n, total_bits);
   const void* in_k = keys_raw;
   const int32_t* in_s = src_raw;
@@ -267,20 +276,20 @@ int launch_radix_sort(const int32_t* keys_raw, const int32_t* src_raw, const flo
     int32_t* tot = hist + (int64_t)kRsMaxBlocks * kRsWaves * kRsMaxBins;
     const int bins = 1 << p.bits[i];
     if (i == 0)
-      k_rs_hist<true><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, sentinel, p.shift[i], p.bits[i], p.ipb,
+      k_rs_hist<true><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, n_live, sentinel, p.shift[i], p.bits[i], p.ipb,
                                                     hist, list_count);
     else
-      k_rs_hist<false><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, sentinel, p.shift[i], p.bits[i],
+      k_rs_hist<false><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, n_live, sentinel, p.shift[i], p.bits[i],
                                                      p.ipb, hist, nullptr);
     ARX_CHECK_LAUNCH();
     k_rs_scan<<<bins / 4, 1024, 0, s>>>(hist, p.nblk * kRsWaves, bins, tot);
     ARX_CHECK_LAUNCH();
     if (i == 0)
-      k_rs_scatter<true><<<p.nblk, kRsThreads, 0, s>>>(in_k, in_s, in_c, n, sentinel, p.shift[i],
+      k_rs_scatter<true><<<p.nblk, kRsThreads, 0, s>>>(in_k, in_s, in_c, n, n_live, sentinel, p.shift[i],
                                                        p.bits[i], p.ipb, hist, tot, out_k, out_s,
                                                        out_c);
     else
-      k_rs_scatter<false><<<p.nblk, kRsThreads, 0, s>>>(in_k, in_s, in_c, n, sentinel, p.shift[i],
+      k_rs_scatter<false><<<p.nblk, kRsThreads, 0, s>>>(in_k, in_s, in_c, n, n_live, sentinel, p.shift[i],
                                                         p.bits[i], p.ipb, hist, tot, out_k, out_s,
                                                         out_c);
     ARX_CHECK_LAUNCH();
