@@ -9,38 +9,26 @@
 // dense update over the whole table can be restricted to the touched rows.
 //
 // Algorithm (deterministic -- no floating-point atomics):
-//   1. keys -> stable radix sort of (key, position)            [rocPRIM]
-//   2. pass A: one sub-group (LPR lanes, float4 each) per sorted position.
-//      A position is a piece LEADER if it starts a run of equal keys or is
-//      aligned to kPiece.  Leaders walk their piece (<= kPiece positions),
-//      summing coef*G[src] rows in sorted (= original) order.
-//        - head whose run ends inside the piece: apply Adagrad at once;
-//        - head whose run continues: push the head on a list (pass B);
-//        - aligned continuation piece: write the partial row to scratch.
-//   3. pass B: one workgroup per listed (long) run: its sub-groups sum the
-//      run's scratch partials (strided, fixed order) + the head piece, combine
-//      through LDS in a fixed order, apply Adagrad.
-// Zipf-heavy attribute tokens (thousands of duplicates) therefore cost
-// O(len / kPiece / 8) dependent loads instead of O(len).
+//   1. contributions (key = table row, src = gradient row, coef) are sorted by key, stably:
+//      n <= 8192: chip-wide LDS rank sort, one launch (k_rank_sort);
+//      larger   : own LSD radix sort (radix_sort.hip), which also drops padded / invalid keys.
+//   2. apply: runs of equal keys are summed in sorted (= original) order and each touched row
+//      gets ONE Adagrad update.
+//      n <= 8192: one sub-group (LPR lanes x float4) per sorted position; multi-piece runs are
+//                 finished by their last-arriving piece (per-row ticket counter) -- k_sparse_onepass;
+//      larger   : one wave (or 8) per window of 64 sorted positions -- k_sparse_win -- plus
+//                 k_sparse_finish for runs that cross windows (short: one sub-group each,
+//                 Zipf-hot: one 1024-thread workgroup each, fixed-order LDS combine).
+//   Several tables can share steps 1-2: the key carries the table index above the row bits.
 #include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
-#include <rocprim/block/block_radix_sort.hpp>
-#include <rocprim/device/device_radix_sort.hpp>
-
 #include "common.h"
 
 namespace arx {
 
 constexpr int kPiece = 64;          // positions per piece
 constexpr int kRankSortMax = 8192;
-// rocPRIM 4.2's onesweep path resets its ordered-block-id counter on gfx942/gfx950 with a
-// BLOCKING hipMemset (ordered_block_id.hpp reset_from_host): it is not captured into a
-// hipGraph, so a replayed graph reads a stale counter and the kernel walks off its
-// lookback array (seen as a GPU segfault), and in eager mode it serialises the host.
-// Pin the merge-sort path (pure kernel launches) for every n above our own LDS rank sort.
-using RsConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                            rocprim::default_config, (size_t)1 << 31>;
 constexpr int kPassBBlocks = 128;   // persistent grid of pass B
 
 __device__ __forceinline__ float4 f4_fma(float c, float4 v, float4 a) {
@@ -48,19 +36,6 @@ __device__ __forceinline__ float4 f4_fma(float c, float4 v, float4 a) {
 }
 __device__ __forceinline__ float4 f4_add2(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-}
-
-__global__ void k_prep_keys(const int32_t* __restrict__ keys, int64_t n, uint32_t sentinel,
-                            uint32_t* __restrict__ keys_tmp, uint32_t* __restrict__ pos,
-                            int32_t* __restrict__ list_count) {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i == 0) { list_count[0] = 0; list_count[1] = 0; }
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) {
-    const int32_t k = keys[i];
-    keys_tmp[i] = (k == ARX_KEY_NONE || k < 0 || (uint32_t)k >= sentinel) ? sentinel : (uint32_t)k;
-    pos[i] = (uint32_t)i;
-  }
 }
 
 // Stable rank sort for n <= 16384 keys, chip-wide in ONE launch: every workgroup keeps
@@ -186,39 +161,6 @@ __global__ __launch_bounds__(256) void k_site_keys(CatSites st, int32_t* __restr
     keys[i] = (key < 0 || key >= rows) ? ARX_KEY_NONE : ((tb << st.kb) | key);
     src[i] = st.row_base[s] + (int32_t)j;
     coef[i] = st.coef[s];
-  }
-}
-
-// n <= 1024*IPT: key normalisation + stable (key, position) sort by ONE workgroup.
-template <int IPT>
-__global__ __launch_bounds__(1024) void k_small_sort(const int32_t* __restrict__ keys, int64_t n,
-                                                     uint32_t sentinel, int key_bits,
-                                                     uint32_t* __restrict__ sk,
-                                                     uint32_t* __restrict__ spos,
-                                                     int32_t* __restrict__ list_count) {
-  using Sort = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint32_t, 1, 1, 8>;
-  __shared__ typename Sort::storage_type storage;
-  if (threadIdx.x == 0) { list_count[0] = 0; list_count[1] = 0; }
-  uint32_t k[IPT], v[IPT];
-#pragma unroll
-  for (int i = 0; i < IPT; ++i) {
-    const int64_t idx = (int64_t)threadIdx.x * IPT + i;
-    uint32_t kk = sentinel;   // padding sorts behind every real entry (stable)
-    if (idx < n) {
-      const int32_t r = keys[idx];
-      kk = (r == ARX_KEY_NONE || r < 0 || (uint32_t)r >= sentinel) ? sentinel : (uint32_t)r;
-    }
-    k[i] = kk;
-    v[i] = (uint32_t)idx;
-  }
-  Sort().sort(k, v, storage, 0, key_bits + 1);
-#pragma unroll
-  for (int i = 0; i < IPT; ++i) {
-    const int64_t idx = (int64_t)threadIdx.x * IPT + i;
-    if (idx < n) {
-      sk[idx] = k[i];
-      spos[idx] = v[i];
-    }
   }
 }
 
@@ -798,25 +740,14 @@ __global__ void k_clip_coef(const float* __restrict__ sq, float max_norm, float*
 constexpr int kNormBlocks = 256;
 static __device__ float g_norm_part[kNormBlocks];
 
-static bool use_rocprim_sort() {
-  static const bool v = getenv("ARX_ROCPRIM_SORT") != nullptr;   // A/B aid
-  return v;
-}
-
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct SparseWs {
   size_t off_keys_tmp, off_keys_out, off_pos_in, off_pos_out, off_list, off_count, off_scratch,
-      off_scratch_b, off_scratch_h, off_scratch_hb, off_ssrc, off_scoef, off_hist, off_temp, temp_bytes, total;
+      off_scratch_b, off_scratch_h, off_scratch_hb, off_ssrc, off_scoef, off_hist, total;
 };
 
 static int sparse_ws_layout(int64_t n, int d, SparseWs* w) {
-  size_t temp = 0;
-  hipError_t e = rocprim::radix_sort_pairs<RsConfig, const uint32_t*, uint32_t*,
-                                           const uint32_t*, uint32_t*>(
-      nullptr, temp, nullptr, nullptr, nullptr, nullptr, (unsigned int)(n > 0 ? n : 1), 0, 32,
-      (hipStream_t)0, false);
-  if (e != hipSuccess) return ARX_EHIP;
   const size_t ni = align_up((size_t)(n > 0 ? n : 1) * 4, 256);
   const size_t pieces = (size_t)(n / kPiece + 2);
   size_t o = 0;
@@ -833,8 +764,6 @@ static int sparse_ws_layout(int64_t n, int d, SparseWs* w) {
   w->off_ssrc = o; o += ni;
   w->off_scoef = o; o += ni;
   w->off_hist = o; o += radix_sort_hist_bytes();
-  w->off_temp = o; o += align_up(temp, 256);
-  w->temp_bytes = temp;
   w->total = o;
   return ARX_OK;
 }
@@ -971,7 +900,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
     rc = launch_rank_sort(keys_buf, n, sentinel, keys_out, pos_out, count, s, src_buf, coef_buf,
                           ssrc, scoef);
     if (rc) return rc;
-  } else if (!use_rocprim_sort()) {   // own LSD radix sort: src/coef come out in sorted order too
+  } else {   // own LSD radix sort: src/coef come out in sorted order too
     rc = launch_radix_sort(keys_buf, src_buf, coef_buf, n, sentinel, key_bits + 1,
                            reinterpret_cast<uint32_t*>(base + w.off_keys_tmp), keys_out,
                            reinterpret_cast<int32_t*>(base + w.off_pos_in), ssrc,
@@ -979,22 +908,6 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
                            reinterpret_cast<int32_t*>(base + w.off_hist), count, count + 2, s);
     if (rc) return rc;
     n_dev = count + 2;
-  } else {   // rocPRIM merge sort (A/B aid); the apply pass follows the position indirection
-    uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(base + w.off_keys_tmp);
-    uint32_t* pos_in = reinterpret_cast<uint32_t*>(base + w.off_pos_in);
-    int64_t g = ceil_div(n, 256);
-    int64_t cap = (int64_t)cu_count() * 8;
-    if (g > cap) g = cap;
-    k_prep_keys<<<(int)g, 256, 0, s>>>(keys_buf, n, sentinel, keys_tmp, pos_in, count);
-    ARX_CHECK_LAUNCH();
-    size_t temp_bytes = w.temp_bytes;
-    ARX_CHECK_HIP((rocprim::radix_sort_pairs<RsConfig, const uint32_t*, uint32_t*,
-                                             const uint32_t*, uint32_t*>(
-        base + w.off_temp, temp_bytes, keys_tmp, keys_out, pos_in, pos_out, (unsigned int)n, 0,
-        key_bits + 1, s, false)));
-    spos_arg = pos_out;
-    src_arg = src_buf;
-    coef_arg = coef_buf;
   }
   bool any_bias = false;
   for (int t = 0; t < ntables; ++t) any_bias = any_bias || ts.bias[t] != nullptr;
@@ -1040,7 +953,7 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
   if (n == 0) return ARX_OK;
   SparseWs w;
   int rc = sparse_ws_layout(n, 256, &w);
-  if (rc) { set_error("arx_sparse_adagrad: rocprim temp-size query failed"); return rc; }
+  if (rc) { set_error("arx_sparse_adagrad: workspace layout failed"); return rc; }
   if (!workspace || workspace_bytes < w.total) {
     set_error("arx_sparse_adagrad: workspace too small (%zu < %zu)", workspace_bytes, w.total);
     return ARX_EWORKSPACE;
@@ -1057,26 +970,14 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
   int32_t* count = reinterpret_cast<int32_t*>(base + w.off_count);
   float* scratch = reinterpret_cast<float*>(base + w.off_scratch);
   float* scratch_b = reinterpret_cast<float*>(base + w.off_scratch_b);
-  void* temp = base + w.off_temp;
   const uint32_t* spos_arg = pos_out;
   const int32_t* n_dev = nullptr;      // live-entry count of the radix sort (pads dropped)
   if (n <= kRankSortMax) {
     // id-only batches (B + S keys): one workgroup sorts everything in LDS -- a
     // single launch instead of the 5-6 of the device-wide radix sort.
-    static const bool use_block_sort = getenv("ARX_BLOCK_SORT") != nullptr;   // A/B aid
-    if (!use_block_sort) {
-      rc = launch_rank_sort(keys, n, sentinel, keys_out, pos_out, count, s);
-      if (rc) return rc;
-    } else {
-      if (n <= 4096)
-        k_small_sort<4><<<1, 1024, 0, s>>>(keys, n, sentinel, key_bits, keys_out, pos_out, count);
-      else if (n <= 8192)
-        k_small_sort<8><<<1, 1024, 0, s>>>(keys, n, sentinel, key_bits, keys_out, pos_out, count);
-      else
-        k_small_sort<16><<<1, 1024, 0, s>>>(keys, n, sentinel, key_bits, keys_out, pos_out, count);
-      ARX_CHECK_LAUNCH();
-    }
-  } else if (!use_rocprim_sort()) {
+    rc = launch_rank_sort(keys, n, sentinel, keys_out, pos_out, count, s);
+    if (rc) return rc;
+  } else {
     // own LSD radix sort; src/coef are emitted in sorted order (one hop less per contribution)
     int32_t* ssrc = reinterpret_cast<int32_t*>(base + w.off_ssrc);
     float* scoef = reinterpret_cast<float*>(base + w.off_scoef);
@@ -1089,17 +990,6 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
     spos_arg = nullptr;
     src = ssrc;
     coef = scoef;
-  } else {   // rocPRIM merge sort (A/B aid)
-    int64_t g = ceil_div(n, 256);
-    int64_t cap = (int64_t)cu_count() * 8;
-    if (g > cap) g = cap;
-    k_prep_keys<<<(int)g, 256, 0, s>>>(keys, n, sentinel, keys_tmp, pos_in, count);
-    ARX_CHECK_LAUNCH();
-    size_t temp_bytes = w.temp_bytes;
-    ARX_CHECK_HIP((rocprim::radix_sort_pairs<RsConfig, const uint32_t*, uint32_t*,
-                                             const uint32_t*, uint32_t*>(
-        temp, temp_bytes, keys_tmp, keys_out, pos_in, pos_out, (unsigned int)n, 0, key_bits + 1,
-        s, false)));
   }
   const float* gb_in = bias ? Gb : nullptr;
   TableSet ts = {};
@@ -1113,7 +1003,7 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
                       gscale_dev, scratch, scratch_b,
                       reinterpret_cast<float*>(base + w.off_scratch_h),
                       reinterpret_cast<float*>(base + w.off_scratch_hb), list, count,
-                      /*short_runs=*/n <= (1 << 19)   /* 8 waves per window measured faster up to ~0.5 M contributions (mulhot100k 92 -> 73 us), slower at 1.3 M */, /*multi=*/false, n_dev, s);
+                      /*short_runs=*/n <= (1 << 21)   /* 8 waves per window measured faster up to ~0.5 M LIVE contributions (mulhot100k 92 -> 73 us), slower at 1.3 M; n is the padded capacity (~3x the live count for multi-hot sites) */, /*multi=*/false, n_dev, s);
 }
 
 int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const float* lr_dev,
