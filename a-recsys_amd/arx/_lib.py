@@ -61,6 +61,8 @@ PROTOTYPES = {
                                       i64, f32p, f32p, i64, f32p, vp]),
     "arx_loss_warp_fwdbwd_pos": (cint, [f32p, i64, i32p, i32p, i32p, i32p, i32p, i64, f32, f32p,
                                         i64, i64, f32p, f32p, i64, vp]),
+    "arx_sample_wor_workspace_bytes": (sz, [i64]),
+    "arx_sample_wor": (cint, [f32p, i64, i64, u64, u64, i32p, vp, sz, vp]),
     "arx_loss_rs_fwdbwd": (cint, [f32p, i64, i32p, u8p, i64, i32p, i32p, i32p, i32p, i64, cint, cint,
                                   f32, f32, f32p, i64, i64, f32p, f32p, i64, vp]),
     "arx_loss_ce_fwdbwd": (cint, [f32p, i64, i32p, f32, f32p, i64, i64, f32p, f32p, i64, vp]),
@@ -132,7 +134,8 @@ lib = _load()
 
 _NO_CHECK = ("arx_last_error", "arx_version", "arx_csr_expand_workspace_bytes",
              "arx_col_sum_workspace_bytes",
-             "arx_gemm_f32_workspace_bytes", "arx_sparse_adagrad_workspace_bytes")
+             "arx_gemm_f32_workspace_bytes", "arx_sparse_adagrad_workspace_bytes",
+             "arx_sample_wor_workspace_bytes")
 
 
 def call(name, *args):

@@ -222,6 +222,15 @@ def loss_warp_pos(logits, target, user_ids, pos_ptr, pos_items, item2slot, batch
          _p(batch_loss), _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _stream())
 
 
+def sample_wor(weights, S, seed, counter, out, ws):
+    """Weighted sampling without replacement on device (exponential race); out: int32 [S]."""
+    n = int(weights.shape[0])
+    wsp, wsn = ws.get(_lib.lib.arx_sample_wor_workspace_bytes(n))
+    call("arx_sample_wor", _p(weights), n, int(S), int(seed) & (2 ** 64 - 1),
+         int(counter) & (2 ** 64 - 1), _p(out), wsp, wsn, _stream())
+    return out
+
+
 RS_KINDS = {'rs': 0, 'rs-sig': 1, 'rs-sig2': 2, 'bbpr': 3}
 RS_FUNCS = {'log': 0, 'exp': 1, 'poly': 2, 'poly2': 3, 'linear': 4, 'square': 5}
 

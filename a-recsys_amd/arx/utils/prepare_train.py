@@ -43,3 +43,35 @@ def positive_items(data_tr, data_va):
     for rec in data_va:
         hist_va.setdefault(rec[0], set()).add(rec[1])
     return ({u: list(s) for u, s in hist.items()}, {u: list(s) for u, s in hist_va.items()})
+
+
+class DeviceSampler(object):
+    """On-device twin of sample_items(items, n, p, replace=False) for large item sets
+    (SURVEY 8f #1): same distribution (sequential weighted draws without replacement), drawn as
+    an exponential race by arx_sample_wor -- not numpy's random stream.  `items` are the global
+    item ids the positions of `p` refer to (item_frequency's item_population)."""
+
+    def __init__(self, items, p, device=None, seed=0):
+        import torch
+        from .. import ops
+        self._ops = ops
+        dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self.items = torch.as_tensor(np.asarray(items, dtype=np.int32)).to(dev)
+        pw = np.ones(len(items), dtype=np.float32) if p is None or not len(p) else np.asarray(p, dtype=np.float32)
+        self.w = torch.from_numpy(np.ascontiguousarray(pw)).to(dev)
+        self.ws = ops.Workspace(dev)
+        self.seed = int(seed)
+        self.counter = 0
+
+    def sample(self, n, out=None):
+        """-> int32 device tensor [n] of item ids (draw order).  The id->slot map the reference
+        builds next (prepare_train.py:12-16) is the model's device slot map (update_sampled_pool)."""
+        import torch
+        pos = torch.empty((n,), dtype=torch.int32, device=self.w.device)
+        self._ops.sample_wor(self.w, n, self.seed, self.counter, pos, self.ws)
+        self.counter += 1
+        ids = self.items[pos.long()]
+        if out is not None:
+            out.copy_(ids)
+            return out
+        return ids

@@ -204,8 +204,10 @@ def main():
     dev = model.rt.device
     total = args.steps + args.warmup
     rng = np.random.default_rng(1)
-    n_pools = total // args.n_resample + 2
-    pools = [torch.from_numpy(syn.sample_pool(S, rng)).to(dev) for _ in range(n_pools)]
+    # the shared negative pool is redrawn every n_resample steps ON DEVICE, inside the timed
+    # region (prepare_train.py:7-17 sample_items with p ~ count^0.5 -> arx_sample_wor)
+    from arx.utils.prepare_train import DeviceSampler
+    sampler = DeviceSampler(syn.item_population, syn.p_sample, device=dev, seed=1)
     nb = min(total, 64)      # device-resident ring of distinct batches
     batches = []
     for _ in range(nb):
@@ -216,7 +218,7 @@ def main():
 
     def run(k0, k1):
         for k in range(k0, k1):
-            pool = pools[k // args.n_resample] if k % args.n_resample == 0 else None
+            pool = sampler.sample(S) if k % args.n_resample == 0 else None
             u, i = batches[k % nb]
             model.step_async(None, u, i, None, pool, None, loss='mw')
 
@@ -269,7 +271,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "C2: synthetic %d-item/%d-user HMF, dim %d, id-only%s, WMRB 'mw' loss, "
-                               "%d shared negatives/step (pool redrawn every %d steps), Adagrad, "
+                               "%d shared negatives/step (pool redrawn on device every %d steps), Adagrad, "
                                "B=%d interactions/step" % (args.n_items, args.n_users, d,
                                                            " + multi-hot item attribute (C3)" if args.mulhot else "",
                                                            S, args.n_resample, B),

@@ -165,6 +165,17 @@ int arx_loss_warp_fwdbwd(const float* logits, int64_t ldl, const int32_t* target
                          const float* row_w,
                          int64_t B, int64_t V, float* batch_loss, float* dlogits, int64_t lddl,
                          void* stream);
+/* Negative-pool sampler on device (replaces utils/prepare_train.py:7-17
+ * np.random.choice(items, S, replace=False, p)): weighted sampling without replacement as an
+ * exponential race -- key_i = -ln(u_i)/w_i, the S smallest keys in ascending order have the law
+ * of S sequential weighted draws without replacement.  weights [n] need not be normalised;
+ * entries <= 0 are never drawn.  out_idx [S]: item positions in draw order (-1 if fewer than S
+ * positive weights).  Deterministic in (seed, counter); NOT numpy's random stream.
+ * workspace >= arx_sample_wor_workspace_bytes(n). */
+size_t arx_sample_wor_workspace_bytes(int64_t n);
+int arx_sample_wor(const float* weights, int64_t n, int64_t S, uint64_t seed, uint64_t counter,
+                   int32_t* out_idx, void* workspace, size_t workspace_bytes, void* stream);
+
 /* rs / rs-sig / rs-sig2 / bbpr losses (embed_attribute.py:551-603 _compute_rs_loss) over full
  * logits [B, V], forward + backward fused.  kind: 0 rs, 1 rs-sig, 2 rs-sig2, 3 bbpr;
  * loss_func (hmf_model.py loss_func): 0 log, 1 exp, 2 poly, 3 poly2, 4 linear, 5 square, with

@@ -1,0 +1,104 @@
+"""On-device negative-pool sampler (arx_sample_wor / DeviceSampler) against the distribution of
+the reference's host call  np.random.choice(items, S, replace=False, p)  (utils/prepare_train.py:7-17):
+same law (sequential weighted draws without replacement), different random stream."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(dev, a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_sample_wor_basic_properties(dev):
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(0)
+    n, S = 100000, 1024
+    w = rng.random(n).astype(np.float32) ** 3
+    w[rng.choice(n, size=n // 4, replace=False)] = 0.0           # never drawn
+    ws = ops.Workspace(dev)
+    out = torch.empty(S, dtype=torch.int32, device=dev)
+    ops.sample_wor(_t(dev, w), S, seed=7, counter=3, out=out, ws=ws)
+    a = out.cpu().numpy()
+    assert a.min() >= 0 and a.max() < n
+    assert len(np.unique(a)) == S                                 # without replacement
+    assert np.all(w[a] > 0)
+    out2 = torch.empty(S, dtype=torch.int32, device=dev)
+    ops.sample_wor(_t(dev, w), S, seed=7, counter=3, out=out2, ws=ws)
+    assert torch.equal(out, out2)                                 # deterministic in (seed, counter)
+    ops.sample_wor(_t(dev, w), S, seed=7, counter=4, out=out2, ws=ws)
+    assert not torch.equal(out, out2)
+    # heavier items are drawn far more often than light ones
+    assert w[a].mean() > 2.0 * w[w > 0].mean()
+    # fewer positive weights than S -> the tail is -1
+    w2 = np.zeros(50, dtype=np.float32)
+    w2[:7] = 1.0
+    o3 = torch.empty(10, dtype=torch.int32, device=dev)
+    ops.sample_wor(_t(dev, w2), 10, seed=1, counter=0, out=o3, ws=ws)
+    b = o3.cpu().numpy()
+    assert sorted(b[:7].tolist()) == list(range(7)) and np.all(b[7:] == -1)
+
+
+def test_sample_wor_matches_numpy_choice_distribution(dev):
+    """Inclusion frequencies and first-draw marginals over many draws vs numpy's sequential
+    sampler (the reference's host call) on a small skewed item set."""
+    from arx import ops
+    import torch
+    n, S, draws = 40, 6, 6000
+    p = (1.0 / np.arange(1, n + 1) ** 1.1)
+    p = (p / p.sum()).astype(np.float64)
+    rs = np.random.RandomState(123)
+    ref_incl = np.zeros(n)
+    ref_first = np.zeros(n)
+    for _ in range(draws):
+        s = rs.choice(n, S, replace=False, p=p)
+        ref_incl[s] += 1
+        ref_first[s[0]] += 1
+    w = _t(dev, p.astype(np.float32))
+    ws = ops.Workspace(dev)
+    outs = torch.empty((draws, S), dtype=torch.int32, device=dev)
+    for k in range(draws):
+        ops.sample_wor(w, S, seed=99, counter=k, out=outs[k], ws=ws)
+    got = outs.cpu().numpy()
+    got_incl = np.bincount(got.reshape(-1), minlength=n).astype(float)
+    got_first = np.bincount(got[:, 0], minlength=n).astype(float)
+    # first draw is exactly ~ p
+    exp_first = p * draws
+    z = (got_first - exp_first) / np.sqrt(exp_first * (1 - p) + 1e-9)
+    assert np.abs(z).max() < 4.5, z
+    # inclusion counts: two independent Monte-Carlo estimates of the same probabilities
+    pi = (ref_incl + got_incl) / (2.0 * draws)
+    sd = np.sqrt(2.0 * draws * pi * (1 - pi) + 1e-9)
+    z2 = (got_incl - ref_incl) / sd
+    assert np.abs(z2).max() < 4.5, z2
+    assert abs(got_incl.sum() - draws * S) < 1e-6
+
+
+def test_device_sampler_feeds_model_pool(dev):
+    """DeviceSampler -> LatentProductModel.step(item_sampled=<device tensor>): the pool never
+    touches the host."""
+    from arx.utils.prepare_train import DeviceSampler
+    from arx.utils.synthetic import SyntheticHMF
+    from arx.hmf.hmf_model import LatentProductModel
+    syn = SyntheticHMF(n_users=300, n_items=400, logit_size=400, seed=2)
+    S, B, d = 64, 32, 32
+    model = LatentProductModel(syn.n_users, syn.n_items, d, 1, B, 0.3, 1.0, syn.u_attr, syn.i_attr,
+                               syn.item_ind2logit_ind_dict(), syn.logit_ind2item_ind,
+                               loss_function='mw', n_sampled=S)
+    pos = syn.positives_dict()
+    model.prepare_warp(pos, pos)
+    counts = np.bincount(syn.pos_items, minlength=syn.n_items).astype(np.float64) + 1.0
+    pw = (counts / counts.sum()) ** 0.5
+    sampler = DeviceSampler(np.arange(syn.n_items), pw / pw.sum(), device=dev, seed=5)
+    rng = np.random.default_rng(1)
+    losses = []
+    for step in range(6):
+        users, items = syn.sample_batch(B, rng)
+        pool = sampler.sample(S) if step % 2 == 0 else None
+        losses.append(model.step(None, list(users), list(items), None, pool, None, loss='mw'))
+    assert np.all(np.isfinite(losses))
+    p = sampler.sample(S).cpu().numpy()
+    assert len(np.unique(p)) == S and p.min() >= 0 and p.max() < syn.n_items
