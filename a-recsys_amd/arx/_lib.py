@@ -66,6 +66,7 @@ PROTOTYPES = {
     "arx_loss_rs_fwdbwd": (cint, [f32p, i64, i32p, u8p, i64, i32p, i32p, i32p, i32p, i64, cint, cint,
                                   f32, f32, f32p, i64, i64, f32p, f32p, i64, vp]),
     "arx_loss_ce_fwdbwd": (cint, [f32p, i64, i32p, f32, f32p, i64, i64, f32p, f32p, i64, vp]),
+    "arx_row_logsumexp": (cint, [f32p, i64, i64, i64, f32p, vp]),
     "arx_loss_warp_eval": (cint, [f32p, i64, i32p, u8p, i64, i64, i64, i64, f32p, i32p, vp]),
     "arx_sparse_adagrad_workspace_bytes": (sz, [i64]),
     "arx_sparse_adagrad": (cint, [f32p, f32p, f32p, f32p, cint, i32p, i32p, f32p, i64, f32p, i64,

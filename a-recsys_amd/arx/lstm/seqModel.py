@@ -173,6 +173,23 @@ class SeqLoss(G.Node):
         return self.value
 
 
+class TopKSoftmax(G.Node):
+    """seqModel.py:514-517  tf.nn.top_k(tf.nn.softmax(full_logits), topk_n, sorted=True) for every
+    time-major row: top-k of the logits (same order as the softmax) + the row logsumexp;
+    the softmax values of the k winners are exp(v - lse)."""
+
+    def __init__(self, rt, logits, k):
+        super().__init__(rt, (logits.shape[0], k), (logits,))
+        self.k = k
+        self.indices = torch.empty((logits.shape[0], k), dtype=torch.int32, device=rt.device)
+        self.lse = torch.empty((logits.shape[0],), dtype=torch.float32, device=rt.device)
+
+    def forward(self, train):
+        x = self.inputs[0].value
+        ops.topk(x, self.k, self.alloc_value(), self.indices)
+        ops.row_logsumexp(x, self.lse)
+
+
 class SeqModel(object):
     def __init__(self, buckets, size, num_layers, max_gradient_norm, batch_size, learning_rate,
                  learning_rate_decay_factor, embeddingAttribute, withAdagrad=True, num_samples=512,
@@ -290,6 +307,8 @@ class SeqModel(object):
             bk['eval'] = SeqLoss(rt, bl_full, wn2)
         else:
             bk['eval'] = bk['train']
+            full = logits
+        bk['recommend'] = TopKSoftmax(rt, full, min(self.topk_n, full.shape[1]))      # :514-517
         bk['plans'] = {}
         self._bk[bucket_id] = bk
         return bk
@@ -301,6 +320,8 @@ class SeqModel(object):
             if key == 'train':
                 masks = [m.mask[self.loss]] if self.loss in m.mask else []
                 bk['plans'][key] = G.Plan(self.rt, [bk['train']], True, masks)
+            elif key == 'recommend':
+                bk['plans'][key] = G.Plan(self.rt, [bk['recommend']], False, [])
             else:
                 l = 'warp' if self.loss == 'mw' else self.loss
                 masks = [m.mask[l]] if l in m.mask else []
@@ -439,8 +460,27 @@ class SeqModel(object):
         return float(node.read().item())
 
     def step_recommend(self, session, user_input, item_inputs, positions, bucket_id):
-        raise NotImplementedError("step_recommend: planned with the streaming full-vocabulary "
-                                  "scorer + top-k (SURVEY 8f #3)")
+        """seqModel.py:326-353 -> [(uid, values[topk_n], indexes[topk_n])]: the top-k softmax
+        values / logit indexes at time position positions[i] of sequence i.  The full
+        [L*mb, V] logits are materialised (the streaming scorer + running top-k is SURVEY 8f #3)."""
+        L = self.buckets[bucket_id]
+        m, B = self.att_emb, self.batch_size
+        it = item_inputs
+        if not isinstance(it, torch.Tensor):
+            it = torch.from_numpy(np.ascontiguousarray(np.asarray(it, dtype=np.int32)[:L].reshape(-1)))
+        m.input_all.value[:L * B].copy_(it.reshape(-1), non_blocking=True)
+        m.add_input({}, user_input, None, forward_only=True, recommend=True, loss=self.loss)
+        self._plan(bucket_id, 'recommend').run()
+        node = self._bucket(bucket_id)['recommend']
+        vals = node.value.cpu().numpy()
+        idx = node.indices.cpu().numpy()
+        lse = node.lse.cpu().numpy()
+        users = user_input.cpu().numpy() if isinstance(user_input, torch.Tensor) else user_input
+        results = []
+        for i, pos in enumerate(positions):
+            r = int(pos) * B + i
+            results.append((users[i], np.exp(vals[r] - lse[r]), idx[r]))
+        return results
 
     # ---------------------------------------------------- get_batch (:356-404)
     def get_batch(self, data_set, bucket_id, start_id=None):

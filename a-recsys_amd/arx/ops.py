@@ -247,6 +247,12 @@ def loss_rs(logits, target, kind, loss_func, exp_p, batch_loss, dlogits, gscale,
          _p(batch_loss), _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _stream())
 
 
+def row_logsumexp(logits, out):
+    call("arx_row_logsumexp", _p(logits), _ld(logits), int(logits.shape[0]), int(logits.shape[1]),
+         _p(out), _stream())
+    return out
+
+
 def loss_ce(logits, target, batch_loss, dlogits, gscale, row_w=None):
     B, V = int(logits.shape[0]), int(logits.shape[1])
     call("arx_loss_ce_fwdbwd", _p(logits), _ld(logits), _p(target), float(gscale), _p(row_w), B, V,

@@ -353,6 +353,21 @@ __global__ __launch_bounds__(256) void k_loss_ce(
   }
 }
 
+// per-row logsumexp (softmax normaliser of the recommend path, seqModel.py:514-517)
+__global__ __launch_bounds__(256) void k_row_lse(const float* __restrict__ logits, int64_t ldl,
+                                                 int64_t V, float* __restrict__ out) {
+  __shared__ float sh[4];
+  const int64_t r = blockIdx.x;
+  const float* x = logits + r * ldl;
+  float mx = -INFINITY;
+  for (int64_t c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, x[c]);
+  mx = block_max(mx, sh);
+  float se = 0.f;
+  for (int64_t c = threadIdx.x; c < V; c += 256) se += expf(x[c] - mx);
+  se = block_sum(se, sh);
+  if (threadIdx.x == 0) out[r] = logf(se) + mx;
+}
+
 __global__ __launch_bounds__(256) void k_warp_eval(
     const float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ target,
     const uint8_t* __restrict__ mask, int64_t ldm, int64_t mask_rows, int64_t V,
@@ -587,6 +602,15 @@ int arx_loss_ce_fwdbwd(const float* logits, int64_t ldl, const int32_t* target, 
   if (B == 0) return ARX_OK;
   k_loss_ce<<<(int)B, 256, 0, as_stream(stream)>>>(logits, ldl, target, gscale, row_w, V,
                                                    batch_loss, dlogits, lddl);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_row_logsumexp(const float* logits, int64_t ldl, int64_t B, int64_t V, float* out,
+                      void* stream) {
+  ARX_CHECK_ARG(logits && out && V > 0 && B >= 0, "arx_row_logsumexp: bad argument");
+  if (B == 0) return ARX_OK;
+  k_row_lse<<<(int)B, 256, 0, as_stream(stream)>>>(logits, ldl, V, out);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

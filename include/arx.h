@@ -209,6 +209,12 @@ int arx_loss_warp_fwdbwd_pos(const float* logits, int64_t ldl, const int32_t* ta
 int arx_loss_ce_fwdbwd(const float* logits, int64_t ldl, const int32_t* target, float gscale,
                        const float* row_w, int64_t B, int64_t V, float* batch_loss,
                        float* dlogits, int64_t lddl, void* stream);
+/* out[r] = log(sum_c exp(logits[r, c])): the softmax normaliser of the recommend path
+ * (seqModel.py:514-517 top_k(softmax(full_logits))): top-k of the logits + this gives the
+ * softmax values of the top-k without materialising the softmax. */
+int arx_row_logsumexp(const float* logits, int64_t ldl, int64_t B, int64_t V, float* out,
+                      void* stream);
+
 /* embed_attribute.py:620-639 warp_eval -> margin_rank[B] (float), true_rank[B] (int32) */
 int arx_loss_warp_eval(const float* logits, int64_t ldl, const int32_t* target,
                        const uint8_t* mask, int64_t ldm, int64_t mask_rows, int64_t B, int64_t V,

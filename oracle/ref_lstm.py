@@ -98,6 +98,29 @@ class RefSeqModel(object):
         embAttr.slots['lstm_b'] = np.full(self.b.shape, 0.1, dt)
         self.last = {}
 
+    def step_recommend(self, user_input, item_inputs, positions, topk_n=30):
+        """seqModel.py:326-353 + :514-517: per position top_k(softmax(full logits), topk_n,
+        sorted=True) -> [(uid, values[topk_n], indexes[topk_n])] for position positions[i] of
+        sequence i (ties: lower index first, like tf.nn.top_k)."""
+        m, L = self.m, self.L
+        u, _ = m.get_batch_user(user_input, concat=False, no_id=self.no_user_id)
+        xs = []
+        for t in range(L):
+            feats, _, _ = m.get_batch_item(item_inputs[t], concat=False,
+                                           no_attribute=self.no_input_item_feature)
+            it = np.mean(np.stack(feats, 0), 0)
+            xs.append(np.mean(np.stack([u, it], 0), 0))
+        hs, _, _ = lstm_fwd(np.stack(xs, 0), self.W, self.b, 1.0)
+        results = []
+        for i, pos in enumerate(positions):
+            logits, _ = m.get_prediction(hs[pos], 'full', self.output_feat)
+            x = logits[i]
+            pr = np.exp(x - x.max())
+            pr = pr / pr.sum()
+            idx = np.argsort(-pr, kind='stable')[:topk_n]
+            results.append((user_input[i], pr[idx], idx.astype(np.int32)))
+        return results
+
     def step(self, user_input, item_inputs, targets, target_weights, item_sampled=None,
              item_sampled_id2idx=None, forward_only=False):
         """seqModel.py:289-324; inputs are time-major python lists [L][B]."""

@@ -120,3 +120,30 @@ def test_seq_no_user_id_and_mw_eval(dev):
     e_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), forward_only=True)
     e_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, forward_only=True)
     np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
+
+
+@pytest.mark.parametrize("loss,S", [('ce', None), ('mw', 64)])
+def test_seq_step_recommend(dev, loss, S):
+    """seqModel.py:326-353,514-517: top_k(softmax(full logits)) at one position per sequence,
+    indexes exact, softmax values to rtol 1e-4, after a training step (tables have moved)."""
+    syn, emb, model, remb, ref = _build(CFG_ID, loss, 64, 16, 4, S, 5.0, seed=11)
+    model.topk_n = 7
+    rng = np.random.default_rng(2)
+    users, inp, tg, w = _batch(syn, rng, 4, 16)
+    if loss == 'mw':
+        pool = syn.sample_pool(S, rng)
+        id2idx = {int(v): i for i, v in enumerate(pool)}
+        ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), pool, id2idx)
+        model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, pool, id2idx)
+    else:
+        ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist())
+        model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0)
+    users, inp, tg, w = _batch(syn, rng, 4, 16)
+    positions = rng.integers(0, 4, size=16).tolist()
+    r_ref = ref.step_recommend(list(users), inp.tolist(), positions, topk_n=7)
+    r_got = model.step_recommend(None, list(users), inp.tolist(), positions, 0)
+    assert len(r_got) == len(r_ref) == 16
+    for (u0, v0, i0), (u1, v1, i1) in zip(r_got, r_ref):
+        assert int(u0) == int(u1)
+        np.testing.assert_array_equal(np.asarray(i0), i1)
+        np.testing.assert_allclose(v0, v1, rtol=RTOL, atol=1e-9)
