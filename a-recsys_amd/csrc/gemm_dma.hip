@@ -130,9 +130,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
 
   auto tile = [&](int64_t t, const float* cA, const float* cB, float* nA, float* nB) {
     if (t + PD < nt) dma(t + PD, nA, nB);
-#pragma unroll
-    for (int s = 0; s < kBK / 8; ++s) {
-      float av[FM][4], bv[FN][4];
+    // operands of step s+1 are read from LDS before the MFMAs of step s issue (pinned with
+    // sched_barrier: hipcc otherwise sinks the reads to just in front of their use and the wave
+    // sits in s_waitcnt lgkmcnt for an LDS round trip per step -- PMC SQ_WAIT_ANY 27-37%)
+    auto load_ops = [&](int s, float (&av)[FM][4], float (&bv)[FN][4]) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         const int r = wm * (BM / 2) + i * 32 + l31;
@@ -145,15 +146,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
           for (int j = 0; j < 4; ++j) av[i][j] = cA[(8 * s + 4 * lhi + j) * BM + r];
         }
       }
-      if (want_rs) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i) rsl[i] += (av[i][0] + av[i][1]) + (av[i][2] + av[i][3]);
-      }
 #pragma unroll
       for (int jn = 0; jn < FN; ++jn)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           bv[jn][j] = cB[(8 * s + 4 * lhi + j) * kBN + wn * (kBN / 2) + jn * 32 + l31];
+    };
+    float av[FM][4], bv[FN][4];
+    load_ops(0, av, bv);
+#pragma unroll
+    for (int s = 0; s < kBK / 8; ++s) {
+      float nav[FM][4], nbv[FN][4];
+      if (s + 1 < kBK / 8) load_ops(s + 1, nav, nbv);
+      __builtin_amdgcn_sched_barrier(0);
+      if (want_rs) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) rsl[i] += (av[i][0] + av[i][1]) + (av[i][2] + av[i][3]);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -161,6 +170,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
 #pragma unroll
           for (int jn = 0; jn < FN; ++jn)
             acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j], bv[jn][j], acc[i][jn], 0, 0, 0);
+      if (s + 1 < kBK / 8) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) av[i][j] = nav[i][j];
+#pragma unroll
+        for (int jn = 0; jn < FN; ++jn)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bv[jn][j] = nbv[jn][j];
+      }
     }
     // this wave's pieces of tile t+1 have landed once at most the NP pieces of tile t+2 are
     // outstanding (vmcnt retires in order); the barrier then covers every wave's pieces and

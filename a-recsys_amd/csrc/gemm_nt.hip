@@ -130,11 +130,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
     }
     const float* b0p = cur_img + l31 * KT;
     const float* b1p = b0p + 32 * KT;
+    // operands of step s+1 are fetched from LDS before the 8 MFMAs of step s issue (an LDS
+    // round trip is ~128 cycles; issued right in front of their use they stalled ~20% of the
+    // wave's cycles in s_waitcnt lgkmcnt -- PMC SQ_WAIT_ANY)
+    float4 b0 = *reinterpret_cast<const float4*>(b0p + ((lhi ^ sw) * 4));
+    float4 b1 = *reinterpret_cast<const float4*>(b1p + ((lhi ^ sw) * 4));
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const int off = ((2 * s + lhi) ^ sw) * 4;
-      const float4 b0 = *reinterpret_cast<const float4*>(b0p + off);
-      const float4 b1 = *reinterpret_cast<const float4*>(b1p + off);
+      float4 n0 = b0, n1 = b1;
+      if (s + 1 < NS) {
+        const int off = ((2 * (s + 1) + lhi) ^ sw) * 4;
+        n0 = *reinterpret_cast<const float4*>(b0p + off);
+        n1 = *reinterpret_cast<const float4*>(b1p + off);
+      }
+      __builtin_amdgcn_sched_barrier(0);      // keep the fetch ahead of this step's MFMAs (hipcc sinks it otherwise)
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].x, b0.x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].x, b1.x, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].y, b0.y, acc0, 0, 0, 0);
@@ -143,6 +152,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].z, b1.z, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].w, b0.w, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].w, b1.w, acc1, 0, 0, 0);
+      b0 = n0;
+      b1 = n1;
     }
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
     const int64_t n0 = t * kNtBN;
