@@ -101,6 +101,8 @@ PROTOTYPES = {
     "arx_act_bwd": (cint, [f32p, f32p, i64, cint, f32p, vp]),
     "arx_add_col_bias": (cint, [f32p, i64, i64, i64, f32p, vp]),
     "arx_topk": (cint, [f32p, i64, i64, i64, cint, f32p, i32p, vp]),
+    "arx_topk_chunk": (cint, [f32p, i64, i64, i64, cint, i32, f32p, i32p, vp]),
+    "arx_topk_merge": (cint, [f32p, i32p, f32p, i32p, i64, cint, cint, cint, f32p, i32p, vp]),
     "arx_lstm_fwd": (cint, [f32p, f32p, f32p, i64, i64, cint, cint, f32, f32p, f32p, f32p, vp]),
     "arx_lstm_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, i64, i64, cint, cint, f32p, vp]),
     "arx_seq_weights": (cint, [f32p, i64, i64, f32p, vp]),

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import random
 
+import os
+
 import numpy as np
 import torch
 
@@ -93,6 +95,48 @@ class TopK(G.Node):
 
     def forward(self, train):
         ops.topk(self.inputs[0].value, self.k, self.alloc_value(), self.indices)
+
+
+class StreamTopK(G.Node):
+    """top_k over the FULL vocabulary without the [mb, V] logits: the scorer GEMM
+    runs over chunks of the pool rows, every chunk keeps its k best per row (radix select) and a
+    merge folds them into the running result -- same indices/values as TopK(Prediction)."""
+
+    def __init__(self, rt, latent, pool, k, chunk=65536):
+        super().__init__(rt, (latent.shape[0], k), (latent, pool))
+        self.k, self.chunk = k, max(int(chunk), k)
+        B, V, dev = latent.shape[0], pool.shape[0], rt.device
+        f32, i32 = torch.float32, torch.int32
+        self.indices = torch.empty((B, k), dtype=i32, device=dev)
+        self._buf = torch.empty((B, min(self.chunk, V)), dtype=f32, device=dev)
+        self._cv, self._ci = torch.empty((B, k), dtype=f32, device=dev), torch.empty((B, k), dtype=i32, device=dev)
+        self._ov, self._oi = torch.empty((B, k), dtype=f32, device=dev), torch.empty((B, k), dtype=i32, device=dev)
+        tail = V % self.chunk                       # a last chunk narrower than k keeps only `tail` entries
+        kt = tail if 0 < tail < k else k
+        self._tv, self._ti = torch.empty((B, kt), dtype=f32, device=dev), torch.empty((B, kt), dtype=i32, device=dev)
+
+    def forward(self, train):
+        latent, pool = self.inputs
+        V, k = pool.shape[0], self.k
+        run_v, run_i = self.alloc_value(), self.indices
+        out_v, out_i = self._ov, self._oi
+        for c0 in range(0, V, self.chunk):
+            c1 = min(V, c0 + self.chunk)
+            kc = min(k, c1 - c0)
+            lg = self._buf[:, :c1 - c0]
+            bias = pool.bias_value[c0:c1] if pool.bias_value is not None else None
+            ops.gemm(latent.value, pool.value[c0:c1], lg, self.rt.ws, transB=True, col_bias=bias)
+            if c0 == 0:                              # chunk >= k and V >= k: the first chunk fills all k
+                ops.topk_chunk(lg, k, 0, run_v, run_i)
+                continue
+            cv, ci = (self._cv, self._ci) if kc == k else (self._tv, self._ti)
+            ops.topk_chunk(lg, kc, c0, cv, ci)
+            ops.topk_merge(run_v, run_i, cv, ci, k, out_v, out_i)
+            run_v, out_v = out_v, run_v
+            run_i, out_i = out_i, run_i
+        if run_v.data_ptr() != self.value.data_ptr():
+            self.value.copy_(run_v)
+            self.indices.copy_(run_i)
 
 
 class LatentProductModel(object):
@@ -187,7 +231,13 @@ class LatentProductModel(object):
         self.loss = G.MeanLoss(rt, batch_loss)                                # :140
         self.loss.lazy = True
         self.loss_eval = G.MeanLoss(rt, batch_loss_eval) if loss == 'mw' else self.loss  # :144
-        self.topk = TopK(rt, logits, min(self.top_N_items, self.logit_size))  # :154
+        kk = min(self.top_N_items, self.logit_size)
+        stream_min = int(os.environ.get('ARX_STREAM_TOPK_BYTES', str(1 << 30)))
+        if batch_size * self.logit_size * 4 > stream_min and kk <= 1024:
+            # [mb, V] would not be worth materialising: chunked scorer + running top-k
+            self.topk = StreamTopK(rt, logits.inputs[0], logits.inputs[1], kk)
+        else:
+            self.topk = TopK(rt, logits, kk)                                     # :154
         self.indices = self.topk
         self.saver = Saver(self)
 

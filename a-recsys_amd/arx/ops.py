@@ -423,6 +423,16 @@ def act_bwd(y, dy, kind, dx):
     call("arx_act_bwd", _p(y), _p(dy), int(y.numel()), int(kind), _p(dx), _stream())
 
 
+def topk_chunk(logits, k, idx_base, values, indices):
+    call("arx_topk_chunk", _p(logits), _ld(logits), int(logits.shape[0]), int(logits.shape[1]), int(k),
+         int(idx_base), _p(values), _p(indices), _stream())
+
+
+def topk_merge(va, ia, vb, ib, k, vo, io):
+    call("arx_topk_merge", _p(va), _p(ia), _p(vb), _p(ib), int(va.shape[0]), int(va.shape[1]),
+         int(vb.shape[1]), int(k), _p(vo), _p(io), _stream())
+
+
 def topk(logits, k, values, indices):
     call("arx_topk", _p(logits), _ld(logits), int(logits.shape[0]), int(logits.shape[1]), int(k),
          _p(values), _p(indices), _stream())

@@ -114,6 +114,10 @@ int gemm_dma_launch(int transA, int64_t M, int64_t N, int64_t K, float alpha, co
                     const float* col_bias, float* partial, int bm, int splits, int64_t kchunk,
                     float* a_rowsum, float* rowsum_partial, hipStream_t s);
 
+// topk.hip: radix-select top-k of every row (k <= 1024); indices are offset by idx_base.
+int topk_select_launch(const float* logits, int64_t ld, int64_t B, int64_t V, int k, int32_t idx_base,
+                       float* values, int32_t* indices, hipStream_t s);
+
 // radix_sort.hip: graph-safe stable LSD sort of (key, src, coef) triples, n > 8192.
 // keys_raw: caller keys (ARX_KEY_NONE / out-of-range -> sentinel); src_raw/coef_raw may be
 // null (identity / 1.0).  *_tmp: ping-pong buffers of n entries; hist: radix_sort_hist_bytes().

@@ -109,6 +109,11 @@ int arx_topk(const float* logits, int64_t ld, int64_t B, int64_t V, int k, float
   ARX_CHECK_ARG(logits && indices, "arx_topk: null pointer");
   ARX_CHECK_ARG(k > 0 && k <= V, "arx_topk: need 0 < k <= V");
   if (B <= 0) return ARX_OK;
+  ARX_CHECK_ARG(k <= 1024, "arx_topk: k <= 1024");
+  // k passes over the row (k_topk) only pay for tiny problems; otherwise radix select (topk.hip):
+  // four passes whatever k is
+  if (values && k > 4 && V >= 2048)
+    return topk_select_launch(logits, ld, B, V, k, 0, values, indices, as_stream(stream));
   k_topk<<<(int)B, 256, 0, as_stream(stream)>>>(logits, ld, V, k, values, indices);
   ARX_CHECK_LAUNCH();
   return ARX_OK;

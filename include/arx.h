@@ -343,6 +343,15 @@ int arx_add_col_bias(float* y, int64_t ld, int64_t rows, int64_t cols, const flo
  * ties broken by lower index.  k <= 1024. */
 int arx_topk(const float* logits, int64_t ld, int64_t B, int64_t V, int k, float* values,
              int32_t* indices, void* stream);
+/* Streaming full-vocabulary recommend: the [B, V] logits are never materialised --
+ * the scorer GEMM runs over a chunk of the vocabulary, arx_topk_chunk keeps the chunk's k best
+ * per row (indices offset by idx_base = first column of the chunk), arx_topk_merge folds them
+ * into the running result (both lists sorted: descending value, ascending index; on equal
+ * values list A -- the earlier chunks, lower indices -- wins, which is tf.nn.top_k's tie rule). */
+int arx_topk_chunk(const float* logits, int64_t ld, int64_t B, int64_t V, int k, int32_t idx_base,
+                   float* values, int32_t* indices, void* stream);
+int arx_topk_merge(const float* va, const int32_t* ia, const float* vb, const int32_t* ib, int64_t B,
+                   int ka, int kb, int k, float* vo, int32_t* io, void* stream);
 
 /* ---- a19-a20: LSTM encoder (K9) ---------------------------------------------
  * lstm/seqModel.py:99-103,477 -- tf.contrib.rnn LSTMCell(h), no peepholes,

@@ -185,3 +185,23 @@ def test_checkpoint_roundtrip(dev, tmp_path):
         np.testing.assert_array_equal(before[k], after[k])
     l2b = model.step(None, list(users2), list(items2), None, None, id2idx, loss='mw')
     assert l2 == l2b     # deterministic kernels: same state + same batch -> same loss bits
+
+
+def test_recommend_streaming_topk_equals_materialised(dev, monkeypatch):
+    """chunked scorer + running top-k (StreamTopK) returns exactly the
+    recommendation of the materialised [mb, V] path (index-exact, same tie rule)."""
+    from arx.hmf import hmf_model as hm
+    cfg = dict(n_users=200, n_items=5000, logit_size=5000)
+    syn, model_a, ref = _build(cfg, 'ce', 32, 32, None, seed=4)
+    monkeypatch.setenv('ARX_STREAM_TOPK_BYTES', '0')             # force the streaming node
+    syn2, model_b, _ = _build(cfg, 'ce', 32, 32, None, seed=4)
+    assert isinstance(model_b.topk, hm.StreamTopK) and isinstance(model_a.topk, hm.TopK)
+    model_b.topk.chunk = 1536                                     # several chunks + a ragged tail
+    model_b.topk._buf = model_b.topk._buf[:, :1536].contiguous()
+    rng = np.random.default_rng(0)
+    users, items = syn.sample_batch(32, rng)
+    ra = model_a.step(None, list(users), list(items), recommend=True)
+    rb = model_b.step(None, list(users), list(items), recommend=True)
+    rr = ref.step(list(users), list(items), recommend=True)
+    np.testing.assert_array_equal(ra, rr)
+    np.testing.assert_array_equal(rb, rr)

@@ -412,6 +412,67 @@ def test_topk_matches_tf_order(dev):
     np.testing.assert_array_equal(vals.cpu().numpy(), np.take_along_axis(logits, ref, 1))
 
 
+@pytest.mark.parametrize("B,V,k", [(5, 100000, 100), (3, 4096, 1024), (7, 2048, 5), (2, 1000003, 30)])
+def test_topk_radix_select(dev, B, V, k):
+    """Radix-select top-k (topk.hip): index-exact against a stable argsort, with heavy ties
+    (quantised values, a constant row, negative values, +-0)."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(V + k)
+    logits = rng.standard_normal((B, V)).astype(np.float32)
+    logits[0] = np.round(logits[0] * 4) / 4               # many exact ties
+    if B > 1:
+        logits[1] = -1.5                                   # all equal: lowest k columns win
+    if B > 2:
+        logits[2, ::3] = 0.0
+        logits[2, 1::3] = -0.0
+    ref = np.argsort(-logits, axis=1, kind='stable')[:, :k]
+    vals = torch.empty((B, k), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, k), dtype=torch.int32, device=dev)
+    ops.topk(_t(dev, logits), k, vals, idx)
+    got = idx.cpu().numpy()
+    gv = vals.cpu().numpy()
+    # numpy's stable argsort treats -0.0 == 0.0; the kernel orders +0 above -0: compare values
+    # exactly and indices wherever the value is not a signed zero
+    np.testing.assert_array_equal(np.abs(gv), np.abs(np.take_along_axis(logits, ref, 1)))
+    nz = np.take_along_axis(logits, ref, 1) != 0
+    np.testing.assert_array_equal(got[nz], ref[nz])
+    for r in range(B):
+        assert len(np.unique(got[r])) == k
+
+
+def test_topk_streaming_chunks_equal_full(dev):
+    """Chunked top-k + merge (the streaming recommend path) == top-k of the full row."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(9)
+    B, V, k, Vc = 6, 50000, 64, 8192
+    logits = np.round(rng.standard_normal((B, V)) * 8).astype(np.float32) / 8     # ties across chunks
+    ref = np.argsort(-logits, axis=1, kind='stable')[:, :k]
+    tl = _t(dev, logits)
+    run_v = torch.empty((B, k), dtype=torch.float32, device=dev)
+    run_i = torch.empty((B, k), dtype=torch.int32, device=dev)
+    tmp_v, tmp_i = torch.empty_like(run_v), torch.empty_like(run_i)
+    out_v, out_i = torch.empty_like(run_v), torch.empty_like(run_i)
+    first = True
+    for c0 in range(0, V, Vc):
+        c1 = min(V, c0 + Vc)
+        kc = min(k, c1 - c0)
+        cv = tmp_v[:, :kc] if kc == k else torch.empty((B, kc), dtype=torch.float32, device=dev)
+        ci = tmp_i[:, :kc] if kc == k else torch.empty((B, kc), dtype=torch.int32, device=dev)
+        ops.topk_chunk(tl[:, c0:c1], kc, c0, cv, ci)
+        if first:
+            run_v.copy_(cv)
+            run_i.copy_(ci)
+            first = False
+        else:
+            ops.topk_merge(run_v, run_i, cv, ci, k, out_v, out_i)
+            run_v, out_v = out_v, run_v
+            run_i, out_i = out_i, run_i
+    np.testing.assert_array_equal(run_i.cpu().numpy(), ref)
+    np.testing.assert_array_equal(run_v.cpu().numpy(), np.take_along_axis(logits, ref, 1))
+
+
 def test_small_utils(dev):
     from arx import ops
     import torch
