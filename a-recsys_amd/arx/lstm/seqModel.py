@@ -12,7 +12,7 @@ Same constructor / step / get_batch signatures.  What differs from the TF graph:
     vocabulary, as hmf_model.py:130 does: the reference's own losses_full graph
     for 'mw' (seqModel.py:510) mixes a [mb, n_sampled] mask with [mb, V] logits
     and cannot be built unless n_sampled == V.
-Not implemented (raise): num_layers > 1, dropout < 1, use_concat=True,
+Not implemented (raise): num_layers > 1, dropout < 1,
 withAdagrad=False, beam search (dead code in the reference).
 """
 from __future__ import annotations
@@ -76,6 +76,59 @@ class SeqInputMean(G.Node):
             self._tmp = torch.empty((self.B, d), dtype=torch.float32, device=self.rt.device)
         ops.col_sum(self.grad.view(self.L, self.B * d), self._tmp.view(-1), self.rt.ws)
         ops.add_rows_bcast(0.5, self._tmp, user.grad_beta(), user.alloc_grad())
+
+
+class InputProject(G.Node):
+    """seqModel.py:130-146 (use_concat): x_t = concat_f(user) . w_input_user + concat_f(item_t) . w_input_item.
+    The concatenation is never materialised: every feature keeps its own lookup node (width d_f,
+    so its gradient rows stay in the arena of its table's width) and contributes
+    e_f . W[rows of f]; the weight gradient is written block-row by block-row."""
+
+    requires_grad = True
+
+    def __init__(self, rt, item_feats, user_feats, Wi, Wu, L, B):
+        size = Wi.w.shape[1]
+        super().__init__(rt, (L * B, size), tuple(item_feats) + tuple(user_feats))
+        self.item_feats, self.user_feats = list(item_feats), list(user_feats)
+        self.Wi, self.Wu, self.L, self.B, self.size = Wi, Wu, L, B, size
+        self._xu = self._dxu = None
+        if user_feats:
+            self._xu = torch.empty((B, size), dtype=torch.float32, device=rt.device)
+            self._dxu = torch.empty((B, size), dtype=torch.float32, device=rt.device)
+
+    @staticmethod
+    def _blocks(nodes):
+        off = 0
+        for n in nodes:
+            yield n, off, off + n.shape[1]
+            off += n.shape[1]
+
+    def forward(self, train):
+        rt = self.rt
+        x = self.alloc_value()
+        for k, (n, a, b) in enumerate(self._blocks(self.item_feats)):
+            ops.gemm(n.value, self.Wi.w[a:b], x, rt.ws, beta=1.0 if k else 0.0)           # :144
+        if self.user_feats:
+            for k, (n, a, b) in enumerate(self._blocks(self.user_feats)):
+                ops.gemm(n.value, self.Wu.w[a:b], self._xu, rt.ws, beta=1.0 if k else 0.0)   # :138
+            ops.add_rows_bcast(1.0, self._xu, 1.0, x)                                      # :145
+
+    def backward(self):
+        rt = self.rt
+        dx = self.grad
+        for n, a, b in self._blocks(self.item_feats):
+            if n.requires_grad:
+                ops.gemm(dx, self.Wi.w[a:b], n.alloc_grad(), rt.ws, transB=True, beta=n.grad_beta())
+            ops.gemm(n.value, dx, self.Wi.grad[a:b], rt.ws, transA=True)
+        self.Wi.touched = True
+        if self.user_feats:
+            ops.col_sum(dx.view(self.L, self.B * self.size), self._dxu.view(-1), rt.ws)
+            for n, a, b in self._blocks(self.user_feats):
+                if n.requires_grad:
+                    ops.gemm(self._dxu, self.Wu.w[a:b], n.alloc_grad(), rt.ws, transB=True,
+                             beta=n.grad_beta())
+                ops.gemm(n.value, self._dxu, self.Wu.grad[a:b], rt.ws, transA=True)
+            self.Wu.touched = True
 
 
 class LSTM(G.Node):
@@ -201,8 +254,6 @@ class SeqModel(object):
             raise NotImplementedError("MultiRNNCell with num_layers != 1")
         if float(dropoutRate) != 1.0:
             raise NotImplementedError("DropoutWrapper with keep_prob < 1 (parity runs use 1.0)")
-        if use_concat:
-            raise NotImplementedError("use_concat=True (w_input_user / w_input_item projection)")
         if not withAdagrad:
             raise NotImplementedError("GradientDescentOptimizer")
         if loss not in ('ce', 'warp', 'mw'):
@@ -263,7 +314,27 @@ class SeqModel(object):
         self._gnorm = torch.zeros(1, dtype=torch.float32, device=rt.device)
         rt.pre_apply_hooks.append(self._clip_hook)
 
-        self.user_embed, _ = m.get_batch_user(1.0, concat=False, no_id=no_user_id)   # :148
+        self.use_concat = bool(use_concat)
+        if use_concat:                                                                # :130-146
+            ua, ia = m.user_attributes, m.item_attributes
+            self._ufeats = m._select_feats(m.user_feats, ua, no_id=no_user_id)
+            self._ifeats = m._select_feats(m.item_feats, ia, no_attribute=no_input_item_feature)
+            du, di = sum(f.d for f in self._ufeats), sum(f.d for f in self._ifeats)
+            self.Wi = G.DenseParam('w_input_item', m._new_var('w_input_item', (di, size), params).contiguous())
+            rt.dense['w_input_item'] = self.Wi
+            self.Wu = None
+            if du:
+                self.Wu = G.DenseParam('w_input_user',
+                                       m._new_var('w_input_user', (du, size), params).contiguous())
+                rt.dense['w_input_user'] = self.Wu
+            uid = m.u_indices['input']
+            self.user_nodes = [G.EntityEmbed(rt, uid, [f], with_bias=False) for f in self._ufeats]
+            if no_user_id and ua.num_features_cat == 1:
+                # embed_attribute.py:356-366: the lookup short-circuits to zeros (other user
+                # features included), so w_input_user sees a zero input and never moves
+                self.user_nodes = []
+        else:
+            self.user_embed, _ = m.get_batch_user(1.0, concat=False, no_id=no_user_id)   # :148
         self._bk = {}
         self._pool_scale = {}
         self.saver = Saver(self)
@@ -283,8 +354,12 @@ class SeqModel(object):
 
         ids_in = view(m.input_all, 'item_input_%d' % L)
         feats = m._select_feats(m.item_feats, m.item_attributes, no_attribute=self.no_input_item_feature)
-        item_half = G.EntityEmbed(rt, ids_in, feats, with_bias=False, out_scale=0.5)   # :150-154
-        x = SeqInputMean(rt, item_half, self.user_embed, L, B)                           # :155
+        if self.use_concat:
+            item_nodes = [G.EntityEmbed(rt, ids_in, [f], with_bias=False) for f in feats]   # :142
+            x = InputProject(rt, item_nodes, self.user_nodes, self.Wi, self.Wu, L, B)        # :144-145
+        else:
+            item_half = G.EntityEmbed(rt, ids_in, feats, with_bias=False, out_scale=0.5)   # :150-154
+            x = SeqInputMean(rt, item_half, self.user_embed, L, B)                           # :155
         hs = LSTM(rt, x, self.W, self.b, L, B)                                           # :477
         wn = SeqWeights(rt, self.weights_all if L == Lmax else _FloatView(rt, self.weights_all, n), L, B)
         tid = view(self.target_ids_all, 'target_id_%d' % L)
@@ -354,6 +429,53 @@ class SeqModel(object):
                 ops.axpby(1.0, tmp, 1.0, out)
         return out
 
+    def _injective(self, f):
+        """True when distinct pool items always hit distinct rows of the feature's table (the id
+        feature): the per-row merge of the reference's dense matmul gradient is then a no-op."""
+        if not hasattr(f, '_inj'):
+            if f.kind != 'cat':
+                f._inj = False
+            elif f.maps[0] is None:
+                f._inj = True
+            else:
+                f._inj = bool(torch.unique(f.maps[0]).numel() == f.maps[0].numel())
+        return f._inj
+
+    def _shared_rows_norm(self, n, sp, f, sites_of, sq):
+        """Pool feature whose table rows are shared between pool items (multi-hot tokens, a
+        categorical attribute): embed_attribute.py:171,188 score the WHOLE table
+        (innerp = E . u^T + b) and gather afterwards, so the gradient of each unrolled step is a
+        dense [rows, d] matrix in which items sharing a row are already summed."""
+        rt = self.rt
+        L, S, d = sp.C_steps.shape
+        F = len(n.feats)
+        cache = self.__dict__.setdefault('_rs_cache', {})
+        key = ('shared', id(n), id(f))
+        if key not in cache:
+            cap = S if f.kind == 'cat' else S * f.max_len
+            dev = rt.device
+            cache[key] = (torch.empty(cap, dtype=torch.int32, device=dev),
+                          torch.empty(cap, dtype=torch.int32, device=dev),
+                          torch.empty(cap, dtype=torch.float32, device=dev),
+                          torch.zeros(S + 1, dtype=torch.int32, device=dev),
+                          torch.zeros(1, dtype=torch.int32, device=dev))
+        ks, ss, cs, offs, tot = cache[key]
+        ids = n.inputs[0].value
+        if f.kind == 'cat':
+            ops.sparse_site_onehot(f.maps[0], ids, 0, 1.0 / F, ks, ss, cs)
+        else:
+            ops.csr_expand(f.maps[0], f.maps[1], f.maps[2], ids, ks.shape[0], rt.ws, pad_token=G.KEY_NONE,
+                           pad_seg=0, seg_base=0, coef_scale=1.0 / F, want_coef=True,
+                           out=(ks, ss, offs, tot, cs))
+        others = [s for s in sites_of.get(id(f.table), []) if s.node is not n]
+        others_b = [s for s in others if s.node.with_bias]
+        # any IndexedSlices contribution to the variable -> every step's dense gradient is kept
+        # apart (un-merged concat); otherwise the steps are add_n'ed first
+        X, Lx = (sp.C_steps, L) if others else (n.grad, 1)
+        Xb, Lb = (sp.rs_steps, L) if others_b else (n.bias_grad, 1)
+        ops.merged_sq_norm(ks, ss, cs, f.table.E.shape[0], sq, rt.ws, X=X, d=d, L=Lx, step_stride=S * d,
+                           Xb=Xb, Lb=Lb, stepb_stride=S)
+
     def _tiled(self, rs, L, tag):
         S = rs.shape[0]
         if S % 4 != 0:
@@ -388,9 +510,14 @@ class SeqModel(object):
             if id(n) in seq_pools:
                 sp = seq_pools[id(n)]
                 L, S, d = sp.C_steps.shape
+                shared = [f for f in n.feats if not self._injective(f)]
+                for f in shared:
+                    self._shared_rows_norm(n, sp, f, sites_of, sq)
                 for for_bias in (False, True):
                     per_step, merged = [], []
                     for f in n.feats:
+                        if f in shared:
+                            continue
                         others = [s for s in sites_of.get(id(f.table), []) if s.node is not n]
                         if for_bias:
                             others = [s for s in others if s.node.with_bias]

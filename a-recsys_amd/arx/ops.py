@@ -365,6 +365,17 @@ def sq_norm_accum(x, out_accum, d=1, row_scale=None, n=None):
          _p(out_accum), _stream())
 
 
+def merged_sq_norm(keys, src, coef, table_rows, out_accum, ws, X=None, d=0, L=1, step_stride=0,
+                   Xb=None, Lb=1, stepb_stride=0, n=None):
+    """out += sum_t sum_rows ||sum_{c -> row} coef_c X_t[src_c]||^2 (+ the d = 1 analogue on Xb):
+    the norm of a table gradient after merging contributions per table row."""
+    n = int(keys.shape[0]) if n is None else int(n)
+    wsp, wsn = ws.get(_lib.lib.arx_sparse_adagrad_workspace_bytes(n))
+    call("arx_merged_sq_norm", _p(keys), _p(src), _p(coef), n, key_bits_for(table_rows),
+         _p(X), int(X.stride(-2)) if X is not None else 0, int(d), int(L), int(step_stride),
+         _p(Xb), int(Lb), int(stepb_stride), _p(out_accum), wsp, wsn, _stream())
+
+
 def clip_coef(sqnorm, max_norm, coef_out, gnorm_out=None):
     call("arx_clip_coef", _p(sqnorm), float(max_norm), _p(coef_out), _p(gnorm_out), _stream())
 

@@ -742,6 +742,55 @@ static __device__ float g_norm_part[kNormBlocks];
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Squared norm of a gradient AFTER merging contributions by table row:
+//   out += sum_t sum_rows || sum_{contributions c of the row} coef_c * X_t[src_c, :] ||^2
+// over sorted contributions (sk ascending; entries >= sentinel are pads).  This is the norm
+// tf.clip_by_global_norm sees for the dense gradient a matmul'd attribute table receives in
+// each unrolled step (seqModel.py:180; embed_attribute.py:171,188: innerp = E . u^T is taken
+// over the WHOLE table and gathered afterwards, so pool items that share a row are summed
+// before the norm).  One sub-group of GS lanes per run head; Xb is the d = 1 bias analogue.
+template <int GS>
+__global__ __launch_bounds__(256) void k_merged_sq_norm(
+    const uint32_t* __restrict__ sk, const int32_t* __restrict__ ssrc, const float* __restrict__ scoef,
+    int64_t n_host, const int32_t* __restrict__ n_dev, uint32_t sentinel, const float* __restrict__ X,
+    int64_t ldx, int d, int L, int64_t step_stride, const float* __restrict__ Xb, int Lb,
+    int64_t stepb_stride, float* __restrict__ out) {
+  const int64_t n = n_dev ? min((int64_t)*n_dev, n_host) : n_host;
+  const int lane = threadIdx.x % GS;
+  const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GS;
+  float tot = 0.f;
+  if (p < n) {
+    const uint32_t key = sk[p];
+    if (key < sentinel && (p == 0 || sk[p - 1] != key)) {
+      int64_t q1 = p + 1;
+      while (q1 < n && sk[q1] == key) ++q1;
+      for (int t = 0; t < L; ++t) {
+        const float* Xt = X + (int64_t)t * step_stride;
+        for (int e = lane; e < d; e += GS) {
+          float a = 0.f;
+          for (int64_t q = p; q < q1; ++q) a = fmaf(scoef[q], Xt[(int64_t)ssrc[q] * ldx + e], a);
+          tot = fmaf(a, a, tot);
+        }
+      }
+      for (int t = lane; t < Lb; t += GS) {
+        const float* Xt = Xb + (int64_t)t * stepb_stride;
+        float a = 0.f;
+        for (int64_t q = p; q < q1; ++q) a = fmaf(scoef[q], Xt[ssrc[q]], a);
+        tot = fmaf(a, a, tot);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = part[0] + part[1] + part[2] + part[3];
+    if (v != 0.f) atomicAdd(out, v);
+  }
+}
+
 struct SparseWs {
   size_t off_keys_tmp, off_keys_out, off_pos_in, off_pos_out, off_list, off_count, off_scratch,
       off_scratch_b, off_scratch_h, off_scratch_hb, off_ssrc, off_scoef, off_hist, total;
@@ -1004,6 +1053,54 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
                       reinterpret_cast<float*>(base + w.off_scratch_h),
                       reinterpret_cast<float*>(base + w.off_scratch_hb), list, count,
                       /*short_runs=*/n <= (1 << 21)   /* 8 waves per window measured faster up to ~0.5 M LIVE contributions (mulhot100k 92 -> 73 us), slower at 1.3 M; n is the padded capacity (~3x the live count for multi-hot sites) */, /*multi=*/false, n_dev, s);
+}
+
+int arx_merged_sq_norm(const int32_t* keys, const int32_t* src, const float* coef, int64_t n,
+                       int key_bits, const float* X, int64_t ldx, int d, int L, int64_t step_stride,
+                       const float* Xb, int Lb, int64_t stepb_stride, float* out, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  ARX_CHECK_ARG(keys && src && coef && out, "arx_merged_sq_norm: null pointer");
+  ARX_CHECK_ARG(X || Xb, "arx_merged_sq_norm: neither X nor Xb given");
+  ARX_CHECK_ARG(!X || (d > 0 && ldx >= d && L > 0), "arx_merged_sq_norm: bad X shape");
+  ARX_CHECK_ARG(!Xb || Lb > 0, "arx_merged_sq_norm: bad Xb shape");
+  ARX_CHECK_ARG(n >= 0 && n < (int64_t)0x7fffffff, "arx_merged_sq_norm: bad n");
+  if (n == 0) return ARX_OK;
+  SparseWs w;
+  int rc = sparse_ws_layout(n, 256, &w);
+  if (rc) { set_error("arx_merged_sq_norm: workspace layout failed"); return rc; }
+  if (!workspace || workspace_bytes < w.total) {
+    set_error("arx_merged_sq_norm: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+    return ARX_EWORKSPACE;
+  }
+  if (key_bits <= 0 || key_bits > 30) key_bits = 30;
+  const uint32_t sentinel = 1u << key_bits;
+  hipStream_t s = as_stream(stream);
+  char* base = reinterpret_cast<char*>(workspace);
+  uint32_t* keys_out = reinterpret_cast<uint32_t*>(base + w.off_keys_out);
+  int32_t* count = reinterpret_cast<int32_t*>(base + w.off_count);
+  int32_t* ssrc = reinterpret_cast<int32_t*>(base + w.off_ssrc);
+  float* scoef = reinterpret_cast<float*>(base + w.off_scoef);
+  const int32_t* n_dev = nullptr;
+  if (n <= kRankSortMax) {
+    rc = launch_rank_sort(keys, n, sentinel, keys_out, reinterpret_cast<uint32_t*>(base + w.off_pos_out),
+                          count, s, src, coef, ssrc, scoef);
+  } else {
+    rc = launch_radix_sort(keys, src, coef, n, sentinel, key_bits + 1,
+                           reinterpret_cast<uint32_t*>(base + w.off_keys_tmp), keys_out,
+                           reinterpret_cast<int32_t*>(base + w.off_pos_in), ssrc,
+                           reinterpret_cast<float*>(base + w.off_pos_out), scoef,
+                           reinterpret_cast<int32_t*>(base + w.off_hist), count, count + 2, s);
+    n_dev = count + 2;
+  }
+  if (rc) return rc;
+  constexpr int GS = 16;
+  const int64_t blocks = ceil_div(n * GS, (int64_t)256);
+  ARX_CHECK_ARG(blocks < (int64_t)0x7fffffff, "arx_merged_sq_norm: n too large");
+  k_merged_sq_norm<GS><<<(int)blocks, 256, 0, s>>>(keys_out, ssrc, scoef, n, n_dev, sentinel, X, ldx,
+                                                    X ? d : 0, X ? L : 0, step_stride, Xb, Xb ? Lb : 0,
+                                                    stepb_stride, out);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
 }
 
 int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const float* lr_dev,

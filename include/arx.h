@@ -307,6 +307,17 @@ int arx_sq_norm_accum(const float* x, int64_t n, int d, const float* row_scale,
                       float* out_accum, void* stream);
 int arx_clip_coef(const float* sqnorm_dev, float max_norm, float* coef_out, float* gnorm_out,
                   void* stream);
+/* Norm of a table gradient AFTER summing the contributions that land on the same table row
+ * (the dense gradient tf.gradients produces for  innerp = E . u^T  gathered by pool item,
+ * embed_attribute.py:171-172,188-193, as clip_by_global_norm sees it, seqModel.py:180):
+ *   *out_accum += sum_{t<L}  sum_rows || sum_{c: keys[c]==row} coef[c] * X[t*step_stride + src[c]*ldx + 0..d) ||^2
+ *              +  sum_{t<Lb} sum_rows (  sum_{c: keys[c]==row} coef[c] * Xb[t*stepb_stride + src[c]] )^2
+ * keys/src/coef as for arx_sparse_adagrad (ARX_KEY_NONE = padding); X or Xb may be NULL.
+ * Workspace: arx_sparse_adagrad_workspace_bytes(n). */
+int arx_merged_sq_norm(const int32_t* keys, const int32_t* src, const float* coef, int64_t n,
+                       int key_bits, const float* X, int64_t ldx, int d, int L, int64_t step_stride,
+                       const float* Xb, int Lb, int64_t stepb_stride, float* out_accum,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- small device utilities ------------------------------------------------ */
 int arx_fill_f32(float* p, int64_t n, float v, void* stream);

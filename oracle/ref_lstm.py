@@ -76,7 +76,7 @@ class RefSeqModel(object):
 
     def __init__(self, L, size, max_gradient_norm, batch_size, learning_rate, embAttr,
                  loss='mw', no_user_id=False, no_input_item_feature=False, output_feat=1,
-                 params=None, withAdagrad=True):
+                 params=None, withAdagrad=True, use_concat=False):
         self.L = L
         self.size = size
         self.max_gradient_norm = max_gradient_norm
@@ -96,6 +96,13 @@ class RefSeqModel(object):
         embAttr.params['lstm_b'] = self.b
         embAttr.slots['lstm_w'] = np.full(self.W.shape, 0.1, dt)
         embAttr.slots['lstm_b'] = np.full(self.b.shape, 0.1, dt)
+        # use_concat (:130-146): input_t = concat_f(user) . w_input_user + concat_f(item_t) . w_input_item
+        self.use_concat = use_concat
+        if use_concat:
+            for nm in ('w_input_user', 'w_input_item'):
+                w = np.array(params[nm], dtype=dt)
+                embAttr.params[nm] = w
+                embAttr.slots[nm] = np.full(w.shape, 0.1, dt)
         self.last = {}
 
     def step_recommend(self, user_input, item_inputs, positions, topk_n=30):
@@ -103,13 +110,23 @@ class RefSeqModel(object):
         sorted=True) -> [(uid, values[topk_n], indexes[topk_n])] for position positions[i] of
         sequence i (ties: lower index first, like tf.nn.top_k)."""
         m, L = self.m, self.L
-        u, _ = m.get_batch_user(user_input, concat=False, no_id=self.no_user_id)
         xs = []
-        for t in range(L):
-            feats, _, _ = m.get_batch_item(item_inputs[t], concat=False,
-                                           no_attribute=self.no_input_item_feature)
-            it = np.mean(np.stack(feats, 0), 0)
-            xs.append(np.mean(np.stack([u, it], 0), 0))
+        if self.use_concat:
+            Wu, Wi = m.params['w_input_user'], m.params['w_input_item']
+            ut = 0.0
+            if Wu.shape[0] > 0:
+                ut = m.get_batch_user(user_input, concat=True, no_id=self.no_user_id)[0] @ Wu
+            for t in range(L):
+                it = m.get_batch_item(item_inputs[t], concat=True,
+                                      no_attribute=self.no_input_item_feature)[0]
+                xs.append(ut + it @ Wi)
+        else:
+            u, _ = m.get_batch_user(user_input, concat=False, no_id=self.no_user_id)
+            for t in range(L):
+                feats, _, _ = m.get_batch_item(item_inputs[t], concat=False,
+                                               no_attribute=self.no_input_item_feature)
+                it = np.mean(np.stack(feats, 0), 0)
+                xs.append(np.mean(np.stack([u, it], 0), 0))
         hs, _, _ = lstm_fwd(np.stack(xs, 0), self.W, self.b, 1.0)
         results = []
         for i, pos in enumerate(positions):
@@ -130,14 +147,28 @@ class RefSeqModel(object):
         targets_mapped = m.target_mapping(targets)                          # :294
         w = np.asarray(target_weights, dtype=dt)                            # [L,B]
         # ---- inputs (:148-156) ----
-        u, c_user = m.get_batch_user(user_input, concat=False, no_id=self.no_user_id)
-        xs, c_items = [], []
-        for t in range(L):
-            feats, _, c_it = m.get_batch_item(item_inputs[t], concat=False,
-                                              no_attribute=self.no_input_item_feature)
-            it = np.mean(np.stack(feats, 0), 0)                             # :154
-            xs.append(np.mean(np.stack([u, it], 0), 0))                     # :155
-            c_items.append(c_it)
+        xs, c_items, its = [], [], []
+        if self.use_concat:
+            Wu, Wi = m.params['w_input_user'], m.params['w_input_item']
+            if Wu.shape[0] > 0:
+                u, c_user = m.get_batch_user(user_input, concat=True, no_id=self.no_user_id)   # :131
+                ut = u @ Wu                                                                 # :138
+            else:                                   # no_user_id with an id-only user: zero-width embed
+                u, c_user, ut = np.zeros((B, 0), dtype=dt), {'sites': []}, 0.0
+            for t in range(L):
+                it, _, c_it = m.get_batch_item(item_inputs[t], concat=True,
+                                               no_attribute=self.no_input_item_feature)     # :142
+                xs.append(ut + it @ Wi)                                                     # :144-145
+                its.append(it)
+                c_items.append(c_it)
+        else:
+            u, c_user = m.get_batch_user(user_input, concat=False, no_id=self.no_user_id)
+            for t in range(L):
+                feats, _, c_it = m.get_batch_item(item_inputs[t], concat=False,
+                                                  no_attribute=self.no_input_item_feature)
+                it = np.mean(np.stack(feats, 0), 0)                             # :154
+                xs.append(np.mean(np.stack([u, it], 0), 0))                     # :155
+                c_items.append(c_it)
         x = np.stack(xs, 0)
         hs, cs, gates = lstm_fwd(x, self.W, self.b, 1.0)                    # :477
         # ---- per-step scorer + loss (:480-493) ----
@@ -183,15 +214,31 @@ class RefSeqModel(object):
         dz, dx, dW, db = lstm_bwd(x, self.W, hs, cs, gates, dhs)
         grads.add_dense('lstm_w', dW)
         grads.add_dense('lstm_b', db)
-        du = np.zeros_like(u)
-        for t in range(L):
-            du += dx[t] / 2
-            c_it = c_items[t]
-            n = len(c_it['sites'])
-            if n:
-                m.get_embedded_bwd(c_it, [dx[t] / 2 / n] * n, None, grads)
-        if c_user['sites']:
-            m.get_batch_user_bwd(c_user, du, grads)
+        if self.use_concat:
+            Wu, Wi = m.params['w_input_user'], m.params['w_input_item']
+            dxs = dx.sum(0)
+            for t in range(L):
+                grads.add_dense('w_input_item', its[t].T @ dx[t])        # one dense grad per unrolled matmul
+                d_it = dx[t] @ Wi.T
+                c_it = c_items[t]
+                if len(c_it['sites']):
+                    offs = np.cumsum([0] + c_it['dims'])
+                    m.get_embedded_bwd(c_it, [d_it[:, offs[k]:offs[k + 1]] for k in range(len(c_it['dims']))],
+                                       None, grads)
+            if Wu.shape[0] > 0:
+                grads.add_dense('w_input_user', u.T @ dxs)
+                if c_user['sites']:
+                    m.get_batch_user_bwd(c_user, dxs @ Wu.T, grads)
+        else:
+            du = np.zeros_like(u)
+            for t in range(L):
+                du += dx[t] / 2
+                c_it = c_items[t]
+                n = len(c_it['sites'])
+                if n:
+                    m.get_embedded_bwd(c_it, [dx[t] / 2 / n] * n, None, grads)
+            if c_user['sites']:
+                m.get_batch_user_bwd(c_user, du, grads)
         # clip_by_global_norm (:180): norm over the aggregated-but-unmerged values
         sq = sum(grads.sq_norm_unmerged(n) for n in grads.names())
         gnorm = np.sqrt(sq)

@@ -832,3 +832,39 @@ def test_sparse_adagrad_cat_multi(dev, d, rows, ns):
         if tabs[t]['has_bias']:
             np.testing.assert_allclose(outs[0][t][2].cpu().numpy(), rb, rtol=2e-4, atol=2e-5)
         assert torch.equal(outs[0][t][0], outs[1][t][0]) and torch.equal(outs[0][t][1], outs[1][t][1])
+
+
+@pytest.mark.parametrize("n,rows,d,L", [(700, 90, 64, 5), (20000, 1500, 32, 3), (300, 300, 8, 1)])
+def test_merged_sq_norm(dev, n, rows, d, L):
+    """arx_merged_sq_norm: norm of a table gradient after contributions to the same row are summed
+    (the dense per-step matmul gradient of embed_attribute.py:171,188 under seqModel.py:180)."""
+    import torch
+    from arx import ops
+    rng = np.random.default_rng(n + d)
+    S = 257
+    keys = rng.integers(0, rows, size=n).astype(np.int32)
+    pads = rng.random(n) < 0.2
+    keys[pads] = ops.KEY_NONE
+    src = rng.integers(0, S, size=n).astype(np.int32)
+    coef = rng.random(n).astype(np.float32) + 0.1
+    X = rng.standard_normal((L, S, d)).astype(np.float32)
+    Xb = rng.standard_normal((L, S)).astype(np.float32)
+    exp = 0.0
+    for t in range(L):
+        M = np.zeros((rows, d))
+        mb = np.zeros(rows)
+        live = ~pads
+        np.add.at(M, keys[live], coef[live, None].astype(np.float64) * X[t][src[live]])
+        np.add.at(mb, keys[live], coef[live].astype(np.float64) * Xb[t][src[live]])
+        exp += (M ** 2).sum() + (mb ** 2).sum()
+    out = torch.full((1,), 3.0, dtype=torch.float32, device=dev)
+    ws = ops.Workspace(dev)
+    ops.merged_sq_norm(_t(dev, keys), _t(dev, src), _t(dev, coef), rows, out, ws, X=_t(dev, X), d=d, L=L,
+                       step_stride=S * d, Xb=_t(dev, Xb), Lb=L, stepb_stride=S)
+    np.testing.assert_allclose(float(out.item()) - 3.0, exp, rtol=2e-5)
+    # E part only, single step
+    out.zero_()
+    ops.merged_sq_norm(_t(dev, keys), _t(dev, src), _t(dev, coef), rows, out, ws, X=_t(dev, X[0]), d=d, L=1)
+    M = np.zeros((rows, d))
+    np.add.at(M, keys[~pads], coef[~pads, None].astype(np.float64) * X[0][src[~pads]])
+    np.testing.assert_allclose(float(out.item()), (M ** 2).sum(), rtol=2e-5)

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4
 
 
-def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False):
+def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False, use_concat=False):
     from arx.attributes.embed_attribute import EmbeddingAttribute
     from arx.lstm.seqModel import SeqModel
     from arx.utils.synthetic import SyntheticHMF
@@ -23,19 +23,25 @@ def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False):
     rng = np.random.default_rng(seed + 2)
     params['lstm_w'] = (rng.standard_normal((2 * size, 4 * size)) * 0.15).astype(np.float32)
     params['lstm_b'] = (rng.standard_normal((4 * size,)) * 0.05).astype(np.float32)
+    if use_concat:                                   # seqModel.py:132-137 w_input_user / w_input_item
+        du = sum(syn.u_attr._embedding_size_list_cat[(1 if no_user_id else 0):]) + \
+            sum(syn.u_attr._embedding_size_list_mulhot)
+        di = sum(syn.i_attr._embedding_size_list_cat) + sum(syn.i_attr._embedding_size_list_mulhot)
+        params['w_input_user'] = (rng.standard_normal((du, size)) * 0.2).astype(np.float32)
+        params['w_input_item'] = (rng.standard_normal((di, size)) * 0.2).astype(np.float32)
     i2l = syn.item_ind2logit_ind_dict()
     START = syn.n_items
     i2l[START] = 0                                   # lstm/run.py:277
     l2i = syn.logit_ind2item_ind
     n_s = S if loss == 'mw' else None
     emb = EmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i, params=params)
-    model = SeqModel([L], size, 1, clip, B, 0.5, 0.83, emb, loss=loss, use_concat=False,
+    model = SeqModel([L], size, 1, clip, B, 0.5, 0.83, emb, loss=loss, use_concat=use_concat,
                      no_user_id=no_user_id, START_ID=START, params=params)
     remb = rg.RefEmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i,
                                     params={k: v for k, v in params.items() if not k.startswith('lstm')},
                                     dtype=np.float64)
     ref = ref_lstm.RefSeqModel(L, size, clip, B, 0.5, remb, loss=loss, no_user_id=no_user_id,
-                               params=params)
+                               params=params, use_concat=use_concat)
     pos = syn.positives_dict()
     emb.prepare_warp(pos, pos)
     remb.prepare_warp(pos, pos)
@@ -57,6 +63,12 @@ def _compare(emb, model, remb, ref, rtol=RTOL, atol=3e-6):
         np.testing.assert_allclose(v, remb.params[k], rtol=rtol, atol=atol, err_msg=k)
     np.testing.assert_allclose(model.W.w.cpu().numpy(), ref.W, rtol=rtol, atol=atol, err_msg='lstm_w')
     np.testing.assert_allclose(model.b.w.cpu().numpy(), ref.b, rtol=rtol, atol=atol, err_msg='lstm_b')
+    if getattr(model, 'use_concat', False):
+        np.testing.assert_allclose(model.Wi.w.cpu().numpy(), remb.params['w_input_item'], rtol=rtol,
+                                   atol=atol, err_msg='w_input_item')
+        if model.Wu is not None:
+            np.testing.assert_allclose(model.Wu.w.cpu().numpy(), remb.params['w_input_user'], rtol=rtol,
+                                       atol=atol, err_msg='w_input_user')
 
 
 CFG_ID = dict(n_users=300, n_items=500, logit_size=500)
@@ -68,6 +80,7 @@ CFG_HET = dict(n_users=300, n_items=500, logit_size=500, item_mulhot=True, mulho
     (CFG_ID, 64, 16, 5, 128, 5.0),       # MFMA LSTM kernel, clipping active
     (CFG_ID, 32, 16, 4, 64, 0.5),        # generic LSTM kernel, hard clipping
     (CFG_HET, 64, 32, 6, 128, 1e9),      # multi-hot item attributes, no clipping
+    (CFG_HET, 64, 16, 4, 64, 0.5),       # multi-hot tokens shared between pool items, hard clipping
 ])
 def test_seq_mw_steps_match_oracle(dev, cfg, size, B, L, S, clip):
     syn, emb, model, remb, ref = _build(cfg, 'mw', size, B, L, S, clip, seed=4)
@@ -145,5 +158,44 @@ def test_seq_step_recommend(dev, loss, S):
     assert len(r_got) == len(r_ref) == 16
     for (u0, v0, i0), (u1, v1, i1) in zip(r_got, r_ref):
         assert int(u0) == int(u1)
+        np.testing.assert_array_equal(np.asarray(i0), i1)
+        np.testing.assert_allclose(v0, v1, rtol=RTOL, atol=1e-9)
+
+
+CFG_HET_U = dict(n_users=300, n_items=500, logit_size=500, item_mulhot=True, user_mulhot=True,
+                 mulhot_vocab=150, avg_len=5, max_len=12)
+
+
+@pytest.mark.parametrize("cfg,loss,S,clip,no_uid", [
+    (CFG_ID, 'mw', 64, 5.0, False),        # ids only: x_t = E_u . Wu + E_i(t) . Wi
+    (CFG_HET, 'ce', None, 0.5, False),     # item id + multi-hot attribute blocks of w_input_item, hard clip
+    (CFG_HET_U, 'mw', 128, 5.0, False),    # user id + user multi-hot blocks of w_input_user
+    (CFG_HET_U, 'mw', 128, 5.0, True),     # no_user_id with one categorical user feature: zero user input
+])
+def test_seq_use_concat(dev, cfg, loss, S, clip, no_uid):
+    """seqModel.py:130-146: concatenated feature embeddings through w_input_user / w_input_item."""
+    size, B, L = 64, 16, 4
+    syn, emb, model, remb, ref = _build(cfg, loss, size, B, L, S, clip, seed=13, no_user_id=no_uid,
+                                        use_concat=True)
+    model.topk_n = 5
+    rng = np.random.default_rng(17)
+    pool = id2idx = None
+    if loss == 'mw':
+        pool = syn.sample_pool(S, rng)
+        id2idx = {int(v): i for i, v in enumerate(pool)}
+    for step in range(3):
+        users, inp, tg, w = _batch(syn, rng, L, B)
+        ps = pool if step == 0 else None
+        l_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), ps, id2idx)
+        l_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, ps, id2idx)
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='loss step %d' % step)
+        np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL,
+                                   err_msg='global norm step %d' % step)
+        _compare(emb, model, remb, ref)
+    users, inp, tg, w = _batch(syn, rng, L, B)
+    positions = rng.integers(0, L, size=B).tolist()
+    r_ref = ref.step_recommend(list(users), inp.tolist(), positions, topk_n=5)
+    r_got = model.step_recommend(None, list(users), inp.tolist(), positions, 0)
+    for (u0, v0, i0), (u1, v1, i1) in zip(r_got, r_ref):
         np.testing.assert_array_equal(np.asarray(i0), i1)
         np.testing.assert_allclose(v0, v1, rtol=RTOL, atol=1e-9)

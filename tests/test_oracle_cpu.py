@@ -340,3 +340,55 @@ def test_synthetic_layout_follows_reference_preprocessing():
     np.testing.assert_array_equal(fl, lens[l2i])
     exp_vals = np.concatenate([vals[starts[i]:starts[i] + lens[i]] for i in l2i])
     np.testing.assert_array_equal(np.asarray(ia.full_values_tr[0]), exp_vals)
+
+
+def test_oracle_seq_use_concat_gradient_by_finite_differences():
+    """use_concat input projection of the LSTM restatement (seqModel.py:130-146): the gradient
+    implied by one un-clipped Adagrad step equals central differences of the loss."""
+    from arx.utils.synthetic import SyntheticHMF
+    size, B, L = 8, 4, 3
+    syn = SyntheticHMF(n_users=30, n_items=40, logit_size=40, item_mulhot=True, user_mulhot=True,
+                       mulhot_vocab=20, avg_len=3, max_len=6, seed=3)
+    syn.u_attr.set_model_size(size)
+    syn.i_attr.set_model_size(size)
+    base = syn.glorot_params(size, seed=4, scale=0.5)
+    rng = np.random.default_rng(5)
+    base['lstm_w'] = rng.standard_normal((2 * size, 4 * size)) * 0.3
+    base['lstm_b'] = rng.standard_normal(4 * size) * 0.1
+    base['w_input_user'] = rng.standard_normal((2 * size, size)) * 0.4
+    base['w_input_item'] = rng.standard_normal((2 * size, size)) * 0.4
+    i2l = syn.item_ind2logit_ind_dict()
+    i2l[syn.n_items] = 0
+    users = rng.integers(0, syn.n_users, size=B)
+    tg = rng.integers(0, syn.n_items, size=(L, B))
+    inp = np.concatenate([np.full((1, B), syn.n_items), tg[:-1]], 0)
+    w = np.ones((L, B))
+
+    def make(params):
+        remb = rg.RefEmbeddingAttribute(syn.u_attr, syn.i_attr, B, None, L, False, i2l, syn.logit_ind2item_ind,
+                                        params={k: v for k, v in params.items() if not k.startswith('lstm')},
+                                        dtype=np.float64)
+        return remb, ref_lstm.RefSeqModel(L, size, 1e12, B, 0.5, remb, loss='ce', params=params,
+                                          use_concat=True)
+
+    def loss_at(params):
+        _, ref = make(params)
+        return ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), forward_only=True)
+
+    remb, ref = make(base)
+    ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist())
+    emb_name = [k for k in remb.params if k.startswith('user') and 'mulhot' in k][0]
+    for name, pick in (('w_input_item', (3, 2)), ('w_input_item', (size + 1, 5)), ('w_input_user', (2, 1)),
+                       ('w_input_user', (size + 3, 0)), (emb_name, None)):
+        p0 = np.array(base[name], dtype=np.float64)
+        if pick is None:                     # a multi-hot token row that the batch touched
+            moved = np.argwhere(np.abs(remb.params[name] - p0) > 0)
+            pick = tuple(moved[0])
+        r = (remb.params[name][pick] - p0[pick]) / 0.5
+        g_step = -r * np.sqrt(0.1 / (1.0 - r * r))
+        eps = 1e-5
+        hi, lo = dict(base), dict(base)
+        hi[name] = p0.copy(); hi[name][pick] += eps
+        lo[name] = p0.copy(); lo[name][pick] -= eps
+        g_fd = (loss_at(hi) - loss_at(lo)) / (2 * eps)
+        np.testing.assert_allclose(g_step, g_fd, rtol=2e-5, atol=1e-8, err_msg='%s%s' % (name, pick))
