@@ -145,6 +145,7 @@ class LSTM(G.Node):
         self.cs = torch.empty((L * B, h), dtype=torch.float32, device=dev)
         self.gates = torch.empty((L * B, 4 * h), dtype=torch.float32, device=dev)
         self.dz = None
+        self._wt = self._dwt = None
 
     def forward(self, train):
         x = self.inputs[0]
@@ -158,14 +159,25 @@ class LSTM(G.Node):
             self.dz = torch.empty((L * B, 4 * h), dtype=torch.float32, device=rt.device)
         dz = self.dz
         ops.lstm_bwd(self.W.w, self.value, self.cs, self.gates, self.grad, L, B, din, h, dz)
+        # All three products stream the [L*B, 4h] matrix dz once through the LDS-DMA GEMM, whose
+        # output tile is at most 128 columns wide: so dx uses W_x^T as a plain [4h, din] operand
+        # and the weight gradients are formed transposed (dW^T = dz^T . [x ; h_prev], 4h rows,
+        # din / h columns) and flipped afterwards by a 16 k-element transpose.  db = column sums
+        # of dz falls out of the first product as its row-sum side output.
+        if self._wt is None:
+            dev = rt.device
+            self._wt = torch.empty((4 * h, din), dtype=torch.float32, device=dev)
+            self._dwt = torch.empty((4 * h, max(din, h)), dtype=torch.float32, device=dev)
         if x.requires_grad:
-            ops.gemm(dz, self.W.w[:din], x.alloc_grad(), rt.ws, transB=True, beta=x.grad_beta())
-        ops.gemm(x.value, dz, self.W.grad[:din], rt.ws, transA=True)
+            ops.transpose(self.W.w[:din], self._wt)
+            ops.gemm(dz, self._wt, x.alloc_grad(), rt.ws, beta=x.grad_beta())
+        ops.gemm(dz, x.value, self._dwt[:, :din], rt.ws, transA=True, a_rowsum=self.b.grad)
+        ops.transpose(self._dwt[:, :din], self.W.grad[:din])
         if L > 1:
-            ops.gemm(self.value[:(L - 1) * B], dz[B:], self.W.grad[din:], rt.ws, transA=True)
+            ops.gemm(dz[B:], self.value[:(L - 1) * B], self._dwt[:, :h], rt.ws, transA=True)
+            ops.transpose(self._dwt[:, :h], self.W.grad[din:])
         else:
             ops.fill_f32(self.W.grad[din:], 0.0)
-        ops.col_sum(dz, self.b.grad, rt.ws)
         self.W.touched = self.b.touched = True
 
 

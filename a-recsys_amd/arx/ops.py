@@ -111,6 +111,13 @@ def copy_2d(src, dst):
 
 
 # ---- a5 ---------------------------------------------------------------------
+def transpose(src, dst):
+    """dst[c, r] = src[r, c] for 2-D fp32 views with unit inner stride."""
+    rows, cols = int(src.shape[0]), int(src.shape[1])
+    call("arx_transpose_f32", _p(src), int(src.stride(0)), rows, cols, _p(dst), int(dst.stride(0)),
+         _stream())
+
+
 def gather_onehot(E, bias, cat_map, ids, out, scale=1.0, accumulate=False, bias_out=None):
     _chk(E, torch.float32, 'E'); _chk(ids, torch.int32, 'ids'); _chk(out, torch.float32, 'out')
     call("arx_gather_onehot_fwd", _p(E), _p(bias), _p(cat_map), _p(ids), int(ids.shape[0]),

@@ -248,6 +248,91 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(
   }
 }
 
+// Same reduction with the splits spread over 16 lanes per output element group: every thread has
+// its (<= 4 at 64 splits) loads in flight at once instead of walking the splits one L2 round
+// trip at a time (64 splits x [256 x 64]: 24 us -> a few us).  Fixed combine order => deterministic.
+// Blocks [0, nb_main): 16 float4 of C each; blocks [nb_main, ...): 16 row sums each.
+__global__ __launch_bounds__(256) void k_splitk_reduce_lanes(
+    const float* __restrict__ partial, int splits, int64_t M, int64_t N, float alpha, float beta,
+    float* __restrict__ C, int64_t ldc, const float* __restrict__ col_bias,
+    const float* __restrict__ rowsum_partial, float* __restrict__ a_rowsum, int nb_main) {
+  __shared__ float4 sh[16][17];
+  const int cx = threadIdx.x & 15, sy = threadIdx.x >> 4;
+  const int64_t total = M * N;
+  if ((int)blockIdx.x < nb_main) {
+    const int64_t i4 = (int64_t)blockIdx.x * 16 + cx;       // float4 index into [M*N]
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 * 4 < total) {
+      const float4* p4 = reinterpret_cast<const float4*>(partial) + i4;
+      const int64_t st4 = total >> 2;
+      for (int z = sy; z < splits; z += 16) {
+        const float4 v = p4[(int64_t)z * st4];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    }
+    sh[sy][cx] = a;
+    __syncthreads();
+    if (sy == 0 && i4 * 4 < total) {
+      float4 t = sh[0][cx];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) {
+        const float4 v = sh[k][cx];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      const int64_t e = i4 * 4, r = e / N, c = e % N;
+      float4 o = make_float4(alpha * t.x, alpha * t.y, alpha * t.z, alpha * t.w);
+      float4* dst = reinterpret_cast<float4*>(C + r * ldc + c);
+      if (beta != 0.f) {
+        const float4 old = *dst;
+        o.x += beta * old.x; o.y += beta * old.y; o.z += beta * old.z; o.w += beta * old.w;
+      }
+      if (col_bias) {
+        const float4 cb = *reinterpret_cast<const float4*>(col_bias + c);
+        o.x += cb.x; o.y += cb.y; o.z += cb.z; o.w += cb.w;
+      }
+      *dst = o;
+    }
+  } else {
+    float* shf = reinterpret_cast<float*>(sh);
+    const int64_t m = (int64_t)(blockIdx.x - nb_main) * 16 + cx;
+    float a = 0.f;
+    if (m < M)
+      for (int z = sy; z < splits; z += 16) a += rowsum_partial[(int64_t)z * M + m];
+    shf[sy * 17 + cx] = a;
+    __syncthreads();
+    if (sy == 0 && m < M) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += shf[k * 17 + cx];
+      a_rowsum[m] = t;
+    }
+  }
+}
+
+// picks the lane-parallel variant when the layout allows float4 traffic
+static inline void launch_splitk_reduce(const float* partial, int splits, int64_t M, int64_t N,
+                                        float alpha, float beta, float* C, int64_t ldc,
+                                        const float* col_bias, const float* rowsum_partial,
+                                        float* a_rowsum, hipStream_t s) {
+  const int64_t total = M * N;
+  const bool v4 = (N % 4 == 0) && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(partial) & 15) == 0) &&
+                  (!col_bias || (reinterpret_cast<uintptr_t>(col_bias) & 15) == 0) && splits >= 8 &&
+                  total / 64 + M / 16 + 2 < 0x7fffffff;
+  if (v4) {
+    const int nb_main = (int)ceil_div(total, (int64_t)64);
+    const int nb_rs = a_rowsum ? (int)ceil_div(M, (int64_t)16) : 0;
+    k_splitk_reduce_lanes<<<nb_main + nb_rs, 256, 0, s>>>(partial, splits, M, N, alpha, beta, C, ldc,
+                                                          col_bias, rowsum_partial, a_rowsum, nb_main);
+    return;
+  }
+  int64_t g = ceil_div(total, 256);
+  int64_t cap = (int64_t)cu_count() * 8;
+  if (g > cap) g = cap;
+  k_splitk_reduce<<<(int)g, 256, 0, s>>>(partial, splits, M, N, alpha, beta, C, ldc, col_bias,
+                                         rowsum_partial, a_rowsum);
+}
+
 struct GemmPlan {
   bool big;
   int splits;
@@ -364,11 +449,7 @@ int arx_gemm_f32_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K,
                                bm, sp, kc, a_rowsum, rsp, s);
     if (rc_d) return rc_d;
     if (part) {
-      int64_t g = ceil_div(M * N, 256);
-      int64_t cap = (int64_t)cu_count() * 8;
-      if (g > cap) g = cap;
-      k_splitk_reduce<<<(int)g, 256, 0, s>>>(part, sp, M, N, alpha, beta, C, ldc, col_bias, rsp,
-                                             a_rowsum);
+      launch_splitk_reduce(part, sp, M, N, alpha, beta, C, ldc, col_bias, rsp, a_rowsum, s);
       ARX_CHECK_LAUNCH();
     }
     return ARX_OK;
@@ -402,12 +483,7 @@ int arx_gemm_f32_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K,
 #undef ARX_GO
   if (rc) return rc;
   if (partial) {
-    int64_t total = M * N;
-    int64_t g = ceil_div(total, 256);
-    int64_t cap = (int64_t)cu_count() * 8;
-    if (g > cap) g = cap;
-    k_splitk_reduce<<<(int)g, 256, 0, s>>>(partial, p.splits, M, N, alpha, beta, C, ldc,
-                                           col_bias, rs_partial, a_rowsum);
+    launch_splitk_reduce(partial, p.splits, M, N, alpha, beta, C, ldc, col_bias, rs_partial, a_rowsum, s);
     ARX_CHECK_LAUNCH();
   }
   return ARX_OK;
@@ -427,18 +503,23 @@ int arx_gemm_f32_steps_tn(int64_t steps, int64_t M, int64_t N, int64_t Kb, const
   p.big = false;
   p.splits = (int)steps;
   p.kchunk = Kb;
-  int rc = launch_gemm<64, 64, 16>(1, 0, M, N, steps * Kb, 1.f, A, lda, B, ldb, 0.f, C_steps, N,
+  static const bool dma_off = getenv("ARX_GEMM_DMA_OFF") != nullptr;
+  int rc;
+  if (!dma_off && steps > 1 && Kb % 32 == 0 &&
+      gemm_dma_supported(1, 0, M, N, steps * Kb, A, lda, B, ldb)) {
+    // one split-K slice per step on the LDS-DMA kernel: the "partials" ARE the per-step products
+    static const int sbm = getenv("ARX_STEPS_BM") ? atoi(getenv("ARX_STEPS_BM")) : 128;
+    rc = gemm_dma_launch(1, M, N, steps * Kb, 1.f, A, lda, B, ldb, 0.f, C_steps, N, nullptr, C_steps,
+                         (sbm == 64 || M % 128 != 0) ? 64 : 128, (int)steps, Kb, rowsum_steps, rowsum_steps, s);
+  } else
+  rc = launch_gemm<64, 64, 16>(1, 0, M, N, steps * Kb, 1.f, A, lda, B, ldb, 0.f, C_steps, N,
                                nullptr, C_steps, p, s, rowsum_steps ? rowsum_steps : nullptr,
                                rowsum_steps);
   if (rc) return rc;
   if (C_sum) {
     ARX_CHECK_ARG(ldc >= N, "arx_gemm_f32_steps_tn: ldc too small");
-    int64_t total = M * N;
-    int64_t g = ceil_div(total, 256);
-    int64_t cap = (int64_t)cu_count() * 8;
-    if (g > cap) g = cap;
-    k_splitk_reduce<<<(int)g, 256, 0, s>>>(C_steps, (int)steps, M, N, 1.f, beta, C_sum, ldc,
-                                           nullptr, rowsum_steps, rowsum_sum);
+    launch_splitk_reduce(C_steps, (int)steps, M, N, 1.f, beta, C_sum, ldc, nullptr, rowsum_steps,
+                         rowsum_sum, s);
     ARX_CHECK_LAUNCH();
   }
   return ARX_OK;

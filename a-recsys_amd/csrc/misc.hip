@@ -64,30 +64,48 @@ __global__ __launch_bounds__(256) void k_topk(const float* __restrict__ logits, 
   }
 }
 
-__global__ void k_seq_weights(const float* __restrict__ w, int64_t L, int64_t B,
-                              float* __restrict__ out) {
-  const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  float tot = 0.f;
-  for (int64_t t = 0; t < L; ++t) tot += w[t * B + b];  // add_n over time steps
-  tot += 1e-12f;
-  for (int64_t t = 0; t < L; ++t) out[t * B + b] = w[t * B + b] / tot;
+// 256 threads = 32 sequences x 8 time lanes; fixed-order combine through LDS
+__global__ __launch_bounds__(256) void k_seq_weights(const float* __restrict__ w, int64_t L, int64_t B,
+                                                     float* __restrict__ out) {
+  __shared__ float part[8][33];
+  const int cx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t b = blockIdx.x * 32 + cx;
+  float s = 0.f;
+  if (b < B)
+    for (int64_t t = ty; t < L; t += 8) s += w[t * B + b];   // add_n over time steps
+  part[ty][cx] = s;
+  __syncthreads();
+  float tot = 1e-12f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tot += part[k][cx];
+  if (b < B)
+    for (int64_t t = ty; t < L; t += 8) out[t * B + b] = w[t * B + b] / tot;
 }
 
-// single workgroup, fixed order: *out = scale * sum_i x[i]*y[i]
+// single workgroup, fixed order: *out = scale * sum_i x[i]*y[i]; 4 independent loads in flight
 __global__ __launch_bounds__(1024) void k_dot_scaled(const float* __restrict__ x,
                                                       const float* __restrict__ y, int64_t n,
                                                       float scale, float* __restrict__ out) {
   __shared__ float part[16];
-  float s = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) s += x[i] * y[i];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int64_t i = threadIdx.x;
+  for (; i + 3 * 1024 < n; i += 4 * 1024) {
+    const float a0 = x[i], a1 = x[i + 1024], a2 = x[i + 2048], a3 = x[i + 3072];
+    const float b0 = y[i], b1 = y[i + 1024], b2 = y[i + 2048], b3 = y[i + 3072];
+    s0 = fmaf(a0, b0, s0);
+    s1 = fmaf(a1, b1, s1);
+    s2 = fmaf(a2, b2, s2);
+    s3 = fmaf(a3, b3, s3);
+  }
+  for (; i < n; i += 1024) s0 = fmaf(x[i], y[i], s0);
+  float s = (s0 + s1) + (s2 + s3);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
     float t = 0.f;
-    for (int i = 0; i < 16; ++i) t += part[i];
+    for (int k = 0; k < 16; ++k) t += part[k];
     *out = t * scale;
   }
 }
@@ -139,7 +157,7 @@ int arx_inv_len_scale(const int32_t* lens, const int32_t* ids, int64_t n, float 
 int arx_seq_weights(const float* w, int64_t L, int64_t B, float* out, void* stream) {
   ARX_CHECK_ARG(w && out, "arx_seq_weights: null pointer");
   if (B <= 0 || L <= 0) return ARX_OK;
-  k_seq_weights<<<(int)ceil_div(B, 256), 256, 0, as_stream(stream)>>>(w, L, B, out);
+  k_seq_weights<<<(int)ceil_div(B, 32), 256, 0, as_stream(stream)>>>(w, L, B, out);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

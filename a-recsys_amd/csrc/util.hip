@@ -100,8 +100,18 @@ __global__ void k_col_sum_partial(const float* __restrict__ x, int64_t ld, int64
   const int64_t r0 = blockIdx.y * rows_per_chunk;
   const int64_t r1 = min(rows, r0 + rows_per_chunk);
   float s = 0.f;
-  if (c < cols)
-    for (int64_t r = r0 + ry; r < r1; r += 4) s += x[r * ld + c];
+  if (c < cols) {
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;          // 4 independent loads in flight
+    int64_t r = r0 + ry;
+    for (; r + 12 < r1; r += 16) {
+      s += x[r * ld + c];
+      s1 += x[(r + 4) * ld + c];
+      s2 += x[(r + 8) * ld + c];
+      s3 += x[(r + 12) * ld + c];
+    }
+    for (; r < r1; r += 4) s += x[r * ld + c];
+    s = (s + s1) + (s2 + s3);
+  }
   part[ry][cx] = s;
   __syncthreads();
   if (ry == 0 && c < cols)
@@ -217,6 +227,26 @@ static inline int grid_for(int64_t n, int block) {
   return (int)g;
 }
 
+// dst[c, r] = src[r, c]: 32x32 tiles through LDS (padded: conflict-free both ways)
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ src, int64_t lds,
+                                                   int64_t rows, int64_t cols, float* __restrict__ dst,
+                                                   int64_t ldd) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  const int64_t r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t r = r0 + ty + 8 * k, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 8 * k][tx] = src[r * lds + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t c = c0 + ty + 8 * k, r = r0 + tx;
+    if (r < rows && c < cols) dst[c * ldd + r] = tile[tx][ty + 8 * k];
+  }
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -313,6 +343,17 @@ int arx_col_sum(const float* x, int64_t ld, int64_t rows, int64_t cols, float* o
   k_col_sum_partial<<<grid, 256, 0, as_stream(stream)>>>(x, ld, rows, cols, rpc, partial);
   ARX_CHECK_LAUNCH();
   k_col_sum_final<<<(int)ceil_div(cols, 64), 256, 0, as_stream(stream)>>>(partial, nchunk, cols, out);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_transpose_f32(const float* src, int64_t lds, int64_t rows, int64_t cols, float* dst,
+                      int64_t ldd, void* stream) {
+  ARX_CHECK_ARG(src && dst, "arx_transpose_f32: null pointer");
+  ARX_CHECK_ARG(lds >= cols && ldd >= rows, "arx_transpose_f32: leading dimension too small");
+  if (rows <= 0 || cols <= 0) return ARX_OK;
+  dim3 grid((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32));
+  k_transpose<<<grid, 256, 0, as_stream(stream)>>>(src, lds, rows, cols, dst, ldd);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
