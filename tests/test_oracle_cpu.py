@@ -392,3 +392,43 @@ def test_oracle_seq_use_concat_gradient_by_finite_differences():
         lo[name] = p0.copy(); lo[name][pick] -= eps
         g_fd = (loss_at(hi) - loss_at(lo)) / (2 * eps)
         np.testing.assert_allclose(g_step, g_fd, rtol=2e-5, atol=1e-8, err_msg='%s%s' % (name, pick))
+
+
+@pytest.mark.parametrize("kind", ['skipgram', 'cbow'])
+def test_oracle_w2v_gradient_by_finite_differences(kind):
+    """word2vec-style restatement (oracle/ref_w2v.py): the gradient implied by one Adagrad step
+    on a context-item row and on a user row equals central differences of the training loss."""
+    from oracle import ref_w2v
+    from arx.utils.synthetic import SyntheticHMF
+    d, B, n_in = 6, 5, 3
+    syn = SyntheticHMF(n_users=20, n_items=30, logit_size=30, seed=2)
+    syn.u_attr.set_model_size(d)
+    syn.i_attr.set_model_size(d)
+    base = {k: v.astype(np.float64) for k, v in syn.glorot_params(d, seed=3, item_output=True, scale=0.6).items()}
+    rng = np.random.default_rng(4)
+    users = rng.integers(0, 20, size=B)
+    ctx = rng.integers(0, 30, size=(n_in, B))
+    tgt = rng.integers(0, 30, size=B)
+
+    def make(params):
+        return ref_w2v.RefW2VModel(kind, d, B, 0.5, syn.u_attr, syn.i_attr, syn.item_ind2logit_ind_dict(),
+                                   syn.logit_ind2item_ind, n_input_items=n_in, loss_function='ce',
+                                   params=params)
+
+    def train_loss(params):
+        # the loss of a step is computed before the update; lr does not enter it
+        return float(make(params).step(list(users), ctx.tolist(), list(tgt)))
+
+    ref = make(base)
+    ref.step(list(users), ctx.tolist(), list(tgt))
+    for name, row in (('itemembed_cat_0', int(syn.i_attr.features_cat[0][ctx[0, 0]])),
+                      ('itemembed_cat_0', int(syn.i_attr.features_cat[0][ctx[2, 1]])),
+                      ('userembed_cat_0', int(syn.u_attr.features_cat[0][users[0]]))):
+        pick = (row, 1)
+        r = (ref.att_emb.params[name][pick] - base[name][pick]) / 0.5
+        g_step = -r * np.sqrt(0.1 / (1.0 - r * r)) if r != 0 else 0.0
+        hi, lo = dict(base), dict(base)
+        hi[name] = base[name].copy(); hi[name][pick] += 1e-5
+        lo[name] = base[name].copy(); lo[name][pick] -= 1e-5
+        g_fd = (train_loss(hi) - train_loss(lo)) / 2e-5
+        np.testing.assert_allclose(g_step, g_fd, rtol=3e-5, atol=1e-9, err_msg='%s %s %s' % (kind, name, pick))
