@@ -51,15 +51,20 @@ class ZeroEmbed(G.Node):
 
 
 class Dropout(G.Node):
-    """tf.nn.dropout (embed_attribute.py:236).  keep_prob is read at run time from
-    rt.keep_prob (1.0 => identity); RNG is counter-based (not TF's Philox), so
-    parity runs use keep_prob = 1.0."""
+    """tf.nn.dropout (embed_attribute.py:236; DropoutWrapper seqModel.py:100,103).  keep_prob is
+    read from rt.keep_prob when the plan is built / captured (1.0 => identity; changing it makes
+    the plans re-capture); RNG is counter-based (not TF's Philox): parity tests replay the
+    drawn masks (`keep`) through the oracle."""
 
     requires_grad = True
 
     def __init__(self, rt, x):
         super().__init__(rt, x.shape, (x,))
         self.keep = None
+        rt.dropout_calls += 1
+        self.sid = rt.dropout_calls          # fixed stream id of this node; the step counter
+                                             # (rt.step_dev, bumped once per train step inside the
+                                             # plan / captured graph) varies the draw per step
 
     def forward(self, train):
         x = self.inputs[0]
@@ -72,8 +77,8 @@ class Dropout(G.Node):
             self.keep = torch.empty(int(np.prod(self.shape)), dtype=torch.uint8, device=self.rt.device)
             self._own = torch.empty(self.shape, dtype=torch.float32, device=self.rt.device)
         self.value = self._own
-        self.rt.dropout_calls += 1
-        ops.dropout_fwd(x.value, kp, self.rt.seed * 1000003 + self.rt.dropout_calls, self.value, self.keep)
+        ops.dropout_fwd_step(x.value, kp, self.rt.seed * 1000003 + self.sid, self.rt.step_dev, self.value,
+                             self.keep)
 
     def alloc_grad(self):
         x = self.inputs[0]
@@ -117,8 +122,6 @@ class EmbeddingAttribute(object):
         self.rt = runtime if runtime is not None else G.Runtime()
         rt = self.rt
         rt.seed = seed
-        rt.keep_prob = 1.0
-        rt.dropout_calls = 0
         self._rng = torch.Generator(device=rt.device)
         self._rng.manual_seed(seed)
         params = params or {}

@@ -425,6 +425,8 @@ class Plan(object):
         self.order = rt.topo(fetch)
         self.graph = None
         self.warm = 0
+        self._kp = rt.keep_prob
+        self.has_dropout = any(type(n).__name__ == 'Dropout' for n in self.order)
         self.tables = []
         self.arenas = []
         if train:
@@ -476,6 +478,8 @@ class Plan(object):
     # ---- execution ----
     def _execute(self):
         rt = self.rt
+        if self.train and self.has_dropout and rt.keep_prob < 1.0:
+            ops.counter_add(rt.step_dev, 1)      # fresh dropout masks on every (replayed) step
         for m in self.masks:
             if not m.fused:
                 m.scatter(0)                               # set_mask (hmf_model.py:209-210)
@@ -679,6 +683,11 @@ class Plan(object):
 
     def run(self):
         rt = self.rt
+        if self.train and self._kp != rt.keep_prob:
+            # keep_prob is baked into the kernel sequence (identity vs masked): rebuild
+            self._kp = rt.keep_prob
+            self.graph = None
+            self.warm = 0
         if rt.use_graph and self.warm >= 1:
             if self.graph is None:
                 g = ops.CapturedGraph()
@@ -720,6 +729,10 @@ class Runtime(object):
         self.use_graph = use_graph
         self.global_step = 0
         self.pre_apply_hooks = []
+        self.seed = 0
+        self.keep_prob = 1.0            # dropout keep probability of train plans (Dropout nodes)
+        self.dropout_calls = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)   # device step counter
         import os as _os
         self.force_sort_path = bool(_os.environ.get('ARX_FORCE_SORT'))
         self.cat_mode = 1 if _os.environ.get('ARX_CAT_ATOMIC') else 0

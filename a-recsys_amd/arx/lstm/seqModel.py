@@ -12,8 +12,7 @@ Same constructor / step / get_batch signatures.  What differs from the TF graph:
     vocabulary, as hmf_model.py:130 does: the reference's own losses_full graph
     for 'mw' (seqModel.py:510) mixes a [mb, n_sampled] mask with [mb, V] logits
     and cannot be built unless n_sampled == V.
-Not implemented (raise): num_layers > 1, dropout < 1,
-withAdagrad=False, beam search (dead code in the reference).
+Not implemented (raise): withAdagrad=False, beam search (dead code in the reference).
 """
 from __future__ import annotations
 
@@ -24,7 +23,7 @@ import torch
 
 from .. import graph as G
 from .. import ops
-from ..attributes.embed_attribute import ZeroEmbed
+from ..attributes.embed_attribute import Dropout, ZeroEmbed
 from ..hmf.hmf_model import _Op, _Var
 from ..utils.checkpoint import Saver
 
@@ -255,6 +254,22 @@ class TopKSoftmax(G.Node):
         ops.row_logsumexp(x, self.lse)
 
 
+class _KeepProb(object):
+    """model.dropoutRate: .eval() reads, .assign(v) returns an op that sets the keep probability."""
+
+    def __init__(self, rt):
+        self.rt = rt
+
+    def eval(self, session=None):
+        return self.rt.keep_prob
+
+    def set(self, v):
+        self.rt.keep_prob = float(v)
+
+    def assign(self, v):
+        return _Op(lambda: self.set(v))
+
+
 class SeqModel(object):
     def __init__(self, buckets, size, num_layers, max_gradient_norm, batch_size, learning_rate,
                  learning_rate_decay_factor, embeddingAttribute, withAdagrad=True, num_samples=512,
@@ -262,10 +277,10 @@ class SeqModel(object):
                  run_options=None, run_metadata=None, use_concat=True, output_feat=1,
                  no_input_item_feature=False, no_user_id=True, topk_n=30, dtype='float32',
                  params=None):
-        if num_layers != 1:
-            raise NotImplementedError("MultiRNNCell with num_layers != 1")
-        if float(dropoutRate) != 1.0:
-            raise NotImplementedError("DropoutWrapper with keep_prob < 1 (parity runs use 1.0)")
+        if num_layers < 1:
+            raise ValueError("num_layers must be >= 1")
+        if not (0.0 < float(dropoutRate) <= 1.0):
+            raise ValueError("dropoutRate (keep probability) must be in (0, 1]")
         if not withAdagrad:
             raise NotImplementedError("GradientDescentOptimizer")
         if loss not in ('ce', 'warp', 'mw'):
@@ -297,7 +312,13 @@ class SeqModel(object):
         self.learning_rate = _Var(lambda: rt.lr_host)
         self.learning_rate_decay_op = _Op(lambda: rt.set_learning_rate(rt.lr_host * self._lr_decay))
         self.global_step = _Var(lambda: rt.global_step)
-        self.dropoutRate = _Var(lambda: 1.0)
+        # seqModel.py:88-91: keep probability of the DropoutWrappers, switched to 1.0 by the runner
+        # around evaluation (lstm/run.py:580,744).  Forward-only plans never drop.
+        rt.keep_prob = float(dropoutRate)
+        self.dropoutRate = _KeepProb(rt)
+        self.dropoutAssign_op = _Op(lambda: self.dropoutRate.set(float(dropoutRate)))
+        self.dropout10_op = _Op(lambda: self.dropoutRate.set(1.0))
+        self.num_layers = num_layers
 
         # feeds (seqModel.py:118-124): time-major [L*mb]
         self.target_ids_all = G.IdsInput(rt, Lmax * B, 'target_id_all')
@@ -307,19 +328,26 @@ class SeqModel(object):
         # LSTM weights: TF names of static_rnn(MultiRNNCell([LSTMCell])) variables
         params = params or {}
         din = size
-        wname, bname = 'rnn/multi_rnn_cell/cell_0/lstm_cell/weights', 'rnn/multi_rnn_cell/cell_0/lstm_cell/biases'
-        if 'lstm_w' in params:
-            W = rt.upload(np.asarray(params['lstm_w'], dtype=np.float32), torch.float32)
-        else:
-            W = m._new_var(wname, (din + size, 4 * size), params)
-        if 'lstm_b' in params:
-            b = rt.upload(np.asarray(params['lstm_b'], dtype=np.float32), torch.float32)
-        else:
-            b = torch.zeros(4 * size, dtype=torch.float32, device=rt.device)    # zero-init biases
-        self.W = G.DenseParam(wname, W.contiguous())
-        self.b = G.DenseParam(bname, b.contiguous())
-        rt.dense[wname] = self.W
-        rt.dense[bname] = self.b
+        # MultiRNNCell([cell] * num_layers) (:99-103): every layer maps size -> size with its own
+        # weights; initial values under 'lstm_w' / 'lstm_b' (layer 0) and 'lstm_w_<l>' / 'lstm_b_<l>'
+        self.Ws, self.bs = [], []
+        for l in range(num_layers):
+            wname = 'rnn/multi_rnn_cell/cell_%d/lstm_cell/weights' % l
+            bname = 'rnn/multi_rnn_cell/cell_%d/lstm_cell/biases' % l
+            wk, bk_ = ('lstm_w', 'lstm_b') if l == 0 else ('lstm_w_%d' % l, 'lstm_b_%d' % l)
+            if wk in params:
+                W = rt.upload(np.asarray(params[wk], dtype=np.float32), torch.float32)
+            else:
+                W = m._new_var(wname, (din + size, 4 * size), params)
+            if bk_ in params:
+                b = rt.upload(np.asarray(params[bk_], dtype=np.float32), torch.float32)
+            else:
+                b = torch.zeros(4 * size, dtype=torch.float32, device=rt.device)    # zero-init biases
+            Wp, bp = G.DenseParam(wname, W.contiguous()), G.DenseParam(bname, b.contiguous())
+            rt.dense[wname], rt.dense[bname] = Wp, bp
+            self.Ws.append(Wp)
+            self.bs.append(bp)
+        self.W, self.b = self.Ws[0], self.bs[0]
 
         rt.clip_coef_dev = torch.ones(1, dtype=torch.float32, device=rt.device)
         self._sq = torch.zeros(1, dtype=torch.float32, device=rt.device)
@@ -372,11 +400,20 @@ class SeqModel(object):
         else:
             item_half = G.EntityEmbed(rt, ids_in, feats, with_bias=False, out_scale=0.5)   # :150-154
             x = SeqInputMean(rt, item_half, self.user_embed, L, B)                           # :155
-        hs = LSTM(rt, x, self.W, self.b, L, B)                                           # :477
+        # DropoutWrapper(input_keep_prob) inside every layer, DropoutWrapper(output_keep_prob) on
+        # the stack (:100-103); the nodes are the identity while rt.keep_prob == 1
+        hs = x
+        bk_drop = []
+        for l in range(self.num_layers):
+            hs = Dropout(rt, hs)
+            bk_drop.append(hs)
+            hs = LSTM(rt, hs, self.Ws[l], self.bs[l], L, B)                                # :477
+        hs = Dropout(rt, hs)
+        bk_drop.append(hs)
         wn = SeqWeights(rt, self.weights_all if L == Lmax else _FloatView(rt, self.weights_all, n), L, B)
         tid = view(self.target_ids_all, 'target_id_%d' % L)
         tgt = view(self.targets_all, 'target_%d' % L)
-        bk = {'L': L}
+        bk = {'L': L, 'dropouts': bk_drop}
         if self.loss == 'mw':
             logits = SeqPrediction(rt, hs, m._pool_embed('sampled', self.output_feat), L, B)  # :492
             tscore = m.get_target_score(hs, tid)                                            # :493

@@ -429,6 +429,16 @@ def dropout_fwd(x, keep_prob, seed, y, keep_mask):
          _p(keep_mask), _stream())
 
 
+def dropout_fwd_step(x, keep_prob, seed, step_dev, y, keep_mask):
+    """dropout whose seed also takes a device-side step counter (int64 tensor [1])."""
+    call("arx_dropout_fwd_step", _p(x), int(x.numel()), float(keep_prob), int(seed) & (2 ** 64 - 1),
+         _p(step_dev), _p(y), _p(keep_mask), _stream())
+
+
+def counter_add(counter_dev, v=1):
+    call("arx_counter_add", _p(counter_dev), int(v), _stream())
+
+
 def dropout_bwd(dy, keep_mask, keep_prob, dx):
     call("arx_dropout_bwd", _p(dy), _p(keep_mask), int(dy.numel()), float(keep_prob), _p(dx), _stream())
 

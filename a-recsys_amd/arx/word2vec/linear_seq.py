@@ -17,6 +17,7 @@ import torch
 from .. import graph as G
 from .. import ops
 from ..attributes import embed_attribute
+from ..attributes.embed_attribute import Dropout
 from ..hmf.hmf_model import TopK, _Op, _Var
 from ..utils.checkpoint import Saver
 
@@ -118,7 +119,7 @@ class LinearSeq(object):
             x_train = ContextMean(rt, first, user, 1, mb)                         # skipgram_model.py:87
         if float(dropout) != 1.0:
             rt.keep_prob = float(dropout)
-            x_train = G.Dropout(rt, x_train)                                      # :88
+            x_train = Dropout(rt, x_train)                                      # :88
         x_test = user if n_input_items == 0 else mean_all                         # :91-99
         logits = m.get_prediction(x_train, output_feat=output_feat)
         logits_test = m.get_prediction(x_test, output_feat=output_feat)

@@ -169,9 +169,12 @@ __device__ __forceinline__ uint32_t mix32(uint64_t z) {
   return (uint32_t)(z >> 32);
 }
 
+// `step` (nullable): device-side step counter added into the seed, so that a captured
+// (hipGraph-replayed) launch draws a fresh mask every replay
 __global__ void k_dropout_fwd(const float* __restrict__ x, int64_t n, float keep_prob,
-                              uint64_t seed, float* __restrict__ y,
-                              uint8_t* __restrict__ keep) {
+                              uint64_t seed, const uint64_t* __restrict__ step,
+                              float* __restrict__ y, uint8_t* __restrict__ keep) {
+  if (step) seed += *step * 0x9e3779b97f4a7c15ull;
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   float inv = 1.f / keep_prob;
@@ -182,6 +185,8 @@ __global__ void k_dropout_fwd(const float* __restrict__ x, int64_t n, float keep
     y[i] = k ? x[i] * inv : 0.f;
   }
 }
+
+__global__ void k_counter_add(uint64_t* c, uint64_t v) { *c += v; }
 
 __global__ void k_dropout_bwd(const float* __restrict__ dy, const uint8_t* __restrict__ keep,
                               int64_t n, float keep_prob, float* __restrict__ dx) {
@@ -370,8 +375,26 @@ int arx_dropout_fwd(const float* x, int64_t n, float keep_prob, uint64_t seed, f
   ARX_CHECK_ARG(x && y, "arx_dropout_fwd: null pointer");
   ARX_CHECK_ARG(keep_prob > 0.f && keep_prob <= 1.f, "arx_dropout_fwd: keep_prob must be in (0,1]");
   if (n <= 0) return ARX_OK;
-  k_dropout_fwd<<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(x, n, keep_prob, seed, y,
+  k_dropout_fwd<<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(x, n, keep_prob, seed, nullptr, y,
                                                                  keep_mask);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_dropout_fwd_step(const float* x, int64_t n, float keep_prob, uint64_t seed,
+                         const uint64_t* step_dev, float* y, uint8_t* keep_mask, void* stream) {
+  ARX_CHECK_ARG(x && y && step_dev, "arx_dropout_fwd_step: null pointer");
+  ARX_CHECK_ARG(keep_prob > 0.f && keep_prob <= 1.f, "arx_dropout_fwd_step: keep_prob must be in (0,1]");
+  if (n <= 0) return ARX_OK;
+  k_dropout_fwd<<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(x, n, keep_prob, seed, step_dev, y,
+                                                                 keep_mask);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_counter_add(uint64_t* counter_dev, uint64_t v, void* stream) {
+  ARX_CHECK_ARG(counter_dev, "arx_counter_add: null pointer");
+  k_counter_add<<<1, 1, 0, as_stream(stream)>>>(counter_dev, v);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

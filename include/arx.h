@@ -346,6 +346,11 @@ int arx_dropout_fwd(const float* x, int64_t n, float keep_prob, uint64_t seed, f
                     uint8_t* keep_mask, void* stream);
 int arx_dropout_bwd(const float* dy, const uint8_t* keep_mask, int64_t n, float keep_prob,
                     float* dx, void* stream);
+/* Same draw with a DEVICE-side step counter mixed into the seed: a launch captured in a hipGraph
+ * yields a new mask on every replay once the graph also bumps the counter (arx_counter_add). */
+int arx_dropout_fwd_step(const float* x, int64_t n, float keep_prob, uint64_t seed,
+                         const uint64_t* step_dev, float* y, uint8_t* keep_mask, void* stream);
+int arx_counter_add(uint64_t* counter_dev, uint64_t v, void* stream);
 /* elementwise activation for the optional MLP (hmf_model.py:80-94): kind 0=relu 1=tanh */
 int arx_act_fwd(const float* x, int64_t n, int kind, float* y, void* stream);
 int arx_act_bwd(const float* y, const float* dy, int64_t n, int kind, float* dx, void* stream);

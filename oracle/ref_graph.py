@@ -650,13 +650,19 @@ class RefLatentProductModel(object):
         return dh0 * self._dact(h0, u)
 
     def step(self, user_input, item_input, item_sampled=None, item_sampled_id2idx=None,
-             forward_only=False, recommend=False, loss=None):
-        """hmf_model.py:162-228 (session dropped; keep_prob == 1)."""
+             forward_only=False, recommend=False, loss=None, keep_prob=1.0, user_mask=None):
+        """hmf_model.py:162-228 (session dropped).  tf.nn.dropout on the user embedding
+        (embed_attribute.py:236, hmf_model.py:78): `user_mask` replays an externally drawn 0/1
+        keep mask [mb, d] -- u * mask / keep_prob."""
         m = self.att_emb
         loss = loss or self.loss_function
         if item_sampled is not None and loss in ('mw', 'mce'):
             m.update_sampled(item_sampled)                          # :206-207
         u, c_user = m.get_batch_user(user_input, concat=False)      # :78
+        drop = None
+        if user_mask is not None and keep_prob < 1.0:
+            drop = np.asarray(user_mask, dtype=self.dt) / self.dt.type(keep_prob)
+            u = u * drop
         c_mlp = None
         if self.nonlinear in ('relu', 'tanh'):
             u, c_mlp = self._mlp_fwd(u)
@@ -698,6 +704,8 @@ class RefLatentProductModel(object):
             d_u = d_u + m.get_target_score_bwd(c_t, d_t, grads)
         if c_mlp is not None:
             d_u = self._mlp_bwd(c_mlp, d_u, grads)
+        if drop is not None:
+            d_u = d_u * drop
         m.get_batch_user_bwd(c_user, d_u, grads)
         m.apply_gradients(grads, self.learning_rate)                # :150
         self.global_step += 1

@@ -76,7 +76,7 @@ class RefSeqModel(object):
 
     def __init__(self, L, size, max_gradient_norm, batch_size, learning_rate, embAttr,
                  loss='mw', no_user_id=False, no_input_item_feature=False, output_feat=1,
-                 params=None, withAdagrad=True, use_concat=False):
+                 params=None, withAdagrad=True, use_concat=False, num_layers=1):
         self.L = L
         self.size = size
         self.max_gradient_norm = max_gradient_norm
@@ -90,12 +90,18 @@ class RefSeqModel(object):
         self.withAdagrad = withAdagrad
         dt = embAttr.dt
         self.dt = dt
-        self.W = np.array(params['lstm_w'], dtype=dt)     # [din+h, 4h]
-        self.b = np.array(params['lstm_b'], dtype=dt)     # [4h]
-        embAttr.params['lstm_w'] = self.W
-        embAttr.params['lstm_b'] = self.b
-        embAttr.slots['lstm_w'] = np.full(self.W.shape, 0.1, dt)
-        embAttr.slots['lstm_b'] = np.full(self.b.shape, 0.1, dt)
+        # MultiRNNCell([cell] * num_layers) (:99-103): one (W, b) per layer, every layer size -> size
+        self.num_layers = num_layers
+        self.Ws, self.bs, self.wnames, self.bnames = [], [], [], []
+        for l in range(num_layers):
+            wn, bn = ('lstm_w', 'lstm_b') if l == 0 else ('lstm_w_%d' % l, 'lstm_b_%d' % l)
+            W = np.array(params[wn], dtype=dt)            # [din+h, 4h]
+            b = np.array(params[bn], dtype=dt)            # [4h]
+            embAttr.params[wn], embAttr.params[bn] = W, b
+            embAttr.slots[wn] = np.full(W.shape, 0.1, dt)
+            embAttr.slots[bn] = np.full(b.shape, 0.1, dt)
+            self.Ws.append(W); self.bs.append(b); self.wnames.append(wn); self.bnames.append(bn)
+        self.W, self.b = self.Ws[0], self.bs[0]
         # use_concat (:130-146): input_t = concat_f(user) . w_input_user + concat_f(item_t) . w_input_item
         self.use_concat = use_concat
         if use_concat:
@@ -127,7 +133,9 @@ class RefSeqModel(object):
                                                no_attribute=self.no_input_item_feature)
                 it = np.mean(np.stack(feats, 0), 0)
                 xs.append(np.mean(np.stack([u, it], 0), 0))
-        hs, _, _ = lstm_fwd(np.stack(xs, 0), self.W, self.b, 1.0)
+        hs = np.stack(xs, 0)
+        for l in range(self.num_layers):                                    # keep_prob == 1 when recommending
+            hs, _, _ = lstm_fwd(hs, self.Ws[l], self.bs[l], 1.0)
         results = []
         for i, pos in enumerate(positions):
             logits, _ = m.get_prediction(hs[pos], 'full', self.output_feat)
@@ -139,8 +147,12 @@ class RefSeqModel(object):
         return results
 
     def step(self, user_input, item_inputs, targets, target_weights, item_sampled=None,
-             item_sampled_id2idx=None, forward_only=False):
-        """seqModel.py:289-324; inputs are time-major python lists [L][B]."""
+             item_sampled_id2idx=None, forward_only=False, keep_prob=1.0, masks=None):
+        """seqModel.py:289-324; inputs are time-major python lists [L][B].
+        Dropout (DropoutWrapper, :100,103): `masks` = {'in': [0/1 array [L,B,size] per layer],
+        'out': 0/1 array [L,B,size]} replays externally drawn keep masks -- the layer input is
+        x * mask / keep_prob (input_keep_prob, every layer), the top output likewise
+        (output_keep_prob); the recurrent state is never dropped."""
         m, L, B, dt = self.m, self.L, self.batch_size, self.dt
         if item_sampled is not None and self.loss in ('mw', 'mce'):
             m.update_sampled(item_sampled)                                  # :306-307
@@ -170,7 +182,16 @@ class RefSeqModel(object):
                 xs.append(np.mean(np.stack([u, it], 0), 0))                     # :155
                 c_items.append(c_it)
         x = np.stack(xs, 0)
-        hs, cs, gates = lstm_fwd(x, self.W, self.b, 1.0)                    # :477
+        kp = dt.type(keep_prob)
+        drop = masks is not None and keep_prob < 1.0 and not forward_only
+        layers = []
+        inp = x
+        for l in range(self.num_layers):
+            xin = inp * (np.asarray(masks['in'][l], dtype=dt) / kp) if drop else inp
+            hs_l, cs_l, gates_l = lstm_fwd(xin, self.Ws[l], self.bs[l], 1.0)       # :477
+            layers.append((xin, hs_l, cs_l, gates_l))
+            inp = hs_l
+        hs = inp * (np.asarray(masks['out'], dtype=dt) / kp) if drop else inp
         # ---- per-step scorer + loss (:480-493) ----
         the_loss = self.loss
         if forward_only:
@@ -211,9 +232,16 @@ class RefSeqModel(object):
             if c_t is not None:
                 dh = dh + m.get_target_score_bwd(c_t, d_t, grads)
             dhs[t] = dh
-        dz, dx, dW, db = lstm_bwd(x, self.W, hs, cs, gates, dhs)
-        grads.add_dense('lstm_w', dW)
-        grads.add_dense('lstm_b', db)
+        if drop:
+            dhs = dhs * (np.asarray(masks['out'], dtype=dt) / kp)
+        for l in reversed(range(self.num_layers)):
+            xin, hs_l, cs_l, gates_l = layers[l]
+            dz, dx, dW, db = lstm_bwd(xin, self.Ws[l], hs_l, cs_l, gates_l, dhs)
+            grads.add_dense(self.wnames[l], dW)
+            grads.add_dense(self.bnames[l], db)
+            if drop:
+                dx = dx * (np.asarray(masks['in'][l], dtype=dt) / kp)
+            dhs = dx
         if self.use_concat:
             Wu, Wi = m.params['w_input_user'], m.params['w_input_item']
             dxs = dx.sum(0)

@@ -205,3 +205,43 @@ def test_recommend_streaming_topk_equals_materialised(dev, monkeypatch):
     rr = ref.step(list(users), list(items), recommend=True)
     np.testing.assert_array_equal(ra, rr)
     np.testing.assert_array_equal(rb, rr)
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_hmf_user_dropout_replayed_through_oracle(dev, use_graph):
+    """hmf_model.py:78 / run_hmf.py:35 (keep_prob default 0.5): dropout on the user embedding.
+    The device draws the masks (new on every step, also under hipGraph replay); the oracle
+    replays them."""
+    from arx.utils.synthetic import SyntheticHMF
+    from arx.hmf.hmf_model import LatentProductModel
+    d, B, S, keep = 32, 64, 128, 0.5
+    syn = SyntheticHMF(seed=5, **CFG_HET)
+    params = syn.glorot_params(d, seed=6, scale=0.5)
+    i2l, l2i = syn.item_ind2logit_ind_dict(), syn.logit_ind2item_ind
+    model = LatentProductModel(syn.n_users, syn.n_items, d, 1, B, 0.5, 1.0, syn.u_attr, syn.i_attr, i2l, l2i,
+                               loss_function='mw', n_sampled=S, params=params, dropout=keep,
+                               use_graph=use_graph)
+    ref = rg.RefLatentProductModel(d, B, 0.5, syn.u_attr, syn.i_attr, i2l, l2i, loss_function='mw',
+                                   n_sampled=S, params=params, dtype=np.float64)
+    pos = syn.positives_dict()
+    model.prepare_warp(pos, pos)
+    ref.prepare_warp(pos, pos)
+    rng = np.random.default_rng(8)
+    pool = syn.sample_pool(S, rng)
+    id2idx = {int(v): i for i, v in enumerate(pool)}
+    prev = None
+    for step in range(4):
+        users, items = syn.sample_batch(B, rng)
+        ps = pool if step == 0 else None
+        l_got = model.step(None, list(users), list(items), None, ps, id2idx if ps is not None else None, loss='mw')
+        mask = model.embedded_user.keep.cpu().numpy().reshape(B, d)
+        assert abs(mask.mean() - keep) < 0.05
+        if prev is not None:
+            assert (mask != prev).any()
+        prev = mask
+        l_ref = ref.step(list(users), list(items), ps, id2idx, loss='mw', keep_prob=keep, user_mask=mask)
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='step %d' % step)
+        _compare_state(model, ref)
+    e_ref = ref.step(list(users), list(items), forward_only=True, loss='mw')
+    e_got = model.step(None, list(users), list(items), forward_only=True, loss='mw')
+    np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4
 
 
-def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False, use_concat=False):
+def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False, use_concat=False, num_layers=1,
+           keep=1.0):
     from arx.attributes.embed_attribute import EmbeddingAttribute
     from arx.lstm.seqModel import SeqModel
     from arx.utils.synthetic import SyntheticHMF
@@ -23,6 +24,9 @@ def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False, use_concat=Fa
     rng = np.random.default_rng(seed + 2)
     params['lstm_w'] = (rng.standard_normal((2 * size, 4 * size)) * 0.15).astype(np.float32)
     params['lstm_b'] = (rng.standard_normal((4 * size,)) * 0.05).astype(np.float32)
+    for l in range(1, num_layers):
+        params['lstm_w_%d' % l] = (rng.standard_normal((2 * size, 4 * size)) * 0.15).astype(np.float32)
+        params['lstm_b_%d' % l] = (rng.standard_normal((4 * size,)) * 0.05).astype(np.float32)
     if use_concat:                                   # seqModel.py:132-137 w_input_user / w_input_item
         du = sum(syn.u_attr._embedding_size_list_cat[(1 if no_user_id else 0):]) + \
             sum(syn.u_attr._embedding_size_list_mulhot)
@@ -35,13 +39,13 @@ def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False, use_concat=Fa
     l2i = syn.logit_ind2item_ind
     n_s = S if loss == 'mw' else None
     emb = EmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i, params=params)
-    model = SeqModel([L], size, 1, clip, B, 0.5, 0.83, emb, loss=loss, use_concat=use_concat,
-                     no_user_id=no_user_id, START_ID=START, params=params)
+    model = SeqModel([L], size, num_layers, clip, B, 0.5, 0.83, emb, loss=loss, use_concat=use_concat,
+                     no_user_id=no_user_id, START_ID=START, params=params, dropoutRate=keep)
     remb = rg.RefEmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i,
                                     params={k: v for k, v in params.items() if not k.startswith('lstm')},
                                     dtype=np.float64)
     ref = ref_lstm.RefSeqModel(L, size, clip, B, 0.5, remb, loss=loss, no_user_id=no_user_id,
-                               params=params, use_concat=use_concat)
+                               params=params, use_concat=use_concat, num_layers=num_layers)
     pos = syn.positives_dict()
     emb.prepare_warp(pos, pos)
     remb.prepare_warp(pos, pos)
@@ -63,6 +67,9 @@ def _compare(emb, model, remb, ref, rtol=RTOL, atol=3e-6):
         np.testing.assert_allclose(v, remb.params[k], rtol=rtol, atol=atol, err_msg=k)
     np.testing.assert_allclose(model.W.w.cpu().numpy(), ref.W, rtol=rtol, atol=atol, err_msg='lstm_w')
     np.testing.assert_allclose(model.b.w.cpu().numpy(), ref.b, rtol=rtol, atol=atol, err_msg='lstm_b')
+    for l in range(1, getattr(model, 'num_layers', 1)):
+        np.testing.assert_allclose(model.Ws[l].w.cpu().numpy(), ref.Ws[l], rtol=rtol, atol=atol, err_msg='lstm_w_%d' % l)
+        np.testing.assert_allclose(model.bs[l].w.cpu().numpy(), ref.bs[l], rtol=rtol, atol=atol, err_msg='lstm_b_%d' % l)
     if getattr(model, 'use_concat', False):
         np.testing.assert_allclose(model.Wi.w.cpu().numpy(), remb.params['w_input_item'], rtol=rtol,
                                    atol=atol, err_msg='w_input_item')
@@ -199,3 +206,54 @@ def test_seq_use_concat(dev, cfg, loss, S, clip, no_uid):
     for (u0, v0, i0), (u1, v1, i1) in zip(r_got, r_ref):
         np.testing.assert_array_equal(np.asarray(i0), i1)
         np.testing.assert_allclose(v0, v1, rtol=RTOL, atol=1e-9)
+
+
+@pytest.mark.parametrize("loss,S,layers,keep", [('mw', 64, 2, 0.6), ('ce', None, 1, 0.5), ('mw', 64, 3, 1.0)])
+def test_seq_layers_and_dropout(dev, loss, S, layers, keep):
+    """MultiRNNCell([cell] * num_layers) with DropoutWrapper(input_keep_prob) per layer and
+    DropoutWrapper(output_keep_prob) on the stack (seqModel.py:99-103).  The device draws its own
+    masks (counter RNG, new on every hipGraph replay); the oracle replays them."""
+    size, B, L = 64, 16, 4
+    syn, emb, model, remb, ref = _build(CFG_HET, loss, size, B, L, S, 5.0, seed=23, num_layers=layers, keep=keep)
+    rng = np.random.default_rng(29)
+    pool = id2idx = None
+    if loss == 'mw':
+        pool = syn.sample_pool(S, rng)
+        id2idx = {int(v): i for i, v in enumerate(pool)}
+    prev = None
+    for step in range(4):
+        users, inp, tg, w = _batch(syn, rng, L, B)
+        ps = pool if step == 0 else None
+        l_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, ps, id2idx)
+        masks = None
+        if keep < 1.0:
+            nodes = model._bucket(0)['dropouts']
+            ms = [n.keep.cpu().numpy().reshape(L, B, size) for n in nodes]
+            assert len(ms) == layers + 1
+            masks = {'in': ms[:layers], 'out': ms[layers]}
+            frac = np.mean([m.mean() for m in ms])
+            assert abs(frac - keep) < 0.03, frac
+            if prev is not None:                       # a fresh draw on every step (graph replays included)
+                assert any((a != b).any() for a, b in zip(ms, prev))
+            assert (ms[0] != ms[-1]).any()
+            prev = ms
+        l_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), ps, id2idx, keep_prob=keep,
+                         masks=masks)
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='loss step %d' % step)
+        np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL,
+                                   err_msg='global norm step %d' % step)
+        _compare(emb, model, remb, ref)
+    # evaluation never drops (lstm/run.py:580 sets the rate to 1.0 around it)
+    users, inp, tg, w = _batch(syn, rng, L, B)
+    e_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), forward_only=True)
+    e_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, forward_only=True)
+    np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
+    # dropout10_op / dropoutAssign_op switch the training plan between identity and masked
+    model.dropout10_op.run()
+    assert model.dropoutRate.eval() == 1.0
+    l_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), None, id2idx)
+    l_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, None, id2idx)
+    np.testing.assert_allclose(l_got, l_ref, rtol=RTOL)
+    _compare(emb, model, remb, ref)
+    model.dropoutAssign_op.run()
+    assert model.dropoutRate.eval() == keep
