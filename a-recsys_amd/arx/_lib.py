@@ -34,6 +34,7 @@ PROTOTYPES = {
     "arx_csr_expand_workspace_bytes": (sz, [i64]),
     "arx_csr_expand": (cint, [i32p, i32p, i32p, i32p, i64, i32p, i32p, i64, i32p, i32p, i32, i32,
                               i32, f32, f32p, vp, sz, vp]),
+    "arx_bag_expand_padded": (cint, [i32p, i32p, i32p, i32p, i64, cint, i32, i32, f32, i32p, i32p, f32p, vp]),
     "arx_sparse_site_onehot": (cint, [i32p, i32p, i64, i32, f32, i32p, i32p, f32p, vp]),
     "arx_shard_route": (cint, [i32p, i64, cint, cint, i32, i32p, i32p, vp]),
     "arx_copy_2d": (cint, [f32p, i64, f32p, i64, i64, i64, vp]),

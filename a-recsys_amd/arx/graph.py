@@ -55,6 +55,7 @@ class SparseSite(object):
         self.maps = maps          # cat: (cat_map,) ; mulhot: (vals, starts, lens)
         self.n = n                # lookups (rows of the gradient source)
         self.cap = n if kind == 'cat' else n * max_len
+        self.max_len = max_len
         self.coef = coef
         self.node = node          # EntityEmbed node owning G rows (arena slice)
         self.col_off = 0          # column offset inside the node's grad (concat)
@@ -466,8 +467,6 @@ class Plan(object):
                 'keys': torch.full((total,), KEY_NONE, dtype=torch.int32, device=rt.device),
                 'src': torch.zeros((total,), dtype=torch.int32, device=rt.device),
                 'coef': torch.zeros((total,), dtype=torch.float32, device=rt.device),
-                'offs': torch.zeros((max(s.n for s in sites) + 1,), dtype=torch.int32, device=rt.device),
-                'tot': torch.zeros((1,), dtype=torch.int32, device=rt.device),
                 'hot': torch.zeros((total // 16 + 4,), dtype=torch.int32, device=rt.device),
             }
             widths = set(s.node.shape[1] for s in sites)
@@ -601,17 +600,13 @@ class Plan(object):
                        keys=torch.empty(n, dtype=torch.int32, device=dev),
                        src=torch.empty(n, dtype=torch.int32, device=dev),
                        coef=torch.empty(n, dtype=torch.float32, device=dev),
-                       offs=[torch.zeros((x.n + 1,), dtype=torch.int32, device=dev) for x in xsites],
-                       tot=torch.zeros((1,), dtype=torch.int32, device=dev),
                        any_bias=any(t[2] is not None for t in tables))
             cache[key] = ent
         args = ent['args']
-        for x, off, offs in zip(ent['xsites'], args.extra_off, ent['offs']):   # multi-hot lookups
-            ops.csr_expand(x.maps[0], x.maps[1], x.maps[2], x.ids_node.value, x.cap, rt.ws,
-                           pad_token=KEY_NONE, pad_seg=0, seg_base=x.node.row0, coef_scale=x.coef,
-                           want_coef=True,
-                           out=(ent['keys'][off:off + x.cap], ent['src'][off:off + x.cap], offs,
-                                ent['tot'], ent['coef'][off:off + x.cap]))
+        for x, off in zip(ent['xsites'], args.extra_off):   # multi-hot lookups: padded slots, the sort drops the pads
+            ops.bag_expand_padded(x.maps[0], x.maps[1], x.maps[2], x.ids_node.value, x.max_len, x.node.row0,
+                                  x.coef, ent['keys'][off:off + x.cap], ent['src'][off:off + x.cap],
+                                  ent['coef'][off:off + x.cap])
         node0 = (group[0][1] + group[0][2])[0].node
         ops.sparse_adagrad_cat_multi(args, node0.arena, node0.arena_b if ent['any_bias'] else None,
                                      rt.lr, ent['keys'], ent['src'], ent['coef'], rt.ws,
@@ -659,10 +654,8 @@ class Plan(object):
                 if s.kind == 'cat':
                     ops.sparse_site_onehot(s.maps[0], s.ids_node.value, node.row0, s.coef, ks, ss, cs)
                 else:
-                    ops.csr_expand(s.maps[0], s.maps[1], s.maps[2], s.ids_node.value, s.cap, rt.ws,
-                                   pad_token=KEY_NONE, pad_seg=0, seg_base=node.row0,
-                                   coef_scale=s.coef, want_coef=True,
-                                   out=(ks, ss, bufs['offs'], bufs['tot'], cs))
+                    ops.bag_expand_padded(s.maps[0], s.maps[1], s.maps[2], s.ids_node.value, s.max_len,
+                                          node.row0, s.coef, ks, ss, cs)
             if not live:
                 continue
             node0 = sites[0].node

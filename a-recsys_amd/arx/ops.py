@@ -95,6 +95,18 @@ def csr_expand(vals, starts, lens, row_ids, capacity, ws, pad_token=KEY_NONE, pa
     return tok, seg, offs, tot, coef
 
 
+def bag_expand_padded(vals, starts, lens, row_ids, max_len, seg_base, coef_scale, keys_out, src_out,
+                      coef_out, pad_token=KEY_NONE):
+    """Un-compacted bag expansion for K7 (slot r*max_len + j; pads = pad_token): one launch."""
+    B = int(row_ids.shape[0]) if row_ids is not None else int(lens.shape[0])
+    if int(keys_out.shape[0]) < B * int(max_len):
+        raise ValueError("bag_expand_padded: output buffers hold %d < %d entries"
+                         % (int(keys_out.shape[0]), B * int(max_len)))
+    call("arx_bag_expand_padded", _p(vals), _p(starts), _p(lens), _p(row_ids), B, int(max_len),
+         int(pad_token), int(seg_base), float(coef_scale), _p(keys_out), _p(src_out), _p(coef_out),
+         _stream())
+
+
 def sparse_site_onehot(cat_map, ids, row_base, coef, keys_out, src_out, coef_out):
     call("arx_sparse_site_onehot", _p(cat_map), _p(ids), int(ids.shape[0]), int(row_base),
          float(coef), _p(keys_out), _p(src_out), _p(coef_out), _stream())

@@ -336,6 +336,30 @@ static inline int grid_waves(int64_t nwaves) {
   return (int)g;
 }
 
+
+// Padded (un-compacted) bag expansion for the gradient scatter: slot r * max_len + j holds token j
+// of bag r, slots past the bag's length hold pad_token.  No prefix sums -- K7's sort drops the
+// pads in its first pass anyway, so compacting them first (arx_csr_expand: four launches) buys
+// nothing there.  Order of the live entries = (r, j), the same as the compact form.
+__global__ __launch_bounds__(256) void k_bag_expand_padded(
+    const int32_t* __restrict__ vals, const int32_t* __restrict__ starts,
+    const int32_t* __restrict__ lens, const int32_t* __restrict__ row_ids, int64_t B, int max_len,
+    int32_t pad_token, int32_t seg_base, float coef_scale, int32_t* __restrict__ token_ids,
+    int32_t* __restrict__ segids, float* __restrict__ coef_out) {
+  const int64_t total = B * (int64_t)max_len;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = q / max_len;
+    const int j = (int)(q - r * max_len);
+    const int32_t row = row_ids ? row_ids[r] : (int32_t)r;
+    const int32_t len = lens[row];
+    const bool live = j < len;
+    token_ids[q] = live ? vals[(int64_t)starts[row] + j] : pad_token;
+    segids[q] = seg_base + (int32_t)r;
+    if (coef_out) coef_out[q] = live ? coef_scale / (float)len : 0.f;
+  }
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -514,6 +538,23 @@ int arx_csr_expand(const int32_t* vals, const int32_t* starts, const int32_t* le
                                          capacity, pad_token, pad_seg, seg_base, coef_scale, coef_out);
     ARX_CHECK_LAUNCH();
   }
+  return ARX_OK;
+}
+
+int arx_bag_expand_padded(const int32_t* vals, const int32_t* starts, const int32_t* lens,
+                          const int32_t* row_ids, int64_t B, int max_len, int32_t pad_token,
+                          int32_t seg_base, float coef_scale, int32_t* token_ids, int32_t* segids,
+                          float* coef_out, void* stream) {
+  ARX_CHECK_ARG(vals && starts && lens && token_ids && segids, "arx_bag_expand_padded: null pointer");
+  ARX_CHECK_ARG(B >= 0 && max_len > 0, "arx_bag_expand_padded: bad size");
+  if (B == 0) return ARX_OK;
+  int64_t g = ceil_div(B * (int64_t)max_len, 256);
+  const int64_t cap = (int64_t)cu_count() * 16;
+  if (g > cap) g = cap;
+  k_bag_expand_padded<<<(int)g, 256, 0, as_stream(stream)>>>(vals, starts, lens, row_ids, B, max_len,
+                                                             pad_token, seg_base, coef_scale, token_ids,
+                                                             segids, coef_out);
+  ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
 

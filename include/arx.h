@@ -58,6 +58,14 @@ int arx_csr_expand(const int32_t* vals, const int32_t* starts, const int32_t* le
                    int32_t pad_token, int32_t pad_seg,
                    int32_t seg_base, float coef_scale, float* coef_out,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* The same expansion WITHOUT compaction, for the gradient scatter only: slot r*max_len + j holds
+ * token j of bag r (segid = seg_base + r, coef = coef_scale / len), slots with j >= len hold
+ * pad_token (coef 0).  One launch, no prefix sums: arx_sparse_adagrad* drop the pads in the first
+ * pass of their sort.  Buffers hold B*max_len entries (max_len >= every lens[row]). */
+int arx_bag_expand_padded(const int32_t* vals, const int32_t* starts, const int32_t* lens,
+                          const int32_t* row_ids, int64_t B, int max_len, int32_t pad_token,
+                          int32_t seg_base, float coef_scale, int32_t* token_ids, int32_t* segids,
+                          float* coef_out, void* stream);
 /* One-hot twin of the above for the gradient scatter (a17): keys_out[i] =
  * cat_map ? cat_map[ids[i]] : ids[i]; src_out[i] = row_base + i; coef_out[i] = coef. */
 int arx_sparse_site_onehot(const int32_t* cat_map, const int32_t* ids, int64_t n,
