@@ -103,6 +103,7 @@ PROTOTYPES = {
     "arx_dropout_bwd": (cint, [f32p, u8p, i64, f32, f32p, vp]),
     "arx_dropout_fwd_step": (cint, [f32p, i64, f32, u64, vp, f32p, u8p, vp]),
     "arx_counter_add": (cint, [vp, u64, vp]),
+    "arx_copy_words": (cint, [cint, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp]),
     "arx_act_fwd": (cint, [f32p, i64, cint, f32p, vp]),
     "arx_act_bwd": (cint, [f32p, f32p, i64, cint, f32p, vp]),
     "arx_add_col_bias": (cint, [f32p, i64, i64, i64, f32p, vp]),

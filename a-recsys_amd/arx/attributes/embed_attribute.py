@@ -376,12 +376,10 @@ class EmbeddingAttribute(object):
         the fly by the fused gather kernel; what persists is the id list and the
         item -> slot map (the device twin of item_sampled_id2idx)."""
         buf = self.i_indices['sampled_pass']
-        if self._old_pool is None:
-            self._old_pool = torch.empty_like(buf.value)
-        else:
-            ops.slot_map_set(self.item2slot, self._old_pool, clear=True)
+        if self._old_pool is not None:
+            ops.slot_map_set(self.item2slot, buf.value, clear=True)     # buf still holds the previous pool
+        self._old_pool = True
         buf.feed(item_sampled)
-        self._old_pool.copy_(buf.value)
         ops.slot_map_set(self.item2slot, buf.value, clear=False)
 
     # ------------------------------------------------------------------ loss

@@ -447,6 +447,22 @@ def dropout_fwd_step(x, keep_prob, seed, step_dev, y, keep_mask):
          _p(step_dev), _p(y), _p(keep_mask), _stream())
 
 
+def copy_words(pairs):
+    """[(src, dst), ...] device tensors of 4-byte elements, equal sizes per pair; <= 4 per launch."""
+    import ctypes as C
+    for k in range(0, len(pairs), 4):
+        grp = pairs[k:k + 4]
+        n = len(grp)
+        for s_, d_ in grp:
+            if s_.element_size() != 4 or d_.element_size() != 4 or s_.numel() != d_.numel() \
+                    or not s_.is_contiguous() or not d_.is_contiguous():
+                raise ValueError("copy_words: contiguous 4-byte tensors of equal size expected")
+        src = (C.c_void_p * n)(*[_p(s_) for s_, _ in grp])
+        dst = (C.c_void_p * n)(*[_p(d_) for _, d_ in grp])
+        cnt = (C.c_int64 * n)(*[int(s_.numel()) for s_, _ in grp])
+        call("arx_copy_words", n, src, dst, cnt, _stream())
+
+
 def counter_add(counter_dev, v=1):
     call("arx_counter_add", _p(counter_dev), int(v), _stream())
 

@@ -188,6 +188,25 @@ __global__ void k_dropout_fwd(const float* __restrict__ x, int64_t n, float keep
 
 __global__ void k_counter_add(uint64_t* c, uint64_t v) { *c += v; }
 
+// up to 4 device-to-device copies of 4-byte words in ONE launch (placeholder feeds: the
+// runtime's blit kernel costs ~5-10 us per hipMemcpyAsync at these sizes)
+struct CopySet {
+  const uint32_t* src[4];
+  uint32_t* dst[4];
+  int64_t n[4];
+  int count;
+};
+__global__ __launch_bounds__(256) void k_copy_words(CopySet cs) {
+  for (int a = 0; a < cs.count; ++a) {
+    const uint32_t* __restrict__ s = cs.src[a];
+    uint32_t* __restrict__ d = cs.dst[a];
+    const int64_t n = cs.n[a];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+      d[i] = s[i];
+  }
+}
+
 __global__ void k_dropout_bwd(const float* __restrict__ dy, const uint8_t* __restrict__ keep,
                               int64_t n, float keep_prob, float* __restrict__ dx) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -388,6 +407,26 @@ int arx_dropout_fwd_step(const float* x, int64_t n, float keep_prob, uint64_t se
   if (n <= 0) return ARX_OK;
   k_dropout_fwd<<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(x, n, keep_prob, seed, step_dev, y,
                                                                  keep_mask);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_copy_words(int count, const void* const* src, void* const* dst, const int64_t* n_words,
+                   void* stream) {
+  ARX_CHECK_ARG(count >= 0 && count <= 4, "arx_copy_words: at most 4 copies per call");
+  ARX_CHECK_ARG(count == 0 || (src && dst && n_words), "arx_copy_words: null pointer");
+  CopySet cs = {};
+  int64_t nmax = 0;
+  for (int a = 0; a < count; ++a) {
+    ARX_CHECK_ARG(n_words[a] >= 0 && (n_words[a] == 0 || (src[a] && dst[a])), "arx_copy_words: bad entry");
+    cs.src[a] = reinterpret_cast<const uint32_t*>(src[a]);
+    cs.dst[a] = reinterpret_cast<uint32_t*>(dst[a]);
+    cs.n[a] = n_words[a];
+    if (n_words[a] > nmax) nmax = n_words[a];
+  }
+  cs.count = count;
+  if (nmax == 0) return ARX_OK;
+  k_copy_words<<<grid_for(nmax, 256), 256, 0, as_stream(stream)>>>(cs);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
