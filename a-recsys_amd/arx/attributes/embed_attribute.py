@@ -380,6 +380,7 @@ class EmbeddingAttribute(object):
             ops.slot_map_set(self.item2slot, buf.value, clear=True)     # buf still holds the previous pool
         self._old_pool = True
         buf.feed(item_sampled)
+        self.rt.flush_feeds()
         ops.slot_map_set(self.item2slot, buf.value, clear=False)
 
     # ------------------------------------------------------------------ loss
@@ -475,6 +476,7 @@ class EmbeddingAttribute(object):
 
     def target_mapping_device(self, item_ids_dev, out_dev):
         """device twin of target_mapping: out[i] = item_ind2logit_ind[item[i]]."""
+        self.rt.flush_feeds()
         ops.sparse_site_onehot(self._item2logit_dev, item_ids_dev, 0, 0.0, out_dev, None, None)
         return out_dev
 

@@ -121,7 +121,10 @@ class IdsInput(Node):
             raise ValueError("placeholder %s expects %d ids, got %d" % (self.name, self.value.numel(),
                                                                           src.numel()))
         if src.is_cuda and src.is_contiguous():
-            ops.copy_words([(src, self.value)])        # own kernel: cheaper than the runtime's blit
+            # device-resident batch: queued, all feeds of a step go out as ONE copy launch when the
+            # plan runs (Runtime.flush_feeds; eager readers of .value flush first)
+            self.rt.pending_feeds = [(s_, d_) for s_, d_ in self.rt.pending_feeds if d_ is not self.value]
+            self.rt.pending_feeds.append((src, self.value))
         else:
             self.value.copy_(src.reshape(self.value.shape), non_blocking=True)
 
@@ -679,6 +682,7 @@ class Plan(object):
 
     def run(self):
         rt = self.rt
+        rt.flush_feeds()
         if self.train and self._kp != rt.keep_prob:
             # keep_prob is baked into the kernel sequence (identity vs masked): rebuild
             self._kp = rt.keep_prob
@@ -729,6 +733,7 @@ class Runtime(object):
         self.keep_prob = 1.0            # dropout keep probability of train plans (Dropout nodes)
         self.dropout_calls = 0
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)   # device step counter
+        self.pending_feeds = []         # (src, placeholder buffer) device-to-device feeds not yet issued
         import os as _os
         self.force_sort_path = bool(_os.environ.get('ARX_FORCE_SORT'))
         self.cat_mode = 1 if _os.environ.get('ARX_CAT_ATOMIC') else 0
@@ -740,6 +745,12 @@ class Runtime(object):
         self._side = None
         self._side_ws = None
         self._pending = []
+
+    def flush_feeds(self):
+        """Issue the queued placeholder feeds (one launch per four buffers)."""
+        if self.pending_feeds:
+            pf, self.pending_feeds = self.pending_feeds, []
+            ops.copy_words(pf)
 
     # ---- fork/join onto side streams: independent branches of a step (the lookups of
     # different entities, the dU / dI GEMMs, the per-table sparse updates) run

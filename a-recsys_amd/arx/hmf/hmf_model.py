@@ -269,11 +269,11 @@ class LatentProductModel(object):
     def _feed(self, user_input, item_input, recommend, loss, item_sampled, item_sampled_id2idx,
               forward_only):
         m = self.att_emb
+        map_on_device = False
         if not recommend:
             if isinstance(item_input, torch.Tensor):
                 self.item_id_target.feed(item_input)
-                if self.loss_function != 'mw' or forward_only:
-                    m.target_mapping_device(self.item_id_target.value, self.item_target.value)
+                map_on_device = self.loss_function != 'mw' or forward_only
             else:
                 if self.loss_function != 'mw' or forward_only:
                     targets = m.target_mapping([item_input])                  # :173
@@ -282,6 +282,8 @@ class LatentProductModel(object):
         update_sampled, _, _ = m.add_input({}, user_input, item_input, item_sampled=item_sampled,
                                            item_sampled_id2idx=item_sampled_id2idx,
                                            forward_only=forward_only, recommend=recommend, loss=loss)
+        if map_on_device:     # after add_input: the user and item feeds leave in one copy launch
+            m.target_mapping_device(self.item_id_target.value, self.item_target.value)
         for op in update_sampled:                                             # :206-207
             op()
 

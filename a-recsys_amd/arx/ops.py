@@ -453,13 +453,11 @@ def copy_words(pairs):
     for k in range(0, len(pairs), 4):
         grp = pairs[k:k + 4]
         n = len(grp)
-        for s_, d_ in grp:
-            if s_.element_size() != 4 or d_.element_size() != 4 or s_.numel() != d_.numel() \
-                    or not s_.is_contiguous() or not d_.is_contiguous():
-                raise ValueError("copy_words: contiguous 4-byte tensors of equal size expected")
-        src = (C.c_void_p * n)(*[_p(s_) for s_, _ in grp])
-        dst = (C.c_void_p * n)(*[_p(d_) for _, d_ in grp])
-        cnt = (C.c_int64 * n)(*[int(s_.numel()) for s_, _ in grp])
+        src, dst, cnt = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int64 * n)()
+        for a, (s_, d_) in enumerate(grp):
+            if s_.element_size() != 4 or d_.element_size() != 4 or s_.numel() != d_.numel():
+                raise ValueError("copy_words: 4-byte tensors of equal size expected")
+            src[a], dst[a], cnt[a] = s_.data_ptr(), d_.data_ptr(), s_.numel()
         call("arx_copy_words", n, src, dst, cnt, _stream())
 
 
