@@ -12,6 +12,8 @@ raises NotImplementedError.  torch tensors are device-memory holders only.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -270,9 +272,14 @@ class TargetScore(Node):
 
     def __init__(self, rt, latent, target_embed):
         super().__init__(rt, (latent.shape[0],), (latent, target_embed))
+        self.fused_into_loss = False      # set by BatchLoss('mw'): the loss kernel forms the score
+                                          # and both rank-one gradients itself
 
     def forward(self, train):
         latent, te = self.inputs
+        if self.fused_into_loss:
+            self.alloc_value()
+            return
         ops.dot_score(latent.value, te.value, te.bias_value, self.alloc_value())
 
     def alloc_grad(self):
@@ -286,6 +293,8 @@ class TargetScore(Node):
 
     def backward(self):
         latent, te = self.inputs
+        if self.fused_into_loss:
+            return
         ds = self.grad
         g = latent.alloc_grad()
         dT = te.alloc_grad() if te.train_tables else None
@@ -317,6 +326,16 @@ class BatchLoss(Node):
         self.gscale = 1.0
         self.row_w = None             # FloatInput-like node
         self.rank_value = None
+        # 'mw' over <= 2048 sampled columns with the in-kernel positive mask: the wave that owns
+        # a row also forms its target score and the two rank-one gradients (2 launches less)
+        self.fuse_ts = False
+        if (kind == 'mw' and isinstance(target, TargetScore) and mask is not None and mask.fused
+                and not os.environ.get('ARX_LOSS_NOFUSE')):
+            lat, te = target.inputs
+            d, W = lat.shape[1], logits.shape[1]
+            if W <= 2048 and W % 4 == 0 and d % 4 == 0 and d <= 256 and te.shape[1] == d:
+                self.fuse_ts = True
+                target.fused_into_loss = True
 
     def forward(self, train):
         logits, target = self.inputs
@@ -335,7 +354,23 @@ class BatchLoss(Node):
             dt = target.alloc_grad() if train else None
             if train:
                 target.grad_beta()
-            if fused:
+            if self.fuse_ts:
+                lat, te = target.inputs
+                dU = dT = None
+                if train:
+                    if lat.requires_grad:
+                        dU = lat.alloc_grad()
+                        if lat.grad_beta() != 0.0:
+                            raise RuntimeError("fused target score must be the first writer of the latent gradient")
+                    if te.train_tables:
+                        dT = te.alloc_grad()
+                        te.grad_beta()
+                        te.bias_grad_used = True
+                        if dt.data_ptr() != te.bias_grad.data_ptr():
+                            raise RuntimeError("target-score gradient is expected to alias the bias gradient rows")
+                ops.loss_mw_fused_pos(logits.value, lat.value, te.value, te.bias_value, uid, ptr, items, i2s,
+                                      bl, dl, target.value, dt, dU, dT, self.gscale, rw, self.mask_rows)
+            elif fused:
                 ops.loss_mw_pos(logits.value, target.value, uid, ptr, items, i2s, bl, dl, dt,
                                 self.gscale, rw, self.mask_rows)
             else:

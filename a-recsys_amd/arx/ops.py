@@ -233,6 +233,18 @@ def loss_mw_pos(logits, tscore, user_ids, pos_ptr, pos_items, item2slot, batch_l
          _stream())
 
 
+def loss_mw_fused_pos(logits, U, T, tbias, user_ids, pos_ptr, pos_items, item2slot, batch_loss, dlogits,
+                      tscore_out, dtscore, dU, dT, gscale, row_w=None, mask_rows=0):
+    """'mw' loss with the target score t = U.T + tbias, dT = dt*U and dU = dt*T formed by the
+    same kernel (dU is WRITTEN: accumulate the scorer's dU onto it afterwards)."""
+    B, S = int(logits.shape[0]), int(logits.shape[1])
+    call("arx_loss_mw_fused_pos", _p(logits), _ld(logits), _p(U), _ld(U), _p(T), _ld(T), _p(tbias),
+         int(U.shape[1]), _p(user_ids), _p(pos_ptr), _p(pos_items), _p(item2slot), int(mask_rows),
+         float(gscale), _p(row_w), B, S, _p(batch_loss), _p(dlogits),
+         _ld(dlogits) if dlogits is not None else 0, _p(tscore_out), _p(dtscore), _p(dU),
+         _ld(dU) if dU is not None else 0, _p(dT), _ld(dT) if dT is not None else 0, _stream())
+
+
 def loss_warp_pos(logits, target, user_ids, pos_ptr, pos_items, item2slot, batch_loss, dlogits,
                   gscale, row_w=None, mask_rows=0):
     B, V = int(logits.shape[0]), int(logits.shape[1])

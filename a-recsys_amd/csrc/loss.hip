@@ -53,6 +53,24 @@ struct PosMask {
   const int32_t* item2slot;  // item -> column (or -1)
 };
 
+// Optional fusion of the target score into the margin-loss kernel (embed_attribute.py:208-220 +
+// :604-649): the wave that owns row r also forms t_r = U_r . T_r + tb_r and, once dt_r is known,
+// the two rank-one gradients dT_r = dt_r U_r and dU_r = dt_r T_r (written, not accumulated: the
+// scorer's dU GEMM adds onto it).  Two ~5 us launches less per step.
+struct DotFuse {
+  const float* U;      // [B, d] latent rows (NULL: not fused, tscore is an input)
+  int64_t ldu;
+  const float* T;      // [B, d] target-item embedding rows
+  int64_t ldt;
+  const float* tb;     // [B] target bias (nullable)
+  int d;
+  float* tscore_out;   // [B] (nullable)
+  float* dU;           // [B, d] (nullable)
+  int64_t lddu;
+  float* dT;           // [B, d] (nullable)
+  int64_t lddt;
+};
+
 __device__ __forceinline__ void build_pos_bits(uint32_t* bits, int64_t W, const PosMask& pm,
                                                int64_t mrow) {
   const int nwords = (int)((W + 31) >> 5);
@@ -123,7 +141,7 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
     const int32_t* __restrict__ target, const uint8_t* __restrict__ mask, int64_t ldm,
     int64_t mask_rows, float gscale, const float* __restrict__ row_w, int64_t B, int64_t W,
     float* __restrict__ batch_loss, float* dlogits, int64_t lddl, float* __restrict__ dtscore,
-    PosMask pm) {
+    PosMask pm, DotFuse df) {
   __shared__ uint32_t bits_all[4][NV * 8];           // NV*256 columns -> NV*8 words per wave
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t r = (int64_t)blockIdx.x * 4 + wv;
@@ -173,7 +191,19 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
     keep = 0xFFFFFFFFu;
   }
   const int tcol = WARP ? target[r] : -1;
-  const float t = WARP ? x[tcol] : tscore[r];
+  float t;
+  float4 ur = make_float4(0.f, 0.f, 0.f, 0.f), tr = ur;     // fused target score: d <= 256
+  if (!WARP && df.U) {
+    const int c4 = lane * 4;
+    if (c4 < df.d) {
+      ur = *reinterpret_cast<const float4*>(df.U + r * df.ldu + c4);
+      tr = *reinterpret_cast<const float4*>(df.T + r * df.ldt + c4);
+    }
+    t = wsum(ur.x * tr.x + ur.y * tr.y + ur.z * tr.z + ur.w * tr.w) + (df.tb ? df.tb[r] : 0.f);
+    if (lane == 0 && df.tscore_out) df.tscore_out[r] = t;
+  } else {
+    t = WARP ? x[tcol] : tscore[r];
+  }
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -213,8 +243,16 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
         if (e == 0) d[i].x += dt; else if (e == 1) d[i].y += dt; else if (e == 2) d[i].z += dt; else d[i].w += dt;
       }
     }
-  } else if (lane == 0 && dtscore) {
-    dtscore[r] = dt;
+  } else {
+    if (lane == 0 && dtscore) dtscore[r] = dt;
+    if (df.U && lane * 4 < df.d) {
+      if (df.dT)
+        *reinterpret_cast<float4*>(df.dT + r * df.lddt + lane * 4) =
+            make_float4(dt * ur.x, dt * ur.y, dt * ur.z, dt * ur.w);
+      if (df.dU)
+        *reinterpret_cast<float4*>(df.dU + r * df.lddu + lane * 4) =
+            make_float4(dt * tr.x, dt * tr.y, dt * tr.z, dt * tr.w);
+    }
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -235,7 +273,7 @@ static bool launch_margin_wave(const float* logits, int64_t ldl, const float* ts
                                const int32_t* target, const uint8_t* mask, int64_t ldm,
                                int64_t mask_rows, float gscale, const float* row_w, int64_t B,
                                int64_t W, float* batch_loss, float* dlogits, int64_t lddl,
-                               float* dtscore, PosMask pm, hipStream_t s) {
+                               float* dtscore, PosMask pm, hipStream_t s, DotFuse df = DotFuse{}) {
   static const bool off = getenv("ARX_LOSS_WAVE_OFF") != nullptr;   // A/B aid
   if (off || W > 2048 || (ldl % 4) || (dlogits && (lddl % 4)) ||
       (reinterpret_cast<uintptr_t>(logits) & 15) || (reinterpret_cast<uintptr_t>(dlogits) & 15))
@@ -244,11 +282,11 @@ static bool launch_margin_wave(const float* logits, int64_t ldl, const float* ts
   if (W <= 1024)
     k_loss_margin_wave<WARP, POS, 4><<<grid, 256, 0, s>>>(logits, ldl, tscore, target, mask, ldm,
                                                           mask_rows, gscale, row_w, B, W, batch_loss,
-                                                          dlogits, lddl, dtscore, pm);
+                                                          dlogits, lddl, dtscore, pm, df);
   else
     k_loss_margin_wave<WARP, POS, 8><<<grid, 256, 0, s>>>(logits, ldl, tscore, target, mask, ldm,
                                                           mask_rows, gscale, row_w, B, W, batch_loss,
-                                                          dlogits, lddl, dtscore, pm);
+                                                          dlogits, lddl, dtscore, pm, df);
   return true;
 }
 
@@ -521,6 +559,38 @@ int arx_loss_mw_fwdbwd_pos(const float* logits, int64_t ldl, const float* tscore
   k_loss_margin<false, true><<<(int)B, 256, lds, as_stream(stream)>>>(
       logits, ldl, tscore, nullptr, nullptr, 0, mask_rows > 0 ? mask_rows : B, gscale, row_w, S,
       batch_loss, dlogits, lddl, dtscore, PosMask{user_ids, pos_ptr, pos_items, item2slot});
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_loss_mw_fused_pos(const float* logits, int64_t ldl, const float* U, int64_t ldu, const float* T,
+                          int64_t ldt, const float* tbias, int d, const int32_t* user_ids,
+                          const int32_t* pos_ptr, const int32_t* pos_items, const int32_t* item2slot,
+                          int64_t mask_rows, float gscale, const float* row_w, int64_t B, int64_t S,
+                          float* batch_loss, float* dlogits, int64_t lddl, float* tscore_out,
+                          float* dtscore, float* dU, int64_t lddu, float* dT, int64_t lddt,
+                          void* stream) {
+  ARX_CHECK_ARG(logits && U && T && user_ids && pos_ptr && pos_items && item2slot,
+                "arx_loss_mw_fused_pos: null pointer");
+  ARX_CHECK_ARG(B >= 0 && S >= 0, "arx_loss_mw_fused_pos: negative size");
+  const bool ok = d > 0 && d <= 256 && d % 4 == 0 && ldu % 4 == 0 && ldt % 4 == 0 &&
+                  (!dU || lddu % 4 == 0) && (!dT || lddt % 4 == 0) && S <= 2048 &&
+                  ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(T) |
+                    reinterpret_cast<uintptr_t>(dU) | reinterpret_cast<uintptr_t>(dT)) & 15) == 0;
+  if (!ok) {
+    set_error("arx_loss_mw_fused_pos: shape not supported (d %% 4, d <= 256, S <= 2048, 16-byte rows)");
+    return ARX_EUNSUPPORTED;
+  }
+  if (B == 0) return ARX_OK;
+  DotFuse df{U, ldu, T, ldt, tbias, d, tscore_out, dU, lddu, dT, lddt};
+  if (!launch_margin_wave<false, true>(logits, ldl, nullptr, nullptr, nullptr, 0,
+                                       mask_rows > 0 ? mask_rows : B, gscale, row_w, B, S, batch_loss,
+                                       dlogits, lddl, dtscore,
+                                       PosMask{user_ids, pos_ptr, pos_items, item2slot},
+                                       as_stream(stream), df)) {
+    set_error("arx_loss_mw_fused_pos: logits / dlogits layout not supported by the wave kernel");
+    return ARX_EUNSUPPORTED;
+  }
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
