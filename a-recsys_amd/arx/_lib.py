@@ -61,8 +61,9 @@ PROTOTYPES = {
                                     i64, vp]),
     "arx_loss_mw_fwdbwd_pos": (cint, [f32p, i64, f32p, i32p, i32p, i32p, i32p, i64, f32, f32p, i64,
                                       i64, f32p, f32p, i64, f32p, vp]),
-    "arx_loss_mw_fused_pos": (cint, [f32p, i64, f32p, i64, f32p, i64, f32p, cint, i32p, i32p, i32p, i32p, i64,
-                                     f32, f32p, i64, i64, f32p, f32p, i64, f32p, f32p, f32p, i64, f32p, i64, vp]),
+    "arx_loss_mw_fused_pos": (cint, [f32p, i64, f32p, i64, f32p, i64, f32p, i64, cint, i32p, i32p, i32p, i32p,
+                                     i64, f32, f32p, i64, i64, f32p, f32p, i64, f32p, f32p, i64, f32p, i64,
+                                     f32p, i64, vp]),
     "arx_loss_warp_fwdbwd_pos": (cint, [f32p, i64, i32p, i32p, i32p, i32p, i32p, i64, f32, f32p,
                                         i64, i64, f32p, f32p, i64, vp]),
     "arx_sample_wor_workspace_bytes": (sz, [i64]),

@@ -71,6 +71,10 @@ class HipBackend(object):
     def loss_mw_pos(self, logits, t, urows, ptr, items, i2s, bl, dl, dt, gscale):
         self.ops.loss_mw_pos(logits, t, urows, ptr, items, i2s, bl, dl, dt, gscale)
 
+    def loss_mw_fused_pos(self, logits, U, T, tb, urows, ptr, items, i2s, bl, dl, t_out, dt, dU, dT, gscale):
+        """loss + target score + rank-one gradients in one kernel; tb / dt may be strided columns."""
+        self.ops.loss_mw_fused_pos(logits, U, T, tb, urows, ptr, items, i2s, bl, dl, t_out, dt, dU, dT, gscale)
+
     def sum_scaled(self, x, scale, out):
         self.ops.sum_scaled(x, scale, out)
 
@@ -288,16 +292,14 @@ class ShardedHMF(object):
             T_send[:, d].copy_(self.tb_send[:R])
         dist.all_to_all_single(self.T_pack, T_send, output_split_sizes=send, input_split_sizes=recv,
                                group=grp)
-        self.tb.copy_(self.T_pack[:, d])
-        be.dot_score(self.U_loc, self.T_pack[:, :d], self.tb, self.t_loc)
-        # loss (global mean => gscale = 1/B)
-        be.loss_mw_pos(self.logits, self.t_loc, self.urows, self.pos_ptr, self.pos_items,
-                       self.item2slot, self.bl, self.dlogits, self.dt_loc, 1.0 / B)
-        # ---- backward ----
+        # loss (global mean => gscale = 1/B) with the target score and its rank-one gradients formed
+        # by the same kernel, straight from / into the packed rows (bias and dt live in column d)
         dU = arena[:B_loc, :d]
-        be.gemm(self.dlogits, self.I_all[:, :d], dU)                     # dU = dL . pool
-        be.dot_score_bwd(self.U_loc, self.T_pack[:, :d], self.dt_loc, dU, True, self.dT_pack[:, :d])
-        self.dT_pack[:, d].copy_(self.dt_loc)
+        be.loss_mw_fused_pos(self.logits, self.U_loc, self.T_pack[:, :d], self.T_pack[:, d], self.urows,
+                             self.pos_ptr, self.pos_items, self.item2slot, self.bl, self.dlogits,
+                             self.t_loc, self.dT_pack[:, d], dU, self.dT_pack[:, :d], 1.0 / B)
+        # ---- backward ----
+        be.gemm(self.dlogits, self.I_all[:, :d], dU, beta=1.0)                # dU += dL . pool
         # pool gradient partials (+ bias gradient = row sums) -> owners
         be.gemm(self.dlogits, self.U_loc, self.dI_all[:, :d], transA=True, a_rowsum=self.gb_all)
         self.dI_all[:, d].copy_(self.gb_all)
@@ -415,6 +417,25 @@ def bench_main(args, world, rank, local_rank):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
     loss = float(model.read_loss().item())
+    # roofline of the dominant kernel (the local scorer GEMM [B_loc, S] x d), HIP events on the
+    # stream the kernel runs on; same definition as the single-GPU bench line
+    roofline = None
+    if rank == 0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        run_gemm = lambda: model.be.gemm(model.U_loc, model.I_all[:, :d], model.logits, transB=True,
+                                         col_bias=model.b_all)
+        for _ in range(5):
+            run_gemm()
+        e0.record()
+        for _ in range(50):
+            run_gemm()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 50
+        flops = 2.0 * B_loc * S * d
+        roofline = {"kernel": "gemm_logits_nt (per rank)", "bound": "mfma", "achieved": flops / ms / 1e9,
+                    "peak": 157.3, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / 157.3, "traffic": None,
+                    "flops_per_launch": flops, "ms_per_launch": ms}
     if rank == 0:
         B = B_loc * world
         out = {
@@ -432,7 +453,7 @@ def bench_main(args, world, rank, local_rank):
                        "parallelism": "row-sharded tables x dp%d" % world,
                        "sampled_negative_logits_per_s": B * S * args.steps / wall,
                        "final_loss": loss, "setup_s": setup_s},
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roofline, "cpu_baseline": None,
         }
     dist.destroy_process_group()
     if rank == 0:

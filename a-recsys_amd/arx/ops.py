@@ -239,9 +239,10 @@ def loss_mw_fused_pos(logits, U, T, tbias, user_ids, pos_ptr, pos_items, item2sl
     same kernel (dU is WRITTEN: accumulate the scorer's dU onto it afterwards)."""
     B, S = int(logits.shape[0]), int(logits.shape[1])
     call("arx_loss_mw_fused_pos", _p(logits), _ld(logits), _p(U), _ld(U), _p(T), _ld(T), _p(tbias),
-         int(U.shape[1]), _p(user_ids), _p(pos_ptr), _p(pos_items), _p(item2slot), int(mask_rows),
-         float(gscale), _p(row_w), B, S, _p(batch_loss), _p(dlogits),
-         _ld(dlogits) if dlogits is not None else 0, _p(tscore_out), _p(dtscore), _p(dU),
+         int(tbias.stride(0)) if tbias is not None else 1, int(U.shape[1]), _p(user_ids), _p(pos_ptr),
+         _p(pos_items), _p(item2slot), int(mask_rows), float(gscale), _p(row_w), B, S, _p(batch_loss),
+         _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _p(tscore_out), _p(dtscore),
+         int(dtscore.stride(0)) if dtscore is not None else 1, _p(dU),
          _ld(dU) if dU is not None else 0, _p(dT), _ld(dT) if dT is not None else 0, _stream())
 
 

@@ -62,9 +62,11 @@ struct DotFuse {
   int64_t ldu;
   const float* T;      // [B, d] target-item embedding rows
   int64_t ldt;
-  const float* tb;     // [B] target bias (nullable)
+  const float* tb;     // target bias, element r at tb[r * tb_stride] (nullable)
+  int64_t tb_stride;
   int d;
   float* tscore_out;   // [B] (nullable)
+  int64_t dts_stride;  // dtscore element r at dtscore[r * dts_stride]
   float* dU;           // [B, d] (nullable)
   int64_t lddu;
   float* dT;           // [B, d] (nullable)
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
       ur = *reinterpret_cast<const float4*>(df.U + r * df.ldu + c4);
       tr = *reinterpret_cast<const float4*>(df.T + r * df.ldt + c4);
     }
-    t = wsum(ur.x * tr.x + ur.y * tr.y + ur.z * tr.z + ur.w * tr.w) + (df.tb ? df.tb[r] : 0.f);
+    t = wsum(ur.x * tr.x + ur.y * tr.y + ur.z * tr.z + ur.w * tr.w) + (df.tb ? df.tb[r * df.tb_stride] : 0.f);
     if (lane == 0 && df.tscore_out) df.tscore_out[r] = t;
   } else {
     t = WARP ? x[tcol] : tscore[r];
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
       }
     }
   } else {
-    if (lane == 0 && dtscore) dtscore[r] = dt;
+    if (lane == 0 && dtscore) dtscore[df.U ? r * df.dts_stride : r] = dt;
     if (df.U && lane * 4 < df.d) {
       if (df.dT)
         *reinterpret_cast<float4*>(df.dT + r * df.lddt + lane * 4) =
@@ -564,12 +566,13 @@ int arx_loss_mw_fwdbwd_pos(const float* logits, int64_t ldl, const float* tscore
 }
 
 int arx_loss_mw_fused_pos(const float* logits, int64_t ldl, const float* U, int64_t ldu, const float* T,
-                          int64_t ldt, const float* tbias, int d, const int32_t* user_ids,
+                          int64_t ldt, const float* tbias, int64_t tbias_stride, int d,
+                          const int32_t* user_ids,
                           const int32_t* pos_ptr, const int32_t* pos_items, const int32_t* item2slot,
                           int64_t mask_rows, float gscale, const float* row_w, int64_t B, int64_t S,
                           float* batch_loss, float* dlogits, int64_t lddl, float* tscore_out,
-                          float* dtscore, float* dU, int64_t lddu, float* dT, int64_t lddt,
-                          void* stream) {
+                          float* dtscore, int64_t dtscore_stride, float* dU, int64_t lddu, float* dT,
+                          int64_t lddt, void* stream) {
   ARX_CHECK_ARG(logits && U && T && user_ids && pos_ptr && pos_items && item2slot,
                 "arx_loss_mw_fused_pos: null pointer");
   ARX_CHECK_ARG(B >= 0 && S >= 0, "arx_loss_mw_fused_pos: negative size");
@@ -582,7 +585,8 @@ int arx_loss_mw_fused_pos(const float* logits, int64_t ldl, const float* U, int6
     return ARX_EUNSUPPORTED;
   }
   if (B == 0) return ARX_OK;
-  DotFuse df{U, ldu, T, ldt, tbias, d, tscore_out, dU, lddu, dT, lddt};
+  DotFuse df{U, ldu, T, ldt, tbias, tbias_stride > 0 ? tbias_stride : 1, d, tscore_out,
+             dtscore_stride > 0 ? dtscore_stride : 1, dU, lddu, dT, lddt};
   if (!launch_margin_wave<false, true>(logits, ldl, nullptr, nullptr, nullptr, 0,
                                        mask_rows > 0 ? mask_rows : B, gscale, row_w, B, S, batch_loss,
                                        dlogits, lddl, dtscore,

@@ -215,14 +215,15 @@ int arx_loss_mw_fwdbwd_pos(const float* logits, int64_t ldl, const float* tscore
 /* The same 'mw' loss with the target score fused in (embed_attribute.py:208-220): the wave that
  * owns row r forms t_r = U_r . T_r + tbias_r (-> tscore_out), and after the loss gradient
  * dT_r = dt_r * U_r and dU_r = dt_r * T_r (both WRITTEN; add the scorer's dU onto dU afterwards).
+ * tbias / dtscore may be strided (element r at [r * stride]: the bias column of packed rows).
  * d % 4 == 0, d <= 256, S <= 2048 (S % 4 == 0), 16-byte aligned rows; else ARX_EUNSUPPORTED. */
 int arx_loss_mw_fused_pos(const float* logits, int64_t ldl, const float* U, int64_t ldu, const float* T,
-                          int64_t ldt, const float* tbias, int d, const int32_t* user_ids,
-                          const int32_t* pos_ptr, const int32_t* pos_items, const int32_t* item2slot,
-                          int64_t mask_rows, float gscale, const float* row_w, int64_t B, int64_t S,
-                          float* batch_loss, float* dlogits, int64_t lddl, float* tscore_out,
-                          float* dtscore, float* dU, int64_t lddu, float* dT, int64_t lddt,
-                          void* stream);
+                          int64_t ldt, const float* tbias, int64_t tbias_stride, int d,
+                          const int32_t* user_ids, const int32_t* pos_ptr, const int32_t* pos_items,
+                          const int32_t* item2slot, int64_t mask_rows, float gscale, const float* row_w,
+                          int64_t B, int64_t S, float* batch_loss, float* dlogits, int64_t lddl,
+                          float* tscore_out, float* dtscore, int64_t dtscore_stride, float* dU,
+                          int64_t lddu, float* dT, int64_t lddt, void* stream);
 int arx_loss_warp_fwdbwd_pos(const float* logits, int64_t ldl, const int32_t* target,
                              const int32_t* user_ids, const int32_t* pos_ptr,
                              const int32_t* pos_items, const int32_t* item2slot,

@@ -3,6 +3,7 @@ arx.dist.ShardedHMF (the product backend is HipBackend / libarx.so).  It lets th
 world_size-2 gloo tests check the sharding + exchange logic on CPU against the
 single-process oracle.  Lives in tests/ on purpose: the package has no CPU path."""
 import numpy as np
+import torch
 
 KEY_NONE = 0x7FFFFFFF
 
@@ -74,6 +75,15 @@ class NumpyBackend(object):
         d = act * g[:, None]
         _n(dl)[...] = d
         _n(dt)[...] = -d.sum(1)
+
+    def loss_mw_fused_pos(self, logits, U, T, tb, urows, ptr, items, i2s, bl, dl, t_out, dt, dU, dT, gscale):
+        """arx_loss_mw_fused_pos: target score + loss + dT = dt*U, dU = dt*T (written)."""
+        self.dot_score(U, T, tb, t_out)
+        tmp = torch.zeros(int(t_out.shape[0]), dtype=torch.float32)
+        self.loss_mw_pos(logits, t_out, urows, ptr, items, i2s, bl, dl, tmp, gscale)
+        dt.copy_(tmp)
+        _n(dU)[...] = 0.0
+        self.dot_score_bwd(U, T, tmp, dU, True, dT)
 
     def sum_scaled(self, x, scale, out):
         _n(out)[...] = _n(x).astype(np.float64).sum() * scale
