@@ -110,6 +110,17 @@ def kernel_rooflines(model, args):
                                                                   tokens=toks)
     # --- scatter + sparse Adagrad (HBM bound): 16d+4 per unique row + 4d per source row ---
     for table, sites, bufs, total in plan.tables:
+        # this table's contributions of the LAST step, rebuilt the way the un-fused K7 pass builds
+        # them (the step itself may have sorted several tables in one shared pass)
+        for s_ in sites:
+            ks = bufs['keys'][s_.key_off:s_.key_off + s_.cap]
+            ss = bufs['src'][s_.key_off:s_.key_off + s_.cap]
+            cs = bufs['coef'][s_.key_off:s_.key_off + s_.cap]
+            if s_.kind == 'cat':
+                ops.sparse_site_onehot(s_.maps[0], s_.ids_node.value, s_.node.row0, s_.coef, ks, ss, cs)
+            else:
+                ops.bag_expand_padded(s_.maps[0], s_.maps[1], s_.maps[2], s_.ids_node.value, s_.max_len,
+                                      s_.node.row0, s_.coef, ks, ss, cs)
         keys = bufs['keys']
         valid = keys[keys != ops.KEY_NONE]
         uniq = int(torch.unique(valid).numel())
