@@ -42,7 +42,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16384,
                     help="interactions per step per GPU (SURVEY 8(d) C2 throughput batches: 4096, 16384)")
-    ap.add_argument("--n-items", type=int, default=1000000)
+    ap.add_argument("--n-items", type=int, default=None,
+                    help="item table rows (default: 1M on one GPU = configs[1]; 100M row-sharded for "
+                         "--gpus N > 1 = configs[4])")
     ap.add_argument("--n-users", type=int, default=1000000)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--n-sampled", type=int, default=1024)
@@ -196,8 +198,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1:
+        if args.n_items is None:
+            args.n_items = 100000000      # configs[4]: 100 M-item dim-128 table, row-sharded
         from arx import dist as arx_dist
         return arx_dist.bench_main(args, world, rank, local_rank)
+    if args.n_items is None:
+        args.n_items = 1000000            # configs[1]
 
     torch.cuda.set_device(0)
     from arx.hmf.hmf_model import LatentProductModel
