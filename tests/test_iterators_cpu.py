@@ -1,0 +1,82 @@
+"""Batch iterators / bucketing of the runners (callers of the hot path): bit-exact against the
+REAL reference classes where they import under Python 3 (word2vec/data_iterator.py; the
+deterministic half of lstm/data_iterator.py), hand-computed for lstm/best_buckets.py (Python-2
+only)."""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_w2v_iterator_bit_exact_with_reference_stream():
+    from arx.word2vec.data_iterator import DataIterator, batch_major
+    cases = json.load(open(os.path.join(HERE, 'golden', 'w2v_iterator.json')))
+    assert {c['gen'] for c in cases} == {'get_next', 'get_next_sg', 'get_next_cbow'}
+    for c in cases:
+        seq = [tuple(x) for x in c['seq']]
+        it = DataIterator(seq, c['end_ind'], c['batch'], c['n_skips'], c['window'], c['sequence'])
+        np.random.seed(c['seed'])
+        g = getattr(it, c['gen'])()
+        for k, b in enumerate(c['batches']):
+            u, i, o = next(g)
+            assert np.asarray(u).tolist() == b['users'], (c['gen'], k)
+            assert np.asarray(i).tolist() == b['inputs'], (c['gen'], k)
+            assert np.asarray(o).tolist() == b['outputs'], (c['gen'], k)
+        assert it.index == c['index_after']
+    assert batch_major([[1, 2, 3], [4, 5, 6]], 2, 3) == [[1, 4], [2, 5], [3, 6]]
+
+
+class _Recorder(object):
+    def __init__(self, sizes, batch):
+        self.sizes, self.batch, self.calls = sizes, batch, []
+
+    def get_batch(self, data_set, bucket_id, start_id=None):
+        self.calls.append(['train', bucket_id, start_id])
+        if start_id is None:
+            return ('u', bucket_id, None), 'i', 'o', 'w', False
+        return ('u', bucket_id, start_id), 'i', 'o', 'w', start_id + self.batch >= self.sizes[bucket_id]
+
+    def get_batch_recommend(self, data_set, bucket_id, start_id=None):
+        self.calls.append(['rec', bucket_id, start_id])
+        return ('r', bucket_id, start_id), 'i', 'o', 'w', start_id + self.batch >= self.sizes[bucket_id]
+
+
+def test_lstm_iterator_matches_reference_sweep():
+    from arx.lstm.data_iterator import DataIterator
+    for c in json.load(open(os.path.join(HERE, 'golden', 'lstm_iterator.json'))):
+        m = _Recorder(c['sizes'], c['batch'])
+        it = DataIterator(m, None, len(c['sizes']), c['batch'], [1.0])
+        ys = []
+        for k, y in enumerate(it.next_sequence(stop=c['stop'], recommend=c['recommend'])):
+            ys.append([list(y[0]), y[4]])
+            if k + 1 >= c['take']:
+                break
+        assert m.calls == c['calls'] and ys == c['yields']
+
+
+def test_lstm_iterator_next_random_follows_bucket_shares():
+    """data_iterator.py:14-22: bucket = first whose cumulative share exceeds a uniform draw."""
+    from arx.lstm.data_iterator import DataIterator
+    m = _Recorder([1, 1, 1], 2)
+    it = DataIterator(m, None, 3, 2, [0.2, 0.5, 1.0])
+    np.random.seed(3)
+    draws = np.random.random_sample(2000)
+    np.random.seed(3)
+    g = it.next_random()
+    got = [next(g)[4] for _ in range(2000)]
+    exp = [int(np.searchsorted([0.2, 0.5, 1.0], x, side='right')) for x in draws]
+    assert got == exp
+    assert abs(got.count(0) / 2000.0 - 0.2) < 0.03 and abs(got.count(2) / 2000.0 - 0.5) < 0.04
+
+
+def test_best_buckets_known_answers():
+    from arx.lstm.best_buckets import calculate_buckets
+    seqs = [(0, [0] * l) for l in [1, 1, 1, 2, 2, 5, 5, 5, 5, 9]]
+    # cumulative counts (1,3) (2,5) (5,9) (9,10): first boundary = the longest length; its best
+    # split saves (9-5) * (9-3) = 24 paddings at length 5 (length 2 would save 7*2 = 14)
+    assert calculate_buckets(seqs, 10, 2) == [9, 5]
+    assert calculate_buckets(seqs, 10, 3) == [9, 5, 2]      # next: inside (1..5): (5-2)*(5-3) = 6
+    assert calculate_buckets(seqs, 10, 8) == [1, 2, 5, 9]   # fewer distinct lengths than buckets
+    assert calculate_buckets(seqs, 6, 2) == [5, 2]          # lengths above max_length are cut off
