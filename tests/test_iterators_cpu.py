@@ -80,3 +80,35 @@ def test_best_buckets_known_answers():
     assert calculate_buckets(seqs, 10, 3) == [9, 5, 2]      # next: inside (1..5): (5-2)*(5-3) = 6
     assert calculate_buckets(seqs, 10, 8) == [1, 2, 5, 9]   # fewer distinct lengths than buckets
     assert calculate_buckets(seqs, 6, 2) == [5, 2]          # lengths above max_length are cut off
+
+
+def test_evaluation_harness_matches_reference(tmp_path):
+    """utils/evaluate.py::Evaluation + utils/submit.py on the ML-1m slice: the four files it
+    writes, the parsed truth / history and the flattened scores of a fixed recommendation dict --
+    all against the real reference classes (tests/golden/evaluation.json)."""
+    import shutil
+    from arx.utils.evaluate import Evaluation
+    from arx.utils.submit import combine_sub, load_submit
+    g = json.load(open(os.path.join(HERE, 'golden', 'evaluation.json')))
+    src = os.path.join(HERE, 'golden', 'ml1m_small')
+    for test in (False, True):
+        e = g[str(test)]
+        d = str(tmp_path / ('t%d' % test))
+        shutil.copytree(src, d)
+        ev = Evaluation(d, test=test)
+        for name, content in e['files'].items():
+            assert open(os.path.join(d, name), 'rb').read().decode('latin-1') == content, name
+        assert [int(u) for u in ev.get_uids()] == e['uids'] and [int(u) for u in ev.get_uinds()] == e['uinds']
+        assert {str(k): v for k, v in ev.T.items()} == e['T']
+        assert {str(k): len(v) for k, v in ev.hist.items()} == e['hist_len']
+        rec = {int(k): list(v) for k, v in e['rec'].items()}
+        ev.eval_on(rec)
+        s_self, s_ex = ev.get_scores()
+        np.testing.assert_allclose(s_self, e['s_self'], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(s_ex, e['s_ex'], rtol=1e-12, atol=0)
+        assert ev.get_user_n() == len(e['uids'])
+        # second construction reuses the files
+        assert load_submit('res_T.csv', submit_dir=d) == Evaluation(d, test=False).T
+    users = np.array([[1], [2], [3]], dtype=object)
+    assert combine_sub({1: ['a', 'b']}, {1: ['b', 'c'], 2: ['x', 'x']}, 0, users) == {1: ['a', 'b', 'c'], 2: ['x']}
+    assert combine_sub({1: ['a', 'b']}, {1: ['b', 'c'], 2: ['x']}, 1, users) == {1: ['c'], 2: ['x']}
