@@ -73,3 +73,60 @@ def test_read_data_feeds_hmf_training(dev, tmp_path, comb, loss):
     e_ref = ref.step(users, items, forward_only=True, loss=loss)
     e_got = model.step(None, users, items, forward_only=True, loss=loss)
     np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
+
+
+def test_train_recommend_evaluate_loop(dev, tmp_path):
+    """hmf/run_hmf.py in miniature on the ML-1m slice: read_data -> train (ce, permuted batches)
+    -> recommend for the evaluation users (run_hmf.py:340-409) -> utils/evaluate.py scores.
+    Training on real interactions must lift the ranking metrics well above the untrained model."""
+    import shutil
+    from arx.attributes.input_attribute import read_data
+    from arx.hmf.hmf_model import LatentProductModel
+    from arx.utils.evaluate import Evaluation
+    raw = str(tmp_path / 'raw')
+    shutil.copytree(DATA, raw)
+    V, d, B, top_n = 400, 32, 32, 30
+    (data_tr, data_va, u_attr, i_attr, i2l, l2i, user_index, item_index) = read_data(
+        raw, str(tmp_path / 'cache'), 'het', V, 1, mylog=lambda m: None)
+    data_tr = [p for p in data_tr if p[1] in i2l]
+    model = LatentProductModel(len(user_index), len(item_index), d, 1, B, 1.0, 1.0, u_attr, i_attr, i2l, l2i,
+                               loss_function='ce', top_N_items=top_n, seed=3)
+    ev = Evaluation(raw, test=False)
+    uids = ev.get_uids()
+    ind2id = {v: k for k, v in item_index.items()}
+    uids_of = {v: k for k, v in user_index.items()}
+
+    def recommend():
+        uinds = [user_index[u] for u in uids]
+        R = {}
+        for s in range(0, len(uinds), B):
+            chunk = uinds[s:s + B]
+            users = chunk + [0] * (B - len(chunk))
+            recs = model.step(None, users, None, None, forward_only=True, recommend=True)
+            for k in range(len(chunk)):
+                R[uids[s + k]] = [ind2id[l2i[int(v)]] for v in recs[k]]
+        return R
+
+    from arx.utils.eval_metrics import metrics
+    T_train = {}
+    for u, i, _ in data_tr:
+        T_train.setdefault(uids_of[u], []).append(str(ind2id[i]))
+
+    def scores(R):
+        ev.eval_on(R)                                      # validation truth, as the runner reports it
+        s_self, s_ex = ev.get_scores()
+        assert len(s_self) == len(s_ex) == 20 and np.all(np.isfinite(s_self + s_ex))
+        fit = metrics({u: [str(v) for v in r] for u, r in R.items()},
+                      {u: t for u, t in T_train.items() if u in R})
+        return fit['prec'][1], s_self[1]                   # prec@5 on the training items / validation
+
+    fit0, val0 = scores(recommend())
+    np.random.seed(0)
+    losses = []
+    for step in range(400):
+        users, items, _ = model.get_permuted_batch(data_tr)
+        losses.append(model.step(None, users, items, loss='ce'))
+    fit1, val1 = scores(recommend())
+    assert np.mean(losses[-20:]) < 0.8 * np.mean(losses[:20])
+    # 60 users x ~10 training interactions: the model must at least rank what it was trained on
+    assert fit1 > 0.3 and fit1 > 10 * max(fit0, 0.005), (fit0, fit1, val0, val1)
