@@ -468,6 +468,7 @@ class Plan(object):
         self.graph = None
         self.warm = 0
         self._kp = rt.keep_prob
+        self._pregather = None
         self.has_dropout = any(type(n).__name__ == 'Dropout' for n in self.order)
         self.tables = []
         self.arenas = []
@@ -527,16 +528,43 @@ class Plan(object):
             n._grad_written = False
             if isinstance(n, EntityEmbed):
                 n.bias_grad_used = False
+        # single one-hot lookups are independent leaves: all of them leave in one launch
+        if self._pregather is None:
+            self._pregather = []
+            groups = {}
+            if not os.environ.get('ARX_NO_MULTI_GATHER'):
+                for n in self.order:
+                    if (isinstance(n, EntityEmbed) and len(n.feats) == 1 and n.feats[0].kind == 'cat'
+                            and not n.concat and getattr(n.inputs[0], 'value', None) is not None
+                            and n.inputs[0].value.dtype == torch.int32):
+                        groups.setdefault(n.shape[1], []).append(n)
+            for d_, nodes in groups.items():
+                for k in range(0, len(nodes), 8):
+                    grp = nodes[k:k + 8]
+                    if len(grp) < 2:
+                        continue
+                    sites = []
+                    for n in grp:
+                        f = n.feats[0]
+                        n.alloc_value()
+                        sites.append((f.table.E, f.table.bias if n.with_bias else None, f.maps[0],
+                                      n.inputs[0].value, n.value, n.out_scale,
+                                      n.bias_value if n.with_bias else None))
+                    self._pregather.append((ops.GatherSet(sites), grp))
+        pre = set()
+        for gs, grp in self._pregather:
+            ops.gather_onehot_multi(gs)
+            pre.update(id(n) for n in grp)
         # lookups whose ids are placeholders are independent of each other: fork them
         roots = [n for n in self.order if isinstance(n, EntityEmbed) and type(n.inputs[0]).__name__ in
-                 ('IdsInput', 'IdsView')]
+                 ('IdsInput', 'IdsView') and id(n) not in pre]
         toks = []
         for k, n in enumerate(roots[1:]):
             t = rt.fork(k)
             n.forward(self.train)
             toks.append(rt.end_fork(t))
         for n in self.order:
-            if n in roots[1:]:
+            if n in roots[1:] or id(n) in pre:
                 continue
             n.forward(self.train)
             if roots and n is roots[0]:

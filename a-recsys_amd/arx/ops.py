@@ -138,6 +138,30 @@ def gather_onehot(E, bias, cat_map, ids, out, scale=1.0, accumulate=False, bias_
     return out
 
 
+class GatherSet(object):
+    """Descriptor arrays of arx_gather_onehot_multi, built once per plan.
+    sites: [(E, bias|None, cat_map|None, ids, out, scale, bias_out|None)], equal width d."""
+
+    def __init__(self, sites):
+        import ctypes as C
+        n = len(sites)
+        self.n = n
+        self.d = int(sites[0][0].shape[1])
+        vp = lambda xs: (C.c_void_p * n)(*[(_p(x) or None) for x in xs])
+        self.E, self.bias = vp([s[0] for s in sites]), vp([s[1] for s in sites])
+        self.cat_map, self.ids = vp([s[2] for s in sites]), vp([s[3] for s in sites])
+        self.out, self.bias_out = vp([s[4] for s in sites]), vp([s[6] for s in sites])
+        self.cnt = (C.c_int64 * n)(*[int(s[3].shape[0]) for s in sites])
+        self.ldo = (C.c_int64 * n)(*[_ld(s[4]) for s in sites])
+        self.scale = (C.c_float * n)(*[float(s[5]) for s in sites])
+        self._keep = sites
+
+
+def gather_onehot_multi(gs):
+    call("arx_gather_onehot_multi", gs.n, gs.E, gs.bias, gs.cat_map, gs.ids, gs.cnt, gs.d, gs.scale, gs.out,
+         gs.ldo, gs.bias_out, _stream())
+
+
 def gather_mulhot_mean(E, bias, vals, starts, lens, ids, out, scale=1.0, accumulate=False,
                        bias_out=None):
     _chk(E, torch.float32, 'E'); _chk(ids, torch.int32, 'ids'); _chk(out, torch.float32, 'out')

@@ -337,6 +337,47 @@ static inline int grid_waves(int64_t nwaves) {
 }
 
 
+// Several one-hot lookups (user ids, target items, the sampled pool, ...) in ONE launch: the step's
+// lookups are independent leaves of the graph and each costs a ~5 us launch slot on its own.
+struct GatherSites {
+  const float* E[kMaxSites];
+  const float* bias[kMaxSites];
+  const int32_t* cat_map[kMaxSites];
+  const int32_t* ids[kMaxSites];
+  float* out[kMaxSites];
+  float* bias_out[kMaxSites];
+  int64_t ldo[kMaxSites];
+  int64_t row_end[kMaxSites];      // exclusive prefix ends over the concatenated rows
+  float scale[kMaxSites];
+  int count;
+};
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_gather_onehot_multi(GatherSites gs, int d) {
+  constexpr int GPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int lig = lane % LPR;
+  const int gid = lane / LPR;
+  const int col = lig * 4;
+  const int64_t total = gs.row_end[gs.count - 1];
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t q = wave * GPW + gid; q < total; q += nwave * GPW) {
+    int s = 0;
+    while (q >= gs.row_end[s]) ++s;
+    const int64_t r = q - (s ? gs.row_end[s - 1] : 0);
+    const int id = gs.ids[s][r];
+    const int row = gs.cat_map[s] ? gs.cat_map[s][id] : id;
+    const float sc = gs.scale[s];
+    if (col < d) {
+      const float4 v = *reinterpret_cast<const float4*>(gs.E[s] + (int64_t)row * d + col);
+      *reinterpret_cast<float4*>(gs.out[s] + r * gs.ldo[s] + col) =
+          make_float4(sc * v.x, sc * v.y, sc * v.z, sc * v.w);
+    }
+    if (gs.bias_out[s] && lig == 0) gs.bias_out[s][r] = sc * gs.bias[s][row];
+  }
+}
+
 // Padded (un-compacted) bag expansion for the gradient scatter: slot r * max_len + j holds token j
 // of bag r, slots past the bag's length hold pad_token.  No prefix sums -- K7's sort drops the
 // pads in its first pass anyway, so compacting them first (arx_csr_expand: four launches) buys
@@ -404,6 +445,41 @@ int arx_gather_onehot_fwd(const float* E, const float* bias, const int32_t* cat_
   ARX_DISPATCH_LPR(lpr, (k_gather_onehot<LPR><<<grid_waves(nwaves), 256, 0, as_stream(stream)>>>(
                             E, bias, cat_map, ids, B, d, scale, accumulate, out, ldo,
                             bias_out)));
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_gather_onehot_multi(int nsites, const float* const* E, const float* const* bias,
+                            const int32_t* const* cat_map, const int32_t* const* ids,
+                            const int64_t* n, int d, const float* scale, float* const* out,
+                            const int64_t* ldo, float* const* bias_out, void* stream) {
+  ARX_CHECK_ARG(nsites >= 1 && nsites <= kMaxSites, "arx_gather_onehot_multi: 1..8 sites");
+  ARX_CHECK_ARG(E && ids && n && out && ldo && scale, "arx_gather_onehot_multi: null pointer");
+  int rc = check_d("arx_gather_onehot_multi", d);
+  if (rc) return rc;
+  GatherSites gs = {};
+  int64_t tot = 0;
+  for (int s = 0; s < nsites; ++s) {
+    ARX_CHECK_ARG(E[s] && ids[s] && out[s] && n[s] >= 0, "arx_gather_onehot_multi: bad site");
+    ARX_CHECK_ARG(ldo[s] % 4 == 0 && ldo[s] >= d && aligned16(E[s]) && aligned16(out[s]),
+                  "arx_gather_onehot_multi: ldo %% 4 and 16-byte alignment required");
+    ARX_CHECK_ARG(!(bias_out && bias_out[s] && !(bias && bias[s])), "arx_gather_onehot_multi: bias_out requires bias");
+    gs.E[s] = E[s];
+    gs.bias[s] = bias ? bias[s] : nullptr;
+    gs.cat_map[s] = cat_map ? cat_map[s] : nullptr;
+    gs.ids[s] = ids[s];
+    gs.out[s] = out[s];
+    gs.bias_out[s] = bias_out ? bias_out[s] : nullptr;
+    gs.ldo[s] = ldo[s];
+    gs.scale[s] = scale[s];
+    tot += n[s];
+    gs.row_end[s] = tot;
+  }
+  gs.count = nsites;
+  if (tot == 0) return ARX_OK;
+  const int lpr = lanes_per_row(d);
+  const int64_t nwaves = ceil_div(tot, 64 / lpr);
+  ARX_DISPATCH_LPR(lpr, (k_gather_onehot_multi<LPR><<<grid_waves(nwaves), 256, 0, as_stream(stream)>>>(gs, d)));
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

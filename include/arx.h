@@ -95,6 +95,14 @@ int arx_gather_onehot_fwd(const float* E, const float* bias, const int32_t* cat_
                           const int32_t* ids, int64_t B, int d, float scale, int accumulate,
                           float* out, int64_t ldo, float* bias_out, void* stream);
 
+/* nsites one-hot lookups of equal width d in ONE launch (site s: out[s][r, 0:d] = scale[s] *
+ * E[s][cat_map[s] ? cat_map[s][ids[s][r]] : ids[s][r], :], bias_out[s][r] likewise; r < n[s]).
+ * The lookups of a step (user ids, target items, sampled pool, input items) are independent. */
+int arx_gather_onehot_multi(int nsites, const float* const* E, const float* const* bias,
+                            const int32_t* const* cat_map, const int32_t* const* ids,
+                            const int64_t* n, int d, const float* scale, float* const* out,
+                            const int64_t* ldo, float* const* bias_out, void* stream);
+
 /* ---- a5: multi-hot gather + segment-mean (K1) ---------------------------
  * embed_attribute.py:382-407 with mulhot_index.py:48-67 fused in:
  *   bag(r) = vals[starts[id_r] : starts[id_r] + lens[id_r]]
