@@ -57,6 +57,7 @@ class Dropout(G.Node):
     drawn masks (`keep`) through the oracle."""
 
     requires_grad = True
+    uses_dropout = True          # plans with such nodes bump the device step counter every step
 
     def __init__(self, rt, x):
         super().__init__(rt, x.shape, (x,))

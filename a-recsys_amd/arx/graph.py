@@ -469,7 +469,7 @@ class Plan(object):
         self.warm = 0
         self._kp = rt.keep_prob
         self._pregather = None
-        self.has_dropout = any(type(n).__name__ == 'Dropout' for n in self.order)
+        self.has_dropout = any(getattr(n, 'uses_dropout', False) for n in self.order)
         self.tables = []
         self.arenas = []
         if train:

@@ -42,9 +42,13 @@ class _Op(object):
 
 
 class MLP(G.Node):
-    """hmf_model.py:80-94: act(act(act(u).W1 + b1).W2 + b2), keep_prob == 1."""
+    """hmf_model.py:80-94: drop(act(drop(act(drop(act(u)) . W1 + b1)) . W2 + b2)) -- tf.nn.dropout
+    after every activation with the model's keep probability (identity in forward-only plans
+    and when rt.keep_prob == 1).  The three keep masks stay readable in `keeps` (parity tests
+    replay them through the oracle)."""
 
     requires_grad = True
+    uses_dropout = True
 
     def __init__(self, rt, x, params, kind):
         self.w1, self.b1, self.w2, self.b2 = params
@@ -52,32 +56,69 @@ class MLP(G.Node):
         self.kind = 0 if kind == 'relu' else 1
         n, hdim = x.shape[0], self.w1.w.shape[1]
         dev = rt.device
-        self.h0 = torch.empty(x.shape, dtype=torch.float32, device=dev)
-        self.h1 = torch.empty((n, hdim), dtype=torch.float32, device=dev)
-        self.d1 = torch.empty((n, hdim), dtype=torch.float32, device=dev)
-        self.d0 = torch.empty(x.shape, dtype=torch.float32, device=dev)
+        f32 = torch.float32
+        self.h0 = torch.empty(x.shape, dtype=f32, device=dev)          # act(u)
+        self.h1 = torch.empty((n, hdim), dtype=f32, device=dev)        # act(z1)
+        self.h2 = torch.empty(self.shape, dtype=f32, device=dev)       # act(z2)
+        self.h0d, self.h1d = torch.empty_like(self.h0), torch.empty_like(self.h1)   # after dropout
+        self.d1 = torch.empty((n, hdim), dtype=f32, device=dev)
+        self.d0 = torch.empty(x.shape, dtype=f32, device=dev)
+        self.keeps = [torch.empty(t.numel(), dtype=torch.uint8, device=dev) for t in (self.h0, self.h1, self.h2)]
+        self.sids = []
+        for _ in range(3):
+            rt.dropout_calls += 1
+            self.sids.append(rt.dropout_calls)
+        self.kp_used = 1.0
+
+    def _drop(self, k, src, dst, kp):
+        ops.dropout_fwd_step(src, kp, self.rt.seed * 1000003 + self.sids[k], self.rt.step_dev, dst, self.keeps[k])
 
     def forward(self, train):
         x = self.inputs[0]
+        rt = self.rt
         out = self.alloc_value()
+        kp = rt.keep_prob if train else 1.0
+        self.kp_used = kp
+        drop = kp < 1.0
         ops.act_fwd(x.value, self.kind, self.h0)
-        ops.gemm(self.h0, self.w1.w, self.h1, self.rt.ws, col_bias=self.b1.w)
+        a0 = self.h0
+        if drop:
+            self._drop(0, self.h0, self.h0d, kp)
+            a0 = self.h0d
+        ops.gemm(a0, self.w1.w, self.h1, rt.ws, col_bias=self.b1.w)
         ops.act_fwd(self.h1, self.kind, self.h1)
-        ops.gemm(self.h1, self.w2.w, out, self.rt.ws, col_bias=self.b2.w)
-        ops.act_fwd(out, self.kind, out)
+        a1 = self.h1
+        if drop:
+            self._drop(1, self.h1, self.h1d, kp)
+            a1 = self.h1d
+        h2 = self.h2 if drop else out
+        ops.gemm(a1, self.w2.w, h2, rt.ws, col_bias=self.b2.w)
+        ops.act_fwd(h2, self.kind, h2)
+        if drop:
+            self._drop(2, self.h2, out, kp)
 
     def backward(self):
         x = self.inputs[0]
         rt = self.rt
+        kp = self.kp_used
+        drop = kp < 1.0
         dz2 = self.grad
-        ops.act_bwd(self.value, dz2, self.kind, dz2)                    # through act(z2)
-        ops.gemm(self.h1, dz2, self.w2.grad, rt.ws, transA=True)
+        if drop:
+            ops.dropout_bwd(dz2, self.keeps[2], kp, dz2)
+        ops.act_bwd(self.h2 if drop else self.value, dz2, self.kind, dz2)      # through act(z2)
+        a1 = self.h1d if drop else self.h1
+        a0 = self.h0d if drop else self.h0
+        ops.gemm(a1, dz2, self.w2.grad, rt.ws, transA=True)
         ops.col_sum(dz2, self.b2.grad, rt.ws)
         ops.gemm(dz2, self.w2.w, self.d1, rt.ws, transB=True)
+        if drop:
+            ops.dropout_bwd(self.d1, self.keeps[1], kp, self.d1)
         ops.act_bwd(self.h1, self.d1, self.kind, self.d1)
-        ops.gemm(self.h0, self.d1, self.w1.grad, rt.ws, transA=True)
+        ops.gemm(a0, self.d1, self.w1.grad, rt.ws, transA=True)
         ops.col_sum(self.d1, self.b1.grad, rt.ws)
         ops.gemm(self.d1, self.w1.w, self.d0, rt.ws, transB=True)
+        if drop:
+            ops.dropout_bwd(self.d0, self.keeps[0], kp, self.d0)
         ops.act_bwd(self.h0, self.d0, self.kind, self.d0)
         g = x.alloc_grad()
         ops.add_rows_bcast(1.0, self.d0, x.grad_beta(), g)
@@ -192,8 +233,6 @@ class LatentProductModel(object):
         self.att_emb = m
         embedded_user, _ = m.get_batch_user(float(dropout), False)          # :78
         if self.nonlinear in ('relu', 'tanh'):
-            if dropout != 1.0:
-                raise NotImplementedError("MLP with dropout < 1")
             ps = []
             for name, shape in (('w1', (size, hidden_size)), ('b1', (hidden_size,)),
                                 ('w2', (hidden_size, size)), ('b2', (size,))):
@@ -202,6 +241,7 @@ class LatentProductModel(object):
                 rt.dense[name] = p
                 ps.append(p)
             embedded_user, _ = m.get_batch_user(1.0, False)                  # :87
+            rt.keep_prob = float(dropout)                                    # :88-94 dropout inside the MLP
             embedded_user = MLP(rt, embedded_user, ps, self.nonlinear)
         self.embedded_user = embedded_user
 

@@ -627,30 +627,36 @@ class RefLatentProductModel(object):
     def _dact(self, y, x):
         return (x > 0).astype(self.dt) if self.nonlinear == 'relu' else 1 - y * y
 
-    def _mlp_fwd(self, u):
+    def _mlp_fwd(self, u, drops=None):
+        """drops: None or three arrays mask/keep_prob (tf.nn.dropout after every activation)."""
         P = self.att_emb.params
+        o = (lambda k, a: a * drops[k]) if drops is not None else (lambda k, a: a)
         h0 = self._act(u)
-        z1 = h0 @ P['w1'] + P['b1']
+        h0d = o(0, h0)
+        z1 = h0d @ P['w1'] + P['b1']
         h1 = self._act(z1)
-        z2 = h1 @ P['w2'] + P['b2']
+        h1d = o(1, h1)
+        z2 = h1d @ P['w2'] + P['b2']
         h2 = self._act(z2)
-        return h2, (u, h0, z1, h1, z2, h2)
+        return o(2, h2), (u, h0, h0d, z1, h1, h1d, z2, h2, drops)
 
     def _mlp_bwd(self, c, d_out, grads):
         P = self.att_emb.params
-        u, h0, z1, h1, z2, h2 = c
-        dz2 = d_out * self._dact(h2, z2)
-        grads.add_dense('w2', h1.T @ dz2)
+        u, h0, h0d, z1, h1, h1d, z2, h2, drops = c
+        o = (lambda k, a: a * drops[k]) if drops is not None else (lambda k, a: a)
+        dz2 = o(2, d_out) * self._dact(h2, z2)
+        grads.add_dense('w2', h1d.T @ dz2)
         grads.add_dense('b2', dz2.sum(0))
-        dh1 = dz2 @ P['w2'].T
+        dh1 = o(1, dz2 @ P['w2'].T)
         dz1 = dh1 * self._dact(h1, z1)
-        grads.add_dense('w1', h0.T @ dz1)
+        grads.add_dense('w1', h0d.T @ dz1)
         grads.add_dense('b1', dz1.sum(0))
-        dh0 = dz1 @ P['w1'].T
+        dh0 = o(0, dz1 @ P['w1'].T)
         return dh0 * self._dact(h0, u)
 
     def step(self, user_input, item_input, item_sampled=None, item_sampled_id2idx=None,
-             forward_only=False, recommend=False, loss=None, keep_prob=1.0, user_mask=None):
+             forward_only=False, recommend=False, loss=None, keep_prob=1.0, user_mask=None,
+             mlp_masks=None):
         """hmf_model.py:162-228 (session dropped).  tf.nn.dropout on the user embedding
         (embed_attribute.py:236, hmf_model.py:78): `user_mask` replays an externally drawn 0/1
         keep mask [mb, d] -- u * mask / keep_prob."""
@@ -665,7 +671,10 @@ class RefLatentProductModel(object):
             u = u * drop
         c_mlp = None
         if self.nonlinear in ('relu', 'tanh'):
-            u, c_mlp = self._mlp_fwd(u)
+            drops = None
+            if mlp_masks is not None and keep_prob < 1.0 and not forward_only and not recommend:
+                drops = [np.asarray(mk, dtype=self.dt) / self.dt.type(keep_prob) for mk in mlp_masks]
+            u, c_mlp = self._mlp_fwd(u, drops)
         if recommend:
             logits, _ = m.get_prediction(u, 'full')
             # tf.nn.top_k(sorted=True): descending values, ties -> lower index first

@@ -245,3 +245,49 @@ def test_hmf_user_dropout_replayed_through_oracle(dev, use_graph):
     e_ref = ref.step(list(users), list(items), forward_only=True, loss='mw')
     e_got = model.step(None, list(users), list(items), forward_only=True, loss='mw')
     np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
+
+
+@pytest.mark.parametrize("nonlinear", ['relu', 'tanh'])
+def test_hmf_mlp_dropout_replayed_through_oracle(dev, nonlinear):
+    """hmf_model.py:80-94 with keep_prob < 1: tf.nn.dropout after each of the three activations
+    of the user MLP (none on the raw lookup, :87)."""
+    d, B, S, keep = 32, 64, 128, 0.7
+    syn, model, ref = None, None, None
+    from arx.utils.synthetic import SyntheticHMF
+    from arx.hmf.hmf_model import LatentProductModel
+    syn = SyntheticHMF(seed=7, **CFG_ID)
+    params = syn.glorot_params(d, seed=8, scale=0.5)
+    rng = np.random.default_rng(9)
+    params['w1'] = (rng.standard_normal((d, 48)) * 0.3).astype(np.float32)
+    params['b1'] = (rng.standard_normal((48,)) * 0.1).astype(np.float32)
+    params['w2'] = (rng.standard_normal((48, d)) * 0.3).astype(np.float32)
+    params['b2'] = (rng.standard_normal((d,)) * 0.1).astype(np.float32)
+    i2l, l2i = syn.item_ind2logit_ind_dict(), syn.logit_ind2item_ind
+    model = LatentProductModel(syn.n_users, syn.n_items, d, 1, B, 0.5, 1.0, syn.u_attr, syn.i_attr, i2l, l2i,
+                               loss_function='mw', n_sampled=S, params=params, dropout=keep,
+                               nonlinear=nonlinear, hidden_size=48)
+    ref = rg.RefLatentProductModel(d, B, 0.5, syn.u_attr, syn.i_attr, i2l, l2i, loss_function='mw',
+                                   n_sampled=S, params=params, dtype=np.float64, nonlinear=nonlinear,
+                                   hidden_size=48)
+    pos = syn.positives_dict()
+    model.prepare_warp(pos, pos)
+    ref.prepare_warp(pos, pos)
+    pool = syn.sample_pool(S, rng)
+    id2idx = {int(v): i for i, v in enumerate(pool)}
+    mlp = model.embedded_user
+    for step in range(3):
+        users, items = syn.sample_batch(B, rng)
+        ps = pool if step == 0 else None
+        l_got = model.step(None, list(users), list(items), None, ps, id2idx if ps is not None else None, loss='mw')
+        masks = [mlp.keeps[0].cpu().numpy().reshape(B, d), mlp.keeps[1].cpu().numpy().reshape(B, 48),
+                 mlp.keeps[2].cpu().numpy().reshape(B, d)]
+        assert all(abs(mk.mean() - keep) < 0.06 for mk in masks)
+        if step:
+            assert any((a != b).any() for a, b in zip(masks, prev_masks))     # fresh draw per (replayed) step
+        prev_masks = masks
+        l_ref = ref.step(list(users), list(items), ps, id2idx, loss='mw', keep_prob=keep, mlp_masks=masks)
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='step %d' % step)
+        _compare_state(model, ref)
+    e_ref = ref.step(list(users), list(items), forward_only=True, loss='mw')
+    e_got = model.step(None, list(users), list(items), forward_only=True, loss='mw')
+    np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
