@@ -33,16 +33,26 @@ constexpr int kBNMax = 128;
 // iteration when the builtin is used in a 3-stage ring; issued this way the copy is invisible
 // to it and ALL ordering is explicit (counted s_waitcnt vmcnt(N) + s_barrier below).  M0 (the
 // wave-uniform LDS base) is saved and restored inside the statement.
+template <bool NT = false>
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
   const uint32_t dst = __builtin_amdgcn_readfirstlane(
       (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lds_wave_base);
   uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(dst)
-      : "memory");
+  if constexpr (NT) {       // streamed operand (read once per launch): do not keep it in L2
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(dst)
+        : "memory");
+  } else {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(dst)
+        : "memory");
+  }
 }
 
 template <bool A_KC, int BM, int kBN>
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
         const int k = f / (BM / 4), mq = f % (BM / 4);
         src = A + (k0 + k) * lda + min(m0 + mq * 4, M - 4);
       }
-      glds16(src, imgA + (f - lane) * 4);
+      glds16<true>(src, imgA + (f - lane) * 4);     // A = dlogits: streamed once
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {

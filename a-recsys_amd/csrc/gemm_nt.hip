@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int ro = (e & 3) + 8 * (e >> 2);
-          if (rbase + ro < M) cp[(int64_t)ro * ldc] = alpha * (j == 0 ? acc0[e] : acc1[e]) + bias;
+          if (rbase + ro < M)
+            __builtin_nontemporal_store(alpha * (j == 0 ? acc0[e] : acc1[e]) + bias, cp + (int64_t)ro * ldc);
         }
       }
     }

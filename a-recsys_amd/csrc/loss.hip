@@ -154,9 +154,13 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int64_t c = (int64_t)i * 256 + lane * 4;
-    v[i] = (c + 3 < W) ? *reinterpret_cast<const float4*>(x + c)
-                       : make_float4(c < W ? x[c] : 0.f, c + 1 < W ? x[c + 1] : 0.f,
-                                     c + 2 < W ? x[c + 2] : 0.f, 0.f);
+    if (c + 3 < W) {       // streaming load: the logits row is read exactly once
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(x + c));
+      v[i] = make_float4(q.x, q.y, q.z, q.w);
+    } else {
+      v[i] = make_float4(c < W ? x[c] : 0.f, c + 1 < W ? x[c + 1] : 0.f, c + 2 < W ? x[c + 2] : 0.f, 0.f);
+    }
   }
   // keep bits of this lane's columns: bit (4*i + e) <-> column i*256 + lane*4 + e
   uint32_t keep = 0u;
@@ -260,7 +264,11 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
   for (int i = 0; i < NV; ++i) {
     const int64_t c = (int64_t)i * 256 + lane * 4;
     if (c + 3 < W) {
-      *reinterpret_cast<float4*>(dx + c) = d[i];
+      // streaming store: dlogits is consumed by the two backward GEMMs, never re-read from L2
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      v4f o;
+      o.x = d[i].x; o.y = d[i].y; o.z = d[i].z; o.w = d[i].w;
+      __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(dx + c));
     } else {
       if (c < W) dx[c] = d[i].x;
       if (c + 1 < W) dx[c + 1] = d[i].y;
