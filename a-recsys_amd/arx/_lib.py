@@ -91,6 +91,12 @@ PROTOTYPES = {
                                             C.POINTER(i64), C.POINTER(i32), C.POINTER(f32), f32p, i64,
                                             f32p, f32p, f32p, i32p, i32p, f32p, cint, C.POINTER(i64),
                                             C.POINTER(i32), vp, sz, vp]),
+    "arx_sparse_adagrad_cat_multi_phase": (cint, [cint, cint, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                                  C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), cint, cint,
+                                                  C.POINTER(i32), C.POINTER(vp), C.POINTER(vp),
+                                                  C.POINTER(i64), C.POINTER(i32), C.POINTER(f32), f32p, i64,
+                                                  f32p, f32p, f32p, i32p, i32p, f32p, cint, C.POINTER(i64),
+                                                  C.POINTER(i32), vp, sz, vp]),
     "arx_adagrad_dense": (cint, [f32p, f32p, f32p, i64, f32p, f32p, vp]),
     "arx_sq_norm_accum": (cint, [f32p, i64, cint, f32p, f32p, vp]),
     "arx_clip_coef": (cint, [f32p, f32, f32p, f32p, vp]),

@@ -403,12 +403,15 @@ class MultiCatArgs(object):
         self._keep = (tables, sites)
 
 
-def sparse_adagrad_cat_multi(args, G, Gb, lr_dev, keys_buf, src_buf, coef_buf, ws, gscale_dev=None):
+def sparse_adagrad_cat_multi(args, G, Gb, lr_dev, keys_buf, src_buf, coef_buf, ws, gscale_dev=None, phase=3):
+    """phase 1: key generation + sort (needs the ids only), phase 2: apply, 3: both.  The two
+    halves must use the same workspace object, untouched in between."""
     wsp, wsn = ws.get(_lib.lib.arx_sparse_adagrad_workspace_bytes(args.total))
-    call("arx_sparse_adagrad_cat_multi", args.nt, args.E, args.acc, args.bias, args.bias_acc,
-         args.rows, args.cnt, args.d, args.ns, args.site_table, args.cat_map, args.ids, args.count,
-         args.row_base, args.coef, _p(G), _ld(G), _p(Gb), _p(lr_dev), _p(gscale_dev), _p(keys_buf),
-         _p(src_buf), _p(coef_buf), args.nx, args.extra_n, args.extra_table, wsp, wsn, _stream())
+    call("arx_sparse_adagrad_cat_multi_phase", int(phase), args.nt, args.E, args.acc, args.bias,
+         args.bias_acc, args.rows, args.cnt, args.d, args.ns, args.site_table, args.cat_map, args.ids,
+         args.count, args.row_base, args.coef, _p(G), _ld(G), _p(Gb), _p(lr_dev), _p(gscale_dev),
+         _p(keys_buf), _p(src_buf), _p(coef_buf), args.nx, args.extra_n, args.extra_table, wsp, wsn,
+         _stream())
 
 
 def adagrad_dense(w, acc, g, lr_dev, gscale_dev=None):

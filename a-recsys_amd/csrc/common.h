@@ -97,7 +97,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
                                 const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
                                 const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
                                 float* coef_buf, void* workspace, size_t workspace_bytes,
-                                hipStream_t s);
+                                hipStream_t s, int phase = 3);   // 1: keys + sort, 2: apply, 3: both
 
 // gemm_nt.hip: logits GEMM with the A operand register-resident (K in {32,64,128});
 // ARX_EUNSUPPORTED for any other shape / alignment.

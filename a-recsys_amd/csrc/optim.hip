@@ -954,7 +954,10 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
                                 const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
                                 const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
                                 float* coef_buf, void* workspace, size_t workspace_bytes,
-                                hipStream_t s) {
+                                hipStream_t s, int phase) {
+  // phase 1 (keys + sort) depends on the lookup ids only, not on any gradient: the caller may run
+  // it on a side stream under the forward / backward GEMMs and join before phase 2 (apply).  Both
+  // phases must see the same workspace, untouched in between.
   const int64_t n = st.offs[st.nsites] + st.xoffs[st.nextra];   // one-hot + pre-expanded
   if (n == 0) return ARX_OK;
   SparseWs w;
@@ -979,7 +982,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   int32_t* count = reinterpret_cast<int32_t*>(base + w.off_count);
   float* scratch = reinterpret_cast<float*>(base + w.off_scratch);
   float* scratch_b = reinterpret_cast<float*>(base + w.off_scratch_b);
-  {
+  if (phase & 1) {
     int64_t g = ceil_div(n, 256);
     k_site_keys<<<(int)g, 256, 0, s>>>(st, keys_buf, src_buf, coef_buf);
     ARX_CHECK_LAUNCH();
@@ -993,18 +996,23 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   const float* coef_arg = scoef;
   const int32_t* n_dev = nullptr;      // live-entry count of the radix sort (pads dropped)
   if (n <= kRankSortMax) {
-    rc = launch_rank_sort(keys_buf, n, sentinel, keys_out, pos_out, count, s, src_buf, coef_buf,
-                          ssrc, scoef);
-    if (rc) return rc;
+    if (phase & 1) {
+      rc = launch_rank_sort(keys_buf, n, sentinel, keys_out, pos_out, count, s, src_buf, coef_buf,
+                            ssrc, scoef);
+      if (rc) return rc;
+    }
   } else {   // own LSD radix sort: src/coef come out in sorted order too
-    rc = launch_radix_sort(keys_buf, src_buf, coef_buf, n, sentinel, key_bits + 1,
-                           reinterpret_cast<uint32_t*>(base + w.off_keys_tmp), keys_out,
-                           reinterpret_cast<int32_t*>(base + w.off_pos_in), ssrc,
-                           reinterpret_cast<float*>(base + w.off_pos_out), scoef,
-                           reinterpret_cast<int32_t*>(base + w.off_hist), count, count + 2, s);
-    if (rc) return rc;
+    if (phase & 1) {
+      rc = launch_radix_sort(keys_buf, src_buf, coef_buf, n, sentinel, key_bits + 1,
+                             reinterpret_cast<uint32_t*>(base + w.off_keys_tmp), keys_out,
+                             reinterpret_cast<int32_t*>(base + w.off_pos_in), ssrc,
+                             reinterpret_cast<float*>(base + w.off_pos_out), scoef,
+                             reinterpret_cast<int32_t*>(base + w.off_hist), count, count + 2, s);
+      if (rc) return rc;
+    }
     n_dev = count + 2;
   }
+  if (!(phase & 2)) return ARX_OK;
   bool any_bias = false;
   for (int t = 0; t < ntables; ++t) any_bias = any_bias || ts.bias[t] != nullptr;
   const float* gb_in = any_bias ? Gb : nullptr;

@@ -350,7 +350,7 @@ int arx_sparse_adagrad_cat(float* E, float* acc, float* bias, float* bias_acc, i
 }
 
 
-int arx_sparse_adagrad_cat_multi(int ntables, float* const* E, float* const* acc, float* const* bias,
+static int cat_multi_impl(int phase, int ntables, float* const* E, float* const* acc, float* const* bias,
                                  float* const* bias_acc, const int64_t* table_rows,
                                  int32_t* const* aux_cnt, int d, int nsites,
                                  const int32_t* site_table, const int32_t* const* site_cat_map,
@@ -428,7 +428,43 @@ int arx_sparse_adagrad_cat_multi(int ntables, float* const* E, float* const* acc
   if (n == 0) return ARX_OK;
   ARX_CHECK_ARG(n < (int64_t)INT_MAX, "arx_sparse_adagrad_cat_multi: too many contributions");
   return sparse_adagrad_sites_sorted(ts, ntables, d, st, G, ldg, Gb, lr_dev, gscale_dev, keys_buf,
-                                     src_buf, coef_buf, workspace, workspace_bytes, as_stream(stream));
+                                     src_buf, coef_buf, workspace, workspace_bytes, as_stream(stream), phase);
+}
+
+int arx_sparse_adagrad_cat_multi(int ntables, float* const* E, float* const* acc, float* const* bias,
+                                 float* const* bias_acc, const int64_t* table_rows,
+                                 int32_t* const* aux_cnt, int d, int nsites,
+                                 const int32_t* site_table, const int32_t* const* site_cat_map,
+                                 const int32_t* const* site_ids, const int64_t* site_n,
+                                 const int32_t* site_row_base, const float* site_coef, const float* G,
+                                 int64_t ldg, const float* Gb, const float* lr_dev,
+                                 const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
+                                 float* coef_buf, int nextra, const int64_t* extra_n,
+                                 const int32_t* extra_table, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  return cat_multi_impl(3, ntables, E, acc, bias, bias_acc, table_rows, aux_cnt, d, nsites, site_table,
+                        site_cat_map, site_ids, site_n, site_row_base, site_coef, G, ldg, Gb, lr_dev,
+                        gscale_dev, keys_buf, src_buf, coef_buf, nextra, extra_n, extra_table, workspace,
+                        workspace_bytes, stream);
+}
+
+int arx_sparse_adagrad_cat_multi_phase(int phase, int ntables, float* const* E, float* const* acc,
+                                       float* const* bias, float* const* bias_acc,
+                                       const int64_t* table_rows, int32_t* const* aux_cnt, int d,
+                                       int nsites, const int32_t* site_table,
+                                       const int32_t* const* site_cat_map,
+                                       const int32_t* const* site_ids, const int64_t* site_n,
+                                       const int32_t* site_row_base, const float* site_coef,
+                                       const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
+                                       const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
+                                       float* coef_buf, int nextra, const int64_t* extra_n,
+                                       const int32_t* extra_table, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  ARX_CHECK_ARG(phase == 1 || phase == 2 || phase == 3, "arx_sparse_adagrad_cat_multi_phase: phase 1, 2 or 3");
+  return cat_multi_impl(phase, ntables, E, acc, bias, bias_acc, table_rows, aux_cnt, d, nsites, site_table,
+                        site_cat_map, site_ids, site_n, site_row_base, site_coef, G, ldg, Gb, lr_dev,
+                        gscale_dev, keys_buf, src_buf, coef_buf, nextra, extra_n, extra_table, workspace,
+                        workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -328,6 +328,22 @@ int arx_sparse_adagrad_cat_multi(int ntables, float* const* E, float* const* acc
                                  float* coef_buf, int nextra, const int64_t* extra_n,
                                  const int32_t* extra_table, void* workspace,
                                  size_t workspace_bytes, void* stream);
+/* The same pass in two halves: phase 1 = key generation + sort (depends on the lookup ids only --
+ * it can run on a side stream under the forward/backward GEMMs), phase 2 = apply (needs G);
+ * phase 3 = both.  Both halves take the same arguments and the same, otherwise untouched,
+ * workspace. */
+int arx_sparse_adagrad_cat_multi_phase(int phase, int ntables, float* const* E, float* const* acc,
+                                       float* const* bias, float* const* bias_acc,
+                                       const int64_t* table_rows, int32_t* const* aux_cnt, int d,
+                                       int nsites, const int32_t* site_table,
+                                       const int32_t* const* site_cat_map,
+                                       const int32_t* const* site_ids, const int64_t* site_n,
+                                       const int32_t* site_row_base, const float* site_coef,
+                                       const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
+                                       const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
+                                       float* coef_buf, int nextra, const int64_t* extra_n,
+                                       const int32_t* extra_table, void* workspace,
+                                       size_t workspace_bytes, void* stream);
 
 /* ---- a16/a19: dense Adagrad, norms, clip ---------------------------------
  * tf.train.AdagradOptimizer dense apply; tf.clip_by_global_norm
