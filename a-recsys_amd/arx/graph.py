@@ -469,7 +469,8 @@ class Plan(object):
         self.warm = 0
         self._kp = rt.keep_prob
         self._pregather = None
-        self._fused_static, self._k7_early, self._k7_stream = None, None, None
+        self._early_jobs, self._k7_early, self._k7_stream, self._k7_done_keys = [], None, None, None
+        self._jobs, self._n_passes = [], 0
         self.has_dropout = any(getattr(n, 'uses_dropout', False) for n in self.order)
         self.tables = []
         self.arenas = []
@@ -633,22 +634,19 @@ class Plan(object):
                         and sum(len(m) for _, _, m in group) <= 8 and rows_bits + 2 <= 30
                         and n_tot <= (1 << 22)):
                     fused = group
+        early = self._k7_early
+        self._k7_early = None
+        self._k7_done_keys = None
+        if early is not None:
+            torch.cuda.current_stream().wait_event(early[1])          # join the sort branch
+            self._k7_done_keys = early[0]
+        self._jobs, self._n_passes = [], 0
         if fused:
             key = self._multi_key(fused)
-            early = self._k7_early
-            self._k7_early = None
-            if early is not None:
-                torch.cuda.current_stream().wait_event(early[1])          # join the sort branch
-            if early is not None and early[0] == key:
-                self._apply_multi(fused, phase=2, key=key)
-            else:
-                self._apply_multi(fused, phase=3, key=key)
-            self._fused_static = (fused, key)
-        else:
-            if self._k7_early is not None:
-                torch.cuda.current_stream().wait_event(self._k7_early[1])
-                self._k7_early = None
-            self._fused_static = None
+            phase = 2 if (self._k7_done_keys is not None and key in self._k7_done_keys) else 3
+            self._apply_multi(fused, phase=phase, key=key)
+            self._jobs.append(('multi', fused, key, sum(x.cap for _, c, m in fused for x in c + m)))
+            self._n_passes += 1
         done = set(id(e) for e, _, _ in fused)
         toks = []
         for ti, entry in enumerate(self.tables):
@@ -660,6 +658,7 @@ class Plan(object):
                 toks.append(rt.end_fork(tok))
         for t in toks:
             rt.join(t)
+        self._plan_early(self._jobs, self._n_passes)
 
     def _multi_key(self, group):
         return tuple(id(x) for _, c, m in group for x in c + m) + tuple(
@@ -708,18 +707,11 @@ class Plan(object):
     def _early_sort(self):
         """The K7 contributions and their sort depend on the lookup ids only: run them on a side
         stream (a parallel branch of the captured graph) under the forward / backward kernels;
-        _apply_sparse joins the branch and only applies.  The group is the one the previous
-        execution of this plan fused (static in steady state; verified again at apply time)."""
+        _apply_sparse joins the branch and only applies.  The jobs are the passes the previous
+        execution of this plan ran (static in steady state; verified again at apply time)."""
         self._k7_early = None
-        st = self._fused_static
-        if st is None or os.environ.get('ARX_K7_NO_EARLY'):
-            return
-        # Only (a) while the sort is a chain of launch-bound little kernels -- with > 10^5
-        # contributions its kernels are wide enough to take CUs from the GEMMs (B=65536: 845 -> 911 us
-        # per step) -- and (b) when the fused pass is the step's ONLY K7 pass: with a separate
-        # multi-hot pass behind it the branch measured slower (C3 B=16384: 469 -> 482 us).
-        n_tot = sum(x.cap for _, c, m in st[0] for x in c + m)
-        if n_tot > int(os.environ.get('ARX_K7_EARLY_MAX', '100000')) or len(st[0]) != len(self.tables):
+        jobs = self._early_jobs
+        if not jobs or os.environ.get('ARX_K7_NO_EARLY'):
             return
         rt = self.rt
         if self._k7_stream is None:
@@ -729,10 +721,52 @@ class Plan(object):
         ev.record(main)
         self._k7_stream.wait_event(ev)
         with torch.cuda.stream(self._k7_stream):
-            self._apply_multi(st[0], phase=1, key=st[1])
+            for kind, what, key in jobs:
+                if kind == 'multi':
+                    self._apply_multi(what, phase=1, key=key)
+                else:
+                    self._cat_pass(what, key, phase=1)
             done = torch.cuda.Event()
             done.record(self._k7_stream)
-        self._k7_early = (st[1], done)
+        self._k7_early = (set(k for _, _, k in jobs), done)
+
+    def _plan_early(self, jobs, n_passes):
+        """Which of this execution's passes may be sorted ahead next time: all of them or none
+        (with a separate heavy pass behind the branch -- the multi-hot table of C3 -- it measured
+        slower: 469 -> 482 us), and only while the sorts are launch-bound little kernels (beyond
+        ~10^5 contributions they take CUs from the GEMMs: B=65536 845 -> 911 us) on a step that is
+        GPU-bound at all."""
+        cap = int(os.environ.get('ARX_K7_EARLY_MAX', '100000'))
+        # tiny steps are bound by the host-side cost of a graph launch, and a graph with a second
+        # branch costs more to launch (C1, B=64: 75 -> 103 us per step with the branch)
+        lo = int(os.environ.get('ARX_K7_EARLY_MIN', '8192'))
+        ok = jobs and len(jobs) == n_passes and lo <= sum(j[3] for j in jobs) <= cap
+        self._early_jobs = [j[:3] for j in jobs] if ok else []
+
+    def _cat_pass(self, entry, key, phase):
+        """One-hot table, its own pass (arx_sparse_adagrad_cat); key = (live sites, use_bias)."""
+        rt = self.rt
+        table, sites, bufs, total = entry
+        live_ids, use_bias = key
+        if bufs.get('cat_key') != live_ids:
+            live_sites = [s for s in sites if id(s) in live_ids]
+            bufs['cat_key'] = live_ids
+            bufs['cat_args'] = ops.CatSiteArgs(
+                [(s.maps[0], None, s.ids_node.value, s.node.row0, s.coef) for s in live_sites])
+            bufs['cat_node0'] = live_sites[0].node
+            bufs['cat_ws'] = ops.Workspace(rt.device)      # the sorted arrays live here between the phases
+        if getattr(table, 'aux_first', None) is None:
+            table.aux_first = torch.full((table.E.shape[0],), 2 ** 31 - 1, dtype=torch.int32,
+                                         device=rt.device)
+            table.aux_cnt = torch.zeros((table.E.shape[0],), dtype=torch.int32, device=rt.device)
+        node0 = bufs['cat_node0']
+        mode = rt.cat_mode if rt.cat_mode else {3: 0, 1: 0x10, 2: 0x20}[phase]
+        ops.sparse_adagrad_cat(table.E, table.acc, table.bias if use_bias else None,
+                               table.bias_acc if use_bias else None, bufs['cat_args'],
+                               node0.arena, node0.arena_b if use_bias else None, rt.lr,
+                               table.aux_first, table.aux_cnt, bufs['hot'], bufs['keys'],
+                               bufs['src'], bufs['coef'], bufs['cat_ws'], gscale_dev=rt.clip_coef_dev,
+                               mode=mode)
 
     def _apply_one(self, entry):
         rt = self.rt
@@ -743,24 +777,14 @@ class Plan(object):
             n_live = sum(s.n for s in live_sites)
             if all(s.kind == 'cat' and s.col_off == 0 for s in live_sites) and n_live <= (1 << 22) \
                     and len(live_sites) <= 8 and not rt.force_sort_path:
-                # one-hot lookups, few contributions: sort-free fast path (optim_cat.hip)
-                key = tuple(id(s) for s in live_sites)
-                if bufs.get('cat_key') != key:
-                    bufs['cat_key'] = key
-                    bufs['cat_args'] = ops.CatSiteArgs(
-                        [(s.maps[0], None, s.ids_node.value, s.node.row0, s.coef) for s in live_sites])
-                if getattr(table, 'aux_first', None) is None:
-                    table.aux_first = torch.full((table.E.shape[0],), 2 ** 31 - 1, dtype=torch.int32,
-                                                 device=rt.device)
-                    table.aux_cnt = torch.zeros((table.E.shape[0],), dtype=torch.int32, device=rt.device)
-                node0 = live_sites[0].node
+                # one-hot lookups: own pass (optim_cat.hip); sorted ahead when _early_sort ran it
                 use_bias = table.bias is not None and any(s.node.bias_grad_used for s in live_sites)
-                ops.sparse_adagrad_cat(table.E, table.acc, table.bias if use_bias else None,
-                                       table.bias_acc if use_bias else None, bufs['cat_args'],
-                                       node0.arena, node0.arena_b if use_bias else None, rt.lr,
-                                       table.aux_first, table.aux_cnt, bufs['hot'], bufs['keys'],
-                                       bufs['src'], bufs['coef'], rt.ws, gscale_dev=rt.clip_coef_dev,
-                                       mode=rt.cat_mode)
+                key = (tuple(id(s) for s in live_sites), use_bias)
+                early = self._k7_done_keys
+                self._cat_pass(entry, key, 2 if (early is not None and key in early and not rt.cat_mode) else 3)
+                if not rt.cat_mode:
+                    self._jobs.append(('cat', entry, key, n_live))
+                self._n_passes += 1
                 continue
             live = False
             for s in sites:
@@ -787,6 +811,7 @@ class Plan(object):
                                table.bias_acc if use_bias else None, bufs['keys'], bufs['src'],
                                bufs['coef'], G, node0.arena_b if use_bias else None, rt.lr, rt.ws,
                                gscale_dev=rt.clip_coef_dev, n=total, aux_cnt=self._aux_cnt(table))
+            self._n_passes += 1           # a pass that is not sorted ahead: no side branch next time
 
     def _aux_cnt(self, table):
         """Per-row arrival counters of the window apply (zero between launches)."""

@@ -308,7 +308,10 @@ int arx_sparse_adagrad_cat(float* E, float* acc, float* bias, float* bias_acc, i
   if (n == 0) return ARX_OK;
   ARX_CHECK_ARG(n < (int64_t)INT_MAX, "arx_sparse_adagrad_cat: too many contributions");
   hipStream_t s = as_stream(stream);
-  if (mode == 0) {   // default: key generation + sort (LDS rank sort or device radix) + apply
+  if (mode == 0 || mode == 0x10 || mode == 0x20) {   // default: key generation + sort (LDS rank sort
+    // or device radix) + apply; 0x10 / 0x20: only the first / the second half (the sort depends on
+    // the ids alone and may run ahead on another stream; same workspace for both halves)
+    const int phase = mode == 0 ? 3 : (mode == 0x10 ? 1 : 2);
     TableSet ts = {};
     ts.E[0] = E;
     ts.acc[0] = acc;
@@ -324,7 +327,7 @@ int arx_sparse_adagrad_cat(float* E, float* acc, float* bias, float* bias_acc, i
     for (int q = 0; q < kMaxSites; ++q) st.table[q] = 0;
     for (int q = 0; q < kMaxTables; ++q) st.rows[q] = table_rows;
     return sparse_adagrad_sites_sorted(ts, 1, d, st, G, ldg, Gb, lr_dev, gscale_dev, keys_buf, src_buf,
-                                       coef_buf, workspace, workspace_bytes, s);
+                                       coef_buf, workspace, workspace_bytes, s, phase);
   }
   {
     int64_t g = ceil_div(n, 256);

@@ -294,7 +294,8 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
  * mode 0 (default): for n <= 16384 the key generation is folded into a
  * single-workgroup LDS radix sort followed by the two Adagrad passes of
  * arx_sparse_adagrad (workspace >= arx_sparse_adagrad_workspace_bytes(n)) -- 3
- * launches, no atomics; larger n and mode 1 use the atomic leader election above. */
+ * launches, no atomics; larger n and mode 1 use the atomic leader election above. * mode 0: the sorted pass described above; mode 0x10 / 0x20: its first half (contributions + sort:
+ * needs the ids only) / second half (apply) on their own -- same arguments, same untouched workspace. */
 int arx_sparse_adagrad_cat(float* E, float* acc, float* bias, float* bias_acc, int64_t table_rows,
                            int d, int nsites, const int32_t* const* site_cat_map,
                            const int32_t* const* site_ids, const int64_t* site_n,
