@@ -1,0 +1,137 @@
+"""BASELINE.json's full sizes (configs[1] / configs[2]: 1 M users, 1 M items, d = 128, S = 1024
+negatives, B = 16384; multi-hot item attributes with ~20 tokens) -- too large for the numpy
+oracle, so the step is checked through properties that do not depend on size:
+  * bit-reproducibility: same seed, same batches -> identical tables (graph replay vs eager too);
+  * locality: rows outside (batch u pool) are untouched, their Adagrad slots still at 0.1, touched
+    slots strictly grew;
+  * conservation of the WMRB gradient: d loss / d target score = - sum of the row's logit gradient;
+  * the loss reported = mean of the per-row losses, and it falls on a repeated batch;
+  * the touched rows equal a float64 recomputation of the sparse Adagrad update from the step's own
+    gradient rows (linear in the number of contributions)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N, D, B, S = 1000000, 128, 16384, 1024
+
+
+def _model(mulhot, use_graph=True, seed=0):
+    from arx.hmf.hmf_model import LatentProductModel
+    from arx.utils.synthetic import SyntheticHMF
+    syn = SyntheticHMF(n_users=N, n_items=N, item_mulhot=mulhot, permute_logits=False, seed=seed)
+    model = LatentProductModel(N, N, D, 1, B, 0.1, 1.0, syn.u_attr, syn.i_attr, syn.item2logit[:N],
+                               syn.logit_ind2item_ind, loss_function='mw', n_sampled=S,
+                               use_graph=use_graph, seed=seed)
+    model.prepare_warp(syn.positives_csr(), syn.positives_csr())
+    return syn, model
+
+
+def _batches(syn, dev, n, seed=1):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        u, i = syn.sample_batch(B, rng)
+        out.append((torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev)))
+    pool = torch.from_numpy(syn.sample_pool(S, rng).astype(np.int32)).to(dev)
+    return out, pool
+
+
+def _tables(model):
+    return {t.name: (t.E.clone(), t.acc.clone(), None if t.bias is None else t.bias.clone())
+            for t in model.att_emb.tables.values()}
+
+
+@pytest.mark.parametrize("mulhot", [False, True])
+def test_fullsize_bit_reproducible_and_graph_equals_eager(dev, mulhot):
+    res = []
+    for use_graph in (True, True, False):
+        syn, model = _model(mulhot, use_graph=use_graph)
+        batches, pool = _batches(syn, model.rt.device, 4)
+        losses = []
+        for k, (u, i) in enumerate(batches):
+            losses.append(model.step(None, u, i, None, pool if k == 0 else None, None, loss='mw'))
+        res.append((losses, _tables(model)))
+        del model
+    for other in res[1:]:
+        assert other[0] == res[0][0]                                   # same floats, bit for bit
+        for name, (E, acc, bias) in res[0][1].items():
+            assert torch.equal(E, other[1][name][0]) and torch.equal(acc, other[1][name][1]), name
+            if bias is not None:
+                assert torch.equal(bias, other[1][name][2]), name
+
+
+@pytest.mark.parametrize("mulhot", [False, True])
+def test_fullsize_locality_conservation_and_update(dev, mulhot):
+    from arx import graph as G
+    syn, model = _model(mulhot)
+    d_ = model.rt.device
+    batches, pool = _batches(syn, d_, 3)
+    u, i = batches[0]
+    model.step(None, u, i, None, pool, None, loss='mw')                # warm (eager) step
+    before = _tables(model)
+    u, i = batches[1]
+    loss = model.step(None, u, i, None, None, None, loss='mw')          # captured step
+    plan = model._plan('train')
+    bl = [n for n in plan.order if isinstance(n, G.BatchLoss)][0]
+    pred = [n for n in plan.order if type(n) is G.Prediction][0]
+    ts = [n for n in plan.order if isinstance(n, G.TargetScore)][0]
+    # loss = mean of the row losses; WMRB gradient conservation (dt = - sum_s dlogits)
+    np.testing.assert_allclose(loss, float(bl.value.double().mean().item()), rtol=1e-6)
+    dl = pred.grad.double()
+    dt = ts.grad.double()
+    np.testing.assert_allclose(dl.sum(1).cpu().numpy(), -dt.cpu().numpy(), rtol=1e-5, atol=1e-12)
+    assert float(dl.min().item()) >= 0.0 and float(dt.max().item()) <= 0.0
+    # which table rows may move
+    m = model.att_emb
+    touched = {}
+    for table, sites, bufs, total in plan.tables:
+        rows = []
+        for s_ in sites:
+            ids = s_.ids_node.value.long()
+            if s_.kind == 'cat':
+                rows.append(s_.maps[0][ids].long() if s_.maps[0] is not None else ids)
+            else:
+                vals, starts, lens = s_.maps
+                st, ln = starts[ids].long(), lens[ids].long()
+                idx = torch.repeat_interleave(st, ln) + (torch.arange(int(ln.sum()), device=d_) -
+                                                         torch.repeat_interleave(torch.cumsum(ln, 0) - ln, ln))
+                rows.append(vals[idx].long())
+        touched[table.name] = torch.unique(torch.cat(rows))
+    after = _tables(model)
+    for name, (E0, a0, b0) in before.items():
+        E1, a1, b1 = after[name]
+        mask = torch.ones(E0.shape[0], dtype=torch.bool, device=d_)
+        mask[touched[name]] = False
+        assert torch.equal(E0[mask], E1[mask]) and torch.equal(a0[mask], a1[mask]), name   # locality
+        assert float((a1[touched[name]] - a0[touched[name]]).min().item()) >= 0.0
+        assert bool((a1 >= 0.1 - 1e-7).all())
+        assert int((E0 != E1).any(1).sum().item()) > 0.2 * len(touched[name])
+    # float64 recomputation of the sparse Adagrad update of the id table of the items from the
+    # step's own gradient rows (arena) -- linear in the contributions
+    for table, sites, bufs, total in plan.tables:
+        if not all(s_.kind == 'cat' for s_ in sites) or table.bias is None:
+            continue
+        E0, a0, b0 = before[table.name]
+        node0 = sites[0].node
+        g = torch.zeros((E0.shape[0], D), dtype=torch.float64, device=d_)
+        gb = torch.zeros((E0.shape[0],), dtype=torch.float64, device=d_)
+        for s_ in sites:
+            ids = s_.ids_node.value.long()
+            rows = s_.maps[0][ids].long() if s_.maps[0] is not None else ids
+            src = node0.arena[s_.node.row0:s_.node.row0 + s_.n].double() * s_.coef
+            g.index_add_(0, rows, src)
+            gb.index_add_(0, rows, node0.arena_b[s_.node.row0:s_.node.row0 + s_.n].double() * s_.bias_coef)
+        rows = touched[table.name]
+        a_exp = a0[rows].double() + g[rows] ** 2
+        E_exp = E0[rows].double() - 0.1 * g[rows] / a_exp.sqrt()
+        np.testing.assert_allclose(after[table.name][1][rows].cpu().numpy(), a_exp.cpu().numpy(), rtol=2e-5, atol=1e-9)
+        np.testing.assert_allclose(after[table.name][0][rows].cpu().numpy(), E_exp.cpu().numpy(), rtol=2e-5, atol=2e-7)
+        break
+    else:
+        pytest.fail("no one-hot table with a bias in the plan")
+    # the same batch again: the loss falls
+    l1 = model.step(None, u, i, None, None, None, loss='mw')
+    l2 = model.step(None, u, i, None, None, None, loss='mw')
+    assert l2 < l1 < loss
