@@ -135,3 +135,49 @@ def test_fullsize_locality_conservation_and_update(dev, mulhot):
     l1 = model.step(None, u, i, None, None, None, loss='mw')
     l2 = model.step(None, u, i, None, None, None, loss='mw')
     assert l2 < l1 < loss
+
+
+def test_fullsize_lstm_reproducible_clipped_and_learning(dev):
+    """configs[3] at full size (d = h = 64, L = 50, 1 M items, S = 1024, B = 1024 sequences):
+    graph replay and eager execution agree bit for bit, the global norm the step clipped with is
+    the norm of what it applied (clip_by_global_norm: applied update = coef * gradient, coef =
+    clip / max(norm, clip)), and a repeated batch gets cheaper."""
+    from arx.attributes.embed_attribute import EmbeddingAttribute
+    from arx.lstm.seqModel import SeqModel
+    from arx.utils.synthetic import SyntheticHMF
+    Bq, L, size, Sq = 1024, 50, 64, 1024
+    runs = []
+    for use_graph in (True, False):
+        syn = SyntheticHMF(n_users=N, n_items=N, permute_logits=False, seed=0)
+        syn.u_attr.set_model_size(size)
+        syn.i_attr.set_model_size(size)
+        emb = EmbeddingAttribute(syn.u_attr, syn.i_attr, Bq, Sq, L, False, None, syn.logit_ind2item_ind)
+        emb.rt.use_graph = use_graph
+        model = SeqModel([L], size, 1, 5.0, Bq, 0.5, 0.99, emb, loss='mw', use_concat=False, START_ID=N)
+        emb.prepare_warp(syn.positives_csr(), syn.positives_csr())
+        d_ = model.rt.device
+        rng = np.random.default_rng(1)
+        users = torch.from_numpy(rng.integers(0, N, size=Bq).astype(np.int32)).to(d_)
+        tg = np.stack([syn.sample_batch(Bq, rng)[1] for _ in range(L)], 0).astype(np.int32)
+        inp = np.concatenate([np.full((1, Bq), N, dtype=np.int32), tg[:-1]], 0)
+        lens = rng.integers(10, L + 1, size=Bq)
+        w = (np.arange(L)[:, None] < lens[None, :]).astype(np.float32)
+        pool = torch.from_numpy(syn.sample_pool(Sq, rng).astype(np.int32)).to(d_)
+        args = (users, torch.from_numpy(inp).to(d_), torch.from_numpy(tg).to(d_), torch.from_numpy(w).to(d_))
+        W0 = model.W.w.clone()
+        losses, norms = [], []
+        for k in range(4):
+            losses.append(model.step(None, *args, 0, pool if k == 0 else None, None))
+            norms.append(float(model._gnorm.item()))
+        runs.append((losses, norms, model.W.w.clone(), model.b.w.clone(), W0, model))
+    (l_g, n_g, W_g, b_g, W0, m_g), (l_e, n_e, W_e, b_e, _, m_e) = runs
+    assert l_g == l_e and n_g == n_e
+    assert torch.equal(W_g, W_e) and torch.equal(b_g, b_e)
+    for (name, t1), (_, t2) in zip(sorted(m_g.att_emb.get_params().items()), sorted(m_e.att_emb.get_params().items())):
+        assert np.array_equal(t1, t2), name
+    assert all(np.isfinite(n_g)) and max(n_g) > 0
+    assert l_g[-1] < l_g[1] < l_g[0]                                 # same batch, four steps
+    # the clip coefficient of the last step is consistent with its norm
+    coef = float(m_g.rt.clip_coef_dev.item())
+    np.testing.assert_allclose(coef, 5.0 / max(n_g[-1], 5.0), rtol=1e-5)
+    assert not torch.equal(W_g, W0)
