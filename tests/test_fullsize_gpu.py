@@ -181,3 +181,55 @@ def test_fullsize_lstm_reproducible_clipped_and_learning(dev):
     coef = float(m_g.rt.clip_coef_dev.item())
     np.testing.assert_allclose(coef, 5.0 / max(n_g[-1], 5.0), rtol=1e-5)
     assert not torch.equal(W_g, W0)
+
+
+def test_fullsize_integer_paths_bit_exact(dev):
+    """Index work at full size, bit-exact against vectorised numpy / torch: ragged CSR expansion of
+    65536 bags of a 1 M-item multi-hot attribute (compact and padded forms), the weighted sampler
+    over 1 M items, top-k over a 1 M-column score row."""
+    from arx import ops
+    from arx.utils.synthetic import SyntheticHMF
+    syn = SyntheticHMF(n_users=1000, n_items=N, item_mulhot=True, permute_logits=False, seed=3)
+    ia = syn.i_attr
+    vals = np.asarray(ia.features_mulhot[0], dtype=np.int32)
+    starts = np.asarray(ia.mulhot_starts[0], dtype=np.int32)
+    lens = np.asarray(ia.mulhot_lengths[0], dtype=np.int32)
+    rng = np.random.default_rng(0)
+    ids = rng.integers(0, N, size=65536).astype(np.int32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ws = ops.Workspace(dev)
+    ln = lens[ids].astype(np.int64)
+    total = int(ln.sum())
+    cap = total + 1000
+    tok, seg, offs, tot, _ = ops.csr_expand(t(vals), t(starts), t(lens), t(ids), cap, ws, pad_token=-7, pad_seg=-1)
+    exp_offs = np.concatenate([[0], np.cumsum(ln)])
+    exp_seg = np.repeat(np.arange(len(ids)), ln)
+    exp_tok = vals[np.repeat(starts[ids].astype(np.int64), ln) + (np.arange(total) - np.repeat(exp_offs[:-1], ln))]
+    assert int(tot.item()) == total
+    assert np.array_equal(offs.cpu().numpy(), exp_offs)
+    assert np.array_equal(seg.cpu().numpy()[:total], exp_seg) and np.array_equal(tok.cpu().numpy()[:total], exp_tok)
+    assert np.all(tok.cpu().numpy()[total:] == -7) and np.all(seg.cpu().numpy()[total:] == -1)
+    # padded form: the live entries, in order, are the compact form
+    mx = int(lens.max())
+    k = torch.empty(len(ids) * mx, dtype=torch.int32, device=dev)
+    s_ = torch.empty_like(k)
+    c = torch.empty(len(ids) * mx, dtype=torch.float32, device=dev)
+    ops.bag_expand_padded(t(vals), t(starts), t(lens), t(ids), mx, 5, 1.0, k, s_, c)
+    kk, ss, cc = k.cpu().numpy(), s_.cpu().numpy(), c.cpu().numpy()
+    live = kk != ops.KEY_NONE
+    assert int(live.sum()) == total and np.array_equal(kk[live], exp_tok) and np.array_equal(ss[live], exp_seg + 5)
+    np.testing.assert_array_equal(cc[live], (1.0 / np.repeat(ln, ln).astype(np.float32)).astype(np.float32))
+    assert np.all(cc[~live] == 0.0)
+    # sampler: S distinct positions with positive weight, reproducible
+    w = rng.random(N).astype(np.float32) ** 2
+    out = torch.empty(1024, dtype=torch.int32, device=dev)
+    ops.sample_wor(t(w), 1024, seed=11, counter=5, out=out, ws=ws)
+    a = out.cpu().numpy()
+    assert len(np.unique(a)) == 1024 and a.min() >= 0 and a.max() < N and np.all(w[a] > 0)
+    # top-k over 1 M columns: exactly torch's (values and, no ties in random floats, indices)
+    x = torch.randn(8, N, device=dev)
+    v = torch.empty((8, 100), dtype=torch.float32, device=dev)
+    ix = torch.empty((8, 100), dtype=torch.int32, device=dev)
+    ops.topk(x, 100, v, ix)
+    tv, ti = torch.topk(x, 100, dim=1, largest=True, sorted=True)
+    assert torch.equal(v, tv) and torch.equal(ix.long(), ti)
