@@ -199,6 +199,15 @@ class EntityEmbed(Node):
         ids = self.inputs[0].value
         F = len(self.feats)
         col = 0
+        if (F == 2 and not self.concat and self.feats[0].kind == 'cat' and self.feats[1].kind == 'mulhot'
+                and self.feats[0].d == self.feats[1].d):
+            # id + one multi-hot attribute (HET items): both lookups in one launch
+            f0, f1 = self.feats
+            wb = self.with_bias
+            ops.gather_id_plus_bag(f0.table.E, f0.table.bias if wb else None, f0.maps[0], f1.table.E,
+                                   f1.table.bias if wb else None, f1.maps[0], f1.maps[1], f1.maps[2], ids, out,
+                                   scale=self.out_scale / F, bias_out=self.bias_value if wb else None)
+            return
         for k, f in enumerate(self.feats):
             if self.concat:
                 dst, scale, acc = out[:, col:col + f.d], 1.0, False

@@ -138,6 +138,14 @@ def gather_onehot(E, bias, cat_map, ids, out, scale=1.0, accumulate=False, bias_
     return out
 
 
+def gather_id_plus_bag(E_id, bias_id, cat_map, E_tok, bias_tok, vals, starts, lens, ids, out, scale=1.0,
+                       accumulate=False, bias_out=None):
+    """id row + bag mean of one entity in one launch (both scaled by `scale`)."""
+    call("arx_gather_id_plus_bag", _p(E_id), _p(bias_id), _p(cat_map), _p(E_tok), _p(bias_tok), _p(vals),
+         _p(starts), _p(lens), _p(ids), int(ids.shape[0]), int(E_id.shape[1]), float(scale),
+         int(bool(accumulate)), _p(out), _ld(out), _p(bias_out), _stream())
+
+
 class GatherSet(object):
     """Descriptor arrays of arx_gather_onehot_multi, built once per plan.
     sites: [(E, bias|None, cat_map|None, ids, out, scale, bias_out|None)], equal width d."""

@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256) void k_gather_mulhot(
     const int32_t* __restrict__ vals, const int32_t* __restrict__ starts,
     const int32_t* __restrict__ lens, const int32_t* __restrict__ ids, int64_t B, int d,
     float scale, int accumulate, float* __restrict__ out, int64_t ldo,
-    float* __restrict__ bias_out) {
+    float* __restrict__ bias_out, const float* __restrict__ E1, const float* __restrict__ bias1,
+    const int32_t* __restrict__ cat_map1) {
+  // E1 (nullable): a one-hot feature of the same entity (its id row), added to the bag mean before
+  // the common scale -- the two lookups of an (id + multi-hot attribute) item in one launch
   constexpr int GPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int lig = lane % LPR;
@@ -78,6 +81,13 @@ __global__ __launch_bounds__(256) void k_gather_mulhot(
     const int id = ids[r];
     const int st = starts[id];
     const int len = lens[id];
+    float4 one = make_float4(0.f, 0.f, 0.f, 0.f);
+    float one_b = 0.f;
+    if (E1) {
+      const int row1 = cat_map1 ? cat_map1[id] : id;
+      if (colok) one = *reinterpret_cast<const float4*>(E1 + (int64_t)row1 * d + col);
+      if (bias1 && lig == 0) one_b = bias1[row1];
+    }
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
     float bacc = 0.f;
     for (int j0 = 0; j0 < len; j0 += LPR) {
@@ -112,17 +122,17 @@ __global__ __launch_bounds__(256) void k_gather_mulhot(
     if (colok) {
       float4* op = reinterpret_cast<float4*>(out + r * ldo + col);
       float4 o = accumulate ? *op : make_float4(0.f, 0.f, 0.f, 0.f);
-      o.x += scale * (a0.x / flen);
-      o.y += scale * (a0.y / flen);
-      o.z += scale * (a0.z / flen);
-      o.w += scale * (a0.w / flen);
+      o.x += scale * (a0.x / flen + one.x);
+      o.y += scale * (a0.y / flen + one.y);
+      o.z += scale * (a0.z / flen + one.z);
+      o.w += scale * (a0.w / flen + one.w);
       *op = o;
     }
     if (bias_out) {
 #pragma unroll
       for (int o = LPR / 2; o > 0; o >>= 1) bacc += __shfl_xor(bacc, o, LPR);
       if (lig == 0) {
-        float b = scale * (bacc / flen);
+        float b = scale * (bacc / flen + one_b);
         bias_out[r] = accumulate ? bias_out[r] + b : b;
       }
     }
@@ -526,7 +536,28 @@ int arx_gather_mulhot_mean_fwd(const float* E, const float* bias, const int32_t*
   const float* b = bias_out ? bias : nullptr;
   ARX_DISPATCH_LPR(lpr, (k_gather_mulhot<LPR><<<grid_waves(nwaves), 256, 0, as_stream(stream)>>>(
                             E, b, vals, starts, lens, ids, B, d, scale, accumulate, out, ldo,
-                            bias_out)));
+                            bias_out, nullptr, nullptr, nullptr)));
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_gather_id_plus_bag(const float* E_id, const float* bias_id, const int32_t* cat_map,
+                           const float* E_tok, const float* bias_tok, const int32_t* vals,
+                           const int32_t* starts, const int32_t* lens, const int32_t* ids, int64_t B,
+                           int d, float scale, int accumulate, float* out, int64_t ldo,
+                           float* bias_out, void* stream) {
+  ARX_CHECK_ARG(E_id && E_tok && vals && starts && lens && ids && out, "arx_gather_id_plus_bag: null pointer");
+  ARX_CHECK_ARG(!(bias_out && !(bias_id && bias_tok)), "arx_gather_id_plus_bag: bias_out requires both biases");
+  int rc = check_d("arx_gather_id_plus_bag", d);
+  if (rc) return rc;
+  ARX_CHECK_ARG(ldo % 4 == 0 && ldo >= d && aligned16(E_id) && aligned16(E_tok) && aligned16(out),
+                "arx_gather_id_plus_bag: ldo %% 4 and 16-byte alignment required");
+  if (B <= 0) return ARX_OK;
+  const int lpr = lanes_per_row(d);
+  const int64_t nwaves = ceil_div(B, 64 / lpr);
+  ARX_DISPATCH_LPR(lpr, (k_gather_mulhot<LPR><<<grid_waves(nwaves), 256, 0, as_stream(stream)>>>(
+                            E_tok, bias_out ? bias_tok : nullptr, vals, starts, lens, ids, B, d, scale,
+                            accumulate, out, ldo, bias_out, E_id, bias_out ? bias_id : nullptr, cat_map)));
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

@@ -95,6 +95,16 @@ int arx_gather_onehot_fwd(const float* E, const float* bias, const int32_t* cat_
                           const int32_t* ids, int64_t B, int d, float scale, int accumulate,
                           float* out, int64_t ldo, float* bias_out, void* stream);
 
+/* An entity with an id feature AND one multi-hot attribute, both lookups in one launch:
+ * out[r] = (accumulate ? out[r] : 0) + scale * ( E_id[cat_map ? cat_map[ids[r]] : ids[r]] + mean of
+ * E_tok over the entity's bag ), bias likewise (embed_attribute.py:371-407 + the reduce_mean of
+ * :219/:235 with scale = 1/F). */
+int arx_gather_id_plus_bag(const float* E_id, const float* bias_id, const int32_t* cat_map,
+                           const float* E_tok, const float* bias_tok, const int32_t* vals,
+                           const int32_t* starts, const int32_t* lens, const int32_t* ids, int64_t B,
+                           int d, float scale, int accumulate, float* out, int64_t ldo,
+                           float* bias_out, void* stream);
+
 /* nsites one-hot lookups of equal width d in ONE launch (site s: out[s][r, 0:d] = scale[s] *
  * E[s][cat_map[s] ? cat_map[s][ids[s][r]] : ids[s][r], :], bias_out[s][r] likewise; r < n[s]).
  * The lookups of a step (user ids, target items, sampled pool, input items) are independent. */
