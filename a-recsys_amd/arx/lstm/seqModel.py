@@ -545,9 +545,10 @@ class SeqModel(object):
         rt = self.rt
         sq = self._sq
         ops.fill_f32(sq, 0.0)
+        norms = []
         for p in rt.dense.values():
             if getattr(p, 'touched', False):
-                ops.sq_norm_accum(p.grad, sq)
+                norms.append((p.grad, 1, None, None))
         seq_pools = {}
         for n in plan.order:
             if isinstance(n, SeqPrediction) and n.inputs[1].train_tables and n._grad_written:
@@ -576,15 +577,15 @@ class SeqModel(object):
                     dd = 1 if for_bias else d
                     if per_step:
                         rs = self._row_scale(n, True, per_step, 'ps%d' % for_bias)
-                        ops.sq_norm_accum(steps_buf, sq, d=dd,
-                                          row_scale=self._tiled(rs, L, (id(n), for_bias)))
+                        norms.append((steps_buf, dd, self._tiled(rs, L, (id(n), for_bias)), None))
                     if merged:
                         rs = self._row_scale(n, True, merged, 'mg%d' % for_bias)
-                        ops.sq_norm_accum(sum_buf, sq, d=dd, row_scale=rs, n=S * dd)
+                        norms.append((sum_buf, dd, rs, S * dd))
             else:
-                ops.sq_norm_accum(n.grad, sq, d=n.shape[1], row_scale=self._row_scale(n), n=n.grad.numel())
+                norms.append((n.grad, n.shape[1], self._row_scale(n), n.grad.numel()))
                 if n.bias_grad_used:
-                    ops.sq_norm_accum(n.bias_grad, sq, d=1, row_scale=self._row_scale(n, True))
+                    norms.append((n.bias_grad, 1, self._row_scale(n, True), None))
+        ops.sq_norm_accum_multi(norms, sq)          # every plain tensor norm of the step: one launch
         ops.clip_coef(sq, self.max_gradient_norm, rt.clip_coef_dev, self._gnorm)
 
     # ---------------------------------------------------------------------- step

@@ -432,6 +432,19 @@ def sq_norm_accum(x, out_accum, d=1, row_scale=None, n=None):
          _p(out_accum), _stream())
 
 
+def sq_norm_accum_multi(items, out_accum):
+    """items: [(x, d, row_scale|None, n|None)]: out += sum over all of them, <= 8 per launch."""
+    import ctypes as C
+    for k in range(0, len(items), 8):
+        grp = items[k:k + 8]
+        m = len(grp)
+        xs = (C.c_void_p * m)(*[_p(g[0]) for g in grp])
+        ns = (C.c_int64 * m)(*[int(g[0].numel() if g[3] is None else g[3]) for g in grp])
+        ds = (C.c_int * m)(*[int(g[1]) for g in grp])
+        rs = (C.c_void_p * m)(*[(_p(g[2]) or None) for g in grp])
+        call("arx_sq_norm_accum_multi", m, xs, ns, ds, rs, _p(out_accum), _stream())
+
+
 def merged_sq_norm(keys, src, coef, table_rows, out_accum, ws, X=None, d=0, L=1, step_stride=0,
                    Xb=None, Lb=1, stepb_stride=0, n=None):
     """out += sum_t sum_rows ||sum_{c -> row} coef_c X_t[src_c]||^2 (+ the d = 1 analogue on Xb):

@@ -779,6 +779,83 @@ __global__ __launch_bounds__(1024) void k_sq_norm(const float* __restrict__ x, i
   }
 }
 
+// The same reduction over up to 8 tensors in one launch (the clip norm of an LSTM step sums 7
+// gradient tensors: one launch instead of seven).  Blocks [blk_end[t-1], blk_end[t]) own tensor t.
+struct NormSet {
+  const float* x[8];
+  const float* rs[8];
+  int64_t n[8];
+  int d[8];
+  int vec[8];
+  int blk_end[8];
+  int count;
+};
+
+__global__ __launch_bounds__(1024) void k_sq_norm_multi(NormSet ns, float* __restrict__ part,
+                                                        unsigned int* ticket, float* __restrict__ out) {
+  __shared__ float sh[16];
+  __shared__ bool s_last;
+  int t = 0;
+  while ((int)blockIdx.x >= ns.blk_end[t]) ++t;
+  const int b0 = t ? ns.blk_end[t - 1] : 0;
+  const int64_t lb = (int)blockIdx.x - b0, nb = ns.blk_end[t] - b0;
+  const float* __restrict__ x = ns.x[t];
+  const float* __restrict__ row_scale = ns.rs[t];
+  const int64_t n = ns.n[t];
+  const int d = ns.d[t];
+  float s = 0.f;
+  const int64_t tid = lb * blockDim.x + threadIdx.x, stride = nb * blockDim.x;
+  if (ns.vec[t]) {
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const uint32_t n4 = (uint32_t)(n >> 2), d4 = (uint32_t)(d >> 2), st = (uint32_t)stride;
+    float a0 = 0.f, a1 = 0.f;
+    uint32_t i = (uint32_t)tid;
+    for (; i + st < n4; i += 2 * st) {
+      const float4 v0 = x4[i], v1 = x4[i + st];
+      const float w0 = row_scale ? row_scale[i / d4] : 1.f, w1 = row_scale ? row_scale[(i + st) / d4] : 1.f;
+      a0 += w0 * (v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w);
+      a1 += w1 * (v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w);
+    }
+    for (; i < n4; i += st) {
+      const float4 v = x4[i];
+      a0 += (row_scale ? row_scale[i / d4] : 1.f) * (v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+    }
+    s = a0 + a1;
+  } else {
+    for (int64_t i = tid; i < n; i += stride) {
+      const float v = x[i];
+      s += (row_scale ? row_scale[i / d] : 1.f) * v * v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float bs = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) bs += sh[k];
+    __hip_atomic_store(&part[blockIdx.x], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+              gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x < 64) {
+    float tt = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 64)
+      tt += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tt += __shfl_xor(tt, o, 64);
+    if (threadIdx.x == 0) {
+      *out += tt;
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 __global__ void k_clip_coef(const float* __restrict__ sq, float max_norm, float* __restrict__ coef,
                             float* __restrict__ gnorm) {
   const float nrm = sqrtf(*sq);
@@ -1191,6 +1268,38 @@ int arx_sq_norm_accum(const float* x, int64_t n, int d, const float* row_scale, 
     k_sq_norm<true><<<nb, threads, 0, as_stream(stream)>>>(x, n, d, row_scale, part, ticket, out_accum);
   else
     k_sq_norm<false><<<nb, threads, 0, as_stream(stream)>>>(x, n, d, row_scale, part, ticket, out_accum);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_sq_norm_accum_multi(int count, const float* const* x, const int64_t* n, const int* d,
+                            const float* const* row_scale, float* out_accum, void* stream) {
+  ARX_CHECK_ARG(count >= 1 && count <= 8, "arx_sq_norm_accum_multi: 1..8 tensors");
+  ARX_CHECK_ARG(x && n && d && out_accum, "arx_sq_norm_accum_multi: null pointer");
+  float* part = nullptr;
+  unsigned int* ticket = nullptr;
+  ARX_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&part), HIP_SYMBOL(g_norm_part)));
+  ARX_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ticket), HIP_SYMBOL(g_norm_ticket)));
+  NormSet ns = {};
+  int blocks = 0;
+  const int per = kNormBlocks / 8;                  // <= 16 fat blocks per tensor
+  for (int t = 0; t < count; ++t) {
+    ARX_CHECK_ARG(x[t] && n[t] >= 0 && d[t] > 0, "arx_sq_norm_accum_multi: bad tensor");
+    ns.x[t] = x[t];
+    ns.rs[t] = row_scale ? row_scale[t] : nullptr;
+    ns.n[t] = n[t];
+    ns.d[t] = d[t];
+    ns.vec[t] = (n[t] % 4 == 0) && (d[t] % 4 == 0) && n[t] < ((int64_t)1 << 31) &&
+                (reinterpret_cast<uintptr_t>(x[t]) & 15) == 0;
+    int nb = (int)ceil_div(ns.vec[t] ? n[t] / 4 : n[t], (int64_t)1024 * 8);
+    if (nb < 1) nb = 1;
+    if (nb > per) nb = per;
+    blocks += nb;
+    ns.blk_end[t] = blocks;
+  }
+  for (int t = count; t < 8; ++t) ns.blk_end[t] = blocks;
+  ns.count = count;
+  k_sq_norm_multi<<<blocks, 1024, 0, as_stream(stream)>>>(ns, part, ticket, out_accum);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

@@ -364,6 +364,9 @@ int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const flo
 /* *out_accum += sum_i w_i * x_i^2 with w_i = row_scale ? row_scale[i / d] : 1 */
 int arx_sq_norm_accum(const float* x, int64_t n, int d, const float* row_scale,
                       float* out_accum, void* stream);
+/* the same accumulation over up to 8 tensors in one launch (the global norm of an LSTM step) */
+int arx_sq_norm_accum_multi(int count, const float* const* x, const int64_t* n, const int* d,
+                            const float* const* row_scale, float* out_accum, void* stream);
 int arx_clip_coef(const float* sqnorm_dev, float max_norm, float* coef_out, float* gnorm_out,
                   void* stream);
 /* Norm of a table gradient AFTER summing the contributions that land on the same table row
