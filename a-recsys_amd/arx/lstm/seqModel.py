@@ -166,17 +166,16 @@ class LSTM(G.Node):
         if self._wt is None:
             dev = rt.device
             self._wt = torch.empty((4 * h, din), dtype=torch.float32, device=dev)
-            self._dwt = torch.empty((4 * h, max(din, h)), dtype=torch.float32, device=dev)
+            self._dwt = torch.empty((4 * h, din + h), dtype=torch.float32, device=dev)     # [dW_x^T | dW_h^T]
         if x.requires_grad:
             ops.transpose(self.W.w[:din], self._wt)
             ops.gemm(dz, self._wt, x.alloc_grad(), rt.ws, beta=x.grad_beta())
         ops.gemm(dz, x.value, self._dwt[:, :din], rt.ws, transA=True, a_rowsum=self.b.grad)
-        ops.transpose(self._dwt[:, :din], self.W.grad[:din])
         if L > 1:
-            ops.gemm(dz[B:], self.value[:(L - 1) * B], self._dwt[:, :h], rt.ws, transA=True)
-            ops.transpose(self._dwt[:, :h], self.W.grad[din:])
+            ops.gemm(dz[B:], self.value[:(L - 1) * B], self._dwt[:, din:], rt.ws, transA=True)
         else:
-            ops.fill_f32(self.W.grad[din:], 0.0)
+            self._dwt[:, din:].zero_()                        # (strided view: torch fill)
+        ops.transpose(self._dwt, self.W.grad)                 # both halves flipped by one launch
         self.W.touched = self.b.touched = True
 
 
@@ -599,18 +598,29 @@ class SeqModel(object):
             return np.asarray(x, dtype=np.int32)[:L].reshape(-1)
 
         n = L * B
-        t = flat_i(targets)
-        self.target_ids_all.value[:n].copy_(t if isinstance(t, torch.Tensor) else
-                                            torch.from_numpy(np.ascontiguousarray(t)), non_blocking=True)
-        if self.loss != 'mw' or forward_only:
-            m.target_mapping_device(self.target_ids_all.value[:n], self.targets_all.value[:n])
+        rt = self.rt
+
+        def put(dst, src, dtype):
+            """device tensors are queued (all feeds of the step leave as one copy launch when the
+            plan runs); host data goes up with one H2D copy"""
+            if isinstance(src, torch.Tensor) and src.is_cuda and src.dtype == dtype and src.is_contiguous():
+                rt.pending_feeds = [(s_, d_) for s_, d_ in rt.pending_feeds if d_.data_ptr() != dst.data_ptr()]
+                rt.pending_feeds.append((src, dst))
+            else:
+                if not isinstance(src, torch.Tensor):
+                    src = torch.from_numpy(np.ascontiguousarray(src))
+                dst.copy_(src.reshape(-1), non_blocking=True)
+
+        put(self.target_ids_all.value[:n], flat_i(targets), torch.int32)
         w = target_weights
         if not isinstance(w, torch.Tensor):
-            w = torch.from_numpy(np.ascontiguousarray(np.asarray(w, dtype=np.float32)[:L].reshape(-1)))
-        self.weights_all.value[:n].copy_(w.reshape(-1), non_blocking=True)
-        it = flat_i(item_inputs)
-        m.input_all.value[:n].copy_(it if isinstance(it, torch.Tensor) else
-                                    torch.from_numpy(np.ascontiguousarray(it)), non_blocking=True)
+            w = np.asarray(w, dtype=np.float32)[:L].reshape(-1)
+        else:
+            w = w.reshape(-1)
+        put(self.weights_all.value[:n], w, torch.float32)
+        put(m.input_all.value[:n], flat_i(item_inputs), torch.int32)
+        if self.loss != 'mw' or forward_only:
+            m.target_mapping_device(self.target_ids_all.value[:n], self.targets_all.value[:n])
         update_sampled, _, _ = m.add_input({}, user_input, None, item_sampled=item_sampled,
                                            item_sampled_id2idx=item_sampled_id2idx,
                                            forward_only=forward_only, recommend=False, loss=self.loss)
