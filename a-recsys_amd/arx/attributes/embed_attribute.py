@@ -50,6 +50,28 @@ class ZeroEmbed(G.Node):
         pass
 
 
+class TargetMapping(G.Node):
+    """item_target = item_ind2logit_ind[item_id_target] (embed_attribute.py:676-695 target_mapping)
+    as a node of the step: the mapping runs inside the captured plan instead of as an eager launch
+    in front of it (a B=64 step is bound by exactly those).  `feed` keeps the placeholder
+    interface for host-mapped targets (the in-plan mapping rewrites the same values)."""
+
+    def __init__(self, rt, ids_node, emb, name):
+        super().__init__(rt, ids_node.shape, (ids_node,))
+        self.emb, self.name = emb, name
+        self.value = torch.zeros(ids_node.shape[0], dtype=torch.int32, device=rt.device)
+
+    def feed(self, arr):
+        src = arr if isinstance(arr, torch.Tensor) else torch.from_numpy(
+            np.ascontiguousarray(np.asarray(arr, dtype=np.int32)))
+        self.value.copy_(src.reshape(self.value.shape), non_blocking=True)
+
+    def forward(self, train):
+        if self.emb._item2logit_dev is None:
+            raise ValueError("target mapping needs item_ind2logit_ind")
+        ops.sparse_site_onehot(self.emb._item2logit_dev, self.inputs[0].value, 0, 0.0, self.value, None, None)
+
+
 class Dropout(G.Node):
     """tf.nn.dropout (embed_attribute.py:236; DropoutWrapper seqModel.py:100,103).  keep_prob is
     read from rt.keep_prob when the plan is built / captured (1.0 => identity; changing it makes

@@ -224,13 +224,14 @@ class LatentProductModel(object):
 
         mb = batch_size
         # mapped item target (logit index) and raw item id target (hmf_model.py:69-70)
-        self.item_target = G.IdsInput(rt, mb, 'item')
         self.item_id_target = G.IdsInput(rt, mb, 'item_id')
+        self.item_target = None      # built below: the in-plan mapping of item_id_target (needs att_emb)
 
         m = embed_attribute.EmbeddingAttribute(user_attributes, item_attributes, mb, self.n_sampled,
                                                0, False, item_ind2logit_ind, logit_ind2item_ind,
                                                params=params, runtime=rt, seed=seed)
         self.att_emb = m
+        self.item_target = embed_attribute.TargetMapping(rt, self.item_id_target, m, 'item')    # :69,173
         embedded_user, _ = m.get_batch_user(float(dropout), False)          # :78
         if self.nonlinear in ('relu', 'tanh'):
             ps = []
@@ -309,21 +310,15 @@ class LatentProductModel(object):
     def _feed(self, user_input, item_input, recommend, loss, item_sampled, item_sampled_id2idx,
               forward_only):
         m = self.att_emb
-        map_on_device = False
         if not recommend:
-            if isinstance(item_input, torch.Tensor):
-                self.item_id_target.feed(item_input)
-                map_on_device = self.loss_function != 'mw' or forward_only
-            else:
-                if self.loss_function != 'mw' or forward_only:
-                    targets = m.target_mapping([item_input])                  # :173
-                    self.item_target.feed(targets[0])
-                self.item_id_target.feed(item_input)                          # :176
+            if not isinstance(item_input, torch.Tensor) and (self.loss_function != 'mw' or forward_only):
+                # host ids: mapped here so that an item without a logit fails like the reference's
+                # dict lookup (:173); the plan maps item_id_target again on device (same values)
+                self.item_target.feed(m.target_mapping([item_input])[0])
+            self.item_id_target.feed(item_input)                              # :176
         update_sampled, _, _ = m.add_input({}, user_input, item_input, item_sampled=item_sampled,
                                            item_sampled_id2idx=item_sampled_id2idx,
                                            forward_only=forward_only, recommend=recommend, loss=loss)
-        if map_on_device:     # after add_input: the user and item feeds leave in one copy launch
-            m.target_mapping_device(self.item_id_target.value, self.item_target.value)
         for op in update_sampled:                                             # :206-207
             op()
 
