@@ -639,7 +639,9 @@ class Plan(object):
                 # below the LDS rank-sort limit a table's own chain is already 3 launches; fusing
                 # would push the union into the 8-launch radix path (measured slower at B=4096)
                 big = any(sum(x.cap for x in c + m) > 8192 for _, c, m in group)
-                if (big and 2 <= len(group) <= 4 and sum(len(c) for _, c, _ in group) <= 8
+                # ... unless the UNION still fits the rank sort: then one 3-launch chain serves all
+                # tables (C1, B=64: two chains of 3 launches -> one)
+                if ((big or (n_tot <= 8192 and not any(m for _, _, m in group))) and 2 <= len(group) <= 4 and sum(len(c) for _, c, _ in group) <= 8
                         and sum(len(m) for _, _, m in group) <= 8 and rows_bits + 2 <= 30
                         and n_tot <= (1 << 22)):
                     fused = group

@@ -968,7 +968,7 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
                         const int32_t* n_dev, hipStream_t s) {
   const int32_t* cnt = ts.cnt[0];
   const int lpr = lanes_per_row(d);
-  if (cnt != nullptr && n <= kRankSortMax) {
+  if (cnt != nullptr && n <= kRankSortMax && n_dev == nullptr) {   // (radix-sorted input has a live count: window path)
     // small batches (single-launch LDS rank sort regime): one sub-group per sorted position --
     // mostly-unique one-hot ids need the parallelism (80 windows would leave the chip idle);
     // every multi-piece run is finished by its last arriver, no second launch.
@@ -1072,7 +1072,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   const int32_t* src_arg = ssrc;
   const float* coef_arg = scoef;
   const int32_t* n_dev = nullptr;      // live-entry count of the radix sort (pads dropped)
-  if (n <= kRankSortMax) {
+  if (n <= kRankSortMax && st.nextra == 0) {     // (pre-expanded multi-hot segments: radix path only)
     if (phase & 1) {
       rc = launch_rank_sort(keys_buf, n, sentinel, keys_out, pos_out, count, s, src_buf, coef_buf,
                             ssrc, scoef);
