@@ -687,8 +687,9 @@ class Plan(object):
             for ti, (e, c, m) in enumerate(group):
                 table = e[0]
                 use_bias = table.bias is not None and any(x.node.bias_grad_used for x in c + m)
-                tables.append((table.E, table.acc, table.bias if use_bias else None,
-                               table.bias_acc if use_bias else None, self._aux_cnt(table)))
+                sgd = rt.optimizer == 'sgd'          # no slots: the kernels do plain gradient descent
+                tables.append((table.E, None if sgd else table.acc, table.bias if use_bias else None,
+                               table.bias_acc if (use_bias and not sgd) else None, self._aux_cnt(table)))
                 for x in c:
                     sites.append((ti, x.maps[0], x.ids_node.value, x.node.row0, x.coef))
                 for x in m:
@@ -772,8 +773,9 @@ class Plan(object):
             table.aux_cnt = torch.zeros((table.E.shape[0],), dtype=torch.int32, device=rt.device)
         node0 = bufs['cat_node0']
         mode = rt.cat_mode if rt.cat_mode else {3: 0, 1: 0x10, 2: 0x20}[phase]
-        ops.sparse_adagrad_cat(table.E, table.acc, table.bias if use_bias else None,
-                               table.bias_acc if use_bias else None, bufs['cat_args'],
+        sgd = rt.optimizer == 'sgd'
+        ops.sparse_adagrad_cat(table.E, None if sgd else table.acc, table.bias if use_bias else None,
+                               table.bias_acc if (use_bias and not sgd) else None, bufs['cat_args'],
                                node0.arena, node0.arena_b if use_bias else None, rt.lr,
                                table.aux_first, table.aux_cnt, bufs['hot'], bufs['keys'],
                                bufs['src'], bufs['coef'], bufs['cat_ws'], gscale_dev=rt.clip_coef_dev,
@@ -818,8 +820,9 @@ class Plan(object):
             node0 = sites[0].node
             G = node0.arena[:, sites[0].col_off:] if sites[0].col_off else node0.arena
             use_bias = table.bias is not None and any(s.node.bias_grad_used for s in sites)
-            ops.sparse_adagrad(table.E, table.acc, table.bias if use_bias else None,
-                               table.bias_acc if use_bias else None, bufs['keys'], bufs['src'],
+            sgd = rt.optimizer == 'sgd'
+            ops.sparse_adagrad(table.E, None if sgd else table.acc, table.bias if use_bias else None,
+                               table.bias_acc if (use_bias and not sgd) else None, bufs['keys'], bufs['src'],
                                bufs['coef'], G, node0.arena_b if use_bias else None, rt.lr, rt.ws,
                                gscale_dev=rt.clip_coef_dev, n=total, aux_cnt=self._aux_cnt(table))
             self._n_passes += 1           # a pass that is not sorted ahead: no side branch next time
@@ -881,6 +884,7 @@ class Runtime(object):
         self.use_graph = use_graph
         self.global_step = 0
         self.pre_apply_hooks = []
+        self.optimizer = 'adagrad'      # or 'sgd' (tf.train.GradientDescentOptimizer, seqModel.py:176)
         self.seed = 0
         self.keep_prob = 1.0            # dropout keep probability of train plans (Dropout nodes)
         self.dropout_calls = 0
@@ -967,7 +971,8 @@ class Runtime(object):
     def apply_dense(self, plan):
         for p in self.dense.values():
             if getattr(p, 'touched', False):
-                ops.adagrad_dense(p.w, p.acc, p.grad, self.lr, gscale_dev=self.clip_coef_dev)
+                ops.adagrad_dense(p.w, None if self.optimizer == 'sgd' else p.acc, p.grad, self.lr,
+                                  gscale_dev=self.clip_coef_dev)
                 p.touched = False
 
     def upload(self, arr, dtype):

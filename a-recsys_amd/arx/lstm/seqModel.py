@@ -12,7 +12,7 @@ Same constructor / step / get_batch signatures.  What differs from the TF graph:
     vocabulary, as hmf_model.py:130 does: the reference's own losses_full graph
     for 'mw' (seqModel.py:510) mixes a [mb, n_sampled] mask with [mb, V] logits
     and cannot be built unless n_sampled == V.
-Not implemented (raise): withAdagrad=False, beam search (dead code in the reference).
+Not implemented (raise): beam search (dead code in the reference).
 """
 from __future__ import annotations
 
@@ -280,11 +280,10 @@ class SeqModel(object):
             raise ValueError("num_layers must be >= 1")
         if not (0.0 < float(dropoutRate) <= 1.0):
             raise ValueError("dropoutRate (keep probability) must be in (0, 1]")
-        if not withAdagrad:
-            raise NotImplementedError("GradientDescentOptimizer")
         if loss not in ('ce', 'warp', 'mw'):
             raise NotImplementedError("loss %r" % loss)
         self.embeddingAttribute = m = embeddingAttribute
+        m.rt.optimizer = 'adagrad' if withAdagrad else 'sgd'          # seqModel.py:173-176
         self.att_emb = m
         self.rt = rt = m.rt
         self.buckets = list(buckets)

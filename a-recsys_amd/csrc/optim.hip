@@ -257,24 +257,34 @@ __device__ __forceinline__ void adagrad_row(float* __restrict__ E, float* __rest
                                             float* __restrict__ bias, float* __restrict__ bias_acc,
                                             int d, uint32_t row, int col, bool colok, int lig,
                                             float4 g, float gb, float lr, float gs) {
+  // acc == nullptr: plain gradient descent (tf.train.GradientDescentOptimizer, seqModel.py:176)
   if (colok) {
     float4* wp = reinterpret_cast<float4*>(E + (int64_t)row * d + col);
-    float4* ap = reinterpret_cast<float4*>(acc + (int64_t)row * d + col);
-    float4 w = *wp, a = *ap;
+    float4 w = *wp;
     g.x *= gs; g.y *= gs; g.z *= gs; g.w *= gs;
-    a.x += g.x * g.x; a.y += g.y * g.y; a.z += g.z * g.z; a.w += g.w * g.w;
-    w.x -= lr * g.x / sqrtf(a.x);
-    w.y -= lr * g.y / sqrtf(a.y);
-    w.z -= lr * g.z / sqrtf(a.z);
-    w.w -= lr * g.w / sqrtf(a.w);
-    *ap = a;
+    if (acc) {
+      float4* ap = reinterpret_cast<float4*>(acc + (int64_t)row * d + col);
+      float4 a = *ap;
+      a.x += g.x * g.x; a.y += g.y * g.y; a.z += g.z * g.z; a.w += g.w * g.w;
+      w.x -= lr * g.x / sqrtf(a.x);
+      w.y -= lr * g.y / sqrtf(a.y);
+      w.z -= lr * g.z / sqrtf(a.z);
+      w.w -= lr * g.w / sqrtf(a.w);
+      *ap = a;
+    } else {
+      w.x -= lr * g.x; w.y -= lr * g.y; w.z -= lr * g.z; w.w -= lr * g.w;
+    }
     *wp = w;
   }
   if (bias && lig == 0) {
     const float gg = gb * gs;
-    const float a = bias_acc[row] + gg * gg;
-    bias_acc[row] = a;
-    bias[row] -= lr * gg / sqrtf(a);
+    if (bias_acc) {
+      const float a = bias_acc[row] + gg * gg;
+      bias_acc[row] = a;
+      bias[row] -= lr * gg / sqrtf(a);
+    } else {
+      bias[row] -= lr * gg;
+    }
   }
 }
 
@@ -296,7 +306,7 @@ __device__ __forceinline__ void adagrad_row(float* __restrict__ E, float* __rest
 constexpr int kBig = 1 << 30;
 constexpr int kShortMaxAligned = 16;    // runs with more aligned pieces get a whole workgroup
 
-template <int LPR, int WPW, bool MT>
+template <int LPR, int WPW, bool MT, bool SGD>
 __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
     TableSet ts, int d, const uint32_t* __restrict__ sk,
     const uint32_t* __restrict__ spos, const int32_t* __restrict__ ssrc,
@@ -377,7 +387,7 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
     float4 wrow = make_float4(0.f, 0.f, 0.f, 0.f), arow = wrow;
     if (complete && colok) {
       wrow = *reinterpret_cast<const float4*>(E + (int64_t)rrow * d + col);
-      arow = *reinterpret_cast<const float4*>(acc + (int64_t)rrow * d + col);
+      if (!SGD) arow = *reinterpret_cast<const float4*>(acc + (int64_t)rrow * d + col);
     }
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int t = 0; t < rows; t += 8) {
@@ -404,19 +414,27 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
     if (complete) {
       if (colok) {
         float4 gg = make_float4(a.x * gs, a.y * gs, a.z * gs, a.w * gs);
-        arow.x += gg.x * gg.x; arow.y += gg.y * gg.y; arow.z += gg.z * gg.z; arow.w += gg.w * gg.w;
-        wrow.x -= lr * gg.x / sqrtf(arow.x);
-        wrow.y -= lr * gg.y / sqrtf(arow.y);
-        wrow.z -= lr * gg.z / sqrtf(arow.z);
-        wrow.w -= lr * gg.w / sqrtf(arow.w);
-        *reinterpret_cast<float4*>(acc + (int64_t)rrow * d + col) = arow;
+        if (!SGD) {
+          arow.x += gg.x * gg.x; arow.y += gg.y * gg.y; arow.z += gg.z * gg.z; arow.w += gg.w * gg.w;
+          wrow.x -= lr * gg.x / sqrtf(arow.x);
+          wrow.y -= lr * gg.y / sqrtf(arow.y);
+          wrow.z -= lr * gg.z / sqrtf(arow.z);
+          wrow.w -= lr * gg.w / sqrtf(arow.w);
+          *reinterpret_cast<float4*>(acc + (int64_t)rrow * d + col) = arow;
+        } else {                                   // gradient descent
+          wrow.x -= lr * gg.x; wrow.y -= lr * gg.y; wrow.z -= lr * gg.z; wrow.w -= lr * gg.w;
+        }
         *reinterpret_cast<float4*>(E + (int64_t)rrow * d + col) = wrow;
       }
       if (bias && lig == 0) {
         const float gg = gb * gs;
-        const float ba = bias_acc[rrow] + gg * gg;
-        bias_acc[rrow] = ba;
-        bias[rrow] -= lr * gg / sqrtf(ba);
+        if (!SGD) {
+          const float ba = bias_acc[rrow] + gg * gg;
+          bias_acc[rrow] = ba;
+          bias[rrow] -= lr * gg / sqrtf(ba);
+        } else {
+          bias[rrow] -= lr * gg;
+        }
       }
     } else {
       // ---- piece of a multi-piece run ----
@@ -696,9 +714,13 @@ __global__ void k_adagrad_dense(float* __restrict__ w, float* __restrict__ acc,
   const float gs = gscale_dev ? *gscale_dev : 1.f;
   for (; i < n; i += stride) {
     const float gg = g[i] * gs;
-    const float a = acc[i] + gg * gg;
-    acc[i] = a;
-    w[i] -= lr * gg / sqrtf(a);
+    if (acc) {
+      const float a = acc[i] + gg * gg;
+      acc[i] = a;
+      w[i] -= lr * gg / sqrtf(a);
+    } else {
+      w[i] -= lr * gg;                             // gradient descent
+    }
   }
 }
 
@@ -990,16 +1012,23 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
   int32_t* list_long = list;                       // <= n/64/17 entries
   int32_t* list_short = list + (n / 64 / (kShortMaxAligned + 1) + 2);   // pairs, <= n/64 entries
   const int grid8 = (int)ceil_div(n, 64);
-#define ARX_WIN_GO(WPW_, MT_, GRID_, THREADS_)                                                      \
-  ARX_DISPATCH_LPR(lpr, (k_sparse_win<LPR, WPW_, MT_><<<GRID_, THREADS_, 0, s>>>(                   \
+  const bool sgd = ts.acc[0] == nullptr;           // gradient descent: no slots (all tables alike)
+#define ARX_WIN_GO2(WPW_, MT_, SGD_, GRID_, THREADS_)                                                \
+  ARX_DISPATCH_LPR(lpr, (k_sparse_win<LPR, WPW_, MT_, SGD_><<<GRID_, THREADS_, 0, s>>>(             \
                             ts, d, sk, spos, ssrc, scoef, n, n_dev, sentinel, G, ldg, gb_in, lr_dev, \
                             gscale_dev, scratch, scratch_b, scratch_h, scratch_hb, list_long,       \
                             list_short, count)))
+#define ARX_WIN_GO(WPW_, MT_, GRID_, THREADS_)                                              \
+  do {                                                                                      \
+    if (sgd) { ARX_WIN_GO2(WPW_, MT_, true, GRID_, THREADS_); }                             \
+    else { ARX_WIN_GO2(WPW_, MT_, false, GRID_, THREADS_); }                                \
+  } while (0)
   if (short_runs) {   // one-hot ids: 8 waves share each window
     if (multi) { ARX_WIN_GO(8, true, grid8, 512); } else { ARX_WIN_GO(8, false, grid8, 512); }
   } else {
     if (multi) { ARX_WIN_GO(1, true, grid, 256); } else { ARX_WIN_GO(1, false, grid, 256); }
   }
+#undef ARX_WIN_GO2
 #undef ARX_WIN_GO
   ARX_CHECK_LAUNCH();
   {
@@ -1122,8 +1151,9 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
                               const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
                               const float* gscale_dev, int key_bits, int32_t* aux_cnt,
                               void* workspace, size_t workspace_bytes, void* stream) {
-  ARX_CHECK_ARG(E && acc && keys && G && lr_dev, "arx_sparse_adagrad: null pointer");
-  ARX_CHECK_ARG((bias == nullptr) == (bias_acc == nullptr), "arx_sparse_adagrad: bias and bias_acc go together");
+  ARX_CHECK_ARG(E && keys && G && lr_dev, "arx_sparse_adagrad: null pointer");
+  ARX_CHECK_ARG(acc ? (bias == nullptr) == (bias_acc == nullptr) : bias_acc == nullptr,
+                "arx_sparse_adagrad: bias and bias_acc go together (acc == NULL: gradient descent, no slots)");
   ARX_CHECK_ARG(!(bias && !Gb), "arx_sparse_adagrad: bias table given without Gb");
   if (d <= 0 || d % 4 != 0 || d > 256) {
     set_error("arx_sparse_adagrad: d=%d unsupported (d %% 4 == 0, d <= 256)", d);
@@ -1237,7 +1267,7 @@ int arx_merged_sq_norm(const int32_t* keys, const int32_t* src, const float* coe
 
 int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const float* lr_dev,
                       const float* gscale_dev, void* stream) {
-  ARX_CHECK_ARG(w && acc && g && lr_dev, "arx_adagrad_dense: null pointer");
+  ARX_CHECK_ARG(w && g && lr_dev, "arx_adagrad_dense: null pointer");
   if (n <= 0) return ARX_OK;
   int64_t gr = ceil_div(n, 256);
   int64_t cap = (int64_t)cu_count() * 8;

@@ -280,12 +280,14 @@ int arx_sparse_adagrad_cat(float* E, float* acc, float* bias, float* bias_acc, i
                            int32_t* aux_hot, int64_t aux_hot_len, int32_t* keys_buf,
                            int32_t* src_buf, float* coef_buf, int mode, void* workspace,
                            size_t workspace_bytes, void* stream) {
-  ARX_CHECK_ARG(E && acc && G && lr_dev && aux_first && aux_cnt && aux_hot && keys_buf && src_buf &&
-                    coef_buf,
+  ARX_CHECK_ARG(E && G && lr_dev && aux_first && aux_cnt && aux_hot && keys_buf && src_buf && coef_buf,
                 "arx_sparse_adagrad_cat: null pointer");
+  ARX_CHECK_ARG(acc || (mode == 0 || mode == 0x10 || mode == 0x20),
+                "arx_sparse_adagrad_cat: acc == NULL (gradient descent) needs the sorted pass (mode 0)");
   ARX_CHECK_ARG(aux_hot_len >= 3, "arx_sparse_adagrad_cat: aux_hot too short");
   ARX_CHECK_ARG(nsites > 0 && nsites <= kMaxSites, "arx_sparse_adagrad_cat: 1..8 lookup sites");
-  ARX_CHECK_ARG((bias == nullptr) == (bias_acc == nullptr), "arx_sparse_adagrad_cat: bias/bias_acc");
+  ARX_CHECK_ARG(acc ? (bias == nullptr) == (bias_acc == nullptr) : bias_acc == nullptr,
+                "arx_sparse_adagrad_cat: bias/bias_acc");
   ARX_CHECK_ARG(!(bias && !Gb), "arx_sparse_adagrad_cat: bias table given without Gb");
   if (d <= 0 || d % 4 != 0 || d > 256) {
     set_error("arx_sparse_adagrad_cat: d=%d unsupported (d %% 4 == 0, d <= 256)", d);
@@ -385,8 +387,8 @@ static int cat_multi_impl(int phase, int ntables, float* const* E, float* const*
   for (int t = 0; t < kMaxTables; ++t) {
     const bool live = t < ntables;
     if (live) {
-      ARX_CHECK_ARG(E[t] && acc[t] && table_rows[t] > 0, "arx_sparse_adagrad_cat_multi: bad table");
-      ARX_CHECK_ARG((bias[t] == nullptr) == (bias_acc[t] == nullptr),
+      ARX_CHECK_ARG(E[t] && table_rows[t] > 0, "arx_sparse_adagrad_cat_multi: bad table");
+      ARX_CHECK_ARG(acc[t] ? (bias[t] == nullptr) == (bias_acc[t] == nullptr) : bias_acc[t] == nullptr,
                     "arx_sparse_adagrad_cat_multi: bias/bias_acc");
       ARX_CHECK_ARG(!(bias[t] && !Gb), "arx_sparse_adagrad_cat_multi: bias table given without Gb");
       while ((1ll << kb) < table_rows[t] && kb < 30) ++kb;

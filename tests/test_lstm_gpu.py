@@ -13,7 +13,7 @@ RTOL = 1e-4
 
 
 def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False, use_concat=False, num_layers=1,
-           keep=1.0):
+           keep=1.0, adagrad=True):
     from arx.attributes.embed_attribute import EmbeddingAttribute
     from arx.lstm.seqModel import SeqModel
     from arx.utils.synthetic import SyntheticHMF
@@ -40,12 +40,14 @@ def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False, use_concat=Fa
     n_s = S if loss == 'mw' else None
     emb = EmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i, params=params)
     model = SeqModel([L], size, num_layers, clip, B, 0.5, 0.83, emb, loss=loss, use_concat=use_concat,
-                     no_user_id=no_user_id, START_ID=START, params=params, dropoutRate=keep)
+                     no_user_id=no_user_id, START_ID=START, params=params, dropoutRate=keep,
+                     withAdagrad=adagrad)
     remb = rg.RefEmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i,
                                     params={k: v for k, v in params.items() if not k.startswith('lstm')},
                                     dtype=np.float64)
     ref = ref_lstm.RefSeqModel(L, size, clip, B, 0.5, remb, loss=loss, no_user_id=no_user_id,
-                               params=params, use_concat=use_concat, num_layers=num_layers)
+                               params=params, use_concat=use_concat, num_layers=num_layers,
+                               withAdagrad=adagrad)
     pos = syn.positives_dict()
     emb.prepare_warp(pos, pos)
     remb.prepare_warp(pos, pos)
@@ -257,3 +259,27 @@ def test_seq_layers_and_dropout(dev, loss, S, layers, keep):
     _compare(emb, model, remb, ref)
     model.dropoutAssign_op.run()
     assert model.dropoutRate.eval() == keep
+
+
+@pytest.mark.parametrize("cfg,loss,S", [(CFG_ID, 'mw', 64), (CFG_HET, 'ce', None)])
+def test_seq_gradient_descent_optimizer(dev, cfg, loss, S):
+    """withAdagrad=False: tf.train.GradientDescentOptimizer on the clipped gradients
+    (seqModel.py:175-176) -- the sparse/dense apply kernels run without accumulator slots."""
+    size, B, L = 64, 16, 4
+    syn, emb, model, remb, ref = _build(cfg, loss, size, B, L, S, 5.0, seed=31, adagrad=False)
+    rng = np.random.default_rng(37)
+    pool = id2idx = None
+    if loss == 'mw':
+        pool = syn.sample_pool(S, rng)
+        id2idx = {int(v): i for i, v in enumerate(pool)}
+    slots0 = {k: v.copy() for k, v in emb.get_slots().items()}
+    for step in range(3):
+        users, inp, tg, w = _batch(syn, rng, L, B)
+        ps = pool if step == 0 else None
+        l_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), ps, id2idx)
+        l_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, ps, id2idx)
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='loss step %d' % step)
+        np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL)
+        _compare(emb, model, remb, ref)
+    for k, v in emb.get_slots().items():           # no optimizer slots are touched
+        assert np.array_equal(v, slots0[k]), k
