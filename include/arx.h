@@ -271,6 +271,9 @@ int arx_loss_warp_eval(const float* logits, int64_t ldl, const int32_t* target,
  *   g *= *gscale_dev (nullable; clip_by_global_norm coefficient)
  *   acc[row] += g^2 ; E[row] -= *lr_dev * g / sqrt(acc[row])
  * src NULL => identity; coef NULL => 1.  bias/bias_acc/Gb nullable together.
+ * acc == NULL (then bias_acc == NULL too): plain gradient descent, E[row] -= lr * g -- the
+ * GradientDescentOptimizer branch of seqModel.py:175-176; the same holds for arx_sparse_adagrad_cat
+ * (sorted pass), arx_sparse_adagrad_cat_multi (acc[t] == NULL) and arx_adagrad_dense.
  * key_bits: number of significant key bits (0 => 31) to shorten the sort. */
 size_t arx_sparse_adagrad_workspace_bytes(int64_t n);
 int arx_sparse_adagrad(float* E, float* acc, float* bias, float* bias_acc, int d,
