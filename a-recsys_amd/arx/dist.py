@@ -272,26 +272,30 @@ class ShardedHMF(object):
         send, recv, R = route['send'], route['recv'], route['R']
         users_in, items_in = route['users'], route['items']
         arena, arena_b = self.arena, self.arena_b
+        # The two large exchanges (target rows out, target-row gradients back: B_loc x (d+4) floats
+        # each) are issued asynchronously and waited for only where their result is needed, so that
+        # they travel under the scorer GEMM and under the two backward GEMMs respectively.
         # ---- forward ----
+        recv_ids = self.recv_ids[:R]
+        w_ids = dist.all_to_all_single(recv_ids, items_in, output_split_sizes=recv, input_split_sizes=send,
+                                       group=grp, async_op=True)     # target ids -> their owners
         be.shard_route(users_in, W, r, 0, self.urows, None)            # all owned: local rows
         be.gather_rows(self.E_user, None, self.urows, self.U_loc, None)
         be.gather_rows(self.E_item, self.b_item, self.pool_rows, self.I_pack[:, :d], self.b_g)
         self.I_pack[:, d].copy_(self.b_g)
         dist.all_gather_into_tensor(self.I_all, self.I_pack, group=grp)
         self.b_all.copy_(self.I_all[:, d])
-        be.gemm(self.U_loc, self.I_all[:, :d], self.logits, transB=True, col_bias=self.b_all)
-        # target rows: ids to their owners, packed rows back
-        recv_ids = self.recv_ids[:R]
-        dist.all_to_all_single(recv_ids, items_in, output_split_sizes=recv, input_split_sizes=send,
-                               group=grp)
+        w_ids.wait()
         recv_rows = self.recv_rows[:R]
         T_send = self.T_send[:R]
         if R > 0:
             be.shard_route(recv_ids, W, r, self.zero_row, recv_rows, None)
             be.gather_rows(self.E_item, self.b_item, recv_rows, T_send[:, :d], self.tb_send[:R])
             T_send[:, d].copy_(self.tb_send[:R])
-        dist.all_to_all_single(self.T_pack, T_send, output_split_sizes=send, input_split_sizes=recv,
-                               group=grp)
+        w_rows = dist.all_to_all_single(self.T_pack, T_send, output_split_sizes=send, input_split_sizes=recv,
+                                        group=grp, async_op=True)    # packed target rows back ...
+        be.gemm(self.U_loc, self.I_all[:, :d], self.logits, transB=True, col_bias=self.b_all)   # ... under the scorer
+        w_rows.wait()
         # loss (global mean => gscale = 1/B) with the target score and its rank-one gradients formed
         # by the same kernel, straight from / into the packed rows (bias and dt live in column d)
         dU = arena[:B_loc, :d]
@@ -299,13 +303,15 @@ class ShardedHMF(object):
                              self.pos_ptr, self.pos_items, self.item2slot, self.bl, self.dlogits,
                              self.t_loc, self.dT_pack[:, d], dU, self.dT_pack[:, :d], 1.0 / B)
         # ---- backward ----
-        be.gemm(self.dlogits, self.I_all[:, :d], dU, beta=1.0)                # dU += dL . pool
+        w_dt = dist.all_to_all_single(arena[B_loc + Sg:B_loc + Sg + R], self.dT_pack,
+                                      output_split_sizes=recv, input_split_sizes=send, group=grp,
+                                      async_op=True)                  # target-row gradients -> owners ...
+        be.gemm(self.dlogits, self.I_all[:, :d], dU, beta=1.0)                # ... under dU += dL . pool
         # pool gradient partials (+ bias gradient = row sums) -> owners
         be.gemm(self.dlogits, self.U_loc, self.dI_all[:, :d], transA=True, a_rowsum=self.gb_all)
         self.dI_all[:, d].copy_(self.gb_all)
         dist.reduce_scatter_tensor(arena[B_loc:B_loc + Sg], self.dI_all, op=dist.ReduceOp.SUM, group=grp)
-        dist.all_to_all_single(arena[B_loc + Sg:B_loc + Sg + R], self.dT_pack,
-                               output_split_sizes=recv, input_split_sizes=send, group=grp)
+        w_dt.wait()
         arena_b[B_loc:B_loc + Sg + R].copy_(arena[B_loc:B_loc + Sg + R, d])
         # one fused scatter + Adagrad pass over both shards
         sites = [(0, self.urows, 0), (1, self.pool_rows, B_loc)]
