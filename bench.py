@@ -58,10 +58,12 @@ def parse():
 
 def _evt_time_ms(fn, iters):
     """Average duration of fn() in ms, HIP events on the stream the kernels use."""
-    for _ in range(3):
+    # warm up as long as the timed loop: after the host-side pause before this call the shader
+    # clock needs a few ms of load to be back at its sustained 2.4 GHz (tools/clockwatch.py) --
+    # in the step's graph the kernels always run on a loaded chip
+    for _ in range(max(3, iters)):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
     e0.record()
     for _ in range(iters):
         fn()
