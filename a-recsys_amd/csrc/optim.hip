@@ -231,6 +231,21 @@ struct TabRow {
 };
 // key = (table << kb) | row  ->  that table's pointers (selects, not a runtime-indexed
 // kernel-argument array: that would go through scratch)
+// a[t] for t < 4 without indexing the kernel-argument struct.  The plain select chain
+// (t == 0 ? a[0] : t == 1 ? ...) is folded back into an indexed load by the optimiser, which
+// copies the whole TableSet to scratch and pays a scratch round trip per looked-up pointer;
+// the empty asm between the selects keeps them selects (v_cndmask on kernel-argument SGPRs).
+template <class P>
+__device__ __forceinline__ P* pick4(P* const (&a)[4], uint32_t t) {
+  uint64_t r = reinterpret_cast<uint64_t>(a[0]);
+  r = (t == 1u) ? reinterpret_cast<uint64_t>(a[1]) : r;
+  asm volatile("" : "+v"(r));
+  r = (t == 2u) ? reinterpret_cast<uint64_t>(a[2]) : r;
+  asm volatile("" : "+v"(r));
+  r = (t == 3u) ? reinterpret_cast<uint64_t>(a[3]) : r;
+  return reinterpret_cast<P*>(r);
+}
+
 template <bool MT>
 __device__ __forceinline__ TabRow tab_of(const TableSet& ts, uint32_t key) {
   TabRow r;
@@ -245,12 +260,19 @@ __device__ __forceinline__ TabRow tab_of(const TableSet& ts, uint32_t key) {
   }
   const uint32_t t = key >> ts.kb;
   r.row = key & ((1u << ts.kb) - 1u);
-  r.E = t == 0 ? ts.E[0] : t == 1 ? ts.E[1] : t == 2 ? ts.E[2] : ts.E[3];
-  r.acc = t == 0 ? ts.acc[0] : t == 1 ? ts.acc[1] : t == 2 ? ts.acc[2] : ts.acc[3];
-  r.bias = t == 0 ? ts.bias[0] : t == 1 ? ts.bias[1] : t == 2 ? ts.bias[2] : ts.bias[3];
-  r.bias_acc = t == 0 ? ts.bias_acc[0] : t == 1 ? ts.bias_acc[1] : t == 2 ? ts.bias_acc[2] : ts.bias_acc[3];
-  r.cnt = t == 0 ? ts.cnt[0] : t == 1 ? ts.cnt[1] : t == 2 ? ts.cnt[2] : ts.cnt[3];
+  r.E = pick4(ts.E, t);
+  r.acc = pick4(ts.acc, t);
+  r.bias = pick4(ts.bias, t);
+  r.bias_acc = pick4(ts.bias_acc, t);
+  r.cnt = pick4(ts.cnt, t);
   return r;
+}
+
+// lr * g / sqrt(a) as lr * g * rsq(a): v_rsq_f32 is good to 1 ulp, the IEEE sqrt + divide
+// sequences cost ~25 VALU instructions per component and the apply kernels are VALU-issue bound
+// (a wave64 instruction holds its SIMD for 4 cycles) -- profiles/README.md, K7.
+__device__ __forceinline__ float adagrad_delta(float lr, float g, float a) {
+  return lr * g * __frsqrt_rn(a);
 }
 
 __device__ __forceinline__ void adagrad_row(float* __restrict__ E, float* __restrict__ acc,
@@ -266,10 +288,10 @@ __device__ __forceinline__ void adagrad_row(float* __restrict__ E, float* __rest
       float4* ap = reinterpret_cast<float4*>(acc + (int64_t)row * d + col);
       float4 a = *ap;
       a.x += g.x * g.x; a.y += g.y * g.y; a.z += g.z * g.z; a.w += g.w * g.w;
-      w.x -= lr * g.x / sqrtf(a.x);
-      w.y -= lr * g.y / sqrtf(a.y);
-      w.z -= lr * g.z / sqrtf(a.z);
-      w.w -= lr * g.w / sqrtf(a.w);
+      w.x -= adagrad_delta(lr, g.x, a.x);
+      w.y -= adagrad_delta(lr, g.y, a.y);
+      w.z -= adagrad_delta(lr, g.z, a.z);
+      w.w -= adagrad_delta(lr, g.w, a.w);
       *ap = a;
     } else {
       w.x -= lr * g.x; w.y -= lr * g.y; w.z -= lr * g.z; w.w -= lr * g.w;
@@ -281,7 +303,7 @@ __device__ __forceinline__ void adagrad_row(float* __restrict__ E, float* __rest
     if (bias_acc) {
       const float a = bias_acc[row] + gg * gg;
       bias_acc[row] = a;
-      bias[row] -= lr * gg / sqrtf(a);
+      bias[row] -= adagrad_delta(lr, gg, a);
     } else {
       bias[row] -= lr * gg;
     }
@@ -325,6 +347,7 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
   __shared__ int s_src[NWV][64];
   __shared__ float s_coef[NWV][64];
   __shared__ uint32_t s_key[NWV][64];
+  __shared__ int s_lead[NWV][66];              // window positions of the run leaders, then nvalid
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int lig = lane % LPR;
@@ -348,7 +371,7 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
   {
     int sv = 0;
     float cv = 0.f;
-    if (valid) {
+    if (inb) {          // (not `valid`: these loads then fly with the key loads)
       const uint32_t i = spos ? spos[p] : (uint32_t)p;
       sv = ssrc ? ssrc[i] : (int32_t)i;
       cv = scoef ? scoef[i] : 1.f;
@@ -363,118 +386,158 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
   const int nvalid = __popcll(V);                          // valid positions are a prefix
   const float lr = *lr_dev;
   const float gs = gscale_dev ? *gscale_dev : 1.f;
+  // leader list: the j-th leader's window position at s_lead[j], its run ends at s_lead[j + 1]
+  const int nlead = __popcll(L);
+  if ((L >> lane) & 1ull) {
+    const int r = __builtin_amdgcn_mbcnt_hi((uint32_t)(L >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)L, 0u));
+    s_lead[wv][r] = lane;
+  }
+  if (lane == 0) s_lead[wv][nlead] = nvalid;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  unsigned long long m = L;
-  for (int k = 0; k < sgi && m; ++k) m &= m - 1;           // this sub-group starts at its sgi-th leader
-  while (m) {
-    const int i = __builtin_ctzll(m);
-    const unsigned long long rest = (i == 63) ? 0ull : (L & ~((2ull << i) - 1ull));
-    const int e = rest ? __builtin_ctzll(rest) : nvalid;
-    const int rows = e - i;
-    const uint32_t rkey = s_key[wv][i];
-    const TabRow T = tab_of<MT>(ts, rkey);
-    float* __restrict__ E = T.E;
-    float* __restrict__ acc = T.acc;
-    float* __restrict__ bias = T.bias;
-    float* __restrict__ bias_acc = T.bias_acc;
-    const uint32_t rrow = T.row;
-    const bool is_head = (H >> i) & 1ull;
-    const bool continues = (e == 64) && (knext == rkey);
-    const bool complete = is_head && !continues;
-    // the table row is known up front: its loads fly with the gradient rows
-    float4 wrow = make_float4(0.f, 0.f, 0.f, 0.f), arow = wrow;
-    if (complete && colok) {
-      wrow = *reinterpret_cast<const float4*>(E + (int64_t)rrow * d + col);
-      if (!SGD) arow = *reinterpret_cast<const float4*>(acc + (int64_t)rrow * d + col);
-    }
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t = 0; t < rows; t += 8) {
-      float4 v[8];
-      float c[8];
+  // Leaders are taken NB at a time: everything a run needs from HBM that does not depend on its
+  // gradient sum -- table row, slot row, bias cells, its first gradient row and the bias
+  // gradients -- is requested for all NB runs before the first one is summed, so a sub-group
+  // pays one HBM round trip per NB runs instead of three per run (rows -> bias gradient ->
+  // bias cells used to be dependent trips).
+  constexpr int NB = (WPW > 1) ? 4 : 2;       // one-hot windows: all 4 leaders of a sub-group at once
+  constexpr int RU = (WPW > 1) ? 4 : 8;       // further gradient rows of a run in flight
+  for (int j0 = sgi; j0 < nlead; j0 += kStride * NB) {
+    int li[NB], lrows[NB];
+    bool lhead[NB], lcomp[NB];
+    float4 wrow[NB], arow[NB], g0[NB];
+    float gbv[NB], bv[NB], bav[NB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const bool ok = t + u < rows;
-        const int idx = i + (ok ? t + u : 0);
-        const int s = s_src[wv][idx];
-        c[u] = ok ? s_coef[wv][idx] : 0.f;
-        v[u] = (ok && colok) ? *reinterpret_cast<const float4*>(G + (int64_t)s * ldg + col)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a = f4_fma(c[u], v[u], a);
-    }
-    float gb = 0.f;
-    if (Gb) {
-      for (int t = lig; t < rows; t += LPR) gb = fmaf(s_coef[wv][i + t], Gb[s_src[wv][i + t]], gb);
-#pragma unroll
-      for (int o = LPR / 2; o > 0; o >>= 1) gb += __shfl_xor(gb, o, LPR);
-    }
-    if (complete) {
-      if (colok) {
-        float4 gg = make_float4(a.x * gs, a.y * gs, a.z * gs, a.w * gs);
-        if (!SGD) {
-          arow.x += gg.x * gg.x; arow.y += gg.y * gg.y; arow.z += gg.z * gg.z; arow.w += gg.w * gg.w;
-          wrow.x -= lr * gg.x / sqrtf(arow.x);
-          wrow.y -= lr * gg.y / sqrtf(arow.y);
-          wrow.z -= lr * gg.z / sqrtf(arow.z);
-          wrow.w -= lr * gg.w / sqrtf(arow.w);
-          *reinterpret_cast<float4*>(acc + (int64_t)rrow * d + col) = arow;
-        } else {                                   // gradient descent
-          wrow.x -= lr * gg.x; wrow.y -= lr * gg.y; wrow.z -= lr * gg.z; wrow.w -= lr * gg.w;
-        }
-        *reinterpret_cast<float4*>(E + (int64_t)rrow * d + col) = wrow;
-      }
-      if (bias && lig == 0) {
-        const float gg = gb * gs;
-        if (!SGD) {
-          const float ba = bias_acc[rrow] + gg * gg;
-          bias_acc[rrow] = ba;
-          bias[rrow] -= lr * gg / sqrtf(ba);
-        } else {
-          bias[rrow] -= lr * gg;
-        }
-      }
-    } else {
-      // ---- piece of a multi-piece run ----
-      const int64_t slot = w0 / 64;
-      const int64_t q = w0 + i;
-      float* prow = (is_head ? scratch_h : scratch) + slot * (int64_t)d;
-      if (colok) *reinterpret_cast<float4*>(prow + col) = a;
-      if (lig == 0) (is_head ? scratch_hb : scratch_b)[slot] = gb;
-      if (is_head) {
-        // aligned pieces that follow: probe 16 window starts per round trip; runs with at
-        // most kShortMaxAligned of them go to the short list (one sub-group each in
-        // k_sparse_finish), Zipf-hot ones to the long list (one workgroup each)
-        const int64_t first = w0 + 64;
-        int na = 0;
-        bool stop = false;
-        while (!stop) {
-          int mc = 0;
-          bool all = true;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const int64_t aa = first + (int64_t)(na + j) * 64;
-            const bool same = (aa < n) && (sk[aa] == rkey);
-            if (all && same) ++mc; else all = false;
+    for (int j = 0; j < NB; ++j) {
+      const int jl = j0 + j * kStride;
+      const bool act = jl < nlead;
+      const int i = act ? s_lead[wv][jl] : 0;
+      const int e = act ? s_lead[wv][jl + 1] : 1;
+      const uint32_t rkey = s_key[wv][i];
+      const bool is_head = (H >> i) & 1ull;
+      const bool continues = (e == 64) && (knext == rkey);
+      li[j] = act ? i : -1;
+      lrows[j] = e - i;
+      lhead[j] = is_head;
+      lcomp[j] = act && is_head && !continues;
+      wrow[j] = arow[j] = g0[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      gbv[j] = bv[j] = bav[j] = 0.f;
+      if (act) {
+        const TabRow T = tab_of<MT>(ts, rkey);
+        if (colok) {
+          g0[j] = *reinterpret_cast<const float4*>(G + (int64_t)s_src[wv][i] * ldg + col);
+          if (lcomp[j]) {
+            wrow[j] = *reinterpret_cast<const float4*>(T.E + (int64_t)T.row * d + col);
+            if (!SGD) arow[j] = *reinterpret_cast<const float4*>(T.acc + (int64_t)T.row * d + col);
           }
-          na += mc;
-          stop = (mc < 16) || (na > kShortMaxAligned);
         }
-        if (lig == 0) {
-          if (na > kShortMaxAligned) {
-            const int sl = atomicAdd(&list_count[0], 1);
-            list_long[sl] = (int32_t)q;
+        if (Gb && lig < lrows[j]) gbv[j] = Gb[s_src[wv][i + lig]];
+        if (lcomp[j] && T.bias && lig == 0) {
+          bv[j] = T.bias[T.row];
+          if (!SGD) bav[j] = T.bias_acc[T.row];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (li[j] < 0) continue;
+      const int i = li[j];
+      const int rows = lrows[j];
+      const uint32_t rkey = s_key[wv][i];
+      const TabRow T = tab_of<MT>(ts, rkey);
+      const uint32_t rrow = T.row;
+      const bool is_head = lhead[j];
+      // same order as a plain walk over the run: row 0 first, then 8 rows in flight at a time
+      float4 a = f4_fma(s_coef[wv][i], g0[j], make_float4(0.f, 0.f, 0.f, 0.f));
+      for (int t = 1; t < rows; t += RU) {
+        float4 v[RU];
+        float c[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const bool ok = t + u < rows;
+          const int idx = i + (ok ? t + u : 0);
+          const int s = s_src[wv][idx];
+          c[u] = ok ? s_coef[wv][idx] : 0.f;
+          v[u] = (ok && colok) ? *reinterpret_cast<const float4*>(G + (int64_t)s * ldg + col)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) a = f4_fma(c[u], v[u], a);
+      }
+      float gb = 0.f;
+      if (Gb) {
+        if (lig < rows) gb = fmaf(s_coef[wv][i + lig], gbv[j], 0.f);
+        for (int t = lig + LPR; t < rows; t += LPR) gb = fmaf(s_coef[wv][i + t], Gb[s_src[wv][i + t]], gb);
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) gb += __shfl_xor(gb, o, LPR);
+      }
+      if (lcomp[j]) {
+        if (colok) {
+          float4 gg = make_float4(a.x * gs, a.y * gs, a.z * gs, a.w * gs);
+          float4 w4 = wrow[j];
+          if (!SGD) {
+            float4 a4 = arow[j];
+            a4.x += gg.x * gg.x; a4.y += gg.y * gg.y; a4.z += gg.z * gg.z; a4.w += gg.w * gg.w;
+            w4.x -= adagrad_delta(lr, gg.x, a4.x);
+            w4.y -= adagrad_delta(lr, gg.y, a4.y);
+            w4.z -= adagrad_delta(lr, gg.z, a4.z);
+            w4.w -= adagrad_delta(lr, gg.w, a4.w);
+            *reinterpret_cast<float4*>(T.acc + (int64_t)rrow * d + col) = a4;
+          } else {                                   // gradient descent
+            w4.x -= lr * gg.x; w4.y -= lr * gg.y; w4.z -= lr * gg.z; w4.w -= lr * gg.w;
+          }
+          *reinterpret_cast<float4*>(T.E + (int64_t)rrow * d + col) = w4;
+        }
+        if (T.bias && lig == 0) {
+          const float gg = gb * gs;
+          if (!SGD) {
+            const float ba = bav[j] + gg * gg;
+            T.bias_acc[rrow] = ba;
+            T.bias[rrow] = bv[j] - adagrad_delta(lr, gg, ba);
           } else {
-            const int sl = atomicAdd(&list_count[1], 1);
-            list_short[2 * sl] = (int32_t)q;
-            list_short[2 * sl + 1] = na;
+            T.bias[rrow] = bv[j] - lr * gg;
+          }
+        }
+      } else {
+        // ---- piece of a multi-piece run ----
+        const int64_t slot = w0 / 64;
+        const int64_t q = w0 + i;
+        float* prow = (is_head ? scratch_h : scratch) + slot * (int64_t)d;
+        if (colok) *reinterpret_cast<float4*>(prow + col) = a;
+        if (lig == 0) (is_head ? scratch_hb : scratch_b)[slot] = gb;
+        if (is_head) {
+          // aligned pieces that follow: probe 16 window starts per round trip; runs with at
+          // most kShortMaxAligned of them go to the short list (one sub-group each in
+          // k_sparse_finish), Zipf-hot ones to the long list (one workgroup each)
+          const int64_t first = w0 + 64;
+          int na = 0;
+          bool stop = false;
+          while (!stop) {
+            int mc = 0;
+            bool all = true;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+              const int64_t aa = first + (int64_t)(na + jj) * 64;
+              const bool same = (aa < n) && (sk[aa] == rkey);
+              if (all && same) ++mc; else all = false;
+            }
+            na += mc;
+            stop = (mc < 16) || (na > kShortMaxAligned);
+          }
+          if (lig == 0) {
+            if (na > kShortMaxAligned) {
+              const int sl = atomicAdd(&list_count[0], 1);
+              list_long[sl] = (int32_t)q;
+            } else {
+              const int sl = atomicAdd(&list_count[1], 1);
+              list_short[2 * sl] = (int32_t)q;
+              list_short[2 * sl + 1] = na;
+            }
           }
         }
       }
     }
-    for (int k = 0; k < kStride && m; ++k) m &= m - 1;     // next leader of this sub-group
   }
 }
 
@@ -1023,7 +1086,10 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
     if (sgd) { ARX_WIN_GO2(WPW_, MT_, true, GRID_, THREADS_); }                             \
     else { ARX_WIN_GO2(WPW_, MT_, false, GRID_, THREADS_); }                                \
   } while (0)
-  if (short_runs) {   // one-hot ids: 8 waves share each window
+  static const int wpw_env = getenv("ARX_WIN_WPW") ? atoi(getenv("ARX_WIN_WPW")) : 0;
+  if (short_runs && wpw_env == 4) {
+    if (multi) { ARX_WIN_GO(4, true, grid8, 256); } else { ARX_WIN_GO(4, false, grid8, 256); }
+  } else if (short_runs) {   // one-hot ids: 8 waves share each window
     if (multi) { ARX_WIN_GO(8, true, grid8, 512); } else { ARX_WIN_GO(8, false, grid8, 512); }
   } else {
     if (multi) { ARX_WIN_GO(1, true, grid, 256); } else { ARX_WIN_GO(1, false, grid, 256); }

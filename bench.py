@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--n-sampled", type=int, default=1024)
     ap.add_argument("--n-resample", type=int, default=50)
     ap.add_argument("--mulhot", action="store_true", help="C3: add a multi-hot item attribute")
+    ap.add_argument("--zipf-items", type=float, default=1.05,
+                    help="popularity exponent of the synthetic item draw (0 = uniform; experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -215,7 +217,7 @@ def main():
     B, S, d = args.batch, args.n_sampled, args.dim
     t_setup = time.time()
     syn = SyntheticHMF(n_users=args.n_users, n_items=args.n_items, item_mulhot=args.mulhot,
-                       permute_logits=False, seed=0)
+                       permute_logits=False, seed=0, zipf_items=args.zipf_items)
     model = LatentProductModel(args.n_users, args.n_items, d, 1, B, 0.1, 1.0, syn.u_attr, syn.i_attr,
                                syn.item2logit[:args.n_items], syn.logit_ind2item_ind,
                                loss_function='mw', n_sampled=S, use_graph=not args.no_graph)
