@@ -1049,7 +1049,7 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
                         const float* scoef, int64_t n, uint32_t sentinel, const float* G, int64_t ldg,
                         const float* gb_in, const float* lr_dev, const float* gscale_dev,
                         float* scratch, float* scratch_b, float* scratch_h, float* scratch_hb,
-                        int32_t* list, int32_t* count, bool short_runs, bool multi,
+                        int32_t* list, int32_t* count, int wpw, bool multi,
                         const int32_t* n_dev, hipStream_t s) {
   const int32_t* cnt = ts.cnt[0];
   const int lpr = lanes_per_row(d);
@@ -1086,11 +1086,14 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
     if (sgd) { ARX_WIN_GO2(WPW_, MT_, true, GRID_, THREADS_); }                             \
     else { ARX_WIN_GO2(WPW_, MT_, false, GRID_, THREADS_); }                                \
   } while (0)
-  static const int wpw_env = getenv("ARX_WIN_WPW") ? atoi(getenv("ARX_WIN_WPW")) : 0;
-  if (short_runs && wpw_env == 4) {
-    if (multi) { ARX_WIN_GO(4, true, grid8, 256); } else { ARX_WIN_GO(4, false, grid8, 256); }
-  } else if (short_runs) {   // one-hot ids: 8 waves share each window
+  // wpw = waves sharing one 64-position window.  8: one-hot ids, alone or fused in -- up to 64
+  // single-row runs per window, a lone wave would walk them serially; 1: pre-expanded multi-hot
+  // segments -- few long runs per window (C3 B=16384, 350 k live tokens: 77 us with 8, 54 with 4,
+  // 52 with 1; the id pass 24 / 27 / 54); 4: callers that cannot tell.
+  if (wpw >= 8) {
     if (multi) { ARX_WIN_GO(8, true, grid8, 512); } else { ARX_WIN_GO(8, false, grid8, 512); }
+  } else if (wpw >= 4) {
+    if (multi) { ARX_WIN_GO(4, true, grid8, 256); } else { ARX_WIN_GO(4, false, grid8, 256); }
   } else {
     if (multi) { ARX_WIN_GO(1, true, grid, 256); } else { ARX_WIN_GO(1, false, grid, 256); }
   }
@@ -1190,7 +1193,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   const float* gb_in = any_bias ? Gb : nullptr;
   return launch_apply(ts, d, keys_out, spos_arg, src_arg, coef_arg, n, sentinel, G, ldg, gb_in, lr_dev,
                       gscale_dev, scratch, scratch_b, scratch_h, scratch_hb, list, count,
-                      /*short_runs=*/(ntables > 1 || n <= (1 << 19)), /*multi=*/ntables > 1, n_dev, s);   // fused passes mix unique-heavy one-hot ids in: 8 waves per window
+                      /*wpw=*/(ntables > 1 || st.nextra == 0) ? 8 : 1, /*multi=*/ntables > 1, n_dev, s);
 }
 
 }  // namespace arx
@@ -1280,7 +1283,7 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
                       gscale_dev, scratch, scratch_b,
                       reinterpret_cast<float*>(base + w.off_scratch_h),
                       reinterpret_cast<float*>(base + w.off_scratch_hb), list, count,
-                      /*short_runs=*/n <= (1 << 21)   /* 8 waves per window measured faster up to ~0.5 M LIVE contributions (mulhot100k 92 -> 73 us), slower at 1.3 M; n is the padded capacity (~3x the live count for multi-hot sites) */, /*multi=*/false, n_dev, s);
+                      /*wpw=*/n <= (1 << 21) ? 4 : 1   /* explicit (key, src, coef) triples: one-hot or multi-hot, not known here; n is the padded capacity (~3x the live count for multi-hot sites) */, /*multi=*/false, n_dev, s);
 }
 
 int arx_merged_sq_norm(const int32_t* keys, const int32_t* src, const float* coef, int64_t n,
