@@ -666,7 +666,10 @@ class Plan(object):
             key = self._multi_key(fused)
             phase = 2 if (self._k7_done_keys is not None and key in self._k7_done_keys) else 3
             self._apply_multi(fused, phase=phase, key=key)
-            self._jobs.append(('multi', fused, key, sum(x.cap for _, c, m in fused for x in c + m)))
+            # size estimate for _plan_early: one-hot sites are all live, a multi-hot site's padded
+            # capacity (max_len slots per bag) holds about a third of that in live tokens
+            self._jobs.append(('multi', fused, key, sum(x.cap for _, c, _m in fused for x in c)
+                               + sum(x.cap for _, _c, m in fused for x in m) // 3))
             self._n_passes += 1
         done = set(id(e) for e, _, _ in fused)
         toks = []
@@ -768,9 +771,10 @@ class Plan(object):
         """Which of this execution's passes may be sorted ahead next time: all of them or none
         (with a separate heavy pass behind the branch -- the multi-hot table of C3 -- it measured
         slower: 469 -> 482 us), and only while the sorts are launch-bound little kernels (beyond
-        ~10^5 contributions they take CUs from the GEMMs: B=65536 845 -> 911 us) on a step that is
-        GPU-bound at all."""
-        cap = int(os.environ.get('ARX_K7_EARLY_MAX', '100000'))
+        ~1.25 * 10^5 live contributions they take CUs from the GEMMs: C2 B=65536, 132 k: 791 -> 827 us;
+        C4, 103 k: 909 -> 895 us; C3 B=4096, ~118 k: 215 -> 192 us) on a step that is GPU-bound at
+        all."""
+        cap = int(os.environ.get('ARX_K7_EARLY_MAX', '125000'))
         # tiny steps are bound by the host-side cost of a graph launch, and a graph with a second
         # branch costs more to launch (C1, B=64: 75 -> 103 us per step with the branch)
         lo = int(os.environ.get('ARX_K7_EARLY_MIN', '8192'))
