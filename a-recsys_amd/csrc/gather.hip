@@ -357,59 +357,71 @@ struct GatherSites {
   float* out[kMaxSites];
   float* bias_out[kMaxSites];
   int64_t ldo[kMaxSites];
-  int64_t row_end[kMaxSites];      // exclusive prefix ends over the concatenated rows
+  int64_t n[kMaxSites];            // rows of each site
+  int32_t blk_end[kMaxSites];      // exclusive prefix ends over the sites' workgroups
   float scale[kMaxSites];
   int count;
 };
 
+constexpr int kGatherUnroll = 4;    // rows per sub-group, all in flight together
+
+// Every workgroup belongs to ONE site, so the site's pointers are wave-uniform (scalar loads of
+// the kernel arguments).  With the site picked per row, each of E[s], ids[s], out[s]... was a
+// vector load from the argument block behind a serial search over the row prefix: six to seven
+// dependent round trips per row (SQ_WAVE_CYCLES: 9 us per wave for two 512-byte rows).
+// A sub-group takes kGatherUnroll rows: ids together, then table rows together, then stores.
 template <int LPR>
 __global__ __launch_bounds__(256) void k_gather_onehot_multi(GatherSites gs, int d) {
   constexpr int GPW = 64 / LPR;
+  constexpr int UN = kGatherUnroll;
+  constexpr int RPB = 4 * GPW * UN;                // rows per workgroup
   const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
   const int lig = lane % LPR;
   const int gid = lane / LPR;
   const int col = lig * 4;
-  const int64_t total = gs.row_end[gs.count - 1];
-  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  // two rows per sub-group and iteration: the id -> row -> table-row chains of both are in flight
-  // together (one row at a time left the kernel latency-bound: 15 us for 34 k rows)
-  const int64_t step = nwave * GPW;
-  for (int64_t q0 = wave * GPW + gid; q0 < total; q0 += 2 * step) {
-    int64_t q[2] = {q0, q0 + step};
-    int sidx[2];
-    int64_t r[2];
-    int id[2], row[2];
-    bool ok[2];
+  int s = 0;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      ok[u] = q[u] < total;
-      int s = 0;
-      if (ok[u]) while (q[u] >= gs.row_end[s]) ++s;
-      sidx[u] = s;
-      r[u] = ok[u] ? q[u] - (s ? gs.row_end[s - 1] : 0) : 0;
-      id[u] = ok[u] ? gs.ids[s][r[u]] : 0;
-    }
+  for (int k = 0; k < kMaxSites - 1; ++k) s += (k < gs.count - 1 && (int)blockIdx.x >= gs.blk_end[k]) ? 1 : 0;
+  const int blk0 = s ? gs.blk_end[s - 1] : 0;
+  const int64_t n = gs.n[s];
+  const float* __restrict__ E = gs.E[s];
+  const float* __restrict__ bias = gs.bias[s];
+  const int32_t* __restrict__ cat_map = gs.cat_map[s];
+  const int32_t* __restrict__ ids = gs.ids[s];
+  float* __restrict__ out = gs.out[s];
+  float* __restrict__ bias_out = gs.bias_out[s];
+  const int64_t ldo = gs.ldo[s];
+  const float sc = gs.scale[s];
+  const int64_t base = (int64_t)((int)blockIdx.x - blk0) * RPB + wv * GPW + gid;
+  int64_t r[UN];
+  int row[UN];
+  bool ok[UN];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) row[u] = (ok[u] && gs.cat_map[sidx[u]]) ? gs.cat_map[sidx[u]][id[u]] : id[u];
-    float4 v[2];
-    float bv[2];
+  for (int u = 0; u < UN; ++u) {
+    r[u] = base + u * (4 * GPW);                   // neighbouring sub-groups take neighbouring rows
+    ok[u] = r[u] < n;
+    row[u] = ok[u] ? ids[r[u]] : 0;
+  }
+  if (cat_map) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      v[u] = (ok[u] && col < d) ? *reinterpret_cast<const float4*>(gs.E[sidx[u]] + (int64_t)row[u] * d + col)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
-      bv[u] = (ok[u] && gs.bias_out[sidx[u]] && lig == 0) ? gs.bias[sidx[u]][row[u]] : 0.f;
-    }
+    for (int u = 0; u < UN; ++u) row[u] = ok[u] ? cat_map[row[u]] : 0;
+  }
+  float4 v[UN];
+  float bv[UN];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (!ok[u]) continue;
-      const int s = sidx[u];
-      const float sc = gs.scale[s];
-      if (col < d)
-        *reinterpret_cast<float4*>(gs.out[s] + r[u] * gs.ldo[s] + col) =
-            make_float4(sc * v[u].x, sc * v[u].y, sc * v[u].z, sc * v[u].w);
-      if (gs.bias_out[s] && lig == 0) gs.bias_out[s][r[u]] = sc * bv[u];
-    }
+  for (int u = 0; u < UN; ++u) {
+    v[u] = (ok[u] && col < d) ? *reinterpret_cast<const float4*>(E + (int64_t)row[u] * d + col)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    bv[u] = (ok[u] && bias_out && lig == 0) ? bias[row[u]] : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    if (!ok[u]) continue;
+    if (col < d)
+      *reinterpret_cast<float4*>(out + r[u] * ldo + col) =
+          make_float4(sc * v[u].x, sc * v[u].y, sc * v[u].z, sc * v[u].w);
+    if (bias_out && lig == 0) bias_out[r[u]] = sc * bv[u];
   }
 }
 
@@ -507,14 +519,20 @@ int arx_gather_onehot_multi(int nsites, const float* const* E, const float* cons
     gs.bias_out[s] = bias_out ? bias_out[s] : nullptr;
     gs.ldo[s] = ldo[s];
     gs.scale[s] = scale[s];
+    gs.n[s] = n[s];
     tot += n[s];
-    gs.row_end[s] = tot;
   }
   gs.count = nsites;
   if (tot == 0) return ARX_OK;
   const int lpr = lanes_per_row(d);
-  const int64_t nwaves = ceil_div(tot, 64 / lpr);
-  ARX_DISPATCH_LPR(lpr, (k_gather_onehot_multi<LPR><<<grid_waves(nwaves), 256, 0, as_stream(stream)>>>(gs, d)));
+  const int64_t rpb = 4 * (64 / lpr) * kGatherUnroll;       // rows per workgroup (one site each)
+  int64_t nblk = 0;
+  for (int s = 0; s < nsites; ++s) {
+    nblk += ceil_div(n[s], rpb);
+    ARX_CHECK_ARG(nblk < (int64_t)0x7fffffff, "arx_gather_onehot_multi: too many rows");
+    gs.blk_end[s] = (int32_t)nblk;
+  }
+  ARX_DISPATCH_LPR(lpr, (k_gather_onehot_multi<LPR><<<(int)nblk, 256, 0, as_stream(stream)>>>(gs, d)));
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
