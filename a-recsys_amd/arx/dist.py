@@ -10,7 +10,8 @@ hmf_model.py on the global batch.  Exchanges per step and rank (SURVEY 8e's
 "gather the pool rows" alternative -- the [B, S] logits never cross xGMI):
 
   all_gather      owned pool rows [S/N, d+4] -> pool [S, d+4]        (0.5 MB at S=1024, d=128)
-  all_to_all(v)   target item ids  -> their owners                   (4 B per interaction)
+  all_to_all(v)   target item ids  -> their owners                   (4 B per interaction; input routing,
+                                                                      done with the batch in prepare_route())
   all_to_all(v)   target rows [*, d+4] back                          (B_loc rows, (N-1)/N cross)
   (local)         logits = U_loc . pool^T + b, WMRB loss, dU, user-shard Adagrad
   reduce_scatter  pool gradient partials [S, d+4] -> owner blocks    (0.5 MB)
@@ -51,6 +52,9 @@ class HipBackend(object):
 
     def gather_rows(self, E, bias, rows, out, bias_out):
         self.ops.gather_onehot(E, bias, None, rows, out, bias_out=bias_out)
+
+    def gather_rows_packed(self, E, bias, rows, out):
+        self.ops.gather_onehot_packed(E, bias, None, rows, out)
 
     def gemm(self, A, B, C, transA=False, transB=False, beta=0.0, col_bias=None, a_rowsum=None):
         self.ops.gemm(A, B, C, self.ws, transA=transA, transB=transB, beta=beta, col_bias=col_bias,
@@ -258,6 +262,19 @@ class ShardedHMF(object):
                  'items': torch.from_numpy(np.ascontiguousarray(it[perm])).to(self.device),
                  'send': [int(v) for v in send.tolist()], 'recv': recv, 'R': int(sum(recv))}
         self._alloc_recv(route['R'])
+        # The ids themselves are routed here too (they are input data, like the owner ordering
+        # above): every owner learns which of its rows this batch asks for, and the local row of
+        # every id is resolved once.  The step path then starts at the table lookups.
+        R = route['R']
+        recv_ids = torch.zeros((R,), dtype=torch.int32, device=self.device)
+        dist.all_to_all_single(recv_ids, route['items'], output_split_sizes=recv,
+                               input_split_sizes=route['send'], group=self.group)
+        recv_rows = torch.zeros((R,), dtype=torch.int32, device=self.device)
+        if R > 0:
+            self.be.shard_route(recv_ids, W, self.rank, self.zero_row, recv_rows, None)
+        urows = torch.zeros((self.B_loc,), dtype=torch.int32, device=self.device)
+        self.be.shard_route(route['users'], W, self.rank, 0, urows, None)   # all owned: local rows
+        route.update(recv_ids=recv_ids, recv_rows=recv_rows, urows=urows)
         return route
 
     # ------------------------------------------------------------------- step
@@ -276,22 +293,15 @@ class ShardedHMF(object):
         # each) are issued asynchronously and waited for only where their result is needed, so that
         # they travel under the scorer GEMM and under the two backward GEMMs respectively.
         # ---- forward ----
-        recv_ids = self.recv_ids[:R]
-        w_ids = dist.all_to_all_single(recv_ids, items_in, output_split_sizes=recv, input_split_sizes=send,
-                                       group=grp, async_op=True)     # target ids -> their owners
-        be.shard_route(users_in, W, r, 0, self.urows, None)            # all owned: local rows
-        be.gather_rows(self.E_user, None, self.urows, self.U_loc, None)
-        be.gather_rows(self.E_item, self.b_item, self.pool_rows, self.I_pack[:, :d], self.b_g)
-        self.I_pack[:, d].copy_(self.b_g)
+        urows, recv_rows = route['urows'], route['recv_rows']
+        self.urows = urows
+        be.gather_rows(self.E_user, None, urows, self.U_loc, None)
+        be.gather_rows_packed(self.E_item, self.b_item, self.pool_rows, self.I_pack)   # row | bias
         dist.all_gather_into_tensor(self.I_all, self.I_pack, group=grp)
         self.b_all.copy_(self.I_all[:, d])
-        w_ids.wait()
-        recv_rows = self.recv_rows[:R]
         T_send = self.T_send[:R]
         if R > 0:
-            be.shard_route(recv_ids, W, r, self.zero_row, recv_rows, None)
-            be.gather_rows(self.E_item, self.b_item, recv_rows, T_send[:, :d], self.tb_send[:R])
-            T_send[:, d].copy_(self.tb_send[:R])
+            be.gather_rows_packed(self.E_item, self.b_item, recv_rows, T_send)
         w_rows = dist.all_to_all_single(self.T_pack, T_send, output_split_sizes=send, input_split_sizes=recv,
                                         group=grp, async_op=True)    # packed target rows back ...
         be.gemm(self.U_loc, self.I_all[:, :d], self.logits, transB=True, col_bias=self.b_all)   # ... under the scorer

@@ -150,6 +150,14 @@ def gather_onehot(E, bias, cat_map, ids, out, scale=1.0, accumulate=False, bias_
     return out
 
 
+def gather_onehot_packed(E, bias, cat_map, ids, out, scale=1.0):
+    """out[r] = [scale * E[row] | scale * bias[row] | pad]: packed rows of the sharded exchanges."""
+    _chk(E, torch.float32, 'E'); _chk(ids, torch.int32, 'ids'); _chk(out, torch.float32, 'out')
+    call("arx_gather_onehot_packed_fwd", _p(E), _p(bias), _p(cat_map), _p(ids), int(ids.shape[0]),
+         int(E.shape[1]), float(scale), _p(out), _ld(out), _stream())
+    return out
+
+
 def gather_id_plus_bag(E_id, bias_id, cat_map, E_tok, bias_tok, vals, starts, lens, ids, out, scale=1.0,
                        accumulate=False, bias_out=None):
     """id row + bag mean of one entity in one launch (both scaled by `scale`)."""

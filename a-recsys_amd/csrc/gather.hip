@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_gather_onehot(
     const float* __restrict__ E, const float* __restrict__ bias,
     const int32_t* __restrict__ cat_map, const int32_t* __restrict__ ids, int64_t B, int d,
     float scale, int accumulate, float* __restrict__ out, int64_t ldo,
-    float* __restrict__ bias_out) {
+    float* bias_out, int64_t ldb) {      // bias_out[r * ldb]; may be a column of `out` (packed rows)
   constexpr int GPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int lig = lane % LPR;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_gather_onehot(
     }
     if (bias_out && lig == 0) {
       float b = scale * bias[row];
-      bias_out[r] = accumulate ? bias_out[r] + b : b;
+      bias_out[r * ldb] = accumulate ? bias_out[r * ldb] + b : b;
     }
   }
 }
@@ -491,7 +491,24 @@ int arx_gather_onehot_fwd(const float* E, const float* bias, const int32_t* cat_
   const int64_t nwaves = ceil_div(B, 64 / lpr);
   ARX_DISPATCH_LPR(lpr, (k_gather_onehot<LPR><<<grid_waves(nwaves), 256, 0, as_stream(stream)>>>(
                             E, bias, cat_map, ids, B, d, scale, accumulate, out, ldo,
-                            bias_out)));
+                            bias_out, 1)));
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_gather_onehot_packed_fwd(const float* E, const float* bias, const int32_t* cat_map,
+                                 const int32_t* ids, int64_t B, int d, float scale, float* out,
+                                 int64_t ldo, void* stream) {
+  ARX_CHECK_ARG(E && bias && ids && out, "arx_gather_onehot_packed_fwd: null pointer");
+  int rc = check_d("arx_gather_onehot_packed_fwd", d);
+  if (rc) return rc;
+  ARX_CHECK_ARG(ldo % 4 == 0 && ldo > d && aligned16(E) && aligned16(out),
+                "arx_gather_onehot_packed_fwd: ldo %% 4, ldo > d and 16-byte alignment required");
+  if (B <= 0) return ARX_OK;
+  const int lpr = lanes_per_row(d);
+  const int64_t nwaves = ceil_div(B, 64 / lpr);
+  ARX_DISPATCH_LPR(lpr, (k_gather_onehot<LPR><<<grid_waves(nwaves), 256, 0, as_stream(stream)>>>(
+                            E, bias, cat_map, ids, B, d, scale, 0, out, ldo, out + d, ldo)));
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

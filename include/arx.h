@@ -95,6 +95,13 @@ int arx_gather_onehot_fwd(const float* E, const float* bias, const int32_t* cat_
                           const int32_t* ids, int64_t B, int d, float scale, int accumulate,
                           float* out, int64_t ldo, float* bias_out, void* stream);
 
+/* Packed form for the sharded exchanges (no reference counterpart): row r of the
+ * output holds [ scale * E[row] (d floats) | scale * bias[row] | pad ], ldo > d -- the bias rides
+ * in column d of the row that is sent to the peer, no second buffer and no copy. */
+int arx_gather_onehot_packed_fwd(const float* E, const float* bias, const int32_t* cat_map,
+                                 const int32_t* ids, int64_t B, int d, float scale, float* out,
+                                 int64_t ldo, void* stream);
+
 /* An entity with an id feature AND one multi-hot attribute, both lookups in one launch:
  * out[r] = (accumulate ? out[r] : 0) + scale * ( E_id[cat_map ? cat_map[ids[r]] : ids[r]] + mean of
  * E_tok over the entity's bag ), bias likewise (embed_attribute.py:371-407 + the reduce_mean of

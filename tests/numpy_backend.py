@@ -19,6 +19,12 @@ class NumpyBackend(object):
         if bias_out is not None:
             _n(bias_out)[...] = _n(bias)[r]
 
+    def gather_rows_packed(self, E, bias, rows, out):
+        r = _n(rows).astype(np.int64)
+        d = _n(E).shape[1]
+        _n(out)[:, :d] = _n(E)[r]
+        _n(out)[:, d] = _n(bias)[r]
+
     def gemm(self, A, B, C, transA=False, transB=False, beta=0.0, col_bias=None, a_rowsum=None):
         a = _n(A).astype(np.float64)
         b = _n(B).astype(np.float64)
