@@ -69,6 +69,9 @@ class HipBackend(object):
     def copy_2d(self, src, dst):
         self.ops.copy_2d(src, dst)
 
+    def copy_strided(self, src, dst):
+        self.ops.copy_strided(src, dst)
+
     def shard_route(self, ids, world, rank, zero_row, rows_out, keys_out):
         self.ops.shard_route(ids, world, rank, zero_row, rows_out, keys_out)
 
@@ -298,7 +301,7 @@ class ShardedHMF(object):
         be.gather_rows(self.E_user, None, urows, self.U_loc, None)
         be.gather_rows_packed(self.E_item, self.b_item, self.pool_rows, self.I_pack)   # row | bias
         dist.all_gather_into_tensor(self.I_all, self.I_pack, group=grp)
-        self.b_all.copy_(self.I_all[:, d])
+        be.copy_strided(self.I_all[:, d], self.b_all)
         T_send = self.T_send[:R]
         if R > 0:
             be.gather_rows_packed(self.E_item, self.b_item, recv_rows, T_send)
@@ -319,10 +322,10 @@ class ShardedHMF(object):
         be.gemm(self.dlogits, self.I_all[:, :d], dU, beta=1.0)                # ... under dU += dL . pool
         # pool gradient partials (+ bias gradient = row sums) -> owners
         be.gemm(self.dlogits, self.U_loc, self.dI_all[:, :d], transA=True, a_rowsum=self.gb_all)
-        self.dI_all[:, d].copy_(self.gb_all)
+        be.copy_strided(self.gb_all, self.dI_all[:, d])
         dist.reduce_scatter_tensor(arena[B_loc:B_loc + Sg], self.dI_all, op=dist.ReduceOp.SUM, group=grp)
         w_dt.wait()
-        arena_b[B_loc:B_loc + Sg + R].copy_(arena[B_loc:B_loc + Sg + R, d])
+        be.copy_strided(arena[B_loc:B_loc + Sg + R, d], arena_b[B_loc:B_loc + Sg + R])
         # one fused scatter + Adagrad pass over both shards
         sites = [(0, self.urows, 0), (1, self.pool_rows, B_loc)]
         if R > 0:

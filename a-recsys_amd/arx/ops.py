@@ -134,6 +134,12 @@ def copy_2d(src, dst):
          _stream())
 
 
+def copy_strided(src, dst):
+    """dst[i] = src[i] for 1-D fp32 views of any (positive) element stride."""
+    call("arx_copy_strided_f32", _p(src), int(src.stride(0)), _p(dst), int(dst.stride(0)),
+         int(src.shape[0]), _stream())
+
+
 # ---- a5 ---------------------------------------------------------------------
 def transpose(src, dst):
     """dst[c, r] = src[r, c] for 2-D fp32 views with unit inner stride."""

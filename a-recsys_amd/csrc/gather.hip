@@ -448,6 +448,15 @@ __global__ __launch_bounds__(256) void k_bag_expand_padded(
   }
 }
 
+// one column of a packed [rows, ld] matrix <-> a dense vector (bias / bias-gradient column of the
+// sharded exchanges' packed rows)
+__global__ __launch_bounds__(256) void k_copy_strided(const float* __restrict__ src, int64_t ss,
+                                                      float* __restrict__ dst, int64_t ds, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    dst[i * ds] = src[i * ss];
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -667,6 +676,19 @@ int arx_copy_2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t 
   int64_t cap = (int64_t)cu_count() * 8;
   if (g > cap) g = cap;
   k_copy_2d<<<(int)g, 256, 0, as_stream(stream)>>>(src, lds, dst, ldd, rows, (int)(cols / 4));
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_copy_strided_f32(const float* src, int64_t src_stride, float* dst, int64_t dst_stride,
+                         int64_t n, void* stream) {
+  ARX_CHECK_ARG(src && dst, "arx_copy_strided_f32: null pointer");
+  ARX_CHECK_ARG(src_stride >= 1 && dst_stride >= 1, "arx_copy_strided_f32: strides must be >= 1");
+  if (n <= 0) return ARX_OK;
+  int64_t g = ceil_div(n, 256);
+  const int64_t cap = (int64_t)cu_count() * 8;
+  if (g > cap) g = cap;
+  k_copy_strided<<<(int)g, 256, 0, as_stream(stream)>>>(src, src_stride, dst, dst_stride, n);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

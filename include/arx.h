@@ -81,6 +81,10 @@ int arx_shard_route(const int32_t* ids, int64_t n, int world, int rank, int32_t 
 /* strided 2-D copy (packs / unpacks the all-to-all blocks of the sharded scorer) */
 int arx_copy_2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows,
                 int64_t cols, void* stream);
+/* dst[i * dst_stride] = src[i * src_stride], i < n: one column of the packed [rows, d+4] rows of
+ * the sharded exchanges <-> a dense vector (bias, bias gradient) */
+int arx_copy_strided_f32(const float* src, int64_t src_stride, float* dst, int64_t dst_stride,
+                         int64_t n, void* stream);
 /* dst[c, r] = src[r, c] (rows x cols -> cols x rows); used to put W_x^T / dW^T of the LSTM
  * into the layouts the streaming GEMMs take (seqModel.py:477 backward) */
 int arx_transpose_f32(const float* src, int64_t lds, int64_t rows, int64_t cols, float* dst,

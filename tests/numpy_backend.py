@@ -51,6 +51,9 @@ class NumpyBackend(object):
         if dT is not None:
             _n(dT)[...] = g * _n(U)
 
+    def copy_strided(self, src, dst):
+        _n(dst)[...] = _n(src)
+
     def copy_2d(self, src, dst):
         dst.copy_(src)
 
