@@ -271,8 +271,10 @@ __device__ __forceinline__ TabRow tab_of(const TableSet& ts, uint32_t key) {
 // lr * g / sqrt(a) as lr * g * rsq(a): v_rsq_f32 is good to 1 ulp, the IEEE sqrt + divide
 // sequences cost ~25 VALU instructions per component and the apply kernels are VALU-issue bound
 // (a wave64 instruction holds its SIMD for 4 cycles) -- profiles/README.md, K7.
+// (v_rsq_f32 flushes denormal inputs to zero -> inf; the slot is clamped to FLT_MIN so a slot
+// that was initialised to 0 and met a gradient below ~1e-19 yields a finite step, not inf.)
 __device__ __forceinline__ float adagrad_delta(float lr, float g, float a) {
-  return lr * g * __frsqrt_rn(a);
+  return lr * g * __frsqrt_rn(a < 1.17549435e-38f ? 1.17549435e-38f : a);   // (NaN slots stay NaN)
 }
 
 __device__ __forceinline__ void adagrad_row(float* __restrict__ E, float* __restrict__ acc,

@@ -282,6 +282,10 @@ def main():
                 hb_key = {"gather": "gather_mulhot" if args.mulhot else "gather_onehot",
                           "scatter": "sparse_apply_window"}.get(hb.split("_")[0])
                 roofline_hbm["traffic"] = (ent.get(hb_key) or {}).get("traffic_bytes")
+                if hb_key == "sparse_apply_window":
+                    # the PMC pass sees the step's FUSED apply (user + item tables in one launch);
+                    # bytes_per_launch above is this one table's stand-alone sort + apply
+                    roofline_hbm["traffic_note"] = "PMC figure = fused user+item window apply of the step"
         except Exception:
             pass
 
