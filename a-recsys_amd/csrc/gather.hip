@@ -508,6 +508,7 @@ int arx_gather_onehot_fwd(const float* E, const float* bias, const int32_t* cat_
 int arx_gather_onehot_packed_fwd(const float* E, const float* bias, const int32_t* cat_map,
                                  const int32_t* ids, int64_t B, int d, float scale, float* out,
                                  int64_t ldo, void* stream) {
+  if (B <= 0) return ARX_OK;
   ARX_CHECK_ARG(E && bias && ids && out, "arx_gather_onehot_packed_fwd: null pointer");
   int rc = check_d("arx_gather_onehot_packed_fwd", d);
   if (rc) return rc;
@@ -533,7 +534,7 @@ int arx_gather_onehot_multi(int nsites, const float* const* E, const float* cons
   GatherSites gs = {};
   int64_t tot = 0;
   for (int s = 0; s < nsites; ++s) {
-    ARX_CHECK_ARG(E[s] && ids[s] && out[s] && n[s] >= 0, "arx_gather_onehot_multi: bad site");
+    ARX_CHECK_ARG(E[s] && n[s] >= 0 && (n[s] == 0 || (ids[s] && out[s])), "arx_gather_onehot_multi: bad site");
     ARX_CHECK_ARG(ldo[s] % 4 == 0 && ldo[s] >= d && aligned16(E[s]) && aligned16(out[s]),
                   "arx_gather_onehot_multi: ldo %% 4 and 16-byte alignment required");
     ARX_CHECK_ARG(!(bias_out && bias_out[s] && !(bias && bias[s])), "arx_gather_onehot_multi: bias_out requires bias");

@@ -95,6 +95,60 @@ def test_gather_onehot(dev, d):
     np.testing.assert_array_equal(out2.cpu().numpy(), E[cmap[ids]])
 
 
+@pytest.mark.parametrize("d,sizes", [(128, [700, 0, 33, 1]), (32, [5, 130]), (16, [257, 64, 3, 0, 19]),
+                                     (128, [16384, 1024, 16384])])
+def test_gather_onehot_multi(dev, d, sizes):
+    """One launch for several one-hot lookups (embed_attribute.py:371-380 per feature): every
+    workgroup serves one site -- ragged and EMPTY sites, with / without cat_map and bias."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(d + len(sizes))
+    sites, want = [], []
+    for k, n in enumerate(sizes):
+        V = 50 + 37 * k
+        E = rng.standard_normal((V, d)).astype(np.float32)
+        bias = rng.standard_normal((V,)).astype(np.float32) if k % 2 == 0 else None
+        N = V + 11
+        cmap = rng.integers(0, V, size=N).astype(np.int32) if k % 3 != 1 else None
+        ids = rng.integers(0, N if cmap is not None else V, size=n).astype(np.int32)
+        rows = cmap[ids] if cmap is not None else ids
+        scale = 1.0 if k == 0 else 0.25 * (k + 1)
+        out = torch.full((max(n, 1), d + 4), 7.0, dtype=torch.float32, device=dev)[:n, :d]
+        bout = torch.full((max(n, 1),), 5.0, dtype=torch.float32, device=dev)[:n] if bias is not None else None
+        sites.append((_t(dev, E), _t(dev, bias) if bias is not None else None,
+                      _t(dev, cmap) if cmap is not None else None, _t(dev, ids), out, scale, bout))
+        want.append((scale * E[rows], scale * bias[rows] if bias is not None else None))
+    ops.gather_onehot_multi(ops.GatherSet(sites))
+    for (E_, b_, c_, i_, out, sc, bout), (w, wb) in zip(sites, want):
+        np.testing.assert_allclose(out.cpu().numpy(), w, rtol=1e-6, atol=0)
+        if wb is not None:
+            np.testing.assert_allclose(bout.cpu().numpy(), wb, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("d,B", [(128, 1000), (32, 7), (64, 0)])
+def test_gather_onehot_packed_and_strided_copy(dev, d, B):
+    """Packed rows of the sharded exchanges: [row | bias | pad]; the bias column <-> vector copies."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(d + B)
+    V = 300
+    E = rng.standard_normal((V, d)).astype(np.float32)
+    bias = rng.standard_normal((V,)).astype(np.float32)
+    ids = rng.integers(0, V, size=B).astype(np.int32)
+    out = torch.full((max(B, 1), d + 4), 9.0, dtype=torch.float32, device=dev)[:B]
+    ops.gather_onehot_packed(_t(dev, E), _t(dev, bias), None, _t(dev, ids), out)
+    got = out.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :d], E[ids])
+    np.testing.assert_array_equal(got[:, d], bias[ids])
+    np.testing.assert_array_equal(got[:, d + 1:], np.full((B, 3), 9.0, np.float32))   # pad untouched
+    if B:
+        vec = torch.zeros((B,), dtype=torch.float32, device=dev)
+        ops.copy_strided(out[:, d], vec)
+        np.testing.assert_array_equal(vec.cpu().numpy(), bias[ids])
+        ops.copy_strided(vec, out[:, d + 2])
+        np.testing.assert_array_equal(out.cpu().numpy()[:, d + 2], bias[ids])
+
+
 @pytest.mark.parametrize("d,max_len,B", [(128, 64, 1000), (32, 18, 64), (64, 5, 257), (20, 3, 10),
                                          (128, 200, 50)])
 def test_gather_mulhot_mean(dev, d, max_len, B):
