@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libarx.so")
+LIB_PATH = os.environ.get("ARX_LIB") or os.path.join(_HERE, "lib", "libarx.so")   # ARX_LIB: A/B builds (tools/)
 
 i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 f32p = C.c_void_p
@@ -101,6 +101,10 @@ PROTOTYPES = {
                                                   C.POINTER(i64), C.POINTER(i32), C.POINTER(f32), f32p, i64,
                                                   f32p, f32p, f32p, i32p, i32p, f32p, cint, C.POINTER(i64),
                                                   C.POINTER(i32), vp, sz, vp]),
+    "arx_sparse_adagrad_bags_workspace_bytes": (sz, [i64, cint, cint]),
+    "arx_sparse_adagrad_bags": (cint, [cint, f32p, f32p, f32p, f32p, i64, cint, i32p, i32p, i32p, i64, cint,
+                                       cint, C.POINTER(vp), C.POINTER(i64), C.POINTER(i32), C.POINTER(f32),
+                                       f32p, i64, f32p, f32p, f32p, i32p, vp, sz, vp]),
     "arx_adagrad_dense": (cint, [f32p, f32p, f32p, i64, f32p, f32p, vp]),
     "arx_sq_norm_accum": (cint, [f32p, i64, cint, f32p, f32p, vp]),
     "arx_clip_coef": (cint, [f32p, f32, f32p, f32p, vp]),

@@ -297,8 +297,6 @@ class EmbeddingAttribute(object):
         ua = self.user_attributes
         ids = self.u_indices['input']
         if no_id and ua.num_features_cat == 1:            # :356-366
-            if ua.num_features_mulhot > 0 and False:
-                pass
             node = ZeroEmbed(self.rt, self.batch_size, ua._embedding_size_list_cat[0])
         else:
             feats = self._select_feats(self.user_feats, ua, no_id=no_id)
@@ -311,8 +309,11 @@ class EmbeddingAttribute(object):
 
     def _ids_node(self, name):
         h = self.i_indices[name]
-        if isinstance(h, tuple):
-            raise NotImplementedError("per-step item placeholders are served by get_batch_item_seq")
+        if isinstance(h, tuple):          # 'input{t}': time step t of the sequence buffer (:87-90)
+            step = h[1]
+            mb = self.batch_size
+            h = G.IdsSlice(self.rt, self.input_all, step * mb, mb, 'item_%s_ind' % name)
+            self.i_indices[name] = h
         return h
 
     def get_batch_item(self, name, batch_size, concat=False, keep_prob=1.0, no_attribute=False,

@@ -125,10 +125,28 @@ class IdsInput(Node):
         if src.is_cuda and src.is_contiguous():
             # device-resident batch: queued, all feeds of a step go out as ONE copy launch when the
             # plan runs (Runtime.flush_feeds; eager readers of .value flush first)
-            self.rt.pending_feeds = [(s_, d_) for s_, d_ in self.rt.pending_feeds if d_ is not self.value]
-            self.rt.pending_feeds.append((src, self.value))
+            self.rt.queue_feed(src, self.value)
         else:
+            self.rt.drop_feed(self.value)        # a queued older feed must not overwrite this one
             self.value.copy_(src.reshape(self.value.shape), non_blocking=True)
+
+    def forward(self, train):
+        pass
+
+
+class IdsSlice(Node):
+    """Rows [start, start + n) of an int placeholder: a bucket shorter than the longest one
+    (start = 0), or one time step 'input{t}' of the sequence buffer
+    (embed_attribute.py:87-90 keeps one placeholder per step; here they are slices of ONE
+    time-major [L*mb] buffer so that the whole sequence can also be looked up by one launch)."""
+
+    def __init__(self, rt, parent, start, n, name):
+        super().__init__(rt, (n,), (parent,))
+        self.name = name
+        self.value = parent.value[start:start + n]
+
+    def feed(self, arr):
+        IdsInput.feed(self, arr)
 
     def forward(self, train):
         pass
@@ -484,6 +502,7 @@ class Plan(object):
         self.has_dropout = any(getattr(n, 'uses_dropout', False) for n in self.order)
         self.tables = []
         self.arenas = []
+        self._bindings = []      # (node, grad, bias_grad, arena, arena_b, row0): see _bind
         if train:
             self._plan_sparse()
 
@@ -501,11 +520,11 @@ class Plan(object):
             arena_b = torch.zeros((rows,), dtype=torch.float32, device=rt.device)
             r0 = 0
             for n in nodes:
-                n.grad = arena[r0:r0 + n.shape[0]]
-                n.bias_grad = arena_b[r0:r0 + n.shape[0]]
-                n.arena, n.arena_b, n.row0 = arena, arena_b, r0
+                self._bindings.append((n, arena[r0:r0 + n.shape[0]], arena_b[r0:r0 + n.shape[0]], arena,
+                                       arena_b, r0))
                 r0 += n.shape[0]
             self.arenas.append((arena, arena_b))
+        self._bind()
         tables = {}
         for n in embeds:
             for s in n.sites():
@@ -528,9 +547,19 @@ class Plan(object):
                 raise NotImplementedError("a table used by lookups of different output widths")
             self.tables.append((table, sites, bufs, total))
 
+    def _bind(self):
+        """Point the lookup nodes at THIS plan's gradient arena.  Lookup nodes can be shared between
+        plans (SeqModel: the cached pool lookup and the user lookups serve every bucket's train
+        plan, each with an arena sized for its own L), so the slices are plan state that is
+        re-attached before every execution / capture, never node state."""
+        for n, g, gb, arena, arena_b, r0 in self._bindings:
+            n.grad, n.bias_grad = g, gb
+            n.arena, n.arena_b, n.row0 = arena, arena_b, r0
+
     # ---- execution ----
     def _execute(self):
         rt = self.rt
+        self._bind()
         if self.train and self.has_dropout and rt.keep_prob < 1.0:
             ops.counter_add(rt.step_dev, 1)      # fresh dropout masks on every (replayed) step
         for m in self.masks:
@@ -574,7 +603,7 @@ class Plan(object):
             self._early_launch()
         # lookups whose ids are placeholders are independent of each other: fork them
         roots = [n for n in self.order if isinstance(n, EntityEmbed) and type(n.inputs[0]).__name__ in
-                 ('IdsInput', 'IdsView') and id(n) not in pre]
+                 ('IdsInput', 'IdsSlice') and id(n) not in pre]
         toks = []
         for k, n in enumerate(roots[1:]):
             t = rt.fork(k)
@@ -617,7 +646,21 @@ class Plan(object):
             return None
         if any(s.col_off != 0 for s in live):
             return None
+        if self._bags_ok(live):
+            return None                   # multi-hot table with its own two-stage pass (_bag_pass)
         return [s for s in live if s.kind == 'cat'], [s for s in live if s.kind != 'cat']
+
+    def _bags_ok(self, live):
+        """Multi-hot lookups of one table take the two-stage pass (merge per entity, then per token:
+        arx_sparse_adagrad_bags) once their padded expansion is past the one-launch rank sort --
+        below that the step is launch-bound and the contribution-level chain has fewer launches."""
+        rt = self.rt
+        if rt.no_bags or rt.force_sort_path or not live or len(live) > 8:
+            return False
+        s0 = live[0]
+        return (all(s.kind == 'mulhot' and s.col_off == 0 and s.maps[0] is s0.maps[0]
+                    and s.node.arena is s0.node.arena for s in live)
+                and sum(s.cap for s in live) > 8192 and sum(s.cap for s in live) < (1 << 31) - 1)
 
     def _apply_sparse(self):
         """One K7 pass per table -- except that tables of equal width that read the same
@@ -761,6 +804,8 @@ class Plan(object):
             for kind, what, key in jobs:
                 if kind == 'multi':
                     self._apply_multi(what, phase=1, key=key)
+                elif kind == 'bags':
+                    self._bag_pass(what, key, phase=1)
                 else:
                     self._cat_pass(what, key, phase=1)
             done = torch.cuda.Event()
@@ -807,6 +852,26 @@ class Plan(object):
                                bufs['src'], bufs['coef'], bufs['cat_ws'], gscale_dev=rt.clip_coef_dev,
                                mode=mode)
 
+    def _bag_pass(self, entry, key, phase):
+        """Multi-hot table, two-stage pass (arx_sparse_adagrad_bags); key = (live sites, use_bias)."""
+        rt = self.rt
+        table, sites, bufs, total = entry
+        live_ids, use_bias = key[1], key[2]
+        if bufs.get('bag_key') != key:
+            live_sites = [s for s in sites if id(s) in live_ids]
+            bufs['bag_key'] = key
+            bufs['bag_args'] = ops.BagSiteArgs([(s.ids_node.value, s.node.row0, s.coef) for s in live_sites],
+                                               max(s.max_len for s in live_sites))
+            bufs['bag_site0'] = live_sites[0]
+            bufs['bag_ws'] = ops.Workspace(rt.device)      # sorted arrays + merged rows live here between the phases
+        s0 = bufs['bag_site0']
+        sgd = rt.optimizer == 'sgd'
+        ops.sparse_adagrad_bags(table.E, None if sgd else table.acc, table.bias if use_bias else None,
+                                table.bias_acc if (use_bias and not sgd) else None, s0.maps[0], s0.maps[1],
+                                s0.maps[2], bufs['bag_args'], s0.node.arena,
+                                s0.node.arena_b if use_bias else None, rt.lr, bufs['bag_ws'],
+                                gscale_dev=rt.clip_coef_dev, phase=phase, aux_cnt=None)
+
     def _apply_one(self, entry):
         rt = self.rt
         for table, sites, bufs, total in (entry,):
@@ -814,6 +879,16 @@ class Plan(object):
             if not live_sites:
                 continue
             n_live = sum(s.n for s in live_sites)
+            if self._bags_ok(live_sites):
+                use_bias = table.bias is not None and any(s.node.bias_grad_used for s in live_sites)
+                key = ('bags', tuple(id(s) for s in live_sites), use_bias)
+                early = self._k7_done_keys
+                self._bag_pass(entry, key, 2 if (early is not None and key in early) else 3)
+                # live tokens after the per-entity merge: about a third of the padded slots hold a
+                # token, and Zipf-popular batches repeat entities about twice
+                self._jobs.append(('bags', entry, key, sum(s.cap for s in live_sites) // 6))
+                self._n_passes += 1
+                continue
             if all(s.kind == 'cat' and s.col_off == 0 for s in live_sites) and n_live <= (1 << 22) \
                     and len(live_sites) <= 8 and not rt.force_sort_path:
                 # one-hot lookups: own pass (optim_cat.hip); sorted ahead when _early_sort ran it
@@ -920,6 +995,7 @@ class Runtime(object):
         self.force_sort_path = bool(_os.environ.get('ARX_FORCE_SORT'))
         self.cat_mode = 1 if _os.environ.get('ARX_CAT_ATOMIC') else 0
         self.no_multi = bool(_os.environ.get('ARX_NO_MULTI'))      # A/B aid: one K7 pass per table
+        self.no_bags = bool(_os.environ.get('ARX_NO_BAGS'))        # A/B aid: contribution-level multi-hot pass
         # fork/join branches inside the captured graph measured SLOWER on ROCm 7.2 (250 us vs
         # 187 us per C2 step: cross-stream graph edges cost more than the overlap buys at
         # these kernel sizes) -- opt-in only.
@@ -927,6 +1003,19 @@ class Runtime(object):
         self._side = None
         self._side_ws = None
         self._pending = []
+
+    def drop_feed(self, dst):
+        """Forget queued feeds whose destination is `dst` (same start address: placeholders and
+        their bucket views alias)."""
+        if self.pending_feeds:
+            p = dst.data_ptr()
+            self.pending_feeds = [(s_, d_) for s_, d_ in self.pending_feeds if d_.data_ptr() != p]
+
+    def queue_feed(self, src, dst):
+        """Queue a device-to-device placeholder feed; the latest feed of a destination wins.  The
+        source tensor is referenced, not copied: it must stay unmodified until the plan runs."""
+        self.drop_feed(dst)
+        self.pending_feeds.append((src, dst))
 
     def flush_feeds(self):
         """Issue the queued placeholder feeds (one launch per four buffers)."""

@@ -16,8 +16,6 @@ Not implemented (raise): beam search (dead code in the reference).
 """
 from __future__ import annotations
 
-import random
-
 import numpy as np
 import torch
 
@@ -26,18 +24,7 @@ from .. import ops
 from ..attributes.embed_attribute import Dropout, ZeroEmbed
 from ..hmf.hmf_model import _Op, _Var
 from ..utils.checkpoint import Saver
-
-
-class IdsView(G.Node):
-    """First n entries of an int placeholder (bucket shorter than the longest)."""
-
-    def __init__(self, rt, parent, n, name):
-        super().__init__(rt, (n,), (parent,))
-        self.name = name
-        self.value = parent.value[:n]
-
-    def forward(self, train):
-        pass
+from .batching import SeqBatching
 
 
 class SeqInputMean(G.Node):
@@ -269,7 +256,7 @@ class _KeepProb(object):
         return _Op(lambda: self.set(v))
 
 
-class SeqModel(object):
+class SeqModel(SeqBatching):
     def __init__(self, buckets, size, num_layers, max_gradient_norm, batch_size, learning_rate,
                  learning_rate_decay_factor, embeddingAttribute, withAdagrad=True, num_samples=512,
                  forward_only=False, dropoutRate=1.0, START_ID=0, loss="ce", devices="",
@@ -388,7 +375,7 @@ class SeqModel(object):
         Lmax = self.buckets[-1]
 
         def view(node, name):
-            return node if L == Lmax else IdsView(rt, node, n, name)
+            return node if L == Lmax else G.IdsSlice(rt, node, 0, n, name)
 
         ids_in = view(m.input_all, 'item_input_%d' % L)
         feats = m._select_feats(m.item_feats, m.item_attributes, no_attribute=self.no_input_item_feature)
@@ -528,7 +515,7 @@ class SeqModel(object):
         if S % 4 != 0:
             raise NotImplementedError("pool size must be a multiple of 4")
         cache = self._rs_cache
-        key = ('tile', tag)
+        key = ('tile', tag, L)              # (the pool lookup is shared by buckets of different L)
         if key not in cache:
             cache[key] = torch.empty(L * S, dtype=torch.float32, device=self.rt.device)
         ops.add_rows_bcast(1.0, rs.view(1, S), 0.0, cache[key].view(L, S))
@@ -603,11 +590,11 @@ class SeqModel(object):
             """device tensors are queued (all feeds of the step leave as one copy launch when the
             plan runs); host data goes up with one H2D copy"""
             if isinstance(src, torch.Tensor) and src.is_cuda and src.dtype == dtype and src.is_contiguous():
-                rt.pending_feeds = [(s_, d_) for s_, d_ in rt.pending_feeds if d_.data_ptr() != dst.data_ptr()]
-                rt.pending_feeds.append((src, dst))
+                rt.queue_feed(src, dst)
             else:
                 if not isinstance(src, torch.Tensor):
                     src = torch.from_numpy(np.ascontiguousarray(src))
+                rt.drop_feed(dst)
                 dst.copy_(src.reshape(-1), non_blocking=True)
 
         put(self.target_ids_all.value[:n], flat_i(targets), torch.int32)
@@ -668,33 +655,7 @@ class SeqModel(object):
             results.append((users[i], np.exp(vals[r] - lse[r]), idx[r]))
         return results
 
-    # ---------------------------------------------------- get_batch (:356-404)
-    def get_batch(self, data_set, bucket_id, start_id=None):
-        length = self.buckets[bucket_id]
-        users, item_inputs, item_outputs, weights = [], [], [], []
-        for i in range(self.batch_size):
-            if start_id is None:
-                user, item_seq = random.choice(data_set[bucket_id])
-            elif start_id + i < len(data_set[bucket_id]):
-                user, item_seq = data_set[bucket_id][start_id + i]
-            else:
-                user, item_seq = self.USER_PAD_ID, []
-            pad_seq = [self.PAD_ID] * (length - len(item_seq))
-            if len(item_seq) == 0:
-                item_input_seq = [self.START_ID] + pad_seq[1:]
-            else:
-                item_input_seq = [self.START_ID] + item_seq[:-1] + pad_seq
-            users.append(user)
-            item_inputs.append(item_input_seq)
-            item_outputs.append(item_seq + pad_seq)
-            weights.append([1.0] * len(item_seq) + [0.0] * len(pad_seq))
-
-        def batch_major(l):
-            return [[l[j][i] for j in range(self.batch_size)] for i in range(len(l[0]))]
-
-        finished = (start_id is not None and start_id + self.batch_size >= len(data_set[bucket_id]))
-        return (users, batch_major(item_inputs), batch_major(item_outputs), batch_major(weights),
-                finished)
+    # get_batch / get_batch_recommend (:356-452): arx.lstm.batching.SeqBatching
 
 
 class _FloatView(G.Node):

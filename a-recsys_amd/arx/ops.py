@@ -448,6 +448,35 @@ def sparse_adagrad_cat_multi(args, G, Gb, lr_dev, keys_buf, src_buf, coef_buf, w
          _stream())
 
 
+class BagSiteArgs(object):
+    """Host-side descriptor arrays of arx_sparse_adagrad_bags, built once per plan.
+    sites: list of (ids, row_base, coef) -- the lookups of one multi-hot table."""
+
+    def __init__(self, sites, max_len):
+        import ctypes as C
+        n = len(sites)
+        self.n = n
+        self.total = sum(int(s[0].shape[0]) for s in sites)
+        self.max_len = int(max_len)
+        self.ids = (C.c_void_p * n)(*[_p(s[0]) for s in sites])
+        self.count = (C.c_int64 * n)(*[int(s[0].shape[0]) for s in sites])
+        self.row_base = (C.c_int32 * n)(*[int(s[1]) for s in sites])
+        self.coef = (C.c_float * n)(*[float(s[2]) for s in sites])
+        self._keep = sites
+
+
+def sparse_adagrad_bags(E, acc, bias, bias_acc, vals, starts, lens, site_args, G, Gb, lr_dev, ws,
+                        gscale_dev=None, phase=3, aux_cnt=None):
+    """Multi-hot lookups of one table: merge per entity, then per token (arx.h).  phase 1: both
+    sorts (ids only), 2: merge + apply, 3: both; same `ws` for both halves."""
+    d = int(E.shape[1])
+    wsp, wsn = ws.get(_lib.lib.arx_sparse_adagrad_bags_workspace_bytes(site_args.total, site_args.max_len, d))
+    call("arx_sparse_adagrad_bags", int(phase), _p(E), _p(acc), _p(bias), _p(bias_acc), int(E.shape[0]), d,
+         _p(vals), _p(starts), _p(lens), int(lens.shape[0]), site_args.max_len, site_args.n, site_args.ids,
+         site_args.count, site_args.row_base, site_args.coef, _p(G), _ld(G), _p(Gb), _p(lr_dev),
+         _p(gscale_dev), _p(aux_cnt), wsp, wsn, _stream())
+
+
 def adagrad_dense(w, acc, g, lr_dev, gscale_dev=None):
     call("arx_adagrad_dense", _p(w), _p(acc), _p(g), int(w.numel()), _p(lr_dev), _p(gscale_dev),
          _stream())

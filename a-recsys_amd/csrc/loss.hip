@@ -101,7 +101,10 @@ __global__ __launch_bounds__(256) void k_loss_margin(
   const uint8_t* m = (!POS && mask) ? mask + (r % mask_rows) * ldm : nullptr;
   if (POS) build_pos_bits(bits, W, pm, r % mask_rows);
   const int tcol = WARP ? target[r] : -1;
-  const float t = WARP ? x[tcol] : tscore[r];
+  // a target without a logit index (the reference's item_ind2logit_ind raises KeyError): the row's
+  // loss is NaN -- loud -- and its gradient zero; nothing is read or written out of bounds
+  const bool bad = WARP && (tcol < 0 || tcol >= W);
+  const float t = WARP ? (bad ? 0.f : x[tcol]) : tscore[r];
   float s = 0.f;
   for (int64_t c = threadIdx.x; c < W; c += 256) {
     const float v = x[c] - t + 1.f;
@@ -109,9 +112,9 @@ __global__ __launch_bounds__(256) void k_loss_margin(
     s += (keep && v > 0.f) ? v : 0.f;
   }
   s = block_sum(s, sh);
-  if (threadIdx.x == 0 && batch_loss) batch_loss[r] = logf(1.f + s);
+  if (threadIdx.x == 0 && batch_loss) batch_loss[r] = bad ? NAN : logf(1.f + s);
   if (!dlogits) return;
-  const float g = gscale * (row_w ? row_w[r] : 1.f) / (1.f + s);
+  const float g = bad ? 0.f : gscale * (row_w ? row_w[r] : 1.f) / (1.f + s);
   float* dx = dlogits + r * lddl;
   float cnt = 0.f;
   for (int64_t c = threadIdx.x; c < W; c += 256) {
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void k_loss_margin(
   cnt = block_sum(cnt, sh);  // (contains the barrier that orders the writes above)
   if (threadIdx.x == 0) {
     const float dt = -g * cnt;
-    if (WARP) dx[tcol] += dt;
+    if (WARP) { if (!bad) dx[tcol] += dt; }
     else if (dtscore) dtscore[r] = dt;
   }
 }
@@ -208,8 +211,9 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
     t = wsum(ur.x * tr.x + ur.y * tr.y + ur.z * tr.z + ur.w * tr.w) + (df.tb ? df.tb[r * df.tb_stride] : 0.f);
     if (lane == 0 && df.tscore_out) df.tscore_out[r] = t;
   } else {
-    t = WARP ? x[tcol] : tscore[r];
+    t = WARP ? ((tcol < 0 || tcol >= W) ? 0.f : x[tcol]) : tscore[r];
   }
+  const bool bad = WARP && (tcol < 0 || tcol >= W);     // see k_loss_margin
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -222,9 +226,9 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
     s += (((keep >> (4 * i + 3)) & 1u) && c + 3 < W && e3 > 0.f) ? e3 : 0.f;
   }
   s = wsum(s);
-  if (lane == 0 && batch_loss) batch_loss[r] = logf(1.f + s);
+  if (lane == 0 && batch_loss) batch_loss[r] = bad ? NAN : logf(1.f + s);
   if (!dlogits) return;
-  const float g = gscale * (row_w ? row_w[r] : 1.f) / (1.f + s);
+  const float g = bad ? 0.f : gscale * (row_w ? row_w[r] : 1.f) / (1.f + s);
   float* dx = dlogits + r * lddl;
   float cnt = 0.f;
   float4 d[NV];
@@ -342,7 +346,8 @@ __global__ __launch_bounds__(256) void k_loss_rs(
   const uint8_t* m = (!POS && mask) ? mask + (r % mask_rows) * ldm : nullptr;
   if (POS) build_pos_bits(bits, W, pm, r % mask_rows);
   const int tcol = target[r];
-  const float t = x[tcol];
+  const bool bad = tcol < 0 || tcol >= W;               // see k_loss_margin
+  const float t = bad ? 0.f : x[tcol];
   float s = 0.f;
   for (int64_t c = threadIdx.x; c < W; c += 256) {
     const bool keep = POS ? !((bits[c >> 5] >> (c & 31)) & 1u) : (m ? (m[c] != 0) : true);
@@ -358,9 +363,9 @@ __global__ __launch_bounds__(256) void k_loss_rs(
   else if (loss_func == 2) { l = powf(s, exp_p); dl = exp_p * powf(s, exp_p - 1.f); }
   else if (loss_func == 3) { l = powf(1.f + s, exp_p); dl = exp_p * powf(1.f + s, exp_p - 1.f); }
   else { l = s * s; dl = 2.f * s; }
-  if (threadIdx.x == 0 && batch_loss) batch_loss[r] = l;
+  if (threadIdx.x == 0 && batch_loss) batch_loss[r] = bad ? NAN : l;
   if (!dlogits) return;
-  const float g = gscale * (row_w ? row_w[r] : 1.f) * dl;
+  const float g = bad ? 0.f : gscale * (row_w ? row_w[r] : 1.f) * dl;
   float* dx = dlogits + r * lddl;
   float tot = 0.f;
   for (int64_t c = threadIdx.x; c < W; c += 256) {
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(256) void k_loss_rs(
     dx[c] = d;
   }
   tot = block_sum(tot, sh);   // (contains the barrier that orders the writes above)
-  if (threadIdx.x == 0) dx[tcol] += -tot;
+  if (threadIdx.x == 0 && !bad) dx[tcol] += -tot;
 }
 
 __global__ __launch_bounds__(256) void k_loss_ce(
@@ -383,7 +388,8 @@ __global__ __launch_bounds__(256) void k_loss_ce(
   const int64_t r = blockIdx.x;
   const float* x = logits + r * ldl;
   const int tcol = target[r];
-  const float xt = x[tcol];
+  const bool bad = tcol < 0 || tcol >= V;               // see k_loss_margin
+  const float xt = bad ? NAN : x[tcol];
   float mx = -INFINITY;
   for (int64_t c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, x[c]);
   mx = block_max(mx, sh);
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(256) void k_loss_ce(
   se = block_sum(se, sh);
   if (threadIdx.x == 0 && batch_loss) batch_loss[r] = logf(se) + mx - xt;
   if (!dlogits) return;
-  const float g = gscale * (row_w ? row_w[r] : 1.f);
+  const float g = bad ? 0.f : gscale * (row_w ? row_w[r] : 1.f);
   const float inv = g / se;
   float* dx = dlogits + r * lddl;
   for (int64_t c = threadIdx.x; c < V; c += 256) {

@@ -327,10 +327,36 @@ __device__ __forceinline__ void adagrad_row(float* __restrict__ E, float* __rest
 //   * otherwise by k_sparse_long (second launch, one workgroup per listed run): the
 //     Zipf-hot rows with hundreds of pieces, summed by 32 sub-groups in parallel.
 // Partials are always summed head first, then in ascending piece order => bit-reproducible.
+// MERGE mode of the window apply / finish kernels (arx_sparse_adagrad_bags, stage 1): the sorted
+// keys are ENTITY ids (items of the batch and of the pool), a run = all gradient rows of one
+// entity; instead of an Adagrad update the run's sum, times 1/len(entity's bag), is written to
+// Gu[sorted position of the run's head] -- the one gradient row the entity's bag tokens then
+// share in stage 2 (duplicate entities cost one row, not one row per occurrence).
+struct MergeOut {
+  float* Gu;               // [n, d] merged rows, indexed by the head's sorted position
+  float* Gub;              // [n] merged bias gradients (null: none)
+  const int32_t* lens;     // bag length per entity
+};
+
+__device__ __forceinline__ void merge_row(const MergeOut& mo, int d, uint32_t key, int64_t head_pos, int col,
+                                          bool colok, int lig, float4 g, float gb) {
+  const float inv = 1.f / (float)mo.lens[key];
+  if (colok)
+    *reinterpret_cast<float4*>(mo.Gu + head_pos * (int64_t)d + col) =
+        make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+  if (mo.Gub && lig == 0) mo.Gub[head_pos] = gb * inv;
+}
+
+#ifndef ARX_WIN_NB1
+#define ARX_WIN_NB1 2
+#endif
+#ifndef ARX_WIN_RU1
+#define ARX_WIN_RU1 8
+#endif
 constexpr int kBig = 1 << 30;
 constexpr int kShortMaxAligned = 16;    // runs with more aligned pieces get a whole workgroup
 
-template <int LPR, int WPW, bool MT, bool SGD>
+template <int LPR, int WPW, bool MT, bool SGD, bool MERGE = false>
 __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
     TableSet ts, int d, const uint32_t* __restrict__ sk,
     const uint32_t* __restrict__ spos, const int32_t* __restrict__ ssrc,
@@ -340,7 +366,7 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
     const float* __restrict__ gscale_dev, float* __restrict__ scratch,
     float* __restrict__ scratch_b, float* __restrict__ scratch_h, float* __restrict__ scratch_hb,
     int32_t* __restrict__ list_long, int32_t* __restrict__ list_short,
-    int32_t* __restrict__ list_count) {
+    int32_t* __restrict__ list_count, MergeOut mo) {
   constexpr int NSG = 64 / LPR;
   constexpr int NWV = (WPW > 4) ? WPW : 4;    // waves per workgroup
   // n_dev: entries that survived the radix sort's first pass (pads dropped); the grid is sized
@@ -403,8 +429,8 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
   // gradients -- is requested for all NB runs before the first one is summed, so a sub-group
   // pays one HBM round trip per NB runs instead of three per run (rows -> bias gradient ->
   // bias cells used to be dependent trips).
-  constexpr int NB = (WPW > 1) ? 4 : 2;       // one-hot windows: all 4 leaders of a sub-group at once
-  constexpr int RU = (WPW > 1) ? 4 : 8;       // further gradient rows of a run in flight
+  constexpr int NB = (WPW > 1) ? 4 : ARX_WIN_NB1;   // one-hot windows: all 4 leaders of a sub-group at once
+  constexpr int RU = (WPW > 1) ? 4 : ARX_WIN_RU1;   // further gradient rows of a run in flight
   for (int j0 = sgi; j0 < nlead; j0 += kStride * NB) {
     int li[NB], lrows[NB];
     bool lhead[NB], lcomp[NB];
@@ -429,13 +455,13 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
         const TabRow T = tab_of<MT>(ts, rkey);
         if (colok) {
           g0[j] = *reinterpret_cast<const float4*>(G + (int64_t)s_src[wv][i] * ldg + col);
-          if (lcomp[j]) {
+          if (!MERGE && lcomp[j]) {
             wrow[j] = *reinterpret_cast<const float4*>(T.E + (int64_t)T.row * d + col);
             if (!SGD) arow[j] = *reinterpret_cast<const float4*>(T.acc + (int64_t)T.row * d + col);
           }
         }
         if (Gb && lig < lrows[j]) gbv[j] = Gb[s_src[wv][i + lig]];
-        if (lcomp[j] && T.bias && lig == 0) {
+        if (!MERGE && lcomp[j] && T.bias && lig == 0) {
           bv[j] = T.bias[T.row];
           if (!SGD) bav[j] = T.bias_acc[T.row];
         }
@@ -474,7 +500,9 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) gb += __shfl_xor(gb, o, LPR);
       }
-      if (lcomp[j]) {
+      if (MERGE && lcomp[j]) {
+        merge_row(mo, d, rkey, w0 + i, col, colok, lig, a, gb);
+      } else if (lcomp[j]) {
         if (colok) {
           float4 gg = make_float4(a.x * gs, a.y * gs, a.z * gs, a.w * gs);
           float4 w4 = wrow[j];
@@ -550,14 +578,14 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
 //     dependent round trips instead of 2000;
 //   remaining blocks: one SUB-GROUP per SHORT run (head partial + <= 16 aligned partials,
 //     two round trips), grid-stride over the short list.
-template <int LPR, bool MT>
+template <int LPR, bool MT, bool MERGE = false>
 __global__ __launch_bounds__(1024) void k_sparse_finish(
     TableSet ts, int d, const uint32_t* __restrict__ sk, int64_t n_host,
     const int32_t* __restrict__ n_dev, const float* __restrict__ lr_dev, const float* __restrict__ gscale_dev,
     const float* __restrict__ scratch, const float* __restrict__ scratch_b,
     const float* __restrict__ scratch_h, const float* __restrict__ scratch_hb,
     const int32_t* __restrict__ list_long, const int32_t* __restrict__ list_short,
-    const int32_t* __restrict__ list_count, int nlong_blocks) {
+    const int32_t* __restrict__ list_count, int nlong_blocks, MergeOut mo) {
   constexpr int NSG = 1024 / LPR;
   __shared__ __attribute__((aligned(16))) float sh[NSG][LPR * 4];
   __shared__ float shb[NSG];
@@ -597,7 +625,9 @@ __global__ __launch_bounds__(1024) void k_sparse_finish(
             tb += vb[u];
           }
       }
-      {
+      if (MERGE) {
+        merge_row(mo, d, key, h, col, colok, lig, tot, tb);
+      } else {
         const TabRow T = tab_of<MT>(ts, key);
         adagrad_row(T.E, T.acc, T.bias, T.bias_acc, d, T.row, col, colok, lig, tot, tb, lr, gs);
       }
@@ -649,7 +679,9 @@ __global__ __launch_bounds__(1024) void k_sparse_finish(
         if (colok) t2 = f4_add2(t2, *reinterpret_cast<const float4*>(&sh[k][col]));
         t2b += shb[k];
       }
-      {
+      if (MERGE) {
+        merge_row(mo, d, key, h, col, colok, lig, t2, t2b);
+      } else {
         const TabRow T = tab_of<MT>(ts, key);
         adagrad_row(T.E, T.acc, T.bias, T.bias_acc, d, T.row, col, colok, lig, t2, t2b, lr, gs);
       }
@@ -1002,6 +1034,34 @@ __global__ __launch_bounds__(256) void k_merged_sq_norm(
   }
 }
 
+// Stage 1b of arx_sparse_adagrad_bags: the bag of every DISTINCT entity of the step, in padded
+// slots: sorted entity position p owns out[p * max_len .. + max_len); a run head writes its bag's
+// tokens (key = table row, src = p = row of the merged gradient Gu), every other slot holds
+// ARX_KEY_NONE, which the token sort's first pass drops.
+__global__ __launch_bounds__(256) void k_bag_expand_heads(
+    const uint32_t* __restrict__ sk, int64_t n_host, const int32_t* __restrict__ n_dev,
+    uint32_t sentinel, const int32_t* __restrict__ vals, const int32_t* __restrict__ starts,
+    const int32_t* __restrict__ lens, int max_len, int64_t table_rows,
+    int32_t* __restrict__ tkeys, int32_t* __restrict__ tsrc) {
+  const int64_t n = n_dev ? min((int64_t)*n_dev, n_host) : n_host;
+  const int64_t total = n_host * (int64_t)max_len;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = q / max_len;
+    const int j = (int)(q - p * max_len);
+    int32_t key = ARX_KEY_NONE;
+    if (p < n) {
+      const uint32_t e = sk[p];
+      if (e < sentinel && (p == 0 || sk[p - 1] != e) && j < lens[e]) {
+        const int32_t t = vals[(int64_t)starts[e] + j];
+        key = (t < 0 || t >= table_rows) ? ARX_KEY_NONE : t;
+      }
+    }
+    tkeys[q] = key;
+    tsrc[q] = (int32_t)p;
+  }
+}
+
 struct SparseWs {
   size_t off_keys_tmp, off_keys_out, off_pos_in, off_pos_out, off_list, off_count, off_scratch,
       off_scratch_b, off_scratch_h, off_scratch_hb, off_ssrc, off_scoef, off_hist, total;
@@ -1052,10 +1112,11 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
                         const float* gb_in, const float* lr_dev, const float* gscale_dev,
                         float* scratch, float* scratch_b, float* scratch_h, float* scratch_hb,
                         int32_t* list, int32_t* count, int wpw, bool multi,
-                        const int32_t* n_dev, hipStream_t s) {
+                        const int32_t* n_dev, hipStream_t s, const MergeOut* merge = nullptr) {
   const int32_t* cnt = ts.cnt[0];
   const int lpr = lanes_per_row(d);
-  if (cnt != nullptr && n <= kRankSortMax && n_dev == nullptr) {   // (radix-sorted input has a live count: window path)
+  const MergeOut mo = merge ? *merge : MergeOut{nullptr, nullptr, nullptr};
+  if (!merge && cnt != nullptr && n <= kRankSortMax && n_dev == nullptr) {   // (radix-sorted input has a live count: window path)
     // small batches (single-launch LDS rank sort regime): one sub-group per sorted position --
     // mostly-unique one-hot ids need the parallelism (80 windows would leave the chip idle);
     // every multi-piece run is finished by its last arriver, no second launch.
@@ -1082,7 +1143,7 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
   ARX_DISPATCH_LPR(lpr, (k_sparse_win<LPR, WPW_, MT_, SGD_><<<GRID_, THREADS_, 0, s>>>(             \
                             ts, d, sk, spos, ssrc, scoef, n, n_dev, sentinel, G, ldg, gb_in, lr_dev, \
                             gscale_dev, scratch, scratch_b, scratch_h, scratch_hb, list_long,       \
-                            list_short, count)))
+                            list_short, count, mo)))
 #define ARX_WIN_GO(WPW_, MT_, GRID_, THREADS_)                                              \
   do {                                                                                      \
     if (sgd) { ARX_WIN_GO2(WPW_, MT_, true, GRID_, THREADS_); }                             \
@@ -1092,7 +1153,12 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
   // single-row runs per window, a lone wave would walk them serially; 1: pre-expanded multi-hot
   // segments -- few long runs per window (C3 B=16384, 350 k live tokens: 77 us with 8, 54 with 4,
   // 52 with 1; the id pass 24 / 27 / 54); 4: callers that cannot tell.
-  if (wpw >= 8) {
+  if (merge) {   // entity-id runs: the one-hot window shape (many short runs per window)
+    ARX_DISPATCH_LPR(lpr, (k_sparse_win<LPR, 8, false, false, true><<<grid8, 512, 0, s>>>(
+                              ts, d, sk, spos, ssrc, scoef, n, n_dev, sentinel, G, ldg, gb_in, lr_dev,
+                              gscale_dev, scratch, scratch_b, scratch_h, scratch_hb, list_long,
+                              list_short, count, mo)));
+  } else if (wpw >= 8) {
     if (multi) { ARX_WIN_GO(8, true, grid8, 512); } else { ARX_WIN_GO(8, false, grid8, 512); }
   } else if (wpw >= 4) {
     if (multi) { ARX_WIN_GO(4, true, grid8, 256); } else { ARX_WIN_GO(4, false, grid8, 256); }
@@ -1109,14 +1175,18 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
     int64_t nshort = ceil_div(ceil_div(n, 64), nsg);                         // upper bound of short runs
     const int64_t cap = (int64_t)cu_count() * 2;
     if (nshort > cap) nshort = cap;
-    if (multi) {
+    if (merge) {
+      ARX_DISPATCH_LPR(lpr, (k_sparse_finish<LPR, false, true><<<(int)(nlong + nshort), 1024, 0, s>>>(
+                                ts, d, sk, n, n_dev, lr_dev, gscale_dev, scratch, scratch_b,
+                                scratch_h, scratch_hb, list_long, list_short, count, (int)nlong, mo)));
+    } else if (multi) {
       ARX_DISPATCH_LPR(lpr, (k_sparse_finish<LPR, true><<<(int)(nlong + nshort), 1024, 0, s>>>(
                                 ts, d, sk, n, n_dev, lr_dev, gscale_dev, scratch, scratch_b,
-                                scratch_h, scratch_hb, list_long, list_short, count, (int)nlong)));
+                                scratch_h, scratch_hb, list_long, list_short, count, (int)nlong, mo)));
     } else {
       ARX_DISPATCH_LPR(lpr, (k_sparse_finish<LPR, false><<<(int)(nlong + nshort), 1024, 0, s>>>(
                                 ts, d, sk, n, n_dev, lr_dev, gscale_dev, scratch, scratch_b,
-                                scratch_h, scratch_hb, list_long, list_short, count, (int)nlong)));
+                                scratch_h, scratch_hb, list_long, list_short, count, (int)nlong, mo)));
     }
     ARX_CHECK_LAUNCH();
   }
@@ -1334,6 +1404,180 @@ int arx_merged_sq_norm(const int32_t* keys, const int32_t* src, const float* coe
                                                     stepb_stride, out);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
+}
+
+// ---- multi-hot lookups: merge per entity first, then per token (see arx.h) ----
+namespace {
+struct BagWs {
+  SparseWs wi, wt;                        // sort / apply workspaces of the two stages
+  size_t off_wi, off_wt, off_ikeys, off_isrc, off_icoef, off_tkeys, off_tsrc, off_gu, off_gub, total;
+};
+int bag_ws_layout(int64_t n_i, int max_len, int d, BagWs* w) {
+  const int64_t n_t = n_i * (int64_t)max_len;
+  if (sparse_ws_layout(n_i, 256, &w->wi) != ARX_OK || sparse_ws_layout(n_t, 256, &w->wt) != ARX_OK)
+    return ARX_EINVAL;
+  size_t o = 0;
+  w->off_wi = o; o += align_up(w->wi.total, 256);
+  w->off_wt = o; o += align_up(w->wt.total, 256);
+  w->off_ikeys = o; o += align_up((size_t)n_i * 4, 256);
+  w->off_isrc = o; o += align_up((size_t)n_i * 4, 256);
+  w->off_icoef = o; o += align_up((size_t)n_i * 4, 256);
+  w->off_tkeys = o; o += align_up((size_t)n_t * 4, 256);
+  w->off_tsrc = o; o += align_up((size_t)n_t * 4, 256);
+  w->off_gu = o; o += align_up((size_t)n_i * (size_t)d * 4, 256);
+  w->off_gub = o; o += align_up((size_t)n_i * 4, 256);
+  w->total = o;
+  return ARX_OK;
+}
+}  // namespace
+
+size_t arx_sparse_adagrad_bags_workspace_bytes(int64_t n_lookups, int max_len, int d) {
+  BagWs w;
+  if (n_lookups <= 0 || max_len <= 0 || d <= 0) return 0;
+  if (bag_ws_layout(n_lookups, max_len, d, &w) != ARX_OK) return 0;
+  return w.total;
+}
+
+int arx_sparse_adagrad_bags(int phase, float* E, float* acc, float* bias, float* bias_acc,
+                            int64_t table_rows, int d, const int32_t* vals, const int32_t* starts,
+                            const int32_t* lens, int64_t n_entities, int max_len, int nsites,
+                            const int32_t* const* site_ids, const int64_t* site_n,
+                            const int32_t* site_row_base, const float* site_coef, const float* G,
+                            int64_t ldg, const float* Gb, const float* lr_dev, const float* gscale_dev,
+                            int32_t* aux_cnt, void* workspace, size_t workspace_bytes, void* stream) {
+  ARX_CHECK_ARG(phase == 1 || phase == 2 || phase == 3, "arx_sparse_adagrad_bags: phase 1, 2 or 3");
+  ARX_CHECK_ARG(E && vals && starts && lens && site_ids && site_n && site_row_base && site_coef && G &&
+                    lr_dev, "arx_sparse_adagrad_bags: null pointer");
+  ARX_CHECK_ARG(nsites > 0 && nsites <= kMaxSites, "arx_sparse_adagrad_bags: 1..8 lookup sites");
+  ARX_CHECK_ARG(acc ? (bias == nullptr) == (bias_acc == nullptr) : bias_acc == nullptr,
+                "arx_sparse_adagrad_bags: bias and bias_acc go together (acc == NULL: gradient descent)");
+  ARX_CHECK_ARG(!(bias && !Gb), "arx_sparse_adagrad_bags: bias table given without Gb");
+  ARX_CHECK_ARG(table_rows > 0 && n_entities > 0 && max_len > 0, "arx_sparse_adagrad_bags: bad sizes");
+  if (d <= 0 || d % 4 != 0 || d > 256) {
+    set_error("arx_sparse_adagrad_bags: d=%d unsupported (d %% 4 == 0, d <= 256)", d);
+    return ARX_EUNSUPPORTED;
+  }
+  ARX_CHECK_ARG(ldg % 4 == 0 && ldg >= d, "arx_sparse_adagrad_bags: ldg must be a multiple of 4 and >= d");
+  CatSites st;
+  st.nsites = nsites;
+  st.offs[0] = 0;
+  for (int q = 0; q < kMaxSites; ++q) {
+    const bool live = q < nsites;
+    st.cat_map[q] = nullptr;                      // key = the entity id itself
+    st.ids[q] = live ? site_ids[q] : nullptr;
+    st.row_base[q] = live ? site_row_base[q] : 0;
+    st.coef[q] = live ? site_coef[q] : 0.f;
+    st.table[q] = 0;
+    st.offs[q + 1] = st.offs[q] + (live ? site_n[q] : 0);
+    if (live) ARX_CHECK_ARG(site_n[q] >= 0 && (site_ids[q] || site_n[q] == 0), "arx_sparse_adagrad_bags: bad site");
+  }
+  for (int t = 0; t < kMaxTables; ++t) st.rows[t] = n_entities;
+  int kbi = 1;
+  while ((1ll << kbi) < n_entities && kbi < 30) ++kbi;
+  int kbt = 1;
+  while ((1ll << kbt) < table_rows && kbt < 30) ++kbt;
+  st.kb = kbi;
+  st.nextra = 0;
+  st.xoffs[0] = 0;
+  const int64_t n_i = st.offs[nsites];
+  if (n_i == 0) return ARX_OK;
+  const int64_t n_t = n_i * (int64_t)max_len;
+  ARX_CHECK_ARG(n_t < (int64_t)0x7fffffff, "arx_sparse_adagrad_bags: too many bag slots");
+  BagWs w;
+  if (bag_ws_layout(n_i, max_len, d, &w) != ARX_OK) {
+    set_error("arx_sparse_adagrad_bags: workspace layout failed");
+    return ARX_EINVAL;
+  }
+  if (!workspace || workspace_bytes < w.total) {
+    set_error("arx_sparse_adagrad_bags: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+    return ARX_EWORKSPACE;
+  }
+  hipStream_t s = as_stream(stream);
+  char* base = reinterpret_cast<char*>(workspace);
+  char* bi = base + w.off_wi;
+  char* bt = base + w.off_wt;
+  int32_t* ikeys = reinterpret_cast<int32_t*>(base + w.off_ikeys);
+  int32_t* isrc = reinterpret_cast<int32_t*>(base + w.off_isrc);
+  float* icoef = reinterpret_cast<float*>(base + w.off_icoef);
+  int32_t* tkeys = reinterpret_cast<int32_t*>(base + w.off_tkeys);
+  int32_t* tsrc = reinterpret_cast<int32_t*>(base + w.off_tsrc);
+  float* Gu = reinterpret_cast<float*>(base + w.off_gu);
+  float* Gub = reinterpret_cast<float*>(base + w.off_gub);
+  const uint32_t sent_i = 1u << kbi, sent_t = 1u << kbt;
+  uint32_t* sk_i = reinterpret_cast<uint32_t*>(bi + w.wi.off_keys_out);
+  int32_t* ssrc_i = reinterpret_cast<int32_t*>(bi + w.wi.off_ssrc);
+  float* scoef_i = reinterpret_cast<float*>(bi + w.wi.off_scoef);
+  int32_t* count_i = reinterpret_cast<int32_t*>(bi + w.wi.off_count);
+  uint32_t* sk_t = reinterpret_cast<uint32_t*>(bt + w.wt.off_keys_out);
+  int32_t* ssrc_t = reinterpret_cast<int32_t*>(bt + w.wt.off_ssrc);
+  float* scoef_t = reinterpret_cast<float*>(bt + w.wt.off_scoef);
+  int32_t* count_t = reinterpret_cast<int32_t*>(bt + w.wt.off_count);
+  const bool rank_i = n_i <= kRankSortMax, rank_t = n_t <= kRankSortMax;
+  const int32_t* ndev_i = rank_i ? nullptr : count_i + 2;
+  const int32_t* ndev_t = rank_t ? nullptr : count_t + 2;
+  int rc;
+  if (phase & 1) {
+    // ---- stage 1a: (entity, gradient row, coef) of every lookup, sorted by entity ----
+    k_site_keys<<<(int)ceil_div(n_i, 256), 256, 0, s>>>(st, ikeys, isrc, icoef);
+    ARX_CHECK_LAUNCH();
+    if (rank_i)
+      rc = launch_rank_sort(ikeys, n_i, sent_i, sk_i, reinterpret_cast<uint32_t*>(bi + w.wi.off_pos_out),
+                            count_i, s, isrc, icoef, ssrc_i, scoef_i);
+    else
+      rc = launch_radix_sort(ikeys, isrc, icoef, n_i, sent_i, kbi + 1,
+                             reinterpret_cast<uint32_t*>(bi + w.wi.off_keys_tmp), sk_i,
+                             reinterpret_cast<int32_t*>(bi + w.wi.off_pos_in), ssrc_i,
+                             reinterpret_cast<float*>(bi + w.wi.off_pos_out), scoef_i,
+                             reinterpret_cast<int32_t*>(bi + w.wi.off_hist), count_i, count_i + 2, s);
+    if (rc) return rc;
+    // ---- stage 1b: bags of the DISTINCT entities, sorted by token ----
+    {
+      int64_t g = ceil_div(n_t, 256);
+      const int64_t cap = (int64_t)cu_count() * 16;
+      if (g > cap) g = cap;
+      k_bag_expand_heads<<<(int)g, 256, 0, s>>>(sk_i, n_i, ndev_i, sent_i, vals, starts, lens, max_len,
+                                                table_rows, tkeys, tsrc);
+      ARX_CHECK_LAUNCH();
+    }
+    if (rank_t)
+      rc = launch_rank_sort(tkeys, n_t, sent_t, sk_t, reinterpret_cast<uint32_t*>(bt + w.wt.off_pos_out),
+                            count_t, s, tsrc, nullptr, ssrc_t, scoef_t);
+    else
+      rc = launch_radix_sort(tkeys, tsrc, nullptr, n_t, sent_t, kbt + 1,
+                             reinterpret_cast<uint32_t*>(bt + w.wt.off_keys_tmp), sk_t,
+                             reinterpret_cast<int32_t*>(bt + w.wt.off_pos_in), ssrc_t,
+                             reinterpret_cast<float*>(bt + w.wt.off_pos_out), scoef_t,
+                             reinterpret_cast<int32_t*>(bt + w.wt.off_hist), count_t, count_t + 2, s);
+    if (rc) return rc;
+  }
+  if (!(phase & 2)) return ARX_OK;
+  // ---- stage 2a: one merged, 1/len-scaled gradient row per distinct entity ----
+  {
+    TableSet none = {};
+    none.kb = kbi;
+    MergeOut mo = {Gu, bias ? Gub : nullptr, lens};
+    rc = launch_apply(none, d, sk_i, nullptr, ssrc_i, scoef_i, n_i, sent_i, G, ldg, bias ? Gb : nullptr,
+                      lr_dev, gscale_dev, reinterpret_cast<float*>(bi + w.wi.off_scratch),
+                      reinterpret_cast<float*>(bi + w.wi.off_scratch_b),
+                      reinterpret_cast<float*>(bi + w.wi.off_scratch_h),
+                      reinterpret_cast<float*>(bi + w.wi.off_scratch_hb),
+                      reinterpret_cast<int32_t*>(bi + w.wi.off_list), count_i, 8, false, ndev_i, s, &mo);
+    if (rc) return rc;
+  }
+  // ---- stage 2b: token runs over the merged rows (every coefficient is 1) -> Adagrad ----
+  TableSet ts = {};
+  ts.E[0] = E;
+  ts.acc[0] = acc;
+  ts.bias[0] = bias;
+  ts.bias_acc[0] = bias_acc;
+  ts.cnt[0] = rank_t ? aux_cnt : nullptr;
+  ts.kb = kbt;
+  return launch_apply(ts, d, sk_t, nullptr, ssrc_t, nullptr, n_t, sent_t, Gu, d, bias ? Gub : nullptr, lr_dev,
+                      gscale_dev, reinterpret_cast<float*>(bt + w.wt.off_scratch),
+                      reinterpret_cast<float*>(bt + w.wt.off_scratch_b),
+                      reinterpret_cast<float*>(bt + w.wt.off_scratch_h),
+                      reinterpret_cast<float*>(bt + w.wt.off_scratch_hb),
+                      reinterpret_cast<int32_t*>(bt + w.wt.off_list), count_t, 1, false, ndev_t, s);
 }
 
 int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const float* lr_dev,

@@ -370,6 +370,31 @@ int arx_sparse_adagrad_cat_multi_phase(int phase, int ntables, float* const* E, 
                                        const int32_t* extra_table, void* workspace,
                                        size_t workspace_bytes, void* stream);
 
+/* Multi-hot lookups of ONE table (embed_attribute.py:397-406: embedding_lookup of the bag
+ * tokens + unsorted_segment_sum / length; hmf_model.py:146-151 one Adagrad apply per variable),
+ * in two merge stages so that an entity that occurs k times in a step (Zipf-popular target
+ * items; a target that is also in the pool) costs its bag ONCE:
+ *   1. the lookups of all sites (site s: ids site_ids[s][0..site_n[s]), gradient rows
+ *      G[site_row_base[s] + j], factor site_coef[s]) are sorted by ENTITY id; every distinct
+ *      entity e gets one merged row Gu = (1/lens[e]) * sum coef * G[row]  (bias gradients alike);
+ *   2. only the distinct entities' bags (vals[starts[e] .. + lens[e])) are expanded, sorted by
+ *      token row and summed per row from Gu (all coefficients 1) -> ONE Adagrad update per
+ *      touched row (acc == NULL: gradient descent).
+ * Deterministic (stable sorts, fixed-order sums, no float atomics).  n_entities = rows of
+ * lens (ids outside [0, n_entities) and tokens outside [0, table_rows) are dropped); max_len >=
+ * every bag length.  phase 1 = everything that depends on the ids only (both sorts), phase 2 =
+ * merge + apply (needs G), 3 = both; same workspace for both halves, untouched in between,
+ * >= arx_sparse_adagrad_bags_workspace_bytes(sum(site_n), max_len, d).  aux_cnt: int32[table_rows]
+ * zeros or NULL (only used when sum(site_n) * max_len <= 8192). */
+size_t arx_sparse_adagrad_bags_workspace_bytes(int64_t n_lookups, int max_len, int d);
+int arx_sparse_adagrad_bags(int phase, float* E, float* acc, float* bias, float* bias_acc,
+                            int64_t table_rows, int d, const int32_t* vals, const int32_t* starts,
+                            const int32_t* lens, int64_t n_entities, int max_len, int nsites,
+                            const int32_t* const* site_ids, const int64_t* site_n,
+                            const int32_t* site_row_base, const float* site_coef, const float* G,
+                            int64_t ldg, const float* Gb, const float* lr_dev, const float* gscale_dev,
+                            int32_t* aux_cnt, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- a16/a19: dense Adagrad, norms, clip ---------------------------------
  * tf.train.AdagradOptimizer dense apply; tf.clip_by_global_norm
  * (seqModel.py:180): coef = max_norm / max(sqrt(sq), max_norm). */

@@ -112,3 +112,51 @@ def test_evaluation_harness_matches_reference(tmp_path):
     users = np.array([[1], [2], [3]], dtype=object)
     assert combine_sub({1: ['a', 'b']}, {1: ['b', 'c'], 2: ['x', 'x']}, 0, users) == {1: ['a', 'b', 'c'], 2: ['x']}
     assert combine_sub({1: ['a', 'b']}, {1: ['b', 'c'], 2: ['x']}, 1, users) == {1: ['c'], 2: ['x']}
+
+
+class _Batcher(object):
+    """SeqBatching needs only these attributes (the GPU model supplies them in production)."""
+
+    def __init__(self, buckets, batch_size, start_id, pad_id, user_pad=0):
+        from arx.lstm.batching import SeqBatching
+        self.__class__ = type('B', (SeqBatching,), {})
+        self.buckets, self.batch_size = buckets, batch_size
+        self.START_ID, self.PAD_ID, self.USER_PAD_ID = start_id, pad_id, user_pad
+
+
+def test_seq_get_batch_and_get_batch_recommend_known_answers():
+    """lstm/seqModel.py:356-452 (TensorFlow module, not importable): hand-computed batches.
+    Bucket of length 4, batch of 3, two real examples then padding; START = PAD = 99."""
+    b = _Batcher([4], 3, 99, 99)
+    data = [[(7, [11, 12, 13]), (8, [21])]]
+    users, inp, tgt, w, fin = b.get_batch(data, 0, start_id=0)
+    assert users == [7, 8, 0] and fin is True
+    # per example: [START, s0, s1, PAD] / [START, PAD, PAD, PAD] / empty slot -> START + PAD; time-major
+    assert inp == [[99, 99, 99], [11, 99, 99], [12, 99, 99], [99, 99, 99]]
+    assert tgt == [[11, 21, 99], [12, 99, 99], [13, 99, 99], [99, 99, 99]]
+    assert w == [[1.0, 1.0, 0.0], [1.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 0.0]]
+    users, inp, pos, valid, fin = b.get_batch_recommend(data, 0, start_id=0)
+    assert users == [7, 8, 0] and pos == [2, 0, 3] and valid == [1, 1, 0] and fin is True
+    assert inp == [[11, 21, 99], [12, 99, 99], [13, 99, 99], [99, 99, 99]]
+    # not finished while examples remain; random draws come from the bucket, one per slot
+    b2 = _Batcher([2, 4], 1, 5, 5)
+    data2 = [[(1, [3])], [(2, [4, 6, 8]), (3, [9, 9, 9, 9])]]
+    assert b2.get_batch(data2, 1, start_id=0)[4] is False and b2.get_batch(data2, 1, start_id=1)[4] is True
+    import random
+    random.seed(3)
+    picks = [random.choice(data2[1]) for _ in range(4)]
+    random.seed(3)
+    for p in picks:
+        users, inp, pos, valid, fin = b2.get_batch_recommend(data2, 1)
+        assert users == [p[0]] and pos == [len(p[1]) - 1] and valid == [1] and fin is False
+
+
+def test_lstm_iterator_recommend_sweep_through_batching():
+    """DataIterator.next_sequence(recommend=True) over the real batching (the
+    iterator called a method the model did not have)."""
+    from arx.lstm.data_iterator import DataIterator
+    b = _Batcher([3], 2, 1, 0)
+    data = [[(5, [2, 3]), (6, [4]), (7, [8, 9, 10])]]
+    got = list(DataIterator(b, data, 1, 2, [1.0]).next_sequence(stop=True, recommend=True))
+    assert [g[0] for g in got] == [[5, 6], [7, 0]]
+    assert [g[2] for g in got] == [[1, 0], [2, 2]] and [g[3] for g in got] == [[1, 1], [1, 0]]

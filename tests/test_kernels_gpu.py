@@ -923,3 +923,75 @@ def test_merged_sq_norm(dev, n, rows, d, L):
     M = np.zeros((rows, d))
     np.add.at(M, keys[~pads], coef[~pads, None].astype(np.float64) * X[0][src[~pads]])
     np.testing.assert_allclose(float(out.item()), (M ** 2).sum(), rtol=2e-5)
+
+
+@pytest.mark.parametrize("d,n_ent,Vf,max_len,ns,phases", [
+    (128, 3000, 400, 12, (4096, 1024), (3,)),        # radix both stages, Zipf duplicates, shared tokens
+    (32, 50, 30, 5, (300, 17), (1, 2)),              # rank-sorted entities, radix tokens, two halves
+    (64, 200, 5000, 3, (64,), (3,)),                 # everything below the rank-sort limit
+    (128, 40000, 100002, 64, (20000, 1024), (1, 2)), # C3-like shape
+    (16, 10, 8, 64, (9000, 0, 5), (3,)),             # few entities: runs of thousands, an empty site
+])
+def test_sparse_adagrad_bags(dev, d, n_ent, Vf, max_len, ns, phases):
+    """arx_sparse_adagrad_bags (merge per entity, then per token) == the plain contribution-level
+    sum: g[tok] = sum over lookups r, tokens k of bag(id_r): coef_s / len * G[row_r]."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(d + n_ent + max_len)
+    vals, starts, lens = _csr(rng, n_ent, Vf, max_len, zipf=True)
+    vals[rng.integers(0, len(vals), size=3)] = Vf + 5          # out-of-range tokens are dropped
+    E = rng.standard_normal((Vf, d)).astype(np.float32)
+    acc = (0.1 + rng.random((Vf, d))).astype(np.float32)
+    bias = rng.standard_normal((Vf,)).astype(np.float32)
+    bacc = np.full((Vf,), 0.1, dtype=np.float32)
+    m = sum(ns) + 7
+    G = rng.standard_normal((m, d)).astype(np.float32)
+    Gb = rng.standard_normal((m,)).astype(np.float32)
+    p = 1.0 / np.arange(1, n_ent + 1) ** 1.05
+    p /= p.sum()
+    sites, keys, src, coef = [], [], [], []
+    row0 = 3
+    for s_i, n in enumerate(ns):
+        ids = rng.choice(n_ent, size=n, p=p).astype(np.int32)
+        if n > 4:
+            ids[:2] = [n_ent + 3, -1]                          # invalid entity ids are dropped
+        c = 0.5 / (s_i + 1)
+        sites.append((ids, row0, c))
+        for j, e in enumerate(ids):
+            if 0 <= e < n_ent:
+                for t in vals[starts[e]:starts[e] + lens[e]]:
+                    if 0 <= t < Vf:
+                        keys.append(t); src.append(row0 + j); coef.append(c / lens[e])
+        row0 += n
+    lr, gs = 0.3, 0.7
+    rE, racc, rb, rbacc = _ref_sparse_adagrad(E, acc, bias, bacc, np.array(keys, dtype=np.int64),
+                                              np.array(src, dtype=np.int64), np.array(coef), G, Gb, lr, gs)
+    lr_dev = torch.tensor([lr], dtype=torch.float32, device=dev)
+    gs_dev = torch.tensor([gs], dtype=torch.float32, device=dev)
+    tv, tst, tl = _t(dev, vals), _t(dev, starts), _t(dev, lens)
+    tG, tGb = _t(dev, G), _t(dev, Gb)
+    outs = []
+    for rep in range(2):
+        tE, tacc, tb, tbacc = _t(dev, E), _t(dev, acc), _t(dev, bias), _t(dev, bacc)
+        args = ops.BagSiteArgs([(_t(dev, ids), r0, c) for ids, r0, c in sites], max_len)
+        ws = ops.Workspace(dev)
+        cnt = torch.zeros(Vf, dtype=torch.int32, device=dev)
+        for ph in phases:
+            ops.sparse_adagrad_bags(tE, tacc, tb, tbacc, tv, tst, tl, args, tG, tGb, lr_dev, ws,
+                                    gscale_dev=gs_dev, phase=ph, aux_cnt=cnt)
+        torch.cuda.synchronize()
+        outs.append((tE, tacc, tb, tbacc))
+        assert int(cnt.abs().sum().item()) == 0
+    tE, tacc, tb, tbacc = outs[0]
+    np.testing.assert_allclose(tacc.cpu().numpy(), racc, rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(tE.cpu().numpy(), rE, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(tbacc.cpu().numpy(), rbacc, rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(tb.cpu().numpy(), rb, rtol=2e-4, atol=2e-5)
+    for a, b in zip(outs[0], outs[1]):                 # bit-reproducible
+        assert torch.equal(a, b)
+    # no bias: the bias side is optional
+    tE, tacc = _t(dev, E), _t(dev, acc)
+    args = ops.BagSiteArgs([(_t(dev, ids), r0, c) for ids, r0, c in sites], max_len)
+    ops.sparse_adagrad_bags(tE, tacc, None, None, tv, tst, tl, args, tG, None, lr_dev, ops.Workspace(dev),
+                            gscale_dev=gs_dev)
+    np.testing.assert_allclose(tE.cpu().numpy(), rE, rtol=2e-4, atol=2e-5)

@@ -13,7 +13,7 @@ RTOL = 1e-4
 
 
 def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False, use_concat=False, num_layers=1,
-           keep=1.0, adagrad=True):
+           keep=1.0, adagrad=True, buckets=None):
     from arx.attributes.embed_attribute import EmbeddingAttribute
     from arx.lstm.seqModel import SeqModel
     from arx.utils.synthetic import SyntheticHMF
@@ -39,7 +39,7 @@ def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False, use_concat=Fa
     l2i = syn.logit_ind2item_ind
     n_s = S if loss == 'mw' else None
     emb = EmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i, params=params)
-    model = SeqModel([L], size, num_layers, clip, B, 0.5, 0.83, emb, loss=loss, use_concat=use_concat,
+    model = SeqModel(buckets or [L], size, num_layers, clip, B, 0.5, 0.83, emb, loss=loss, use_concat=use_concat,
                      no_user_id=no_user_id, START_ID=START, params=params, dropoutRate=keep,
                      withAdagrad=adagrad)
     remb = rg.RefEmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i,
@@ -283,3 +283,27 @@ def test_seq_gradient_descent_optimizer(dev, cfg, loss, S):
         _compare(emb, model, remb, ref)
     for k, v in emb.get_slots().items():           # no optimizer slots are touched
         assert np.array_equal(v, slots0[k]), k
+
+
+@pytest.mark.parametrize("cfg,use_graph", [(CFG_ID, True), (CFG_HET, True), (CFG_HET, False)])
+def test_seq_two_buckets_interleaved(dev, cfg, use_graph):
+    """Two buckets (lstm/run.py takes several from best_buckets) trained in interleaved order: the
+    pool lookup and the user lookup are shared by both buckets' train plans, whose gradient arenas
+    differ in size -- every plan must write / read its OWN arena (eager run, capture and replay)."""
+    size, B, S, Ls = 64, 16, 64, [3, 6]
+    syn, emb, model, remb, ref = _build(cfg, 'mw', size, B, Ls[-1], S, 5.0, seed=41, buckets=Ls)
+    emb.rt.use_graph = use_graph
+    rng = np.random.default_rng(43)
+    pool = syn.sample_pool(S, rng)
+    id2idx = {int(v): i for i, v in enumerate(pool)}
+    for step, bk in enumerate([0, 1, 0, 1, 1, 0, 0, 1]):
+        L = Ls[bk]
+        users, inp, tg, w = _batch(syn, rng, L, B)
+        ps = pool if step == 0 else None
+        ref.L = L                                   # the oracle unrolls as many steps as it is fed
+        l_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), ps, id2idx)
+        l_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), bk, ps, id2idx)
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='loss step %d (bucket %d)' % (step, bk))
+        np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL,
+                                   err_msg='global norm step %d' % step)
+        _compare(emb, model, remb, ref)
