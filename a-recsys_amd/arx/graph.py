@@ -820,10 +820,17 @@ class Plan(object):
         C4, 103 k: 909 -> 895 us; C3 B=4096, ~118 k: 215 -> 192 us) on a step that is GPU-bound at
         all."""
         cap = int(os.environ.get('ARX_K7_EARLY_MAX', '125000'))
+        # a two-stage multi-hot pass has ~100 us of sorts per step (two sorts, the second over the
+        # padded bag slots) that would otherwise sit on the critical path: worth the CUs they take
+        # from the GEMMs far beyond that size (C3 B=16384, ~220 k: 474 -> 404 us)
+        cap_bags = int(os.environ.get('ARX_K7_EARLY_MAX_BAGS', '1500000'))
         # tiny steps are bound by the host-side cost of a graph launch, and a graph with a second
         # branch costs more to launch (C1, B=64: 75 -> 103 us per step with the branch)
         lo = int(os.environ.get('ARX_K7_EARLY_MIN', '8192'))
-        ok = jobs and len(jobs) == n_passes and lo <= sum(j[3] for j in jobs) <= cap
+        n_bags = sum(j[3] for j in jobs if j[0] == 'bags')
+        n_hot = sum(j[3] for j in jobs if j[0] != 'bags')
+        ok = (jobs and len(jobs) == n_passes and lo <= n_bags + n_hot and n_hot <= cap
+              and n_bags <= cap_bags)
         self._early_jobs = [j[:3] for j in jobs] if ok else []
 
     def _cat_pass(self, entry, key, phase):

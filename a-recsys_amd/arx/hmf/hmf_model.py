@@ -186,10 +186,17 @@ class LatentProductModel(object):
                  item_ind2logit_ind=None, logit_ind2item_ind=None, loss_function='ce', GPU=None,
                  logit_size_test=None, nonlinear=None, dropout=1.0, n_sampled=None,
                  indices_item=None, dtype='float32', top_N_items=100, hidden_size=500,
-                 loss_func='log', loss_exp_p=1.005, params=None, use_graph=True, seed=0):
+                 loss_func='log', loss_exp_p=1.005, params=None, use_graph=True, seed=0,
+                 mw_eval_unmasked=False):
         self.user_size = user_size
         self.item_size = item_size
         self.top_N_items = top_N_items
+        # 'mw' models evaluate with the full-vocabulary 'warp' loss (:130,144).  The reference's
+        # step() only runs set_mask['mw'] (:209-210), so ITS eval loss sees an all-True warp mask
+        # (the target column itself adds relu(0 + 1) = 1 inside the log).  Default here: the user's
+        # eval positives ARE masked (what the masks are for); mw_eval_unmasked=True reproduces the
+        # reference's unmasked number for parity comparisons.
+        self.mw_eval_unmasked = bool(mw_eval_unmasked)
         if user_attributes is not None:
             user_attributes.set_model_size(size)             # hmf_model.py:34-36
             self.user_attributes = user_attributes
@@ -263,7 +270,11 @@ class LatentProductModel(object):
             batch_loss, _ = m.compute_loss(logits, self.item_target, loss)
         elif loss == 'mw':
             batch_loss = m.compute_loss(sampled_logits, target_score, loss)
-            batch_loss_eval = m.compute_loss(logits, self.item_target, 'warp')  # :130
+            if self.mw_eval_unmasked:
+                batch_loss_eval = G.BatchLoss(rt, 'warp', logits, self.item_target, mask=None,
+                                              mask_rows=batch_size)
+            else:
+                batch_loss_eval = m.compute_loss(logits, self.item_target, 'warp')  # :130
         else:
             raise NotImplementedError("not implemented!")
         if loss in ('warp', 'warp_eval', 'mw', 'rs', 'rs-sig', 'rs-sig2', 'bbpr'):   # :137

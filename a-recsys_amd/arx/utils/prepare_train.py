@@ -7,42 +7,40 @@ import numpy as np
 
 
 def sample_items(items, n, p=None, replace=False):
-    """prepare_train.py:7-17 -- np.random.choice(items, n, replace, p) + id->slot dict."""
-    if p is not None and len(p):
-        item_sampled = np.random.choice(items, n, replace=replace, p=p)
-    else:
-        item_sampled = np.random.choice(items, n, replace=replace)
-    item_sampled_id2idx = {}
-    for i, item in enumerate(item_sampled):
-        item_sampled_id2idx[item] = i
-    return item_sampled, item_sampled_id2idx
+    """prepare_train.py:7-17: draw the step's shared negative pool with numpy's legacy global
+    stream (np.random.choice -- the goldens pin the exact ids for a given np.random.seed) and
+    return it with its id -> pool-slot dictionary (later duplicates win, as in the reference)."""
+    weights = p if (p is not None and len(p)) else None
+    pool = np.random.choice(items, n, replace=replace, p=weights)
+    return pool, {item: slot for slot, item in enumerate(pool)}
 
 
 def item_frequency(data_tr, power):
-    """prepare_train.py:19-35 -- p(item) ~ (count / total)^power, normalised."""
-    item_counts = {}
-    item_population = set([])
+    """prepare_train.py:19-35: the sampler's distribution p(item) ~ (count / total) ** power over the
+    items seen in training, normalised.  Returns (item_population, p_item) in the iteration
+    order of a Python set of the item ids (that order is part of the reference's behaviour:
+    sample_items indexes into it).  The float arithmetic keeps the reference's operation order
+    (per-item power of count/total, left-to-right sum, per-item divide) so that the goldens
+    match bit for bit."""
+    seen = {}
     for rec in data_tr:
-        i = rec[1]
-        item_counts[i] = 1 if i not in item_counts else item_counts[i] + 1
-        item_population.add(i)
-    item_population = list(item_population)
-    counts = [item_counts[v] for v in item_population]
-    count_sum = sum(counts) * 1.0
-    p_item_unormalized = [np.power(c / count_sum, power) for c in counts]
-    p_item_sum = sum(p_item_unormalized)
-    p_item = [f / p_item_sum for f in p_item_unormalized]
-    return item_population, p_item
+        seen[rec[1]] = seen.get(rec[1], 0) + 1
+    item_population = list(set(seen))
+    total = float(sum(seen[i] for i in item_population))
+    raw = [np.power(seen[i] / total, power) for i in item_population]
+    norm = sum(raw)
+    return item_population, [w / norm for w in raw]
 
 
 def positive_items(data_tr, data_va):
-    """prepare_train.py:37-57 -- {user: [items]} for train and validation."""
-    hist, hist_va = {}, {}
-    for rec in data_tr:
-        hist.setdefault(rec[0], set()).add(rec[1])
-    for rec in data_va:
-        hist_va.setdefault(rec[0], set()).add(rec[1])
-    return ({u: list(s) for u, s in hist.items()}, {u: list(s) for u, s in hist_va.items()})
+    """prepare_train.py:37-57: {user: [distinct items]} of the training and of the validation
+    interactions (the sets the loss masks take out of the negatives)."""
+    def by_user(records):
+        sets = {}
+        for rec in records:
+            sets.setdefault(rec[0], set()).add(rec[1])
+        return {user: list(items) for user, items in sets.items()}
+    return by_user(data_tr), by_user(data_va)
 
 
 class DeviceSampler(object):

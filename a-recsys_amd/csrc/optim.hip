@@ -992,12 +992,14 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // each unrolled step (seqModel.py:180; embed_attribute.py:171,188: innerp = E . u^T is taken
 // over the WHOLE table and gathered afterwards, so pool items that share a row are summed
 // before the norm).  One sub-group of GS lanes per run head; Xb is the d = 1 bias analogue.
+static __device__ unsigned int g_merged_ticket;
+
 template <int GS>
 __global__ __launch_bounds__(256) void k_merged_sq_norm(
     const uint32_t* __restrict__ sk, const int32_t* __restrict__ ssrc, const float* __restrict__ scoef,
     int64_t n_host, const int32_t* __restrict__ n_dev, uint32_t sentinel, const float* __restrict__ X,
     int64_t ldx, int d, int L, int64_t step_stride, const float* __restrict__ Xb, int Lb,
-    int64_t stepb_stride, float* __restrict__ out) {
+    int64_t stepb_stride, float* __restrict__ bpart, unsigned int* ticket, float* __restrict__ out) {
   const int64_t n = n_dev ? min((int64_t)*n_dev, n_host) : n_host;
   const int lane = threadIdx.x % GS;
   const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GS;
@@ -1026,11 +1028,32 @@ __global__ __launch_bounds__(256) void k_merged_sq_norm(
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
   __shared__ float part[4];
+  __shared__ bool s_last;
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = tot;
   __syncthreads();
+  // fixed-slot block partials, summed in slot order by the block that arrives last (same scheme
+  // as k_sq_norm): no float atomics, so the clip norm is bit-reproducible
   if (threadIdx.x == 0) {
-    const float v = part[0] + part[1] + part[2] + part[3];
-    if (v != 0.f) atomicAdd(out, v);
+    const float v = (part[0] + part[1]) + (part[2] + part[3]);
+    __hip_atomic_store(&bpart[blockIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+              gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x < 64) {
+    float t = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 64)
+      t += __hip_atomic_load(&bpart[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (threadIdx.x == 0) {
+      *out += t;
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -1399,9 +1422,13 @@ int arx_merged_sq_norm(const int32_t* keys, const int32_t* src, const float* coe
   constexpr int GS = 16;
   const int64_t blocks = ceil_div(n * GS, (int64_t)256);
   ARX_CHECK_ARG(blocks < (int64_t)0x7fffffff, "arx_merged_sq_norm: n too large");
+  // block partials: the apply pass's scratch rows are free here (>= 4 * n bytes >= 4 * blocks)
+  float* bpart = reinterpret_cast<float*>(base + w.off_scratch);
+  unsigned int* ticket = nullptr;
+  ARX_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ticket), HIP_SYMBOL(g_merged_ticket)));
   k_merged_sq_norm<GS><<<(int)blocks, 256, 0, s>>>(keys_out, ssrc, scoef, n, n_dev, sentinel, X, ldx,
                                                     X ? d : 0, X ? L : 0, step_stride, Xb, Xb ? Lb : 0,
-                                                    stepb_stride, out);
+                                                    stepb_stride, bpart, ticket, out);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

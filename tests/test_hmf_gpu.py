@@ -291,3 +291,32 @@ def test_hmf_mlp_dropout_replayed_through_oracle(dev, nonlinear):
     e_ref = ref.step(list(users), list(items), forward_only=True, loss='mw')
     e_got = model.step(None, list(users), list(items), forward_only=True, loss='mw')
     np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
+
+
+def test_hmf_mw_eval_unmasked_switch(dev):
+    """mw_eval_unmasked=True: the evaluation loss of an 'mw' model is the full-vocabulary warp
+    loss with an all-True mask -- what the reference reports, because its step() only runs
+    set_mask['mw'] (hmf_model.py:209-210) -- checked against numpy on the model's own logits."""
+    from arx.utils.synthetic import SyntheticHMF
+    from arx.hmf.hmf_model import LatentProductModel
+    d, B, S = 32, 64, 128
+    syn = SyntheticHMF(seed=3, **CFG_ID)
+    params = syn.glorot_params(d, seed=4, scale=0.5)
+    i2l, l2i = syn.item_ind2logit_ind_dict(), syn.logit_ind2item_ind
+    losses = {}
+    for unmasked in (True, False):
+        model = LatentProductModel(syn.n_users, syn.n_items, d, 1, B, 0.5, 1.0, syn.u_attr, syn.i_attr,
+                                   i2l, l2i, loss_function='mw', n_sampled=S, params=params,
+                                   mw_eval_unmasked=unmasked)
+        pos = syn.positives_dict()
+        model.prepare_warp(pos, pos)
+        rng = np.random.default_rng(5)
+        users, items = syn.sample_batch(B, rng)
+        losses[unmasked] = model.step(None, list(users), list(items), forward_only=True, loss='mw')
+        if unmasked:
+            x = model.output.value.cpu().numpy().astype(np.float64)
+            tcol = np.array([i2l[int(i)] for i in items])
+            t = x[np.arange(B), tcol]
+            want = np.log1p(np.maximum(x - t[:, None] + 1.0, 0.0).sum(1)).mean()
+            np.testing.assert_allclose(losses[True], want, rtol=RTOL)
+    assert losses[True] > losses[False]            # the masked form drops the positives' hinge terms

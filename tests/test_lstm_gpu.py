@@ -285,14 +285,16 @@ def test_seq_gradient_descent_optimizer(dev, cfg, loss, S):
         assert np.array_equal(v, slots0[k]), k
 
 
-@pytest.mark.parametrize("cfg,use_graph", [(CFG_ID, True), (CFG_HET, True), (CFG_HET, False)])
-def test_seq_two_buckets_interleaved(dev, cfg, use_graph):
+@pytest.mark.parametrize("cfg", [CFG_ID, CFG_HET])
+def test_seq_two_buckets_interleaved(dev, cfg):
     """Two buckets (lstm/run.py takes several from best_buckets) trained in interleaved order: the
     pool lookup and the user lookup are shared by both buckets' train plans, whose gradient arenas
-    differ in size -- every plan must write / read its OWN arena (eager run, capture and replay)."""
+    differ in size -- every plan must write / read its OWN arena (eager run, capture and replay).
+    Checked against the oracle AND graph-replayed == eager, bit for bit."""
     size, B, S, Ls = 64, 16, 64, [3, 6]
     syn, emb, model, remb, ref = _build(cfg, 'mw', size, B, Ls[-1], S, 5.0, seed=41, buckets=Ls)
-    emb.rt.use_graph = use_graph
+    _, emb_e, model_e, _, _ = _build(cfg, 'mw', size, B, Ls[-1], S, 5.0, seed=41, buckets=Ls)
+    emb.rt.use_graph, emb_e.rt.use_graph = True, False
     rng = np.random.default_rng(43)
     pool = syn.sample_pool(S, rng)
     id2idx = {int(v): i for i, v in enumerate(pool)}
@@ -303,7 +305,15 @@ def test_seq_two_buckets_interleaved(dev, cfg, use_graph):
         ref.L = L                                   # the oracle unrolls as many steps as it is fed
         l_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), ps, id2idx)
         l_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), bk, ps, id2idx)
+        l_e = model_e.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), bk, ps, id2idx)
+        assert l_got == l_e, 'graph vs eager loss, step %d' % step
         np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='loss step %d (bucket %d)' % (step, bk))
         np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL,
                                    err_msg='global norm step %d' % step)
-        _compare(emb, model, remb, ref)
+        pg, pe = emb.get_params(), emb_e.get_params()
+        for k in pg:
+            assert np.array_equal(pg[k], pe[k]), 'graph vs eager: %s, step %d' % (k, step)
+        assert np.array_equal(model.W.w.cpu().numpy(), model_e.W.w.cpu().numpy())
+        # eight lr = 0.5 steps of a recurrent model: fp32 summation noise in near-cancelling
+        # gradient sums reaches a few 1e-5 absolute on small weights
+        _compare(emb, model, remb, ref, atol=5e-5)
