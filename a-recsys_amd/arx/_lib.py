@@ -64,11 +64,18 @@ PROTOTYPES = {
     "arx_slot_map_set": (cint, [i32p, i32p, i64, cint, vp]),
     "arx_loss_mw_fwdbwd": (cint, [f32p, i64, f32p, u8p, i64, i64, f32, f32p, i64, i64, f32p, f32p,
                                   i64, f32p, vp]),
+    "arx_loss_mce_fwdbwd": (cint, [f32p, i64, f32p, u8p, i64, i64, f32, f32p, i64, i64, f32p, f32p,
+                                  i64, f32p, vp]),
     "arx_loss_warp_fwdbwd": (cint, [f32p, i64, i32p, u8p, i64, i64, f32, f32p, i64, i64, f32p, f32p,
                                     i64, vp]),
     "arx_loss_mw_fwdbwd_pos": (cint, [f32p, i64, f32p, i32p, i32p, i32p, i32p, i64, f32, f32p, i64,
                                       i64, f32p, f32p, i64, f32p, vp]),
+    "arx_loss_mce_fwdbwd_pos": (cint, [f32p, i64, f32p, i32p, i32p, i32p, i32p, i64, f32, f32p, i64,
+                                      i64, f32p, f32p, i64, f32p, vp]),
     "arx_loss_mw_fused_pos": (cint, [f32p, i64, f32p, i64, f32p, i64, f32p, i64, cint, i32p, i32p, i32p, i32p,
+                                     i64, f32, f32p, i64, i64, f32p, f32p, i64, f32p, f32p, i64, f32p, i64,
+                                     f32p, i64, vp]),
+    "arx_loss_mce_fused_pos": (cint, [f32p, i64, f32p, i64, f32p, i64, f32p, i64, cint, i32p, i32p, i32p, i32p,
                                      i64, f32, f32p, i64, i64, f32p, f32p, i64, f32p, f32p, i64, f32p, i64,
                                      f32p, i64, vp]),
     "arx_loss_warp_fwdbwd_pos": (cint, [f32p, i64, i32p, i32p, i32p, i32p, i32p, i64, f32, f32p,

@@ -410,8 +410,8 @@ class EmbeddingAttribute(object):
     # ------------------------------------------------------------------ loss
     def _mask_state(self, loss, rows):
         if loss not in self.mask:
-            W = self.n_sampled if loss == 'mw' else self.logit_size       # :652
-            if loss == 'mw':
+            W = self.n_sampled if loss in ('mw', 'mce') else self.logit_size       # :652
+            if loss in ('mw', 'mce'):
                 getter = lambda: self.item2slot
             else:
                 getter = lambda: self._item2logit_dev
@@ -422,14 +422,16 @@ class EmbeddingAttribute(object):
     def compute_loss(self, logits, item_target, loss='ce', true_rank=False, loss_func='log',
                      exp_p=1.005, device='/gpu:0'):
         """embed_attribute.py:525-549.  Implemented on device: 'ce', 'warp', 'mw', 'warp_eval',
-        'rs', 'rs-sig', 'rs-sig2', 'bbpr' (loss_func log/exp/poly/poly2/linear/square); 'mce' has no
-        branch in the reference and bpr* needs feeds the reference commented out."""
+        'rs', 'rs-sig', 'rs-sig2', 'bbpr' (loss_func log/exp/poly/poly2/linear/square), and 'mce'
+        -- accepted by the reference's assert (:527) but without a branch there: BUILD-DEFINED as
+        the sampled softmax log(1 + sum_s m_rs exp(x_rs - t_r)) in the shape of 'mw' (arx.h).
+        bpr* needs feeds the reference commented out."""
         if loss not in ['ce', 'mce', 'warp', 'warp_eval', 'rs', 'rs-sig', 'rs-sig2', 'mw', 'bbpr',
                         'bpr', 'bpr-hinge']:
             raise ValueError("unknown loss %r" % loss)
         if loss in ('ce',):
             return G.BatchLoss(self.rt, 'ce', logits, item_target)
-        if loss in ('warp', 'mw', 'warp_eval'):
+        if loss in ('warp', 'mw', 'mce', 'warp_eval'):
             ms = self._mask_state(loss, logits.shape[0])
             node = G.BatchLoss(self.rt, loss, logits, item_target, mask=ms, mask_rows=self.batch_size)
             if loss == 'warp_eval':

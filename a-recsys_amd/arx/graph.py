@@ -341,7 +341,7 @@ class BatchLoss(Node):
     requires_grad = True
 
     def __init__(self, rt, kind, logits, target, mask=None, mask_rows=0, loss_func='log', exp_p=1.005):
-        if kind not in ('ce', 'warp', 'mw', 'warp_eval', 'rs', 'rs-sig', 'rs-sig2', 'bbpr'):
+        if kind not in ('ce', 'warp', 'mw', 'mce', 'warp_eval', 'rs', 'rs-sig', 'rs-sig2', 'bbpr'):
             raise NotImplementedError("loss %r is not implemented on the HIP path" % kind)
         if loss_func not in ops.RS_FUNCS:
             raise ValueError("unknown loss_func %r" % (loss_func,))
@@ -356,7 +356,7 @@ class BatchLoss(Node):
         # 'mw' over <= 2048 sampled columns with the in-kernel positive mask: the wave that owns
         # a row also forms its target score and the two rank-one gradients (2 launches less)
         self.fuse_ts = False
-        if (kind == 'mw' and isinstance(target, TargetScore) and mask is not None and mask.fused
+        if (kind in ('mw', 'mce') and isinstance(target, TargetScore) and mask is not None and mask.fused
                 and not os.environ.get('ARX_LOSS_NOFUSE')):
             lat, te = target.inputs
             d, W = lat.shape[1], logits.shape[1]
@@ -377,7 +377,8 @@ class BatchLoss(Node):
         if fused:
             ptr, items = ms.pos_getter()
             uid, i2s = ms.user_ids.value, ms.slot_map_getter()
-        if self.kind == 'mw':
+        if self.kind in ('mw', 'mce'):        # sampled pool + separate target score ('mce': build-defined)
+            kind = self.kind
             dt = target.alloc_grad() if train else None
             if train:
                 target.grad_beta()
@@ -396,12 +397,14 @@ class BatchLoss(Node):
                         if dt.data_ptr() != te.bias_grad.data_ptr():
                             raise RuntimeError("target-score gradient is expected to alias the bias gradient rows")
                 ops.loss_mw_fused_pos(logits.value, lat.value, te.value, te.bias_value, uid, ptr, items, i2s,
-                                      bl, dl, target.value, dt, dU, dT, self.gscale, rw, self.mask_rows)
+                                      bl, dl, target.value, dt, dU, dT, self.gscale, rw, self.mask_rows,
+                                      kind=kind)
             elif fused:
                 ops.loss_mw_pos(logits.value, target.value, uid, ptr, items, i2s, bl, dl, dt,
-                                self.gscale, rw, self.mask_rows)
+                                self.gscale, rw, self.mask_rows, kind=kind)
             else:
-                ops.loss_mw(logits.value, target.value, m, bl, dl, dt, self.gscale, rw, self.mask_rows)
+                ops.loss_mw(logits.value, target.value, m, bl, dl, dt, self.gscale, rw, self.mask_rows,
+                            kind=kind)
         elif self.kind == 'warp':
             if fused:
                 ops.loss_warp_pos(logits.value, target.value, uid, ptr, items, i2s, bl, dl,

@@ -275,14 +275,20 @@ class LatentProductModel(object):
                                               mask_rows=batch_size)
             else:
                 batch_loss_eval = m.compute_loss(logits, self.item_target, 'warp')  # :130
+        elif loss == 'mce':
+            # build-defined sampled softmax (the reference has no arithmetic for 'mce', see arx.h):
+            # trains like 'mw' on the sampled pool; evaluates with the full softmax 'ce', the loss
+            # run_hmf.py:255,304 groups it with
+            batch_loss = m.compute_loss(sampled_logits, target_score, loss)
+            batch_loss_eval = m.compute_loss(logits, self.item_target, 'ce')
         else:
             raise NotImplementedError("not implemented!")
-        if loss in ('warp', 'warp_eval', 'mw', 'rs', 'rs-sig', 'rs-sig2', 'bbpr'):   # :137
+        if loss in ('warp', 'warp_eval', 'mw', 'mce', 'rs', 'rs-sig', 'rs-sig2', 'bbpr'):   # :137
             self.set_mask, self.reset_mask = m.get_warp_mask()
         self.batch_loss = batch_loss
         self.loss = G.MeanLoss(rt, batch_loss)                                # :140
         self.loss.lazy = True
-        self.loss_eval = G.MeanLoss(rt, batch_loss_eval) if loss == 'mw' else self.loss  # :144
+        self.loss_eval = G.MeanLoss(rt, batch_loss_eval) if loss in ('mw', 'mce') else self.loss  # :144
         kk = min(self.top_N_items, self.logit_size)
         stream_min = int(os.environ.get('ARX_STREAM_TOPK_BYTES', str(1 << 30)))
         if batch_size * self.logit_size * 4 > stream_min and kk <= 1024:
@@ -306,7 +312,7 @@ class LatentProductModel(object):
             masks = [m.mask[loss]] if loss in m.mask else []
             p = G.Plan(rt, [self.loss], True, masks)
         elif key == 'eval':
-            l = 'warp' if loss == 'mw' else loss
+            l = 'warp' if loss == 'mw' else ('ce' if loss == 'mce' else loss)
             masks = [m.mask[l]] if l in m.mask else []
             p = G.Plan(rt, [self.loss_eval], False, masks)
         elif key == 'recommend':
@@ -322,7 +328,7 @@ class LatentProductModel(object):
               forward_only):
         m = self.att_emb
         if not recommend:
-            if not isinstance(item_input, torch.Tensor) and (self.loss_function != 'mw' or forward_only):
+            if not isinstance(item_input, torch.Tensor) and (self.loss_function not in ('mw', 'mce') or forward_only):
                 # host ids: mapped here so that an item without a logit fails like the reference's
                 # dict lookup (:173); the plan maps item_id_target again on device (same values)
                 self.item_target.feed(m.target_mapping([item_input])[0])

@@ -267,7 +267,7 @@ class SeqModel(SeqBatching):
             raise ValueError("num_layers must be >= 1")
         if not (0.0 < float(dropoutRate) <= 1.0):
             raise ValueError("dropoutRate (keep probability) must be in (0, 1]")
-        if loss not in ('ce', 'warp', 'mw'):
+        if loss not in ('ce', 'warp', 'mw', 'mce'):
             raise NotImplementedError("loss %r" % loss)
         self.embeddingAttribute = m = embeddingAttribute
         m.rt.optimizer = 'adagrad' if withAdagrad else 'sgd'          # seqModel.py:173-176
@@ -399,20 +399,20 @@ class SeqModel(SeqBatching):
         tid = view(self.target_ids_all, 'target_id_%d' % L)
         tgt = view(self.targets_all, 'target_%d' % L)
         bk = {'L': L, 'dropouts': bk_drop}
-        if self.loss == 'mw':
+        if self.loss in ('mw', 'mce'):       # ('mce': build-defined sampled softmax, see arx.h)
             logits = SeqPrediction(rt, hs, m._pool_embed('sampled', self.output_feat), L, B)  # :492
             tscore = m.get_target_score(hs, tid)                                            # :493
-            bl = m.compute_loss(logits, tscore, 'mw')
+            bl = m.compute_loss(logits, tscore, self.loss)
         else:
             logits = SeqPrediction(rt, hs, m._pool_embed('full', self.output_feat), L, B)   # :484
             bl = m.compute_loss(logits, tgt, self.loss)
         bk['train'] = SeqLoss(rt, bl, wn)
         bk['train_logits'] = logits
         # losses_full (:510): full-vocabulary loss for evaluation
-        if self.loss == 'mw':
+        if self.loss in ('mw', 'mce'):
             wn2 = SeqWeights(rt, wn.inputs[0], L, B)
             full = G.Prediction(rt, hs, m._pool_embed('full', self.output_feat))
-            bl_full = m.compute_loss(full, tgt, 'warp')
+            bl_full = m.compute_loss(full, tgt, 'warp' if self.loss == 'mw' else 'ce')
             bk['eval'] = SeqLoss(rt, bl_full, wn2)
         else:
             bk['eval'] = bk['train']
@@ -432,7 +432,7 @@ class SeqModel(SeqBatching):
             elif key == 'recommend':
                 bk['plans'][key] = G.Plan(self.rt, [bk['recommend']], False, [])
             else:
-                l = 'warp' if self.loss == 'mw' else self.loss
+                l = 'warp' if self.loss == 'mw' else ('ce' if self.loss == 'mce' else self.loss)
                 masks = [m.mask[l]] if l in m.mask else []
                 bk['plans'][key] = G.Plan(self.rt, [bk['eval']], False, masks)
         return bk['plans'][key]
@@ -605,7 +605,7 @@ class SeqModel(SeqBatching):
             w = w.reshape(-1)
         put(self.weights_all.value[:n], w, torch.float32)
         put(m.input_all.value[:n], flat_i(item_inputs), torch.int32)
-        if self.loss != 'mw' or forward_only:
+        if self.loss not in ('mw', 'mce') or forward_only:
             m.target_mapping_device(self.target_ids_all.value[:n], self.targets_all.value[:n])
         update_sampled, _, _ = m.add_input({}, user_input, None, item_sampled=item_sampled,
                                            item_sampled_id2idx=item_sampled_id2idx,

@@ -264,9 +264,10 @@ def slot_map_set(item2slot, ids, clear=False):
 
 # ---- a10-a12 -----------------------------------------------------------------------
 def loss_mw(logits, tscore, mask, batch_loss, dlogits, dtscore, gscale, row_w=None,
-            mask_rows=0):
+            mask_rows=0, kind='mw'):
+    """kind 'mw' (WMRB hinge, embed_attribute.py:641-649) or 'mce' (build-defined sampled softmax)."""
     B, S = int(logits.shape[0]), int(logits.shape[1])
-    call("arx_loss_mw_fwdbwd", _p(logits), _ld(logits), _p(tscore), _p(mask),
+    call("arx_loss_%s_fwdbwd" % kind, _p(logits), _ld(logits), _p(tscore), _p(mask),
          _ld(mask) if mask is not None else 0, int(mask_rows), float(gscale), _p(row_w), B, S,
          _p(batch_loss), _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _p(dtscore),
          _stream())
@@ -283,20 +284,20 @@ POS_MASK_MAX_COLS = 1 << 20
 
 
 def loss_mw_pos(logits, tscore, user_ids, pos_ptr, pos_items, item2slot, batch_loss, dlogits,
-                dtscore, gscale, row_w=None, mask_rows=0):
+                dtscore, gscale, row_w=None, mask_rows=0, kind='mw'):
     B, S = int(logits.shape[0]), int(logits.shape[1])
-    call("arx_loss_mw_fwdbwd_pos", _p(logits), _ld(logits), _p(tscore), _p(user_ids), _p(pos_ptr),
+    call("arx_loss_%s_fwdbwd_pos" % kind, _p(logits), _ld(logits), _p(tscore), _p(user_ids), _p(pos_ptr),
          _p(pos_items), _p(item2slot), int(mask_rows), float(gscale), _p(row_w), B, S,
          _p(batch_loss), _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _p(dtscore),
          _stream())
 
 
 def loss_mw_fused_pos(logits, U, T, tbias, user_ids, pos_ptr, pos_items, item2slot, batch_loss, dlogits,
-                      tscore_out, dtscore, dU, dT, gscale, row_w=None, mask_rows=0):
-    """'mw' loss with the target score t = U.T + tbias, dT = dt*U and dU = dt*T formed by the
+                      tscore_out, dtscore, dU, dT, gscale, row_w=None, mask_rows=0, kind='mw'):
+    """'mw' (or 'mce') loss with the target score t = U.T + tbias, dT = dt*U and dU = dt*T formed by the
     same kernel (dU is WRITTEN: accumulate the scorer's dU onto it afterwards)."""
     B, S = int(logits.shape[0]), int(logits.shape[1])
-    call("arx_loss_mw_fused_pos", _p(logits), _ld(logits), _p(U), _ld(U), _p(T), _ld(T), _p(tbias),
+    call("arx_loss_%s_fused_pos" % kind, _p(logits), _ld(logits), _p(U), _ld(U), _p(T), _ld(T), _p(tbias),
          int(tbias.stride(0)) if tbias is not None else 1, int(U.shape[1]), _p(user_ids), _p(pos_ptr),
          _p(pos_items), _p(item2slot), int(mask_rows), float(gscale), _p(row_w), B, S, _p(batch_loss),
          _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _p(tscore_out), _p(dtscore),

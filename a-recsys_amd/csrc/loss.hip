@@ -87,7 +87,10 @@ __device__ __forceinline__ void build_pos_bits(uint32_t* bits, int64_t W, const 
   __syncthreads();
 }
 
-template <bool WARP, bool POS>
+// SOFT (build-defined 'mce', sampled softmax; !WARP only): the hinge sum becomes
+//   loss = log(1 + sum_s keep_s * exp(x_s - t)),  dx_s = g * keep_s * exp(x_s - t) / (1 + sum),
+// evaluated around M = max(t, max kept x) for range safety.
+template <bool WARP, bool POS, bool SOFT = false>
 __global__ __launch_bounds__(256) void k_loss_margin(
     const float* __restrict__ logits, int64_t ldl, const float* __restrict__ tscore,
     const int32_t* __restrict__ target, const uint8_t* __restrict__ mask, int64_t ldm,
@@ -105,6 +108,31 @@ __global__ __launch_bounds__(256) void k_loss_margin(
   // loss is NaN -- loud -- and its gradient zero; nothing is read or written out of bounds
   const bool bad = WARP && (tcol < 0 || tcol >= W);
   const float t = WARP ? (bad ? 0.f : x[tcol]) : tscore[r];
+  if constexpr (SOFT) {
+    float mx = t;
+    for (int64_t c = threadIdx.x; c < W; c += 256) {
+      const bool keep = POS ? !((bits[c >> 5] >> (c & 31)) & 1u) : (m ? (m[c] != 0) : true);
+      if (keep) mx = fmaxf(mx, x[c]);
+    }
+    mx = block_max(mx, sh);
+    float se = 0.f;
+    for (int64_t c = threadIdx.x; c < W; c += 256) {
+      const bool keep = POS ? !((bits[c >> 5] >> (c & 31)) & 1u) : (m ? (m[c] != 0) : true);
+      se += keep ? expf(x[c] - mx) : 0.f;
+    }
+    se = block_sum(se, sh);
+    const float z = expf(t - mx) + se;
+    if (threadIdx.x == 0 && batch_loss) batch_loss[r] = mx - t + logf(z);
+    if (!dlogits) return;
+    const float gz = gscale * (row_w ? row_w[r] : 1.f) / z;
+    float* dxs = dlogits + r * lddl;
+    for (int64_t c = threadIdx.x; c < W; c += 256) {
+      const bool keep = POS ? !((bits[c >> 5] >> (c & 31)) & 1u) : (m ? (m[c] != 0) : true);
+      dxs[c] = keep ? gz * expf(x[c] - mx) : 0.f;
+    }
+    if (threadIdx.x == 0 && dtscore) dtscore[r] = -gz * se;
+    return;
+  }
   float s = 0.f;
   for (int64_t c = threadIdx.x; c < W; c += 256) {
     const float v = x[c] - t + 1.f;
@@ -140,7 +168,7 @@ __global__ __launch_bounds__(256) void k_loss_margin(
 // 32 rows per CU are in flight and the chain overlaps the row load.
 // Same arithmetic, same summation order per lane is NOT kept (lane-strided float4 instead
 // of thread-strided scalars): results agree to fp32 rounding, deterministic run to run.
-template <bool WARP, bool POS, int NV>
+template <bool WARP, bool POS, int NV, bool SOFT = false>
 __global__ __launch_bounds__(256) void k_loss_margin_wave(
     const float* __restrict__ logits, int64_t ldl, const float* __restrict__ tscore,
     const int32_t* __restrict__ target, const uint8_t* __restrict__ mask, int64_t ldm,
@@ -215,6 +243,39 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
   }
   const bool bad = WARP && (tcol < 0 || tcol >= W);     // see k_loss_margin
   float s = 0.f;
+  float g, cnt = 0.f;
+  float4 d[NV];
+  float dt_soft = 0.f;
+  if constexpr (SOFT) {                                  // sampled softmax ('mce'), see k_loss_margin
+    float mx = t;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int64_t c = (int64_t)i * 256 + lane * 4;
+      if (((keep >> (4 * i)) & 1u) && c < W) mx = fmaxf(mx, v[i].x);
+      if (((keep >> (4 * i + 1)) & 1u) && c + 1 < W) mx = fmaxf(mx, v[i].y);
+      if (((keep >> (4 * i + 2)) & 1u) && c + 2 < W) mx = fmaxf(mx, v[i].z);
+      if (((keep >> (4 * i + 3)) & 1u) && c + 3 < W) mx = fmaxf(mx, v[i].w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int64_t c = (int64_t)i * 256 + lane * 4;
+      d[i].x = (((keep >> (4 * i)) & 1u) && c < W) ? __expf(v[i].x - mx) : 0.f;
+      d[i].y = (((keep >> (4 * i + 1)) & 1u) && c + 1 < W) ? __expf(v[i].y - mx) : 0.f;
+      d[i].z = (((keep >> (4 * i + 2)) & 1u) && c + 2 < W) ? __expf(v[i].z - mx) : 0.f;
+      d[i].w = (((keep >> (4 * i + 3)) & 1u) && c + 3 < W) ? __expf(v[i].w - mx) : 0.f;
+      s += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+    }
+    s = wsum(s);
+    const float z = __expf(t - mx) + s;
+    if (lane == 0 && batch_loss) batch_loss[r] = mx - t + logf(z);
+    if (!dlogits) return;
+    g = gscale * (row_w ? row_w[r] : 1.f) / z;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) d[i] = make_float4(d[i].x * g, d[i].y * g, d[i].z * g, d[i].w * g);
+    dt_soft = -g * s;
+  } else {
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int64_t c = (int64_t)i * 256 + lane * 4;
@@ -228,10 +289,7 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
   s = wsum(s);
   if (lane == 0 && batch_loss) batch_loss[r] = bad ? NAN : logf(1.f + s);
   if (!dlogits) return;
-  const float g = bad ? 0.f : gscale * (row_w ? row_w[r] : 1.f) / (1.f + s);
-  float* dx = dlogits + r * lddl;
-  float cnt = 0.f;
-  float4 d[NV];
+  g = bad ? 0.f : gscale * (row_w ? row_w[r] : 1.f) / (1.f + s);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int64_t c = (int64_t)i * 256 + lane * 4;
@@ -242,8 +300,10 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
     cnt += (a0 ? 1.f : 0.f) + (a1 ? 1.f : 0.f) + (a2 ? 1.f : 0.f) + (a3 ? 1.f : 0.f);
     d[i] = make_float4(a0 ? g : 0.f, a1 ? g : 0.f, a2 ? g : 0.f, a3 ? g : 0.f);
   }
-  cnt = wsum(cnt);
-  const float dt = -g * cnt;
+  }
+  float* dx = dlogits + r * lddl;
+  cnt = SOFT ? 0.f : wsum(cnt);
+  const float dt = SOFT ? dt_soft : -g * cnt;
   if (WARP) {     // the target column's owner folds dt in before the row is stored
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -282,7 +342,7 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
 }
 
 // launch helper: true if the wave-per-row kernel took the call
-template <bool WARP, bool POS>
+template <bool WARP, bool POS, bool SOFT = false>
 static bool launch_margin_wave(const float* logits, int64_t ldl, const float* tscore,
                                const int32_t* target, const uint8_t* mask, int64_t ldm,
                                int64_t mask_rows, float gscale, const float* row_w, int64_t B,
@@ -294,11 +354,11 @@ static bool launch_margin_wave(const float* logits, int64_t ldl, const float* ts
     return false;
   const int grid = (int)ceil_div(B, 4);
   if (W <= 1024)
-    k_loss_margin_wave<WARP, POS, 4><<<grid, 256, 0, s>>>(logits, ldl, tscore, target, mask, ldm,
+    k_loss_margin_wave<WARP, POS, 4, SOFT><<<grid, 256, 0, s>>>(logits, ldl, tscore, target, mask, ldm,
                                                           mask_rows, gscale, row_w, B, W, batch_loss,
                                                           dlogits, lddl, dtscore, pm, df);
   else
-    k_loss_margin_wave<WARP, POS, 8><<<grid, 256, 0, s>>>(logits, ldl, tscore, target, mask, ldm,
+    k_loss_margin_wave<WARP, POS, 8, SOFT><<<grid, 256, 0, s>>>(logits, ldl, tscore, target, mask, ldm,
                                                           mask_rows, gscale, row_w, B, W, batch_loss,
                                                           dlogits, lddl, dtscore, pm, df);
   return true;
@@ -525,6 +585,28 @@ int arx_loss_mw_fwdbwd(const float* logits, int64_t ldl, const float* tscore,
   return ARX_OK;
 }
 
+int arx_loss_mce_fwdbwd(const float* logits, int64_t ldl, const float* tscore,
+                       const uint8_t* mask, int64_t ldm, int64_t mask_rows, float gscale,
+                       const float* row_w,
+                       int64_t B, int64_t S, float* batch_loss, float* dlogits, int64_t lddl,
+                       float* dtscore, void* stream) {
+  ARX_CHECK_ARG(logits && tscore, "arx_loss_mce_fwdbwd: null pointer");
+  ARX_CHECK_ARG(B >= 0 && S >= 0, "arx_loss_mce_fwdbwd: negative size");
+  if (B == 0) return ARX_OK;
+  if (launch_margin_wave<false, false, true>(logits, ldl, tscore, nullptr, mask, ldm,
+                                       mask_rows > 0 ? mask_rows : B, gscale, row_w, B, S,
+                                       batch_loss, dlogits, lddl, dtscore, PosMask{},
+                                       as_stream(stream))) {
+    ARX_CHECK_LAUNCH();
+    return ARX_OK;
+  }
+  k_loss_margin<false, false, true><<<(int)B, 256, 0, as_stream(stream)>>>(
+      logits, ldl, tscore, nullptr, mask, ldm, mask_rows > 0 ? mask_rows : B, gscale, row_w, S,
+      batch_loss, dlogits, lddl, dtscore, PosMask{});
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
 int arx_loss_warp_fwdbwd(const float* logits, int64_t ldl, const int32_t* target,
                          const uint8_t* mask, int64_t ldm, int64_t mask_rows, float gscale,
                          const float* row_w,
@@ -579,6 +661,36 @@ int arx_loss_mw_fwdbwd_pos(const float* logits, int64_t ldl, const float* tscore
   return ARX_OK;
 }
 
+int arx_loss_mce_fwdbwd_pos(const float* logits, int64_t ldl, const float* tscore,
+                           const int32_t* user_ids, const int32_t* pos_ptr,
+                           const int32_t* pos_items, const int32_t* item2slot, int64_t mask_rows,
+                           float gscale, const float* row_w, int64_t B, int64_t S,
+                           float* batch_loss, float* dlogits, int64_t lddl, float* dtscore,
+                           void* stream) {
+  ARX_CHECK_ARG(logits && tscore && user_ids && pos_ptr && pos_items && item2slot,
+                "arx_loss_mce_fwdbwd_pos: null pointer");
+  ARX_CHECK_ARG(B >= 0 && S >= 0, "arx_loss_mce_fwdbwd_pos: negative size");
+  if (S > ARX_POS_LDS_MAX_COLS) {
+    set_error("arx_loss_mce_fwdbwd_pos: %lld columns exceed the LDS mask (use the mask-array form)", (long long)S);
+    return ARX_EUNSUPPORTED;
+  }
+  if (B == 0) return ARX_OK;
+  if (launch_margin_wave<false, true, true>(logits, ldl, tscore, nullptr, nullptr, 0,
+                                      mask_rows > 0 ? mask_rows : B, gscale, row_w, B, S,
+                                      batch_loss, dlogits, lddl, dtscore,
+                                      PosMask{user_ids, pos_ptr, pos_items, item2slot},
+                                      as_stream(stream))) {
+    ARX_CHECK_LAUNCH();
+    return ARX_OK;
+  }
+  const size_t lds = (size_t)((S + 31) / 32) * 4;
+  k_loss_margin<false, true, true><<<(int)B, 256, lds, as_stream(stream)>>>(
+      logits, ldl, tscore, nullptr, nullptr, 0, mask_rows > 0 ? mask_rows : B, gscale, row_w, S,
+      batch_loss, dlogits, lddl, dtscore, PosMask{user_ids, pos_ptr, pos_items, item2slot});
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
 int arx_loss_mw_fused_pos(const float* logits, int64_t ldl, const float* U, int64_t ldu, const float* T,
                           int64_t ldt, const float* tbias, int64_t tbias_stride, int d,
                           const int32_t* user_ids,
@@ -607,6 +719,40 @@ int arx_loss_mw_fused_pos(const float* logits, int64_t ldl, const float* U, int6
                                        PosMask{user_ids, pos_ptr, pos_items, item2slot},
                                        as_stream(stream), df)) {
     set_error("arx_loss_mw_fused_pos: logits / dlogits layout not supported by the wave kernel");
+    return ARX_EUNSUPPORTED;
+  }
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_loss_mce_fused_pos(const float* logits, int64_t ldl, const float* U, int64_t ldu, const float* T,
+                          int64_t ldt, const float* tbias, int64_t tbias_stride, int d,
+                          const int32_t* user_ids,
+                          const int32_t* pos_ptr, const int32_t* pos_items, const int32_t* item2slot,
+                          int64_t mask_rows, float gscale, const float* row_w, int64_t B, int64_t S,
+                          float* batch_loss, float* dlogits, int64_t lddl, float* tscore_out,
+                          float* dtscore, int64_t dtscore_stride, float* dU, int64_t lddu, float* dT,
+                          int64_t lddt, void* stream) {
+  ARX_CHECK_ARG(logits && U && T && user_ids && pos_ptr && pos_items && item2slot,
+                "arx_loss_mce_fused_pos: null pointer");
+  ARX_CHECK_ARG(B >= 0 && S >= 0, "arx_loss_mce_fused_pos: negative size");
+  const bool ok = d > 0 && d <= 256 && d % 4 == 0 && ldu % 4 == 0 && ldt % 4 == 0 &&
+                  (!dU || lddu % 4 == 0) && (!dT || lddt % 4 == 0) && S <= 2048 &&
+                  ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(T) |
+                    reinterpret_cast<uintptr_t>(dU) | reinterpret_cast<uintptr_t>(dT)) & 15) == 0;
+  if (!ok) {
+    set_error("arx_loss_mce_fused_pos: shape not supported (d %% 4, d <= 256, S <= 2048, 16-byte rows)");
+    return ARX_EUNSUPPORTED;
+  }
+  if (B == 0) return ARX_OK;
+  DotFuse df{U, ldu, T, ldt, tbias, tbias_stride > 0 ? tbias_stride : 1, d, tscore_out,
+             dtscore_stride > 0 ? dtscore_stride : 1, dU, lddu, dT, lddt};
+  if (!launch_margin_wave<false, true, true>(logits, ldl, nullptr, nullptr, nullptr, 0,
+                                       mask_rows > 0 ? mask_rows : B, gscale, row_w, B, S, batch_loss,
+                                       dlogits, lddl, dtscore,
+                                       PosMask{user_ids, pos_ptr, pos_items, item2slot},
+                                       as_stream(stream), df)) {
+    set_error("arx_loss_mce_fused_pos: logits / dlogits layout not supported by the wave kernel");
     return ARX_EUNSUPPORTED;
   }
   ARX_CHECK_LAUNCH();

@@ -253,6 +253,33 @@ int arx_loss_mw_fused_pos(const float* logits, int64_t ldl, const float* U, int6
                           int64_t B, int64_t S, float* batch_loss, float* dlogits, int64_t lddl,
                           float* tscore_out, float* dtscore, int64_t dtscore_stride, float* dU,
                           int64_t lddu, float* dT, int64_t lddt, void* stream);
+
+/* Sampled softmax ('mce').  BUILD-DEFINED: the reference accepts loss 'mce'
+ * (embed_attribute.py:527 assert, :717 feed guard, run_hmf.py:31,100, lstm/run.py:447) but its
+ * compute_loss has no branch for it (:529-549).  Defined here in the shape of 'mw' (:641-649):
+ *   loss_r = log(1 + sum_s m_rs * exp(x_rs - t_r))      (softmax cross-entropy over
+ *            [target score || the sampled logits the positive mask keeps]; no log-Q term)
+ *   dx_rs  = g_r * m_rs * exp(x_rs - t_r) / (1 + sum),  dt_r = -sum_s dx_rs.
+ * Same three forms, arguments and restrictions as the arx_loss_mw_* entries above. */
+int arx_loss_mce_fwdbwd(const float* logits, int64_t ldl, const float* tscore,
+                       const uint8_t* mask, int64_t ldm, int64_t mask_rows, float gscale,
+                       const float* row_w,
+                       int64_t B, int64_t S, float* batch_loss, float* dlogits, int64_t lddl,
+                       float* dtscore, void* stream);
+int arx_loss_mce_fwdbwd_pos(const float* logits, int64_t ldl, const float* tscore,
+                           const int32_t* user_ids, const int32_t* pos_ptr,
+                           const int32_t* pos_items, const int32_t* item2slot, int64_t mask_rows,
+                           float gscale, const float* row_w, int64_t B, int64_t S,
+                           float* batch_loss, float* dlogits, int64_t lddl, float* dtscore,
+                           void* stream);
+int arx_loss_mce_fused_pos(const float* logits, int64_t ldl, const float* U, int64_t ldu, const float* T,
+                          int64_t ldt, const float* tbias, int64_t tbias_stride, int d,
+                          const int32_t* user_ids, const int32_t* pos_ptr, const int32_t* pos_items,
+                          const int32_t* item2slot, int64_t mask_rows, float gscale, const float* row_w,
+                          int64_t B, int64_t S, float* batch_loss, float* dlogits, int64_t lddl,
+                          float* tscore_out, float* dtscore, int64_t dtscore_stride, float* dU,
+                          int64_t lddu, float* dT, int64_t lddt, void* stream);
+
 int arx_loss_warp_fwdbwd_pos(const float* logits, int64_t ldl, const int32_t* target,
                              const int32_t* user_ids, const int32_t* pos_ptr,
                              const int32_t* pos_items, const int32_t* item2slot,

@@ -441,14 +441,15 @@ class RefEmbeddingAttribute(object):
         self.pos_item_set_eval = pos_item_set_eval
 
     def mask_indices(self, user_input, loss, item_sampled_id2idx=None, forward_only=False):
-        V = self.n_sampled if loss == 'mw' else self.logit_size       # :724
-        s_2idx = item_sampled_id2idx if loss == 'mw' else self.item_ind2logit_ind   # :726
+        sampled = loss in ('mw', 'mce')                               # :717
+        V = self.n_sampled if sampled else self.logit_size            # :724
+        s_2idx = item_sampled_id2idx if sampled else self.item_ind2logit_ind   # :726
         item_set = self.pos_item_set_eval if forward_only else self.pos_item_set   # :727
         mask_indices, c = [], 0
         for u in user_input:
             offset = c * V
             if u in item_set:
-                if loss == 'mw':
+                if sampled:
                     mask_indices.extend([s_2idx[v] + offset for v in item_set[u] if v in s_2idx])  # :739
                 else:
                     mask_indices.extend([s_2idx[v] + offset for v in item_set[u]])  # :733
@@ -491,6 +492,17 @@ class RefEmbeddingAttribute(object):
             r = np.maximum(target, 0)
             s = r.sum(1)
             return np.log(1 + s), {'loss': loss, 'act': (target > 0), 's': s, 'tgt': tgt}
+        if loss == 'mce':
+            # BUILD-DEFINED (no reference arithmetic: 'mce' passes the assert at :527 and the feed
+            # guard at :717 but has no branch below :529-549).  Sampled softmax in the shape of 'mw'
+            # (:641-649): softmax cross-entropy over [target score || the sampled logits the mask
+            # keeps], i.e.  log(1 + sum_s m_rs * exp(x_rs - t_r)); no log-Q correction, like 'mw'
+            # has no |Y|/|Z| rescale.  SURVEY.md section 8(a) footnote.
+            tl = np.asarray(item_target, dtype=self.dt).reshape(mb, 1)
+            mx = np.maximum(np.where(mask, logits, -np.inf).max(1, keepdims=True), tl)
+            ex = np.where(mask, np.exp(logits - mx), 0)
+            z = np.exp(tl - mx)[:, 0] + ex.sum(1)
+            return (mx[:, 0] - tl[:, 0] + np.log(z)).astype(self.dt), {'loss': 'mce', 'p': ex / z.reshape(-1, 1)}
         if loss in ('rs', 'rs-sig', 'rs-sig2', 'bbpr'):           # :551-603
             tgt = np.asarray(item_target, dtype=np.int64)
             tl = logits[rows, tgt].reshape(mb, 1)
@@ -535,6 +547,9 @@ class RefEmbeddingAttribute(object):
             d = cache['p'] * g
             d[np.arange(d.shape[0]), cache['tgt']] -= g[:, 0]
             return d.astype(self.dt), None
+        if loss == 'mce':
+            d = (cache['p'] * g).astype(self.dt)
+            return d, (-d.sum(1)).astype(self.dt)
         if loss in ('warp', 'mw'):
             d = cache['act'].astype(self.dt) * (g / (1 + cache['s']).reshape(-1, 1))
             dt = -d.sum(1)
@@ -682,19 +697,20 @@ class RefLatentProductModel(object):
             return idx.astype(np.int32)
         targets = m.target_mapping([item_input])[0]                 # :173
         if forward_only:
-            # loss_eval: 'warp' over full V when training with 'mw' (:130,:144,:195)
-            the_loss = 'warp' if loss == 'mw' else loss
+            # loss_eval: 'warp' over full V when training with 'mw' (:130,:144,:195); build-defined
+            # 'mce' evaluates with the full softmax 'ce' (run_hmf.py:255,304 groups ce with mce)
+            the_loss = 'warp' if loss == 'mw' else ('ce' if loss == 'mce' else loss)
             logits, _ = m.get_prediction(u, 'full')
             mask = None
             if the_loss != 'ce':
                 mask = m.mask(user_input, the_loss, None, forward_only=True)
             bl, _ = m.compute_loss(logits, targets, the_loss, mask, self.loss_func, self.loss_exp_p)
             return self.dt.type(bl.mean())
-        if loss == 'mw':
+        if loss in ('mw', 'mce'):
             logits, c_pred = m.get_prediction(u, 'sampled')         # :112
             tscore, c_t = m.get_target_score(u, item_input)         # :115
-            mask = m.mask(user_input, 'mw', item_sampled_id2idx)
-            bl, c_loss = m.compute_loss(logits, tscore, 'mw', mask)
+            mask = m.mask(user_input, loss, item_sampled_id2idx)
+            bl, c_loss = m.compute_loss(logits, tscore, loss, mask)
         else:
             logits, c_pred = m.get_prediction(u, 'full')            # :118
             mask = None

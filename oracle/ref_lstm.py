@@ -195,18 +195,19 @@ class RefSeqModel(object):
         # ---- per-step scorer + loss (:480-493) ----
         the_loss = self.loss
         if forward_only:
-            the_loss = 'warp' if self.loss == 'mw' else self.loss           # losses_full (:510)
+            # losses_full (:510); the build-defined 'mce' evaluates with the full softmax 'ce'
+            the_loss = 'warp' if self.loss == 'mw' else ('ce' if self.loss == 'mce' else self.loss)
         mask = None
-        if the_loss in ('mw',):
-            mask = m.mask(user_input, 'mw', item_sampled_id2idx)
+        if the_loss in ('mw', 'mce'):
+            mask = m.mask(user_input, the_loss, item_sampled_id2idx)
         elif the_loss == 'warp':
             mask = m.mask(user_input, 'warp', None, forward_only=forward_only)
         bls, caches = [], []
         for t in range(L):
-            if the_loss == 'mw':
+            if the_loss in ('mw', 'mce'):
                 logits, c_p = m.get_prediction(hs[t], 'sampled', self.output_feat)
                 ts, c_t = m.get_target_score(hs[t], targets[t])
-                bl, c_l = m.compute_loss(logits, ts, 'mw', mask)
+                bl, c_l = m.compute_loss(logits, ts, the_loss, mask)
             else:
                 logits, c_p = m.get_prediction(hs[t], 'full', self.output_feat)
                 c_t = None

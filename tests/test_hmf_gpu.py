@@ -25,7 +25,7 @@ def _build(cfg, loss, d, B, S, seed, nonlinear='linear', use_graph=True, loss_fu
         params['b2'] = (rng.standard_normal((d,)) * 0.1).astype(np.float32)
     i2l = syn.item_ind2logit_ind_dict()
     l2i = syn.logit_ind2item_ind
-    n_s = S if loss == 'mw' else None
+    n_s = S if loss in ('mw', 'mce') else None
     model = LatentProductModel(syn.n_users, syn.n_items, d, 1, B, 0.5, 1.0, syn.u_attr, syn.i_attr,
                                i2l, l2i, loss_function=loss, n_sampled=n_s, params=params,
                                nonlinear=nonlinear, hidden_size=48, top_N_items=10,
@@ -35,7 +35,7 @@ def _build(cfg, loss, d, B, S, seed, nonlinear='linear', use_graph=True, loss_fu
                                    nonlinear=nonlinear, hidden_size=48, loss_func=loss_func,
                                    loss_exp_p=exp_p)
     pos = syn.positives_dict()
-    if loss in ('mw', 'warp', 'rs', 'rs-sig', 'rs-sig2', 'bbpr'):
+    if loss in ('mw', 'mce', 'warp', 'rs', 'rs-sig', 'rs-sig2', 'bbpr'):
         model.prepare_warp(pos, pos)
         ref.prepare_warp(pos, pos)
     return syn, model, ref
@@ -64,6 +64,8 @@ CFG_MIX = dict(n_users=400, n_items=600, logit_size=600, item_mulhot=True, user_
     (CFG_ID, 'mw', 128, 64, 256),
     (CFG_HET, 'mw', 128, 64, 256),
     (CFG_MIX, 'mw', 32, 48, 128),
+    (CFG_ID, 'mce', 128, 64, 256),           # build-defined sampled softmax (fused target score)
+    (CFG_HET, 'mce', 64, 32, 128),
     (CFG_ID, 'ce', 32, 64, None),
     (CFG_HET, 'ce', 32, 64, None),
     (CFG_HET, 'warp', 64, 32, None),
@@ -77,7 +79,7 @@ def test_hmf_steps_match_oracle(dev, cfg, loss, d, B, S, use_graph):
         users[1] = users[0]                      # duplicate user rows in one batch
         items[2] = items[3]
         pool = id2idx = None
-        if loss == 'mw' and step % 2 == 0:       # resample cadence
+        if loss in ('mw', 'mce') and step % 2 == 0:       # resample cadence
             pool = syn.sample_pool(S, rng)
             pool[:4] = items[:4]                 # targets inside the pool -> masked
             pool = np.unique(pool)
@@ -86,10 +88,14 @@ def test_hmf_steps_match_oracle(dev, cfg, loss, d, B, S, use_graph):
             id2idx = {int(v): i for i, v in enumerate(pool)}
             last_id2idx = id2idx
         l_ref = ref.step(list(users), list(items), pool, id2idx if id2idx else
-                         (last_id2idx if loss == 'mw' else None), loss=loss)
+                         (last_id2idx if loss in ('mw', 'mce') else None), loss=loss)
         l_got = model.step(None, list(users), list(items), None, pool, id2idx, loss=loss)
         np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='step %d' % step)
         _compare_state(model, ref)
+    if loss == 'mce':                            # evaluates with the full softmax
+        e_ref = ref.step(list(users), list(items), forward_only=True, loss=loss)
+        e_got = model.step(None, list(users), list(items), forward_only=True, loss=loss)
+        np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
 
 
 @pytest.mark.parametrize("loss,loss_func,exp_p", [

@@ -267,32 +267,35 @@ def _mask(rng, B, W, p=0.05):
     return (rng.random((B, W)) > p)
 
 
+@pytest.mark.parametrize("kind", ['mw', 'mce'])
 @pytest.mark.parametrize("B,S", [(64, 1024), (5, 100), (33, 3100)])
-def test_loss_mw(dev, B, S):
+def test_loss_mw(dev, B, S, kind):
+    """'mw' (embed_attribute.py:641-649) and the build-defined sampled softmax 'mce', mask-array form:
+    wave-per-row kernel (S <= 2048, aligned) and workgroup-per-row fallback."""
     from arx import ops
     import torch
     rng = np.random.default_rng(B + S)
-    logits = rng.standard_normal((B, S)).astype(np.float32)
+    logits = (rng.standard_normal((B, S)) * (3.0 if kind == 'mce' else 1.0)).astype(np.float32)
     t = rng.standard_normal((B,)).astype(np.float32)
     mask = _mask(rng, B, S)
     e = rg.RefEmbeddingAttribute.__new__(rg.RefEmbeddingAttribute)
     e.dt = np.dtype(np.float64)
-    bl, cache = e.compute_loss(logits.astype(np.float64), t.astype(np.float64), 'mw', mask)
+    bl, cache = e.compute_loss(logits.astype(np.float64), t.astype(np.float64), kind, mask)
     dl, dt = e.compute_loss_bwd(cache, np.full(B, 1.0 / B))
     L = _t(dev, logits)
     out_l = torch.empty(B, dtype=torch.float32, device=dev)
     out_dt = torch.empty(B, dtype=torch.float32, device=dev)
     dlog = torch.empty((B, S), dtype=torch.float32, device=dev)
-    ops.loss_mw(L, _t(dev, t), _t(dev, mask.astype(np.uint8)), out_l, dlog, out_dt, 1.0 / B)
+    ops.loss_mw(L, _t(dev, t), _t(dev, mask.astype(np.uint8)), out_l, dlog, out_dt, 1.0 / B, kind=kind)
     np.testing.assert_allclose(out_l.cpu().numpy(), bl, rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(dlog.cpu().numpy(), dl, rtol=RTOL, atol=1e-7)
     np.testing.assert_allclose(out_dt.cpu().numpy(), dt, rtol=RTOL, atol=1e-7)
     # in place + no mask + row weights
     rw = rng.random(B).astype(np.float32)
-    bl2, cache2 = e.compute_loss(logits.astype(np.float64), t.astype(np.float64), 'mw',
+    bl2, cache2 = e.compute_loss(logits.astype(np.float64), t.astype(np.float64), kind,
                                  np.ones((B, S), bool))
     dl2, dt2 = e.compute_loss_bwd(cache2, rw.astype(np.float64) * 0.3)
-    ops.loss_mw(L, _t(dev, t), None, out_l, L, out_dt, 0.3, row_w=_t(dev, rw))
+    ops.loss_mw(L, _t(dev, t), None, out_l, L, out_dt, 0.3, row_w=_t(dev, rw), kind=kind)
     np.testing.assert_allclose(L.cpu().numpy(), dl2, rtol=RTOL, atol=1e-7)
     np.testing.assert_allclose(out_dt.cpu().numpy(), dt2, rtol=RTOL, atol=1e-7)
 

@@ -37,7 +37,7 @@ def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False, use_concat=Fa
     START = syn.n_items
     i2l[START] = 0                                   # lstm/run.py:277
     l2i = syn.logit_ind2item_ind
-    n_s = S if loss == 'mw' else None
+    n_s = S if loss in ('mw', 'mce') else None
     emb = EmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i, params=params)
     model = SeqModel(buckets or [L], size, num_layers, clip, B, 0.5, 0.83, emb, loss=loss, use_concat=use_concat,
                      no_user_id=no_user_id, START_ID=START, params=params, dropoutRate=keep,
@@ -111,6 +111,29 @@ def test_seq_mw_steps_match_oracle(dev, cfg, size, B, L, S, clip):
             np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL,
                                        err_msg='global norm step %d' % step)
         _compare(emb, model, remb, ref)
+
+
+@pytest.mark.parametrize("cfg", [CFG_ID, CFG_HET])
+def test_seq_mce_steps_match_oracle(dev, cfg):
+    """Build-defined sampled softmax ('mce', arx.h) through the sequence model: train steps with
+    active clipping and the full-softmax evaluation, vs the oracle's definition of the same."""
+    size, B, L, S = 64, 16, 5, 128
+    syn, emb, model, remb, ref = _build(cfg, 'mce', size, B, L, S, 5.0, seed=14)
+    rng = np.random.default_rng(17)
+    pool = syn.sample_pool(S, rng)
+    id2idx = {int(v): i for i, v in enumerate(pool)}
+    for step in range(3):
+        users, inp, tg, w = _batch(syn, rng, L, B)
+        ps = pool if step == 0 else None
+        l_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), ps, id2idx)
+        l_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, ps, id2idx)
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='loss step %d' % step)
+        np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL)
+        _compare(emb, model, remb, ref)
+    e_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), None, id2idx, forward_only=True)
+    e_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, None, id2idx,
+                       forward_only=True)
+    np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
 
 
 def test_seq_ce_and_eval(dev):

@@ -198,6 +198,11 @@ def _torch_hmf_loss(P, syn_maps, users, items, pool, mask, loss, targets, B):
         It, bt = item_embed(items)
         t = (u * It).sum(1) + bt
         bl = torch.log(1 + (torch.relu(logits - t[:, None] + 1) * m).sum(1))
+    elif loss == 'mce':      # build-defined sampled softmax: CE over [target score || kept sampled logits]
+        It, bt = item_embed(items)
+        t = (u * It).sum(1) + bt
+        cat = torch.cat([t[:, None], logits.masked_fill(~m, float('-inf'))], 1)
+        bl = torch.nn.functional.cross_entropy(cat, torch.zeros(B, dtype=torch.long), reduction='none')
     elif loss == 'warp':
         t = logits[torch.arange(B), torch.as_tensor(targets).long()]
         bl = torch.log(1 + (torch.relu(logits - t[:, None] + 1) * m).sum(1))
@@ -208,7 +213,8 @@ def _torch_hmf_loss(P, syn_maps, users, items, pool, mask, loss, targets, B):
 
 @pytest.mark.parametrize("loss,mulhot,id_feature", [('mw', False, True), ('mw', True, True),
                                                     ('mw', True, False), ('ce', True, True),
-                                                    ('warp', True, True)])
+                                                    ('warp', True, True), ('mce', True, True),
+                                                    ('mce', False, True)])
 def test_oracle_step_equals_torch_autograd_plus_adagrad(loss, mulhot, id_feature):
     from arx.utils.synthetic import SyntheticHMF
     d, B, S = 8, 12, 16
@@ -217,7 +223,7 @@ def test_oracle_step_equals_torch_autograd_plus_adagrad(loss, mulhot, id_feature
     params = syn.glorot_params(d, seed=4, scale=0.5)
     i2l = syn.item_ind2logit_ind_dict()
     ref = rg.RefLatentProductModel(d, B, 0.7, syn.u_attr, syn.i_attr, i2l, syn.logit_ind2item_ind,
-                                   loss_function=loss, n_sampled=S if loss == 'mw' else None,
+                                   loss_function=loss, n_sampled=S if loss in ('mw', 'mce') else None,
                                    params=params, dtype=np.float64)
     pos = syn.positives_dict()
     ref.prepare_warp(pos, pos)
@@ -236,8 +242,8 @@ def test_oracle_step_equals_torch_autograd_plus_adagrad(loss, mulhot, id_feature
             np.asarray(ia.features_mulhot[0]) if mulhot else None,
             np.asarray(ia.mulhot_starts[0]) if mulhot else None,
             np.asarray(ia.mulhot_lengths[0]) if mulhot else None)
-    if loss == 'mw':
-        mask = ref.att_emb.mask(list(users), 'mw', id2idx)
+    if loss in ('mw', 'mce'):
+        mask = ref.att_emb.mask(list(users), loss, id2idx)
         cols = pool
         targets = None
     else:
@@ -246,7 +252,7 @@ def test_oracle_step_equals_torch_autograd_plus_adagrad(loss, mulhot, id_feature
         mask = np.ones((B, len(cols)), bool) if loss == 'ce' else ref.att_emb.mask(list(users), 'warp')
     L = _torch_hmf_loss(P, maps, users, items, cols, mask, loss, targets, B)
     L.backward()
-    l_ref = ref.step(list(users), list(items), pool if loss == 'mw' else None, id2idx, loss=loss)
+    l_ref = ref.step(list(users), list(items), pool if loss in ('mw', 'mce') else None, id2idx, loss=loss)
     assert float(L) == pytest.approx(float(l_ref), rel=1e-10)
     for name, t in P.items():
         g = t.grad.numpy() if t.grad is not None else np.zeros(t.shape)
