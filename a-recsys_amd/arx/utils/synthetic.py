@@ -27,17 +27,30 @@ def _cat_feature(n):
     return m, n + 2
 
 
-def _mulhot_feature(rng, n, vocab, avg_len, max_len, zipf_a):
-    lens = np.clip(rng.poisson(avg_len, size=n), 1, max_len).astype(np.int32)
+def _mulhot_feature(rng, n, vocab, avg_len, max_len, zipf_a, with_id_token=False):
+    """with_id_token: MIX layout (comb_attribute.py:100-148: ONE bag per entity holding its id
+    token 'id<n>' and its attribute tokens, one shared table): the bag of entity e starts with
+    the id token row 2 + e, the attribute tokens live behind the n id rows."""
+    lens = np.clip(rng.poisson(avg_len, size=n), 1, max_len - (1 if with_id_token else 0)).astype(np.int32)
     total = int(lens.sum())
     p = _zipf_probs(vocab, zipf_a)
     perm = rng.permutation(vocab)
     vals = (perm[rng.choice(vocab, size=total, p=p)] + 2).astype(np.int32)
+    rows = vocab + 2
+    if with_id_token:
+        vals = vals + n
+        out = np.empty(total + n, dtype=np.int32)
+        first = np.concatenate([[0], np.cumsum(lens + 1)[:-1]])
+        is_id = np.zeros(total + n, dtype=bool)
+        is_id[first] = True
+        out[is_id] = np.arange(n, dtype=np.int32) + 2
+        out[~is_id] = vals
+        vals, lens, rows = out, lens + 1, vocab + n + 2
     values = np.concatenate([vals, np.array([START_ID], dtype=np.int32)])
     lengths = np.concatenate([lens, np.array([1], dtype=np.int32)])
     starts = np.zeros(n + 2, dtype=np.int32)
     starts[1:] = np.cumsum(lengths)
-    return values, starts, lengths, vocab + 2
+    return values, starts, lengths, rows
 
 
 class SyntheticHMF(object):
@@ -45,7 +58,11 @@ class SyntheticHMF(object):
 
     def __init__(self, n_users, n_items, logit_size=None, item_mulhot=False, user_mulhot=False,
                  mulhot_vocab=100000, avg_len=20, max_len=64, n_pos=20, zipf_items=1.05,
-                 zipf_tokens=1.0, seed=0, permute_logits=True, item_id_feature=True):
+                 zipf_tokens=1.0, seed=0, permute_logits=True, item_id_feature=True, item_mix=False):
+        """item_mix: MIX-style items (one bag = id token + attribute tokens over one table of
+        n_items + mulhot_vocab + 2 rows; implies item_mulhot, no separate id feature)."""
+        if item_mix:
+            item_mulhot, item_id_feature = True, False
         rng = np.random.default_rng(seed)
         self.rng = rng
         self.n_users, self.n_items = n_users, n_items
@@ -68,7 +85,8 @@ class SyntheticHMF(object):
             v_cat.append(iv)
         i_mul = []
         if item_mulhot:
-            i_mul.append(_mulhot_feature(rng, n_items, mulhot_vocab, avg_len, max_len, zipf_tokens))
+            i_mul.append(_mulhot_feature(rng, n_items, mulhot_vocab, avg_len, max_len, zipf_tokens,
+                                         with_id_token=item_mix))
         self.i_attr = Attributes(len(i_cat), i_cat, len(i_mul), [m[0] for m in i_mul], None,
                                  [m[1] for m in i_mul], [m[2] for m in i_mul], v_cat,
                                  [m[3] for m in i_mul])

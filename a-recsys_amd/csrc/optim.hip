@@ -29,6 +29,10 @@ namespace arx {
 
 constexpr int kPiece = 64;          // positions per piece
 constexpr int kRankSortMax = 8192;
+// entity stage of arx_sparse_adagrad_bags.  (Measured: ONE rank-sort launch at n = 17.4 k -- 70 KB of
+// keys staged per workgroup, O(n^2) compares -- costs ~115 us against ~45 us for the 7 launches of
+// the two-pass radix sort; the rank sort stays below 8192.)
+static const int kRankSortEntities = getenv("ARX_RANK_ENT_MAX") ? atoi(getenv("ARX_RANK_ENT_MAX")) : kRankSortMax;
 constexpr int kPassBBlocks = 128;   // persistent grid of pass B
 
 __device__ __forceinline__ float4 f4_fma(float c, float4 v, float4 a) {
@@ -112,6 +116,17 @@ static inline int launch_rank_sort(const int32_t* keys, int64_t n, uint32_t sent
                                    int32_t* ssrc = nullptr, float* scoef = nullptr) {
   static const int tpe = getenv("ARX_RANK_TPE") ? atoi(getenv("ARX_RANK_TPE")) : 16;
   const size_t lds = (size_t)((n + 3) & ~(int64_t)3) * sizeof(uint32_t);
+  if (lds > 64 * 1024) {       // past the default dynamic-LDS limit (n > 16384): opt in once
+    static bool raised = false;
+    if (!raised) {
+      const int cap = 160 * 1024;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_sort<32>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_sort<16>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_sort<8>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_sort<4>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      raised = true;
+    }
+  }
   if (tpe == 32)
     k_rank_sort<32><<<(int)ceil_div(n, 8), 256, lds, s>>>(keys, n, sentinel, sk, spos, count, src_in,
                                                               coef_in, ssrc, scoef);
@@ -1273,7 +1288,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
     }
   } else {   // own LSD radix sort: src/coef come out in sorted order too
     if (phase & 1) {
-      rc = launch_radix_sort(keys_buf, src_buf, coef_buf, n, sentinel, key_bits + 1,
+      rc = launch_radix_sort(keys_buf, src_buf, coef_buf, n, sentinel, key_bits /* survivors of the first pass are < sentinel */,
                              reinterpret_cast<uint32_t*>(base + w.off_keys_tmp), keys_out,
                              reinterpret_cast<int32_t*>(base + w.off_pos_in), ssrc,
                              reinterpret_cast<float*>(base + w.off_pos_out), scoef,
@@ -1356,7 +1371,7 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
     // own LSD radix sort; src/coef are emitted in sorted order (one hop less per contribution)
     int32_t* ssrc = reinterpret_cast<int32_t*>(base + w.off_ssrc);
     float* scoef = reinterpret_cast<float*>(base + w.off_scoef);
-    rc = launch_radix_sort(keys, src, coef, n, sentinel, key_bits + 1, keys_tmp, keys_out,
+    rc = launch_radix_sort(keys, src, coef, n, sentinel, key_bits /* survivors of the first pass are < sentinel */, keys_tmp, keys_out,
                            reinterpret_cast<int32_t*>(pos_in), ssrc,
                            reinterpret_cast<float*>(pos_out), scoef,
                            reinterpret_cast<int32_t*>(base + w.off_hist), count, count + 2, s);
@@ -1411,7 +1426,7 @@ int arx_merged_sq_norm(const int32_t* keys, const int32_t* src, const float* coe
     rc = launch_rank_sort(keys, n, sentinel, keys_out, reinterpret_cast<uint32_t*>(base + w.off_pos_out),
                           count, s, src, coef, ssrc, scoef);
   } else {
-    rc = launch_radix_sort(keys, src, coef, n, sentinel, key_bits + 1,
+    rc = launch_radix_sort(keys, src, coef, n, sentinel, key_bits /* survivors of the first pass are < sentinel */,
                            reinterpret_cast<uint32_t*>(base + w.off_keys_tmp), keys_out,
                            reinterpret_cast<int32_t*>(base + w.off_pos_in), ssrc,
                            reinterpret_cast<float*>(base + w.off_pos_out), scoef,
@@ -1539,7 +1554,7 @@ int arx_sparse_adagrad_bags(int phase, float* E, float* acc, float* bias, float*
   int32_t* ssrc_t = reinterpret_cast<int32_t*>(bt + w.wt.off_ssrc);
   float* scoef_t = reinterpret_cast<float*>(bt + w.wt.off_scoef);
   int32_t* count_t = reinterpret_cast<int32_t*>(bt + w.wt.off_count);
-  const bool rank_i = n_i <= kRankSortMax, rank_t = n_t <= kRankSortMax;
+  const bool rank_i = n_i <= kRankSortEntities, rank_t = n_t <= kRankSortMax;
   const int32_t* ndev_i = rank_i ? nullptr : count_i + 2;
   const int32_t* ndev_t = rank_t ? nullptr : count_t + 2;
   int rc;
@@ -1551,7 +1566,7 @@ int arx_sparse_adagrad_bags(int phase, float* E, float* acc, float* bias, float*
       rc = launch_rank_sort(ikeys, n_i, sent_i, sk_i, reinterpret_cast<uint32_t*>(bi + w.wi.off_pos_out),
                             count_i, s, isrc, icoef, ssrc_i, scoef_i);
     else
-      rc = launch_radix_sort(ikeys, isrc, icoef, n_i, sent_i, kbi + 1,
+      rc = launch_radix_sort(ikeys, isrc, icoef, n_i, sent_i, kbi,
                              reinterpret_cast<uint32_t*>(bi + w.wi.off_keys_tmp), sk_i,
                              reinterpret_cast<int32_t*>(bi + w.wi.off_pos_in), ssrc_i,
                              reinterpret_cast<float*>(bi + w.wi.off_pos_out), scoef_i,
@@ -1570,7 +1585,7 @@ int arx_sparse_adagrad_bags(int phase, float* E, float* acc, float* bias, float*
       rc = launch_rank_sort(tkeys, n_t, sent_t, sk_t, reinterpret_cast<uint32_t*>(bt + w.wt.off_pos_out),
                             count_t, s, tsrc, nullptr, ssrc_t, scoef_t);
     else
-      rc = launch_radix_sort(tkeys, tsrc, nullptr, n_t, sent_t, kbt + 1,
+      rc = launch_radix_sort(tkeys, tsrc, nullptr, n_t, sent_t, kbt,
                              reinterpret_cast<uint32_t*>(bt + w.wt.off_keys_tmp), sk_t,
                              reinterpret_cast<int32_t*>(bt + w.wt.off_pos_in), ssrc_t,
                              reinterpret_cast<float*>(bt + w.wt.off_pos_out), scoef_t,

@@ -934,6 +934,7 @@ def test_merged_sq_norm(dev, n, rows, d, L):
     (64, 200, 5000, 3, (64,), (3,)),                 # everything below the rank-sort limit
     (128, 40000, 100002, 64, (20000, 1024), (1, 2)), # C3-like shape
     (16, 10, 8, 64, (9000, 0, 5), (3,)),             # few entities: runs of thousands, an empty site
+    (32, 5000, 900, 6, (30000, 100), (1, 2)),        # > 24 k lookups: the entity stage takes the radix sort
 ])
 def test_sparse_adagrad_bags(dev, d, n_ent, Vf, max_len, ns, phases):
     """arx_sparse_adagrad_bags (merge per entity, then per token) == the plain contribution-level
