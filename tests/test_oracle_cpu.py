@@ -438,3 +438,102 @@ def test_oracle_w2v_gradient_by_finite_differences(kind):
         lo[name] = base[name].copy(); lo[name][pick] -= 1e-5
         g_fd = (train_loss(hi) - train_loss(lo)) / 2e-5
         np.testing.assert_allclose(g_step, g_fd, rtol=3e-5, atol=1e-9, err_msg='%s %s %s' % (kind, name, pick))
+
+
+# ---------------------------------------- 5. the embedding-space (sparse) oracle == the dense one
+def _assert_sparse_state(emb_model, ref_params, ref_slots, params0, rtol=1e-10):
+    """Rows the sparse oracle updated equal the dense oracle's; every other row is untouched."""
+    for name, st in emb_model.t.items():
+        P = np.asarray(ref_params[name], dtype=np.float64).reshape(st.base.shape)
+        A = np.asarray(ref_slots[name], dtype=np.float64).reshape(st.base.shape)
+        np.testing.assert_allclose(st.val, P[st.idx], rtol=rtol, atol=1e-13, err_msg=name)
+        np.testing.assert_allclose(st.acc, A[st.idx], rtol=rtol, atol=1e-13, err_msg=name + '/Adagrad')
+        rest = np.ones(P.shape[0], dtype=bool)
+        rest[st.idx] = False
+        base = np.asarray(params0[name], dtype=np.float64).reshape(st.base.shape)
+        assert np.array_equal(P[rest], base[rest]), name        # the dense update left them alone
+        assert np.all(A[rest] == 0.1), name
+
+
+@pytest.mark.parametrize("loss", ['mw', 'mce'])
+@pytest.mark.parametrize("cfg", [dict(), dict(item_mulhot=True), dict(item_mix=True, user_mulhot=True)])
+def test_embedding_space_oracle_equals_dense_oracle_hmf(loss, cfg):
+    """oracle/ref_embed.py (what the full-size GPU parity tests use) against ref_graph's
+    reference-form step: id-only, HET and MIX layouts, three consecutive steps, pool resampled."""
+    from arx.utils.synthetic import SyntheticHMF
+    from oracle import ref_embed
+    d, B, S = 8, 12, 16
+    syn = SyntheticHMF(n_users=40, n_items=50, logit_size=50, mulhot_vocab=20, avg_len=3, max_len=6,
+                       seed=5, n_pos=5, **cfg)
+    params = syn.glorot_params(d, seed=6, scale=0.5)
+    i2l = syn.item_ind2logit_ind_dict()
+    ref = rg.RefLatentProductModel(d, B, 0.7, syn.u_attr, syn.i_attr, i2l, syn.logit_ind2item_ind,
+                                   loss_function=loss, n_sampled=S, params=params, dtype=np.float64)
+    pos = syn.positives_dict()
+    ref.prepare_warp(pos, pos)
+    emb = ref_embed.EmbedSpaceHMF(syn.u_attr, syn.i_attr, params, 0.7, loss=loss)
+    ptr, items_csr = syn.positives_csr()
+    rng = np.random.default_rng(1)
+    id2idx = None
+    for step in range(3):
+        users, items = syn.sample_batch(B, rng)
+        users[1] = users[0]
+        items[2] = items[3]
+        pool = None
+        if step != 1:
+            pool = syn.sample_pool(S, rng)
+            pool[0] = items[0]
+            pool = np.unique(pool)
+            pool = np.concatenate([pool, np.setdiff1d(syn.item_population, pool)[:S - len(pool)]])
+            id2idx = {int(v): i for i, v in enumerate(pool)}
+        l_ref = ref.step(list(users), list(items), pool, id2idx, loss=loss)
+        l_emb = emb.step(users, items, pool, ptr, items_csr)
+        assert l_emb == pytest.approx(float(l_ref), rel=1e-12)
+        _assert_sparse_state(emb, ref.att_emb.params, ref.att_emb.slots, params)
+
+
+@pytest.mark.parametrize("loss,cfg,no_uid", [('mw', dict(), True), ('mce', dict(), False),
+                                             ('mw', dict(item_mulhot=True), True)])
+def test_embedding_space_oracle_equals_dense_oracle_lstm(loss, cfg, no_uid):
+    """ref_embed.EmbedSpaceSeq against ref_lstm.RefSeqModel: loss, clip norm (TF-1.0 aggregation
+    rule, active clipping), every table row, LSTM weights -- three steps."""
+    from arx.utils.synthetic import SyntheticHMF
+    from oracle import ref_embed
+    size, B, L, S = 6, 4, 5, 8
+    syn = SyntheticHMF(n_users=30, n_items=40, logit_size=40, mulhot_vocab=15, avg_len=3, max_len=5,
+                       seed=7, n_pos=4, **cfg)
+    syn.u_attr.set_model_size(size)
+    syn.i_attr.set_model_size(size)
+    params = syn.glorot_params(size, seed=8, scale=0.5)
+    rng = np.random.default_rng(2)
+    lw = (rng.standard_normal((2 * size, 4 * size)) * 0.3)
+    lb = (rng.standard_normal((4 * size,)) * 0.1)
+    full = dict(params, lstm_w=lw, lstm_b=lb)
+    i2l = syn.item_ind2logit_ind_dict()
+    i2l[syn.n_items] = 0
+    remb = rg.RefEmbeddingAttribute(syn.u_attr, syn.i_attr, B, S, L, False, i2l, syn.logit_ind2item_ind,
+                                    params=dict(params), dtype=np.float64)
+    ref = ref_lstm.RefSeqModel(L, size, 0.05, B, 0.5, remb, loss=loss, no_user_id=no_uid, params=full)
+    pos = syn.positives_dict()
+    remb.prepare_warp(pos, pos)
+    emb = ref_embed.EmbedSpaceSeq(syn.u_attr, syn.i_attr, params, lw, lb, 0.5, 0.05, loss=loss,
+                                  no_user_id=no_uid)
+    ptr, items_csr = syn.positives_csr()
+    pool = syn.sample_pool(S, rng)
+    id2idx = {int(v): i for i, v in enumerate(pool)}
+    for step in range(3):
+        users = rng.integers(0, syn.n_users, size=B)
+        tg = np.stack([syn.sample_batch(B, rng)[1] for _ in range(L)], 0)
+        inp = np.concatenate([np.full((1, B), syn.n_items), tg[:-1]], 0)
+        lens = rng.integers(1, L + 1, size=B)
+        w = (np.arange(L)[:, None] < lens[None, :]).astype(np.float64)
+        ps = pool if step == 0 else None
+        l_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), ps, id2idx)
+        l_emb = emb.step(users, inp, tg, w, ps, ptr, items_csr)
+        assert l_emb == pytest.approx(float(l_ref), rel=1e-11)
+        assert emb.last['gnorm'] == pytest.approx(ref.last['gnorm'], rel=1e-11)
+        assert ref.last['gnorm'] > 0.05                              # clipping is active
+        tabs = {k: v for k, v in remb.params.items() if not k.startswith('lstm')}
+        _assert_sparse_state(emb, tabs, remb.slots, params, rtol=1e-9)
+        np.testing.assert_allclose(emb.W, ref.W, rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(emb.b, ref.b, rtol=1e-9, atol=1e-13)
