@@ -375,11 +375,15 @@ def _zipf_items(n, n_items, gen, dev):
     return (_hash_u32(rk, 12345) % n_items).to(torch.int32)
 
 
-def bench_main(args, world, rank, local_rank):
+def bench_run(args, world, rank, local_rank, init_pg=True):
+    """The N-rank bench body (every rank calls it); returns the JSON dict on rank 0, None elsewhere.
+    world == 1 runs the very same sharded step on one GPU (all "exchanges" local): the anchor of
+    the weak-scaling curve -- same code path, same 100 M-item table, same eager launches."""
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", device_id=dev)
+    if init_pg:
+        dist.init_process_group("nccl", device_id=dev)
     B_loc, S, d = args.batch, args.n_sampled, args.dim
     t_setup = time.time()
     model = ShardedHMF(args.n_users, args.n_items, d, B_loc, S, 0.1, rank, world, dev, seed=0)
@@ -399,27 +403,49 @@ def bench_main(args, world, rank, local_rank):
         users = (lu * world + rank).to(torch.int32)
         items = pos_items[(lu * n_pos + k)]
         batches.append(model.prepare_route(users, items))      # data-loader side: order by owner
-    # stratified shared pools, identical on every rank
-    pg = torch.Generator(device=dev)
-    pg.manual_seed(4242)
-    n_pools = total // args.n_resample + 2
+    # Shared negative pool, stratified by owner: every rank draws S/N of ITS OWN items without
+    # replacement with p ~ count^0.5 (prepare_train.py:19-35 item_frequency over the training
+    # interactions, run_hmf.py:62 power = 0.5) on device (arx_sample_wor), and one 4 KB
+    # all_gather hands every rank the whole pool, owner-major -- inside the timed region, every
+    # n_resample steps.  Setup: global interaction counts of the owned items (one reduce_scatter).
+    from .utils.prepare_train import DeviceSampler
+    rows = (args.n_items + world - 1) // world
+    from . import ops as _ops
+    cnt = torch.zeros(rows * world, dtype=torch.int32, device=dev)
+    _ops.item_frequency(pos_items, rows * world, cnt)             # arx_item_frequency: counts only
+    mine = torch.empty(rows, dtype=torch.int32, device=dev)
+    if world > 1:
+        dist.reduce_scatter_tensor(mine, cnt.view(rows, world).t().contiguous().view(-1), op=dist.ReduceOp.SUM)
+    else:
+        mine.copy_(cnt)
+    del cnt
+    tot = mine.sum(dtype=torch.int64).to(torch.float64)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    wts = (mine.to(torch.float64) / tot).pow(0.5).to(torch.float32)
+    own = torch.arange(rows, device=dev, dtype=torch.int64) * world + rank
+    wts[own >= args.n_items] = 0.0
+    sampler = DeviceSampler(own.to(torch.int32), wts, device=dev, seed=4242 + rank)
     Sg = S // world
-    pools = []
-    for _ in range(n_pools):
-        blocks = []
-        for g in range(world):
-            ng = (args.n_items - g + world - 1) // world
-            loc = torch.randperm(ng, device=dev, generator=pg)[:Sg]
-            blocks.append((loc * world + g).to(torch.int32))
-        pools.append(torch.cat(blocks))
+    pool_buf = torch.empty(S, dtype=torch.int32, device=dev)
+
+    def redraw():
+        part = sampler.sample(Sg)
+        if world > 1:
+            dist.all_gather_into_tensor(pool_buf, part)
+        else:
+            pool_buf.copy_(part)
+        model.set_pool(pool_buf)
     torch.cuda.synchronize()
     dist.barrier()
     setup_s = time.time() - t_setup
+    redraws = [0]
 
     def run(k0, k1):
         for k in range(k0, k1):
-            if k % args.n_resample == 0:
-                model.set_pool(pools[k // args.n_resample])
+            if k == 0 or (k >= args.warmup and (k - args.warmup) % args.n_resample == 0):
+                redraw()
+                redraws[0] += k >= args.warmup
             model.step(batches[k % nb])
 
     run(0, args.warmup)
@@ -438,7 +464,7 @@ def bench_main(args, world, rank, local_rank):
     loss = float(model.read_loss().item())
     # roofline of the dominant kernel (the local scorer GEMM [B_loc, S] x d), HIP events on the
     # stream the kernel runs on; same definition as the single-GPU bench line
-    roofline = None
+    out = None
     if rank == 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         run_gemm = lambda: model.be.gemm(model.U_loc, model.I_all[:, :d], model.logits, transB=True,
@@ -455,7 +481,6 @@ def bench_main(args, world, rank, local_rank):
         roofline = {"kernel": "gemm_logits_nt (per rank)", "bound": "mfma", "achieved": flops / ms / 1e9,
                     "peak": 157.3, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / 157.3, "traffic": None,
                     "flops_per_launch": flops, "ms_per_launch": ms}
-    if rank == 0:
         B = B_loc * world
         out = {
             "metric": "training interactions/sec + sampled-negatives/sec, dim-128, 1/2/4/8 MI355X",
@@ -463,17 +488,29 @@ def bench_main(args, world, rank, local_rank):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "C5-style: synthetic %d-item/%d-user HMF, dim %d, id-only, WMRB 'mw', item "
-                                   "and user tables row-sharded over %d GPUs (owner = id %% N), %d shared "
-                                   "negatives/step (S/N per owner), RCCL all_gather(pool rows) + all_to_all(target "
-                                   "rows, target grads) + reduce_scatter(pool grads); B_loc=%d per GPU"
-                                   % (args.n_items, args.n_users, d, world, S, B_loc),
+            "config": {"workload": "C5 (BASELINE configs[4]): synthetic %d-item/%d-user HMF, dim %d, id-only, WMRB 'mw', "
+                                   "item and user tables row-sharded over %d GPU(s) (owner = id %% N), %d shared "
+                                   "negatives/step, S/N per owner drawn on device with p ~ count^0.5 and all-gathered "
+                                   "every %d steps (%d redraw(s) inside the timed region); per step: RCCL "
+                                   "all_gather(pool rows) + all_to_all(target rows, target grads) + "
+                                   "reduce_scatter(pool grads); B_loc=%d per GPU.  The batch ROUTING (order by owner, "
+                                   "count / id exchange: data-loader work, ShardedHMF.prepare_route) is done once per "
+                                   "batch of the %d-batch ring, OUTSIDE the timed loop"
+                                   % (args.n_items, args.n_users, d, world, S, args.n_resample, redraws[0], B_loc, nb),
                        "batch_per_gpu": B_loc, "global_batch": B, "n_sampled": S, "dim": d,
                        "parallelism": "row-sharded tables x dp%d" % world,
+                       "routing_in_timed_region": False, "pool_redraws_timed": redraws[0],
                        "sampled_negative_logits_per_s": B * S * args.steps / wall,
                        "final_loss": loss, "setup_s": setup_s},
             "roofline": roofline, "cpu_baseline": None,
         }
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_main(args, world, rank, local_rank):
+    out = bench_run(args, world, rank, local_rank)
     dist.destroy_process_group()
     if rank == 0:
         # RCCL prints its version banner through C stdio: flush it out first so that the JSON

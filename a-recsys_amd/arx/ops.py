@@ -313,12 +313,20 @@ def loss_warp_pos(logits, target, user_ids, pos_ptr, pos_items, item2slot, batch
          _p(batch_loss), _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _stream())
 
 
-def sample_wor(weights, S, seed, counter, out, ws):
-    """Weighted sampling without replacement on device (exponential race); out: int32 [S]."""
+def item_frequency(item_ids, n_items, counts, weights=None, total=0, power=0.5):
+    """counts[v] += #(item_ids == v); weights (optional) = (counts / total)^power, 0 where unseen."""
+    n = 0 if item_ids is None else int(item_ids.shape[0])
+    call("arx_item_frequency", _p(item_ids), n, int(n_items), int(total), float(power), _p(counts),
+         _p(weights), _stream())
+
+
+def sample_wor(weights, S, seed, counter, out, ws, key_cap=0.0):
+    """Weighted sampling without replacement on device (exponential race); out: int32 [S].
+    key_cap > 0: pre-filter for very large item sets (arx_sample_wor_capped)."""
     n = int(weights.shape[0])
     wsp, wsn = ws.get(_lib.lib.arx_sample_wor_workspace_bytes(n))
-    call("arx_sample_wor", _p(weights), n, int(S), int(seed) & (2 ** 64 - 1),
-         int(counter) & (2 ** 64 - 1), _p(out), wsp, wsn, _stream())
+    call("arx_sample_wor_capped", _p(weights), n, int(S), int(seed) & (2 ** 64 - 1),
+         int(counter) & (2 ** 64 - 1), float(key_cap), _p(out), wsp, wsn, _stream())
     return out
 
 

@@ -54,19 +54,47 @@ class DeviceSampler(object):
         from .. import ops
         self._ops = ops
         dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
-        self.items = torch.as_tensor(np.asarray(items, dtype=np.int32)).to(dev)
-        pw = np.ones(len(items), dtype=np.float32) if p is None or not len(p) else np.asarray(p, dtype=np.float32)
-        self.w = torch.from_numpy(np.ascontiguousarray(pw)).to(dev)
+        if isinstance(items, torch.Tensor):           # device-resident population / weights are taken as they are
+            self.items = items.to(dev, torch.int32)
+        else:
+            self.items = torch.as_tensor(np.asarray(items, dtype=np.int32)).to(dev)
+        if isinstance(p, torch.Tensor):
+            self.w = p.to(dev, torch.float32).contiguous()
+        else:
+            pw = np.ones(len(items), dtype=np.float32) if p is None or not len(p) else np.asarray(p, dtype=np.float32)
+            self.w = torch.from_numpy(np.ascontiguousarray(pw)).to(dev)
         self.ws = ops.Workspace(dev)
         self.seed = int(seed)
         self.counter = 0
+        # large populations: keys that cannot be among the n smallest are dropped before the sort
+        # (arx_sample_wor_capped: cap = 8 n / sum(w)); the draw is the un-capped one
+        self._wsum = float(self.w.clamp(min=0).sum(dtype=torch.float64).item()) if self.w.numel() > (1 << 22) else 0.0
+
+    @classmethod
+    def from_interactions(cls, item_ids, n_items, power=0.5, device=None, seed=0):
+        """item_frequency (prepare_train.py:19-35) + the sampler over it, on device: `item_ids` =
+        the item column of the training interactions (device int32 tensor or array).  The
+        population is ALL ids 0..n_items-1 with weight (count/total)^power, 0 for unseen items
+        (the reference lists only the seen ones, in set order; the draw law is the same)."""
+        import torch
+        from .. import ops
+        dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        ids = item_ids if isinstance(item_ids, torch.Tensor) else torch.as_tensor(np.asarray(item_ids, dtype=np.int32))
+        ids = ids.to(dev, torch.int32).contiguous()
+        counts = torch.zeros(n_items, dtype=torch.int32, device=dev)
+        w = torch.empty(n_items, dtype=torch.float32, device=dev)
+        ops.item_frequency(ids, n_items, counts, w, total=int(ids.shape[0]), power=power)
+        s = cls(torch.arange(n_items, dtype=torch.int32, device=dev), w, device=dev, seed=seed)
+        s.counts = counts
+        return s
 
     def sample(self, n, out=None):
         """-> int32 device tensor [n] of item ids (draw order).  The id->slot map the reference
         builds next (prepare_train.py:12-16) is the model's device slot map (update_sampled_pool)."""
         import torch
         pos = torch.empty((n,), dtype=torch.int32, device=self.w.device)
-        self._ops.sample_wor(self.w, n, self.seed, self.counter, pos, self.ws)
+        cap = 8.0 * n / self._wsum if self._wsum > 0 and 16 * n < self.w.numel() else 0.0
+        self._ops.sample_wor(self.w, n, self.seed, self.counter, pos, self.ws, key_cap=cap)
         self.counter += 1
         ids = self.items[pos.long()]
         if out is not None:

@@ -29,7 +29,7 @@ __device__ __forceinline__ uint32_t mix32s(uint64_t z) {
 constexpr uint32_t kInfBits = 0x7f800000u;
 
 __global__ __launch_bounds__(256) void k_race_keys(const float* __restrict__ w, int64_t n,
-                                                   uint64_t seed, uint64_t counter,
+                                                   uint64_t seed, uint64_t counter, float key_cap,
                                                    int32_t* __restrict__ keys) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void k_race_keys(const float* __restrict__ w, 
       const float key = -__logf(u) / wi;
       bits = __float_as_uint(key);
       if (bits >= kInfBits) bits = kInfBits - 1;    // overflow of a tiny weight: last, not dropped
+      if (key_cap > 0.f && key > key_cap) bits = kInfBits;   // cannot be among the S smallest (see arx.h)
     }
     keys[i] = (int32_t)bits;
   }
@@ -55,6 +56,30 @@ __global__ void k_take_first(const int32_t* __restrict__ src, const int32_t* __r
 }
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+// item_frequency on device (utils/prepare_train.py:19-35): counts by integer atomics (the result
+// does not depend on the arrival order), then p ~ (count / total)^power, un-normalised -- the
+// sampler does not need the normalisation.
+__global__ __launch_bounds__(256) void k_count_ids(const int32_t* __restrict__ ids, int64_t n,
+                                                   int64_t n_items, int32_t* __restrict__ counts) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int32_t v = ids[i];
+    if (v >= 0 && v < n_items) atomicAdd(&counts[v], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_power_weights(const int32_t* __restrict__ counts, int64_t n_items,
+                                                       double inv_total, float power,
+                                                       float* __restrict__ w) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n_items; i += stride) {
+    const int32_t c = counts[i];
+    w[i] = c > 0 ? (float)pow((double)c * inv_total, (double)power) : 0.f;
+  }
+}
 
 }  // namespace
 
@@ -70,8 +95,36 @@ size_t arx_sample_wor_workspace_bytes(int64_t n) {
   return ni * 7 + radix_sort_hist_bytes() + 256;
 }
 
+int arx_item_frequency(const int32_t* item_ids, int64_t n, int64_t n_items, int64_t total, float power,
+                       int32_t* counts, float* weights, void* stream) {
+  ARX_CHECK_ARG(counts && (item_ids || n == 0), "arx_item_frequency: null pointer");
+  ARX_CHECK_ARG(n >= 0 && n_items > 0, "arx_item_frequency: bad size");
+  hipStream_t s = as_stream(stream);
+  const int64_t cap = (int64_t)cu_count() * 16;
+  if (n > 0) {
+    int64_t g = ceil_div(n, 256);
+    if (g > cap) g = cap;
+    k_count_ids<<<(int)g, 256, 0, s>>>(item_ids, n, n_items, counts);
+    ARX_CHECK_LAUNCH();
+  }
+  if (weights) {
+    ARX_CHECK_ARG(total > 0, "arx_item_frequency: total interactions must be positive");
+    int64_t g = ceil_div(n_items, 256);
+    if (g > cap) g = cap;
+    k_power_weights<<<(int)g, 256, 0, s>>>(counts, n_items, 1.0 / (double)total, power, weights);
+    ARX_CHECK_LAUNCH();
+  }
+  return ARX_OK;
+}
+
 int arx_sample_wor(const float* weights, int64_t n, int64_t S, uint64_t seed, uint64_t counter,
                    int32_t* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+  return arx_sample_wor_capped(weights, n, S, seed, counter, 0.f, out_idx, workspace, workspace_bytes, stream);
+}
+
+int arx_sample_wor_capped(const float* weights, int64_t n, int64_t S, uint64_t seed, uint64_t counter,
+                          float key_cap, int32_t* out_idx, void* workspace, size_t workspace_bytes,
+                          void* stream) {
   ARX_CHECK_ARG(weights && out_idx, "arx_sample_wor: null pointer");
   ARX_CHECK_ARG(n > 0 && n < (int64_t)0x7fffffff && S > 0 && S <= n, "arx_sample_wor: need 0 < S <= n < 2^31");
   const size_t need = arx_sample_wor_workspace_bytes(n);
@@ -95,7 +148,7 @@ int arx_sample_wor(const float* weights, int64_t n, int64_t S, uint64_t seed, ui
     int64_t g = ceil_div(n, 256);
     const int64_t cap = (int64_t)cu_count() * 16;
     if (g > cap) g = cap;
-    k_race_keys<<<(int)g, 256, 0, s>>>(weights, n, seed, counter, keys_raw);
+    k_race_keys<<<(int)g, 256, 0, s>>>(weights, n, seed, counter, key_cap, keys_raw);
     ARX_CHECK_LAUNCH();
   }
   // 31 key bits (positive floats below +inf); +inf (= sentinel) entries are dropped

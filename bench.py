@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3mix"],
                     help="headline workload (default c3 = BASELINE configs[2], HET layout)")
     ap.add_argument("--mulhot", action="store_true", help="(compat) same as --workload c3")
-    ap.add_argument("--subs", default="c2,c3mix,c4,c4mce,k1",
+    ap.add_argument("--subs", default="c2,c3mix,c4,c4mce,k1,c5w1",
                     help="comma list of sub-results besides the headline ('' = none)")
     ap.add_argument("--sub-steps", type=int, default=50)
     ap.add_argument("--n-items", type=int, default=None,
@@ -495,6 +495,28 @@ def run_lstm(args, loss, steps, warmup):
     return out
 
 
+def run_sharded_world1(args):
+    """The N > 1 code path (arx.dist.ShardedHMF, BASELINE configs[4]: 100 M-item table) on ONE rank:
+    every exchange is a local copy.  This -- not the hipGraph single-process headline above, which
+    is another workload (C3, 1 M items) -- is the N = 1 point of the weak-scaling curve that
+    `bench.py --gpus N` continues for N = 2, 4, 8."""
+    import copy
+    import torch.distributed as dist
+    from arx import dist as arx_dist
+    a = copy.copy(args)
+    a.n_items = 100000000
+    a.steps, a.warmup = args.sub_steps, min(args.warmup, 10)
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(29600 + os.getpid() % 300)),
+                 ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+        os.environ.setdefault(k, v)
+    try:
+        out = arx_dist.bench_run(a, 1, 0, 0)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    return {k: out[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "n_gpus", "config", "roofline")}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -534,6 +556,8 @@ def main():
                 r = k1_past_llc(torch.device('cuda', 0), args.dim)
                 if "roofline_gather" in out:
                     out["roofline_gather"]["past_llc"] = r
+            elif s == "c5w1":
+                r = run_sharded_world1(args)
             else:
                 continue
             sub[s] = r
@@ -541,7 +565,15 @@ def main():
             sub[s] = {"error": "%s: %s" % (type(e).__name__, e)}
     if sub:
         out["sub"] = sub
-    print(json.dumps(out))
+    # RCCL (the world-1 sharded sub-result) prints its version banner through C stdio: flush it out
+    # first so that the JSON line is the LAST line on stdout
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,6 +1,8 @@
-"""world_size-2 gloo test of the row-sharded HMF step (arx.dist.ShardedHMF):
+"""world_size-2 and -4 gloo tests of the row-sharded HMF step (arx.dist.ShardedHMF):
 the exchange / routing logic with a numpy compute double must reproduce the
-single-process oracle step on the global batch (loss and updated tables)."""
+single-process oracle step on the global batch (loss and updated tables) -- including
+steps whose targets are spread unevenly over the owners and a step in which some ranks
+own NO target row at all (R = 0: empty all_to_all blocks, empty gather / scatter sites)."""
 import os
 import sys
 
@@ -49,7 +51,7 @@ def _worker(rank, world, port, out_dir):
     pos = syn.positives_dict()
     ref.prepare_warp(pos, pos)
     rng = np.random.default_rng(5)          # identical stream on both ranks
-    for step in range(4):
+    for step in range(5):
         pool = None
         if step % 2 == 0:                   # stratified pool: S/world items per owner, owner-major
             blocks = []
@@ -70,6 +72,13 @@ def _worker(rank, world, port, out_dir):
         gi[1][2] = gi[1][3]
         if step == 0:
             gi[0][0] = pool[S // world]     # a target that is also a pool slot (owned by rank 1)
+        if step == 3:                       # every target owned by rank 0: R = 0 on all other ranks
+            for g in range(world):
+                gi[g] = (rng.integers(0, n_items // world, size=B_loc) * world).astype(gi[g].dtype)
+        if step == 4:                       # uneven: three quarters of the targets on the last owner
+            for g in range(world):
+                k_ = (3 * B_loc) // 4
+                gi[g][:k_] = rng.integers(0, (n_items - (world - 1) + world - 1) // world - 1, size=k_) * world + (world - 1)
         l_ref = ref.step(np.concatenate(gu).tolist(), np.concatenate(gi).tolist(), pool, id2idx,
                          loss='mw')
         model.step(gu[rank].astype(np.int32), gi[rank].astype(np.int32))
@@ -85,8 +94,9 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_step_matches_oracle_gloo_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_step_matches_oracle_gloo(tmp_path, world):
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 400)
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+    port = 29500 + (os.getpid() % 400) + world
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))

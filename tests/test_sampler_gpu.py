@@ -102,3 +102,46 @@ def test_device_sampler_feeds_model_pool(dev):
     assert np.all(np.isfinite(losses))
     p = sampler.sample(S).cpu().numpy()
     assert len(np.unique(p)) == S and p.min() >= 0 and p.max() < syn.n_items
+
+
+def test_item_frequency_on_device_matches_reference_helper(dev):
+    """arx_item_frequency (counts by integer atomics, p ~ (count/total)^power) against the host
+    helper that is pinned bit for bit to the reference (utils/prepare_train.py:19-35): same
+    probabilities for the seen items, zero for the unseen ones; DeviceSampler.from_interactions
+    draws from it."""
+    import torch
+    from arx.utils.prepare_train import DeviceSampler, item_frequency
+    rng = np.random.default_rng(4)
+    n_items, n = 5000, 60000
+    p = 1.0 / np.arange(1, n_items + 1) ** 1.1
+    items = rng.permutation(n_items)[rng.choice(n_items, size=n, p=p / p.sum())].astype(np.int32)
+    data = [(0, int(i), 0) for i in items]
+    pop, p_ref = item_frequency(data, 0.5)
+    s = DeviceSampler.from_interactions(torch.from_numpy(items).to(dev), n_items, power=0.5, device=dev, seed=3)
+    w = s.w.cpu().numpy().astype(np.float64)
+    cnt = s.counts.cpu().numpy()
+    assert np.array_equal(cnt, np.bincount(items, minlength=n_items))            # integer path: exact
+    np.testing.assert_allclose(w[pop] / w.sum(), np.asarray(p_ref), rtol=1e-5)
+    unseen = np.setdiff1d(np.arange(n_items), pop)
+    assert np.all(w[unseen] == 0.0)
+    draw = s.sample(256).cpu().numpy()
+    assert len(np.unique(draw)) == 256 and np.all(cnt[draw] > 0)                 # only seen items
+
+
+def test_capped_race_equals_uncapped(dev):
+    """arx_sample_wor_capped: dropping the keys above 8 S / sum(w) before the sort does not change the
+    draw (the S smallest keys are below the cap), for skewed weights over 3 M items."""
+    import torch
+    from arx import ops
+    rng = np.random.default_rng(9)
+    n, S = 3000000, 1024
+    w = (rng.random(n) ** 6).astype(np.float32)
+    w[rng.integers(0, n, 1000)] = 0.0
+    tw = torch.from_numpy(w).to(dev)
+    ws = ops.Workspace(dev)
+    a = torch.empty(S, dtype=torch.int32, device=dev)
+    b = torch.empty(S, dtype=torch.int32, device=dev)
+    for counter in (0, 7):
+        ops.sample_wor(tw, S, 5, counter, a, ws)
+        ops.sample_wor(tw, S, 5, counter, b, ws, key_cap=8.0 * S / float(w.astype(np.float64).sum()))
+        assert torch.equal(a, b) and int(a.min().item()) >= 0
