@@ -21,7 +21,9 @@ def main():
     dev = torch.device('cuda:0')
     d = 128
     rng = np.random.default_rng(0)
-    for V in (8192, 32768, 65536, 100002, 1000002, 4000000):
+    Vs = [int(v) for v in os.environ['GB_V'].split(',')] if os.environ.get('GB_V') else \
+        (8192, 32768, 65536, 100002, 1000002, 4000000)
+    for V in Vs:
         E = torch.randn(V, d, device=dev)
         for dist in ('uniform', 'zipf1.0'):
             n_items = nb

@@ -28,6 +28,8 @@ MAP = {
     'sparse_apply_small': ['k_sparse_onepass'],
     'sparse_finish': ['k_sparse_finish'],
     'radix_scatter': ['k_rs_scatter'],
+    'radix_hist': ['k_rs_hist'],
+    'bag_expand_heads': ['k_bag_expand_heads'],
 }
 
 
