@@ -81,6 +81,12 @@ PROTOTYPES = {
     "arx_loss_warp_fwdbwd_pos": (cint, [f32p, i64, i32p, i32p, i32p, i32p, i32p, i64, f32, f32p,
                                         i64, i64, f32p, f32p, i64, vp]),
     "arx_item_frequency": (cint, [i32p, i64, i64, i64, f32, i32p, f32p, vp]),
+    "arx_mw_gemm_fused_workspace_bytes": (sz, [i64, i64]),
+    "arx_mw_gemm_fused_fwd": (cint, [f32p, i64, f32p, i64, f32p, f32p, i64, f32p, i64, cint, i32p, i32p, i32p,
+                                     i32p, i64, f32, f32p, i64, i64, f32p, f32p, vp, i64, f32p, f32p, i64, f32p,
+                                     i64, f32p, i64, f32p, i64, vp, sz, vp]),
+    "arx_gemm_bits_f32": (cint, [cint, i64, i64, i64, vp, i64, f32p, i64, f32, f32p, i64, f32p, f32p, f32p,
+                                 vp, sz, vp]),
     "arx_sample_wor_workspace_bytes": (sz, [i64]),
     "arx_sample_wor": (cint, [f32p, i64, i64, u64, u64, i32p, vp, sz, vp]),
     "arx_sample_wor_capped": (cint, [f32p, i64, i64, u64, u64, f32, i32p, vp, sz, vp]),

@@ -268,13 +268,37 @@ class Prediction(Node):
 
     def __init__(self, rt, latent, pool_embed):
         super().__init__(rt, (latent.shape[0], pool_embed.shape[0]), (latent, pool_embed))
+        # set by BatchLoss('mw'): in train plans the loss node runs the scorer GEMM itself with the
+        # hinge in its epilogue (no [B, S] logits / dlogits in HBM); it leaves the 0/1 activity
+        # matrix as bits, the row factors g and g * U here for the two backward products
+        self.fused_into_loss = False
+        self.act_bits = self.gvec = self.Ug = None
 
     def forward(self, train):
+        if self.fused_into_loss and train:
+            return
         latent, pool = self.inputs
         ops.gemm(latent.value, pool.value, self.alloc_value(), self.rt.ws, transB=True,
                  col_bias=pool.bias_value)
 
+    def _backward_bits(self):
+        """dlogits = g_r * act[r, s]: dU += g * (act . Ibar), dIbar = act^T . (g * U), dbbar = act^T . g."""
+        latent, pool = self.inputs
+        if latent.requires_grad:
+            g = latent.alloc_grad()
+            ops.gemm_bits(self.act_bits, pool.value, g, self.rt.ws, beta=latent.grad_beta(), row_scale=self.gvec)
+        if pool.train_tables:
+            gp = pool.alloc_grad()
+            beta = pool.grad_beta()
+            tok = self.rt.fork(0)
+            ops.gemm_bits(self.act_bits, self.Ug, gp, self.rt.ws, transA=True, beta=beta, gvec=self.gvec,
+                          a_rowsum=pool.bias_grad)
+            self.rt._pending.append(self.rt.end_fork(tok))
+            pool.bias_grad_used = True
+
     def backward(self):
+        if self.fused_into_loss:
+            return self._backward_bits()
         latent, pool = self.inputs
         dl = self.grad
         if latent.requires_grad:
@@ -356,6 +380,7 @@ class BatchLoss(Node):
         # 'mw' over <= 2048 sampled columns with the in-kernel positive mask: the wave that owns
         # a row also forms its target score and the two rank-one gradients (2 launches less)
         self.fuse_ts = False
+        self.gemm_fused = False
         if (kind in ('mw', 'mce') and isinstance(target, TargetScore) and mask is not None and mask.fused
                 and not os.environ.get('ARX_LOSS_NOFUSE')):
             lat, te = target.inputs
@@ -363,12 +388,25 @@ class BatchLoss(Node):
             if W <= 2048 and W % 4 == 0 and d % 4 == 0 and d <= 256 and te.shape[1] == d:
                 self.fuse_ts = True
                 target.fused_into_loss = True
+                # ... and, for the plain pool scorer, the GEMM itself moves in (hinge epilogue)
+                B_ = logits.shape[0]
+                if (kind == 'mw' and type(logits) is Prediction and logits.inputs[0] is lat and d in (64, 128)
+                        and W % 32 == 0 and B_ % 32 == 0 and B_ >= 64 and W >= 64
+                        and os.environ.get('ARX_MW_GEMM_FUSE')):
+                    # OPT-IN (measured, C2 B=16384: 284 us/step against 248 with the separate loss
+                    # kernel): the loss-side HBM traffic drops from 4 passes over [B, S] fp32 to 2 MB
+                    # of bits, but the three GEMMs are MFMA-issue bound at ~56 % of peak whatever
+                    # feeds their A operand (a constant operand: 49 us; fp32 dlogits: 51; bits: 54),
+                    # and the hinge epilogue + pre / row kernels cost what the loss kernel did
+                    self.gemm_fused = True
+                    logits.fused_into_loss = True
 
     def forward(self, train):
         logits, target = self.inputs
         bl = self.alloc_value()
-        dl = logits.alloc_grad() if train else None
-        if train:
+        in_gemm = self.gemm_fused and train           # no [B, S] logits / dlogits at all
+        dl = logits.alloc_grad() if (train and not in_gemm) else None
+        if train and not in_gemm:
             logits.grad_beta()
         ms = self.mask
         fused = ms is not None and ms.fused
@@ -377,6 +415,10 @@ class BatchLoss(Node):
         if fused:
             ptr, items = ms.pos_getter()
             uid, i2s = ms.user_ids.value, ms.slot_map_getter()
+        if self.gemm_fused and train:
+            return self._forward_gemm_fused(bl, rw, uid, ptr, items, i2s)
+        if self.gemm_fused and logits.value is None:
+            raise RuntimeError("the 'mw' loss of a train-fused scorer cannot run forward-only")
         if self.kind in ('mw', 'mce'):        # sampled pool + separate target score ('mce': build-defined)
             kind = self.kind
             dt = target.alloc_grad() if train else None
@@ -426,6 +468,40 @@ class BatchLoss(Node):
                                self.rank_value, self.mask_rows)
             if fused:
                 ms.scatter(1)
+
+
+def _bl_forward_gemm_fused(self, bl, rw, uid, ptr, items, i2s):
+    """scorer GEMM + target score + 'mw' loss fwd/bwd in three launches (arx_mw_gemm_fused_fwd)."""
+    logits, target = self.inputs
+    lat, te = target.inputs
+    pool = logits.inputs[1]
+    rt = self.rt
+    B, S, d = logits.shape[0], logits.shape[1], lat.shape[1]
+    if logits.act_bits is None:
+        dev = rt.device
+        logits.act_bits = torch.zeros((S // 32, B), dtype=torch.int32, device=dev)      # word-major
+        logits.gvec = torch.empty((B,), dtype=torch.float32, device=dev)
+        logits.Ug = torch.empty((B, d), dtype=torch.float32, device=dev)
+    dt = target.alloc_grad()
+    target.grad_beta()
+    logits._grad_written = True                    # its backward consumes the bits
+    dU = dT = None
+    if lat.requires_grad:
+        dU = lat.alloc_grad()
+        if lat.grad_beta() != 0.0:
+            raise RuntimeError("fused target score must be the first writer of the latent gradient")
+    if te.train_tables:
+        dT = te.alloc_grad()
+        te.grad_beta()
+        te.bias_grad_used = True
+        if dt.data_ptr() != te.bias_grad.data_ptr():
+            raise RuntimeError("target-score gradient is expected to alias the bias gradient rows")
+    ops.mw_gemm_fused_fwd(lat.value, pool.value, pool.bias_value, te.value, te.bias_value, uid, ptr, items, i2s,
+                          bl, target.value, logits.act_bits, logits.gvec, logits.Ug, dt, dU, dT, self.gscale,
+                          rt.ws, row_w=rw, mask_rows=self.mask_rows)
+
+
+BatchLoss._forward_gemm_fused = _bl_forward_gemm_fused
 
 
 class MeanLoss(Node):

@@ -305,6 +305,33 @@ def loss_mw_fused_pos(logits, U, T, tbias, user_ids, pos_ptr, pos_items, item2sl
          _ld(dU) if dU is not None else 0, _p(dT), _ld(dT) if dT is not None else 0, _stream())
 
 
+def mw_gemm_fused_fwd(U, P, pbias, T, tbias, user_ids, pos_ptr, pos_items, item2slot, batch_loss, tscore_out,
+                      act_bits, g_out, Ug, dtscore, dU, dT, gscale, ws, row_w=None, mask_rows=0):
+    """'mw' with the hinge in the scorer GEMM's epilogue (arx_mw_gemm_fused_fwd): act bits instead
+    of logits / dlogits.  act_bits: int32 [S / 32, B] (word-major)."""
+    B, S = int(U.shape[0]), int(P.shape[0])
+    wsp, wsn = ws.get(_lib.lib.arx_mw_gemm_fused_workspace_bytes(B, S))
+    call("arx_mw_gemm_fused_fwd", _p(U), _ld(U), _p(P), _ld(P), _p(pbias), _p(T), _ld(T), _p(tbias),
+         int(tbias.stride(0)) if tbias is not None else 1, int(U.shape[1]), _p(user_ids), _p(pos_ptr),
+         _p(pos_items), _p(item2slot), int(mask_rows), float(gscale), _p(row_w), B, S, _p(batch_loss),
+         _p(tscore_out), _p(act_bits), int(act_bits.stride(0)), _p(g_out), _p(Ug), _ld(Ug), _p(dtscore),
+         int(dtscore.stride(0)) if dtscore is not None else 1, _p(dU), _ld(dU) if dU is not None else 0,
+         _p(dT), _ld(dT) if dT is not None else 0, wsp, wsn, _stream())
+
+
+def gemm_bits(bits, B, C, ws, transA=False, beta=0.0, row_scale=None, gvec=None, a_rowsum=None):
+    """C = beta C + [row_scale *] op(A) . B with A a 0/1 matrix given as bits (arx_gemm_bits_f32)."""
+    # bits: [cols / 32, rows] word-major; NN: rows = M, cols = K; TN: rows = K, cols = M
+    if transA:
+        K, M = int(bits.shape[1]), int(C.shape[0])
+    else:
+        M, K = int(bits.shape[1]), int(B.shape[0])
+    N = int(C.shape[1])
+    wsp, wsn = ws.get(_lib.lib.arx_gemm_f32_workspace_bytes(M, N, K))
+    call("arx_gemm_bits_f32", int(bool(transA)), M, N, K, _p(bits), int(bits.stride(0)), _p(B), _ld(B),
+         float(beta), _p(C), _ld(C), _p(row_scale), _p(gvec), _p(a_rowsum), wsp, wsn, _stream())
+
+
 def loss_warp_pos(logits, target, user_ids, pos_ptr, pos_items, item2slot, batch_loss, dlogits,
                   gscale, row_w=None, mask_rows=0):
     B, V = int(logits.shape[0]), int(logits.shape[1])

@@ -105,6 +105,12 @@ int gemm_nt_smallk(int64_t M, int64_t N, int64_t K, float alpha, const float* A,
                    const float* B, int64_t ldb, float* C, int64_t ldc, const float* col_bias,
                    hipStream_t s);
 
+// gemm_nt.hip: the same GEMM with the WMRB hinge epilogue -- act bits + per-(split, row) partial
+// sums instead of logits (see HingeOut); N % 32 == 0.
+int gemm_nt_hinge(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                  int64_t ldb, const float* col_bias, const float* tscore, uint32_t* bits,
+                  int64_t ldbits, float* rs_part, float* cnt_part, int* nsplit_out, hipStream_t s);
+
 // gemm_dma.hip: NN / TN GEMMs with N <= 128 (dU, dI): LDS-DMA streamed operands, dL read once.
 bool gemm_dma_supported(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,
                         int64_t lda, const float* B, int64_t ldb);
@@ -113,6 +119,12 @@ int gemm_dma_launch(int transA, int64_t M, int64_t N, int64_t K, float alpha, co
                     int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc,
                     const float* col_bias, float* partial, int bm, int splits, int64_t kchunk,
                     float* a_rowsum, float* rowsum_partial, hipStream_t s);
+
+// bit-matrix A operand (see k_gemm_dma_bits); same planning as gemm_dma_launch
+int gemm_dma_bits_launch(int transA, int64_t M, int64_t N, int64_t K, const uint32_t* bits, int64_t ldw,
+                         const float* B, int64_t ldb, float beta, float* C, int64_t ldc,
+                         const float* row_scale, const float* gvec, float* partial, int bm, int splits,
+                         int64_t kchunk, float* a_rowsum, float* rowsum_partial, hipStream_t s);
 
 // topk.hip: radix-select top-k of every row (k <= 1024); indices are offset by idx_base.
 int topk_select_launch(const float* logits, int64_t ld, int64_t B, int64_t V, int k, int32_t idx_base,

@@ -39,15 +39,16 @@ __device__ __forceinline__ int nt_swz(int r) {
 
 // HINGE epilogue (WMRB 'mw' training, embed_attribute.py:641-649): the logits never reach HBM.
 // With t_r the row's target score the tile epilogue forms v = x - t_r + 1 and emits
-//   * one BIT per logit, act = (v > 0), packed along the pool axis (bits[r][col / 32]): the 0/1
-//     matrix the WMRB gradient is made of (dlogits = g_r * act), 32x smaller than fp32 logits and
-//     64x less traffic than logits + dlogits;
+//   * one BIT per logit, act = (v > 0), packed along the pool axis and stored WORD-MAJOR
+//     (bits[(col / 32) * ldbits + r]: the 32-slot word of row r; both backward products then fetch
+//     the words of a tile as one contiguous run): the 0/1 matrix the WMRB gradient is made of
+//     (dlogits = g_r * act), 32x smaller than fp32 logits and 64x less traffic than logits + dlogits;
 //   * per (column split, row) partial sums of act * v and of act (summed in fixed order by the
 //     row kernel in loss.hip, which also takes the user's positives out again).
 struct HingeOut {
   const float* tscore;      // [M]
-  uint32_t* bits;           // [M][ldbits]
-  int64_t ldbits;           // words per row (>= N / 32)
+  uint32_t* bits;           // [N / 32][ldbits]
+  int64_t ldbits;           // rows per word plane (>= M)
   float* rs_part;           // [nsplit][M]  sum of act * v over the split's columns
   float* cnt_part;          // [nsplit][M]  number of active columns
 };
@@ -191,6 +192,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
     if constexpr (HINGE) {
       float pv[16];
       const float* tp = sT + wave * 32 + 4 * lhi;
+      const bool full = (n0 + kNtBN <= N) && (m0 + wave * 32 + 32 <= M);     // interior tile: no edge tests
+      const float c0 = bias0 + 1.f, c1 = bias1 + 1.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 t4 = *reinterpret_cast<const float4*>(tp + 8 * q);     // rows 8q + 4 lhi + {0..3}
@@ -199,19 +202,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
         for (int u = 0; u < 4; ++u) {
           const int e = 4 * q + u;                       // ro = (e & 3) + 8 * (e >> 2) = u + 8 q
           const int ro = u + 8 * q;
-          const bool rok = rbase + ro < M;
-          const float v0 = alpha * acc0[e] + bias0 - tq[u] + 1.f;
-          const float v1 = alpha * acc1[e] + bias1 - tq[u] + 1.f;
-          const bool a0 = rok && (n0 + l31 < N) && (v0 > 0.f);
-          const bool a1 = rok && (n0 + 32 + l31 < N) && (v1 > 0.f);
+          const float v0 = alpha * acc0[e] + (c0 - tq[u]);
+          const float v1 = alpha * acc1[e] + (c1 - tq[u]);
+          bool a0 = v0 > 0.f, a1 = v1 > 0.f;
+          if (!full) {
+            const bool rok = rbase + ro < M;
+            a0 = a0 && rok && (n0 + l31 < N);
+            a1 = a1 && rok && (n0 + 32 + l31 < N);
+          }
           pv[e] = (a0 ? v0 : 0.f) + (a1 ? v1 : 0.f);
           const unsigned long long b0 = __ballot(a0), b1 = __ballot(a1);   // lanes 0-31: lhi 0 rows, 32-63: lhi 1
           cnt_lo[e] += __popc((uint32_t)b0) + __popc((uint32_t)b1);
           cnt_hi[e] += __popc((uint32_t)(b0 >> 32)) + __popc((uint32_t)(b1 >> 32));
-          if (l31 == 0 && rok) {
-            uint32_t* wp = ho.bits + (rbase + ro) * ho.ldbits + (n0 >> 5);
+          if (l31 == 0 && rbase + ro < M) {
+            uint32_t* wp = ho.bits + (n0 >> 5) * ho.ldbits + (rbase + ro);
             if (n0 < N) wp[0] = (uint32_t)(lhi ? (b0 >> 32) : b0);
-            if (n0 + 32 < N) wp[1] = (uint32_t)(lhi ? (b1 >> 32) : b1);
+            if (n0 + 32 < N) wp[ho.ldbits] = (uint32_t)(lhi ? (b1 >> 32) : b1);
           }
         }
       }
@@ -271,6 +277,38 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
 }
 
 }  // namespace
+
+// Returns ARX_EUNSUPPORTED when the shape is not this kernel's (caller falls back to the
+// tiled kernel): K in {32, 64, 128}, 16-byte aligned operands.
+int gemm_nt_smallk(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                   const float* B, int64_t ldb, float* C, int64_t ldc, const float* col_bias,
+                   hipStream_t s) {
+  if (!(K == 32 || K == 64 || K == 128)) return ARX_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) ||
+      (lda % 4) || (ldb % 4))
+    return ARX_EUNSUPPORTED;
+  const int64_t panels = ceil_div(M, (int64_t)kNtBM);
+  const int64_t tiles_n = ceil_div(N, (int64_t)kNtBN);
+  // enough workgroups for two per CU; each keeps >= 1 tile
+  int64_t nsplit = ceil_div((int64_t)cu_count() * 2, panels);
+  if (nsplit > tiles_n) nsplit = tiles_n;
+  if (nsplit < 1) nsplit = 1;
+  const int64_t tpb = ceil_div(tiles_n, nsplit);
+  nsplit = ceil_div(tiles_n, tpb);
+  const int64_t grid = panels * nsplit;
+  if (grid > 0x7fffffff) return ARX_EUNSUPPORTED;
+  if (K == 128)
+    k_gemm_nt_areg<128><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, alpha, C, ldc, col_bias,
+                                                   (int)tpb, (int)nsplit, HingeOut{});
+  else if (K == 64)
+    k_gemm_nt_areg<64><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, alpha, C, ldc, col_bias,
+                                                  (int)tpb, (int)nsplit, HingeOut{});
+  else
+    k_gemm_nt_areg<32><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, alpha, C, ldc, col_bias,
+                                                  (int)tpb, (int)nsplit, HingeOut{});
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
 
 // The same GEMM with the WMRB hinge epilogue (no logits written).  *nsplit_out = column splits
 // the partial sums are laid out for (rs_part / cnt_part hold nsplit x M floats each; nsplit <= N/64).

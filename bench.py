@@ -191,16 +191,38 @@ def kernel_rooflines(model, d):
     res = {}
     # --- GEMMs (MFMA bound) ---
     flops = 2.0 * B * S * d
-    t = _evt_time_ms(lambda: ops.gemm(latent.value, pool.value, pred.value, ws, transB=True,
-                                      col_bias=pool.bias_value), 50)
-    res['gemm_logits_nt'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9)
-    dl = pred.grad
-    gU = latent.alloc_grad()
-    t = _evt_time_ms(lambda: ops.gemm(dl, pool.value, gU, ws), 50)
-    res['gemm_dU_nn'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9)
-    gP = pool.alloc_grad()
-    t = _evt_time_ms(lambda: ops.gemm(dl, latent.value, gP, ws, transA=True), 50)
-    res['gemm_dI_tn'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9)
+    if pred.fused_into_loss:
+        # 'mw' train plans: the scorer GEMM carries the hinge in its epilogue (act bits instead of
+        # logits), the backward products read the bits (arx_mw_gemm_fused_fwd / arx_gemm_bits_f32)
+        bl = [n for n in plan.order if isinstance(n, G.BatchLoss) and n.gemm_fused][0]
+        ms = bl.mask
+        ptr, items = ms.pos_getter()
+        uid, i2s = ms.user_ids.value, ms.slot_map_getter()
+        tgt = bl.inputs[1]
+        lat_, te = tgt.inputs
+        t = _evt_time_ms(lambda: ops.mw_gemm_fused_fwd(
+            lat_.value, pool.value, pool.bias_value, te.value, te.bias_value, uid, ptr, items, i2s, bl.value,
+            tgt.value, pred.act_bits, pred.gvec, pred.Ug, tgt.grad, lat_.grad, te.grad, bl.gscale, ws,
+            mask_rows=bl.mask_rows), 50)
+        res['gemm_logits_hinge_fused'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9,
+                                              note="target score + scorer GEMM with hinge epilogue + row kernel")
+        gU, gP = latent.alloc_grad(), pool.alloc_grad()
+        t = _evt_time_ms(lambda: ops.gemm_bits(pred.act_bits, pool.value, gU, ws, beta=1.0, row_scale=pred.gvec), 50)
+        res['gemm_dU_bits'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9)
+        t = _evt_time_ms(lambda: ops.gemm_bits(pred.act_bits, pred.Ug, gP, ws, transA=True, gvec=pred.gvec,
+                                               a_rowsum=pool.bias_grad), 50)
+        res['gemm_dI_bits'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9)
+    else:
+        t = _evt_time_ms(lambda: ops.gemm(latent.value, pool.value, pred.value, ws, transB=True,
+                                          col_bias=pool.bias_value), 50)
+        res['gemm_logits_nt'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9)
+        dl = pred.grad
+        gU = latent.alloc_grad()
+        t = _evt_time_ms(lambda: ops.gemm(dl, pool.value, gU, ws), 50)
+        res['gemm_dU_nn'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9)
+        gP = pool.alloc_grad()
+        t = _evt_time_ms(lambda: ops.gemm(dl, latent.value, gP, ws, transA=True), 50)
+        res['gemm_dI_tn'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9)
     # --- gathers (HBM bound): algorithmic bytes per SURVEY 8(d) ---
     for n in plan.order:
         if isinstance(n, G.EntityEmbed):

@@ -272,6 +272,41 @@ int arx_loss_mw_fused_pos(const float* logits, int64_t ldl, const float* U, int6
                           float* tscore_out, float* dtscore, int64_t dtscore_stride, float* dU,
                           int64_t lddu, float* dT, int64_t lddt, void* stream);
 
+/* 'mw' with the hinge folded into the scorer GEMM (embed_attribute.py:148-206 get_prediction on
+ * the sampled pool + :208-220 get_target_score + :641-649 the 'mw' loss, fwd + bwd): the [B, S]
+ * logits and their gradient never reach HBM.  Forward (three launches):
+ *   t_r = U_r . T_r + tbias_r;   x = U . P^T + pbias  (fp32 MFMA, not stored);
+ *   act[r, s] = mask[r, s] and (x[r, s] - t_r + 1 > 0)  -> act_bits, WORD-MAJOR: bit (s & 31) of
+ *   act_bits[(s >> 5) * ldbits + r], ldbits >= B (so that the 32-slot words of consecutive rows are
+ *   contiguous: what both backward products fetch per tile);
+ *   loss_r = log(1 + sum_s act * (x - t + 1));  g_r = gscale * row_w_r / (1 + sum);  dt_r = -g_r * #act
+ * with the mask built from the positives CSR as in arx_loss_mw_fwdbwd_pos.  Outputs: batch_loss
+ * [B], tscore_out [B] (nullable), act_bits, g_out [B], Ug = g * U [B, d] (the B operand of the dI
+ * product), dtscore (stride dtscore_stride), dU = dt * T and dT = dt * U (nullable).  The backward
+ * products then read the bits: arx_gemm_bits_f32.  d in {32, 64, 128}, S % 32 == 0, S <= 2048.
+ * workspace >= arx_mw_gemm_fused_workspace_bytes(B, S). */
+size_t arx_mw_gemm_fused_workspace_bytes(int64_t B, int64_t S);
+int arx_mw_gemm_fused_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp, const float* pbias,
+                          const float* T, int64_t ldt, const float* tbias, int64_t tb_stride, int d,
+                          const int32_t* user_ids, const int32_t* pos_ptr, const int32_t* pos_items,
+                          const int32_t* item2slot, int64_t mask_rows, float gscale, const float* row_w,
+                          int64_t B, int64_t S, float* batch_loss, float* tscore_out, uint32_t* act_bits,
+                          int64_t ldbits, float* g_out, float* Ug, int64_t ldug, float* dtscore,
+                          int64_t dtscore_stride, float* dU, int64_t lddu, float* dT, int64_t lddt,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/* GEMM whose A operand is a 0/1 matrix given as bits (the act_bits above); fp32 MFMA, B and C fp32.
+ * act[r][c] = bit (c & 31) of bits[(c >> 5) * ldw + r]  (word-major, ldw >= number of rows r).
+ *   transA = 0:  C[m, :] = beta * C[m, :] + row_scale[m] * sum_k act[m][k] B[k, :]      (dU += g * (act . P))
+ *   transA = 1:  C[m, :] = beta * C[m, :] + sum_k act[k][m] B[k, :],  a_rowsum[m] = sum_k act[k][m] gvec[k]
+ *                                                                          (dI = act^T . (g * U), dbias)
+ * row_scale nullable (1); gvec required for transA = 1, a_rowsum nullable.  32 < N <= 128, N % 4 == 0,
+ * M >= 64, M % 4 == 0 (M % 32 == 0 for transA = 1), K % 32 == 0, 16-byte aligned B rows.
+ * workspace >= arx_gemm_f32_workspace_bytes(M, N, K). */
+int arx_gemm_bits_f32(int transA, int64_t M, int64_t N, int64_t K, const uint32_t* bits, int64_t ldw,
+                      const float* B, int64_t ldb, float beta, float* C, int64_t ldc,
+                      const float* row_scale, const float* gvec, float* a_rowsum, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* Sampled softmax ('mce').  BUILD-DEFINED: the reference accepts loss 'mce'
  * (embed_attribute.py:527 assert, :717 feed guard, run_hmf.py:31,100, lstm/run.py:447) but its
  * compute_loss has no branch for it (:529-549).  Defined here in the shape of 'mw' (:641-649):

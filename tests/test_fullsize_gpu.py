@@ -84,7 +84,12 @@ def test_fullsize_locality_conservation_and_update(dev, mulhot):
     ts = [n for n in plan.order if isinstance(n, G.TargetScore)][0]
     # loss = mean of the row losses; WMRB gradient conservation (dt = - sum_s dlogits)
     np.testing.assert_allclose(loss, float(bl.value.double().mean().item()), rtol=1e-6)
-    dl = pred.grad.double()
+    if pred.fused_into_loss:      # hinge in the scorer GEMM's epilogue: dlogits = g_r * act bits
+        w = np.ascontiguousarray(pred.act_bits.cpu().numpy().T).view(np.uint32)     # word-major -> [B][S/32]
+        act = ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(w.shape[0], -1)
+        dl = torch.from_numpy(act.astype(np.float64)).to(d_) * pred.gvec.double()[:, None]
+    else:
+        dl = pred.grad.double()
     dt = ts.grad.double()
     np.testing.assert_allclose(dl.sum(1).cpu().numpy(), -dt.cpu().numpy(), rtol=1e-5, atol=1e-12)
     assert float(dl.min().item()) >= 0.0 and float(dt.max().item()) <= 0.0

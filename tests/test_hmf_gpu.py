@@ -326,3 +326,32 @@ def test_hmf_mw_eval_unmasked_switch(dev):
             want = np.log1p(np.maximum(x - t[:, None] + 1.0, 0.0).sum(1)).mean()
             np.testing.assert_allclose(losses[True], want, rtol=RTOL)
     assert losses[True] > losses[False]            # the masked form drops the positives' hinge terms
+
+
+@pytest.mark.parametrize("cfg,d", [(CFG_ID, 128), (CFG_HET, 64)])
+def test_hmf_mw_scorer_gemm_with_hinge_epilogue(dev, monkeypatch, cfg, d):
+    """ARX_MW_GEMM_FUSE=1 (opt-in): the scorer GEMM carries the WMRB hinge in its epilogue (act bits
+    instead of [B, S] logits / dlogits), the backward products read the bits -- same steps as the
+    default path, against the oracle."""
+    monkeypatch.setenv('ARX_MW_GEMM_FUSE', '1')
+    from arx import graph as G
+    B, S = 64, 256
+    syn, model, ref = _build(cfg, 'mw', d, B, S, seed=5)
+    rng = np.random.default_rng(13)
+    last = None
+    for step in range(4):
+        users, items = syn.sample_batch(B, rng)
+        users[1] = users[0]
+        pool = id2idx = None
+        if step % 2 == 0:
+            pool = syn.sample_pool(S, rng)
+            pool[:4] = items[:4]                 # targets inside the pool -> masked, bit cleared
+            pool = np.unique(pool)
+            pool = np.concatenate([pool, np.setdiff1d(syn.item_population, pool)[:S - len(pool)]]).astype(np.int32)
+            id2idx = last = {int(v): i for i, v in enumerate(pool)}
+        l_ref = ref.step(list(users), list(items), pool, id2idx or last, loss='mw')
+        l_got = model.step(None, list(users), list(items), None, pool, id2idx, loss='mw')
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='step %d' % step)
+        _compare_state(model, ref)
+    plan = model._plan('train')
+    assert any(isinstance(n, G.BatchLoss) and n.gemm_fused for n in plan.order)     # the path under test ran

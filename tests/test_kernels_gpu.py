@@ -999,3 +999,113 @@ def test_sparse_adagrad_bags(dev, d, n_ent, Vf, max_len, ns, phases):
     ops.sparse_adagrad_bags(tE, tacc, None, None, tv, tst, tl, args, tG, None, lr_dev, ops.Workspace(dev),
                             gscale_dev=gs_dev)
     np.testing.assert_allclose(tE.cpu().numpy(), rE, rtol=2e-4, atol=2e-5)
+
+
+def _unpack_bits(words, n):
+    w = words.astype(np.uint32)
+    return ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(w.shape[0], -1)[:, :n].astype(bool)
+
+
+@pytest.mark.parametrize("B,S,d", [(16384, 1024, 128), (320, 256, 64), (96, 64, 32), (1024, 2048, 128), (77, 96, 64)])
+def test_mw_gemm_fused_fwd(dev, B, S, d):
+    """'mw' with the hinge in the scorer GEMM's epilogue: loss, g, dt, rank-one terms and the act
+    BITS against the oracle's logits -> compute_loss('mw') -> compute_loss_bwd chain
+    (embed_attribute.py:148-206, 208-220, 641-649), positives of the row's user masked."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(B + S)
+    U = (rng.standard_normal((B, d)) * 0.3).astype(np.float32)
+    P = (rng.standard_normal((S, d)) * 0.3).astype(np.float32)
+    pb = (rng.standard_normal(S) * 0.1).astype(np.float32)
+    T = (rng.standard_normal((B, d)) * 0.3).astype(np.float32)
+    tb = (rng.standard_normal(B) * 0.1).astype(np.float32)
+    n_items, n_users = 5 * S, 50
+    pool = rng.permutation(n_items)[:S].astype(np.int32)
+    i2s = np.full(n_items + 1, -1, dtype=np.int32)
+    i2s[pool] = np.arange(S, dtype=np.int32)
+    npos = rng.integers(0, 30, size=n_users)
+    ptr = np.concatenate([[0], np.cumsum(npos)]).astype(np.int32)
+    pitems = rng.integers(0, n_items, size=int(ptr[-1])).astype(np.int32)     # duplicates happen
+    users = rng.integers(0, n_users, size=B).astype(np.int32)
+    rw = rng.random(B).astype(np.float32)
+    gscale = 1.0 / B
+    # oracle
+    logits = U.astype(np.float64) @ P.astype(np.float64).T + pb
+    t = (U.astype(np.float64) * T).sum(1) + tb
+    mask = np.ones((B, S), dtype=bool)
+    for r, u in enumerate(users):
+        sl = i2s[pitems[ptr[u]:ptr[u + 1]]]
+        mask[r, sl[sl >= 0]] = False
+    e = rg.RefEmbeddingAttribute.__new__(rg.RefEmbeddingAttribute)
+    e.dt = np.dtype(np.float64)
+    bl, cache = e.compute_loss(logits, t, 'mw', mask)
+    dl, dt = e.compute_loss_bwd(cache, rw.astype(np.float64) * gscale)
+    g = rw.astype(np.float64) * gscale / (1.0 + cache['s'])
+    # device
+    f32, i32 = torch.float32, torch.int32
+    out_bl, out_t, out_g = (torch.empty(B, dtype=f32, device=dev) for _ in range(3))
+    bits = torch.zeros((S // 32, B), dtype=i32, device=dev)             # word-major [S / 32][B]
+    Ug, dU, dT = (torch.empty((B, d), dtype=f32, device=dev) for _ in range(3))
+    dts = torch.empty(B, dtype=f32, device=dev)
+    ws = ops.Workspace(dev)
+    tU, tP = _t(dev, U), _t(dev, P)
+    ops.mw_gemm_fused_fwd(tU, tP, _t(dev, pb), _t(dev, T), _t(dev, tb), _t(dev, users), _t(dev, ptr),
+                          _t(dev, pitems), _t(dev, i2s), out_bl, out_t, bits, out_g, Ug, dts, dU, dT, gscale, ws,
+                          row_w=_t(dev, rw))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out_t.cpu().numpy(), t, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out_bl.cpu().numpy(), bl, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out_g.cpu().numpy(), g, rtol=RTOL, atol=1e-10)
+    np.testing.assert_allclose(dts.cpu().numpy(), dt, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(Ug.cpu().numpy(), g[:, None] * U, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(dU.cpu().numpy(), dt[:, None] * T, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(dT.cpu().numpy(), dt[:, None] * U, rtol=RTOL, atol=1e-9)
+    act = _unpack_bits(np.ascontiguousarray(bits.cpu().numpy().T).view(np.uint32), S)
+    diff = act != cache['act']
+    v = logits - t[:, None] + 1
+    assert np.all(np.abs(v[diff]) < 1e-5) and diff.sum() <= max(3, B * S // 100000)   # fp32 borderline only
+    assert not np.any(act & ~mask)                                  # masked positives carry no bit
+    if B % 32 or d <= 32:   # the bit-operand products need B % 32 == 0 and d > 32 (the plan falls back otherwise)
+        return
+    # ---- the backward products read the bits ----
+    dUx = dU.clone()
+    ops.gemm_bits(bits, tP, dUx, ws, beta=1.0, row_scale=out_g)                  # dU += g * (act . P)
+    exp = dt[:, None] * T + (dl @ P.astype(np.float64)) if not diff.any() else None
+    if exp is not None:
+        np.testing.assert_allclose(dUx.cpu().numpy(), exp, rtol=RTOL, atol=2e-8)
+    if B >= 64:
+        dI = torch.empty((S, d), dtype=f32, device=dev)
+        db = torch.empty(S, dtype=f32, device=dev)
+        ops.gemm_bits(bits, Ug, dI, ws, transA=True, gvec=out_g, a_rowsum=db)    # dI = act^T . (g U)
+        if not diff.any():
+            np.testing.assert_allclose(dI.cpu().numpy(), dl.T @ U.astype(np.float64), rtol=RTOL, atol=2e-8)
+            np.testing.assert_allclose(db.cpu().numpy(), dl.sum(0), rtol=RTOL, atol=2e-8)
+
+
+@pytest.mark.parametrize("M,N,K", [(16384, 128, 1024), (256, 64, 64), (4096, 128, 96), (64, 48, 2048)])
+def test_gemm_bits(dev, M, N, K):
+    """arx_gemm_bits_f32, both forms, against numpy on a random 0/1 matrix."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(M + N + K)
+    A = rng.random((M, K)) < 0.3
+    words = np.ascontiguousarray(np.packbits(A.reshape(M, K // 32, 32), axis=2, bitorder='little')
+                                 .view(np.uint32).reshape(M, K // 32).T)         # word-major [K / 32][M]
+    Bm = rng.standard_normal((K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    rs = rng.random(M).astype(np.float32)
+    ws = ops.Workspace(dev)
+    tb = _t(dev, words.view(np.int32))
+    C = _t(dev, C0)
+    ops.gemm_bits(tb, _t(dev, Bm), C, ws, beta=1.0, row_scale=_t(dev, rs))
+    exp = C0 + rs[:, None] * (A.astype(np.float64) @ Bm)
+    np.testing.assert_allclose(C.cpu().numpy(), exp, rtol=RTOL, atol=1e-4)
+    # transposed form: bits [K2 = M rows][M2 = K columns]
+    if K % 32 == 0 and K >= 64 and M % 32 == 0:
+        B2 = rng.standard_normal((M, N)).astype(np.float32)
+        g = rng.random(M).astype(np.float32)
+        C2 = torch.empty((K, N), dtype=torch.float32, device=dev)
+        r2 = torch.empty(K, dtype=torch.float32, device=dev)
+        ops.gemm_bits(tb, _t(dev, B2), C2, ws, transA=True, gvec=_t(dev, g), a_rowsum=r2)
+        np.testing.assert_allclose(C2.cpu().numpy(), A.T.astype(np.float64) @ B2, rtol=RTOL, atol=2e-4)
+        np.testing.assert_allclose(r2.cpu().numpy(), A.T.astype(np.float64) @ g, rtol=RTOL, atol=1e-4)

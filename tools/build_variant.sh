@@ -10,7 +10,7 @@ cd $ROOT/a-recsys_amd/csrc
 for f in *.hip; do
   o=$OBJ/${f%.hip}.o
   # only optim*.hip depend on the K7 macros; reuse the main build's objects for the rest
-  if [[ $f == optim* || ! -f $ROOT/a-recsys_amd/build/${f%.hip}.o ]]; then
+  if [[ $f == ${VARIANT_FILES:-optim}* || ! -f $ROOT/a-recsys_amd/build/${f%.hip}.o ]]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I. -Wno-unused-result "$@" -c $f -o $o &
   else
     cp $ROOT/a-recsys_amd/build/${f%.hip}.o $o
