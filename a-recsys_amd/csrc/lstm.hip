@@ -400,6 +400,184 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_wreg(
   }
 }
 
+// ---- d = h = 64, FOUR batch rows per workgroup (v_mfma_f32_4x4x1_16b_f32) ----------------------
+// The 16-row kernels above put B / 16 workgroups on the chip: 64 of 256 CUs at the C4 batch
+// (B = 1024).  The 16-block 4x4x1 MFMA has the same flop rate (512 flop / 8 cycles per SIMD) with a
+// 4-row A operand broadcast to its 16 blocks, so a workgroup can own FOUR complete batch rows --
+// B / 4 workgroups, every CU busy at B = 1024, no exchange between workgroups -- at unchanged MFMA
+// efficiency per row.  Operand / result layout (probed on gfx950, tools/probe/mfma4x4.hip):
+// lane l = 4 * block + j supplies A[block][i = l & 3] and B[block][j]; D[block][i][j] is VGPR i of
+// lane 4 * block + j.
+//   forward : block = one of the wave's 16 units, j = gate (i, j, f, o) => a wave forms the four
+//             gate pre-activations of 16 units x 4 rows per instruction chain over K = d + h = 128;
+//             W slice 128 VGPRs; a quad (the 4 gate lanes of a unit) exchanges its values with 16
+//             width-4 shuffles and lane j finishes row j.
+//   backward: thread (row, unit) does the element-wise part; for dh_{t-1} = dz_t . W_h^T the four
+//             waves split K = 4h (wave = gate), blocks x j = the 64 output units, partial sums meet
+//             in LDS and are added in wave order (fixed => deterministic).
+constexpr int kR4 = 4;
+
+template <int DIN>
+__global__ __launch_bounds__(256, 2) void k_lstm_fwd_r4(
+    const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+    int64_t L, int64_t B, float forget_bias, float* __restrict__ hs, float* __restrict__ cs,
+    float* __restrict__ gates) {
+  constexpr int H = 64, H4 = 256, SX = DIN + 4, SH = H + 4, NK = DIN + H;
+  static_assert(DIN == 64, "one x value per thread and step");
+  __shared__ __attribute__((aligned(16))) float xbuf[2][kR4 * SX];
+  __shared__ __attribute__((aligned(16))) float hbuf[2][kR4 * SH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = lane >> 2, j = lane & 3;
+  const int64_t row0 = (int64_t)blockIdx.x * kR4;
+  const int unit = wave * 16 + blk;
+  float wreg[NK];                                   // W[k][gate j of this unit]
+#pragma unroll
+  for (int k = 0; k < NK; ++k) wreg[k] = W[(int64_t)k * H4 + j * H + unit];
+  const float bv = bias[j * H + unit];
+  for (int i = threadIdx.x; i < kR4 * SH; i += 256) hbuf[0][i] = 0.f;
+  {
+    const int r = threadIdx.x / DIN, c = threadIdx.x % DIN;
+    const int64_t gr = row0 + r;
+    xbuf[0][r * SX + c] = (gr < B) ? x[gr * DIN + c] : 0.f;
+  }
+  float cprev = 0.f;                                // cell state of (row j, unit)
+  __syncthreads();
+  for (int64_t t = 0; t < L; ++t) {
+    const int cur = (int)(t & 1), nxt = cur ^ 1;
+    const float* xb = xbuf[cur] + j * SX;           // this lane supplies row i = j of the A operand
+    const float* hb = hbuf[cur] + j * SH;
+    float xn = 0.f;                                 // x_{t+1}: the load flies under the MFMAs
+    const int xr = threadIdx.x / DIN, xc = threadIdx.x % DIN;
+    if (t + 1 < L) xn = x[((t + 1) * B + min(row0 + xr, B - 1)) * DIN + xc];
+    f32x4 a0 = (f32x4){bv, bv, bv, bv}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+#pragma unroll
+    for (int ks = 0; ks < DIN / 4; ++ks) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + 4 * ks);
+      a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.x, wreg[4 * ks + 0], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.y, wreg[4 * ks + 1], a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.z, wreg[4 * ks + 2], a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.w, wreg[4 * ks + 3], a3, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < H / 4; ++ks) {
+      const float4 v = *reinterpret_cast<const float4*>(hb + 4 * ks);
+      a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.x, wreg[DIN + 4 * ks + 0], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.y, wreg[DIN + 4 * ks + 1], a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.z, wreg[DIN + 4 * ks + 2], a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.w, wreg[DIN + 4 * ks + 3], a3, 0, 0, 0);
+    }
+    // z[i] = pre-activation of gate j, unit, row i.  Quad exchange: lane j takes row j's four gates.
+    float zg[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float pick = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float zi = (a0[i] + a1[i]) + (a2[i] + a3[i]);
+        const float got = __shfl(zi, g, 4);         // row i, gate g of this unit
+        pick = (i == j) ? got : pick;
+      }
+      zg[g] = pick;
+    }
+    const float gi = sigmoidf_(zg[0]);
+    const float gj = tanhf(zg[1]);
+    const float gf = sigmoidf_(zg[2] + forget_bias);
+    const float go = sigmoidf_(zg[3]);
+    const float c = gf * cprev + gi * gj;
+    const float hh = go * tanhf(c);
+    cprev = c;
+    hbuf[nxt][j * SH + unit] = hh;
+    const int64_t gr = row0 + j;
+    if (gr < B) {
+      const int64_t o = t * B + gr;
+      hs[o * H + unit] = hh;
+      cs[o * H + unit] = c;
+      float* gp = gates + o * H4 + unit;
+      gp[0] = gi;
+      gp[H] = gj;
+      gp[2 * H] = gf;
+      gp[3 * H] = go;
+    }
+    if (t + 1 < L) xbuf[nxt][xr * SX + xc] = (row0 + xr < B) ? xn : 0.f;
+    __syncthreads();
+  }
+}
+
+template <int DIN>
+__global__ __launch_bounds__(256, 2) void k_lstm_bwd_r4(
+    const float* __restrict__ W, const float* __restrict__ cs, const float* __restrict__ gates,
+    const float* __restrict__ dhs, int64_t L, int64_t B, float* __restrict__ dz) {
+  constexpr int H = 64, H4 = 256, SZ = H4 + 4;
+  __shared__ __attribute__((aligned(16))) float zbuf[kR4 * SZ];
+  __shared__ __attribute__((aligned(16))) float part[4][kR4 * H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = lane >> 2, j = lane & 3;
+  const int64_t row0 = (int64_t)blockIdx.x * kR4;
+  // element-wise role: thread = (row = wave, unit = lane)
+  const int64_t gr = row0 + wave;
+  const bool live = gr < B;
+  const int64_t grc = live ? gr : B - 1;
+  // MFMA role: wave = K quarter (gate `wave` of dz), output unit 4 * blk + j
+  float wt[H];
+#pragma unroll
+  for (int kk = 0; kk < H; ++kk) wt[kk] = W[(int64_t)(DIN + 4 * blk + j) * H4 + wave * H + kk];
+  float dh_rec = 0.f, dc = 0.f;
+  float pg0, pg1, pg2, pg3, pc, pcp, pdh;
+  auto prefetch = [&](int64_t t) {
+    const int64_t o = t * B + grc;
+    const float* gp = gates + o * H4 + lane;
+    pg0 = gp[0]; pg1 = gp[H]; pg2 = gp[2 * H]; pg3 = gp[3 * H];
+    pc = cs[o * H + lane];
+    pcp = (t > 0) ? cs[(o - B) * H + lane] : 0.f;
+    pdh = dhs[o * H + lane];
+  };
+  if (L > 0) prefetch(L - 1);
+  for (int64_t t = L - 1; t >= 0; --t) {
+    float zi = 0.f, zj = 0.f, zf = 0.f, zo = 0.f;
+    if (live) {
+      const float gi = pg0, gj = pg1, gf = pg2, go = pg3;
+      const float dh = pdh + dh_rec;
+      const float tc = tanhf(pc);
+      const float d_o = dh * tc;
+      const float dcc = dc + dh * go * (1.f - tc * tc);
+      zi = dcc * gj * gi * (1.f - gi);
+      zj = dcc * gi * (1.f - gj * gj);
+      zf = dcc * pcp * gf * (1.f - gf);
+      zo = d_o * go * (1.f - go);
+      dc = dcc * gf;
+      float* zp = dz + (t * B + gr) * H4 + lane;
+      zp[0] = zi;
+      zp[H] = zj;
+      zp[2 * H] = zf;
+      zp[3 * H] = zo;
+    }
+    float* zb = zbuf + wave * SZ + lane;
+    zb[0] = zi;
+    zb[H] = zj;
+    zb[2 * H] = zf;
+    zb[3 * H] = zo;
+    __syncthreads();
+    if (t > 0) {
+      prefetch(t - 1);                              // in flight under the dh product
+      const float* ar = zbuf + j * SZ + wave * H;   // A operand: row i = j, this wave's K quarter
+      f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+#pragma unroll
+      for (int ks = 0; ks < H / 4; ++ks) {
+        const float4 v = *reinterpret_cast<const float4*>(ar + 4 * ks);
+        a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.x, wt[4 * ks + 0], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.y, wt[4 * ks + 1], a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.z, wt[4 * ks + 2], a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.w, wt[4 * ks + 3], a3, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[wave][i * H + 4 * blk + j] = (a0[i] + a1[i]) + (a2[i] + a3[i]);
+      __syncthreads();
+      dh_rec = (part[0][wave * H + lane] + part[1][wave * H + lane]) +
+               (part[2][wave * H + lane] + part[3][wave * H + lane]);
+    }
+  }
+}
+
 // ---- generic fallback (any din, h): one workgroup per batch row -------------
 __global__ __launch_bounds__(256) void k_lstm_fwd_generic(
     const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
@@ -494,7 +672,12 @@ int arx_lstm_fwd(const float* x, const float* W, const float* b, int64_t L, int6
   hipStream_t s = as_stream(stream);
   const bool mfma_ok = (h % 64 == 0) && (h <= 128) && (din % 4 == 0);
   static const bool wreg_off = getenv("ARX_LSTM_WREG_OFF") != nullptr;   // A/B aid
-  if (h == 64 && din == 64 && !wreg_off) {
+  // four-row workgroups while they fill the chip better than sixteen-row ones (B / 16 < 2 per CU)
+  static const bool r4_off = getenv("ARX_LSTM_R4_OFF") != nullptr;       // A/B aid
+  const bool r4 = !r4_off && h == 64 && din == 64 && ceil_div(B, kRows) < 2 * (int64_t)cu_count();
+  if (r4) {
+    k_lstm_fwd_r4<64><<<(int)ceil_div(B, kR4), 256, 0, s>>>(x, W, b, L, B, forget_bias, hs, cs, gates);
+  } else if (h == 64 && din == 64 && !wreg_off) {
     k_lstm_fwd_wreg<64><<<(int)ceil_div(B, kRows), 256, 0, s>>>(x, W, b, L, B, forget_bias, hs, cs,
                                                                    gates);
   } else if (mfma_ok) {
@@ -521,7 +704,11 @@ int arx_lstm_bwd(const float* W, const float* hs, const float* cs, const float* 
   hipStream_t s = as_stream(stream);
   const bool mfma_ok = (h % 64 == 0) && (h <= 128);
   static const bool wreg_off = getenv("ARX_LSTM_WREG_OFF") != nullptr;   // A/B aid
-  if (h == 64 && din == 64 && !wreg_off) {
+  static const bool r4_off = getenv("ARX_LSTM_R4_OFF") != nullptr;       // A/B aid
+  const bool r4 = !r4_off && h == 64 && din == 64 && ceil_div(B, kRows) < 2 * (int64_t)cu_count();
+  if (r4) {
+    k_lstm_bwd_r4<64><<<(int)ceil_div(B, kR4), 256, 0, s>>>(W, cs, gates, dhs, L, B, dz);
+  } else if (h == 64 && din == 64 && !wreg_off) {
     k_lstm_bwd_wreg<64><<<(int)ceil_div(B, kRows), 256, 0, s>>>(W, cs, gates, dhs, L, B, dz);
   } else if (mfma_ok) {
     const size_t lds = (size_t)(kRows * (4 * h + 2)) * sizeof(float);
