@@ -120,6 +120,11 @@ PROTOTYPES = {
     "arx_sparse_adagrad_bags": (cint, [cint, f32p, f32p, f32p, f32p, i64, cint, i32p, i32p, i32p, i64, cint,
                                        cint, C.POINTER(vp), C.POINTER(i64), C.POINTER(i32), C.POINTER(f32),
                                        f32p, i64, f32p, f32p, f32p, i32p, vp, sz, vp]),
+    "arx_segment_pool_fwd": (cint, [f32p, i64, i32p, i64, i64, cint, f32p, f32p, i64, vp]),
+    "arx_segment_pool_bwd": (cint, [f32p, i64, i32p, i64, i64, i64, cint, f32p, f32p, i64, f32p, i64, f32p, i64,
+                                    f32p, vp]),
+    "arx_max_argmax": (cint, [f32p, i64, i64, i64, i64, cint, f32p, i32p, vp]),
+    "arx_gmax_residual_bwd": (cint, [f32p, i32p, f32p, i64, f32p, cint, f32p, f32p, f32p, i64, vp]),
     "arx_adagrad_dense": (cint, [f32p, f32p, f32p, i64, f32p, f32p, vp]),
     "arx_sq_norm_accum": (cint, [f32p, i64, cint, f32p, f32p, vp]),
     "arx_clip_coef": (cint, [f32p, f32, f32p, f32p, vp]),

@@ -345,7 +345,7 @@ class EmbeddingAttribute(object):
         if key in self._pool_nodes:
             return self._pool_nodes[key]
         if output_feat not in (0, 1):
-            raise NotImplementedError('Error: Attribute combination not implemented!')  # :202 (2,3: max / lse)
+            raise ValueError("_pool_embed serves output_feat 0 / 1; 2 / 3 pool in score space (_pooled_prediction)")
         rt = self.rt
         ia = self.item_attributes
         if pool == 'sampled':
@@ -382,11 +382,73 @@ class EmbeddingAttribute(object):
         self._pool_nodes[key] = node
         return node
 
-    def get_prediction(self, latent, pool='full', device='/gpu:0', output_feat=1):
-        """embed_attribute.py:148-206 -> logits [rows(latent), V or n_sampled]."""
+    def get_prediction(self, latent, pool='full', device='/gpu:0', output_feat=1, pred_cls=None):
+        """embed_attribute.py:148-206 -> logits [rows(latent), V or n_sampled].
+        output_feat 0 / 1: embedding-space scorer (pool rows averaged first, one GEMM);
+        2 / 3: the multi-hot features pool their per-token SCORES (max / log-sum-exp, :194-200).
+        pred_cls: scorer node class (SeqModel passes its per-time-step variant)."""
         if isinstance(latent, list):
             raise NotImplementedError("per-feature latent lists (:169,178) are not implemented")
-        return G.Prediction(self.rt, latent, self._pool_embed(pool, output_feat))
+        mk = pred_cls or (lambda lat, pe: G.Prediction(self.rt, lat, pe))
+        if output_feat in (0, 1):
+            return mk(latent, self._pool_embed(pool, output_feat))
+        if output_feat not in (2, 3):
+            raise NotImplementedError('Error: Attribute combination not implemented!')    # :202
+        return self._pooled_prediction(latent, pool, output_feat, mk)
+
+    def _pool_ids_and_maps(self, pool):
+        """(ids node, per-feature maps in pool order, W): the sampled placeholder with the item
+        maps, or 0..V-1 with the logit-ordered copies (embed_attribute.py:100-108)."""
+        rt, ia = self.rt, self.item_attributes
+        key = ('ids', pool)
+        if key in self._pool_nodes:
+            return self._pool_nodes[key]
+        if pool == 'sampled':
+            ids = self.i_indices['sampled_pass']
+            feats = self._select_feats(self.item_out_feats, ia)
+            res = (ids, [(f.kind, f.table, f.maps, f.max_len) for f in feats], ids.shape[0], False)
+        else:
+            V = self.logit_size
+            full = self._pool_embed('full', 1)             # builds the logit-ordered maps once
+            res = (full.inputs[0], [(f.kind, f.table, f.maps, f.max_len) for f in full.feats], V, True)
+        self._pool_nodes[key] = res
+        return res
+
+    def _pooled_prediction(self, latent, pool, output_feat, mk):
+        """logits = mean over output features of: the plain score for a categorical feature, the
+        pooled token scores of a multi-hot one."""
+        rt = self.rt
+        ids, fmaps, W, static = self._pool_ids_and_maps(pool)
+        parts = []
+        for k, (kind, table, maps, max_len) in enumerate(fmaps):
+            if kind == 'cat':
+                pe = G.EntityEmbed(rt, ids, [G.Feature('cat', table, maps)], with_bias=True)
+                parts.append(mk(latent, pe))
+                continue
+            if static:
+                cap = int(maps[2].sum().item())
+            else:
+                cap = W * max_len
+            cap = (cap + 3) // 4 * 4
+            bag = G.BagTokens(rt, ids, maps, cap, static=static)
+            tokf = G.Feature('cat', table, (None,))
+            tokf._inj = False                   # bag tokens repeat: shared table rows (clip norm)
+            te = G.EntityEmbed(rt, bag, [tokf], with_bias=True)
+            scores = mk(latent, te)
+            gmax = None
+            if output_feat == 3:
+                if mk is not None and type(scores) is not G.Prediction:
+                    raise NotImplementedError("output_feat 3 under a per-time-step scorer (one reduce_max per "
+                                              "unrolled step) is not implemented")
+                gmax = G.GlobalMax(rt, latent, table)
+                vf = G.Feature('cat', table, (None,))
+                vf._inj = True
+                gmax.vstar = G.EntityEmbed(rt, G._IdsOf(rt, gmax, gmax.best_idx[1:2], 'gmax_row'), [vf],
+                                           with_bias=True)
+                for pnode in parts + [scores]:          # its backward must follow every scorer's
+                    pnode.extra_inputs = tuple(getattr(pnode, 'extra_inputs', ())) + (gmax,)
+            parts.append(G.SegmentPool(rt, scores, bag, W, output_feat, gmax))
+        return parts[0] if len(parts) == 1 else G.MeanOf(rt, parts)
 
     def get_target_score(self, latent, inds, device='/gpu:0'):
         """embed_attribute.py:208-220; `inds` is an item-index placeholder."""

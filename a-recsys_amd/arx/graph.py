@@ -316,6 +316,143 @@ class Prediction(Node):
             pool.bias_grad_used = True
 
 
+class BagTokens(Node):
+    """Packed bag tokens of a pool's items for ONE multi-hot feature (mulhot_index.py:48-67
+    batch_slice2 / batch_segids2 on device): value = token rows int32 [cap] (pads = row 0, their
+    scores are never pooled and their gradients are zero), offs int32 [W + 1]."""
+
+    def __init__(self, rt, ids_node, maps, cap, static=False):
+        super().__init__(rt, (cap,), (ids_node,))
+        self.name = 'bag_tokens'
+        self.maps, self.static, self._done = maps, static, False
+        W = ids_node.shape[0]
+        dev = rt.device
+        self.value = torch.zeros(cap, dtype=torch.int32, device=dev)
+        self.seg = torch.zeros(cap, dtype=torch.int32, device=dev)
+        self.offs = torch.zeros(W + 1, dtype=torch.int32, device=dev)
+        self.tot = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def forward(self, train):
+        if self.static and self._done:
+            return
+        vals, starts, lens = self.maps
+        ops.csr_expand(vals, starts, lens, self.inputs[0].value, self.shape[0], self.rt.ws, pad_token=0,
+                       pad_seg=0, out=(self.value, self.seg, self.offs, self.tot, None))
+        self._done = True
+
+
+class MeanOf(Node):
+    """tf.reduce_mean(innerps, 0) over the per-feature score matrices (embed_attribute.py:205)."""
+
+    requires_grad = True
+
+    def __init__(self, rt, parts):
+        super().__init__(rt, parts[0].shape, tuple(parts))
+
+    def forward(self, train):
+        out = self.alloc_value()
+        F = len(self.inputs)
+        for k, p in enumerate(self.inputs):
+            ops.axpby(1.0 / F, p.value, 1.0 if k else 0.0, out)
+
+    def backward(self):
+        F = len(self.inputs)
+        for p in self.inputs:
+            if p.requires_grad:
+                g = p.alloc_grad()
+                ops.axpby(1.0 / F, self.grad, p.grad_beta(), g)
+
+
+class GlobalMax(Node):
+    """score_max = tf.reduce_max(innerp) over the WHOLE feature table's score matrix
+    (embed_attribute.py:197): chunked scorer GEMM + running arg-max; nothing of size [B, Vf] is
+    kept.  backward: the gradient that flows through the max (collected by SegmentPool) goes to
+    its arg-max element -- table row v*, batch row r* -- through `vstar` (a one-row lookup)."""
+
+    requires_grad = True
+
+    def __init__(self, rt, latent, table, chunk=65536):
+        super().__init__(rt, (1,), (latent,))
+        self.table = table
+        dev = rt.device
+        self.best = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.best_idx = torch.zeros(2, dtype=torch.int32, device=dev)      # (batch row, table row)
+        self.resid = torch.zeros(1, dtype=torch.float32, device=dev)
+        V = int(table.E.shape[0])
+        self.chunk = min(V, int(chunk))
+        self._tmp = torch.empty((latent.shape[0], self.chunk), dtype=torch.float32, device=dev)
+        self.vstar = None            # EntityEmbed over the arg-max row, set by the builder
+
+    def forward(self, train):
+        lat = self.inputs[0]
+        E, b = self.table.E, self.table.bias
+        V = int(E.shape[0])
+        for c0 in range(0, V, self.chunk):
+            n = min(self.chunk, V - c0)
+            tmp = self._tmp[:, :n]
+            ops.gemm(lat.value, E[c0:c0 + n], tmp, self.rt.ws, transB=True,
+                     col_bias=b[c0:c0 + n] if b is not None else None)
+            ops.max_argmax(tmp, c0, c0 == 0, self.best, self.best_idx)
+
+    def backward(self):
+        lat, vs = self.inputs[0], self.vstar
+        dU = None
+        if lat.requires_grad:
+            dU = lat.alloc_grad()
+            if lat.grad_beta() == 0.0:
+                raise RuntimeError("the max residual must not be the first writer of the latent gradient")
+        rg = vs.alloc_grad()
+        vs.grad_beta()
+        vs.bias_grad_used = True
+        ops.gmax_residual_bwd(self.resid, self.best_idx, lat.value, vs.value, rg, vs.bias_grad, dU)
+
+
+class _IdsOf(Node):
+    """int32 view of another node's device index tensor (the arg-max row of GlobalMax)."""
+
+    def __init__(self, rt, parent, tensor, name):
+        super().__init__(rt, (tensor.shape[0],), (parent,))
+        self.name = name
+        self.value = tensor
+
+    def forward(self, train):
+        pass
+
+
+class SegmentPool(Node):
+    """embed_attribute.py:194-200: per-bag pooling of the token scores, output_feat 2 (segment_max)
+    or 3 (score_max + log(1 + segment_sum(exp(score - score_max))))."""
+
+    requires_grad = True
+
+    def __init__(self, rt, scores, bag, W, mode, gmax=None):
+        super().__init__(rt, (scores.shape[0], W), (scores, bag) + ((gmax,) if gmax is not None else ()))
+        self.mode, self.W, self.gmax = mode, W, gmax
+        self.extra_inputs = (gmax.vstar,) if gmax is not None else ()
+        self._resid_rows = None
+
+    def forward(self, train):
+        scores, bag = self.inputs[0], self.inputs[1]
+        ops.segment_pool_fwd(scores.value, bag.offs, self.W, self.mode, self.alloc_value(),
+                             gmax=self.gmax.best if self.gmax is not None else None)
+
+    def backward(self):
+        scores, bag = self.inputs[0], self.inputs[1]
+        ds = scores.alloc_grad()
+        if scores.grad_beta() != 0.0:
+            raise NotImplementedError("pooled token scores with a second consumer")
+        rr = None
+        if self.mode == 3:
+            if self._resid_rows is None:
+                self._resid_rows = torch.empty(self.shape[0], dtype=torch.float32, device=self.rt.device)
+            rr = self._resid_rows
+        ops.segment_pool_bwd(scores.value, bag.offs, self.W, self.mode, self.value, self.grad, ds,
+                             gmax=self.gmax.best if self.gmax is not None else None, resid_rows=rr)
+        if self.mode == 3:
+            ops.sum_scaled(rr, 1.0, self.gmax.resid)
+            self.gmax._grad_written = True            # its backward applies the residual (runs later)
+
+
 class TargetScore(Node):
     """embed_attribute.py:208-220 get_target_score."""
 
@@ -655,7 +792,7 @@ class Plan(object):
             if not os.environ.get('ARX_NO_MULTI_GATHER'):
                 for n in self.order:
                     if (isinstance(n, EntityEmbed) and len(n.feats) == 1 and n.feats[0].kind == 'cat'
-                            and not n.concat and getattr(n.inputs[0], 'value', None) is not None
+                            and not n.concat and type(n.inputs[0]).__name__ in ('IdsInput', 'IdsSlice')
                             and n.inputs[0].value.dtype == torch.int32):
                         groups.setdefault(n.shape[1], []).append(n)
             for d_, nodes in groups.items():

@@ -399,19 +399,20 @@ class SeqModel(SeqBatching):
         tid = view(self.target_ids_all, 'target_id_%d' % L)
         tgt = view(self.targets_all, 'target_%d' % L)
         bk = {'L': L, 'dropouts': bk_drop}
+        seq_pred = lambda lat, pe: SeqPrediction(rt, lat, pe, L, B)     # scorer of all L time steps at once
         if self.loss in ('mw', 'mce'):       # ('mce': build-defined sampled softmax, see arx.h)
-            logits = SeqPrediction(rt, hs, m._pool_embed('sampled', self.output_feat), L, B)  # :492
+            logits = m.get_prediction(hs, 'sampled', output_feat=self.output_feat, pred_cls=seq_pred)  # :492
             tscore = m.get_target_score(hs, tid)                                            # :493
             bl = m.compute_loss(logits, tscore, self.loss)
         else:
-            logits = SeqPrediction(rt, hs, m._pool_embed('full', self.output_feat), L, B)   # :484
+            logits = m.get_prediction(hs, 'full', output_feat=self.output_feat, pred_cls=seq_pred)   # :484
             bl = m.compute_loss(logits, tgt, self.loss)
         bk['train'] = SeqLoss(rt, bl, wn)
         bk['train_logits'] = logits
         # losses_full (:510): full-vocabulary loss for evaluation
         if self.loss in ('mw', 'mce'):
             wn2 = SeqWeights(rt, wn.inputs[0], L, B)
-            full = G.Prediction(rt, hs, m._pool_embed('full', self.output_feat))
+            full = m.get_prediction(hs, 'full', output_feat=self.output_feat)
             bl_full = m.compute_loss(full, tgt, 'warp' if self.loss == 'mw' else 'ce')
             bk['eval'] = SeqLoss(rt, bl_full, wn2)
         else:

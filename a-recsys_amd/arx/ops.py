@@ -513,6 +513,27 @@ def sparse_adagrad_bags(E, acc, bias, bias_acc, vals, starts, lens, site_args, G
          _p(gscale_dev), _p(aux_cnt), wsp, wsn, _stream())
 
 
+def segment_pool_fwd(scores, offs, W, mode, out, gmax=None):
+    call("arx_segment_pool_fwd", _p(scores), _ld(scores), _p(offs), int(scores.shape[0]), int(W), int(mode),
+         _p(gmax), _p(out), _ld(out), _stream())
+
+
+def segment_pool_bwd(scores, offs, W, mode, out, dout, dscores, gmax=None, resid_rows=None):
+    call("arx_segment_pool_bwd", _p(scores), _ld(scores), _p(offs), int(scores.shape[0]), int(W),
+         int(dscores.shape[1]), int(mode), _p(gmax), _p(out), _ld(out), _p(dout), _ld(dout), _p(dscores),
+         _ld(dscores), _p(resid_rows), _stream())
+
+
+def max_argmax(x, col_base, first, best, best_idx):
+    call("arx_max_argmax", _p(x), int(x.shape[0]), int(x.shape[1]), _ld(x), int(col_base), int(bool(first)),
+         _p(best), _p(best_idx), _stream())
+
+
+def gmax_residual_bwd(resid, idx, U, E_row, row_grad, bias_grad, dU):
+    call("arx_gmax_residual_bwd", _p(resid), _p(idx), _p(U), _ld(U), _p(E_row), int(U.shape[1]), _p(row_grad),
+         _p(bias_grad), _p(dU), _ld(dU) if dU is not None else 0, _stream())
+
+
 def adagrad_dense(w, acc, g, lr_dev, gscale_dev=None):
     call("arx_adagrad_dense", _p(w), _p(acc), _p(g), int(w.numel()), _p(lr_dev), _p(gscale_dev),
          _stream())

@@ -475,6 +475,34 @@ int arx_sparse_adagrad_bags(int phase, float* E, float* acc, float* bias, float*
                             int64_t ldg, const float* Gb, const float* lr_dev, const float* gscale_dev,
                             int32_t* aux_cnt, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- a8: output_feat 2 / 3 -- pooling over a bag in SCORE space ------------------------------
+ * embed_attribute.py:194-200.  scores [B, >= offs[W]] are the per-token scores of the pool's
+ * packed bag tokens (latent . E[tok] + b[tok]: arx_gemm_f32 over the gathered token rows); bag j
+ * is the column range [offs[j], offs[j+1]) (arx_csr_expand's offsets).
+ *   mode 2  out[r, j] = max over the bag                           (tf.segment_max, :195)
+ *   mode 3  out[r, j] = M + log(1 + sum exp(score - M)), M = *gmax_dev = reduce_max over the WHOLE
+ *           table's score matrix (:197-200; arx_max_argmax over chunks of the table)
+ * Backward: dscores [B, cap] (columns >= offs[W] zeroed); mode 2 sends the gradient to the arg-max
+ * entries (ties share equally, like tf.segment_max's gradient); mode 3 also writes, per row, the
+ * part of the gradient that flows through M (resid_rows[r] = sum_j dout / (1 + s)): its total goes
+ * to the arg-max element of the table's score matrix (arx_gmax_residual_bwd). */
+int arx_segment_pool_fwd(const float* scores, int64_t lds, const int32_t* offs, int64_t B, int64_t W,
+                         int mode, const float* gmax_dev, float* out, int64_t ldo, void* stream);
+int arx_segment_pool_bwd(const float* scores, int64_t lds, const int32_t* offs, int64_t B, int64_t W,
+                         int64_t cap, int mode, const float* gmax_dev, const float* out, int64_t ldo,
+                         const float* dout, int64_t ldd, float* dscores, int64_t ldds, float* resid_rows,
+                         void* stream);
+/* Running maximum and its FIRST arg-max (smallest (global column, row)) over x[rows, cols] whose
+ * columns are col_base.. of a wider matrix: best[0] = value, best_idx = {row, global column};
+ * first != 0 starts a new scan, otherwise the previous best takes part.  Deterministic. */
+int arx_max_argmax(const float* x, int64_t rows, int64_t cols, int64_t ld, int64_t col_base, int first,
+                   float* best, int32_t* best_idx, void* stream);
+/* row_grad[0..d) = resid * U[idx[0], :], bias_grad[0] = resid, dU[idx[0], :] += resid * E_row
+ * (E_row = the table row idx[1], already gathered); bias_grad / dU nullable. */
+int arx_gmax_residual_bwd(const float* resid_dev, const int32_t* idx_dev, const float* U, int64_t ldu,
+                          const float* E_row, int d, float* row_grad, float* bias_grad, float* dU,
+                          int64_t lddu, void* stream);
+
 /* ---- a16/a19: dense Adagrad, norms, clip ---------------------------------
  * tf.train.AdagradOptimizer dense apply; tf.clip_by_global_norm
  * (seqModel.py:180): coef = max_norm / max(sqrt(sq), max_norm). */

@@ -13,7 +13,7 @@ RTOL = 1e-4
 
 
 def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False, use_concat=False, num_layers=1,
-           keep=1.0, adagrad=True, buckets=None):
+           keep=1.0, adagrad=True, buckets=None, output_feat=1):
     from arx.attributes.embed_attribute import EmbeddingAttribute
     from arx.lstm.seqModel import SeqModel
     from arx.utils.synthetic import SyntheticHMF
@@ -41,13 +41,13 @@ def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False, use_concat=Fa
     emb = EmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i, params=params)
     model = SeqModel(buckets or [L], size, num_layers, clip, B, 0.5, 0.83, emb, loss=loss, use_concat=use_concat,
                      no_user_id=no_user_id, START_ID=START, params=params, dropoutRate=keep,
-                     withAdagrad=adagrad)
+                     withAdagrad=adagrad, output_feat=output_feat)
     remb = rg.RefEmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i,
                                     params={k: v for k, v in params.items() if not k.startswith('lstm')},
                                     dtype=np.float64)
     ref = ref_lstm.RefSeqModel(L, size, clip, B, 0.5, remb, loss=loss, no_user_id=no_user_id,
                                params=params, use_concat=use_concat, num_layers=num_layers,
-                               withAdagrad=adagrad)
+                               withAdagrad=adagrad, output_feat=output_feat)
     pos = syn.positives_dict()
     emb.prepare_warp(pos, pos)
     remb.prepare_warp(pos, pos)
@@ -129,6 +129,33 @@ def test_seq_mce_steps_match_oracle(dev, cfg):
         l_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, ps, id2idx)
         np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='loss step %d' % step)
         np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL)
+        _compare(emb, model, remb, ref)
+    e_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), None, id2idx, forward_only=True)
+    e_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, None, id2idx,
+                       forward_only=True)
+    np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
+
+
+@pytest.mark.parametrize("loss,S,clip", [('mw', 64, 0.5), ('ce', None, 5.0)])
+def test_seq_output_feat_2_max_pooled_scores(dev, loss, S, clip):
+    """output_feat = 2 (lstm/run.py:80 "2: use, max-pool"): the multi-hot output feature takes the
+    MAX of its bag's token scores (embed_attribute.py:195 tf.segment_max) -- score-space pooling,
+    gradient to the arg-max tokens (ties share), clip norm over the per-step dense table gradients."""
+    size, B, L = 64, 16, 4
+    syn, emb, model, remb, ref = _build(CFG_HET, loss, size, B, L, S, clip, seed=21, output_feat=2)
+    rng = np.random.default_rng(23)
+    pool = id2idx = None
+    if loss == 'mw':
+        pool = syn.sample_pool(S, rng)
+        id2idx = {int(v): i for i, v in enumerate(pool)}
+    for step in range(3):
+        users, inp, tg, w = _batch(syn, rng, L, B)
+        ps = pool if step == 0 else None
+        l_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), ps, id2idx)
+        l_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, ps, id2idx)
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='loss step %d' % step)
+        np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL,
+                                   err_msg='global norm step %d' % step)
         _compare(emb, model, remb, ref)
     e_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), None, id2idx, forward_only=True)
     e_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, None, id2idx,
