@@ -387,9 +387,11 @@ class EmbeddingAttribute(object):
         output_feat 0 / 1: embedding-space scorer (pool rows averaged first, one GEMM);
         2 / 3: the multi-hot features pool their per-token SCORES (max / log-sum-exp, :194-200).
         pred_cls: scorer node class (SeqModel passes its per-time-step variant)."""
-        if isinstance(latent, list):
-            raise NotImplementedError("per-feature latent lists (:169,178) are not implemented")
         mk = pred_cls or (lambda lat, pe: G.Prediction(self.rt, lat, pe))
+        if isinstance(latent, list):          # one latent per output feature (:169, :178)
+            if output_feat not in (1, 2, 3):
+                raise NotImplementedError('Error: Attribute combination not implemented!')
+            return self._pooled_prediction(latent, pool, output_feat, mk)
         if output_feat in (0, 1):
             return mk(latent, self._pool_embed(pool, output_feat))
         if output_feat not in (2, 3):
@@ -419,10 +421,14 @@ class EmbeddingAttribute(object):
         pooled token scores of a multi-hot one."""
         rt = self.rt
         ids, fmaps, W, static = self._pool_ids_and_maps(pool)
+        if isinstance(latent, list) and len(latent) < len(fmaps):
+            raise ValueError("latent list shorter than the number of output features")
+        lat_all = latent
         parts = []
         for k, (kind, table, maps, max_len) in enumerate(fmaps):
-            if kind == 'cat':
-                pe = G.EntityEmbed(rt, ids, [G.Feature('cat', table, maps)], with_bias=True)
+            latent = lat_all[k] if isinstance(lat_all, list) else lat_all
+            if kind == 'cat' or output_feat == 1:      # plain score / mean over the bag (embedding space)
+                pe = G.EntityEmbed(rt, ids, [G.Feature(kind, table, maps, max_len)], with_bias=True)
                 parts.append(mk(latent, pe))
                 continue
             if static:

@@ -63,3 +63,51 @@ def test_get_prediction_pooled_scores_train_step(dev, pool, of, mix):
         got = emb.get_params()
         for k, v in got.items():
             np.testing.assert_allclose(v, remb.params[k], rtol=RTOL, atol=ATOL, err_msg='%s step %d' % (k, step))
+
+
+@pytest.mark.parametrize("of", [1, 2])
+def test_get_prediction_latent_list(dev, of):
+    """embed_attribute.py:169,178: `latent` may be a list with one latent per output feature;
+    logits = mean over features of (that feature's scores with its own latent)."""
+    from arx import graph as G
+    from arx.attributes.embed_attribute import EmbeddingAttribute
+    from arx.utils.synthetic import SyntheticHMF
+    d, B, S, lr = 32, 16, 32, 0.5
+    syn = SyntheticHMF(n_users=80, n_items=120, logit_size=120, mulhot_vocab=40, avg_len=4, max_len=8, seed=15,
+                       item_mulhot=True)
+    syn.u_attr.set_model_size(d)
+    syn.i_attr.set_model_size(d)
+    params = syn.glorot_params(d, seed=16, scale=0.6)
+    i2l, l2i = syn.item_ind2logit_ind_dict(), syn.logit_ind2item_ind
+    emb = EmbeddingAttribute(syn.u_attr, syn.i_attr, B, S, 0, False, i2l, l2i, params=params)
+    emb.rt.set_learning_rate(lr)
+    remb = rg.RefEmbeddingAttribute(syn.u_attr, syn.i_attr, B, S, 0, False, i2l, l2i, params=params,
+                                    dtype=np.float64)
+    u1, _ = emb.get_batch_user(1.0, concat=False)
+    u2 = G.EntityEmbed(emb.rt, emb.u_indices['input'], emb.user_feats, with_bias=False, out_scale=0.5)
+    logits = emb.get_prediction([u1, u2], 'sampled', output_feat=of)
+    tgt = G.IdsInput(emb.rt, B, 'tgt')
+    loss = G.MeanLoss(emb.rt, emb.compute_loss(logits, tgt, 'ce'))
+    plan = G.Plan(emb.rt, [loss], True, [])
+    rng = np.random.default_rng(5)
+    for step in range(2):
+        users = rng.integers(0, syn.n_users, size=B).astype(np.int32)
+        targets = rng.integers(0, S, size=B).astype(np.int32)
+        if step == 0:
+            ps = syn.sample_pool(S, rng).astype(np.int32)
+            emb.update_sampled_pool(ps)
+            remb.update_sampled(ps)
+        u, cu = remb.get_batch_user(list(users), concat=False)
+        lg, cp = remb.get_prediction([u, 0.5 * u], 'sampled', of)
+        bl, cl = remb.compute_loss(lg, targets, 'ce')
+        grads = rg.Grads()
+        dl, _ = remb.compute_loss_bwd(cl, np.full(B, 1.0 / B))
+        dus = remb.get_prediction_bwd(cp, dl, grads)
+        remb.get_batch_user_bwd(cu, dus[0] + 0.5 * dus[1], grads)
+        remb.apply_gradients(grads, lr)
+        emb.u_indices['input'].feed(users)
+        tgt.feed(targets)
+        plan.run()
+        np.testing.assert_allclose(float(loss.read().item()), bl.mean(), rtol=RTOL)
+        for k, v in emb.get_params().items():
+            np.testing.assert_allclose(v, remb.params[k], rtol=RTOL, atol=ATOL, err_msg='%s step %d' % (k, step))
