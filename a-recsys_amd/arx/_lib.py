@@ -81,6 +81,10 @@ PROTOTYPES = {
     "arx_loss_warp_fwdbwd_pos": (cint, [f32p, i64, i32p, i32p, i32p, i32p, i32p, i64, f32, f32p,
                                         i64, i64, f32p, f32p, i64, vp]),
     "arx_item_frequency": (cint, [i32p, i64, i64, i64, f32, i32p, f32p, vp]),
+    "arx_eval_chunk_accum": (cint, [f32p, i64, i64, i64, f32p, cint, cint, f32p, f32p, vp]),
+    "arx_eval_warp_unmask": (cint, [f32p, i64, f32p, i64, f32p, cint, f32p, i32p, i32p, i32p, i32p, i64, i64,
+                                    i64, f32p, vp]),
+    "arx_eval_finish": (cint, [cint, f32p, f32p, f32p, i64, f32p, vp]),
     "arx_mw_gemm_fused_workspace_bytes": (sz, [i64, i64]),
     "arx_mw_gemm_fused_fwd": (cint, [f32p, i64, f32p, i64, f32p, f32p, i64, f32p, i64, cint, i32p, i32p, i32p,
                                      i32p, i64, f32, f32p, i64, i64, f32p, f32p, vp, i64, f32p, f32p, i64, f32p,

@@ -641,6 +641,50 @@ def _bl_forward_gemm_fused(self, bl, rw, uid, ptr, items, i2s):
 BatchLoss._forward_gemm_fused = _bl_forward_gemm_fused
 
 
+class StreamEvalLoss(Node):
+    """Full-vocabulary 'ce' / 'warp' batch loss WITHOUT the [rows, V] logits (forward only:
+    hmf_model.py:130,144, seqModel.py:510 -- the evaluation loss of a sampled-loss model): chunked
+    scorer GEMM + running per-row reductions (arx_eval_chunk_accum), target logit from the
+    target's pool row, positives taken out afterwards (arx_eval_warp_unmask)."""
+
+    def __init__(self, rt, kind, latent, pool, target, mask=None, mask_rows=0, chunk=65536):
+        if kind not in ('ce', 'warp'):
+            raise NotImplementedError("streaming evaluation loss %r" % kind)
+        super().__init__(rt, (latent.shape[0],), (latent, pool, target))
+        self.kind, self.mask, self.mask_rows = kind, mask, mask_rows
+        self.gscale, self.row_w = 1.0, None
+        B, V, dev = latent.shape[0], pool.shape[0], rt.device
+        self.chunk = min(int(os.environ.get('ARX_STREAM_EVAL_CHUNK', chunk)), V)
+        f32 = torch.float32
+        self._buf = torch.empty((B, self.chunk), dtype=f32, device=dev)
+        self._t = torch.empty((B,), dtype=f32, device=dev)
+        self._T = torch.empty((B, pool.shape[1]), dtype=f32, device=dev)
+        self._tb = torch.empty((B,), dtype=f32, device=dev)
+        self._a0, self._a1 = torch.empty((B,), dtype=f32, device=dev), torch.empty((B,), dtype=f32, device=dev)
+
+    def forward(self, train):
+        if train:
+            raise RuntimeError("StreamEvalLoss is an evaluation node")
+        latent, pool, target = self.inputs
+        rt, V = self.rt, pool.shape[0]
+        mode = 0 if self.kind == 'ce' else 1
+        # target logit = latent . pool_row(target) + bias (the target is a logit index = a pool row)
+        ops.gather_onehot(pool.value, pool.bias_value, None, target.value, self._T, bias_out=self._tb)
+        ops.dot_score(latent.value, self._T, self._tb, self._t)
+        for c0 in range(0, V, self.chunk):
+            c1 = min(V, c0 + self.chunk)
+            lg = self._buf[:, :c1 - c0]
+            bias = pool.bias_value[c0:c1] if pool.bias_value is not None else None
+            ops.gemm(latent.value, pool.value[c0:c1], lg, rt.ws, transB=True, col_bias=bias)
+            ops.eval_chunk_accum(lg, self._t, mode, c0 == 0, self._a0, self._a1)
+        ms = self.mask
+        if mode == 1 and ms is not None:
+            ptr, items = ms.pos_getter()
+            ops.eval_warp_unmask(latent.value, pool.value, pool.bias_value, self._t, ms.user_ids.value, ptr, items,
+                                 ms.slot_map_getter(), self._a0, mask_rows=self.mask_rows)
+        ops.eval_finish(mode, self._a0, self._a1, self._t, self.alloc_value())
+
+
 class MeanLoss(Node):
     """hmf_model.py:140 tf.reduce_mean(batch_loss)."""
 

@@ -263,11 +263,21 @@ class LatentProductModel(object):
         logits = m.get_prediction(embedded_user)                              # :118
         self.output = logits
         batch_loss_eval = None
+        # [mb, V] logits of the evaluation loss are streamed, not materialised, past this size
+        stream_eval = batch_size * self.logit_size * 4 > int(os.environ.get('ARX_STREAM_TOPK_BYTES', str(1 << 30)))
         if loss in ('warp', 'ce', 'rs', 'rs-sig', 'rs-sig2', 'bbpr'):            # :121-122
             batch_loss = m.compute_loss(logits, self.item_target, loss, loss_func=self.loss_func,
                                         exp_p=self.loss_exp_p)
         elif loss == 'warp_eval':
             batch_loss, _ = m.compute_loss(logits, self.item_target, loss)
+        elif loss == 'mw' and stream_eval:
+            batch_loss = m.compute_loss(sampled_logits, target_score, loss)
+            ms = None if self.mw_eval_unmasked else m._mask_state('warp', batch_size)
+            batch_loss_eval = G.StreamEvalLoss(rt, 'warp', embedded_user, m._pool_embed('full', 1),
+                                               self.item_target, mask=ms, mask_rows=batch_size)
+        elif loss == 'mce' and stream_eval:
+            batch_loss = m.compute_loss(sampled_logits, target_score, loss)
+            batch_loss_eval = G.StreamEvalLoss(rt, 'ce', embedded_user, m._pool_embed('full', 1), self.item_target)
         elif loss == 'mw':
             batch_loss = m.compute_loss(sampled_logits, target_score, loss)
             if self.mw_eval_unmasked:
@@ -314,6 +324,8 @@ class LatentProductModel(object):
         elif key == 'eval':
             l = 'warp' if loss == 'mw' else ('ce' if loss == 'mce' else loss)
             masks = [m.mask[l]] if l in m.mask else []
+            if isinstance(self.loss_eval.inputs[0], G.StreamEvalLoss):
+                masks = []                 # the streaming loss reads the positives CSR itself
             p = G.Plan(rt, [self.loss_eval], False, masks)
         elif key == 'recommend':
             p = G.Plan(rt, [self.topk], False, [])

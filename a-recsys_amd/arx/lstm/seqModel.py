@@ -413,7 +413,16 @@ class SeqModel(SeqBatching):
         if self.loss in ('mw', 'mce'):
             wn2 = SeqWeights(rt, wn.inputs[0], L, B)
             full = m.get_prediction(hs, 'full', output_feat=self.output_feat)
-            bl_full = m.compute_loss(full, tgt, 'warp' if self.loss == 'mw' else 'ce')
+            kind_full = 'warp' if self.loss == 'mw' else 'ce'
+            import os as _os
+            big = n * m.logit_size * 4 > int(_os.environ.get('ARX_STREAM_TOPK_BYTES', str(1 << 30)))
+            if big and self.output_feat in (0, 1):     # [L*mb, V] logits streamed, not materialised
+                ms = m._mask_state('warp', n) if kind_full == 'warp' else None
+                bl_full = G.StreamEvalLoss(rt, kind_full, hs, m._pool_embed('full', self.output_feat), tgt,
+                                           mask=ms, mask_rows=B)
+                bk['eval_streamed'] = True
+            else:
+                bl_full = m.compute_loss(full, tgt, kind_full)
             bk['eval'] = SeqLoss(rt, bl_full, wn2)
         else:
             bk['eval'] = bk['train']
@@ -434,7 +443,7 @@ class SeqModel(SeqBatching):
                 bk['plans'][key] = G.Plan(self.rt, [bk['recommend']], False, [])
             else:
                 l = 'warp' if self.loss == 'mw' else ('ce' if self.loss == 'mce' else self.loss)
-                masks = [m.mask[l]] if l in m.mask else []
+                masks = [m.mask[l]] if (l in m.mask and not bk.get('eval_streamed')) else []
                 bk['plans'][key] = G.Plan(self.rt, [bk['eval']], False, masks)
         return bk['plans'][key]
 

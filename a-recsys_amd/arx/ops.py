@@ -305,6 +305,21 @@ def loss_mw_fused_pos(logits, U, T, tbias, user_ids, pos_ptr, pos_items, item2sl
          _ld(dU) if dU is not None else 0, _p(dT), _ld(dT) if dT is not None else 0, _stream())
 
 
+def eval_chunk_accum(logits, tscore, mode, first, acc0, acc1):
+    call("arx_eval_chunk_accum", _p(logits), _ld(logits), int(logits.shape[0]), int(logits.shape[1]), _p(tscore),
+         int(mode), int(bool(first)), _p(acc0), _p(acc1), _stream())
+
+
+def eval_warp_unmask(U, P, pbias, tscore, user_ids, pos_ptr, pos_items, item2col, s_acc, mask_rows=0):
+    call("arx_eval_warp_unmask", _p(U), _ld(U), _p(P), _ld(P), _p(pbias), int(U.shape[1]), _p(tscore), _p(user_ids),
+         _p(pos_ptr), _p(pos_items), _p(item2col), int(mask_rows), int(U.shape[0]), int(P.shape[0]), _p(s_acc),
+         _stream())
+
+
+def eval_finish(mode, acc0, acc1, tscore, out):
+    call("arx_eval_finish", int(mode), _p(acc0), _p(acc1), _p(tscore), int(out.shape[0]), _p(out), _stream())
+
+
 def mw_gemm_fused_fwd(U, P, pbias, T, tbias, user_ids, pos_ptr, pos_items, item2slot, batch_loss, tscore_out,
                       act_bits, g_out, Ug, dtscore, dU, dT, gscale, ws, row_w=None, mask_rows=0):
     """'mw' with the hinge in the scorer GEMM's epilogue (arx_mw_gemm_fused_fwd): act bits instead

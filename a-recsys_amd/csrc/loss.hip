@@ -496,6 +496,102 @@ __global__ __launch_bounds__(256) void k_mw_rows(MwRows a, PosMask pm, int64_t m
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Streaming full-vocabulary evaluation losses (hmf_model.py:130,144: loss_eval of a sampled-loss
+// model = 'warp' / 'ce' over ALL V logits).  The [B, V] logits are never materialised: the scorer
+// GEMM runs over chunks of the pool and these kernels fold every chunk into two running values per
+// row -- ce: (max, sum exp) of an online log-sum-exp; warp: sum of relu(x - t + 1) -- with the
+// target logit t_r formed directly from the target's pool row.  The positive mask of 'warp' is
+// applied afterwards by taking the masked columns' terms out again (their logits recomputed).
+__global__ __launch_bounds__(256) void k_eval_chunk(const float* __restrict__ x, int64_t ld, int64_t n,
+                                                    const float* __restrict__ t, int mode, int first,
+                                                    float* __restrict__ acc0, float* __restrict__ acc1,
+                                                    int64_t B) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (r >= B) return;
+  const float* row = x + r * ld;
+  if (mode == 0) {                       // ce: online log-sum-exp
+    float m = -INFINITY;
+    for (int64_t c = lane; c < n; c += 64) m = fmaxf(m, row[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float l = 0.f;
+    for (int64_t c = lane; c < n; c += 64) l += expf(row[c] - m);
+    l = wsum(l);
+    if (lane == 0) {
+      if (first) { acc0[r] = m; acc1[r] = l; }
+      else {
+        const float m0 = acc0[r], l0 = acc1[r];
+        const float mm = fmaxf(m0, m);
+        acc0[r] = mm;
+        acc1[r] = l0 * expf(m0 - mm) + l * expf(m - mm);
+      }
+    }
+  } else {                               // warp: hinge sum against the target logit
+    const float tt = t[r];
+    float s = 0.f;
+    for (int64_t c = lane; c < n; c += 64) {
+      const float v = row[c] - tt + 1.f;
+      s += v > 0.f ? v : 0.f;
+    }
+    s = wsum(s);
+    if (lane == 0) acc0[r] = first ? s : acc0[r] + s;
+  }
+}
+
+// take the terms of the masked columns (the user's positives that have a logit) out of the hinge
+// sum again: one wave per row, every distinct column once
+__global__ __launch_bounds__(256) void k_eval_unmask(const float* __restrict__ U, int64_t ldu,
+                                                     const float* __restrict__ P, int64_t ldp,
+                                                     const float* __restrict__ pb, int d,
+                                                     const float* __restrict__ t, PosMask pm, int64_t mask_rows,
+                                                     int64_t V, float* __restrict__ s_acc, int64_t B) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (r >= B) return;
+  float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool colok = lane * 4 < d;
+  if (colok) u = *reinterpret_cast<const float4*>(U + r * ldu + lane * 4);
+  const float tt = t[r];
+  const int usr = pm.user_ids[r % mask_rows];
+  const int beg = pm.pos_ptr[usr], end = pm.pos_ptr[usr + 1];
+  float sub = 0.f;
+  for (int p0 = beg; p0 < end; p0 += 64) {
+    const int p = p0 + lane;
+    int j = -1;
+    if (p < end) {
+      j = pm.item2slot[pm.pos_items[p]];
+      if (j < 0 || j >= V) j = -1;
+    }
+    // a column named twice (here or in an earlier batch of 64) counts once: the mask is a set
+    if (j >= 0) {
+      for (int q = beg; q < p; ++q) {
+        if (pm.item2slot[pm.pos_items[q]] == j) { j = -1; break; }
+      }
+    }
+    unsigned long long hm = __ballot(j >= 0);
+    while (hm) {
+      const int src = __builtin_ctzll(hm);
+      hm &= hm - 1;
+      const int jj = __shfl(j, src, 64);
+      float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (colok) pr = *reinterpret_cast<const float4*>(P + (int64_t)jj * ldp + lane * 4);
+      const float x = wsum(u.x * pr.x + u.y * pr.y + u.z * pr.z + u.w * pr.w) + (pb ? pb[jj] : 0.f);
+      const float v = x - tt + 1.f;
+      sub += v > 0.f ? v : 0.f;
+    }
+  }
+  if (lane == 0) s_acc[r] = fmaxf(s_acc[r] - sub, 0.f);
+}
+
+__global__ void k_eval_finish(int mode, const float* __restrict__ acc0, const float* __restrict__ acc1,
+                              const float* __restrict__ t, int64_t B, float* __restrict__ out) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= B) return;
+  out[r] = mode == 0 ? acc0[r] + logf(acc1[r]) - t[r] : logf(1.f + acc0[r]);
+}
+
 // launch helper: true if the wave-per-row kernel took the call
 template <bool WARP, bool POS, bool SOFT = false>
 static bool launch_margin_wave(const float* logits, int64_t ldl, const float* tscore,
@@ -842,6 +938,41 @@ int arx_loss_mce_fwdbwd_pos(const float* logits, int64_t ldl, const float* tscor
   k_loss_margin<false, true, true><<<(int)B, 256, lds, as_stream(stream)>>>(
       logits, ldl, tscore, nullptr, nullptr, 0, mask_rows > 0 ? mask_rows : B, gscale, row_w, S,
       batch_loss, dlogits, lddl, dtscore, PosMask{user_ids, pos_ptr, pos_items, item2slot});
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_eval_chunk_accum(const float* logits, int64_t ldl, int64_t B, int64_t n, const float* tscore,
+                         int mode, int first, float* acc0, float* acc1, void* stream) {
+  ARX_CHECK_ARG(logits && acc0 && (mode == 1 ? tscore != nullptr : acc1 != nullptr) && (mode == 0 || mode == 1),
+                "arx_eval_chunk_accum: bad argument");
+  if (B <= 0 || n <= 0) return ARX_OK;
+  k_eval_chunk<<<(int)ceil_div(B, 4), 256, 0, as_stream(stream)>>>(logits, ldl, n, tscore, mode, first, acc0,
+                                                                   acc1, B);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_eval_warp_unmask(const float* U, int64_t ldu, const float* P, int64_t ldp, const float* pbias, int d,
+                         const float* tscore, const int32_t* user_ids, const int32_t* pos_ptr,
+                         const int32_t* pos_items, const int32_t* item2col, int64_t mask_rows, int64_t B,
+                         int64_t V, float* s_acc, void* stream) {
+  ARX_CHECK_ARG(U && P && tscore && user_ids && pos_ptr && pos_items && item2col && s_acc,
+                "arx_eval_warp_unmask: null pointer");
+  ARX_CHECK_ARG(d > 0 && d <= 256 && d % 4 == 0 && ldu % 4 == 0 && ldp % 4 == 0, "arx_eval_warp_unmask: d %% 4, d <= 256");
+  if (B <= 0) return ARX_OK;
+  k_eval_unmask<<<(int)ceil_div(B, 4), 256, 0, as_stream(stream)>>>(
+      U, ldu, P, ldp, pbias, d, tscore, PosMask{user_ids, pos_ptr, pos_items, item2col},
+      mask_rows > 0 ? mask_rows : B, V, s_acc, B);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_eval_finish(int mode, const float* acc0, const float* acc1, const float* tscore, int64_t B,
+                    float* batch_loss, void* stream) {
+  ARX_CHECK_ARG(acc0 && batch_loss && (mode == 1 || (acc1 && tscore)), "arx_eval_finish: bad argument");
+  if (B <= 0) return ARX_OK;
+  k_eval_finish<<<(int)ceil_div(B, 256), 256, 0, as_stream(stream)>>>(mode, acc0, acc1, tscore, B, batch_loss);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

@@ -272,6 +272,24 @@ int arx_loss_mw_fused_pos(const float* logits, int64_t ldl, const float* U, int6
                           float* tscore_out, float* dtscore, int64_t dtscore_stride, float* dU,
                           int64_t lddu, float* dT, int64_t lddt, void* stream);
 
+/* Streaming full-vocabulary evaluation losses (hmf_model.py:130,144; lstm/seqModel.py:510: the
+ * loss_eval of a model trained with a sampled loss is 'warp' / 'ce' over ALL V logits).  The
+ * caller runs the scorer GEMM over chunks of the pool and folds every [B, n] chunk of logits in:
+ *   mode 0 (ce)   acc0 = running max, acc1 = running sum exp(x - max)   (online log-sum-exp)
+ *   mode 1 (warp) acc0 += sum_j relu(x_j - t + 1)                       (t = the target's logit)
+ * first != 0 starts the scan.  arx_eval_warp_unmask then takes the terms of the masked columns --
+ * the row's user's positives that have a logit (item2col >= 0), each distinct column once,
+ * embed_attribute.py:729-741 -- out again (their logits are recomputed from U and the pool rows
+ * P / pbias).  arx_eval_finish: batch_loss = acc0 + log(acc1) - t (ce) or log(1 + acc0) (warp). */
+int arx_eval_chunk_accum(const float* logits, int64_t ldl, int64_t B, int64_t n, const float* tscore,
+                         int mode, int first, float* acc0, float* acc1, void* stream);
+int arx_eval_warp_unmask(const float* U, int64_t ldu, const float* P, int64_t ldp, const float* pbias, int d,
+                         const float* tscore, const int32_t* user_ids, const int32_t* pos_ptr,
+                         const int32_t* pos_items, const int32_t* item2col, int64_t mask_rows, int64_t B,
+                         int64_t V, float* s_acc, void* stream);
+int arx_eval_finish(int mode, const float* acc0, const float* acc1, const float* tscore, int64_t B,
+                    float* batch_loss, void* stream);
+
 /* 'mw' with the hinge folded into the scorer GEMM (embed_attribute.py:148-206 get_prediction on
  * the sampled pool + :208-220 get_target_score + :641-649 the 'mw' loss, fwd + bwd): the [B, S]
  * logits and their gradient never reach HBM.  Forward (three launches):

@@ -319,3 +319,45 @@ def test_fullsize_lstm_matches_embedding_space_oracle(dev):
                 _cmp_rows(tb.name, st, tb.E, tb.acc)
                 if tb.bias is not None:
                     _cmp_rows(tb.bias_name, oracle.t[tb.bias_name], tb.bias, tb.bias_acc)
+
+
+def test_fullsize_streaming_eval(dev):
+    """Evaluation loss of the C3 model ('warp' over all 1 M logits, B = 16384): streamed -- the 64 GB
+    [B, V] logits never exist -- and, for a sample of rows, equal to an fp64 numpy evaluation of
+    the same rows against the model's tables (positives of the row's user masked)."""
+    from arx import graph as G
+    syn, model = _model(True)
+    assert isinstance(model.loss_eval.inputs[0], G.StreamEvalLoss)
+    d_ = model.rt.device
+    batches, pool = _batches(syn, d_, 1)
+    u, i = batches[0]
+    model.step(None, u, i, None, pool, None, loss='mw')
+    e = model.step(None, u, i, None, None, None, forward_only=True, loss='mw')
+    bl = model.loss_eval.inputs[0].value.cpu().numpy()
+    assert np.isfinite(e) and abs(e - bl.mean()) <= 1e-5 * abs(e)
+    # fp64 check of 6 rows
+    P = model.att_emb.get_params()
+    ia = syn.i_attr
+    icat = np.asarray(ia.features_cat[0])
+    vals, st, ln = (np.asarray(x) for x in (ia.features_mulhot[0], ia.mulhot_starts[0], ia.mulhot_lengths[0]))
+    Eid, bid = P['itemembed_cat_0'].astype(np.float64), P['item_bias_cat_0'].astype(np.float64)[:, 0]
+    Em, bm = P['itemembed_mulhot_0'].astype(np.float64), P['item_bias_mulhot_0'].astype(np.float64)[:, 0]
+    Eu = P['userembed_cat_0']
+    ucat = np.asarray(syn.u_attr.features_cat[0])
+    # full pool embedding (logit j = item j here): 0.5 * (id row + mean of the bag rows)
+    lens = ln[:N].astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    bag = np.add.reduceat(Em[vals[:lens.sum()]], offs, axis=0) / lens[:, None]
+    bagb = np.add.reduceat(bm[vals[:lens.sum()]], offs) / lens
+    pool_emb = 0.5 * (Eid[icat[:N]] + bag)
+    pool_b = 0.5 * (bid[icat[:N]] + bagb)
+    un, it = u.cpu().numpy(), i.cpu().numpy()
+    ptr, pit = syn.positives_csr()
+    for r in (0, 1, 77, 4095, 9999, 16383):
+        uu = Eu[ucat[un[r]]].astype(np.float64)
+        x = pool_emb @ uu + pool_b
+        t = x[it[r]]
+        m = np.ones(N, dtype=bool)
+        m[pit[ptr[un[r]]:ptr[un[r] + 1]]] = False
+        want = np.log1p(np.maximum(x - t + 1.0, 0.0)[m].sum())
+        np.testing.assert_allclose(bl[r], want, rtol=1e-4, err_msg='row %d' % r)

@@ -355,3 +355,29 @@ def test_hmf_mw_scorer_gemm_with_hinge_epilogue(dev, monkeypatch, cfg, d):
         _compare_state(model, ref)
     plan = model._plan('train')
     assert any(isinstance(n, G.BatchLoss) and n.gemm_fused for n in plan.order)     # the path under test ran
+
+
+@pytest.mark.parametrize("cfg,loss", [(CFG_ID, 'mw'), (CFG_HET, 'mw'), (CFG_HET, 'mce')])
+def test_hmf_streaming_eval_loss(dev, monkeypatch, cfg, loss):
+    """Evaluation loss of a sampled-loss model over the FULL vocabulary without [mb, V] logits
+    (StreamEvalLoss: chunked scorer GEMM + running per-row reductions + positives taken out):
+    equal to the oracle's forward_only loss and to the materialising path."""
+    monkeypatch.setenv('ARX_STREAM_TOPK_BYTES', '1')          # force streaming at this size
+    monkeypatch.setenv('ARX_STREAM_EVAL_CHUNK', '96')         # several ragged chunks of the pool
+    from arx import graph as G
+    d, B, S = 32, 48, 128
+    syn, model, ref = _build(cfg, loss, d, B, S, seed=6)
+    assert isinstance(model.loss_eval.inputs[0], G.StreamEvalLoss)
+    rng = np.random.default_rng(2)
+    pool = syn.sample_pool(S, rng)
+    id2idx = {int(v): i for i, v in enumerate(pool)}
+    for step in range(2):
+        users, items = syn.sample_batch(B, rng)
+        users[3] = users[2]
+        ps = pool if step == 0 else None
+        l_ref = ref.step(list(users), list(items), ps, id2idx, loss=loss)
+        l_got = model.step(None, list(users), list(items), None, ps, id2idx if ps is not None else None, loss=loss)
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL)
+    e_ref = ref.step(list(users), list(items), forward_only=True, loss=loss)
+    e_got = model.step(None, list(users), list(items), forward_only=True, loss=loss)
+    np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)

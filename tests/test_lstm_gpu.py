@@ -367,3 +367,25 @@ def test_seq_two_buckets_interleaved(dev, cfg):
         # eight lr = 0.5 steps of a recurrent model: fp32 summation noise in near-cancelling
         # gradient sums reaches a few 1e-5 absolute on small weights
         _compare(emb, model, remb, ref, atol=5e-5)
+
+
+@pytest.mark.parametrize("loss", ['mw', 'mce'])
+def test_seq_streaming_eval_loss(dev, monkeypatch, loss):
+    """forward_only of a sampled-loss sequence model: the full-vocabulary loss over all L*mb
+    time-step rows is streamed (no [L*mb, V] logits), equal to the oracle's."""
+    monkeypatch.setenv('ARX_STREAM_TOPK_BYTES', '1')
+    monkeypatch.setenv('ARX_STREAM_EVAL_CHUNK', '200')
+    size, B, L, S = 64, 16, 4, 64
+    syn, emb, model, remb, ref = _build(CFG_HET, loss, size, B, L, S, 5.0, seed=27)
+    rng = np.random.default_rng(29)
+    pool = syn.sample_pool(S, rng)
+    id2idx = {int(v): i for i, v in enumerate(pool)}
+    users, inp, tg, w = _batch(syn, rng, L, B)
+    l_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), pool, id2idx)
+    l_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, pool, id2idx)
+    np.testing.assert_allclose(l_got, l_ref, rtol=RTOL)
+    e_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), None, id2idx, forward_only=True)
+    e_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, None, id2idx,
+                       forward_only=True)
+    assert model._bucket(0).get('eval_streamed')
+    np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
