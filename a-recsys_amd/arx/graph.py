@@ -965,34 +965,108 @@ class Plan(object):
             torch.cuda.current_stream().wait_event(early[1])          # join the sort branch
             self._k7_done_keys = early[0]
         self._jobs, self._n_passes = [], 0
-        if fused:
-            key = self._multi_key(fused)
-            phase = 2 if (self._k7_done_keys is not None and key in self._k7_done_keys) else 3
-            self._apply_multi(fused, phase=phase, key=key)
-            # size estimate for _plan_early: one-hot sites are all live, a multi-hot site's padded
-            # capacity (max_len slots per bag) holds about a third of that in live tokens
-            self._jobs.append(('multi', fused, key, sum(x.cap for _, c, _m in fused for x in c)
-                               + sum(x.cap for _, _c, m in fused for x in m) // 3))
-            self._n_passes += 1
         done = set(id(e) for e, _, _ in fused)
         toks = []
-        for ti, entry in enumerate(self.tables):
-            if id(entry) in done:
-                continue
-            tok = rt.fork(ti, 'tables') if ti > 0 else None          # tables are independent
-            self._apply_one(entry)
-            if tok is not None:
-                toks.append(rt.end_fork(tok))
+
+        def rest(first_on_main):
+            for ti, entry in enumerate(self.tables):
+                if id(entry) in done:
+                    continue
+                tok = rt.fork(ti, 'tables') if (ti > 0 or not first_on_main) else None   # tables are independent
+                self._apply_one(entry)
+                if tok is not None:
+                    toks.append(rt.end_fork(tok))
+
+        rider = self._find_rider(fused, done) if fused else None
+        if rider is not None:
+            # a multi-hot table looked up with exactly the lookups of one fused one-hot table (HET: an
+            # item's id row and its bag): it rides on the fused pass -- that table goes first (its
+            # keys sort first), the bag needs no entity sort / merge pass of its own
+            gi, bag_entry, bag_live = rider
+            fused = [fused[gi]] + fused[:gi] + fused[gi + 1:]
+            done.add(id(bag_entry))
+        side_first = bool(fused) and rt.use_streams in ('tables', '1')
+        if side_first:
+            rest(False)          # the other tables' passes go to side branches, under the fused pass
+        if fused:
+            key = self._multi_key(fused)
+            bag = None
+            if rider is not None:
+                use_bias = bag_entry[0].bias is not None and any(x.node.bias_grad_used for x in bag_live)
+                key = key + ('rider', id(bag_entry), use_bias)
+                bag = (bag_entry, bag_live, use_bias)
+            phase = 2 if (self._k7_done_keys is not None and key in self._k7_done_keys) else 3
+            self._apply_multi(fused, phase=phase, key=key, bag=bag)
+            # size estimate for _plan_early: one-hot sites are all live, a multi-hot site's padded
+            # capacity (max_len slots per bag) holds about a third of that in live tokens
+            job = ('multi', (fused, bag), key, sum(x.cap for _, c, _m in fused for x in c)
+                   + sum(x.cap for _, _c, m in fused for x in m) // 3)
+            if bag is not None:
+                job = job + (sum(x.cap for x in bag_live) // 6,)
+            self._jobs.append(job)
+            self._n_passes += 1
+        if not side_first:
+            rest(True)
         for t in toks:
             rt.join(t)
         self._plan_early(self._jobs, self._n_passes)
+
+    def _find_rider(self, fused, done):
+        """(index in the fused group, table entry, live sites) of a two-stage multi-hot table whose
+        lookups are exactly the lookups of one fused one-hot table: same id tensors, gradient rows,
+        coefficients and arena (arx_sparse_adagrad_cat_multi_bags), or None."""
+        rt = self.rt
+        if rt.no_rider or any(m for _, _, m in fused):
+            return None
+        for entry in self.tables:
+            if id(entry) in done:
+                continue
+            live = [x for x in entry[1] if x.node._grad_written]
+            if not self._bags_ok(live):
+                continue
+            for gi, (e, c, _m) in enumerate(fused):
+                if len(c) != len(live) or e[0].E.shape[1] != entry[0].E.shape[1]:
+                    continue
+                if any(x.maps[0] is not c[0].maps[0] for x in c):
+                    continue
+                if self._rider_csr(c[0].maps[0], live[0].maps[1], live[0].maps[2], int(e[0].E.shape[0])) is None:
+                    continue                    # (entity -> id-table row must be one-to-one)
+                if all(a.ids_node.value.data_ptr() == b.ids_node.value.data_ptr()
+                       and a.ids_node.value.shape == b.ids_node.value.shape and a.node.row0 == b.node.row0
+                       and a.coef == b.coef and a.node.arena is b.node.arena and a.node.arena_b is b.node.arena_b
+                       for a, b in zip(c, live)):
+                    return gi, entry, live
+        return None
+
+    def _rider_csr(self, m, starts, lens, rows):
+        """The bag index (starts, lens) of a multi-hot feature re-indexed by the ROW of the one-hot
+        table whose lookups it shares (m: entity -> row, None = identity): the sorted keys of the
+        fused pass are rows.  None unless m is one-to-one.  Built once per (map, bag index)."""
+        cache = self.__dict__.setdefault('_rider_cache', {})
+        k = (0 if m is None else m.data_ptr(), starts.data_ptr(), lens.data_ptr(), rows)
+        if k not in cache:
+            out = None
+            n = int(lens.shape[0]) if m is None else min(int(m.shape[0]), int(lens.shape[0]))
+            if m is None:
+                out = (starts, lens) if rows <= n else None
+            elif n > 0:
+                mm = m[:n].long()
+                if int(mm.min()) >= 0 and int(mm.max()) < rows and int(torch.bincount(mm, minlength=rows).max()) <= 1:
+                    st_r = torch.zeros(rows, dtype=torch.int32, device=m.device)
+                    ln_r = torch.zeros(rows, dtype=torch.int32, device=m.device)
+                    st_r[mm] = starts[:n]
+                    ln_r[mm] = lens[:n]
+                    out = (st_r, ln_r)
+            cache[k] = out
+        return cache[k]
 
     def _multi_key(self, group):
         return tuple(id(x) for _, c, m in group for x in c + m) + tuple(
             bool(e[0].bias is not None and any(x.node.bias_grad_used for x in c + m)) for e, c, m in group)
 
-    def _apply_multi(self, group, phase=3, key=None):
-        """phase 1: contributions + sort (ids only), 2: apply, 3: both -- see _early_sort."""
+    def _apply_multi(self, group, phase=3, key=None, bag=None):
+        """phase 1: contributions + sort (ids only), 2: apply, 3: both -- see _early_sort.
+        bag: (table entry, live sites, use_bias) of a multi-hot table riding on table 0 of the group."""
         rt = self.rt
         if key is None:
             key = self._multi_key(group)
@@ -1028,6 +1102,21 @@ class Plan(object):
                                       x.node.row0, x.coef, ent['keys'][off:off + x.cap],
                                       ent['src'][off:off + x.cap], ent['coef'][off:off + x.cap])
         node0 = (group[0][1] + group[0][2])[0].node
+        if bag is not None:
+            bag_entry, bag_live, bag_bias = bag
+            bt, s0 = bag_entry[0], bag_live[0]
+            if 'bag_ws' not in ent:
+                ent['bag_ws'] = ops.Workspace(rt.device)     # token lists + merged rows, between the phases
+            sgd = rt.optimizer == 'sgd'
+            starts_r, lens_r = self._rider_csr(group[0][1][0].maps[0], s0.maps[1], s0.maps[2],
+                                               int(group[0][0][0].E.shape[0]))
+            ops.sparse_adagrad_cat_multi_bags(
+                args, node0.arena, node0.arena_b if (ent['any_bias'] or bag_bias) else None, rt.lr,
+                ent['keys'], ent['src'], ent['coef'], ent['ws'], bt.E, None if sgd else bt.acc,
+                bt.bias if bag_bias else None, bt.bias_acc if (bag_bias and not sgd) else None,
+                s0.maps[0], starts_r, lens_r, max(x.max_len for x in bag_live), ent['bag_ws'],
+                gscale_dev=rt.clip_coef_dev, phase=phase, bag_aux_cnt=None)
+            return
         ops.sparse_adagrad_cat_multi(args, node0.arena, node0.arena_b if ent['any_bias'] else None,
                                      rt.lr, ent['keys'], ent['src'], ent['coef'], ent['ws'],
                                      gscale_dev=rt.clip_coef_dev, phase=phase)
@@ -1063,7 +1152,7 @@ class Plan(object):
         with torch.cuda.stream(self._k7_stream):
             for kind, what, key in jobs:
                 if kind == 'multi':
-                    self._apply_multi(what, phase=1, key=key)
+                    self._apply_multi(what[0], phase=1, key=key, bag=what[1])
                 elif kind == 'bags':
                     self._bag_pass(what, key, phase=1)
                 else:
@@ -1087,7 +1176,7 @@ class Plan(object):
         # tiny steps are bound by the host-side cost of a graph launch, and a graph with a second
         # branch costs more to launch (C1, B=64: 75 -> 103 us per step with the branch)
         lo = int(os.environ.get('ARX_K7_EARLY_MIN', '8192'))
-        n_bags = sum(j[3] for j in jobs if j[0] == 'bags')
+        n_bags = sum(j[3] for j in jobs if j[0] == 'bags') + sum(j[4] for j in jobs if len(j) > 4)
         n_hot = sum(j[3] for j in jobs if j[0] != 'bags')
         ok = (jobs and len(jobs) == n_passes and lo <= n_bags + n_hot and n_hot <= cap
               and n_bags <= cap_bags)
@@ -1263,6 +1352,7 @@ class Runtime(object):
         self.cat_mode = 1 if _os.environ.get('ARX_CAT_ATOMIC') else 0
         self.no_multi = bool(_os.environ.get('ARX_NO_MULTI'))      # A/B aid: one K7 pass per table
         self.no_bags = bool(_os.environ.get('ARX_NO_BAGS'))        # A/B aid: contribution-level multi-hot pass
+        self.no_rider = bool(_os.environ.get('ARX_NO_RIDER'))      # A/B aid: the bag table keeps its own two-stage pass
         # fork/join branches inside the captured graph measured SLOWER on ROCm 7.2 (250 us vs
         # 187 us per C2 step: cross-stream graph edges cost more than the overlap buys at
         # these kernel sizes) -- opt-in only.

@@ -499,6 +499,25 @@ def sparse_adagrad_cat_multi(args, G, Gb, lr_dev, keys_buf, src_buf, coef_buf, w
          _stream())
 
 
+def sparse_adagrad_cat_multi_bags(args, G, Gb, lr_dev, keys_buf, src_buf, coef_buf, ws, bag_E, bag_acc,
+                                  bag_bias, bag_bias_acc, vals, starts, lens, max_len, bag_ws,
+                                  gscale_dev=None, phase=3, bag_aux_cnt=None):
+    """arx_sparse_adagrad_cat_multi with a multi-hot table riding on it: the lookups of one-hot
+    table 0 are also the lookups of the bags of table bag_E -- an item's id row and its multi-hot
+    attribute (HET layout); starts / lens are indexed by the ROW of table 0 (arx.h).  Same phases as
+    sparse_adagrad_cat_multi; `ws` and `bag_ws` must be the same objects for both halves."""
+    assert args.nx == 0
+    n0 = sum(int(args.count[q]) for q in range(args.ns) if int(args.site_table[q]) == 0)
+    wsp, wsn = ws.get(_lib.lib.arx_sparse_adagrad_workspace_bytes(args.total))
+    bwp, bwn = bag_ws.get(_lib.lib.arx_sparse_adagrad_bags_workspace_bytes(max(n0, 1), int(max_len), args.d))
+    call("arx_sparse_adagrad_cat_multi_bags", int(phase), args.nt, args.E, args.acc, args.bias,
+         args.bias_acc, args.rows, args.cnt, args.d, args.ns, args.site_table, args.cat_map, args.ids,
+         args.count, args.row_base, args.coef, _p(G), _ld(G), _p(Gb), _p(lr_dev), _p(gscale_dev),
+         _p(keys_buf), _p(src_buf), _p(coef_buf), wsp, wsn, _p(bag_E), _p(bag_acc), _p(bag_bias),
+         _p(bag_bias_acc), int(bag_E.shape[0]), _p(vals), _p(starts), _p(lens), int(max_len),
+         _p(bag_aux_cnt), bwp, bwn, _stream())
+
+
 class BagSiteArgs(object):
     """Host-side descriptor arrays of arx_sparse_adagrad_bags, built once per plan.
     sites: list of (ids, row_base, coef) -- the lookups of one multi-hot table."""

@@ -97,7 +97,25 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
                                 const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
                                 const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
                                 float* coef_buf, void* workspace, size_t workspace_bytes,
-                                hipStream_t s, int phase = 3);   // 1: keys + sort, 2: apply, 3: both
+                                hipStream_t s, int phase = 3,    // 1: keys + sort, 2: apply, 3: both
+                                const struct BagStage* bag = nullptr);
+
+// A multi-hot table riding on a one-hot pass (arx_sparse_adagrad_cat_multi_bags): the lookups of
+// one-hot table 0 of the pass are also the entity lookups of this table's bags.
+struct BagStage {
+  float* E;
+  float* acc;
+  float* bias;
+  float* bias_acc;
+  int64_t rows;                    // token rows of the multi-hot table
+  const int32_t* vals;             // CSR of the bags: tokens of entity e at vals[starts[e] .. + lens[e])
+  const int32_t* starts;
+  const int32_t* lens;
+  int max_len;
+  int32_t* aux_cnt;                // per-token-row ticket counters (may be null)
+  void* ws;                        // arx_sparse_adagrad_bags_workspace_bytes(lookups of table 0, max_len, d)
+  size_t ws_bytes;
+};
 
 // gemm_nt.hip: logits GEMM with the A operand register-resident (K in {32,64,128});
 // ARX_EUNSUPPORTED for any other shape / alignment.

@@ -351,7 +351,17 @@ struct MergeOut {
   float* Gu;               // [n, d] merged rows, indexed by the head's sorted position
   float* Gub;              // [n] merged bias gradients (null: none)
   const int32_t* lens;     // bag length per entity
+  // table < 0: MERGE mode proper (every key is an entity id).  table >= 0: SIDE output of an
+  // ordinary Adagrad pass (arx_sparse_adagrad_cat_multi_bags): runs of that table -- an item's id
+  // row, whose lookups are also the lookups of the item's bag -- are applied AND written here, so
+  // the bag's token stage needs no entity sort and no merge pass of its own.
+  int table;
+  int kb;                  // row bits of the key (side output: key = (table << kb) | entity)
 };
+
+__device__ __forceinline__ bool merge_side(const MergeOut& mo, uint32_t key) {
+  return mo.Gu != nullptr && mo.table >= 0 && (int)(key >> mo.kb) == mo.table;
+}
 
 __device__ __forceinline__ void merge_row(const MergeOut& mo, int d, uint32_t key, int64_t head_pos, int col,
                                           bool colok, int lig, float4 g, float gb) {
@@ -518,6 +528,7 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
       if (MERGE && lcomp[j]) {
         merge_row(mo, d, rkey, w0 + i, col, colok, lig, a, gb);
       } else if (lcomp[j]) {
+        if (!MERGE && merge_side(mo, rkey)) merge_row(mo, d, rrow, w0 + i, col, colok, lig, a, gb);
         if (colok) {
           float4 gg = make_float4(a.x * gs, a.y * gs, a.z * gs, a.w * gs);
           float4 w4 = wrow[j];
@@ -644,6 +655,7 @@ __global__ __launch_bounds__(1024) void k_sparse_finish(
         merge_row(mo, d, key, h, col, colok, lig, tot, tb);
       } else {
         const TabRow T = tab_of<MT>(ts, key);
+        if (merge_side(mo, key)) merge_row(mo, d, T.row, h, col, colok, lig, tot, tb);
         adagrad_row(T.E, T.acc, T.bias, T.bias_acc, d, T.row, col, colok, lig, tot, tb, lr, gs);
       }
     }
@@ -698,6 +710,7 @@ __global__ __launch_bounds__(1024) void k_sparse_finish(
         merge_row(mo, d, key, h, col, colok, lig, t2, t2b);
       } else {
         const TabRow T = tab_of<MT>(ts, key);
+        if (merge_side(mo, key)) merge_row(mo, d, T.row, h, col, colok, lig, t2, t2b);
         adagrad_row(T.E, T.acc, T.bias, T.bias_acc, d, T.row, col, colok, lig, t2, t2b, lr, gs);
       }
     }
@@ -1078,9 +1091,11 @@ __global__ __launch_bounds__(256) void k_merged_sq_norm(
 // ARX_KEY_NONE, which the token sort's first pass drops.
 __global__ __launch_bounds__(256) void k_bag_expand_heads(
     const uint32_t* __restrict__ sk, int64_t n_host, const int32_t* __restrict__ n_dev,
-    uint32_t sentinel, const int32_t* __restrict__ vals, const int32_t* __restrict__ starts,
-    const int32_t* __restrict__ lens, int max_len, int64_t table_rows,
-    int32_t* __restrict__ tkeys, int32_t* __restrict__ tsrc) {
+    uint32_t sentinel, int ent_kb, uint32_t ent_tag, const int32_t* __restrict__ vals,
+    const int32_t* __restrict__ starts, const int32_t* __restrict__ lens, int max_len,
+    int64_t table_rows, int32_t* __restrict__ tkeys, int32_t* __restrict__ tsrc) {
+  // sk may be the sorted key list of a pass over several tables: entity keys carry ent_tag above
+  // their ent_kb row bits, every other key is skipped
   const int64_t n = n_dev ? min((int64_t)*n_dev, n_host) : n_host;
   const int64_t total = n_host * (int64_t)max_len;
   for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total;
@@ -1089,8 +1104,9 @@ __global__ __launch_bounds__(256) void k_bag_expand_heads(
     const int j = (int)(q - p * max_len);
     int32_t key = ARX_KEY_NONE;
     if (p < n) {
-      const uint32_t e = sk[p];
-      if (e < sentinel && (p == 0 || sk[p - 1] != e) && j < lens[e]) {
+      const uint32_t ke = sk[p];
+      const uint32_t e = ke & ((1u << ent_kb) - 1u);
+      if (ke < sentinel && (ke >> ent_kb) == ent_tag && (p == 0 || sk[p - 1] != ke) && j < lens[e]) {
         const int32_t t = vals[(int64_t)starts[e] + j];
         key = (t < 0 || t >= table_rows) ? ARX_KEY_NONE : t;
       }
@@ -1153,7 +1169,8 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
                         const int32_t* n_dev, hipStream_t s, const MergeOut* merge = nullptr) {
   const int32_t* cnt = ts.cnt[0];
   const int lpr = lanes_per_row(d);
-  const MergeOut mo = merge ? *merge : MergeOut{nullptr, nullptr, nullptr};
+  const MergeOut mo = merge ? *merge : MergeOut{nullptr, nullptr, nullptr, -1, 0};
+  const bool pure_merge = merge && merge->table < 0;      // (table >= 0: side output of an Adagrad pass)
   if (!merge && cnt != nullptr && n <= kRankSortMax && n_dev == nullptr) {   // (radix-sorted input has a live count: window path)
     // small batches (single-launch LDS rank sort regime): one sub-group per sorted position --
     // mostly-unique one-hot ids need the parallelism (80 windows would leave the chip idle);
@@ -1191,7 +1208,7 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
   // single-row runs per window, a lone wave would walk them serially; 1: pre-expanded multi-hot
   // segments -- few long runs per window (C3 B=16384, 350 k live tokens: 77 us with 8, 54 with 4,
   // 52 with 1; the id pass 24 / 27 / 54); 4: callers that cannot tell.
-  if (merge) {   // entity-id runs: the one-hot window shape (many short runs per window)
+  if (pure_merge) {   // entity-id runs: the one-hot window shape (many short runs per window)
     ARX_DISPATCH_LPR(lpr, (k_sparse_win<LPR, 8, false, false, true><<<grid8, 512, 0, s>>>(
                               ts, d, sk, spos, ssrc, scoef, n, n_dev, sentinel, G, ldg, gb_in, lr_dev,
                               gscale_dev, scratch, scratch_b, scratch_h, scratch_hb, list_long,
@@ -1213,7 +1230,7 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
     int64_t nshort = ceil_div(ceil_div(n, 64), nsg);                         // upper bound of short runs
     const int64_t cap = (int64_t)cu_count() * 2;
     if (nshort > cap) nshort = cap;
-    if (merge) {
+    if (pure_merge) {
       ARX_DISPATCH_LPR(lpr, (k_sparse_finish<LPR, false, true><<<(int)(nlong + nshort), 1024, 0, s>>>(
                                 ts, d, sk, n, n_dev, lr_dev, gscale_dev, scratch, scratch_b,
                                 scratch_h, scratch_hb, list_long, list_short, count, (int)nlong, mo)));
@@ -1233,13 +1250,106 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
 
 }  // namespace arx
 
+// ---- multi-hot lookups: merge per entity first, then per token (see arx.h) ----
+namespace {
+struct BagWs {
+  SparseWs wi, wt;                        // sort / apply workspaces of the two stages
+  size_t off_wi, off_wt, off_ikeys, off_isrc, off_icoef, off_tkeys, off_tsrc, off_gu, off_gub, total;
+};
+int bag_ws_layout(int64_t n_i, int max_len, int d, BagWs* w) {
+  const int64_t n_t = n_i * (int64_t)max_len;
+  if (sparse_ws_layout(n_i, 256, &w->wi) != ARX_OK || sparse_ws_layout(n_t, 256, &w->wt) != ARX_OK)
+    return ARX_EINVAL;
+  size_t o = 0;
+  w->off_wi = o; o += align_up(w->wi.total, 256);
+  w->off_wt = o; o += align_up(w->wt.total, 256);
+  w->off_ikeys = o; o += align_up((size_t)n_i * 4, 256);
+  w->off_isrc = o; o += align_up((size_t)n_i * 4, 256);
+  w->off_icoef = o; o += align_up((size_t)n_i * 4, 256);
+  w->off_tkeys = o; o += align_up((size_t)n_t * 4, 256);
+  w->off_tsrc = o; o += align_up((size_t)n_t * 4, 256);
+  w->off_gu = o; o += align_up((size_t)n_i * (size_t)d * 4, 256);
+  w->off_gub = o; o += align_up((size_t)n_i * 4, 256);
+  w->total = o;
+  return ARX_OK;
+}
+}  // namespace
+
+namespace arx {
+namespace {
+
+// Stage 1b: the bags of the DISTINCT entities of a sorted entity-key list, sorted by token.
+int bag_token_sort(const BagWs& w, char* base, const uint32_t* sk_ent, int64_t n_i, const int32_t* ndev_i,
+                   uint32_t sent_i, int ent_kb, uint32_t ent_tag, const int32_t* vals, const int32_t* starts,
+                   const int32_t* lens, int max_len, int64_t table_rows, hipStream_t s) {
+  const int64_t n_t = n_i * (int64_t)max_len;
+  char* bt = base + w.off_wt;
+  int32_t* tkeys = reinterpret_cast<int32_t*>(base + w.off_tkeys);
+  int32_t* tsrc = reinterpret_cast<int32_t*>(base + w.off_tsrc);
+  uint32_t* sk_t = reinterpret_cast<uint32_t*>(bt + w.wt.off_keys_out);
+  int32_t* ssrc_t = reinterpret_cast<int32_t*>(bt + w.wt.off_ssrc);
+  float* scoef_t = reinterpret_cast<float*>(bt + w.wt.off_scoef);
+  int32_t* count_t = reinterpret_cast<int32_t*>(bt + w.wt.off_count);
+  int kbt = 1;
+  while ((1ll << kbt) < table_rows && kbt < 30) ++kbt;
+  const uint32_t sent_t = 1u << kbt;
+  {
+    int64_t g = ceil_div(n_t, 256);
+    const int64_t cap = (int64_t)cu_count() * 16;
+    if (g > cap) g = cap;
+    k_bag_expand_heads<<<(int)g, 256, 0, s>>>(sk_ent, n_i, ndev_i, sent_i, ent_kb, ent_tag, vals, starts, lens,
+                                              max_len, table_rows, tkeys, tsrc);
+    ARX_CHECK_LAUNCH();
+  }
+  if (n_t <= kRankSortMax)
+    return launch_rank_sort(tkeys, n_t, sent_t, sk_t, reinterpret_cast<uint32_t*>(bt + w.wt.off_pos_out),
+                            count_t, s, tsrc, nullptr, ssrc_t, scoef_t);
+  return launch_radix_sort(tkeys, tsrc, nullptr, n_t, sent_t, kbt,
+                           reinterpret_cast<uint32_t*>(bt + w.wt.off_keys_tmp), sk_t,
+                           reinterpret_cast<int32_t*>(bt + w.wt.off_pos_in), ssrc_t,
+                           reinterpret_cast<float*>(bt + w.wt.off_pos_out), scoef_t,
+                           reinterpret_cast<int32_t*>(bt + w.wt.off_hist), count_t, count_t + 2, s);
+}
+
+// Stage 2b: token runs over the merged rows Gu (every coefficient is 1) -> Adagrad.
+int bag_token_apply(const BagWs& w, char* base, int64_t n_i, int max_len, float* E, float* acc, float* bias,
+                    float* bias_acc, int64_t table_rows, int32_t* aux_cnt, int d, const float* lr_dev,
+                    const float* gscale_dev, hipStream_t s) {
+  const int64_t n_t = n_i * (int64_t)max_len;
+  char* bt = base + w.off_wt;
+  const bool rank_t = n_t <= kRankSortMax;
+  int32_t* count_t = reinterpret_cast<int32_t*>(bt + w.wt.off_count);
+  int kbt = 1;
+  while ((1ll << kbt) < table_rows && kbt < 30) ++kbt;
+  TableSet ts = {};
+  ts.E[0] = E;
+  ts.acc[0] = acc;
+  ts.bias[0] = bias;
+  ts.bias_acc[0] = bias_acc;
+  ts.cnt[0] = rank_t ? aux_cnt : nullptr;
+  ts.kb = kbt;
+  return launch_apply(ts, d, reinterpret_cast<uint32_t*>(bt + w.wt.off_keys_out), nullptr,
+                      reinterpret_cast<int32_t*>(bt + w.wt.off_ssrc), nullptr, n_t, 1u << kbt,
+                      reinterpret_cast<float*>(base + w.off_gu), d,
+                      bias ? reinterpret_cast<float*>(base + w.off_gub) : nullptr, lr_dev, gscale_dev,
+                      reinterpret_cast<float*>(bt + w.wt.off_scratch),
+                      reinterpret_cast<float*>(bt + w.wt.off_scratch_b),
+                      reinterpret_cast<float*>(bt + w.wt.off_scratch_h),
+                      reinterpret_cast<float*>(bt + w.wt.off_scratch_hb),
+                      reinterpret_cast<int32_t*>(bt + w.wt.off_list), count_t, 1, false,
+                      rank_t ? nullptr : count_t + 2, s);
+}
+
+}  // namespace
+}  // namespace arx
+
 namespace arx {
 
 int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const CatSites& st,
                                 const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
                                 const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
                                 float* coef_buf, void* workspace, size_t workspace_bytes,
-                                hipStream_t s, int phase) {
+                                hipStream_t s, int phase, const BagStage* bag) {
   // phase 1 (keys + sort) depends on the lookup ids only, not on any gradient: the caller may run
   // it on a side stream under the forward / backward GEMMs and join before phase 2 (apply).  Both
   // phases must see the same workspace, untouched in between.
@@ -1297,13 +1407,45 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
     }
     n_dev = count + 2;
   }
+  // ---- a multi-hot table whose entity lookups are the lookups of table 0 (BagStage): its
+  // distinct entities are the run heads of table 0 in the sorted list just made -- no entity sort
+  // of its own; the merged gradient row of each comes out of the apply below as a side output
+  BagWs bw;
+  char* bbase = nullptr;
+  int64_t n0 = 0;                              // lookups of table 0 (host count: its keys sort first)
+  if (bag) {
+    if (st.nextra != 0) { set_error("arx_sparse_adagrad_cat_multi_bags: no pre-expanded segments"); return ARX_EINVAL; }
+    for (int q = 0; q < st.nsites; ++q)
+      if (st.table[q] == 0) n0 += st.offs[q + 1] - st.offs[q];
+    if (n0 == 0) bag = nullptr;
+  }
+  if (bag) {
+    if (bag_ws_layout(n0, bag->max_len, d, &bw) != ARX_OK || !bag->ws || bag->ws_bytes < bw.total) {
+      set_error("arx_sparse_adagrad_cat_multi_bags: bag workspace too small (%zu < %zu)", bag->ws_bytes, bw.total);
+      return ARX_EWORKSPACE;
+    }
+    bbase = reinterpret_cast<char*>(bag->ws);
+    if (phase & 1) {
+      rc = bag_token_sort(bw, bbase, keys_out, n0, n_dev, sentinel, ts.kb, 0u, bag->vals, bag->starts,
+                          bag->lens, bag->max_len, bag->rows, s);
+      if (rc) return rc;
+    }
+  }
   if (!(phase & 2)) return ARX_OK;
-  bool any_bias = false;
+  bool any_bias = bag && bag->bias;
   for (int t = 0; t < ntables; ++t) any_bias = any_bias || ts.bias[t] != nullptr;
   const float* gb_in = any_bias ? Gb : nullptr;
-  return launch_apply(ts, d, keys_out, spos_arg, src_arg, coef_arg, n, sentinel, G, ldg, gb_in, lr_dev,
-                      gscale_dev, scratch, scratch_b, scratch_h, scratch_hb, list, count,
-                      /*wpw=*/(ntables > 1 || st.nextra == 0) ? 8 : 1, /*multi=*/ntables > 1, n_dev, s);
+  MergeOut side = {nullptr, nullptr, nullptr, -1, 0};
+  if (bag)
+    side = MergeOut{reinterpret_cast<float*>(bbase + bw.off_gu),
+                    bag->bias ? reinterpret_cast<float*>(bbase + bw.off_gub) : nullptr, bag->lens, 0, ts.kb};
+  rc = launch_apply(ts, d, keys_out, spos_arg, src_arg, coef_arg, n, sentinel, G, ldg, gb_in, lr_dev,
+                    gscale_dev, scratch, scratch_b, scratch_h, scratch_hb, list, count,
+                    /*wpw=*/(ntables > 1 || st.nextra == 0) ? 8 : 1, /*multi=*/ntables > 1, n_dev, s,
+                    bag ? &side : nullptr);
+  if (rc || !bag) return rc;
+  return bag_token_apply(bw, bbase, n0, bag->max_len, bag->E, bag->acc, bag->bias, bag->bias_acc, bag->rows,
+                         bag->aux_cnt, d, lr_dev, gscale_dev, s);
 }
 
 }  // namespace arx
@@ -1448,30 +1590,6 @@ int arx_merged_sq_norm(const int32_t* keys, const int32_t* src, const float* coe
   return ARX_OK;
 }
 
-// ---- multi-hot lookups: merge per entity first, then per token (see arx.h) ----
-namespace {
-struct BagWs {
-  SparseWs wi, wt;                        // sort / apply workspaces of the two stages
-  size_t off_wi, off_wt, off_ikeys, off_isrc, off_icoef, off_tkeys, off_tsrc, off_gu, off_gub, total;
-};
-int bag_ws_layout(int64_t n_i, int max_len, int d, BagWs* w) {
-  const int64_t n_t = n_i * (int64_t)max_len;
-  if (sparse_ws_layout(n_i, 256, &w->wi) != ARX_OK || sparse_ws_layout(n_t, 256, &w->wt) != ARX_OK)
-    return ARX_EINVAL;
-  size_t o = 0;
-  w->off_wi = o; o += align_up(w->wi.total, 256);
-  w->off_wt = o; o += align_up(w->wt.total, 256);
-  w->off_ikeys = o; o += align_up((size_t)n_i * 4, 256);
-  w->off_isrc = o; o += align_up((size_t)n_i * 4, 256);
-  w->off_icoef = o; o += align_up((size_t)n_i * 4, 256);
-  w->off_tkeys = o; o += align_up((size_t)n_t * 4, 256);
-  w->off_tsrc = o; o += align_up((size_t)n_t * 4, 256);
-  w->off_gu = o; o += align_up((size_t)n_i * (size_t)d * 4, 256);
-  w->off_gub = o; o += align_up((size_t)n_i * 4, 256);
-  w->total = o;
-  return ARX_OK;
-}
-}  // namespace
 
 size_t arx_sparse_adagrad_bags_workspace_bytes(int64_t n_lookups, int max_len, int d) {
   BagWs w;
@@ -1516,8 +1634,6 @@ int arx_sparse_adagrad_bags(int phase, float* E, float* acc, float* bias, float*
   for (int t = 0; t < kMaxTables; ++t) st.rows[t] = n_entities;
   int kbi = 1;
   while ((1ll << kbi) < n_entities && kbi < 30) ++kbi;
-  int kbt = 1;
-  while ((1ll << kbt) < table_rows && kbt < 30) ++kbt;
   st.kb = kbi;
   st.nextra = 0;
   st.xoffs[0] = 0;
@@ -1537,26 +1653,18 @@ int arx_sparse_adagrad_bags(int phase, float* E, float* acc, float* bias, float*
   hipStream_t s = as_stream(stream);
   char* base = reinterpret_cast<char*>(workspace);
   char* bi = base + w.off_wi;
-  char* bt = base + w.off_wt;
   int32_t* ikeys = reinterpret_cast<int32_t*>(base + w.off_ikeys);
   int32_t* isrc = reinterpret_cast<int32_t*>(base + w.off_isrc);
   float* icoef = reinterpret_cast<float*>(base + w.off_icoef);
-  int32_t* tkeys = reinterpret_cast<int32_t*>(base + w.off_tkeys);
-  int32_t* tsrc = reinterpret_cast<int32_t*>(base + w.off_tsrc);
   float* Gu = reinterpret_cast<float*>(base + w.off_gu);
   float* Gub = reinterpret_cast<float*>(base + w.off_gub);
-  const uint32_t sent_i = 1u << kbi, sent_t = 1u << kbt;
+  const uint32_t sent_i = 1u << kbi;
   uint32_t* sk_i = reinterpret_cast<uint32_t*>(bi + w.wi.off_keys_out);
   int32_t* ssrc_i = reinterpret_cast<int32_t*>(bi + w.wi.off_ssrc);
   float* scoef_i = reinterpret_cast<float*>(bi + w.wi.off_scoef);
   int32_t* count_i = reinterpret_cast<int32_t*>(bi + w.wi.off_count);
-  uint32_t* sk_t = reinterpret_cast<uint32_t*>(bt + w.wt.off_keys_out);
-  int32_t* ssrc_t = reinterpret_cast<int32_t*>(bt + w.wt.off_ssrc);
-  float* scoef_t = reinterpret_cast<float*>(bt + w.wt.off_scoef);
-  int32_t* count_t = reinterpret_cast<int32_t*>(bt + w.wt.off_count);
-  const bool rank_i = n_i <= kRankSortEntities, rank_t = n_t <= kRankSortMax;
+  const bool rank_i = n_i <= kRankSortEntities;
   const int32_t* ndev_i = rank_i ? nullptr : count_i + 2;
-  const int32_t* ndev_t = rank_t ? nullptr : count_t + 2;
   int rc;
   if (phase & 1) {
     // ---- stage 1a: (entity, gradient row, coef) of every lookup, sorted by entity ----
@@ -1573,23 +1681,7 @@ int arx_sparse_adagrad_bags(int phase, float* E, float* acc, float* bias, float*
                              reinterpret_cast<int32_t*>(bi + w.wi.off_hist), count_i, count_i + 2, s);
     if (rc) return rc;
     // ---- stage 1b: bags of the DISTINCT entities, sorted by token ----
-    {
-      int64_t g = ceil_div(n_t, 256);
-      const int64_t cap = (int64_t)cu_count() * 16;
-      if (g > cap) g = cap;
-      k_bag_expand_heads<<<(int)g, 256, 0, s>>>(sk_i, n_i, ndev_i, sent_i, vals, starts, lens, max_len,
-                                                table_rows, tkeys, tsrc);
-      ARX_CHECK_LAUNCH();
-    }
-    if (rank_t)
-      rc = launch_rank_sort(tkeys, n_t, sent_t, sk_t, reinterpret_cast<uint32_t*>(bt + w.wt.off_pos_out),
-                            count_t, s, tsrc, nullptr, ssrc_t, scoef_t);
-    else
-      rc = launch_radix_sort(tkeys, tsrc, nullptr, n_t, sent_t, kbt,
-                             reinterpret_cast<uint32_t*>(bt + w.wt.off_keys_tmp), sk_t,
-                             reinterpret_cast<int32_t*>(bt + w.wt.off_pos_in), ssrc_t,
-                             reinterpret_cast<float*>(bt + w.wt.off_pos_out), scoef_t,
-                             reinterpret_cast<int32_t*>(bt + w.wt.off_hist), count_t, count_t + 2, s);
+    rc = bag_token_sort(w, base, sk_i, n_i, ndev_i, sent_i, kbi, 0u, vals, starts, lens, max_len, table_rows, s);
     if (rc) return rc;
   }
   if (!(phase & 2)) return ARX_OK;
@@ -1597,7 +1689,7 @@ int arx_sparse_adagrad_bags(int phase, float* E, float* acc, float* bias, float*
   {
     TableSet none = {};
     none.kb = kbi;
-    MergeOut mo = {Gu, bias ? Gub : nullptr, lens};
+    MergeOut mo = {Gu, bias ? Gub : nullptr, lens, -1, 0};
     rc = launch_apply(none, d, sk_i, nullptr, ssrc_i, scoef_i, n_i, sent_i, G, ldg, bias ? Gb : nullptr,
                       lr_dev, gscale_dev, reinterpret_cast<float*>(bi + w.wi.off_scratch),
                       reinterpret_cast<float*>(bi + w.wi.off_scratch_b),
@@ -1607,19 +1699,8 @@ int arx_sparse_adagrad_bags(int phase, float* E, float* acc, float* bias, float*
     if (rc) return rc;
   }
   // ---- stage 2b: token runs over the merged rows (every coefficient is 1) -> Adagrad ----
-  TableSet ts = {};
-  ts.E[0] = E;
-  ts.acc[0] = acc;
-  ts.bias[0] = bias;
-  ts.bias_acc[0] = bias_acc;
-  ts.cnt[0] = rank_t ? aux_cnt : nullptr;
-  ts.kb = kbt;
-  return launch_apply(ts, d, sk_t, nullptr, ssrc_t, nullptr, n_t, sent_t, Gu, d, bias ? Gub : nullptr, lr_dev,
-                      gscale_dev, reinterpret_cast<float*>(bt + w.wt.off_scratch),
-                      reinterpret_cast<float*>(bt + w.wt.off_scratch_b),
-                      reinterpret_cast<float*>(bt + w.wt.off_scratch_h),
-                      reinterpret_cast<float*>(bt + w.wt.off_scratch_hb),
-                      reinterpret_cast<int32_t*>(bt + w.wt.off_list), count_t, 1, false, ndev_t, s);
+  return bag_token_apply(w, base, n_i, max_len, E, acc, bias, bias_acc, table_rows, aux_cnt, d, lr_dev,
+                         gscale_dev, s);
 }
 
 int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const float* lr_dev,

@@ -365,7 +365,7 @@ static int cat_multi_impl(int phase, int ntables, float* const* E, float* const*
                                  const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
                                  float* coef_buf, int nextra, const int64_t* extra_n,
                                  const int32_t* extra_table, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+                                 size_t workspace_bytes, void* stream, const BagStage* bag = nullptr) {
   ARX_CHECK_ARG(ntables >= 1 && ntables <= kMaxTables, "arx_sparse_adagrad_cat_multi: 1..4 tables");
   ARX_CHECK_ARG(nsites >= 0 && nsites <= kMaxSites && nextra >= 0 && nextra <= kMaxSites &&
                     nsites + nextra > 0,
@@ -416,7 +416,8 @@ static int cat_multi_impl(int phase, int ntables, float* const* E, float* const*
     st.table[q] = live ? site_table[q] : 0;
     st.offs[q + 1] = st.offs[q] + (live ? site_n[q] : 0);
     if (live)
-      ARX_CHECK_ARG(site_ids[q] && site_n[q] >= 0 && site_table[q] >= 0 && site_table[q] < ntables,
+      ARX_CHECK_ARG((site_ids[q] || site_n[q] == 0) && site_n[q] >= 0 && site_table[q] >= 0 &&
+                        site_table[q] < ntables,
                     "arx_sparse_adagrad_cat_multi: bad site");
   }
   st.nextra = nextra;
@@ -433,7 +434,7 @@ static int cat_multi_impl(int phase, int ntables, float* const* E, float* const*
   if (n == 0) return ARX_OK;
   ARX_CHECK_ARG(n < (int64_t)INT_MAX, "arx_sparse_adagrad_cat_multi: too many contributions");
   return sparse_adagrad_sites_sorted(ts, ntables, d, st, G, ldg, Gb, lr_dev, gscale_dev, keys_buf,
-                                     src_buf, coef_buf, workspace, workspace_bytes, as_stream(stream), phase);
+                                     src_buf, coef_buf, workspace, workspace_bytes, as_stream(stream), phase, bag);
 }
 
 int arx_sparse_adagrad_cat_multi(int ntables, float* const* E, float* const* acc, float* const* bias,
@@ -470,6 +471,34 @@ int arx_sparse_adagrad_cat_multi_phase(int phase, int ntables, float* const* E, 
                         site_cat_map, site_ids, site_n, site_row_base, site_coef, G, ldg, Gb, lr_dev,
                         gscale_dev, keys_buf, src_buf, coef_buf, nextra, extra_n, extra_table, workspace,
                         workspace_bytes, stream);
+}
+
+int arx_sparse_adagrad_cat_multi_bags(int phase, int ntables, float* const* E, float* const* acc,
+                                      float* const* bias, float* const* bias_acc,
+                                      const int64_t* table_rows, int32_t* const* aux_cnt, int d,
+                                      int nsites, const int32_t* site_table,
+                                      const int32_t* const* site_cat_map,
+                                      const int32_t* const* site_ids, const int64_t* site_n,
+                                      const int32_t* site_row_base, const float* site_coef,
+                                      const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
+                                      const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
+                                      float* coef_buf, void* workspace, size_t workspace_bytes,
+                                      float* bag_E, float* bag_acc, float* bag_bias, float* bag_bias_acc,
+                                      int64_t bag_rows, const int32_t* vals, const int32_t* starts,
+                                      const int32_t* lens, int max_len, int32_t* bag_aux_cnt,
+                                      void* bag_workspace, size_t bag_workspace_bytes, void* stream) {
+  ARX_CHECK_ARG(phase == 1 || phase == 2 || phase == 3, "arx_sparse_adagrad_cat_multi_bags: phase 1, 2 or 3");
+  ARX_CHECK_ARG(bag_E && vals && starts && lens && bag_rows > 0 && max_len > 0 && bag_workspace,
+                "arx_sparse_adagrad_cat_multi_bags: null pointer / bad sizes");
+  ARX_CHECK_ARG(bag_acc ? (bag_bias == nullptr) == (bag_bias_acc == nullptr) : bag_bias_acc == nullptr,
+                "arx_sparse_adagrad_cat_multi_bags: bag bias and bias_acc go together");
+  ARX_CHECK_ARG(!(bag_bias && !Gb), "arx_sparse_adagrad_cat_multi_bags: bag bias given without Gb");
+  BagStage bag = {bag_E, bag_acc, bag_bias, bag_bias_acc, bag_rows, vals, starts, lens, max_len, bag_aux_cnt,
+                  bag_workspace, bag_workspace_bytes};
+  return cat_multi_impl(phase, ntables, E, acc, bias, bias_acc, table_rows, aux_cnt, d, nsites, site_table,
+                        site_cat_map, site_ids, site_n, site_row_base, site_coef, G, ldg, Gb, lr_dev,
+                        gscale_dev, keys_buf, src_buf, coef_buf, 0, nullptr, nullptr, workspace,
+                        workspace_bytes, stream, &bag);
 }
 
 }  // extern "C"

@@ -158,9 +158,9 @@ def k7_in_situ(model, d):
     jobs = list(plan._jobs)
 
     def sorts():
-        for kind, what, key, _n in jobs:
+        for kind, what, key in (j[:3] for j in jobs):
             if kind == 'multi':
-                plan._apply_multi(what, phase=1, key=key)
+                plan._apply_multi(what[0], phase=1, key=key, bag=what[1])
             elif kind == 'bags':
                 plan._bag_pass(what, key, phase=1)
             else:

@@ -468,6 +468,35 @@ int arx_sparse_adagrad_cat_multi_phase(int phase, int ntables, float* const* E, 
                                        const int32_t* extra_table, void* workspace,
                                        size_t workspace_bytes, void* stream);
 
+/* arx_sparse_adagrad_cat_multi_phase with a MULTI-HOT table riding on the pass (HET layout,
+ * attributes/comb_attribute.py:151-176: an item has an id feature AND a multi-hot attribute, both looked
+ * up with the same item ids and fed by the same gradient rows -- embed_attribute.py:383-400).  The
+ * lookups of one-hot table 0 (site_table == 0) are also the entity lookups of the bags of table
+ * bag_E[bag_rows, d].  The bag index is given PER ROW OF TABLE 0 (the sorted keys of the pass are
+ * rows): the bag of the entity that maps to row r is vals[starts[r] .. starts[r] + lens[r]); starts,
+ * lens: int32[table_rows[0]].  The entity -> row map (site_cat_map, or the identity) must be one-to-one.
+ *   phase 1: the one-hot sort, then -- from its sorted list, whose run heads of table 0 ARE the
+ *            distinct entities -- the bags of the distinct entities, sorted by token;
+ *   phase 2: the one-hot apply, which writes the merged, 1/len-scaled gradient row of every
+ *            distinct entity as a side output, then the token runs over those rows -> ONE Adagrad
+ *            update per touched token row (same result as arx_sparse_adagrad_bags on the same sites).
+ * Saves the entity sort and the merge pass of arx_sparse_adagrad_bags.  No pre-expanded segments.
+ * bag_workspace >= arx_sparse_adagrad_bags_workspace_bytes(lookups of table 0, max_len, d). */
+int arx_sparse_adagrad_cat_multi_bags(int phase, int ntables, float* const* E, float* const* acc,
+                                      float* const* bias, float* const* bias_acc,
+                                      const int64_t* table_rows, int32_t* const* aux_cnt, int d,
+                                      int nsites, const int32_t* site_table,
+                                      const int32_t* const* site_cat_map,
+                                      const int32_t* const* site_ids, const int64_t* site_n,
+                                      const int32_t* site_row_base, const float* site_coef,
+                                      const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
+                                      const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
+                                      float* coef_buf, void* workspace, size_t workspace_bytes,
+                                      float* bag_E, float* bag_acc, float* bag_bias, float* bag_bias_acc,
+                                      int64_t bag_rows, const int32_t* vals, const int32_t* starts,
+                                      const int32_t* lens, int max_len, int32_t* bag_aux_cnt,
+                                      void* bag_workspace, size_t bag_workspace_bytes, void* stream);
+
 /* Multi-hot lookups of ONE table (embed_attribute.py:397-406: embedding_lookup of the bag
  * tokens + unsorted_segment_sum / length; hmf_model.py:146-151 one Adagrad apply per variable),
  * in two merge stages so that an entity that occurs k times in a step (Zipf-popular target

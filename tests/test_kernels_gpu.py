@@ -814,11 +814,13 @@ def test_sparse_adagrad_cat_multi_with_multihot_segments(dev, B):
 
 @pytest.mark.parametrize("d,rows,ns", [(128, (5000, 7000), (4096, 1024, 4096)),
                                        (32, (40, 1000, 17), (300, 64, 50, 2000)),
-                                       (64, (100000, 300000), (20000, 30000))])
+                                       (64, (100000, 300000), (20000, 30000)),
+                                       (32, (1 << 20, 70000, 300), (16384, 17000, 5000, 1024)),   # one-launch LDS sort, 2 passes
+                                       (16, (3000000, 50), (12000, 9000))])                       # ... 22 key bits: 3 passes
 def test_sparse_adagrad_cat_multi(dev, d, rows, ns):
     """Several one-hot tables in one pass (table index in the sort key) == one reference
     update per table; deterministic; counters left clean.  Small n: LDS rank sort + ticket
-    apply; large n: radix sort + window apply."""
+    apply; up to 20 k keys per table: one-launch LDS radix sort; larger: global radix sort; window apply."""
     from arx import ops
     import torch
     rng = np.random.default_rng(d + sum(ns))
@@ -935,6 +937,7 @@ def test_merged_sq_norm(dev, n, rows, d, L):
     (128, 40000, 100002, 64, (20000, 1024), (1, 2)), # C3-like shape
     (16, 10, 8, 64, (9000, 0, 5), (3,)),             # few entities: runs of thousands, an empty site
     (32, 5000, 900, 6, (30000, 100), (1, 2)),        # > 24 k lookups: the entity stage takes the radix sort
+    (64, 30000, 2000, 8, (16384, 1024), (1, 2)),     # C3-sized entity stage: the one-launch LDS sort
 ])
 def test_sparse_adagrad_bags(dev, d, n_ent, Vf, max_len, ns, phases):
     """arx_sparse_adagrad_bags (merge per entity, then per token) == the plain contribution-level
@@ -999,6 +1002,116 @@ def test_sparse_adagrad_bags(dev, d, n_ent, Vf, max_len, ns, phases):
     ops.sparse_adagrad_bags(tE, tacc, None, None, tv, tst, tl, args, tG, None, lr_dev, ops.Workspace(dev),
                             gscale_dev=gs_dev)
     np.testing.assert_allclose(tE.cpu().numpy(), rE, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("d,n_ent,n_user,Vf,max_len,ns,phases", [
+    (128, 40000, 50000, 100002, 48, (16384, 1024, 16384), (1, 2)),   # C3 HET shape: radix sort, window apply
+    (32, 300, 100, 70, 6, (500, 40, 300), (3,)),                      # below the rank-sort limit
+    (64, 5000, 7000, 900, 9, (6000, 0, 5000), (1, 2)),                # an empty site; 11 k keys
+    (16, 12, 9, 8, 30, (9000, 100, 50), (3,)),                        # few entities: runs of thousands (finish kernel side output)
+])
+def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, phases):
+    """arx_sparse_adagrad_cat_multi_bags: the one-hot pass over (item id table, user table) with the
+    item's multi-hot table riding on it == the three tables updated separately from the plain
+    contribution lists (id rows: coef * G[row]; token rows: coef / len * G[row] per bag token)."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(d + n_ent + max_len)
+    vals, starts, lens = _csr(rng, n_ent, Vf, max_len, zipf=True)
+    vals[rng.integers(0, len(vals), size=3)] = Vf + 5          # out-of-range tokens are dropped
+    m = sum(ns) + 5
+    G = rng.standard_normal((m, d)).astype(np.float32)
+    Gb = rng.standard_normal((m,)).astype(np.float32)
+    p_it = 1.0 / np.arange(1, n_ent + 1) ** 1.05
+    p_it /= p_it.sum()
+    n_t, n_p, n_u = ns
+    it_t = rng.choice(n_ent, size=n_t, p=p_it).astype(np.int32)
+    it_p = rng.choice(n_ent, size=n_p, replace=n_p > n_ent).astype(np.int32)
+    us = rng.integers(0, n_user, size=n_u).astype(np.int32)
+    if n_t > 4:
+        it_t[:2] = [n_ent + 3, n_ent + 5]                      # ids the map sends to -1 are dropped everywhere
+    sites = [(0, it_t, 2, 0.5), (0, it_p, 2 + n_t, 0.25), (1, us, 2 + n_t + n_p, 1.0)]
+    # entity -> id-table row: one-to-one, not the identity (vocabulary rows 0, 1 are reserved)
+    ent2row = (rng.permutation(n_ent) + 2).astype(np.int32)
+    n_rows0 = n_ent + 2
+
+    def table(V):
+        return (rng.standard_normal((V, d)).astype(np.float32), (0.1 + rng.random((V, d))).astype(np.float32),
+                rng.standard_normal((V,)).astype(np.float32), np.full((V,), 0.1, dtype=np.float32))
+    T_it, T_us, T_bag = table(n_rows0), table(n_user), table(Vf)
+    lr, gs = 0.3, 0.7
+
+    def ref(tab, keys, src, coef):
+        E, acc, bias, bacc = [x.astype(np.float64).copy() for x in tab]
+        g = np.zeros_like(E)
+        gb = np.zeros_like(bias)
+        np.add.at(g, keys, coef[:, None] * G[src].astype(np.float64))
+        np.add.at(gb, keys, coef * Gb[src].astype(np.float64))
+        g *= gs
+        gb *= gs
+        t = np.zeros(E.shape[0], bool)
+        t[keys] = True
+        acc[t] += g[t] ** 2
+        E[t] -= lr * g[t] / np.sqrt(acc[t])
+        bacc[t] += gb[t] ** 2
+        bias[t] -= lr * gb[t] / np.sqrt(bacc[t])
+        return E, acc, bias, bacc
+
+    def contribs(tb):
+        ks, ss, cs = [], [], []
+        for t, ids, r0, c in sites:
+            if t != tb:
+                continue
+            ok = (ids >= 0) & (ids < (n_ent if tb == 0 else n_user))
+            ks.append(ids[ok].astype(np.int64)); ss.append(r0 + np.nonzero(ok)[0]); cs.append(np.full(ok.sum(), c))
+        return np.concatenate(ks), np.concatenate(ss), np.concatenate(cs)
+    k0, s0, c0 = contribs(0)
+    R_it = ref(T_it, ent2row[k0].astype(np.int64), s0, c0)
+    R_us = ref(T_us, *contribs(1))
+    bk, bs, bc = [], [], []
+    for e, s_, c_ in zip(k0, s0, c0):
+        toks = vals[starts[e]:starts[e] + lens[e]]
+        ok = (toks >= 0) & (toks < Vf)
+        bk.append(toks[ok].astype(np.int64)); bs.append(np.full(ok.sum(), s_)); bc.append(np.full(ok.sum(), c_ / lens[e]))
+    R_bag = ref(T_bag, np.concatenate(bk), np.concatenate(bs), np.concatenate(bc))
+
+    lr_dev = torch.tensor([lr], dtype=torch.float32, device=dev)
+    gs_dev = torch.tensor([gs], dtype=torch.float32, device=dev)
+    starts_r = np.zeros(n_rows0, dtype=np.int32)
+    lens_r = np.zeros(n_rows0, dtype=np.int32)
+    starts_r[ent2row] = starts
+    lens_r[ent2row] = lens
+    tv, tst, tl = _t(dev, vals), _t(dev, starts_r), _t(dev, lens_r)
+    # the map is indexed by the lookup id: out-of-range ids must not reach it (the reference's ids are
+    # always entities); the test's two invalid ids are mapped through a padded copy
+    map_pad = np.full(n_ent + 8, -1, dtype=np.int32)
+    map_pad[:n_ent] = ent2row
+    tmap = _t(dev, map_pad)
+    tG, tGb = _t(dev, G), _t(dev, Gb)
+    outs = []
+    for rep in range(2):
+        D_it, D_us, D_bag = [[_t(dev, x) for x in tab] for tab in (T_it, T_us, T_bag)]
+        cnts = [torch.zeros(n_rows0, dtype=torch.int32, device=dev), torch.zeros(n_user, dtype=torch.int32, device=dev)]
+        args = ops.MultiCatArgs([(D_it[0], D_it[1], D_it[2], D_it[3], cnts[0]),
+                                 (D_us[0], D_us[1], D_us[2], D_us[3], cnts[1])],
+                                [(t, tmap if t == 0 else None, _t(dev, ids), r0, c) for t, ids, r0, c in sites])
+        n = args.total
+        kb_ = torch.empty(n, dtype=torch.int32, device=dev)
+        sb_ = torch.empty(n, dtype=torch.int32, device=dev)
+        cb_ = torch.empty(n, dtype=torch.float32, device=dev)
+        ws, bws = ops.Workspace(dev), ops.Workspace(dev)
+        bcnt = torch.zeros(Vf, dtype=torch.int32, device=dev)
+        for ph in phases:
+            ops.sparse_adagrad_cat_multi_bags(args, tG, tGb, lr_dev, kb_, sb_, cb_, ws, D_bag[0], D_bag[1],
+                                              D_bag[2], D_bag[3], tv, tst, tl, max_len, bws,
+                                              gscale_dev=gs_dev, phase=ph, bag_aux_cnt=bcnt)
+        torch.cuda.synchronize()
+        assert int(bcnt.abs().sum().item()) == 0 and all(int(c.abs().sum().item()) == 0 for c in cnts)
+        outs.append(D_it + D_us + D_bag)
+    for got, want in zip(outs[0], list(R_it) + list(R_us) + list(R_bag)):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-5)
+    for a, b in zip(outs[0], outs[1]):                 # bit-reproducible
+        assert torch.equal(a, b)
 
 
 def _unpack_bits(words, n):
