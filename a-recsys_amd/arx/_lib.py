@@ -44,6 +44,8 @@ PROTOTYPES = {
     "arx_gather_onehot_packed_fwd": (cint, [f32p, f32p, i32p, i32p, i64, cint, f32, f32p, i64, vp]),
     "arx_gather_id_plus_bag": (cint, [f32p, f32p, i32p, f32p, f32p, i32p, i32p, i32p, i32p, i64, cint, f32,
                                       cint, f32p, i64, f32p, vp]),
+    "arx_lookup_multi": (cint, [cint] + [C.POINTER(vp)] * 9 + [C.POINTER(i64), cint, C.POINTER(f32), C.POINTER(vp),
+                                C.POINTER(i64), C.POINTER(vp), vp]),
     "arx_gather_onehot_multi": (cint, [cint, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                        C.POINTER(i64), cint, C.POINTER(f32), C.POINTER(vp), C.POINTER(i64),
                                        C.POINTER(vp), vp]),

@@ -835,8 +835,10 @@ class Plan(object):
             groups = {}
             if not os.environ.get('ARX_NO_MULTI_GATHER'):
                 for n in self.order:
-                    if (isinstance(n, EntityEmbed) and len(n.feats) == 1 and n.feats[0].kind == 'cat'
-                            and not n.concat and type(n.inputs[0]).__name__ in ('IdsInput', 'IdsSlice')
+                    kinds = tuple(f.kind for f in n.feats) if isinstance(n, EntityEmbed) else ()
+                    if (kinds in (('cat',), ('mulhot',), ('cat', 'mulhot')) and not n.concat
+                            and all(f.d == n.feats[0].d for f in n.feats)
+                            and type(n.inputs[0]).__name__ in ('IdsInput', 'IdsSlice')
                             and n.inputs[0].value.dtype == torch.int32):
                         groups.setdefault(n.shape[1], []).append(n)
             for d_, nodes in groups.items():
@@ -844,21 +846,44 @@ class Plan(object):
                     grp = nodes[k:k + 8]
                     if len(grp) < 2:
                         continue
+                    for n in grp:
+                        n.alloc_value()
+                    if all(len(n.feats) == 1 and n.feats[0].kind == 'cat' for n in grp):
+                        sites = [(n.feats[0].table.E, n.feats[0].table.bias if n.with_bias else None,
+                                  n.feats[0].maps[0], n.inputs[0].value, n.value, n.out_scale,
+                                  n.bias_value if n.with_bias else None) for n in grp]
+                        self._pregather.append((ops.GatherSet(sites), grp))
+                        continue
+                    # one-hot and / or multi-hot features per lookup (users, HET / MIX items): arx_lookup_multi
                     sites = []
                     for n in grp:
-                        f = n.feats[0]
-                        n.alloc_value()
-                        sites.append((f.table.E, f.table.bias if n.with_bias else None, f.maps[0],
-                                      n.inputs[0].value, n.value, n.out_scale,
-                                      n.bias_value if n.with_bias else None))
-                    self._pregather.append((ops.GatherSet(sites), grp))
+                        fc = next((f for f in n.feats if f.kind == 'cat'), None)
+                        fm = next((f for f in n.feats if f.kind == 'mulhot'), None)
+                        wb = n.with_bias
+                        sites.append((fc.table.E if fc else None, fc.table.bias if (fc and wb) else None,
+                                      fc.maps[0] if fc else None, fm.table.E if fm else None,
+                                      fm.table.bias if (fm and wb) else None,
+                                      fm.maps[0] if fm else None, fm.maps[1] if fm else None,
+                                      fm.maps[2] if fm else None, n.inputs[0].value, n.value,
+                                      n.out_scale / len(n.feats), n.bias_value if wb else None))
+                    self._pregather.append((ops.LookupSet(sites), grp))
         if self.train:
             self._early_sort()
         pre = set()
         for gs, grp in self._pregather:
-            ops.gather_onehot_multi(gs)
+            if isinstance(gs, ops.LookupSet):
+                ops.lookup_multi(gs)
+            else:
+                ops.gather_onehot_multi(gs)
             pre.update(id(n) for n in grp)
-        early_after = int(os.environ.get('ARX_K7_EARLY_AFTER', '0')) if self.train else -1
+        # where the sort branch is issued decides which chain the graph gives the first queue to.
+        # Measured (B=16384): with the bag table riding on the one-hot pass (C3 HET, ~100 us of
+        # sorts) the branch issued BEFORE the lookups ran ahead of them -- the first gather started
+        # ~50 us after the feed: 367 us/step; issued after the first lookup: 352 us.  With a
+        # two-stage bag pass of its own (C3-MIX, ~135 us of sorts) the early start wins (414 vs 423
+        # us); one-hot only (C2): no difference.
+        rider = any(j[0] == 'multi' and j[1][1] is not None for j in self._early_jobs)
+        early_after = int(os.environ.get('ARX_K7_EARLY_AFTER', '1' if rider else '0')) if self.train else -1
         if early_after == 0:
             self._early_launch()
         # lookups whose ids are placeholders are independent of each other: fork them

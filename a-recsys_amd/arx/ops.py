@@ -196,6 +196,32 @@ def gather_onehot_multi(gs):
          gs.ldo, gs.bias_out, _stream())
 
 
+class LookupSet(object):
+    """Descriptor arrays of arx_lookup_multi, built once per plan.  sites: [(E_id|None, bias_id|None,
+    cat_map|None, E_tok|None, bias_tok|None, vals|None, starts|None, lens|None, ids, out, scale,
+    bias_out|None)], equal width d."""
+
+    def __init__(self, sites):
+        import ctypes as C
+        n = len(sites)
+        self.n = n
+        self.d = int((sites[0][0] if sites[0][0] is not None else sites[0][3]).shape[1])
+        vp = lambda xs: (C.c_void_p * n)(*[(_p(x) or None) for x in xs])
+        col = lambda k: vp([s[k] for s in sites])
+        self.E_id, self.bias_id, self.cat_map = col(0), col(1), col(2)
+        self.E_tok, self.bias_tok, self.vals, self.starts, self.lens = col(3), col(4), col(5), col(6), col(7)
+        self.ids, self.out, self.bias_out = col(8), col(9), col(11)
+        self.cnt = (C.c_int64 * n)(*[int(s[8].shape[0]) for s in sites])
+        self.ldo = (C.c_int64 * n)(*[_ld(s[9]) for s in sites])
+        self.scale = (C.c_float * n)(*[float(s[10]) for s in sites])
+        self._keep = sites
+
+
+def lookup_multi(ls):
+    call("arx_lookup_multi", ls.n, ls.E_id, ls.bias_id, ls.cat_map, ls.E_tok, ls.bias_tok, ls.vals, ls.starts,
+         ls.lens, ls.ids, ls.cnt, ls.d, ls.scale, ls.out, ls.ldo, ls.bias_out, _stream())
+
+
 def gather_mulhot_mean(E, bias, vals, starts, lens, ids, out, scale=1.0, accumulate=False,
                        bias_out=None):
     _chk(E, torch.float32, 'E'); _chk(ids, torch.int32, 'ids'); _chk(out, torch.float32, 'out')

@@ -349,6 +349,135 @@ static inline int grid_waves(int64_t nwaves) {
 
 // Several one-hot lookups (user ids, target items, the sampled pool, ...) in ONE launch: the step's
 // lookups are independent leaves of the graph and each costs a ~5 us launch slot on its own.
+// ---------------------------------------------------------------------------
+// Several lookups of a step in ONE launch, one-hot and / or multi-hot features per lookup
+// (embed_attribute.py:371-407 for users, target items and the sampled pool: three dependent-free
+// launches of ~6-15 us each, issued back to back, cost more in launch latency than in rows).
+// Site s: out[r] = scale * ( E_id[map[id]] (if E_id) + mean over the bag of id of E_tok rows (if E_tok) ).
+// Every workgroup belongs to one site (wave-uniform pointers: scalar loads of the kernel arguments);
+// a sub-group of LPR lanes takes kLookupRows rows, as in k_gather_mulhot.
+// ---------------------------------------------------------------------------
+struct LookupSites {
+  const float* E_id[kMaxSites];
+  const float* bias_id[kMaxSites];
+  const int32_t* cat_map[kMaxSites];
+  const float* E_tok[kMaxSites];
+  const float* bias_tok[kMaxSites];
+  const int32_t* vals[kMaxSites];
+  const int32_t* starts[kMaxSites];
+  const int32_t* lens[kMaxSites];
+  const int32_t* ids[kMaxSites];
+  float* out[kMaxSites];
+  float* bias_out[kMaxSites];
+  int64_t ldo[kMaxSites];
+  int64_t n[kMaxSites];
+  int32_t blk_end[kMaxSites];
+  float scale[kMaxSites];
+  int count;
+};
+
+constexpr int kLookupRows = 2;      // rows per sub-group
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_lookup_multi(LookupSites ls, int d) {
+  constexpr int GPW = 64 / LPR;
+  constexpr int RPB = 4 * GPW * kLookupRows;
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int lig = lane % LPR;
+  const int gid = lane / LPR;
+  const int col = lig * 4;
+  const bool colok = col < d;
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < kMaxSites - 1; ++k) s += (k < ls.count - 1 && (int)blockIdx.x >= ls.blk_end[k]) ? 1 : 0;
+  const int blk0 = s ? ls.blk_end[s - 1] : 0;
+  const int64_t n = ls.n[s];
+  const float* __restrict__ E1 = ls.E_id[s];
+  const float* __restrict__ bias1 = ls.bias_id[s];
+  const int32_t* __restrict__ cat_map1 = ls.cat_map[s];
+  const float* __restrict__ E = ls.E_tok[s];
+  const float* __restrict__ bias = ls.bias_tok[s];
+  const int32_t* __restrict__ vals = ls.vals[s];
+  const int32_t* __restrict__ starts = ls.starts[s];
+  const int32_t* __restrict__ lens = ls.lens[s];
+  const int32_t* __restrict__ ids = ls.ids[s];
+  float* __restrict__ out = ls.out[s];
+  float* __restrict__ bias_out = ls.bias_out[s];
+  const int64_t ldo = ls.ldo[s];
+  const float scale = ls.scale[s];
+  const int64_t base = (int64_t)((int)blockIdx.x - blk0) * RPB + wv * GPW + gid;
+#pragma unroll
+  for (int u = 0; u < kLookupRows; ++u) {
+    const int64_t r = base + u * (4 * GPW);
+    if (r >= n) continue;
+    const int id = ids[r];
+    float4 one = make_float4(0.f, 0.f, 0.f, 0.f);
+    float one_b = 0.f;
+    if (E1) {
+      const int row1 = cat_map1 ? cat_map1[id] : id;
+      if (colok) one = *reinterpret_cast<const float4*>(E1 + (int64_t)row1 * d + col);
+      if (bias_out && lig == 0) one_b = bias1[row1];
+    }
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    float bacc = 0.f;
+    int len = 1;
+    if (E) {
+      const int st = starts[id];
+      len = lens[id];
+      for (int j0 = 0; j0 < len; j0 += LPR) {
+        const int myj = j0 + lig;
+        const int mytok = (myj < len) ? vals[st + myj] : 0;
+        if (bias_out && myj < len) bacc += bias[mytok];
+        const int cnt = min(LPR, len - j0);
+        int t = 0;
+        for (; t + 4 <= cnt; t += 4) {
+          const int t0 = __shfl(mytok, t, LPR);
+          const int t1 = __shfl(mytok, t + 1, LPR);
+          const int t2 = __shfl(mytok, t + 2, LPR);
+          const int t3 = __shfl(mytok, t + 3, LPR);
+          if (colok) {
+            float4 v0 = *reinterpret_cast<const float4*>(E + (int64_t)t0 * d + col);
+            float4 v1 = *reinterpret_cast<const float4*>(E + (int64_t)t1 * d + col);
+            float4 v2 = *reinterpret_cast<const float4*>(E + (int64_t)t2 * d + col);
+            float4 v3 = *reinterpret_cast<const float4*>(E + (int64_t)t3 * d + col);
+            a0 = f4_add(a0, v0);
+            a1 = f4_add(a1, v1);
+            a2 = f4_add(a2, v2);
+            a3 = f4_add(a3, v3);
+          }
+        }
+        for (; t < cnt; ++t) {
+          const int t0 = __shfl(mytok, t, LPR);
+          if (colok) a0 = f4_add(a0, *reinterpret_cast<const float4*>(E + (int64_t)t0 * d + col));
+        }
+      }
+      a0 = f4_add(f4_add(a0, a1), f4_add(a2, a3));
+    }
+    // same arithmetic as k_gather_mulhot / k_gather_onehot: sum / len (a true divide), + id row, * scale
+    const float flen = (float)len;
+    if (colok) {
+      float4 o;
+      if (E) {
+        o.x = scale * (a0.x / flen + one.x);
+        o.y = scale * (a0.y / flen + one.y);
+        o.z = scale * (a0.z / flen + one.z);
+        o.w = scale * (a0.w / flen + one.w);
+      } else {
+        o.x = scale * one.x; o.y = scale * one.y; o.z = scale * one.z; o.w = scale * one.w;
+      }
+      *reinterpret_cast<float4*>(out + r * ldo + col) = o;
+    }
+    if (bias_out) {
+      if (E) {
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) bacc += __shfl_xor(bacc, o, LPR);
+      }
+      if (lig == 0) bias_out[r] = E ? scale * (bacc / flen + one_b) : scale * one_b;
+    }
+  }
+}
+
 struct GatherSites {
   const float* E[kMaxSites];
   const float* bias[kMaxSites];
@@ -560,6 +689,60 @@ int arx_gather_onehot_multi(int nsites, const float* const* E, const float* cons
     gs.blk_end[s] = (int32_t)nblk;
   }
   ARX_DISPATCH_LPR(lpr, (k_gather_onehot_multi<LPR><<<(int)nblk, 256, 0, as_stream(stream)>>>(gs, d)));
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_lookup_multi(int nsites, const float* const* E_id, const float* const* bias_id,
+                     const int32_t* const* cat_map, const float* const* E_tok,
+                     const float* const* bias_tok, const int32_t* const* vals,
+                     const int32_t* const* starts, const int32_t* const* lens,
+                     const int32_t* const* ids, const int64_t* n, int d, const float* scale,
+                     float* const* out, const int64_t* ldo, float* const* bias_out, void* stream) {
+  ARX_CHECK_ARG(nsites >= 1 && nsites <= kMaxSites, "arx_lookup_multi: 1..8 sites");
+  ARX_CHECK_ARG(E_id && E_tok && ids && n && out && ldo && scale, "arx_lookup_multi: null pointer");
+  int rc = check_d("arx_lookup_multi", d);
+  if (rc) return rc;
+  LookupSites ls = {};
+  int64_t tot = 0;
+  for (int s = 0; s < nsites; ++s) {
+    ARX_CHECK_ARG((E_id[s] || E_tok[s]) && n[s] >= 0 && (n[s] == 0 || (ids[s] && out[s])),
+                  "arx_lookup_multi: bad site (a one-hot table, a multi-hot table or both)");
+    ARX_CHECK_ARG(!E_tok[s] || (vals && starts && lens && vals[s] && starts[s] && lens[s]),
+                  "arx_lookup_multi: a multi-hot feature needs vals / starts / lens");
+    ARX_CHECK_ARG(ldo[s] % 4 == 0 && ldo[s] >= d && (!E_id[s] || aligned16(E_id[s])) &&
+                      (!E_tok[s] || aligned16(E_tok[s])) && aligned16(out[s]),
+                  "arx_lookup_multi: ldo %% 4 and 16-byte alignment required");
+    const bool wb = bias_out && bias_out[s];
+    ARX_CHECK_ARG(!wb || ((!E_id[s] || (bias_id && bias_id[s])) && (!E_tok[s] || (bias_tok && bias_tok[s]))),
+                  "arx_lookup_multi: bias_out requires the bias of every feature of the site");
+    ls.E_id[s] = E_id[s];
+    ls.bias_id[s] = (wb && E_id[s]) ? bias_id[s] : nullptr;
+    ls.cat_map[s] = cat_map ? cat_map[s] : nullptr;
+    ls.E_tok[s] = E_tok[s];
+    ls.bias_tok[s] = (wb && E_tok[s]) ? bias_tok[s] : nullptr;
+    ls.vals[s] = E_tok[s] ? vals[s] : nullptr;
+    ls.starts[s] = E_tok[s] ? starts[s] : nullptr;
+    ls.lens[s] = E_tok[s] ? lens[s] : nullptr;
+    ls.ids[s] = ids[s];
+    ls.out[s] = out[s];
+    ls.bias_out[s] = wb ? bias_out[s] : nullptr;
+    ls.ldo[s] = ldo[s];
+    ls.scale[s] = scale[s];
+    ls.n[s] = n[s];
+    tot += n[s];
+  }
+  ls.count = nsites;
+  if (tot == 0) return ARX_OK;
+  const int lpr = lanes_per_row(d);
+  const int64_t rpb = 4 * (64 / lpr) * kLookupRows;
+  int64_t nblk = 0;
+  for (int s = 0; s < nsites; ++s) {
+    nblk += ceil_div(n[s], rpb);
+    ARX_CHECK_ARG(nblk < (int64_t)0x7fffffff, "arx_lookup_multi: too many rows");
+    ls.blk_end[s] = (int32_t)nblk;
+  }
+  ARX_DISPATCH_LPR(lpr, (k_lookup_multi<LPR><<<(int)nblk, 256, 0, as_stream(stream)>>>(ls, d)));
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

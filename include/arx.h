@@ -116,6 +116,21 @@ int arx_gather_id_plus_bag(const float* E_id, const float* bias_id, const int32_
                            int d, float scale, int accumulate, float* out, int64_t ldo,
                            float* bias_out, void* stream);
 
+/* Several lookups of a step in ONE launch (embed_attribute.py:371-407 for the users, the target
+ * items and the sampled pool of a step -- three independent launches otherwise).  Site s has a one-hot
+ * feature (E_id[s], nullable, with cat_map[s] / bias_id[s]), a multi-hot feature (E_tok[s], nullable,
+ * with vals / starts / lens / bias_tok[s]) or both:
+ *   out[s][r] = scale[s] * ( E_id[map[id]] + mean over the bag of id of E_tok rows ),  id = ids[s][r]
+ * (the same arithmetic, bit for bit, as arx_gather_onehot_fwd / arx_gather_mulhot_mean_fwd /
+ * arx_gather_id_plus_bag on that site).  bias_out[s] (nullable): the same combination of the bias
+ * cells.  All tables d wide; nsites <= 8. */
+int arx_lookup_multi(int nsites, const float* const* E_id, const float* const* bias_id,
+                     const int32_t* const* cat_map, const float* const* E_tok,
+                     const float* const* bias_tok, const int32_t* const* vals,
+                     const int32_t* const* starts, const int32_t* const* lens,
+                     const int32_t* const* ids, const int64_t* n, int d, const float* scale,
+                     float* const* out, const int64_t* ldo, float* const* bias_out, void* stream);
+
 /* nsites one-hot lookups of equal width d in ONE launch (site s: out[s][r, 0:d] = scale[s] *
  * E[s][cat_map[s] ? cat_map[s][ids[s][r]] : ids[s][r], :], bias_out[s][r] likewise; r < n[s]).
  * The lookups of a step (user ids, target items, sampled pool, input items) are independent. */

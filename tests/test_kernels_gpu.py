@@ -1114,6 +1114,52 @@ def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, p
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("d,sizes", [(128, (16384, 16384, 1024)), (32, (5, 0, 300)), (64, (7, 1, 2048))])
+def test_lookup_multi(dev, d, sizes):
+    """arx_lookup_multi: one-hot, multi-hot and (id + bag) lookups in one launch == the three
+    single-site entry points, bit for bit (ragged sizes, an empty site, with and without bias)."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(d + sum(sizes))
+    n_ent, Vf, Vu = 3000, 900, 700
+    vals, starts, lens = _csr(rng, n_ent, Vf, 24, zipf=True)
+    E_id = _t(dev, rng.standard_normal((n_ent + 2, d)).astype(np.float32))
+    b_id = _t(dev, rng.standard_normal((n_ent + 2,)).astype(np.float32))
+    cmap = _t(dev, (rng.permutation(n_ent) + 2).astype(np.int32))
+    E_tok = _t(dev, rng.standard_normal((Vf, d)).astype(np.float32))
+    b_tok = _t(dev, rng.standard_normal((Vf,)).astype(np.float32))
+    E_u = _t(dev, rng.standard_normal((Vu, d)).astype(np.float32))
+    b_u = _t(dev, rng.standard_normal((Vu,)).astype(np.float32))
+    tv, tst, tl = _t(dev, vals), _t(dev, starts), _t(dev, lens)
+    n_u, n_b, n_ib = sizes
+    ids_u = _t(dev, rng.integers(0, Vu, size=n_u).astype(np.int32))
+    ids_b = _t(dev, rng.integers(0, n_ent, size=n_b).astype(np.int32))
+    ids_ib = _t(dev, rng.integers(0, n_ent, size=n_ib).astype(np.int32))
+    for wb in (True, False):
+        outs = [torch.full((n, d), 7.0, dtype=torch.float32, device=dev) for n in sizes]
+        bouts = [torch.full((n,), 7.0, dtype=torch.float32, device=dev) if wb else None for n in sizes]
+        ls = ops.LookupSet([
+            (E_u, b_u if wb else None, None, None, None, None, None, None, ids_u, outs[0], 1.0, bouts[0]),
+            (None, None, None, E_tok, b_tok if wb else None, tv, tst, tl, ids_b, outs[1], 0.7, bouts[1]),
+            (E_id, b_id if wb else None, cmap, E_tok, b_tok if wb else None, tv, tst, tl, ids_ib, outs[2], 0.5,
+             bouts[2])])
+        ops.lookup_multi(ls)
+        refs = [torch.empty_like(o) for o in outs]
+        rb = [torch.empty_like(b) if wb else None for b in bouts]
+        if n_u:
+            ops.gather_onehot(E_u, b_u if wb else None, None, ids_u, refs[0], scale=1.0, bias_out=rb[0])
+        if n_b:
+            ops.gather_mulhot_mean(E_tok, b_tok if wb else None, tv, tst, tl, ids_b, refs[1], scale=0.7, bias_out=rb[1])
+        if n_ib:
+            ops.gather_id_plus_bag(E_id, b_id if wb else None, cmap, E_tok, b_tok if wb else None, tv, tst, tl,
+                                   ids_ib, refs[2], scale=0.5, bias_out=rb[2])
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert torch.equal(outs[k], refs[k]), k
+            if wb:
+                assert torch.equal(bouts[k], rb[k]), k
+
+
 def _unpack_bits(words, n):
     w = words.astype(np.uint32)
     return ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(w.shape[0], -1)[:, :n].astype(bool)
