@@ -960,7 +960,10 @@ class Plan(object):
                 f = self._fusable(entry)
                 if f is not None:
                     cand.append((entry, f[0], f[1]))
-            if len(cand) >= 2:
+            virt = None
+            if len(cand) == 1 and not cand[0][2]:
+                virt = self._find_rider([cand[0]], {id(cand[0][0])}, virtual_only=True)
+            if len(cand) >= 2 or virt is not None:
                 e0, c0, m0 = cand[0]
                 n0 = (c0 + m0)[0].node
                 d0 = e0[0].E.shape[1]
@@ -979,7 +982,9 @@ class Plan(object):
                 big = any(sum(x.cap for x in c + m) > 8192 for _, c, m in group)
                 # ... unless the UNION still fits the rank sort: then one 3-launch chain serves all
                 # tables (C1, B=64: two chains of 3 launches -> one)
-                if ((big or (n_tot <= 8192 and not any(m for _, _, m in group))) and 2 <= len(group) <= 4 and sum(len(c) for _, c, _ in group) <= 8
+                if virt is not None and len(group) == 1:
+                    fused = group            # one one-hot table + the entity ids of a bag table (below)
+                elif ((big or (n_tot <= 8192 and not any(m for _, _, m in group))) and 2 <= len(group) <= 4 and sum(len(c) for _, c, _ in group) <= 8
                         and sum(len(m) for _, _, m in group) <= 8 and rows_bits + 2 <= 30
                         and n_tot <= (1 << 22)):
                     fused = group
@@ -1006,10 +1011,16 @@ class Plan(object):
         if rider is not None:
             # a multi-hot table looked up with exactly the lookups of one fused one-hot table (HET: an
             # item's id row and its bag): it rides on the fused pass -- that table goes first (its
-            # keys sort first), the bag needs no entity sort / merge pass of its own
+            # keys sort first), the bag needs no entity sort / merge pass of its own.  Without such a
+            # table (MIX: the id token lives in the bag) the entity ids join the pass as a VIRTUAL
+            # table 0: sorted with the others, runs merged, no rows updated.
             gi, bag_entry, bag_live = rider
-            fused = [fused[gi]] + fused[:gi] + fused[gi + 1:]
+            if gi is not None:
+                fused = [fused[gi]] + fused[:gi] + fused[gi + 1:]
             done.add(id(bag_entry))
+        elif len(fused) == 1:
+            fused = []                       # (a lone one-hot table keeps its own pass)
+            done = set()
         side_first = bool(fused) and rt.use_streams in ('tables', '1')
         if side_first:
             rest(False)          # the other tables' passes go to side branches, under the fused pass
@@ -1018,8 +1029,8 @@ class Plan(object):
             bag = None
             if rider is not None:
                 use_bias = bag_entry[0].bias is not None and any(x.node.bias_grad_used for x in bag_live)
-                key = key + ('rider', id(bag_entry), use_bias)
-                bag = (bag_entry, bag_live, use_bias)
+                key = key + ('rider', id(bag_entry), use_bias, gi is None)
+                bag = (bag_entry, bag_live, use_bias, gi is None)
             phase = 2 if (self._k7_done_keys is not None and key in self._k7_done_keys) else 3
             self._apply_multi(fused, phase=phase, key=key, bag=bag)
             # size estimate for _plan_early: one-hot sites are all live, a multi-hot site's padded
@@ -1036,13 +1047,17 @@ class Plan(object):
             rt.join(t)
         self._plan_early(self._jobs, self._n_passes)
 
-    def _find_rider(self, fused, done):
+    def _find_rider(self, fused, done, virtual_only=False):
         """(index in the fused group, table entry, live sites) of a two-stage multi-hot table whose
         lookups are exactly the lookups of one fused one-hot table: same id tensors, gradient rows,
-        coefficients and arena (arx_sparse_adagrad_cat_multi_bags), or None."""
+        coefficients and arena (arx_sparse_adagrad_cat_multi_bags), or None.  Index None: no such
+        table, but the bag table's lookups read the group's arena and fit the pass as a virtual
+        table (its entity ids only)."""
         rt = self.rt
         if rt.no_rider or any(m for _, _, m in fused):
             return None
+        virtual = None
+        n0 = fused[0][1][0].node
         for entry in self.tables:
             if id(entry) in done:
                 continue
@@ -1059,9 +1074,14 @@ class Plan(object):
                 if all(a.ids_node.value.data_ptr() == b.ids_node.value.data_ptr()
                        and a.ids_node.value.shape == b.ids_node.value.shape and a.node.row0 == b.node.row0
                        and a.coef == b.coef and a.node.arena is b.node.arena and a.node.arena_b is b.node.arena_b
-                       for a, b in zip(c, live)):
+                       for a, b in zip(c, live)) and not virtual_only:
                     return gi, entry, live
-        return None
+            if (virtual is None and len(fused) <= 3 and sum(len(c) for _, c, _ in fused) + len(live) <= 8
+                    and entry[0].E.shape[1] == fused[0][0][0].E.shape[1]
+                    and all(x.node.arena is n0.arena and x.node.arena_b is n0.arena_b for x in live)
+                    and int(live[0].maps[2].shape[0]).bit_length() + 2 <= 30 and not rt.no_virtual):
+                virtual = (None, entry, live)
+        return virtual
 
     def _rider_csr(self, m, starts, lens, rows):
         """The bag index (starts, lens) of a multi-hot feature re-indexed by the ROW of the one-hot
@@ -1099,7 +1119,14 @@ class Plan(object):
         ent = cache.get(key)
         if ent is None:
             tables, sites, extra, xsites = [], [], [], []
-            for ti, (e, c, m) in enumerate(group):
+            t_off = 0
+            if bag is not None and bag[3]:
+                # virtual table 0: the bag table's entity lookups (key = entity id)
+                tables.append((None, None, None, None, None, int(bag[1][0].maps[2].shape[0])))
+                for x in bag[1]:
+                    sites.append((0, None, x.ids_node.value, x.node.row0, x.coef))
+                t_off = 1
+            for ti, (e, c, m) in enumerate(group, start=t_off):
                 table = e[0]
                 use_bias = table.bias is not None and any(x.node.bias_grad_used for x in c + m)
                 sgd = rt.optimizer == 'sgd'          # no slots: the kernels do plain gradient descent
@@ -1128,13 +1155,16 @@ class Plan(object):
                                       ent['src'][off:off + x.cap], ent['coef'][off:off + x.cap])
         node0 = (group[0][1] + group[0][2])[0].node
         if bag is not None:
-            bag_entry, bag_live, bag_bias = bag
+            bag_entry, bag_live, bag_bias, bag_virtual = bag
             bt, s0 = bag_entry[0], bag_live[0]
             if 'bag_ws' not in ent:
                 ent['bag_ws'] = ops.Workspace(rt.device)     # token lists + merged rows, between the phases
             sgd = rt.optimizer == 'sgd'
-            starts_r, lens_r = self._rider_csr(group[0][1][0].maps[0], s0.maps[1], s0.maps[2],
-                                               int(group[0][0][0].E.shape[0]))
+            if bag_virtual:
+                starts_r, lens_r = s0.maps[1], s0.maps[2]
+            else:
+                starts_r, lens_r = self._rider_csr(group[0][1][0].maps[0], s0.maps[1], s0.maps[2],
+                                                   int(group[0][0][0].E.shape[0]))
             ops.sparse_adagrad_cat_multi_bags(
                 args, node0.arena, node0.arena_b if (ent['any_bias'] or bag_bias) else None, rt.lr,
                 ent['keys'], ent['src'], ent['coef'], ent['ws'], bt.E, None if sgd else bt.acc,
@@ -1378,6 +1408,7 @@ class Runtime(object):
         self.no_multi = bool(_os.environ.get('ARX_NO_MULTI'))      # A/B aid: one K7 pass per table
         self.no_bags = bool(_os.environ.get('ARX_NO_BAGS'))        # A/B aid: contribution-level multi-hot pass
         self.no_rider = bool(_os.environ.get('ARX_NO_RIDER'))      # A/B aid: the bag table keeps its own two-stage pass
+        self.no_virtual = bool(_os.environ.get('ARX_NO_VIRTUAL'))  # A/B aid: ... unless an id table shares its lookups
         # fork/join branches inside the captured graph measured SLOWER on ROCm 7.2 (250 us vs
         # 187 us per C2 step: cross-stream graph edges cost more than the overlap buys at
         # these kernel sizes) -- opt-in only.

@@ -487,7 +487,9 @@ class MultiCatArgs(object):
         import ctypes as C
         nt, ns = len(tables), len(sites)
         self.nt, self.ns = nt, ns
-        self.d = int(tables[0][0].shape[1])
+        # a table may be VIRTUAL -- (None, None, None, None, None, rows): entity ids of a bag table
+        # riding on the pass (arx_sparse_adagrad_cat_multi_bags), no rows of its own
+        self.d = int(next(t[0] for t in tables if t[0] is not None).shape[1])
         self.n_cat = sum(int(s[2].shape[0]) for s in sites)
         self.nx = len(extra)
         self.extra_n = (C.c_int64 * max(self.nx, 1))(*[int(e[1]) for e in extra])
@@ -502,7 +504,7 @@ class MultiCatArgs(object):
         self.acc = (C.c_void_p * nt)(*[_p(t[1]) for t in tables])
         self.bias = (C.c_void_p * nt)(*[_p(t[2]) or None for t in tables])
         self.bias_acc = (C.c_void_p * nt)(*[_p(t[3]) or None for t in tables])
-        self.rows = (C.c_int64 * nt)(*[int(t[0].shape[0]) for t in tables])
+        self.rows = (C.c_int64 * nt)(*[int(t[0].shape[0]) if t[0] is not None else int(t[5]) for t in tables])
         self.cnt = (C.c_void_p * nt)(*[_p(t[4]) or None for t in tables])
         m = max(ns, 1)
         self.site_table = (C.c_int32 * m)(*[int(s[0]) for s in sites])

@@ -376,7 +376,10 @@ struct LookupSites {
   int count;
 };
 
-constexpr int kLookupRows = 2;      // rows per sub-group
+#ifndef ARX_LOOKUP_ROWS
+#define ARX_LOOKUP_ROWS 1
+#endif
+constexpr int kLookupRows = ARX_LOOKUP_ROWS;      // rows per sub-group (1: the bag chains are latency-bound, more sub-groups in flight win)
 
 template <int LPR>
 __global__ __launch_bounds__(256) void k_lookup_multi(LookupSites ls, int d) {

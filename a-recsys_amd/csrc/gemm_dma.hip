@@ -139,11 +139,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
   for (int i = 0; i < FM; ++i) rsl[i] = 0.f;
 
   auto tile = [&](int64_t t, const float* cA, const float* cB, float* nA, float* nB) {
+#ifndef ARX_ABL_NODMA
     if (t + PD < nt) dma(t + PD, nA, nB);
+#endif
     // operands of step s+1 are read from LDS before the MFMAs of step s issue (pinned with
     // sched_barrier: hipcc otherwise sinks the reads to just in front of their use and the wave
     // sits in s_waitcnt lgkmcnt for an LDS round trip per step -- PMC SQ_WAIT_ANY 27-37%)
     auto load_ops = [&](int s, float (&av)[FM][4], float (&bv)[FN][4]) {
+#ifdef ARX_ABL_NOLDS
+      for (int i = 0; i < FM; ++i) for (int j = 0; j < 4; ++j) av[i][j] = (float)(s + lane);
+      for (int i = 0; i < FN; ++i) for (int j = 0; j < 4; ++j) bv[i][j] = (float)(s - lane);
+      return;
+#endif
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         const int r = wm * (BM / 2) + i * 32 + l31;
@@ -179,7 +186,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int jn = 0; jn < FN; ++jn)
+#ifdef ARX_ABL_NOMFMA
+            acc[i][jn][0] += av[i][j] * bv[jn][j];
+#else
             acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j], bv[jn][j], acc[i][jn], 0, 0, 0);
+#endif
       if (s + 1 < kBK / 8) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -197,7 +208,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
     if (PD > 1 && t + PD < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * (NPA + NPB)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef ARX_ABL_NOBAR
     __builtin_amdgcn_s_barrier();
+#endif
   };
 
   if (nt > 0) {

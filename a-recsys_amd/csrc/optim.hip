@@ -32,6 +32,7 @@ constexpr int kRankSortMax = 8192;
 // entity stage of arx_sparse_adagrad_bags.  (Measured: ONE rank-sort launch at n = 17.4 k -- 70 KB of
 // keys staged per workgroup, O(n^2) compares -- costs ~115 us against ~45 us for the 7 launches of
 // the two-pass radix sort; the rank sort stays below 8192.)
+static const int kTokenWpw = getenv("ARX_TOKEN_WPW") ? atoi(getenv("ARX_TOKEN_WPW")) : 4;   // waves per window of the token stage (merged rows: 342 us/step with 1, 336 with 4, 344 with 8 at C3 B=16384)
 static const int kRankSortEntities = getenv("ARX_RANK_ENT_MAX") ? atoi(getenv("ARX_RANK_ENT_MAX")) : kRankSortMax;
 constexpr int kPassBBlocks = 128;   // persistent grid of pass B
 
@@ -480,7 +481,7 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
         const TabRow T = tab_of<MT>(ts, rkey);
         if (colok) {
           g0[j] = *reinterpret_cast<const float4*>(G + (int64_t)s_src[wv][i] * ldg + col);
-          if (!MERGE && lcomp[j]) {
+          if (!MERGE && lcomp[j] && T.E) {      // (T.E null: a virtual table -- entity ids of a riding bag table)
             wrow[j] = *reinterpret_cast<const float4*>(T.E + (int64_t)T.row * d + col);
             if (!SGD) arow[j] = *reinterpret_cast<const float4*>(T.acc + (int64_t)T.row * d + col);
           }
@@ -529,7 +530,7 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
         merge_row(mo, d, rkey, w0 + i, col, colok, lig, a, gb);
       } else if (lcomp[j]) {
         if (!MERGE && merge_side(mo, rkey)) merge_row(mo, d, rrow, w0 + i, col, colok, lig, a, gb);
-        if (colok) {
+        if (colok && T.E) {
           float4 gg = make_float4(a.x * gs, a.y * gs, a.z * gs, a.w * gs);
           float4 w4 = wrow[j];
           if (!SGD) {
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(1024) void k_sparse_finish(
       } else {
         const TabRow T = tab_of<MT>(ts, key);
         if (merge_side(mo, key)) merge_row(mo, d, T.row, h, col, colok, lig, tot, tb);
-        adagrad_row(T.E, T.acc, T.bias, T.bias_acc, d, T.row, col, colok, lig, tot, tb, lr, gs);
+        if (T.E) adagrad_row(T.E, T.acc, T.bias, T.bias_acc, d, T.row, col, colok, lig, tot, tb, lr, gs);
       }
     }
     return;
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(1024) void k_sparse_finish(
       } else {
         const TabRow T = tab_of<MT>(ts, key);
         if (merge_side(mo, key)) merge_row(mo, d, T.row, h, col, colok, lig, t2, t2b);
-        adagrad_row(T.E, T.acc, T.bias, T.bias_acc, d, T.row, col, colok, lig, t2, t2b, lr, gs);
+        if (T.E) adagrad_row(T.E, T.acc, T.bias, T.bias_acc, d, T.row, col, colok, lig, t2, t2b, lr, gs);
       }
     }
   }
@@ -1193,7 +1194,8 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
   int32_t* list_long = list;                       // <= n/64/17 entries
   int32_t* list_short = list + (n / 64 / (kShortMaxAligned + 1) + 2);   // pairs, <= n/64 entries
   const int grid8 = (int)ceil_div(n, 64);
-  const bool sgd = ts.acc[0] == nullptr;           // gradient descent: no slots (all tables alike)
+  bool sgd = ts.acc[0] == nullptr;                 // gradient descent: no slots (all tables alike)
+  if (!ts.E[0] && ts.E[1]) sgd = ts.acc[1] == nullptr;   // (table 0 virtual: the entity ids of a riding bag table)
 #define ARX_WIN_GO2(WPW_, MT_, SGD_, GRID_, THREADS_)                                                \
   ARX_DISPATCH_LPR(lpr, (k_sparse_win<LPR, WPW_, MT_, SGD_><<<GRID_, THREADS_, 0, s>>>(             \
                             ts, d, sk, spos, ssrc, scoef, n, n_dev, sentinel, G, ldg, gb_in, lr_dev, \
@@ -1336,7 +1338,7 @@ int bag_token_apply(const BagWs& w, char* base, int64_t n_i, int max_len, float*
                       reinterpret_cast<float*>(bt + w.wt.off_scratch_b),
                       reinterpret_cast<float*>(bt + w.wt.off_scratch_h),
                       reinterpret_cast<float*>(bt + w.wt.off_scratch_hb),
-                      reinterpret_cast<int32_t*>(bt + w.wt.off_list), count_t, 1, false,
+                      reinterpret_cast<int32_t*>(bt + w.wt.off_list), count_t, kTokenWpw, false,
                       rank_t ? nullptr : count_t + 2, s);
 }
 

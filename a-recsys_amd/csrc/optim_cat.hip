@@ -386,7 +386,12 @@ static int cat_multi_impl(int phase, int ntables, float* const* E, float* const*
   bool all_cnt = true, any_cnt = false;
   for (int t = 0; t < kMaxTables; ++t) {
     const bool live = t < ntables;
-    if (live) {
+    if (live && t == 0 && bag && !E[0]) {
+      // virtual table: the entity ids of the riding bag table, no rows of its own to update
+      ARX_CHECK_ARG(table_rows[0] > 0 && !acc[0] && !bias[0] && !bias_acc[0] && ntables >= 2,
+                    "arx_sparse_adagrad_cat_multi_bags: a virtual table 0 has no acc / bias and needs a real table beside it");
+      while ((1ll << kb) < table_rows[0] && kb < 30) ++kb;
+    } else if (live) {
       ARX_CHECK_ARG(E[t] && table_rows[t] > 0, "arx_sparse_adagrad_cat_multi: bad table");
       ARX_CHECK_ARG(acc[t] ? (bias[t] == nullptr) == (bias_acc[t] == nullptr) : bias_acc[t] == nullptr,
                     "arx_sparse_adagrad_cat_multi: bias/bias_acc");

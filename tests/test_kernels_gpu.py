@@ -1010,10 +1010,12 @@ def test_sparse_adagrad_bags(dev, d, n_ent, Vf, max_len, ns, phases):
     (64, 5000, 7000, 900, 9, (6000, 0, 5000), (1, 2)),                # an empty site; 11 k keys
     (16, 12, 9, 8, 30, (9000, 100, 50), (3,)),                        # few entities: runs of thousands (finish kernel side output)
 ])
-def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, phases):
+@pytest.mark.parametrize("virtual", [False, True])
+def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, phases, virtual):
     """arx_sparse_adagrad_cat_multi_bags: the one-hot pass over (item id table, user table) with the
     item's multi-hot table riding on it == the three tables updated separately from the plain
-    contribution lists (id rows: coef * G[row]; token rows: coef / len * G[row] per bag token)."""
+    contribution lists (id rows: coef * G[row]; token rows: coef / len * G[row] per bag token).
+    virtual: no item id table (MIX layout) -- table 0 of the pass is just the entity ids."""
     from arx import ops
     import torch
     rng = np.random.default_rng(d + n_ent + max_len)
@@ -1081,6 +1083,8 @@ def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, p
     lens_r = np.zeros(n_rows0, dtype=np.int32)
     starts_r[ent2row] = starts
     lens_r[ent2row] = lens
+    if virtual:
+        starts_r, lens_r = starts, lens
     tv, tst, tl = _t(dev, vals), _t(dev, starts_r), _t(dev, lens_r)
     # the map is indexed by the lookup id: out-of-range ids must not reach it (the reference's ids are
     # always entities); the test's two invalid ids are mapped through a padded copy
@@ -1092,9 +1096,10 @@ def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, p
     for rep in range(2):
         D_it, D_us, D_bag = [[_t(dev, x) for x in tab] for tab in (T_it, T_us, T_bag)]
         cnts = [torch.zeros(n_rows0, dtype=torch.int32, device=dev), torch.zeros(n_user, dtype=torch.int32, device=dev)]
-        args = ops.MultiCatArgs([(D_it[0], D_it[1], D_it[2], D_it[3], cnts[0]),
-                                 (D_us[0], D_us[1], D_us[2], D_us[3], cnts[1])],
-                                [(t, tmap if t == 0 else None, _t(dev, ids), r0, c) for t, ids, r0, c in sites])
+        t0 = (None, None, None, None, None, n_ent) if virtual else (D_it[0], D_it[1], D_it[2], D_it[3], cnts[0])
+        args = ops.MultiCatArgs([t0, (D_us[0], D_us[1], D_us[2], D_us[3], None if virtual else cnts[1])],
+                                [(t, tmap if (t == 0 and not virtual) else None, _t(dev, ids), r0, c)
+                                 for t, ids, r0, c in sites])
         n = args.total
         kb_ = torch.empty(n, dtype=torch.int32, device=dev)
         sb_ = torch.empty(n, dtype=torch.int32, device=dev)
@@ -1108,7 +1113,8 @@ def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, p
         torch.cuda.synchronize()
         assert int(bcnt.abs().sum().item()) == 0 and all(int(c.abs().sum().item()) == 0 for c in cnts)
         outs.append(D_it + D_us + D_bag)
-    for got, want in zip(outs[0], list(R_it) + list(R_us) + list(R_bag)):
+    want_it = list(T_it) if virtual else list(R_it)          # virtual: the id table is not part of the pass
+    for got, want in zip(outs[0], want_it + list(R_us) + list(R_bag)):
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-5)
     for a, b in zip(outs[0], outs[1]):                 # bit-reproducible
         assert torch.equal(a, b)
