@@ -361,6 +361,189 @@ class ShardedHMF(object):
 # --------------------------------------------------------------------------
 # bench entry for N > 1 (driver: python -m torch.distributed.run ... bench.py --gpus N)
 # --------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------
+# Data-parallel sequence model (the LSTM recommender has no table big enough to shard at
+# C4's size -- 1 M x 64 x 4 B = 256 MB -- so the replicas split the BATCH).
+# ---------------------------------------------------------------------------------------------
+class _GIds(object):
+    def __init__(self, value):
+        self.value = value
+
+
+class _GNode(object):
+    """Stand-in for the lookup node of a gathered site: rows of the gathered gradient arena."""
+
+    def __init__(self, row0, arena, arena_b, node):
+        self.row0, self.arena, self.arena_b = row0, arena, arena_b
+        self._grad_written = True
+        self.bias_grad_used = node.bias_grad_used
+        self.with_bias = node.with_bias
+        self.shape = node.shape
+
+
+class _GSite(object):
+    """One lookup site of the GLOBAL batch: ids and gradient rows of every replica, rank-major."""
+
+    def __init__(self, s, ids, node, n):
+        self.table, self.kind, self.maps, self.max_len, self.coef = s.table, s.kind, s.maps, s.max_len, s.coef
+        self.bias_coef = getattr(s, 'bias_coef', 1.0)
+        self.col_off, self.key_off = 0, 0
+        self.ids_node, self.node = _GIds(ids), node
+        self.n = self.cap = n
+
+
+class SeqDataParallel(object):
+    """`world` replicas of a SeqModel (lstm/seqModel.py), one per GPU, each fed 1/world of the
+    sequences of a step; one step of the group == the single-process step on the global batch
+    (the reference has no multi-device path: SURVEY 8e).  sequence_loss sums over the examples
+    (seqModel.py:596), so local gradients simply add.  Per step, between backward and apply:
+
+      all_reduce   dense gradients (lstm_w / lstm_b of every layer, w_input_*), packed in one buffer
+      all_reduce   the pool gradients: per-unrolled-step [L, S, d] (+ bias [L, S]) and their sums --
+                   tf.gradients yields ONE dense matmul gradient per step for the global batch, and
+                   clip_by_global_norm squares them step by step (seqModel.py:179-180)
+      all_reduce   one scalar: the squared norms of the batch lookups' IndexedSlices (un-merged in
+                   TF's norm, hence additive over replicas)
+      all_gather   ids + gradient rows of every batch lookup (inputs, targets, users): every replica
+                   then runs the SAME sparse-Adagrad pass over the global lookups -- duplicates
+                   across replicas are merged before the one update per row, tables stay identical.
+
+    The pool of sampled negatives must be the same on every replica (draw it with a shared seed or
+    broadcast it: broadcast_pool).  One-hot item / user features (config C4); steps run eagerly (the
+    collectives are not captured into the hipGraph)."""
+
+    def __init__(self, model, group=None):
+        self.model, self.rt, self.group = model, model.rt, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if getattr(model, 'output_feat', 1) not in (0, 1):
+            raise NotImplementedError("SeqDataParallel: output_feat 0 / 1 only")
+        self.rt.dp = self
+        self.rt.use_graph = False
+        self._plans = {}
+        self._loss = torch.zeros(1, dtype=torch.float32, device=self.rt.device)
+
+    # ---- collectives --------------------------------------------------------------------------
+    def all_reduce_sum(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def _all_reduce_packed(self, tensors):
+        """One all-reduce for a list of tensors (bucketed: a ring all-reduce over xGMI is bound by
+        its per-link latency at these sizes, not by bytes)."""
+        if self.world == 1 or not tensors:
+            return
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view(t.shape))
+            off += n
+
+    def _all_gather(self, src, dst):
+        """dst[w * n : (w + 1) * n] = src of replica w."""
+        if self.world == 1:
+            dst.copy_(src)
+            return
+        n = src.shape[0]
+        dist.all_gather([dst[w * n:(w + 1) * n] for w in range(self.world)], src.contiguous(), group=self.group)
+
+    def broadcast_pool(self, pool_ids):
+        """Replica 0's sampled pool for everyone (int32 device tensor, in place)."""
+        if self.world > 1:
+            dist.broadcast(pool_ids, src=0, group=self.group)
+        return pool_ids
+
+    def global_loss(self, local_loss):
+        self._loss.fill_(float(local_loss))
+        return float(self.all_reduce_sum(self._loss).item())
+
+    # ---- the exchange -------------------------------------------------------------------------
+    def _state(self, plan):
+        from . import graph as G
+        st = self._plans.get(id(plan))
+        if st is not None:
+            return st
+        rt = self.rt
+        # pool lookups: their gradient is a dense [S, d] sum over the batch -> all-reduced, replicated
+        pools, preds = set(), []
+        for n in plan.order:
+            if isinstance(n, G.Prediction) and n.inputs[1].train_tables:
+                pools.add(id(n.inputs[1]))
+                preds.append(n)
+        tables = []
+        for table, sites, bufs, total in plan.tables:
+            if any(s.kind != 'cat' or s.col_off != 0 for s in sites):
+                raise NotImplementedError("SeqDataParallel: one-hot, mean-combined features only")
+            width = sites[0].node.shape[1]
+            rows = sum(s.n * (1 if id(s.node) in pools else self.world) for s in sites)
+            arena = torch.zeros((rows, width), dtype=torch.float32, device=rt.device)
+            arena_b = torch.zeros((rows,), dtype=torch.float32, device=rt.device)
+            gs, r0 = [], 0
+            for s in sites:
+                rep = id(s.node) in pools
+                n = s.n if rep else s.n * self.world
+                ids = s.ids_node.value if rep else torch.empty(n, dtype=torch.int32, device=rt.device)
+                gs.append((s, _GSite(s, ids, _GNode(r0, arena, arena_b, s.node), n), rep))
+                r0 += n
+            gbufs = {'keys': torch.full((rows,), G.KEY_NONE, dtype=torch.int32, device=rt.device),
+                     'src': torch.zeros((rows,), dtype=torch.int32, device=rt.device),
+                     'coef': torch.zeros((rows,), dtype=torch.float32, device=rt.device),
+                     'hot': torch.zeros((rows // 16 + 4,), dtype=torch.int32, device=rt.device)}
+            off = 0
+            for _, g, _ in gs:
+                g.key_off = off
+                off += g.cap
+            tables.append((table, gs, gbufs, rows))
+        st = dict(preds=preds, tables=tables)
+        self._plans[id(plan)] = st
+        return st
+
+    def exchange(self, plan):
+        """Called by the plan between backward and the optimiser (graph.py Plan._execute)."""
+        rt = self.rt
+        st = self._state(plan)
+        # dense + pool gradients: one packed all-reduce
+        pack = [p.grad for p in rt.dense.values() if getattr(p, 'touched', False)]
+        for n in st['preds']:
+            if not n._grad_written:
+                continue
+            pool = n.inputs[1]
+            if getattr(n, 'C_steps', None) is not None:
+                pack += [n.C_steps, n.rs_steps]
+            pack.append(pool.grad)
+            if pool.bias_grad_used:
+                pack.append(pool.bias_grad)
+        self._all_reduce_packed(pack)
+        # batch lookups: ids and gradient rows of every replica; pool rows: copied (already global)
+        for table, gs, gbufs, rows in st['tables']:
+            for s, g, rep in gs:
+                node = s.node
+                g.node._grad_written = node._grad_written
+                g.node.bias_grad_used = node.bias_grad_used
+                if not node._grad_written:
+                    continue
+                a = g.node.arena[g.node.row0:g.node.row0 + g.n]
+                ab = g.node.arena_b[g.node.row0:g.node.row0 + g.n]
+                src = node.arena[node.row0:node.row0 + s.n]
+                src_b = node.arena_b[node.row0:node.row0 + s.n]
+                if rep:
+                    a.copy_(src)
+                    if node.bias_grad_used:
+                        ab.copy_(src_b)
+                else:
+                    self._all_gather(s.ids_node.value, g.ids_node.value)
+                    self._all_gather(src, a)
+                    if node.bias_grad_used:
+                        self._all_gather(src_b, ab)
+
+    def gathered_tables(self, plan):
+        """plan.tables with the gathered sites in place of the local ones (same tuple layout)."""
+        return [(table, [g for _, g, _ in gs], gbufs, rows) for table, gs, gbufs, rows in self._state(plan)['tables']]
+
+
 def _hash_u32(x, salt):
     x = (x.to(torch.int64) * 2654435761 + salt) & 0xFFFFFFFF
     x = ((x ^ (x >> 15)) * 2246822519) & 0xFFFFFFFF

@@ -915,8 +915,21 @@ class Plan(object):
             for t in rt._pending:
                 rt.join(t)
             rt._pending = []
+            dp = rt.dp
+            if dp is not None:
+                # data-parallel replicas (arx.dist.SeqDataParallel): dense and pool gradients are
+                # all-reduced, the rows of the batch lookups gathered, so that every replica applies
+                # the update of the GLOBAL batch
+                dp.exchange(self)
             rt.pre_apply(self)
-            self._apply_sparse()
+            if dp is not None:
+                local_tables, self.tables = self.tables, dp.gathered_tables(self)
+                try:
+                    self._apply_sparse()
+                finally:
+                    self.tables = local_tables
+            else:
+                self._apply_sparse()
             rt.apply_dense(self)
         for m in self.masks:
             if not m.fused:
@@ -1184,8 +1197,8 @@ class Plan(object):
         self._k7_early = None
         self._k7_fork = None
         jobs = self._early_jobs
-        if not jobs or os.environ.get('ARX_K7_NO_EARLY'):
-            return
+        if not jobs or os.environ.get('ARX_K7_NO_EARLY') or self.rt.dp is not None:
+            return                            # (data-parallel: the apply sorts the GATHERED lookups)
         rt = self.rt
         if self._k7_stream is None:
             self._k7_stream = torch.cuda.Stream(device=rt.device)
@@ -1416,6 +1429,7 @@ class Runtime(object):
         self._side = None
         self._side_ws = None
         self._pending = []
+        self.dp = None                  # arx.dist.SeqDataParallel: gradient exchange between replicas
 
     def drop_feed(self, dst):
         """Forget queued feeds whose destination is `dst` (same start address: placeholders and

@@ -540,7 +540,14 @@ class SeqModel(SeqBatching):
         rt = self.rt
         sq = self._sq
         ops.fill_f32(sq, 0.0)
+        # Data-parallel replicas (rt.dp): the dense and the pool gradients were all-reduced before this
+        # hook -- their norms are the global batch's on every replica; the IndexedSlices of the batch
+        # lookups stay un-merged in TF's norm, i.e. their squared norms ADD over the replicas: those
+        # are accumulated first and all-reduced as one scalar.
+        dp = rt.dp if (rt.dp is not None and rt.dp.world > 1) else None
         norms = []
+        local = []                    # indices into norms: batch lookups (additive over replicas)
+        deferred = []                 # _shared_rows_norm calls (pool gradients: replicated)
         for p in rt.dense.values():
             if getattr(p, 'touched', False):
                 norms.append((p.grad, 1, None, None))
@@ -557,7 +564,10 @@ class SeqModel(SeqBatching):
                 L, S, d = sp.C_steps.shape
                 shared = [f for f in n.feats if not self._injective(f)]
                 for f in shared:
-                    self._shared_rows_norm(n, sp, f, sites_of, sq)
+                    if dp is None:
+                        self._shared_rows_norm(n, sp, f, sites_of, sq)
+                    else:
+                        deferred.append((n, sp, f))
                 for for_bias in (False, True):
                     per_step, merged = [], []
                     for f in n.feats:
@@ -577,10 +587,23 @@ class SeqModel(SeqBatching):
                         rs = self._row_scale(n, True, merged, 'mg%d' % for_bias)
                         norms.append((sum_buf, dd, rs, S * dd))
             else:
+                local.append(len(norms))
                 norms.append((n.grad, n.shape[1], self._row_scale(n), n.grad.numel()))
                 if n.bias_grad_used:
+                    local.append(len(norms))
                     norms.append((n.bias_grad, 1, self._row_scale(n, True), None))
-        ops.sq_norm_accum_multi(norms, sq)          # every plain tensor norm of the step: one launch
+        if dp is None:
+            ops.sq_norm_accum_multi(norms, sq)          # every plain tensor norm of the step: one launch
+        else:
+            mine = [norms[i] for i in local]
+            if mine:
+                ops.sq_norm_accum_multi(mine, sq)
+            dp.all_reduce_sum(sq)
+            for n, sp, f in deferred:
+                self._shared_rows_norm(n, sp, f, sites_of, sq)
+            rest = [e for i, e in enumerate(norms) if i not in set(local)]
+            if rest:
+                ops.sq_norm_accum_multi(rest, sq)
         ops.clip_coef(sq, self.max_gradient_norm, rt.clip_coef_dev, self._gnorm)
 
     # ---------------------------------------------------------------------- step

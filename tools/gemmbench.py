@@ -18,3 +18,15 @@ tag = 'B=%d bm=%s splits=%s' % (B, os.environ.get('ARX_DMA_BM'), os.environ.get(
 print(tag, 'logits %.1f us' % t(lambda: ops.gemm(U, I, L, ws, transB=True)),
       'dU %.1f us' % t(lambda: ops.gemm(dL, I, dU, ws)),
       'dI %.1f us' % t(lambda: ops.gemm(dL, U, dI, ws, transA=True)))
+# dU and dI issued on two streams (do two co-resident workgroups per CU fill each other's stalls?)
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+ws2 = ops.Workspace(dev)
+def both():
+    cur = torch.cuda.current_stream()
+    s1.wait_stream(cur); s2.wait_stream(cur)
+    with torch.cuda.stream(s1):
+        ops.gemm(dL, I, dU, ws)
+    with torch.cuda.stream(s2):
+        ops.gemm(dL, U, dI, ws2, transA=True)
+    cur.wait_stream(s1); cur.wait_stream(s2)
+print(tag, 'dU || dI on two streams %.1f us' % t(both))
