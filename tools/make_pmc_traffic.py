@@ -24,6 +24,7 @@ MAP = {
     'loss_mw': ['k_loss_margin'],
     'gather_onehot': ['k_gather_onehot'],
     'gather_mulhot': ['k_gather_mulhot'],
+    'lookup_multi': ['k_lookup_multi'],
     'sparse_apply_window': ['k_sparse_win'],
     'sparse_apply_small': ['k_sparse_onepass'],
     'sparse_finish': ['k_sparse_finish'],
