@@ -46,16 +46,26 @@ __device__ __forceinline__ uint32_t load_key(const void* keys_in, int64_t i, uin
 
 constexpr int kRsWaves = kRsThreads / 64;
 
+// Items per block when the live count is only known on the device (the grid is sized for the
+// host-side capacity): the same rule as rs_plan, applied to the device count, so that the live
+// items spread over ALL blocks of the grid instead of filling the first few of them.
+__device__ __forceinline__ int64_t rs_ipb_dev(int64_t n, int nblk) {
+  const int64_t per = (n + nblk - 1) / nblk;
+  return ((per + kRsThreads - 1) / kRsThreads) * kRsThreads;
+}
+
 // per-WAVE digit histograms: hist[(blk * 4 + wave)][bin] over the wave's contiguous quarter
 template <bool RAW>
 __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__ keys_in, int64_t n_host,
                                                         const int32_t* __restrict__ n_dev,
                                                         uint32_t sentinel, int shift, int bits,
-                                                        int64_t ipb, int32_t* __restrict__ hist,
+                                                        int64_t ipb_host, int32_t* __restrict__ hist,
                                                         int32_t* __restrict__ list_count) {
-  // n_dev: live entries after the first pass dropped the sentinels (device-side count; the
-  // grid is still sized for the padded capacity, surplus blocks write zero rows)
-  const int64_t n = (!RAW && n_dev) ? (int64_t)*n_dev : n_host;
+  // n_dev: live entries after the first pass dropped the sentinels (device-side count; the grid
+  // is sized for the host-side capacity: the live entries are dealt over ALL its blocks)
+  const int32_t* cnt = RAW ? nullptr : n_dev;
+  const int64_t n = cnt ? min((int64_t)*cnt, n_host) : n_host;
+  const int64_t ipb = cnt ? rs_ipb_dev(n, gridDim.x) : ipb_host;
   __shared__ int h[kRsWaves][kRsMaxBins];
   const int bins = 1 << bits;
   const int lane = threadIdx.x & 63;
@@ -128,10 +138,12 @@ template <bool RAW>
 __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(
     const void* __restrict__ keys_in, const int32_t* __restrict__ src_in,
     const float* __restrict__ coef_in, int64_t n_host, int32_t* __restrict__ n_live,
-    uint32_t sentinel, int shift, int bits, int64_t ipb, const int32_t* __restrict__ hist,
+    uint32_t sentinel, int shift, int bits, int64_t ipb_host, const int32_t* __restrict__ hist,
     const int32_t* __restrict__ tot, uint32_t* __restrict__ keys_out, int32_t* __restrict__ src_out,
     float* __restrict__ coef_out) {
-  const int64_t n = (!RAW && n_live) ? (int64_t)*n_live : n_host;
+  const int32_t* cnt = RAW ? nullptr : n_live;
+  const int64_t n = cnt ? min((int64_t)*cnt, n_host) : n_host;
+  const int64_t ipb = cnt ? rs_ipb_dev(n, gridDim.x) : ipb_host;
   constexpr int NW = kRsWaves;
   __shared__ int wcnt[NW][kRsMaxBins];
   __shared__ int gbase[kRsMaxBins];
