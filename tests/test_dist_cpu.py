@@ -100,3 +100,52 @@ def test_sharded_step_matches_oracle_gloo(tmp_path, world):
     port = 29500 + (os.getpid() % 400) + world
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
+
+
+def _dp_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "a-recsys_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arx.dist import SeqDataParallel
+    dp = object.__new__(SeqDataParallel)          # the exchange helpers alone (no model / GPU runtime)
+    dp.world, dp.rank, dp.group = world, rank, None
+    # packed all-reduce: every tensor ends as the sum over replicas, shapes and views preserved
+    big = torch.arange(24, dtype=torch.float32).reshape(2, 3, 4) * (rank + 1)
+    view = torch.zeros(10)
+    part = view[2:7]
+    part.copy_(torch.full((5,), float(rank + 1)))
+    scalar = torch.tensor([0.5 * (rank + 1)])
+    dp._all_reduce_packed([big, part, scalar])
+    tot = sum(r + 1 for r in range(world))
+    assert torch.equal(big, torch.arange(24, dtype=torch.float32).reshape(2, 3, 4) * tot)
+    assert torch.equal(view, torch.tensor([0, 0] + [float(tot)] * 5 + [0, 0, 0]))
+    assert abs(float(scalar) - 0.5 * tot) < 1e-6
+    # rank-major gather of lookup ids and gradient rows
+    ids = torch.arange(3, dtype=torch.int32) + 10 * rank
+    rows = torch.full((3, 2), float(rank))
+    g_ids = torch.empty(3 * world, dtype=torch.int32)
+    g_rows = torch.empty(3 * world, 2)
+    dp._all_gather(ids, g_ids)
+    dp._all_gather(rows, g_rows)
+    assert g_ids.tolist() == [k + 10 * r for r in range(world) for k in range(3)]
+    assert torch.equal(g_rows, torch.repeat_interleave(torch.arange(world, dtype=torch.float32), 3)[:, None].expand(-1, 2))
+    dp._loss = torch.zeros(1)
+    assert abs(dp.global_loss(1.5 + rank) - sum(1.5 + r for r in range(world))) < 1e-6
+    with open(os.path.join(out_dir, "dp%d" % rank), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_seq_data_parallel_collectives_gloo(tmp_path, world):
+    """The exchange helpers of arx.dist.SeqDataParallel over gloo (the model-level test against the
+    oracle needs the HIP runtime: tests/test_seq_dp_gpu.py)."""
+    import torch.multiprocessing as mp
+    port = 29100 + (os.getpid() % 400) + world
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("dp%d" % r)) for r in range(world))
