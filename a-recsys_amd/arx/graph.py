@@ -975,7 +975,7 @@ class Plan(object):
                     cand.append((entry, f[0], f[1]))
             virt = None
             if len(cand) == 1 and not cand[0][2]:
-                virt = self._find_rider([cand[0]], {id(cand[0][0])}, virtual_only=True)
+                virt = self._find_rider([cand[0]], {id(cand[0][0])})     # a bag table that can ride on it?
             if len(cand) >= 2 or virt is not None:
                 e0, c0, m0 = cand[0]
                 n0 = (c0 + m0)[0].node
@@ -1060,7 +1060,7 @@ class Plan(object):
             rt.join(t)
         self._plan_early(self._jobs, self._n_passes)
 
-    def _find_rider(self, fused, done, virtual_only=False):
+    def _find_rider(self, fused, done):
         """(index in the fused group, table entry, live sites) of a two-stage multi-hot table whose
         lookups are exactly the lookups of one fused one-hot table: same id tensors, gradient rows,
         coefficients and arena (arx_sparse_adagrad_cat_multi_bags), or None.  Index None: no such
@@ -1087,7 +1087,7 @@ class Plan(object):
                 if all(a.ids_node.value.data_ptr() == b.ids_node.value.data_ptr()
                        and a.ids_node.value.shape == b.ids_node.value.shape and a.node.row0 == b.node.row0
                        and a.coef == b.coef and a.node.arena is b.node.arena and a.node.arena_b is b.node.arena_b
-                       for a, b in zip(c, live)) and not virtual_only:
+                       for a, b in zip(c, live)):
                     return gi, entry, live
             if (virtual is None and len(fused) <= 3 and sum(len(c) for _, c, _ in fused) + len(live) <= 8
                     and entry[0].E.shape[1] == fused[0][0][0].E.shape[1]
