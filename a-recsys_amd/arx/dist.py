@@ -50,8 +50,30 @@ class HipBackend(object):
         self.ops = ops
         self.ws = ops.Workspace(device)
 
-    def gather_rows(self, E, bias, rows, out, bias_out):
-        self.ops.gather_onehot(E, bias, None, rows, out, bias_out=bias_out)
+    def gather_rows(self, E, bias, rows, out, bias_out, scale=1.0):
+        self.ops.gather_onehot(E, bias, None, rows, out, scale=scale, bias_out=bias_out)
+
+    def gather_bags(self, E, bias, vals, starts, lens, ids, out, bias_out, scale=1.0, accumulate=False):
+        """out[r] (+)= scale * mean over the bag of ids[r] of E rows; bias_out likewise."""
+        self.ops.gather_mulhot_mean(E, bias, vals, starts, lens, ids, out, scale=scale, accumulate=accumulate,
+                                    bias_out=bias_out)
+
+    def bags_adagrad(self, E, acc, bias, bias_acc, vals, starts, lens, sites, G, Gb, lr):
+        """Two-stage multi-hot pass (arx_sparse_adagrad_bags); sites: [(entity ids, row_base, coef)].
+        Tokens >= E.shape[0] (rows of other shards, mapped to the padding row) are dropped."""
+        ops = self.ops
+        key = tuple((i.data_ptr(), int(i.shape[0]), b, c) for i, b, c in sites)
+        cache = self.__dict__.setdefault('_bags', {})
+        ent = cache.get(key)
+        if ent is None:
+            if len(cache) > 64:
+                cache.clear()
+            mx = self.__dict__.setdefault('_bag_maxlen', {})
+            if lens.data_ptr() not in mx:
+                mx[lens.data_ptr()] = int(lens.max().item())
+            ent = cache[key] = (ops.BagSiteArgs(sites, mx[lens.data_ptr()]), ops.Workspace(G.device))
+        args, ws = ent
+        ops.sparse_adagrad_bags(E, acc, bias, bias_acc, vals, starts, lens, args, G, Gb, lr, ws)
 
     def gather_rows_packed(self, E, bias, rows, out):
         self.ops.gather_onehot_packed(E, bias, None, rows, out)
@@ -92,7 +114,8 @@ class HipBackend(object):
         """tables: [(E, acc, bias|None, bias_acc|None)]; sites: [(table, local_rows, row_base)]:
         one fused pass (arx_sparse_adagrad_cat_multi)."""
         ops = self.ops
-        key = tuple((t, r.data_ptr(), int(r.shape[0]), b) for t, r, b in sites)
+        sites = [(x[0], x[1], x[2], x[3] if len(x) > 3 else 1.0) for x in sites]   # (table, rows, base[, coef])
+        key = tuple((t, r.data_ptr(), int(r.shape[0]), b, c) for t, r, b, c in sites)
         cache = self.__dict__.setdefault('_multi', {})
         ent = cache.get(key)
         if ent is None:
@@ -106,7 +129,7 @@ class HipBackend(object):
                 if c is None:
                     c = cnts[E.data_ptr()] = torch.zeros((E.shape[0],), dtype=torch.int32, device=dev)
                 tabs.append((E, acc, bias, bacc, c))
-            args = ops.MultiCatArgs(tabs, [(t, None, r, b, 1.0) for t, r, b in sites])
+            args = ops.MultiCatArgs(tabs, [(t, None, r, b, c) for t, r, b, c in sites])
             n = max(args.total, 1)
             bufs = self.__dict__.get('_multi_bufs')
             if bufs is None or bufs[0].shape[0] < n:
@@ -358,6 +381,156 @@ class ShardedHMF(object):
         return out
 
 
+class ShardedHMFBags(ShardedHMF):
+    """ShardedHMF with HET items (comb_attribute.py:151-176): item = mean(id row, bag mean) of an id
+    feature and ONE multi-hot attribute -- the id table striped by item as before, the TOKEN table
+    striped by token (owner = token % world).  An item's tokens live on several
+    ranks, so every rank forms its PARTIAL of every embedding the step needs -- half its own id row
+    (zeros where it does not own the item) plus half the bag mean restricted to its own tokens --
+    and the partials are summed by the collective that distributes them:
+
+      all_reduce      pool partials [S, d+4]                      -> the S pool embeddings, everywhere
+      reduce_scatter  target partials [B, d+4] -> [B_loc, d+4]    -> each rank's own target embeddings
+      (local)         logits, WMRB loss, dU, user-shard rows      (as ShardedHMF)
+      all_reduce      pool-gradient partials [S, d+4]             -> the pool gradient, everywhere
+      all_gather      target-row gradients [B_loc, d+4] -> [B, d+4]
+      (local)         one fused one-hot pass (user shard; id shard: pool + ALL B targets, rows of other
+                      owners dropped, coefficient 1/2) and one two-stage bag pass over the token shard
+                      (tokens of other owners dropped, coefficient 1/2 . 1/len)
+
+    No all_to_all is left on the path; the target ids of the global batch are all-gathered with the
+    batch (prepare_route: input data).  The bag index (vals / starts / lens, global item ids, global
+    token ids) is replicated; each rank keeps a copy of `vals` in which its own tokens are local rows
+    and every other token points at the shard's padding row (forward: adds zeros; backward: out of
+    range, dropped by the sort).  Volume per rank and step: 2 x B x (d+4) x 4 bytes through the
+    reduce_scatter / all_gather (B = global batch) -- the price of token sharding; the id-only step
+    moves 2 x B_loc x (d+4) x 4."""
+
+    def __init__(self, n_users, n_items, d, B_loc, S, learning_rate, rank, world, device, bags, n_tokens,
+                 backend=None, group=None, tables=None, seed=0, acc0=0.1):
+        super().__init__(n_users, n_items, d, B_loc, S, learning_rate, rank, world, device, backend=backend,
+                         group=group, tables=tables, seed=seed, acc0=acc0)
+        dev, f32, i32 = self.device, torch.float32, torch.int32
+        vals, starts, lens = [np.asarray(a) for a in bags]
+        nt = (n_tokens - rank + world - 1) // world
+        self.n_tokens, self.nt_loc = n_tokens, nt
+        if tables is not None:
+            T = np.asarray(tables['token'], dtype=np.float32)[rank::world]
+            bT = np.asarray(tables['token_bias'], dtype=np.float32).reshape(-1)[rank::world]
+            self.E_tok = torch.zeros((nt + 1, d), dtype=f32, device=dev)
+            self.E_tok[:nt].copy_(torch.from_numpy(np.ascontiguousarray(T)))
+            self.b_tok = torch.zeros((nt + 1,), dtype=f32, device=dev)
+            self.b_tok[:nt].copy_(torch.from_numpy(np.ascontiguousarray(bT)))
+        else:
+            g = torch.Generator(device=dev)
+            g.manual_seed(seed * 2003 + rank)
+            lim = float(np.sqrt(6.0 / (n_tokens + d)))
+            self.E_tok = torch.empty((nt + 1, d), dtype=f32, device=dev).uniform_(-lim, lim, generator=g)
+            self.b_tok = torch.empty((nt + 1,), dtype=f32, device=dev).uniform_(-lim, lim, generator=g)
+            self.E_tok[nt].zero_()
+            self.b_tok[nt] = 0.0
+        self.A_tok = torch.full_like(self.E_tok, acc0)
+        self.Ab_tok = torch.full_like(self.b_tok, acc0)
+        v = vals.astype(np.int64)
+        mine = np.where(v % world == rank, v // world, nt).astype(np.int32)      # other owners -> padding row
+        self.bag_vals = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
+        self.bag_starts = torch.from_numpy(np.ascontiguousarray(starts.astype(np.int32))).to(dev)
+        self.bag_lens = torch.from_numpy(np.ascontiguousarray(lens.astype(np.int32))).to(dev)
+        B, dp = self.B, self.dp
+        z = lambda *s_: torch.zeros(s_, dtype=f32, device=dev)
+        self.P_part, self.Pb = z(S, dp), z(S)               # pool partials -> (all_reduce) pool embeddings
+        self.T_part, self.Tb = z(B, dp), z(B)               # target partials of the GLOBAL batch
+        self.pool_fwd = torch.zeros(S, dtype=i32, device=dev)    # id-shard row of every pool slot (padding row: not mine)
+        self.pool_bwd = torch.zeros(S, dtype=i32, device=dev)    # ... or KEY_NONE
+        self.arena = z(B_loc + S + B, dp)                   # [dU_loc ; pool gradient ; target gradients of the batch]
+        self.arena_b = z(B_loc + S + B)
+
+    def _alloc_recv(self, cap):
+        return                                              # (no variable-size exchange in this step)
+
+    def set_pool(self, pool_ids):
+        super().set_pool(pool_ids)
+        self.be.shard_route(self.pool_ids, self.world, self.rank, self.zero_row, self.pool_fwd, self.pool_bwd)
+
+    def prepare_route(self, users, items):
+        W = self.world
+        dev = self.device
+        u = users if isinstance(users, torch.Tensor) else torch.as_tensor(np.asarray(users, dtype=np.int32))
+        it = items if isinstance(items, torch.Tensor) else torch.as_tensor(np.asarray(items, dtype=np.int32))
+        u, it = u.to(dev, torch.int32), it.to(dev, torch.int32)
+        tgt_all = torch.empty(self.B, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(tgt_all, it.contiguous(), group=self.group)   # target ids of the global batch
+        fwd = torch.zeros(self.B, dtype=torch.int32, device=dev)
+        bwd = torch.zeros(self.B, dtype=torch.int32, device=dev)
+        self.be.shard_route(tgt_all, W, self.rank, self.zero_row, fwd, bwd)
+        urows = torch.zeros(self.B_loc, dtype=torch.int32, device=dev)
+        self.be.shard_route(u, W, self.rank, 0, urows, None)
+        return {'users': u, 'items': it, 'urows': urows, 'tgt_all': tgt_all, 'tgt_fwd': fwd, 'tgt_bwd': bwd}
+
+    def step(self, users, items=None):
+        route = users if isinstance(users, dict) else self.prepare_route(users, items)
+        be, grp = self.be, self.group
+        B, B_loc, S, d = self.B, self.B_loc, self.S, self.d
+        arena, arena_b = self.arena, self.arena_b
+        urows = route['urows']
+        self.urows = urows
+        bag = (self.bag_vals, self.bag_starts, self.bag_lens)
+        # ---- forward: partial embeddings, summed by the collectives ----
+        be.gather_rows(self.E_user, None, urows, self.U_loc, None)
+        be.gather_rows(self.E_item, self.b_item, self.pool_fwd, self.P_part[:, :d], self.Pb, scale=0.5)
+        be.gather_bags(self.E_tok, self.b_tok, *bag, self.pool_ids, self.P_part[:, :d], self.Pb, scale=0.5,
+                       accumulate=True)
+        be.copy_strided(self.Pb, self.P_part[:, d])
+        w_pool = dist.all_reduce(self.P_part, op=dist.ReduceOp.SUM, group=grp, async_op=True)
+        be.gather_rows(self.E_item, self.b_item, route['tgt_fwd'], self.T_part[:, :d], self.Tb, scale=0.5)
+        be.gather_bags(self.E_tok, self.b_tok, *bag, route['tgt_all'], self.T_part[:, :d], self.Tb, scale=0.5,
+                       accumulate=True)
+        be.copy_strided(self.Tb, self.T_part[:, d])
+        w_pool.wait()
+        w_tgt = dist.reduce_scatter_tensor(self.T_pack, self.T_part, op=dist.ReduceOp.SUM, group=grp,
+                                           async_op=True)             # own target embeddings ...
+        be.copy_strided(self.P_part[:, d], self.b_all)
+        be.gemm(self.U_loc, self.P_part[:, :d], self.logits, transB=True, col_bias=self.b_all)   # ... under the scorer
+        w_tgt.wait()
+        dU = arena[:B_loc, :d]
+        be.loss_mw_fused_pos(self.logits, self.U_loc, self.T_pack[:, :d], self.T_pack[:, d], urows,
+                             self.pos_ptr, self.pos_items, self.item2slot, self.bl, self.dlogits,
+                             self.t_loc, self.dT_pack[:, d], dU, self.dT_pack[:, :d], 1.0 / B)
+        # ---- backward ----
+        w_dt = dist.all_gather_into_tensor(arena[B_loc + S:], self.dT_pack, group=grp, async_op=True)
+        be.gemm(self.dlogits, self.P_part[:, :d], dU, beta=1.0)                    # dU += dL . pool
+        gP = arena[B_loc:B_loc + S]
+        be.gemm(self.dlogits, self.U_loc, gP[:, :d], transA=True, a_rowsum=self.gb_all)
+        be.copy_strided(self.gb_all, gP[:, d])
+        dist.all_reduce(gP, op=dist.ReduceOp.SUM, group=grp)
+        w_dt.wait()
+        be.copy_strided(arena[B_loc:, d], arena_b[B_loc:])
+        # id shard + user shard: one fused one-hot pass (rows of other owners carry KEY_NONE)
+        be.sparse_adagrad_multi([(self.E_user, self.A_user, None, None),
+                                 (self.E_item, self.A_item, self.b_item, self.Ab_item)],
+                                [(0, urows, 0, 1.0), (1, self.pool_bwd, B_loc, 0.5),
+                                 (1, route['tgt_bwd'], B_loc + S, 0.5)], arena[:, :d], arena_b, self.lr)
+        # token shard: merge per item, then per token; tokens of other owners are out of range
+        nt = self.nt_loc
+        be.bags_adagrad(self.E_tok[:nt], self.A_tok[:nt], self.b_tok[:nt], self.Ab_tok[:nt], *bag,
+                        [(self.pool_ids, B_loc, 0.5), (route['tgt_all'], B_loc + S, 0.5)], arena[:, :d], arena_b,
+                        self.lr)
+        self.steps += 1
+
+    def gather_global_tables(self):
+        out = super().gather_global_tables()
+        W = self.world
+        for name, t, n in (('token', self.E_tok[:self.nt_loc], self.n_tokens),
+                           ('token_bias', self.b_tok[:self.nt_loc], self.n_tokens)):
+            rows = (n + W - 1) // W
+            pad = torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            pad[:t.shape[0]] = t
+            parts = [torch.empty_like(pad) for _ in range(W)]
+            dist.all_gather(parts, pad, group=self.group)
+            out[name] = torch.stack(parts, 1).reshape((rows * W,) + tuple(t.shape[1:]))[:n].cpu().numpy()
+        return out
+
+
 # --------------------------------------------------------------------------
 # bench entry for N > 1 (driver: python -m torch.distributed.run ... bench.py --gpus N)
 # --------------------------------------------------------------------------
@@ -569,7 +742,19 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
         dist.init_process_group("nccl", device_id=dev)
     B_loc, S, d = args.batch, args.n_sampled, args.dim
     t_setup = time.time()
-    model = ShardedHMF(args.n_users, args.n_items, d, B_loc, S, 0.1, rank, world, dev, seed=0)
+    with_bags = bool(getattr(args, 'sharded_bags', False))
+    if with_bags:
+        # HET items: a multi-hot attribute of 20 tokens over a 100 k-token table striped by token
+        n_tok, L_bag = 100000, 20
+        rng = np.random.default_rng(11)                      # the SAME bag index on every rank
+        p_tok = 1.0 / np.arange(1, n_tok + 1)
+        vals = rng.choice(n_tok, size=(args.n_items + 1) * L_bag, p=p_tok / p_tok.sum()).astype(np.int32)
+        lens = np.full(args.n_items + 1, L_bag, dtype=np.int32)
+        starts = (np.arange(args.n_items + 1, dtype=np.int64) * L_bag).astype(np.int32)
+        model = ShardedHMFBags(args.n_users, args.n_items, d, B_loc, S, 0.1, rank, world, dev,
+                               (vals, starts, lens), n_tok, seed=0)
+    else:
+        model = ShardedHMF(args.n_users, args.n_items, d, B_loc, S, 0.1, rank, world, dev, seed=0)
     gen = torch.Generator(device=dev)
     gen.manual_seed(77 + rank)
     n_pos = 20
@@ -650,7 +835,8 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
     out = None
     if rank == 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        run_gemm = lambda: model.be.gemm(model.U_loc, model.I_all[:, :d], model.logits, transB=True,
+        pool_mat = model.P_part if with_bags else model.I_all
+        run_gemm = lambda: model.be.gemm(model.U_loc, pool_mat[:, :d], model.logits, transB=True,
                                          col_bias=model.b_all)
         for _ in range(5):
             run_gemm()
@@ -671,7 +857,10 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "C5 (BASELINE configs[4]): synthetic %d-item/%d-user HMF, dim %d, id-only, WMRB 'mw', "
+            "config": {"workload": ("C3 sharded: HET items (id + 20-token bag over a 100 k-token table striped by TOKEN; "
+                                    "per step all_reduce(pool partials, pool grads) + reduce_scatter(target partials) + "
+                                    "all_gather(target grads), arx.dist.ShardedHMFBags) -- " if with_bags else "") +
+                                   "C5 (BASELINE configs[4]): synthetic %d-item/%d-user HMF, dim %d, id-only, WMRB 'mw', "
                                    "item and user tables row-sharded over %d GPU(s) (owner = id %% N), %d shared "
                                    "negatives/step, S/N per owner drawn on device with p ~ count^0.5 and all-gathered "
                                    "every %d steps (%d redraw(s) inside the timed region); per step: RCCL "

@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--zipf-items", type=float, default=1.05,
                     help="popularity exponent of the synthetic item draw (0 = uniform; experiments only)")
     ap.add_argument("--lstm-batch", type=int, default=1024)
+    ap.add_argument("--sharded-bags", action="store_true",
+                    help="N > 1 (or WORLD_SIZE set): HET items on the sharded step -- id table striped by item, "
+                         "a 100 k-token multi-hot table striped by TOKEN (arx.dist.ShardedHMFBags); 1 M items")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-rooflines", action="store_true", help="skip the per-kernel timings (profiling runs)")
@@ -562,7 +565,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1:
         if args.n_items is None:
-            args.n_items = 100000000      # configs[4]: 100 M-item dim-128 table, row-sharded
+            # configs[4]: 100 M-item dim-128 table, row-sharded (with --sharded-bags: 1 M items, 20 tokens each)
+            args.n_items = 1000000 if args.sharded_bags else 100000000
         from arx import dist as arx_dist
         return arx_dist.bench_main(args, world, rank, local_rank)
     if args.n_items is None:

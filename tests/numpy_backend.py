@@ -13,11 +13,43 @@ def _n(t):
 
 
 class NumpyBackend(object):
-    def gather_rows(self, E, bias, rows, out, bias_out):
+    def gather_rows(self, E, bias, rows, out, bias_out, scale=1.0):
         r = _n(rows).astype(np.int64)
-        _n(out)[...] = _n(E)[r]
+        _n(out)[...] = scale * _n(E)[r]
         if bias_out is not None:
-            _n(bias_out)[...] = _n(bias)[r]
+            _n(bias_out)[...] = scale * _n(bias)[r]
+
+    def gather_bags(self, E, bias, vals, starts, lens, ids, out, bias_out, scale=1.0, accumulate=False):
+        e, b, v, st, ln = _n(E), _n(bias), _n(vals), _n(starts), _n(lens)
+        o, ob = _n(out), _n(bias_out)
+        for r, i in enumerate(_n(ids).astype(np.int64)):
+            tok = v[st[i]:st[i] + ln[i]].astype(np.int64)
+            row = scale * e[tok].astype(np.float64).sum(0) / float(ln[i])
+            bb = scale * b[tok].astype(np.float64).sum() / float(ln[i])
+            o[r] = (o[r] + row) if accumulate else row
+            ob[r] = (ob[r] + bb) if accumulate else bb
+
+    def bags_adagrad(self, E, acc, bias, bias_acc, vals, starts, lens, sites, G, Gb, lr):
+        """sites: [(entity ids, row_base, coef)]; tokens >= E.shape[0] are dropped."""
+        e, a, b, ba = _n(E), _n(acc), _n(bias), _n(bias_acc)
+        v, st, ln = _n(vals), _n(starts), _n(lens)
+        g_all, gb_all = _n(G).astype(np.float64), _n(Gb).astype(np.float64)
+        g = np.zeros(e.shape, dtype=np.float64)
+        gb = np.zeros(e.shape[0], dtype=np.float64)
+        touched = np.zeros(e.shape[0], dtype=bool)
+        for ids, base, coef in sites:
+            for j, i in enumerate(_n(ids).astype(np.int64)):
+                for t in v[st[i]:st[i] + ln[i]].astype(np.int64):
+                    if 0 <= t < e.shape[0]:
+                        g[t] += coef / float(ln[i]) * g_all[base + j][:e.shape[1]]
+                        gb[t] += coef / float(ln[i]) * gb_all[base + j]
+                        touched[t] = True
+        lrv = float(_n(lr)[0])
+        rows = np.nonzero(touched)[0]
+        a[rows] = a[rows] + g[rows] ** 2
+        e[rows] = e[rows] - lrv * g[rows] / np.sqrt(a[rows])
+        ba[rows] = ba[rows] + gb[rows] ** 2
+        b[rows] = b[rows] - lrv * gb[rows] / np.sqrt(ba[rows])
 
     def gather_rows_packed(self, E, bias, rows, out):
         r = _n(rows).astype(np.int64)
@@ -115,7 +147,7 @@ class NumpyBackend(object):
             b[rows] = b[rows] - lrv * gb[rows] / np.sqrt(ba[rows])
 
     def sparse_adagrad_multi(self, tables, sites, G, Gb, lr):
-        """tables: [(E, acc, bias|None, bias_acc|None)]; sites: [(table, local_rows, row_base)]."""
+        """tables: [(E, acc, bias|None, bias_acc|None)]; sites: [(table, local_rows, row_base[, coef])]."""
         g_all, gb_all = _n(G).astype(np.float64), _n(Gb).astype(np.float64)
         lrv = float(_n(lr)[0])
         for t, (E, acc, bias, bacc) in enumerate(tables):
@@ -123,13 +155,17 @@ class NumpyBackend(object):
             g = np.zeros(e.shape, dtype=np.float64)
             gb = np.zeros(e.shape[0], dtype=np.float64)
             touched = []
-            for tt, rows, base in sites:
+            for site in sites:
+                tt, rows, base = site[0], site[1], site[2]
+                coef = site[3] if len(site) > 3 else 1.0
                 if tt != t:
                     continue
                 k = _n(rows).astype(np.int64)
                 src = base + np.arange(len(k))
-                np.add.at(g, k, g_all[src][:, :e.shape[1]])
-                np.add.at(gb, k, gb_all[src])
+                ok = (k >= 0) & (k < e.shape[0])                 # KEY_NONE: rows of other owners
+                k, src = k[ok], src[ok]
+                np.add.at(g, k, coef * g_all[src][:, :e.shape[1]])
+                np.add.at(gb, k, coef * gb_all[src])
                 touched.append(k)
             if not touched:
                 continue

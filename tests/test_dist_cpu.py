@@ -149,3 +149,88 @@ def test_seq_data_parallel_collectives_gloo(tmp_path, world):
     port = 29100 + (os.getpid() % 400) + world
     mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ("dp%d" % r)) for r in range(world))
+
+
+def _bags_worker(rank, world, port, out_dir):
+    """Token-sharded multi-hot table (arx.dist.ShardedHMFBags): HET items = mean(id row, bag mean),
+    id table striped by item, token table striped by token; vs the single-process oracle."""
+    for p in (ROOT, os.path.join(ROOT, "a-recsys_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arx.dist import ShardedHMFBags
+    from arx.utils.synthetic import SyntheticHMF
+    from numpy_backend import NumpyBackend
+    from oracle import ref_graph as rg
+
+    n_users, n_items, d, B_loc, S, V = 60, 90, 16, 8, 16, 37
+    syn = SyntheticHMF(n_users=n_users, n_items=n_items, seed=1, permute_logits=False, n_pos=6,
+                       item_mulhot=True, mulhot_vocab=V, avg_len=4, max_len=9)
+    ia = syn.i_attr
+    n_tok = ia._embedding_classes_list_mulhot[0]
+    params = syn.glorot_params(d, seed=2, scale=0.5)
+    tables = {'user': params['userembed_cat_0'][2:], 'item': params['itemembed_cat_0'][2:],
+              'item_bias': params['item_bias_cat_0'][2:], 'token': params['itemembed_mulhot_0'],
+              'token_bias': params['item_bias_mulhot_0']}
+    bags = (np.asarray(ia.features_mulhot[0]), np.asarray(ia.mulhot_starts[0]), np.asarray(ia.mulhot_lengths[0]))
+    model = ShardedHMFBags(n_users, n_items, d, B_loc, S, 0.5, rank, world, 'cpu', bags, n_tok,
+                           backend=NumpyBackend(), tables=tables)
+    own_users = np.arange(rank, n_users, world)
+    ptr = np.zeros(len(own_users) + 2, dtype=np.int32)
+    items = []
+    for k, u in enumerate(own_users):
+        items.extend(syn.pos_items[syn.pos_ptr[u]:syn.pos_ptr[u + 1]].tolist())
+        ptr[k + 1] = len(items)
+    ptr[-1] = ptr[-2]
+    model.set_positives(ptr, np.asarray(items, dtype=np.int32))
+    B = B_loc * world
+    ref = rg.RefLatentProductModel(d, B, 0.5, syn.u_attr, syn.i_attr, syn.item_ind2logit_ind_dict(),
+                                   syn.logit_ind2item_ind, loss_function='mw', n_sampled=S, params=params,
+                                   dtype=np.float64)
+    pos = syn.positives_dict()
+    ref.prepare_warp(pos, pos)
+    rng = np.random.default_rng(5)
+    for step in range(4):
+        pool = None
+        if step % 2 == 0:
+            blocks = [rng.choice(np.arange(g, n_items, world), size=S // world, replace=False) for g in range(world)]
+            pool = np.concatenate(blocks).astype(np.int32)
+            id2idx = {int(v): i for i, v in enumerate(pool)}
+            model.set_pool(pool)
+        gu, gi = [], []
+        for g in range(world):
+            users = rng.integers(0, len(np.arange(g, n_users, world)), size=B_loc) * world + g
+            gu.append(users)
+            gi.append(syn.pos_items[syn.pos_ptr[users] + rng.integers(0, syn.n_pos, size=B_loc)])
+        gu[0][1] = gu[0][0]
+        gi[1][2] = gi[1][3]                        # duplicate targets: merged before the token stage
+        if step == 0:
+            gi[0][0] = pool[S // world]            # a target that is also a pool slot
+        if step == 3:                              # every target's id row owned by rank 0
+            for g in range(world):
+                gi[g] = (rng.integers(0, n_items // world, size=B_loc) * world).astype(gi[g].dtype)
+        l_ref = ref.step(np.concatenate(gu).tolist(), np.concatenate(gi).tolist(), pool, id2idx, loss='mw')
+        model.step(gu[rank].astype(np.int32), gi[rank].astype(np.int32))
+        l_got = float(model.read_loss().item())
+        assert abs(l_got - l_ref) <= 1e-5 * abs(l_ref), (step, l_got, l_ref)
+    got = model.gather_global_tables()
+    P = ref.att_emb.params
+    for name, want in (('user', P['userembed_cat_0'][2:]), ('item', P['itemembed_cat_0'][2:]),
+                       ('item_bias', P['item_bias_cat_0'][2:, 0]), ('token', P['itemembed_mulhot_0']),
+                       ('token_bias', P['item_bias_mulhot_0'][:, 0])):
+        np.testing.assert_allclose(got[name], want, rtol=1e-4, atol=1e-6, err_msg=name)
+    with open(os.path.join(out_dir, "bags%d" % rank), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_token_sharded_bags_match_oracle_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+    port = 29300 + (os.getpid() % 400) + world
+    mp.spawn(_bags_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("bags%d" % r)) for r in range(world))
