@@ -90,6 +90,7 @@ CFG_HET = dict(n_users=300, n_items=500, logit_size=500, item_mulhot=True, mulho
     (CFG_ID, 32, 16, 4, 64, 0.5),        # generic LSTM kernel, hard clipping
     (CFG_HET, 64, 32, 6, 128, 1e9),      # multi-hot item attributes, no clipping
     (CFG_HET, 64, 16, 4, 64, 0.5),       # multi-hot tokens shared between pool items, hard clipping
+    (CFG_HET, 64, 64, 8, 128, 5.0),      # > 8192 bag slots: the bag table rides on the fused one-hot pass (K7c)
 ])
 def test_seq_mw_steps_match_oracle(dev, cfg, size, B, L, S, clip):
     syn, emb, model, remb, ref = _build(cfg, 'mw', size, B, L, S, clip, seed=4)
