@@ -520,15 +520,19 @@ class SeqModel(SeqBatching):
         ops.merged_sq_norm(ks, ss, cs, f.table.E.shape[0], sq, rt.ws, X=X, d=d, L=Lx, step_stride=S * d,
                            Xb=Xb, Lb=Lb, stepb_stride=S)
 
-    def _tiled(self, rs, L, tag):
+    def _tiled(self, rs, L, tag, static=False):
+        """rs repeated for each of the L unrolled steps; static: rs never changes (one-hot features
+        only, see _row_scale) -- tiled once, not in every step."""
         S = rs.shape[0]
         if S % 4 != 0:
             raise NotImplementedError("pool size must be a multiple of 4")
         cache = self._rs_cache
         key = ('tile', tag, L)              # (the pool lookup is shared by buckets of different L)
-        if key not in cache:
+        fresh = key not in cache
+        if fresh:
             cache[key] = torch.empty(L * S, dtype=torch.float32, device=self.rt.device)
-        ops.add_rows_bcast(1.0, rs.view(1, S), 0.0, cache[key].view(L, S))
+        if fresh or not static:
+            ops.add_rows_bcast(1.0, rs.view(1, S), 0.0, cache[key].view(L, S))
         return cache[key]
 
     def _clip_hook(self, plan):
@@ -582,7 +586,8 @@ class SeqModel(SeqBatching):
                     dd = 1 if for_bias else d
                     if per_step:
                         rs = self._row_scale(n, True, per_step, 'ps%d' % for_bias)
-                        norms.append((steps_buf, dd, self._tiled(rs, L, (id(n), for_bias)), None))
+                        norms.append((steps_buf, dd, self._tiled(rs, L, (id(n), for_bias),
+                                                                 static=all(f.kind == 'cat' for f in per_step)), None))
                     if merged:
                         rs = self._row_scale(n, True, merged, 'mg%d' % for_bias)
                         norms.append((sum_buf, dd, rs, S * dd))
