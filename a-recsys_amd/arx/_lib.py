@@ -143,6 +143,8 @@ PROTOTYPES = {
     "arx_clip_coef": (cint, [f32p, f32, f32p, f32p, vp]),
     "arx_sq_norm_accum_multi": (cint, [cint, C.POINTER(vp), C.POINTER(i64), C.POINTER(cint), C.POINTER(vp),
                                        f32p, vp]),
+    "arx_sq_norm_clip_multi": (cint, [cint, C.POINTER(vp), C.POINTER(i64), C.POINTER(cint), C.POINTER(vp), cint,
+                                      f32p, C.c_float, f32p, f32p, vp]),
     "arx_merged_sq_norm": (cint, [i32p, i32p, f32p, i64, cint, f32p, i64, cint, cint, i64, f32p, cint,
                                   i64, f32p, vp, sz, vp]),
     "arx_fill_f32": (cint, [f32p, i64, f32, vp]),

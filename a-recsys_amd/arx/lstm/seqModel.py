@@ -543,7 +543,12 @@ class SeqModel(SeqBatching):
         un-merged values -- i.e. each unrolled step's dense matmul gradient separately."""
         rt = self.rt
         sq = self._sq
-        ops.fill_f32(sq, 0.0)
+        zeroed = [False]
+
+        def zero_sq():                    # (only paths that ACCUMULATE onto sq before the last launch need it)
+            if not zeroed[0]:
+                ops.fill_f32(sq, 0.0)
+                zeroed[0] = True
         # Data-parallel replicas (rt.dp): the dense and the pool gradients were all-reduced before this
         # hook -- their norms are the global batch's on every replica; the IndexedSlices of the batch
         # lookups stay un-merged in TF's norm, i.e. their squared norms ADD over the replicas: those
@@ -569,6 +574,7 @@ class SeqModel(SeqBatching):
                 shared = [f for f in n.feats if not self._injective(f)]
                 for f in shared:
                     if dp is None:
+                        zero_sq()
                         self._shared_rows_norm(n, sp, f, sites_of, sq)
                     else:
                         deferred.append((n, sp, f))
@@ -598,8 +604,12 @@ class SeqModel(SeqBatching):
                     local.append(len(norms))
                     norms.append((n.bias_grad, 1, self._row_scale(n, True), None))
         if dp is None:
-            ops.sq_norm_accum_multi(norms, sq)          # every plain tensor norm of the step: one launch
+            # every plain tensor norm of the step + the clip coefficient: one launch (no fill, no clip_coef)
+            ops.sq_norm_clip_multi(norms, sq, self.max_gradient_norm, rt.clip_coef_dev, self._gnorm,
+                                   init=not zeroed[0])
+            return
         else:
+            zero_sq()
             mine = [norms[i] for i in local]
             if mine:
                 ops.sq_norm_accum_multi(mine, sq)

@@ -619,6 +619,34 @@ def sq_norm_accum_multi(items, out_accum):
         call("arx_sq_norm_accum_multi", m, xs, ns, ds, rs, _p(out_accum), _stream())
 
 
+def sq_norm_clip_multi(items, sqnorm, max_norm, coef_out, gnorm_out=None, init=True):
+    """sq_norm_accum_multi + clip_coef in as few launches as tensors / 8: the LAST launch also forms
+    coef = max_norm / max(||g||, max_norm) (arx_sq_norm_clip_multi); init: sqnorm is overwritten by the
+    first launch instead of accumulated onto (no fill launch)."""
+    import ctypes as C
+    groups = [items[k:k + 8] for k in range(0, len(items), 8)]
+    if not groups:
+        if init:
+            fill_f32(sqnorm, 0.0)
+        clip_coef(sqnorm, max_norm, coef_out, gnorm_out)
+        return
+    for gi, grp in enumerate(groups):
+        m = len(grp)
+        xs = (C.c_void_p * m)(*[_p(g[0]) for g in grp])
+        ns = (C.c_int64 * m)(*[int(g[0].numel() if g[3] is None else g[3]) for g in grp])
+        ds = (C.c_int * m)(*[int(g[1]) for g in grp])
+        rs = (C.c_void_p * m)(*[(_p(g[2]) or None) for g in grp])
+        first, last = gi == 0, gi == len(groups) - 1
+        if last:
+            call("arx_sq_norm_clip_multi", m, xs, ns, ds, rs, int(bool(init and first)), _p(sqnorm), float(max_norm),
+                 _p(coef_out), _p(gnorm_out), _stream())
+        elif init and first:
+            fill_f32(sqnorm, 0.0)
+            call("arx_sq_norm_accum_multi", m, xs, ns, ds, rs, _p(sqnorm), _stream())
+        else:
+            call("arx_sq_norm_accum_multi", m, xs, ns, ds, rs, _p(sqnorm), _stream())
+
+
 def merged_sq_norm(keys, src, coef, table_rows, out_accum, ws, X=None, d=0, L=1, step_stride=0,
                    Xb=None, Lb=1, stepb_stride=0, n=None):
     """out += sum_t sum_rows ||sum_{c -> row} coef_c X_t[src_c]||^2 (+ the d = 1 analogue on Xb):

@@ -939,8 +939,13 @@ struct NormSet {
   int count;
 };
 
+// init: out = sum instead of out += sum; coef (nullable): the last block also forms the
+// clip_by_global_norm coefficient max_norm / max(||g||, max_norm) and ||g|| from the final sum
+// (arx_sq_norm_clip_multi: the fill / norm / coefficient chain of a step in one launch).
 __global__ __launch_bounds__(1024) void k_sq_norm_multi(NormSet ns, float* __restrict__ part,
-                                                        unsigned int* ticket, float* __restrict__ out) {
+                                                        unsigned int* ticket, float* __restrict__ out,
+                                                        int init, float max_norm, float* __restrict__ coef,
+                                                        float* __restrict__ gnorm) {
   __shared__ float sh[16];
   __shared__ bool s_last;
   int t = 0;
@@ -998,7 +1003,13 @@ __global__ __launch_bounds__(1024) void k_sq_norm_multi(NormSet ns, float* __res
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) tt += __shfl_xor(tt, o, 64);
     if (threadIdx.x == 0) {
-      *out += tt;
+      const float total = init ? tt : *out + tt;
+      *out = total;
+      if (coef) {
+        const float nrm = sqrtf(total);
+        if (gnorm) *gnorm = nrm;
+        *coef = max_norm / fmaxf(nrm, max_norm);
+      }
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -1742,10 +1753,12 @@ int arx_sq_norm_accum(const float* x, int64_t n, int d, const float* row_scale, 
   return ARX_OK;
 }
 
-int arx_sq_norm_accum_multi(int count, const float* const* x, const int64_t* n, const int* d,
-                            const float* const* row_scale, float* out_accum, void* stream) {
-  ARX_CHECK_ARG(count >= 1 && count <= 8, "arx_sq_norm_accum_multi: 1..8 tensors");
-  ARX_CHECK_ARG(x && n && d && out_accum, "arx_sq_norm_accum_multi: null pointer");
+static int sq_norm_multi_impl(const char* who, int count, const float* const* x, const int64_t* n, const int* d,
+                             const float* const* row_scale, float* out_accum, int init, float max_norm,
+                             float* coef_out, float* gnorm_out, void* stream) {
+  (void)who;
+  ARX_CHECK_ARG(count >= 1 && count <= 8, "arx_sq_norm_accum_multi / arx_sq_norm_clip_multi: 1..8 tensors");
+  ARX_CHECK_ARG(x && n && d && out_accum, "arx_sq_norm_accum_multi / arx_sq_norm_clip_multi: null pointer");
   float* part = nullptr;
   unsigned int* ticket = nullptr;
   ARX_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&part), HIP_SYMBOL(g_norm_part)));
@@ -1769,9 +1782,24 @@ int arx_sq_norm_accum_multi(int count, const float* const* x, const int64_t* n, 
   }
   for (int t = count; t < 8; ++t) ns.blk_end[t] = blocks;
   ns.count = count;
-  k_sq_norm_multi<<<blocks, 1024, 0, as_stream(stream)>>>(ns, part, ticket, out_accum);
+  k_sq_norm_multi<<<blocks, 1024, 0, as_stream(stream)>>>(ns, part, ticket, out_accum, init, max_norm, coef_out,
+                                                          gnorm_out);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
+}
+
+int arx_sq_norm_accum_multi(int count, const float* const* x, const int64_t* n, const int* d,
+                            const float* const* row_scale, float* out_accum, void* stream) {
+  return sq_norm_multi_impl("arx_sq_norm_accum_multi", count, x, n, d, row_scale, out_accum, 0, 0.f, nullptr,
+                            nullptr, stream);
+}
+
+int arx_sq_norm_clip_multi(int count, const float* const* x, const int64_t* n, const int* d,
+                           const float* const* row_scale, int init, float* sqnorm_out, float max_norm,
+                           float* coef_out, float* gnorm_out, void* stream) {
+  ARX_CHECK_ARG(coef_out, "arx_sq_norm_clip_multi: null pointer");
+  return sq_norm_multi_impl("arx_sq_norm_clip_multi", count, x, n, d, row_scale, sqnorm_out, init ? 1 : 0,
+                            max_norm, coef_out, gnorm_out, stream);
 }
 
 int arx_clip_coef(const float* sqnorm_dev, float max_norm, float* coef_out, float* gnorm_out,

@@ -576,6 +576,13 @@ int arx_sq_norm_accum(const float* x, int64_t n, int d, const float* row_scale,
 /* the same accumulation over up to 8 tensors in one launch (the global norm of an LSTM step) */
 int arx_sq_norm_accum_multi(int count, const float* const* x, const int64_t* n, const int* d,
                             const float* const* row_scale, float* out_accum, void* stream);
+/* arx_sq_norm_accum_multi and arx_clip_coef in ONE launch: the last-arriving workgroup, which already
+ * combines the partial sums, also forms coef = max_norm / max(||g||, max_norm) and ||g||
+ * (seqModel.py:179-180 clip_by_global_norm).  init != 0: *sqnorm_out = sum (no prior fill);
+ * init == 0: accumulated onto *sqnorm_out first (norms of earlier launches). */
+int arx_sq_norm_clip_multi(int count, const float* const* x, const int64_t* n, const int* d,
+                           const float* const* row_scale, int init, float* sqnorm_out, float max_norm,
+                           float* coef_out, float* gnorm_out, void* stream);
 int arx_clip_coef(const float* sqnorm_dev, float max_norm, float* coef_out, float* gnorm_out,
                   void* stream);
 /* Norm of a table gradient AFTER summing the contributions that land on the same table row
