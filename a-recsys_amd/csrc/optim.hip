@@ -852,7 +852,7 @@ __global__ void k_adagrad_dense(float* __restrict__ w, float* __restrict__ acc,
 
 // Deterministic squared norm in ONE launch: per-block partials in fixed slots, then the block
 // that arrives last (ticket) adds them up in slot order.  float4 loads, 4 in flight per thread.
-constexpr int kNormBlocks = 128;
+constexpr int kNormBlocks = 512;     // fixed slots of block partials (combined in slot order: deterministic)
 static __device__ float g_norm_part[kNormBlocks];
 static __device__ unsigned int g_norm_ticket;
 
@@ -1742,7 +1742,7 @@ int arx_sq_norm_accum(const float* x, int64_t n, int d, const float* row_scale, 
   const int threads = (vec ? n / 4 : n) >= 64 * 1024 ? 1024 : 256;
   int nb = (int)ceil_div(vec ? n / 4 : n, (int64_t)threads * 4);
   if (nb < 1) nb = 1;
-  static const int cap = getenv("ARX_NORM_BLOCKS") ? atoi(getenv("ARX_NORM_BLOCKS")) : kNormBlocks;
+  static const int cap = getenv("ARX_NORM_BLOCKS") ? atoi(getenv("ARX_NORM_BLOCKS")) : 128;
   if (nb > cap) nb = cap;
   if (nb > kNormBlocks) nb = kNormBlocks;
   if (vec)
@@ -1765,7 +1765,12 @@ static int sq_norm_multi_impl(const char* who, int count, const float* const* x,
   ARX_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ticket), HIP_SYMBOL(g_norm_ticket)));
   NormSet ns = {};
   int blocks = 0;
-  const int per = kNormBlocks / 8;                  // <= 16 fat blocks per tensor
+  // blocks per tensor: one per 8 K float4 per thread-row (32 KB), at most kNormBlocks / count -- the
+  // step's big tensors (13 MB each at C4) were latency-bound with 16 blocks: 20.7 us for 39 MB
+  // (more is not better: every block ends in a ticket atomic that serialises at ~16 ns)
+  static const int per_cap = getenv("ARX_NORM_PER") ? atoi(getenv("ARX_NORM_PER")) : 64;
+  int per = kNormBlocks / (count < 1 ? 1 : count);
+  if (per > per_cap) per = per_cap;
   for (int t = 0; t < count; ++t) {
     ARX_CHECK_ARG(x[t] && n[t] >= 0 && d[t] > 0, "arx_sq_norm_accum_multi: bad tensor");
     ns.x[t] = x[t];
