@@ -1511,11 +1511,16 @@ class Runtime(object):
             h(plan)
 
     def apply_dense(self, plan):
-        for p in self.dense.values():
-            if getattr(p, 'touched', False):
-                ops.adagrad_dense(p.w, None if self.optimizer == 'sgd' else p.acc, p.grad, self.lr,
-                                  gscale_dev=self.clip_coef_dev)
-                p.touched = False
+        todo = [p for p in self.dense.values() if getattr(p, 'touched', False)]
+        sgd = self.optimizer == 'sgd'
+        if len(todo) == 1:
+            p = todo[0]
+            ops.adagrad_dense(p.w, None if sgd else p.acc, p.grad, self.lr, gscale_dev=self.clip_coef_dev)
+        elif todo:                          # all dense parameters of the step: one launch
+            ops.adagrad_dense_multi([(p.w, None if sgd else p.acc, p.grad) for p in todo], self.lr,
+                                    gscale_dev=self.clip_coef_dev)
+        for p in todo:
+            p.touched = False
 
     def upload(self, arr, dtype):
         t = torch.from_numpy(np.ascontiguousarray(np.asarray(arr))).to(dtype)

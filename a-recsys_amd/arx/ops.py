@@ -601,6 +601,19 @@ def adagrad_dense(w, acc, g, lr_dev, gscale_dev=None):
          _stream())
 
 
+def adagrad_dense_multi(params, lr_dev, gscale_dev=None):
+    """params: [(w, acc|None, g)]: one launch per 8 parameters (arx_adagrad_dense_multi)."""
+    import ctypes as C
+    for k in range(0, len(params), 8):
+        grp = params[k:k + 8]
+        m = len(grp)
+        ws_ = (C.c_void_p * m)(*[_p(p[0]) for p in grp])
+        accs = (C.c_void_p * m)(*[(_p(p[1]) or None) for p in grp])
+        gs = (C.c_void_p * m)(*[_p(p[2]) for p in grp])
+        ns = (C.c_int64 * m)(*[int(p[0].numel()) for p in grp])
+        call("arx_adagrad_dense_multi", m, ws_, accs, gs, ns, _p(lr_dev), _p(gscale_dev), _stream())
+
+
 def sq_norm_accum(x, out_accum, d=1, row_scale=None, n=None):
     call("arx_sq_norm_accum", _p(x), int(x.numel() if n is None else n), int(d), _p(row_scale),
          _p(out_accum), _stream())

@@ -89,6 +89,13 @@ __global__ __launch_bounds__(1024) void k_dot_scaled(const float* __restrict__ x
   __shared__ float part[16];
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int64_t i = threadIdx.x;
+  for (; i + 7 * 1024 < n; i += 8 * 1024) {       // 16 loads in flight: one workgroup, latency-bound
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a[u] = x[i + u * 1024]; b[u] = y[i + u * 1024]; }
+    s0 = fmaf(a[0], b[0], s0); s1 = fmaf(a[1], b[1], s1); s2 = fmaf(a[2], b[2], s2); s3 = fmaf(a[3], b[3], s3);
+    s0 = fmaf(a[4], b[4], s0); s1 = fmaf(a[5], b[5], s1); s2 = fmaf(a[6], b[6], s2); s3 = fmaf(a[7], b[7], s3);
+  }
   for (; i + 3 * 1024 < n; i += 4 * 1024) {
     const float a0 = x[i], a1 = x[i + 1024], a2 = x[i + 2048], a3 = x[i + 3072];
     const float b0 = y[i], b1 = y[i + 1024], b2 = y[i + 2048], b3 = y[i + 3072];

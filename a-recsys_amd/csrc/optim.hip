@@ -850,6 +850,41 @@ __global__ void k_adagrad_dense(float* __restrict__ w, float* __restrict__ acc,
   }
 }
 
+// Up to 8 dense parameters in one launch (the LSTM weights / biases / input projections of a step:
+// 2-6 tensors of 256 B - 128 KB, each a launch of its own otherwise).  Blocks [blk_end[t-1], blk_end[t])
+// own tensor t.
+struct DenseSet {
+  float* w[8];
+  float* acc[8];
+  const float* g[8];
+  int64_t n[8];
+  int blk_end[8];
+  int count;
+};
+__global__ __launch_bounds__(256) void k_adagrad_dense_multi(DenseSet ds, const float* __restrict__ lr_dev,
+                                                             const float* __restrict__ gscale_dev) {
+  int t = 0;
+  while ((int)blockIdx.x >= ds.blk_end[t]) ++t;
+  const int b0 = t ? ds.blk_end[t - 1] : 0;
+  float* __restrict__ w = ds.w[t];
+  float* __restrict__ acc = ds.acc[t];
+  const float* __restrict__ g = ds.g[t];
+  const int64_t n = ds.n[t];
+  const int64_t stride = (int64_t)(ds.blk_end[t] - b0) * blockDim.x;
+  const float lr = *lr_dev;
+  const float gs = gscale_dev ? *gscale_dev : 1.f;
+  for (int64_t i = ((int)blockIdx.x - b0) * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gg = g[i] * gs;
+    if (acc) {
+      const float a = acc[i] + gg * gg;
+      acc[i] = a;
+      w[i] -= lr * gg / sqrtf(a);
+    } else {
+      w[i] -= lr * gg;
+    }
+  }
+}
+
 // Deterministic squared norm in ONE launch: per-block partials in fixed slots, then the block
 // that arrives last (ticket) adds them up in slot order.  float4 loads, 4 in flight per thread.
 constexpr int kNormBlocks = 512;     // fixed slots of block partials (combined in slot order: deterministic)
@@ -1724,6 +1759,31 @@ int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const flo
   int64_t cap = (int64_t)cu_count() * 8;
   if (gr > cap) gr = cap;
   k_adagrad_dense<<<(int)gr, 256, 0, as_stream(stream)>>>(w, acc, g, n, lr_dev, gscale_dev);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_adagrad_dense_multi(int count, float* const* w, float* const* acc, const float* const* g,
+                            const int64_t* n, const float* lr_dev, const float* gscale_dev, void* stream) {
+  ARX_CHECK_ARG(count >= 1 && count <= 8, "arx_adagrad_dense_multi: 1..8 tensors");
+  ARX_CHECK_ARG(w && acc && g && n && lr_dev, "arx_adagrad_dense_multi: null pointer");
+  DenseSet ds = {};
+  int blocks = 0;
+  const int64_t cap = (int64_t)cu_count() * 8 / count;
+  for (int t = 0; t < count; ++t) {
+    ARX_CHECK_ARG(w[t] && g[t] && n[t] >= 0, "arx_adagrad_dense_multi: bad tensor");
+    ds.w[t] = w[t];
+    ds.acc[t] = acc[t];
+    ds.g[t] = g[t];
+    ds.n[t] = n[t];
+    int64_t nb = ceil_div(n[t] > 0 ? n[t] : 1, 256);
+    if (nb > cap) nb = cap;
+    blocks += (int)nb;
+    ds.blk_end[t] = blocks;
+  }
+  for (int t = count; t < 8; ++t) ds.blk_end[t] = blocks;
+  ds.count = count;
+  k_adagrad_dense_multi<<<blocks, 256, 0, as_stream(stream)>>>(ds, lr_dev, gscale_dev);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

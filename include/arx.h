@@ -570,6 +570,10 @@ int arx_gmax_residual_bwd(const float* resid_dev, const int32_t* idx_dev, const 
  * (seqModel.py:180): coef = max_norm / max(sqrt(sq), max_norm). */
 int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const float* lr_dev,
                       const float* gscale_dev, void* stream);
+/* The same update for up to 8 dense parameters in one launch (the LSTM weights, biases and input
+ * projections of a step: seqModel.py:173-182 applies one op per variable).  acc[t] NULL: gradient descent. */
+int arx_adagrad_dense_multi(int count, float* const* w, float* const* acc, const float* const* g,
+                            const int64_t* n, const float* lr_dev, const float* gscale_dev, void* stream);
 /* *out_accum += sum_i w_i * x_i^2 with w_i = row_scale ? row_scale[i / d] : 1 */
 int arx_sq_norm_accum(const float* x, int64_t n, int d, const float* row_scale,
                       float* out_accum, void* stream);
