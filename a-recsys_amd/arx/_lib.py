@@ -64,6 +64,7 @@ PROTOTYPES = {
     "arx_inv_len_scale": (cint, [i32p, i32p, i64, f32, f32p, vp]),
     "arx_pos_mask_scatter": (cint, [i32p, i64, i32p, i32p, i32p, u8p, i64, cint, vp]),
     "arx_slot_map_set": (cint, [i32p, i32p, i64, cint, vp]),
+    "arx_slot_map_attach_bitmap": (cint, [i32p, i32p]),
     "arx_loss_mw_fwdbwd": (cint, [f32p, i64, f32p, u8p, i64, i64, f32, f32p, i64, i64, f32p, f32p,
                                   i64, f32p, vp]),
     "arx_loss_mce_fwdbwd": (cint, [f32p, i64, f32p, u8p, i64, i64, f32, f32p, i64, i64, f32p, f32p,

@@ -147,6 +147,9 @@ class HipBackend(object):
     def slot_map_set(self, m, ids, clear):
         self.ops.slot_map_set(m, ids, clear=clear)
 
+    def attach_pool_bitmap(self, m, bits):
+        self.ops.slot_map_attach_bitmap(m, bits)
+
     def copy_i32(self, src, dst):
         dst.copy_(src, non_blocking=True)
 
@@ -209,6 +212,9 @@ class ShardedHMF(object):
         self.pool_rows = zi(Sg)                             # local rows of the owned block
         self.pool_old = None
         self.item2slot = torch.full((n_items + 1,), -1, dtype=i32, device=dev)
+        if hasattr(self.be, 'attach_pool_bitmap'):          # (1 bit per item in front of the map: HIP backend)
+            self._pool_bits = torch.zeros((n_items + 1 + 32) // 32, dtype=i32, device=dev)
+            self.be.attach_pool_bitmap(self.item2slot, self._pool_bits)
         self.I_pack, self.b_g = z(Sg, dp), z(Sg)            # owned pool rows | bias in column d
         self.I_all, self.b_all = z(S, dp), z(S)             # gathered pool
         self.logits = z(B_loc, S)

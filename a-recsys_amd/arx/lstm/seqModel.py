@@ -337,6 +337,11 @@ class SeqModel(SeqBatching):
         rt.clip_coef_dev = torch.ones(1, dtype=torch.float32, device=rt.device)
         self._sq = torch.zeros(1, dtype=torch.float32, device=rt.device)
         self._gnorm = torch.zeros(1, dtype=torch.float32, device=rt.device)
+        # the "in the pool?" bitmap in front of item2slot pays when every row probes ITS OWN user's
+        # positives (HMF); here the L steps of a sequence share one user, the map lines are L2-hot after
+        # the first step and the extra dependent load only costs (C4: 690 vs 681 us/step) -- detached
+        if getattr(self.att_emb, 'item2slot', None) is not None:
+            ops.slot_map_attach_bitmap(self.att_emb.item2slot, None)
         rt.pre_apply_hooks.append(self._clip_hook)
 
         self.use_concat = bool(use_concat)

@@ -284,6 +284,26 @@ def pos_mask_scatter(user_ids, pos_ptr, pos_items, item2slot, mask, value):
          _p(item2slot), _p(mask), _ld(mask), int(value), _stream())
 
 
+def _slot_map_detach(ptr, _bits_keepalive):
+    import ctypes as C
+    try:
+        _lib.lib.arx_slot_map_attach_bitmap(C.c_void_p(ptr), None)
+    except Exception:
+        pass
+
+
+def slot_map_attach_bitmap(item2slot, bits):
+    """Register the "in the pool?" bitmap (int32 zeros [(items + 32) // 32]) of an item2slot map.
+    The registration is keyed by the map's device address: it is dropped when the map TENSOR is
+    collected (weakref finaliser, which also keeps `bits` alive until then), so a stale entry can
+    never meet a new allocation at the same address.  Best effort: with 16 maps registered the call
+    is a no-op and the losses probe the map directly."""
+    import weakref
+    call("arx_slot_map_attach_bitmap", _p(item2slot), _p(bits))       # (bits None: detach)
+    if bits is not None:
+        weakref.finalize(item2slot, _slot_map_detach, item2slot.data_ptr(), bits)
+
+
 def slot_map_set(item2slot, ids, clear=False):
     call("arx_slot_map_set", _p(item2slot), _p(ids), int(ids.shape[0]), int(bool(clear)), _stream())
 

@@ -9,6 +9,8 @@
 // L2, and dlogits may overwrite logits in place.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace arx {
@@ -51,7 +53,17 @@ struct PosMask {
   const int32_t* pos_ptr;    // CSR over users
   const int32_t* pos_items;
   const int32_t* item2slot;  // item -> column (or -1)
+  // 1 bit per item: "is in the pool?" (arx_slot_map_attach_bitmap; nullable).  A user's positives are
+  // random items of the catalogue and almost none of them is among the S sampled negatives: the probe
+  // of the 4-byte item2slot cell (a 64-byte line per positive, from a table of 4 B x items) is
+  // answered by a bit of a table 32x smaller that stays in L2 (125 KB at 1 M items).
+  const uint32_t* bits;
 };
+
+__device__ __forceinline__ int pos_slot(const PosMask& pm, int item) {
+  if (pm.bits && !((pm.bits[item >> 5] >> (item & 31)) & 1u)) return -1;
+  return pm.item2slot[item];
+}
 
 // Optional fusion of the target score into the margin-loss kernel (embed_attribute.py:208-220 +
 // :604-649): the wave that owns row r also forms t_r = U_r . T_r + tb_r and, once dt_r is known,
@@ -81,7 +93,7 @@ __device__ __forceinline__ void build_pos_bits(uint32_t* bits, int64_t W, const 
   const int u = pm.user_ids[mrow];
   const int beg = pm.pos_ptr[u], end = pm.pos_ptr[u + 1];
   for (int p = beg + threadIdx.x; p < end; p += 256) {
-    const int j = pm.item2slot[pm.pos_items[p]];
+    const int j = pos_slot(pm, pm.pos_items[p]);
     if (j >= 0 && j < W) atomicOr(&bits[j >> 5], 1u << (j & 31));
   }
   __syncthreads();
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
     const int u = pm.user_ids[mrow];
     const int beg = pm.pos_ptr[u], end = pm.pos_ptr[u + 1];
     for (int p = beg + lane; p < end; p += 64) {
-      const int j = pm.item2slot[pm.pos_items[p]];
+      const int j = pos_slot(pm, pm.pos_items[p]);
       if (j >= 0 && j < W) atomicOr(&bits[j >> 5], 1u << (j & 31));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(256) void k_mw_tscore(const float* __restrict__ U, 
     const int p = p0 + lane;
     int j = -1;
     if (p < end) {
-      j = pm.item2slot[pm.pos_items[p]];
+      j = pos_slot(pm, pm.pos_items[p]);
       if (j < 0 || j >= S) j = -1;
     }
     const unsigned long long hm = __ballot(j >= 0);
@@ -468,7 +480,7 @@ __global__ __launch_bounds__(256) void k_mw_rows(MwRows a, PosMask pm, int64_t m
         const int p = p0 + lane;
         int j = -1;
         if (p < end) {
-          j = pm.item2slot[pm.pos_items[p]];
+          j = pos_slot(pm, pm.pos_items[p]);
           if (j < 0 || j >= S) j = -1;
         }
         unsigned long long hm = __ballot(j >= 0);
@@ -561,13 +573,13 @@ __global__ __launch_bounds__(256) void k_eval_unmask(const float* __restrict__ U
     const int p = p0 + lane;
     int j = -1;
     if (p < end) {
-      j = pm.item2slot[pm.pos_items[p]];
+      j = pos_slot(pm, pm.pos_items[p]);
       if (j < 0 || j >= V) j = -1;
     }
     // a column named twice (here or in an earlier batch of 64) counts once: the mask is a set
     if (j >= 0) {
       for (int q = beg; q < p; ++q) {
-        if (pm.item2slot[pm.pos_items[q]] == j) { j = -1; break; }
+        if (pos_slot(pm, pm.pos_items[q]) == j) { j = -1; break; }
       }
     }
     unsigned long long hm = __ballot(j >= 0);
@@ -776,11 +788,34 @@ __global__ __launch_bounds__(256) void k_pos_mask_scatter(
 }
 
 __global__ void k_slot_map_set(int32_t* __restrict__ map, const int32_t* __restrict__ ids,
-                               int64_t S, int clear) {
+                               int64_t S, int clear, uint32_t* __restrict__ bits) {
   const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (s >= S) return;
-  if (clear) map[ids[s]] = -1;
-  else atomicMax(&map[ids[s]], (int32_t)s);  // duplicate ids: last slot wins (dict semantics)
+  const int id = ids[s];
+  if (clear) map[id] = -1;
+  else atomicMax(&map[id], (int32_t)s);  // duplicate ids: last slot wins (dict semantics)
+  if (bits) {                              // the attached "in the pool?" bitmap follows the map
+    if (clear) atomicAnd(&bits[id >> 5], ~(1u << (id & 31)));
+    else atomicOr(&bits[id >> 5], 1u << (id & 31));
+  }
+}
+
+// item2slot map -> its attached bitmap (arx_slot_map_attach_bitmap); host side, a handful of entries
+struct SlotBits { const void* map; uint32_t* bits; };
+static SlotBits g_slot_bits[16];
+static int g_slot_bits_n = 0;
+static std::mutex g_slot_bits_mu;
+
+static uint32_t* slot_bits_of(const void* map) {
+  std::lock_guard<std::mutex> lk(g_slot_bits_mu);
+  for (int i = 0; i < g_slot_bits_n; ++i)
+    if (g_slot_bits[i].map == map) return g_slot_bits[i].bits;
+  return nullptr;
+}
+
+static PosMask make_pm(const int32_t* user_ids, const int32_t* pos_ptr, const int32_t* pos_items,
+                       const int32_t* item2slot) {
+  return PosMask{user_ids, pos_ptr, pos_items, item2slot, slot_bits_of(item2slot)};
 }
 
 }  // namespace arx
@@ -809,8 +844,24 @@ int arx_slot_map_set(int32_t* item2slot, const int32_t* ids, int64_t S, int clea
                      void* stream) {
   ARX_CHECK_ARG(item2slot && ids, "arx_slot_map_set: null pointer");
   if (S <= 0) return ARX_OK;
-  k_slot_map_set<<<(int)ceil_div(S, 256), 256, 0, as_stream(stream)>>>(item2slot, ids, S, clear);
+  k_slot_map_set<<<(int)ceil_div(S, 256), 256, 0, as_stream(stream)>>>(item2slot, ids, S, clear,
+                                                                       slot_bits_of(item2slot));
   ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_slot_map_attach_bitmap(const int32_t* item2slot, uint32_t* bits) {
+  ARX_CHECK_ARG(item2slot, "arx_slot_map_attach_bitmap: null pointer");
+  std::lock_guard<std::mutex> lk(g_slot_bits_mu);
+  for (int i = 0; i < g_slot_bits_n; ++i)
+    if (g_slot_bits[i].map == item2slot) {
+      if (bits) { g_slot_bits[i].bits = bits; return ARX_OK; }
+      g_slot_bits[i] = g_slot_bits[--g_slot_bits_n];                 // detach
+      return ARX_OK;
+    }
+  if (!bits) return ARX_OK;
+  if (g_slot_bits_n >= 16) return ARX_OK;       // best effort: this map is probed directly
+  g_slot_bits[g_slot_bits_n++] = SlotBits{item2slot, bits};
   return ARX_OK;
 }
 
@@ -899,7 +950,7 @@ int arx_loss_mw_fwdbwd_pos(const float* logits, int64_t ldl, const float* tscore
   if (launch_margin_wave<false, true>(logits, ldl, tscore, nullptr, nullptr, 0,
                                       mask_rows > 0 ? mask_rows : B, gscale, row_w, B, S,
                                       batch_loss, dlogits, lddl, dtscore,
-                                      PosMask{user_ids, pos_ptr, pos_items, item2slot},
+                                      make_pm(user_ids, pos_ptr, pos_items, item2slot),
                                       as_stream(stream))) {
     ARX_CHECK_LAUNCH();
     return ARX_OK;
@@ -907,7 +958,7 @@ int arx_loss_mw_fwdbwd_pos(const float* logits, int64_t ldl, const float* tscore
   const size_t lds = (size_t)((S + 31) / 32) * 4;
   k_loss_margin<false, true><<<(int)B, 256, lds, as_stream(stream)>>>(
       logits, ldl, tscore, nullptr, nullptr, 0, mask_rows > 0 ? mask_rows : B, gscale, row_w, S,
-      batch_loss, dlogits, lddl, dtscore, PosMask{user_ids, pos_ptr, pos_items, item2slot});
+      batch_loss, dlogits, lddl, dtscore, make_pm(user_ids, pos_ptr, pos_items, item2slot));
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
@@ -929,7 +980,7 @@ int arx_loss_mce_fwdbwd_pos(const float* logits, int64_t ldl, const float* tscor
   if (launch_margin_wave<false, true, true>(logits, ldl, tscore, nullptr, nullptr, 0,
                                       mask_rows > 0 ? mask_rows : B, gscale, row_w, B, S,
                                       batch_loss, dlogits, lddl, dtscore,
-                                      PosMask{user_ids, pos_ptr, pos_items, item2slot},
+                                      make_pm(user_ids, pos_ptr, pos_items, item2slot),
                                       as_stream(stream))) {
     ARX_CHECK_LAUNCH();
     return ARX_OK;
@@ -937,7 +988,7 @@ int arx_loss_mce_fwdbwd_pos(const float* logits, int64_t ldl, const float* tscor
   const size_t lds = (size_t)((S + 31) / 32) * 4;
   k_loss_margin<false, true, true><<<(int)B, 256, lds, as_stream(stream)>>>(
       logits, ldl, tscore, nullptr, nullptr, 0, mask_rows > 0 ? mask_rows : B, gscale, row_w, S,
-      batch_loss, dlogits, lddl, dtscore, PosMask{user_ids, pos_ptr, pos_items, item2slot});
+      batch_loss, dlogits, lddl, dtscore, make_pm(user_ids, pos_ptr, pos_items, item2slot));
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
@@ -1018,7 +1069,7 @@ int arx_mw_gemm_fused_fwd(const float* U, int64_t ldu, const float* P, int64_t l
   int32_t* hits = reinterpret_cast<int32_t*>(cnt_part + splits * B);
   int32_t* nhit = hits + (size_t)B * kMwHits;
   const int grid = (int)ceil_div(B, 4);
-  const PosMask pm{user_ids, pos_ptr, pos_items, item2slot};
+  const PosMask pm = make_pm(user_ids, pos_ptr, pos_items, item2slot);
   const int64_t mrows = mask_rows > 0 ? mask_rows : B;
   k_mw_tscore<<<grid, 256, 0, s>>>(U, ldu, T, ldt, tbias, tb_stride > 0 ? tb_stride : 1, d, B, t, pm, mrows, S,
                                    hits, nhit);
@@ -1060,7 +1111,7 @@ int arx_loss_mw_fused_pos(const float* logits, int64_t ldl, const float* U, int6
   if (!launch_margin_wave<false, true>(logits, ldl, nullptr, nullptr, nullptr, 0,
                                        mask_rows > 0 ? mask_rows : B, gscale, row_w, B, S, batch_loss,
                                        dlogits, lddl, dtscore,
-                                       PosMask{user_ids, pos_ptr, pos_items, item2slot},
+                                       make_pm(user_ids, pos_ptr, pos_items, item2slot),
                                        as_stream(stream), df)) {
     set_error("arx_loss_mw_fused_pos: logits / dlogits layout not supported by the wave kernel");
     return ARX_EUNSUPPORTED;
@@ -1094,7 +1145,7 @@ int arx_loss_mce_fused_pos(const float* logits, int64_t ldl, const float* U, int
   if (!launch_margin_wave<false, true, true>(logits, ldl, nullptr, nullptr, nullptr, 0,
                                        mask_rows > 0 ? mask_rows : B, gscale, row_w, B, S, batch_loss,
                                        dlogits, lddl, dtscore,
-                                       PosMask{user_ids, pos_ptr, pos_items, item2slot},
+                                       make_pm(user_ids, pos_ptr, pos_items, item2slot),
                                        as_stream(stream), df)) {
     set_error("arx_loss_mce_fused_pos: logits / dlogits layout not supported by the wave kernel");
     return ARX_EUNSUPPORTED;
@@ -1120,7 +1171,7 @@ int arx_loss_warp_fwdbwd_pos(const float* logits, int64_t ldl, const int32_t* ta
   if (launch_margin_wave<true, true>(logits, ldl, nullptr, target, nullptr, 0,
                                      mask_rows > 0 ? mask_rows : B, gscale, row_w, B, V,
                                      batch_loss, dlogits, lddl, nullptr,
-                                     PosMask{user_ids, pos_ptr, pos_items, item2slot},
+                                     make_pm(user_ids, pos_ptr, pos_items, item2slot),
                                      as_stream(stream))) {
     ARX_CHECK_LAUNCH();
     return ARX_OK;
@@ -1132,7 +1183,7 @@ int arx_loss_warp_fwdbwd_pos(const float* logits, int64_t ldl, const int32_t* ta
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   kern<<<(int)B, 256, lds, as_stream(stream)>>>(
       logits, ldl, nullptr, target, nullptr, 0, mask_rows > 0 ? mask_rows : B, gscale, row_w, V,
-      batch_loss, dlogits, lddl, nullptr, PosMask{user_ids, pos_ptr, pos_items, item2slot});
+      batch_loss, dlogits, lddl, nullptr, make_pm(user_ids, pos_ptr, pos_items, item2slot));
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
@@ -1162,7 +1213,7 @@ int arx_loss_rs_fwdbwd(const float* logits, int64_t ldl, const int32_t* target, 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<(int)B, 256, lds, as_stream(stream)>>>(logits, ldl, target, nullptr, 0, mr, kind, loss_func,
                                                   exp_p, gscale, row_w, V, batch_loss, dlogits, lddl,
-                                                  PosMask{user_ids, pos_ptr, pos_items, item2slot});
+                                                  make_pm(user_ids, pos_ptr, pos_items, item2slot));
   } else {
     k_loss_rs<false><<<(int)B, 256, 0, as_stream(stream)>>>(logits, ldl, target, mask, ldm, mr, kind,
                                                             loss_func, exp_p, gscale, row_w, V,

@@ -202,6 +202,14 @@ int arx_pos_mask_scatter(const int32_t* user_ids, int64_t B, const int32_t* pos_
 /* item -> pool-slot map maintenance for the sampled pool (the device twin of
  * utils/prepare_train.py:12-16 item_sampled_id2idx): map[ids[s]] = s (or -1). */
 int arx_slot_map_set(int32_t* item2slot, const int32_t* ids, int64_t S, int clear, void* stream);
+/* Optional 1-bit-per-item "is in the pool?" table in front of an item2slot map: bits = caller-owned
+ * uint32[(items + 32) / 32], zero-initialised, registered for THIS map pointer (bits NULL: detach --
+ * REQUIRED before the map's memory is released; with 16 maps registered the call is a no-op and the
+ * map is probed directly).  arx_slot_map_set keeps it in step with the map; every `*_pos` loss entry that is
+ * given the map then answers "not in the pool" -- the case for almost every positive of a user --
+ * from the bit (a table 32x smaller, L2-resident) instead of a random 4-byte read of the map
+ * (embed_attribute.py:729-745: the per-user loop over positives, `if i in item_sampled_id2idx`). */
+int arx_slot_map_attach_bitmap(const int32_t* item2slot, uint32_t* bits);
 
 /* ---- a10-a12: batch losses, forward + backward fused ---------------------
  * d(total)/d(batch_loss[r]) = gscale * (row_w ? row_w[r] : 1).

@@ -1174,6 +1174,49 @@ def test_lookup_multi(dev, d, sizes):
                 assert torch.equal(bouts[k], rb[k]), k
 
 
+def test_pool_bitmap_in_front_of_slot_map(dev):
+    """arx_slot_map_attach_bitmap: the 1-bit "in the pool?" table follows arx_slot_map_set (set, clear,
+    redraw with overlap, duplicates) and the `_pos` losses give bit-identical results with it."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(11)
+    V, S, B, NU, NP = 5000, 256, 96, 300, 30
+    maps = [torch.full((V + 1,), -1, dtype=torch.int32, device=dev) for _ in range(2)]
+    bits = torch.zeros((V + 1 + 32) // 32, dtype=torch.int32, device=dev)
+    ops.slot_map_attach_bitmap(maps[0], bits)                       # maps[1]: probed directly
+    logits = _t(dev, rng.standard_normal((B, S)).astype(np.float32))
+    ts = _t(dev, rng.standard_normal((B,)).astype(np.float32))
+    users = _t(dev, rng.integers(0, NU, size=B).astype(np.int32))
+    ptr = _t(dev, (np.arange(NU + 1) * NP).astype(np.int32))
+    old = None
+    for rnd in range(3):
+        pool = rng.choice(V, size=S, replace=False).astype(np.int32)
+        if old is not None:
+            pool[:S // 2] = old[:S // 2]                            # half of the previous pool stays
+        pool[3] = pool[7]                                           # a duplicate id: the later slot wins
+        items = rng.integers(0, V, size=NU * NP).astype(np.int32)
+        items[::7] = pool[rng.integers(0, S, size=len(items[::7]))]      # some positives ARE in the pool
+        t_items, t_pool = _t(dev, items), _t(dev, pool)
+        outs = []
+        for m in maps:
+            if old is not None:
+                ops.slot_map_set(m, _t(dev, old), clear=True)
+            ops.slot_map_set(m, t_pool, clear=False)
+            bl = torch.empty(B, device=dev); dl = torch.empty(B, S, device=dev); dt = torch.empty(B, device=dev)
+            ops.loss_mw_pos(logits, ts, users, ptr, t_items, m, bl, dl, dt, 1.0 / B)
+            outs.append((bl, dl, dt))
+        torch.cuda.synchronize()
+        assert torch.equal(maps[0], maps[1])
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)
+        want = np.zeros(len(bits) * 32, dtype=bool)
+        want[:V + 1] = maps[0].cpu().numpy() >= 0
+        got = np.unpackbits(bits.cpu().numpy().view(np.uint8), bitorder='little').astype(bool)
+        assert np.array_equal(got, want), rnd
+        assert float(outs[0][1].abs().sum().item()) > 0
+        old = pool
+
+
 def _unpack_bits(words, n):
     w = words.astype(np.uint32)
     return ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(w.shape[0], -1)[:, :n].astype(bool)
