@@ -36,6 +36,29 @@ static const int kTokenWpw = getenv("ARX_TOKEN_WPW") ? atoi(getenv("ARX_TOKEN_WP
 static const int kRankSortEntities = getenv("ARX_RANK_ENT_MAX") ? atoi(getenv("ARX_RANK_ENT_MAX")) : kRankSortMax;
 constexpr int kPassBBlocks = 128;   // persistent grid of pass B
 
+// Table rows are touched ONCE per pass (one Adagrad update per row): streamed past L2 so that they
+// do not evict the gradient rows the token stage re-reads (ARX_WIN_NT=0: plain loads / stores).
+#ifndef ARX_WIN_NT
+#define ARX_WIN_NT 1
+#endif
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 row_load(const float* p) {
+#if ARX_WIN_NT
+  const v4f_nt q = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt*>(p));
+  return make_float4(q.x, q.y, q.z, q.w);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void row_store(float* p, float4 v) {
+#if ARX_WIN_NT
+  v4f_nt q = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(q, reinterpret_cast<v4f_nt*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 __device__ __forceinline__ float4 f4_fma(float c, float4 v, float4 a) {
   return make_float4(fmaf(c, v.x, a.x), fmaf(c, v.y, a.y), fmaf(c, v.z, a.z), fmaf(c, v.w, a.w));
 }
@@ -482,8 +505,8 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
         if (colok) {
           g0[j] = *reinterpret_cast<const float4*>(G + (int64_t)s_src[wv][i] * ldg + col);
           if (!MERGE && lcomp[j] && T.E) {      // (T.E null: a virtual table -- entity ids of a riding bag table)
-            wrow[j] = *reinterpret_cast<const float4*>(T.E + (int64_t)T.row * d + col);
-            if (!SGD) arow[j] = *reinterpret_cast<const float4*>(T.acc + (int64_t)T.row * d + col);
+            wrow[j] = row_load(T.E + (int64_t)T.row * d + col);
+            if (!SGD) arow[j] = row_load(T.acc + (int64_t)T.row * d + col);
           }
         }
         if (Gb && lig < lrows[j]) gbv[j] = Gb[s_src[wv][i + lig]];
@@ -540,11 +563,11 @@ __global__ __launch_bounds__((WPW > 4 ? WPW : 4) * 64) void k_sparse_win(
             w4.y -= adagrad_delta(lr, gg.y, a4.y);
             w4.z -= adagrad_delta(lr, gg.z, a4.z);
             w4.w -= adagrad_delta(lr, gg.w, a4.w);
-            *reinterpret_cast<float4*>(T.acc + (int64_t)rrow * d + col) = a4;
+            row_store(T.acc + (int64_t)rrow * d + col, a4);
           } else {                                   // gradient descent
             w4.x -= lr * gg.x; w4.y -= lr * gg.y; w4.z -= lr * gg.z; w4.w -= lr * gg.w;
           }
-          *reinterpret_cast<float4*>(T.E + (int64_t)rrow * d + col) = w4;
+          row_store(T.E + (int64_t)rrow * d + col, w4);
         }
         if (T.bias && lig == 0) {
           const float gg = gb * gs;
