@@ -68,7 +68,7 @@ class DeviceSampler(object):
         self.counter = 0
         # large populations: keys that cannot be among the n smallest are dropped before the sort
         # (arx_sample_wor_capped: cap = 8 n / sum(w)); the draw is the un-capped one
-        self._wsum = float(self.w.clamp(min=0).sum(dtype=torch.float64).item()) if self.w.numel() > (1 << 22) else 0.0
+        self._wsum = float(self.w.clamp(min=0).sum(dtype=torch.float64).item()) if self.w.numel() > (1 << 16) else 0.0
 
     @classmethod
     def from_interactions(cls, item_ids, n_items, power=0.5, device=None, seed=0):
