@@ -1135,7 +1135,9 @@ class Plan(object):
             t_off = 0
             if bag is not None and bag[3]:
                 # virtual table 0: the bag table's entity lookups (key = entity id)
-                tables.append((None, None, None, None, None, int(bag[1][0].maps[2].shape[0])))
+                n_ent = int(bag[1][0].maps[2].shape[0])
+                vmap = torch.zeros(n_ent, dtype=torch.int32, device=rt.device)    # per-entity map of the grouped K7 path
+                tables.append((None, None, None, None, vmap, n_ent))
                 for x in bag[1]:
                     sites.append((0, None, x.ids_node.value, x.node.row0, x.coef))
                 t_off = 1
@@ -1183,7 +1185,7 @@ class Plan(object):
                 ent['keys'], ent['src'], ent['coef'], ent['ws'], bt.E, None if sgd else bt.acc,
                 bt.bias if bag_bias else None, bt.bias_acc if (bag_bias and not sgd) else None,
                 s0.maps[0], starts_r, lens_r, max(x.max_len for x in bag_live), ent['bag_ws'],
-                gscale_dev=rt.clip_coef_dev, phase=phase, bag_aux_cnt=None)
+                gscale_dev=rt.clip_coef_dev, phase=phase, bag_aux_cnt=self._aux_cnt(bt))
             return
         ops.sparse_adagrad_cat_multi(args, node0.arena, node0.arena_b if ent['any_bias'] else None,
                                      rt.lr, ent['keys'], ent['src'], ent['coef'], ent['ws'],

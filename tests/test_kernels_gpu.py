@@ -1009,13 +1009,19 @@ def test_sparse_adagrad_bags(dev, d, n_ent, Vf, max_len, ns, phases):
     (32, 300, 100, 70, 6, (500, 40, 300), (3,)),                      # below the rank-sort limit
     (64, 5000, 7000, 900, 9, (6000, 0, 5000), (1, 2)),                # an empty site; 11 k keys
     (16, 12, 9, 8, 30, (9000, 100, 50), (3,)),                        # few entities: runs of thousands (finish kernel side output)
+    (64, 12, 9, 8, 30, (9000, 100, 50), (1, 2)),                      # the same past d = 32: long runs of several work items (group.hip)
+    (128, 2000, 3000, 50, 40, (30000, 500, 20000), (1, 2)),           # 50 token rows: long token runs, duplicate tokens inside the bags
+    (256, 700, 50, 3000, 70, (9000, 0, 300), (3,)),                   # d = 256, bags longer than a wave
 ])
-@pytest.mark.parametrize("virtual,sgd", [(False, False), (True, False), (False, True), (True, True)])
-def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, phases, virtual, sgd):
+@pytest.mark.parametrize("virtual,sgd,maps", [(False, False, True), (True, False, True), (False, True, True),
+                                              (True, True, True), (False, False, False), (True, False, False)])
+def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, phases, virtual, sgd, maps):
     """arx_sparse_adagrad_cat_multi_bags: the one-hot pass over (item id table, user table) with the
     item's multi-hot table riding on it == the three tables updated separately from the plain
     contribution lists (id rows: coef * G[row]; token rows: coef / len * G[row] per bag token).
-    virtual: no item id table (MIX layout) -- table 0 of the pass is just the entity ids."""
+    virtual: no item id table (MIX layout) -- table 0 of the pass is just the entity ids.
+    maps: every table brings its zeroed per-row map -> past 8192 contributions the pass takes the
+    grouped path (group.hip: no sort, run-centric apply); without them the radix / window path."""
     from arx import ops
     import torch
     rng = np.random.default_rng(d + n_ent + max_len)
@@ -1103,8 +1109,14 @@ def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, p
         if sgd:
             for D in (D_it, D_us, D_bag):
                 D[1] = D[3] = None
-        t0 = (None, None, None, None, None, n_ent) if virtual else (D_it[0], D_it[1], D_it[2], D_it[3], cnts[0])
-        args = ops.MultiCatArgs([t0, (D_us[0], D_us[1], D_us[2], D_us[3], None if virtual else cnts[1])],
+        vcnt = torch.zeros(n_ent, dtype=torch.int32, device=dev)
+        if not maps:
+            cnts_ = [None, None]
+        else:
+            cnts_ = cnts
+        t0 = ((None, None, None, None, vcnt if maps else None, n_ent) if virtual
+              else (D_it[0], D_it[1], D_it[2], D_it[3], cnts_[0]))
+        args = ops.MultiCatArgs([t0, (D_us[0], D_us[1], D_us[2], D_us[3], cnts_[1])],
                                 [(t, tmap if (t == 0 and not virtual) else None, _t(dev, ids), r0, c)
                                  for t, ids, r0, c in sites])
         n = args.total
@@ -1116,9 +1128,10 @@ def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, p
         for ph in phases:
             ops.sparse_adagrad_cat_multi_bags(args, tG, tGb, lr_dev, kb_, sb_, cb_, ws, D_bag[0], D_bag[1],
                                               D_bag[2], D_bag[3], tv, tst, tl, max_len, bws,
-                                              gscale_dev=gs_dev, phase=ph, bag_aux_cnt=bcnt)
+                                              gscale_dev=gs_dev, phase=ph, bag_aux_cnt=bcnt if maps else None)
         torch.cuda.synchronize()
         assert int(bcnt.abs().sum().item()) == 0 and all(int(c.abs().sum().item()) == 0 for c in cnts)
+        assert int(vcnt.abs().sum().item()) == 0
         outs.append(D_it + D_us + D_bag)
     want_it = list(T_it) if virtual else list(R_it)          # virtual: the id table is not part of the pass
     for got, want in zip(outs[0], want_it + list(R_us) + list(R_bag)):
