@@ -67,8 +67,9 @@ class DeviceSampler(object):
         self.seed = int(seed)
         self.counter = 0
         # large populations: keys that cannot be among the n smallest are dropped before the sort
-        # (arx_sample_wor_capped: cap = 8 n / sum(w)); the draw is the un-capped one
-        self._wsum = float(self.w.clamp(min=0).sum(dtype=torch.float64).item()) if self.w.numel() > (1 << 16) else 0.0
+        # (arx_sample_wor_capped); the draw is the un-capped one.  The cap depends on n: _cap_for
+        self._caps = {}
+        self._npos = None
 
     @classmethod
     def from_interactions(cls, item_ids, n_items, power=0.5, device=None, seed=0):
@@ -88,12 +89,50 @@ class DeviceSampler(object):
         s.counts = counts
         return s
 
+    def _cap_for(self, n):
+        """Key threshold t of the capped race for draws of n items: an item survives the cap with
+        probability 1 - exp(-w t), so t is chosen such that the EXPECTED number of survivors,
+        sum_i (1 - exp(-w_i t)), is 8 n (the count is a sum of independent indicators: fewer than n
+        of 8 n expected is out of reach).  `8 n / sum(w)` -- round 2 -- only equals that while
+        w t << 1 for every item: with heavy-tailed weights (w ~ rank^-1.5, 1 M items, n = 1000) it
+        let ~630 keys through, the draw came back short and the missing positions indexed
+        items[-1].  0.0 = no cap (small populations, or too few positive weights for one to pay).
+        Computed once per n (a few reductions over the weights, with host reads: set-up work)."""
+        import torch
+        if n in self._caps:
+            return self._caps[n]
+        N = int(self.w.numel())
+        if self._npos is None:
+            self._npos = int((self.w > 0).sum().item())
+        if self._npos < n:
+            raise ValueError("DeviceSampler.sample(%d): only %d items have a positive weight" % (n, self._npos))
+        cap = 0.0
+        target = 8.0 * n
+        if N > (1 << 16) and 16 * n < N and self._npos >= 2 * target:
+            w = self.w.clamp(min=0)
+
+            def expected(t):
+                return float((-torch.expm1(w * (-t))).sum(dtype=torch.float64).item())
+            hi = target / max(float(w.sum(dtype=torch.float64).item()), 1e-300)
+            while expected(hi) < target:          # (terminates: expected(inf) = npos >= 2 * target)
+                hi *= 2.0
+            lo = 0.0
+            for _ in range(40):
+                mid = 0.5 * (lo + hi)
+                if expected(mid) < target:
+                    lo = mid
+                else:
+                    hi = mid
+            cap = hi
+        self._caps[n] = cap
+        return cap
+
     def sample(self, n, out=None):
         """-> int32 device tensor [n] of item ids (draw order).  The id->slot map the reference
         builds next (prepare_train.py:12-16) is the model's device slot map (update_sampled_pool)."""
         import torch
         pos = torch.empty((n,), dtype=torch.int32, device=self.w.device)
-        cap = 8.0 * n / self._wsum if self._wsum > 0 and 16 * n < self.w.numel() else 0.0
+        cap = self._cap_for(int(n))
         self._ops.sample_wor(self.w, n, self.seed, self.counter, pos, self.ws, key_cap=cap)
         self.counter += 1
         ids = self.items[pos.long()]

@@ -151,7 +151,7 @@ int topk_select_launch(const float* logits, int64_t ld, int64_t B, int64_t V, in
 // radix_sort.hip: graph-safe stable LSD sort of (key, src, coef) triples, n > 8192.
 // keys_raw: caller keys (ARX_KEY_NONE / out-of-range -> sentinel); src_raw/coef_raw may be
 // null (identity / 1.0).  *_tmp: ping-pong buffers of n entries; hist: radix_sort_hist_bytes().
-// list_count (optional): two ints zeroed by the first launch.
+// list_count (optional): 512 ints (2 KB) zeroed by the first launch.
 // n_live (optional, device int32): the first pass drops sentinel entries (pads, invalid keys)
 // and writes the number of survivors here; later passes -- and the caller's apply kernels --
 // work on that many entries (the grids stay sized for n).
@@ -159,6 +159,7 @@ size_t radix_sort_hist_bytes();
 int launch_radix_sort(const int32_t* keys_raw, const int32_t* src_raw, const float* coef_raw, int64_t n,
                       uint32_t sentinel, int total_bits, uint32_t* keys_tmp, uint32_t* keys_out,
                       int32_t* src_tmp, int32_t* src_out, float* coef_tmp, float* coef_out,
-                      int32_t* hist, int32_t* list_count, int32_t* n_live, hipStream_t s);
+                      int32_t* hist, int32_t* list_count, int32_t* n_live, hipStream_t s,
+                      const int32_t* n_in_dev = nullptr /* first pass: device-side number of input entries */);
 
 }  // namespace arx

@@ -1,5 +1,5 @@
-// k7.h -- device helpers shared by the sparse-Adagrad kernels (optim.hip: sorted / window path,
-// group.hip: direct-address grouping + run-centric apply).  gfx950 only.
+// k7.h -- device helpers shared by the sparse-Adagrad kernels (optim.hip: sorts, window apply;
+// group.hip: run records + run-centric apply).  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -124,15 +124,34 @@ __device__ __forceinline__ void merge_row(const MergeOut& mo, int d, uint32_t ke
   if (mo.Gub && lig == 0) mo.Gub[head_pos] = gb * inv;
 }
 
-// group.hip: direct-address grouping + run-centric apply (n > 8192, one-hot sites only, d >= 32,
-// a zeroed per-row int32 map for every table of the pass and for the riding bag table).
-bool grouped_supported(const TableSet& ts, int ntables, int d, const CatSites& st, const BagStage* bag);
-size_t grouped_ws_bytes(int64_t n, int d);
-size_t grouped_bag_ws_bytes(int64_t n0, int max_len, int64_t bag_rows, int d);
-int sparse_adagrad_sites_grouped(const TableSet& ts, int ntables, int d, const CatSites& st, const float* G,
-                                 int64_t ldg, int64_t g_rows, const float* Gb, const float* lr_dev,
-                                 const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf, float* coef_buf,
-                                 void* workspace, size_t workspace_bytes, hipStream_t s, int phase,
-                                 const BagStage* bag);
+// group.hip: run records of a radix-sorted pass + the run-centric apply (d >= 32).
+enum { kNRuns = 0, kNLong = 2, kNItems = 3, kNPart = 4 };      // counters of a pass (ints, zeroed by the sort)
+struct RunLists {
+  int4* R;              // run records {key, offset, count, head position}
+  int2* R2;             // first entry of every run {src, coef bits}
+  int4* LR;             // long runs {run, first partial row, items, ticket}
+  int2* items;          // work items {long run, item}
+  const int32_t* ssrc;  // the pass's sorted gradient-source rows / coefficients
+  const float* scoef;
+  int32_t* ctr;
+  float* part;          // partial rows of the long runs with several items
+  float* part_b;
+  int64_t cap_long, cap_items, cap_part;
+};
+size_t run_lists_bytes(int64_t n, int d);
+RunLists run_lists_of(char* base, int64_t n, int d, const int32_t* ssrc, const float* scoef, int32_t* ctr);
+bool runs_path(int d);
+// ent_lens (optional): also the ordered exclusive offsets hoff[p] of the bags of the entity heads
+// ((key >> ent_kb) == ent_tag) in a compact token list, and its length; lookback: 8 bytes per
+// workgroup (runs_extract_blocks(n)), zero on entry.
+int launch_runs_extract(const uint32_t* sk, int64_t n, const int32_t* n_dev, uint32_t sentinel, const RunLists& rl,
+                        int d, hipStream_t s, const int32_t* ent_lens = nullptr, int ent_kb = 0,
+                        uint32_t ent_tag = 0, int max_len = 0, int32_t* hoff = nullptr, int64_t hoff_n = 0,
+                        int32_t* total = nullptr,
+                        void* lookback = nullptr);
+int runs_extract_blocks(int64_t n);
+int launch_run_apply(const TableSet& ts, bool multi, int d, const RunLists& rl, int64_t n, const float* G,
+                     int64_t ldg, const float* Gb, const float* lr_dev, const float* gscale_dev, const MergeOut& mo,
+                     bool sgd, hipStream_t s);
 
 }  // namespace arx

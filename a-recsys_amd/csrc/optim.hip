@@ -1071,9 +1071,93 @@ __global__ __launch_bounds__(256) void k_bag_expand_heads(
   }
 }
 
+// Compacted bag expansion (round 3): the padded slot layout above made the token sort's first pass read
+// lookups x max_len slots at ~13 % live (1.1 M at C3).  k_head_len_scan: exclusive scan of the bag
+// lengths of the DISTINCT entities over the sorted entity list (one workgroup, thread = contiguous
+// chunk; positions follow the sorted order, so the token list -- and with it the summation order of
+// every token run -- stays deterministic); k_bag_expand_compact writes the tokens densely.
+__global__ __launch_bounds__(1024) void k_head_len_scan(
+    const uint32_t* __restrict__ sk, int64_t n_host, const int32_t* __restrict__ n_dev, uint32_t sentinel,
+    int ent_kb, uint32_t ent_tag, const int32_t* __restrict__ lens, int max_len, int32_t* __restrict__ hoff,
+    int32_t* __restrict__ total) {
+  __shared__ int wsum[16];
+  constexpr int BT = 32;                                 // positions per batch: their loads fly together
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t n = n_dev ? min((int64_t)*n_dev, n_host) : n_host;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t p0 = tid * per, p1 = min(n, p0 + per);
+  // pass 1: bag length of every run head of the entity table (0 elsewhere) -> hoff, chunk sum
+  int local = 0;
+  for (int64_t c0 = p0; c0 < p1; c0 += BT) {
+    uint32_t k[BT + 1];
+    k[0] = c0 > 0 ? sk[c0 - 1] : 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < BT; ++u) k[u + 1] = c0 + u < p1 ? sk[c0 + u] : 0xffffffffu;
+    int l[BT];
+#pragma unroll
+    for (int u = 0; u < BT; ++u) {
+      const uint32_t ke = k[u + 1];
+      const bool h = c0 + u < p1 && ke < sentinel && (ke >> ent_kb) == ent_tag && (c0 + u == 0 || k[u] != ke);
+      l[u] = h ? lens[ke & ((1u << ent_kb) - 1u)] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < BT; ++u)
+      if (c0 + u < p1) {
+        const int v = min(l[u], max_len);
+        hoff[c0 + u] = v;
+        local += v;
+      }
+  }
+  int incl = local;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  int run = incl - local;
+  for (int q = 0; q < wv; ++q) run += wsum[q];
+  if (tid == 1023) *total = run + local;
+  // pass 2: lengths -> exclusive offsets (the thread re-reads its own stores)
+  for (int64_t c0 = p0; c0 < p1; c0 += BT) {
+    int l[BT];
+#pragma unroll
+    for (int u = 0; u < BT; ++u) l[u] = c0 + u < p1 ? hoff[c0 + u] : 0;
+#pragma unroll
+    for (int u = 0; u < BT; ++u)
+      if (c0 + u < p1) {
+        hoff[c0 + u] = run;
+        run += l[u];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bag_expand_compact(
+    const uint32_t* __restrict__ sk, int64_t n_host, const int32_t* __restrict__ n_dev, uint32_t sentinel,
+    int ent_kb, uint32_t ent_tag, const int32_t* __restrict__ vals, const int32_t* __restrict__ starts,
+    const int32_t* __restrict__ lens, int max_len, int64_t table_rows, const int32_t* __restrict__ hoff,
+    int32_t* __restrict__ tkeys, int32_t* __restrict__ tsrc) {
+  const int64_t n = n_dev ? min((int64_t)*n_dev, n_host) : n_host;
+  const int64_t total = n * (int64_t)max_len;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = q / max_len;
+    const int j = (int)(q - p * max_len);
+    const uint32_t ke = sk[p];
+    const uint32_t e = ke & ((1u << ent_kb) - 1u);
+    if (ke < sentinel && (ke >> ent_kb) == ent_tag && (p == 0 || sk[p - 1] != ke) && j < lens[e]) {
+      const int32_t t = vals[(int64_t)starts[e] + j];
+      const int64_t slot = (int64_t)hoff[p] + j;
+      tkeys[slot] = (t < 0 || t >= table_rows) ? ARX_KEY_NONE : t;
+      tsrc[slot] = (int32_t)p;
+    }
+  }
+}
+
 struct SparseWs {
   size_t off_keys_tmp, off_keys_out, off_pos_in, off_pos_out, off_list, off_count, off_scratch,
-      off_scratch_b, off_scratch_h, off_scratch_hb, off_ssrc, off_scoef, off_hist, total;
+      off_scratch_b, off_scratch_h, off_scratch_hb, off_ssrc, off_scoef, off_hist, off_runs, total;
 };
 
 static int sparse_ws_layout(int64_t n, int d, SparseWs* w) {
@@ -1085,14 +1169,15 @@ static int sparse_ws_layout(int64_t n, int d, SparseWs* w) {
   w->off_pos_in = o; o += ni;
   w->off_pos_out = o; o += ni;
   w->off_list = o; o += align_up(pieces * 4 * 3, 256);   // long list + (position, pieces) pairs of the short list
-  w->off_count = o; o += 256;
+  w->off_count = o; o += 2048;
   w->off_scratch = o; o += align_up(pieces * (size_t)d * 4, 256);
   w->off_scratch_b = o; o += align_up(pieces * 4, 256);
   w->off_scratch_h = o; o += align_up(pieces * (size_t)d * 4, 256);
   w->off_scratch_hb = o; o += align_up(pieces * 4, 256);
   w->off_ssrc = o; o += ni;
   w->off_scoef = o; o += ni;
-  w->off_hist = o; o += radix_sort_hist_bytes();
+  w->off_hist = o; o += align_up(radix_sort_hist_bytes(), 256);
+  w->off_runs = o; o += run_lists_bytes(n > 0 ? n : 1, d);      // run records of the run-centric apply (group.hip)
   w->total = o;
   return ARX_OK;
 }
@@ -1121,11 +1206,24 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
                         const float* gb_in, const float* lr_dev, const float* gscale_dev,
                         float* scratch, float* scratch_b, float* scratch_h, float* scratch_hb,
                         int32_t* list, int32_t* count, int wpw, bool multi,
-                        const int32_t* n_dev, hipStream_t s, const MergeOut* merge = nullptr) {
+                        const int32_t* n_dev, hipStream_t s, const MergeOut* merge = nullptr,
+                        const RunLists* runs = nullptr) {
   const int32_t* cnt = ts.cnt[0];
   const int lpr = lanes_per_row(d);
   const MergeOut mo = merge ? *merge : MergeOut{nullptr, nullptr, nullptr, -1, 0};
   const bool pure_merge = merge && merge->table < 0;      // (table >= 0: side output of an Adagrad pass)
+  if (runs && n_dev && runs_path(d)) {
+    // radix-sorted pass: the run records were extracted behind the sort (phase 1) -- one launch, no
+    // windows, no finish launch (group.hip)
+    bool sgd2 = ts.acc[0] == nullptr;
+    if (!ts.E[0] && ts.E[1]) sgd2 = ts.acc[1] == nullptr;
+    MergeOut m2 = mo;
+    if (pure_merge) {           // every key is an entity id: a side output of "table 0", which has no rows
+      m2.table = 0;
+      m2.kb = 30;
+    }
+    return launch_run_apply(ts, multi, d, *runs, n, G, ldg, gb_in, lr_dev, gscale_dev, m2, sgd2, s);
+  }
   if (!merge && cnt != nullptr && n <= kRankSortMax && n_dev == nullptr) {   // (radix-sorted input has a live count: window path)
     // small batches (single-launch LDS rank sort regime): one sub-group per sorted position --
     // mostly-unique one-hot ids need the parallelism (80 windows would leave the chip idle);
@@ -1210,7 +1308,7 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
 namespace {
 struct BagWs {
   SparseWs wi, wt;                        // sort / apply workspaces of the two stages
-  size_t off_wi, off_wt, off_ikeys, off_isrc, off_icoef, off_tkeys, off_tsrc, off_gu, off_gub, total;
+  size_t off_wi, off_wt, off_ikeys, off_isrc, off_icoef, off_tkeys, off_tsrc, off_gu, off_gub, off_hoff, total;
 };
 int bag_ws_layout(int64_t n_i, int max_len, int d, BagWs* w) {
   const int64_t n_t = n_i * (int64_t)max_len;
@@ -1226,6 +1324,7 @@ int bag_ws_layout(int64_t n_i, int max_len, int d, BagWs* w) {
   w->off_tsrc = o; o += align_up((size_t)n_t * 4, 256);
   w->off_gu = o; o += align_up((size_t)n_i * (size_t)d * 4, 256);
   w->off_gub = o; o += align_up((size_t)n_i * 4, 256);
+  w->off_hoff = o; o += align_up((size_t)(n_i + 64) * 4, 256);       // head offsets of the compacted expansion + its total
   w->total = o;
   return ARX_OK;
 }
@@ -1234,10 +1333,15 @@ int bag_ws_layout(int64_t n_i, int max_len, int d, BagWs* w) {
 namespace arx {
 namespace {
 
+static bool bag_compact(int64_t n_i, int max_len) {
+  static const bool padded = getenv("ARX_K7_PADDED_BAGS") != nullptr;    // A/B: round-2 padded slots
+  return !padded && n_i * (int64_t)max_len > kRankSortMax && n_i <= (1 << 18);
+}
+
 // Stage 1b: the bags of the DISTINCT entities of a sorted entity-key list, sorted by token.
 int bag_token_sort(const BagWs& w, char* base, const uint32_t* sk_ent, int64_t n_i, const int32_t* ndev_i,
                    uint32_t sent_i, int ent_kb, uint32_t ent_tag, const int32_t* vals, const int32_t* starts,
-                   const int32_t* lens, int max_len, int64_t table_rows, hipStream_t s) {
+                   const int32_t* lens, int max_len, int64_t table_rows, int d, hipStream_t s, bool have_hoff) {
   const int64_t n_t = n_i * (int64_t)max_len;
   char* bt = base + w.off_wt;
   int32_t* tkeys = reinterpret_cast<int32_t*>(base + w.off_tkeys);
@@ -1249,22 +1353,38 @@ int bag_token_sort(const BagWs& w, char* base, const uint32_t* sk_ent, int64_t n
   int kbt = 1;
   while ((1ll << kbt) < table_rows && kbt < 30) ++kbt;
   const uint32_t sent_t = 1u << kbt;
+  const bool compact = bag_compact(n_i, max_len);
+  int32_t* hoff = reinterpret_cast<int32_t*>(base + w.off_hoff);
+  int32_t* ttotal = hoff + n_i;
   {
     int64_t g = ceil_div(n_t, 256);
     const int64_t cap = (int64_t)cu_count() * 16;
     if (g > cap) g = cap;
-    k_bag_expand_heads<<<(int)g, 256, 0, s>>>(sk_ent, n_i, ndev_i, sent_i, ent_kb, ent_tag, vals, starts, lens,
-                                              max_len, table_rows, tkeys, tsrc);
+    if (compact) {
+      if (!have_hoff) {        // (normally a by-product of the entity list's run extraction, group.hip)
+        k_head_len_scan<<<1, 1024, 0, s>>>(sk_ent, n_i, ndev_i, sent_i, ent_kb, ent_tag, lens, max_len, hoff, ttotal);
+        ARX_CHECK_LAUNCH();
+      }
+      k_bag_expand_compact<<<(int)g, 256, 0, s>>>(sk_ent, n_i, ndev_i, sent_i, ent_kb, ent_tag, vals, starts, lens,
+                                                  max_len, table_rows, hoff, tkeys, tsrc);
+    } else {
+      k_bag_expand_heads<<<(int)g, 256, 0, s>>>(sk_ent, n_i, ndev_i, sent_i, ent_kb, ent_tag, vals, starts, lens,
+                                                max_len, table_rows, tkeys, tsrc);
+    }
     ARX_CHECK_LAUNCH();
   }
   if (n_t <= kRankSortMax)
     return launch_rank_sort(tkeys, n_t, sent_t, sk_t, reinterpret_cast<uint32_t*>(bt + w.wt.off_pos_out),
                             count_t, s, tsrc, nullptr, ssrc_t, scoef_t);
-  return launch_radix_sort(tkeys, tsrc, nullptr, n_t, sent_t, kbt,
-                           reinterpret_cast<uint32_t*>(bt + w.wt.off_keys_tmp), sk_t,
-                           reinterpret_cast<int32_t*>(bt + w.wt.off_pos_in), ssrc_t,
-                           reinterpret_cast<float*>(bt + w.wt.off_pos_out), scoef_t,
-                           reinterpret_cast<int32_t*>(bt + w.wt.off_hist), count_t, count_t + 2, s);
+  const int rc = launch_radix_sort(tkeys, tsrc, nullptr, n_t, sent_t, kbt,
+                                   reinterpret_cast<uint32_t*>(bt + w.wt.off_keys_tmp), sk_t,
+                                   reinterpret_cast<int32_t*>(bt + w.wt.off_pos_in), ssrc_t,
+                                   reinterpret_cast<float*>(bt + w.wt.off_pos_out), scoef_t,
+                                   reinterpret_cast<int32_t*>(bt + w.wt.off_hist), count_t, count_t + 2, s,
+                                   compact ? ttotal : nullptr);
+  if (rc || !runs_path(d)) return rc;
+  const RunLists rl = run_lists_of(bt + w.wt.off_runs, n_t, 256, ssrc_t, scoef_t, count_t + 8);
+  return launch_runs_extract(sk_t, n_t, count_t + 2, sent_t, rl, d, s);
 }
 
 // Stage 2b: token runs over the merged rows Gu (every coefficient is 1) -> Adagrad.
@@ -1284,6 +1404,8 @@ int bag_token_apply(const BagWs& w, char* base, int64_t n_i, int max_len, float*
   ts.bias_acc[0] = bias_acc;
   ts.cnt[0] = rank_t ? aux_cnt : nullptr;
   ts.kb = kbt;
+  const RunLists rl = run_lists_of(bt + w.wt.off_runs, n_t, 256, reinterpret_cast<int32_t*>(bt + w.wt.off_ssrc),
+                                   reinterpret_cast<float*>(bt + w.wt.off_scoef), count_t + 8);
   return launch_apply(ts, d, reinterpret_cast<uint32_t*>(bt + w.wt.off_keys_out), nullptr,
                       reinterpret_cast<int32_t*>(bt + w.wt.off_ssrc), nullptr, n_t, 1u << kbt,
                       reinterpret_cast<float*>(base + w.off_gu), d,
@@ -1293,7 +1415,7 @@ int bag_token_apply(const BagWs& w, char* base, int64_t n_i, int max_len, float*
                       reinterpret_cast<float*>(bt + w.wt.off_scratch_h),
                       reinterpret_cast<float*>(bt + w.wt.off_scratch_hb),
                       reinterpret_cast<int32_t*>(bt + w.wt.off_list), count_t, kTokenWpw, false,
-                      rank_t ? nullptr : count_t + 2, s);
+                      rank_t ? nullptr : count_t + 2, s, nullptr, &rl);
 }
 
 }  // namespace
@@ -1311,10 +1433,6 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   // phases must see the same workspace, untouched in between.
   const int64_t n = st.offs[st.nsites] + st.xoffs[st.nextra];   // one-hot + pre-expanded
   if (n == 0) return ARX_OK;
-  // past the one-launch rank sort: no sort at all when every table brings its per-row map (group.hip)
-  if (n > kRankSortMax && grouped_supported(ts, ntables, d, st, bag))
-    return sparse_adagrad_sites_grouped(ts, ntables, d, st, G, ldg, 0, Gb, lr_dev, gscale_dev, keys_buf, src_buf,
-                                        coef_buf, workspace, workspace_bytes, s, phase, bag);
   SparseWs w;
   int rc = sparse_ws_layout(n, 256, &w);
   if (rc) { set_error("arx_sparse_adagrad_cat: workspace layout failed"); return rc; }
@@ -1350,6 +1468,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   const int32_t* src_arg = ssrc;
   const float* coef_arg = scoef;
   const int32_t* n_dev = nullptr;      // live-entry count of the radix sort (pads dropped)
+  bool sorted_runs = false;
   if (n <= kRankSortMax && st.nextra == 0) {     // (pre-expanded multi-hot segments: radix path only)
     if (phase & 1) {
       rc = launch_rank_sort(keys_buf, n, sentinel, keys_out, pos_out, count, s, src_buf, coef_buf,
@@ -1364,6 +1483,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
                              reinterpret_cast<float*>(base + w.off_pos_out), scoef,
                              reinterpret_cast<int32_t*>(base + w.off_hist), count, count + 2, s);
       if (rc) return rc;
+      sorted_runs = runs_path(d);                // run records: extracted below, once the riding bag table is known
     }
     n_dev = count + 2;
   }
@@ -1372,6 +1492,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   // of its own; the merged gradient row of each comes out of the apply below as a side output
   BagWs bw;
   char* bbase = nullptr;
+  bool have_hoff = false;
   int64_t n0 = 0;                              // lookups of table 0 (host count: its keys sort first)
   if (bag) {
     if (st.nextra != 0) { set_error("arx_sparse_adagrad_cat_multi_bags: no pre-expanded segments"); return ARX_EINVAL; }
@@ -1385,11 +1506,27 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
       return ARX_EWORKSPACE;
     }
     bbase = reinterpret_cast<char*>(bag->ws);
-    if (phase & 1) {
-      rc = bag_token_sort(bw, bbase, keys_out, n0, n_dev, sentinel, ts.kb, 0u, bag->vals, bag->starts,
-                          bag->lens, bag->max_len, bag->rows, s);
+  }
+  if (sorted_runs) {
+    // run records of the one-hot list -- unless a bag table rides on it: then the sort branch of the step has
+    // no room for them (measured at C3: the branch ends 40 us behind the backward GEMMs), the one-hot pass
+    // keeps the window apply (same time for mostly single-entry runs) and the sweep only produces the ordered
+    // offsets of the distinct entities' bags in the compact token list
+    const bool hoff = bag && bag_compact(n0, bag->max_len) && runs_extract_blocks(n) <= 224;
+    int32_t* hp = hoff ? reinterpret_cast<int32_t*>(bbase + bw.off_hoff) : nullptr;
+    RunLists rl = run_lists_of(base + w.off_runs, n, 256, ssrc, scoef, count + 8);
+    if (bag) rl.R = nullptr;
+    if (!bag || hoff) {
+      rc = launch_runs_extract(keys_out, n, count + 2, sentinel, rl, d, s, hoff ? bag->lens : nullptr, ts.kb, 0u,
+                               bag ? bag->max_len : 0, hp, n0, hoff ? hp + n0 : nullptr, count + 32);
       if (rc) return rc;
     }
+    have_hoff = hoff;
+  }
+  if (bag && (phase & 1)) {
+    rc = bag_token_sort(bw, bbase, keys_out, n0, n_dev, sentinel, ts.kb, 0u, bag->vals, bag->starts,
+                        bag->lens, bag->max_len, bag->rows, d, s, have_hoff);
+    if (rc) return rc;
   }
   if (!(phase & 2)) return ARX_OK;
   bool any_bias = bag && bag->bias;
@@ -1399,10 +1536,11 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   if (bag)
     side = MergeOut{reinterpret_cast<float*>(bbase + bw.off_gu),
                     bag->bias ? reinterpret_cast<float*>(bbase + bw.off_gub) : nullptr, bag->lens, 0, ts.kb};
+  const RunLists rl_sites = run_lists_of(base + w.off_runs, n, 256, ssrc, scoef, count + 8);
   rc = launch_apply(ts, d, keys_out, spos_arg, src_arg, coef_arg, n, sentinel, G, ldg, gb_in, lr_dev,
                     gscale_dev, scratch, scratch_b, scratch_h, scratch_hb, list, count,
                     /*wpw=*/(ntables > 1 || st.nextra == 0) ? 8 : 1, /*multi=*/ntables > 1, n_dev, s,
-                    bag ? &side : nullptr);
+                    bag ? &side : nullptr, bag ? nullptr : &rl_sites);
   if (rc || !bag) return rc;
   return bag_token_apply(bw, bbase, n0, bag->max_len, bag->E, bag->acc, bag->bias, bag->bias_acc, bag->rows,
                          bag->aux_cnt, d, lr_dev, gscale_dev, s);
@@ -1415,8 +1553,7 @@ extern "C" {
 size_t arx_sparse_adagrad_workspace_bytes(int64_t n) {
   SparseWs w;
   if (sparse_ws_layout(n, 256, &w) != ARX_OK) return 0;  // d <= 256 (largest supported row)
-  const size_t g = grouped_ws_bytes(n, 256);              // (the grouped path of group.hip shares the buffer)
-  return w.total > g ? w.total : g;
+  return w.total;
 }
 
 int arx_sparse_adagrad(float* E, float* acc, float* bias, float* bias_acc, int d,
@@ -1483,6 +1620,11 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
     spos_arg = nullptr;
     src = ssrc;
     coef = scoef;
+    if (runs_path(d)) {
+      rc = launch_runs_extract(keys_out, n, count + 2, sentinel,
+                               run_lists_of(base + w.off_runs, n, 256, ssrc, scoef, count + 8), d, s);
+      if (rc) return rc;
+    }
   }
   const float* gb_in = bias ? Gb : nullptr;
   TableSet ts = {};
@@ -1492,11 +1634,14 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
   ts.bias_acc[0] = bias_acc;
   ts.cnt[0] = aux_cnt;
   ts.kb = key_bits;                            // single table: key >> kb == 0 for every real key
+  const RunLists rl_one = run_lists_of(base + w.off_runs, n, 256, reinterpret_cast<int32_t*>(base + w.off_ssrc),
+                                       reinterpret_cast<float*>(base + w.off_scoef), count + 8);
   return launch_apply(ts, d, keys_out, spos_arg, src, coef, n, sentinel, G, ldg, gb_in, lr_dev,
                       gscale_dev, scratch, scratch_b,
                       reinterpret_cast<float*>(base + w.off_scratch_h),
                       reinterpret_cast<float*>(base + w.off_scratch_hb), list, count,
-                      /*wpw=*/n <= (1 << 21) ? 4 : 1   /* explicit (key, src, coef) triples: one-hot or multi-hot, not known here; n is the padded capacity (~3x the live count for multi-hot sites) */, /*multi=*/false, n_dev, s);
+                      /*wpw=*/n <= (1 << 21) ? 4 : 1   /* explicit (key, src, coef) triples: one-hot or multi-hot, not known here; n is the padded capacity (~3x the live count for multi-hot sites) */, /*multi=*/false, n_dev, s,
+                      nullptr, &rl_one);
 }
 
 int arx_merged_sq_norm(const int32_t* keys, const int32_t* src, const float* coef, int64_t n,
@@ -1556,8 +1701,7 @@ size_t arx_sparse_adagrad_bags_workspace_bytes(int64_t n_lookups, int max_len, i
   BagWs w;
   if (n_lookups <= 0 || max_len <= 0 || d <= 0) return 0;
   if (bag_ws_layout(n_lookups, max_len, d, &w) != ARX_OK) return 0;
-  const size_t g = grouped_bag_ws_bytes(n_lookups, max_len, 0, d);
-  return w.total > g ? w.total : g;
+  return w.total;
 }
 
 int arx_sparse_adagrad_bags(int phase, float* E, float* acc, float* bias, float* bias_acc,
@@ -1642,8 +1786,18 @@ int arx_sparse_adagrad_bags(int phase, float* E, float* acc, float* bias, float*
                              reinterpret_cast<float*>(bi + w.wi.off_pos_out), scoef_i,
                              reinterpret_cast<int32_t*>(bi + w.wi.off_hist), count_i, count_i + 2, s);
     if (rc) return rc;
+    bool have_hoff = false;
+    if (!rank_i && runs_path(d)) {
+      have_hoff = bag_compact(n_i, max_len) && runs_extract_blocks(n_i) <= 224;
+      int32_t* hp = reinterpret_cast<int32_t*>(base + w.off_hoff);
+      rc = launch_runs_extract(sk_i, n_i, count_i + 2, sent_i,
+                               run_lists_of(bi + w.wi.off_runs, n_i, 256, ssrc_i, scoef_i, count_i + 8), d, s,
+                               have_hoff ? lens : nullptr, kbi, 0u, max_len, hp, n_i, have_hoff ? hp + n_i : nullptr,
+                               count_i + 32);
+      if (rc) return rc;
+    }
     // ---- stage 1b: bags of the DISTINCT entities, sorted by token ----
-    rc = bag_token_sort(w, base, sk_i, n_i, ndev_i, sent_i, kbi, 0u, vals, starts, lens, max_len, table_rows, s);
+    rc = bag_token_sort(w, base, sk_i, n_i, ndev_i, sent_i, kbi, 0u, vals, starts, lens, max_len, table_rows, d, s, have_hoff);
     if (rc) return rc;
   }
   if (!(phase & 2)) return ARX_OK;
@@ -1652,12 +1806,13 @@ int arx_sparse_adagrad_bags(int phase, float* E, float* acc, float* bias, float*
     TableSet none = {};
     none.kb = kbi;
     MergeOut mo = {Gu, bias ? Gub : nullptr, lens, -1, 0};
+    const RunLists rl_ent = run_lists_of(bi + w.wi.off_runs, n_i, 256, ssrc_i, scoef_i, count_i + 8);
     rc = launch_apply(none, d, sk_i, nullptr, ssrc_i, scoef_i, n_i, sent_i, G, ldg, bias ? Gb : nullptr,
                       lr_dev, gscale_dev, reinterpret_cast<float*>(bi + w.wi.off_scratch),
                       reinterpret_cast<float*>(bi + w.wi.off_scratch_b),
                       reinterpret_cast<float*>(bi + w.wi.off_scratch_h),
                       reinterpret_cast<float*>(bi + w.wi.off_scratch_hb),
-                      reinterpret_cast<int32_t*>(bi + w.wi.off_list), count_i, 8, false, ndev_i, s, &mo);
+                      reinterpret_cast<int32_t*>(bi + w.wi.off_list), count_i, 8, false, ndev_i, s, &mo, &rl_ent);
     if (rc) return rc;
   }
   // ---- stage 2b: token runs over the merged rows (every coefficient is 1) -> Adagrad ----

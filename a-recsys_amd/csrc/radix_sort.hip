@@ -28,10 +28,12 @@ namespace arx {
 
 namespace {
 
-constexpr int kRsThreads = 256;
-constexpr int kRsMaxBlocks = 256;
+// 128 threads: the scatter kernel's LDS (per-wave cursors + bin bases) is 24 KB then -- it has to fit the
+// 32 KB the scorer GEMMs (2 x 64 KB per CU) leave, or the sort waits for a whole GEMM (measured: 52 us)
+constexpr int kRsThreads = 128;
+constexpr int kRsMaxBlocks = 512;
 constexpr int kRsMaxBits = 11;    // 2 passes cover 22 key bits (a 1M-row table + the sentinel bit)
-constexpr int kRsPer = (1 << kRsMaxBits) / 256;   // bins per thread in the bin-base scan
+constexpr int kRsPer = (1 << kRsMaxBits) / kRsThreads;   // bins per thread in the bin-base scan
 constexpr int kRsMaxBins = 1 << kRsMaxBits;
 
 __device__ __forceinline__ uint32_t norm_key(int32_t k, uint32_t sentinel) {
@@ -60,10 +62,13 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__
                                                         const int32_t* __restrict__ n_dev,
                                                         uint32_t sentinel, int shift, int bits,
                                                         int64_t ipb_host, int32_t* __restrict__ hist,
-                                                        int32_t* __restrict__ list_count) {
+                                                        int32_t* __restrict__ list_count,
+                                                        const int32_t* __restrict__ n_in_dev) {
   // n_dev: live entries after the first pass dropped the sentinels (device-side count; the grid
   // is sized for the host-side capacity: the live entries are dealt over ALL its blocks)
-  const int32_t* cnt = RAW ? nullptr : n_dev;
+  // (first pass: n_in_dev, if given, is the number of input entries -- a compacted list whose length
+  // is only known on the device)
+  const int32_t* cnt = RAW ? n_in_dev : n_dev;
   const int64_t n = cnt ? min((int64_t)*cnt, n_host) : n_host;
   const int64_t ipb = cnt ? rs_ipb_dev(n, gridDim.x) : ipb_host;
   __shared__ int h[kRsWaves][kRsMaxBins];
@@ -71,10 +76,10 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   for (int b = lane; b < bins; b += 64) h[w][b] = 0;
-  if (list_count && blockIdx.x == 0 && threadIdx.x == 0) {
-    list_count[0] = 0;
-    list_count[1] = 0;
-  }
+  // the caller's 2 KB counter block: [0], [1] run lists of the window apply, [2] live count (written by this
+  // pass's scatter), [8 ..] counters of the run-centric apply, [32 ..] its look-back cells (k7.h)
+  if (list_count && blockIdx.x == 0)
+    for (int t = threadIdx.x; t < 512; t += kRsThreads) list_count[t] = 0;
   const int64_t base = blockIdx.x * ipb;
   const int64_t end = min(n, base + ipb);
   const int64_t ipw = ipb / kRsWaves;
@@ -140,8 +145,8 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(
     const float* __restrict__ coef_in, int64_t n_host, int32_t* __restrict__ n_live,
     uint32_t sentinel, int shift, int bits, int64_t ipb_host, const int32_t* __restrict__ hist,
     const int32_t* __restrict__ tot, uint32_t* __restrict__ keys_out, int32_t* __restrict__ src_out,
-    float* __restrict__ coef_out) {
-  const int32_t* cnt = RAW ? nullptr : n_live;
+    float* __restrict__ coef_out, const int32_t* __restrict__ n_in_dev) {
+  const int32_t* cnt = RAW ? n_in_dev : n_live;
   const int64_t n = cnt ? min((int64_t)*cnt, n_host) : n_host;
   const int64_t ipb = cnt ? rs_ipb_dev(n, gridDim.x) : ipb_host;
   constexpr int NW = kRsWaves;
@@ -257,7 +262,7 @@ RsPlan rs_plan(int64_t n, int total_bits) {
     p.shift[i] = sh;
     sh += p.bits[i];
   }
-  int64_t nblk = ceil_div(n, 1024);   // one 4-round batch per wave at small n (latency-bound there)
+  int64_t nblk = ceil_div(n, 4 * kRsThreads);   // one 4-round batch per wave at small n (latency-bound there)
   if (nblk > kRsMaxBlocks) nblk = kRsMaxBlocks;
   if (nblk < 1) nblk = 1;
   p.ipb = ceil_div(ceil_div(n, nblk), kRsThreads) * kRsThreads;
@@ -274,7 +279,8 @@ size_t radix_sort_hist_bytes() {   // per-wave rows + the column totals
 int launch_radix_sort(const int32_t* keys_raw, const int32_t* src_raw, const float* coef_raw, int64_t n,
                       uint32_t sentinel, int total_bits, uint32_t* keys_tmp, uint32_t* keys_out,
                       int32_t* src_tmp, int32_t* src_out, float* coef_tmp, float* coef_out,
-                      int32_t* hist, int32_t* list_count, int32_t* n_live, hipStream_t s) {
+                      int32_t* hist, int32_t* list_count, int32_t* n_live, hipStream_t s,
+                      const int32_t* n_in_dev) {
   const RsPlan p = rs_plan(n, total_bits);
   const void* in_k = keys_raw;
   const int32_t* in_s = src_raw;
@@ -289,21 +295,26 @@ int launch_radix_sort(const int32_t* keys_raw, const int32_t* src_raw, const flo
     const int bins = 1 << p.bits[i];
     if (i == 0)
       k_rs_hist<true><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, n_live, sentinel, p.shift[i], p.bits[i], p.ipb,
-                                                    hist, list_count);
+                                                    hist, list_count, n_in_dev);
     else
       k_rs_hist<false><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, n_live, sentinel, p.shift[i], p.bits[i],
-                                                     p.ipb, hist, nullptr);
+                                                     p.ipb, hist, nullptr, nullptr);
     ARX_CHECK_LAUNCH();
-    k_rs_scan<<<bins / 4, 1024, 0, s>>>(hist, p.nblk * kRsWaves, bins, tot);
+    {
+      // thread r <-> row r: as many waves as there are rows (a 16-wave workgroup waits for a whole CU's worth of
+      // slots next to the step's GEMMs: measured 44 us for a 132-row scan)
+      const int rows = p.nblk * kRsWaves;
+      k_rs_scan<<<bins / 4, (rows + 63) / 64 * 64, 0, s>>>(hist, rows, bins, tot);
+    }
     ARX_CHECK_LAUNCH();
     if (i == 0)
       k_rs_scatter<true><<<p.nblk, kRsThreads, 0, s>>>(in_k, in_s, in_c, n, n_live, sentinel, p.shift[i],
                                                        p.bits[i], p.ipb, hist, tot, out_k, out_s,
-                                                       out_c);
+                                                       out_c, n_in_dev);
     else
       k_rs_scatter<false><<<p.nblk, kRsThreads, 0, s>>>(in_k, in_s, in_c, n, n_live, sentinel, p.shift[i],
                                                         p.bits[i], p.ipb, hist, tot, out_k, out_s,
-                                                        out_c);
+                                                        out_c, nullptr);
     ARX_CHECK_LAUNCH();
     in_k = out_k;
     in_s = out_s;

@@ -145,3 +145,30 @@ def test_capped_race_equals_uncapped(dev):
         ops.sample_wor(tw, S, 5, counter, a, ws)
         ops.sample_wor(tw, S, 5, counter, b, ws, key_cap=8.0 * S / float(w.astype(np.float64).sum()))
         assert torch.equal(a, b) and int(a.min().item()) >= 0
+
+
+def test_device_sampler_heavy_tailed_weights(dev):
+    """DeviceSampler on Zipf(1.5)-like weights (round-2 advisor finding): with the cap 8 S / sum(w)
+    only ~600 of 1 M keys survived, the draw of 1000 came back short and the missing positions
+    indexed items[-1].  The cap now solves sum_i (1 - exp(-w_i t)) = 8 S: the draw is complete,
+    duplicate-free and equal to the un-capped race; too few positive weights raise."""
+    import torch
+    from arx import ops
+    from arx.utils.prepare_train import DeviceSampler
+    n, S = 1000000, 1000
+    w = (1.0 / np.arange(1, n + 1) ** 1.5).astype(np.float32)
+    items = np.arange(n, dtype=np.int32)[::-1].copy()            # item ids != positions
+    s = DeviceSampler(items, w, device=dev, seed=3)
+    assert s._cap_for(S) > 8.0 * S / float(w.astype(np.float64).sum())      # the old cap was too tight
+    tw = torch.from_numpy(w).to(dev)
+    ws = ops.Workspace(dev)
+    ref = torch.empty(S, dtype=torch.int32, device=dev)
+    for counter in range(3):
+        got = s.sample(S).cpu().numpy()
+        ops.sample_wor(tw, S, 3, counter, ref, ws)                # un-capped race, same seed / counter
+        assert len(np.unique(got)) == S
+        np.testing.assert_array_equal(got, items[ref.cpu().numpy()])
+    few = np.zeros(200000, dtype=np.float32)
+    few[:10] = 1.0
+    with pytest.raises(ValueError):
+        DeviceSampler(np.arange(200000, dtype=np.int32), few, device=dev).sample(64)

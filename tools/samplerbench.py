@@ -16,4 +16,4 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 torch.cuda.synchronize(); e0.record()
 for _ in range(20): s.sample(1024, out)
 e1.record(); torch.cuda.synchronize()
-print('n=%d  sample(1024): %.1f us  (cap in use: %s)' % (n, e0.elapsed_time(e1) / 20 * 1e3, s._wsum > 0))
+print('n=%d  sample(1024): %.1f us  (cap in use: %s)' % (n, e0.elapsed_time(e1) / 20 * 1e3, s._cap_for(1024) > 0))
