@@ -1004,8 +1004,13 @@ class Plan(object):
         early = self._k7_early
         self._k7_early = None
         self._k7_done_keys = None
+        split_join = None
         if early is not None:
-            torch.cuda.current_stream().wait_event(early[1])          # join the sort branch
+            if early[2] is not None:
+                torch.cuda.current_stream().wait_event(early[2])      # the one-hot sort is done ...
+                split_join = early[1]                                 # ... the token chain is joined before its apply
+            else:
+                torch.cuda.current_stream().wait_event(early[1])      # join the sort branch
             self._k7_done_keys = early[0]
         self._jobs, self._n_passes = [], 0
         done = set(id(e) for e, _, _ in fused)
@@ -1045,7 +1050,16 @@ class Plan(object):
                 key = key + ('rider', id(bag_entry), use_bias, gi is None)
                 bag = (bag_entry, bag_live, use_bias, gi is None)
             phase = 2 if (self._k7_done_keys is not None and key in self._k7_done_keys) else 3
-            self._apply_multi(fused, phase=phase, key=key, bag=bag)
+            if phase == 2 and split_join is not None and bag is not None:
+                self._apply_multi(fused, phase=7, key=key, bag=bag)
+                torch.cuda.current_stream().wait_event(split_join)
+                split_join = None
+                self._apply_multi(fused, phase=8, key=key, bag=bag)
+            else:
+                if split_join is not None:
+                    torch.cuda.current_stream().wait_event(split_join)
+                    split_join = None
+                self._apply_multi(fused, phase=phase, key=key, bag=bag)
             # size estimate for _plan_early: one-hot sites are all live, a multi-hot site's padded
             # capacity (max_len slots per bag) holds about a third of that in live tokens
             job = ('multi', (fused, bag), key, sum(x.cap for _, c, _m in fused for x in c)
@@ -1054,6 +1068,8 @@ class Plan(object):
                 job = job + (sum(x.cap for x in bag_live) // 6,)
             self._jobs.append(job)
             self._n_passes += 1
+        if split_join is not None:
+            torch.cuda.current_stream().wait_event(split_join)
         if not side_first:
             rest(True)
         for t in toks:
@@ -1220,8 +1236,16 @@ class Plan(object):
         self._k7_fork = None
         self._k7_stream.wait_event(ev)
         with torch.cuda.stream(self._k7_stream):
+            mid = None
             for kind, what, key in jobs:
-                if kind == 'multi':
+                if kind == 'multi' and what[1] is not None and len(jobs) == 1 and not os.environ.get('ARX_K7_NO_SPLIT'):
+                    # a bag table rides on the pass: the one-hot apply only needs the one-hot sort --
+                    # the token chain behind it may still run while that apply does (quarter phases)
+                    self._apply_multi(what[0], phase=5, key=key, bag=what[1])
+                    mid = torch.cuda.Event()
+                    mid.record(self._k7_stream)
+                    self._apply_multi(what[0], phase=6, key=key, bag=what[1])
+                elif kind == 'multi':
                     self._apply_multi(what[0], phase=1, key=key, bag=what[1])
                 elif kind == 'bags':
                     self._bag_pass(what, key, phase=1)
@@ -1229,7 +1253,7 @@ class Plan(object):
                     self._cat_pass(what, key, phase=1)
             done = torch.cuda.Event()
             done.record(self._k7_stream)
-        self._k7_early = (set(k for _, _, k in jobs), done)
+        self._k7_early = (set(k for _, _, k in jobs), done, mid)
 
     def _plan_early(self, jobs, n_passes):
         """Which of this execution's passes may be sorted ahead next time: all of them or none

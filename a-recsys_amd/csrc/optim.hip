@@ -1430,7 +1430,12 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
                                 hipStream_t s, int phase, const BagStage* bag) {
   // phase 1 (keys + sort) depends on the lookup ids only, not on any gradient: the caller may run
   // it on a side stream under the forward / backward GEMMs and join before phase 2 (apply).  Both
-  // phases must see the same workspace, untouched in between.
+  // phases must see the same workspace, untouched in between.  With a riding bag table each half
+  // splits again (phases 5 .. 8): A one-hot keys + sort (+ bag offsets), B the token chain, C the
+  // one-hot apply (its side output: the merged rows), D the token apply -- the caller joins the
+  // branch after A for C and after B for D, so the tail of the token chain hides under C.
+  const int mask = phase == 1 ? 3 : phase == 2 ? 12 : phase == 3 ? 15 : phase == 5 ? 1 : phase == 6 ? 2
+                   : phase == 7 ? 4 : phase == 8 ? 8 : 0;
   const int64_t n = st.offs[st.nsites] + st.xoffs[st.nextra];   // one-hot + pre-expanded
   if (n == 0) return ARX_OK;
   SparseWs w;
@@ -1455,7 +1460,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   int32_t* count = reinterpret_cast<int32_t*>(base + w.off_count);
   float* scratch = reinterpret_cast<float*>(base + w.off_scratch);
   float* scratch_b = reinterpret_cast<float*>(base + w.off_scratch_b);
-  if (phase & 1) {
+  if (mask & 1) {
     int64_t g = ceil_div(n, 256);
     k_site_keys<<<(int)g, 256, 0, s>>>(st, keys_buf, src_buf, coef_buf);
     ARX_CHECK_LAUNCH();
@@ -1470,13 +1475,13 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   const int32_t* n_dev = nullptr;      // live-entry count of the radix sort (pads dropped)
   bool sorted_runs = false;
   if (n <= kRankSortMax && st.nextra == 0) {     // (pre-expanded multi-hot segments: radix path only)
-    if (phase & 1) {
+    if (mask & 1) {
       rc = launch_rank_sort(keys_buf, n, sentinel, keys_out, pos_out, count, s, src_buf, coef_buf,
                             ssrc, scoef);
       if (rc) return rc;
     }
   } else {   // own LSD radix sort: src/coef come out in sorted order too
-    if (phase & 1) {
+    if (mask & 1) {
       rc = launch_radix_sort(keys_buf, src_buf, coef_buf, n, sentinel, key_bits /* survivors of the first pass are < sentinel */,
                              reinterpret_cast<uint32_t*>(base + w.off_keys_tmp), keys_out,
                              reinterpret_cast<int32_t*>(base + w.off_pos_in), ssrc,
@@ -1507,12 +1512,13 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
     }
     bbase = reinterpret_cast<char*>(bag->ws);
   }
+  const bool hoff_ok = bag && n_dev && runs_path(d) && bag_compact(n0, bag->max_len) && runs_extract_blocks(n) <= 224;
   if (sorted_runs) {
     // run records of the one-hot list -- unless a bag table rides on it: then the sort branch of the step has
     // no room for them (measured at C3: the branch ends 40 us behind the backward GEMMs), the one-hot pass
     // keeps the window apply (same time for mostly single-entry runs) and the sweep only produces the ordered
     // offsets of the distinct entities' bags in the compact token list
-    const bool hoff = bag && bag_compact(n0, bag->max_len) && runs_extract_blocks(n) <= 224;
+    const bool hoff = hoff_ok;
     int32_t* hp = hoff ? reinterpret_cast<int32_t*>(bbase + bw.off_hoff) : nullptr;
     RunLists rl = run_lists_of(base + w.off_runs, n, 256, ssrc, scoef, count + 8);
     if (bag) rl.R = nullptr;
@@ -1521,14 +1527,14 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
                                bag ? bag->max_len : 0, hp, n0, hoff ? hp + n0 : nullptr, count + 32);
       if (rc) return rc;
     }
-    have_hoff = hoff;
   }
-  if (bag && (phase & 1)) {
+  have_hoff = hoff_ok;
+  if (bag && (mask & 2)) {
     rc = bag_token_sort(bw, bbase, keys_out, n0, n_dev, sentinel, ts.kb, 0u, bag->vals, bag->starts,
                         bag->lens, bag->max_len, bag->rows, d, s, have_hoff);
     if (rc) return rc;
   }
-  if (!(phase & 2)) return ARX_OK;
+  if (!(mask & 12)) return ARX_OK;
   bool any_bias = bag && bag->bias;
   for (int t = 0; t < ntables; ++t) any_bias = any_bias || ts.bias[t] != nullptr;
   const float* gb_in = any_bias ? Gb : nullptr;
@@ -1537,11 +1543,13 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
     side = MergeOut{reinterpret_cast<float*>(bbase + bw.off_gu),
                     bag->bias ? reinterpret_cast<float*>(bbase + bw.off_gub) : nullptr, bag->lens, 0, ts.kb};
   const RunLists rl_sites = run_lists_of(base + w.off_runs, n, 256, ssrc, scoef, count + 8);
-  rc = launch_apply(ts, d, keys_out, spos_arg, src_arg, coef_arg, n, sentinel, G, ldg, gb_in, lr_dev,
+  rc = ARX_OK;
+  if (mask & 4)
+    rc = launch_apply(ts, d, keys_out, spos_arg, src_arg, coef_arg, n, sentinel, G, ldg, gb_in, lr_dev,
                     gscale_dev, scratch, scratch_b, scratch_h, scratch_hb, list, count,
                     /*wpw=*/(ntables > 1 || st.nextra == 0) ? 8 : 1, /*multi=*/ntables > 1, n_dev, s,
                     bag ? &side : nullptr, bag ? nullptr : &rl_sites);
-  if (rc || !bag) return rc;
+  if (rc || !bag || !(mask & 8)) return rc;
   return bag_token_apply(bw, bbase, n0, bag->max_len, bag->E, bag->acc, bag->bias, bag->bias_acc, bag->rows,
                          bag->aux_cnt, d, lr_dev, gscale_dev, s);
 }

@@ -492,7 +492,8 @@ int arx_sparse_adagrad_cat_multi_bags(int phase, int ntables, float* const* E, f
                                       int64_t bag_rows, const int32_t* vals, const int32_t* starts,
                                       const int32_t* lens, int max_len, int32_t* bag_aux_cnt,
                                       void* bag_workspace, size_t bag_workspace_bytes, void* stream) {
-  ARX_CHECK_ARG(phase == 1 || phase == 2 || phase == 3, "arx_sparse_adagrad_cat_multi_bags: phase 1, 2 or 3");
+  ARX_CHECK_ARG((phase >= 1 && phase <= 3) || (phase >= 5 && phase <= 8),
+                "arx_sparse_adagrad_cat_multi_bags: phase 1, 2, 3 or the quarter phases 5 .. 8");
   ARX_CHECK_ARG(bag_E && vals && starts && lens && bag_rows > 0 && max_len > 0 && bag_workspace,
                 "arx_sparse_adagrad_cat_multi_bags: null pointer / bad sizes");
   ARX_CHECK_ARG(bag_acc ? (bag_bias == nullptr) == (bag_bias_acc == nullptr) : bag_bias_acc == nullptr,

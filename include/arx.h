@@ -504,6 +504,10 @@ int arx_sparse_adagrad_cat_multi_phase(int phase, int ntables, float* const* E, 
  *            distinct entity as a side output, then the token runs over those rows -> ONE Adagrad
  *            update per touched token row (same result as arx_sparse_adagrad_bags on the same sites).
  * Saves the entity sort and the merge pass of arx_sparse_adagrad_bags.  No pre-expanded segments.
+ * Each half splits again for callers that overlap the pass with other work (round 3):
+ *   phase 5 = the one-hot keys + sort (+ the bag offsets), phase 6 = the token chain (needs 5),
+ *   phase 7 = the one-hot apply with its side output (needs 5 and G), phase 8 = the token apply
+ *   (needs 6 and 7) -- so the tail of the token chain can run under the one-hot apply.
  * bag_workspace >= arx_sparse_adagrad_bags_workspace_bytes(lookups of table 0, max_len, d). */
 int arx_sparse_adagrad_cat_multi_bags(int phase, int ntables, float* const* E, float* const* acc,
                                       float* const* bias, float* const* bias_acc,
