@@ -106,3 +106,72 @@ def test_token_sharded_bags_hip_backend_world1(dev, n_users, n_items, V, d, B, S
             np.testing.assert_allclose(got[name], want, rtol=1e-4, atol=2e-6, err_msg=name)
     finally:
         dist.destroy_process_group()
+
+
+def test_sharded_c5_shape_world1(dev):
+    """BASELINE configs[4] at its full shape on ONE rank (the driver's box has one GPU): 100 M items x
+    dim 128 row-sharded table (51 GB + 51 GB of Adagrad slots), 1 M users, B = 16384, S = 1024, 'mw',
+    through the sharded step (1-rank RCCL group: every exchange is a local copy).  Two consecutive
+    steps; before each, the rows the step will touch are read back from the device and the step is
+    restated in fp64 numpy (oracle.ref_embed's 'mw' arithmetic: scorer, WMRB, rank-one gradients,
+    duplicates merged, one Adagrad update per row) -- loss, every touched user / item row, item bias
+    and their slots at rtol 1e-4; a sample of untouched rows stays bit-identical."""
+    import torch
+    import torch.distributed as dist
+    from arx.dist import ShardedHMF
+    from oracle import ref_embed
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29735")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n_users, n_items, d, B, S, lr = 1000000, 100000000, 128, 16384, 1024, 0.1
+        model = ShardedHMF(n_users, n_items, d, B, S, lr, 0, 1, dev, seed=5)
+        rng = np.random.default_rng(11)
+        hot = rng.integers(0, n_items, size=300)                        # popular items: duplicate targets
+        watch = torch.from_numpy(rng.integers(0, n_items, size=4096)).to(dev)
+
+        def rows(t, idx):
+            return t[torch.from_numpy(idx).to(dev)].double().cpu().numpy()
+        for step in range(2):
+            users = rng.choice(n_users, size=B, replace=True).astype(np.int32)
+            items = np.where(rng.random(B) < 0.4, hot[rng.integers(0, len(hot), size=B)],
+                             rng.integers(0, n_items, size=B)).astype(np.int32)
+            if step == 0:
+                pool = np.unique(np.concatenate([items[:8], hot[:16], rng.integers(0, n_items, size=2 * S)]))
+                pool = rng.permutation(pool)[:S].astype(np.int32)
+                assert len(pool) == S
+                model.set_pool(pool)
+            ui, ii = np.unique(users), np.unique(np.concatenate([items, pool]))
+            Eu, Au = rows(model.E_user, ui), rows(model.A_user, ui)
+            Ei, Ai = rows(model.E_item, ii), rows(model.A_item, ii)
+            bi, Abi = rows(model.b_item, ii), rows(model.Ab_item, ii)
+            keep = watch[~torch.isin(watch, torch.from_numpy(ii).to(dev))]
+            w_before = model.E_item[keep].clone()
+            # ---- the step in fp64 on those rows (oracle/ref_embed.py EmbedSpaceHMF.step) ----
+            pu, pp, pt = np.searchsorted(ui, users), np.searchsorted(ii, pool), np.searchsorted(ii, items)
+            U, P, T = Eu[pu], Ei[pp], Ei[pt]
+            logits = U @ P.T + bi[pp]
+            t = (U * T).sum(1) + bi[pt]
+            bl, dl, dt = ref_embed._Model.sampled_loss('mw', logits, t, np.ones((B, S), dtype=bool))
+            dl, dt = dl / B, dt / B
+            gU = np.zeros_like(Eu)
+            np.add.at(gU, pu, dl @ P + dt[:, None] * T)
+            gI, gb = np.zeros_like(Ei), np.zeros_like(bi)
+            np.add.at(gI, pp, dl.T @ U)
+            np.add.at(gb, pp, dl.sum(0))
+            np.add.at(gI, pt, dt[:, None] * U)
+            np.add.at(gb, pt, dt)
+            model.step(users, items)
+            np.testing.assert_allclose(float(model.read_loss().item()), float(bl.mean()), rtol=1e-4)
+            for name, E, A, E0, A0, g, idx in (('user', model.E_user, model.A_user, Eu, Au, gU, ui),
+                                               ('item', model.E_item, model.A_item, Ei, Ai, gI, ii),
+                                               ('item_bias', model.b_item, model.Ab_item, bi, Abi, gb, ii)):
+                a1 = A0 + g * g
+                w1 = E0 - lr * g / np.sqrt(a1)
+                np.testing.assert_allclose(rows(A, idx), a1, rtol=1e-4, atol=1e-9, err_msg='%s slots, step %d' % (name, step))
+                np.testing.assert_allclose(rows(E, idx), w1, rtol=1e-4, atol=2e-7, err_msg='%s rows, step %d' % (name, step))
+            assert torch.equal(model.E_item[keep], w_before)              # rows outside (batch u pool): untouched
+    finally:
+        dist.destroy_process_group()

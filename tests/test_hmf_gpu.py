@@ -117,6 +117,10 @@ def test_hmf_rs_family_matches_oracle(dev, loss, loss_func, exp_p):
         l_ref = ref.step(list(users), list(items), loss=loss)
         l_got = model.step(None, list(users), list(items), loss=loss)
         np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='step %d' % step)
+        # 'square' (loss_func): per-logit gradients of magnitude ~1e2 with both signs are summed into ONE bias
+        # cell per token row; the sum cancels to ~1e0, so fp32 summation order shows up at 1.3e-4 of the
+        # SQUARED sum in the Adagrad slot (ill-conditioned input, not kernel error: every other transform
+        # and every other tensor of this case holds 1e-4) -- the one documented exception to RTOL
         _compare_state(model, ref, rtol=2e-4 if loss_func == 'square' else RTOL, atol=2e-5)
     e_ref = ref.step(list(users), list(items), forward_only=True, loss=loss)
     e_got = model.step(None, list(users), list(items), forward_only=True, loss=loss)
@@ -171,7 +175,7 @@ def test_mlp_variant(dev, nonlinear):
         l_got = model.step(None, list(users), list(items), None, pool if step == 0 else None, id2idx,
                            loss='mw')
         np.testing.assert_allclose(l_got, l_ref, rtol=RTOL)
-    _compare_state(model, ref, rtol=2e-4, atol=1e-5)
+    _compare_state(model, ref, rtol=1e-4, atol=1e-5)
 
 
 def test_checkpoint_roundtrip(dev, tmp_path):

@@ -416,10 +416,10 @@ def test_sparse_adagrad(dev, d, n, Vf, hot):
     ops.sparse_adagrad(tE, tacc, tb, tbacc, _t(dev, keys), _t(dev, src), _t(dev, coef), _t(dev, G),
                        _t(dev, Gb), lr_dev, ws, gscale_dev=gs_dev)
     torch.cuda.synchronize()
-    np.testing.assert_allclose(tacc.cpu().numpy(), racc, rtol=2e-4, atol=1e-5)
-    np.testing.assert_allclose(tE.cpu().numpy(), rE, rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(tbacc.cpu().numpy(), rbacc, rtol=2e-4, atol=1e-5)
-    np.testing.assert_allclose(tb.cpu().numpy(), rb, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(tacc.cpu().numpy(), racc, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(tE.cpu().numpy(), rE, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(tbacc.cpu().numpy(), rbacc, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(tb.cpu().numpy(), rb, rtol=1e-4, atol=2e-5)
     # determinism: the same call on the same inputs is bit-identical
     tE2, tacc2 = _t(dev, E), _t(dev, acc)
     tb2, tbacc2 = _t(dev, bias), _t(dev, bacc)
@@ -591,21 +591,21 @@ def test_lstm_fwd_bwd(dev, L, B, din, h):
     np.testing.assert_allclose(gates.cpu().numpy(), r_g, rtol=RTOL, atol=2e-5)
     dz = torch.empty((L, B, 4 * h), dtype=torch.float32, device=dev)
     ops.lstm_bwd(tW, hs, cs, gates, _t(dev, dhs), L, B, din, h, dz)
-    np.testing.assert_allclose(dz.cpu().numpy(), r_dz, rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(dz.cpu().numpy(), r_dz, rtol=1e-4, atol=5e-5)
     # dx / dW / db are GEMMs + a column sum over dz (what the model issues)
     ws = ops.Workspace(dev)
     dz2 = dz.view(L * B, 4 * h)
     dx = torch.empty((L * B, din), dtype=torch.float32, device=dev)
     ops.gemm(dz2, tW[:din], dx, ws, transB=True)
-    np.testing.assert_allclose(dx.cpu().numpy(), r_dx.reshape(L * B, din), rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(dx.cpu().numpy(), r_dx.reshape(L * B, din), rtol=1e-4, atol=1e-4)
     dW = torch.zeros((din + h, 4 * h), dtype=torch.float32, device=dev)
     ops.gemm(_t(dev, x).view(L * B, din), dz2, dW[:din], ws, transA=True)
     if L > 1:
         ops.gemm(hs.view(L * B, h)[:(L - 1) * B], dz2[B:], dW[din:], ws, transA=True)
-    np.testing.assert_allclose(dW.cpu().numpy(), r_dW, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(dW.cpu().numpy(), r_dW, rtol=1e-4, atol=2e-4)
     db = torch.empty(4 * h, dtype=torch.float32, device=dev)
     ops.col_sum(dz2, db, ws)
-    np.testing.assert_allclose(db.cpu().numpy(), r_db, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), r_db, rtol=1e-4, atol=2e-4)
 
 
 def test_loss_pos_variants_equal_mask_array(dev):
@@ -714,9 +714,9 @@ def test_sparse_adagrad_cat_fast_path(dev, d, Vf, ns):
         assert int((first != 2 ** 31 - 1).sum().item()) == 0 and int(cnt.abs().sum().item()) == 0
         assert int(hot[:2].abs().sum().item()) == 0
     for o in (outs[0], outs[2]):
-        np.testing.assert_allclose(o[1].cpu().numpy(), racc, rtol=2e-4, atol=1e-5)
-        np.testing.assert_allclose(o[0].cpu().numpy(), rE, rtol=2e-4, atol=2e-5)
-        np.testing.assert_allclose(o[2].cpu().numpy(), rb, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(o[1].cpu().numpy(), racc, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(o[0].cpu().numpy(), rE, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(o[2].cpu().numpy(), rb, rtol=1e-4, atol=2e-5)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[2][0], outs[3][0]) and torch.equal(outs[2][1], outs[3][1])
 
@@ -804,11 +804,11 @@ def test_sparse_adagrad_cat_multi_with_multihot_segments(dev, B):
     lr = torch.tensor([0.3], dtype=torch.float32, device=dev)
     ops.sparse_adagrad_cat_multi(args, _t(dev, G), _t(dev, Gb), lr, kb, sb, cb, ws)
     torch.cuda.synchronize()
-    np.testing.assert_allclose(t0[0].cpu().numpy(), r0[0], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(t0[1].cpu().numpy(), r0[1], rtol=2e-4, atol=1e-5)
-    np.testing.assert_allclose(t1[0].cpu().numpy(), r1[0], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(t1[1].cpu().numpy(), r1[1], rtol=2e-4, atol=1e-5)
-    np.testing.assert_allclose(t1[2].cpu().numpy(), r1[2], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(t0[0].cpu().numpy(), r0[0], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(t0[1].cpu().numpy(), r0[1], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(t1[0].cpu().numpy(), r1[0], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(t1[1].cpu().numpy(), r1[1], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(t1[2].cpu().numpy(), r1[2], rtol=1e-4, atol=2e-5)
     assert int(t0[4].abs().sum().item()) == 0 and int(t1[4].abs().sum().item()) == 0
 
 
@@ -887,10 +887,10 @@ def test_sparse_adagrad_cat_multi(dev, d, rows, ns):
         outs.append(dtab)
     for t in range(nt):
         rE, racc, rb, rbacc = refs[t]
-        np.testing.assert_allclose(outs[0][t][1].cpu().numpy(), racc, rtol=2e-4, atol=1e-5)
-        np.testing.assert_allclose(outs[0][t][0].cpu().numpy(), rE, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(outs[0][t][1].cpu().numpy(), racc, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(outs[0][t][0].cpu().numpy(), rE, rtol=1e-4, atol=2e-5)
         if tabs[t]['has_bias']:
-            np.testing.assert_allclose(outs[0][t][2].cpu().numpy(), rb, rtol=2e-4, atol=2e-5)
+            np.testing.assert_allclose(outs[0][t][2].cpu().numpy(), rb, rtol=1e-4, atol=2e-5)
         assert torch.equal(outs[0][t][0], outs[1][t][0]) and torch.equal(outs[0][t][1], outs[1][t][1])
 
 
@@ -990,10 +990,10 @@ def test_sparse_adagrad_bags(dev, d, n_ent, Vf, max_len, ns, phases):
         outs.append((tE, tacc, tb, tbacc))
         assert int(cnt.abs().sum().item()) == 0
     tE, tacc, tb, tbacc = outs[0]
-    np.testing.assert_allclose(tacc.cpu().numpy(), racc, rtol=2e-4, atol=1e-5)
-    np.testing.assert_allclose(tE.cpu().numpy(), rE, rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(tbacc.cpu().numpy(), rbacc, rtol=2e-4, atol=1e-5)
-    np.testing.assert_allclose(tb.cpu().numpy(), rb, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(tacc.cpu().numpy(), racc, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(tE.cpu().numpy(), rE, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(tbacc.cpu().numpy(), rbacc, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(tb.cpu().numpy(), rb, rtol=1e-4, atol=2e-5)
     for a, b in zip(outs[0], outs[1]):                 # bit-reproducible
         assert torch.equal(a, b)
     # no bias: the bias side is optional
@@ -1001,7 +1001,7 @@ def test_sparse_adagrad_bags(dev, d, n_ent, Vf, max_len, ns, phases):
     args = ops.BagSiteArgs([(_t(dev, ids), r0, c) for ids, r0, c in sites], max_len)
     ops.sparse_adagrad_bags(tE, tacc, None, None, tv, tst, tl, args, tG, None, lr_dev, ops.Workspace(dev),
                             gscale_dev=gs_dev)
-    np.testing.assert_allclose(tE.cpu().numpy(), rE, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(tE.cpu().numpy(), rE, rtol=1e-4, atol=2e-5)
 
 
 @pytest.mark.parametrize("d,n_ent,n_user,Vf,max_len,ns,phases", [
@@ -1136,7 +1136,7 @@ def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, p
     want_it = list(T_it) if virtual else list(R_it)          # virtual: the id table is not part of the pass
     for got, want in zip(outs[0], want_it + list(R_us) + list(R_bag)):
         if got is not None:
-            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-5)
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=2e-5)
     for a, b in zip(outs[0], outs[1]):                 # bit-reproducible
         assert a is None or torch.equal(a, b)
 
