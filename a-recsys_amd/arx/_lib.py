@@ -97,6 +97,7 @@ PROTOTYPES = {
     "arx_sample_wor_workspace_bytes": (sz, [i64]),
     "arx_sample_wor": (cint, [f32p, i64, i64, u64, u64, i32p, vp, sz, vp]),
     "arx_sample_wor_capped": (cint, [f32p, i64, i64, u64, u64, f32, i32p, vp, sz, vp]),
+    "arx_sample_wor_keys": (cint, [f32p, i64, i64, u64, u64, f32, i32p, f32p, vp, sz, vp]),
     "arx_loss_rs_fwdbwd": (cint, [f32p, i64, i32p, u8p, i64, i32p, i32p, i32p, i32p, i64, cint, cint,
                                   f32, f32, f32p, i64, i64, f32p, f32p, i64, vp]),
     "arx_loss_ce_fwdbwd": (cint, [f32p, i64, i32p, f32, f32p, i64, i64, f32p, f32p, i64, vp]),

@@ -160,12 +160,13 @@ class ShardedHMF(object):
 
     def __init__(self, n_users, n_items, d, B_loc, S, learning_rate, rank, world, device,
                  backend=None, group=None, tables=None, seed=0, acc0=0.1):
-        if S % world != 0:
-            raise ValueError("n_sampled must be divisible by the world size (stratified pool)")
-        if (S // world) % 4 != 0 or d % 4 != 0:
-            raise ValueError("S/world and d must be multiples of 4")
+        if S % 4 != 0 or d % 4 != 0:
+            raise ValueError("n_sampled and d must be multiples of 4")
         self.n_users, self.n_items, self.d = n_users, n_items, d
-        self.B_loc, self.S, self.Sg = B_loc, S, S // world
+        # The shared pool is ONE draw over all items (prepare_train.py:7-17), so the number of pool items
+        # a rank owns varies from draw to draw: the owned blocks travel padded to `cap` rows (the largest
+        # owner count of the current pool, a multiple of 4; set_pool).  Sg = capacity of a block.
+        self.B_loc, self.S, self.Sg = B_loc, S, S
         self.rank, self.world = rank, world
         self.B = B_loc * world
         self.device = torch.device(device)
@@ -209,7 +210,11 @@ class ShardedHMF(object):
         self.urows = zi(B_loc)
         self.U_loc = z(B_loc, d)
         self.pool_ids = zi(S)                               # owner-major global ids
-        self.pool_rows = zi(Sg)                             # local rows of the owned block
+        self.pool_rows = zi(Sg)                             # local rows of the owned block (padding row behind it)
+        self.cap = S if world == 1 else 0                   # rows of a block in the current exchange
+        self.gidx = zi(S)                                   # pool slot -> row of the gathered blocks
+        self.my_slots = zi(S)                               # block row -> pool slot (S: none, a zero row)
+        self.I_gath = z(world * S, dp) if world > 1 else None
         self.pool_old = None
         self.item2slot = torch.full((n_items + 1,), -1, dtype=i32, device=dev)
         if hasattr(self.be, 'attach_pool_bitmap'):          # (1 bit per item in front of the map: HIP backend)
@@ -222,7 +227,7 @@ class ShardedHMF(object):
         self.t_loc, self.dt_loc = z(B_loc), z(B_loc)
         self.bl, self.loss = z(B_loc), z(1)
         self.dlogits = z(B_loc, S)
-        self.dI_all, self.gb_all = z(S, dp), z(S)           # pool-gradient partials (all columns)
+        self.dI_all, self.gb_all = z(S + 1, dp), z(S)       # pool-gradient partials (all columns) + a zero row
         self.dT_pack = z(B_loc, dp)                         # target-row gradients to send
         self.cap_r = 0                                      # capacity for received target rows
         self._alloc_recv(B_loc)
@@ -257,8 +262,10 @@ class ShardedHMF(object):
         self.pos_items = it.to(dev, torch.int32)
 
     def set_pool(self, pool_ids):
-        """Stratified shared pool: pool_ids[g*Sg:(g+1)*Sg] must be owned by rank g
-        (embed_attribute.py:320-348 update_sampled, sharded)."""
+        """The shared negative pool, global item ids in slot order -- any owners (one draw over all
+        items: embed_attribute.py:320-348 update_sampled, sharded).  Every rank sees the same ids and
+        derives the same block layout: owner g's pool items, in slot order, are rows [0, count_g) of
+        its block; all blocks travel padded to cap = max_g count_g rows."""
         be = self.be
         new = pool_ids if isinstance(pool_ids, torch.Tensor) else \
             torch.as_tensor(np.asarray(pool_ids, dtype=np.int32))
@@ -270,8 +277,27 @@ class ShardedHMF(object):
         be.copy_i32(new, self.pool_ids)
         be.copy_i32(new, self.pool_old)
         be.slot_map_set(self.item2slot, self.pool_ids, False)
-        mine = self.pool_ids[self.rank * self.Sg:(self.rank + 1) * self.Sg]
-        be.shard_route(mine, self.world, self.rank, self.zero_row, self.pool_rows, None)
+        W, r, S = self.world, self.rank, self.S
+        if W == 1:
+            be.shard_route(self.pool_ids, W, r, self.zero_row, self.pool_rows, None)
+            return
+        # block layout (redraw path, every n_resample steps: index arithmetic on S ids, one host read)
+        ids = self.pool_ids.long()
+        owner = ids % W
+        order = torch.argsort(owner, stable=True)                       # slots by owner, slot order inside
+        counts = torch.bincount(owner, minlength=W)
+        start = torch.cumsum(counts, 0) - counts
+        cap = (int(counts.max().item()) + 3) // 4 * 4
+        self.cap = cap
+        pos = torch.empty(S, dtype=torch.int64, device=self.device)
+        pos[order] = torch.arange(S, device=self.device) - start[owner[order]]
+        self.gidx.copy_((owner * cap + pos).to(torch.int32))
+        cnt_r, st_r = int(counts[r].item()), int(start[r].item())
+        mine = order[st_r:st_r + cnt_r]
+        self.my_slots.fill_(S)
+        self.my_slots[:cnt_r] = mine.to(torch.int32)
+        self.pool_rows.fill_(self.zero_row)
+        self.pool_rows[:cnt_r] = (ids[mine] // W).to(torch.int32)
 
     # ------------------------------------------------------------------ route
     def prepare_route(self, users, items):
@@ -328,8 +354,13 @@ class ShardedHMF(object):
         urows, recv_rows = route['urows'], route['recv_rows']
         self.urows = urows
         be.gather_rows(self.E_user, None, urows, self.U_loc, None)
-        be.gather_rows_packed(self.E_item, self.b_item, self.pool_rows, self.I_pack)   # row | bias
-        dist.all_gather_into_tensor(self.I_all, self.I_pack, group=grp)
+        cap = self.cap
+        if W == 1:
+            be.gather_rows_packed(self.E_item, self.b_item, self.pool_rows, self.I_all)   # row | bias
+        else:
+            be.gather_rows_packed(self.E_item, self.b_item, self.pool_rows[:cap], self.I_pack[:cap])
+            dist.all_gather_into_tensor(self.I_gath[:W * cap], self.I_pack[:cap], group=grp)
+            be.gather_rows(self.I_gath, None, self.gidx, self.I_all, None)    # blocks -> pool (slot) order
         be.copy_strided(self.I_all[:, d], self.b_all)
         T_send = self.T_send[:R]
         if R > 0:
@@ -350,13 +381,18 @@ class ShardedHMF(object):
                                       async_op=True)                  # target-row gradients -> owners ...
         be.gemm(self.dlogits, self.I_all[:, :d], dU, beta=1.0)                # ... under dU += dL . pool
         # pool gradient partials (+ bias gradient = row sums) -> owners
-        be.gemm(self.dlogits, self.U_loc, self.dI_all[:, :d], transA=True, a_rowsum=self.gb_all)
-        be.copy_strided(self.gb_all, self.dI_all[:, d])
-        dist.reduce_scatter_tensor(arena[B_loc:B_loc + Sg], self.dI_all, op=dist.ReduceOp.SUM, group=grp)
+        be.gemm(self.dlogits, self.U_loc, self.dI_all[:S, :d], transA=True, a_rowsum=self.gb_all)
+        be.copy_strided(self.gb_all, self.dI_all[:S, d])
+        if W == 1:
+            be.copy_2d(self.dI_all[:S], arena[B_loc:B_loc + S])
+        else:
+            # 0.5 MB: summed everywhere, every owner picks the rows of its block (padding -> the zero row)
+            dist.all_reduce(self.dI_all[:S], op=dist.ReduceOp.SUM, group=grp)
+            be.gather_rows(self.dI_all, None, self.my_slots[:cap], arena[B_loc:B_loc + cap], None)
         w_dt.wait()
         be.copy_strided(arena[B_loc:B_loc + Sg + R, d], arena_b[B_loc:B_loc + Sg + R])
         # one fused scatter + Adagrad pass over both shards
-        sites = [(0, self.urows, 0), (1, self.pool_rows, B_loc)]
+        sites = [(0, self.urows, 0), (1, self.pool_rows[:cap], B_loc)]
         if R > 0:
             sites.append((1, recv_rows, B_loc + Sg))
         be.sparse_adagrad_multi([(self.E_user, self.A_user, None, None),
@@ -737,6 +773,73 @@ def _zipf_items(n, n_items, gen, dev):
     return (_hash_u32(rk, 12345) % n_items).to(torch.int32)
 
 
+def draw_global_pool(sampler, S, group=None):
+    """ONE weighted draw without replacement of S items over an item set whose weights are sharded over
+    the ranks of `group` (utils/prepare_train.py:7-17 draws the pool from one distribution): every rank
+    races its own shard (sampler.sample_with_keys: exponential keys -ln(u)/w, weights on a common
+    scale, independent seeds), the ranks exchange their S smallest (key, id) pairs -- 8 KB each -- and
+    every rank keeps the S smallest keys of the union: the S smallest keys of the whole item set, the
+    single-process draw.  Identical on every rank (stable order: key, then rank, then position)."""
+    ids, keys = sampler.sample_with_keys(S)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world > 1:
+        allk = torch.empty(world * S, dtype=keys.dtype, device=keys.device)
+        alli = torch.empty(world * S, dtype=ids.dtype, device=ids.device)
+        dist.all_gather_into_tensor(allk, keys.contiguous(), group=group)
+        dist.all_gather_into_tensor(alli, ids.contiguous(), group=group)
+        ids = alli[torch.argsort(allk, stable=True)[:S]]
+    if int(ids.min().item()) < 0:
+        raise ValueError("draw_global_pool(%d): fewer items with a positive weight in all shards together" % S)
+    return ids
+
+
+def _time_collective(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    t = torch.tensor([e0.elapsed_time(e1) / iters], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+XGMI_LINK_GBS = 153.0     # per direction and link, 7 links per GPU (SURVEY section 5 / MI355X_MICROARCH.md)
+
+
+def comm_roofline(model, world, grp=None):
+    """The step's collectives alone, at the step's payloads (every rank calls it): achieved GB/s per
+    rank against what its xGMI links allow.  A rank moves (N-1)/N of a payload P over N-1 links in an
+    all_gather / all_to_all, 2 (N-1)/N in an all_reduce: with every link busy the floor is
+    P / N / 153 GB/s (twice that for the all_reduce)."""
+    if world == 1:
+        return {"note": "one rank: every exchange is a local copy, no xGMI traffic"}
+    S, dp, B_loc, cap = model.S, model.dp, model.B_loc, max(model.cap, 4)
+    out = {}
+    x_pack, x_gath = model.I_pack[:cap], model.I_gath[:world * cap]
+    rows = torch.zeros((B_loc, dp), dtype=torch.float32, device=model.device)
+    back = torch.zeros_like(rows)
+    g = torch.zeros((S, dp), dtype=torch.float32, device=model.device)
+    cases = [
+        ("all_gather_pool_blocks", lambda: dist.all_gather_into_tensor(x_gath, x_pack, group=grp),
+         cap * dp * 4 * world, 1.0),
+        ("all_to_all_target_rows", lambda: dist.all_to_all_single(back, rows, group=grp), B_loc * dp * 4, 1.0),
+        ("all_reduce_pool_grads", lambda: dist.all_reduce(g, op=dist.ReduceOp.SUM, group=grp), S * dp * 4, 2.0),
+    ]
+    for name, fn, payload, factor in cases:
+        ms = _time_collective(fn)
+        wire = payload * factor * (world - 1) / world               # bytes this rank sends (= receives)
+        floor_ms = wire / (world - 1) / (XGMI_LINK_GBS * 1e9) * 1e3   # all N-1 links busy
+        out[name] = {"payload_bytes": payload, "ms": ms, "achieved_gbs_per_rank": wire / ms / 1e6,
+                     "peak_gbs_per_rank": XGMI_LINK_GBS * (world - 1), "frac": floor_ms / ms}
+    return out
+
+
 def bench_run(args, world, rank, local_rank, init_pg=True):
     """The N-rank bench body (every rank calls it); returns the JSON dict on rank 0, None elsewhere.
     world == 1 runs the very same sharded step on one GPU (all "exchanges" local): the anchor of
@@ -777,11 +880,12 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
         users = (lu * world + rank).to(torch.int32)
         items = pos_items[(lu * n_pos + k)]
         batches.append(model.prepare_route(users, items))      # data-loader side: order by owner
-    # Shared negative pool, stratified by owner: every rank draws S/N of ITS OWN items without
-    # replacement with p ~ count^0.5 (prepare_train.py:19-35 item_frequency over the training
-    # interactions, run_hmf.py:62 power = 0.5) on device (arx_sample_wor), and one 4 KB
-    # all_gather hands every rank the whole pool, owner-major -- inside the timed region, every
-    # n_resample steps.  Setup: global interaction counts of the owned items (one reduce_scatter).
+    # Shared negative pool: ONE draw of S items without replacement with p ~ count^0.5 over ALL items
+    # (prepare_train.py:7-35 sample_items over item_frequency, run_hmf.py:62 power = 0.5): every rank
+    # races its own shard on device (arx_sample_wor_keys), the ranks exchange their S best (key, id)
+    # pairs (8 KB each) and keep the S smallest keys of the union (draw_global_pool) -- inside the
+    # timed region, every n_resample steps.  Setup: global interaction counts of the owned items (one
+    # reduce_scatter).
     from .utils.prepare_train import DeviceSampler
     rows = (args.n_items + world - 1) // world
     from . import ops as _ops
@@ -800,16 +904,9 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
     own = torch.arange(rows, device=dev, dtype=torch.int64) * world + rank
     wts[own >= args.n_items] = 0.0
     sampler = DeviceSampler(own.to(torch.int32), wts, device=dev, seed=4242 + rank)
-    Sg = S // world
-    pool_buf = torch.empty(S, dtype=torch.int32, device=dev)
-
     def redraw():
-        part = sampler.sample(Sg)
-        if world > 1:
-            dist.all_gather_into_tensor(pool_buf, part)
-        else:
-            pool_buf.copy_(part)
-        model.set_pool(pool_buf)
+        # ONE draw of S items over all shards (draw_global_pool): the reference's sampling law at any N
+        model.set_pool(draw_global_pool(sampler, S))
     torch.cuda.synchronize()
     dist.barrier()
     setup_s = time.time() - t_setup
@@ -836,6 +933,7 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
     loss = float(model.read_loss().item())
+    comm = comm_roofline(model, world) if not with_bags else None
     # roofline of the dominant kernel (the local scorer GEMM [B_loc, S] x d), HIP events on the
     # stream the kernel runs on; same definition as the single-GPU bench line
     out = None
@@ -868,10 +966,10 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
                                     "all_gather(target grads), arx.dist.ShardedHMFBags) -- " if with_bags else "") +
                                    "C5 (BASELINE configs[4]): synthetic %d-item/%d-user HMF, dim %d, id-only, WMRB 'mw', "
                                    "item and user tables row-sharded over %d GPU(s) (owner = id %% N), %d shared "
-                                   "negatives/step, S/N per owner drawn on device with p ~ count^0.5 and all-gathered "
-                                   "every %d steps (%d redraw(s) inside the timed region); per step: RCCL "
-                                   "all_gather(pool rows) + all_to_all(target rows, target grads) + "
-                                   "reduce_scatter(pool grads); B_loc=%d per GPU.  The batch ROUTING (order by owner, "
+                                   "negatives/step = ONE draw over all shards with p ~ count^0.5 (per-rank races on device, "
+                                   "the S best keys of the union) every %d steps (%d redraw(s) inside the timed region); "
+                                   "per step: RCCL all_gather(pool rows, blocks padded to the largest owner count) + "
+                                   "all_to_all(target rows, target grads) + all_reduce(pool grads); B_loc=%d per GPU.  The batch ROUTING (order by owner, "
                                    "count / id exchange: data-loader work, ShardedHMF.prepare_route) is done once per "
                                    "batch of the %d-batch ring, OUTSIDE the timed loop"
                                    % (args.n_items, args.n_users, d, world, S, args.n_resample, redraws[0], B_loc, nb),
@@ -880,7 +978,11 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
                        "routing_in_timed_region": False, "pool_redraws_timed": redraws[0],
                        "sampled_negative_logits_per_s": B * S * args.steps / wall,
                        "final_loss": loss, "setup_s": setup_s},
-            "roofline": roofline, "cpu_baseline": None,
+            "roofline": roofline, "roofline_comm": comm,
+            "cpu_baseline": {"value": None, "unit": "interactions/s", "cores": None, "kind": "port",
+                             "sample": None,
+                             "why": "timed on rank 0 at N = 1 only (bench contract): the N = 1 line of the same run "
+                                    "carries the reference-algorithm restatement on this box's host cores"},
         }
     del model
     torch.cuda.empty_cache()

@@ -127,6 +127,26 @@ class DeviceSampler(object):
         self._caps[n] = cap
         return cap
 
+    def sample_with_keys(self, n):
+        """-> (item ids int32 [n], race keys float32 [n], ascending): this sampler's part of ONE draw over
+        an item set sharded over several ranks (arx.dist.draw_global_pool keeps the n smallest keys of
+        the union).  Where the shard has fewer than n items of positive weight the tail is
+        (id -1, key +inf)."""
+        import torch
+        if self._npos is None:
+            self._npos = int((self.w > 0).sum().item())
+        m = min(int(n), self._npos)
+        dev = self.w.device
+        ids = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        keys = torch.full((n,), float('inf'), dtype=torch.float32, device=dev)
+        if m > 0:
+            pos = torch.empty((m,), dtype=torch.int32, device=dev)
+            self._ops.sample_wor(self.w, m, self.seed, self.counter, pos, self.ws, key_cap=self._cap_for(m),
+                                 out_keys=keys[:m])
+            ids[:m] = self.items[pos.long()]
+        self.counter += 1
+        return ids, keys
+
     def sample(self, n, out=None):
         """-> int32 device tensor [n] of item ids (draw order).  The id->slot map the reference
         builds next (prepare_train.py:12-16) is the model's device slot map (update_sampled_pool)."""

@@ -49,10 +49,14 @@ __global__ __launch_bounds__(256) void k_race_keys(const float* __restrict__ w, 
   }
 }
 
-__global__ void k_take_first(const int32_t* __restrict__ src, const int32_t* __restrict__ n_live,
-                             int64_t S, int32_t* __restrict__ out) {
+__global__ void k_take_first(const int32_t* __restrict__ src, const uint32_t* __restrict__ keys,
+                             const int32_t* __restrict__ n_live, int64_t S, int32_t* __restrict__ out,
+                             float* __restrict__ out_keys) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < S) out[i] = (i < *n_live) ? src[i] : -1;
+  if (i >= S) return;
+  const bool live = i < *n_live;
+  out[i] = live ? src[i] : -1;
+  if (out_keys) out_keys[i] = live ? __uint_as_float(keys[i]) : __uint_as_float(kInfBits);
 }
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -125,6 +129,13 @@ int arx_sample_wor(const float* weights, int64_t n, int64_t S, uint64_t seed, ui
 int arx_sample_wor_capped(const float* weights, int64_t n, int64_t S, uint64_t seed, uint64_t counter,
                           float key_cap, int32_t* out_idx, void* workspace, size_t workspace_bytes,
                           void* stream) {
+  return arx_sample_wor_keys(weights, n, S, seed, counter, key_cap, out_idx, nullptr, workspace, workspace_bytes,
+                             stream);
+}
+
+int arx_sample_wor_keys(const float* weights, int64_t n, int64_t S, uint64_t seed, uint64_t counter,
+                        float key_cap, int32_t* out_idx, float* out_keys, void* workspace,
+                        size_t workspace_bytes, void* stream) {
   ARX_CHECK_ARG(weights && out_idx, "arx_sample_wor: null pointer");
   ARX_CHECK_ARG(n > 0 && n < (int64_t)0x7fffffff && S > 0 && S <= n, "arx_sample_wor: need 0 < S <= n < 2^31");
   const size_t need = arx_sample_wor_workspace_bytes(n);
@@ -155,7 +166,7 @@ int arx_sample_wor_capped(const float* weights, int64_t n, int64_t S, uint64_t s
   int rc = launch_radix_sort(keys_raw, nullptr, nullptr, n, kInfBits, 31, keys_tmp, keys_out, src_tmp,
                              src_out, coef_tmp, coef_out, hist, nullptr, n_live, s);
   if (rc) return rc;
-  k_take_first<<<(int)ceil_div(S, 256), 256, 0, s>>>(src_out, n_live, S, out_idx);
+  k_take_first<<<(int)ceil_div(S, 256), 256, 0, s>>>(src_out, keys_out, n_live, S, out_idx, out_keys);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

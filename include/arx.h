@@ -257,6 +257,15 @@ int arx_sample_wor(const float* weights, int64_t n, int64_t S, uint64_t seed, ui
 int arx_sample_wor_capped(const float* weights, int64_t n, int64_t S, uint64_t seed, uint64_t counter,
                           float key_cap, int32_t* out_idx, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* ... and the race keys of the drawn items (out_keys [S], ascending; +inf where out_idx is -1; NULL:
+ * not wanted).  For ONE draw over an item set that is sharded over several ranks (the reference draws
+ * its S negatives from one distribution, prepare_train.py:7-17): every rank races its own shard
+ * -- weights on a common scale, independent seeds --, the ranks exchange their S smallest (key, id)
+ * pairs and keep the S smallest of the union: the S smallest keys of the whole item set, i.e. exactly
+ * the single-process draw (arx.dist.draw_global_pool). */
+int arx_sample_wor_keys(const float* weights, int64_t n, int64_t S, uint64_t seed, uint64_t counter,
+                        float key_cap, int32_t* out_idx, float* out_keys, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* rs / rs-sig / rs-sig2 / bbpr losses (embed_attribute.py:551-603 _compute_rs_loss) over full
  * logits [B, V], forward + backward fused.  kind: 0 rs, 1 rs-sig, 2 rs-sig2, 3 bbpr;

@@ -1,4 +1,4 @@
-"""world_size-2 and -4 gloo tests of the row-sharded HMF step (arx.dist.ShardedHMF):
+"""world_size-2, -3 and -4 gloo tests of the row-sharded HMF step (arx.dist.ShardedHMF):
 the exchange / routing logic with a numpy compute double must reproduce the
 single-process oracle step on the global batch (loss and updated tables) -- including
 steps whose targets are spread unevenly over the owners and a step in which some ranks
@@ -53,12 +53,19 @@ def _worker(rank, world, port, out_dir):
     rng = np.random.default_rng(5)          # identical stream on both ranks
     for step in range(5):
         pool = None
-        if step % 2 == 0:                   # stratified pool: S/world items per owner, owner-major
-            blocks = []
-            for g in range(world):
-                cand = np.arange(g, n_items, world)
-                blocks.append(rng.choice(cand, size=S // world, replace=False))
-            pool = np.concatenate(blocks).astype(np.int32)
+        if step % 2 == 0:
+            # the pool is ONE draw over all items (prepare_train.py:7-17): any owners, in any order --
+            # step 0 the usual mixed case, step 2 every pool item on ONE owner (the other ranks' blocks
+            # are all padding), step 4 a skewed mix
+            if step == 0:
+                pool = rng.choice(n_items, size=S, replace=False)
+            elif step == 2:
+                pool = rng.choice(np.arange(world - 1, n_items, world), size=S, replace=False)
+            else:
+                hot = rng.choice(np.arange(0, n_items, world), size=(3 * S) // 4, replace=False)
+                rest = rng.choice(np.setdiff1d(np.arange(n_items), hot), size=S - len(hot), replace=False)
+                pool = rng.permutation(np.concatenate([hot, rest]))
+            pool = pool.astype(np.int32)
             id2idx = {int(v): i for i, v in enumerate(pool)}
             model.set_pool(pool)
         gu, gi = [], []
@@ -71,7 +78,7 @@ def _worker(rank, world, port, out_dir):
         gu[0][1] = gu[0][0]                 # duplicate user / target rows
         gi[1][2] = gi[1][3]
         if step == 0:
-            gi[0][0] = pool[S // world]     # a target that is also a pool slot (owned by rank 1)
+            gi[0][0] = pool[np.nonzero(pool % world == 1)[0][0]]     # a target that is also a pool slot (owned by rank 1)
         if step == 3:                       # every target owned by rank 0: R = 0 on all other ranks
             for g in range(world):
                 gi[g] = (rng.integers(0, n_items // world, size=B_loc) * world).astype(gi[g].dtype)
@@ -94,7 +101,7 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_sharded_step_matches_oracle_gloo(tmp_path, world):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() % 400) + world
@@ -234,3 +241,60 @@ def test_token_sharded_bags_match_oracle_gloo(tmp_path, world):
     port = 29300 + (os.getpid() % 400) + world
     mp.spawn(_bags_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ("bags%d" % r)) for r in range(world))
+
+
+def _pool_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "a-recsys_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arx.dist import draw_global_pool
+    n_items, S = 997, 64
+    rng = np.random.default_rng(123)                 # the same weights and uniforms on every rank
+    w = (1.0 / np.arange(1, n_items + 1) ** 1.2)
+    w[rng.integers(0, n_items, 50)] = 0.0
+
+    class Shard(object):
+        """Stand-in for DeviceSampler.sample_with_keys on this rank's rows (id % world == rank): the
+        exponential race arx_sample_wor_keys runs on device, here in numpy."""
+        def __init__(self):
+            self.draw = 0
+
+        def sample_with_keys(self, n):
+            u = np.random.default_rng(1000 + self.draw).random(n_items)       # one uniform per ITEM, any world
+            self.draw += 1
+            keys = np.where(w > 0, -np.log(u) / np.maximum(w, 1e-300), np.inf)
+            mine = np.arange(rank, n_items, world)
+            order = mine[np.argsort(keys[mine], kind='stable')][:n]
+            ids = np.full(n, -1, dtype=np.int32)
+            ks = np.full(n, np.inf, dtype=np.float32)
+            live = np.isfinite(keys[order])
+            ids[:live.sum()] = order[live]
+            ks[:live.sum()] = keys[order][live]
+            return torch.from_numpy(ids), torch.from_numpy(ks)
+    sh = Shard()
+    for draw in range(3):
+        pool = draw_global_pool(sh, S).numpy()
+        u = np.random.default_rng(1000 + draw).random(n_items)
+        keys = np.where(w > 0, -np.log(u) / np.maximum(w, 1e-300), np.inf).astype(np.float32)
+        want = np.argsort(keys, kind='stable')[:S]                              # the single-process draw
+        np.testing.assert_array_equal(np.sort(pool), np.sort(want))
+        np.testing.assert_array_equal(keys[pool], np.sort(keys[want]))          # ... in draw order
+    with open(os.path.join(out_dir, "ok%d" % rank), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_global_pool_draw_equals_single_process_draw_gloo(tmp_path, world):
+    """arx.dist.draw_global_pool: per-rank races over the owned rows + the S best keys of the union ==
+    the S smallest keys over ALL items (the reference's one draw, utils/prepare_train.py:7-17), the
+    same pool on every rank -- not S/N items per owner."""
+    import torch.multiprocessing as mp
+    port = 29950 + (os.getpid() % 40) + world
+    mp.spawn(_pool_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
