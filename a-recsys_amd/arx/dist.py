@@ -62,18 +62,20 @@ class HipBackend(object):
         """Two-stage multi-hot pass (arx_sparse_adagrad_bags); sites: [(entity ids, row_base, coef)].
         Tokens >= E.shape[0] (rows of other shards, mapped to the padding row) are dropped."""
         ops = self.ops
-        key = tuple((i.data_ptr(), int(i.shape[0]), b, c) for i, b, c in sites)
+        # one workspace per SHAPE of the pass (counts, row bases, coefficients); the id tensors may be
+        # fresh every step (prepare_route): only the pointer arrays are rebuilt then
+        key = tuple((int(i.shape[0]), b, c) for i, b, c in sites)
+        ptrs = tuple(i.data_ptr() for i, _, _ in sites)
         cache = self.__dict__.setdefault('_bags', {})
         ent = cache.get(key)
+        mx = self.__dict__.setdefault('_bag_maxlen', {})
+        if lens.data_ptr() not in mx:
+            mx[lens.data_ptr()] = (lens, int(lens.max().item()))      # (the tensor is kept: its address stays its own)
         if ent is None:
-            if len(cache) > 64:
-                cache.clear()
-            mx = self.__dict__.setdefault('_bag_maxlen', {})
-            if lens.data_ptr() not in mx:
-                mx[lens.data_ptr()] = int(lens.max().item())
-            ent = cache[key] = (ops.BagSiteArgs(sites, mx[lens.data_ptr()]), ops.Workspace(G.device))
-        args, ws = ent
-        ops.sparse_adagrad_bags(E, acc, bias, bias_acc, vals, starts, lens, args, G, Gb, lr, ws)
+            ent = cache[key] = [None, None, ops.Workspace(G.device)]
+        if ent[0] != ptrs:
+            ent[0], ent[1] = ptrs, ops.BagSiteArgs(sites, mx[lens.data_ptr()][1])
+        ops.sparse_adagrad_bags(E, acc, bias, bias_acc, vals, starts, lens, ent[1], G, Gb, lr, ent[2])
 
     def gather_rows_packed(self, E, bias, rows, out):
         self.ops.gather_onehot_packed(E, bias, None, rows, out)

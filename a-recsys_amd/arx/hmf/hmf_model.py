@@ -187,15 +187,15 @@ class LatentProductModel(object):
                  logit_size_test=None, nonlinear=None, dropout=1.0, n_sampled=None,
                  indices_item=None, dtype='float32', top_N_items=100, hidden_size=500,
                  loss_func='log', loss_exp_p=1.005, params=None, use_graph=True, seed=0,
-                 mw_eval_unmasked=False):
+                 mw_eval_unmasked=True):
         self.user_size = user_size
         self.item_size = item_size
         self.top_N_items = top_N_items
         # 'mw' models evaluate with the full-vocabulary 'warp' loss (:130,144).  The reference's
         # step() only runs set_mask['mw'] (:209-210), so ITS eval loss sees an all-True warp mask
-        # (the target column itself adds relu(0 + 1) = 1 inside the log).  Default here: the user's
-        # eval positives ARE masked (what the masks are for); mw_eval_unmasked=True reproduces the
-        # reference's unmasked number for parity comparisons.
+        # (the target column itself adds relu(0 + 1) = 1 inside the log).  That is the default
+        # (run_hmf.py selects checkpoints, patience and learning-rate decay on this number);
+        # mw_eval_unmasked=False masks the user's eval positives instead (what the masks are for).
         self.mw_eval_unmasked = bool(mw_eval_unmasked)
         if user_attributes is not None:
             user_attributes.set_model_size(size)             # hmf_model.py:34-36

@@ -608,7 +608,11 @@ class RefLatentProductModel(object):
                  item_ind2logit_ind, logit_ind2item_ind, loss_function='ce',
                  n_sampled=None, params=None, dtype=np.float32, top_N_items=100,
                  nonlinear='linear', hidden_size=500, loss_func='log', loss_exp_p=1.005,
-                 learning_rate_decay_factor=1.0):
+                 learning_rate_decay_factor=1.0, mw_eval_unmasked=True):
+        # mw_eval_unmasked: step() only runs set_mask[loss_function] (hmf_model.py:209-210), so the
+        # 'warp' mask of an 'mw' model's evaluation graph keeps its initial all-True value -- the
+        # reference's eval loss of an 'mw' model does NOT mask the user's positives.  False: masked.
+        self.mw_eval_unmasked = bool(mw_eval_unmasked)
         user_attributes.set_model_size(size)        # hmf_model.py:35
         item_attributes.set_model_size(size)        # :38
         self.loss_function = loss_function
@@ -703,7 +707,10 @@ class RefLatentProductModel(object):
             logits, _ = m.get_prediction(u, 'full')
             mask = None
             if the_loss != 'ce':
-                mask = m.mask(user_input, the_loss, None, forward_only=True)
+                if loss == 'mw' and self.mw_eval_unmasked:
+                    mask = np.ones(logits.shape, dtype=bool)        # the 'warp' mask variable's initial value
+                else:
+                    mask = m.mask(user_input, the_loss, None, forward_only=True)
             bl, _ = m.compute_loss(logits, targets, the_loss, mask, self.loss_func, self.loss_exp_p)
             return self.dt.type(bl.mean())
         if loss in ('mw', 'mce'):

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 N, D, B, S = 1000000, 128, 16384, 1024
 
 
-def _model(mulhot, use_graph=True, seed=0):
+def _model(mulhot, use_graph=True, seed=0, **kw):
     from arx.hmf.hmf_model import LatentProductModel
     from arx.utils.synthetic import SyntheticHMF
     syn = SyntheticHMF(n_users=N, n_items=N, item_mulhot=mulhot, permute_logits=False, seed=seed)
@@ -326,7 +326,7 @@ def test_fullsize_streaming_eval(dev):
     [B, V] logits never exist -- and, for a sample of rows, equal to an fp64 numpy evaluation of
     the same rows against the model's tables (positives of the row's user masked)."""
     from arx import graph as G
-    syn, model = _model(True)
+    syn, model = _model(True, mw_eval_unmasked=False)     # the masked form: positives taken out of the streamed sums
     assert isinstance(model.loss_eval.inputs[0], G.StreamEvalLoss)
     d_ = model.rt.device
     batches, pool = _batches(syn, d_, 1)

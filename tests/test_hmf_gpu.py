@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-4, 2e-6
 
 
-def _build(cfg, loss, d, B, S, seed, nonlinear='linear', use_graph=True, loss_func='log', exp_p=1.005):
+def _build(cfg, loss, d, B, S, seed, nonlinear='linear', use_graph=True, loss_func='log', exp_p=1.005,
+           mw_eval_unmasked=True):
     from arx.utils.synthetic import SyntheticHMF
     from arx.hmf.hmf_model import LatentProductModel
     syn = SyntheticHMF(seed=seed, **cfg)
@@ -29,11 +30,12 @@ def _build(cfg, loss, d, B, S, seed, nonlinear='linear', use_graph=True, loss_fu
     model = LatentProductModel(syn.n_users, syn.n_items, d, 1, B, 0.5, 1.0, syn.u_attr, syn.i_attr,
                                i2l, l2i, loss_function=loss, n_sampled=n_s, params=params,
                                nonlinear=nonlinear, hidden_size=48, top_N_items=10,
-                               use_graph=use_graph, loss_func=loss_func, loss_exp_p=exp_p)
+                               use_graph=use_graph, loss_func=loss_func, loss_exp_p=exp_p,
+                               mw_eval_unmasked=mw_eval_unmasked)
     ref = rg.RefLatentProductModel(d, B, 0.5, syn.u_attr, syn.i_attr, i2l, l2i, loss_function=loss,
                                    n_sampled=n_s, params=params, dtype=np.float64, top_N_items=10,
                                    nonlinear=nonlinear, hidden_size=48, loss_func=loss_func,
-                                   loss_exp_p=exp_p)
+                                   loss_exp_p=exp_p, mw_eval_unmasked=mw_eval_unmasked)
     pos = syn.positives_dict()
     if loss in ('mw', 'mce', 'warp', 'rs', 'rs-sig', 'rs-sig2', 'bbpr'):
         model.prepare_warp(pos, pos)
@@ -142,7 +144,9 @@ def test_c1_shape_ce_three_seeds(dev):
 
 
 def test_eval_recommend_and_logits(dev):
-    syn, model, ref = _build(CFG_HET, 'mw', 64, 32, 128, seed=5)
+    # (mw_eval_unmasked=False: the evaluation graph with the eval positives masked -- the numeric check of
+    # that form; the reference's default, unmasked, is what every other 'mw' test evaluates with)
+    syn, model, ref = _build(CFG_HET, 'mw', 64, 32, 128, seed=5, mw_eval_unmasked=False)
     rng = np.random.default_rng(2)
     users, items = syn.sample_batch(32, rng)
     pool = syn.sample_pool(128, rng)
