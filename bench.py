@@ -450,15 +450,16 @@ def run_hmf(args, name, steps, warmup, with_cpu=False):
                            "flops_per_launch": kr[dom]['flops'], "ms_per_launch": kr[dom]['ms']}
         k7 = kr['k7_step_fused']
         out["roofline_hbm"] = {
-            "kernel": "K7 scatter + sparse Adagrad, the step's fused passes over ALL tables (%s): sorts + "
-                      "merge/apply + finish, replayed in situ" % "+".join(k7['passes']),
+            "kernel": "K7 scatter + sparse Adagrad, the step's fused passes over ALL tables (%s): sorts + run "
+                      "records + apply (k_run_apply; the one-hot pass a bag table rides on: window apply + "
+                      "finish), replayed in situ" % "+".join(k7['passes']),
             "bound": "hbm", "achieved": k7['gbs'], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": k7['gbs'] / HBM_PEAK_GBS, "bytes_per_launch": k7['bytes'], "ms_per_launch": k7['ms'],
             "ms_sorts": k7.get('ms_sorts'), "ms_apply_finish": k7.get('ms_apply'),
             "frac_apply_finish_only": (k7['gbs_apply'] / HBM_PEAK_GBS) if 'gbs_apply' in k7 else None,
             "unique_rows": k7['unique_rows'], "contributions": k7['contributions'],
             "traffic": sum(((pmc or {}).get(k) or {}).get("traffic_bytes") or 0
-                           for k in ("sparse_apply_window", "sparse_finish")) or None}
+                           for k in ("sparse_apply_window", "sparse_finish", "sparse_apply_runs")) or None}
         gk = [k for k in kr if k.startswith('gather') and kr[k].get('kind') == 'mulhot']
         if gk:
             fused_lookup = [k for k in gk if 'pmc_key' in kr[k]]

@@ -28,6 +28,9 @@ MAP = {
     'sparse_apply_window': ['k_sparse_win'],
     'sparse_apply_small': ['k_sparse_onepass'],
     'sparse_finish': ['k_sparse_finish'],
+    'sparse_apply_runs': ['k_run_apply'],
+    'runs_extract': ['k_runs_extract'],
+    'bag_expand_compact': ['k_bag_expand_compact'],
     'radix_scatter': ['k_rs_scatter'],
     'radix_hist': ['k_rs_hist'],
     'bag_expand_heads': ['k_bag_expand_heads'],

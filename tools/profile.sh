@@ -14,7 +14,7 @@ OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 cd /tmp
 export TMPDIR=/tmp
-ARGS="--steps 100 --warmup 20 --no-cpu-baseline --subs= $*"
+ARGS="--steps 100 --warmup 20 --repeats 1 --no-cpu-baseline --subs= $*"
 
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o ks -- \
   python "$REPO/bench.py" $ARGS > "$OUT/${TAG}_bench_under_rocprof.json" 2> /tmp/ks.err
@@ -24,7 +24,7 @@ f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
 for C in FETCH_SIZE WRITE_SIZE; do
   lc=$(echo $C | tr 'A-Z' 'a-z' | sed 's/_size//')
   timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_${TAG}_$lc -o pmc -- \
-    python "$REPO/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-rooflines --subs= $* > /dev/null 2> /tmp/pmc_$lc.err
+    python "$REPO/bench.py" --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-graph --no-rooflines --subs= $* > /dev/null 2> /tmp/pmc_$lc.err
   f=$(find /tmp/pmc_${TAG}_$lc -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
     python "$REPO/tools/pmc_summarize.py" "$f" $C > "$OUT/${TAG}_pmc_${lc}.csv"
