@@ -42,6 +42,25 @@ import torch
 import torch.distributed as dist
 
 
+class _Done(object):
+    def wait(self):
+        return True
+
+
+def _all_to_all(out, inp, out_splits=None, in_splits=None, group=None, async_op=False):
+    """dist.all_to_all_single -- RCCL in production.  Test rigs run several ranks on ONE GPU over gloo,
+    which has no all-to-all for device tensors: there the blocks are staged through the host."""
+    if inp.is_cuda and dist.get_backend(group) == 'gloo':
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu().contiguous(), output_split_sizes=out_splits,
+                               input_split_sizes=in_splits, group=group)
+        out.copy_(o)
+        return _Done()
+    w = dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group,
+                               async_op=async_op)
+    return w if async_op else _Done()
+
+
 class HipBackend(object):
     """Compute stages on libarx.so (include/arx.h)."""
 
@@ -316,7 +335,7 @@ class ShardedHMF(object):
         send = np.bincount(owner, minlength=W).astype(np.int64)
         st = torch.from_numpy(send).to(self.device)
         rt = torch.empty_like(st)
-        dist.all_to_all_single(rt, st, group=self.group)
+        _all_to_all(rt, st, group=self.group)
         recv = [int(v) for v in rt.cpu().tolist()]
         route = {'users': torch.from_numpy(np.ascontiguousarray(u[perm])).to(self.device),
                  'items': torch.from_numpy(np.ascontiguousarray(it[perm])).to(self.device),
@@ -327,8 +346,7 @@ class ShardedHMF(object):
         # every id is resolved once.  The step path then starts at the table lookups.
         R = route['R']
         recv_ids = torch.zeros((R,), dtype=torch.int32, device=self.device)
-        dist.all_to_all_single(recv_ids, route['items'], output_split_sizes=recv,
-                               input_split_sizes=route['send'], group=self.group)
+        _all_to_all(recv_ids, route['items'], recv, route['send'], group=self.group)
         recv_rows = torch.zeros((R,), dtype=torch.int32, device=self.device)
         if R > 0:
             self.be.shard_route(recv_ids, W, self.rank, self.zero_row, recv_rows, None)
@@ -367,8 +385,7 @@ class ShardedHMF(object):
         T_send = self.T_send[:R]
         if R > 0:
             be.gather_rows_packed(self.E_item, self.b_item, recv_rows, T_send)
-        w_rows = dist.all_to_all_single(self.T_pack, T_send, output_split_sizes=send, input_split_sizes=recv,
-                                        group=grp, async_op=True)    # packed target rows back ...
+        w_rows = _all_to_all(self.T_pack, T_send, send, recv, group=grp, async_op=True)   # packed target rows back ...
         be.gemm(self.U_loc, self.I_all[:, :d], self.logits, transB=True, col_bias=self.b_all)   # ... under the scorer
         w_rows.wait()
         # loss (global mean => gscale = 1/B) with the target score and its rank-one gradients formed
@@ -378,9 +395,8 @@ class ShardedHMF(object):
                              self.pos_ptr, self.pos_items, self.item2slot, self.bl, self.dlogits,
                              self.t_loc, self.dT_pack[:, d], dU, self.dT_pack[:, :d], 1.0 / B)
         # ---- backward ----
-        w_dt = dist.all_to_all_single(arena[B_loc + Sg:B_loc + Sg + R], self.dT_pack,
-                                      output_split_sizes=recv, input_split_sizes=send, group=grp,
-                                      async_op=True)                  # target-row gradients -> owners ...
+        w_dt = _all_to_all(arena[B_loc + Sg:B_loc + Sg + R], self.dT_pack, recv, send, group=grp,
+                           async_op=True)                             # target-row gradients -> owners ...
         be.gemm(self.dlogits, self.I_all[:, :d], dU, beta=1.0)                # ... under dU += dL . pool
         # pool gradient partials (+ bias gradient = row sums) -> owners
         be.gemm(self.dlogits, self.U_loc, self.dI_all[:S, :d], transA=True, a_rowsum=self.gb_all)
@@ -806,7 +822,7 @@ def _time_collective(fn, iters=20):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    t = torch.tensor([e0.elapsed_time(e1) / iters], dtype=torch.float64, device='cuda')
+    t = torch.tensor([e0.elapsed_time(e1) / iters], dtype=torch.float64, device=torch.device('cuda', torch.cuda.current_device()))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -830,7 +846,7 @@ def comm_roofline(model, world, grp=None):
     cases = [
         ("all_gather_pool_blocks", lambda: dist.all_gather_into_tensor(x_gath, x_pack, group=grp),
          cap * dp * 4 * world, 1.0),
-        ("all_to_all_target_rows", lambda: dist.all_to_all_single(back, rows, group=grp), B_loc * dp * 4, 1.0),
+        ("all_to_all_target_rows", lambda: _all_to_all(back, rows, group=grp), B_loc * dp * 4, 1.0),
         ("all_reduce_pool_grads", lambda: dist.all_reduce(g, op=dist.ReduceOp.SUM, group=grp), S * dp * 4, 2.0),
     ]
     for name, fn, payload, factor in cases:
@@ -846,11 +862,20 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
     """The N-rank bench body (every rank calls it); returns the JSON dict on rank 0, None elsewhere.
     world == 1 runs the very same sharded step on one GPU (all "exchanges" local): the anchor of
     the weak-scaling curve -- same code path, same 100 M-item table, same eager launches."""
+    # ARX_DIST_BACKEND=gloo + ARX_DIST_ONE_GPU=1: a rig without a second GPU (this repo's test box) runs the
+    # N > 1 code path with every rank on device 0 and gloo underneath -- for checking the path, not for numbers
+    one_gpu = bool(os.environ.get("ARX_DIST_ONE_GPU"))
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if init_pg:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("ARX_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     B_loc, S, d = args.batch, args.n_sampled, args.dim
     t_setup = time.time()
     with_bags = bool(getattr(args, 'sharded_bags', False))
@@ -893,11 +918,9 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
     from . import ops as _ops
     cnt = torch.zeros(rows * world, dtype=torch.int32, device=dev)
     _ops.item_frequency(pos_items, rows * world, cnt)             # arx_item_frequency: counts only
-    mine = torch.empty(rows, dtype=torch.int32, device=dev)
     if world > 1:
-        dist.reduce_scatter_tensor(mine, cnt.view(rows, world).t().contiguous().view(-1), op=dist.ReduceOp.SUM)
-    else:
-        mine.copy_(cnt)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)                 # (set-up; 4 B per item)
+    mine = cnt.view(rows, world)[:, rank].contiguous()
     del cnt
     tot = mine.sum(dtype=torch.int64).to(torch.float64)
     if world > 1:

@@ -595,7 +595,11 @@ int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const flo
  * projections of a step: seqModel.py:173-182 applies one op per variable).  acc[t] NULL: gradient descent. */
 int arx_adagrad_dense_multi(int count, float* const* w, float* const* acc, const float* const* g,
                             const int64_t* n, const float* lr_dev, const float* gscale_dev, void* stream);
-/* *out_accum += sum_i w_i * x_i^2 with w_i = row_scale ? row_scale[i / d] : 1 */
+/* *out_accum += sum_i w_i * x_i^2 with w_i = row_scale ? row_scale[i / d] : 1.
+ * NOT re-entrant across streams: the norm entry points (arx_sq_norm_accum[_multi], arx_sq_norm_clip_multi,
+ * arx_merged_sq_norm) and arx_max_argmax keep their block partials and the arrival ticket of the
+ * deterministic one-launch reduction in library-owned device memory -- two such launches that can overlap
+ * on the GPU must be issued on ONE stream (a step's plan issues them on its main stream only). */
 int arx_sq_norm_accum(const float* x, int64_t n, int d, const float* row_scale,
                       float* out_accum, void* stream);
 /* the same accumulation over up to 8 tensors in one launch (the global norm of an LSTM step) */

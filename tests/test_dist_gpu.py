@@ -175,3 +175,94 @@ def test_sharded_c5_shape_world1(dev):
             assert torch.equal(model.E_item[keep], w_before)              # rows outside (batch u pool): untouched
     finally:
         dist.destroy_process_group()
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "a-recsys_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    from arx.dist import ShardedHMF, draw_global_pool
+    from arx.utils.prepare_train import DeviceSampler
+    from arx.utils.synthetic import SyntheticHMF
+
+    n_users, n_items, d, B_loc, S = 301, 503, 64, 32, 60             # S not a multiple of the world size
+    syn = SyntheticHMF(n_users=n_users, n_items=n_items, seed=1, permute_logits=False, n_pos=8)
+    params = syn.glorot_params(d, seed=2, scale=0.5)
+    tables = {'user': params['userembed_cat_0'][2:], 'item': params['itemembed_cat_0'][2:],
+              'item_bias': params['item_bias_cat_0'][2:]}
+    model = ShardedHMF(n_users, n_items, d, B_loc, S, 0.5, rank, world, dev, tables=tables)
+    own_users = np.arange(rank, n_users, world)
+    ptr = np.zeros(len(own_users) + 2, dtype=np.int32)
+    its = []
+    for k, u in enumerate(own_users):
+        its.extend(syn.pos_items[syn.pos_ptr[u]:syn.pos_ptr[u + 1]].tolist())
+        ptr[k + 1] = len(its)
+    ptr[-1] = ptr[-2]
+    model.set_positives(ptr, np.asarray(its, dtype=np.int32))
+    B = B_loc * world
+    ref = rg.RefLatentProductModel(d, B, 0.5, syn.u_attr, syn.i_attr, syn.item_ind2logit_ind_dict(),
+                                   syn.logit_ind2item_ind, loss_function='mw', n_sampled=S, params=params,
+                                   dtype=np.float64)
+    pos = syn.positives_dict()
+    ref.prepare_warp(pos, pos)
+    # the pool: ONE device draw over both shards (p ~ a Zipf weight per item), the same on every rank
+    w_all = (1.0 / np.arange(1, n_items + 1) ** 0.8).astype(np.float32)
+    mine = np.arange(rank, n_items, world)
+    sampler = DeviceSampler(mine.astype(np.int32), w_all[mine], device=dev, seed=100 + rank)
+    rng = np.random.default_rng(5)                                    # identical stream on both ranks
+    for step in range(4):
+        pool = None
+        if step % 2 == 0:
+            pool_t = draw_global_pool(sampler, S)
+            both = [torch.empty_like(pool_t) for _ in range(world)]
+            dist.all_gather(both, pool_t)
+            assert all(torch.equal(both[0], b) for b in both)         # every rank holds the same pool
+            pool = pool_t.cpu().numpy()
+            assert len(np.unique(pool)) == S and pool.min() >= 0 and pool.max() < n_items
+            if step == 2:                                             # ... and an all-on-one-owner pool
+                pool = rng.choice(np.arange(1, n_items, world), size=S, replace=False).astype(np.int32)
+            id2idx = {int(v): i for i, v in enumerate(pool)}
+            model.set_pool(pool)
+            cur = pool
+        gu, gi = [], []
+        for g in range(world):
+            lu = rng.integers(0, len(np.arange(g, n_users, world)), size=B_loc)
+            users = lu * world + g
+            k = rng.integers(0, syn.n_pos, size=B_loc)
+            gu.append(users)
+            gi.append(syn.pos_items[syn.pos_ptr[users] + k])
+        gi[0][0] = cur[0]                                             # a target that is also a pool slot
+        l_ref = ref.step(np.concatenate(gu).tolist(), np.concatenate(gi).tolist(), pool, id2idx, loss='mw')
+        model.step(gu[rank].astype(np.int32), gi[rank].astype(np.int32))
+        np.testing.assert_allclose(float(model.read_loss().item()), l_ref, rtol=1e-4, err_msg='step %d' % step)
+    got = model.gather_global_tables()
+    np.testing.assert_allclose(got['user'], ref.att_emb.params['userembed_cat_0'][2:], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(got['item'], ref.att_emb.params['itemembed_cat_0'][2:], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(got['item_bias'], ref.att_emb.params['item_bias_cat_0'][2:, 0], rtol=1e-4, atol=2e-6)
+    with open(os.path.join(out_dir, "ok%d" % rank), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+def test_sharded_hip_backend_two_ranks_one_gpu(dev, tmp_path):
+    """The N > 1 branches of the sharded step on the HIP backend: two rank PROCESSES share the test box's
+    one GPU and exchange over gloo (RCCL refuses two ranks on one device; the all-to-all is staged
+    through the host there -- arx.dist._all_to_all).  Pool = one device draw over both shards
+    (draw_global_pool over DeviceSampler.sample_with_keys), blocks padded to the largest owner
+    count, an all-on-one-owner pool, S not divisible by the world size; four steps vs the oracle on
+    the global batch."""
+    import torch.multiprocessing as mp
+    port = 29860 + (os.getpid() % 100)
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(2))
