@@ -307,6 +307,9 @@ class Prediction(Node):
         if pool.train_tables:
             gp = pool.alloc_grad()
             beta = pool.grad_beta()
+            hook = getattr(self.rt, '_between_backward_gemms', None)
+            if hook is not None:
+                hook()
             # dIbar = dL^T . U ; dbbar = rowsum(dL^T) rides in the same kernel.  Independent
             # of the dU GEMM above: runs on a side branch, joined before the optimiser.
             tok = self.rt.fork(0)
@@ -909,9 +912,23 @@ class Plan(object):
             self._early_launch()          # (no-op when already issued)
         if self.train:
             rt._pending = []
+            # The one-hot sort of the K7 branch is long done when the backward GEMMs start: the main
+            # chain takes that dependency THERE (between dU and dI), where it costs nothing, instead
+            # of in front of the one-hot apply, where a two-parent node starts ~10 us late (measured)
+            self._mid_waited = False
+            # (measured: with a VIRTUAL entity table -- MIX -- 350 -> 340 us/step; with a real id table -- HET
+            # -- 313 -> 315, so there the dependency stays at the apply)
+            mid_at = os.environ.get('ARX_K7_MID_AT') or ('dI' if getattr(self, '_k7_virtual', False) else 'apply')
+            if self._k7_early is not None and self._k7_early[2] is not None and mid_at == 'dI':
+                def _mid_wait(ev=self._k7_early[2]):
+                    if not self._mid_waited:
+                        torch.cuda.current_stream().wait_event(ev)
+                        self._mid_waited = True
+                rt._between_backward_gemms = _mid_wait
             for n in reversed(self.order):
                 if n.requires_grad and n._grad_written:
                     n.backward()
+            rt._between_backward_gemms = None
             for t in rt._pending:
                 rt.join(t)
             rt._pending = []
@@ -1007,7 +1024,8 @@ class Plan(object):
         split_join = None
         if early is not None:
             if early[2] is not None:
-                torch.cuda.current_stream().wait_event(early[2])      # the one-hot sort is done ...
+                if not getattr(self, '_mid_waited', False):
+                    torch.cuda.current_stream().wait_event(early[2])  # the one-hot sort is done ...
                 split_join = early[1]                                 # ... the token chain is joined before its apply
             else:
                 torch.cuda.current_stream().wait_event(early[1])      # join the sort branch
@@ -1242,6 +1260,7 @@ class Plan(object):
                     # a bag table rides on the pass: the one-hot apply only needs the one-hot sort --
                     # the token chain behind it may still run while that apply does (quarter phases)
                     self._apply_multi(what[0], phase=5, key=key, bag=what[1])
+                    self._k7_virtual = bool(what[1][3])
                     mid = torch.cuda.Event()
                     mid.record(self._k7_stream)
                     self._apply_multi(what[0], phase=6, key=key, bag=what[1])

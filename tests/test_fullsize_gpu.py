@@ -276,9 +276,10 @@ def test_fullsize_hmf_matches_embedding_space_oracle(dev, layout):
             _check_tables(model, oracle)
 
 
-def test_fullsize_lstm_matches_embedding_space_oracle(dev):
-    """configs[3] at full size (d = h = 64, L = 50, B = 1024 sequences, 1 M items, S = 1024, 'mw',
-    clip 5.0 -- active): two consecutive steps against ref_embed.EmbedSpaceSeq: summed sequence
+@pytest.mark.parametrize("loss", ['mw', 'mce'])
+def test_fullsize_lstm_matches_embedding_space_oracle(dev, loss):
+    """configs[3] at full size (d = h = 64, L = 50, B = 1024 sequences, 1 M items, S = 1024, 'mw' and the
+    build-defined sampled softmax 'mce', clip 5.0 -- active): two consecutive steps against ref_embed.EmbedSpaceSeq: summed sequence
     loss, the global norm the step clipped with, LSTM weights / biases, every touched table row."""
     from arx.attributes.embed_attribute import EmbeddingAttribute
     from arx.lstm.seqModel import SeqModel
@@ -289,11 +290,11 @@ def test_fullsize_lstm_matches_embedding_space_oracle(dev):
     syn.u_attr.set_model_size(size)
     syn.i_attr.set_model_size(size)
     emb = EmbeddingAttribute(syn.u_attr, syn.i_attr, Bq, Sq, L, False, None, syn.logit_ind2item_ind)
-    model = SeqModel([L], size, 1, 5.0, Bq, 0.5, 0.99, emb, loss='mw', use_concat=False, START_ID=N)
+    model = SeqModel([L], size, 1, 5.0, Bq, 0.5, 0.99, emb, loss=loss, use_concat=False, START_ID=N)
     emb.prepare_warp(syn.positives_csr(), syn.positives_csr())
     params0 = emb.get_params()
     oracle = ref_embed.EmbedSpaceSeq(syn.u_attr, syn.i_attr, params0, model.W.w.cpu().numpy(),
-                                     model.b.w.cpu().numpy(), 0.5, 5.0, loss='mw', no_user_id=True)
+                                     model.b.w.cpu().numpy(), 0.5, 5.0, loss=loss, no_user_id=True)
     ptr, pit = syn.positives_csr()
     d_ = model.rt.device
     rng = np.random.default_rng(1)
