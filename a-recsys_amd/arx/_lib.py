@@ -95,6 +95,7 @@ PROTOTYPES = {
     "arx_gemm_bits_f32": (cint, [cint, i64, i64, i64, vp, i64, f32p, i64, f32, f32p, i64, f32p, f32p, f32p,
                                  vp, sz, vp]),
     "arx_sample_wor_workspace_bytes": (sz, [i64]),
+    "arx_sample_wor_keys_workspace_bytes": (sz, [i64, i64, f32]),
     "arx_sample_wor": (cint, [f32p, i64, i64, u64, u64, i32p, vp, sz, vp]),
     "arx_sample_wor_capped": (cint, [f32p, i64, i64, u64, u64, f32, i32p, vp, sz, vp]),
     "arx_sample_wor_keys": (cint, [f32p, i64, i64, u64, u64, f32, i32p, f32p, vp, sz, vp]),
@@ -205,7 +206,7 @@ lib = _load()
 _NO_CHECK = ("arx_last_error", "arx_version", "arx_csr_expand_workspace_bytes",
              "arx_col_sum_workspace_bytes",
              "arx_gemm_f32_workspace_bytes", "arx_sparse_adagrad_workspace_bytes",
-             "arx_sample_wor_workspace_bytes")
+             "arx_sample_wor_workspace_bytes", "arx_sample_wor_keys_workspace_bytes")
 
 
 def call(name, *args):

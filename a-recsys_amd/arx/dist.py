@@ -68,6 +68,7 @@ class HipBackend(object):
         from . import ops
         self.ops = ops
         self.ws = ops.Workspace(device)
+        self.ws_k7 = ops.Workspace(device)     # K7's own: its sort half may run ahead, under the GEMMs (which use ws)
 
     def gather_rows(self, E, bias, rows, out, bias_out, scale=1.0):
         self.ops.gather_onehot(E, bias, None, rows, out, scale=scale, bias_out=bias_out)
@@ -131,9 +132,10 @@ class HipBackend(object):
     def sparse_adagrad(self, E, acc, bias, bias_acc, keys, G, Gb, lr):
         self.ops.sparse_adagrad(E, acc, bias, bias_acc, keys, None, None, G, Gb, lr, self.ws)
 
-    def sparse_adagrad_multi(self, tables, sites, G, Gb, lr):
+    def sparse_adagrad_multi(self, tables, sites, G, Gb, lr, phase=3):
         """tables: [(E, acc, bias|None, bias_acc|None)]; sites: [(table, local_rows, row_base)]:
-        one fused pass (arx_sparse_adagrad_cat_multi)."""
+        one fused pass (arx_sparse_adagrad_cat_multi).  phase 1: keys + sorts + run records (needs the
+        ids only), 2: apply, 3: both."""
         ops = self.ops
         sites = [(x[0], x[1], x[2], x[3] if len(x) > 3 else 1.0) for x in sites]   # (table, rows, base[, coef])
         key = tuple((t, r.data_ptr(), int(r.shape[0]), b, c) for t, r, b, c in sites)
@@ -163,7 +165,7 @@ class HipBackend(object):
             self._multi_bufs = kb, sb, cb = (torch.empty(ent.total, dtype=torch.int32, device=G.device),
                                              torch.empty(ent.total, dtype=torch.int32, device=G.device),
                                              torch.empty(ent.total, dtype=torch.float32, device=G.device))
-        ops.sparse_adagrad_cat_multi(ent, G, Gb, lr, kb, sb, cb, self.ws)
+        ops.sparse_adagrad_cat_multi(ent, G, Gb, lr, kb, sb, cb, self.ws_k7, phase=phase)
 
     def slot_map_set(self, m, ids, clear):
         self.ops.slot_map_set(m, ids, clear=clear)
@@ -180,7 +182,7 @@ class ShardedHMF(object):
     the API; `users` passed to step() must all be owned by this rank."""
 
     def __init__(self, n_users, n_items, d, B_loc, S, learning_rate, rank, world, device,
-                 backend=None, group=None, tables=None, seed=0, acc0=0.1):
+                 backend=None, group=None, tables=None, seed=0, acc0=0.1, graphs=None):
         if S % 4 != 0 or d % 4 != 0:
             raise ValueError("n_sampled and d must be multiples of 4")
         self.n_users, self.n_items, self.d = n_users, n_items, d
@@ -193,6 +195,17 @@ class ShardedHMF(object):
         self.device = torch.device(device)
         self.group = group
         self.be = backend if backend is not None else HipBackend(self.device)
+        # hipGraph segments (_step_static): the product backend on a GPU, unless switched off
+        if graphs is None:
+            graphs = not os.environ.get("ARX_DIST_EAGER")
+        self.use_graphs = bool(graphs) and type(self) is ShardedHMF and isinstance(self.be, HipBackend) \
+            and self.device.type == 'cuda'
+        self._graphs, self._graph_key, self._warm_key, self.g_idx = {}, None, None, None
+        self.n_captures, self.n_replays = 0, 0
+        # (the legacy default stream cannot be captured: the step runs on a stream of its own, joined with
+        # the caller's stream on both sides)
+        self._stream = torch.cuda.Stream(device=self.device) if self.use_graphs else None
+        self._side = torch.cuda.Stream(device=self.device) if self.use_graphs else None
         dev = self.device
         f32, i32 = torch.float32, torch.int32
         nu = (n_users - rank + world - 1) // world        # owned rows
@@ -264,6 +277,8 @@ class ShardedHMF(object):
             return
         dev, f32, i32 = self.device, torch.float32, torch.int32
         B_loc, Sg, dp = self.B_loc, self.Sg, self.dp
+        if self.use_graphs and self.cap_r > 0:
+            cap = (cap + cap // 8 + 63) // 64 * 64        # new buffers = new graphs: grow with slack
         self.cap_r = cap
         self.recv_ids = torch.zeros((cap,), dtype=i32, device=dev)
         self.recv_rows = torch.zeros((cap,), dtype=i32, device=dev)
@@ -309,6 +324,8 @@ class ShardedHMF(object):
         counts = torch.bincount(owner, minlength=W)
         start = torch.cumsum(counts, 0) - counts
         cap = (int(counts.max().item()) + 3) // 4 * 4
+        if self.use_graphs:      # block capacity only grows (a new capacity = new graphs), with slack
+            cap = self.cap if cap <= self.cap else min(S, (cap + cap // 8 + 15) // 16 * 16)
         self.cap = cap
         pos = torch.empty(S, dtype=torch.int64, device=self.device)
         pos[order] = torch.arange(S, device=self.device) - start[owner[order]]
@@ -361,11 +378,17 @@ class ShardedHMF(object):
         nothing but kernels and collectives on the step path) or a users array with `items`
         (routed here on the host)."""
         route = users if isinstance(users, dict) else self.prepare_route(users, items)
+        if self.use_graphs:
+            outer = torch.cuda.current_stream(self.device)
+            self._stream.wait_stream(outer)
+            with torch.cuda.stream(self._stream):
+                self._step_static(route)
+            outer.wait_stream(self._stream)
+            return
         be, W, r = self.be, self.world, self.rank
         B, B_loc, S, Sg, d, dp = self.B, self.B_loc, self.S, self.Sg, self.d, self.dp
         grp = self.group
         send, recv, R = route['send'], route['recv'], route['R']
-        users_in, items_in = route['users'], route['items']
         arena, arena_b = self.arena, self.arena_b
         # The two large exchanges (target rows out, target-row gradients back: B_loc x (d+4) floats
         # each) are issued asynchronously and waited for only where their result is needed, so that
@@ -416,6 +439,154 @@ class ShardedHMF(object):
         be.sparse_adagrad_multi([(self.E_user, self.A_user, None, None),
                                  (self.E_item, self.A_item, self.b_item, self.Ab_item)],
                                 sites, arena[:, :d], arena_b, self.lr)
+        self.steps += 1
+
+
+    # ------------------------------------------------------- step, hipGraph segments
+    def _segment(self, mode, name, fn):
+        """eager: run; capture: record the launches of `fn` into a hipGraph, keep it, launch it;
+        replay: launch the kept graph."""
+        if mode == 'eager':
+            fn()
+        elif mode == 'capture':
+            g = self.be.ops.CapturedGraph()
+            g.begin()
+            try:
+                fn()
+            finally:
+                g.end()
+            self._graphs[name] = g
+            g.launch()
+        else:
+            self._graphs[name].launch()
+
+    def _step_static(self, route):
+        """The step of step() with every buffer at a fixed address and a fixed size, so that the
+        kernels between two collectives are ONE hipGraph launch each (5 segments + K7's sort half as a
+        sixth, on a second stream under the forward kernels + 4 collectives + one index copy per step
+        instead of ~35 kernel launches from Python; world 1: four graphs, no collective).  What varies from batch to batch is the index vector [user rows ; received target
+        rows], padded with the shard's padding row to the capacity cap_r (gathers: a zero row;
+        K7: the tables are passed without the padding row, so padded keys are out of range and dropped)
+        and the split sizes of the two all-to-alls, which stay outside the graphs.  A configuration
+        (block capacity, receive capacity) runs eagerly once (module loads, workspaces), is captured
+        on its second step and replayed from then on."""
+        be, W = self.be, self.world
+        B, B_loc, S, Sg, d = self.B, self.B_loc, self.S, self.Sg, self.d
+        grp, dev = self.group, self.device
+        send, recv, R = route['send'], route['recv'], route['R']
+        if R > self.cap_r:
+            self._alloc_recv(R)
+        cap, cap_r = self.cap, self.cap_r
+        n_idx = B_loc + cap_r
+        idx = route.get('idx')
+        if idx is None or idx.shape[0] != n_idx:
+            idx = torch.full((n_idx,), self.zero_row, dtype=torch.int32, device=dev)
+            idx[:B_loc] = route['urows']
+            if R > 0:
+                idx[B_loc:B_loc + R] = route['recv_rows']
+            route['idx'] = idx
+        if self.g_idx is None or self.g_idx.shape[0] != n_idx:
+            self.g_idx = torch.empty(n_idx, dtype=torch.int32, device=dev)
+        self.g_idx.copy_(idx, non_blocking=True)
+        key = (cap, cap_r, self.g_idx.data_ptr(), self.arena.data_ptr(), self.pos_ptr.data_ptr(),
+               self.pos_items.data_ptr())
+        if self._graph_key == key:
+            mode = 'replay'
+        elif self._warm_key == key:
+            mode, self._graphs = 'capture', {}
+        else:
+            mode, self._graphs, self._graph_key = 'eager', {}, None
+        seg = lambda name, fn: self._segment(mode, name, fn)
+        arena, arena_b = self.arena, self.arena_b
+        urows, rrows = self.g_idx[:B_loc], self.g_idx[B_loc:]
+        self.urows = urows
+        ni = self.ni_loc
+        dU = arena[:B_loc, :d]
+        T_in = self.T_pack if W == 1 else self.T_send[:cap_r]              # target rows as gathered
+        dT = arena[B_loc + Sg:B_loc + Sg + B_loc] if W == 1 else self.dT_pack
+
+        def fwd_gather():
+            be.gather_rows(self.E_user, None, urows, self.U_loc, None)
+            if W == 1:
+                be.gather_rows_packed(self.E_item, self.b_item, self.pool_rows, self.I_all)
+                be.gather_rows_packed(self.E_item, self.b_item, rrows[:B_loc], T_in)
+            else:
+                be.gather_rows_packed(self.E_item, self.b_item, self.pool_rows[:cap], self.I_pack[:cap])
+                be.gather_rows_packed(self.E_item, self.b_item, rrows, T_in)
+
+        def fwd_score():
+            if W > 1:
+                be.gather_rows(self.I_gath, None, self.gidx, self.I_all, None)     # blocks -> pool (slot) order
+            be.copy_strided(self.I_all[:, d], self.b_all)
+            be.gemm(self.U_loc, self.I_all[:, :d], self.logits, transB=True, col_bias=self.b_all)
+
+        def loss():
+            be.loss_mw_fused_pos(self.logits, self.U_loc, self.T_pack[:, :d], self.T_pack[:, d], urows,
+                                 self.pos_ptr, self.pos_items, self.item2slot, self.bl, self.dlogits,
+                                 self.t_loc, dT[:, d], dU, dT[:, :d], 1.0 / B)
+
+        def bwd_gemms():
+            be.gemm(self.dlogits, self.I_all[:, :d], dU, beta=1.0)
+            be.gemm(self.dlogits, self.U_loc, self.dI_all[:S, :d], transA=True, a_rowsum=self.gb_all)
+            be.copy_strided(self.gb_all, self.dI_all[:S, d])
+
+        def k7(phase):
+            be.sparse_adagrad_multi([(self.E_user, self.A_user, None, None),
+                                     (self.E_item[:ni], self.A_item[:ni], self.b_item[:ni], self.Ab_item[:ni])],
+                                    [(0, urows, 0), (1, self.pool_rows[:cap], B_loc),
+                                     (1, rrows[:B_loc] if W == 1 else rrows, B_loc + Sg)],
+                                    arena[:, :d], arena_b, self.lr, phase=phase)
+
+        def apply():
+            if W == 1:
+                be.copy_2d(self.dI_all[:S], arena[B_loc:B_loc + S])
+            else:
+                be.gather_rows(self.dI_all, None, self.my_slots[:cap], arena[B_loc:B_loc + cap], None)
+            n_rows = B_loc + Sg + (B_loc if W == 1 else cap_r)
+            be.copy_strided(arena[B_loc:n_rows, d], arena_b[B_loc:n_rows])
+            k7(2)
+
+        def k7_sorts():
+            # K7's keys, sorts and run records need the ids only: a graph of its own on a second stream,
+            # under the forward kernels (the ~70 us chain leaves the critical path)
+            main, side = torch.cuda.current_stream(dev), self._side
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                seg('k7_sorts', lambda: k7(1))
+                done = torch.cuda.Event()
+                done.record(side)
+            return done
+
+        if W == 1:
+            seg('fwd_gather', fwd_gather)
+            sorted_ = k7_sorts()
+            seg('step', lambda: (fwd_score(), loss(), bwd_gemms()))
+            torch.cuda.current_stream(dev).wait_event(sorted_)
+            seg('apply', apply)
+        else:
+            seg('fwd_gather', fwd_gather)
+            sorted_ = k7_sorts()
+            dist.all_gather_into_tensor(self.I_gath[:W * cap], self.I_pack[:cap], group=grp)
+            w_rows = _all_to_all(self.T_pack, self.T_send[:R], send, recv, group=grp, async_op=True)
+            seg('fwd_score', fwd_score)                       # scorer GEMM under the target-row exchange
+            w_rows.wait()
+            seg('loss', loss)
+            w_dt = _all_to_all(arena[B_loc + Sg:B_loc + Sg + R], self.dT_pack, recv, send, group=grp,
+                               async_op=True)
+            seg('bwd_gemms', bwd_gemms)                       # dU, dI under the gradient exchange
+            dist.all_reduce(self.dI_all[:S], op=dist.ReduceOp.SUM, group=grp)
+            w_dt.wait()
+            torch.cuda.current_stream(dev).wait_event(sorted_)
+            seg('apply', apply)
+        if mode == 'eager':
+            self._warm_key = key
+        elif mode == 'capture':
+            self._graph_key = key
+            self.n_captures += 1
+        else:
+            self.n_replays += 1
         self.steps += 1
 
     def read_loss(self):
@@ -1001,6 +1172,8 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
                        "batch_per_gpu": B_loc, "global_batch": B, "n_sampled": S, "dim": d,
                        "parallelism": "row-sharded tables x dp%d" % world,
                        "routing_in_timed_region": False, "pool_redraws_timed": redraws[0],
+                       "hipgraph_segments": (sorted(model._graphs) if model.use_graphs else None),
+                       "hipgraph_captures": model.n_captures, "hipgraph_replays": model.n_replays,
                        "sampled_negative_logits_per_s": B * S * args.steps / wall,
                        "final_loss": loss, "setup_s": setup_s},
             "roofline": roofline, "roofline_comm": comm,

@@ -413,7 +413,7 @@ def sample_wor(weights, S, seed, counter, out, ws, key_cap=0.0, out_keys=None):
     key_cap > 0: pre-filter for very large item sets (arx_sample_wor_capped).  out_keys (float32
     [S]): the race keys of the drawn items, ascending (arx_sample_wor_keys)."""
     n = int(weights.shape[0])
-    wsp, wsn = ws.get(_lib.lib.arx_sample_wor_workspace_bytes(n))
+    wsp, wsn = ws.get(_lib.lib.arx_sample_wor_keys_workspace_bytes(n, int(S), float(key_cap)))
     call("arx_sample_wor_keys", _p(weights), n, int(S), int(seed) & (2 ** 64 - 1),
          int(counter) & (2 ** 64 - 1), float(key_cap), _p(out), _p(out_keys), wsp, wsn, _stream())
     return out

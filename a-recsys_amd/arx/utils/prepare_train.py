@@ -92,8 +92,9 @@ class DeviceSampler(object):
     def _cap_for(self, n):
         """Key threshold t of the capped race for draws of n items: an item survives the cap with
         probability 1 - exp(-w t), so t is chosen such that the EXPECTED number of survivors,
-        sum_i (1 - exp(-w_i t)), is 8 n (the count is a sum of independent indicators: fewer than n
-        of 8 n expected is out of reach).  `8 n / sum(w)` -- round 2 -- only equals that while
+        sum_i (1 - exp(-w_i t)), is 7.5 n (the count is a sum of independent indicators: fewer than n
+        of 7.5 n expected is out of reach; and no more than 8 n -- the power of two the survivors'
+        one-workgroup sort pads to -- at n = 1024: 7680 + 5 sigma < 8192).  `8 n / sum(w)` -- round 2 -- only equals that while
         w t << 1 for every item: with heavy-tailed weights (w ~ rank^-1.5, 1 M items, n = 1000) it
         let ~630 keys through, the draw came back short and the missing positions indexed
         items[-1].  0.0 = no cap (small populations, or too few positive weights for one to pay).
@@ -107,7 +108,7 @@ class DeviceSampler(object):
         if self._npos < n:
             raise ValueError("DeviceSampler.sample(%d): only %d items have a positive weight" % (n, self._npos))
         cap = 0.0
-        target = 8.0 * n
+        target = 7.5 * n
         if N > (1 << 16) and 16 * n < N and self._npos >= 2 * target:
             w = self.w.clamp(min=0)
 

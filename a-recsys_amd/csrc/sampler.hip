@@ -13,6 +13,11 @@
 //                 zero-weight items get +inf and are dropped by the sort's first pass.
 // ~170 us for 1 M items, every n_resample (50) steps; the host call it replaces takes
 // ~10 ms at 1 M items.
+// Capped race (key_cap > 0: item sets of 10^7..10^8 rows, where all but ~8 S keys are known to
+// lose): the keys are never stored -- k_race_compact appends the few survivors (key, item) to a
+// list, k_bitonic_take sorts them as 64-bit (key, item) words in the LDS of ONE workgroup and
+// writes the S smallest.  Same keys, same (key, item) order as the sort path => the same draw;
+// 100 M items: one 400 MB read of the weights instead of that plus two passes over 100 M keys.
 #include "common.h"
 
 namespace arx {
@@ -28,24 +33,113 @@ __device__ __forceinline__ uint32_t mix32s(uint64_t z) {
 
 constexpr uint32_t kInfBits = 0x7f800000u;
 
+__device__ __forceinline__ uint64_t race_base(uint64_t seed, uint64_t counter) {
+  return (seed * 0x9E3779B97F4A7C15ull) ^ (counter * 0xD1B54A32D192ED03ull);
+}
+
+// key bits of item i (kInfBits: never drawn / above the cap)
+__device__ __forceinline__ uint32_t race_bits(float wi, int64_t i, uint64_t base, float key_cap) {
+  uint32_t bits = kInfBits;                       // zero / negative / NaN weight: never drawn
+  if (wi > 0.f) {
+    const uint32_t r = mix32s(base + (uint64_t)i * 0x100000001b3ull);
+    const float u = ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
+    const float key = -__logf(u) / wi;
+    bits = __float_as_uint(key);
+    if (bits >= kInfBits) bits = kInfBits - 1;    // overflow of a tiny weight: last, not dropped
+    if (key_cap > 0.f && key > key_cap) bits = kInfBits;   // cannot be among the S smallest (see arx.h)
+  }
+  return bits;
+}
+
 __global__ __launch_bounds__(256) void k_race_keys(const float* __restrict__ w, int64_t n,
                                                    uint64_t seed, uint64_t counter, float key_cap,
                                                    int32_t* __restrict__ keys) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const uint64_t base = (seed * 0x9E3779B97F4A7C15ull) ^ (counter * 0xD1B54A32D192ED03ull);
-  for (; i < n; i += stride) {
-    const float wi = w[i];
-    uint32_t bits = kInfBits;                       // zero / negative / NaN weight: never drawn
-    if (wi > 0.f) {
-      const uint32_t r = mix32s(base + (uint64_t)i * 0x100000001b3ull);
-      const float u = ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
-      const float key = -__logf(u) / wi;
-      bits = __float_as_uint(key);
-      if (bits >= kInfBits) bits = kInfBits - 1;    // overflow of a tiny weight: last, not dropped
-      if (key_cap > 0.f && key > key_cap) bits = kInfBits;   // cannot be among the S smallest (see arx.h)
+  const uint64_t base = race_base(seed, counter);
+  for (; i < n; i += stride) keys[i] = (int32_t)race_bits(w[i], i, base, key_cap);
+}
+
+// Capped race without the key array: survivors (a few thousand of up to 2^31 items) are appended to
+// `list` as (key bits, item) -- one atomic per wave that has any; order of arrival, sorted next.
+constexpr int kCompactCap = 16384;                 // list capacity = what one workgroup sorts in LDS (128 KB)
+
+__device__ __forceinline__ void race_append(bool live, uint32_t bits, int64_t i, uint2* __restrict__ list,
+                                            int32_t* __restrict__ count) {
+  const uint64_t m = __ballot(live);
+  if (m == 0) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, __popcll(m));
+  base = __shfl(base, __ffsll((long long)m) - 1);
+  if (live) {
+    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (pos < kCompactCap) list[pos] = make_uint2(bits, (uint32_t)i);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_race_compact(const float* __restrict__ w, int64_t n,
+                                                      uint64_t seed, uint64_t counter, float key_cap,
+                                                      uint2* __restrict__ list, int32_t* __restrict__ count) {
+  const uint64_t base = race_base(seed, counter);
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t rounds = (n4 + stride - 1) / stride;          // wave-uniform trip count (ballots inside)
+  int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (int64_t r = 0; r < rounds; ++r, q += stride) {
+    const bool in = q < n4;
+    const float4 w4 = in ? reinterpret_cast<const float4*>(w)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t i = q << 2;
+    const uint32_t b0 = race_bits(w4.x, i, base, key_cap), b1 = race_bits(w4.y, i + 1, base, key_cap);
+    const uint32_t b2 = race_bits(w4.z, i + 2, base, key_cap), b3 = race_bits(w4.w, i + 3, base, key_cap);
+    if (__any((b0 & b1 & b2 & b3) < kInfBits || b0 < kInfBits || b1 < kInfBits || b2 < kInfBits || b3 < kInfBits)) {
+      race_append(b0 < kInfBits, b0, i, list, count);
+      race_append(b1 < kInfBits, b1, i + 1, list, count);
+      race_append(b2 < kInfBits, b2, i + 2, list, count);
+      race_append(b3 < kInfBits, b3, i + 3, list, count);
     }
-    keys[i] = (int32_t)bits;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {                   // the last n % 4 items
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    const bool in = threadIdx.x < (n & 3);
+    const uint32_t b = in ? race_bits(w[i], i, base, key_cap) : kInfBits;
+    race_append(b < kInfBits, b, i, list, count);
+  }
+}
+
+// One workgroup: bitonic sort of the survivors as (key << 32 | item) words in LDS, the S smallest out.
+// More survivors than the list holds (a cap far above the documented one): every output is -1.
+__global__ __launch_bounds__(1024) void k_bitonic_take(const uint2* __restrict__ list,
+                                                       const int32_t* __restrict__ count, int64_t S,
+                                                       int32_t* __restrict__ out, float* __restrict__ out_keys) {
+  extern __shared__ uint64_t sk[];
+  const int tid = threadIdx.x;
+  const int c = *count;
+  const int m = c > kCompactCap ? 0 : c;
+  int P = 2;
+  while (P < m) P <<= 1;
+  for (int i = tid; i < P; i += 1024)
+    sk[i] = i < m ? ((uint64_t)list[i].x << 32) | (uint64_t)list[i].y : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (P >> 1); t += 1024) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i | j;
+        const uint64_t a = sk[i], b = sk[l];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) {
+          sk[i] = b;
+          sk[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  for (int64_t i = tid; i < S; i += 1024) {
+    const bool live = i < m;
+    const uint64_t v = live ? sk[i] : 0ull;
+    out[i] = live ? (int32_t)(uint32_t)v : -1;
+    if (out_keys) out_keys[i] = __uint_as_float(live ? (uint32_t)(v >> 32) : kInfBits);
   }
 }
 
@@ -93,6 +187,14 @@ using namespace arx;
 
 extern "C" {
 
+// capped draws of up to kCompactCap / 8 items: survivor list + its count
+static bool compact_path(int64_t S, float key_cap) { return key_cap > 0.f && S * 8 <= kCompactCap; }
+
+size_t arx_sample_wor_keys_workspace_bytes(int64_t n, int64_t S, float key_cap) {
+  if (compact_path(S, key_cap)) return (size_t)kCompactCap * 8 + 256;
+  return arx_sample_wor_workspace_bytes(n);
+}
+
 size_t arx_sample_wor_workspace_bytes(int64_t n) {
   const size_t ni = align256((size_t)(n > 0 ? n : 1) * 4);
   // raw keys, 2 x (keys, src, coef) ping-pong, histograms, live count
@@ -138,12 +240,33 @@ int arx_sample_wor_keys(const float* weights, int64_t n, int64_t S, uint64_t see
                         size_t workspace_bytes, void* stream) {
   ARX_CHECK_ARG(weights && out_idx, "arx_sample_wor: null pointer");
   ARX_CHECK_ARG(n > 0 && n < (int64_t)0x7fffffff && S > 0 && S <= n, "arx_sample_wor: need 0 < S <= n < 2^31");
-  const size_t need = arx_sample_wor_workspace_bytes(n);
+  const size_t need = arx_sample_wor_keys_workspace_bytes(n, S, key_cap);
   if (!workspace || workspace_bytes < need) {
     set_error("arx_sample_wor: workspace too small (%zu < %zu)", workspace_bytes, need);
     return ARX_EWORKSPACE;
   }
   hipStream_t s = as_stream(stream);
+  if (compact_path(S, key_cap)) {
+    ARX_CHECK_ARG((reinterpret_cast<uintptr_t>(weights) & 15) == 0, "arx_sample_wor: weights must be 16-byte aligned");
+    uint2* list = reinterpret_cast<uint2*>(workspace);
+    int32_t* count = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + (size_t)kCompactCap * 8);
+    ARX_CHECK_HIP(hipMemsetAsync(count, 0, 4, s));
+    int64_t g = ceil_div(ceil_div(n, 4), 256);
+    const int64_t cap = (int64_t)cu_count() * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    k_race_compact<<<(int)g, 256, 0, s>>>(weights, n, seed, counter, key_cap, list, count);
+    ARX_CHECK_LAUNCH();
+    static bool raised = false;
+    if (!raised) {
+      ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bitonic_take),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kCompactCap * 8));
+      raised = true;
+    }
+    k_bitonic_take<<<1, 1024, (size_t)kCompactCap * 8, s>>>(list, count, S, out_idx, out_keys);
+    ARX_CHECK_LAUNCH();
+    return ARX_OK;
+  }
   const size_t ni = align256((size_t)n * 4);
   char* base = reinterpret_cast<char*>(workspace);
   int32_t* keys_raw = reinterpret_cast<int32_t*>(base);

@@ -253,10 +253,16 @@ int arx_sample_wor(const float* weights, int64_t n, int64_t S, uint64_t seed, ui
  * probability 1 - exp(-w_i t)), so for c = 8 the S smallest keys are all below the cap except with
  * probability < exp(-3S) and the result is the un-capped one -- while the sort's later passes
  * handle ~8 S entries instead of n (100 M-item shard: ~5 ms -> ~0.3 ms per redraw).  Entries of
- * out_idx are -1 if fewer than S keys survive. */
+ * out_idx are -1 if fewer than S keys survive.
+ * Draws of S <= 2048 items with a cap never store the n keys: the survivors are appended to a list
+ * of 16384 entries and sorted by one workgroup (same keys, same (key, item) order: the same draw; the
+ * workspace is arx_sample_wor_keys_workspace_bytes(n, S, key_cap) = 128 KB instead of 28 n bytes).  A
+ * cap that lets MORE than 16384 keys through (8 S expected survivors is the contract) yields -1 in
+ * every entry. */
 int arx_sample_wor_capped(const float* weights, int64_t n, int64_t S, uint64_t seed, uint64_t counter,
                           float key_cap, int32_t* out_idx, void* workspace, size_t workspace_bytes,
                           void* stream);
+size_t arx_sample_wor_keys_workspace_bytes(int64_t n, int64_t S, float key_cap);
 /* ... and the race keys of the drawn items (out_keys [S], ascending; +inf where out_idx is -1; NULL:
  * not wanted).  For ONE draw over an item set that is sharded over several ranks (the reference draws
  * its S negatives from one distribution, prepare_train.py:7-17): every rank races its own shard

@@ -721,10 +721,14 @@ def test_sparse_adagrad_cat_fast_path(dev, d, Vf, ns):
     assert torch.equal(outs[2][0], outs[3][0]) and torch.equal(outs[2][1], outs[3][1])
 
 
-@pytest.mark.parametrize("n,Vf", [(60000, 3000), (20000, 50)])
-def test_sparse_adagrad_ticket_large_n(dev, n, Vf):
-    """Device radix-sort path (n > 8192) with the one-launch ticket apply: Zipf-heavy keys
-    (runs of thousands of duplicates spanning many pieces) == reference, deterministic."""
+@pytest.mark.parametrize("n,Vf,dist", [(60000, 3000, 'zipf'), (20000, 50, 'zipf'),
+                                       (100000, 1, 'zipf'),          # ONE run of 80 k entries: 313 work items
+                                       (50001, 200000, 'uniform'),   # almost every run is one entry
+                                       (16385, 7, 'blocks')])        # runs that end exactly on tile borders
+def test_sparse_adagrad_ticket_large_n(dev, n, Vf, dist):
+    """Device radix-sort path (n > 8192) with the run records + run-centric apply: Zipf-heavy keys
+    (runs of thousands of duplicates spanning many work items), one giant run, all-distinct
+    keys, runs cut at the extraction tile size == reference, deterministic."""
     from arx import ops
     import torch
     rng = np.random.default_rng(n)
@@ -736,9 +740,15 @@ def test_sparse_adagrad_ticket_large_n(dev, n, Vf):
     m = 400
     G = rng.standard_normal((m, d)).astype(np.float32)
     Gb = rng.standard_normal((m,)).astype(np.float32)
-    p = 1.0 / np.arange(1, Vf + 1)
-    keys = rng.choice(Vf, size=n, p=p / p.sum()).astype(np.int32)
-    keys[rng.choice(n, size=n // 5, replace=False)] = 0x7FFFFFFF
+    if dist == 'zipf':
+        p = 1.0 / np.arange(1, Vf + 1)
+        keys = rng.choice(Vf, size=n, p=p / p.sum()).astype(np.int32)
+        keys[rng.choice(n, size=n // 5, replace=False)] = 0x7FFFFFFF
+    elif dist == 'uniform':
+        keys = rng.integers(0, Vf, size=n).astype(np.int32)
+    else:   # sorted order = runs of exactly 2048 (the extraction tile), then a tail of one
+        keys = rng.permutation((np.arange(n) // 2048).astype(np.int32) % Vf)
+        keys[keys == 0] = np.where(rng.random((keys == 0).sum()) < 0.5, 0, Vf - 1)
     src = rng.integers(0, m, size=n).astype(np.int32)
     coef = rng.random(n).astype(np.float32)
     rE, racc, rb, rbacc = _ref_sparse_adagrad(E, acc, bias, bacc, keys, src, coef, G, Gb, 0.3, 1.0)

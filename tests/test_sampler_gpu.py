@@ -147,6 +147,33 @@ def test_capped_race_equals_uncapped(dev):
         assert torch.equal(a, b) and int(a.min().item()) >= 0
 
 
+@pytest.mark.parametrize("n,S", [(1000003, 1024), (262147, 64), (70001, 2048), (500002, 4096)])
+def test_capped_race_survivor_list_edges(dev, n, S):
+    """The capped race of S <= 2048 never stores the n keys (k_race_compact -> k_bitonic_take): item
+    counts that are not multiples of 4, survivors in the tail, keys out == the un-capped race's, a cap
+    that lets more than the list's 16384 entries through -> all -1; S = 4096 takes the sort path."""
+    import torch
+    from arx import ops
+    rng = np.random.default_rng(n)
+    w = (rng.random(n) ** 3).astype(np.float32)
+    w[-3:] = 1e7                                                    # the tail items are (almost) always drawn
+    tw = torch.from_numpy(w).to(dev)
+    ws, ws2 = ops.Workspace(dev), ops.Workspace(dev)
+    a, b = (torch.empty(S, dtype=torch.int32, device=dev) for _ in range(2))
+    ka, kb = (torch.empty(S, dtype=torch.float32, device=dev) for _ in range(2))
+    cap = 7.5 * S / float(w[:-3].astype(np.float64).sum())         # (w t << 1 for all but the three heavy items)
+    for counter in (1, 2):
+        ops.sample_wor(tw, S, 11, counter, a, ws, out_keys=ka)
+        ops.sample_wor(tw, S, 11, counter, b, ws2, key_cap=cap, out_keys=kb)
+        assert torch.equal(a, b) and torch.equal(ka, kb) and int(a.min().item()) >= 0
+        assert set(range(n - 3, n)) <= set(a.cpu().numpy().tolist())
+        assert bool((ka[1:] >= ka[:-1]).all())
+    if S <= 2048:
+        assert ws2.buf.numel() == (1 << 20)                              # no 28 n-byte workspace on this path
+        ops.sample_wor(tw, S, 11, 3, b, ws2, key_cap=1e30)           # every positive weight survives the cap
+        assert int(b.max().item()) == -1
+
+
 def test_device_sampler_heavy_tailed_weights(dev):
     """DeviceSampler on Zipf(1.5)-like weights (round-2 advisor finding): with the cap 8 S / sum(w)
     only ~600 of 1 M keys survived, the draw of 1000 came back short and the missing positions
