@@ -100,6 +100,20 @@ class HipBackend(object):
     def gather_rows_packed(self, E, bias, rows, out):
         self.ops.gather_onehot_packed(E, bias, None, rows, out)
 
+    def gather_rows_multi(self, sites):
+        """Several lookups of equal width in one launch; sites: [(E, bias|None, rows, out, bias_out)],
+        bias_out None | a vector | 'packed' (column d of the out rows).  Static buffers: the descriptor
+        is built once per set of addresses."""
+        key = tuple((E.data_ptr(), r.data_ptr(), int(r.shape[0]), o.data_ptr(),
+                     b if isinstance(b, str) else (b.data_ptr() if b is not None else 0)) for E, _, r, o, b in sites)
+        cache = self.__dict__.setdefault('_gsets', {})
+        gs = cache.get(key)
+        if gs is None:
+            if len(cache) > 16:
+                cache.clear()
+            gs = cache[key] = self.ops.GatherSet([(E, bias, None, r, o, 1.0, b) for E, bias, r, o, b in sites])
+        self.ops.gather_onehot_multi(gs)
+
     def gemm(self, A, B, C, transA=False, transB=False, beta=0.0, col_bias=None, a_rowsum=None):
         self.ops.gemm(A, B, C, self.ws, transA=transA, transB=transB, beta=beta, col_bias=col_bias,
                       a_rowsum=a_rowsum)
@@ -464,7 +478,7 @@ class ShardedHMF(object):
         """The step of step() with every buffer at a fixed address and a fixed size, so that the
         kernels between two collectives are ONE hipGraph launch each (5 segments + K7's sort half as a
         sixth, on a second stream under the forward kernels + 4 collectives + one index copy per step
-        instead of ~35 kernel launches from Python; world 1: four graphs, no collective).  What varies from batch to batch is the index vector [user rows ; received target
+        instead of ~35 kernel launches from Python; world 1: ONE graph, the sort half a branch of it).  What varies from batch to batch is the index vector [user rows ; received target
         rows], padded with the shard's padding row to the capacity cap_r (gathers: a zero row;
         K7: the tables are passed without the padding row, so padded keys are out of range and dropped)
         and the split sizes of the two all-to-alls, which stay outside the graphs.  A configuration
@@ -490,7 +504,9 @@ class ShardedHMF(object):
         self.g_idx.copy_(idx, non_blocking=True)
         key = (cap, cap_r, self.g_idx.data_ptr(), self.arena.data_ptr(), self.pos_ptr.data_ptr(),
                self.pos_items.data_ptr())
-        if self._graph_key == key:
+        if os.environ.get("ARX_DIST_NO_CAPTURE"):        # (profiling: the static step, launched kernel by kernel)
+            mode = 'eager'
+        elif self._graph_key == key:
             mode = 'replay'
         elif self._warm_key == key:
             mode, self._graphs = 'capture', {}
@@ -505,28 +521,36 @@ class ShardedHMF(object):
         T_in = self.T_pack if W == 1 else self.T_send[:cap_r]              # target rows as gathered
         dT = arena[B_loc + Sg:B_loc + Sg + B_loc] if W == 1 else self.dT_pack
 
-        def fwd_gather():
-            be.gather_rows(self.E_user, None, urows, self.U_loc, None)
+        # world 1: nothing travels, so nothing is packed twice -- the pool bias goes straight to b_all, the pool
+        # gradient and its row sums straight into the K7 arena, the target-bias gradient straight into arena_b
+        def fwd_gather():      # the step's three lookups, one launch
             if W == 1:
-                be.gather_rows_packed(self.E_item, self.b_item, self.pool_rows, self.I_all)
-                be.gather_rows_packed(self.E_item, self.b_item, rrows[:B_loc], T_in)
+                be.gather_rows_multi([(self.E_user, None, urows, self.U_loc, None),
+                                      (self.E_item, self.b_item, self.pool_rows, self.I_all, self.b_all),
+                                      (self.E_item, self.b_item, rrows[:B_loc], T_in, 'packed')])
             else:
-                be.gather_rows_packed(self.E_item, self.b_item, self.pool_rows[:cap], self.I_pack[:cap])
-                be.gather_rows_packed(self.E_item, self.b_item, rrows, T_in)
+                be.gather_rows_multi([(self.E_user, None, urows, self.U_loc, None),
+                                      (self.E_item, self.b_item, self.pool_rows[:cap], self.I_pack[:cap], 'packed'),
+                                      (self.E_item, self.b_item, rrows, T_in, 'packed')])
 
         def fwd_score():
             if W > 1:
                 be.gather_rows(self.I_gath, None, self.gidx, self.I_all, None)     # blocks -> pool (slot) order
-            be.copy_strided(self.I_all[:, d], self.b_all)
+                be.copy_strided(self.I_all[:, d], self.b_all)
             be.gemm(self.U_loc, self.I_all[:, :d], self.logits, transB=True, col_bias=self.b_all)
 
         def loss():
+            dt = arena_b[B_loc + Sg:B_loc + Sg + B_loc] if W == 1 else dT[:, d]
             be.loss_mw_fused_pos(self.logits, self.U_loc, self.T_pack[:, :d], self.T_pack[:, d], urows,
                                  self.pos_ptr, self.pos_items, self.item2slot, self.bl, self.dlogits,
-                                 self.t_loc, dT[:, d], dU, dT[:, :d], 1.0 / B)
+                                 self.t_loc, dt, dU, dT[:, :d], 1.0 / B)
 
         def bwd_gemms():
             be.gemm(self.dlogits, self.I_all[:, :d], dU, beta=1.0)
+            if W == 1:
+                be.gemm(self.dlogits, self.U_loc, arena[B_loc:B_loc + S, :d], transA=True,
+                        a_rowsum=arena_b[B_loc:B_loc + S])
+                return
             be.gemm(self.dlogits, self.U_loc, self.dI_all[:S, :d], transA=True, a_rowsum=self.gb_all)
             be.copy_strided(self.gb_all, self.dI_all[:S, d])
 
@@ -538,36 +562,43 @@ class ShardedHMF(object):
                                     arena[:, :d], arena_b, self.lr, phase=phase)
 
         def apply():
-            if W == 1:
-                be.copy_2d(self.dI_all[:S], arena[B_loc:B_loc + S])
-            else:
+            if W > 1:
                 be.gather_rows(self.dI_all, None, self.my_slots[:cap], arena[B_loc:B_loc + cap], None)
-            n_rows = B_loc + Sg + (B_loc if W == 1 else cap_r)
-            be.copy_strided(arena[B_loc:n_rows, d], arena_b[B_loc:n_rows])
+                n_rows = B_loc + Sg + cap_r
+                be.copy_strided(arena[B_loc:n_rows, d], arena_b[B_loc:n_rows])
             k7(2)
 
-        def k7_sorts():
-            # K7's keys, sorts and run records need the ids only: a graph of its own on a second stream,
-            # under the forward kernels (the ~70 us chain leaves the critical path)
+        def k7_sorts(own_graph):
+            # K7's keys, sorts and run records need the ids only: on a second stream, under the forward
+            # kernels (the ~70 us chain leaves the critical path) -- a graph of its own between the
+            # segments, a branch of the one graph at world 1
             main, side = torch.cuda.current_stream(dev), self._side
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                seg('k7_sorts', lambda: k7(1))
+                if own_graph:
+                    seg('k7_sorts', lambda: k7(1))
+                else:
+                    k7(1)
                 done = torch.cuda.Event()
                 done.record(side)
             return done
 
-        if W == 1:
-            seg('fwd_gather', fwd_gather)
-            sorted_ = k7_sorts()
-            seg('step', lambda: (fwd_score(), loss(), bwd_gemms()))
+        def whole_step():
+            fwd_gather()
+            sorted_ = k7_sorts(False)
+            fwd_score()
+            loss()
+            bwd_gemms()
             torch.cuda.current_stream(dev).wait_event(sorted_)
-            seg('apply', apply)
+            apply()
+
+        if W == 1:
+            seg('step', whole_step)
         else:
             seg('fwd_gather', fwd_gather)
-            sorted_ = k7_sorts()
+            sorted_ = k7_sorts(True)
             dist.all_gather_into_tensor(self.I_gath[:W * cap], self.I_pack[:cap], group=grp)
             w_rows = _all_to_all(self.T_pack, self.T_send[:R], send, recv, group=grp, async_op=True)
             seg('fwd_score', fwd_score)                       # scorer GEMM under the target-row exchange

@@ -174,7 +174,8 @@ def gather_id_plus_bag(E_id, bias_id, cat_map, E_tok, bias_tok, vals, starts, le
 
 class GatherSet(object):
     """Descriptor arrays of arx_gather_onehot_multi, built once per plan.
-    sites: [(E, bias|None, cat_map|None, ids, out, scale, bias_out|None)], equal width d."""
+    sites: [(E, bias|None, cat_map|None, ids, out, scale, bias_out|None)], equal width d.
+    bias_out may be the string 'packed': the bias goes to column d of the site's out rows."""
 
     def __init__(self, sites):
         import ctypes as C
@@ -184,16 +185,21 @@ class GatherSet(object):
         vp = lambda xs: (C.c_void_p * n)(*[(_p(x) or None) for x in xs])
         self.E, self.bias = vp([s[0] for s in sites]), vp([s[1] for s in sites])
         self.cat_map, self.ids = vp([s[2] for s in sites]), vp([s[3] for s in sites])
-        self.out, self.bias_out = vp([s[4] for s in sites]), vp([s[6] for s in sites])
+        packed = [isinstance(s[6], str) for s in sites]
+        assert all(s[6] == 'packed' and _ld(s[4]) > self.d for s, pk in zip(sites, packed) if pk)
+        self.out = vp([s[4] for s in sites])
+        self.bias_out = (C.c_void_p * n)(*[(_p(s[4]) + 4 * self.d) if pk else (_p(s[6]) or None)
+                                           for s, pk in zip(sites, packed)])
         self.cnt = (C.c_int64 * n)(*[int(s[3].shape[0]) for s in sites])
         self.ldo = (C.c_int64 * n)(*[_ld(s[4]) for s in sites])
+        self.ldb = (C.c_int64 * n)(*[_ld(s[4]) if pk else 1 for s, pk in zip(sites, packed)])
         self.scale = (C.c_float * n)(*[float(s[5]) for s in sites])
         self._keep = sites
 
 
 def gather_onehot_multi(gs):
-    call("arx_gather_onehot_multi", gs.n, gs.E, gs.bias, gs.cat_map, gs.ids, gs.cnt, gs.d, gs.scale, gs.out,
-         gs.ldo, gs.bias_out, _stream())
+    call("arx_gather_onehot_multi_ld", gs.n, gs.E, gs.bias, gs.cat_map, gs.ids, gs.cnt, gs.d, gs.scale, gs.out,
+         gs.ldo, gs.bias_out, gs.ldb, _stream())
 
 
 class LookupSet(object):

@@ -489,6 +489,7 @@ struct GatherSites {
   float* out[kMaxSites];
   float* bias_out[kMaxSites];
   int64_t ldo[kMaxSites];
+  int64_t ldb[kMaxSites];          // bias_out[r * ldb]: 1, or ldo for a column of `out` (packed rows)
   int64_t n[kMaxSites];            // rows of each site
   int32_t blk_end[kMaxSites];      // exclusive prefix ends over the sites' workgroups
   float scale[kMaxSites];
@@ -524,6 +525,7 @@ __global__ __launch_bounds__(256) void k_gather_onehot_multi(GatherSites gs, int
   float* __restrict__ out = gs.out[s];
   float* __restrict__ bias_out = gs.bias_out[s];
   const int64_t ldo = gs.ldo[s];
+  const int64_t ldb = gs.ldb[s];
   const float sc = gs.scale[s];
   const int64_t base = (int64_t)((int)blockIdx.x - blk0) * RPB + wv * GPW + gid;
   int64_t r[UN];
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(256) void k_gather_onehot_multi(GatherSites gs, int
     if (col < d)
       *reinterpret_cast<float4*>(out + r[u] * ldo + col) =
           make_float4(sc * v[u].x, sc * v[u].y, sc * v[u].z, sc * v[u].w);
-    if (bias_out && lig == 0) bias_out[r[u]] = sc * bv[u];
+    if (bias_out && lig == 0) bias_out[r[u] * ldb] = sc * bv[u];
   }
 }
 
@@ -659,6 +661,13 @@ int arx_gather_onehot_multi(int nsites, const float* const* E, const float* cons
                             const int32_t* const* cat_map, const int32_t* const* ids,
                             const int64_t* n, int d, const float* scale, float* const* out,
                             const int64_t* ldo, float* const* bias_out, void* stream) {
+  return arx_gather_onehot_multi_ld(nsites, E, bias, cat_map, ids, n, d, scale, out, ldo, bias_out, nullptr, stream);
+}
+
+int arx_gather_onehot_multi_ld(int nsites, const float* const* E, const float* const* bias,
+                               const int32_t* const* cat_map, const int32_t* const* ids,
+                               const int64_t* n, int d, const float* scale, float* const* out,
+                               const int64_t* ldo, float* const* bias_out, const int64_t* ldb, void* stream) {
   ARX_CHECK_ARG(nsites >= 1 && nsites <= kMaxSites, "arx_gather_onehot_multi: 1..8 sites");
   ARX_CHECK_ARG(E && ids && n && out && ldo && scale, "arx_gather_onehot_multi: null pointer");
   int rc = check_d("arx_gather_onehot_multi", d);
@@ -677,6 +686,8 @@ int arx_gather_onehot_multi(int nsites, const float* const* E, const float* cons
     gs.out[s] = out[s];
     gs.bias_out[s] = bias_out ? bias_out[s] : nullptr;
     gs.ldo[s] = ldo[s];
+    gs.ldb[s] = ldb ? ldb[s] : 1;
+    ARX_CHECK_ARG(gs.ldb[s] >= 1, "arx_gather_onehot_multi: bad ldb");
     gs.scale[s] = scale[s];
     gs.n[s] = n[s];
     tot += n[s];

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("graphs", [True, False])
 def test_sharded_hip_backend_world1(dev, graphs):
-    """graphs=True: the step is four hipGraphs (ShardedHMF._step_static: eager on step 0, captured on step
+    """graphs=True: the step is ONE hipGraph (ShardedHMF._step_static: eager on step 0, captured on step
     1, replayed from step 2 on -- through two pool redraws and fresh batches)."""
     import torch
     import torch.distributed as dist
@@ -50,7 +50,7 @@ def test_sharded_hip_backend_world1(dev, graphs):
             model.step(users, items)
             l_got = float(model.read_loss().item())
             np.testing.assert_allclose(l_got, l_ref, rtol=1e-4)
-        assert (model._graph_key is not None and set(model._graphs) == {'fwd_gather', 'k7_sorts', 'step', 'apply'}) == graphs
+        assert (model._graph_key is not None and set(model._graphs) == {'step'}) == graphs
         got = model.gather_global_tables()
         np.testing.assert_allclose(got['user'], ref.att_emb.params['userembed_cat_0'][2:], rtol=1e-4, atol=2e-6)
         np.testing.assert_allclose(got['item'], ref.att_emb.params['itemembed_cat_0'][2:], rtol=1e-4, atol=2e-6)
