@@ -49,8 +49,8 @@ PROTOTYPES = {
     "arx_gather_onehot_multi": (cint, [cint, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                        C.POINTER(i64), cint, C.POINTER(f32), C.POINTER(vp), C.POINTER(i64),
                                        C.POINTER(vp), vp]),
-    "arx_gather_onehot_multi_ld": (cint, [cint, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
-                                          C.POINTER(i64), cint, C.POINTER(f32), C.POINTER(vp), C.POINTER(i64),
+    "arx_gather_onehot_multi_ld": (cint, [cint, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(vp),
+                                          C.POINTER(vp), C.POINTER(i64), cint, C.POINTER(f32), C.POINTER(vp), C.POINTER(i64),
                                           C.POINTER(vp), C.POINTER(i64), vp]),
     "arx_gather_mulhot_mean_fwd": (cint, [f32p, f32p, i32p, i32p, i32p, i32p, i64, cint, f32, cint,
                                           f32p, i64, f32p, vp]),

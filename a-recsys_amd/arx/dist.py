@@ -101,11 +101,12 @@ class HipBackend(object):
         self.ops.gather_onehot_packed(E, bias, None, rows, out)
 
     def gather_rows_multi(self, sites):
-        """Several lookups of equal width in one launch; sites: [(E, bias|None, rows, out, bias_out)],
-        bias_out None | a vector | 'packed' (column d of the out rows).  Static buffers: the descriptor
+        """Several lookups of equal width in one launch; sites: [(E, bias|None|column, rows, out, bias_out)],
+        bias an int: that column of E's (packed) rows; bias_out None | a vector | 'packed' (column d of the
+        out rows).  Static buffers: the descriptor
         is built once per set of addresses."""
-        key = tuple((E.data_ptr(), r.data_ptr(), int(r.shape[0]), o.data_ptr(),
-                     b if isinstance(b, str) else (b.data_ptr() if b is not None else 0)) for E, _, r, o, b in sites)
+        key = tuple((E.data_ptr(), bi if isinstance(bi, int) else -1, r.data_ptr(), int(r.shape[0]), o.data_ptr(),
+                     b if isinstance(b, str) else (b.data_ptr() if b is not None else 0)) for E, bi, r, o, b in sites)
         cache = self.__dict__.setdefault('_gsets', {})
         gs = cache.get(key)
         if gs is None:
@@ -534,9 +535,8 @@ class ShardedHMF(object):
                                       (self.E_item, self.b_item, rrows, T_in, 'packed')])
 
         def fwd_score():
-            if W > 1:
-                be.gather_rows(self.I_gath, None, self.gidx, self.I_all, None)     # blocks -> pool (slot) order
-                be.copy_strided(self.I_all[:, d], self.b_all)
+            if W > 1:    # blocks -> pool (slot) order, their bias column -> b_all
+                be.gather_rows_multi([(self.I_gath, d, self.gidx, self.I_all, self.b_all)])
             be.gemm(self.U_loc, self.I_all[:, :d], self.logits, transB=True, col_bias=self.b_all)
 
         def loss():
@@ -562,10 +562,11 @@ class ShardedHMF(object):
                                     arena[:, :d], arena_b, self.lr, phase=phase)
 
         def apply():
-            if W > 1:
-                be.gather_rows(self.dI_all, None, self.my_slots[:cap], arena[B_loc:B_loc + cap], None)
-                n_rows = B_loc + Sg + cap_r
-                be.copy_strided(arena[B_loc:n_rows, d], arena_b[B_loc:n_rows])
+            if W > 1:    # the rows of this rank's block out of the summed pool gradient (bias column -> arena_b),
+                #              the bias column of the received target-row gradients
+                be.gather_rows_multi([(self.dI_all, d, self.my_slots[:cap], arena[B_loc:B_loc + cap],
+                                       arena_b[B_loc:B_loc + cap])])
+                be.copy_strided(arena[B_loc + Sg:B_loc + Sg + cap_r, d], arena_b[B_loc + Sg:B_loc + Sg + cap_r])
             k7(2)
 
         def k7_sorts(own_graph):

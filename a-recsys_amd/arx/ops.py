@@ -175,7 +175,8 @@ def gather_id_plus_bag(E_id, bias_id, cat_map, E_tok, bias_tok, vals, starts, le
 class GatherSet(object):
     """Descriptor arrays of arx_gather_onehot_multi, built once per plan.
     sites: [(E, bias|None, cat_map|None, ids, out, scale, bias_out|None)], equal width d.
-    bias_out may be the string 'packed': the bias goes to column d of the site's out rows."""
+    bias_out may be the string 'packed': the bias goes to column d of the site's out rows.
+    bias may be an int c: column c of the (packed) table rows themselves."""
 
     def __init__(self, sites):
         import ctypes as C
@@ -183,7 +184,11 @@ class GatherSet(object):
         self.n = n
         self.d = int(sites[0][0].shape[1])
         vp = lambda xs: (C.c_void_p * n)(*[(_p(x) or None) for x in xs])
-        self.E, self.bias = vp([s[0] for s in sites]), vp([s[1] for s in sites])
+        self.E = vp([s[0] for s in sites])
+        colb = [isinstance(s[1], int) for s in sites]
+        self.bias = (C.c_void_p * n)(*[(_p(s[0]) + 4 * s[1]) if cb else (_p(s[1]) or None)
+                                       for s, cb in zip(sites, colb)])
+        self.ldbi = (C.c_int64 * n)(*[self.d if cb else 1 for cb in colb])
         self.cat_map, self.ids = vp([s[2] for s in sites]), vp([s[3] for s in sites])
         packed = [isinstance(s[6], str) for s in sites]
         assert all(s[6] == 'packed' and _ld(s[4]) > self.d for s, pk in zip(sites, packed) if pk)
@@ -198,7 +203,7 @@ class GatherSet(object):
 
 
 def gather_onehot_multi(gs):
-    call("arx_gather_onehot_multi_ld", gs.n, gs.E, gs.bias, gs.cat_map, gs.ids, gs.cnt, gs.d, gs.scale, gs.out,
+    call("arx_gather_onehot_multi_ld", gs.n, gs.E, gs.bias, gs.ldbi, gs.cat_map, gs.ids, gs.cnt, gs.d, gs.scale, gs.out,
          gs.ldo, gs.bias_out, gs.ldb, _stream())
 
 

@@ -490,6 +490,7 @@ struct GatherSites {
   float* bias_out[kMaxSites];
   int64_t ldo[kMaxSites];
   int64_t ldb[kMaxSites];          // bias_out[r * ldb]: 1, or ldo for a column of `out` (packed rows)
+  int64_t ldbi[kMaxSites];         // bias[row * ldbi]: 1, or the row stride of a packed table
   int64_t n[kMaxSites];            // rows of each site
   int32_t blk_end[kMaxSites];      // exclusive prefix ends over the sites' workgroups
   float scale[kMaxSites];
@@ -526,6 +527,7 @@ __global__ __launch_bounds__(256) void k_gather_onehot_multi(GatherSites gs, int
   float* __restrict__ bias_out = gs.bias_out[s];
   const int64_t ldo = gs.ldo[s];
   const int64_t ldb = gs.ldb[s];
+  const int64_t ldbi = gs.ldbi[s];
   const float sc = gs.scale[s];
   const int64_t base = (int64_t)((int)blockIdx.x - blk0) * RPB + wv * GPW + gid;
   int64_t r[UN];
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(256) void k_gather_onehot_multi(GatherSites gs, int
   for (int u = 0; u < UN; ++u) {
     v[u] = (ok[u] && col < d) ? *reinterpret_cast<const float4*>(E + (int64_t)row[u] * d + col)
                               : make_float4(0.f, 0.f, 0.f, 0.f);
-    bv[u] = (ok[u] && bias_out && lig == 0) ? bias[row[u]] : 0.f;
+    bv[u] = (ok[u] && bias_out && lig == 0) ? bias[(int64_t)row[u] * ldbi] : 0.f;
   }
 #pragma unroll
   for (int u = 0; u < UN; ++u) {
@@ -661,10 +663,11 @@ int arx_gather_onehot_multi(int nsites, const float* const* E, const float* cons
                             const int32_t* const* cat_map, const int32_t* const* ids,
                             const int64_t* n, int d, const float* scale, float* const* out,
                             const int64_t* ldo, float* const* bias_out, void* stream) {
-  return arx_gather_onehot_multi_ld(nsites, E, bias, cat_map, ids, n, d, scale, out, ldo, bias_out, nullptr, stream);
+  return arx_gather_onehot_multi_ld(nsites, E, bias, nullptr, cat_map, ids, n, d, scale, out, ldo, bias_out, nullptr,
+                                    stream);
 }
 
-int arx_gather_onehot_multi_ld(int nsites, const float* const* E, const float* const* bias,
+int arx_gather_onehot_multi_ld(int nsites, const float* const* E, const float* const* bias, const int64_t* ldbi,
                                const int32_t* const* cat_map, const int32_t* const* ids,
                                const int64_t* n, int d, const float* scale, float* const* out,
                                const int64_t* ldo, float* const* bias_out, const int64_t* ldb, void* stream) {
@@ -687,7 +690,8 @@ int arx_gather_onehot_multi_ld(int nsites, const float* const* E, const float* c
     gs.bias_out[s] = bias_out ? bias_out[s] : nullptr;
     gs.ldo[s] = ldo[s];
     gs.ldb[s] = ldb ? ldb[s] : 1;
-    ARX_CHECK_ARG(gs.ldb[s] >= 1, "arx_gather_onehot_multi: bad ldb");
+    gs.ldbi[s] = ldbi ? ldbi[s] : 1;
+    ARX_CHECK_ARG(gs.ldb[s] >= 1 && gs.ldbi[s] >= 1, "arx_gather_onehot_multi: bad bias stride");
     gs.scale[s] = scale[s];
     gs.n[s] = n[s];
     tot += n[s];

@@ -138,11 +138,13 @@ int arx_gather_onehot_multi(int nsites, const float* const* E, const float* cons
                             const int32_t* const* cat_map, const int32_t* const* ids,
                             const int64_t* n, int d, const float* scale, float* const* out,
                             const int64_t* ldo, float* const* bias_out, void* stream);
-/* ... with a stride for every site's bias output: bias_out[s][r * ldb[s]] (ldb NULL: 1 everywhere).
- * bias_out[s] = out[s] + d with ldb[s] = ldo[s] gives the packed rows of arx_gather_onehot_packed_fwd:
- * the sharded step's three lookups (own user rows; pool block and requested target rows, packed for
- * the exchanges) are one launch. */
-int arx_gather_onehot_multi_ld(int nsites, const float* const* E, const float* const* bias,
+/* ... with a stride for every site's bias output, bias_out[s][r * ldb[s]], and bias input,
+ * bias[s][row * ldbi[s]] (NULL: 1 everywhere).  bias_out[s] = out[s] + d with ldb[s] = ldo[s] gives
+ * the packed rows of arx_gather_onehot_packed_fwd: the sharded step's three lookups (own user rows;
+ * pool block and requested target rows, packed for the exchanges) are one launch.  bias[s] = E[s] + d0
+ * with ldbi[s] = d reads column d0 of a table of PACKED rows (d = its full row width): reordering
+ * received packed rows and splitting off their bias column is one launch too. */
+int arx_gather_onehot_multi_ld(int nsites, const float* const* E, const float* const* bias, const int64_t* ldbi,
                                const int32_t* const* cat_map, const int32_t* const* ids,
                                const int64_t* n, int d, const float* scale, float* const* out,
                                const int64_t* ldo, float* const* bias_out, const int64_t* ldb, void* stream);

@@ -125,6 +125,42 @@ def test_gather_onehot_multi(dev, d, sizes):
             np.testing.assert_allclose(bout.cpu().numpy(), wb, rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("d,sizes", [(128, [300, 77, 1030]), (64, [5, 0, 9])])
+def test_gather_onehot_multi_packed_sites(dev, d, sizes):
+    """arx_gather_onehot_multi_ld: sites whose bias goes to column d of their packed out rows ('packed'),
+    and a site that reorders PACKED rows and splits off their bias column (bias = column d of the table
+    itself) -- the sharded step's fused lookups (arx.dist.ShardedHMF._step_static)."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(d)
+    V = 211
+    E = rng.standard_normal((V, d)).astype(np.float32)
+    bias = rng.standard_normal((V,)).astype(np.float32)
+    tE, tb = _t(dev, E), _t(dev, bias)
+    ids = [rng.integers(0, V, size=n).astype(np.int32) for n in sizes]
+    plain = torch.full((max(sizes[0], 1), d), 3.0, dtype=torch.float32, device=dev)[:sizes[0]]
+    vec = torch.full((max(sizes[0], 1),), 3.0, dtype=torch.float32, device=dev)[:sizes[0]]
+    packed = [torch.full((max(n, 1), d + 4), 9.0, dtype=torch.float32, device=dev)[:n] for n in sizes[1:]]
+    ops.gather_onehot_multi(ops.GatherSet(
+        [(tE, tb, None, _t(dev, ids[0]), plain, 1.0, vec)] +
+        [(tE, tb, None, _t(dev, i), o, 1.0, 'packed') for i, o in zip(ids[1:], packed)]))
+    np.testing.assert_array_equal(plain.cpu().numpy(), E[ids[0]])
+    np.testing.assert_array_equal(vec.cpu().numpy(), bias[ids[0]])
+    for i, o in zip(ids[1:], packed):
+        got = o.cpu().numpy()
+        np.testing.assert_array_equal(got[:, :d], E[i])
+        np.testing.assert_array_equal(got[:, d], bias[i])
+        assert np.all(got[:, d + 1:] == 9.0)                              # the padding columns are not written
+    # packed table in, reordered packed rows + bias vector out
+    P = rng.standard_normal((V, d + 4)).astype(np.float32)
+    order = rng.integers(0, V, size=sizes[2]).astype(np.int32)
+    out = torch.zeros((max(sizes[2], 1), d + 4), dtype=torch.float32, device=dev)[:sizes[2]]
+    bvec = torch.zeros((max(sizes[2], 1),), dtype=torch.float32, device=dev)[:sizes[2]]
+    ops.gather_onehot_multi(ops.GatherSet([(_t(dev, P), d, None, _t(dev, order), out, 1.0, bvec)]))
+    np.testing.assert_array_equal(out.cpu().numpy(), P[order])
+    np.testing.assert_array_equal(bvec.cpu().numpy(), P[order, d])
+
+
 @pytest.mark.parametrize("d,B", [(128, 1000), (32, 7), (64, 0)])
 def test_gather_onehot_packed_and_strided_copy(dev, d, B):
     """Packed rows of the sharded exchanges: [row | bias | pad]; the bias column <-> vector copies."""
