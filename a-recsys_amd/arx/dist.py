@@ -395,6 +395,9 @@ class ShardedHMF(object):
         route = users if isinstance(users, dict) else self.prepare_route(users, items)
         if self.use_graphs:
             outer = torch.cuda.current_stream(self.device)
+            if outer == self._stream:          # the caller already works on the model's stream (model.stream)
+                self._step_static(route)
+                return
             self._stream.wait_stream(outer)
             with torch.cuda.stream(self._stream):
                 self._step_static(route)
@@ -457,6 +460,13 @@ class ShardedHMF(object):
         self.steps += 1
 
 
+    @property
+    def stream(self):
+        """The stream the graph-segment step runs on (None: eager step, the caller's stream).  A training loop
+        that makes it the current stream (`with torch.cuda.stream(model.stream)`) saves the two stream
+        joins per step that a caller on another stream pays."""
+        return self._stream
+
     # ------------------------------------------------------- step, hipGraph segments
     def _segment(self, mode, name, fn):
         """eager: run; capture: record the launches of `fn` into a hipGraph, keep it, launch it;
@@ -502,7 +512,7 @@ class ShardedHMF(object):
             route['idx'] = idx
         if self.g_idx is None or self.g_idx.shape[0] != n_idx:
             self.g_idx = torch.empty(n_idx, dtype=torch.int32, device=dev)
-        self.g_idx.copy_(idx, non_blocking=True)
+        be.ops.copy_words([(idx, self.g_idx)])         # (a kernel: a device-to-device hipMemcpyAsync costs more)
         key = (cap, cap_r, self.g_idx.data_ptr(), self.arena.data_ptr(), self.pos_ptr.data_ptr(),
                self.pos_items.data_ptr())
         if os.environ.get("ARX_DIST_NO_CAPTURE"):        # (profiling: the static step, launched kernel by kernel)
@@ -1140,12 +1150,17 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
     setup_s = time.time() - t_setup
     redraws = [0]
 
+    import contextlib
+
     def run(k0, k1):
-        for k in range(k0, k1):
-            if k == 0 or (k >= args.warmup and (k - args.warmup) % args.n_resample == 0):
-                redraw()
-                redraws[0] += k >= args.warmup
-            model.step(batches[k % nb])
+        # the whole loop (redraws, steps) on the model's own stream: no stream joins around the steps
+        own = getattr(model, 'stream', None)
+        with (torch.cuda.stream(own) if own is not None else contextlib.nullcontext()):
+            for k in range(k0, k1):
+                if k == 0 or (k >= args.warmup and (k - args.warmup) % args.n_resample == 0):
+                    redraw()
+                    redraws[0] += k >= args.warmup
+                model.step(batches[k % nb])
 
     run(0, args.warmup)
     torch.cuda.synchronize()
