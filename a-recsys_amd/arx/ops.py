@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 
 from . import _lib
@@ -256,6 +258,22 @@ def dot_score_bwd(U, T, dscore, dU, acc_dU, dT):
 
 
 # ---- a8 -----------------------------------------------------------------------
+_BX6 = bool(os.environ.get("ARX_GEMM_BX6"))      # EXPERIMENT: the logits GEMM on the bf16 pipe, f32-exact
+_bx6_ws = {}
+
+
+def gemm_nt_bx6(A, B, C, col_bias=None):
+    """C[M, N] = A[M, K] . B[N, K]^T + col_bias by six bf16 MFMAs per f32 product term (csrc/gemm_bx6.hip):
+    every bit of an f32 multiply-add chain at 16/6 of the f32 MFMA peak.  K in {64, 128}, N % 128 == 0."""
+    M, K = int(A.shape[0]), int(A.shape[1])
+    N = int(B.shape[0])
+    ws = _bx6_ws.setdefault(A.device, Workspace(A.device))
+    wsp, wsn = ws.get(_lib.lib.arx_gemm_nt_bx6_workspace_bytes(N, K))
+    call("arx_gemm_nt_bx6", M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(col_bias), _p(C), _ld(C), wsp, wsn,
+         _stream())
+    return C
+
+
 def gemm(A, B, C, ws, transA=False, transB=False, alpha=1.0, beta=0.0, col_bias=None,
          a_rowsum=None):
     """C[M,N] = alpha * op(A) . op(B) + beta * C + col_bias  (fp32 MFMA);
@@ -265,6 +283,9 @@ def gemm(A, B, C, ws, transA=False, transB=False, alpha=1.0, beta=0.0, col_bias=
     kb = int(B.shape[1] if transB else B.shape[0])
     if K != kb:
         raise ValueError("gemm: inner dimensions differ (%d vs %d)" % (K, kb))
+    if (_BX6 and transB and not transA and K in (64, 128) and N % 128 == 0 and alpha == 1.0 and beta == 0.0
+            and a_rowsum is None and M >= 4096):
+        return gemm_nt_bx6(A, B, C, col_bias)
     wsp, wsn = ws.get(_lib.lib.arx_gemm_f32_workspace_bytes(M, N, K))
     call("arx_gemm_f32_rowsum", int(bool(transA)), int(bool(transB)), M, N, K, float(alpha), _p(A),
          _ld(A), _p(B), _ld(B), float(beta), _p(C), _ld(C), _p(col_bias), _p(a_rowsum), wsp, wsn,

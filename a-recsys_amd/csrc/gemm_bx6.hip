@@ -1,0 +1,310 @@
+// gemm_bx6.hip -- f32 GEMMs of the scorer on the bf16 matrix pipe, f32-exact ("bf16 x 6").
+//
+// gfx950's f32-input MFMA runs at the f32 VECTOR rate (157 TF, 1/16 of the bf16 MFMA rate:
+// MI355X_MICROARCH.md, peak table); there is no xf32.  An f32 value splits EXACTLY into three bf16
+// pieces (8 + 8 + 8 mantissa bits, the pieces carry their own signs):
+//     a = a1 + a2 + a3,  a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)
+// (both subtractions are exact in f32; |a2| <= 2^-9 |a|, |a3| <= 2^-18 |a|), and a product of two
+// bf16 values is exact in f32 (16 mantissa bits).  So
+//     a b = a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1) + [a2 b3 + a3 b2 + a3 b3]
+// where the bracket is <= 2^-26 |a b| -- a quarter ulp of the product: six bf16 MFMAs with f32
+// accumulation carry every bit an f32 multiply-add chain carries, at 16/6 = 2.7x the f32 MFMA peak.
+// The five small terms go to their own accumulator (added once at the end), so they are not
+// swallowed one by one by the large a1 b1 sum.  tests/test_kernels_gpu.py::test_gemm_nt_bx6: error
+// against an f64 product <= the error of the f32-MFMA kernel on the same inputs (measured: a third of it).
+// STATUS: experiment -- ops.gemm takes this path only with ARX_GEMM_BX6=1.
+//
+// Kernels:
+//   k_split3      f32 [R, K] -> bf16 planes [3][R][K]  (the small operand: the pool rows)
+//   k_nt_bx6      C[M, N] = A[M, K] . B[N, K]^T + bias[n], K = 64 | 128 (the logits GEMM): a wave keeps
+//                 its 32 rows of A as bf16 pieces in registers for the whole kernel, the B planes stream
+//                 through LDS in tiles of 32 columns.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace arx {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t bf16_rne(float x) {       // f32 -> bf16 bits, round to nearest even
+  const uint32_t u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// x -> its three bf16 pieces (bits)
+__device__ __forceinline__ void split3(float x, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  p1 = bf16_rne(x);
+  const float r1 = x - __uint_as_float(p1 << 16);
+  p2 = bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float(p2 << 16);
+  p3 = bf16_rne(r2);
+}
+
+__global__ __launch_bounds__(256) void k_split3(const float* __restrict__ X, int64_t ldx, int64_t R, int K,
+                                                uint16_t* __restrict__ planes) {
+  const int64_t total = R * (int64_t)(K / 4);
+  const int64_t plane = R * (int64_t)K;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = q / (K / 4);
+    const int c = (int)(q - r * (K / 4)) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(X + r * ldx + c);
+    uint32_t a[3], b[3], cc[3], dd[3];
+    split3(v.x, a[0], a[1], a[2]);
+    split3(v.y, b[0], b[1], b[2]);
+    split3(v.z, cc[0], cc[1], cc[2]);
+    split3(v.w, dd[0], dd[1], dd[2]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      *reinterpret_cast<uint2*>(planes + p * plane + r * K + c) =
+          make_uint2(a[p] | (b[p] << 16), cc[p] | (dd[p] << 16));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C = A . B^T + bias, K = KD.  512 threads = 8 waves, two per SIMD, SPECIALISED:
+//   waves 0..3 (compute): wave (rt, cp) keeps rows [32 rt, 32 rt + 32) of the block's 64 as bf16 pieces in
+//     registers and owns the column tiles ct = cp (mod 2); per tile 48 MFMAs out of the B planes in LDS,
+//     then D (hi + lo) goes to an LDS tile -- a compute wave never touches global memory after its prologue,
+//     its only waits are LDS reads and the stage barrier;
+//   waves 4..7 (movers): load the next stage's B planes (global -> registers -> LDS) and write the
+//     PREVIOUS stage's C tiles (LDS -> + bias -> global, whole 128-byte lines per 8 lanes).
+// Both run on every SIMD, so the MFMA pipe of a SIMD is fed while its mover waits for memory.  One
+// barrier per stage; B slots and C tiles are double-buffered.
+// MFMA 32x32x16 bf16: lane l holds, of the first operand, row l % 32, k = 8 (l / 32) .. + 8 of the
+// 16-wide chunk; of the second, column l % 32, the same k; of D, column l % 32, rows
+// (i & 3) + 8 (i >> 2) + 4 (l >> 5).  The pool tile is the FIRST operand: D[pool column][row of A], so a
+// lane's registers 4 g .. 4 g + 3 are four consecutive columns of one row of C.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBxRowPad = 8;                       // bf16 of padding per LDS row: 16-byte reads of a wave spread over all banks
+constexpr int kBxCRow = 36;                        // floats per row of a C tile in LDS (32 + 4: ditto for the 16-byte writes)
+
+template <int KD>
+__global__ __launch_bounds__(512) void k_nt_bx6(int64_t M, int64_t N, const float* __restrict__ A, int64_t lda,
+                                                const uint16_t* __restrict__ Bp, const float* __restrict__ bias,
+                                                float* __restrict__ C, int64_t ldc) {
+  constexpr int NCP = 2;                           // column phases = column tiles of a stage
+  constexpr int NCH = KD / 16;                     // k chunks
+  constexpr int LDR = KD + kBxRowPad;              // LDS row (bf16)
+  constexpr int TILE = 32 * LDR;                   // one plane of one column tile (bf16)
+  constexpr int BSLOT = NCP * 3 * TILE;            // bf16 per B slot
+  constexpr int CT = 32 * kBxCRow;                 // floats per C tile
+  extern __shared__ uint16_t lds[];                // [2][NCP tiles][3 planes][32][LDR] bf16, then [2][4 waves][32][36] f32
+  float* cbuf = reinterpret_cast<float*>(lds + 2 * BSLOT);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int ntile = (int)(N / 32);
+  const int nstage = ntile / NCP;
+  const int64_t plane = N * (int64_t)KD;
+  const int64_t brow0 = (int64_t)blockIdx.x * 64;
+
+  if (wv < 4) {
+    // ================================ compute waves ================================
+    const int rt = wv & 1, cp = wv >> 1;
+    const int lr = lane & 31, kg = lane >> 5;
+    const int64_t row0 = brow0 + rt * 32;
+    bf16x8 a1[NCH], a2[NCH], a3[NCH];
+    {
+      const int64_t r = row0 + lr;
+      const bool ok = r < M;
+      const float* ap = A + (ok ? r : 0) * lda + 8 * kg;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (ok) {
+          v0 = *reinterpret_cast<const float4*>(ap + 16 * c);
+          v1 = *reinterpret_cast<const float4*>(ap + 16 * c + 4);
+        }
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        uint32_t p1[8], p2[8], p3[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split3(x[e], p1[e], p2[e], p3[e]);
+        uint4 q1 = make_uint4(p1[0] | (p1[1] << 16), p1[2] | (p1[3] << 16), p1[4] | (p1[5] << 16), p1[6] | (p1[7] << 16));
+        uint4 q2 = make_uint4(p2[0] | (p2[1] << 16), p2[2] | (p2[3] << 16), p2[4] | (p2[5] << 16), p2[6] | (p2[7] << 16));
+        uint4 q3 = make_uint4(p3[0] | (p3[1] << 16), p3[2] | (p3[3] << 16), p3[4] | (p3[5] << 16), p3[6] | (p3[7] << 16));
+        a1[c] = __builtin_bit_cast(bf16x8, q1);
+        a2[c] = __builtin_bit_cast(bf16x8, q2);
+        a3[c] = __builtin_bit_cast(bf16x8, q3);
+      }
+    }
+    __syncthreads();                                         // B stage 0 is in LDS
+    for (int st = 0; st < nstage; ++st) {
+      const int slot = st & 1;
+      const uint16_t* tb = lds + slot * BSLOT + (cp * 3) * TILE + lr * LDR + 8 * kg;
+      f32x16 hi = {0}, lo = {0};
+      // the three B fragments of chunk c + 1 are requested before the six MFMAs of chunk c are issued
+      uint4 f1 = *reinterpret_cast<const uint4*>(tb), f2 = *reinterpret_cast<const uint4*>(tb + TILE),
+            f3 = *reinterpret_cast<const uint4*>(tb + 2 * TILE);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, f1), b2 = __builtin_bit_cast(bf16x8, f2),
+                     b3 = __builtin_bit_cast(bf16x8, f3);
+        if (c + 1 < NCH) {
+          f1 = *reinterpret_cast<const uint4*>(tb + 16 * (c + 1));
+          f2 = *reinterpret_cast<const uint4*>(tb + TILE + 16 * (c + 1));
+          f3 = *reinterpret_cast<const uint4*>(tb + 2 * TILE + 16 * (c + 1));
+        }
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, a1[c], lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a3[c], lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a2[c], lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a1[c], lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a2[c], lo, 0, 0, 0);
+        hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1[c], hi, 0, 0, 0);
+      }
+      // D -> this wave's C tile of the stage: lane = row lr, columns 8 g + 4 kg + 0..3
+      float* ct = cbuf + (slot * 4 + wv) * CT + lr * kBxCRow + 4 * kg;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(ct + 8 * g) = make_float4(hi[4 * g] + lo[4 * g], hi[4 * g + 1] + lo[4 * g + 1],
+                                                             hi[4 * g + 2] + lo[4 * g + 2], hi[4 * g + 3] + lo[4 * g + 3]);
+      __syncthreads();
+    }
+    __syncthreads();                                         // (the movers' last C stage)
+    return;
+  }
+
+  // =================================== mover waves ===================================
+  // B loader: the stage's NCP * 32 pool rows are consecutive in every plane; thread -> (row rl of a pass of
+  // RPP rows, 16-byte piece k8), HP passes per plane: compile-time offsets.
+  const int mt = tid - 256;                          // 0..255
+  const int mw = wv - 4;                             // writes the C tiles of compute wave mw
+  constexpr int RPP = 256 / (KD / 8);
+  constexpr int HP = NCP * 32 / RPP;
+  constexpr int PER = 3 * HP;
+  static_assert(PER <= 12, "BX6_REP covers 12 pieces per thread");
+  const int k8 = mt % (KD / 8), rl = mt / (KD / 8);
+  const uint16_t* gsrc = Bp + (int64_t)rl * KD + 8 * k8;
+  uint16_t* ldst = lds + ((rl / 32) * 3) * TILE + (rl % 32) * LDR + 8 * k8;
+  uint4 nbA[PER];
+  // (element indices are literal constants -- BX6_REP -- so that the two register sets are promoted to
+  // registers although they live across the loop's back edge; with unrolled index loops they stayed in scratch)
+#define BX6_REP(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11)
+#define BX6_LOAD1(nb_, st_, J)                                                                          \
+  if constexpr (J < PER) {                                                                              \
+    constexpr int pl = J / HP, h = J % HP;                                                              \
+    nb_[J] = *reinterpret_cast<const uint4*>(gsrc + pl * plane + ((int64_t)(st_) * NCP * 32 + h * RPP) * KD); \
+  }
+#define BX6_STORE1(nb_, slot_, J)                                                                       \
+  if constexpr (J < PER) {                                                                              \
+    constexpr int pl = J / HP, h = J % HP;                                                              \
+    constexpr int t = (h * RPP) / 32, r = RPP <= 32 ? (h * RPP) % 32 : 0;                               \
+    *reinterpret_cast<uint4*>(ldst + (slot_) * BSLOT + (t * 3 + pl) * TILE + r * LDR) = nb_[J];         \
+  }
+#define BX6_LOAD(nb_, st_)                                                                              \
+  {                                                                                                     \
+    const int64_t st__ = (st_);                                                                         \
+    BX6_LOAD1(nb_, st__, 0) BX6_LOAD1(nb_, st__, 1) BX6_LOAD1(nb_, st__, 2) BX6_LOAD1(nb_, st__, 3)     \
+    BX6_LOAD1(nb_, st__, 4) BX6_LOAD1(nb_, st__, 5) BX6_LOAD1(nb_, st__, 6) BX6_LOAD1(nb_, st__, 7)     \
+    BX6_LOAD1(nb_, st__, 8) BX6_LOAD1(nb_, st__, 9) BX6_LOAD1(nb_, st__, 10) BX6_LOAD1(nb_, st__, 11)   \
+  }
+#define BX6_STORE(nb_, slot_)                                                                           \
+  {                                                                                                     \
+    const int sl__ = (slot_);                                                                           \
+    BX6_STORE1(nb_, sl__, 0) BX6_STORE1(nb_, sl__, 1) BX6_STORE1(nb_, sl__, 2) BX6_STORE1(nb_, sl__, 3) \
+    BX6_STORE1(nb_, sl__, 4) BX6_STORE1(nb_, sl__, 5) BX6_STORE1(nb_, sl__, 6) BX6_STORE1(nb_, sl__, 7) \
+    BX6_STORE1(nb_, sl__, 8) BX6_STORE1(nb_, sl__, 9) BX6_STORE1(nb_, sl__, 10) BX6_STORE1(nb_, sl__, 11) \
+  }
+  // C writer: lane -> (row lane / 8 + 8 p, 16-byte piece lane % 8) of compute wave mw's tile
+  const int crow = lane >> 3, cc4 = (lane & 7) * 4;
+  const int wrt = mw & 1, wcp = mw >> 1;
+  const int last = nstage - 1;
+  const int rot = (int)(blockIdx.x % (unsigned)nstage);
+#define BX6_BIAS(st_) (bias ? *reinterpret_cast<const float4*>(bias + (int64_t)(NCP * (st_) + wcp) * 32 + cc4) \
+                            : make_float4(0.f, 0.f, 0.f, 0.f))
+#define BX6_WRITE_C(st_, cs_, bv_)                                                                      \
+  {                                                                                                     \
+    const float* ct = cbuf + (((st_) & 1) * 4 + mw) * CT + crow * kBxCRow + cc4;                        \
+    const int64_t col = (int64_t)(NCP * (cs_) + wcp) * 32 + cc4;                                        \
+    _Pragma("unroll") for (int pp = 0; pp < 4; ++pp) {                                                  \
+      const int64_t r = brow0 + wrt * 32 + crow + 8 * pp;                                               \
+      const float4 v = *reinterpret_cast<const float4*>(ct + 8 * pp * kBxCRow);                         \
+      if (r < M)                                                                                        \
+        *reinterpret_cast<float4*>(C + r * ldc + col) =                                                 \
+            make_float4(v.x + bv_.x, v.y + bv_.y, v.z + bv_.z, v.w + bv_.w);                            \
+    }                                                                                                   \
+  }
+  // blocks start at different stages (rot): at any moment the chip's blocks read DIFFERENT B tiles, not all the
+  // same 48 KB of L2
+  BX6_LOAD(nbA, rot)
+  BX6_STORE(nbA, 0)
+  float4 bv = BX6_BIAS(rot);                                 // bias of the stage whose C is written next
+  __syncthreads();                                           // the first B stage is in LDS
+  // iteration st: loads of stage st + 1 go out, C of stage st - 1 is written, stage st + 1 goes to LDS
+  for (int st = 0; st < nstage; ++st) {
+    const int cur = st + rot < nstage ? st + rot : st + rot - nstage;
+    const int nxt = cur + 1 < nstage ? cur + 1 : 0;
+    const int prv = cur > 0 ? cur - 1 : last;
+    BX6_LOAD(nbA, nxt)
+    if (st > 0) BX6_WRITE_C(st - 1, prv, bv)
+    bv = BX6_BIAS(cur);
+    BX6_STORE(nbA, (st + 1) & 1)
+    __syncthreads();
+  }
+  {
+    const int cur = last + rot < nstage ? last + rot : last + rot - nstage;
+    BX6_WRITE_C(last, cur, bv)
+  }
+  __syncthreads();
+#undef BX6_BIAS
+#undef BX6_WRITE_C
+#undef BX6_LOAD
+#undef BX6_STORE
+#undef BX6_LOAD1
+#undef BX6_STORE1
+#undef BX6_REP
+}
+
+size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+}  // namespace arx
+
+using namespace arx;
+
+extern "C" {
+
+size_t arx_gemm_nt_bx6_workspace_bytes(int64_t N, int64_t K) { return align256((size_t)3 * N * K * 2); }
+
+int arx_gemm_nt_bx6(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                    const float* col_bias, float* C, int64_t ldc, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  ARX_CHECK_ARG(A && B && C && M > 0 && N > 0, "arx_gemm_nt_bx6: null pointer / empty");
+  ARX_CHECK_ARG((K == 64 || K == 128) && N % 128 == 0, "arx_gemm_nt_bx6: K in {64, 128}, N %% 128 == 0");
+  ARX_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && lda >= K && ldb >= K && ldc >= N,
+                "arx_gemm_nt_bx6: bad leading dimension");
+  const size_t need = arx_gemm_nt_bx6_workspace_bytes(N, K);
+  if (!workspace || workspace_bytes < need) {
+    set_error("arx_gemm_nt_bx6: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return ARX_EWORKSPACE;
+  }
+  hipStream_t s = as_stream(stream);
+  uint16_t* planes = reinterpret_cast<uint16_t*>(workspace);
+  {
+    int64_t g = ceil_div(N * (K / 4), 256);
+    k_split3<<<(int)g, 256, 0, s>>>(B, ldb, N, (int)K, planes);
+    ARX_CHECK_LAUNCH();
+  }
+  const int64_t nblk = ceil_div(M, 64);
+  const size_t lds = (size_t)2 * 2 * 3 * 32 * (K + kBxRowPad) * 2 + (size_t)2 * 4 * 32 * kBxCRow * 4;
+  static bool raised = false;
+  if (!raised) {
+    const int cap = 160 * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_nt_bx6<128>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_nt_bx6<64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    raised = true;
+  }
+  if (K == 128)
+    k_nt_bx6<128><<<(int)nblk, 512, lds, s>>>(M, N, A, lda, planes, col_bias, C, ldc);
+  else
+    k_nt_bx6<64><<<(int)nblk, 512, lds, s>>>(M, N, A, lda, planes, col_bias, C, ldc);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+}  // extern "C"

@@ -184,6 +184,16 @@ int arx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float 
 /* Same, and additionally a_rowsum[m] = sum_k op(A)[m,k] (nullable).  With
  * op(A) = dlogits^T this is the item-bias gradient (embed_attribute.py:171 `+ bias`
  * back-propagated), produced by the dI GEMM for free instead of a separate pass. */
+/* EXPERIMENT (off unless ARX_GEMM_BX6=1 in arx.ops): the same C = A . B^T + col_bias
+ * (embed_attribute.py:171 matmul(user, item^T) + bias), f32 in / f32 out, on the bf16 matrix pipe: every
+ * f32 operand is split exactly into three bf16 pieces and six of the nine piece products (the other three are
+ * below 2^-26 of the product) are accumulated in f32 -- every bit an f32 multiply-add chain carries, at 16/6 of
+ * the f32-MFMA peak (gfx950 runs f32-input MFMA at 1/16 of the bf16 rate).  K in {64, 128}, N % 128 == 0,
+ * lda / ldb / ldc % 4 == 0; workspace >= arx_gemm_nt_bx6_workspace_bytes(N, K) (the bf16 planes of B). */
+size_t arx_gemm_nt_bx6_workspace_bytes(int64_t N, int64_t K);
+int arx_gemm_nt_bx6(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                    const float* col_bias, float* C, int64_t ldc, void* workspace, size_t workspace_bytes,
+                    void* stream);
 int arx_gemm_f32_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                         const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
                         float* C, int64_t ldc, const float* col_bias, float* a_rowsum,

@@ -1384,3 +1384,32 @@ def test_gemm_bits(dev, M, N, K):
         ops.gemm_bits(tb, _t(dev, B2), C2, ws, transA=True, gvec=_t(dev, g), a_rowsum=r2)
         np.testing.assert_allclose(C2.cpu().numpy(), A.T.astype(np.float64) @ B2, rtol=RTOL, atol=2e-4)
         np.testing.assert_allclose(r2.cpu().numpy(), A.T.astype(np.float64) @ g, rtol=RTOL, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(16384, 1024, 128), (4097, 256, 64), (70, 128, 128)])
+def test_gemm_nt_bx6(dev, M, N, K):
+    """arx_gemm_nt_bx6 (experimental logits GEMM on the bf16 pipe, three exact bf16 pieces per f32 operand, six
+    MFMAs per product term): against an f64 product its error is no larger than the f32-MFMA kernel's on the
+    same inputs -- rows of very different magnitude, a bias, ragged M, strided operands -- and within the
+    f32 bound K * 2^-24 * sum |a||b|; logits equal to rtol 1e-6 of that scale."""
+    from arx import ops
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(M + K)
+    Ubuf = torch.randn(M, K + 8, device=dev, generator=g) * torch.exp(3 * torch.randn(M, 1, device=dev, generator=g))
+    U = Ubuf[:, :K]                                                   # lda = K + 8
+    I = torch.randn(N, K, device=dev, generator=g)
+    I[:, 0] = torch.arange(N, device=dev) * 0.01                      # asymmetric: a swapped C layout cannot pass
+    b = torch.randn(N, device=dev, generator=g)
+    Lbuf = torch.full((M, N + 4), 7.0, device=dev)
+    L1 = Lbuf[:, :N]                                                  # ldc = N + 4
+    L0 = torch.empty(M, N, device=dev)
+    ops.gemm(U, I, L0, ops.Workspace(dev), transB=True, col_bias=b)   # f32 MFMA
+    ops.gemm_nt_bx6(U, I, L1, b)
+    ref = U.double() @ I.double().T + b.double()
+    scale = U.double().abs() @ I.double().abs().T + b.double().abs()
+    e0 = ((L0.double() - ref).abs() / scale)
+    e1 = ((L1.double() - ref).abs() / scale)
+    assert float(e1.max()) <= K * 2.0 ** -24
+    assert float(e1.mean()) <= float(e0.mean()) * 1.05 and float(e1.max()) <= float(e0.max()) * 1.05
+    assert bool((Lbuf[:, N:] == 7.0).all())                           # nothing written past the row
