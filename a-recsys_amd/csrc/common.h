@@ -129,6 +129,13 @@ int gemm_nt_hinge(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, 
                   int64_t ldb, const float* col_bias, const float* tscore, uint32_t* bits,
                   int64_t ldbits, float* rs_part, float* cnt_part, int* nsplit_out, hipStream_t s);
 
+// gemm_bx6.hip: the hinge GEMM on the bf16 pipe (f32-exact: three bf16 pieces per operand, six MFMAs per term);
+// planes: 3 * N * K bf16 of scratch; K in {64, 128}, N % 128 == 0.  EXPERIMENT (ARX_GEMM_BX6=1).
+int gemm_nt_hinge_bx6(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                      const float* col_bias, const float* tscore, uint32_t* bits, int64_t ldbits, float* rs_part,
+                      float* cnt_part, int* nsplit_out, uint16_t* planes, hipStream_t s);
+bool bx6_enabled();      // ARX_GEMM_BX6 set (read once)
+
 // gemm_dma.hip: NN / TN GEMMs with N <= 128 (dU, dI): LDS-DMA streamed operands, dL read once.
 bool gemm_dma_supported(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,
                         int64_t lda, const float* B, int64_t ldb);

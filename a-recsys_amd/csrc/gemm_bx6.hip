@@ -259,9 +259,193 @@ __global__ __launch_bounds__(512) void k_nt_bx6(int64_t M, int64_t N, const floa
 #undef BX6_REP
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same product with the WMRB hinge in the epilogue (gemm_nt.hip's gemm_nt_hinge on the bf16 pipe): no
+// logits leave the chip.  Per row r and 32-column tile: act = (x - t_r + 1 > 0) as one word of `bits`
+// (word-major: bits[tile * ldbits + r]), and the wave's running sums of act * (x - t_r + 1) and of act go
+// to rs_part / cnt_part [2][M] (one split per column phase).  Waves 0..3 compute, waves 4..7 only load
+// the B planes (there is nothing to store but 2 MB of bits).
+// ---------------------------------------------------------------------------------------------
+template <int KD>
+__global__ __launch_bounds__(512) void k_nt_hinge_bx6(int64_t M, int64_t N, const float* __restrict__ A, int64_t lda,
+                                                      const uint16_t* __restrict__ Bp, const float* __restrict__ bias,
+                                                      const float* __restrict__ tscore, uint32_t* __restrict__ bits,
+                                                      int64_t ldbits, float* __restrict__ rs_part,
+                                                      float* __restrict__ cnt_part) {
+  constexpr int NCP = 2;
+  constexpr int NCH = KD / 16;
+  constexpr int LDR = KD + kBxRowPad;
+  constexpr int TILE = 32 * LDR;
+  constexpr int BSLOT = NCP * 3 * TILE;
+  extern __shared__ uint16_t lds[];                // [2][NCP tiles][3 planes][32][LDR] bf16, then bias [N] f32
+  float* sbias = reinterpret_cast<float*>(lds + 2 * BSLOT);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int ntile = (int)(N / 32);
+  const int nstage = ntile / NCP;
+  const int64_t plane = N * (int64_t)KD;
+  const int64_t brow0 = (int64_t)blockIdx.x * 64;
+  const int rot = (int)(blockIdx.x % (unsigned)nstage);
+  for (int i = tid; i < N; i += 512) sbias[i] = bias ? bias[i] : 0.f;
+
+  if (wv < 4) {
+    const int rt = wv & 1, cp = wv >> 1;
+    const int lr = lane & 31, kg = lane >> 5;
+    const int64_t row = brow0 + rt * 32 + lr;
+    const bool ok = row < M;
+    bf16x8 a1[NCH], a2[NCH], a3[NCH];
+    {
+      const float* ap = A + (ok ? row : 0) * lda + 8 * kg;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (ok) {
+          v0 = *reinterpret_cast<const float4*>(ap + 16 * c);
+          v1 = *reinterpret_cast<const float4*>(ap + 16 * c + 4);
+        }
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        uint32_t p1[8], p2[8], p3[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split3(x[e], p1[e], p2[e], p3[e]);
+        uint4 q1 = make_uint4(p1[0] | (p1[1] << 16), p1[2] | (p1[3] << 16), p1[4] | (p1[5] << 16), p1[6] | (p1[7] << 16));
+        uint4 q2 = make_uint4(p2[0] | (p2[1] << 16), p2[2] | (p2[3] << 16), p2[4] | (p2[5] << 16), p2[6] | (p2[7] << 16));
+        uint4 q3 = make_uint4(p3[0] | (p3[1] << 16), p3[2] | (p3[3] << 16), p3[4] | (p3[5] << 16), p3[6] | (p3[7] << 16));
+        a1[c] = __builtin_bit_cast(bf16x8, q1);
+        a2[c] = __builtin_bit_cast(bf16x8, q2);
+        a3[c] = __builtin_bit_cast(bf16x8, q3);
+      }
+    }
+    const float tm1 = (ok ? tscore[row] : 0.f) - 1.f;         // v = x - (t - 1)
+    float rs = 0.f, cnt = 0.f;
+    __syncthreads();                                         // B stage 0 and the bias are in LDS
+    for (int st = 0; st < nstage; ++st) {
+      const int slot = st & 1;
+      const int cur = st + rot < nstage ? st + rot : st + rot - nstage;
+      const uint16_t* tb = lds + slot * BSLOT + (cp * 3) * TILE + lr * LDR + 8 * kg;
+      f32x16 hi = {0}, lo = {0};
+      uint4 f1 = *reinterpret_cast<const uint4*>(tb), f2 = *reinterpret_cast<const uint4*>(tb + TILE),
+            f3 = *reinterpret_cast<const uint4*>(tb + 2 * TILE);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, f1), b2 = __builtin_bit_cast(bf16x8, f2),
+                     b3 = __builtin_bit_cast(bf16x8, f3);
+        if (c + 1 < NCH) {
+          f1 = *reinterpret_cast<const uint4*>(tb + 16 * (c + 1));
+          f2 = *reinterpret_cast<const uint4*>(tb + TILE + 16 * (c + 1));
+          f3 = *reinterpret_cast<const uint4*>(tb + 2 * TILE + 16 * (c + 1));
+        }
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, a1[c], lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a3[c], lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a2[c], lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a1[c], lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a2[c], lo, 0, 0, 0);
+        hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1[c], hi, 0, 0, 0);
+      }
+      // hinge: lane = row lr, columns 8 g + 4 kg + e of the tile
+      const int tile = NCP * cur + cp;
+      const float* bt = sbias + tile * 32 + 4 * kg;
+      uint32_t w = 0u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>(bt + 8 * g);
+        const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = hi[4 * g + e] + lo[4 * g + e] + bvv[e] - tm1;
+          const bool act = v > 0.f;
+          w |= act ? (1u << (8 * g + 4 * kg + e)) : 0u;
+          rs += act ? v : 0.f;
+          cnt += act ? 1.f : 0.f;
+        }
+      }
+      w |= (uint32_t)__shfl_xor((int)w, 32, 64);
+      if (kg == 0 && ok) bits[(int64_t)tile * ldbits + row] = w;
+      __syncthreads();
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    cnt += __shfl_xor(cnt, 32, 64);
+    if (kg == 0 && ok) {
+      rs_part[(int64_t)cp * M + row] = rs;
+      cnt_part[(int64_t)cp * M + row] = cnt;
+    }
+    return;
+  }
+
+  // loaders: the next stage's B planes, global -> registers -> LDS
+  const int mt = tid - 256;
+  constexpr int RPP = 256 / (KD / 8);
+  constexpr int HP = NCP * 32 / RPP;
+  constexpr int PER = 3 * HP;
+  const int k8 = mt % (KD / 8), rl = mt / (KD / 8);
+  const uint16_t* gsrc = Bp + (int64_t)rl * KD + 8 * k8;
+  uint16_t* ldst = lds + ((rl / 32) * 3) * TILE + (rl % 32) * LDR + 8 * k8;
+  uint4 nb[PER];
+#define BX6_LOAD(st_)                                                                                   \
+  _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                                     \
+    const int pl = j / HP, h = j % HP;                                                                   \
+    nb[j] = *reinterpret_cast<const uint4*>(gsrc + pl * plane + ((int64_t)(st_) * NCP * 32 + h * RPP) * KD); \
+  }
+#define BX6_STORE(slot_)                                                                                \
+  _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                                     \
+    const int pl = j / HP, h = j % HP;                                                                   \
+    const int t = (h * RPP) / 32, r = RPP <= 32 ? (h * RPP) % 32 : 0;                                    \
+    *reinterpret_cast<uint4*>(ldst + (slot_) * BSLOT + (t * 3 + pl) * TILE + r * LDR) = nb[j];           \
+  }
+  BX6_LOAD(rot)
+  BX6_STORE(0)
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int cur = st + rot < nstage ? st + rot : st + rot - nstage;
+    const int nxt = cur + 1 < nstage ? cur + 1 : 0;
+    BX6_LOAD(nxt)
+    BX6_STORE((st + 1) & 1)
+    __syncthreads();
+  }
+#undef BX6_LOAD
+#undef BX6_STORE
+}
+
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace
+
+}  // namespace arx
+
+namespace arx {
+
+bool bx6_enabled() {
+  static const bool on = getenv("ARX_GEMM_BX6") != nullptr;
+  return on;
+}
+
+// loss.hip (arx_mw_gemm_fused_fwd with ARX_GEMM_BX6): planes = 3 * N * K bf16 of scratch
+int gemm_nt_hinge_bx6(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                      const float* col_bias, const float* tscore, uint32_t* bits, int64_t ldbits, float* rs_part,
+                      float* cnt_part, int* nsplit_out, uint16_t* planes, hipStream_t s) {
+  if (!(K == 64 || K == 128) || (N % 128) || N > 2048 || (lda % 4) || (ldb % 4)) return ARX_EUNSUPPORTED;
+  {
+    int64_t g = ceil_div(N * (K / 4), 256);
+    k_split3<<<(int)g, 256, 0, s>>>(B, ldb, N, (int)K, planes);
+    ARX_CHECK_LAUNCH();
+  }
+  const int64_t nblk = ceil_div(M, 64);
+  const size_t lds = (size_t)2 * 2 * 3 * 32 * (K + kBxRowPad) * 2 + (size_t)N * 4;
+  static bool raised = false;
+  if (!raised) {
+    const int cap = 160 * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_nt_hinge_bx6<128>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_nt_hinge_bx6<64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    raised = true;
+  }
+  *nsplit_out = 2;
+  if (K == 128)
+    k_nt_hinge_bx6<128><<<(int)nblk, 512, lds, s>>>(M, N, A, lda, planes, col_bias, tscore, bits, ldbits, rs_part, cnt_part);
+  else
+    k_nt_hinge_bx6<64><<<(int)nblk, 512, lds, s>>>(M, N, A, lda, planes, col_bias, tscore, bits, ldbits, rs_part, cnt_part);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
 
 }  // namespace arx
 

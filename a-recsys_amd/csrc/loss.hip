@@ -1031,7 +1031,8 @@ int arx_eval_finish(int mode, const float* acc0, const float* acc1, const float*
 size_t arx_mw_gemm_fused_workspace_bytes(int64_t B, int64_t S) {
   // target scores + (row sums, counts) of up to S / 64 column splits + the positives' hit lists
   const size_t splits = (size_t)((S + 63) / 64);
-  return ((size_t)B * (1 + 2 * splits + kMwHits + 1)) * sizeof(float) + 256;
+  // (+ the bf16 planes of the pool rows for the bf16-pipe hinge GEMM: 3 * S * 128 * 2 bytes)
+  return ((size_t)B * (1 + 2 * splits + kMwHits + 1)) * sizeof(float) + 256 + (size_t)3 * S * 128 * 2 + 256;
 }
 
 int arx_mw_gemm_fused_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp, const float* pbias,
@@ -1075,7 +1076,14 @@ int arx_mw_gemm_fused_fwd(const float* U, int64_t ldu, const float* P, int64_t l
                                    hits, nhit);
   ARX_CHECK_LAUNCH();
   int nsplit = 0;
-  int rc = gemm_nt_hinge(B, S, d, U, ldu, P, ldp, pbias, t, act_bits, ldbits, rs_part, cnt_part, &nsplit, s);
+  int rc;
+  if (bx6_enabled() && (d == 64 || d == 128) && S % 128 == 0) {
+    uint16_t* planes = reinterpret_cast<uint16_t*>(
+        (reinterpret_cast<uintptr_t>(nhit + B) + 255) / 256 * 256);      // behind the hit lists
+    rc = gemm_nt_hinge_bx6(B, S, d, U, ldu, P, ldp, pbias, t, act_bits, ldbits, rs_part, cnt_part, &nsplit, planes, s);
+  } else {
+    rc = gemm_nt_hinge(B, S, d, U, ldu, P, ldp, pbias, t, act_bits, ldbits, rs_part, cnt_part, &nsplit, s);
+  }
   if (rc == ARX_EUNSUPPORTED) set_error("arx_mw_gemm_fused_fwd: scorer shape not supported by the hinge GEMM");
   if (rc) return rc;
   MwRows a{rs_part, cnt_part, nsplit, act_bits, ldbits, t, U, ldu, T, ldt, P, ldp, pbias, d, gscale, row_w,

@@ -1328,17 +1328,18 @@ def test_mw_gemm_fused_fwd(dev, B, S, d):
                           _t(dev, pitems), _t(dev, i2s), out_bl, out_t, bits, out_g, Ug, dts, dU, dT, gscale, ws,
                           row_w=_t(dev, rw))
     torch.cuda.synchronize()
-    np.testing.assert_allclose(out_t.cpu().numpy(), t, rtol=RTOL, atol=ATOL)
-    np.testing.assert_allclose(out_bl.cpu().numpy(), bl, rtol=RTOL, atol=ATOL)
-    np.testing.assert_allclose(out_g.cpu().numpy(), g, rtol=RTOL, atol=1e-10)
-    np.testing.assert_allclose(dts.cpu().numpy(), dt, rtol=RTOL, atol=1e-9)
-    np.testing.assert_allclose(Ug.cpu().numpy(), g[:, None] * U, rtol=RTOL, atol=1e-9)
-    np.testing.assert_allclose(dU.cpu().numpy(), dt[:, None] * T, rtol=RTOL, atol=1e-9)
-    np.testing.assert_allclose(dT.cpu().numpy(), dt[:, None] * U, rtol=RTOL, atol=1e-9)
     act = _unpack_bits(np.ascontiguousarray(bits.cpu().numpy().T).view(np.uint32), S)
     diff = act != cache['act']
     v = logits - t[:, None] + 1
     assert np.all(np.abs(v[diff]) < 1e-5) and diff.sum() <= max(3, B * S // 100000)   # fp32 borderline only
+    same = ~diff.any(axis=1)           # a row with a borderline hinge has another count: dt = -g * cnt moves by g
+    np.testing.assert_allclose(out_t.cpu().numpy(), t, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out_bl.cpu().numpy(), bl, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out_g.cpu().numpy(), g, rtol=RTOL, atol=1e-10)
+    np.testing.assert_allclose(dts.cpu().numpy()[same], dt[same], rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(Ug.cpu().numpy(), g[:, None] * U, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(dU.cpu().numpy()[same], (dt[:, None] * T)[same], rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(dT.cpu().numpy()[same], (dt[:, None] * U)[same], rtol=RTOL, atol=1e-9)
     assert not np.any(act & ~mask)                                  # masked positives carry no bit
     if B % 32 or d <= 32:   # the bit-operand products need B % 32 == 0 and d > 32 (the plan falls back otherwise)
         return
