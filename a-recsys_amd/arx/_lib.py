@@ -58,6 +58,7 @@ PROTOTYPES = {
     "arx_dot_score_bwd": (cint, [f32p, i64, f32p, i64, f32p, i64, cint, f32p, i64, cint, f32p, i64, vp]),
     "arx_gemm_f32_workspace_bytes": (sz, [i64, i64, i64]),
     "arx_gemm_nt_bx6_workspace_bytes": (sz, [i64, i64]),
+    "arx_gemm_bits_workspace_bytes": (sz, [cint, i64, i64, i64]),
     "arx_gemm_nt_bx6": (cint, [i64, i64, i64, f32p, i64, f32p, i64, f32p, f32p, i64, vp, sz, vp]),
     "arx_gemm_f32": (cint, [cint, cint, i64, i64, i64, f32, f32p, i64, f32p, i64, f32, f32p, i64,
                             f32p, vp, sz, vp]),
@@ -212,7 +213,7 @@ _NO_CHECK = ("arx_last_error", "arx_version", "arx_csr_expand_workspace_bytes",
              "arx_col_sum_workspace_bytes",
              "arx_gemm_f32_workspace_bytes", "arx_sparse_adagrad_workspace_bytes",
              "arx_sample_wor_workspace_bytes", "arx_sample_wor_keys_workspace_bytes",
-             "arx_gemm_nt_bx6_workspace_bytes")
+             "arx_gemm_nt_bx6_workspace_bytes", "arx_gemm_bits_workspace_bytes")
 
 
 def call(name, *args):

@@ -420,7 +420,7 @@ def gemm_bits(bits, B, C, ws, transA=False, beta=0.0, row_scale=None, gvec=None,
     else:
         M, K = int(bits.shape[1]), int(B.shape[0])
     N = int(C.shape[1])
-    wsp, wsn = ws.get(_lib.lib.arx_gemm_f32_workspace_bytes(M, N, K))
+    wsp, wsn = ws.get(_lib.lib.arx_gemm_bits_workspace_bytes(int(bool(transA)), M, N, K))
     call("arx_gemm_bits_f32", int(bool(transA)), M, N, K, _p(bits), int(bits.stride(0)), _p(B), _ld(B),
          float(beta), _p(C), _ld(C), _p(row_scale), _p(gvec), _p(a_rowsum), wsp, wsn, _stream())
 

@@ -135,6 +135,13 @@ int gemm_nt_hinge_bx6(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
                       const float* col_bias, const float* tscore, uint32_t* bits, int64_t ldbits, float* rs_part,
                       float* cnt_part, int* nsplit_out, uint16_t* planes, hipStream_t s);
 bool bx6_enabled();      // ARX_GEMM_BX6 set (read once)
+// ... and the two bit-operand products of its backward (three MFMAs per term: the 0/1 operand is exact in bf16)
+size_t gemm_bits_bx3_planes_bytes(int64_t N, int64_t rowsB);
+bool gemm_bits_bx3_supported(int transA, int64_t M, int64_t N, int64_t K, int64_t ldb);
+int gemm_bits_bx3_slices(int64_t M, int64_t K);
+int gemm_bits_bx3_launch(int transA, int64_t M, int64_t N, int64_t K, const uint32_t* bits, int64_t ldw,
+                         const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* row_scale,
+                         const float* gvec, float* part, float* rsp, int nsl, uint16_t* planes, hipStream_t s);
 
 // gemm_dma.hip: NN / TN GEMMs with N <= 128 (dU, dI): LDS-DMA streamed operands, dL read once.
 bool gemm_dma_supported(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,

@@ -525,6 +525,13 @@ int arx_gemm_f32_steps_tn(int64_t steps, int64_t M, int64_t N, int64_t Kb, const
   return ARX_OK;
 }
 
+size_t arx_gemm_bits_workspace_bytes(int transA, int64_t M, int64_t N, int64_t K) {
+  size_t need = arx_gemm_f32_workspace_bytes(M, N, K);
+  const size_t bx = gemm_bits_bx3_planes_bytes(N, K) +
+                    (transA ? (size_t)gemm_bits_bx3_slices(M, K) * ((size_t)M * N + M) * sizeof(float) : 0) + 256;
+  return need > bx ? need : bx;
+}
+
 int arx_gemm_bits_f32(int transA, int64_t M, int64_t N, int64_t K, const uint32_t* bits, int64_t ldw,
                       const float* B, int64_t ldb, float beta, float* C, int64_t ldc,
                       const float* row_scale, const float* gvec, float* a_rowsum, void* workspace,
@@ -543,6 +550,28 @@ int arx_gemm_bits_f32(int transA, int64_t M, int64_t N, int64_t K, const uint32_
     return ARX_EUNSUPPORTED;
   }
   hipStream_t s = as_stream(stream);
+  if (bx6_enabled() && gemm_bits_bx3_supported(transA, M, N, K, ldb) && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+      ldc % 4 == 0) {
+    // EXPERIMENT (ARX_GEMM_BX6): the same products on the bf16 pipe -- workspace: planes | partials | row sums
+    const int nsl = transA ? gemm_bits_bx3_slices(M, K) : 1;
+    const size_t pb = gemm_bits_bx3_planes_bytes(N, K);
+    const size_t need = pb + (transA ? (size_t)nsl * ((size_t)M * N + M) * sizeof(float) : 0);
+    if (!workspace || workspace_bytes < need) {
+      set_error("arx_gemm_bits_f32: workspace too small (%zu < %zu)", workspace_bytes, need);
+      return ARX_EWORKSPACE;
+    }
+    uint16_t* planes = reinterpret_cast<uint16_t*>(workspace);
+    float* part = transA ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pb) : nullptr;
+    float* rsp = (transA && a_rowsum) ? part + (size_t)nsl * M * N : nullptr;
+    int rc = gemm_bits_bx3_launch(transA, M, N, K, bits, ldw, B, ldb, beta, C, ldc, row_scale, gvec, part, rsp, nsl,
+                                  planes, s);
+    if (rc) return rc;
+    if (transA) {
+      launch_splitk_reduce(part, nsl, M, N, 1.f, beta, C, ldc, nullptr, rsp, a_rowsum, s);
+      ARX_CHECK_LAUNCH();
+    }
+    return ARX_OK;
+  }
   int bm, sp;
   int64_t kc;
   gemm_dma_plan(M, N, K, &bm, &sp, &kc);

@@ -406,6 +406,233 @@ __global__ __launch_bounds__(512) void k_nt_hinge_bx6(int64_t M, int64_t N, cons
 #undef BX6_STORE
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward products of the fused 'mw' scorer on the bf16 pipe: the A operand is the 0/1 activity matrix
+// (act bits of k_nt_hinge_bx6 -- EXACT in one bf16 piece), the B operand an f32 matrix in three bf16
+// pieces: three MFMAs per term.
+//   NN (TN = false):  C[m, :] = beta C[m, :] + g[m] * sum_k act[m][k] P[k, :]        dU += g (act . P)
+//   TN (TN = true):   part[slice][m, :] = sum_{k in slice} act[k][m] Ug[k, :],       dI = act^T . (g U)
+//                     rsp[slice][m] = sum_{k in slice} act[k][m] g[k]                (bias gradient)
+// act[r][c] = bit (c & 31) of bits[(c >> 5) * ldw + r].  The f32 operand arrives as TRANSPOSED planes
+// XT[3][N][R] (k_split3_t), so that a lane's 8 k values are 16 contiguous bytes.  MFMA: first operand = XT rows
+// (D row = output column n), second operand = act (D column = output row m): a lane's registers 4 g .. 4 g + 3
+// are four consecutive output columns of one row -- 16-byte traffic on C.
+// 512 threads: waves 0..3 compute (wave = (m-tile of 32, half of the N columns)), waves 4..7 stream the
+// XT planes through LDS in stages of 64 k.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bf16_pair01(uint32_t b0, uint32_t b1) {      // two bits -> two bf16 (0.0 / 1.0)
+  return b0 * 0x3F80u + b1 * 0x3F800000u;
+}
+
+template <int N, bool TN>
+__global__ __launch_bounds__(512) void k_bits_bx3(int64_t M, int64_t K, int64_t kc, const uint32_t* __restrict__ bits,
+                                                  int64_t ldw, const uint16_t* __restrict__ XT, int64_t xt_rows,
+                                                  float beta, float* __restrict__ C, int64_t ldc,
+                                                  const float* __restrict__ gvec, float* __restrict__ rsp) {
+  constexpr int NTW = N / 64;                      // n-tiles per compute wave
+  constexpr int LDR = 64 + 8;                      // LDS row: 64 k + pad (bf16)
+  constexpr int SLOT = 3 * N * LDR;                // bf16 per stage
+  extern __shared__ uint16_t lds[];                // [2][3 planes][N][LDR]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int64_t mblocks = (M + 63) / 64;
+  const int64_t mb = TN ? (int64_t)blockIdx.x % mblocks : (int64_t)blockIdx.x;
+  const int64_t slice = TN ? (int64_t)blockIdx.x / mblocks : 0;
+  const int64_t k0 = slice * kc;
+  const int64_t kend = (k0 + kc < K) ? k0 + kc : K;
+  const int nstage = (int)((kend - k0) / 64);
+  const int64_t plane = (int64_t)N * xt_rows;
+
+  if (wv < 4) {
+    const int mt = wv & 1, nh = wv >> 1;
+    const int lr = lane & 31, kg = lane >> 5;
+    const int64_t m = mb * 64 + mt * 32 + lr;
+    const bool ok = m < M;
+    const int64_t mtile = mb * 2 + mt;               // TN: the word row of this wave's 32 pool columns
+    f32x16 hi[NTW], lo[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      hi[t] = f32x16{0};
+      lo[t] = f32x16{0};
+    }
+    float rs = 0.f;
+    __syncthreads();                                         // stage 0 is in LDS
+    for (int st = 0; st < nstage; ++st) {
+      const int slot = st & 1;
+      const int64_t kb = k0 + 64 * (int64_t)st;
+      // this stage's activity bits
+      uint32_t w_lo = 0u, w_hi = 0u;
+      uint4 bw[8];
+      float4 gw[8];
+      if (!TN) {
+        if (ok) {
+          w_lo = bits[(kb >> 5) * ldw + m];
+          w_hi = bits[((kb >> 5) + 1) * ldw + m];
+        }
+      } else {
+        const bool tok = mtile * 32 < M;
+        const uint32_t* bp = bits + mtile * ldw + kb + 8 * kg;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          bw[2 * c] = tok ? *reinterpret_cast<const uint4*>(bp + 16 * c) : make_uint4(0, 0, 0, 0);
+          bw[2 * c + 1] = tok ? *reinterpret_cast<const uint4*>(bp + 16 * c + 4) : make_uint4(0, 0, 0, 0);
+        }
+        if (nh == 0 && rsp) {
+          const float* gp = gvec + kb + 8 * kg;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            gw[2 * c] = *reinterpret_cast<const float4*>(gp + 16 * c);
+            gw[2 * c + 1] = *reinterpret_cast<const float4*>(gp + 16 * c + 4);
+          }
+        }
+      }
+      const uint16_t* tb = lds + slot * SLOT + ((nh * NTW) * 32 + lr) * LDR + 8 * kg;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint4 aq;
+        if (!TN) {
+          const uint32_t b = ((c < 2 ? w_lo : w_hi) >> ((16 * c + 8 * kg) & 31)) & 0xFFu;
+          aq = make_uint4(bf16_pair01(b & 1u, (b >> 1) & 1u), bf16_pair01((b >> 2) & 1u, (b >> 3) & 1u),
+                          bf16_pair01((b >> 4) & 1u, (b >> 5) & 1u), bf16_pair01((b >> 6) & 1u, (b >> 7) & 1u));
+        } else {
+          const uint4 x = bw[2 * c], y = bw[2 * c + 1];
+          const uint32_t e0 = (x.x >> lr) & 1u, e1 = (x.y >> lr) & 1u, e2 = (x.z >> lr) & 1u, e3 = (x.w >> lr) & 1u;
+          const uint32_t e4 = (y.x >> lr) & 1u, e5 = (y.y >> lr) & 1u, e6 = (y.z >> lr) & 1u, e7 = (y.w >> lr) & 1u;
+          aq = make_uint4(bf16_pair01(e0, e1), bf16_pair01(e2, e3), bf16_pair01(e4, e5), bf16_pair01(e6, e7));
+          if (nh == 0 && rsp) {
+            const float4 ga = gw[2 * c], gb = gw[2 * c + 1];
+            rs += (e0 ? ga.x : 0.f) + (e1 ? ga.y : 0.f) + (e2 ? ga.z : 0.f) + (e3 ? ga.w : 0.f) +
+                  (e4 ? gb.x : 0.f) + (e5 ? gb.y : 0.f) + (e6 ? gb.z : 0.f) + (e7 ? gb.w : 0.f);
+          }
+        }
+        const bf16x8 af = __builtin_bit_cast(bf16x8, aq);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          const uint16_t* tp = tb + t * 32 * LDR + 16 * c;
+          const bf16x8 p1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tp));
+          const bf16x8 p2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tp + N * LDR));
+          const bf16x8 p3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tp + 2 * N * LDR));
+          lo[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, af, lo[t], 0, 0, 0);
+          lo[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, af, lo[t], 0, 0, 0);
+          hi[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, af, hi[t], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+    // epilogue: lane = output row m, columns (nh NTW + t) 32 + 8 g + 4 kg + 0..3
+    if (!TN) {
+      if (ok) {
+        const float gm = gvec ? gvec[m] : 1.f;
+        float* crow = C + m * ldc + (nh * NTW) * 32 + 4 * kg;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float4* cp4 = reinterpret_cast<float4*>(crow + t * 32 + 8 * g);
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (beta != 0.f) {
+              o = *cp4;
+              o.x *= beta; o.y *= beta; o.z *= beta; o.w *= beta;
+            }
+            o.x += gm * (hi[t][4 * g] + lo[t][4 * g]);
+            o.y += gm * (hi[t][4 * g + 1] + lo[t][4 * g + 1]);
+            o.z += gm * (hi[t][4 * g + 2] + lo[t][4 * g + 2]);
+            o.w += gm * (hi[t][4 * g + 3] + lo[t][4 * g + 3]);
+            *cp4 = o;
+          }
+      }
+    } else {
+      if (ok) {
+        float* prow = C + (slice * M + m) * (int64_t)N + (nh * NTW) * 32 + 4 * kg;      // C = partials [slices][M][N]
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(prow + t * 32 + 8 * g) =
+                make_float4(hi[t][4 * g] + lo[t][4 * g], hi[t][4 * g + 1] + lo[t][4 * g + 1],
+                            hi[t][4 * g + 2] + lo[t][4 * g + 2], hi[t][4 * g + 3] + lo[t][4 * g + 3]);
+      }
+      if (nh == 0 && rsp) {
+        rs += __shfl_xor(rs, 32, 64);
+        if (kg == 0 && ok) rsp[slice * M + m] = rs;
+      }
+    }
+    return;
+  }
+
+  // loaders: thread -> (row n = q / 8 of a pass of 32 rows, 16-byte piece q % 8); N / 32 passes per plane
+  const int lt = tid - 256;
+  constexpr int HP = N / 32;
+  constexpr int PER = 3 * HP;
+  const int k8 = lt & 7, nl = lt >> 3;
+  const uint16_t* gsrc = XT + (int64_t)nl * xt_rows + k0 + 8 * k8;
+  uint16_t* ldst = lds + nl * LDR + 8 * k8;
+  uint4 nb[PER];
+#define BX3_LOAD(st_)                                                                                   \
+  _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                                     \
+    const int pl = j / HP, h = j % HP;                                                                   \
+    nb[j] = *reinterpret_cast<const uint4*>(gsrc + pl * plane + (int64_t)(h * 32) * xt_rows + 64 * (int64_t)(st_)); \
+  }
+#define BX3_STORE(slot_)                                                                                \
+  _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                                     \
+    const int pl = j / HP, h = j % HP;                                                                   \
+    *reinterpret_cast<uint4*>(ldst + (slot_) * SLOT + (pl * N + h * 32) * LDR) = nb[j];                  \
+  }
+  if (nstage > 0) {
+    BX3_LOAD(0)
+    BX3_STORE(0)
+  }
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int nxt = st + 1 < nstage ? st + 1 : st;
+    BX3_LOAD(nxt)
+    BX3_STORE((st + 1) & 1)
+    __syncthreads();
+  }
+#undef BX3_LOAD
+#undef BX3_STORE
+}
+
+// f32 [R, N] (ld) -> TRANSPOSED bf16 planes [3][N][R]: the backward products' f32 operand (pool rows, g U)
+__global__ __launch_bounds__(256) void k_split3_t(const float* __restrict__ X, int64_t ldx, int64_t R, int N,
+                                                  uint16_t* __restrict__ planes) {
+  __shared__ float tile[64][65];
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int n0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 64 * 16; i += 256) {          // 64 rows x 16 float4
+    const int r = i >> 4, c4 = (i & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < R && n0 + c4 < N) v = *reinterpret_cast<const float4*>(X + (r0 + r) * ldx + n0 + c4);
+    tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+  }
+  __syncthreads();
+  const int n = tid >> 2, q = tid & 3;                // column n, rows 16 q .. 16 q + 15
+  if (n0 + n >= N) return;
+  uint32_t w[3][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    uint32_t a[3], b[3];
+    split3(tile[16 * q + 2 * e][n], a[0], a[1], a[2]);
+    split3(tile[16 * q + 2 * e + 1][n], b[0], b[1], b[2]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) w[p][e] = a[p] | (b[p] << 16);
+  }
+  const int64_t plane = (int64_t)N * R;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    uint16_t* dst = planes + p * plane + (int64_t)(n0 + n) * R + r0 + 16 * q;
+    if (r0 + 16 * q + 16 <= R) {
+      *reinterpret_cast<uint4*>(dst) = make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]);
+      *reinterpret_cast<uint4*>(dst + 8) = make_uint4(w[p][4], w[p][5], w[p][6], w[p][7]);
+    } else {
+      for (int e = 0; e < 16; ++e)
+        if (r0 + 16 * q + e < R) dst[e] = (uint16_t)(w[p][e >> 1] >> (16 * (e & 1)));
+    }
+  }
+}
+
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace
@@ -443,6 +670,60 @@ int gemm_nt_hinge_bx6(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
     k_nt_hinge_bx6<128><<<(int)nblk, 512, lds, s>>>(M, N, A, lda, planes, col_bias, tscore, bits, ldbits, rs_part, cnt_part);
   else
     k_nt_hinge_bx6<64><<<(int)nblk, 512, lds, s>>>(M, N, A, lda, planes, col_bias, tscore, bits, ldbits, rs_part, cnt_part);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+// gemm.hip (arx_gemm_bits_f32 with ARX_GEMM_BX6): both bit-operand products on the bf16 pipe.  planes: 3 * N *
+// (transA ? K : K) ... = 3 * N * rows(B) bf16; part: [*nsl][M][N] (+ rsp [*nsl][M]) for the transposed form.
+size_t gemm_bits_bx3_planes_bytes(int64_t N, int64_t rowsB) { return align256((size_t)3 * N * rowsB * 2); }
+
+bool gemm_bits_bx3_supported(int transA, int64_t M, int64_t N, int64_t K, int64_t ldb) {
+  if (!(N == 64 || N == 128) || ldb % 4) return false;
+  if (!transA) return K % 64 == 0 && K >= 64;
+  return M % 32 == 0 && K % 64 == 0 && K >= 64;
+}
+
+int gemm_bits_bx3_slices(int64_t M, int64_t K) {       // K slices of the transposed form (multiples of 64)
+  const int64_t mblocks = (M + 63) / 64;
+  int64_t nsl = ((int64_t)cu_count() + mblocks - 1) / mblocks;
+  if (nsl < 1) nsl = 1;
+  int64_t kc = ((K + nsl - 1) / nsl + 63) / 64 * 64;
+  return (int)((K + kc - 1) / kc);
+}
+
+int gemm_bits_bx3_launch(int transA, int64_t M, int64_t N, int64_t K, const uint32_t* bits, int64_t ldw,
+                         const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* row_scale,
+                         const float* gvec, float* part, float* rsp, int nsl, uint16_t* planes, hipStream_t s) {
+  {
+    dim3 g((unsigned)ceil_div(K, 64), (unsigned)ceil_div(N, 64));
+    k_split3_t<<<g, 256, 0, s>>>(B, ldb, K, (int)N, planes);          // B [K, N] -> planes [3][N][K]
+    ARX_CHECK_LAUNCH();
+  }
+  static bool raised = false;
+  if (!raised) {
+    const int cap = 160 * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bits_bx3<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bits_bx3<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bits_bx3<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bits_bx3<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    raised = true;
+  }
+  const size_t lds = (size_t)2 * 3 * N * (64 + 8) * 2;
+  const int64_t mblocks = ceil_div(M, 64);
+  if (!transA) {
+    if (N == 128)
+      k_bits_bx3<128, false><<<(int)mblocks, 512, lds, s>>>(M, K, K, bits, ldw, planes, K, beta, C, ldc, row_scale, nullptr);
+    else
+      k_bits_bx3<64, false><<<(int)mblocks, 512, lds, s>>>(M, K, K, bits, ldw, planes, K, beta, C, ldc, row_scale, nullptr);
+  } else {
+    const int64_t kc = ((K + nsl - 1) / nsl + 63) / 64 * 64;
+    const int64_t grid = mblocks * nsl;
+    if (N == 128)
+      k_bits_bx3<128, true><<<(int)grid, 512, lds, s>>>(M, K, kc, bits, ldw, planes, K, 0.f, part, N, gvec, rsp);
+    else
+      k_bits_bx3<64, true><<<(int)grid, 512, lds, s>>>(M, K, kc, bits, ldw, planes, K, 0.f, part, N, gvec, rsp);
+  }
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

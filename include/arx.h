@@ -377,7 +377,8 @@ int arx_mw_gemm_fused_fwd(const float* U, int64_t ldu, const float* P, int64_t l
  *                                                                          (dI = act^T . (g * U), dbias)
  * row_scale nullable (1); gvec required for transA = 1, a_rowsum nullable.  32 < N <= 128, N % 4 == 0,
  * M >= 64, M % 4 == 0 (M % 32 == 0 for transA = 1), K % 32 == 0, 16-byte aligned B rows.
- * workspace >= arx_gemm_f32_workspace_bytes(M, N, K). */
+ * workspace >= arx_gemm_bits_workspace_bytes(transA, M, N, K). */
+size_t arx_gemm_bits_workspace_bytes(int transA, int64_t M, int64_t N, int64_t K);
 int arx_gemm_bits_f32(int transA, int64_t M, int64_t N, int64_t K, const uint32_t* bits, int64_t ldw,
                       const float* B, int64_t ldb, float beta, float* C, int64_t ldc,
                       const float* row_scale, const float* gvec, float* a_rowsum, void* workspace,
