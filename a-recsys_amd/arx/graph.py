@@ -291,7 +291,10 @@ class Prediction(Node):
             gp = pool.alloc_grad()
             beta = pool.grad_beta()
             tok = self.rt.fork(0)
-            ops.gemm_bits(self.act_bits, self.Ug, gp, self.rt.ws, transA=True, beta=beta, gvec=self.gvec,
+            # (its own workspace: this product runs on a forked stream next to the dU product, and on the bf16
+            # pipe BOTH keep operand planes in their workspace)
+            ws2 = self.rt.__dict__.setdefault('_ws_bits_tn', ops.Workspace(self.rt.device))
+            ops.gemm_bits(self.act_bits, self.Ug, gp, ws2, transA=True, beta=beta, gvec=self.gvec,
                           a_rowsum=pool.bias_grad)
             self.rt._pending.append(self.rt.end_fork(tok))
             pool.bias_grad_used = True

@@ -642,7 +642,7 @@ size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 namespace arx {
 
 bool bx6_enabled() {
-  static const bool on = getenv("ARX_GEMM_BX6") != nullptr;
+  static const bool on = getenv("ARX_GEMM_BX6") != nullptr && getenv("ARX_GEMM_BX6")[0] != '\0';
   return on;
 }
 
