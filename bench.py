@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3mix"],
                     help="headline workload (default c3 = BASELINE configs[2], HET layout)")
     ap.add_argument("--mulhot", action="store_true", help="(compat) same as --workload c3")
-    ap.add_argument("--subs", default="c2,c3mix,c4,c4mce,k1,c5w1",
+    ap.add_argument("--subs", default="c2,c3mix,c4,c4mce,k1,c5w1,c3_bf16pipe,c2_bf16pipe",
                     help="comma list of sub-results besides the headline ('' = none)")
     ap.add_argument("--sub-steps", type=int, default=50)
     ap.add_argument("--repeats", type=int, default=5,
@@ -591,6 +591,30 @@ def run_sharded_world1(args):
     return {k: out[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "n_gpus", "config", "roofline")}
 
 
+def run_bf16pipe(args, workload):
+    """EXPERIMENT, reported beside the headline, never as it: the same workload with the scorer
+    on the bf16 matrix pipe -- f32 operands split exactly into three bf16 pieces, six (forward) / three (backward,
+    0/1 operand) MFMAs per product term, f32 accumulation; 'mw' forward fused (act bits instead of logits /
+    dlogits).  The switches are read once per process: a child process runs the workload."""
+    import subprocess
+    env = dict(os.environ, ARX_GEMM_BX6="1", ARX_MW_GEMM_FUSE="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--subs", "", "--no-rooflines",
+           "--no-cpu-baseline", "--steps", str(args.sub_steps), "--warmup", str(min(args.warmup, 10)),
+           "--batch", str(args.batch), "--n-sampled", str(args.n_sampled), "--dim", str(args.dim)]
+    if args.n_items:
+        cmd += ["--n-items", str(args.n_items)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+    line = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+            "dtype": "f32 in / f32 accumulate; products as 6 (3 with the 0/1 operand) exact bf16 x bf16 MFMA terms",
+            "switches": "ARX_GEMM_BX6=1 ARX_MW_GEMM_FUSE=1 (off by default)",
+            "parity": "tests/test_bf16pipe_gpu.py: the kernel, whole-step and BASELINE-sized oracle tests at the same 1e-4; "
+                      "error of the split product against f64 measured a third of the f32-MFMA kernel's",
+            "config": {k: j["config"][k] for k in ("workload", "final_loss", "ms_per_step_min", "ms_per_step_max")
+                       if k in j["config"]}}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -633,6 +657,8 @@ def main():
                     out["roofline_gather"]["past_llc"] = r
             elif s == "c5w1":
                 r = run_sharded_world1(args)
+            elif s.endswith("_bf16pipe") and s[:-9] in WORKLOADS:
+                r = run_bf16pipe(args, s[:-9])
             else:
                 continue
             sub[s] = r
