@@ -420,19 +420,25 @@ __global__ __launch_bounds__(512) void k_nt_hinge_bx6(int64_t M, int64_t N, cons
 // 512 threads: waves 0..3 compute (wave = (m-tile of 32, half of the N columns)), waves 4..7 stream the
 // XT planes through LDS in stages of 64 k.
 // ---------------------------------------------------------------------------------------------
+// Workgroup barrier for the loader waves: LDS writes done, then s_barrier.  (__syncthreads() carries IR fences,
+// and a register array that lives ACROSS a fence is left in scratch by the compiler -- measured: 400 bytes of
+// private segment and a 3x slower kernel; with this form the staging registers stay registers.)
+__device__ __forceinline__ void bx_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ uint32_t bf16_pair01(uint32_t b0, uint32_t b1) {      // two bits -> two bf16 (0.0 / 1.0)
   return b0 * 0x3F80u + b1 * 0x3F800000u;
 }
 
 template <int N, bool TN>
-__global__ __launch_bounds__(512) void k_bits_bx3(int64_t M, int64_t K, int64_t kc, const uint32_t* __restrict__ bits,
+__global__ __launch_bounds__(768) void k_bits_bx3(int64_t M, int64_t K, int64_t kc, const uint32_t* __restrict__ bits,
                                                   int64_t ldw, const uint16_t* __restrict__ XT, int64_t xt_rows,
                                                   float beta, float* __restrict__ C, int64_t ldc,
                                                   const float* __restrict__ gvec, float* __restrict__ rsp) {
   constexpr int NTW = N / 64;                      // n-tiles per compute wave
   constexpr int LDR = 64 + 8;                      // LDS row: 64 k + pad (bf16)
   constexpr int SLOT = 3 * N * LDR;                // bf16 per stage
-  extern __shared__ uint16_t lds[];                // [2][3 planes][N][LDR]
+  extern __shared__ uint16_t lds[];                // [2][3 planes][N][LDR], then [2][192] words: the stage's act bits (+ g)
+  uint32_t* xw = reinterpret_cast<uint32_t*>(lds + 2 * SLOT);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = tid >> 6;
@@ -461,25 +467,25 @@ __global__ __launch_bounds__(512) void k_bits_bx3(int64_t M, int64_t K, int64_t 
     for (int st = 0; st < nstage; ++st) {
       const int slot = st & 1;
       const int64_t kb = k0 + 64 * (int64_t)st;
-      // this stage's activity bits
+      // this stage's activity bits (and row factors), staged in LDS by the loaders with the planes:
+      //   NN: xs[h * 64 + r] = word (kb / 32 + h) of row mb * 64 + r;  TN: xs[t * 64 + k] = word of m-tile t, row kb + k;
+      //   xs[128 + k] = g[kb + k]
+      const uint32_t* xs = xw + slot * 192;
       uint32_t w_lo = 0u, w_hi = 0u;
       uint4 bw[8];
       float4 gw[8];
       if (!TN) {
-        if (ok) {
-          w_lo = bits[(kb >> 5) * ldw + m];
-          w_hi = bits[((kb >> 5) + 1) * ldw + m];
-        }
+        w_lo = xs[mt * 32 + lr];
+        w_hi = xs[64 + mt * 32 + lr];
       } else {
-        const bool tok = mtile * 32 < M;
-        const uint32_t* bp = bits + mtile * ldw + kb + 8 * kg;
+        const uint32_t* bp = xs + mt * 64 + 8 * kg;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          bw[2 * c] = tok ? *reinterpret_cast<const uint4*>(bp + 16 * c) : make_uint4(0, 0, 0, 0);
-          bw[2 * c + 1] = tok ? *reinterpret_cast<const uint4*>(bp + 16 * c + 4) : make_uint4(0, 0, 0, 0);
+          bw[2 * c] = *reinterpret_cast<const uint4*>(bp + 16 * c);
+          bw[2 * c + 1] = *reinterpret_cast<const uint4*>(bp + 16 * c + 4);
         }
         if (nh == 0 && rsp) {
-          const float* gp = gvec + kb + 8 * kg;
+          const float* gp = reinterpret_cast<const float*>(xs + 128) + 8 * kg;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             gw[2 * c] = *reinterpret_cast<const float4*>(gp + 16 * c);
@@ -561,35 +567,65 @@ __global__ __launch_bounds__(512) void k_bits_bx3(int64_t M, int64_t K, int64_t 
     return;
   }
 
-  // loaders: thread -> (row n = q / 8 of a pass of 32 rows, 16-byte piece q % 8); N / 32 passes per plane
-  const int lt = tid - 256;
+  // loaders: TWO groups of four waves (768 threads per workgroup), group p streams the stages of parity p -- each stage's loads are issued two
+  // stages before its data is read (one stage in flight in registers, stored to the slot the compute waves
+  // have just left, while the other pair's stage is being read): the ~2 600-cycle trip to L2 is covered by
+  // two stage periods instead of one.  Thread -> (row nl = q / 8 of a pass of 32 rows, 16-byte piece q % 8);
+  // N / 32 passes per plane.  A register set is loaded and stored within ONE loop body (never carried over
+  // the back edge: such arrays stay in scratch).
+  const int pr = (wv - 4) >> 2;                      // group of four loader waves
+  const int lt = tid - 256 - 256 * pr;               // 0..255
   constexpr int HP = N / 32;
   constexpr int PER = 3 * HP;
   const int k8 = lt & 7, nl = lt >> 3;
   const uint16_t* gsrc = XT + (int64_t)nl * xt_rows + k0 + 8 * k8;
   uint16_t* ldst = lds + nl * LDR + 8 * k8;
-  uint4 nb[PER];
+  // ... and one word of the stage's act bits (threads < 128) or row factors (TN: threads 128..191) each
+  const uint32_t* xsrc = nullptr;                    // advances by xstep per stage
+  int64_t xstep = 0;
+  if (!TN) {
+    if (lt < 128 && mb * 64 + (lt & 63) < M) {
+      xsrc = bits + ((k0 >> 5) + (lt >> 6)) * ldw + mb * 64 + (lt & 63);
+      xstep = 2 * ldw;
+    }
+  } else {
+    if (lt < 128 && (mb * 2 + (lt >> 6)) * 32 < M) xsrc = bits + (mb * 2 + (lt >> 6)) * ldw + k0 + (lt & 63);
+    else if (lt >= 128 && lt < 192 && gvec) xsrc = reinterpret_cast<const uint32_t*>(gvec) + k0 + (lt - 128);
+    xstep = 64;
+  }
+  uint32_t xv = 0u;
 #define BX3_LOAD(st_)                                                                                   \
   _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                                     \
     const int pl = j / HP, h = j % HP;                                                                   \
     nb[j] = *reinterpret_cast<const uint4*>(gsrc + pl * plane + (int64_t)(h * 32) * xt_rows + 64 * (int64_t)(st_)); \
-  }
+  }                                                                                                     \
+  xv = xsrc ? xsrc[(int64_t)(st_) * xstep] : 0u;
 #define BX3_STORE(slot_)                                                                                \
   _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                                     \
     const int pl = j / HP, h = j % HP;                                                                   \
     *reinterpret_cast<uint4*>(ldst + (slot_) * SLOT + (pl * N + h * 32) * LDR) = nb[j];                  \
+  }                                                                                                     \
+  if (lt < 192) xw[(slot_) * 192 + lt] = xv;
+  // ONE code path for both pairs (two branches with an array each are merged by the compiler and the array
+  // lands in scratch): pair 1 runs one barrier phase behind pair 0.
+  //   pair 0: load 0, store -> B0 | load 2 .. E(0) store E(1) | load 4 .. E(2) store E(3) | ...
+  //   pair 1: load 1 -> B0, store, E(0)    | load 3 .. E(1) store E(2) | ...               | E(last)
+  const int last = nstage - 1;                       // (nstage is even and >= 2: K slices are multiples of 128)
+  uint4 nb[PER];                                     // (<= 12: a set of 24 stays in scratch)
+  BX3_LOAD((pr <= last ? pr : last))
+  if (pr == 1) bx_barrier();                                 // B0
+  BX3_STORE(pr)
+  if (pr == 0) bx_barrier();                                 // B0: stage 0 is in LDS
+  if (pr == 1) bx_barrier();                                 // E(0)
+  const int iters = nstage / 2 - pr;
+  for (int it = 0; it < iters; ++it) {
+    const int sn = 2 * it + pr + 2;                          // the pair's next stage
+    BX3_LOAD((sn <= last ? sn : last))
+    bx_barrier();                                            // end of stage sn - 2: slot pr is free
+    BX3_STORE(pr)
+    bx_barrier();                                            // end of stage sn - 1
   }
-  if (nstage > 0) {
-    BX3_LOAD(0)
-    BX3_STORE(0)
-  }
-  __syncthreads();
-  for (int st = 0; st < nstage; ++st) {
-    const int nxt = st + 1 < nstage ? st + 1 : st;
-    BX3_LOAD(nxt)
-    BX3_STORE((st + 1) & 1)
-    __syncthreads();
-  }
+  if (pr == 1) bx_barrier();                                 // E(last)
 #undef BX3_LOAD
 #undef BX3_STORE
 }
@@ -680,15 +716,15 @@ size_t gemm_bits_bx3_planes_bytes(int64_t N, int64_t rowsB) { return align256((s
 
 bool gemm_bits_bx3_supported(int transA, int64_t M, int64_t N, int64_t K, int64_t ldb) {
   if (!(N == 64 || N == 128) || ldb % 4) return false;
-  if (!transA) return K % 64 == 0 && K >= 64;
-  return M % 32 == 0 && K % 64 == 0 && K >= 64;
+  if (!transA) return K % 128 == 0;                  // (an even number of 64-wide stages)
+  return M % 32 == 0 && K % 128 == 0;
 }
 
 int gemm_bits_bx3_slices(int64_t M, int64_t K) {       // K slices of the transposed form (multiples of 64)
   const int64_t mblocks = (M + 63) / 64;
   int64_t nsl = ((int64_t)cu_count() + mblocks - 1) / mblocks;
   if (nsl < 1) nsl = 1;
-  int64_t kc = ((K + nsl - 1) / nsl + 63) / 64 * 64;
+  int64_t kc = ((K + nsl - 1) / nsl + 127) / 128 * 128;
   return (int)((K + kc - 1) / kc);
 }
 
@@ -709,20 +745,20 @@ int gemm_bits_bx3_launch(int transA, int64_t M, int64_t N, int64_t K, const uint
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bits_bx3<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     raised = true;
   }
-  const size_t lds = (size_t)2 * 3 * N * (64 + 8) * 2;
+  const size_t lds = (size_t)2 * 3 * N * (64 + 8) * 2 + 2 * 192 * 4;
   const int64_t mblocks = ceil_div(M, 64);
   if (!transA) {
     if (N == 128)
-      k_bits_bx3<128, false><<<(int)mblocks, 512, lds, s>>>(M, K, K, bits, ldw, planes, K, beta, C, ldc, row_scale, nullptr);
+      k_bits_bx3<128, false><<<(int)mblocks, 768, lds, s>>>(M, K, K, bits, ldw, planes, K, beta, C, ldc, row_scale, nullptr);
     else
-      k_bits_bx3<64, false><<<(int)mblocks, 512, lds, s>>>(M, K, K, bits, ldw, planes, K, beta, C, ldc, row_scale, nullptr);
+      k_bits_bx3<64, false><<<(int)mblocks, 768, lds, s>>>(M, K, K, bits, ldw, planes, K, beta, C, ldc, row_scale, nullptr);
   } else {
-    const int64_t kc = ((K + nsl - 1) / nsl + 63) / 64 * 64;
+    const int64_t kc = ((K + nsl - 1) / nsl + 127) / 128 * 128;
     const int64_t grid = mblocks * nsl;
     if (N == 128)
-      k_bits_bx3<128, true><<<(int)grid, 512, lds, s>>>(M, K, kc, bits, ldw, planes, K, 0.f, part, N, gvec, rsp);
+      k_bits_bx3<128, true><<<(int)grid, 768, lds, s>>>(M, K, kc, bits, ldw, planes, K, 0.f, part, N, gvec, rsp);
     else
-      k_bits_bx3<64, true><<<(int)grid, 512, lds, s>>>(M, K, kc, bits, ldw, planes, K, 0.f, part, N, gvec, rsp);
+      k_bits_bx3<64, true><<<(int)grid, 768, lds, s>>>(M, K, kc, bits, ldw, planes, K, 0.f, part, N, gvec, rsp);
   }
   ARX_CHECK_LAUNCH();
   return ARX_OK;
