@@ -27,6 +27,19 @@ namespace arx {
 
 namespace {
 
+// -DBX6_TRACE: cycle stamps of workgroup 7 (tools/bx6_trace.py), 256 events per wave
+#ifdef BX6_TRACE
+__device__ unsigned long long g_bx6_trace[12 * 256];
+#define BX6_T(ev_)                                                                                       \
+  if (blockIdx.x == 7 && (threadIdx.x & 63) == 0 && tcount < 256)                                        \
+    g_bx6_trace[(threadIdx.x >> 6) * 256 + tcount++] =                                                   \
+        ((unsigned long long)(ev_) << 56) | (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFFFull);
+#define BX6_TDECL int tcount = 0;
+#else
+#define BX6_T(ev_)
+#define BX6_TDECL
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -463,7 +476,10 @@ __global__ __launch_bounds__(768) void k_bits_bx3(int64_t M, int64_t K, int64_t 
       lo[t] = f32x16{0};
     }
     float rs = 0.f;
+    BX6_TDECL
+    BX6_T(1)
     __syncthreads();                                         // stage 0 is in LDS
+    BX6_T(2)
     for (int st = 0; st < nstage; ++st) {
       const int slot = st & 1;
       const int64_t kb = k0 + 64 * (int64_t)st;
@@ -472,42 +488,49 @@ __global__ __launch_bounds__(768) void k_bits_bx3(int64_t M, int64_t K, int64_t 
       //   xs[128 + k] = g[kb + k]
       const uint32_t* xs = xw + slot * 192;
       uint32_t w_lo = 0u, w_hi = 0u;
-      uint4 bw[8];
-      float4 gw[8];
+      uint4 bw[2][2];                                 // TN: the 8 words (and row factors) of a chunk, double-buffered
+      float4 gw[2][2];
+      const uint32_t* bp = xs + mt * 64 + 8 * kg;
+      const float* gp = reinterpret_cast<const float*>(xs + 128) + 8 * kg;
+      const bool do_rs = TN && nh == 0 && rsp != nullptr;
+#define BX3_BITS(buf_, c_)                                                                              \
+  if (TN) {                                                                                             \
+    bw[buf_][0] = *reinterpret_cast<const uint4*>(bp + 16 * (c_));                                      \
+    bw[buf_][1] = *reinterpret_cast<const uint4*>(bp + 16 * (c_) + 4);                                  \
+    if (do_rs) {                                                                                        \
+      gw[buf_][0] = *reinterpret_cast<const float4*>(gp + 16 * (c_));                                   \
+      gw[buf_][1] = *reinterpret_cast<const float4*>(gp + 16 * (c_) + 4);                               \
+    }                                                                                                   \
+  }
       if (!TN) {
         w_lo = xs[mt * 32 + lr];
         w_hi = xs[64 + mt * 32 + lr];
-      } else {
-        const uint32_t* bp = xs + mt * 64 + 8 * kg;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          bw[2 * c] = *reinterpret_cast<const uint4*>(bp + 16 * c);
-          bw[2 * c + 1] = *reinterpret_cast<const uint4*>(bp + 16 * c + 4);
-        }
-        if (nh == 0 && rsp) {
-          const float* gp = reinterpret_cast<const float*>(xs + 128) + 8 * kg;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            gw[2 * c] = *reinterpret_cast<const float4*>(gp + 16 * c);
-            gw[2 * c + 1] = *reinterpret_cast<const float4*>(gp + 16 * c + 4);
-          }
-        }
       }
+      BX3_BITS(0, 0)
       const uint16_t* tb = lds + slot * SLOT + ((nh * NTW) * 32 + lr) * LDR + 8 * kg;
+      // the plane fragments of chunk c + 1 are requested BEFORE the MFMAs of chunk c are issued (left to itself
+      // the compiler emits read, wait, MFMA, read, wait, MFMA ...: 24 exposed LDS round trips per stage)
+      uint4 fr[2][NTW * 3];
+#define BX3_FRAGS(buf_, c_)                                                                             \
+  _Pragma("unroll") for (int t = 0; t < NTW; ++t) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)       \
+      fr[buf_][t * 3 + pl] = *reinterpret_cast<const uint4*>(tb + t * 32 * LDR + pl * N * LDR + 16 * (c_));
+      BX3_FRAGS(0, 0)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
+        if (c + 1 < 4) { BX3_FRAGS((c + 1) & 1, c + 1) BX3_BITS((c + 1) & 1, c + 1) }
+        __builtin_amdgcn_sched_barrier(0);
         uint4 aq;
         if (!TN) {
           const uint32_t b = ((c < 2 ? w_lo : w_hi) >> ((16 * c + 8 * kg) & 31)) & 0xFFu;
           aq = make_uint4(bf16_pair01(b & 1u, (b >> 1) & 1u), bf16_pair01((b >> 2) & 1u, (b >> 3) & 1u),
                           bf16_pair01((b >> 4) & 1u, (b >> 5) & 1u), bf16_pair01((b >> 6) & 1u, (b >> 7) & 1u));
         } else {
-          const uint4 x = bw[2 * c], y = bw[2 * c + 1];
+          const uint4 x = bw[c & 1][0], y = bw[c & 1][1];
           const uint32_t e0 = (x.x >> lr) & 1u, e1 = (x.y >> lr) & 1u, e2 = (x.z >> lr) & 1u, e3 = (x.w >> lr) & 1u;
           const uint32_t e4 = (y.x >> lr) & 1u, e5 = (y.y >> lr) & 1u, e6 = (y.z >> lr) & 1u, e7 = (y.w >> lr) & 1u;
           aq = make_uint4(bf16_pair01(e0, e1), bf16_pair01(e2, e3), bf16_pair01(e4, e5), bf16_pair01(e6, e7));
-          if (nh == 0 && rsp) {
-            const float4 ga = gw[2 * c], gb = gw[2 * c + 1];
+          if (do_rs) {
+            const float4 ga = gw[c & 1][0], gb = gw[c & 1][1];
             rs += (e0 ? ga.x : 0.f) + (e1 ? ga.y : 0.f) + (e2 ? ga.z : 0.f) + (e3 ? ga.w : 0.f) +
                   (e4 ? gb.x : 0.f) + (e5 ? gb.y : 0.f) + (e6 ? gb.z : 0.f) + (e7 ? gb.w : 0.f);
           }
@@ -515,16 +538,20 @@ __global__ __launch_bounds__(768) void k_bits_bx3(int64_t M, int64_t K, int64_t 
         const bf16x8 af = __builtin_bit_cast(bf16x8, aq);
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-          const uint16_t* tp = tb + t * 32 * LDR + 16 * c;
-          const bf16x8 p1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tp));
-          const bf16x8 p2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tp + N * LDR));
-          const bf16x8 p3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tp + 2 * N * LDR));
+          const bf16x8 p1 = __builtin_bit_cast(bf16x8, fr[c & 1][t * 3]);
+          const bf16x8 p2 = __builtin_bit_cast(bf16x8, fr[c & 1][t * 3 + 1]);
+          const bf16x8 p3 = __builtin_bit_cast(bf16x8, fr[c & 1][t * 3 + 2]);
           lo[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, af, lo[t], 0, 0, 0);
           lo[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, af, lo[t], 0, 0, 0);
           hi[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, af, hi[t], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
+#undef BX3_FRAGS
+#undef BX3_BITS
+      BX6_T(3)
       __syncthreads();
+      BX6_T(4)
     }
     // epilogue: lane = output row m, columns (nh NTW + t) 32 + 8 g + 4 kg + 0..3
     if (!TN) {
@@ -618,11 +645,15 @@ __global__ __launch_bounds__(768) void k_bits_bx3(int64_t M, int64_t K, int64_t 
   if (pr == 0) bx_barrier();                                 // B0: stage 0 is in LDS
   if (pr == 1) bx_barrier();                                 // E(0)
   const int iters = nstage / 2 - pr;
+  BX6_TDECL
   for (int it = 0; it < iters; ++it) {
     const int sn = 2 * it + pr + 2;                          // the pair's next stage
+    BX6_T(5)
     BX3_LOAD((sn <= last ? sn : last))
     bx_barrier();                                            // end of stage sn - 2: slot pr is free
+    BX6_T(6)
     BX3_STORE(pr)
+    BX6_T(7)
     bx_barrier();                                            // end of stage sn - 1
   }
   if (pr == 1) bx_barrier();                                 // E(last)
@@ -769,6 +800,10 @@ int gemm_bits_bx3_launch(int transA, int64_t M, int64_t N, int64_t K, const uint
 using namespace arx;
 
 extern "C" {
+
+#ifdef BX6_TRACE
+int arx_bx6_trace_read(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bx6_trace), sizeof(g_bx6_trace)); }
+#endif
 
 size_t arx_gemm_nt_bx6_workspace_bytes(int64_t N, int64_t K) { return align256((size_t)3 * N * K * 2); }
 
