@@ -439,7 +439,9 @@ __global__ __launch_bounds__(512) void k_nt_hinge_bx6(int64_t M, int64_t N, cons
 __device__ __forceinline__ void bx_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ uint32_t bf16_pair01(uint32_t b0, uint32_t b1) {      // two bits -> two bf16 (0.0 / 1.0)
-  return b0 * 0x3F80u + b1 * 0x3F800000u;
+  // 24-bit multiplies (full rate; a 32-bit v_mul_lo_u32 is quarter rate and made this expansion -- not the MFMAs,
+  // not LDS -- the bound of the kernel: 1 700 cycles per stage of 24 MFMAs)
+  return __umul24(b0, 0x3F80u) | (__umul24(b1, 0x3F80u) << 16);
 }
 
 template <int N, bool TN>
@@ -447,7 +449,6 @@ __global__ __launch_bounds__(768) void k_bits_bx3(int64_t M, int64_t K, int64_t 
                                                   int64_t ldw, const uint16_t* __restrict__ XT, int64_t xt_rows,
                                                   float beta, float* __restrict__ C, int64_t ldc,
                                                   const float* __restrict__ gvec, float* __restrict__ rsp) {
-  constexpr int NTW = N / 64;                      // n-tiles per compute wave
   constexpr int LDR = 64 + 8;                      // LDS row: 64 k + pad (bf16)
   constexpr int SLOT = 3 * N * LDR;                // bf16 per stage
   extern __shared__ uint16_t lds[];                // [2][3 planes][N][LDR], then [2][192] words: the stage's act bits (+ g)
@@ -464,105 +465,142 @@ __global__ __launch_bounds__(768) void k_bits_bx3(int64_t M, int64_t K, int64_t 
   const int64_t plane = (int64_t)N * xt_rows;
 
   if (wv < 4) {
-    const int mt = wv & 1, nh = wv >> 1;
+    // N = 128: wave w owns n-tile w and BOTH m-tiles of the block -- a plane fragment read from LDS feeds two
+    // MFMAs (LDS bandwidth, not the matrix pipe, bounds this kernel); N = 64: wave = (n-tile w & 1, m-tile w >> 1).
+    constexpr int NMT = N == 128 ? 2 : 1;            // m-tiles per compute wave
+    const int nt = N == 128 ? wv : (wv & 1);
+    const int mt0 = N == 128 ? 0 : (wv >> 1);
     const int lr = lane & 31, kg = lane >> 5;
-    const int64_t m = mb * 64 + mt * 32 + lr;
-    const bool ok = m < M;
-    const int64_t mtile = mb * 2 + mt;               // TN: the word row of this wave's 32 pool columns
-    f32x16 hi[NTW], lo[NTW];
+    f32x16 hi[NMT], lo[NMT];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
+    for (int t = 0; t < NMT; ++t) {
       hi[t] = f32x16{0};
       lo[t] = f32x16{0};
     }
-    float rs = 0.f;
+    float rs[NMT];
+#pragma unroll
+    for (int t = 0; t < NMT; ++t) rs[t] = 0.f;
+    const bool do_rs = TN && nt == 0 && rsp != nullptr;
     BX6_TDECL
     BX6_T(1)
     __syncthreads();                                         // stage 0 is in LDS
     BX6_T(2)
     for (int st = 0; st < nstage; ++st) {
       const int slot = st & 1;
-      const int64_t kb = k0 + 64 * (int64_t)st;
       // this stage's activity bits (and row factors), staged in LDS by the loaders with the planes:
       //   NN: xs[h * 64 + r] = word (kb / 32 + h) of row mb * 64 + r;  TN: xs[t * 64 + k] = word of m-tile t, row kb + k;
       //   xs[128 + k] = g[kb + k]
       const uint32_t* xs = xw + slot * 192;
-      uint32_t w_lo = 0u, w_hi = 0u;
-      uint4 bw[2][2];                                 // TN: the 8 words (and row factors) of a chunk, double-buffered
-      float4 gw[2][2];
-      const uint32_t* bp = xs + mt * 64 + 8 * kg;
+      uint32_t w_lo[NMT], w_hi[NMT];
+      uint4 bw[2][NMT][2];                            // TN: the 8 words of a chunk per m-tile, double-buffered
+      float4 gw[2][2];                                //     and the chunk's row factors
+      const uint32_t* bp = xs + mt0 * 64 + 8 * kg;
       const float* gp = reinterpret_cast<const float*>(xs + 128) + 8 * kg;
-      const bool do_rs = TN && nh == 0 && rsp != nullptr;
 #define BX3_BITS(buf_, c_)                                                                              \
   if (TN) {                                                                                             \
-    bw[buf_][0] = *reinterpret_cast<const uint4*>(bp + 16 * (c_));                                      \
-    bw[buf_][1] = *reinterpret_cast<const uint4*>(bp + 16 * (c_) + 4);                                  \
+    _Pragma("unroll") for (int t = 0; t < NMT; ++t) {                                                   \
+      bw[buf_][t][0] = *reinterpret_cast<const uint4*>(bp + t * 64 + 16 * (c_));                        \
+      bw[buf_][t][1] = *reinterpret_cast<const uint4*>(bp + t * 64 + 16 * (c_) + 4);                    \
+    }                                                                                                   \
     if (do_rs) {                                                                                        \
       gw[buf_][0] = *reinterpret_cast<const float4*>(gp + 16 * (c_));                                   \
       gw[buf_][1] = *reinterpret_cast<const float4*>(gp + 16 * (c_) + 4);                               \
     }                                                                                                   \
   }
       if (!TN) {
-        w_lo = xs[mt * 32 + lr];
-        w_hi = xs[64 + mt * 32 + lr];
+#pragma unroll
+        for (int t = 0; t < NMT; ++t) {
+          w_lo[t] = xs[(mt0 + t) * 32 + lr];
+          w_hi[t] = xs[64 + (mt0 + t) * 32 + lr];
+        }
       }
       BX3_BITS(0, 0)
-      const uint16_t* tb = lds + slot * SLOT + ((nh * NTW) * 32 + lr) * LDR + 8 * kg;
-      // the plane fragments of chunk c + 1 are requested BEFORE the MFMAs of chunk c are issued (left to itself
-      // the compiler emits read, wait, MFMA, read, wait, MFMA ...: 24 exposed LDS round trips per stage)
-      uint4 fr[2][NTW * 3];
+      BX3_BITS(1, 1)
+      const uint16_t* tb = lds + slot * SLOT + (nt * 32 + lr) * LDR + 8 * kg;
+      uint4 fr[2][3];
 #define BX3_FRAGS(buf_, c_)                                                                             \
-  _Pragma("unroll") for (int t = 0; t < NTW; ++t) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)       \
-      fr[buf_][t * 3 + pl] = *reinterpret_cast<const uint4*>(tb + t * 32 * LDR + pl * N * LDR + 16 * (c_));
+  _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                      \
+      fr[buf_][pl] = *reinterpret_cast<const uint4*>(tb + pl * N * LDR + 16 * (c_));
+      // act fragment of m-tile t_, chunk c_ (NN: from the row's two words; TN: bit lr of the chunk's 8 words)
+#define BX3_ACT(dst_, t_, c_)                                                                           \
+  {                                                                                                     \
+    if (!TN) {                                                                                          \
+      const uint32_t b = (((c_) < 2 ? w_lo[t_] : w_hi[t_]) >> ((16 * (c_) + 8 * kg) & 31)) & 0xFFu;    \
+      dst_ = make_uint4(bf16_pair01(b & 1u, (b >> 1) & 1u), bf16_pair01((b >> 2) & 1u, (b >> 3) & 1u),  \
+                        bf16_pair01((b >> 4) & 1u, (b >> 5) & 1u), bf16_pair01((b >> 6) & 1u, (b >> 7) & 1u)); \
+    } else {                                                                                            \
+      const uint4 x = bw[(c_) & 1][t_][0], y = bw[(c_) & 1][t_][1];                                     \
+      const uint32_t e0 = (x.x >> lr) & 1u, e1 = (x.y >> lr) & 1u, e2 = (x.z >> lr) & 1u, e3 = (x.w >> lr) & 1u; \
+      const uint32_t e4 = (y.x >> lr) & 1u, e5 = (y.y >> lr) & 1u, e6 = (y.z >> lr) & 1u, e7 = (y.w >> lr) & 1u; \
+      dst_ = make_uint4(bf16_pair01(e0, e1), bf16_pair01(e2, e3), bf16_pair01(e4, e5), bf16_pair01(e6, e7)); \
+      if (do_rs) {                                                                                      \
+        const float4 ga = gw[(c_) & 1][0], gb = gw[(c_) & 1][1];                                        \
+        rs[t_] += (e0 ? ga.x : 0.f) + (e1 ? ga.y : 0.f) + (e2 ? ga.z : 0.f) + (e3 ? ga.w : 0.f) +       \
+                  (e4 ? gb.x : 0.f) + (e5 ? gb.y : 0.f) + (e6 ? gb.z : 0.f) + (e7 ? gb.w : 0.f);        \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
       BX3_FRAGS(0, 0)
+      uint4 ac[NMT], an[NMT];                         // act fragments of this chunk / the next one
+#pragma unroll
+      for (int t = 0; t < NMT; ++t) BX3_ACT(ac[t], t, 0)
+      // Software pipeline, per chunk c:  A: LDS requests for chunk c + 1 (planes) and c + 2 (TN bit words);
+      // B: the MFMAs of chunk c with the VALU expansion of chunk c + 1's act fragments BETWEEN them -- into other
+      // registers (an): written into the registers the running MFMAs still read, the expansion waits for them, and
+      // back-to-back MFMAs on one accumulator wait for each other (both measured: 1 700 cycles per stage of 24
+      // MFMAs).  Accumulators alternate so that dependent MFMAs are >= 3 apart.
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        if (c + 1 < 4) { BX3_FRAGS((c + 1) & 1, c + 1) BX3_BITS((c + 1) & 1, c + 1) }
+        if (c + 1 < 4) { BX3_FRAGS((c + 1) & 1, c + 1) }
         __builtin_amdgcn_sched_barrier(0);
-        uint4 aq;
-        if (!TN) {
-          const uint32_t b = ((c < 2 ? w_lo : w_hi) >> ((16 * c + 8 * kg) & 31)) & 0xFFu;
-          aq = make_uint4(bf16_pair01(b & 1u, (b >> 1) & 1u), bf16_pair01((b >> 2) & 1u, (b >> 3) & 1u),
-                          bf16_pair01((b >> 4) & 1u, (b >> 5) & 1u), bf16_pair01((b >> 6) & 1u, (b >> 7) & 1u));
-        } else {
-          const uint4 x = bw[c & 1][0], y = bw[c & 1][1];
-          const uint32_t e0 = (x.x >> lr) & 1u, e1 = (x.y >> lr) & 1u, e2 = (x.z >> lr) & 1u, e3 = (x.w >> lr) & 1u;
-          const uint32_t e4 = (y.x >> lr) & 1u, e5 = (y.y >> lr) & 1u, e6 = (y.z >> lr) & 1u, e7 = (y.w >> lr) & 1u;
-          aq = make_uint4(bf16_pair01(e0, e1), bf16_pair01(e2, e3), bf16_pair01(e4, e5), bf16_pair01(e6, e7));
-          if (do_rs) {
-            const float4 ga = gw[c & 1][0], gb = gw[c & 1][1];
-            rs += (e0 ? ga.x : 0.f) + (e1 ? ga.y : 0.f) + (e2 ? ga.z : 0.f) + (e3 ? ga.w : 0.f) +
-                  (e4 ? gb.x : 0.f) + (e5 ? gb.y : 0.f) + (e6 ? gb.z : 0.f) + (e7 ? gb.w : 0.f);
-          }
-        }
-        const bf16x8 af = __builtin_bit_cast(bf16x8, aq);
+        const bf16x8 p1 = __builtin_bit_cast(bf16x8, fr[c & 1][0]);
+        const bf16x8 p2 = __builtin_bit_cast(bf16x8, fr[c & 1][1]);
+        const bf16x8 p3 = __builtin_bit_cast(bf16x8, fr[c & 1][2]);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-          const bf16x8 p1 = __builtin_bit_cast(bf16x8, fr[c & 1][t * 3]);
-          const bf16x8 p2 = __builtin_bit_cast(bf16x8, fr[c & 1][t * 3 + 1]);
-          const bf16x8 p3 = __builtin_bit_cast(bf16x8, fr[c & 1][t * 3 + 2]);
-          lo[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, af, lo[t], 0, 0, 0);
-          lo[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, af, lo[t], 0, 0, 0);
-          hi[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, af, hi[t], 0, 0, 0);
+        for (int t = 0; t < NMT; ++t)
+          lo[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, __builtin_bit_cast(bf16x8, ac[t]), lo[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NMT; ++t)
+          hi[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, __builtin_bit_cast(bf16x8, ac[t]), hi[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NMT; ++t)
+          lo[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, __builtin_bit_cast(bf16x8, ac[t]), lo[t], 0, 0, 0);
+        if (c + 1 < 4) {
+#pragma unroll
+          for (int t = 0; t < NMT; ++t) BX3_ACT(an[t], t, c + 1)
+        }
+        // interleave: one MFMA, then a share of the VALU work
+#pragma unroll
+        for (int i = 0; i < 3 * NMT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, TN ? 12 : 7, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < 4) { BX3_BITS(c & 1, c + 2) }             // (its buffer's words were consumed for chunk c)
+        if (c + 1 < 4) {
+#pragma unroll
+          for (int t = 0; t < NMT; ++t) ac[t] = an[t];
+        }
       }
 #undef BX3_FRAGS
 #undef BX3_BITS
+#undef BX3_ACT
       BX6_T(3)
       __syncthreads();
       BX6_T(4)
     }
-    // epilogue: lane = output row m, columns (nh NTW + t) 32 + 8 g + 4 kg + 0..3
-    if (!TN) {
-      if (ok) {
-        const float gm = gvec ? gvec[m] : 1.f;
-        float* crow = C + m * ldc + (nh * NTW) * 32 + 4 * kg;
+    // epilogue: lane = output row m (one per m-tile), columns nt * 32 + 8 g + 4 kg + 0..3
 #pragma unroll
-        for (int t = 0; t < NTW; ++t)
+    for (int t = 0; t < NMT; ++t) {
+      const int64_t m = mb * 64 + (mt0 + t) * 32 + lr;
+      const bool ok = m < M;
+      if (!TN) {
+        if (ok) {
+          const float gm = gvec ? gvec[m] : 1.f;
+          float* crow = C + m * ldc + nt * 32 + 4 * kg;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            float4* cp4 = reinterpret_cast<float4*>(crow + t * 32 + 8 * g);
+            float4* cp4 = reinterpret_cast<float4*>(crow + 8 * g);
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (beta != 0.f) {
               o = *cp4;
@@ -574,21 +612,20 @@ __global__ __launch_bounds__(768) void k_bits_bx3(int64_t M, int64_t K, int64_t 
             o.w += gm * (hi[t][4 * g + 3] + lo[t][4 * g + 3]);
             *cp4 = o;
           }
-      }
-    } else {
-      if (ok) {
-        float* prow = C + (slice * M + m) * (int64_t)N + (nh * NTW) * 32 + 4 * kg;      // C = partials [slices][M][N]
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
+        }
+      } else {
+        if (ok) {
+          float* prow = C + (slice * M + m) * (int64_t)N + nt * 32 + 4 * kg;            // C = partials [slices][M][N]
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(prow + t * 32 + 8 * g) =
+            *reinterpret_cast<float4*>(prow + 8 * g) =
                 make_float4(hi[t][4 * g] + lo[t][4 * g], hi[t][4 * g + 1] + lo[t][4 * g + 1],
                             hi[t][4 * g + 2] + lo[t][4 * g + 2], hi[t][4 * g + 3] + lo[t][4 * g + 3]);
-      }
-      if (nh == 0 && rsp) {
-        rs += __shfl_xor(rs, 32, 64);
-        if (kg == 0 && ok) rsp[slice * M + m] = rs;
+        }
+        if (do_rs) {
+          const float r = rs[t] + __shfl_xor(rs[t], 32, 64);
+          if (kg == 0 && ok) rsp[slice * M + m] = r;
+        }
       }
     }
     return;
