@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void k_run_apply(TableSet ts, int d, RunLists 
       }
       float4 a[NB];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) a[j] = act[j] ? f4_fma(__int_as_float(r2[j].y), g0[j], z4) : z4;
+      for (int j = 0; j < NB; ++j) a[j] = act[j] ? f4_fma(__int_as_float(r2[j].y), g0[j], z4) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (maxcnt > 1) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void k_run_apply(TableSet ts, int d, RunLists 
               const bool ok = k0 + u < r[j].z;
               const int s = s_src[sgl][j][ok ? k0 + u : 1];
               c[j][u] = s_coef[sgl][j][ok ? k0 + u : 1];
-              v[j][u] = (ok && colok) ? *reinterpret_cast<const float4*>(G + (int64_t)s * ldg + col) : z4;
+              v[j][u] = (ok && colok) ? *reinterpret_cast<const float4*>(G + (int64_t)s * ldg + col) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
           for (int j = 0; j < NB; ++j)
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void k_run_apply(TableSet ts, int d, RunLists 
         const bool ok = t + u < m;
         const int s = __shfl(es, ok ? t + u : 0, LPR);
         c[u] = ok ? __shfl(ec, ok ? t + u : 0, LPR) : 0.f;
-        v[u] = (ok && colok) ? *reinterpret_cast<const float4*>(G + (int64_t)s * ldg + col) : z4;
+        v[u] = (ok && colok) ? *reinterpret_cast<const float4*>(G + (int64_t)s * ldg + col) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < LRU; ++u)
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void k_run_apply(TableSet ts, int d, RunLists 
           for (int u = 0; u < LRU; ++u) {
             const bool ok = q + u < q1;
             const int64_t pr = (int64_t)lr4.y + (ok ? q + u : q0);
-            v[u] = colok ? agent_load4(sg.part + pr * d + col) : z4;
+            v[u] = colok ? agent_load4(sg.part + pr * d + col) : make_float4(0.f, 0.f, 0.f, 0.f);
             vb[u] = __hip_atomic_load(sg.part_b + pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
 #pragma unroll
