@@ -460,6 +460,19 @@ class ShardedHMF(object):
         self.steps += 1
 
 
+    def _fused_scorer(self):
+        """True when the step takes the bf16-pipe scorer (switches on, shapes it supports); allocates its buffers."""
+        if not (os.environ.get("ARX_GEMM_BX6") and os.environ.get("ARX_MW_GEMM_FUSE")) or self.d not in (64, 128) \
+                or self.S % 128 != 0 or self.B_loc % 32 != 0 or self.B_loc < 64:
+            return False
+        if getattr(self, 'act_bits', None) is None:
+            dev = self.device
+            self.act_bits = torch.zeros((self.S // 32, self.B_loc), dtype=torch.int32, device=dev)
+            self.gvec = torch.zeros((self.B_loc,), dtype=torch.float32, device=dev)
+            self.Ug = torch.zeros((self.B_loc, self.d), dtype=torch.float32, device=dev)
+            self.be.ws_k7b = self.be.ops.Workspace(dev)
+        return True
+
     @property
     def stream(self):
         """The stream the graph-segment step runs on (None: eager step, the caller's stream).  A training loop
@@ -544,18 +557,39 @@ class ShardedHMF(object):
                                       (self.E_item, self.b_item, self.pool_rows[:cap], self.I_pack[:cap], 'packed'),
                                       (self.E_item, self.b_item, rrows, T_in, 'packed')])
 
+        # EXPERIMENT (ARX_GEMM_BX6=1 ARX_MW_GEMM_FUSE=1): the scorer on the bf16 matrix pipe --
+        # hinge GEMM (act bits instead of logits / dlogits) + the two bit-operand backward products
+        fused = self._fused_scorer()
+
         def fwd_score():
             if W > 1:    # blocks -> pool (slot) order, their bias column -> b_all
                 be.gather_rows_multi([(self.I_gath, d, self.gidx, self.I_all, self.b_all)])
-            be.gemm(self.U_loc, self.I_all[:, :d], self.logits, transB=True, col_bias=self.b_all)
+            if not fused:
+                be.gemm(self.U_loc, self.I_all[:, :d], self.logits, transB=True, col_bias=self.b_all)
 
         def loss():
             dt = arena_b[B_loc + Sg:B_loc + Sg + B_loc] if W == 1 else dT[:, d]
+            if fused:
+                be.ops.mw_gemm_fused_fwd(self.U_loc, self.I_all[:, :d], self.b_all, self.T_pack[:, :d],
+                                         self.T_pack[:, d], urows, self.pos_ptr, self.pos_items, self.item2slot,
+                                         self.bl, self.t_loc, self.act_bits, self.gvec, self.Ug, dt, dU, dT[:, :d],
+                                         1.0 / B, be.ws)
+                return
             be.loss_mw_fused_pos(self.logits, self.U_loc, self.T_pack[:, :d], self.T_pack[:, d], urows,
                                  self.pos_ptr, self.pos_items, self.item2slot, self.bl, self.dlogits,
                                  self.t_loc, dt, dU, dT[:, :d], 1.0 / B)
 
         def bwd_gemms():
+            if fused:
+                be.ops.gemm_bits(self.act_bits, self.I_all[:, :d], dU, be.ws, beta=1.0, row_scale=self.gvec)
+                if W == 1:
+                    be.ops.gemm_bits(self.act_bits, self.Ug, arena[B_loc:B_loc + S, :d], be.ws_k7b, transA=True,
+                                     gvec=self.gvec, a_rowsum=arena_b[B_loc:B_loc + S])
+                    return
+                be.ops.gemm_bits(self.act_bits, self.Ug, self.dI_all[:S, :d], be.ws_k7b, transA=True, gvec=self.gvec,
+                                 a_rowsum=self.gb_all)
+                be.copy_strided(self.gb_all, self.dI_all[:S, d])
+                return
             be.gemm(self.dlogits, self.I_all[:, :d], dU, beta=1.0)
             if W == 1:
                 be.gemm(self.dlogits, self.U_loc, arena[B_loc:B_loc + S, :d], transA=True,

@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3mix"],
                     help="headline workload (default c3 = BASELINE configs[2], HET layout)")
     ap.add_argument("--mulhot", action="store_true", help="(compat) same as --workload c3")
-    ap.add_argument("--subs", default="c2,c3mix,c4,c4mce,k1,c5w1,c3_bf16pipe,c2_bf16pipe",
+    ap.add_argument("--subs", default="c2,c3mix,c4,c4mce,k1,c5w1,c3_bf16pipe,c2_bf16pipe,c5w1_bf16pipe",
                     help="comma list of sub-results besides the headline ('' = none)")
     ap.add_argument("--sub-steps", type=int, default=50)
     ap.add_argument("--repeats", type=int, default=5,
@@ -598,14 +598,20 @@ def run_bf16pipe(args, workload):
     dlogits).  The switches are read once per process: a child process runs the workload."""
     import subprocess
     env = dict(os.environ, ARX_GEMM_BX6="1", ARX_MW_GEMM_FUSE="1")
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--subs", "", "--no-rooflines",
-           "--no-cpu-baseline", "--steps", str(args.sub_steps), "--warmup", str(min(args.warmup, 10)),
+    sharded = workload == "c5w1"            # the world-1 sharded step: a sub-result of a (short) child run
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "c2" if sharded else workload,
+           "--subs", "c5w1" if sharded else "", "--no-rooflines",
+           "--no-cpu-baseline", "--steps", str(10 if sharded else args.sub_steps), "--warmup", str(min(args.warmup, 10)),
+           "--sub-steps", str(args.sub_steps), "--repeats", "1" if sharded else str(args.repeats),
            "--batch", str(args.batch), "--n-sampled", str(args.n_sampled), "--dim", str(args.dim)]
     if args.n_items:
         cmd += ["--n-items", str(args.n_items)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
     line = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
+    if sharded:
+        j = j["sub"]["c5w1"]
+        j.setdefault("steps", args.sub_steps)
     return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
             "dtype": "f32 in / f32 accumulate; products as 6 (3 with the 0/1 operand) exact bf16 x bf16 MFMA terms",
             "switches": "ARX_GEMM_BX6=1 ARX_MW_GEMM_FUSE=1 (off by default)",
@@ -657,7 +663,7 @@ def main():
                     out["roofline_gather"]["past_llc"] = r
             elif s == "c5w1":
                 r = run_sharded_world1(args)
-            elif s.endswith("_bf16pipe") and s[:-9] in WORKLOADS:
+            elif s.endswith("_bf16pipe") and (s[:-9] in WORKLOADS or s[:-9] == "c5w1"):
                 r = run_bf16pipe(args, s[:-9])
             else:
                 continue

@@ -32,6 +32,11 @@ def test_bf16pipe_training_steps_match_oracle(dev):
     assert " passed" in out and "failed" not in out
 
 
+def test_bf16pipe_sharded_step_matches_oracle(dev):
+    out = _run(["tests/test_dist_gpu.py", "-k", "sharded_hip_backend_world1 or sharded_c5_shape"], 900)
+    assert " passed" in out and "failed" not in out
+
+
 def test_bf16pipe_fullsize_steps_match_oracle(dev):
     out = _run(["tests/test_fullsize_gpu.py", "-k", "not lstm"], 1200)
     assert " passed" in out and "failed" not in out

@@ -10,8 +10,9 @@ from oracle import ref_graph as rg
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("B,S", [(32, 64), (128, 128)])     # (the second shape is one the bf16-pipe scorer takes)
 @pytest.mark.parametrize("graphs", [True, False])
-def test_sharded_hip_backend_world1(dev, graphs):
+def test_sharded_hip_backend_world1(dev, graphs, B, S):
     """graphs=True: the step is ONE hipGraph (ShardedHMF._step_static: eager on step 0, captured on step
     1, replayed from step 2 on -- through two pool redraws and fresh batches)."""
     import torch
@@ -24,7 +25,7 @@ def test_sharded_hip_backend_world1(dev, graphs):
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
-        n_users, n_items, d, B, S = 300, 500, 64, 32, 64
+        n_users, n_items, d = 300, 500, 64
         syn = SyntheticHMF(n_users=n_users, n_items=n_items, seed=1, permute_logits=False, n_pos=8)
         params = syn.glorot_params(d, seed=2, scale=0.5)
         tables = {'user': params['userembed_cat_0'][2:], 'item': params['itemembed_cat_0'][2:],
