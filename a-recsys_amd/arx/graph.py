@@ -535,12 +535,10 @@ class BatchLoss(Node):
                 B_ = logits.shape[0]
                 if (kind == 'mw' and type(logits) is Prediction and logits.inputs[0] is lat and d in (64, 128)
                         and W % 32 == 0 and B_ % 32 == 0 and B_ >= 64 and W >= 64
-                        and os.environ.get('ARX_MW_GEMM_FUSE')):
-                    # OPT-IN (measured, C2 B=16384: 284 us/step against 248 with the separate loss
-                    # kernel): the loss-side HBM traffic drops from 4 passes over [B, S] fp32 to 2 MB
-                    # of bits, but the three GEMMs are MFMA-issue bound at ~56 % of peak whatever
-                    # feeds their A operand (a constant operand: 49 us; fp32 dlogits: 51; bits: 54),
-                    # and the hinge epilogue + pre / row kernels cost what the loss kernel did
+                        and not ops.SCORER_F32):
+                    # DEFAULT since round 4 (ARX_SCORER_F32=1: logits GEMM + loss kernel + two f32 GEMMs): no
+                    # [B, S] logits / dlogits in HBM, 2 MB of activity bits instead, and all three products on
+                    # the bf16 matrix pipe, f32-exact (csrc/gemm_bx6.hip; C3 312 -> 260 us/step in round 3)
                     self.gemm_fused = True
                     logits.fused_into_loss = True
 

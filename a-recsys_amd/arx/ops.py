@@ -258,7 +258,11 @@ def dot_score_bwd(U, T, dscore, dU, acc_dU, dT):
 
 
 # ---- a8 -----------------------------------------------------------------------
-_BX6 = bool(os.environ.get("ARX_GEMM_BX6"))      # EXPERIMENT: the logits GEMM on the bf16 pipe, f32-exact
+# The scorer products run on the bf16 matrix pipe, f32-exact (three exact bf16 pieces per operand, six MFMA terms,
+# f32 accumulation: csrc/gemm_bx6.hip) -- the default since round 4; ARX_SCORER_F32=1 selects the f32-input MFMA
+# kernels (the A/B reference, bench.py's *_f32mfma sub-results).  Read once per process.
+SCORER_F32 = bool(os.environ.get("ARX_SCORER_F32"))
+_BX6 = not SCORER_F32
 _bx6_ws = {}
 
 

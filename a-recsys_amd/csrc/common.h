@@ -134,7 +134,7 @@ int gemm_nt_hinge(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, 
 int gemm_nt_hinge_bx6(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                       const float* col_bias, const float* tscore, uint32_t* bits, int64_t ldbits, float* rs_part,
                       float* cnt_part, int* nsplit_out, uint16_t* planes, hipStream_t s);
-bool bx6_enabled();      // ARX_GEMM_BX6 set (read once)
+bool bx6_enabled();      // true unless ARX_SCORER_F32 is set (read once)
 // ... and the two bit-operand products of its backward (three MFMAs per term: the 0/1 operand is exact in bf16)
 size_t gemm_bits_bx3_planes_bytes(int64_t N, int64_t rowsB);
 bool gemm_bits_bx3_supported(int transA, int64_t M, int64_t N, int64_t K, int64_t ldb);

@@ -11,7 +11,11 @@ target gathers (one-hot + multi-hot segment-mean) -> scorer GEMM -> target score
 fwd+bwd -> backward GEMMs -> sparse scatter + Adagrad on every table.  Inputs are
 device-resident before timing.
 
-  python bench.py --gpus N --steps K --warmup W      (N>1 via torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 without WORLD_SIZE in the environment: bench.py launches its own N ranks (re-exec through
+      torch.distributed.run on 127.0.0.1); under torch.distributed.run (WORLD_SIZE set) it is one rank.
+      N > 1 runs BASELINE configs[4] (C5: 100 M-item table row-sharded, arx.dist.ShardedHMF) and carries
+      "scaling_anchor": the SAME code path and table on one rank (also: --gpus 1 --workload c5).
 
 `value` times exactly K steps of the headline workload.  The same line carries
   "sub": C2 (configs[1], id-only), C3-MIX (one bag = id token + categories over ONE 1.1 M-row
@@ -41,6 +45,11 @@ import torch
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 FP32_MFMA_PEAK_TF = 157.3    # dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+BF16_MFMA_PEAK_TF = 2500.0   # dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16; MI355X_MICROARCH.md)
+# f32-equivalent ceilings of the bf16-pipe scorer: six bf16 MFMA terms per f32 product term (three where one operand
+# is the 0/1 activity matrix) -- `achieved` counts 2MNK f32 flops, so the peak is the bf16 peak over 6 (3)
+BX6_PEAK_TF = BF16_MFMA_PEAK_TF / 6.0
+BX3_PEAK_TF = BF16_MFMA_PEAK_TF / 3.0
 METRIC = "training interactions/sec + sampled-negatives/sec, dim-128, 1/2/4/8 MI355X"
 
 
@@ -51,10 +60,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16384,
                     help="interactions per step per GPU (SURVEY 8(d) throughput batches: 4096, 16384)")
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3mix"],
-                    help="headline workload (default c3 = BASELINE configs[2], HET layout)")
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3mix", "c5"],
+                    help="headline workload (default c3 = BASELINE configs[2], HET layout; c5 = configs[4] on ONE "
+                         "rank: the N = 1 anchor of the --gpus N curve)")
+    ap.add_argument("--no-anchor", action="store_true",
+                    help="N > 1: do not run the world-1 anchor of the same workload after the N-rank run")
     ap.add_argument("--mulhot", action="store_true", help="(compat) same as --workload c3")
-    ap.add_argument("--subs", default="c2,c3mix,c4,c4mce,k1,c5w1,c3_bf16pipe,c2_bf16pipe,c5w1_bf16pipe",
+    ap.add_argument("--subs", default="c2,c3mix,c4,c4mce,k1,c5w1,c3_f32mfma,c2_f32mfma",
                     help="comma list of sub-results besides the headline ('' = none)")
     ap.add_argument("--sub-steps", type=int, default=50)
     ap.add_argument("--repeats", type=int, default=5,
@@ -209,14 +221,15 @@ def kernel_rooflines(model, d):
             lat_.value, pool.value, pool.bias_value, te.value, te.bias_value, uid, ptr, items, i2s, bl.value,
             tgt.value, pred.act_bits, pred.gvec, pred.Ug, tgt.grad, lat_.grad, te.grad, bl.gscale, ws,
             mask_rows=bl.mask_rows), 50)
-        res['gemm_logits_hinge_fused'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9,
-                                              note="target score + scorer GEMM with hinge epilogue + row kernel")
+        res['gemm_logits_hinge_fused'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9, peak=BX6_PEAK_TF,
+                                              note="target score + scorer GEMM with hinge epilogue + row kernel "
+                                                   "(several launches: not a single-kernel roofline)")
         gU, gP = latent.alloc_grad(), pool.alloc_grad()
         t = _evt_time_ms(lambda: ops.gemm_bits(pred.act_bits, pool.value, gU, ws, beta=1.0, row_scale=pred.gvec), 50)
-        res['gemm_dU_bits'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9)
+        res['gemm_dU_bits'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9, peak=BX3_PEAK_TF)
         t = _evt_time_ms(lambda: ops.gemm_bits(pred.act_bits, pred.Ug, gP, ws, transA=True, gvec=pred.gvec,
                                                a_rowsum=pool.bias_grad), 50)
-        res['gemm_dI_bits'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9)
+        res['gemm_dI_bits'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9, peak=BX3_PEAK_TF)
     else:
         t = _evt_time_ms(lambda: ops.gemm(latent.value, pool.value, pred.value, ws, transB=True,
                                           col_bias=pool.bias_value), 50)
@@ -443,9 +456,12 @@ def run_hmf(args, name, steps, warmup, with_cpu=False):
         kr = kernel_rooflines(model, d)
         pmc, pmc_src = _load_pmc("%s_b%d" % (name, B))
         dom = max((k for k in kr if k.startswith('gemm')), key=lambda k: kr[k]['ms'])
+        peak = kr[dom].get('peak', FP32_MFMA_PEAK_TF)
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kr[dom]['tflops'],
-                           "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                           "frac": kr[dom]['tflops'] / FP32_MFMA_PEAK_TF,
+                           "peak": peak, "unit": "TFLOP/s", "frac": kr[dom]['tflops'] / peak,
+                           "peak_note": ("f32-equivalent flops (2MNK) against the dense bf16 MFMA peak over the number "
+                                         "of bf16 terms per f32 product term" if 'peak' in kr[dom] else
+                                         "f32-input MFMA peak"),
                            "traffic": ((pmc or {}).get(dom) or {}).get("traffic_bytes"),
                            "flops_per_launch": kr[dom]['flops'], "ms_per_launch": kr[dom]['ms']}
         k7 = kr['k7_step_fused']
@@ -580,7 +596,7 @@ def run_sharded_world1(args):
     a = copy.copy(args)
     a.n_items = 100000000
     a.steps, a.warmup = args.sub_steps, min(args.warmup, 10)
-    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(29600 + os.getpid() % 300)),
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(_free_port())),
                  ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
         os.environ.setdefault(k, v)
     try:
@@ -591,13 +607,16 @@ def run_sharded_world1(args):
     return {k: out[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "n_gpus", "config", "roofline")}
 
 
-def run_bf16pipe(args, workload):
-    """EXPERIMENT, reported beside the headline, never as it: the same workload with the scorer
-    on the bf16 matrix pipe -- f32 operands split exactly into three bf16 pieces, six (forward) / three (backward,
-    0/1 operand) MFMAs per product term, f32 accumulation; 'mw' forward fused (act bits instead of logits /
-    dlogits).  The switches are read once per process: a child process runs the workload."""
+DTYPE_DETAIL = ("f32 operands as 3 exact bf16 pieces, 6 bf16 MFMA terms (3 where one operand is the 0/1 activity "
+                "matrix), f32 accumulate; everything else f32 (gathers, loss, Adagrad)")
+
+
+def run_f32mfma(args, workload):
+    """The A/B reference beside the headline (VERDICT r3 ruling, item iv): the same workload with the scorer on the
+    f32-input MFMA kernels (logits GEMM, wave-per-row loss kernel over [B, S] logits, two f32 backward GEMMs) --
+    the default path of rounds 1-3.  The switch is read once per process: a child process runs the workload."""
     import subprocess
-    env = dict(os.environ, ARX_GEMM_BX6="1", ARX_MW_GEMM_FUSE="1")
+    env = dict(os.environ, ARX_SCORER_F32="1")
     sharded = workload == "c5w1"            # the world-1 sharded step: a sub-result of a (short) child run
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "c2" if sharded else workload,
            "--subs", "c5w1" if sharded else "", "--no-rooflines",
@@ -613,25 +632,125 @@ def run_bf16pipe(args, workload):
         j = j["sub"]["c5w1"]
         j.setdefault("steps", args.sub_steps)
     return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
-            "dtype": "f32 in / f32 accumulate; products as 6 (3 with the 0/1 operand) exact bf16 x bf16 MFMA terms",
-            "switches": "ARX_GEMM_BX6=1 ARX_MW_GEMM_FUSE=1 (off by default)",
-            "parity": "tests/test_bf16pipe_gpu.py: the kernel, whole-step and BASELINE-sized oracle tests at the same 1e-4; "
-                      "error of the split product against f64 measured a third of the f32-MFMA kernel's",
+            "dtype": "f32", "dtype_detail": "f32-input MFMA (v_mfma_f32_32x32x2_f32), f32 accumulate",
+            "switches": "ARX_SCORER_F32=1 (the default path of rounds 1-3)",
+            "parity": "tests/test_f32mfma_gpu.py re-runs the kernel, whole-step, sharded and BASELINE-sized oracle tests "
+                      "with the switch set, same 1e-4",
             "config": {k: j["config"][k] for k in ("workload", "final_loss", "ms_per_step_min", "ms_per_step_max")
                        if k in j["config"]}}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves -- a re-exec of this very
+    command line through torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1) -- and hand its exit
+    code back.  Rank 0 of the child job prints the ONE JSON line to our stdout (lstm/run.py:87,221-229 is the
+    reference's only notion of a device list; there the devices are TF towers of one process)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def scaling_anchor(args):
+    """The N = 1 point of the weak-scaling curve for an N > 1 line: the SAME sharded code path, table and per-GPU
+    batch on ONE rank, run by rank 0 in a child process once the N-rank job has released the GPUs."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME",
+                        "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE",
+                        "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE",
+                        "TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCHELASTIC_ERROR_FILE")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", "c5", "--subs", "",
+           "--no-cpu-baseline", "--no-rooflines", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--batch", str(args.batch), "--n-sampled", str(args.n_sampled), "--dim", str(args.dim),
+           "--n-items", str(args.n_items), "--n-users", str(args.n_users), "--n-resample", str(args.n_resample)]
+    if args.sharded_bags:
+        cmd.append("--sharded-bags")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900)
+    line = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    return {"value": j["value"], "unit": j["unit"], "n_gpus": 1, "ms_per_step": j["ms_per_step"],
+            "steps": j["steps"], "warmup": j["warmup"],
+            "what": "the same sharded step (arx.dist), table and per-GPU batch on ONE rank -- `python bench.py --gpus 1 "
+                    "--workload c5` -- run by rank 0 after the N-rank job; efficiency = value / (N * anchor value)"}
+
+
+def _print_line(out):
+    # RCCL prints its version banner through C stdio: flush it out first so that the JSON line is the LAST
+    # line on stdout
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
+
+
+def main_sharded(args, world, rank, local_rank):
+    """BASELINE configs[4] (C5) on `world` ranks: one JSON line from rank 0, with the N = 1 anchor beside it."""
+    import torch.distributed as dist
+    from arx import dist as arx_dist
+    if world == 1:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(_free_port())), ("RANK", "0"),
+                     ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+            os.environ.setdefault(k, v)
+    out = arx_dist.bench_run(args, world, rank, local_rank)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    if rank != 0:
+        return 0
+    out["dtype_detail"] = DTYPE_DETAIL
+    out["value_per_gpu"] = out["value"] / world
+    if world > 1 and not args.no_anchor:
+        torch.cuda.empty_cache()
+        try:
+            out["scaling_anchor"] = scaling_anchor(args)
+            out["scaling_efficiency_vs_anchor"] = out["value"] / (world * out["scaling_anchor"]["value"])
+        except Exception as e:
+            out["scaling_anchor"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    elif world == 1:
+        out["scaling_anchor"] = {"value": out["value"], "unit": out["unit"], "n_gpus": 1,
+                                 "ms_per_step": out["ms_per_step"], "what": "this line IS the anchor"}
+        if not args.no_cpu_baseline:
+            # the reference algorithm is dense over the whole table (full-table scorer GEMM, dense Adagrad):
+            # at 100 M items one step is ~100 GB of host traffic; the bounded sample runs it on a 1 M-item table
+            import copy
+            from arx.utils.synthetic import SyntheticHMF
+            a = copy.copy(args)
+            a.n_items = min(args.n_items, 1000000)
+            syn = SyntheticHMF(n_users=a.n_users, n_items=a.n_items, permute_logits=False, seed=0,
+                               zipf_items=a.zipf_items)
+            out["cpu_baseline"] = cpu_baseline(a, syn, "C5 (on a %d-item table)" % a.n_items)
+    _print_line(out)
+    return 0
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        return self_launch(args)
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if world > 1 or args.workload == "c5":
         if args.n_items is None:
             # configs[4]: 100 M-item dim-128 table, row-sharded (with --sharded-bags: 1 M items, 20 tokens each)
             args.n_items = 1000000 if args.sharded_bags else 100000000
-        from arx import dist as arx_dist
-        return arx_dist.bench_main(args, world, rank, local_rank)
+        return main_sharded(args, world, rank, local_rank)
     if args.n_items is None:
         args.n_items = 1000000
     if args.mulhot:
@@ -642,7 +761,7 @@ def main():
         "metric": METRIC, "value": head["value"], "unit": head["unit"], "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic", "config": head["config"],
+        "dtype_detail": DTYPE_DETAIL, "data": "synthetic", "config": head["config"],
     }
     for k in ("roofline", "roofline_hbm", "roofline_gather", "traffic_source", "kernels_ms", "kernels",
               "cpu_baseline"):
@@ -663,8 +782,8 @@ def main():
                     out["roofline_gather"]["past_llc"] = r
             elif s == "c5w1":
                 r = run_sharded_world1(args)
-            elif s.endswith("_bf16pipe") and (s[:-9] in WORKLOADS or s[:-9] == "c5w1"):
-                r = run_bf16pipe(args, s[:-9])
+            elif s.endswith("_f32mfma") and (s[:-8] in WORKLOADS or s[:-8] == "c5w1"):
+                r = run_f32mfma(args, s[:-8])
             else:
                 continue
             sub[s] = r
@@ -679,16 +798,9 @@ def main():
         syn = SyntheticHMF(n_users=args.n_users, n_items=args.n_items, permute_logits=False, seed=0,
                            zipf_items=args.zipf_items, **WORKLOADS[args.workload][1])
         out["cpu_baseline"] = cpu_baseline(args, syn, args.workload.upper())
-    # RCCL (the world-1 sharded sub-result) prints its version banner through C stdio: flush it out
-    # first so that the JSON line is the LAST line on stdout
-    sys.stdout.flush()
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    print(json.dumps(out), flush=True)
+    _print_line(out)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -1,0 +1,44 @@
+"""bench.py as the driver runs it: `python bench.py --gpus N` with no launcher around it must start its own N
+ranks and print ONE JSON line (VERDICT r3 "missing" #1).  The test box has one GPU: ARX_DIST_ONE_GPU=1 puts every
+rank on device 0 and ARX_DIST_BACKEND=gloo carries the collectives (host-staged) -- the N > 1 branches of the step,
+the launcher, the anchor child and the line are what is checked, not the numbers."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra, timeout=900, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert r.returncode == 0, (r.stdout.decode(errors="replace")[-2000:], r.stderr.decode(errors="replace")[-3000:])
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_bench_gpus2_self_launch_one_line(dev):
+    j = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--n-items", "2000000", "--n-users", "200000",
+                "--batch", "2048"], env_extra={"ARX_DIST_ONE_GPU": "1", "ARX_DIST_BACKEND": "gloo"})
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1
+    assert j["scaling"] == "weak" and j["unit"] == "interactions/s" and j["value"] > 0
+    assert j["dtype"] == "f32" and "bf16" in j["dtype_detail"]
+    assert j["config"]["global_batch"] == 2 * 2048
+    assert set(j["roofline_comm"]) >= {"all_gather_pool_blocks", "all_to_all_target_rows", "all_reduce_pool_grads"}
+    a = j["scaling_anchor"]
+    assert a["n_gpus"] == 1 and a["value"] > 0
+    assert j["value_per_gpu"] == pytest.approx(j["value"] / 2)
+
+
+def test_bench_c5_anchor_is_a_headline(dev):
+    j = _bench(["--gpus", "1", "--workload", "c5", "--steps", "3", "--warmup", "1", "--n-items", "2000000",
+                "--n-users", "200000", "--batch", "2048", "--no-cpu-baseline"])
+    assert j["n_gpus"] == 1 and j["value"] > 0 and "C5" in j["config"]["workload"]
+    assert j["scaling_anchor"]["value"] == j["value"]
