@@ -145,18 +145,19 @@ PROTOTYPES = {
     "arx_segment_pool_fwd": (cint, [f32p, i64, i32p, i64, i64, cint, f32p, f32p, i64, vp]),
     "arx_segment_pool_bwd": (cint, [f32p, i64, i32p, i64, i64, i64, cint, f32p, f32p, i64, f32p, i64, f32p, i64,
                                     f32p, vp]),
-    "arx_max_argmax": (cint, [f32p, i64, i64, i64, i64, cint, f32p, i32p, vp]),
+    "arx_max_argmax": (cint, [f32p, i64, i64, i64, i64, cint, f32p, i32p, vp, vp]),
+    "arx_reduce_scratch_bytes": (sz, []),
     "arx_gmax_residual_bwd": (cint, [f32p, i32p, f32p, i64, f32p, cint, f32p, f32p, f32p, i64, vp]),
     "arx_adagrad_dense": (cint, [f32p, f32p, f32p, i64, f32p, f32p, vp]),
     "arx_adagrad_dense_multi": (cint, [cint, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), f32p, f32p, vp]),
-    "arx_sq_norm_accum": (cint, [f32p, i64, cint, f32p, f32p, vp]),
+    "arx_sq_norm_accum": (cint, [f32p, i64, cint, f32p, f32p, vp, vp]),
     "arx_clip_coef": (cint, [f32p, f32, f32p, f32p, vp]),
     "arx_sq_norm_accum_multi": (cint, [cint, C.POINTER(vp), C.POINTER(i64), C.POINTER(cint), C.POINTER(vp),
-                                       f32p, vp]),
+                                       f32p, vp, vp]),
     "arx_sq_norm_clip_multi": (cint, [cint, C.POINTER(vp), C.POINTER(i64), C.POINTER(cint), C.POINTER(vp), cint,
-                                      f32p, C.c_float, f32p, f32p, vp]),
+                                      f32p, C.c_float, f32p, f32p, vp, vp]),
     "arx_merged_sq_norm": (cint, [i32p, i32p, f32p, i64, cint, f32p, i64, cint, cint, i64, f32p, cint,
-                                  i64, f32p, vp, sz, vp]),
+                                  i64, f32p, vp, sz, vp, vp]),
     "arx_fill_f32": (cint, [f32p, i64, f32, vp]),
     "arx_fill_i32": (cint, [i32p, i64, i32, vp]),
     "arx_fill_u8": (cint, [u8p, i64, cint, vp]),
@@ -213,7 +214,7 @@ _NO_CHECK = ("arx_last_error", "arx_version", "arx_csr_expand_workspace_bytes",
              "arx_col_sum_workspace_bytes",
              "arx_gemm_f32_workspace_bytes", "arx_sparse_adagrad_workspace_bytes",
              "arx_sample_wor_workspace_bytes", "arx_sample_wor_keys_workspace_bytes",
-             "arx_gemm_nt_bx6_workspace_bytes", "arx_gemm_bits_workspace_bytes")
+             "arx_gemm_nt_bx6_workspace_bytes", "arx_gemm_bits_workspace_bytes", "arx_reduce_scratch_bytes")
 
 
 def call(name, *args):

@@ -163,9 +163,10 @@ class HipBackend(object):
             cnts = self.__dict__.setdefault('_cnt', {})
             tabs = []
             for E, acc, bias, bacc in tables:
-                c = cnts.get(E.data_ptr())
+                ck = (E.data_ptr(), int(E.shape[0]))      # (E_item[:ni] and E_item share a pointer, not a row count)
+                c = cnts.get(ck)
                 if c is None:
-                    c = cnts[E.data_ptr()] = torch.zeros((E.shape[0],), dtype=torch.int32, device=dev)
+                    c = cnts[ck] = torch.zeros((E.shape[0],), dtype=torch.int32, device=dev)
                 tabs.append((E, acc, bias, bacc, c))
             args = ops.MultiCatArgs(tabs, [(t, None, r, b, c) for t, r, b, c in sites])
             n = max(args.total, 1)

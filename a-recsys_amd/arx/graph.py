@@ -293,7 +293,9 @@ class Prediction(Node):
             tok = self.rt.fork(0)
             # (its own workspace: this product runs on a forked stream next to the dU product, and on the bf16
             # pipe BOTH keep operand planes in their workspace)
-            ws2 = self.rt.__dict__.setdefault('_ws_bits_tn', ops.Workspace(self.rt.device))
+            ws2 = self.rt.__dict__.get('_ws_bits_tn')
+            if ws2 is None:
+                ws2 = self.rt._ws_bits_tn = ops.Workspace(self.rt.device)
             ops.gemm_bits(self.act_bits, self.Ug, gp, ws2, transA=True, beta=beta, gvec=self.gvec,
                           a_rowsum=pool.bias_grad)
             self.rt._pending.append(self.rt.end_fork(tok))
@@ -398,7 +400,7 @@ class GlobalMax(Node):
             tmp = self._tmp[:, :n]
             ops.gemm(lat.value, E[c0:c0 + n], tmp, self.rt.ws, transB=True,
                      col_bias=b[c0:c0 + n] if b is not None else None)
-            ops.max_argmax(tmp, c0, c0 == 0, self.best, self.best_idx)
+            ops.max_argmax(tmp, c0, c0 == 0, self.best, self.best_idx, scratch=self.rt.scratch)
 
     def backward(self):
         lat, vs = self.inputs[0], self.vstar
@@ -926,10 +928,12 @@ class Plan(object):
                         torch.cuda.current_stream().wait_event(ev)
                         self._mid_waited = True
                 rt._between_backward_gemms = _mid_wait
-            for n in reversed(self.order):
-                if n.requires_grad and n._grad_written:
-                    n.backward()
-            rt._between_backward_gemms = None
+            try:
+                for n in reversed(self.order):
+                    if n.requires_grad and n._grad_written:
+                        n.backward()
+            finally:
+                rt._between_backward_gemms = None     # (never leave a closure over this step's event behind)
             for t in rt._pending:
                 rt.join(t)
             rt._pending = []
@@ -1445,6 +1449,7 @@ class Runtime(object):
             device = torch.device('cuda', torch.cuda.current_device())
         self.device = torch.device(device)
         self.ws = ops.Workspace(self.device)
+        self.scratch = ops.new_reduce_scratch(self.device)     # this runtime's own reduce scratch (re-entrancy)
         self.nodes = []
         self.tables = {}
         self.dense = {}

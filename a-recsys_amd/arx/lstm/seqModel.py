@@ -522,7 +522,7 @@ class SeqModel(SeqBatching):
         # apart (un-merged concat); otherwise the steps are add_n'ed first
         X, Lx = (sp.C_steps, L) if others else (n.grad, 1)
         Xb, Lb = (sp.rs_steps, L) if others_b else (n.bias_grad, 1)
-        ops.merged_sq_norm(ks, ss, cs, f.table.E.shape[0], sq, rt.ws, X=X, d=d, L=Lx, step_stride=S * d,
+        ops.merged_sq_norm(ks, ss, cs, f.table.E.shape[0], sq, rt.ws, scratch=rt.scratch, X=X, d=d, L=Lx, step_stride=S * d,
                            Xb=Xb, Lb=Lb, stepb_stride=S)
 
     def _tiled(self, rs, L, tag, static=False):
@@ -611,19 +611,19 @@ class SeqModel(SeqBatching):
         if dp is None:
             # every plain tensor norm of the step + the clip coefficient: one launch (no fill, no clip_coef)
             ops.sq_norm_clip_multi(norms, sq, self.max_gradient_norm, rt.clip_coef_dev, self._gnorm,
-                                   init=not zeroed[0])
+                                   init=not zeroed[0], scratch=rt.scratch)
             return
         else:
             zero_sq()
             mine = [norms[i] for i in local]
             if mine:
-                ops.sq_norm_accum_multi(mine, sq)
+                ops.sq_norm_accum_multi(mine, sq, scratch=rt.scratch)
             dp.all_reduce_sum(sq)
             for n, sp, f in deferred:
                 self._shared_rows_norm(n, sp, f, sites_of, sq)
             rest = [e for i, e in enumerate(norms) if i not in set(local)]
             if rest:
-                ops.sq_norm_accum_multi(rest, sq)
+                ops.sq_norm_accum_multi(rest, sq, scratch=rt.scratch)
         ops.clip_coef(sq, self.max_gradient_norm, rt.clip_coef_dev, self._gnorm)
 
     # ---------------------------------------------------------------------- step

@@ -643,9 +643,29 @@ def segment_pool_bwd(scores, offs, W, mode, out, dout, dscores, gmax=None, resid
          _ld(dscores), _p(resid_rows), _stream())
 
 
-def max_argmax(x, col_base, first, best, best_idx):
+_reduce_scratch = {}
+
+
+def new_reduce_scratch(device):
+    """A zeroed arx_reduce_scratch_bytes() buffer: the caller-owned block partials + arrival ticket of the
+    deterministic one-launch reductions (norms, running arg-max).  Launches that may overlap on the GPU need
+    different buffers (a Runtime owns one); every call leaves it zeroed."""
+    return torch.zeros(int(_lib.lib.arx_reduce_scratch_bytes()), dtype=torch.uint8, device=device)
+
+
+def _rscratch(x, scratch):
+    """scratch given by the caller, else ONE buffer per device (fine for launches on one stream only)."""
+    if scratch is not None:
+        return _p(scratch)
+    s = _reduce_scratch.get(x.device)
+    if s is None:
+        s = _reduce_scratch[x.device] = new_reduce_scratch(x.device)
+    return _p(s)
+
+
+def max_argmax(x, col_base, first, best, best_idx, scratch=None):
     call("arx_max_argmax", _p(x), int(x.shape[0]), int(x.shape[1]), _ld(x), int(col_base), int(bool(first)),
-         _p(best), _p(best_idx), _stream())
+         _p(best), _p(best_idx), _rscratch(x, scratch), _stream())
 
 
 def gmax_residual_bwd(resid, idx, U, E_row, row_grad, bias_grad, dU):
@@ -671,12 +691,12 @@ def adagrad_dense_multi(params, lr_dev, gscale_dev=None):
         call("arx_adagrad_dense_multi", m, ws_, accs, gs, ns, _p(lr_dev), _p(gscale_dev), _stream())
 
 
-def sq_norm_accum(x, out_accum, d=1, row_scale=None, n=None):
+def sq_norm_accum(x, out_accum, d=1, row_scale=None, n=None, scratch=None):
     call("arx_sq_norm_accum", _p(x), int(x.numel() if n is None else n), int(d), _p(row_scale),
-         _p(out_accum), _stream())
+         _p(out_accum), _rscratch(x, scratch), _stream())
 
 
-def sq_norm_accum_multi(items, out_accum):
+def sq_norm_accum_multi(items, out_accum, scratch=None):
     """items: [(x, d, row_scale|None, n|None)]: out += sum over all of them, <= 8 per launch."""
     import ctypes as C
     for k in range(0, len(items), 8):
@@ -686,10 +706,10 @@ def sq_norm_accum_multi(items, out_accum):
         ns = (C.c_int64 * m)(*[int(g[0].numel() if g[3] is None else g[3]) for g in grp])
         ds = (C.c_int * m)(*[int(g[1]) for g in grp])
         rs = (C.c_void_p * m)(*[(_p(g[2]) or None) for g in grp])
-        call("arx_sq_norm_accum_multi", m, xs, ns, ds, rs, _p(out_accum), _stream())
+        call("arx_sq_norm_accum_multi", m, xs, ns, ds, rs, _p(out_accum), _rscratch(out_accum, scratch), _stream())
 
 
-def sq_norm_clip_multi(items, sqnorm, max_norm, coef_out, gnorm_out=None, init=True):
+def sq_norm_clip_multi(items, sqnorm, max_norm, coef_out, gnorm_out=None, init=True, scratch=None):
     """sq_norm_accum_multi + clip_coef in as few launches as tensors / 8: the LAST launch also forms
     coef = max_norm / max(||g||, max_norm) (arx_sq_norm_clip_multi); init: sqnorm is overwritten by the
     first launch instead of accumulated onto (no fill launch)."""
@@ -709,23 +729,23 @@ def sq_norm_clip_multi(items, sqnorm, max_norm, coef_out, gnorm_out=None, init=T
         first, last = gi == 0, gi == len(groups) - 1
         if last:
             call("arx_sq_norm_clip_multi", m, xs, ns, ds, rs, int(bool(init and first)), _p(sqnorm), float(max_norm),
-                 _p(coef_out), _p(gnorm_out), _stream())
+                 _p(coef_out), _p(gnorm_out), _rscratch(sqnorm, scratch), _stream())
         elif init and first:
             fill_f32(sqnorm, 0.0)
-            call("arx_sq_norm_accum_multi", m, xs, ns, ds, rs, _p(sqnorm), _stream())
+            call("arx_sq_norm_accum_multi", m, xs, ns, ds, rs, _p(sqnorm), _rscratch(sqnorm, scratch), _stream())
         else:
-            call("arx_sq_norm_accum_multi", m, xs, ns, ds, rs, _p(sqnorm), _stream())
+            call("arx_sq_norm_accum_multi", m, xs, ns, ds, rs, _p(sqnorm), _rscratch(sqnorm, scratch), _stream())
 
 
 def merged_sq_norm(keys, src, coef, table_rows, out_accum, ws, X=None, d=0, L=1, step_stride=0,
-                   Xb=None, Lb=1, stepb_stride=0, n=None):
+                   Xb=None, Lb=1, stepb_stride=0, n=None, scratch=None):
     """out += sum_t sum_rows ||sum_{c -> row} coef_c X_t[src_c]||^2 (+ the d = 1 analogue on Xb):
     the norm of a table gradient after merging contributions per table row."""
     n = int(keys.shape[0]) if n is None else int(n)
     wsp, wsn = ws.get(_lib.lib.arx_sparse_adagrad_workspace_bytes(n))
     call("arx_merged_sq_norm", _p(keys), _p(src), _p(coef), n, key_bits_for(table_rows),
          _p(X), int(X.stride(-2)) if X is not None else 0, int(d), int(L), int(step_stride),
-         _p(Xb), int(Lb), int(stepb_stride), _p(out_accum), wsp, wsn, _stream())
+         _p(Xb), int(Lb), int(stepb_stride), _p(out_accum), wsp, wsn, _rscratch(out_accum, scratch), _stream())
 
 
 def clip_coef(sqnorm, max_norm, coef_out, gnorm_out=None):

@@ -104,6 +104,10 @@ class DeviceSampler(object):
             return self._caps[n]
         N = int(self.w.numel())
         if self._npos is None:
+            # (set-up: one pass + host read) NaN / inf weights would collapse the cap's bisection to ~0 and
+            # the whole pool to one repeated item (advisor, round 3)
+            if not bool(torch.isfinite(self.w).all().item()) or bool((self.w < 0).any().item()):
+                raise ValueError("DeviceSampler: weights must be finite and >= 0")
             self._npos = int((self.w > 0).sum().item())
         if self._npos < n:
             raise ValueError("DeviceSampler.sample(%d): only %d items have a positive weight" % (n, self._npos))
@@ -144,7 +148,11 @@ class DeviceSampler(object):
             pos = torch.empty((m,), dtype=torch.int32, device=dev)
             self._ops.sample_wor(self.w, m, self.seed, self.counter, pos, self.ws, key_cap=self._cap_for(m),
                                  out_keys=keys[:m])
-            ids[:m] = self.items[pos.long()]
+            # a short capped draw (compact list overflow / fewer than m keys under the cap) leaves -1 positions:
+            # they stay (id -1, key +inf) instead of silently becoming items[-1] (advisor, round 3)
+            ok = pos >= 0
+            ids[:m] = torch.where(ok, self.items[pos.clamp(min=0).long()], torch.full_like(pos, -1))
+            keys[:m] = torch.where(ok, keys[:m], torch.full_like(keys[:m], float('inf')))
         self.counter += 1
         return ids, keys
 
@@ -156,7 +164,9 @@ class DeviceSampler(object):
         cap = self._cap_for(int(n))
         self._ops.sample_wor(self.w, n, self.seed, self.counter, pos, self.ws, key_cap=cap)
         self.counter += 1
-        ids = self.items[pos.long()]
+        # positions the capped race could not fill come back as -1: map them to id -1 (update_sampled_pool and
+        # draw_global_pool reject negative ids) instead of letting -1 index items[-1] (advisor, round 3)
+        ids = torch.where(pos >= 0, self.items[pos.clamp(min=0).long()], torch.full_like(pos, -1))
         if out is not None:
             out.copy_(ids)
             return out

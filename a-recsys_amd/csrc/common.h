@@ -134,6 +134,11 @@ int gemm_nt_hinge(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, 
 int gemm_nt_hinge_bx6(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                       const float* col_bias, const float* tscore, uint32_t* bits, int64_t ldbits, float* rs_part,
                       float* cnt_part, int* nsplit_out, uint16_t* planes, hipStream_t s);
+// Reduce scratch (arx_reduce_scratch_bytes): the caller's memory for the deterministic one-launch reductions
+// (norms, running arg-max) -- [0] arrival ticket (zero between calls), [64 ..) block partials.
+constexpr size_t kReduceScratchBytes = 64 + 512 * 16;
+inline unsigned int* reduce_scratch_ticket(void* p) { return reinterpret_cast<unsigned int*>(p); }
+inline float* reduce_scratch_f32(void* p) { return reinterpret_cast<float*>(reinterpret_cast<char*>(p) + 64); }
 bool bx6_enabled();      // true unless ARX_SCORER_F32 is set (read once)
 // ... and the two bit-operand products of its backward (three MFMAs per term: the 0/1 operand is exact in bf16)
 size_t gemm_bits_bx3_planes_bytes(int64_t N, int64_t rowsB);

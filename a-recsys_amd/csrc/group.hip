@@ -112,8 +112,10 @@ __global__ __launch_bounds__(kExtThreads) void k_runs_extract(const uint32_t* __
   reinterpret_cast<unsigned char*>(bm)[tid] = (unsigned char)mk;
   if (tid < 64) {                                        // the 64 positions behind the tile
     const int64_t q = t0 + kExtTile + tid;
-    const uint32_t kq = sk[min(q, n - 1)], kp = sk[min(q, n - 1) - (n > 1 ? 1 : 0)];
-    const bool mark = q >= n || kq >= sentinel || kq != kp;
+    // (n == 0 -- every lookup dropped -- : no probe at all, everything behind the tile is marked)
+    const int64_t qq = n > 0 ? min(q, n - 1) : 0;
+    const uint32_t kq = n > 0 ? sk[qq] : sentinel, kp = n > 1 ? sk[qq - (qq > 0 ? 1 : 0)] : kq;
+    const bool mark = q >= n || kq >= sentinel || (qq > 0 && kq != kp);
     const unsigned long long m2 = __ballot(mark);
     if (tid == 0) {
       bm[kExtTile / 32] = (uint32_t)m2;

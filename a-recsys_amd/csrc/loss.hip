@@ -792,6 +792,7 @@ __global__ void k_slot_map_set(int32_t* __restrict__ map, const int32_t* __restr
   const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (s >= S) return;
   const int id = ids[s];
+  if (id < 0) return;                      // (a short device draw marks its missing positions with -1)
   if (clear) map[id] = -1;
   else atomicMax(&map[id], (int32_t)s);  // duplicate ids: last slot wins (dict semantics)
   if (bits) {                              // the attached "in the pool?" bitmap follows the map

@@ -129,6 +129,9 @@ using namespace arx;
 
 extern "C" {
 
+size_t arx_reduce_scratch_bytes(void) { return arx::kReduceScratchBytes; }
+
+
 int arx_topk(const float* logits, int64_t ld, int64_t B, int64_t V, int k, float* values,
              int32_t* indices, void* stream) {
   ARX_CHECK_ARG(logits && indices, "arx_topk: null pointer");

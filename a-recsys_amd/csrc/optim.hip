@@ -795,9 +795,10 @@ __global__ __launch_bounds__(256) void k_adagrad_dense_multi(DenseSet ds, const 
 
 // Deterministic squared norm in ONE launch: per-block partials in fixed slots, then the block
 // that arrives last (ticket) adds them up in slot order.  float4 loads, 4 in flight per thread.
+static_assert(64 + 512 * 4 <= kReduceScratchBytes, "reduce scratch too small");
 constexpr int kNormBlocks = 512;     // fixed slots of block partials (combined in slot order: deterministic)
-static __device__ float g_norm_part[kNormBlocks];
-static __device__ unsigned int g_norm_ticket;
+// (round 4: block partials and the arrival ticket live in the CALLER's reduce scratch -- common.h reduce_scratch_* --
+// so that two launches on different streams cannot meet in library-owned memory)
 
 template <bool VEC>
 __global__ __launch_bounds__(1024) void k_sq_norm(const float* __restrict__ x, int64_t n, int d,
@@ -975,7 +976,6 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // each unrolled step (seqModel.py:180; embed_attribute.py:171,188: innerp = E . u^T is taken
 // over the WHOLE table and gathered afterwards, so pool items that share a row are summed
 // before the norm).  One sub-group of GS lanes per run head; Xb is the d = 1 bias analogue.
-static __device__ unsigned int g_merged_ticket;
 
 template <int GS>
 __global__ __launch_bounds__(256) void k_merged_sq_norm(
@@ -1655,7 +1655,7 @@ int arx_sparse_adagrad_ticket(float* E, float* acc, float* bias, float* bias_acc
 int arx_merged_sq_norm(const int32_t* keys, const int32_t* src, const float* coef, int64_t n,
                        int key_bits, const float* X, int64_t ldx, int d, int L, int64_t step_stride,
                        const float* Xb, int Lb, int64_t stepb_stride, float* out, void* workspace,
-                       size_t workspace_bytes, void* stream) {
+                       size_t workspace_bytes, void* scratch, void* stream) {
   ARX_CHECK_ARG(keys && src && coef && out, "arx_merged_sq_norm: null pointer");
   ARX_CHECK_ARG(X || Xb, "arx_merged_sq_norm: neither X nor Xb given");
   ARX_CHECK_ARG(!X || (d > 0 && ldx >= d && L > 0), "arx_merged_sq_norm: bad X shape");
@@ -1695,8 +1695,8 @@ int arx_merged_sq_norm(const int32_t* keys, const int32_t* src, const float* coe
   ARX_CHECK_ARG(blocks < (int64_t)0x7fffffff, "arx_merged_sq_norm: n too large");
   // block partials: the apply pass's scratch rows are free here (>= 4 * n bytes >= 4 * blocks)
   float* bpart = reinterpret_cast<float*>(base + w.off_scratch);
-  unsigned int* ticket = nullptr;
-  ARX_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ticket), HIP_SYMBOL(g_merged_ticket)));
+  ARX_CHECK_ARG(scratch, "arx_merged_sq_norm: reduce scratch is NULL (arx_reduce_scratch_bytes)");
+  unsigned int* ticket = reduce_scratch_ticket(scratch);
   k_merged_sq_norm<GS><<<(int)blocks, 256, 0, s>>>(keys_out, ssrc, scoef, n, n_dev, sentinel, X, ldx,
                                                     X ? d : 0, X ? L : 0, step_stride, Xb, Xb ? Lb : 0,
                                                     stepb_stride, bpart, ticket, out);
@@ -1866,13 +1866,12 @@ int arx_adagrad_dense_multi(int count, float* const* w, float* const* acc, const
 }
 
 int arx_sq_norm_accum(const float* x, int64_t n, int d, const float* row_scale, float* out_accum,
-                      void* stream) {
+                      void* scratch, void* stream) {
   ARX_CHECK_ARG(x && out_accum && d > 0, "arx_sq_norm_accum: bad argument");
+  ARX_CHECK_ARG(scratch, "arx_sq_norm_accum: reduce scratch is NULL (arx_reduce_scratch_bytes)");
   if (n <= 0) return ARX_OK;
-  float* part = nullptr;
-  unsigned int* ticket = nullptr;
-  ARX_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&part), HIP_SYMBOL(g_norm_part)));
-  ARX_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ticket), HIP_SYMBOL(g_norm_ticket)));
+  float* part = reduce_scratch_f32(scratch);
+  unsigned int* ticket = reduce_scratch_ticket(scratch);
   const bool vec = (n % 4 == 0) && (d % 4 == 0) && n < ((int64_t)1 << 31) &&
                    (reinterpret_cast<uintptr_t>(x) & 15) == 0;
   // few, fat blocks: the ticket atomics serialise at ~16 ns each (1024 blocks: 16 us, measured)
@@ -1892,14 +1891,13 @@ int arx_sq_norm_accum(const float* x, int64_t n, int d, const float* row_scale, 
 
 static int sq_norm_multi_impl(const char* who, int count, const float* const* x, const int64_t* n, const int* d,
                              const float* const* row_scale, float* out_accum, int init, float max_norm,
-                             float* coef_out, float* gnorm_out, void* stream) {
+                             float* coef_out, float* gnorm_out, void* scratch, void* stream) {
   (void)who;
   ARX_CHECK_ARG(count >= 1 && count <= 8, "arx_sq_norm_accum_multi / arx_sq_norm_clip_multi: 1..8 tensors");
   ARX_CHECK_ARG(x && n && d && out_accum, "arx_sq_norm_accum_multi / arx_sq_norm_clip_multi: null pointer");
-  float* part = nullptr;
-  unsigned int* ticket = nullptr;
-  ARX_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&part), HIP_SYMBOL(g_norm_part)));
-  ARX_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ticket), HIP_SYMBOL(g_norm_ticket)));
+  ARX_CHECK_ARG(scratch, "arx_sq_norm_accum_multi / arx_sq_norm_clip_multi: reduce scratch is NULL (arx_reduce_scratch_bytes)");
+  float* part = reduce_scratch_f32(scratch);
+  unsigned int* ticket = reduce_scratch_ticket(scratch);
   NormSet ns = {};
   int blocks = 0;
   // blocks per tensor: one per 8 K float4 per thread-row (32 KB), at most kNormBlocks / count -- the
@@ -1931,17 +1929,17 @@ static int sq_norm_multi_impl(const char* who, int count, const float* const* x,
 }
 
 int arx_sq_norm_accum_multi(int count, const float* const* x, const int64_t* n, const int* d,
-                            const float* const* row_scale, float* out_accum, void* stream) {
+                            const float* const* row_scale, float* out_accum, void* scratch, void* stream) {
   return sq_norm_multi_impl("arx_sq_norm_accum_multi", count, x, n, d, row_scale, out_accum, 0, 0.f, nullptr,
-                            nullptr, stream);
+                            nullptr, scratch, stream);
 }
 
 int arx_sq_norm_clip_multi(int count, const float* const* x, const int64_t* n, const int* d,
                            const float* const* row_scale, int init, float* sqnorm_out, float max_norm,
-                           float* coef_out, float* gnorm_out, void* stream) {
+                           float* coef_out, float* gnorm_out, void* scratch, void* stream) {
   ARX_CHECK_ARG(coef_out, "arx_sq_norm_clip_multi: null pointer");
   return sq_norm_multi_impl("arx_sq_norm_clip_multi", count, x, n, d, row_scale, sqnorm_out, init ? 1 : 0,
-                            max_norm, coef_out, gnorm_out, stream);
+                            max_norm, coef_out, gnorm_out, scratch, stream);
 }
 
 int arx_clip_coef(const float* sqnorm_dev, float max_norm, float* coef_out, float* gnorm_out,

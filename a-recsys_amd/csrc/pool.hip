@@ -85,13 +85,12 @@ __global__ __launch_bounds__(256) void k_segpool_bwd(const float* __restrict__ s
 // running (max, first arg-max) of a [rows, cols] block: per-block candidates in fixed slots, the
 // last-arriving block folds them in slot order into best[0] (value) / best_idx[0..1] (row, col)
 constexpr int kMaxBlocks = 256;
-static __device__ float g_mx_val[kMaxBlocks];
-static __device__ long long g_mx_pos[kMaxBlocks];
-static __device__ unsigned int g_mx_ticket;
+// block partials {value [kMaxBlocks], position [kMaxBlocks]} and the arrival ticket: the caller's reduce scratch
 
 __global__ __launch_bounds__(256) void k_max_argmax(const float* __restrict__ x, int64_t rows, int64_t cols,
                                                     int64_t ld, int64_t col_base, int first,
-                                                    float* __restrict__ best, int32_t* __restrict__ best_idx) {
+                                                    float* __restrict__ best, int32_t* __restrict__ best_idx,
+                                                    float* mx_val, long long* mx_pos, unsigned int* mx_ticket) {
   __shared__ float sv[256];
   __shared__ long long sp[256];
   __shared__ bool s_last;
@@ -121,12 +120,12 @@ __global__ __launch_bounds__(256) void k_max_argmax(const float* __restrict__ x,
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    __hip_atomic_store(&g_mx_val[blockIdx.x], sv[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&g_mx_pos[blockIdx.x], sp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&mx_val[blockIdx.x], sv[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&mx_pos[blockIdx.x], sp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
     __builtin_amdgcn_s_waitcnt(0);
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    s_last = (__hip_atomic_fetch_add(&g_mx_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+    s_last = (__hip_atomic_fetch_add(mx_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
               gridDim.x - 1);
   }
   __syncthreads();
@@ -134,14 +133,14 @@ __global__ __launch_bounds__(256) void k_max_argmax(const float* __restrict__ x,
   float v0 = first ? -INFINITY : best[0];
   long long p0 = first ? -1 : ((long long)best_idx[1] * rows + best_idx[0]);
   for (int b = 0; b < (int)gridDim.x; ++b) {
-    const float v = __hip_atomic_load(&g_mx_val[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long p = __hip_atomic_load(&g_mx_pos[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float v = __hip_atomic_load(&mx_val[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long p = __hip_atomic_load(&mx_pos[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p >= 0 && (v > v0 || (v == v0 && (p0 < 0 || p < p0)))) { v0 = v; p0 = p; }
   }
   best[0] = v0;
   best_idx[0] = (int32_t)(p0 % rows);
   best_idx[1] = (int32_t)(p0 / rows);
-  __hip_atomic_store(&g_mx_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(mx_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // the gradient that flows through score_max = reduce_max(innerp) lands on the arg-max element
@@ -194,12 +193,17 @@ int arx_segment_pool_bwd(const float* scores, int64_t lds, const int32_t* offs, 
 }
 
 int arx_max_argmax(const float* x, int64_t rows, int64_t cols, int64_t ld, int64_t col_base, int first,
-                   float* best, int32_t* best_idx, void* stream) {
+                   float* best, int32_t* best_idx, void* scratch, void* stream) {
   ARX_CHECK_ARG(x && best && best_idx && rows > 0 && cols > 0, "arx_max_argmax: bad argument");
+  ARX_CHECK_ARG(scratch, "arx_max_argmax: reduce scratch is NULL (arx_reduce_scratch_bytes)");
+  static_assert(64 + kMaxBlocks * 12 <= kReduceScratchBytes, "reduce scratch too small for k_max_argmax");
+  float* mx_val = reduce_scratch_f32(scratch);
+  long long* mx_pos = reinterpret_cast<long long*>(mx_val + kMaxBlocks);
   int64_t g = ceil_div(rows * cols, (int64_t)256 * 8);
   if (g > kMaxBlocks) g = kMaxBlocks;
   if (g < 1) g = 1;
-  k_max_argmax<<<(int)g, 256, 0, as_stream(stream)>>>(x, rows, cols, ld, col_base, first, best, best_idx);
+  k_max_argmax<<<(int)g, 256, 0, as_stream(stream)>>>(x, rows, cols, ld, col_base, first, best, best_idx, mx_val,
+                                                      mx_pos, reduce_scratch_ticket(scratch));
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

@@ -257,12 +257,10 @@ int arx_sample_wor_keys(const float* weights, int64_t n, int64_t S, uint64_t see
     if (g < 1) g = 1;
     k_race_compact<<<(int)g, 256, 0, s>>>(weights, n, seed, counter, key_cap, list, count);
     ARX_CHECK_LAUNCH();
-    static bool raised = false;
-    if (!raised) {
-      ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bitonic_take),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kCompactCap * 8));
-      raised = true;
-    }
+    // per call: the attribute is per device and the call is cheap (a process-wide flag broke the second GPU
+    // of a multi-device process -- advisor, round 3)
+    ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bitonic_take),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kCompactCap * 8));
     k_bitonic_take<<<1, 1024, (size_t)kCompactCap * 8, s>>>(list, count, S, out_idx, out_keys);
     ARX_CHECK_LAUNCH();
     return ARX_OK;

@@ -606,7 +606,8 @@ int arx_segment_pool_bwd(const float* scores, int64_t lds, const int32_t* offs, 
  * columns are col_base.. of a wider matrix: best[0] = value, best_idx = {row, global column};
  * first != 0 starts a new scan, otherwise the previous best takes part.  Deterministic. */
 int arx_max_argmax(const float* x, int64_t rows, int64_t cols, int64_t ld, int64_t col_base, int first,
-                   float* best, int32_t* best_idx, void* stream);
+                   float* best, int32_t* best_idx, void* scratch /* reduce scratch, see arx_reduce_scratch_bytes */,
+                   void* stream);
 /* row_grad[0..d) = resid * U[idx[0], :], bias_grad[0] = resid, dU[idx[0], :] += resid * E_row
  * (E_row = the table row idx[1], already gathered); bias_grad / dU nullable. */
 int arx_gmax_residual_bwd(const float* resid_dev, const int32_t* idx_dev, const float* U, int64_t ldu,
@@ -623,22 +624,24 @@ int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const flo
 int arx_adagrad_dense_multi(int count, float* const* w, float* const* acc, const float* const* g,
                             const int64_t* n, const float* lr_dev, const float* gscale_dev, void* stream);
 /* *out_accum += sum_i w_i * x_i^2 with w_i = row_scale ? row_scale[i / d] : 1.
- * NOT re-entrant across streams: the norm entry points (arx_sq_norm_accum[_multi], arx_sq_norm_clip_multi,
- * arx_merged_sq_norm) and arx_max_argmax keep their block partials and the arrival ticket of the
- * deterministic one-launch reduction in library-owned device memory -- two such launches that can overlap
- * on the GPU must be issued on ONE stream (a step's plan issues them on its main stream only). */
+ * Re-entrant (round 4): the deterministic one-launch reductions (arx_sq_norm_accum[_multi],
+ * arx_sq_norm_clip_multi, arx_merged_sq_norm, arx_max_argmax) keep their block partials and the arrival
+ * ticket in a CALLER-provided `scratch` of arx_reduce_scratch_bytes() bytes: zero it once after allocation,
+ * every call leaves it zeroed; launches that may overlap on the GPU (different streams, different models in
+ * one process) take different scratch buffers, launches on one stream may share one.  NULL is an error. */
+size_t arx_reduce_scratch_bytes(void);
 int arx_sq_norm_accum(const float* x, int64_t n, int d, const float* row_scale,
-                      float* out_accum, void* stream);
+                      float* out_accum, void* scratch, void* stream);
 /* the same accumulation over up to 8 tensors in one launch (the global norm of an LSTM step) */
 int arx_sq_norm_accum_multi(int count, const float* const* x, const int64_t* n, const int* d,
-                            const float* const* row_scale, float* out_accum, void* stream);
+                            const float* const* row_scale, float* out_accum, void* scratch, void* stream);
 /* arx_sq_norm_accum_multi and arx_clip_coef in ONE launch: the last-arriving workgroup, which already
  * combines the partial sums, also forms coef = max_norm / max(||g||, max_norm) and ||g||
  * (seqModel.py:179-180 clip_by_global_norm).  init != 0: *sqnorm_out = sum (no prior fill);
  * init == 0: accumulated onto *sqnorm_out first (norms of earlier launches). */
 int arx_sq_norm_clip_multi(int count, const float* const* x, const int64_t* n, const int* d,
                            const float* const* row_scale, int init, float* sqnorm_out, float max_norm,
-                           float* coef_out, float* gnorm_out, void* stream);
+                           float* coef_out, float* gnorm_out, void* scratch, void* stream);
 int arx_clip_coef(const float* sqnorm_dev, float max_norm, float* coef_out, float* gnorm_out,
                   void* stream);
 /* Norm of a table gradient AFTER summing the contributions that land on the same table row
@@ -651,7 +654,7 @@ int arx_clip_coef(const float* sqnorm_dev, float max_norm, float* coef_out, floa
 int arx_merged_sq_norm(const int32_t* keys, const int32_t* src, const float* coef, int64_t n,
                        int key_bits, const float* X, int64_t ldx, int d, int L, int64_t step_stride,
                        const float* Xb, int Lb, int64_t stepb_stride, float* out_accum,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       void* workspace, size_t workspace_bytes, void* scratch, void* stream);
 
 /* ---- small device utilities ------------------------------------------------ */
 int arx_fill_f32(float* p, int64_t n, float v, void* stream);

@@ -464,6 +464,50 @@ def test_sparse_adagrad(dev, d, n, Vf, hot):
     assert torch.equal(tE, tE2) and torch.equal(tacc, tacc2)
 
 
+def test_one_launch_reductions_are_reentrant_across_streams(dev):
+    """arx_sq_norm_clip_multi and arx_max_argmax on TWO streams at once: block partials and the
+    arrival ticket live in the caller's reduce scratch (arx_reduce_scratch_bytes), one per stream here, so the
+    launches cannot meet in library-owned memory.  Many rounds of overlapping launches with different data;
+    every result is checked, the norms bit for bit against a quiet single-stream run."""
+    from arx import ops
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    n = 1 << 20
+    xs = [torch.randn(n, device=dev, generator=g) * (1.0 + k) for k in range(2)]
+    ys = [torch.randn(4, n // 4, device=dev, generator=g) for _ in range(2)]
+    for k in range(2):
+        ys[k][k, 1000 + k] = 50.0 + k
+    sc = [ops.new_reduce_scratch(dev) for _ in range(2)]
+    quiet = []
+    for k in range(2):
+        sq, coef, gn = (torch.zeros(1, device=dev) for _ in range(3))
+        ops.sq_norm_clip_multi([(xs[k], 1, None, None)], sq, 5.0, coef, gn, scratch=sc[k])
+        quiet.append((float(sq.item()), float(coef.item())))
+        assert quiet[k][0] == pytest.approx(float((xs[k].double() ** 2).sum().item()), rel=1e-5)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    outs = [[(torch.zeros(1, device=dev), torch.zeros(1, device=dev), torch.zeros(1, device=dev),
+              torch.zeros(1, device=dev), torch.zeros(2, dtype=torch.int32, device=dev)) for _ in range(40)]
+            for _ in range(2)]
+    torch.cuda.synchronize()
+    for r in range(40):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                sq, coef, gn, best, bidx = outs[k][r]
+                ops.sq_norm_clip_multi([(xs[k], 1, None, None)], sq, 5.0, coef, gn, scratch=sc[k])
+                ops.max_argmax(ys[k], 0, True, best, bidx, scratch=sc[k])
+    torch.cuda.synchronize()
+    for k in range(2):
+        for sq, coef, gn, best, bidx in outs[k]:
+            assert (float(sq.item()), float(coef.item())) == quiet[k]
+            assert float(best.item()) == 50.0 + k and bidx.tolist() == [k, 1000 + k]
+        assert int(sc[k].view(torch.int32)[0].item()) == 0             # the ticket is back at zero
+    with pytest.raises(Exception):
+        from arx._lib import call
+        call("arx_max_argmax", ys[0].data_ptr(), 4, n // 4, n // 4, 0, 1, outs[0][0][3].data_ptr(),
+             outs[0][0][4].data_ptr(), None, None)                     # no scratch: an error, not a global
+
+
 def test_dense_adagrad_norm_clip(dev):
     from arx import ops
     import torch
