@@ -58,7 +58,6 @@ PROTOTYPES = {
     "arx_dot_score_bwd": (cint, [f32p, i64, f32p, i64, f32p, i64, cint, f32p, i64, cint, f32p, i64, vp]),
     "arx_gemm_f32_workspace_bytes": (sz, [i64, i64, i64]),
     "arx_gemm_nt_bx6_workspace_bytes": (sz, [i64, i64]),
-    "arx_gemm_bits_workspace_bytes": (sz, [cint, i64, i64, i64]),
     "arx_gemm_nt_bx6": (cint, [i64, i64, i64, f32p, i64, f32p, i64, f32p, f32p, i64, vp, sz, vp]),
     "arx_gemm_f32": (cint, [cint, cint, i64, i64, i64, f32, f32p, i64, f32p, i64, f32, f32p, i64,
                             f32p, vp, sz, vp]),
@@ -94,12 +93,17 @@ PROTOTYPES = {
     "arx_eval_warp_unmask": (cint, [f32p, i64, f32p, i64, f32p, cint, f32p, i32p, i32p, i32p, i32p, i64, i64,
                                     i64, f32p, vp]),
     "arx_eval_finish": (cint, [cint, f32p, f32p, f32p, i64, f32p, vp]),
-    "arx_mw_gemm_fused_workspace_bytes": (sz, [i64, i64]),
-    "arx_mw_gemm_fused_fwd": (cint, [f32p, i64, f32p, i64, f32p, f32p, i64, f32p, i64, cint, i32p, i32p, i32p,
-                                     i32p, i64, f32, f32p, i64, i64, f32p, f32p, vp, i64, f32p, f32p, i64, f32p,
-                                     i64, f32p, i64, f32p, i64, vp, sz, vp]),
-    "arx_gemm_bits_f32": (cint, [cint, i64, i64, i64, vp, i64, f32p, i64, f32, f32p, i64, f32p, f32p, f32p,
-                                 vp, sz, vp]),
+    "arx_mw_scorer_supported": (cint, [i64, i64, cint]),
+    "arx_mw_scorer_state_bytes": (sz, [i64, i64, cint]),
+    "arx_mw_scorer_state_layout": (cint, [i64, i64, cint, C.POINTER(i64)]),
+    "arx_mw_scorer_fwd": (cint, [f32p, i64, f32p, i64, f32p, f32p, i64, f32p, i64, cint, i32p, i32p, i32p, i32p,
+                                 i64, f32, f32p, i64, i64, f32p, f32p, f32p, i64, f32p, i64, f32p, i64, vp, sz, vp]),
+    "arx_mw_scorer_fwd_phases": (cint, [f32p, i64, f32p, i64, f32p, f32p, i64, f32p, i64, cint, i32p, i32p, i32p, i32p,
+                                        i64, f32, f32p, i64, i64, f32p, f32p, f32p, i64, f32p, i64, f32p, i64, vp, sz,
+                                        cint, vp]),
+    "arx_mw_scorer_bwd_du": (cint, [i64, i64, cint, vp, f32, f32p, i64, vp]),
+    "arx_mw_scorer_bwd_di_workspace_bytes": (sz, [i64, i64, cint, i64]),
+    "arx_mw_scorer_bwd_di": (cint, [i64, i64, cint, vp, i64, f32, f32p, i64, f32p, f32p, f32p, vp, sz, vp]),
     "arx_sample_wor_workspace_bytes": (sz, [i64]),
     "arx_sample_wor_keys_workspace_bytes": (sz, [i64, i64, f32]),
     "arx_sample_wor": (cint, [f32p, i64, i64, u64, u64, i32p, vp, sz, vp]),
@@ -214,7 +218,8 @@ _NO_CHECK = ("arx_last_error", "arx_version", "arx_csr_expand_workspace_bytes",
              "arx_col_sum_workspace_bytes",
              "arx_gemm_f32_workspace_bytes", "arx_sparse_adagrad_workspace_bytes",
              "arx_sample_wor_workspace_bytes", "arx_sample_wor_keys_workspace_bytes",
-             "arx_gemm_nt_bx6_workspace_bytes", "arx_gemm_bits_workspace_bytes", "arx_reduce_scratch_bytes")
+             "arx_gemm_nt_bx6_workspace_bytes", "arx_reduce_scratch_bytes", "arx_mw_scorer_supported",
+             "arx_mw_scorer_state_bytes", "arx_mw_scorer_bwd_di_workspace_bytes")
 
 
 def call(name, *args):

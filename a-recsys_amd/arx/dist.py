@@ -464,15 +464,10 @@ class ShardedHMF(object):
     def _fused_scorer(self):
         """True when the step takes the bf16-pipe scorer (switches on, shapes it supports); allocates its buffers."""
         ops_ = getattr(self.be, 'ops', None)          # (the numpy test double has no kernels to pick from)
-        if ops_ is None or ops_.SCORER_F32 or self.d not in (64, 128) \
-                or self.S % 128 != 0 or self.B_loc % 32 != 0 or self.B_loc < 64:
+        if ops_ is None or not ops_.mw_scorer_supported(self.B_loc, self.S, self.d):
             return False
-        if getattr(self, 'act_bits', None) is None:
-            dev = self.device
-            self.act_bits = torch.zeros((self.S // 32, self.B_loc), dtype=torch.int32, device=dev)
-            self.gvec = torch.zeros((self.B_loc,), dtype=torch.float32, device=dev)
-            self.Ug = torch.zeros((self.B_loc, self.d), dtype=torch.float32, device=dev)
-            self.be.ws_k7b = self.be.ops.Workspace(dev)
+        if getattr(self, 'scorer', None) is None:
+            self.scorer = ops_.MwScorer(self.B_loc, self.S, self.d, self.device)
         return True
 
     @property
@@ -572,10 +567,9 @@ class ShardedHMF(object):
         def loss():
             dt = arena_b[B_loc + Sg:B_loc + Sg + B_loc] if W == 1 else dT[:, d]
             if fused:
-                be.ops.mw_gemm_fused_fwd(self.U_loc, self.I_all[:, :d], self.b_all, self.T_pack[:, :d],
-                                         self.T_pack[:, d], urows, self.pos_ptr, self.pos_items, self.item2slot,
-                                         self.bl, self.t_loc, self.act_bits, self.gvec, self.Ug, dt, dU, dT[:, :d],
-                                         1.0 / B, be.ws)
+                self.scorer.fwd(self.U_loc, self.I_all[:, :d], self.b_all, self.T_pack[:, :d], self.T_pack[:, d],
+                                urows, self.pos_ptr, self.pos_items, self.item2slot, self.bl, self.t_loc, dt, dU,
+                                dT[:, :d], 1.0 / B)
                 return
             be.loss_mw_fused_pos(self.logits, self.U_loc, self.T_pack[:, :d], self.T_pack[:, d], urows,
                                  self.pos_ptr, self.pos_items, self.item2slot, self.bl, self.dlogits,
@@ -583,13 +577,11 @@ class ShardedHMF(object):
 
         def bwd_gemms():
             if fused:
-                be.ops.gemm_bits(self.act_bits, self.I_all[:, :d], dU, be.ws, beta=1.0, row_scale=self.gvec)
+                self.scorer.bwd_dU(dU, beta=1.0)
                 if W == 1:
-                    be.ops.gemm_bits(self.act_bits, self.Ug, arena[B_loc:B_loc + S, :d], be.ws_k7b, transA=True,
-                                     gvec=self.gvec, a_rowsum=arena_b[B_loc:B_loc + S])
+                    self.scorer.bwd_dI(arena[B_loc:B_loc + S, :d], db=arena_b[B_loc:B_loc + S])
                     return
-                be.ops.gemm_bits(self.act_bits, self.Ug, self.dI_all[:S, :d], be.ws_k7b, transA=True, gvec=self.gvec,
-                                 a_rowsum=self.gb_all)
+                self.scorer.bwd_dI(self.dI_all[:S, :d], db=self.gb_all)
                 be.copy_strided(self.gb_all, self.dI_all[:S, d])
                 return
             be.gemm(self.dlogits, self.I_all[:, :d], dU, beta=1.0)

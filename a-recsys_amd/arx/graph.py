@@ -272,7 +272,7 @@ class Prediction(Node):
         # hinge in its epilogue (no [B, S] logits / dlogits in HBM); it leaves the 0/1 activity
         # matrix as bits, the row factors g and g * U here for the two backward products
         self.fused_into_loss = False
-        self.act_bits = self.gvec = self.Ug = None
+        self.scorer = None            # ops.MwScorer (its state holds the act bits, g and the operand planes)
 
     def forward(self, train):
         if self.fused_into_loss and train:
@@ -286,19 +286,14 @@ class Prediction(Node):
         latent, pool = self.inputs
         if latent.requires_grad:
             g = latent.alloc_grad()
-            ops.gemm_bits(self.act_bits, pool.value, g, self.rt.ws, beta=latent.grad_beta(), row_scale=self.gvec)
+            self.scorer.bwd_dU(g, beta=latent.grad_beta())
         if pool.train_tables:
             gp = pool.alloc_grad()
             beta = pool.grad_beta()
-            tok = self.rt.fork(0)
-            # (its own workspace: this product runs on a forked stream next to the dU product, and on the bf16
-            # pipe BOTH keep operand planes in their workspace)
-            ws2 = self.rt.__dict__.get('_ws_bits_tn')
-            if ws2 is None:
-                ws2 = self.rt._ws_bits_tn = ops.Workspace(self.rt.device)
-            ops.gemm_bits(self.act_bits, self.Ug, gp, ws2, transA=True, beta=beta, gvec=self.gvec,
-                          a_rowsum=pool.bias_grad)
-            self.rt._pending.append(self.rt.end_fork(tok))
+            hook = getattr(self.rt, '_between_backward_gemms', None)
+            if hook is not None:
+                hook()
+            self.scorer.bwd_dI(gp, db=pool.bias_grad, beta=beta)
             pool.bias_grad_used = True
 
     def backward(self):
@@ -535,9 +530,8 @@ class BatchLoss(Node):
                 target.fused_into_loss = True
                 # ... and, for the plain pool scorer, the GEMM itself moves in (hinge epilogue)
                 B_ = logits.shape[0]
-                if (kind == 'mw' and type(logits) is Prediction and logits.inputs[0] is lat and d in (64, 128)
-                        and W % 32 == 0 and B_ % 32 == 0 and B_ >= 64 and W >= 64
-                        and not ops.SCORER_F32):
+                if (kind == 'mw' and type(logits) is Prediction and logits.inputs[0] is lat
+                        and ops.mw_scorer_supported(B_, W, d)):
                     # DEFAULT since round 4 (ARX_SCORER_F32=1: logits GEMM + loss kernel + two f32 GEMMs): no
                     # [B, S] logits / dlogits in HBM, 2 MB of activity bits instead, and all three products on
                     # the bf16 matrix pipe, f32-exact (csrc/gemm_bx6.hip; C3 312 -> 260 us/step in round 3)
@@ -614,17 +608,14 @@ class BatchLoss(Node):
 
 
 def _bl_forward_gemm_fused(self, bl, rw, uid, ptr, items, i2s):
-    """scorer GEMM + target score + 'mw' loss fwd/bwd in three launches (arx_mw_gemm_fused_fwd)."""
+    """scorer GEMM + target score + 'mw' loss fwd/bwd in three launches (arx_mw_scorer_fwd)."""
     logits, target = self.inputs
     lat, te = target.inputs
     pool = logits.inputs[1]
     rt = self.rt
     B, S, d = logits.shape[0], logits.shape[1], lat.shape[1]
-    if logits.act_bits is None:
-        dev = rt.device
-        logits.act_bits = torch.zeros((S // 32, B), dtype=torch.int32, device=dev)      # word-major
-        logits.gvec = torch.empty((B,), dtype=torch.float32, device=dev)
-        logits.Ug = torch.empty((B, d), dtype=torch.float32, device=dev)
+    if logits.scorer is None:
+        logits.scorer = ops.MwScorer(B, S, d, rt.device)
     dt = target.alloc_grad()
     target.grad_beta()
     logits._grad_written = True                    # its backward consumes the bits
@@ -639,9 +630,8 @@ def _bl_forward_gemm_fused(self, bl, rw, uid, ptr, items, i2s):
         te.bias_grad_used = True
         if dt.data_ptr() != te.bias_grad.data_ptr():
             raise RuntimeError("target-score gradient is expected to alias the bias gradient rows")
-    ops.mw_gemm_fused_fwd(lat.value, pool.value, pool.bias_value, te.value, te.bias_value, uid, ptr, items, i2s,
-                          bl, target.value, logits.act_bits, logits.gvec, logits.Ug, dt, dU, dT, self.gscale,
-                          rt.ws, row_w=rw, mask_rows=self.mask_rows)
+    logits.scorer.fwd(lat.value, pool.value, pool.bias_value, te.value, te.bias_value, uid, ptr, items, i2s,
+                      bl, target.value, dt, dU, dT, self.gscale, row_w=rw, mask_rows=self.mask_rows)
 
 
 BatchLoss._forward_gemm_fused = _bl_forward_gemm_fused

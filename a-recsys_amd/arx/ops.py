@@ -402,31 +402,56 @@ def eval_finish(mode, acc0, acc1, tscore, out):
     call("arx_eval_finish", int(mode), _p(acc0), _p(acc1), _p(tscore), int(out.shape[0]), _p(out), _stream())
 
 
-def mw_gemm_fused_fwd(U, P, pbias, T, tbias, user_ids, pos_ptr, pos_items, item2slot, batch_loss, tscore_out,
-                      act_bits, g_out, Ug, dtscore, dU, dT, gscale, ws, row_w=None, mask_rows=0):
-    """'mw' with the hinge in the scorer GEMM's epilogue (arx_mw_gemm_fused_fwd): act bits instead
-    of logits / dlogits.  act_bits: int32 [S / 32, B] (word-major)."""
-    B, S = int(U.shape[0]), int(P.shape[0])
-    wsp, wsn = ws.get(_lib.lib.arx_mw_gemm_fused_workspace_bytes(B, S))
-    call("arx_mw_gemm_fused_fwd", _p(U), _ld(U), _p(P), _ld(P), _p(pbias), _p(T), _ld(T), _p(tbias),
-         int(tbias.stride(0)) if tbias is not None else 1, int(U.shape[1]), _p(user_ids), _p(pos_ptr),
-         _p(pos_items), _p(item2slot), int(mask_rows), float(gscale), _p(row_w), B, S, _p(batch_loss),
-         _p(tscore_out), _p(act_bits), int(act_bits.stride(0)), _p(g_out), _p(Ug), _ld(Ug), _p(dtscore),
-         int(dtscore.stride(0)) if dtscore is not None else 1, _p(dU), _ld(dU) if dU is not None else 0,
-         _p(dT), _ld(dT) if dT is not None else 0, wsp, wsn, _stream())
+def mw_scorer_supported(B, S, d):
+    """True when the fused 'mw' scorer (csrc/scorer.hip) takes this shape: d in {64, 128}, S % 128 == 0,
+    128 <= S <= 2048 -- and the process has not asked for the f32-MFMA reference (ARX_SCORER_F32)."""
+    return (not SCORER_F32) and bool(_lib.lib.arx_mw_scorer_supported(int(B), int(S), int(d)))
 
 
-def gemm_bits(bits, B, C, ws, transA=False, beta=0.0, row_scale=None, gvec=None, a_rowsum=None):
-    """C = beta C + [row_scale *] op(A) . B with A a 0/1 matrix given as bits (arx_gemm_bits_f32)."""
-    # bits: [cols / 32, rows] word-major; NN: rows = M, cols = K; TN: rows = K, cols = M
-    if transA:
-        K, M = int(bits.shape[1]), int(C.shape[0])
-    else:
-        M, K = int(bits.shape[1]), int(B.shape[0])
-    N = int(C.shape[1])
-    wsp, wsn = ws.get(_lib.lib.arx_gemm_bits_workspace_bytes(int(bool(transA)), M, N, K))
-    call("arx_gemm_bits_f32", int(bool(transA)), M, N, K, _p(bits), int(bits.stride(0)), _p(B), _ld(B),
-         float(beta), _p(C), _ld(C), _p(row_scale), _p(gvec), _p(a_rowsum), wsp, wsn, _stream())
+class MwScorer(object):
+    """The 'mw' scorer of a training step on the bf16 matrix pipe, f32-exact (include/arx.h, "a8-a11 fused"):
+    fwd() forms target score, act bits, loss and row factors without [B, S] logits; bwd_dU() / bwd_dI() are the two
+    backward products out of the bits.  Owns the caller-side state buffer (one per model and stream)."""
+
+    def __init__(self, B, S, d, device):
+        import ctypes as C
+        self.B, self.S, self.d = int(B), int(S), int(d)
+        n = int(_lib.lib.arx_mw_scorer_state_bytes(self.B, self.S, self.d))
+        if n == 0:
+            raise ValueError("MwScorer: shape not supported (B=%d, S=%d, d=%d)" % (B, S, d))
+        self.state = torch.zeros(n, dtype=torch.uint8, device=device)
+        lay = (C.c_int64 * 6)()
+        call("arx_mw_scorer_state_layout", self.B, self.S, self.d, lay)
+        self.Bp = int(lay[4])
+        ld, ldt = int(lay[1]), int(lay[5])
+        i32 = self.state.view(torch.int32)
+        self.act_bits = i32[lay[0] // 4: lay[0] // 4 + (self.S // 32) * ld].view(self.S // 32, ld)     # word-major
+        self.act_bits_t = i32[lay[2] // 4: lay[2] // 4 + (self.Bp // 32) * ldt].view(self.Bp // 32, ldt)[:, :self.S]
+        self.g = self.state.view(torch.float32)[lay[3] // 4: lay[3] // 4 + self.Bp]
+        self.ws = Workspace(device)
+
+    def fwd(self, U, P, pbias, T, tbias, user_ids, pos_ptr, pos_items, item2slot, batch_loss, tscore_out, dtscore,
+            dU, dT, gscale, row_w=None, mask_rows=0, phases=7):
+        """phases: 1 pool planes + hit lists, 2 hinge GEMM, 4 row kernel (arx_mw_scorer_fwd_phases)"""
+        call("arx_mw_scorer_fwd_phases", _p(U), _ld(U), _p(P), _ld(P), _p(pbias), _p(T), _ld(T), _p(tbias),
+             int(tbias.stride(0)) if tbias is not None else 1, self.d, _p(user_ids), _p(pos_ptr), _p(pos_items),
+             _p(item2slot), int(mask_rows), float(gscale), _p(row_w), self.B, self.S, _p(batch_loss), _p(tscore_out),
+             _p(dtscore), int(dtscore.stride(0)) if dtscore is not None else 1, _p(dU),
+             _ld(dU) if dU is not None else 0, _p(dT), _ld(dT) if dT is not None else 0, _p(self.state),
+             int(self.state.numel()), int(phases), _stream())
+
+    def bwd_dU(self, dU, beta=1.0):
+        """dU = beta dU + g * (act . P)"""
+        call("arx_mw_scorer_bwd_du", self.B, self.S, self.d, _p(self.state), float(beta), _p(dU), _ld(dU), _stream())
+
+    def bwd_dI(self, dI, db=None, beta=0.0, step_rows=0, dI_steps=None, db_steps=None):
+        """dI = beta dI + act^T . (g U), db = act^T . g; step_rows > 0: the per-time-step products too."""
+        wsp, wsn = (None, 0)
+        if dI_steps is None:
+            wsp, wsn = self.ws.get(_lib.lib.arx_mw_scorer_bwd_di_workspace_bytes(self.B, self.S, self.d,
+                                                                                 int(step_rows)))
+        call("arx_mw_scorer_bwd_di", self.B, self.S, self.d, _p(self.state), int(step_rows), float(beta), _p(dI),
+             _ld(dI), _p(db), _p(dI_steps), _p(db_steps), wsp, wsn, _stream())
 
 
 def loss_warp_pos(logits, target, user_ids, pos_ptr, pos_items, item2slot, batch_loss, dlogits,

@@ -123,31 +123,12 @@ int gemm_nt_smallk(int64_t M, int64_t N, int64_t K, float alpha, const float* A,
                    const float* B, int64_t ldb, float* C, int64_t ldc, const float* col_bias,
                    hipStream_t s);
 
-// gemm_nt.hip: the same GEMM with the WMRB hinge epilogue -- act bits + per-(split, row) partial
-// sums instead of logits (see HingeOut); N % 32 == 0.
-int gemm_nt_hinge(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
-                  int64_t ldb, const float* col_bias, const float* tscore, uint32_t* bits,
-                  int64_t ldbits, float* rs_part, float* cnt_part, int* nsplit_out, hipStream_t s);
-
-// gemm_bx6.hip: the hinge GEMM on the bf16 pipe (f32-exact: three bf16 pieces per operand, six MFMAs per term);
-// planes: 3 * N * K bf16 of scratch; K in {64, 128}, N % 128 == 0.  EXPERIMENT (ARX_GEMM_BX6=1).
-int gemm_nt_hinge_bx6(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                      const float* col_bias, const float* tscore, uint32_t* bits, int64_t ldbits, float* rs_part,
-                      float* cnt_part, int* nsplit_out, uint16_t* planes, hipStream_t s);
 // Reduce scratch (arx_reduce_scratch_bytes): the caller's memory for the deterministic one-launch reductions
 // (norms, running arg-max) -- [0] arrival ticket (zero between calls), [64 ..) block partials.
 constexpr size_t kReduceScratchBytes = 64 + 512 * 16;
 inline unsigned int* reduce_scratch_ticket(void* p) { return reinterpret_cast<unsigned int*>(p); }
 inline float* reduce_scratch_f32(void* p) { return reinterpret_cast<float*>(reinterpret_cast<char*>(p) + 64); }
 bool bx6_enabled();      // true unless ARX_SCORER_F32 is set (read once)
-// ... and the two bit-operand products of its backward (three MFMAs per term: the 0/1 operand is exact in bf16)
-size_t gemm_bits_bx3_planes_bytes(int64_t N, int64_t rowsB);
-bool gemm_bits_bx3_supported(int transA, int64_t M, int64_t N, int64_t K, int64_t ldb);
-int gemm_bits_bx3_slices(int64_t M, int64_t K);
-int gemm_bits_bx3_launch(int transA, int64_t M, int64_t N, int64_t K, const uint32_t* bits, int64_t ldw,
-                         const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* row_scale,
-                         const float* gvec, float* part, float* rsp, int nsl, uint16_t* planes, hipStream_t s);
-
 // gemm_dma.hip: NN / TN GEMMs with N <= 128 (dU, dI): LDS-DMA streamed operands, dL read once.
 bool gemm_dma_supported(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,
                         int64_t lda, const float* B, int64_t ldb);
@@ -156,12 +137,6 @@ int gemm_dma_launch(int transA, int64_t M, int64_t N, int64_t K, float alpha, co
                     int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc,
                     const float* col_bias, float* partial, int bm, int splits, int64_t kchunk,
                     float* a_rowsum, float* rowsum_partial, hipStream_t s);
-
-// bit-matrix A operand (see k_gemm_dma_bits); same planning as gemm_dma_launch
-int gemm_dma_bits_launch(int transA, int64_t M, int64_t N, int64_t K, const uint32_t* bits, int64_t ldw,
-                         const float* B, int64_t ldb, float beta, float* C, int64_t ldc,
-                         const float* row_scale, const float* gvec, float* partial, int bm, int splits,
-                         int64_t kchunk, float* a_rowsum, float* rowsum_partial, hipStream_t s);
 
 // topk.hip: radix-select top-k of every row (k <= 1024); indices are offset by idx_base.
 int topk_select_launch(const float* logits, int64_t ld, int64_t B, int64_t V, int k, int32_t idx_base,

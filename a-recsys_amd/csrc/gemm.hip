@@ -525,80 +525,6 @@ int arx_gemm_f32_steps_tn(int64_t steps, int64_t M, int64_t N, int64_t Kb, const
   return ARX_OK;
 }
 
-size_t arx_gemm_bits_workspace_bytes(int transA, int64_t M, int64_t N, int64_t K) {
-  size_t need = arx_gemm_f32_workspace_bytes(M, N, K);
-  const size_t bx = gemm_bits_bx3_planes_bytes(N, K) +
-                    (transA ? (size_t)gemm_bits_bx3_slices(M, K) * ((size_t)M * N + M) * sizeof(float) : 0) + 256;
-  return need > bx ? need : bx;
-}
-
-int arx_gemm_bits_f32(int transA, int64_t M, int64_t N, int64_t K, const uint32_t* bits, int64_t ldw,
-                      const float* B, int64_t ldb, float beta, float* C, int64_t ldc,
-                      const float* row_scale, const float* gvec, float* a_rowsum, void* workspace,
-                      size_t workspace_bytes, void* stream) {
-  ARX_CHECK_ARG(bits && B && C, "arx_gemm_bits_f32: null pointer");
-  ARX_CHECK_ARG(M > 0 && N > 0 && K > 0, "arx_gemm_bits_f32: bad dimension");
-  ARX_CHECK_ARG(!transA || gvec, "arx_gemm_bits_f32: the transposed form needs gvec");
-  ARX_CHECK_ARG(transA || !a_rowsum, "arx_gemm_bits_f32: a_rowsum belongs to the transposed form");
-  const bool ok = N > 32 && N <= 128 && N % 4 == 0 && M >= 64 && M % 4 == 0 && K >= 64 && K % 32 == 0 &&
-                  (!transA || M % 32 == 0) && ldb % 4 == 0 && ldb >= N && ldc >= N &&
-                  ldw >= (transA ? K : M) && (reinterpret_cast<uintptr_t>(B) & 15) == 0 &&
-                  (reinterpret_cast<uintptr_t>(bits) & 3) == 0;
-  if (!ok) {
-    set_error("arx_gemm_bits_f32: shape not supported (32 < N <= 128, N %% 4, M >= 64, K %% 32, M %% 32 for the "
-              "transposed form)");
-    return ARX_EUNSUPPORTED;
-  }
-  hipStream_t s = as_stream(stream);
-  if (bx6_enabled() && gemm_bits_bx3_supported(transA, M, N, K, ldb) && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
-      ldc % 4 == 0) {
-    // EXPERIMENT (ARX_GEMM_BX6): the same products on the bf16 pipe -- workspace: planes | partials | row sums
-    const int nsl = transA ? gemm_bits_bx3_slices(M, K) : 1;
-    const size_t pb = gemm_bits_bx3_planes_bytes(N, K);
-    const size_t need = pb + (transA ? (size_t)nsl * ((size_t)M * N + M) * sizeof(float) : 0);
-    if (!workspace || workspace_bytes < need) {
-      set_error("arx_gemm_bits_f32: workspace too small (%zu < %zu)", workspace_bytes, need);
-      return ARX_EWORKSPACE;
-    }
-    uint16_t* planes = reinterpret_cast<uint16_t*>(workspace);
-    float* part = transA ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pb) : nullptr;
-    float* rsp = (transA && a_rowsum) ? part + (size_t)nsl * M * N : nullptr;
-    int rc = gemm_bits_bx3_launch(transA, M, N, K, bits, ldw, B, ldb, beta, C, ldc, row_scale, gvec, part, rsp, nsl,
-                                  planes, s);
-    if (rc) return rc;
-    if (transA) {
-      launch_splitk_reduce(part, nsl, M, N, 1.f, beta, C, ldc, nullptr, rsp, a_rowsum, s);
-      ARX_CHECK_LAUNCH();
-    }
-    return ARX_OK;
-  }
-  int bm, sp;
-  int64_t kc;
-  gemm_dma_plan(M, N, K, &bm, &sp, &kc);
-  if (!transA) {          // the row scale lives in the kernel's epilogue: no split-K
-    sp = 1;
-    kc = K;
-  }
-  float* part = nullptr;
-  float* rsp = nullptr;
-  if (sp > 1) {
-    const size_t need = (size_t)sp * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
-    if (!workspace || workspace_bytes < need) {
-      set_error("arx_gemm_bits_f32: workspace too small (%zu < %zu)", workspace_bytes, need);
-      return ARX_EWORKSPACE;
-    }
-    part = reinterpret_cast<float*>(workspace);
-    if (a_rowsum) rsp = part + (size_t)sp * (size_t)M * (size_t)N;
-  }
-  int rc = gemm_dma_bits_launch(transA, M, N, K, bits, ldw, B, ldb, beta, C, ldc, row_scale, gvec, part, bm,
-                                sp, kc, a_rowsum, rsp, s);
-  if (rc) return rc;
-  if (part) {
-    launch_splitk_reduce(part, sp, M, N, 1.f, beta, C, ldc, nullptr, rsp, a_rowsum, s);
-    ARX_CHECK_LAUNCH();
-  }
-  return ARX_OK;
-}
 
 int arx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                  const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,

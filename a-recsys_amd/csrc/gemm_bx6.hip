@@ -16,7 +16,8 @@
 //
 // Kernels:
 //   k_split3      f32 [R, K] -> bf16 planes [3][R][K]  (the small operand: the pool rows)
-//   k_nt_bx6      C[M, N] = A[M, K] . B[N, K]^T + bias[n], K = 64 | 128 (the logits GEMM): a wave keeps
+//   k_nt_bx6      C[M, N] = A[M, K] . B[N, K]^T + bias[n], K = 64 | 128 (the MATERIALISING logits GEMM of the losses
+//                 that need logits -- 'ce', 'warp', evaluation; the 'mw' training scorer is scorer.hip): a wave keeps
 //                 its 32 rows of A as bf16 pieces in registers for the whole kernel, the B planes stream
 //                 through LDS in tiles of 32 columns.
 #include <stdlib.h>
@@ -26,19 +27,6 @@
 namespace arx {
 
 namespace {
-
-// -DBX6_TRACE: cycle stamps of workgroup 7 (tools/bx6_trace.py), 256 events per wave
-#ifdef BX6_TRACE
-__device__ unsigned long long g_bx6_trace[12 * 256];
-#define BX6_T(ev_)                                                                                       \
-  if (blockIdx.x == 7 && (threadIdx.x & 63) == 0 && tcount < 256)                                        \
-    g_bx6_trace[(threadIdx.x >> 6) * 256 + tcount++] =                                                   \
-        ((unsigned long long)(ev_) << 56) | (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFFFull);
-#define BX6_TDECL int tcount = 0;
-#else
-#define BX6_T(ev_)
-#define BX6_TDECL
-#endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -272,471 +260,6 @@ __global__ __launch_bounds__(512) void k_nt_bx6(int64_t M, int64_t N, const floa
 #undef BX6_REP
 }
 
-// ---------------------------------------------------------------------------------------------
-// The same product with the WMRB hinge in the epilogue (gemm_nt.hip's gemm_nt_hinge on the bf16 pipe): no
-// logits leave the chip.  Per row r and 32-column tile: act = (x - t_r + 1 > 0) as one word of `bits`
-// (word-major: bits[tile * ldbits + r]), and the wave's running sums of act * (x - t_r + 1) and of act go
-// to rs_part / cnt_part [2][M] (one split per column phase).  Waves 0..3 compute, waves 4..7 only load
-// the B planes (there is nothing to store but 2 MB of bits).
-// ---------------------------------------------------------------------------------------------
-template <int KD>
-__global__ __launch_bounds__(512) void k_nt_hinge_bx6(int64_t M, int64_t N, const float* __restrict__ A, int64_t lda,
-                                                      const uint16_t* __restrict__ Bp, const float* __restrict__ bias,
-                                                      const float* __restrict__ tscore, uint32_t* __restrict__ bits,
-                                                      int64_t ldbits, float* __restrict__ rs_part,
-                                                      float* __restrict__ cnt_part) {
-  constexpr int NCP = 2;
-  constexpr int NCH = KD / 16;
-  constexpr int LDR = KD + kBxRowPad;
-  constexpr int TILE = 32 * LDR;
-  constexpr int BSLOT = NCP * 3 * TILE;
-  extern __shared__ uint16_t lds[];                // [2][NCP tiles][3 planes][32][LDR] bf16, then bias [N] f32
-  float* sbias = reinterpret_cast<float*>(lds + 2 * BSLOT);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = tid >> 6;
-  const int ntile = (int)(N / 32);
-  const int nstage = ntile / NCP;
-  const int64_t plane = N * (int64_t)KD;
-  const int64_t brow0 = (int64_t)blockIdx.x * 64;
-  const int rot = (int)(blockIdx.x % (unsigned)nstage);
-  for (int i = tid; i < N; i += 512) sbias[i] = bias ? bias[i] : 0.f;
-
-  if (wv < 4) {
-    const int rt = wv & 1, cp = wv >> 1;
-    const int lr = lane & 31, kg = lane >> 5;
-    const int64_t row = brow0 + rt * 32 + lr;
-    const bool ok = row < M;
-    bf16x8 a1[NCH], a2[NCH], a3[NCH];
-    {
-      const float* ap = A + (ok ? row : 0) * lda + 8 * kg;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-        if (ok) {
-          v0 = *reinterpret_cast<const float4*>(ap + 16 * c);
-          v1 = *reinterpret_cast<const float4*>(ap + 16 * c + 4);
-        }
-        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        uint32_t p1[8], p2[8], p3[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) split3(x[e], p1[e], p2[e], p3[e]);
-        uint4 q1 = make_uint4(p1[0] | (p1[1] << 16), p1[2] | (p1[3] << 16), p1[4] | (p1[5] << 16), p1[6] | (p1[7] << 16));
-        uint4 q2 = make_uint4(p2[0] | (p2[1] << 16), p2[2] | (p2[3] << 16), p2[4] | (p2[5] << 16), p2[6] | (p2[7] << 16));
-        uint4 q3 = make_uint4(p3[0] | (p3[1] << 16), p3[2] | (p3[3] << 16), p3[4] | (p3[5] << 16), p3[6] | (p3[7] << 16));
-        a1[c] = __builtin_bit_cast(bf16x8, q1);
-        a2[c] = __builtin_bit_cast(bf16x8, q2);
-        a3[c] = __builtin_bit_cast(bf16x8, q3);
-      }
-    }
-    const float tm1 = (ok ? tscore[row] : 0.f) - 1.f;         // v = x - (t - 1)
-    float rs = 0.f, cnt = 0.f;
-    __syncthreads();                                         // B stage 0 and the bias are in LDS
-    for (int st = 0; st < nstage; ++st) {
-      const int slot = st & 1;
-      const int cur = st + rot < nstage ? st + rot : st + rot - nstage;
-      const uint16_t* tb = lds + slot * BSLOT + (cp * 3) * TILE + lr * LDR + 8 * kg;
-      f32x16 hi = {0}, lo = {0};
-      uint4 f1 = *reinterpret_cast<const uint4*>(tb), f2 = *reinterpret_cast<const uint4*>(tb + TILE),
-            f3 = *reinterpret_cast<const uint4*>(tb + 2 * TILE);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, f1), b2 = __builtin_bit_cast(bf16x8, f2),
-                     b3 = __builtin_bit_cast(bf16x8, f3);
-        if (c + 1 < NCH) {
-          f1 = *reinterpret_cast<const uint4*>(tb + 16 * (c + 1));
-          f2 = *reinterpret_cast<const uint4*>(tb + TILE + 16 * (c + 1));
-          f3 = *reinterpret_cast<const uint4*>(tb + 2 * TILE + 16 * (c + 1));
-        }
-        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, a1[c], lo, 0, 0, 0);
-        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a3[c], lo, 0, 0, 0);
-        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a2[c], lo, 0, 0, 0);
-        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a1[c], lo, 0, 0, 0);
-        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a2[c], lo, 0, 0, 0);
-        hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1[c], hi, 0, 0, 0);
-      }
-      // hinge: lane = row lr, columns 8 g + 4 kg + e of the tile
-      const int tile = NCP * cur + cp;
-      const float* bt = sbias + tile * 32 + 4 * kg;
-      uint32_t w = 0u;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bv = *reinterpret_cast<const float4*>(bt + 8 * g);
-        const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = hi[4 * g + e] + lo[4 * g + e] + bvv[e] - tm1;
-          const bool act = v > 0.f;
-          w |= act ? (1u << (8 * g + 4 * kg + e)) : 0u;
-          rs += act ? v : 0.f;
-          cnt += act ? 1.f : 0.f;
-        }
-      }
-      w |= (uint32_t)__shfl_xor((int)w, 32, 64);
-      if (kg == 0 && ok) bits[(int64_t)tile * ldbits + row] = w;
-      __syncthreads();
-    }
-    rs += __shfl_xor(rs, 32, 64);
-    cnt += __shfl_xor(cnt, 32, 64);
-    if (kg == 0 && ok) {
-      rs_part[(int64_t)cp * M + row] = rs;
-      cnt_part[(int64_t)cp * M + row] = cnt;
-    }
-    return;
-  }
-
-  // loaders: the next stage's B planes, global -> registers -> LDS
-  const int mt = tid - 256;
-  constexpr int RPP = 256 / (KD / 8);
-  constexpr int HP = NCP * 32 / RPP;
-  constexpr int PER = 3 * HP;
-  const int k8 = mt % (KD / 8), rl = mt / (KD / 8);
-  const uint16_t* gsrc = Bp + (int64_t)rl * KD + 8 * k8;
-  uint16_t* ldst = lds + ((rl / 32) * 3) * TILE + (rl % 32) * LDR + 8 * k8;
-  uint4 nb[PER];
-#define BX6_LOAD(st_)                                                                                   \
-  _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                                     \
-    const int pl = j / HP, h = j % HP;                                                                   \
-    nb[j] = *reinterpret_cast<const uint4*>(gsrc + pl * plane + ((int64_t)(st_) * NCP * 32 + h * RPP) * KD); \
-  }
-#define BX6_STORE(slot_)                                                                                \
-  _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                                     \
-    const int pl = j / HP, h = j % HP;                                                                   \
-    const int t = (h * RPP) / 32, r = RPP <= 32 ? (h * RPP) % 32 : 0;                                    \
-    *reinterpret_cast<uint4*>(ldst + (slot_) * BSLOT + (t * 3 + pl) * TILE + r * LDR) = nb[j];           \
-  }
-  BX6_LOAD(rot)
-  BX6_STORE(0)
-  __syncthreads();
-  for (int st = 0; st < nstage; ++st) {
-    const int cur = st + rot < nstage ? st + rot : st + rot - nstage;
-    const int nxt = cur + 1 < nstage ? cur + 1 : 0;
-    BX6_LOAD(nxt)
-    BX6_STORE((st + 1) & 1)
-    __syncthreads();
-  }
-#undef BX6_LOAD
-#undef BX6_STORE
-}
-
-// ---------------------------------------------------------------------------------------------
-// Backward products of the fused 'mw' scorer on the bf16 pipe: the A operand is the 0/1 activity matrix
-// (act bits of k_nt_hinge_bx6 -- EXACT in one bf16 piece), the B operand an f32 matrix in three bf16
-// pieces: three MFMAs per term.
-//   NN (TN = false):  C[m, :] = beta C[m, :] + g[m] * sum_k act[m][k] P[k, :]        dU += g (act . P)
-//   TN (TN = true):   part[slice][m, :] = sum_{k in slice} act[k][m] Ug[k, :],       dI = act^T . (g U)
-//                     rsp[slice][m] = sum_{k in slice} act[k][m] g[k]                (bias gradient)
-// act[r][c] = bit (c & 31) of bits[(c >> 5) * ldw + r].  The f32 operand arrives as TRANSPOSED planes
-// XT[3][N][R] (k_split3_t), so that a lane's 8 k values are 16 contiguous bytes.  MFMA: first operand = XT rows
-// (D row = output column n), second operand = act (D column = output row m): a lane's registers 4 g .. 4 g + 3
-// are four consecutive output columns of one row -- 16-byte traffic on C.
-// 512 threads: waves 0..3 compute (wave = (m-tile of 32, half of the N columns)), waves 4..7 stream the
-// XT planes through LDS in stages of 64 k.
-// ---------------------------------------------------------------------------------------------
-// Workgroup barrier for the loader waves: LDS writes done, then s_barrier.  (__syncthreads() carries IR fences,
-// and a register array that lives ACROSS a fence is left in scratch by the compiler -- measured: 400 bytes of
-// private segment and a 3x slower kernel; with this form the staging registers stay registers.)
-__device__ __forceinline__ void bx_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__device__ __forceinline__ uint32_t bf16_pair01(uint32_t b0, uint32_t b1) {      // two bits -> two bf16 (0.0 / 1.0)
-  // 24-bit multiplies (full rate; a 32-bit v_mul_lo_u32 is quarter rate and made this expansion -- not the MFMAs,
-  // not LDS -- the bound of the kernel: 1 700 cycles per stage of 24 MFMAs)
-  return __umul24(b0, 0x3F80u) | (__umul24(b1, 0x3F80u) << 16);
-}
-
-template <int N, bool TN>
-__global__ __launch_bounds__(768) void k_bits_bx3(int64_t M, int64_t K, int64_t kc, const uint32_t* __restrict__ bits,
-                                                  int64_t ldw, const uint16_t* __restrict__ XT, int64_t xt_rows,
-                                                  float beta, float* __restrict__ C, int64_t ldc,
-                                                  const float* __restrict__ gvec, float* __restrict__ rsp) {
-  constexpr int LDR = 64 + 8;                      // LDS row: 64 k + pad (bf16)
-  constexpr int SLOT = 3 * N * LDR;                // bf16 per stage
-  extern __shared__ uint16_t lds[];                // [2][3 planes][N][LDR], then [2][192] words: the stage's act bits (+ g)
-  uint32_t* xw = reinterpret_cast<uint32_t*>(lds + 2 * SLOT);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = tid >> 6;
-  const int64_t mblocks = (M + 63) / 64;
-  const int64_t mb = TN ? (int64_t)blockIdx.x % mblocks : (int64_t)blockIdx.x;
-  const int64_t slice = TN ? (int64_t)blockIdx.x / mblocks : 0;
-  const int64_t k0 = slice * kc;
-  const int64_t kend = (k0 + kc < K) ? k0 + kc : K;
-  const int nstage = (int)((kend - k0) / 64);
-  const int64_t plane = (int64_t)N * xt_rows;
-
-  if (wv < 4) {
-    // N = 128: wave w owns n-tile w and BOTH m-tiles of the block -- a plane fragment read from LDS feeds two
-    // MFMAs (LDS bandwidth, not the matrix pipe, bounds this kernel); N = 64: wave = (n-tile w & 1, m-tile w >> 1).
-    constexpr int NMT = N == 128 ? 2 : 1;            // m-tiles per compute wave
-    const int nt = N == 128 ? wv : (wv & 1);
-    const int mt0 = N == 128 ? 0 : (wv >> 1);
-    const int lr = lane & 31, kg = lane >> 5;
-    f32x16 hi[NMT], lo[NMT];
-#pragma unroll
-    for (int t = 0; t < NMT; ++t) {
-      hi[t] = f32x16{0};
-      lo[t] = f32x16{0};
-    }
-    float rs[NMT];
-#pragma unroll
-    for (int t = 0; t < NMT; ++t) rs[t] = 0.f;
-    const bool do_rs = TN && nt == 0 && rsp != nullptr;
-    BX6_TDECL
-    BX6_T(1)
-    __syncthreads();                                         // stage 0 is in LDS
-    BX6_T(2)
-    for (int st = 0; st < nstage; ++st) {
-      const int slot = st & 1;
-      // this stage's activity bits (and row factors), staged in LDS by the loaders with the planes:
-      //   NN: xs[h * 64 + r] = word (kb / 32 + h) of row mb * 64 + r;  TN: xs[t * 64 + k] = word of m-tile t, row kb + k;
-      //   xs[128 + k] = g[kb + k]
-      const uint32_t* xs = xw + slot * 192;
-      uint32_t w_lo[NMT], w_hi[NMT];
-      uint4 bw[2][NMT][2];                            // TN: the 8 words of a chunk per m-tile, double-buffered
-      float4 gw[2][2];                                //     and the chunk's row factors
-      const uint32_t* bp = xs + mt0 * 64 + 8 * kg;
-      const float* gp = reinterpret_cast<const float*>(xs + 128) + 8 * kg;
-#define BX3_BITS(buf_, c_)                                                                              \
-  if (TN) {                                                                                             \
-    _Pragma("unroll") for (int t = 0; t < NMT; ++t) {                                                   \
-      bw[buf_][t][0] = *reinterpret_cast<const uint4*>(bp + t * 64 + 16 * (c_));                        \
-      bw[buf_][t][1] = *reinterpret_cast<const uint4*>(bp + t * 64 + 16 * (c_) + 4);                    \
-    }                                                                                                   \
-    if (do_rs) {                                                                                        \
-      gw[buf_][0] = *reinterpret_cast<const float4*>(gp + 16 * (c_));                                   \
-      gw[buf_][1] = *reinterpret_cast<const float4*>(gp + 16 * (c_) + 4);                               \
-    }                                                                                                   \
-  }
-      if (!TN) {
-#pragma unroll
-        for (int t = 0; t < NMT; ++t) {
-          w_lo[t] = xs[(mt0 + t) * 32 + lr];
-          w_hi[t] = xs[64 + (mt0 + t) * 32 + lr];
-        }
-      }
-      BX3_BITS(0, 0)
-      BX3_BITS(1, 1)
-      const uint16_t* tb = lds + slot * SLOT + (nt * 32 + lr) * LDR + 8 * kg;
-      uint4 fr[2][3];
-#define BX3_FRAGS(buf_, c_)                                                                             \
-  _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                      \
-      fr[buf_][pl] = *reinterpret_cast<const uint4*>(tb + pl * N * LDR + 16 * (c_));
-      // act fragment of m-tile t_, chunk c_ (NN: from the row's two words; TN: bit lr of the chunk's 8 words)
-#define BX3_ACT(dst_, t_, c_)                                                                           \
-  {                                                                                                     \
-    if (!TN) {                                                                                          \
-      const uint32_t b = (((c_) < 2 ? w_lo[t_] : w_hi[t_]) >> ((16 * (c_) + 8 * kg) & 31)) & 0xFFu;    \
-      dst_ = make_uint4(bf16_pair01(b & 1u, (b >> 1) & 1u), bf16_pair01((b >> 2) & 1u, (b >> 3) & 1u),  \
-                        bf16_pair01((b >> 4) & 1u, (b >> 5) & 1u), bf16_pair01((b >> 6) & 1u, (b >> 7) & 1u)); \
-    } else {                                                                                            \
-      const uint4 x = bw[(c_) & 1][t_][0], y = bw[(c_) & 1][t_][1];                                     \
-      const uint32_t e0 = (x.x >> lr) & 1u, e1 = (x.y >> lr) & 1u, e2 = (x.z >> lr) & 1u, e3 = (x.w >> lr) & 1u; \
-      const uint32_t e4 = (y.x >> lr) & 1u, e5 = (y.y >> lr) & 1u, e6 = (y.z >> lr) & 1u, e7 = (y.w >> lr) & 1u; \
-      dst_ = make_uint4(bf16_pair01(e0, e1), bf16_pair01(e2, e3), bf16_pair01(e4, e5), bf16_pair01(e6, e7)); \
-      if (do_rs) {                                                                                      \
-        const float4 ga = gw[(c_) & 1][0], gb = gw[(c_) & 1][1];                                        \
-        rs[t_] += (e0 ? ga.x : 0.f) + (e1 ? ga.y : 0.f) + (e2 ? ga.z : 0.f) + (e3 ? ga.w : 0.f) +       \
-                  (e4 ? gb.x : 0.f) + (e5 ? gb.y : 0.f) + (e6 ? gb.z : 0.f) + (e7 ? gb.w : 0.f);        \
-      }                                                                                                 \
-    }                                                                                                   \
-  }
-      BX3_FRAGS(0, 0)
-      uint4 ac[NMT], an[NMT];                         // act fragments of this chunk / the next one
-#pragma unroll
-      for (int t = 0; t < NMT; ++t) BX3_ACT(ac[t], t, 0)
-      // Software pipeline, per chunk c:  A: LDS requests for chunk c + 1 (planes) and c + 2 (TN bit words);
-      // B: the MFMAs of chunk c with the VALU expansion of chunk c + 1's act fragments BETWEEN them -- into other
-      // registers (an): written into the registers the running MFMAs still read, the expansion waits for them, and
-      // back-to-back MFMAs on one accumulator wait for each other (both measured: 1 700 cycles per stage of 24
-      // MFMAs).  Accumulators alternate so that dependent MFMAs are >= 3 apart.
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (c + 1 < 4) { BX3_FRAGS((c + 1) & 1, c + 1) }
-        __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 p1 = __builtin_bit_cast(bf16x8, fr[c & 1][0]);
-        const bf16x8 p2 = __builtin_bit_cast(bf16x8, fr[c & 1][1]);
-        const bf16x8 p3 = __builtin_bit_cast(bf16x8, fr[c & 1][2]);
-#pragma unroll
-        for (int t = 0; t < NMT; ++t)
-          lo[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, __builtin_bit_cast(bf16x8, ac[t]), lo[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NMT; ++t)
-          hi[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, __builtin_bit_cast(bf16x8, ac[t]), hi[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NMT; ++t)
-          lo[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, __builtin_bit_cast(bf16x8, ac[t]), lo[t], 0, 0, 0);
-        if (c + 1 < 4) {
-#pragma unroll
-          for (int t = 0; t < NMT; ++t) BX3_ACT(an[t], t, c + 1)
-        }
-        // interleave: one MFMA, then a share of the VALU work
-#pragma unroll
-        for (int i = 0; i < 3 * NMT; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, TN ? 12 : 7, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 2 < 4) { BX3_BITS(c & 1, c + 2) }             // (its buffer's words were consumed for chunk c)
-        if (c + 1 < 4) {
-#pragma unroll
-          for (int t = 0; t < NMT; ++t) ac[t] = an[t];
-        }
-      }
-#undef BX3_FRAGS
-#undef BX3_BITS
-#undef BX3_ACT
-      BX6_T(3)
-      __syncthreads();
-      BX6_T(4)
-    }
-    // epilogue: lane = output row m (one per m-tile), columns nt * 32 + 8 g + 4 kg + 0..3
-#pragma unroll
-    for (int t = 0; t < NMT; ++t) {
-      const int64_t m = mb * 64 + (mt0 + t) * 32 + lr;
-      const bool ok = m < M;
-      if (!TN) {
-        if (ok) {
-          const float gm = gvec ? gvec[m] : 1.f;
-          float* crow = C + m * ldc + nt * 32 + 4 * kg;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            float4* cp4 = reinterpret_cast<float4*>(crow + 8 * g);
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (beta != 0.f) {
-              o = *cp4;
-              o.x *= beta; o.y *= beta; o.z *= beta; o.w *= beta;
-            }
-            o.x += gm * (hi[t][4 * g] + lo[t][4 * g]);
-            o.y += gm * (hi[t][4 * g + 1] + lo[t][4 * g + 1]);
-            o.z += gm * (hi[t][4 * g + 2] + lo[t][4 * g + 2]);
-            o.w += gm * (hi[t][4 * g + 3] + lo[t][4 * g + 3]);
-            *cp4 = o;
-          }
-        }
-      } else {
-        if (ok) {
-          float* prow = C + (slice * M + m) * (int64_t)N + nt * 32 + 4 * kg;            // C = partials [slices][M][N]
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(prow + 8 * g) =
-                make_float4(hi[t][4 * g] + lo[t][4 * g], hi[t][4 * g + 1] + lo[t][4 * g + 1],
-                            hi[t][4 * g + 2] + lo[t][4 * g + 2], hi[t][4 * g + 3] + lo[t][4 * g + 3]);
-        }
-        if (do_rs) {
-          const float r = rs[t] + __shfl_xor(rs[t], 32, 64);
-          if (kg == 0 && ok) rsp[slice * M + m] = r;
-        }
-      }
-    }
-    return;
-  }
-
-  // loaders: TWO groups of four waves (768 threads per workgroup), group p streams the stages of parity p -- each stage's loads are issued two
-  // stages before its data is read (one stage in flight in registers, stored to the slot the compute waves
-  // have just left, while the other pair's stage is being read): the ~2 600-cycle trip to L2 is covered by
-  // two stage periods instead of one.  Thread -> (row nl = q / 8 of a pass of 32 rows, 16-byte piece q % 8);
-  // N / 32 passes per plane.  A register set is loaded and stored within ONE loop body (never carried over
-  // the back edge: such arrays stay in scratch).
-  const int pr = (wv - 4) >> 2;                      // group of four loader waves
-  const int lt = tid - 256 - 256 * pr;               // 0..255
-  constexpr int HP = N / 32;
-  constexpr int PER = 3 * HP;
-  const int k8 = lt & 7, nl = lt >> 3;
-  const uint16_t* gsrc = XT + (int64_t)nl * xt_rows + k0 + 8 * k8;
-  uint16_t* ldst = lds + nl * LDR + 8 * k8;
-  // ... and one word of the stage's act bits (threads < 128) or row factors (TN: threads 128..191) each
-  const uint32_t* xsrc = nullptr;                    // advances by xstep per stage
-  int64_t xstep = 0;
-  if (!TN) {
-    if (lt < 128 && mb * 64 + (lt & 63) < M) {
-      xsrc = bits + ((k0 >> 5) + (lt >> 6)) * ldw + mb * 64 + (lt & 63);
-      xstep = 2 * ldw;
-    }
-  } else {
-    if (lt < 128 && (mb * 2 + (lt >> 6)) * 32 < M) xsrc = bits + (mb * 2 + (lt >> 6)) * ldw + k0 + (lt & 63);
-    else if (lt >= 128 && lt < 192 && gvec) xsrc = reinterpret_cast<const uint32_t*>(gvec) + k0 + (lt - 128);
-    xstep = 64;
-  }
-  uint32_t xv = 0u;
-#define BX3_LOAD(st_)                                                                                   \
-  _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                                     \
-    const int pl = j / HP, h = j % HP;                                                                   \
-    nb[j] = *reinterpret_cast<const uint4*>(gsrc + pl * plane + (int64_t)(h * 32) * xt_rows + 64 * (int64_t)(st_)); \
-  }                                                                                                     \
-  xv = xsrc ? xsrc[(int64_t)(st_) * xstep] : 0u;
-#define BX3_STORE(slot_)                                                                                \
-  _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                                     \
-    const int pl = j / HP, h = j % HP;                                                                   \
-    *reinterpret_cast<uint4*>(ldst + (slot_) * SLOT + (pl * N + h * 32) * LDR) = nb[j];                  \
-  }                                                                                                     \
-  if (lt < 192) xw[(slot_) * 192 + lt] = xv;
-  // ONE code path for both pairs (two branches with an array each are merged by the compiler and the array
-  // lands in scratch): pair 1 runs one barrier phase behind pair 0.
-  //   pair 0: load 0, store -> B0 | load 2 .. E(0) store E(1) | load 4 .. E(2) store E(3) | ...
-  //   pair 1: load 1 -> B0, store, E(0)    | load 3 .. E(1) store E(2) | ...               | E(last)
-  const int last = nstage - 1;                       // (nstage is even and >= 2: K slices are multiples of 128)
-  uint4 nb[PER];                                     // (<= 12: a set of 24 stays in scratch)
-  BX3_LOAD((pr <= last ? pr : last))
-  if (pr == 1) bx_barrier();                                 // B0
-  BX3_STORE(pr)
-  if (pr == 0) bx_barrier();                                 // B0: stage 0 is in LDS
-  if (pr == 1) bx_barrier();                                 // E(0)
-  const int iters = nstage / 2 - pr;
-  BX6_TDECL
-  for (int it = 0; it < iters; ++it) {
-    const int sn = 2 * it + pr + 2;                          // the pair's next stage
-    BX6_T(5)
-    BX3_LOAD((sn <= last ? sn : last))
-    bx_barrier();                                            // end of stage sn - 2: slot pr is free
-    BX6_T(6)
-    BX3_STORE(pr)
-    BX6_T(7)
-    bx_barrier();                                            // end of stage sn - 1
-  }
-  if (pr == 1) bx_barrier();                                 // E(last)
-#undef BX3_LOAD
-#undef BX3_STORE
-}
-
-// f32 [R, N] (ld) -> TRANSPOSED bf16 planes [3][N][R]: the backward products' f32 operand (pool rows, g U)
-__global__ __launch_bounds__(256) void k_split3_t(const float* __restrict__ X, int64_t ldx, int64_t R, int N,
-                                                  uint16_t* __restrict__ planes) {
-  __shared__ float tile[64][65];
-  const int64_t r0 = (int64_t)blockIdx.x * 64;
-  const int n0 = blockIdx.y * 64;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 64 * 16; i += 256) {          // 64 rows x 16 float4
-    const int r = i >> 4, c4 = (i & 15) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r0 + r < R && n0 + c4 < N) v = *reinterpret_cast<const float4*>(X + (r0 + r) * ldx + n0 + c4);
-    tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
-  }
-  __syncthreads();
-  const int n = tid >> 2, q = tid & 3;                // column n, rows 16 q .. 16 q + 15
-  if (n0 + n >= N) return;
-  uint32_t w[3][8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    uint32_t a[3], b[3];
-    split3(tile[16 * q + 2 * e][n], a[0], a[1], a[2]);
-    split3(tile[16 * q + 2 * e + 1][n], b[0], b[1], b[2]);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) w[p][e] = a[p] | (b[p] << 16);
-  }
-  const int64_t plane = (int64_t)N * R;
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    uint16_t* dst = planes + p * plane + (int64_t)(n0 + n) * R + r0 + 16 * q;
-    if (r0 + 16 * q + 16 <= R) {
-      *reinterpret_cast<uint4*>(dst) = make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]);
-      *reinterpret_cast<uint4*>(dst + 8) = make_uint4(w[p][4], w[p][5], w[p][6], w[p][7]);
-    } else {
-      for (int e = 0; e < 16; ++e)
-        if (r0 + 16 * q + e < R) dst[e] = (uint16_t)(w[p][e >> 1] >> (16 * (e & 1)));
-    }
-  }
-}
-
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace
@@ -752,97 +275,11 @@ bool bx6_enabled() {
   return on;
 }
 
-// loss.hip (arx_mw_gemm_fused_fwd with ARX_GEMM_BX6): planes = 3 * N * K bf16 of scratch
-int gemm_nt_hinge_bx6(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                      const float* col_bias, const float* tscore, uint32_t* bits, int64_t ldbits, float* rs_part,
-                      float* cnt_part, int* nsplit_out, uint16_t* planes, hipStream_t s) {
-  if (!(K == 64 || K == 128) || (N % 128) || N > 2048 || (lda % 4) || (ldb % 4)) return ARX_EUNSUPPORTED;
-  {
-    int64_t g = ceil_div(N * (K / 4), 256);
-    k_split3<<<(int)g, 256, 0, s>>>(B, ldb, N, (int)K, planes);
-    ARX_CHECK_LAUNCH();
-  }
-  const int64_t nblk = ceil_div(M, 64);
-  const size_t lds = (size_t)2 * 2 * 3 * 32 * (K + kBxRowPad) * 2 + (size_t)N * 4;
-  static bool raised = false;
-  if (!raised) {
-    const int cap = 160 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_nt_hinge_bx6<128>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_nt_hinge_bx6<64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    raised = true;
-  }
-  *nsplit_out = 2;
-  if (K == 128)
-    k_nt_hinge_bx6<128><<<(int)nblk, 512, lds, s>>>(M, N, A, lda, planes, col_bias, tscore, bits, ldbits, rs_part, cnt_part);
-  else
-    k_nt_hinge_bx6<64><<<(int)nblk, 512, lds, s>>>(M, N, A, lda, planes, col_bias, tscore, bits, ldbits, rs_part, cnt_part);
-  ARX_CHECK_LAUNCH();
-  return ARX_OK;
-}
-
-// gemm.hip (arx_gemm_bits_f32 with ARX_GEMM_BX6): both bit-operand products on the bf16 pipe.  planes: 3 * N *
-// (transA ? K : K) ... = 3 * N * rows(B) bf16; part: [*nsl][M][N] (+ rsp [*nsl][M]) for the transposed form.
-size_t gemm_bits_bx3_planes_bytes(int64_t N, int64_t rowsB) { return align256((size_t)3 * N * rowsB * 2); }
-
-bool gemm_bits_bx3_supported(int transA, int64_t M, int64_t N, int64_t K, int64_t ldb) {
-  if (!(N == 64 || N == 128) || ldb % 4) return false;
-  if (!transA) return K % 128 == 0;                  // (an even number of 64-wide stages)
-  return M % 32 == 0 && K % 128 == 0;
-}
-
-int gemm_bits_bx3_slices(int64_t M, int64_t K) {       // K slices of the transposed form (multiples of 64)
-  const int64_t mblocks = (M + 63) / 64;
-  int64_t nsl = ((int64_t)cu_count() + mblocks - 1) / mblocks;
-  if (nsl < 1) nsl = 1;
-  int64_t kc = ((K + nsl - 1) / nsl + 127) / 128 * 128;
-  return (int)((K + kc - 1) / kc);
-}
-
-int gemm_bits_bx3_launch(int transA, int64_t M, int64_t N, int64_t K, const uint32_t* bits, int64_t ldw,
-                         const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* row_scale,
-                         const float* gvec, float* part, float* rsp, int nsl, uint16_t* planes, hipStream_t s) {
-  {
-    dim3 g((unsigned)ceil_div(K, 64), (unsigned)ceil_div(N, 64));
-    k_split3_t<<<g, 256, 0, s>>>(B, ldb, K, (int)N, planes);          // B [K, N] -> planes [3][N][K]
-    ARX_CHECK_LAUNCH();
-  }
-  static bool raised = false;
-  if (!raised) {
-    const int cap = 160 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bits_bx3<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bits_bx3<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bits_bx3<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bits_bx3<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    raised = true;
-  }
-  const size_t lds = (size_t)2 * 3 * N * (64 + 8) * 2 + 2 * 192 * 4;
-  const int64_t mblocks = ceil_div(M, 64);
-  if (!transA) {
-    if (N == 128)
-      k_bits_bx3<128, false><<<(int)mblocks, 768, lds, s>>>(M, K, K, bits, ldw, planes, K, beta, C, ldc, row_scale, nullptr);
-    else
-      k_bits_bx3<64, false><<<(int)mblocks, 768, lds, s>>>(M, K, K, bits, ldw, planes, K, beta, C, ldc, row_scale, nullptr);
-  } else {
-    const int64_t kc = ((K + nsl - 1) / nsl + 127) / 128 * 128;
-    const int64_t grid = mblocks * nsl;
-    if (N == 128)
-      k_bits_bx3<128, true><<<(int)grid, 768, lds, s>>>(M, K, kc, bits, ldw, planes, K, 0.f, part, N, gvec, rsp);
-    else
-      k_bits_bx3<64, true><<<(int)grid, 768, lds, s>>>(M, K, kc, bits, ldw, planes, K, 0.f, part, N, gvec, rsp);
-  }
-  ARX_CHECK_LAUNCH();
-  return ARX_OK;
-}
-
 }  // namespace arx
 
 using namespace arx;
 
 extern "C" {
-
-#ifdef BX6_TRACE
-int arx_bx6_trace_read(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bx6_trace), sizeof(g_bx6_trace)); }
-#endif
 
 size_t arx_gemm_nt_bx6_workspace_bytes(int64_t N, int64_t K) { return align256((size_t)3 * N * K * 2); }
 

@@ -271,220 +271,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// The same two GEMMs with the A operand given as BITS (the 0/1 hinge-activity matrix of the WMRB
-// loss, written by the scorer GEMM's epilogue: gemm_nt.hip HINGE), word-major: with r the batch row
-// and c the pool slot, act[r][c] = bit (c & 31) of bits[(c >> 5) * ldw + r].  NN form (dU):
-// A[m = r][k = c]; TN form (dI): A^T[m = c][k = r].  A K tile of 32 is ONE word per row / 32 words
-// per slot word, contiguous in memory in both forms, so the A side shrinks from 8-16 KB of LDS-DMA
-// per tile to one 256-byte dword DMA per wave (every wave fetches the words of its own rows: no
-// cross-wave dependency), expanded to 0.0 / 1.0 in registers; the 67 MB dlogits read of each GEMM
-// (B = 16384, S = 1024) becomes a 2 MB read served by L2.
-//   NN: C[m, :] = beta * C[m, :] + row_scale[m] * sum_k A[m][k] B[k, :]     (row_scale = g: dU)
-//   TN: C[m, :] = sum_k A^T[m][k] B[k, :],  a_rowsum[m] = sum_k A^T[m][k] gvec[k]   (B = g * U: dI)
-template <bool NTL>
-__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
-  const uint32_t dst = __builtin_amdgcn_readfirstlane(
-      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(dst)
-      : "memory");
-}
-
-template <bool A_KC, int BM, int kBN>
-__global__ __launch_bounds__(256, 2) void k_gemm_dma_bits(
-    int64_t M, int64_t N, int64_t K, const uint32_t* __restrict__ bits, int64_t ldw,
-    const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C, int64_t ldc,
-    const float* __restrict__ row_scale, const float* __restrict__ gvec, float* __restrict__ partial,
-    int64_t kchunk, float* __restrict__ a_rowsum, float* __restrict__ rowsum_partial) {
-  constexpr int FM = BM / 64;
-  constexpr int NPA = A_KC ? 1 : 2;           // word piece (+ g piece in the TN form)
-  constexpr int NPB = kBK * kBN / 4 / 256;
-  constexpr int FN = kBN / 64;
-  constexpr int STAGES = 3;                   // the A side needs 1-2 KB per stage: three stages always fit
-  constexpr int PD = STAGES - 1;
-  __shared__ __attribute__((aligned(1024))) uint32_t sW0[256];
-  __shared__ __attribute__((aligned(1024))) uint32_t sW1[256];
-  __shared__ __attribute__((aligned(1024))) uint32_t sW2[256];
-  __shared__ __attribute__((aligned(1024))) float sG0[256];
-  __shared__ __attribute__((aligned(1024))) float sG1[256];
-  __shared__ __attribute__((aligned(1024))) float sG2[256];
-  __shared__ __attribute__((aligned(1024))) float sB0[kBK * kBN];
-  __shared__ __attribute__((aligned(1024))) float sB1[kBK * kBN];
-  __shared__ __attribute__((aligned(1024))) float sB2[kBK * kBN];
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l31 = lane & 31, lhi = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  int bx = blockIdx.x, bz = blockIdx.z;
-  {
-    const int nx = gridDim.x, nz = gridDim.z;
-    if (nz > 1 && nz % 8 == 0) {              // M tiles of one K chunk on one XCD (see k_gemm_dma)
-      const int lin = bx + nx * bz;
-      const int xcd = lin & 7, slot = lin >> 3;
-      bz = xcd * (nz / 8) + slot / nx;
-      bx = slot % nx;
-    }
-  }
-  const int64_t m0 = (int64_t)bx * BM;
-  const int64_t kbeg = (int64_t)bz * kchunk;
-  const int64_t kend = min(K, kbeg + kchunk);
-  const int64_t nt = (kend - kbeg) / kBK;
-
-  auto dma = [&](int64_t t, uint32_t* imgW, float* imgG, float* imgB) {
-    const int64_t k0 = kbeg + t * kBK;
-    if (A_KC) {        // this wave's rows: one word (plane k0 >> 5) each, consecutive rows
-      const int64_t row = m0 + wm * (BM / 2) + (FM == 2 ? lane : l31);
-      glds4<false>(bits + (k0 >> 5) * ldw + min(row, M - 1), imgW + wave * 64);
-    } else {           // 32 k rows of the wave's FM word planes; the g values of the 32 k rows
-      const int64_t mw = min(m0 + wm * (BM / 2) + (FM == 2 ? lhi * 32 : 0), M - 1) >> 5;
-      glds4<false>(bits + mw * ldw + (k0 + l31), imgW + wave * 64);
-      glds4<false>(gvec + k0 + l31, imgG + wave * 64);
-    }
-#pragma unroll
-    for (int i = 0; i < NPB; ++i) {
-      const int f = threadIdx.x + i * 256;
-      const int k = f / (kBN / 4), nq = f % (kBN / 4);
-      const float* src = B + (k0 + k) * ldb + min((int64_t)nq * 4, N - 4);
-      glds16(src, imgB + (f - lane) * 4);
-    }
-  };
-
-  f32x16 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  float rsl[FM];
-#pragma unroll
-  for (int i = 0; i < FM; ++i) rsl[i] = 0.f;
-
-  auto tile = [&](int64_t t, const uint32_t* cW, const float* cG, const float* cB, uint32_t* nW, float* nG,
-                  float* nB) {
-    if (t + PD < nt) dma(t + PD, nW, nG, nB);
-    uint32_t wrow[FM];                       // NN: this lane's row word of the tile
-    if (A_KC) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i) wrow[i] = cW[wave * 64 + (FM == 2 ? i * 32 : 0) + l31];
-    }
-    auto load_ops = [&](int s, float (&av)[FM][4], float (&bv)[FN][4], float (&gk)[4]) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int kk = 8 * s + 4 * lhi + j;
-        if (A_KC) {
-#pragma unroll
-#ifdef ARX_BITS_EXP_CONST
-          for (int i = 0; i < FM; ++i) av[i][j] = 1.f;
-#else
-          for (int i = 0; i < FM; ++i) av[i][j] = ((wrow[i] >> kk) & 1u) ? 1.f : 0.f;
-#endif
-          gk[j] = 0.f;
-        } else {
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-            av[i][j] = ((cW[wave * 64 + (FM == 2 ? i * 32 : 0) + kk] >> l31) & 1u) ? 1.f : 0.f;
-          gk[j] = cG[wave * 64 + kk];
-        }
-      }
-#pragma unroll
-      for (int jn = 0; jn < FN; ++jn)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          bv[jn][j] = cB[(8 * s + 4 * lhi + j) * kBN + wn * (kBN / 2) + jn * 32 + l31];
-    };
-    float av[FM][4], bv[FN][4], gk[4];
-    load_ops(0, av, bv, gk);
-#pragma unroll
-    for (int s = 0; s < kBK / 8; ++s) {
-      float nav[FM][4], nbv[FN][4], ngk[4];
-      if (s + 1 < kBK / 8) load_ops(s + 1, nav, nbv, ngk);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!A_KC) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-          rsl[i] += (av[i][0] * gk[0] + av[i][1] * gk[1]) + (av[i][2] * gk[2] + av[i][3] * gk[3]);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int jn = 0; jn < FN; ++jn)
-            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j], bv[jn][j], acc[i][jn], 0, 0, 0);
-      if (s + 1 < kBK / 8) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) av[i][j] = nav[i][j];
-#pragma unroll
-        for (int jn = 0; jn < FN; ++jn)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bv[jn][j] = nbv[jn][j];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) gk[j] = ngk[j];
-      }
-    }
-    if (t + PD < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * (NPA + NPB)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
-
-  if (nt > 0) {
-    dma(0, sW0, sG0, sB0);
-    if (nt > 1) {
-      dma(1, sW1, sG1, sB1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPA + NPB) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    for (int64_t t = 0; t < nt; t += 3) {
-      tile(t, sW0, sG0, sB0, sW2, sG2, sB2);
-      if (t + 1 < nt) tile(t + 1, sW1, sG1, sB1, sW0, sG0, sB0);
-      if (t + 2 < nt) tile(t + 2, sW2, sG2, sB2, sW1, sG1, sB1);
-    }
-  }
-
-  if (!A_KC && a_rowsum) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const float tot = rsl[i] + __shfl_xor(rsl[i], 32, 64);     // the two k halves of the row
-      const int64_t row = m0 + wm * (BM / 2) + i * 32 + l31;
-      if (wn == 0 && lhi == 0 && row < M) {
-        if (rowsum_partial) rowsum_partial[(int64_t)bz * M + row] = tot;
-        else a_rowsum[row] = tot;
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int jn = 0; jn < FN; ++jn) {
-      const int64_t col = wn * (kBN / 2) + jn * 32 + l31;
-      if (col >= N) continue;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-        if (row >= M) continue;
-        float v = acc[i][jn][e];
-        if (partial) {
-          partial[((int64_t)bz * M + row) * N + col] = v;
-        } else {
-          if (row_scale) v *= row_scale[row];
-          if (beta != 0.f) v += beta * C[row * ldc + col];
-          C[row * ldc + col] = v;
-        }
-      }
-    }
-}
-
 }  // namespace
 
 // Shapes: op(B) n-contiguous (transB == 0), 4 <= N <= 128, N % 4 == 0, M % 4 == 0 (M >= 4),
@@ -553,29 +339,6 @@ int gemm_dma_launch(int transA, int64_t M, int64_t N, int64_t K, float alpha, co
     else { if (narrow) ARX_DMA_GO(false, 64, 64); else ARX_DMA_GO(false, 64, 128); }
   }
 #undef ARX_DMA_GO
-  ARX_CHECK_LAUNCH();
-  return ARX_OK;
-}
-
-int gemm_dma_bits_launch(int transA, int64_t M, int64_t N, int64_t K, const uint32_t* bits, int64_t ldw,
-                         const float* B, int64_t ldb, float beta, float* C, int64_t ldc,
-                         const float* row_scale, const float* gvec, float* partial, int bm, int splits,
-                         int64_t kchunk, float* a_rowsum, float* rowsum_partial, hipStream_t s) {
-  dim3 grid((unsigned)ceil_div(M, (int64_t)bm), 1, (unsigned)splits);
-  float* part = splits > 1 ? partial : nullptr;
-  float* rsp = splits > 1 ? rowsum_partial : nullptr;
-#define ARX_DMAB_GO(AKC, BM_, BN_)                                                                 \
-  k_gemm_dma_bits<AKC, BM_, BN_><<<grid, 256, 0, s>>>(M, N, K, bits, ldw, B, ldb, beta, C, ldc,   \
-                                                      row_scale, gvec, part, kchunk, a_rowsum, rsp)
-  const bool narrow = N <= 64;
-  if (!transA) {
-    if (bm == 128) { if (narrow) ARX_DMAB_GO(true, 128, 64); else ARX_DMAB_GO(true, 128, 128); }
-    else { if (narrow) ARX_DMAB_GO(true, 64, 64); else ARX_DMAB_GO(true, 64, 128); }
-  } else {
-    if (bm == 128) { if (narrow) ARX_DMAB_GO(false, 128, 64); else ARX_DMAB_GO(false, 128, 128); }
-    else { if (narrow) ARX_DMAB_GO(false, 64, 64); else ARX_DMAB_GO(false, 64, 128); }
-  }
-#undef ARX_DMAB_GO
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

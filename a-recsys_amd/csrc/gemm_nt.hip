@@ -37,27 +37,11 @@ __device__ __forceinline__ int nt_swz(int r) {
   return (KT >= 64) ? (r & 15) : ((r >> 1) & 7);
 }
 
-// HINGE epilogue (WMRB 'mw' training, embed_attribute.py:641-649): the logits never reach HBM.
-// With t_r the row's target score the tile epilogue forms v = x - t_r + 1 and emits
-//   * one BIT per logit, act = (v > 0), packed along the pool axis and stored WORD-MAJOR
-//     (bits[(col / 32) * ldbits + r]: the 32-slot word of row r; both backward products then fetch
-//     the words of a tile as one contiguous run): the 0/1 matrix the WMRB gradient is made of
-//     (dlogits = g_r * act), 32x smaller than fp32 logits and 64x less traffic than logits + dlogits;
-//   * per (column split, row) partial sums of act * v and of act (summed in fixed order by the
-//     row kernel in loss.hip, which also takes the user's positives out again).
-struct HingeOut {
-  const float* tscore;      // [M]
-  uint32_t* bits;           // [N / 32][ldbits]
-  int64_t ldbits;           // rows per word plane (>= M)
-  float* rs_part;           // [nsplit][M]  sum of act * v over the split's columns
-  float* cnt_part;          // [nsplit][M]  number of active columns
-};
-
-template <int KT, bool HINGE = false>
+template <int KT>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
     int64_t M, int64_t N, const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
     int64_t ldb, float alpha, float* __restrict__ C, int64_t ldc,
-    const float* __restrict__ col_bias, int tiles_per_block, int nsplit, HingeOut ho) {
+    const float* __restrict__ col_bias, int tiles_per_block, int nsplit) {
   constexpr int NS = KT / 8;                  // steps of 4 MFMAs
   constexpr int CPR = KT / 4;                 // 16-B chunks per pool row
   constexpr int NLB = kNtBN * CPR / 256;      // DMA pieces per thread per tile
@@ -123,21 +107,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
     bias0 = col_bias[c0];
     bias1 = col_bias[c1];
   }
-  // HINGE: the workgroup's 128 target scores wait in LDS (16 more registers per lane would push
-  // the K = 128 kernel past the 256 it may use at two workgroups per CU); per lane ONE running
-  // partial sum (row e = l31 / 2 of its half-wave, see the epilogue) and, wave-uniform, the 32
-  // active-column counts of the wave's rows (popcounts of the ballots: scalar registers)
-  __shared__ __attribute__((aligned(16))) float sT[HINGE ? kNtBM : 4];
-  float psum = 0.f;
-  int cnt_lo[HINGE ? 16 : 1], cnt_hi[HINGE ? 16 : 1];
-  if constexpr (HINGE) {
-    if (threadIdx.x < kNtBM) {
-      const int64_t row = m0 + threadIdx.x;
-      sT[threadIdx.x] = ho.tscore[row < M ? row : M - 1];
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) cnt_lo[e] = cnt_hi[e] = 0;
-  }
   __syncthreads();
 
   // read-side swizzle: chunk 2s + lhi of pool row (l31 [+32]); swz(l31) == swz(l31 + 32)
@@ -189,55 +158,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
     const int64_t n0 = t * kNtBN;
     const int64_t rbase = m0 + wave * 32 + 4 * lhi;
-    if constexpr (HINGE) {
-      float pv[16];
-      const float* tp = sT + wave * 32 + 4 * lhi;
-      const bool full = (n0 + kNtBN <= N) && (m0 + wave * 32 + 32 <= M);     // interior tile: no edge tests
-      const float c0 = bias0 + 1.f, c1 = bias1 + 1.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 t4 = *reinterpret_cast<const float4*>(tp + 8 * q);     // rows 8q + 4 lhi + {0..3}
-        const float tq[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = 4 * q + u;                       // ro = (e & 3) + 8 * (e >> 2) = u + 8 q
-          const int ro = u + 8 * q;
-          const float v0 = alpha * acc0[e] + (c0 - tq[u]);
-          const float v1 = alpha * acc1[e] + (c1 - tq[u]);
-          bool a0 = v0 > 0.f, a1 = v1 > 0.f;
-          if (!full) {
-            const bool rok = rbase + ro < M;
-            a0 = a0 && rok && (n0 + l31 < N);
-            a1 = a1 && rok && (n0 + 32 + l31 < N);
-          }
-          pv[e] = (a0 ? v0 : 0.f) + (a1 ? v1 : 0.f);
-          const unsigned long long b0 = __ballot(a0), b1 = __ballot(a1);   // lanes 0-31: lhi 0 rows, 32-63: lhi 1
-          cnt_lo[e] += __popc((uint32_t)b0) + __popc((uint32_t)b1);
-          cnt_hi[e] += __popc((uint32_t)(b0 >> 32)) + __popc((uint32_t)(b1 >> 32));
-          if (l31 == 0 && rbase + ro < M) {
-            uint32_t* wp = ho.bits + (n0 >> 5) * ho.ldbits + (rbase + ro);
-            if (n0 < N) wp[0] = (uint32_t)(lhi ? (b0 >> 32) : b0);
-            if (n0 + 32 < N) wp[ho.ldbits] = (uint32_t)(lhi ? (b1 >> 32) : b1);
-          }
-        }
-      }
-      // 16 rows x 32 column lanes -> one row total per lane, halving butterfly (fixed order):
-      // after the steps over lane bits 4..1 lane l31 holds row e = l31 >> 1; bit 0 closes the sum
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const int off = 16 >> st, half = 8 >> st;          // lanes with the bit set keep the upper half
-        const bool up = (l31 & off) != 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (k < half) {
-            const float keep = up ? pv[k + half] : pv[k];
-            const float send = up ? pv[k] : pv[k + half];
-            pv[k] = keep + __shfl_xor(send, off, 32);
-          }
-        }
-      }
-      psum += pv[0] + __shfl_xor(pv[0], 1, 32);
-    } else {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int64_t col = n0 + j * 32 + l31;
@@ -252,7 +172,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
         }
       }
     }
-    }
     bias0 = nb0;
     bias1 = nb1;
     __syncthreads();          // tile t+1 landed (vmcnt(0) rides on the barrier); buffer cur free
@@ -260,19 +179,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
   for (int64_t t = t_beg; t < t_end; t += 2) {
     tile(t, sB0, sB1);
     if (t + 1 < t_end) tile(t + 1, sB1, sB0);
-  }
-  if constexpr (HINGE) {      // this split's row partials
-    const int64_t rb = m0 + wave * 32 + 4 * lhi;
-    const int e = l31 >> 1;
-    const int64_t row = rb + (e & 3) + 8 * (e >> 2);
-    if ((l31 & 1) == 0 && row < M) ho.rs_part[(int64_t)part * M + row] = psum;
-    if (lane == 0 || lane == 32) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int64_t r2 = rb + (q & 3) + 8 * (q >> 2);
-        if (r2 < M) ho.cnt_part[(int64_t)part * M + r2] = (float)(lhi ? cnt_hi[q] : cnt_lo[q]);
-      }
-    }
   }
 }
 
@@ -299,46 +205,13 @@ int gemm_nt_smallk(int64_t M, int64_t N, int64_t K, float alpha, const float* A,
   if (grid > 0x7fffffff) return ARX_EUNSUPPORTED;
   if (K == 128)
     k_gemm_nt_areg<128><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, alpha, C, ldc, col_bias,
-                                                   (int)tpb, (int)nsplit, HingeOut{});
+                                                   (int)tpb, (int)nsplit);
   else if (K == 64)
     k_gemm_nt_areg<64><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, alpha, C, ldc, col_bias,
-                                                  (int)tpb, (int)nsplit, HingeOut{});
+                                                  (int)tpb, (int)nsplit);
   else
     k_gemm_nt_areg<32><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, alpha, C, ldc, col_bias,
-                                                  (int)tpb, (int)nsplit, HingeOut{});
-  ARX_CHECK_LAUNCH();
-  return ARX_OK;
-}
-
-// The same GEMM with the WMRB hinge epilogue (no logits written).  *nsplit_out = column splits
-// the partial sums are laid out for (rs_part / cnt_part hold nsplit x M floats each; nsplit <= N/64).
-int gemm_nt_hinge(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
-                  int64_t ldb, const float* col_bias, const float* tscore, uint32_t* bits,
-                  int64_t ldbits, float* rs_part, float* cnt_part, int* nsplit_out, hipStream_t s) {
-  if (!(K == 32 || K == 64 || K == 128) || (N % 32)) return ARX_EUNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) ||
-      (lda % 4) || (ldb % 4))
-    return ARX_EUNSUPPORTED;
-  const int64_t panels = ceil_div(M, (int64_t)kNtBM);
-  const int64_t tiles_n = ceil_div(N, (int64_t)kNtBN);
-  int64_t nsplit = ceil_div((int64_t)cu_count() * 2, panels);
-  if (nsplit > tiles_n) nsplit = tiles_n;
-  if (nsplit < 1) nsplit = 1;
-  const int64_t tpb = ceil_div(tiles_n, nsplit);
-  nsplit = ceil_div(tiles_n, tpb);
-  const int64_t grid = panels * nsplit;
-  if (grid > 0x7fffffff) return ARX_EUNSUPPORTED;
-  *nsplit_out = (int)nsplit;
-  HingeOut ho{tscore, bits, ldbits, rs_part, cnt_part};
-  if (K == 128)
-    k_gemm_nt_areg<128, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, 1.f, nullptr, 0, col_bias,
-                                                         (int)tpb, (int)nsplit, ho);
-  else if (K == 64)
-    k_gemm_nt_areg<64, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, 1.f, nullptr, 0, col_bias,
-                                                        (int)tpb, (int)nsplit, ho);
-  else
-    k_gemm_nt_areg<32, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, 1.f, nullptr, 0, col_bias,
-                                                        (int)tpb, (int)nsplit, ho);
+                                                  (int)tpb, (int)nsplit);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

@@ -12,6 +12,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "posmask.h"
 
 namespace arx {
 
@@ -48,23 +49,6 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 // one bit per logit column in LDS, set for every positive item of the row's user
 // that has a slot in this pool.  Replaces the persistent [mb, W] bool variable and
 // its two scatter_update launches per step.
-struct PosMask {
-  const int32_t* user_ids;   // [mask_rows]
-  const int32_t* pos_ptr;    // CSR over users
-  const int32_t* pos_items;
-  const int32_t* item2slot;  // item -> column (or -1)
-  // 1 bit per item: "is in the pool?" (arx_slot_map_attach_bitmap; nullable).  A user's positives are
-  // random items of the catalogue and almost none of them is among the S sampled negatives: the probe
-  // of the 4-byte item2slot cell (a 64-byte line per positive, from a table of 4 B x items) is
-  // answered by a bit of a table 32x smaller that stays in L2 (125 KB at 1 M items).
-  const uint32_t* bits;
-};
-
-__device__ __forceinline__ int pos_slot(const PosMask& pm, int item) {
-  if (pm.bits && !((pm.bits[item >> 5] >> (item & 31)) & 1u)) return -1;
-  return pm.item2slot[item];
-}
-
 // Optional fusion of the target score into the margin-loss kernel (embed_attribute.py:208-220 +
 // :604-649): the wave that owns row r also forms t_r = U_r . T_r + tb_r and, once dt_r is known,
 // the two rank-one gradients dT_r = dt_r U_r and dU_r = dt_r T_r (written, not accumulated: the
@@ -350,161 +334,6 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
       if (c + 1 < W) dx[c + 1] = d[i].y;
       if (c + 2 < W) dx[c + 2] = d[i].z;
     }
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// 'mw' with the hinge in the scorer GEMM's epilogue (gemm_nt.hip, HINGE): the [B, S] logits and
-// their gradient never exist in HBM.  Three launches replace scorer GEMM + loss kernel:
-//   k_mw_tscore   t_r = U_r . T_r + tb_r                                  (one sub-wave per row)
-//   gemm_nt_hinge act bits + per-(split, row) sums of act * (x - t + 1) and of act
-//   k_mw_rows     one wave per row: adds the splits up in fixed order, takes the user's positives
-//                 that sit in the pool out again (their logit is recomputed from the row's
-//                 latent and the pool row; the bit is cleared), then
-//                 loss = log(1 + s), g = gscale * w / (1 + s), dt = -g * cnt, and the rank-one
-//                 terms dT = dt * U, dU = dt * T, Ug = g * U (the B operand of the dI GEMM).
-// The backward GEMMs read the bits (gemm_dma.hip, ABITS): dU += g_r * (act . P), dI = act^T . Ug.
-constexpr int kMwHits = 8;       // pool slots of a row's positives kept in the hit list
-
-// Pre-kernel (before the scorer GEMM): one wave per row forms t_r = U_r . T_r + tb_r and, while
-// those rows are in flight, walks the user's positives (user -> pos_ptr -> pos_items -> item2slot,
-// embed_attribute.py:729-741) and lists the ones that are pool slots: hits[r][0..nhit).  More than
-// kMwHits of them: nhit = -1 and the row kernel walks the chain itself.
-__global__ __launch_bounds__(256) void k_mw_tscore(const float* __restrict__ U, int64_t ldu,
-                                                   const float* __restrict__ T, int64_t ldt,
-                                                   const float* __restrict__ tb, int64_t tb_stride,
-                                                   int d, int64_t B, float* __restrict__ t_out,
-                                                   PosMask pm, int64_t mask_rows, int64_t S,
-                                                   int32_t* __restrict__ hits, int32_t* __restrict__ nhit) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-  if (r >= B) return;
-  float4 u = make_float4(0.f, 0.f, 0.f, 0.f), t = u;
-  if (lane * 4 < d) {
-    u = *reinterpret_cast<const float4*>(U + r * ldu + lane * 4);
-    t = *reinterpret_cast<const float4*>(T + r * ldt + lane * 4);
-  }
-  const int usr = pm.user_ids[r % mask_rows];
-  const int beg = pm.pos_ptr[usr], end = pm.pos_ptr[usr + 1];
-  int n = 0;
-  for (int p0 = beg; p0 < end && n >= 0; p0 += 64) {
-    const int p = p0 + lane;
-    int j = -1;
-    if (p < end) {
-      j = pos_slot(pm, pm.pos_items[p]);
-      if (j < 0 || j >= S) j = -1;
-    }
-    const unsigned long long hm = __ballot(j >= 0);
-    const int k = __popcll(hm);
-    if (n + k > kMwHits) { n = -1; break; }
-    if (j >= 0) hits[r * kMwHits + n + __popcll(hm & ((1ull << lane) - 1ull))] = j;
-    n += k;
-  }
-  const float v = wsum(u.x * t.x + u.y * t.y + u.z * t.z + u.w * t.w);
-  if (lane == 0) {
-    t_out[r] = v + (tb ? tb[r * tb_stride] : 0.f);
-    nhit[r] = n;
-  }
-}
-
-struct MwRows {
-  const float* rs_part;      // [nsplit][B]
-  const float* cnt_part;     // [nsplit][B]
-  int nsplit;
-  uint32_t* bits;            // word-major [S / 32][ldbits]
-  int64_t ldbits;
-  const float* tscore;       // [B]
-  const float* U; int64_t ldu;
-  const float* T; int64_t ldt;
-  const float* P; int64_t ldp;     // pool rows [S, d]
-  const float* pb;                 // pool bias [S] (nullable)
-  int d;
-  float gscale;
-  const float* row_w;              // nullable
-  float* batch_loss;               // [B] nullable
-  float* g_out;                    // [B]
-  float* dtscore; int64_t dts_stride;
-  float* dU; int64_t lddu;         // dt * T   (nullable)
-  float* dT; int64_t lddt;         // dt * U   (nullable)
-  float* Ug; int64_t ldug;         // g * U
-  const int32_t* hits;             // [B][kMwHits]
-  const int32_t* nhit;             // [B]  (-1: walk the positives)
-};
-
-// one wave per row: the splits' partial sums in fixed order, the positives taken out again (their
-// logit is recomputed from the row's latent and the pool row; the bit is cleared), the row's loss
-// and gradient factors, the rank-one terms
-__global__ __launch_bounds__(256) void k_mw_rows(MwRows a, PosMask pm, int64_t mask_rows, int64_t B,
-                                                 int64_t S) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-  if (r >= B) return;                                 // whole wave
-  float s = 0.f, c = 0.f;
-  for (int p = 0; p < a.nsplit; ++p) {                // fixed order: bit-reproducible
-    s += a.rs_part[(int64_t)p * B + r];
-    c += a.cnt_part[(int64_t)p * B + r];
-  }
-  const float t = a.tscore[r];
-  float4 u = make_float4(0.f, 0.f, 0.f, 0.f), tr = u;
-  const bool colok = lane * 4 < a.d;
-  if (colok) {
-    u = *reinterpret_cast<const float4*>(a.U + r * a.ldu + lane * 4);
-    tr = *reinterpret_cast<const float4*>(a.T + r * a.ldt + lane * 4);
-  }
-  const int nh = a.nhit[r];
-  if (nh != 0) {
-    // the row's bit words live in the lanes (word w in lane w; S <= 2048), so a slot that the
-    // positives name twice is taken out once and the write-back is one store per changed word
-    const int nwords = (int)(S >> 5);
-    uint32_t* bcol = a.bits + r;
-    const uint32_t w0 = lane < nwords ? bcol[(int64_t)lane * a.ldbits] : 0u;
-    uint32_t myw = w0;
-    auto take_out = [&](int jj) {                     // jj wave-uniform
-      const uint32_t w = __shfl(myw, jj >> 5, 64);
-      if (!((w >> (jj & 31)) & 1u)) return;           // hinge not active there (or already taken out)
-      float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (colok) pr = *reinterpret_cast<const float4*>(a.P + (int64_t)jj * a.ldp + lane * 4);
-      const float x = wsum(u.x * pr.x + u.y * pr.y + u.z * pr.z + u.w * pr.w) + (a.pb ? a.pb[jj] : 0.f);
-      const float v = x - t + 1.f;
-      s -= v > 0.f ? v : 0.f;
-      c -= 1.f;
-      if (lane == (jj >> 5)) myw &= ~(1u << (jj & 31));
-    };
-    if (nh > 0) {
-      const int myhit = lane < nh ? a.hits[r * kMwHits + lane] : 0;
-      for (int k = 0; k < nh; ++k) take_out(__shfl(myhit, k, 64));
-    } else {                                          // long list: walk the positives here
-      const int usr = pm.user_ids[r % mask_rows];
-      const int beg = pm.pos_ptr[usr], end = pm.pos_ptr[usr + 1];
-      for (int p0 = beg; p0 < end; p0 += 64) {
-        const int p = p0 + lane;
-        int j = -1;
-        if (p < end) {
-          j = pos_slot(pm, pm.pos_items[p]);
-          if (j < 0 || j >= S) j = -1;
-        }
-        unsigned long long hm = __ballot(j >= 0);
-        while (hm) {
-          const int src = __builtin_ctzll(hm);
-          hm &= hm - 1;
-          take_out(__shfl(j, src, 64));
-        }
-      }
-    }
-    if (lane < nwords && myw != w0) bcol[(int64_t)lane * a.ldbits] = myw;
-  }
-  s = fmaxf(s, 0.f);
-  const float g = a.gscale * (a.row_w ? a.row_w[r] : 1.f) / (1.f + s);
-  const float dt = -g * c;
-  if (lane == 0) {
-    if (a.batch_loss) a.batch_loss[r] = logf(1.f + s);
-    a.g_out[r] = g;
-    if (a.dtscore) a.dtscore[r * a.dts_stride] = dt;
-  }
-  if (colok) {
-    if (a.dT) *reinterpret_cast<float4*>(a.dT + r * a.lddt + lane * 4) = make_float4(dt * u.x, dt * u.y, dt * u.z, dt * u.w);
-    if (a.dU) *reinterpret_cast<float4*>(a.dU + r * a.lddu + lane * 4) = make_float4(dt * tr.x, dt * tr.y, dt * tr.z, dt * tr.w);
-    *reinterpret_cast<float4*>(a.Ug + r * a.ldug + lane * 4) = make_float4(g * u.x, g * u.y, g * u.z, g * u.w);
   }
 }
 
@@ -819,6 +648,11 @@ static PosMask make_pm(const int32_t* user_ids, const int32_t* pos_ptr, const in
   return PosMask{user_ids, pos_ptr, pos_items, item2slot, slot_bits_of(item2slot)};
 }
 
+PosMask make_pos_mask(const int32_t* user_ids, const int32_t* pos_ptr, const int32_t* pos_items,
+                      const int32_t* item2slot) {
+  return make_pm(user_ids, pos_ptr, pos_items, item2slot);
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -1025,72 +859,6 @@ int arx_eval_finish(int mode, const float* acc0, const float* acc1, const float*
   ARX_CHECK_ARG(acc0 && batch_loss && (mode == 1 || (acc1 && tscore)), "arx_eval_finish: bad argument");
   if (B <= 0) return ARX_OK;
   k_eval_finish<<<(int)ceil_div(B, 256), 256, 0, as_stream(stream)>>>(mode, acc0, acc1, tscore, B, batch_loss);
-  ARX_CHECK_LAUNCH();
-  return ARX_OK;
-}
-
-size_t arx_mw_gemm_fused_workspace_bytes(int64_t B, int64_t S) {
-  // target scores + (row sums, counts) of up to S / 64 column splits + the positives' hit lists
-  const size_t splits = (size_t)((S + 63) / 64);
-  // (+ the bf16 planes of the pool rows for the bf16-pipe hinge GEMM: 3 * S * 128 * 2 bytes)
-  return ((size_t)B * (1 + 2 * splits + kMwHits + 1)) * sizeof(float) + 256 + (size_t)3 * S * 128 * 2 + 256;
-}
-
-int arx_mw_gemm_fused_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp, const float* pbias,
-                          const float* T, int64_t ldt, const float* tbias, int64_t tb_stride, int d,
-                          const int32_t* user_ids, const int32_t* pos_ptr, const int32_t* pos_items,
-                          const int32_t* item2slot, int64_t mask_rows, float gscale, const float* row_w,
-                          int64_t B, int64_t S, float* batch_loss, float* tscore_out, uint32_t* act_bits,
-                          int64_t ldbits, float* g_out, float* Ug, int64_t ldug, float* dtscore,
-                          int64_t dtscore_stride, float* dU, int64_t lddu, float* dT, int64_t lddt,
-                          void* workspace, size_t workspace_bytes, void* stream) {
-  ARX_CHECK_ARG(U && P && T && user_ids && pos_ptr && pos_items && item2slot && act_bits && g_out && Ug,
-                "arx_mw_gemm_fused_fwd: null pointer");
-  ARX_CHECK_ARG(B >= 0 && S > 0, "arx_mw_gemm_fused_fwd: bad size");
-  const bool ok = (d == 32 || d == 64 || d == 128) && S % 32 == 0 && S <= 2048 && ldbits >= B && ldu % 4 == 0 &&
-                  ldp % 4 == 0 && ldt % 4 == 0 && ldug % 4 == 0 && (!dU || lddu % 4 == 0) &&
-                  (!dT || lddt % 4 == 0) &&
-                  ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(P) |
-                    reinterpret_cast<uintptr_t>(T) | reinterpret_cast<uintptr_t>(Ug) |
-                    reinterpret_cast<uintptr_t>(dU) | reinterpret_cast<uintptr_t>(dT)) & 15) == 0;
-  if (!ok) {
-    set_error("arx_mw_gemm_fused_fwd: shape not supported (d in {32, 64, 128}, S %% 32 == 0, S <= 2048, 16-byte rows)");
-    return ARX_EUNSUPPORTED;
-  }
-  if (B == 0) return ARX_OK;
-  const size_t need = arx_mw_gemm_fused_workspace_bytes(B, S);
-  if (!workspace || workspace_bytes < need) {
-    set_error("arx_mw_gemm_fused_fwd: workspace too small (%zu < %zu)", workspace_bytes, need);
-    return ARX_EWORKSPACE;
-  }
-  hipStream_t s = as_stream(stream);
-  float* t = tscore_out ? tscore_out : reinterpret_cast<float*>(workspace);
-  float* rs_part = reinterpret_cast<float*>(workspace) + B;
-  const int64_t splits = (S + 63) / 64;
-  float* cnt_part = rs_part + splits * B;
-  int32_t* hits = reinterpret_cast<int32_t*>(cnt_part + splits * B);
-  int32_t* nhit = hits + (size_t)B * kMwHits;
-  const int grid = (int)ceil_div(B, 4);
-  const PosMask pm = make_pm(user_ids, pos_ptr, pos_items, item2slot);
-  const int64_t mrows = mask_rows > 0 ? mask_rows : B;
-  k_mw_tscore<<<grid, 256, 0, s>>>(U, ldu, T, ldt, tbias, tb_stride > 0 ? tb_stride : 1, d, B, t, pm, mrows, S,
-                                   hits, nhit);
-  ARX_CHECK_LAUNCH();
-  int nsplit = 0;
-  int rc;
-  if (bx6_enabled() && (d == 64 || d == 128) && S % 128 == 0) {
-    uint16_t* planes = reinterpret_cast<uint16_t*>(
-        (reinterpret_cast<uintptr_t>(nhit + B) + 255) / 256 * 256);      // behind the hit lists
-    rc = gemm_nt_hinge_bx6(B, S, d, U, ldu, P, ldp, pbias, t, act_bits, ldbits, rs_part, cnt_part, &nsplit, planes, s);
-  } else {
-    rc = gemm_nt_hinge(B, S, d, U, ldu, P, ldp, pbias, t, act_bits, ldbits, rs_part, cnt_part, &nsplit, s);
-  }
-  if (rc == ARX_EUNSUPPORTED) set_error("arx_mw_gemm_fused_fwd: scorer shape not supported by the hinge GEMM");
-  if (rc) return rc;
-  MwRows a{rs_part, cnt_part, nsplit, act_bits, ldbits, t, U, ldu, T, ldt, P, ldp, pbias, d, gscale, row_w,
-           batch_loss, g_out, dtscore, dtscore_stride > 0 ? dtscore_stride : 1, dU, lddu, dT, lddt, Ug, ldug,
-           hits, nhit};
-  k_mw_rows<<<grid, 256, 0, s>>>(a, pm, mrows, B, S);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

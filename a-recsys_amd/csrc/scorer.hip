@@ -1,0 +1,1199 @@
+// scorer.hip -- the sampled-loss scorer of a training step on the bf16 matrix pipe, f32-exact (round 4).
+//
+//   logits = U . P^T + b (embed_attribute.py:171,188-193), WMRB 'mw' (:641-649), target score (:208-220) and the two
+//   backward products dU = dL . P, dP = dL^T . U (tf.gradients of the same lines) -- without [B, S] logits or
+//   dlogits in HBM.  An f32 value is EXACTLY three bf16 pieces (8 + 8 + 8 mantissa bits), a bf16 x bf16 product
+//   is exact in f32, and of the nine piece products the three smallest are below 2^-26 of the product: six
+//   v_mfma_f32_32x32x16_bf16 per k-chunk with f32 accumulation (small terms in their own accumulator) carry
+//   every bit an f32 multiply-add chain carries (three where one operand is the 0/1 hinge-activity matrix).
+//
+// What round 3's kernels (gemm_bx6.hip) got wrong, measured with tools/probe/mfma_issue.hip on the part
+// (profiles/r04_mfma_issue_probe.txt): (1) a wave can issue <= 6 plain VALU or one ds_read_b128 per MFMA gap for
+// free, the accumulator pattern does not matter, packed-f32 VALU costs +18 cycles each -- the matrix pipe was
+// never the limit; (2) every workgroup streamed ALL planes of the small operand (768 KB) through its CU: 196 MB of
+// L2 -> LDS traffic per launch, and the loaders prefetched ONE stage ahead of a ~2 600-cycle L2 round trip.
+// This file: 128 x 512 (forward) and 256 x 32 (backward) workgroup tiles -- 2x / 4x less plane traffic --, LDS-DMA
+// loader waves (global_load_lds_dwordx4: no staging registers) three stages ahead in a four-slot ring, the hinge
+// epilogue of tile j - 1 interleaved with the MFMAs of tile j, the target score formed in the forward kernel's
+// prologue, and every operand plane produced by the kernel that has the data in registers anyway (k_sc_prep: pool
+// rows in both layouts; k_sc_rows: g U transposed) -- no split launches.
+//
+// Launches of a step:  k_sc_prep -> k_sc_hinge -> k_sc_rows          (arx_mw_scorer_fwd)
+//                      k_sc_bits (dU += g (act . P))                 (arx_mw_scorer_bwd_du)
+//                      k_sc_bits (slices of act^T . (g U)) -> k_sc_tn_reduce   (arx_mw_scorer_bwd_di)
+#include <stdlib.h>
+
+#include "common.h"
+#include "posmask.h"
+#ifdef SC_ABL_ASMTILE
+#include "sc_abl_asmtile.inc"
+#endif
+
+namespace arx {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Ablation builds (tools/build_variant.sh <name> -DSC_ABL_...; WRONG results, the clock is what counts):
+//   SC_ABL_NODMA   loaders issue no LDS-DMA (compute reads whatever is in LDS)
+//   SC_ABL_NOEPI   the forward kernel's hinge epilogue is compiled out
+//   SC_ABL_NOBAR   no per-stage barriers (loaders and compute waves run free)
+//   SC_ABL_NOMFMA  the MFMAs are compiled out (reads, epilogue and barriers stay)
+//   SC_TRACE       cycle stamps (s_memtime) of one compute wave of workgroup 5: arx_sc_trace_read (tools/sc_trace.py)
+#ifndef SC_TRACE_CHUNKS
+#define SC_TRACE_CHUNKS 0            // 1: a stamp after every chunk (perturbs: each stamp drains the LDS counter)
+#endif
+#ifdef SC_TRACE
+__device__ unsigned long long g_sc_trace[4096];
+#define SC_T(ev_)                                                                                        \
+  if (blockIdx.x == (gridDim.x > 5 ? 5 : 0) && threadIdx.x == 0 && tcount < 4096)                        \
+    g_sc_trace[tcount++] = ((unsigned long long)(ev_) << 56) | (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFFFull);
+#define SC_TDECL int tcount = 0;
+#else
+#define SC_T(ev_)
+#define SC_TDECL
+#endif
+constexpr int kScHits = 8;            // pool slots of a row's positives kept in the hit list (more: the row kernel walks)
+constexpr int kScSlots = 4;           // LDS ring: the stage being read + three in flight
+constexpr int kScAhead = 3;
+constexpr int kScStageBytes = 3 * 32 * 256;      // one stage = 3 planes x 32 operand rows x 256 bytes (24 KB)
+
+__device__ __forceinline__ uint32_t bf16_rne(float x) {       // f32 -> bf16 bits, round to nearest even
+  const uint32_t u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// x -> its three bf16 pieces (bits): both residual subtractions are exact
+__device__ __forceinline__ void split3(float x, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  p1 = bf16_rne(x);
+  const float r1 = x - __uint_as_float(p1 << 16);
+  p2 = bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float(p2 << 16);
+  p3 = bf16_rne(r2);
+}
+
+#ifdef SC_ABL_NOBAR
+__device__ __forceinline__ void sc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#define SC_RAW_BARRIER() asm volatile("s_nop 0" ::: "memory")
+#else
+__device__ __forceinline__ void sc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#define SC_RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
+#endif
+#ifdef SC_ABL_NOMFMA
+#define SC_MFMA(a_, b_, c_) (c_)
+#else
+#define SC_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0)
+#endif
+
+// 16-byte chunk position of chunk q of operand row r inside an LDS stage image (rows of ROWB bytes, unpadded: the
+// LDS-DMA writes lane-linear): XOR swizzle such that the 16 lanes a ds_read_b128 services per cycle hit 16 slots
+template <int ROWB>
+__device__ __forceinline__ int sc_swz(int r) {
+  return ROWB == 256 ? (r & 15) : ((r >> 1) & 7);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Loader waves: one stage = 24 pieces of 1 KiB (64 lanes x 16 B, LDS-DMA), six per loader wave.  The image of a
+// stage: [tile][plane][32 rows][ROWB bytes]; lane -> (row of its piece, chunk position), fetching the chunk the
+// swizzle puts there.  `src` is this lane's byte pointer for piece i of stage 0 without the stage advance.
+// ------------------------------------------------------------------------------------------------------------
+template <int ROWB>
+struct ScLoader {
+  const char* src[6];                // per piece: plane / tile / row / chunk resolved
+  int64_t stage_step;                // bytes between consecutive stages in the source
+  uint32_t dst[6];                   // LDS byte offset of the piece inside a stage image (wave-uniform)
+  const char* srcx = nullptr;        // a seventh piece per stage (k_sc_bits: one 256-word row piece of the act bits)
+  int64_t stepx = 0;
+
+  // planes: [3][rows_total][row_bytes]; a stage = TPS tiles of 32 consecutive rows (TPS * ROWB == 256 ... see callers)
+  __device__ __forceinline__ void init(const char* planes, int64_t plane_bytes, int64_t row_bytes, int64_t row0,
+                                       int64_t col_byte0, int lw, int lane, int64_t rows_total) {
+    constexpr int RP = 1024 / ROWB;            // rows per piece
+    constexpr int PPT = 32 / RP;               // pieces per (tile, plane)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int p = lw * 6 + i;
+      const int pt = p / PPT, rg = p % PPT;
+      const int t = pt / 3, pl = pt % 3;
+      const int row = rg * RP + lane / (ROWB / 16), pos = lane % (ROWB / 16);
+      const int q = pos ^ sc_swz<ROWB>(row);
+      int64_t r = row0 + t * 32 + row;
+      if (r > rows_total - 1) r = rows_total - 1;          // (clamped: such rows are never used)
+      src[i] = planes + pl * plane_bytes + r * row_bytes + col_byte0 + q * 16;
+      dst[i] = (uint32_t)(p * 1024);
+    }
+  }
+  template <bool EXTRA = false>
+  __device__ __forceinline__ void issue(char* lds_stage, int64_t st, char* lds_x = nullptr) const {
+#ifdef SC_ABL_NODMA
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + st * stage_step),
+                                       (__attribute__((address_space(3))) void*)(lds_stage + dst[i]), 16, 0, 0);
+    if (EXTRA)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + st * stepx),
+                                       (__attribute__((address_space(3))) void*)lds_x, 16, 0, 0);
+  }
+};
+
+// The loader waves' loop.  Ring of kScSlots stage images; protocol with the compute waves (one s_barrier per stage):
+//   B0     stage 0 has landed (and whatever the workgroup staged in LDS itself)
+//   E(st)  the compute waves arrive in the MIDDLE of stage st: they are done with stage st - 1 (its slot may be
+//          overwritten: stage st + 3 goes there) and may read stage st + 1 from now on (the loaders waited for it) --
+//          so the first fragments of stage st + 1 are requested under the last MFMAs of stage st, never behind a
+//          barrier.
+// EXTRA: a seventh piece per stage and loader wave lands at ldsx + slot * 4096 + lw * 1024.
+template <int ROWB, bool EXTRA = false>
+__device__ __forceinline__ void sc_loader_loop(const ScLoader<ROWB>& ld, char* lds, int nstage, char* ldsx = nullptr,
+                                               int lw = 0) {
+#pragma unroll
+  for (int a = 0; a < kScAhead; ++a)
+    ld.template issue<EXTRA>(lds + a * kScStageBytes, a < nstage ? a : nstage - 1, ldsx + a * 4096 + lw * 1024);
+  if (EXTRA) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // stage 0 has landed
+  sc_barrier();                                               // B0
+  for (int st = 0; st < nstage; ++st) {
+    if (EXTRA) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // stage st + 1 has landed (st + 2 may be in flight)
+    SC_RAW_BARRIER();                                         // E(st)
+    const int nx = st + kScAhead;
+    ld.template issue<EXTRA>(lds + (nx % kScSlots) * kScStageBytes, nx < nstage ? nx : nstage - 1,
+                             ldsx + (nx % kScSlots) * 4096 + lw * 1024);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// f32 tile [R rows][ld floats] in LDS -> TRANSPOSED bf16 planes dst[pl][n][k0 .. k0 + R): thread -> (column n, 8 rows)
+__device__ __forceinline__ void sc_emit_planes_t(const float* tile, int ld, int R, int N, uint16_t* dst,
+                                                 int64_t plane_elems, int64_t ldk, int64_t k0, int tid, int nthreads) {
+  const int groups = R / 8;
+  for (int it = tid; it < N * groups; it += nthreads) {
+    const int n = it % N, q = it / N;
+    uint32_t w[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t a[3], b[3];
+      split3(tile[(8 * q + 2 * e) * ld + n], a[0], a[1], a[2]);
+      split3(tile[(8 * q + 2 * e + 1) * ld + n], b[0], b[1], b[2]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) w[p][e] = a[p] | (b[p] << 16);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      *reinterpret_cast<uint4*>(dst + p * plane_elems + (int64_t)n * ldk + k0 + 8 * q) =
+          make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]);
+  }
+}
+
+__device__ __forceinline__ float sc_wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_sc_prep: blocks [0, S / 32): 32 pool rows -> planes Pp [3][S][d] (forward operand, k contiguous) and
+// PT [3][d][S] (dU operand, pool index contiguous); the other blocks: one wave per batch row walks the user's
+// positives (user -> pos_ptr -> pos_items -> item2slot, embed_attribute.py:729-741) and lists the ones that are
+// pool slots: hits[r][0 .. nhit) (more than kScHits: nhit = -1, the row kernel walks the chain itself).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sc_prep(const float* __restrict__ P, int64_t ldp, int64_t S, int d,
+                                                 const float* __restrict__ pbias, uint16_t* __restrict__ Pp,
+                                                 uint16_t* __restrict__ PT, int64_t ldpt, float* __restrict__ pool_bad,
+                                                 PosMask pm,
+                                                 int64_t mask_rows, int64_t B, int32_t* __restrict__ hits,
+                                                 int32_t* __restrict__ nhit) {
+  __shared__ float tile[32 * 129];
+  __shared__ float sbad[4];
+  const int tid = threadIdx.x;
+  const int64_t pblocks = S / 32;
+  if ((int64_t)blockIdx.x < pblocks) {
+    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    const int ld = d + 1;
+    const int c4n = d / 4;
+    // 0 * x is NaN exactly for a non-finite x: pool_bad[block] poisons every row's loss (what an f32 chain would do)
+    float bad = (pbias && tid < 32) ? pbias[r0 + tid] * 0.f : 0.f;
+    for (int it = tid; it < 32 * c4n; it += 256) {
+      const int r = it / c4n, c = (it % c4n) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(P + (r0 + r) * ldp + c);
+      bad += (v.x + v.y + v.z + v.w) * 0.f;
+      tile[r * ld + c] = v.x; tile[r * ld + c + 1] = v.y; tile[r * ld + c + 2] = v.z; tile[r * ld + c + 3] = v.w;
+      uint32_t a[3], b[3], cc[3], dd[3];
+      split3(v.x, a[0], a[1], a[2]);
+      split3(v.y, b[0], b[1], b[2]);
+      split3(v.z, cc[0], cc[1], cc[2]);
+      split3(v.w, dd[0], dd[1], dd[2]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<uint2*>(Pp + ((int64_t)p * S + r0 + r) * d + c) =
+            make_uint2(a[p] | (b[p] << 16), cc[p] | (dd[p] << 16));
+    }
+    bad = sc_wsum(bad);
+    if ((tid & 63) == 0) sbad[tid >> 6] = bad;
+    __syncthreads();
+    if (tid == 0) pool_bad[blockIdx.x] = (sbad[0] + sbad[1]) + (sbad[2] + sbad[3]);
+    sc_emit_planes_t(tile, ld, 32, d, PT, (int64_t)d * ldpt, ldpt, r0, tid, 256);
+    return;
+  }
+  const int lane = tid & 63;
+  const int64_t r = (((int64_t)blockIdx.x - pblocks) * 256 + tid) >> 6;
+  if (r >= B) return;
+  const int usr = pm.user_ids[r % mask_rows];
+  const int beg = pm.pos_ptr[usr], end = pm.pos_ptr[usr + 1];
+  int n = 0;
+  for (int p0 = beg; p0 < end && n >= 0; p0 += 64) {
+    const int p = p0 + lane;
+    int j = -1;
+    if (p < end) {
+      j = pos_slot(pm, pm.pos_items[p]);
+      if (j < 0 || j >= S) j = -1;
+    }
+    const unsigned long long hm = __ballot(j >= 0);
+    const int k = __popcll(hm);
+    if (n + k > kScHits) { n = -1; break; }
+    if (j >= 0) hits[r * kScHits + n + __popcll(hm & ((1ull << lane) - 1ull))] = j;
+    n += k;
+  }
+  if (lane == 0) nhit[r] = n;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_sc_hinge<KD>: workgroup = 128 batch rows x CW pool columns (CW = S / nsplit).  Waves 0..3 compute: wave w
+// keeps rows [32 w, 32 w + 32) of U as bf16 pieces in registers for the whole kernel (lane = row l % 32, k = 8 (l / 32)
+// .. + 8 of each 16-chunk) and forms t_r = U_r . T_r + tb_r on the way; per 32-column tile 6 KD / 16 MFMAs out of
+// the pool planes in LDS (pool tile = FIRST operand: D[pool column][row], a lane's 16 accumulator values are columns
+// 8 g + 4 (l / 32) + e of its row).  The hinge of tile j - 1 (v = x - t + 1: one act bit per logit, running
+// sum act * v and count) is written between the MFMAs of tile j (two accumulator sets).  Waves 4..7: LDS-DMA loaders.
+// Outputs: bits[tile * ldbits + row] (bit c = column 32 tile + c), rs_part / cnt_part [nsplit][B], tscore [B].
+// ------------------------------------------------------------------------------------------------------------
+template <int KD>
+__global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, const float* __restrict__ U, int64_t ldu,
+                                                  const float* __restrict__ T, int64_t ldt,
+                                                  const float* __restrict__ tb, int64_t tb_stride,
+                                                  const uint16_t* __restrict__ Pp, const float* __restrict__ bias,
+                                                  float* __restrict__ tscore, float* __restrict__ tscore2,
+                                                  uint32_t* __restrict__ bits, int64_t ldbits, float* __restrict__ rs_part,
+                                                  float* __restrict__ cnt_part) {
+  constexpr int NCH = KD / 16;
+  constexpr int ROWB = KD * 2;                     // bytes per operand row
+  constexpr int TPS = 256 / ROWB;                  // tiles per stage (1 at K = 128, 2 at K = 64)
+  constexpr int TILEB = 3 * 32 * ROWB;             // bytes per tile (three planes)
+  extern __shared__ __attribute__((aligned(1024))) char lds[];      // [kScSlots][24 KB], bias [CW] f32, words [CW / 32][128]
+  float* sbias = reinterpret_cast<float*>(lds + kScSlots * kScStageBytes);
+  // the act words of the workgroup's rows wait in LDS and leave after the loop: a compute wave issues NO global
+  // memory instruction inside its loop (with the loaders' LDS-DMA in flight a single global_store_dword per tile
+  // stalled the wave's in-order issue for ~400 cycles: measured, tools/sc_trace.py)
+  uint32_t* swords = reinterpret_cast<uint32_t*>(sbias + CW);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int nsplit = (int)(S / CW);
+  const int64_t rb = (int64_t)blockIdx.x / nsplit;
+  const int ch = (int)((int64_t)blockIdx.x % nsplit);
+  const int64_t col0 = (int64_t)ch * CW;
+  const int ntile = CW / 32;
+  const int nstage = ntile / TPS;
+  for (int i = tid; i < CW; i += 512) sbias[i] = bias ? bias[col0 + i] : 0.f;
+
+  if (wv >= 4) {
+    // ================================== loaders ==================================
+    ScLoader<ROWB> ld;
+    ld.init(reinterpret_cast<const char*>(Pp), S * (int64_t)ROWB, ROWB, col0, 0, wv - 4, lane, S);
+    ld.stage_step = (int64_t)TPS * 32 * ROWB;
+    sc_loader_loop<ROWB>(ld, lds, nstage);
+    return;
+  }
+
+  // ================================== compute waves ==================================
+  const int lr = lane & 31, kg = lane >> 5;
+  const int64_t row = rb * 128 + wv * 32 + lr;
+  const bool ok = row < B;
+  bf16x8 a1[NCH], a2[NCH], a3[NCH];
+  float tm1;
+  {
+    const float* up = U + (ok ? row : 0) * ldu + 8 * kg;
+    const float* tp = T + (ok ? row : 0) * ldt + 8 * kg;
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, t0 = v0, t1 = v0;
+      if (ok) {
+        v0 = *reinterpret_cast<const float4*>(up + 16 * c);
+        v1 = *reinterpret_cast<const float4*>(up + 16 * c + 4);
+        t0 = *reinterpret_cast<const float4*>(tp + 16 * c);
+        t1 = *reinterpret_cast<const float4*>(tp + 16 * c + 4);
+      }
+      dot += v0.x * t0.x + v0.y * t0.y + v0.z * t0.z + v0.w * t0.w + v1.x * t1.x + v1.y * t1.y + v1.z * t1.z + v1.w * t1.w;
+      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      uint32_t p1[8], p2[8], p3[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split3(x[e], p1[e], p2[e], p3[e]);
+      a1[c] = __builtin_bit_cast(bf16x8, make_uint4(p1[0] | (p1[1] << 16), p1[2] | (p1[3] << 16), p1[4] | (p1[5] << 16), p1[6] | (p1[7] << 16)));
+      a2[c] = __builtin_bit_cast(bf16x8, make_uint4(p2[0] | (p2[1] << 16), p2[2] | (p2[3] << 16), p2[4] | (p2[5] << 16), p2[6] | (p2[7] << 16)));
+      a3[c] = __builtin_bit_cast(bf16x8, make_uint4(p3[0] | (p3[1] << 16), p3[2] | (p3[3] << 16), p3[4] | (p3[5] << 16), p3[6] | (p3[7] << 16)));
+    }
+    dot += __shfl_xor(dot, 32, 64);
+    const float t = dot + ((ok && tb) ? tb[row * tb_stride] : 0.f);
+    if (ch == 0 && kg == 0 && ok) {
+      tscore[row] = t;
+      if (tscore2) tscore2[row] = t;
+    }
+    tm1 = t - 1.f;                                            // v = x - (t - 1)
+  }
+  float rs = 0.f;
+  int cnt = 0;
+  // LDS byte address of this lane's fragment of chunk c in the CURRENT tile's image (plane pl: + pl * 32 * ROWB).
+  // Advanced IN PLACE to the next tile's image right after its last use (a scalar step): the reads of a tile then
+  // depend on nothing computed inside that tile's scheduling region, so the scheduler can hoist them.
+  uint32_t fa[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) fa[c] = (uint32_t)(lr * ROWB + 16 * ((2 * c + kg) ^ sc_swz<ROWB>(lr)));
+
+  f32x16 hiA, loA, hiB, loB;
+  // The instruction stream of a tile is laid out BY HAND, chunk by chunk (left alone the scheduler emits ds_read /
+  // wait / MFMA triples and the matrix pipe idles for an LDS round trip per fragment; sched_group_barrier alone
+  // does not hoist the reads either):
+  //   [3 fragment reads of the NEXT chunk -- in the last chunk: of the next tile's chunk 0, plus the 4 bias reads of
+  //    the tile after next]                                                          | sched_barrier |
+  //   [6 MFMAs of chunk c, each followed by its share of the PREVIOUS tile's hinge: VPC values per chunk -- sign bit of
+  //    -(v) into h (v_alignbit), rs += relu(v), then the value's accumulator pair is re-initialised for the tile after
+  //    next: hi = bias - (t - 1), lo = 0; chunk 0 also assembles and stores the word of the tile before that]
+  //                                                                                   | sched_barrier |
+  // and the stage barrier E sits in the MIDDLE of a tile (sc_loader_loop): nothing waits behind it.
+  // tools/probe/mfma_issue.hip: <= 6 plain VALU or one ds_read_b128 per MFMA gap are free.
+  constexpr int VPC = 16 / NCH;                               // hinge values per chunk (2 at K = 128, 4 at K = 64)
+  constexpr int VPM = KD == 128 ? 2 : 4;                      // VALU per MFMA gap inside a chunk (6 VPC + 1 over 6 MFMAs)
+  // this lane's word of tile j: swords[j * 128 + 32 wv + lr] (both halves of the wave hold the full word after the
+  // swap and write the same value)
+  uint32_t* wptr = swords + wv * 32 + lr;
+  // fragment ring: chunk c of a tile consumes set c % 4 and requests set (c + SC_PF) % 4 (SC_PF chunks ahead, into
+  // the next tile's image at the end of a tile)
+  uint4 fr[4][3];
+  float4 bvn[4];
+  uint32_t h = 0u;
+  // A zero the compiler cannot fold: the `lo` accumulators are re-initialised by a real v_mov and stay LIVE between a
+  // tile's hinge and the next tile's MFMAs.  With a literal 0 hipcc starts the next tile's first MFMA from an inline
+  // constant and uses the 16 dead registers for the fragments of the running tile -- then every re-initialising VALU
+  // write waits for the in-flight MFMAs that still read those registers, the wave's in-order issue stalls behind it,
+  // and the hinge costs 1 450 cycles per tile instead of hiding in the MFMA gaps (measured: 30 vs 20 us per launch).
+  float zero_v;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
+#ifndef SC_PF
+#define SC_PF 1
+#endif
+#define SC_LD3(set_, c_)                                                                                 \
+  {                                                                                                      \
+    fr[set_][0] = *reinterpret_cast<const uint4*>(lds + fa[c_]);                                         \
+    fr[set_][1] = *reinterpret_cast<const uint4*>(lds + fa[c_] + 32 * ROWB);                             \
+    fr[set_][2] = *reinterpret_cast<const uint4*>(lds + fa[c_] + 64 * ROWB);                             \
+  }
+#define SC_MFMA6(hi_, lo_, c_)                                                                           \
+  lo_ = SC_MFMA(b3, a1[c_], lo_);                                                                        \
+  hi_ = SC_MFMA(b1, a1[c_], hi_);                                                                        \
+  lo_ = SC_MFMA(b1, a3[c_], lo_);                                                                        \
+  lo_ = SC_MFMA(b2, a2[c_], lo_);                                                                        \
+  lo_ = SC_MFMA(b2, a1[c_], lo_);                                                                        \
+  lo_ = SC_MFMA(b1, a2[c_], lo_);
+  // the finished word (hw_: bit i = value i = column 8 (i / 4) + 4 kg + i % 4 of the tile, upper 16 bits garbage):
+  // the two halves of the wave meet through v_permlane32_swap
+#define SC_WORD(hw_, j_)                                                                                 \
+  {                                                                                                      \
+    const uint32_t hh = (hw_) & 0xFFFFu;                                                                 \
+    cnt += __popc(hh);                                                                                   \
+    const uint32_t w = ((hh & 0xFu) | ((hh & 0xF0u) << 4) | ((hh & 0xF00u) << 8) | ((hh & 0xF000u) << 12)) << (4 * kg); \
+    const auto sw = __builtin_amdgcn_permlane32_swap(w, w, false, false);                                \
+    wptr[(j_) * 128] = sw[0] | sw[1];                                                                    \
+  }
+#ifdef SC_ABL_NOEPI
+#define SC_EPI_ON(x_) false
+#else
+#define SC_EPI_ON(x_) (x_)
+#endif
+  // the hinge of the previous tile starts in chunk SC_EPI_C0 of a tile and takes SC_EPI_V values per chunk
+#ifndef SC_EPI_C0
+#define SC_EPI_C0 0
+#endif
+#ifndef SC_EPI_V
+#define SC_EPI_V VPC
+#endif
+  // SC_ABL_EPI_NOREAD: the hinge arithmetic runs on a register that is NOT an accumulator; SC_ABL_EPI_NOWRITE: the
+  // accumulators are not re-initialised (both: timing only)
+#ifdef SC_ABL_EPI_NOREAD
+#define SC_EPI_READ(x_) (bvn[i >> 2].x + tm1)
+#else
+#define SC_EPI_READ(x_) (x_)
+#endif
+#ifdef SC_ABL_EPI_NOWRITE
+#define SC_EPI_WRITE(x_)
+#else
+#define SC_EPI_WRITE(x_) x_
+#endif
+  // one tile: MFMAs into (hi_, lo_).  EPI_: the previous tile's accumulators (hy_, ly_) are turned into hinge bits /
+  // sums and re-initialised from bvn; jw_ >= 0: the word of tile jw_ (finished one tile ago) is assembled and stored in
+  // chunk 0; jb0_ / jb_: the tiles whose bias quad 0 (chunk 0) / quads 1..3 (later chunks) are re-read -- see below;
+  // dl_: byte step to the next tile's image; BAR_: the stage barrier E in the middle of this tile
+#define SC_TILE(hi_, lo_, hy_, ly_, EPI_, jw_, jb0_, jb_, dl_, BAR_)                                     \
+  {                                                                                                      \
+    const uint32_t dl = (uint32_t)(dl_);                                                                 \
+    _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                    \
+      if ((BAR_) && c == NCH / 2) sc_barrier();                                                          \
+      const bf16x8 b1 = __builtin_bit_cast(bf16x8, fr[c % 4][0]), b2 = __builtin_bit_cast(bf16x8, fr[c % 4][1]), \
+                   b3 = __builtin_bit_cast(bf16x8, fr[c % 4][2]);                                        \
+      SC_LD3((c + SC_PF) % 4, (c + SC_PF) % NCH)   /* (past the tile's end: fa[] already points into the next image) */ \
+      /* the bias quads are re-read one by one, each in the chunk after its last use (quad g serves the values */ \
+      /* 4 g .. 4 g + 3), with the bias of the tile after next (jb_); a quad used up to the tile's last chunk is */ \
+      /* re-read in the NEXT tile's chunk 0 (then as jb0_ = that tile's next tile) */                   \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
+        const int lastc = SC_EPI_C0 + (15 - 4 * g) / SC_EPI_V;          /* chunk of the quad's last use */ \
+        if (lastc + 1 < NCH ? c == lastc + 1 : c == 0)                                                   \
+          bvn[g] = *reinterpret_cast<const float4*>(sbias + (lastc + 1 < NCH ? (jb_) : (jb0_)) * 32 + 4 * kg + 8 * g); \
+      }                                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                 \
+      SC_MFMA6(hi_, lo_, c)                                                                              \
+      fa[c] += dl;                                                                                       \
+      if (c == 0 && (jw_) >= 0) {                                                                        \
+        const uint32_t hw = h;                                                                           \
+        SC_WORD(hw, jw_)                                                                                 \
+      }                                                                                                  \
+      if (SC_EPI_ON(EPI_) && c >= SC_EPI_C0 && c < SC_EPI_C0 + 16 / SC_EPI_V) {                          \
+        _Pragma("unroll") for (int q = 0; q < SC_EPI_V; ++q) {                                           \
+          const int i = 15 - ((c - SC_EPI_C0) * SC_EPI_V + q);                                           \
+          const float nv = SC_EPI_READ(-hy_[i] - ly_[i]);                                                \
+          h = __builtin_amdgcn_alignbit(h, __float_as_uint(nv), 31);                                     \
+          rs += fmaxf(-nv, 0.f);                                                                         \
+          const float4 bq = bvn[i >> 2];                                                                 \
+          SC_EPI_WRITE(hy_[i] = ((i & 3) == 0 ? bq.x : (i & 3) == 1 ? bq.y : (i & 3) == 2 ? bq.z : bq.w) - tm1;) \
+          SC_EPI_WRITE({ float z_; asm volatile("v_mov_b32 %0, 0" : "=v"(z_)); ly_[i] = z_; })          \
+        }                                                                                                \
+      }                                                                                                  \
+      _Pragma("unroll") for (int m = 0; m < 6; ++m) {                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
+        if (c == 0) __builtin_amdgcn_sched_group_barrier(0x002, VPM + 3, 0);                             \
+        else __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);                                        \
+      }                                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                 \
+      if (SC_TRACE_CHUNKS || c == NCH - 1) { SC_T(1 + c) }                                               \
+    }                                                                                                    \
+  }
+#define SC_INIT(hi_, lo_, j_)                                                                            \
+  {                                                                                                      \
+    const float* bt = sbias + (j_) * 32 + 4 * kg;                                                        \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                      \
+      const float4 bv = *reinterpret_cast<const float4*>(bt + 8 * g);                                    \
+      hi_[4 * g] = bv.x - tm1; hi_[4 * g + 1] = bv.y - tm1; hi_[4 * g + 2] = bv.z - tm1; hi_[4 * g + 3] = bv.w - tm1; \
+    }                                                                                                    \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) lo_[e] = zero_v;                                      \
+  }
+  // byte offset of tile j's image in the ring, and the step from tile j to tile j + 1 (wave-uniform)
+  auto img = [&](int j) -> int { return ((j / TPS) % kScSlots) * kScStageBytes + (j % TPS) * TILEB; };
+  auto step = [&](int j) -> int { return img(j + 1) - img(j); };
+  SC_TDECL
+  SC_T(100)
+  sc_barrier();                                               // B0: stage 0 and the bias are in LDS
+  SC_T(101)
+  SC_INIT(hiA, loA, 0)
+  SC_INIT(hiB, loB, 1)
+#pragma unroll
+  for (int c = 0; c < SC_PF; ++c) SC_LD3(c, c)
+  // tile 0 -> A (no hinge to do yet); the stage barrier: in every tile at K = 128, in the odd ones at K = 64
+  auto tcl = [&](int j) -> int { return j < ntile ? j : ntile - 1; };
+  SC_TILE(hiA, loA, hiB, loB, false, -1, tcl(1), tcl(2), step(0), TPS == 1)
+  // tile 1 -> B with the hinge of tile 0 (A), A re-initialised for tile 2
+  SC_TILE(hiB, loB, hiA, loA, true, -1, tcl(2), tcl(3), step(1), true)
+#ifdef SC_ABL_ASMTILE
+  // ablation: the steady-state tiles as ONE hand-written asm block per tile (the probe's "TILE as compiled" stream:
+  // same MFMAs / reads / epilogue ops, registers pinned) inside the real kernel -- garbage results, the clock counts
+  {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    u32x4 q0 = {1, 2, 3, 4}, q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;
+    float f0 = 1.f, f1 = 2.f, f7 = 3.f;
+    uint32_t i0 = 5;
+    const float k0 = 1.0001f, k1 = 0.5f;
+    const uint32_t la = (uint32_t)(lane * 16);
+    for (int j = 2; j < ntile; ++j) {
+      if (TPS == 1 || (j & 1)) sc_barrier();
+      asm volatile(SC_ASMTILE_TEXT
+                   : [c0] "+{v[0:15]}"(c0), [c1] "+{v[16:31]}"(c1), [c2] "+{v[32:47]}"(c2), [c3] "+{v[48:63]}"(c3),
+                     [q0] "+v"(q0), [q1] "+v"(q1), [q2] "+v"(q2), [q3] "+v"(q3), [q4] "+v"(q4), [q5] "+v"(q5),
+                     [f0] "+v"(f0), [f1] "+v"(f1), [f7] "+v"(f7), [i0] "+v"(i0)
+                   : [k0] "v"(k0), [k1] "v"(k1), [la] "v"(la), [fa0] "v"(fa[0]), [fa1] "v"(fa[1]), [fa2] "v"(fa[2]),
+                     [fa3] "v"(fa[3]), [fa4] "v"(fa[4]), [fa5] "v"(fa[5]), [fa6] "v"(fa[6]), [fa7] "v"(fa[7])
+                   : "memory");
+      {
+        const uint32_t dl = (uint32_t)step(j);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) fa[c] += dl;
+      }
+      SC_T(8)
+    }
+    rs += f0 + f1 + f7 + c0[0] + c1[1] + c2[2] + c3[3] + (float)(i0 + q0.x + q1.x + q2.x + q3.x + q4.x + q5.x);
+  }
+#else
+  for (int j = 2; j + 1 < ntile; j += 2) {
+    // tile j -> A with the hinge of tile j - 1 (B) and the word of tile j - 2; B re-initialised for tile j + 1
+    SC_TILE(hiA, loA, hiB, loB, true, j - 2, tcl(j + 1), tcl(j + 2), step(j), TPS == 1)
+    // tile j + 1 -> B with the hinge of tile j (A) and the word of tile j - 1; A re-initialised for tile j + 2
+    SC_TILE(hiB, loB, hiA, loA, true, j - 1, tcl(j + 2), tcl(j + 3), step(j + 1), true)
+  }
+#endif
+  // tail: the word of tile ntile - 2 (h holds it), then the hinge and the word of the last tile (B)
+  SC_WORD(h, ntile - 2)
+#pragma unroll
+  for (int i = 15; i >= 0; --i) {
+    const float nv = -hiB[i] - loB[i];
+    h = __builtin_amdgcn_alignbit(h, __float_as_uint(nv), 31);
+    rs += fmaxf(-nv, 0.f);
+  }
+  SC_WORD(h, ntile - 1)
+  // the wave's words leave: lane (lr, kg) stores the tiles of parity kg (its own LDS writes: no barrier needed)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (ok) {
+    for (int j = kg; j < ntile; j += 2) bits[(col0 / 32 + j) * ldbits + row] = swords[j * 128 + wv * 32 + lr];
+  }
+#undef SC_LD3
+#undef SC_MFMA6
+#undef SC_TILE
+#undef SC_WORD
+#undef SC_INIT
+  rs += __shfl_xor(rs, 32, 64);
+  cnt += __shfl_xor(cnt, 32, 64);
+  if (kg == 0 && ok) {
+    rs_part[(int64_t)ch * B + row] = rs;
+    cnt_part[(int64_t)ch * B + row] = (float)cnt;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_sc_rows: workgroup = 32 batch rows (8 waves x 4 rows).  Per row: the column splits' partial sums in fixed
+// order, the user's positives that sit in the pool taken out again (their logit recomputed from the row's latent
+// and the pool row, the act bit cleared), loss = log(1 + s), g = gscale * w / (1 + s), dt = -g * cnt and the
+// rank-one terms dT = dt U, dU = dt T.  Per workgroup: g U as TRANSPOSED bf16 planes UgT [3][d][Bp] (the dI
+// operand), the act bits TRANSPOSED (bitsT[blk][s]: bit r = row 32 blk + r) and the bias-gradient partials
+// dbp[blk][s] = sum_r act[r][s] g[r].
+// ------------------------------------------------------------------------------------------------------------
+struct ScRows {
+  const float* rs_part;      // [nsplit][B]
+  const float* cnt_part;
+  int nsplit;
+  uint32_t* bits;            // word-major [S / 32][ldbits]
+  int64_t ldbits;
+  uint32_t* bitsT; int64_t ldbt;   // [Bp / 32][ldbt]
+  const float* tscore;       // [B]
+  const float* U; int64_t ldu;
+  const float* T; int64_t ldt;
+  const float* P; int64_t ldp;     // pool rows [S, d]
+  const float* pb;                 // pool bias [S] (nullable)
+  int d;
+  float gscale;
+  const float* row_w;              // nullable
+  float* batch_loss;               // [B] nullable
+  float* g_out;                    // [Bp]
+  float* dtscore; int64_t dts_stride;
+  float* dU; int64_t lddu;         // dt * T   (nullable)
+  float* dT; int64_t lddt;         // dt * U   (nullable)
+  uint16_t* UgT; int64_t ldug;     // [3][d][ldug]
+  float* dbp;                      // [Bp / 32][S]
+  const int32_t* hits;             // [B][kScHits]
+  const int32_t* nhit;             // [B]  (-1: walk the positives)
+  const float* pool_bad;           // [S / 32]: NaN where a block of pool rows / biases holds a non-finite value
+};
+
+__global__ __launch_bounds__(512) void k_sc_rows(ScRows a, PosMask pm, int64_t mask_rows, int64_t B, int64_t S) {
+  __shared__ float tile[32 * 129];              // g U of the block's rows, f32 [32][d + 1]
+  __shared__ uint32_t sbits[32 * 64];           // final act words of the rows [32][S / 32]
+  __shared__ float sg[32];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * 32;
+  const int nwords = (int)(S >> 5);
+  const int ld = a.d + 1;
+  const bool colok = lane * 4 < a.d;
+  // non-finite inputs poison the loss like an f32 chain would (the hinge itself drops a NaN logit: v > 0 is false)
+  const float pbad = sc_wsum(lane < (int)(S >> 5) ? a.pool_bad[lane] : 0.f);
+  constexpr int RPW = 4;                          // rows per wave, all loads of the four rows issued up front
+  float4 u[RPW], tr[RPW];
+  float s[RPW], c[RPW], t[RPW];
+  int nh[RPW];
+  uint32_t w0[RPW];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    const int64_t r = r0 + wv * RPW + q;
+    const bool live = r < B;
+    u[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    tr[q] = u[q];
+    s[q] = c[q] = t[q] = 0.f;
+    nh[q] = 0;
+    w0[q] = 0u;
+    if (live) {
+      for (int p = 0; p < a.nsplit; ++p) {                    // fixed order: bit-reproducible
+        s[q] += a.rs_part[(int64_t)p * B + r];
+        c[q] += a.cnt_part[(int64_t)p * B + r];
+      }
+      t[q] = a.tscore[r];
+      if (colok) {
+        u[q] = *reinterpret_cast<const float4*>(a.U + r * a.ldu + lane * 4);
+        tr[q] = *reinterpret_cast<const float4*>(a.T + r * a.ldt + lane * 4);
+      }
+      nh[q] = a.nhit[r];
+      if (lane < nwords) w0[q] = a.bits[(int64_t)lane * a.ldbits + r];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    const int rl = wv * RPW + q;
+    const int64_t r = r0 + rl;
+    const bool live = r < B;
+    uint32_t myw = w0[q];
+    float sq = s[q], cq = c[q];
+    const float4 uq = u[q], tq = tr[q];
+    if (live && nh[q] != 0) {
+      // the row's bit words live in the lanes (word w in lane w; S <= 2048): a slot the positives name twice is
+      // taken out once, and the write-back is one store per changed word
+      auto take_out = [&](int jj) {                   // jj wave-uniform
+        const uint32_t w = __shfl(myw, jj >> 5, 64);
+        if (!((w >> (jj & 31)) & 1u)) return;         // hinge not active there (or already taken out)
+        float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (colok) pr = *reinterpret_cast<const float4*>(a.P + (int64_t)jj * a.ldp + lane * 4);
+        const float x = sc_wsum(uq.x * pr.x + uq.y * pr.y + uq.z * pr.z + uq.w * pr.w) + (a.pb ? a.pb[jj] : 0.f);
+        const float v = x - t[q] + 1.f;
+        sq -= v > 0.f ? v : 0.f;
+        cq -= 1.f;
+        if (lane == (jj >> 5)) myw &= ~(1u << (jj & 31));
+      };
+      if (nh[q] > 0) {
+        const int myhit = lane < nh[q] ? a.hits[r * kScHits + lane] : 0;
+        for (int k = 0; k < nh[q]; ++k) take_out(__shfl(myhit, k, 64));
+      } else {                                        // long list: walk the positives here
+        const int usr = pm.user_ids[r % mask_rows];
+        const int beg = pm.pos_ptr[usr], end = pm.pos_ptr[usr + 1];
+        for (int p0 = beg; p0 < end; p0 += 64) {
+          const int p = p0 + lane;
+          int j = -1;
+          if (p < end) {
+            j = pos_slot(pm, pm.pos_items[p]);
+            if (j < 0 || j >= S) j = -1;
+          }
+          unsigned long long hm = __ballot(j >= 0);
+          while (hm) {
+            const int src = __builtin_ctzll(hm);
+            hm &= hm - 1;
+            take_out(__shfl(j, src, 64));
+          }
+        }
+      }
+      if (lane < nwords && myw != w0[q]) a.bits[(int64_t)lane * a.ldbits + r] = myw;
+    }
+    sq = fmaxf(sq, 0.f) + (pbad + sc_wsum(((uq.x + uq.y) + (uq.z + uq.w) + (tq.x + tq.y) + (tq.z + tq.w)) * 0.f) + t[q] * 0.f);
+    const float g = live ? a.gscale * (a.row_w ? a.row_w[r] : 1.f) / (1.f + sq) : 0.f;
+    const float dt = -g * cq;
+    if (lane == 0) {
+      sg[rl] = g;
+      if (live) {
+        if (a.batch_loss) a.batch_loss[r] = logf(1.f + sq);
+        if (a.dtscore) a.dtscore[r * a.dts_stride] = dt;
+      }
+      a.g_out[r] = g;                                 // (rows past B inside the padded length: 0)
+    }
+    if (lane < nwords) sbits[rl * 64 + lane] = myw;
+    if (colok) {
+      if (live) {
+        if (a.dT) *reinterpret_cast<float4*>(a.dT + r * a.lddt + lane * 4) = make_float4(dt * uq.x, dt * uq.y, dt * uq.z, dt * uq.w);
+        if (a.dU) *reinterpret_cast<float4*>(a.dU + r * a.lddu + lane * 4) = make_float4(dt * tq.x, dt * tq.y, dt * tq.z, dt * tq.w);
+      }
+      float* tp = tile + rl * ld + lane * 4;
+      tp[0] = g * uq.x; tp[1] = g * uq.y; tp[2] = g * uq.z; tp[3] = g * uq.w;
+    }
+  }
+  __syncthreads();
+  // g U -> transposed planes, 32 consecutive k (= batch rows) per column n
+  sc_emit_planes_t(tile, ld, 32, a.d, a.UgT, (int64_t)a.d * a.ldug, a.ldug, r0, tid, 512);
+  // act bits transposed + the bias-gradient partial of the block
+  for (int col = tid; col < S; col += 512) {
+    const uint32_t* wp = sbits + (col >> 5);
+    const int sh = col & 31;
+    uint32_t word = 0u;
+    float db = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      const uint32_t b = (wp[r * 64] >> sh) & 1u;
+      word |= b << r;
+      db += b ? sg[r] : 0.f;
+    }
+    a.bitsT[(int64_t)blockIdx.x * a.ldbt + col] = word;
+    a.dbp[(int64_t)blockIdx.x * S + col] = db;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_sc_bits: C[m, n] (+)= sum_k act[m][k] X[k][n] with act a 0/1 matrix given as bits, word-major:
+// act[m][k] = bit (k & 31) of bits[(k >> 5) * ldw + m], and X as TRANSPOSED bf16 planes XT [3][N][ldx].
+// Workgroup = 256 m x 32 n x one K slice; compute wave = 64 m (two m-tiles) x the n-tile: per 16-chunk three plane
+// fragments from LDS (FIRST operand, rows = n), two act fragments expanded from the lane's own bit words in ten
+// VALU instructions each (v_bfe, v_lshl_or, 4 x (v_and, v_mul_u32_u24): exact 0.0 / 1.0 bf16), six MFMAs.
+//   SLICED == false (dU):  C[m, :] = beta C[m, :] + g[m] * acc        (one slice = all of K)
+//   SLICED == true  (dI):  part[slice][m, :] = acc                    (k_sc_tn_reduce adds the slices up)
+// Stages of 128 k; loaders as in k_sc_hinge.  K (= Kp) is a multiple of 128, bits / planes zero-padded up to it.
+// ------------------------------------------------------------------------------------------------------------
+template <bool SLICED>
+__global__ __launch_bounds__(512) void k_sc_bits(int64_t M, int N, int64_t kslice, int64_t Kp,
+                                                 const uint32_t* __restrict__ bits, int64_t ldw,
+                                                 const uint16_t* __restrict__ XT, int64_t ldx, float beta,
+                                                 float* __restrict__ C, int64_t ldc, const float* __restrict__ gvec) {
+  constexpr int ROWB = 256;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];      // [kScSlots][24 KB] planes, [kScSlots][4][256] bit words
+  char* ldsw = lds + kScSlots * kScStageBytes;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int ntn = N / 32;
+  const int64_t mblocks = (M + 255) / 256;
+  int64_t bid = blockIdx.x;
+  const int nt = (int)(bid % ntn);
+  bid /= ntn;
+  const int64_t mb = bid % mblocks;
+  const int64_t sl = bid / mblocks;
+  const int64_t k0 = sl * kslice;
+  const int64_t kend = k0 + kslice < Kp ? k0 + kslice : Kp;
+  const int nstage = (int)((kend - k0) / 128);
+
+  if (wv >= 4) {
+    ScLoader<ROWB> ld;
+    ld.init(reinterpret_cast<const char*>(XT), (int64_t)N * ldx * 2, ldx * 2, (int64_t)nt * 32, k0 * 2, wv - 4, lane, N);
+    ld.stage_step = 256;
+    // ... and the stage's act words: loader wave q fetches word row (k0 / 32 + 4 st + q), rows mb * 256 .. + 256 (one
+    // 1 KiB piece: the compute waves issue no global memory instruction in their loop)
+    ld.srcx = reinterpret_cast<const char*>(bits + ((k0 >> 5) + (wv - 4)) * ldw + mb * 256 + lane * 4);
+    ld.stepx = 4 * ldw * 4;
+    sc_loader_loop<ROWB, true>(ld, lds, nstage, ldsw, wv - 4);
+    return;
+  }
+
+  const int lr = lane & 31, kg = lane >> 5;
+  const int64_t m_a = mb * 256 + wv * 64 + lr, m_b = m_a + 32;
+  const bool ok_a = m_a < M, ok_b = m_b < M;
+  // (the stream of a stage is laid out by hand, chunk by chunk -- see k_sc_hinge)
+  uint32_t fa[8];                                              // LDS byte address of the lane's fragment of chunk c
+#pragma unroll
+  for (int c = 0; c < 8; ++c) fa[c] = (uint32_t)(lr * ROWB + 16 * ((2 * c + kg) ^ sc_swz<ROWB>(lr)));
+  f32x16 hi0 = {0}, lo0 = {0}, hi1 = {0}, lo1 = {0};
+  // 8 bits -> four dwords of two bf16 (0.0 / 1.0) each: y = b | b << 15 puts bit 2 j at position 2 j and bit 2 j + 1
+  // at position 2 j + 16; (y & (0x10001 << 2 j)) * (0x3F80 >> 2 j) is the pair, no carries: ten VALU per fragment
+#define SC_EXPAND(dst_, x_, odd_)                                                                       \
+  {                                                                                                      \
+    const uint32_t b = __builtin_amdgcn_ubfe((x_), (odd_) ? 16 : 0, 8);                                  \
+    const uint32_t y = b | (b << 15);                                                                    \
+    dst_ = make_uint4(__umul24(y & 0x00010001u, 0x3F80u), __umul24(y & 0x00040004u, 0x0FE0u),            \
+                      __umul24(y & 0x00100010u, 0x03F8u), __umul24(y & 0x00400040u, 0x00FEu));           \
+  }
+#define SC_LD3(c_)                                                                                       \
+  {                                                                                                      \
+    f1 = *reinterpret_cast<const uint4*>(lds + fa[c_]);                                                  \
+    f2 = *reinterpret_cast<const uint4*>(lds + fa[c_] + 32 * ROWB);                                      \
+    f3 = *reinterpret_cast<const uint4*>(lds + fa[c_] + 64 * ROWB);                                      \
+  }
+  // the bit words of the stage being computed (pre-shifted by 8 kg: the lane's bytes are 0 and 2 of each word) and
+  // of the next one (raw), both m-tiles, from the loaders' LDS images [slot][4 word rows][256 rows]; rows past M masked
+  const uint32_t mk_a = ok_a ? 0xFFFFFFFFu : 0u, mk_b = ok_b ? 0xFFFFFFFFu : 0u;
+  const uint32_t* wl = reinterpret_cast<const uint32_t*>(ldsw) + wv * 64 + lr;
+  uint32_t wa[4], wb[4], na[4], nb[4];
+  uint4 f1, f2, f3, ea, eb;
+  sc_barrier();                                               // B0
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    wa[q] = (wl[q * 256] & mk_a) >> (8 * kg);
+    wb[q] = (wl[q * 256 + 32] & mk_b) >> (8 * kg);
+  }
+  SC_EXPAND(ea, wa[0], 0)
+  SC_EXPAND(eb, wb[0], 0)
+  SC_LD3(0)
+  for (int st = 0; st < nstage; ++st) {
+    const uint32_t dl = (uint32_t)((((st + 1) % kScSlots) - (st % kScSlots)) * kScStageBytes);
+    const uint32_t* wn = wl + ((st + 1) % kScSlots) * 1024;   // next stage's words (its image is there after E(st))
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (c == 4) {
+        sc_barrier();                                         // E(st), in the middle of the stage (sc_loader_loop)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          na[q] = wn[q * 256];
+          nb[q] = wn[q * 256 + 32];
+        }
+      }
+      const bf16x8 p1 = __builtin_bit_cast(bf16x8, f1), p2 = __builtin_bit_cast(bf16x8, f2),
+                   p3 = __builtin_bit_cast(bf16x8, f3);
+      const bf16x8 aa = __builtin_bit_cast(bf16x8, ea), ab = __builtin_bit_cast(bf16x8, eb);
+      if (c + 1 < 8) SC_LD3(c + 1)
+      else SC_LD3(0)                                          // (fa[0] already points into the next stage's image)
+      __builtin_amdgcn_sched_barrier(0);
+      hi0 = SC_MFMA(p1, aa, hi0);
+      hi1 = SC_MFMA(p1, ab, hi1);
+      lo0 = SC_MFMA(p2, aa, lo0);
+      lo1 = SC_MFMA(p2, ab, lo1);
+      lo0 = SC_MFMA(p3, aa, lo0);
+      lo1 = SC_MFMA(p3, ab, lo1);
+      fa[c] += dl;
+      if (c + 1 < 8) {                                        // the act fragments of chunk c + 1
+        SC_EXPAND(ea, wa[(c + 1) >> 1], (c + 1) & 1)
+        SC_EXPAND(eb, wb[(c + 1) >> 1], (c + 1) & 1)
+      } else {                                                // ... of the next stage's chunk 0; its words move in
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          wa[q] = (na[q] & mk_a) >> (8 * kg);
+          wb[q] = (nb[q] & mk_b) >> (8 * kg);
+        }
+        SC_EXPAND(ea, wa[0], 0)
+        SC_EXPAND(eb, wb[0], 0)
+      }
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (c + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#undef SC_EXPAND
+#undef SC_LD3
+  // epilogue: lane = output row m (one per m-tile), columns nt * 32 + 8 g + 4 kg + 0..3
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int64_t m = t ? m_b : m_a;
+    if (!(t ? ok_b : ok_a)) continue;
+    const f32x16& hi = t ? hi1 : hi0;
+    const f32x16& lo = t ? lo1 : lo0;
+    if (!SLICED) {
+      const float gm = gvec ? gvec[m] : 1.f;
+      float* crow = C + m * ldc + nt * 32 + 4 * kg;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4* cp4 = reinterpret_cast<float4*>(crow + 8 * g);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (beta != 0.f) {
+          o = *cp4;
+          o.x *= beta; o.y *= beta; o.z *= beta; o.w *= beta;
+        }
+        o.x += gm * (hi[4 * g] + lo[4 * g]);
+        o.y += gm * (hi[4 * g + 1] + lo[4 * g + 1]);
+        o.z += gm * (hi[4 * g + 2] + lo[4 * g + 2]);
+        o.w += gm * (hi[4 * g + 3] + lo[4 * g + 3]);
+        *cp4 = o;
+      }
+    } else {
+      float* prow = C + (sl * M + m) * (int64_t)N + nt * 32 + 4 * kg;             // C = partials [slices][M][N]
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(prow + 8 * g) =
+            make_float4(hi[4 * g] + lo[4 * g], hi[4 * g + 1] + lo[4 * g + 1], hi[4 * g + 2] + lo[4 * g + 2],
+                        hi[4 * g + 3] + lo[4 * g + 3]);
+    }
+  }
+}
+
+// dI[m, :] = beta dI[m, :] + sum_slices part[sl][m, :]   (fixed order); the LAST blocks of the grid (dbblocks of them, 64
+// columns each): db[m] = sum_blocks dbp[blk][m] -- four waves take a quarter of the partial rows each (coalesced
+// 256-byte rows, independent loads), combined in wave order
+__global__ __launch_bounds__(256) void k_sc_tn_reduce(const float* __restrict__ part, int nsl, int64_t M, int N,
+                                                      float beta, float* __restrict__ C, int64_t ldc,
+                                                      const float* __restrict__ dbp, int64_t nblk,
+                                                      float* __restrict__ db, int dbblocks) {
+  __shared__ float sp[4][64];
+  const int nmain = (int)gridDim.x - dbblocks;
+  if ((int)blockIdx.x >= nmain) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t m = (int64_t)((int)blockIdx.x - nmain) * 64 + lane;
+    const int64_t per = (nblk + 3) / 4, b0 = wv * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (m < M) {
+      int64_t b = b0;
+      for (; b + 3 < b1; b += 4) {
+        a0 += dbp[b * M + m]; a1 += dbp[(b + 1) * M + m]; a2 += dbp[(b + 2) * M + m]; a3 += dbp[(b + 3) * M + m];
+      }
+      for (; b < b1; ++b) a0 += dbp[b * M + m];
+    }
+    sp[wv][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wv == 0 && m < M) db[m] = (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
+    return;
+  }
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = N / 4;
+  if (q < M * n4) {
+    const int64_t m = q / n4;
+    const int c = (int)(q % n4) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nsl; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(part + ((int64_t)s * M + m) * N + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float4* cp = reinterpret_cast<float4*>(C + m * ldc + c);
+    if (beta != 0.f) {
+      const float4 o = *cp;
+      acc.x += beta * o.x; acc.y += beta * o.y; acc.z += beta * o.z; acc.w += beta * o.w;
+    }
+    *cp = acc;
+  }
+}
+
+// db_steps[t][s] = sum of the bps block partials of time step t (fixed order)
+__global__ __launch_bounds__(256) void k_sc_db_steps(const float* __restrict__ dbp, int64_t bps, int64_t S, int64_t L,
+                                                     float* __restrict__ db_steps) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= L * S) return;
+  const int64_t t = q / S, s = q % S;
+  float acc = 0.f;
+  for (int64_t b = 0; b < bps; ++b) acc += dbp[(t * bps + b) * S + s];
+  db_steps[q] = acc;
+}
+
+size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+// Layout of the caller's scorer state (one buffer): everything the three launches of the forward leave for the two
+// backward products.  Offsets in bytes.
+struct ScLayout {
+  int64_t Bp, ldbits, ldbt, nblk;
+  int64_t ldpt, ldug;       // row strides (bf16 elements) of the TRANSPOSED planes PT [3][d][ldpt], UgT [3][d][ldug]: a
+                            // power-of-two stride (2 KB, 32 KB) would put the 32 rows of a stage into one or two
+                            // memory channels -- measured: the dI product 143 us instead of ~15
+  int nsplit, CW;
+  size_t bits, bitsT, g, t, rs, cnt, hits, nhit, Pp, PT, UgT, dbp, pbad, total;
+};
+
+static bool sc_layout(int64_t B, int64_t S, int d, ScLayout* L) {
+  if (!(d == 64 || d == 128) || S % 128 != 0 || S < 128 || S > 2048 || B < 1) return false;
+  L->Bp = (B + 127) / 128 * 128;
+  L->ldbits = (B + 255) / 256 * 256;      // rows of 256-word pieces: the backward kernels fetch them by LDS-DMA
+  L->ldbt = (S + 255) / 256 * 256;
+  L->nblk = L->Bp / 32;
+  L->ldpt = S + 128;
+  L->ldug = L->Bp + 128;
+  L->CW = S >= 1024 ? 512 : (S >= 256 ? (int)(S / 2) : (int)S);
+  L->nsplit = (int)(S / L->CW);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += al256(bytes); return at; };
+  L->bits = take((size_t)(S / 32) * L->ldbits * 4);
+  L->bitsT = take((size_t)L->nblk * L->ldbt * 4);
+  L->g = take((size_t)L->Bp * 4);
+  L->t = take((size_t)B * 4);
+  L->rs = take((size_t)L->nsplit * B * 4);
+  L->cnt = take((size_t)L->nsplit * B * 4);
+  L->hits = take((size_t)B * kScHits * 4);
+  L->nhit = take((size_t)B * 4);
+  L->Pp = take((size_t)3 * S * d * 2);
+  L->PT = take((size_t)3 * d * L->ldpt * 2);
+  L->UgT = take((size_t)3 * d * L->ldug * 2);
+  L->dbp = take((size_t)L->nblk * S * 4);
+  L->pbad = take(64 * 4);
+  L->total = o;
+  return true;
+}
+
+static int sc_raise_lds() {
+  // (per call: the attribute is per device and the call is cheap)
+  const int cap = 160 * 1024;
+  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_hinge<128>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_hinge<64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_bits<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_bits<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  return ARX_OK;
+}
+
+}  // namespace arx
+
+using namespace arx;
+
+extern "C" {
+
+#ifdef SC_TRACE
+int arx_sc_trace_read(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sc_trace), sizeof(g_sc_trace)); }
+#endif
+
+int arx_mw_scorer_supported(int64_t B, int64_t S, int d) {
+  ScLayout L;
+  return sc_layout(B, S, d, &L) ? 1 : 0;
+}
+
+size_t arx_mw_scorer_state_bytes(int64_t B, int64_t S, int d) {
+  ScLayout L;
+  return sc_layout(B, S, d, &L) ? L.total : 0;
+}
+
+/* offsets (bytes) of the state's regions a caller may look at: out[0] act bits (word-major [S / 32][out[1] = ld]),
+ * out[2] transposed bits [Bp / 32][out[5] = ld], out[3] g [Bp], out[4] Bp */
+int arx_mw_scorer_state_layout(int64_t B, int64_t S, int d, int64_t* out) {
+  ScLayout L;
+  ARX_CHECK_ARG(out && sc_layout(B, S, d, &L), "arx_mw_scorer_state_layout: shape not supported");
+  out[0] = (int64_t)L.bits;
+  out[1] = L.ldbits;
+  out[2] = (int64_t)L.bitsT;
+  out[3] = (int64_t)L.g;
+  out[4] = L.Bp;
+  out[5] = L.ldbt;
+  return ARX_OK;
+}
+
+int arx_mw_scorer_fwd_phases(const float* U, int64_t ldu, const float* P, int64_t ldp, const float* pbias,
+                             const float* T, int64_t ldt, const float* tbias, int64_t tb_stride, int d,
+                             const int32_t* user_ids, const int32_t* pos_ptr, const int32_t* pos_items,
+                             const int32_t* item2slot, int64_t mask_rows, float gscale, const float* row_w, int64_t B,
+                             int64_t S, float* batch_loss, float* tscore_out, float* dtscore, int64_t dtscore_stride,
+                             float* dU, int64_t lddu, float* dT, int64_t lddt, void* state, size_t state_bytes,
+                             int phases, void* stream) {
+  ARX_CHECK_ARG(U && P && T && user_ids && pos_ptr && pos_items && item2slot && state,
+                "arx_mw_scorer_fwd: null pointer");
+  ScLayout L;
+  const bool ok = sc_layout(B, S, d, &L) && ldu % 4 == 0 && ldp % 4 == 0 && ldt % 4 == 0 && ldu >= d && ldp >= d &&
+                  ldt >= d && (!dU || (lddu % 4 == 0 && lddu >= d)) && (!dT || (lddt % 4 == 0 && lddt >= d)) &&
+                  ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(T) |
+                    reinterpret_cast<uintptr_t>(dU) | reinterpret_cast<uintptr_t>(dT) |
+                    reinterpret_cast<uintptr_t>(state)) & 15) == 0;
+  if (!ok) {
+    set_error("arx_mw_scorer_fwd: shape not supported (d in {64, 128}, S %% 128 == 0, 128 <= S <= 2048, 16-byte rows)");
+    return ARX_EUNSUPPORTED;
+  }
+  if (state_bytes < L.total) {
+    set_error("arx_mw_scorer_fwd: state too small (%zu < %zu)", state_bytes, L.total);
+    return ARX_EWORKSPACE;
+  }
+  if (int rc = sc_raise_lds()) return rc;
+  hipStream_t s = as_stream(stream);
+  char* st = reinterpret_cast<char*>(state);
+  uint32_t* bits = reinterpret_cast<uint32_t*>(st + L.bits);
+  float* t = reinterpret_cast<float*>(st + L.t);
+  float* rs_part = reinterpret_cast<float*>(st + L.rs);
+  float* cnt_part = reinterpret_cast<float*>(st + L.cnt);
+  int32_t* hits = reinterpret_cast<int32_t*>(st + L.hits);
+  int32_t* nhit = reinterpret_cast<int32_t*>(st + L.nhit);
+  uint16_t* Pp = reinterpret_cast<uint16_t*>(st + L.Pp);
+  uint16_t* PT = reinterpret_cast<uint16_t*>(st + L.PT);
+  const PosMask pm = make_pos_mask(user_ids, pos_ptr, pos_items, item2slot);
+  const int64_t mrows = mask_rows > 0 ? mask_rows : B;
+  if (phases & 1) {
+    const int64_t grid = S / 32 + ceil_div(B, 4);
+    k_sc_prep<<<(int)grid, 256, 0, s>>>(P, ldp, S, d, pbias, Pp, PT, L.ldpt, reinterpret_cast<float*>(st + L.pbad), pm,
+                                        mrows, B, hits, nhit);
+    ARX_CHECK_LAUNCH();
+  }
+  if (phases & 2) {
+    const int64_t grid = ceil_div(B, 128) * L.nsplit;
+    const size_t lds = (size_t)kScSlots * kScStageBytes + (size_t)L.CW * 4 + (size_t)(L.CW / 32) * 128 * 4;
+    if (d == 128)
+      k_sc_hinge<128><<<(int)grid, 512, lds, s>>>(B, S, L.CW, U, ldu, T, ldt, tbias, tb_stride > 0 ? tb_stride : 1, Pp,
+                                                  pbias, t, tscore_out, bits, L.ldbits, rs_part, cnt_part);
+    else
+      k_sc_hinge<64><<<(int)grid, 512, lds, s>>>(B, S, L.CW, U, ldu, T, ldt, tbias, tb_stride > 0 ? tb_stride : 1, Pp,
+                                                 pbias, t, tscore_out, bits, L.ldbits, rs_part, cnt_part);
+    ARX_CHECK_LAUNCH();
+  }
+  if (phases & 4) {
+    ScRows a{rs_part, cnt_part, L.nsplit, bits, L.ldbits, reinterpret_cast<uint32_t*>(st + L.bitsT), L.ldbt, t, U, ldu, T, ldt,
+             P, ldp, pbias, d, gscale, row_w, batch_loss, reinterpret_cast<float*>(st + L.g), dtscore,
+             dtscore_stride > 0 ? dtscore_stride : 1, dU, lddu, dT, lddt, reinterpret_cast<uint16_t*>(st + L.UgT), L.ldug,
+             reinterpret_cast<float*>(st + L.dbp), hits, nhit, reinterpret_cast<const float*>(st + L.pbad)};
+    k_sc_rows<<<(int)L.nblk, 512, 0, s>>>(a, pm, mrows, B, S);
+    ARX_CHECK_LAUNCH();
+  }
+  return ARX_OK;
+}
+
+int arx_mw_scorer_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp, const float* pbias, const float* T,
+                      int64_t ldt, const float* tbias, int64_t tb_stride, int d, const int32_t* user_ids,
+                      const int32_t* pos_ptr, const int32_t* pos_items, const int32_t* item2slot, int64_t mask_rows,
+                      float gscale, const float* row_w, int64_t B, int64_t S, float* batch_loss, float* tscore_out,
+                      float* dtscore, int64_t dtscore_stride, float* dU, int64_t lddu, float* dT, int64_t lddt,
+                      void* state, size_t state_bytes, void* stream) {
+  return arx_mw_scorer_fwd_phases(U, ldu, P, ldp, pbias, T, ldt, tbias, tb_stride, d, user_ids, pos_ptr, pos_items,
+                                  item2slot, mask_rows, gscale, row_w, B, S, batch_loss, tscore_out, dtscore,
+                                  dtscore_stride, dU, lddu, dT, lddt, state, state_bytes, 7, stream);
+}
+
+/* dU[m, :] = beta dU[m, :] + g[m] * sum_s act[m][s] P[s, :]   (embed_attribute.py:171 backward, latent side) */
+int arx_mw_scorer_bwd_du(int64_t B, int64_t S, int d, const void* state, float beta, float* dU, int64_t lddu,
+                         void* stream) {
+  ScLayout L;
+  ARX_CHECK_ARG(state && dU && sc_layout(B, S, d, &L), "arx_mw_scorer_bwd_du: bad argument / shape");
+  ARX_CHECK_ARG(lddu % 4 == 0 && lddu >= d && (reinterpret_cast<uintptr_t>(dU) & 15) == 0,
+                "arx_mw_scorer_bwd_du: dU rows must be 16-byte aligned");
+  if (int rc = sc_raise_lds()) return rc;
+  const char* st = reinterpret_cast<const char*>(state);
+  const int64_t grid = ceil_div(B, 256) * (d / 32);
+  k_sc_bits<false><<<(int)grid, 512, (size_t)kScSlots * (kScStageBytes + 4096), as_stream(stream)>>>(
+      B, d, S, S, reinterpret_cast<const uint32_t*>(st + L.bits), L.ldbits,
+      reinterpret_cast<const uint16_t*>(st + L.PT), L.ldpt, beta, dU, lddu, reinterpret_cast<const float*>(st + L.g));
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+size_t arx_mw_scorer_bwd_di_workspace_bytes(int64_t B, int64_t S, int d, int64_t step_rows) {
+  ScLayout L;
+  if (!sc_layout(B, S, d, &L)) return 0;
+  int64_t ks = step_rows > 0 ? step_rows : 0;
+  if (ks <= 0) {
+    const int64_t wg = ceil_div(S, 256) * (d / 32);
+    int64_t nsl = ceil_div((int64_t)cu_count(), wg);
+    ks = ceil_div(ceil_div(L.Bp, nsl), 128) * 128;
+  }
+  const int64_t nsl = ceil_div(L.Bp, ks);
+  return (size_t)nsl * S * d * 4 + 256;
+}
+
+/* dI[s, :] = beta dI[s, :] + sum_r act[r][s] g[r] U[r, :], db[s] = sum_r act[r][s] g[r]
+ * (embed_attribute.py:171 backward, pool side).  step_rows > 0 (the sequence model: B = L * step_rows time-major
+ * rows, step_rows % 128 == 0): the products of the single steps are kept as well -- dI_steps [L][S][d] (may alias
+ * the workspace's slices: pass NULL to use the workspace) and db_steps [L][S] -- for TF-1.0's per-unrolled-step
+ * clip norm (seqModel.py:179-180). */
+int arx_mw_scorer_bwd_di(int64_t B, int64_t S, int d, const void* state, int64_t step_rows, float beta, float* dI,
+                         int64_t lddi, float* db, float* dI_steps, float* db_steps, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  ScLayout L;
+  ARX_CHECK_ARG(state && dI && sc_layout(B, S, d, &L), "arx_mw_scorer_bwd_di: bad argument / shape");
+  ARX_CHECK_ARG(lddi % 4 == 0 && lddi >= d && (reinterpret_cast<uintptr_t>(dI) & 15) == 0,
+                "arx_mw_scorer_bwd_di: dI rows must be 16-byte aligned");
+  ARX_CHECK_ARG(step_rows == 0 || (step_rows % 128 == 0 && B % step_rows == 0),
+                "arx_mw_scorer_bwd_di: step_rows must divide B and be a multiple of 128");
+  if (int rc = sc_raise_lds()) return rc;
+  int64_t ks = step_rows;
+  if (ks <= 0) {
+    const int64_t wg = ceil_div(S, 256) * (d / 32);
+    const int64_t nsl0 = ceil_div((int64_t)cu_count(), wg);
+    ks = ceil_div(ceil_div(L.Bp, nsl0), 128) * 128;
+  }
+  const int64_t nsl = ceil_div(L.Bp, ks);
+  float* part = dI_steps;
+  if (!part) {
+    const size_t need = (size_t)nsl * S * d * 4;
+    if (!workspace || workspace_bytes < need) {
+      set_error("arx_mw_scorer_bwd_di: workspace too small (%zu < %zu)", workspace_bytes, need);
+      return ARX_EWORKSPACE;
+    }
+    part = reinterpret_cast<float*>(workspace);
+  }
+  hipStream_t s = as_stream(stream);
+  const char* st = reinterpret_cast<const char*>(state);
+  const int64_t grid = ceil_div(S, 256) * (d / 32) * nsl;
+  k_sc_bits<true><<<(int)grid, 512, (size_t)kScSlots * (kScStageBytes + 4096), s>>>(
+      S, d, ks, L.Bp, reinterpret_cast<const uint32_t*>(st + L.bitsT), L.ldbt,
+      reinterpret_cast<const uint16_t*>(st + L.UgT), L.ldug, 0.f, part, d, nullptr);
+  ARX_CHECK_LAUNCH();
+  const float* dbp = reinterpret_cast<const float*>(st + L.dbp);
+  const int dbblocks = db ? (int)ceil_div(S, 64) : 0;
+  k_sc_tn_reduce<<<(int)ceil_div(S * (d / 4), 256) + dbblocks, 256, 0, s>>>(part, (int)nsl, S, d, beta, dI, lddi, dbp,
+                                                                           L.nblk, db, dbblocks);
+  ARX_CHECK_LAUNCH();
+  if (db_steps && step_rows > 0) {
+    const int64_t Lsteps = B / step_rows, bps = step_rows / 32;
+    k_sc_db_steps<<<(int)ceil_div(Lsteps * S, 256), 256, 0, s>>>(dbp, bps, S, Lsteps, db_steps);
+    ARX_CHECK_LAUNCH();
+  }
+  return ARX_OK;
+}
+
+}  // extern "C"

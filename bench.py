@@ -209,27 +209,32 @@ def kernel_rooflines(model, d):
     # --- GEMMs (MFMA bound) ---
     flops = 2.0 * B * S * d
     if pred.fused_into_loss:
-        # 'mw' train plans: the scorer GEMM carries the hinge in its epilogue (act bits instead of
-        # logits), the backward products read the bits (arx_mw_gemm_fused_fwd / arx_gemm_bits_f32)
+        # 'mw' train plans (default): csrc/scorer.hip -- no logits / dlogits; each launch of the forward timed alone
+        # (arx_mw_scorer_fwd_phases), the hinge GEMM and the two bit-operand products priced against the bf16 pipe
         bl = [n for n in plan.order if isinstance(n, G.BatchLoss) and n.gemm_fused][0]
         ms = bl.mask
         ptr, items = ms.pos_getter()
         uid, i2s = ms.user_ids.value, ms.slot_map_getter()
         tgt = bl.inputs[1]
         lat_, te = tgt.inputs
-        t = _evt_time_ms(lambda: ops.mw_gemm_fused_fwd(
-            lat_.value, pool.value, pool.bias_value, te.value, te.bias_value, uid, ptr, items, i2s, bl.value,
-            tgt.value, pred.act_bits, pred.gvec, pred.Ug, tgt.grad, lat_.grad, te.grad, bl.gscale, ws,
-            mask_rows=bl.mask_rows), 50)
-        res['gemm_logits_hinge_fused'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9, peak=BX6_PEAK_TF,
-                                              note="target score + scorer GEMM with hinge epilogue + row kernel "
-                                                   "(several launches: not a single-kernel roofline)")
+        sc = pred.scorer
+
+        def fwd(ph):
+            sc.fwd(lat_.value, pool.value, pool.bias_value, te.value, te.bias_value, uid, ptr, items, i2s, bl.value,
+                   tgt.value, tgt.grad, lat_.grad, te.grad, bl.gscale, mask_rows=bl.mask_rows, phases=ph)
+        t = _evt_time_ms(lambda: fwd(1), 50)
+        res['scorer_prep'] = dict(ms=t, note="pool rows -> bf16 planes (both layouts) + positives' hit lists")
+        t = _evt_time_ms(lambda: fwd(2), 50)
+        res['gemm_logits_hinge'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9, peak=BX6_PEAK_TF,
+                                        note="k_sc_hinge: target score + scorer GEMM + hinge epilogue (act bits)")
+        t = _evt_time_ms(lambda: fwd(4), 50)
+        res['scorer_rows'] = dict(ms=t, note="loss, g, rank-one terms, g U planes, transposed bits")
         gU, gP = latent.alloc_grad(), pool.alloc_grad()
-        t = _evt_time_ms(lambda: ops.gemm_bits(pred.act_bits, pool.value, gU, ws, beta=1.0, row_scale=pred.gvec), 50)
+        t = _evt_time_ms(lambda: sc.bwd_dU(gU, beta=1.0), 50)
         res['gemm_dU_bits'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9, peak=BX3_PEAK_TF)
-        t = _evt_time_ms(lambda: ops.gemm_bits(pred.act_bits, pred.Ug, gP, ws, transA=True, gvec=pred.gvec,
-                                               a_rowsum=pool.bias_grad), 50)
-        res['gemm_dI_bits'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9, peak=BX3_PEAK_TF)
+        t = _evt_time_ms(lambda: sc.bwd_dI(gP, db=pool.bias_grad), 50)
+        res['gemm_dI_bits'] = dict(ms=t, flops=flops, tflops=flops / t / 1e9, peak=BX3_PEAK_TF,
+                                   note="k_sc_bits over K slices + k_sc_tn_reduce")
     else:
         t = _evt_time_ms(lambda: ops.gemm(latent.value, pool.value, pred.value, ws, transB=True,
                                           col_bias=pool.bias_value), 50)

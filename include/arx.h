@@ -348,41 +348,60 @@ int arx_eval_warp_unmask(const float* U, int64_t ldu, const float* P, int64_t ld
 int arx_eval_finish(int mode, const float* acc0, const float* acc1, const float* tscore, int64_t B,
                     float* batch_loss, void* stream);
 
-/* 'mw' with the hinge folded into the scorer GEMM (embed_attribute.py:148-206 get_prediction on
- * the sampled pool + :208-220 get_target_score + :641-649 the 'mw' loss, fwd + bwd): the [B, S]
- * logits and their gradient never reach HBM.  Forward (three launches):
- *   t_r = U_r . T_r + tbias_r;   x = U . P^T + pbias  (fp32 MFMA, not stored);
- *   act[r, s] = mask[r, s] and (x[r, s] - t_r + 1 > 0)  -> act_bits, WORD-MAJOR: bit (s & 31) of
- *   act_bits[(s >> 5) * ldbits + r], ldbits >= B (so that the 32-slot words of consecutive rows are
- *   contiguous: what both backward products fetch per tile);
+/* ---- a8-a11 fused: the 'mw' scorer of a training step (csrc/scorer.hip) ----------------------------
+ * embed_attribute.py:148-206 get_prediction on the sampled pool + :208-220 get_target_score + :641-649 the
+ * 'mw' loss, forward and backward, WITHOUT [B, S] logits or dlogits in HBM, all three products on the bf16
+ * matrix pipe, f32-exact: every f32 operand is split exactly into three bf16 pieces, six of the nine piece
+ * products (the other three are below 2^-26 of the product) are accumulated in f32 with the small terms in
+ * their own accumulator; where one operand is the 0/1 hinge-activity matrix (exact in ONE piece) three do.
+ *
+ * arx_mw_scorer_fwd (three launches):
+ *   t_r = U_r . T_r + tbias_r;   x = U . P^T + pbias  (not stored);
+ *   act[r, s] = mask[r, s] and (x[r, s] - t_r + 1 > 0), one bit per logit, kept in `state`;
  *   loss_r = log(1 + sum_s act * (x - t + 1));  g_r = gscale * row_w_r / (1 + sum);  dt_r = -g_r * #act
- * with the mask built from the positives CSR as in arx_loss_mw_fwdbwd_pos.  Outputs: batch_loss
- * [B], tscore_out [B] (nullable), act_bits, g_out [B], Ug = g * U [B, d] (the B operand of the dI
- * product), dtscore (stride dtscore_stride), dU = dt * T and dT = dt * U (nullable).  The backward
- * products then read the bits: arx_gemm_bits_f32.  d in {32, 64, 128}, S % 32 == 0, S <= 2048.
- * workspace >= arx_mw_gemm_fused_workspace_bytes(B, S). */
-size_t arx_mw_gemm_fused_workspace_bytes(int64_t B, int64_t S);
-int arx_mw_gemm_fused_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp, const float* pbias,
-                          const float* T, int64_t ldt, const float* tbias, int64_t tb_stride, int d,
-                          const int32_t* user_ids, const int32_t* pos_ptr, const int32_t* pos_items,
-                          const int32_t* item2slot, int64_t mask_rows, float gscale, const float* row_w,
-                          int64_t B, int64_t S, float* batch_loss, float* tscore_out, uint32_t* act_bits,
-                          int64_t ldbits, float* g_out, float* Ug, int64_t ldug, float* dtscore,
-                          int64_t dtscore_stride, float* dU, int64_t lddu, float* dT, int64_t lddt,
-                          void* workspace, size_t workspace_bytes, void* stream);
-/* GEMM whose A operand is a 0/1 matrix given as bits (the act_bits above); fp32 MFMA, B and C fp32.
- * act[r][c] = bit (c & 31) of bits[(c >> 5) * ldw + r]  (word-major, ldw >= number of rows r).
- *   transA = 0:  C[m, :] = beta * C[m, :] + row_scale[m] * sum_k act[m][k] B[k, :]      (dU += g * (act . P))
- *   transA = 1:  C[m, :] = beta * C[m, :] + sum_k act[k][m] B[k, :],  a_rowsum[m] = sum_k act[k][m] gvec[k]
- *                                                                          (dI = act^T . (g * U), dbias)
- * row_scale nullable (1); gvec required for transA = 1, a_rowsum nullable.  32 < N <= 128, N % 4 == 0,
- * M >= 64, M % 4 == 0 (M % 32 == 0 for transA = 1), K % 32 == 0, 16-byte aligned B rows.
- * workspace >= arx_gemm_bits_workspace_bytes(transA, M, N, K). */
-size_t arx_gemm_bits_workspace_bytes(int transA, int64_t M, int64_t N, int64_t K);
-int arx_gemm_bits_f32(int transA, int64_t M, int64_t N, int64_t K, const uint32_t* bits, int64_t ldw,
-                      const float* B, int64_t ldb, float beta, float* C, int64_t ldc,
-                      const float* row_scale, const float* gvec, float* a_rowsum, void* workspace,
-                      size_t workspace_bytes, void* stream);
+ * with the mask built from the positives CSR as in arx_loss_mw_fwdbwd_pos (user of row r = user_ids[r %
+ * mask_rows]).  Outputs: batch_loss [B], tscore_out [B] (nullable), dtscore (stride dtscore_stride; nullable),
+ * dU = dt * T and dT = dt * U (rank-one terms of the target score, WRITTEN; nullable).  `state` keeps what the
+ * backward products read: the act bits in both orientations, g, the bf16 planes of P (both layouts) and of
+ * g * U, the bias-gradient partials.
+ * arx_mw_scorer_bwd_du:  dU[r, :] = beta dU[r, :] + g_r sum_s act[r, s] P[s, :]
+ * arx_mw_scorer_bwd_di:  dI[s, :] = beta dI[s, :] + sum_r act[r, s] g_r U[r, :],  db[s] = sum_r act[r, s] g_r;
+ *   step_rows > 0 (the sequence model: B = L * step_rows time-major rows, step_rows % 128 == 0): the products of
+ *   the single time steps are kept too -- dI_steps [L][S][d] (NULL: they live in the workspace only) and
+ *   db_steps [L][S] -- because TF-1.0's clip_by_global_norm squares one dense gradient per unrolled step
+ *   (seqModel.py:179-180).
+ * Shapes: d in {64, 128}, S % 128 == 0, 128 <= S <= 2048, any B >= 1; U / P / T / dU / dT / dI rows 16-byte
+ * aligned (ld % 4 == 0).  arx_mw_scorer_supported tells; callers take the unfused path (arx_gemm_f32 +
+ * arx_loss_mw_fused_pos) otherwise.  `state`: arx_mw_scorer_state_bytes(B, S, d) bytes, 256-byte aligned,
+ * ZEROED once by the caller, private to one (model, stream).  arx_mw_scorer_state_layout: byte offsets of the
+ * regions a caller may inspect -- out[0] act bits, word-major: bit (s & 31) of word [(s >> 5) * out[1] + r];
+ * out[2] the transposed bits: bit (r & 31) of word [(r >> 5) * out[5] + s]; out[3] g [out[4]]; out[4] = B rounded
+ * up to 128 (out: 6 values). */
+int arx_mw_scorer_supported(int64_t B, int64_t S, int d);
+size_t arx_mw_scorer_state_bytes(int64_t B, int64_t S, int d);
+int arx_mw_scorer_state_layout(int64_t B, int64_t S, int d, int64_t* out);
+int arx_mw_scorer_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp, const float* pbias, const float* T,
+                      int64_t ldt, const float* tbias, int64_t tb_stride, int d, const int32_t* user_ids,
+                      const int32_t* pos_ptr, const int32_t* pos_items, const int32_t* item2slot, int64_t mask_rows,
+                      float gscale, const float* row_w, int64_t B, int64_t S, float* batch_loss, float* tscore_out,
+                      float* dtscore, int64_t dtscore_stride, float* dU, int64_t lddu, float* dT, int64_t lddt,
+                      void* state, size_t state_bytes, void* stream);
+/* the same in parts -- phases: bit 0 the pool planes + the positives' hit lists (needs P and the ids only: may run
+ * ahead), bit 1 the hinge GEMM (target score, act bits, partial sums), bit 2 the row kernel (loss, g, rank-one
+ * terms, the g U planes); in this order on one stream.  arx_mw_scorer_fwd == phases 7. */
+int arx_mw_scorer_fwd_phases(const float* U, int64_t ldu, const float* P, int64_t ldp, const float* pbias,
+                             const float* T, int64_t ldt, const float* tbias, int64_t tb_stride, int d,
+                             const int32_t* user_ids, const int32_t* pos_ptr, const int32_t* pos_items,
+                             const int32_t* item2slot, int64_t mask_rows, float gscale, const float* row_w, int64_t B,
+                             int64_t S, float* batch_loss, float* tscore_out, float* dtscore, int64_t dtscore_stride,
+                             float* dU, int64_t lddu, float* dT, int64_t lddt, void* state, size_t state_bytes,
+                             int phases, void* stream);
+int arx_mw_scorer_bwd_du(int64_t B, int64_t S, int d, const void* state, float beta, float* dU, int64_t lddu,
+                         void* stream);
+size_t arx_mw_scorer_bwd_di_workspace_bytes(int64_t B, int64_t S, int d, int64_t step_rows);
+int arx_mw_scorer_bwd_di(int64_t B, int64_t S, int d, const void* state, int64_t step_rows, float beta, float* dI,
+                         int64_t lddi, float* db, float* dI_steps, float* db_steps, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* Sampled softmax ('mce').  BUILD-DEFINED: the reference accepts loss 'mce'
  * (embed_attribute.py:527 assert, :717 feed guard, run_hmf.py:31,100, lstm/run.py:447) but its

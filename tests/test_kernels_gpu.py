@@ -1325,11 +1325,15 @@ def _unpack_bits(words, n):
     return ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(w.shape[0], -1)[:, :n].astype(bool)
 
 
-@pytest.mark.parametrize("B,S,d", [(16384, 1024, 128), (320, 256, 64), (96, 64, 32), (1024, 2048, 128), (77, 96, 64)])
-def test_mw_gemm_fused_fwd(dev, B, S, d):
-    """'mw' with the hinge in the scorer GEMM's epilogue: loss, g, dt, rank-one terms and the act
-    BITS against the oracle's logits -> compute_loss('mw') -> compute_loss_bwd chain
-    (embed_attribute.py:148-206, 208-220, 641-649), positives of the row's user masked."""
+@pytest.mark.parametrize("B,S,d,mask_rows", [(16384, 1024, 128, 0), (320, 256, 64, 0), (1024, 2048, 128, 0),
+                                              (77, 128, 64, 0), (1, 128, 128, 0), (4096, 512, 64, 1024),
+                                              (200, 384, 128, 0)])
+def test_mw_scorer(dev, B, S, d, mask_rows):
+    """The fused 'mw' scorer (csrc/scorer.hip: arx_mw_scorer_fwd / _bwd_du / _bwd_di): target score, loss, g, dt, the
+    rank-one terms and the act BITS (both orientations) against the oracle's logits -> compute_loss('mw') ->
+    compute_loss_bwd chain (embed_attribute.py:148-206, 208-220, 641-649), positives of the row's user masked
+    (user of row r = users[r % mask_rows]: the sequence model's time-major rows); then the two backward products
+    and the bias gradient out of the bits, incl. the per-time-step products (step_rows)."""
     from arx import ops
     import torch
     rng = np.random.default_rng(B + S)
@@ -1345,14 +1349,16 @@ def test_mw_gemm_fused_fwd(dev, B, S, d):
     npos = rng.integers(0, 30, size=n_users)
     ptr = np.concatenate([[0], np.cumsum(npos)]).astype(np.int32)
     pitems = rng.integers(0, n_items, size=int(ptr[-1])).astype(np.int32)     # duplicates happen
-    users = rng.integers(0, n_users, size=B).astype(np.int32)
+    mrows = mask_rows or B
+    users = rng.integers(0, n_users, size=mrows).astype(np.int32)
     rw = rng.random(B).astype(np.float32)
     gscale = 1.0 / B
     # oracle
     logits = U.astype(np.float64) @ P.astype(np.float64).T + pb
     t = (U.astype(np.float64) * T).sum(1) + tb
     mask = np.ones((B, S), dtype=bool)
-    for r, u in enumerate(users):
+    for r in range(B):
+        u = users[r % mrows]
         sl = i2s[pitems[ptr[u]:ptr[u + 1]]]
         mask[r, sl[sl >= 0]] = False
     e = rg.RefEmbeddingAttribute.__new__(rg.RefEmbeddingAttribute)
@@ -1361,74 +1367,146 @@ def test_mw_gemm_fused_fwd(dev, B, S, d):
     dl, dt = e.compute_loss_bwd(cache, rw.astype(np.float64) * gscale)
     g = rw.astype(np.float64) * gscale / (1.0 + cache['s'])
     # device
-    f32, i32 = torch.float32, torch.int32
-    out_bl, out_t, out_g = (torch.empty(B, dtype=f32, device=dev) for _ in range(3))
-    bits = torch.zeros((S // 32, B), dtype=i32, device=dev)             # word-major [S / 32][B]
-    Ug, dU, dT = (torch.empty((B, d), dtype=f32, device=dev) for _ in range(3))
+    f32 = torch.float32
+    sc = ops.MwScorer(B, S, d, dev)
+    out_bl, out_t = (torch.empty(B, dtype=f32, device=dev) for _ in range(2))
+    dU, dT = (torch.empty((B, d), dtype=f32, device=dev) for _ in range(2))
     dts = torch.empty(B, dtype=f32, device=dev)
-    ws = ops.Workspace(dev)
     tU, tP = _t(dev, U), _t(dev, P)
-    ops.mw_gemm_fused_fwd(tU, tP, _t(dev, pb), _t(dev, T), _t(dev, tb), _t(dev, users), _t(dev, ptr),
-                          _t(dev, pitems), _t(dev, i2s), out_bl, out_t, bits, out_g, Ug, dts, dU, dT, gscale, ws,
-                          row_w=_t(dev, rw))
+    for rep in range(2):               # twice: the state is reusable (the second call overwrites every bit)
+        sc.fwd(tU, tP, _t(dev, pb), _t(dev, T), _t(dev, tb), _t(dev, users), _t(dev, ptr), _t(dev, pitems),
+               _t(dev, i2s), out_bl, out_t, dts, dU, dT, gscale, row_w=_t(dev, rw), mask_rows=mask_rows)
     torch.cuda.synchronize()
-    act = _unpack_bits(np.ascontiguousarray(bits.cpu().numpy().T).view(np.uint32), S)
+    words = sc.act_bits[:, :B].cpu().numpy()                              # [S / 32, B]
+    act = _unpack_bits(np.ascontiguousarray(words.T).view(np.uint32), S)
     diff = act != cache['act']
     v = logits - t[:, None] + 1
     assert np.all(np.abs(v[diff]) < 1e-5) and diff.sum() <= max(3, B * S // 100000)   # fp32 borderline only
+    # the transposed copy: bit (r & 31) of word [r >> 5][s]
+    wt = sc.act_bits_t.cpu().numpy().view(np.uint32)                      # [Bp / 32, S]
+    act_t = ((wt[:, None, :] >> np.arange(32, dtype=np.uint32)[None, :, None]) & 1).reshape(-1, S).astype(bool)
+    assert np.array_equal(act_t[:B], act) and not act_t[B:].any()
     same = ~diff.any(axis=1)           # a row with a borderline hinge has another count: dt = -g * cnt moves by g
     np.testing.assert_allclose(out_t.cpu().numpy(), t, rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(out_bl.cpu().numpy(), bl, rtol=RTOL, atol=ATOL)
-    np.testing.assert_allclose(out_g.cpu().numpy(), g, rtol=RTOL, atol=1e-10)
+    np.testing.assert_allclose(sc.g[:B].cpu().numpy(), g, rtol=RTOL, atol=1e-10)
+    assert not sc.g[B:].cpu().numpy().any()
     np.testing.assert_allclose(dts.cpu().numpy()[same], dt[same], rtol=RTOL, atol=1e-9)
-    np.testing.assert_allclose(Ug.cpu().numpy(), g[:, None] * U, rtol=RTOL, atol=1e-9)
     np.testing.assert_allclose(dU.cpu().numpy()[same], (dt[:, None] * T)[same], rtol=RTOL, atol=1e-9)
     np.testing.assert_allclose(dT.cpu().numpy()[same], (dt[:, None] * U)[same], rtol=RTOL, atol=1e-9)
     assert not np.any(act & ~mask)                                  # masked positives carry no bit
-    if B % 32 or d <= 32:   # the bit-operand products need B % 32 == 0 and d > 32 (the plan falls back otherwise)
-        return
     # ---- the backward products read the bits ----
+    exact = not diff.any()
     dUx = dU.clone()
-    ops.gemm_bits(bits, tP, dUx, ws, beta=1.0, row_scale=out_g)                  # dU += g * (act . P)
-    exp = dt[:, None] * T + (dl @ P.astype(np.float64)) if not diff.any() else None
-    if exp is not None:
-        np.testing.assert_allclose(dUx.cpu().numpy(), exp, rtol=RTOL, atol=2e-8)
-    if B >= 64:
-        dI = torch.empty((S, d), dtype=f32, device=dev)
-        db = torch.empty(S, dtype=f32, device=dev)
-        ops.gemm_bits(bits, Ug, dI, ws, transA=True, gvec=out_g, a_rowsum=db)    # dI = act^T . (g U)
-        if not diff.any():
-            np.testing.assert_allclose(dI.cpu().numpy(), dl.T @ U.astype(np.float64), rtol=RTOL, atol=2e-8)
-            np.testing.assert_allclose(db.cpu().numpy(), dl.sum(0), rtol=RTOL, atol=2e-8)
+    sc.bwd_dU(dUx, beta=1.0)                                                     # dU += g * (act . P)
+    if exact:
+        np.testing.assert_allclose(dUx.cpu().numpy(), dt[:, None] * T + (dl @ P.astype(np.float64)), rtol=RTOL,
+                                   atol=2e-8)
+    dI0 = rng.standard_normal((S, d)).astype(np.float32)
+    dI = _t(dev, dI0)
+    db = torch.empty(S, dtype=f32, device=dev)
+    sc.bwd_dI(dI, db=db, beta=0.5)                                               # dI = 0.5 dI + act^T . (g U)
+    if exact:
+        np.testing.assert_allclose(dI.cpu().numpy(), 0.5 * dI0 + dl.T @ U.astype(np.float64), rtol=RTOL, atol=2e-8)
+        np.testing.assert_allclose(db.cpu().numpy(), dl.sum(0), rtol=RTOL, atol=2e-8)
+    if mask_rows and exact:            # per-time-step products (TF-1.0's clip norm squares them one by one)
+        L = B // mask_rows
+        dIs = torch.empty((L, S, d), dtype=f32, device=dev)
+        dbs = torch.empty((L, S), dtype=f32, device=dev)
+        dI2 = torch.empty((S, d), dtype=f32, device=dev)
+        sc.bwd_dI(dI2, db=db, step_rows=mask_rows, dI_steps=dIs, db_steps=dbs)
+        for k in range(L):
+            rows = slice(k * mask_rows, (k + 1) * mask_rows)
+            np.testing.assert_allclose(dIs[k].cpu().numpy(), dl[rows].T @ U[rows].astype(np.float64), rtol=RTOL,
+                                       atol=2e-8)
+            np.testing.assert_allclose(dbs[k].cpu().numpy(), dl[rows].sum(0), rtol=RTOL, atol=2e-8)
+        np.testing.assert_allclose(dI2.cpu().numpy(), dl.T @ U.astype(np.float64), rtol=RTOL, atol=2e-8)
 
 
-@pytest.mark.parametrize("M,N,K", [(16384, 128, 1024), (256, 64, 64), (4096, 128, 96), (64, 48, 2048)])
-def test_gemm_bits(dev, M, N, K):
-    """arx_gemm_bits_f32, both forms, against numpy on a random 0/1 matrix."""
+def test_mw_scorer_products_f32_exact(dev):
+    """The piece arithmetic of the scorer at its edges (the round-3 ruling's condition ii).  Stated input domain:
+    finite f32 operands whose products and sums stay inside the f32 normal range -- what an f32 FMA chain needs as
+    well; non-finite inputs are covered by the next test.  Here: operand magnitudes over 2^-20 .. 2^20 per row /
+    column (products over 2^-40 .. 2^40), a row of 2^60 against a row of 2^-60 (pieces 2 and 3 of tiny values are
+    bf16 subnormals or zero: they must not be needed), a value whose bf16 rounding carries into the exponent
+    (0x3F7FFFFF), negative zeros.  The hinge decision equals an f64 evaluation except where the f64 sum itself is a
+    rounding away from zero; the row sums and the backward product match f64 at 1e-5 of the term scale."""
     from arx import ops
     import torch
-    rng = np.random.default_rng(M + N + K)
-    A = rng.random((M, K)) < 0.3
-    words = np.ascontiguousarray(np.packbits(A.reshape(M, K // 32, 32), axis=2, bitorder='little')
-                                 .view(np.uint32).reshape(M, K // 32).T)         # word-major [K / 32][M]
-    Bm = rng.standard_normal((K, N)).astype(np.float32)
-    C0 = rng.standard_normal((M, N)).astype(np.float32)
-    rs = rng.random(M).astype(np.float32)
-    ws = ops.Workspace(dev)
-    tb = _t(dev, words.view(np.int32))
-    C = _t(dev, C0)
-    ops.gemm_bits(tb, _t(dev, Bm), C, ws, beta=1.0, row_scale=_t(dev, rs))
-    exp = C0 + rs[:, None] * (A.astype(np.float64) @ Bm)
-    np.testing.assert_allclose(C.cpu().numpy(), exp, rtol=RTOL, atol=1e-4)
-    # transposed form: bits [K2 = M rows][M2 = K columns]
-    if K % 32 == 0 and K >= 64 and M % 32 == 0:
-        B2 = rng.standard_normal((M, N)).astype(np.float32)
-        g = rng.random(M).astype(np.float32)
-        C2 = torch.empty((K, N), dtype=torch.float32, device=dev)
-        r2 = torch.empty(K, dtype=torch.float32, device=dev)
-        ops.gemm_bits(tb, _t(dev, B2), C2, ws, transA=True, gvec=_t(dev, g), a_rowsum=r2)
-        np.testing.assert_allclose(C2.cpu().numpy(), A.T.astype(np.float64) @ B2, rtol=RTOL, atol=2e-4)
-        np.testing.assert_allclose(r2.cpu().numpy(), A.T.astype(np.float64) @ g, rtol=RTOL, atol=1e-4)
+    B, S, d = 256, 128, 128
+    rng = np.random.default_rng(7)
+    U = rng.standard_normal((B, d)).astype(np.float32)
+    P = rng.standard_normal((S, d)).astype(np.float32)
+    U *= (2.0 ** rng.integers(-20, 21, size=(B, 1))).astype(np.float32)
+    P *= (2.0 ** rng.integers(-20, 21, size=(S, 1))).astype(np.float32)
+    U[0, :] = np.float32(1.0)
+    P[0, :] = np.frombuffer(np.uint32(0x3F7FFFFF).tobytes(), dtype=np.float32)[0]     # rounds UP to 1.0 in bf16
+    U[1, ::2] = -0.0
+    P[1, :] = 2.0 ** -60
+    U[2, :] = 2.0 ** 60
+    pb = np.zeros(S, np.float32)
+    T = np.zeros((B, d), np.float32)
+    tb = np.ones(B, np.float32)                                   # t = 1: v = x
+    users = np.zeros(B, np.int32)
+    ptr = np.zeros(3, np.int32)
+    i2s = np.full(S + 1, -1, np.int32)
+    sc = ops.MwScorer(B, S, d, dev)
+    f32 = torch.float32
+    bl, tt, dts = (torch.empty(B, dtype=f32, device=dev) for _ in range(3))
+    dU, dT = (torch.zeros((B, d), dtype=f32, device=dev) for _ in range(2))
+    sc.fwd(_t(dev, U), _t(dev, P), _t(dev, pb), _t(dev, T), _t(dev, tb), _t(dev, users), _t(dev, ptr),
+           _t(dev, np.zeros(1, np.int32)), _t(dev, i2s), bl, tt, dts, dU, dT, 1.0)
+    x = U.astype(np.float64) @ P.astype(np.float64).T
+    scale = np.abs(U.astype(np.float64)) @ np.abs(P.astype(np.float64)).T
+    act = _unpack_bits(np.ascontiguousarray(sc.act_bits[:, :B].cpu().numpy().T).view(np.uint32), S)
+    wrong = act != (x > 0)
+    assert np.all(np.abs(x[wrong]) <= 1e-6 * scale[wrong])
+    s_ref = np.where(x > 0, x, 0.0).sum(1)
+    got = np.expm1(bl.cpu().numpy().astype(np.float64))          # loss = log(1 + s)
+    ok = (s_ref < 1e30) & (s_ref > 1e-3)                         # (log1p / expm1 of tiny or huge sums: f32 log range)
+    assert np.isfinite(bl.cpu().numpy()).all()
+    np.testing.assert_allclose(got[ok], s_ref[ok], rtol=2e-5)
+    g = sc.g[:B].cpu().numpy().astype(np.float64)
+    sc.bwd_dU(dU, beta=0.0)
+    ref = g[:, None] * (act.astype(np.float64) @ P.astype(np.float64))
+    bound = g[:, None] * (act.astype(np.float64) @ np.abs(P.astype(np.float64)))
+    assert np.all(np.abs(dU.cpu().numpy() - ref) <= 1e-5 * bound + 1e-37)
+
+
+def test_mw_scorer_nonfinite_inputs_propagate(dev):
+    """NaN / Inf in a latent row or a pool row (the ruling's condition ii): the split of a non-finite value keeps it
+    non-finite (piece 1 = the value, pieces 2 / 3 = NaN), so the affected rows' losses come out non-finite -- as
+    they do with an f32 FMA chain -- and every OTHER row is untouched; an Inf logit that loses the hinge
+    (x = -inf) contributes nothing."""
+    from arx import ops
+    import torch
+    B, S, d = 128, 128, 64
+    rng = np.random.default_rng(3)
+    U = (rng.standard_normal((B, d)) * 0.3).astype(np.float32)
+    P = (rng.standard_normal((S, d)) * 0.3).astype(np.float32)
+    clean_U, clean_P = U.copy(), P.copy()
+    U[5, 3] = np.nan
+    U[9, 0] = np.inf
+    pb = np.zeros(S, np.float32)
+    T = (rng.standard_normal((B, d)) * 0.3).astype(np.float32)
+    tb = np.zeros(B, np.float32)
+    users = np.zeros(B, np.int32)
+    ptr = np.zeros(3, np.int32)
+    i2s = np.full(S + 1, -1, np.int32)
+    f32 = torch.float32
+    res = []
+    for UU, PP in ((U, P), (clean_U, clean_P)):
+        sc = ops.MwScorer(B, S, d, dev)
+        bl, tt, dts = (torch.empty(B, dtype=f32, device=dev) for _ in range(3))
+        dU, dT = (torch.zeros((B, d), dtype=f32, device=dev) for _ in range(2))
+        sc.fwd(_t(dev, UU), _t(dev, PP), _t(dev, pb), _t(dev, T), _t(dev, tb), _t(dev, users), _t(dev, ptr),
+               _t(dev, np.zeros(1, np.int32)), _t(dev, i2s), bl, tt, dts, dU, dT, 1.0)
+        res.append(bl.cpu().numpy())
+    dirty, clean = res
+    assert not np.isfinite(dirty[5]) and not np.isfinite(dirty[9])
+    keep = np.ones(B, bool)
+    keep[[5, 9]] = False
+    assert np.array_equal(dirty[keep], clean[keep])
 
 
 @pytest.mark.parametrize("M,N,K", [(16384, 1024, 128), (4097, 256, 64), (70, 128, 128)])
