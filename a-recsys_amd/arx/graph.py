@@ -274,6 +274,10 @@ class Prediction(Node):
         self.fused_into_loss = False
         self.scorer = None            # ops.MwScorer (its state holds the act bits, g and the operand planes)
 
+    def fusable(self, rows):
+        """May BatchLoss('mw') take the scorer GEMM in (csrc/scorer.hip)?  Subclasses with their own backward say."""
+        return type(self) is Prediction
+
     def forward(self, train):
         if self.fused_into_loss and train:
             return
@@ -530,8 +534,8 @@ class BatchLoss(Node):
                 target.fused_into_loss = True
                 # ... and, for the plain pool scorer, the GEMM itself moves in (hinge epilogue)
                 B_ = logits.shape[0]
-                if (kind == 'mw' and type(logits) is Prediction and logits.inputs[0] is lat
-                        and ops.mw_scorer_supported(B_, W, d)):
+                if (kind == 'mw' and isinstance(logits, Prediction) and logits.fusable(B_)
+                        and logits.inputs[0] is lat and ops.mw_scorer_supported(B_, W, d)):
                     # DEFAULT since round 4 (ARX_SCORER_F32=1: logits GEMM + loss kernel + two f32 GEMMs): no
                     # [B, S] logits / dlogits in HBM, 2 MB of activity bits instead, and all three products on
                     # the bf16 matrix pipe, f32-exact (csrc/gemm_bx6.hip; C3 312 -> 260 us/step in round 3)

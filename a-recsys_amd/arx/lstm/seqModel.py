@@ -176,17 +176,40 @@ class SeqPrediction(G.Prediction):
         self.L, self.B = L, B
         self.C_steps = None
 
+    def fusable(self, rows):
+        # the fused 'mw' scorer keeps the per-step products when a step's rows are whole 128-row K slices
+        return type(self) is SeqPrediction and rows == self.L * self.B and self.B % 128 == 0
+
+    def _steps(self, S, d):
+        if self.C_steps is None:
+            dev = self.rt.device
+            self.C_steps = torch.empty((self.L, S, d), dtype=torch.float32, device=dev)
+            self.rs_steps = torch.empty((self.L, S), dtype=torch.float32, device=dev)
+
+    def _backward_bits(self):
+        """The fused scorer's backward (graph.Prediction._backward_bits) with the per-time-step products kept:
+        arx_mw_scorer_bwd_di slices K = L * B by time step, its partial products ARE C_steps."""
+        latent, pool = self.inputs
+        S, d = pool.shape
+        if latent.requires_grad:
+            self.scorer.bwd_dU(latent.alloc_grad(), beta=latent.grad_beta())
+        if pool.train_tables:
+            self._steps(S, d)
+            gp = pool.alloc_grad()
+            self.scorer.bwd_dI(gp, db=pool.bias_grad, beta=pool.grad_beta(), step_rows=self.B,
+                               dI_steps=self.C_steps, db_steps=self.rs_steps)
+            pool.bias_grad_used = True
+
     def backward(self):
+        if self.fused_into_loss:
+            return self._backward_bits()
         latent, pool = self.inputs
         dl = self.grad
         S, d = pool.shape
         if latent.requires_grad:
             ops.gemm(dl, pool.value, latent.alloc_grad(), self.rt.ws, beta=latent.grad_beta())
         if pool.train_tables:
-            if self.C_steps is None:
-                dev = self.rt.device
-                self.C_steps = torch.empty((self.L, S, d), dtype=torch.float32, device=dev)
-                self.rs_steps = torch.empty((self.L, S), dtype=torch.float32, device=dev)
+            self._steps(S, d)
             gp = pool.alloc_grad()
             ops.gemm_steps_tn(dl, latent.value, self.C_steps, self.rs_steps, self.L, self.B,
                               C_sum=gp, beta=pool.grad_beta(), rowsum_sum=pool.bias_grad)

@@ -85,9 +85,10 @@ def test_fullsize_locality_conservation_and_update(dev, mulhot):
     # loss = mean of the row losses; WMRB gradient conservation (dt = - sum_s dlogits)
     np.testing.assert_allclose(loss, float(bl.value.double().mean().item()), rtol=1e-6)
     if pred.fused_into_loss:      # hinge in the scorer GEMM's epilogue: dlogits = g_r * act bits
-        w = np.ascontiguousarray(pred.act_bits.cpu().numpy().T).view(np.uint32)     # word-major -> [B][S/32]
+        nB = pred.shape[0]
+        w = np.ascontiguousarray(pred.scorer.act_bits[:, :nB].cpu().numpy().T).view(np.uint32)   # word-major -> [B][S/32]
         act = ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(w.shape[0], -1)
-        dl = torch.from_numpy(act.astype(np.float64)).to(d_) * pred.gvec.double()[:, None]
+        dl = torch.from_numpy(act.astype(np.float64)).to(d_) * pred.scorer.g[:nB].double()[:, None]
     else:
         dl = pred.grad.double()
     dt = ts.grad.double()

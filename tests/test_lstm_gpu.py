@@ -91,9 +91,14 @@ CFG_HET = dict(n_users=300, n_items=500, logit_size=500, item_mulhot=True, mulho
     (CFG_HET, 64, 32, 6, 128, 1e9),      # multi-hot item attributes, no clipping
     (CFG_HET, 64, 16, 4, 64, 0.5),       # multi-hot tokens shared between pool items, hard clipping
     (CFG_HET, 64, 64, 8, 128, 5.0),      # > 8192 bag slots: the bag table rides on the fused one-hot pass (K7c)
+    (CFG_ID, 64, 128, 3, 128, 0.5),      # B % 128 == 0: the fused 'mw' scorer with per-time-step dI slices (scorer.hip)
+    (CFG_HET, 64, 128, 2, 256, 5.0),     # ... with multi-hot items
 ])
 def test_seq_mw_steps_match_oracle(dev, cfg, size, B, L, S, clip):
     syn, emb, model, remb, ref = _build(cfg, 'mw', size, B, L, S, clip, seed=4)
+    if B % 128 == 0:
+        from arx import graph as G, ops
+        plan_fused = lambda: any(isinstance(n, G.BatchLoss) and n.gemm_fused for n in model._plan(0, 'train').order)
     rng = np.random.default_rng(7)
     pool = syn.sample_pool(S, rng)
     id2idx = {int(v): i for i, v in enumerate(pool)}
@@ -112,6 +117,8 @@ def test_seq_mw_steps_match_oracle(dev, cfg, size, B, L, S, clip):
             np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL,
                                        err_msg='global norm step %d' % step)
         _compare(emb, model, remb, ref)
+    if B % 128 == 0:
+        assert ops.SCORER_F32 or plan_fused()                     # the path under test ran
 
 
 @pytest.mark.parametrize("cfg", [CFG_ID, CFG_HET])
