@@ -60,18 +60,18 @@ constexpr int kScSlots = 4;           // LDS ring: the stage being read + three 
 constexpr int kScAhead = 3;
 constexpr int kScStageBytes = 3 * 32 * 256;      // one stage = 3 planes x 32 operand rows x 256 bytes (24 KB)
 
-__device__ __forceinline__ uint32_t bf16_rne(float x) {       // f32 -> bf16 bits, round to nearest even
-  const uint32_t u = __float_as_uint(x);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-
-// x -> its three bf16 pieces (bits): both residual subtractions are exact
-__device__ __forceinline__ void split3(float x, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-  p1 = bf16_rne(x);
-  const float r1 = x - __uint_as_float(p1 << 16);
-  p2 = bf16_rne(r1);
-  const float r2 = r1 - __uint_as_float(p2 << 16);
-  p3 = bf16_rne(r2);
+// (x, y) -> their three bf16 pieces, packed {lo: x, hi: y} per piece (the layout of two consecutive k of an MFMA
+// operand): v_cvt_pk_bf16_f32 rounds to nearest even, both residual subtractions are exact in f32.  7.5 VALU per
+// value pair and piece instead of ~20 for the integer rounding sequence (the forward kernel's prologue splits 64 values
+// per lane: 2.8 us of its 27)
+typedef __bf16 sc_bf2 __attribute__((ext_vector_type(2)));
+typedef float sc_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3x2(float x, float y, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector((sc_f2){x, y}, sc_bf2));
+  const float rx = x - __uint_as_float(p1 << 16), ry = y - __uint_as_float(p1 & 0xFFFF0000u);
+  p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector((sc_f2){rx, ry}, sc_bf2));
+  const float sx = rx - __uint_as_float(p2 << 16), sy = ry - __uint_as_float(p2 & 0xFFFF0000u);
+  p3 = __builtin_bit_cast(uint32_t, __builtin_convertvector((sc_f2){sx, sy}, sc_bf2));
 }
 
 #ifdef SC_ABL_NOBAR
@@ -175,13 +175,8 @@ __device__ __forceinline__ void sc_emit_planes_t(const float* tile, int ld, int 
     const int n = it % N, q = it / N;
     uint32_t w[3][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      uint32_t a[3], b[3];
-      split3(tile[(8 * q + 2 * e) * ld + n], a[0], a[1], a[2]);
-      split3(tile[(8 * q + 2 * e + 1) * ld + n], b[0], b[1], b[2]);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) w[p][e] = a[p] | (b[p] << 16);
-    }
+    for (int e = 0; e < 4; ++e)
+      split3x2(tile[(8 * q + 2 * e) * ld + n], tile[(8 * q + 2 * e + 1) * ld + n], w[0][e], w[1][e], w[2][e]);
 #pragma unroll
     for (int p = 0; p < 3; ++p)
       *reinterpret_cast<uint4*>(dst + p * plane_elems + (int64_t)n * ldk + k0 + 8 * q) =
@@ -222,15 +217,12 @@ __global__ __launch_bounds__(256) void k_sc_prep(const float* __restrict__ P, in
       const float4 v = *reinterpret_cast<const float4*>(P + (r0 + r) * ldp + c);
       bad += (v.x + v.y + v.z + v.w) * 0.f;
       tile[r * ld + c] = v.x; tile[r * ld + c + 1] = v.y; tile[r * ld + c + 2] = v.z; tile[r * ld + c + 3] = v.w;
-      uint32_t a[3], b[3], cc[3], dd[3];
-      split3(v.x, a[0], a[1], a[2]);
-      split3(v.y, b[0], b[1], b[2]);
-      split3(v.z, cc[0], cc[1], cc[2]);
-      split3(v.w, dd[0], dd[1], dd[2]);
+      uint32_t a[3], b[3];
+      split3x2(v.x, v.y, a[0], a[1], a[2]);
+      split3x2(v.z, v.w, b[0], b[1], b[2]);
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        *reinterpret_cast<uint2*>(Pp + ((int64_t)p * S + r0 + r) * d + c) =
-            make_uint2(a[p] | (b[p] << 16), cc[p] | (dd[p] << 16));
+        *reinterpret_cast<uint2*>(Pp + ((int64_t)p * S + r0 + r) * d + c) = make_uint2(a[p], b[p]);
     }
     bad = sc_wsum(bad);
     if ((tid & 63) == 0) sbad[tid >> 6] = bad;
@@ -328,13 +320,14 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
         t1 = *reinterpret_cast<const float4*>(tp + 16 * c + 4);
       }
       dot += v0.x * t0.x + v0.y * t0.y + v0.z * t0.z + v0.w * t0.w + v1.x * t1.x + v1.y * t1.y + v1.z * t1.z + v1.w * t1.w;
-      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      uint32_t p1[8], p2[8], p3[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) split3(x[e], p1[e], p2[e], p3[e]);
-      a1[c] = __builtin_bit_cast(bf16x8, make_uint4(p1[0] | (p1[1] << 16), p1[2] | (p1[3] << 16), p1[4] | (p1[5] << 16), p1[6] | (p1[7] << 16)));
-      a2[c] = __builtin_bit_cast(bf16x8, make_uint4(p2[0] | (p2[1] << 16), p2[2] | (p2[3] << 16), p2[4] | (p2[5] << 16), p2[6] | (p2[7] << 16)));
-      a3[c] = __builtin_bit_cast(bf16x8, make_uint4(p3[0] | (p3[1] << 16), p3[2] | (p3[3] << 16), p3[4] | (p3[5] << 16), p3[6] | (p3[7] << 16)));
+      uint32_t p1[4], p2[4], p3[4];
+      split3x2(v0.x, v0.y, p1[0], p2[0], p3[0]);
+      split3x2(v0.z, v0.w, p1[1], p2[1], p3[1]);
+      split3x2(v1.x, v1.y, p1[2], p2[2], p3[2]);
+      split3x2(v1.z, v1.w, p1[3], p2[3], p3[3]);
+      a1[c] = __builtin_bit_cast(bf16x8, make_uint4(p1[0], p1[1], p1[2], p1[3]));
+      a2[c] = __builtin_bit_cast(bf16x8, make_uint4(p2[0], p2[1], p2[2], p2[3]));
+      a3[c] = __builtin_bit_cast(bf16x8, make_uint4(p3[0], p3[1], p3[2], p3[3]));
     }
     dot += __shfl_xor(dot, 32, 64);
     const float t = dot + ((ok && tb) ? tb[row * tb_stride] : 0.f);
@@ -432,6 +425,27 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
 #else
 #define SC_EPI_WRITE(x_) x_
 #endif
+  // where the VALU of a chunk go between its six MFMAs: evenly (default) or in two bursts (SC_SCHED_BURST: after the
+  // first and the fourth MFMA, the layout of tools/probe's hand-written tile)
+#ifdef SC_SCHED_BURST
+#define SC_CHUNK_SCHED(c_)                                                                               \
+  {                                                                                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+    if ((c_) == 0) __builtin_amdgcn_sched_group_barrier(0x002, 3 * VPM + 9, 0);                          \
+    else __builtin_amdgcn_sched_group_barrier(0x002, 3 * VPM, 0);                                        \
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                   \
+    if ((c_) == 0) __builtin_amdgcn_sched_group_barrier(0x002, 3 * VPM + 9, 0);                          \
+    else __builtin_amdgcn_sched_group_barrier(0x002, 3 * VPM + 1, 0);                                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                   \
+  }
+#else
+#define SC_CHUNK_SCHED(c_)                                                                               \
+  _Pragma("unroll") for (int m = 0; m < 6; ++m) {                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+    if ((c_) == 0) __builtin_amdgcn_sched_group_barrier(0x002, VPM + 3, 0);                              \
+    else __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);                                            \
+  }
+#endif
   // one tile: MFMAs into (hi_, lo_).  EPI_: the previous tile's accumulators (hy_, ly_) are turned into hinge bits /
   // sums and re-initialised from bvn; jw_ >= 0: the word of tile jw_ (finished one tile ago) is assembled and stored in
   // chunk 0; jb0_ / jb_: the tiles whose bias quad 0 (chunk 0) / quads 1..3 (later chunks) are re-read -- see below;
@@ -470,11 +484,7 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
           SC_EPI_WRITE({ float z_; asm volatile("v_mov_b32 %0, 0" : "=v"(z_)); ly_[i] = z_; })          \
         }                                                                                                \
       }                                                                                                  \
-      _Pragma("unroll") for (int m = 0; m < 6; ++m) {                                                    \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
-        if (c == 0) __builtin_amdgcn_sched_group_barrier(0x002, VPM + 3, 0);                             \
-        else __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);                                        \
-      }                                                                                                  \
+      SC_CHUNK_SCHED(c)                                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                 \
       if (SC_TRACE_CHUNKS || c == NCH - 1) { SC_T(1 + c) }                                               \
     }                                                                                                    \

@@ -155,8 +155,16 @@ def test_eval_recommend_and_logits(dev):
     l_got = model.step(None, list(users), list(items), None, pool, id2idx, loss='mw')
     np.testing.assert_allclose(l_got, l_ref, rtol=RTOL)
     # sampled logits of that step
-    np.testing.assert_allclose(model.batch_loss.inputs[0].value.cpu().numpy(), ref.last['logits'],
-                               rtol=RTOL, atol=1e-5)
+    pred = model.batch_loss.inputs[0]
+    if pred.value is None:        # fused 'mw' scorer: no [B, S] logits in a train step -- materialise them here
+        import torch
+        from arx import ops
+        lat, pe = pred.inputs
+        lg = torch.empty(pred.shape, dtype=torch.float32, device=lat.value.device)
+        ops.gemm(lat.value, pe.value, lg, model.rt.ws, transB=True, col_bias=pe.bias_value)
+    else:
+        lg = pred.value
+    np.testing.assert_allclose(lg.cpu().numpy(), ref.last['logits'], rtol=RTOL, atol=1e-5)
     # forward_only -> loss_eval ('warp' over the full vocabulary with the eval positives)
     e_ref = ref.step(list(users), list(items), forward_only=True, loss='warp')
     e_got = model.step(None, list(users), list(items), forward_only=True, loss='warp')
