@@ -133,6 +133,26 @@ class IdsInput(Node):
     def forward(self, train):
         pass
 
+    def next_value(self):
+        """Placeholder of the NEXT step's ids (Plan ring mode: that step's K7 sort half runs one step early)."""
+        if getattr(self, '_next', None) is None:
+            self._next = torch.zeros_like(self.value)
+        return self._next
+
+    def feed_next(self, arr):
+        dst = self.next_value()
+        if isinstance(arr, torch.Tensor):
+            src = arr.to(dtype=torch.int32)
+        else:
+            src = torch.from_numpy(np.ascontiguousarray(np.asarray(arr, dtype=np.int32)))
+        if src.numel() != dst.numel():
+            raise ValueError("placeholder %s expects %d ids, got %d" % (self.name, dst.numel(), src.numel()))
+        if src.is_cuda and src.is_contiguous():
+            self.rt.queue_feed(src, dst)
+        else:
+            self.rt.drop_feed(dst)
+            dst.copy_(src.reshape(dst.shape), non_blocking=True)
+
 
 class IdsSlice(Node):
     """Rows [start, start + n) of an int placeholder: a bucket shorter than the longest one
@@ -147,6 +167,16 @@ class IdsSlice(Node):
 
     def feed(self, arr):
         IdsInput.feed(self, arr)
+
+    def next_value(self):
+        if getattr(self, '_next', None) is None:
+            a = self.value.data_ptr() - self.inputs[0].value.data_ptr()
+            start = a // 4
+            self._next = self.inputs[0].next_value()[start:start + self.value.numel()]
+        return self._next
+
+    def feed_next(self, arr):
+        IdsInput.feed_next(self, arr)
 
     def forward(self, train):
         pass
@@ -759,6 +789,13 @@ class Plan(object):
         self._early_jobs, self._k7_early, self._k7_stream, self._k7_done_keys = [], None, None, None
         self._k7_fork = None
         self._jobs, self._n_passes = [], 0
+        # ring mode (prepare_next): the K7 sort half of step t + 1 runs as the side branch of step t's graph
+        self.ring_req = False          # set by the model for the coming run()
+        self._ring = False             # inside a ring execution / capture
+        self._ring_par = 0             # slot the coming step APPLIES from; its branch sorts into 1 - _ring_par
+        self._ring_ready = False       # slot _ring_par holds the sorted lookups of the coming step
+        self._ring_graphs = {}
+        self._ring_warm = {}
         self.has_dropout = any(getattr(n, 'uses_dropout', False) for n in self.order)
         self.tables = []
         self.arenas = []
@@ -916,7 +953,8 @@ class Plan(object):
             # (measured: with a VIRTUAL entity table -- MIX -- 350 -> 340 us/step; with a real id table -- HET
             # -- 313 -> 315, so there the dependency stays at the apply)
             mid_at = os.environ.get('ARX_K7_MID_AT') or ('dI' if getattr(self, '_k7_virtual', False) else 'apply')
-            if self._k7_early is not None and self._k7_early[2] is not None and mid_at == 'dI':
+            if (self._k7_early is not None and self._k7_early[2] is not None and self._k7_early[2] != 'ring'
+                    and mid_at == 'dI'):
                 def _mid_wait(ev=self._k7_early[2]):
                     if not self._mid_waited:
                         torch.cuda.current_stream().wait_event(ev)
@@ -1021,7 +1059,11 @@ class Plan(object):
         self._k7_early = None
         self._k7_done_keys = None
         split_join = None
-        if early is not None:
+        ring_done = None
+        if early is not None and early[2] == 'ring':
+            ring_done = early[1]
+            self._k7_done_keys = early[0]           # this step's sort half ran one step ago (slot _ring_par)
+        elif early is not None:
             if early[2] is not None:
                 if not getattr(self, '_mid_waited', False):
                     torch.cuda.current_stream().wait_event(early[2])  # the one-hot sort is done ...
@@ -1067,7 +1109,19 @@ class Plan(object):
                 key = key + ('rider', id(bag_entry), use_bias, gi is None)
                 bag = (bag_entry, bag_live, use_bias, gi is None)
             phase = 2 if (self._k7_done_keys is not None and key in self._k7_done_keys) else 3
-            if phase == 2 and split_join is not None and bag is not None:
+            if self._ring and phase != 2:
+                raise RuntimeError("ring mode: the step's K7 pass differs from the one sorted ahead")
+            if phase == 2 and ring_done is not None and bag is not None:
+                self._apply_multi(fused, phase=7, key=key, bag=bag)
+                # the branch (the NEXT step's sorts) rejoins here, not at the end of the step: nothing below
+                # needs it, but a branch whose only successor is the graph's last node was started ~90 us late
+                # by the graph scheduler (measured: the step took 269 us instead of 251); with the join where
+                # the two-phase graph has it the branch starts behind the first lookup again
+                if os.environ.get('ARX_RING_JOIN', 'apply') == 'apply':
+                    torch.cuda.current_stream().wait_event(ring_done)
+                    ring_done = None
+                self._apply_multi(fused, phase=8, key=key, bag=bag)
+            elif phase == 2 and split_join is not None and bag is not None:
                 self._apply_multi(fused, phase=7, key=key, bag=bag)
                 torch.cuda.current_stream().wait_event(split_join)
                 split_join = None
@@ -1091,6 +1145,8 @@ class Plan(object):
             rest(True)
         for t in toks:
             rt.join(t)
+        if ring_done is not None:
+            torch.cuda.current_stream().wait_event(ring_done)      # rejoin the branch (next step's sorts)
         self._plan_early(self._jobs, self._n_passes)
 
     def _find_rider(self, fused, done):
@@ -1155,14 +1211,24 @@ class Plan(object):
         return tuple(id(x) for _, c, m in group for x in c + m) + tuple(
             bool(e[0].bias is not None and any(x.node.bias_grad_used for x in c + m)) for e, c, m in group)
 
-    def _apply_multi(self, group, phase=3, key=None, bag=None):
+    def _apply_multi(self, group, phase=3, key=None, bag=None, slot=None):
         """phase 1: contributions + sort (ids only), 2: apply, 3: both -- see _early_sort.
-        bag: (table entry, live sites, use_bias) of a multi-hot table riding on table 0 of the group."""
+        bag: (table entry, live sites, use_bias) of a multi-hot table riding on table 0 of the group.
+        slot (ring mode): one of two buffer sets; its sort half reads the NEXT step's id placeholders."""
         rt = self.rt
         if key is None:
             key = self._multi_key(group)
+        if slot is None and self._ring:
+            if phase in (1, 5, 6):
+                slot = 1 - self._ring_par        # the branch: the NEXT step's sort half
+            elif phase in (2, 7, 8):
+                slot = self._ring_par            # this step's apply, from what the previous step's branch left
+            else:
+                raise RuntimeError("ring mode runs the two halves of a K7 pass in different steps (phase %d)" % phase)
+        ids_of = (lambda x: x.ids_node.value) if slot is None else (lambda x: x.ids_node.next_value())
         cache = self.__dict__.setdefault('_multi_cache', {})
-        ent = cache.get(key)
+        ck = key if slot is None else (key, 'slot', slot)
+        ent = cache.get(ck)
         if ent is None:
             tables, sites, extra, xsites = [], [], [], []
             t_off = 0
@@ -1172,16 +1238,21 @@ class Plan(object):
                 vmap = torch.zeros(n_ent, dtype=torch.int32, device=rt.device)    # per-entity map of the grouped K7 path
                 tables.append((None, None, None, None, vmap, n_ent))
                 for x in bag[1]:
-                    sites.append((0, None, x.ids_node.value, x.node.row0, x.coef))
+                    sites.append((0, None, ids_of(x), x.node.row0, x.coef))
                 t_off = 1
+            # which tables update their bias is part of the pass key (_multi_key, taken at apply time): the
+            # nodes' bias_grad_used flags are only set once the step's backward ran -- a sort branch that builds
+            # this entry runs before it
+            n_ids = sum(len(c) + len(m) for _, c, m in group)
+            key_bias = key[n_ids:n_ids + len(group)]
             for ti, (e, c, m) in enumerate(group, start=t_off):
                 table = e[0]
-                use_bias = table.bias is not None and any(x.node.bias_grad_used for x in c + m)
+                use_bias = bool(key_bias[ti - t_off])
                 sgd = rt.optimizer == 'sgd'          # no slots: the kernels do plain gradient descent
                 tables.append((table.E, None if sgd else table.acc, table.bias if use_bias else None,
                                table.bias_acc if (use_bias and not sgd) else None, self._aux_cnt(table)))
                 for x in c:
-                    sites.append((ti, x.maps[0], x.ids_node.value, x.node.row0, x.coef))
+                    sites.append((ti, x.maps[0], ids_of(x), x.node.row0, x.coef))
                 for x in m:
                     extra.append((ti, x.cap))
                     xsites.append(x)
@@ -1194,11 +1265,11 @@ class Plan(object):
                        coef=torch.empty(n, dtype=torch.float32, device=dev),
                        any_bias=any(t[2] is not None for t in tables),
                        ws=ops.Workspace(dev))       # own workspace: the sorted arrays live in it
-            cache[key] = ent                        # between the two phases
+            cache[ck] = ent                         # between the two phases
         args = ent['args']
         if phase & 1:
             for x, off in zip(ent['xsites'], args.extra_off):   # multi-hot lookups: padded slots, the sort drops the pads
-                ops.bag_expand_padded(x.maps[0], x.maps[1], x.maps[2], x.ids_node.value, x.max_len,
+                ops.bag_expand_padded(x.maps[0], x.maps[1], x.maps[2], ids_of(x), x.max_len,
                                       x.node.row0, x.coef, ent['keys'][off:off + x.cap],
                                       ent['src'][off:off + x.cap], ent['coef'][off:off + x.cap])
         node0 = (group[0][1] + group[0][2])[0].node
@@ -1232,7 +1303,7 @@ class Plan(object):
         self._k7_early = None
         self._k7_fork = None
         jobs = self._early_jobs
-        if not jobs or os.environ.get('ARX_K7_NO_EARLY') or self.rt.dp is not None:
+        if not jobs or (os.environ.get('ARX_K7_NO_EARLY') and not self._ring) or self.rt.dp is not None:
             return                            # (data-parallel: the apply sorts the GATHERED lookups)
         rt = self.rt
         if self._k7_stream is None:
@@ -1271,6 +1342,11 @@ class Plan(object):
                     self._cat_pass(what, key, phase=1)
             done = torch.cuda.Event()
             done.record(self._k7_stream)
+        if self._ring:
+            # the branch sorted the NEXT step's lookups (slot 1 - _ring_par): nothing in this step waits for it
+            # but the end of the step (a captured branch has to rejoin its origin)
+            self._k7_early = (set(k for _, _, k in jobs), done, 'ring')
+            return
         self._k7_early = (set(k for _, _, k in jobs), done, mid)
 
     def _plan_early(self, jobs, n_passes):
@@ -1404,6 +1480,74 @@ class Plan(object):
             table.aux_cnt = torch.zeros((table.E.shape[0],), dtype=torch.int32, device=self.rt.device)
         return table.aux_cnt
 
+    # ---- ring mode: the NEXT step's K7 sort half as this step's side branch -------------------------------------
+    def ring_capable(self):
+        """The passes of this plan are known (it has run before) and all of the fused kind whose sort half can read
+        another id placeholder; hipGraph replay on (ring mode is a property of the captured graph)."""
+        rt = self.rt
+        return bool(self.train and rt.use_graph and rt.dp is None and self.warm >= 1 and self._early_jobs
+                    and all(j[0] == 'multi' for j in self._early_jobs) and len(self._early_jobs) == 1
+                    and not rt.no_multi)
+
+    def ring_ids(self):
+        """The id placeholders the K7 sites read (each once)."""
+        seen, out = set(), []
+        for _t, sites, _b, _n in self.tables:
+            for s_ in sites:
+                n = s_.ids_node
+                if id(n) not in seen:
+                    seen.add(id(n))
+                    out.append(n)
+        return out
+
+    def ring_bootstrap(self):
+        """First ring step (or the first after a step without prepare_next): nobody sorted THIS step's lookups ahead.
+        Do it now, eagerly: the current ids go through the next-step placeholders into slot _ring_par."""
+        rt = self.rt
+        rt.flush_feeds()
+        ops.copy_words([(n.value, n.next_value()) for n in self.ring_ids()])
+        self._bind()
+        self._ring, par = True, self._ring_par
+        try:
+            self._ring_par = 1 - par              # (_apply_multi sorts into 1 - _ring_par)
+            for kind, what, key in self._early_jobs:
+                if what[1] is not None:
+                    self._apply_multi(what[0], phase=5, key=key, bag=what[1])
+                    self._apply_multi(what[0], phase=6, key=key, bag=what[1])
+                else:
+                    self._apply_multi(what[0], phase=1, key=key, bag=what[1])
+        finally:
+            self._ring, self._ring_par = False, par
+        self._ring_ready = True
+
+    def _run_ring(self):
+        rt = self.rt
+        par = self._ring_par
+        self._ring = True
+        try:
+            if self._ring_warm.get(par, 0) >= 1:
+                g = self._ring_graphs.get(par)
+                if g is None:
+                    g = ops.CapturedGraph()
+                    side = torch.cuda.Stream(device=rt.device)
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        g.begin()
+                        try:
+                            self._execute()
+                        finally:
+                            g.end()
+                    torch.cuda.current_stream().wait_stream(side)
+                    self._ring_graphs[par] = g
+                g.launch()
+            else:
+                self._execute()
+                self._ring_warm[par] = self._ring_warm.get(par, 0) + 1
+        finally:
+            self._ring = False
+        self._ring_par = 1 - par                   # the branch sorted slot 1 - par: the next step applies from it
+        self._ring_ready = True
+
     def run(self):
         rt = self.rt
         rt.flush_feeds()
@@ -1412,6 +1556,16 @@ class Plan(object):
             self._kp = rt.keep_prob
             self.graph = None
             self.warm = 0
+            self._ring_graphs, self._ring_warm, self._ring_ready = {}, {}, False
+        ring, self.ring_req = self.ring_req, False
+        if ring and self._ring_ready and self.ring_capable():
+            self._run_ring()
+            if self.train:
+                for n in self.fetch:
+                    if isinstance(n, MeanLoss) and n.lazy:
+                        n._stale = True
+            return
+        self._ring_ready = False
         if rt.use_graph and self.warm >= 1:
             if self.graph is None:
                 g = ops.CapturedGraph()

@@ -351,6 +351,46 @@ class LatentProductModel(object):
         for op in update_sampled:                                             # :206-207
             op()
 
+    def prepare_next(self, user_input, item_input, item_sampled=None):
+        """Announce the batch of the NEXT training step before calling step() for the current one (the host loop
+        draws batches before it trains on them: hmf/run_hmf.py:234-242, so a loader can hand step t + 1's ids over
+        one step early).  The half of the sparse update that needs the ids only -- contribution keys, their sort,
+        the run records (K7, hmf_model.py:146-151) -- then runs for step t + 1 as a side branch of step t's graph,
+        off the critical path.  item_sampled: the pool step t + 1 will be given, if it is a new one.  Optional:
+        step() without it (or with other ids than announced) computes the same numbers, bit for bit."""
+        self._next_batch = (user_input, item_input, item_sampled)
+
+    def _ring_feed(self, plan, item_sampled):
+        """step t: queue the announced ids of step t + 1 into the next-step placeholders; True if the plan may run
+        in ring mode."""
+        nxt, self._next_batch = getattr(self, '_next_batch', None), None
+        ann, self._announced = getattr(self, '_announced', None), None
+        if nxt is None or not plan.ring_capable():
+            return False
+        m = self.att_emb
+        nodes = {id(m.u_indices['input']): nxt[0], id(self.item_id_target): nxt[1]}
+        pool = m.i_indices.get('sampled_pass') if hasattr(m.i_indices, 'get') else None
+        known = set(nodes) | ({id(pool)} if pool is not None else set())
+        if any(id(n) not in known for n in plan.ring_ids()):
+            return False                      # a lookup this method does not know how to announce
+        # what step t - 1 sorted ahead is only valid for the ids it was told (tensor identity; a pool given now
+        # must be the one announced)
+        if ann is None or ann[0] is not self._cur[0] or ann[1] is not self._cur[1] or \
+                (item_sampled is not None and ann[2] is not item_sampled):
+            plan._ring_ready = False
+        if not plan._ring_ready:
+            plan.ring_bootstrap()
+        for n in plan.ring_ids():
+            if id(n) in nodes:
+                n.feed_next(nodes[id(n)])
+            elif nxt[2] is not None:
+                n.feed_next(nxt[2])
+            else:
+                n.feed_next(item_sampled if item_sampled is not None else n.value)   # same pool as this step
+        self._announced = nxt
+        plan.ring_req = True
+        return True
+
     def step_async(self, session, user_input, item_input, neg_item_input=None, item_sampled=None,
                    item_sampled_id2idx=None, forward_only=False, recommend=False,
                    recommend_new=False, loss=None, run_op=None, run_meta=None):
@@ -358,6 +398,7 @@ class LatentProductModel(object):
         node (call .read() for the device scalar) / the top-k index tensor."""
         if loss is None:
             loss = self.loss_function
+        self._cur = (user_input, item_input)
         self._feed(user_input, item_input, recommend, loss, item_sampled, item_sampled_id2idx,
                    forward_only)
         if recommend:
@@ -369,7 +410,12 @@ class LatentProductModel(object):
         if forward_only:
             self._plan('eval').run()
             return self.loss_eval
-        self._plan('train').run()
+        plan = self._plan('train')
+        if getattr(self, '_next_batch', None) is not None:
+            self._ring_feed(plan, item_sampled)
+        else:
+            self._announced = None
+        plan.run()
         self.rt.global_step += 1
         return self.loss
 

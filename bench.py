@@ -85,6 +85,9 @@ def parse():
                          "a 100 k-token multi-hot table striped by TOKEN (arx.dist.ShardedHMFBags); 1 M items")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--ring", action="store_true",
+                    help="announce the next batch (prepare_next): step t sorts step t + 1's lookups.  Off by default: "
+                         "measured slower (DESIGN.md section 4: two graphs launched in turn cost ~15 us per step)")
     ap.add_argument("--no-rooflines", action="store_true", help="skip the per-kernel timings (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -412,13 +415,25 @@ def run_hmf(args, name, steps, warmup, with_cpu=False):
     redraws = [0]
 
     def run(k0, k1):
-        for k in range(k0, k1):
-            pool = None
+        # --ring: the loader hands the NEXT step's ids (and its pool, when that step redraws) over one step early
+        # (LatentProductModel.prepare_next): the ids-only half of the sparse update then runs a step ahead
+        drawn = {}
+
+        def pool_of(k):
             if k == 0 or (k >= warmup and (k - warmup) % args.n_resample == 0):
-                pool = sampler.sample(S)
-                redraws[0] += k >= warmup
+                if k not in drawn:
+                    drawn[k] = sampler.sample(S)
+                    redraws[0] += k >= warmup
+                return drawn[k]
+            return None
+        for k in range(k0, k1):
+            pool = pool_of(k)
             u, i = batches[k % nb]
+            if args.ring and k + 1 < k1:
+                un, in_ = batches[(k + 1) % nb]
+                model.prepare_next(un, in_, pool_of(k + 1))
             model.step_async(None, u, i, None, pool, None, loss='mw')
+            drawn.pop(k, None)
 
     run(0, warmup)
     torch.cuda.synchronize()
@@ -451,6 +466,7 @@ def run_hmf(args, name, steps, warmup, with_cpu=False):
                                % (label, args.n_items, args.n_users, d, S, args.n_resample, redraws[0], B),
                    "batch": B, "n_sampled": S, "dim": d, "n_items": args.n_items, "n_users": args.n_users,
                    "hipgraph": not args.no_graph, "pool_redraws_timed": redraws[0],
+                   "next_batch_announced": bool(args.ring),
                    "sampled_negative_logits_per_s": B * S * steps / wall,
                    "pool_rows_per_s": S * steps / wall, "hip_event_ms_per_step": ev_ms / steps,
                    "timed_regions": len(walls), "ms_per_step_min": 1e3 * min(walls) / steps,

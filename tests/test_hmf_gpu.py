@@ -396,3 +396,44 @@ def test_hmf_streaming_eval_loss(dev, monkeypatch, cfg, loss):
     e_ref = ref.step(list(users), list(items), forward_only=True, loss=loss)
     e_got = model.step(None, list(users), list(items), forward_only=True, loss=loss)
     np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
+
+
+@pytest.mark.parametrize("cfg", [CFG_ID, CFG_HET])
+def test_hmf_prepare_next_ring_mode_bit_identical(dev, monkeypatch, cfg):
+    """prepare_next (ring mode: the K7 sort half of step t + 1 runs as a side branch of step t): the same steps with
+    and without the announcement leave bit-identical tables and losses -- through graph capture of both parities, a
+    pool redraw that is announced, one that is NOT, and a step without announcement in the middle -- and match the
+    oracle."""
+    import torch
+    monkeypatch.setenv('ARX_K7_EARLY_MIN', '0')           # (the sort branch exists at this small size too)
+    B, S, d = 512, 128, 64
+    steps = 12
+    rng = np.random.default_rng(3)
+    syn0, m_plain, ref = _build(cfg, 'mw', d, B, S, seed=9)
+    _, m_ring, _ = _build(cfg, 'mw', d, B, S, seed=9)
+    dev_ = m_ring.rt.device
+    batches = [syn0.sample_batch(B, rng) for _ in range(steps)]
+    pools = {0: syn0.sample_pool(S, rng), 6: syn0.sample_pool(S, rng), 9: syn0.sample_pool(S, rng)}
+    tb = [(torch.from_numpy(u.astype(np.int32)).to(dev_), torch.from_numpy(i.astype(np.int32)).to(dev_))
+          for u, i in batches]
+    tp = {k: torch.from_numpy(v.astype(np.int32)).to(dev_) for k, v in pools.items()}
+    id2idx = None
+    for k in range(steps):
+        u, i = batches[k]
+        pool = pools.get(k)
+        if pool is not None:
+            id2idx = {int(v): j for j, v in enumerate(pool)}
+        l_ref = ref.step(list(u), list(i), pool, id2idx, loss='mw')
+        l_a = m_plain.step(None, tb[k][0], tb[k][1], None, tp.get(k), None, loss='mw')
+        if k + 1 < steps and k != 4:                      # (step 4 announces nothing: step 5 sorts for itself)
+            nxt_pool = tp.get(k + 1) if k + 1 != 9 else None      # the redraw of step 9 is NOT announced
+            m_ring.prepare_next(tb[k + 1][0], tb[k + 1][1], nxt_pool)
+        l_b = m_ring.step(None, tb[k][0], tb[k][1], None, tp.get(k), None, loss='mw')
+        assert l_a == l_b, (k, l_a, l_b)
+        np.testing.assert_allclose(l_a, l_ref, rtol=RTOL, err_msg='step %d' % k)
+    pa, pb = m_plain.att_emb.get_params(), m_ring.att_emb.get_params()
+    for name in pa:
+        assert np.array_equal(pa[name], pb[name]), name
+    plan = m_ring._plan('train')
+    assert len(plan._ring_graphs) == 2                    # both parities were captured and replayed
+    _compare_state(m_plain, ref)
