@@ -741,5 +741,7 @@ class RefLatentProductModel(object):
         m.get_batch_user_bwd(c_user, d_u, grads)
         m.apply_gradients(grads, self.learning_rate)                # :150
         self.global_step += 1
-        self.last = {'logits': logits, 'batch_loss': bl, 'mask': mask, 'u': u}
+        # (kept for the tests' condition-aware bounds: the un-merged contributions and what produced them)
+        self.last = {'logits': logits, 'batch_loss': bl, 'mask': mask, 'u': u, 'd_logits': d_logits,
+                     'c_pred': c_pred, 'grads': grads}
         return self.dt.type(the_loss)

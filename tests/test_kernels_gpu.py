@@ -417,6 +417,27 @@ def _ref_sparse_adagrad(E, acc, bias, bacc, keys, src, coef, G, Gb, lr, gs=1.0):
     return E, acc, bias, bacc
 
 
+def _sparse_adagrad_sum_bound(E, acc0, keys, src, coef, G, lr, gs=1.0):
+    """First-order bound of what f32 summation ORDER may change in a sparse Adagrad update (the merged row is a
+    sum of n_k terms c*G[s]; any f32 order is within n_k * 2^-24 * sum|c*G[s]| of the exact sum -- Higham,
+    Accuracy and Stability, (4.4)), carried through acc += g^2 and E -= lr * g / sqrt(acc).  Returns
+    (bound on acc, bound on E), both [rows, d]: zero for rows whose run is one entry."""
+    live = keys != 0x7FFFFFFF
+    k, s_, c = keys[live].astype(np.int64), src[live], coef[live].astype(np.float64)
+    rows, d = E.shape
+    absg = np.zeros((rows, d))
+    g = np.zeros((rows, d))
+    np.add.at(absg, k, np.abs(c[:, None] * G[s_].astype(np.float64)))
+    np.add.at(g, k, c[:, None] * G[s_].astype(np.float64))
+    n_k = np.bincount(k, minlength=rows).astype(np.float64)[:, None]
+    gam = np.where(n_k > 1, n_k, 0.0) * 2.0 ** -24 * absg * gs
+    g = np.abs(g) * gs
+    acc = acc0.astype(np.float64) + g * g
+    b_acc = 2 * g * gam + gam * gam
+    b_E = lr * (gam / np.sqrt(acc) + g * b_acc / (2 * acc ** 1.5))
+    return b_acc, b_E
+
+
 @pytest.mark.parametrize("d,n,Vf,hot", [(128, 5000, 300, 0), (128, 20000, 5000, 3000),
                                         (32, 777, 50, 400), (64, 64, 1000, 0), (128, 130, 2, 0),
                                         # n > 8192: device-wide LSD radix sort (2 / 3 passes,
@@ -843,9 +864,16 @@ def test_sparse_adagrad_ticket_large_n(dev, n, Vf, dist):
         torch.cuda.synchronize()
         assert int(cnt.abs().sum().item()) == 0
         outs.append((tE, tacc, tb))
-    np.testing.assert_allclose(outs[0][1].cpu().numpy(), racc, rtol=3e-4, atol=1e-4)
-    np.testing.assert_allclose(outs[0][0].cpu().numpy(), rE, rtol=3e-4, atol=1e-4)
-    np.testing.assert_allclose(outs[0][2].cpu().numpy(), rb, rtol=3e-4, atol=1e-4)
+    # the tolerance of every other K7 test (rtol 1e-4, atol 1e-5 / 2e-5) plus a DERIVED term for the summation
+    # order of long runs -- up to 80 k entries of mixed sign here, where cancellation, not the kernel, sets the
+    # error: n_k * 2^-24 * sum|c*g| carried through the Adagrad formula (_sparse_adagrad_sum_bound)
+    b_acc, b_E = _sparse_adagrad_sum_bound(E, acc, keys, src, coef, G, 0.3)
+    bb_acc, bb_E = _sparse_adagrad_sum_bound(bias[:, None], bacc[:, None], keys, src, coef, Gb[:, None], 0.3)
+    for got, ref, bound, atol in ((outs[0][1], racc, b_acc, 1e-5), (outs[0][0], rE, b_E, 2e-5),
+                                  (outs[0][2], rb, bb_E[:, 0], 2e-5)):
+        err = np.abs(got.cpu().numpy().astype(np.float64) - ref)
+        lim = 1e-4 * np.abs(ref) + atol + bound
+        assert (err <= lim).all(), (float((err - lim).max()), float(bound.max()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
