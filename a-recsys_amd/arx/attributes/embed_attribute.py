@@ -188,9 +188,7 @@ class EmbeddingAttribute(object):
             self.item2slot = torch.full((self.n_items + 1,), -1, dtype=torch.int32, device=rt.device)
             # 1 bit per item "in the pool?" in front of the map (arx_slot_map_attach_bitmap)
             self._pool_bits = torch.zeros(((self.n_items + 1) + 32) // 32, dtype=torch.int32, device=rt.device)
-            import os as _os
-            if not _os.environ.get('ARX_NO_POOL_BITMAP'):                     # A/B aid
-                ops.slot_map_attach_bitmap(self.item2slot, self._pool_bits)
+            ops.slot_map_attach_bitmap(self.item2slot, self._pool_bits)
         self._item2logit_dev = None
         self._item2logit_np = None
         if item_ind2logit_ind is not None:

@@ -344,12 +344,9 @@ class Prediction(Node):
             hook = getattr(self.rt, '_between_backward_gemms', None)
             if hook is not None:
                 hook()
-            # dIbar = dL^T . U ; dbbar = rowsum(dL^T) rides in the same kernel.  Independent
-            # of the dU GEMM above: runs on a side branch, joined before the optimiser.
-            tok = self.rt.fork(0)
+            # dIbar = dL^T . U ; dbbar = rowsum(dL^T) rides in the same kernel
             ops.gemm(dl, latent.value, gp, self.rt.ws, transA=True, beta=beta,
                      a_rowsum=pool.bias_grad)
-            self.rt._pending.append(self.rt.end_fork(tok))
             pool.bias_grad_used = True
 
 
@@ -555,8 +552,7 @@ class BatchLoss(Node):
         # a row also forms its target score and the two rank-one gradients (2 launches less)
         self.fuse_ts = False
         self.gemm_fused = False
-        if (kind in ('mw', 'mce') and isinstance(target, TargetScore) and mask is not None and mask.fused
-                and not os.environ.get('ARX_LOSS_NOFUSE')):
+        if kind in ('mw', 'mce') and isinstance(target, TargetScore) and mask is not None and mask.fused:
             lat, te = target.inputs
             d, W = lat.shape[1], logits.shape[1]
             if W <= 2048 and W % 4 == 0 and d % 4 == 0 and d <= 256 and te.shape[1] == d:
@@ -870,14 +866,13 @@ class Plan(object):
         if self._pregather is None:
             self._pregather = []
             groups = {}
-            if not os.environ.get('ARX_NO_MULTI_GATHER'):
-                for n in self.order:
-                    kinds = tuple(f.kind for f in n.feats) if isinstance(n, EntityEmbed) else ()
-                    if (kinds in (('cat',), ('mulhot',), ('cat', 'mulhot')) and not n.concat
-                            and all(f.d == n.feats[0].d for f in n.feats)
-                            and type(n.inputs[0]).__name__ in ('IdsInput', 'IdsSlice')
-                            and n.inputs[0].value.dtype == torch.int32):
-                        groups.setdefault(n.shape[1], []).append(n)
+            for n in self.order:
+                kinds = tuple(f.kind for f in n.feats) if isinstance(n, EntityEmbed) else ()
+                if (kinds in (('cat',), ('mulhot',), ('cat', 'mulhot')) and not n.concat
+                        and all(f.d == n.feats[0].d for f in n.feats)
+                        and type(n.inputs[0]).__name__ in ('IdsInput', 'IdsSlice')
+                        and n.inputs[0].value.dtype == torch.int32):
+                    groups.setdefault(n.shape[1], []).append(n)
             for d_, nodes in groups.items():
                 for k in range(0, len(nodes), 8):
                     grp = nodes[k:k + 8]
@@ -920,39 +915,27 @@ class Plan(object):
         # two-stage bag pass of its own (C3-MIX, ~135 us of sorts) the early start wins (414 vs 423
         # us); one-hot only (C2): no difference.
         rider = any(j[0] == 'multi' and j[1][1] is not None for j in self._early_jobs)
-        early_after = int(os.environ.get('ARX_K7_EARLY_AFTER', '1' if rider else '0')) if self.train else -1
+        early_after = (1 if rider else 0) if self.train else -1
         if early_after == 0:
             self._early_launch()
-        # lookups whose ids are placeholders are independent of each other: fork them
-        roots = [n for n in self.order if isinstance(n, EntityEmbed) and type(n.inputs[0]).__name__ in
-                 ('IdsInput', 'IdsSlice') and id(n) not in pre]
-        toks = []
-        for k, n in enumerate(roots[1:]):
-            t = rt.fork(k)
-            n.forward(self.train)
-            toks.append(rt.end_fork(t))
         k_fwd = 0
         for n in self.order:
-            if n in roots[1:] or id(n) in pre:
+            if id(n) in pre:
                 continue
             n.forward(self.train)
-            if roots and n is roots[0]:
-                for t in toks:
-                    rt.join(t)
             k_fwd += 1
             if k_fwd == early_after:
                 self._early_launch()
         if self.train:
             self._early_launch()          # (no-op when already issued)
         if self.train:
-            rt._pending = []
             # The one-hot sort of the K7 branch is long done when the backward GEMMs start: the main
             # chain takes that dependency THERE (between dU and dI), where it costs nothing, instead
             # of in front of the one-hot apply, where a two-parent node starts ~10 us late (measured)
             self._mid_waited = False
             # (measured: with a VIRTUAL entity table -- MIX -- 350 -> 340 us/step; with a real id table -- HET
             # -- 313 -> 315, so there the dependency stays at the apply)
-            mid_at = os.environ.get('ARX_K7_MID_AT') or ('dI' if getattr(self, '_k7_virtual', False) else 'apply')
+            mid_at = 'dI' if getattr(self, '_k7_virtual', False) else 'apply'
             if (self._k7_early is not None and self._k7_early[2] is not None and self._k7_early[2] != 'ring'
                     and mid_at == 'dI'):
                 def _mid_wait(ev=self._k7_early[2]):
@@ -966,9 +949,6 @@ class Plan(object):
                         n.backward()
             finally:
                 rt._between_backward_gemms = None     # (never leave a closure over this step's event behind)
-            for t in rt._pending:
-                rt.join(t)
-            rt._pending = []
             dp = rt.dp
             if dp is not None:
                 # data-parallel replicas (arx.dist.SeqDataParallel): dense and pool gradients are
@@ -1073,17 +1053,6 @@ class Plan(object):
             self._k7_done_keys = early[0]
         self._jobs, self._n_passes = [], 0
         done = set(id(e) for e, _, _ in fused)
-        toks = []
-
-        def rest(first_on_main):
-            for ti, entry in enumerate(self.tables):
-                if id(entry) in done:
-                    continue
-                tok = rt.fork(ti, 'tables') if (ti > 0 or not first_on_main) else None   # tables are independent
-                self._apply_one(entry)
-                if tok is not None:
-                    toks.append(rt.end_fork(tok))
-
         rider = self._find_rider(fused, done) if fused else None
         if rider is not None:
             # a multi-hot table looked up with exactly the lookups of one fused one-hot table (HET: an
@@ -1098,9 +1067,6 @@ class Plan(object):
         elif len(fused) == 1:
             fused = []                       # (a lone one-hot table keeps its own pass)
             done = set()
-        side_first = bool(fused) and rt.use_streams in ('tables', '1')
-        if side_first:
-            rest(False)          # the other tables' passes go to side branches, under the fused pass
         if fused:
             key = self._multi_key(fused)
             bag = None
@@ -1113,13 +1079,6 @@ class Plan(object):
                 raise RuntimeError("ring mode: the step's K7 pass differs from the one sorted ahead")
             if phase == 2 and ring_done is not None and bag is not None:
                 self._apply_multi(fused, phase=7, key=key, bag=bag)
-                # the branch (the NEXT step's sorts) rejoins here, not at the end of the step: nothing below
-                # needs it, but a branch whose only successor is the graph's last node was started ~90 us late
-                # by the graph scheduler (measured: the step took 269 us instead of 251); with the join where
-                # the two-phase graph has it the branch starts behind the first lookup again
-                if os.environ.get('ARX_RING_JOIN', 'apply') == 'apply':
-                    torch.cuda.current_stream().wait_event(ring_done)
-                    ring_done = None
                 self._apply_multi(fused, phase=8, key=key, bag=bag)
             elif phase == 2 and split_join is not None and bag is not None:
                 self._apply_multi(fused, phase=7, key=key, bag=bag)
@@ -1141,10 +1100,9 @@ class Plan(object):
             self._n_passes += 1
         if split_join is not None:
             torch.cuda.current_stream().wait_event(split_join)
-        if not side_first:
-            rest(True)
-        for t in toks:
-            rt.join(t)
+        for entry in self.tables:            # the tables that are not part of the fused pass: one pass each
+            if id(entry) not in done:
+                self._apply_one(entry)
         if ring_done is not None:
             torch.cuda.current_stream().wait_event(ring_done)      # rejoin the branch (next step's sorts)
         self._plan_early(self._jobs, self._n_passes)
@@ -1303,7 +1261,7 @@ class Plan(object):
         self._k7_early = None
         self._k7_fork = None
         jobs = self._early_jobs
-        if not jobs or (os.environ.get('ARX_K7_NO_EARLY') and not self._ring) or self.rt.dp is not None:
+        if not jobs or self.rt.dp is not None:
             return                            # (data-parallel: the apply sorts the GATHERED lookups)
         rt = self.rt
         if self._k7_stream is None:
@@ -1326,7 +1284,7 @@ class Plan(object):
         with torch.cuda.stream(self._k7_stream):
             mid = None
             for kind, what, key in jobs:
-                if kind == 'multi' and what[1] is not None and len(jobs) == 1 and not os.environ.get('ARX_K7_NO_SPLIT'):
+                if kind == 'multi' and what[1] is not None and len(jobs) == 1:
                     # a bag table rides on the pass: the one-hot apply only needs the one-hot sort --
                     # the token chain behind it may still run while that apply does (quarter phases)
                     self._apply_multi(what[0], phase=5, key=key, bag=what[1])
@@ -1614,20 +1572,14 @@ class Runtime(object):
         self.dropout_calls = 0
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)   # device step counter
         self.pending_feeds = []         # (src, placeholder buffer) device-to-device feeds not yet issued
-        import os as _os
-        self.force_sort_path = bool(_os.environ.get('ARX_FORCE_SORT'))
-        self.cat_mode = 1 if _os.environ.get('ARX_CAT_ATOMIC') else 0
-        self.no_multi = bool(_os.environ.get('ARX_NO_MULTI'))      # A/B aid: one K7 pass per table
-        self.no_bags = bool(_os.environ.get('ARX_NO_BAGS'))        # A/B aid: contribution-level multi-hot pass
-        self.no_rider = bool(_os.environ.get('ARX_NO_RIDER'))      # A/B aid: the bag table keeps its own two-stage pass
-        self.no_virtual = bool(_os.environ.get('ARX_NO_VIRTUAL'))  # A/B aid: ... unless an id table shares its lookups
-        # fork/join branches inside the captured graph measured SLOWER on ROCm 7.2 (250 us vs
-        # 187 us per C2 step: cross-stream graph edges cost more than the overlap buys at
-        # these kernel sizes) -- opt-in only.
-        self.use_streams = _os.environ.get('ARX_STREAMS') or False    # '1': all branches, 'tables': K7 only
-        self._side = None
-        self._side_ws = None
-        self._pending = []
+        # K7 pass selection overrides (attributes, not environment switches: set them on the runtime object to
+        # force a pass shape that the sizes would not pick; all False / 0 in production)
+        self.force_sort_path = False     # every table through arx_sparse_adagrad (explicit triples)
+        self.cat_mode = 0                # 1: atomic-election one-hot pass (arx_sparse_adagrad_cat mode 1)
+        self.no_multi = False            # one K7 pass per table
+        self.no_bags = False             # contribution-level multi-hot pass
+        self.no_rider = False            # the bag table keeps its own two-stage pass
+        self.no_virtual = False          # ... unless an id table shares its lookups
         self.dp = None                  # arx.dist.SeqDataParallel: gradient exchange between replicas
 
     def drop_feed(self, dst):
@@ -1648,42 +1600,6 @@ class Runtime(object):
         if self.pending_feeds:
             pf, self.pending_feeds = self.pending_feeds, []
             ops.copy_words(pf)
-
-    # ---- fork/join onto side streams: independent branches of a step (the lookups of
-    # different entities, the dU / dI GEMMs, the per-table sparse updates) run
-    # concurrently; captured into the hipGraph the forks become parallel graph edges.
-    def fork(self, k, kind='other'):
-        """Start side branch k: returns a token for join().  Work issued until the
-        matching end_fork() goes to side stream k with its own workspace."""
-        if not self.use_streams or (self.use_streams == 'tables' and kind != 'tables'):
-            return None
-        if self._side is None:
-            self._side = [torch.cuda.Stream(device=self.device) for _ in range(3)]
-            self._side_ws = [ops.Workspace(self.device) for _ in range(3)]
-        k = k % len(self._side)
-        main = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(main)
-        self._side[k].wait_event(ev)
-        ctx = torch.cuda.stream(self._side[k])
-        ctx.__enter__()
-        tok = {'k': k, 'ctx': ctx, 'ws': self.ws, 'main': main}
-        self.ws = self._side_ws[k]
-        return tok
-
-    def end_fork(self, tok):
-        if tok is None:
-            return None
-        ev = torch.cuda.Event()
-        ev.record(self._side[tok['k']])
-        tok['ctx'].__exit__(None, None, None)
-        self.ws = tok['ws']
-        tok['done'] = ev
-        return tok
-
-    def join(self, tok):
-        if tok is not None:
-            torch.cuda.current_stream().wait_event(tok['done'])
 
     def set_learning_rate(self, v):
         self.lr_host = float(v)

@@ -344,9 +344,6 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
   const int cus = cu_count();
   const int64_t tiles_big = ceil_div(M, 128) * ceil_div(N, 128);
   p.big = tiles_big * 4 >= (int64_t)cus * 3;
-  static const char* force = getenv("ARX_GEMM_FORCE");   // tuning aid: "big" | "small"
-  if (force && force[0] == 'b') p.big = true;
-  if (force && force[0] == 's') p.big = false;
   p.splits = 1;
   p.kchunk = K > 0 ? K : 1;
   if (!p.big) {
@@ -423,14 +420,10 @@ int arx_gemm_f32_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K,
                 "arx_gemm_f32: leading dimension too small");
   hipStream_t s = as_stream(stream);
   if (!transA && transB && beta == 0.f && !a_rowsum) {   // the scorer shape: K = embedding width
-    static const bool old_nt = getenv("ARX_GEMM_NT_OLD") != nullptr;   // A/B aid
-    if (!old_nt) {
-      const int rc_nt = gemm_nt_smallk(M, N, K, alpha, A, lda, B, ldb, C, ldc, col_bias, s);
-      if (rc_nt != ARX_EUNSUPPORTED) return rc_nt;
-    }
+    const int rc_nt = gemm_nt_smallk(M, N, K, alpha, A, lda, B, ldb, C, ldc, col_bias, s);
+    if (rc_nt != ARX_EUNSUPPORTED) return rc_nt;
   }
-  static const bool old_bwd = getenv("ARX_GEMM_DMA_OFF") != nullptr;   // A/B aid
-  if (!old_bwd && gemm_dma_supported(transA, transB, M, N, K, A, lda, B, ldb)) {
+  if (gemm_dma_supported(transA, transB, M, N, K, A, lda, B, ldb)) {
     int bm, sp;
     int64_t kc;
     gemm_dma_plan(M, N, K, &bm, &sp, &kc);
@@ -467,18 +460,13 @@ int arx_gemm_f32_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K,
     if (a_rowsum) rs_partial = partial + (size_t)p.splits * (size_t)M * (size_t)N;
   }
   int rc;
-  static const int bk_big = getenv("ARX_GEMM_BK_BIG") ? atoi(getenv("ARX_GEMM_BK_BIG")) : 16;
-  static const int bk_small = getenv("ARX_GEMM_BK_SMALL") ? atoi(getenv("ARX_GEMM_BK_SMALL")) : 16;
 #define ARX_GO(BM_, BN_, BK_)                                                                   \
   rc = launch_gemm<BM_, BN_, BK_>(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
                                   col_bias, partial, p, s, a_rowsum, rs_partial)
   if (p.big) {
-    if (bk_big == 32) ARX_GO(128, 128, 32);
-    else ARX_GO(128, 128, 16);
+    ARX_GO(128, 128, 16);
   } else {
-    if (bk_small == 64) ARX_GO(64, 64, 64);
-    else if (bk_small == 32) ARX_GO(64, 64, 32);
-    else ARX_GO(64, 64, 16);
+    ARX_GO(64, 64, 16);
   }
 #undef ARX_GO
   if (rc) return rc;
@@ -503,14 +491,12 @@ int arx_gemm_f32_steps_tn(int64_t steps, int64_t M, int64_t N, int64_t Kb, const
   p.big = false;
   p.splits = (int)steps;
   p.kchunk = Kb;
-  static const bool dma_off = getenv("ARX_GEMM_DMA_OFF") != nullptr;
   int rc;
-  if (!dma_off && steps > 1 && Kb % 32 == 0 &&
+  if (steps > 1 && Kb % 32 == 0 &&
       gemm_dma_supported(1, 0, M, N, steps * Kb, A, lda, B, ldb)) {
     // one split-K slice per step on the LDS-DMA kernel: the "partials" ARE the per-step products
-    static const int sbm = getenv("ARX_STEPS_BM") ? atoi(getenv("ARX_STEPS_BM")) : 128;
     rc = gemm_dma_launch(1, M, N, steps * Kb, 1.f, A, lda, B, ldb, 0.f, C_steps, N, nullptr, C_steps,
-                         (sbm == 64 || M % 128 != 0) ? 64 : 128, (int)steps, Kb, rowsum_steps, rowsum_steps, s);
+                         (M % 128 != 0) ? 64 : 128, (int)steps, Kb, rowsum_steps, rowsum_steps, s);
   } else
   rc = launch_gemm<64, 64, 16>(1, 0, M, N, steps * Kb, 1.f, A, lda, B, ldb, 0.f, C_steps, N,
                                nullptr, C_steps, p, s, rowsum_steps ? rowsum_steps : nullptr,

@@ -290,15 +290,6 @@ void gemm_dma_plan(int64_t M, int64_t N, int64_t K, int* bm, int* splits, int64_
   (void)N;
   const int cus = cu_count();
   const int64_t tiles128 = ceil_div(M, (int64_t)128);
-  static const int f_bm = getenv("ARX_DMA_BM") ? atoi(getenv("ARX_DMA_BM")) : 0;        // tuning aids
-  static const int f_sp = getenv("ARX_DMA_SPLITS") ? atoi(getenv("ARX_DMA_SPLITS")) : 0;
-  if (f_bm && f_sp) {
-    *bm = f_bm;
-    int64_t chunk = ceil_div(ceil_div(K, (int64_t)f_sp), (int64_t)kBK) * kBK;
-    *kchunk = chunk;
-    *splits = (int)ceil_div(K, chunk);
-    return;
-  }
   if (tiles128 >= cus) {
     *bm = 128;
     *splits = 1;

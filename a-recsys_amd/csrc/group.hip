@@ -605,8 +605,7 @@ size_t al(size_t v) { return (v + 255) / 256 * 256; }
 }  // namespace
 
 bool runs_path(int d) {
-  static const bool off = getenv("ARX_K7_WINDOWS") != nullptr;      // A/B: the window + finish kernels of optim.hip
-  return !off && lanes_per_row(d) >= 8;
+  return lanes_per_row(d) >= 8;
 }
 
 // long runs have more than 8 entries (LPR >= 8)

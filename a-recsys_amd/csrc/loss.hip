@@ -440,8 +440,7 @@ static bool launch_margin_wave(const float* logits, int64_t ldl, const float* ts
                                int64_t mask_rows, float gscale, const float* row_w, int64_t B,
                                int64_t W, float* batch_loss, float* dlogits, int64_t lddl,
                                float* dtscore, PosMask pm, hipStream_t s, DotFuse df = DotFuse{}) {
-  static const bool off = getenv("ARX_LOSS_WAVE_OFF") != nullptr;   // A/B aid
-  if (off || W > 2048 || (ldl % 4) || (dlogits && (lddl % 4)) ||
+  if (W > 2048 || (ldl % 4) || (dlogits && (lddl % 4)) ||
       (reinterpret_cast<uintptr_t>(logits) & 15) || (reinterpret_cast<uintptr_t>(dlogits) & 15))
     return false;
   const int grid = (int)ceil_div(B, 4);

@@ -671,13 +671,11 @@ int arx_lstm_fwd(const float* x, const float* W, const float* b, int64_t L, int6
   if (L == 0 || B == 0) return ARX_OK;
   hipStream_t s = as_stream(stream);
   const bool mfma_ok = (h % 64 == 0) && (h <= 128) && (din % 4 == 0);
-  static const bool wreg_off = getenv("ARX_LSTM_WREG_OFF") != nullptr;   // A/B aid
   // four-row workgroups while they fill the chip better than sixteen-row ones (B / 16 < 2 per CU)
-  static const bool r4_off = getenv("ARX_LSTM_R4_OFF") != nullptr;       // A/B aid
-  const bool r4 = !r4_off && h == 64 && din == 64 && ceil_div(B, kRows) < 2 * (int64_t)cu_count();
+  const bool r4 = h == 64 && din == 64 && ceil_div(B, kRows) < 2 * (int64_t)cu_count();
   if (r4) {
     k_lstm_fwd_r4<64><<<(int)ceil_div(B, kR4), 256, 0, s>>>(x, W, b, L, B, forget_bias, hs, cs, gates);
-  } else if (h == 64 && din == 64 && !wreg_off) {
+  } else if (h == 64 && din == 64) {
     k_lstm_fwd_wreg<64><<<(int)ceil_div(B, kRows), 256, 0, s>>>(x, W, b, L, B, forget_bias, hs, cs,
                                                                    gates);
   } else if (mfma_ok) {
@@ -703,12 +701,10 @@ int arx_lstm_bwd(const float* W, const float* hs, const float* cs, const float* 
   if (L == 0 || B == 0) return ARX_OK;
   hipStream_t s = as_stream(stream);
   const bool mfma_ok = (h % 64 == 0) && (h <= 128);
-  static const bool wreg_off = getenv("ARX_LSTM_WREG_OFF") != nullptr;   // A/B aid
-  static const bool r4_off = getenv("ARX_LSTM_R4_OFF") != nullptr;       // A/B aid
-  const bool r4 = !r4_off && h == 64 && din == 64 && ceil_div(B, kRows) < 2 * (int64_t)cu_count();
+  const bool r4 = h == 64 && din == 64 && ceil_div(B, kRows) < 2 * (int64_t)cu_count();
   if (r4) {
     k_lstm_bwd_r4<64><<<(int)ceil_div(B, kR4), 256, 0, s>>>(W, cs, gates, dhs, L, B, dz);
-  } else if (h == 64 && din == 64 && !wreg_off) {
+  } else if (h == 64 && din == 64) {
     k_lstm_bwd_wreg<64><<<(int)ceil_div(B, kRows), 256, 0, s>>>(W, cs, gates, dhs, L, B, dz);
   } else if (mfma_ok) {
     const size_t lds = (size_t)(kRows * (4 * h + 2)) * sizeof(float);

@@ -33,8 +33,8 @@ constexpr int kRankSortMax = 8192;
 // entity stage of arx_sparse_adagrad_bags.  (Measured: ONE rank-sort launch at n = 17.4 k -- 70 KB of
 // keys staged per workgroup, O(n^2) compares -- costs ~115 us against ~45 us for the 7 launches of
 // the two-pass radix sort; the rank sort stays below 8192.)
-static const int kTokenWpw = getenv("ARX_TOKEN_WPW") ? atoi(getenv("ARX_TOKEN_WPW")) : 4;   // waves per window of the token stage (merged rows: 342 us/step with 1, 336 with 4, 344 with 8 at C3 B=16384)
-static const int kRankSortEntities = getenv("ARX_RANK_ENT_MAX") ? atoi(getenv("ARX_RANK_ENT_MAX")) : kRankSortMax;
+static const int kTokenWpw = 4;   // waves per window of the token stage (merged rows: 342 us/step with 1, 336 with 4, 344 with 8 at C3 B=16384)
+static const int kRankSortEntities = kRankSortMax;
 constexpr int kPassBBlocks = 128;   // persistent grid of pass B
 
 // Stable rank sort for n <= 16384 keys, chip-wide in ONE launch: every workgroup keeps
@@ -109,7 +109,7 @@ static inline int launch_rank_sort(const int32_t* keys, int64_t n, uint32_t sent
                                    uint32_t* spos, int32_t* count, hipStream_t s,
                                    const int32_t* src_in = nullptr, const float* coef_in = nullptr,
                                    int32_t* ssrc = nullptr, float* scoef = nullptr) {
-  static const int tpe = getenv("ARX_RANK_TPE") ? atoi(getenv("ARX_RANK_TPE")) : 16;
+  const int tpe = 16;      // lanes sharing one element (32 / 8 / 4 measured slower at n = 5 k .. 16 k)
   const size_t lds = (size_t)((n + 3) & ~(int64_t)3) * sizeof(uint32_t);
   if (lds > 64 * 1024) {       // past the default dynamic-LDS limit (n > 16384): opt in once
     static bool raised = false;
@@ -1334,8 +1334,7 @@ namespace arx {
 namespace {
 
 static bool bag_compact(int64_t n_i, int max_len) {
-  static const bool padded = getenv("ARX_K7_PADDED_BAGS") != nullptr;    // A/B: round-2 padded slots
-  return !padded && n_i * (int64_t)max_len > kRankSortMax && n_i <= (1 << 18);
+  return n_i * (int64_t)max_len > kRankSortMax && n_i <= (1 << 18);
 }
 
 // Stage 1b: the bags of the DISTINCT entities of a sorted entity-key list, sorted by token.
@@ -1878,7 +1877,7 @@ int arx_sq_norm_accum(const float* x, int64_t n, int d, const float* row_scale, 
   const int threads = (vec ? n / 4 : n) >= 64 * 1024 ? 1024 : 256;
   int nb = (int)ceil_div(vec ? n / 4 : n, (int64_t)threads * 4);
   if (nb < 1) nb = 1;
-  static const int cap = getenv("ARX_NORM_BLOCKS") ? atoi(getenv("ARX_NORM_BLOCKS")) : 128;
+  const int cap = 128;
   if (nb > cap) nb = cap;
   if (nb > kNormBlocks) nb = kNormBlocks;
   if (vec)
@@ -1903,7 +1902,7 @@ static int sq_norm_multi_impl(const char* who, int count, const float* const* x,
   // blocks per tensor: one per 8 K float4 per thread-row (32 KB), at most kNormBlocks / count -- the
   // step's big tensors (13 MB each at C4) were latency-bound with 16 blocks: 20.7 us for 39 MB
   // (more is not better: every block ends in a ticket atomic that serialises at ~16 ns)
-  static const int per_cap = getenv("ARX_NORM_PER") ? atoi(getenv("ARX_NORM_PER")) : 64;
+  const int per_cap = 64;
   int per = kNormBlocks / (count < 1 ? 1 : count);
   if (per > per_cap) per = per_cap;
   for (int t = 0; t < count; ++t) {
