@@ -519,7 +519,12 @@ def run_hmf(args, name, steps, warmup, with_cpu=False):
                     ent["frac"] = None
             out["roofline_gather"] = ent
         if pmc_src:
+            # the `traffic` fields are NOT measured by this run: they are read from the committed PMC summary of
+            # the builder's own rocprofv3 --pmc passes over the same command (tools/profile.sh; FETCH_SIZE x2)
             out["traffic_source"] = pmc_src
+            for rk in ("roofline", "roofline_hbm", "roofline_gather"):
+                if rk in out and out[rk].get("traffic") is not None:
+                    out[rk]["builder_profile"] = True
         out["kernels_ms"] = {k: v['ms'] for k, v in kr.items()}
         out["kernels"] = kr
     if with_cpu:

@@ -17,6 +17,12 @@ CAL_BYTES = 256 * 2 ** 20
 
 # bench.py kernel name -> substrings of the device kernels that implement it
 MAP = {
+    'gemm_logits_hinge': ['k_sc_hinge'],
+    'gemm_dU_bits': ['k_sc_bits<false'],
+    'gemm_dI_bits': ['k_sc_bits<true'],
+    'scorer_prep': ['k_sc_prep'],
+    'scorer_rows': ['k_sc_rows'],
+    'scorer_tn_reduce': ['k_sc_tn_reduce'],
     'gemm_logits_nt': ['k_gemm_nt_areg'],
     'gemm_dU_nn': ['k_gemm_dma<true', 'k_gemm_f32<64, 64, 16, true, false>', 'k_gemm_f32<128, 128, 16, true, false>'],
     'gemm_dI_tn': ['k_gemm_dma<false', 'k_gemm_f32<64, 64, 16, false, false>', 'k_gemm_f32<128, 128, 16, false, false>'],
