@@ -913,35 +913,73 @@ __global__ __launch_bounds__(256) void k_sc_tn_reduce(const float* __restrict__ 
                                                       float beta, float* __restrict__ C, int64_t ldc,
                                                       const float* __restrict__ dbp, int64_t nblk,
                                                       float* __restrict__ db, int dbblocks) {
-  __shared__ float sp[4][64];
   const int nmain = (int)gridDim.x - dbblocks;
   if ((int)blockIdx.x >= nmain) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t m = (int64_t)((int)blockIdx.x - nmain) * 64 + lane;
-    const int64_t per = (nblk + 3) / 4, b0 = wv * per, b1 = b0 + per < nblk ? b0 + per : nblk;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (m < M) {
-      int64_t b = b0;
-      for (; b + 3 < b1; b += 4) {
-        a0 += dbp[b * M + m]; a1 += dbp[(b + 1) * M + m]; a2 += dbp[(b + 2) * M + m]; a3 += dbp[(b + 3) * M + m];
+    // 64 columns per workgroup: thread = (row group rg of 16, four columns cg); a thread adds up the partial rows
+    // rg, rg + 16, ... with sixteen 16-byte loads in flight (four waves walking 128 rows each, four loads at a time,
+    // were a chain of 32 L2 round trips: 12 us -- longer than the product this kernel finishes)
+    __shared__ float4 sdb[16][16];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int64_t m0 = (int64_t)((int)blockIdx.x - nmain) * 64 + cg * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m0 < M) {
+      for (int64_t b = rg; b < nblk; b += 16 * 16) {
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int64_t bb = b + 16 * u;
+          v[u] = bb < nblk ? *reinterpret_cast<const float4*>(dbp + bb * M + m0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
       }
-      for (; b < b1; ++b) a0 += dbp[b * M + m];
     }
-    sp[wv][lane] = (a0 + a1) + (a2 + a3);
+    sdb[rg][cg] = a;
     __syncthreads();
-    if (wv == 0 && m < M) db[m] = (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
+    if (rg == 0 && m0 < M) {
+      float4 t = sdb[0][cg];
+      for (int r = 1; r < 16; ++r) { const float4 o = sdb[r][cg]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+      *reinterpret_cast<float4*>(db + m0) = t;
+    }
     return;
   }
-  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // 64 float4 outputs per workgroup; wave w adds up its quarter of the slices (loads in batches of four, added in
+  // slice order), the four sub-sums meet in LDS in wave order: every load of a thread is in flight at once (one
+  // thread per output walked the slices as a chain of L2 round trips: 11-16 us for 16 slices of 0.5 MB)
+  __shared__ float4 sq[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.x * 64 + lane;
   const int n4 = N / 4;
-  if (q < M * n4) {
-    const int64_t m = q / n4;
-    const int c = (int)(q % n4) * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < nsl; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(part + ((int64_t)s * M + m) * N + c);
+  const bool live = q < M * n4;
+  const int64_t m = live ? q / n4 : 0;
+  const int c = live ? (int)(q % n4) * 4 : 0;
+  const int per = (nsl + 3) / 4, s0 = wv * per, s1 = min(nsl, s0 + per);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    const float* p0 = part + m * N + c;
+    const int64_t sl = M * (int64_t)N;
+    int sI = s0;
+    for (; sI + 3 < s1; sI += 4) {
+      const float4 v0 = *reinterpret_cast<const float4*>(p0 + (int64_t)sI * sl);
+      const float4 v1 = *reinterpret_cast<const float4*>(p0 + (int64_t)(sI + 1) * sl);
+      const float4 v2 = *reinterpret_cast<const float4*>(p0 + (int64_t)(sI + 2) * sl);
+      const float4 v3 = *reinterpret_cast<const float4*>(p0 + (int64_t)(sI + 3) * sl);
+      acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+      acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+      acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+      acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+    }
+    for (; sI < s1; ++sI) {
+      const float4 v = *reinterpret_cast<const float4*>(p0 + (int64_t)sI * sl);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
+  }
+  sq[wv][lane] = acc;
+  __syncthreads();
+  if (wv == 0 && live) {
+    const float4 a = sq[0][lane], b = sq[1][lane], e = sq[2][lane], f = sq[3][lane];
+    acc.x = (a.x + b.x) + (e.x + f.x); acc.y = (a.y + b.y) + (e.y + f.y);
+    acc.z = (a.z + b.z) + (e.z + f.z); acc.w = (a.w + b.w) + (e.w + f.w);
     float4* cp = reinterpret_cast<float4*>(C + m * ldc + c);
     if (beta != 0.f) {
       const float4 o = *cp;
@@ -1195,7 +1233,7 @@ int arx_mw_scorer_bwd_di(int64_t B, int64_t S, int d, const void* state, int64_t
   ARX_CHECK_LAUNCH();
   const float* dbp = reinterpret_cast<const float*>(st + L.dbp);
   const int dbblocks = db ? (int)ceil_div(S, 64) : 0;
-  k_sc_tn_reduce<<<(int)ceil_div(S * (d / 4), 256) + dbblocks, 256, 0, s>>>(part, (int)nsl, S, d, beta, dI, lddi, dbp,
+  k_sc_tn_reduce<<<(int)ceil_div(S * (d / 4), 64) + dbblocks, 256, 0, s>>>(part, (int)nsl, S, d, beta, dI, lddi, dbp,
                                                                            L.nblk, db, dbblocks);
   ARX_CHECK_LAUNCH();
   if (db_steps && step_rows > 0) {
