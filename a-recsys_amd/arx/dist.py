@@ -134,6 +134,9 @@ class HipBackend(object):
     def shard_route(self, ids, world, rank, zero_row, rows_out, keys_out):
         self.ops.shard_route(ids, world, rank, zero_row, rows_out, keys_out)
 
+    def pool_blocks(self, ids, world, rank, zero_row, cap, counts, gidx=None, my_slots=None, pool_rows=None):
+        self.ops.pool_blocks(ids, world, rank, zero_row, cap, counts, gidx, my_slots, pool_rows)
+
     def loss_mw_pos(self, logits, t, urows, ptr, items, i2s, bl, dl, dt, gscale):
         self.ops.loss_mw_pos(logits, t, urows, ptr, items, i2s, bl, dl, dt, gscale)
 
@@ -333,25 +336,17 @@ class ShardedHMF(object):
         if W == 1:
             be.shard_route(self.pool_ids, W, r, self.zero_row, self.pool_rows, None)
             return
-        # block layout (redraw path, every n_resample steps: index arithmetic on S ids, one host read)
-        ids = self.pool_ids.long()
-        owner = ids % W
-        order = torch.argsort(owner, stable=True)                       # slots by owner, slot order inside
-        counts = torch.bincount(owner, minlength=W)
-        start = torch.cumsum(counts, 0) - counts
-        cap = (int(counts.max().item()) + 3) // 4 * 4
+        # block layout (redraw path, every n_resample steps): two launches of arx_pool_blocks around ONE host
+        # read of the W owner counts (the block capacity is a host decision: it sizes the exchanges)
+        if getattr(self, '_pool_counts', None) is None:
+            self._pool_counts = torch.zeros(W, dtype=torch.int32, device=self.device)
+        be.pool_blocks(self.pool_ids, W, r, self.zero_row, 0, self._pool_counts)
+        cap = (int(self._pool_counts.max().item()) + 3) // 4 * 4
         if self.use_graphs:      # block capacity only grows (a new capacity = new graphs), with slack
             cap = self.cap if cap <= self.cap else min(S, (cap + cap // 8 + 15) // 16 * 16)
         self.cap = cap
-        pos = torch.empty(S, dtype=torch.int64, device=self.device)
-        pos[order] = torch.arange(S, device=self.device) - start[owner[order]]
-        self.gidx.copy_((owner * cap + pos).to(torch.int32))
-        cnt_r, st_r = int(counts[r].item()), int(start[r].item())
-        mine = order[st_r:st_r + cnt_r]
-        self.my_slots.fill_(S)
-        self.my_slots[:cnt_r] = mine.to(torch.int32)
-        self.pool_rows.fill_(self.zero_row)
-        self.pool_rows[:cnt_r] = (ids[mine] // W).to(torch.int32)
+        be.pool_blocks(self.pool_ids, W, r, self.zero_row, cap, self._pool_counts, self.gidx, self.my_slots,
+                       self.pool_rows)
 
     # ------------------------------------------------------------------ route
     def prepare_route(self, users, items):

@@ -131,6 +131,12 @@ def shard_route(ids, world, rank, zero_row, rows_out, keys_out):
          _p(rows_out), _p(keys_out), _stream())
 
 
+def pool_blocks(ids, world, rank, zero_row, cap, counts, gidx=None, my_slots=None, pool_rows=None):
+    """Block layout of a pool striped over `world` owners (arx.h); cap == 0: counts only."""
+    call("arx_pool_blocks", _p(ids), int(ids.shape[0]), int(world), int(rank), int(zero_row), int(cap),
+         _p(counts), _p(gidx), _p(my_slots), _p(pool_rows), _stream())
+
+
 def copy_2d(src, dst):
     call("arx_copy_2d", _p(src), _ld(src), _p(dst), _ld(dst), int(src.shape[0]), int(src.shape[1]),
          _stream())

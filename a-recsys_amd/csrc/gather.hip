@@ -312,6 +312,40 @@ __global__ void k_site_onehot(const int32_t* __restrict__ cat_map, const int32_t
 }
 
 // row-sharded table routing (mod-N striping): owner = id % world, local row = id / world
+// Block layout of a pool whose items are striped over `world` owners (owner = id % world): the owner's
+// items, in slot order, are rows [0, count_g) of its block.  One workgroup: S <= 4096 slots in LDS; a slot's
+// position in its block = the number of earlier slots of the same owner (O(S^2 / 1024) LDS reads).
+__global__ __launch_bounds__(1024) void k_pool_blocks(const int32_t* __restrict__ ids, int S, int world, int rank,
+                                                      int32_t zero_row, int cap, int32_t* __restrict__ counts,
+                                                      int32_t* __restrict__ gidx, int32_t* __restrict__ my_slots,
+                                                      int32_t* __restrict__ pool_rows) {
+  __shared__ int16_t own[4096];
+  __shared__ int cnt[64];
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) cnt[i] = 0;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) own[i] = (int16_t)(ids[i] % world);
+  __syncthreads();
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    const int o = own[i];
+    int pos = 0;
+    for (int j = 0; j < i; ++j) pos += own[j] == o;
+    atomicAdd(&cnt[o], 1);
+    if (cap > 0) {
+      gidx[i] = o * cap + pos;
+      if (o == rank) {
+        my_slots[pos] = i;
+        pool_rows[pos] = ids[i] / world;
+      }
+    }
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < world; g += blockDim.x) counts[g] = cnt[g];
+  if (cap > 0)
+    for (int i = cnt[rank] + threadIdx.x; i < S; i += blockDim.x) {     // the tail of this rank's lists: padding
+      my_slots[i] = S;
+      pool_rows[i] = zero_row;
+    }
+}
+
 __global__ void k_shard_route(const int32_t* __restrict__ ids, int64_t n, int world, int rank,
                               int32_t zero_row, int32_t* __restrict__ rows_out,
                               int32_t* __restrict__ keys_out) {
@@ -853,6 +887,17 @@ int arx_sparse_site_onehot(const int32_t* cat_map, const int32_t* ids, int64_t n
   if (g > cap) g = cap;
   k_site_onehot<<<(int)g, 256, 0, as_stream(stream)>>>(cat_map, ids, n, row_base, coef, keys_out,
                                                        src_out, coef_out);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_pool_blocks(const int32_t* ids, int64_t S, int world, int rank, int32_t zero_row, int64_t cap,
+                    int32_t* counts, int32_t* gidx, int32_t* my_slots, int32_t* pool_rows, void* stream) {
+  ARX_CHECK_ARG(ids && counts && world > 0 && world <= 64 && rank >= 0 && rank < world, "arx_pool_blocks: bad argument");
+  ARX_CHECK_ARG(S > 0 && S <= 4096, "arx_pool_blocks: 1 <= S <= 4096");
+  ARX_CHECK_ARG(cap == 0 || (gidx && my_slots && pool_rows), "arx_pool_blocks: cap > 0 needs the three outputs");
+  k_pool_blocks<<<1, 1024, 0, as_stream(stream)>>>(ids, (int)S, world, rank, zero_row, (int)cap, counts, gidx,
+                                                    my_slots, pool_rows);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

@@ -441,7 +441,7 @@ def run_hmf(args, name, steps, warmup, with_cpu=False):
     # at the driver's --steps 20 one region is 7 ms, a single host hiccup moves it by several
     # percent.  `value` is the MEDIAN region (min / max in config); wall clock and HIP events side
     # by side.  Every region starts on a pool redraw (the cadence restarts with the region).
-    walls, evs = [], []
+    walls, evs, hosts = [], [], []
     for rep in range(max(1, args.repeats)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
@@ -449,6 +449,7 @@ def run_hmf(args, name, steps, warmup, with_cpu=False):
         e0.record()
         run(warmup, total)
         e1.record()
+        hosts.append(time.time() - t0)          # host time to ENQUEUE the region (the GPU is still running)
         torch.cuda.synchronize()
         walls.append(time.time() - t0)
         evs.append(e0.elapsed_time(e1))
@@ -467,6 +468,7 @@ def run_hmf(args, name, steps, warmup, with_cpu=False):
                    "batch": B, "n_sampled": S, "dim": d, "n_items": args.n_items, "n_users": args.n_users,
                    "hipgraph": not args.no_graph, "pool_redraws_timed": redraws[0],
                    "next_batch_announced": bool(args.ring),
+                   "host_enqueue_ms_per_step": 1e3 * hosts[med] / steps,
                    "sampled_negative_logits_per_s": B * S * steps / wall,
                    "pool_rows_per_s": S * steps / wall, "hip_event_ms_per_step": ev_ms / steps,
                    "timed_regions": len(walls), "ms_per_step_min": 1e3 * min(walls) / steps,

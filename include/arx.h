@@ -78,6 +78,14 @@ int arx_sparse_site_onehot(const int32_t* cat_map, const int32_t* ids, int64_t n
  * keys_out[i] = local row or ARX_KEY_NONE (so non-owned lookups get no update). */
 int arx_shard_route(const int32_t* ids, int64_t n, int world, int rank, int32_t zero_row,
                     int32_t* rows_out, int32_t* keys_out, void* stream);
+/* Block layout of the shared negative pool on a row-sharded item table (the pool itself:
+ * embed_attribute.py:320-348 update_sampled).  Owner g's pool items, in slot order, are rows
+ * [0, counts[g]) of its block; blocks travel padded to `cap` rows.  cap == 0: only counts[world] is
+ * written (the caller reads it to choose cap).  cap > 0: gidx[s] = owner * cap + position (row of slot s
+ * in the gathered [world * cap] blocks), my_slots[0 .. counts[rank]) = this rank's slots (rest = S),
+ * pool_rows[...] = their local rows (rest = zero_row).  1 <= S <= 4096, world <= 64; one launch. */
+int arx_pool_blocks(const int32_t* ids, int64_t S, int world, int rank, int32_t zero_row, int64_t cap,
+                    int32_t* counts, int32_t* gidx, int32_t* my_slots, int32_t* pool_rows, void* stream);
 /* strided 2-D copy (packs / unpacks the all-to-all blocks of the sharded scorer) */
 int arx_copy_2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows,
                 int64_t cols, void* stream);

@@ -97,6 +97,25 @@ class NumpyBackend(object):
         if keys_out is not None:
             _n(keys_out)[...] = np.where(own, i // world, KEY_NONE).astype(np.int32)
 
+    def pool_blocks(self, ids, world, rank, zero_row, cap, counts, gidx=None, my_slots=None, pool_rows=None):
+        i = _n(ids).astype(np.int64)
+        S = i.shape[0]
+        owner = i % world
+        _n(counts)[...] = np.bincount(owner, minlength=world).astype(np.int32)
+        if cap == 0:
+            return
+        pos = np.zeros(S, np.int64)
+        for g in range(world):
+            sel = np.nonzero(owner == g)[0]
+            pos[sel] = np.arange(len(sel))
+        _n(gidx)[...] = (owner * cap + pos).astype(np.int32)
+        mine = np.nonzero(owner == rank)[0]
+        ms, pr = _n(my_slots), _n(pool_rows)
+        ms[...] = S
+        pr[...] = zero_row
+        ms[:len(mine)] = mine.astype(np.int32)
+        pr[:len(mine)] = (i[mine] // world).astype(np.int32)
+
     def loss_mw_pos(self, logits, t, urows, ptr, items, i2s, bl, dl, dt, gscale):
         x = _n(logits).astype(np.float64)
         tt = _n(t).astype(np.float64)

@@ -279,3 +279,37 @@ def test_sharded_hip_backend_two_ranks_one_gpu(dev, tmp_path, graphs):
     port = 29860 + (os.getpid() % 100)
     mp.spawn(_two_rank_worker, args=(2, port + (50 if graphs else 0), str(tmp_path), graphs), nprocs=2, join=True)
     assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(2))
+
+
+@pytest.mark.parametrize("S,world", [(1024, 8), (1000, 3), (128, 2), (4096, 64), (7, 4)])
+def test_pool_blocks_match_numpy_double(dev, S, world):
+    """arx_pool_blocks (the block layout of a pool striped over the owners; dist.ShardedHMF.set_pool) == the
+    numpy restatement the gloo tests run on, for every rank: counts, slot -> gathered row, the rank's slots and
+    local rows with their padding; incl. an owner without pool items."""
+    import torch
+    from arx import ops
+    from numpy_backend import NumpyBackend
+    rng = np.random.default_rng(S + world)
+    ids = rng.choice(10 * S + 100, size=S, replace=False).astype(np.int32)
+    if world > 2:
+        ids = ids[ids % world != 1]                      # owner 1 owns nothing
+        ids = np.concatenate([ids, (ids[:S - len(ids)] // world) * world * 7 + 0]).astype(np.int32)[:S]
+    S = len(ids)
+    nb = NumpyBackend()
+    t_ids = torch.from_numpy(ids).to(dev)
+    c_ids = torch.from_numpy(ids)
+    for rank in range(min(world, 4)):
+        cnt_ref = torch.zeros(world, dtype=torch.int32)
+        nb.pool_blocks(c_ids, world, rank, 777, 0, cnt_ref)
+        cap = (int(cnt_ref.max()) + 3) // 4 * 4
+        g_ref, ms_ref, pr_ref = (torch.zeros(S, dtype=torch.int32) for _ in range(3))
+        nb.pool_blocks(c_ids, world, rank, 777, cap, cnt_ref, g_ref, ms_ref, pr_ref)
+        cnt = torch.zeros(world, dtype=torch.int32, device=dev)
+        ops.pool_blocks(t_ids, world, rank, 777, 0, cnt)
+        assert torch.equal(cnt.cpu(), cnt_ref)
+        g, ms, pr = (torch.full((S,), -5, dtype=torch.int32, device=dev) for _ in range(3))
+        ops.pool_blocks(t_ids, world, rank, 777, cap, cnt, g, ms, pr)
+        assert torch.equal(cnt.cpu(), cnt_ref)
+        assert torch.equal(g.cpu(), g_ref)
+        assert torch.equal(ms.cpu(), ms_ref)
+        assert torch.equal(pr.cpu(), pr_ref)
