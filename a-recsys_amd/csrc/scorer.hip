@@ -45,7 +45,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SC_TRACE_CHUNKS
 #define SC_TRACE_CHUNKS 0            // 1: a stamp after every chunk (perturbs: each stamp drains the LDS counter)
 #endif
-#ifdef SC_TRACE
+#if defined(SC_TRACE) || defined(SC_TRACE_ROWS)
 __device__ unsigned long long g_sc_trace[4096];
 #define SC_T(ev_)                                                                                        \
   if (blockIdx.x == (gridDim.x > 5 ? 5 : 0) && threadIdx.x == 0 && tcount < 4096)                        \
@@ -54,6 +54,11 @@ __device__ unsigned long long g_sc_trace[4096];
 #else
 #define SC_T(ev_)
 #define SC_TDECL
+#endif
+#ifdef SC_TRACE_ROWS                  // the same stamps in k_sc_rows (phases of one wave of workgroup 5)
+#define SC_TR(ev_) SC_T(ev_)
+#else
+#define SC_TR(ev_)
 #endif
 constexpr int kScHits = 8;            // pool slots of a row's positives kept in the hit list (more: the row kernel walks)
 constexpr int kScSlots = 4;           // LDS ring: the stage being read + three in flight
@@ -723,21 +728,47 @@ __global__ __launch_bounds__(512) void k_sc_rows(ScRows a, PosMask pm, int64_t m
   __syncthreads();
   // g U -> transposed planes, 32 consecutive k (= batch rows) per column n
   sc_emit_planes_t(tile, ld, 32, a.d, a.UgT, (int64_t)a.d * a.ldug, a.ldug, r0, tid, 512);
-  // act bits transposed + the bias-gradient partial of the block
+  SC_TR(12)
+  // act bits transposed: a 32 x 32 bit block is 32 ballots -- lane l of a half-wave holds row l's word of one word
+  // column, ballot k collects bit k of the 32 rows = the transposed word of column 32 c + k (the low half of the
+  // ballot for the word column of lanes 0..31, the high half for the one of lanes 32..63).  Then the block's
+  // bias-gradient partial per column from that word (the per-column loop over 32 LDS words it replaces took 9.7 k
+  // cycles of the workgroup's 28 k)
+  uint32_t* tw = reinterpret_cast<uint32_t*>(tile);            // (the f32 tile is dead: planes emitted above)
+  __syncthreads();
+  for (int c0 = wv * 2; c0 < nwords; c0 += 16) {
+    const int c = c0 + (lane >> 5);
+    const uint32_t w = c < nwords ? sbits[(lane & 31) * 64 + c] : 0u;
+    uint32_t mine = 0u;                                        // lane 32 h + k ends up with ballot k's half h
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const unsigned long long bal = __ballot((w >> k) & 1u);
+      // (s_nop: a v_writelane that reads an SGPR a VALU compare has just written needs wait states the compiler
+      // cannot insert inside inline asm -- without them the lanes got garbage; probed on gfx950)
+      asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
+                   : "+v"(mine) : "s"((uint32_t)bal), "s"((uint32_t)(bal >> 32)), "n"(k), "n"(32 + k));
+    }
+    if (c < nwords) tw[c * 32 + (lane & 31)] = mine;
+  }
+  SC_TR(14)
+  __syncthreads();
+  // (g of the 32 rows read from LDS as broadcasts, four at a time: kept in 32 registers the kernel went from 88 to
+  // 115 VGPRs and the radix scatter that runs beside it in the step no longer fitted on the SIMDs -- 13 -> 32 us)
   for (int col = tid; col < S; col += 512) {
-    const uint32_t* wp = sbits + (col >> 5);
-    const int sh = col & 31;
-    uint32_t word = 0u;
+    const uint32_t word = tw[col];
     float db = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < 32; ++r) {
-      const uint32_t b = (wp[r * 64] >> sh) & 1u;
-      word |= b << r;
-      db += b ? sg[r] : 0.f;
+#pragma unroll 1
+    for (int r4 = 0; r4 < 32; r4 += 4) {
+      const float4 g4 = *reinterpret_cast<const float4*>(&sg[r4]);
+      db += ((word >> r4) & 1u) ? g4.x : 0.f;
+      db += ((word >> (r4 + 1)) & 1u) ? g4.y : 0.f;
+      db += ((word >> (r4 + 2)) & 1u) ? g4.z : 0.f;
+      db += ((word >> (r4 + 3)) & 1u) ? g4.w : 0.f;
     }
     a.bitsT[(int64_t)blockIdx.x * a.ldbt + col] = word;
     a.dbp[(int64_t)blockIdx.x * S + col] = db;
   }
+  SC_TR(13)
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1060,7 +1091,7 @@ using namespace arx;
 
 extern "C" {
 
-#ifdef SC_TRACE
+#if defined(SC_TRACE) || defined(SC_TRACE_ROWS)
 int arx_sc_trace_read(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sc_trace), sizeof(g_sc_trace)); }
 #endif
 

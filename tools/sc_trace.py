@@ -9,7 +9,7 @@ import numpy as np
 import torch
 from arx import ops, _lib
 
-B, S, d = (int(sys.argv[1]) if len(sys.argv) > 1 else 16384), 1024, 128
+B, S, d = (int(sys.argv[1]) if len(sys.argv) > 1 else 16384), 1024, (int(sys.argv[2]) if len(sys.argv) > 2 else 128)
 dev = torch.device('cuda', 0)
 g = torch.Generator(device=dev)
 g.manual_seed(0)
@@ -26,7 +26,7 @@ sc = ops.MwScorer(B, S, d, dev)
 for _ in range(20):
     sc.fwd(U, P, pb, T, tb, users, ptr, items, i2s, bl, ts, dts, dU, dT, 1.0 / B)
 torch.cuda.synchronize()
-sc.fwd(U, P, pb, T, tb, users, ptr, items, i2s, bl, ts, dts, dU, dT, 1.0 / B, phases=2)
+sc.fwd(U, P, pb, T, tb, users, ptr, items, i2s, bl, ts, dts, dU, dT, 1.0 / B, phases=int(os.environ.get("SC_PHASE", "2")))
 torch.cuda.synchronize()
 buf = np.zeros(4096, dtype=np.uint64)
 lib = ctypes.CDLL(_lib.LIB_PATH)
