@@ -71,10 +71,11 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__
   const int32_t* cnt = RAW ? n_in_dev : n_dev;
   const int64_t n = cnt ? min((int64_t)*cnt, n_host) : n_host;
   const int64_t ipb = cnt ? rs_ipb_dev(n, gridDim.x) : ipb_host;
-  __shared__ int h[kRsWaves][kRsMaxBins];
+  __shared__ __attribute__((aligned(16))) int h[kRsWaves][kRsMaxBins];
   const int bins = 1 << bits;
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
+#pragma unroll 4
   for (int b = lane; b < bins; b += 64) h[w][b] = 0;
   // the caller's 2 KB counter block: [0], [1] run lists of the window apply, [2] live count (written by this
   // pass's scatter), [8 ..] counters of the run-centric apply, [32 ..] its look-back cells (k7.h)
@@ -88,6 +89,9 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__
   const uint32_t mask = (uint32_t)bins - 1u;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  // (register budget: the kernels of this file run beside the scorer's k_sc_hinge in the step, two waves of which
+  // leave 48 VGPRs of a SIMD's register file -- with 62, from a 16-fold unrolled row copy below, this kernel waited
+  // for the whole hinge launch whenever the two coincided: 5 -> 23 us, r04 timelines)
   for (int64_t i0 = wb + lane; i0 < we; i0 += 8 * 64) {
     uint32_t k[8];
 #pragma unroll
@@ -104,7 +108,14 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   int32_t* row = hist + ((int64_t)blockIdx.x * kRsWaves + w) * bins;
-  for (int b = lane; b < bins; b += 64) row[b] = h[w][b];
+  if (bins >= 256) {               // (16-byte pieces, two in flight: register budget above)
+#pragma unroll 2
+    for (int b = lane * 4; b < bins; b += 256)
+      *reinterpret_cast<int4*>(row + b) = *reinterpret_cast<const int4*>(&h[w][b]);
+  } else {
+#pragma unroll 1
+    for (int b = lane; b < bins; b += 64) row[b] = h[w][b];
+  }
 }
 
 // Exclusive scan over the rows (waves, in sort order) of each histogram column, in place;

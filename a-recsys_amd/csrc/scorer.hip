@@ -347,9 +347,16 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
   // LDS byte address of this lane's fragment of chunk c in the CURRENT tile's image (plane pl: + pl * 32 * ROWB).
   // Advanced IN PLACE to the next tile's image right after its last use (a scalar step): the reads of a tile then
   // depend on nothing computed inside that tile's scheduling region, so the scheduler can hoist them.
-  uint32_t fa[NCH];
+  // K = 128 (ROWB = 256): ONE register -- chunk c's address is fa[0] ^ (c << 5): the chunk index only enters through
+  // the XOR swizzle, (2 c + kg) ^ sw = ((c ^ (sw >> 1)) << 1) | (kg ^ (sw & 1)), and bits 5..7 of everything else
+  // are zero.  Seven registers less: 239 -> 232, which is what lets a 40-VGPR wave of another kernel -- the radix
+  // scatter of the K7 sort branch -- share a SIMD with two waves of this one (2 x 240 left 32: the branch stood still
+  // for the 30 us of this kernel, r04 timelines).
+  constexpr bool FA1 = ROWB == 256;
+  uint32_t fa[FA1 ? 1 : NCH];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) fa[c] = (uint32_t)(lr * ROWB + 16 * ((2 * c + kg) ^ sc_swz<ROWB>(lr)));
+  for (int c = 0; c < (FA1 ? 1 : NCH); ++c) fa[c] = (uint32_t)(lr * ROWB + 16 * ((2 * c + kg) ^ sc_swz<ROWB>(lr)));
+#define SC_FA(c_) (FA1 ? (fa[0] ^ (uint32_t)((c_) << 5)) : fa[FA1 ? 0 : (c_)])
 
   f32x16 hiA, loA, hiB, loB;
   // The instruction stream of a tile is laid out BY HAND, chunk by chunk (left alone the scheduler emits ds_read /
@@ -383,11 +390,13 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
 #ifndef SC_PF
 #define SC_PF 1
 #endif
+  static_assert(SC_PF == 1 || !FA1, "the single address register steps to the next image one chunk ahead");
 #define SC_LD3(set_, c_)                                                                                 \
   {                                                                                                      \
-    fr[set_][0] = *reinterpret_cast<const uint4*>(lds + fa[c_]);                                         \
-    fr[set_][1] = *reinterpret_cast<const uint4*>(lds + fa[c_] + 32 * ROWB);                             \
-    fr[set_][2] = *reinterpret_cast<const uint4*>(lds + fa[c_] + 64 * ROWB);                             \
+    const uint32_t fa_ = SC_FA(c_);                                                                      \
+    fr[set_][0] = *reinterpret_cast<const uint4*>(lds + fa_);                                            \
+    fr[set_][1] = *reinterpret_cast<const uint4*>(lds + fa_ + 32 * ROWB);                                \
+    fr[set_][2] = *reinterpret_cast<const uint4*>(lds + fa_ + 64 * ROWB);                                \
   }
 #define SC_MFMA6(hi_, lo_, c_)                                                                           \
   lo_ = SC_MFMA(b3, a1[c_], lo_);                                                                        \
@@ -462,6 +471,7 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
       if ((BAR_) && c == NCH / 2) sc_barrier();                                                          \
       const bf16x8 b1 = __builtin_bit_cast(bf16x8, fr[c % 4][0]), b2 = __builtin_bit_cast(bf16x8, fr[c % 4][1]), \
                    b3 = __builtin_bit_cast(bf16x8, fr[c % 4][2]);                                        \
+      if (FA1 && c == NCH - 1) fa[0] += dl;        /* (one address register: step to the next image before its chunk 0) */ \
       SC_LD3((c + SC_PF) % 4, (c + SC_PF) % NCH)   /* (past the tile's end: fa[] already points into the next image) */ \
       /* the bias quads are re-read one by one, each in the chunk after its last use (quad g serves the values */ \
       /* 4 g .. 4 g + 3), with the bias of the tile after next (jb_); a quad used up to the tile's last chunk is */ \
@@ -473,7 +483,7 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
       }                                                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                 \
       SC_MFMA6(hi_, lo_, c)                                                                              \
-      fa[c] += dl;                                                                                       \
+      if (!FA1) fa[FA1 ? 0 : c] += dl;                                                                   \
       if (c == 0 && (jw_) >= 0) {                                                                        \
         const uint32_t hw = h;                                                                           \
         SC_WORD(hw, jw_)                                                                                 \
