@@ -154,6 +154,8 @@ int launch_radix_sort(const int32_t* keys_raw, const int32_t* src_raw, const flo
                       uint32_t sentinel, int total_bits, uint32_t* keys_tmp, uint32_t* keys_out,
                       int32_t* src_tmp, int32_t* src_out, float* coef_tmp, float* coef_out,
                       int32_t* hist, int32_t* list_count, int32_t* n_live, hipStream_t s,
-                      const int32_t* n_in_dev = nullptr /* first pass: device-side number of input entries */);
+                      const int32_t* n_in_dev = nullptr /* first pass: device-side number of input entries */,
+                      const CatSites* sites = nullptr /* first pass: form (key, src, coef) from these lookups (keys_raw,
+                                                         src_raw, coef_raw unused; no pre-expanded segments) */);
 
 }  // namespace arx

@@ -1459,7 +1459,10 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   int32_t* count = reinterpret_cast<int32_t*>(base + w.off_count);
   float* scratch = reinterpret_cast<float*>(base + w.off_scratch);
   float* scratch_b = reinterpret_cast<float*>(base + w.off_scratch_b);
-  if (mask & 1) {
+  // radix-sorted pass without pre-expanded segments: the sort's first pass forms the keys itself (radix_sort.hip),
+  // no k_site_keys launch, keys_buf / src_buf / coef_buf stay untouched
+  const bool fused_keys = n > kRankSortMax && st.nextra == 0;
+  if ((mask & 1) && !fused_keys) {
     int64_t g = ceil_div(n, 256);
     k_site_keys<<<(int)g, 256, 0, s>>>(st, keys_buf, src_buf, coef_buf);
     ARX_CHECK_LAUNCH();
@@ -1485,7 +1488,8 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
                              reinterpret_cast<uint32_t*>(base + w.off_keys_tmp), keys_out,
                              reinterpret_cast<int32_t*>(base + w.off_pos_in), ssrc,
                              reinterpret_cast<float*>(base + w.off_pos_out), scoef,
-                             reinterpret_cast<int32_t*>(base + w.off_hist), count, count + 2, s);
+                             reinterpret_cast<int32_t*>(base + w.off_hist), count, count + 2, s, nullptr,
+                             fused_keys ? &st : nullptr);
       if (rc) return rc;
       sorted_runs = runs_path(d);                // run records: extracted below, once the riding bag table is known
     }

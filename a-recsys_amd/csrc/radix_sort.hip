@@ -40,9 +40,33 @@ __device__ __forceinline__ uint32_t norm_key(int32_t k, uint32_t sentinel) {
   return (k == ARX_KEY_NONE || k < 0 || (uint32_t)k >= sentinel) ? sentinel : (uint32_t)k;
 }
 
-template <bool RAW>
+// RAW: 0 = keys of an earlier pass, 1 = the caller's raw int32 keys, 2 = the lookups of a CatSites set: the first
+// pass forms key / source row / coefficient of contribution i itself (what k_site_keys wrote to three arrays for it
+// to read back: one launch and 3 x 4 n bytes each way less at the head of the step's sort branch)
+__device__ __forceinline__ uint32_t site_key(const CatSites& st, int64_t i, uint32_t sentinel, int32_t* src, float* coef) {
+  int s = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxSites; ++q)
+    if (q < st.nsites && i >= st.offs[q]) s = q;
+  const int64_t j = i - st.offs[s];
+  const int id = st.ids[s][j];
+  const int key = st.cat_map[s] ? st.cat_map[s][id] : id;
+  const int tb = st.table[s];
+  const int64_t rows = tb == 0 ? st.rows[0] : tb == 1 ? st.rows[1] : tb == 2 ? st.rows[2] : st.rows[3];
+  if (src) {
+    *src = st.row_base[s] + (int32_t)j;
+    *coef = st.coef[s];
+  }
+  return (key < 0 || key >= rows) ? sentinel : (uint32_t)((tb << st.kb) | key);
+}
+
+struct NoSites {};
+template <int RAW> struct SitesArg { typedef NoSites type; };
+template <> struct SitesArg<2> { typedef CatSites type; };
+
+template <int RAW>
 __device__ __forceinline__ uint32_t load_key(const void* keys_in, int64_t i, uint32_t sentinel) {
-  if constexpr (RAW) return norm_key(reinterpret_cast<const int32_t*>(keys_in)[i], sentinel);
+  if constexpr (RAW == 1) return norm_key(reinterpret_cast<const int32_t*>(keys_in)[i], sentinel);
   else return reinterpret_cast<const uint32_t*>(keys_in)[i];
 }
 
@@ -57,13 +81,14 @@ __device__ __forceinline__ int64_t rs_ipb_dev(int64_t n, int nblk) {
 }
 
 // per-WAVE digit histograms: hist[(blk * 4 + wave)][bin] over the wave's contiguous quarter
-template <bool RAW>
+template <int RAW>
 __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__ keys_in, int64_t n_host,
                                                         const int32_t* __restrict__ n_dev,
                                                         uint32_t sentinel, int shift, int bits,
                                                         int64_t ipb_host, int32_t* __restrict__ hist,
                                                         int32_t* __restrict__ list_count,
-                                                        const int32_t* __restrict__ n_in_dev) {
+                                                        const int32_t* __restrict__ n_in_dev,
+                                                        typename SitesArg<RAW>::type st) {
   // n_dev: live entries after the first pass dropped the sentinels (device-side count; the grid
   // is sized for the host-side capacity: the live entries are dealt over ALL its blocks)
   // (first pass: n_in_dev, if given, is the number of input entries -- a compacted list whose length
@@ -97,7 +122,8 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__
 #pragma unroll
     for (int u = 0; u < 8; ++u) {      // 8 loads in flight: the loop is a chain of L2 round trips otherwise
       const int64_t i = i0 + u * 64;
-      k[u] = (i < we) ? load_key<RAW>(keys_in, i, sentinel) : 0u;
+      if constexpr (RAW == 2) k[u] = (i < we) ? site_key(st, i, sentinel, nullptr, nullptr) : 0u;
+      else k[u] = (i < we) ? load_key<RAW>(keys_in, i, sentinel) : 0u;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -150,13 +176,13 @@ __global__ __launch_bounds__(1024) void k_rs_scan(int32_t* __restrict__ hist, in
         make_int4(off.x + incl.x, off.y + incl.y, off.z + incl.z, off.w + incl.w);
 }
 
-template <bool RAW>
+template <int RAW>
 __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(
     const void* __restrict__ keys_in, const int32_t* __restrict__ src_in,
     const float* __restrict__ coef_in, int64_t n_host, int32_t* __restrict__ n_live,
     uint32_t sentinel, int shift, int bits, int64_t ipb_host, const int32_t* __restrict__ hist,
     const int32_t* __restrict__ tot, uint32_t* __restrict__ keys_out, int32_t* __restrict__ src_out,
-    float* __restrict__ coef_out, const int32_t* __restrict__ n_in_dev) {
+    float* __restrict__ coef_out, const int32_t* __restrict__ n_in_dev, typename SitesArg<RAW>::type st) {
   const int32_t* cnt = RAW ? n_in_dev : n_live;
   const int64_t n = cnt ? min((int64_t)*cnt, n_host) : n_host;
   const int64_t ipb = cnt ? rs_ipb_dev(n, gridDim.x) : ipb_host;
@@ -223,8 +249,15 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(
     for (int u = 0; u < 4; ++u) {
       const int64_t i = i0 + u * 64 + lane;
       const bool valid = i < we;
-      k[u] = valid ? load_key<RAW>(keys_in, i, sentinel) : 0u;
-      if constexpr (RAW) {
+      if constexpr (RAW == 2) {
+        sv[u] = 0;
+        cv[u] = 0.f;
+        k[u] = valid ? site_key(st, i, sentinel, &sv[u], &cv[u]) : 0u;
+      } else {
+        k[u] = valid ? load_key<RAW>(keys_in, i, sentinel) : 0u;
+      }
+      if constexpr (RAW == 2) {
+      } else if constexpr (RAW == 1) {
         sv[u] = (valid && src_in) ? src_in[i] : (int32_t)i;
         cv[u] = (valid && coef_in) ? coef_in[i] : 1.f;
       } else {
@@ -291,7 +324,7 @@ int launch_radix_sort(const int32_t* keys_raw, const int32_t* src_raw, const flo
                       uint32_t sentinel, int total_bits, uint32_t* keys_tmp, uint32_t* keys_out,
                       int32_t* src_tmp, int32_t* src_out, float* coef_tmp, float* coef_out,
                       int32_t* hist, int32_t* list_count, int32_t* n_live, hipStream_t s,
-                      const int32_t* n_in_dev) {
+                      const int32_t* n_in_dev, const CatSites* sites) {
   const RsPlan p = rs_plan(n, total_bits);
   const void* in_k = keys_raw;
   const int32_t* in_s = src_raw;
@@ -304,12 +337,15 @@ int launch_radix_sort(const int32_t* keys_raw, const int32_t* src_raw, const flo
     float* out_c = to_out ? coef_out : coef_tmp;
     int32_t* tot = hist + (int64_t)kRsMaxBlocks * kRsWaves * kRsMaxBins;
     const int bins = 1 << p.bits[i];
-    if (i == 0)
-      k_rs_hist<true><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, n_live, sentinel, p.shift[i], p.bits[i], p.ipb,
-                                                    hist, list_count, n_in_dev);
+    if (i == 0 && sites)
+      k_rs_hist<2><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, n_live, sentinel, p.shift[i], p.bits[i], p.ipb,
+                                                 hist, list_count, n_in_dev, *sites);
+    else if (i == 0)
+      k_rs_hist<1><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, n_live, sentinel, p.shift[i], p.bits[i], p.ipb,
+                                                 hist, list_count, n_in_dev, NoSites{});
     else
-      k_rs_hist<false><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, n_live, sentinel, p.shift[i], p.bits[i],
-                                                     p.ipb, hist, nullptr, nullptr);
+      k_rs_hist<0><<<p.nblk, kRsThreads, 0, s>>>(in_k, n, n_live, sentinel, p.shift[i], p.bits[i],
+                                                 p.ipb, hist, nullptr, nullptr, NoSites{});
     ARX_CHECK_LAUNCH();
     {
       // thread r <-> row r: as many waves as there are rows (a 16-wave workgroup waits for a whole CU's worth of
@@ -318,14 +354,15 @@ int launch_radix_sort(const int32_t* keys_raw, const int32_t* src_raw, const flo
       k_rs_scan<<<bins / 4, (rows + 63) / 64 * 64, 0, s>>>(hist, rows, bins, tot);
     }
     ARX_CHECK_LAUNCH();
-    if (i == 0)
-      k_rs_scatter<true><<<p.nblk, kRsThreads, 0, s>>>(in_k, in_s, in_c, n, n_live, sentinel, p.shift[i],
-                                                       p.bits[i], p.ipb, hist, tot, out_k, out_s,
-                                                       out_c, n_in_dev);
+    if (i == 0 && sites)
+      k_rs_scatter<2><<<p.nblk, kRsThreads, 0, s>>>(in_k, in_s, in_c, n, n_live, sentinel, p.shift[i], p.bits[i],
+                                                    p.ipb, hist, tot, out_k, out_s, out_c, n_in_dev, *sites);
+    else if (i == 0)
+      k_rs_scatter<1><<<p.nblk, kRsThreads, 0, s>>>(in_k, in_s, in_c, n, n_live, sentinel, p.shift[i], p.bits[i],
+                                                    p.ipb, hist, tot, out_k, out_s, out_c, n_in_dev, NoSites{});
     else
-      k_rs_scatter<false><<<p.nblk, kRsThreads, 0, s>>>(in_k, in_s, in_c, n, n_live, sentinel, p.shift[i],
-                                                        p.bits[i], p.ipb, hist, tot, out_k, out_s,
-                                                        out_c, nullptr);
+      k_rs_scatter<0><<<p.nblk, kRsThreads, 0, s>>>(in_k, in_s, in_c, n, n_live, sentinel, p.shift[i], p.bits[i],
+                                                    p.ipb, hist, tot, out_k, out_s, out_c, nullptr, NoSites{});
     ARX_CHECK_LAUNCH();
     in_k = out_k;
     in_s = out_s;
