@@ -388,6 +388,8 @@ class ShardedHMF(object):
         """One training step.  `users` is either a route from prepare_route() (the fast way:
         nothing but kernels and collectives on the step path) or a users array with `items`
         (routed here on the host)."""
+        if self.world > 1 and self.cap <= 0:
+            raise RuntimeError("ShardedHMF.step before set_pool(): the pool's block layout sizes the exchanges")
         route = users if isinstance(users, dict) else self.prepare_route(users, items)
         if self.use_graphs:
             outer = torch.cuda.current_stream(self.device)

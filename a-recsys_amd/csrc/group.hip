@@ -212,8 +212,11 @@ __global__ __launch_bounds__(kExtThreads) void k_runs_extract(const uint32_t* __
   }
   __syncthreads();
   if (hl.lens && wv == 0) {
-    // ordered prefix of the bag lengths: workgroups are few (<= 64) and resident; every one publishes its
-    // total before it waits for the ones in front
+    // ordered prefix of the bag lengths: every workgroup publishes its total BEFORE it waits for the ones in front,
+    // and it only waits for lower block indices.  Progress therefore needs in-order dispatch (block b is never
+    // started before every block < b has been) -- which the hardware dispatcher gives -- not full co-residency: the
+    // lowest unfinished block never waits for anything that has not started.  The caller bounds the grid
+    // (runs_extract_blocks(n) <= 224, optim.hip) and otherwise takes the one-workgroup k_head_len_scan.
     if (lane == 0)
       __hip_atomic_store(&hl.lookback[blockIdx.x], (1ull << 63) | (unsigned long long)s_base[4], __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
