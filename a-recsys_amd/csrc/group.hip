@@ -52,7 +52,8 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 // the sorted keys.  Per workgroup: one atomic per list counter (few workgroups: ~10 ns each on one
 // address), and -- for the riding bag table -- the ORDERED prefix of the bag lengths of the entity
 // heads (published totals of the workgroups in front: the token list they address stays deterministic).
-constexpr int kExtThreads = 256;     // (small workgroups: they must find a slot next to the GEMMs of the step)
+constexpr int kExtThreads = 128;     // (small workgroups: they must find a slot next to the GEMMs of the step; 128: twice the
+                                     // workgroups for the ~75 live tiles of the C3 token list -- the last kernel of the sort branch, 2 us)
 constexpr int kExtPer = 8;
 constexpr int kExtTile = kExtThreads * kExtPer;
 
