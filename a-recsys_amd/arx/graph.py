@@ -1614,7 +1614,7 @@ class Runtime(object):
         self.pending_feeds.append((src, dst))
 
     def flush_feeds(self):
-        """Issue the queued placeholder feeds (one launch per four buffers)."""
+        """Issue the queued placeholder feeds (one launch per eight buffers)."""
         if self.pending_feeds:
             pf, self.pending_feeds = self.pending_feeds, []
             ops.copy_words(pf)

@@ -832,10 +832,10 @@ def dropout_fwd_step(x, keep_prob, seed, step_dev, y, keep_mask):
 
 
 def copy_words(pairs):
-    """[(src, dst), ...] device tensors of 4-byte elements, equal sizes per pair; <= 4 per launch."""
+    """[(src, dst), ...] device tensors of 4-byte elements, equal sizes per pair; <= 8 per launch."""
     import ctypes as C
-    for k in range(0, len(pairs), 4):
-        grp = pairs[k:k + 4]
+    for k in range(0, len(pairs), 8):
+        grp = pairs[k:k + 8]
         n = len(grp)
         src, dst, cnt = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int64 * n)()
         for a, (s_, d_) in enumerate(grp):

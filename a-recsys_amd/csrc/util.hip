@@ -188,12 +188,12 @@ __global__ void k_dropout_fwd(const float* __restrict__ x, int64_t n, float keep
 
 __global__ void k_counter_add(uint64_t* c, uint64_t v) { *c += v; }
 
-// up to 4 device-to-device copies of 4-byte words in ONE launch (placeholder feeds: the
+// up to 8 device-to-device copies of 4-byte words in ONE launch (placeholder feeds: the
 // runtime's blit kernel costs ~5-10 us per hipMemcpyAsync at these sizes)
 struct CopySet {
-  const uint32_t* src[4];
-  uint32_t* dst[4];
-  int64_t n[4];
+  const uint32_t* src[8];
+  uint32_t* dst[8];
+  int64_t n[8];
   int count;
 };
 __global__ __launch_bounds__(256) void k_copy_words(CopySet cs) {
@@ -413,7 +413,7 @@ int arx_dropout_fwd_step(const float* x, int64_t n, float keep_prob, uint64_t se
 
 int arx_copy_words(int count, const void* const* src, void* const* dst, const int64_t* n_words,
                    void* stream) {
-  ARX_CHECK_ARG(count >= 0 && count <= 4, "arx_copy_words: at most 4 copies per call");
+  ARX_CHECK_ARG(count >= 0 && count <= 8, "arx_copy_words: at most 8 copies per call");
   ARX_CHECK_ARG(count == 0 || (src && dst && n_words), "arx_copy_words: null pointer");
   CopySet cs = {};
   int64_t nmax = 0;

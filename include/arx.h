@@ -711,7 +711,7 @@ int arx_dropout_bwd(const float* dy, const uint8_t* keep_mask, int64_t n, float 
 int arx_dropout_fwd_step(const float* x, int64_t n, float keep_prob, uint64_t seed,
                          const uint64_t* step_dev, float* y, uint8_t* keep_mask, void* stream);
 int arx_counter_add(uint64_t* counter_dev, uint64_t v, void* stream);
-/* up to 4 device-to-device copies of 4-byte words in one launch (placeholder feeds,
+/* up to 8 device-to-device copies of 4-byte words in one launch (placeholder feeds,
  * embed_attribute.py:697-719 add_input: users, items, targets, ... of one step) */
 int arx_copy_words(int count, const void* const* src, void* const* dst, const int64_t* n_words,
                    void* stream);
