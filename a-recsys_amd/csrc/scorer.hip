@@ -25,9 +25,6 @@
 
 #include "common.h"
 #include "posmask.h"
-#ifdef SC_ABL_ASMTILE
-#include "sc_abl_asmtile.inc"
-#endif
 
 namespace arx {
 
@@ -529,43 +526,12 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
   SC_TILE(hiA, loA, hiB, loB, false, -1, tcl(1), tcl(2), step(0), TPS == 1)
   // tile 1 -> B with the hinge of tile 0 (A), A re-initialised for tile 2
   SC_TILE(hiB, loB, hiA, loA, true, -1, tcl(2), tcl(3), step(1), true)
-#ifdef SC_ABL_ASMTILE
-  // ablation: the steady-state tiles as ONE hand-written asm block per tile (the probe's "TILE as compiled" stream:
-  // same MFMAs / reads / epilogue ops, registers pinned) inside the real kernel -- garbage results, the clock counts
-  {
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
-    u32x4 q0 = {1, 2, 3, 4}, q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;
-    float f0 = 1.f, f1 = 2.f, f7 = 3.f;
-    uint32_t i0 = 5;
-    const float k0 = 1.0001f, k1 = 0.5f;
-    const uint32_t la = (uint32_t)(lane * 16);
-    for (int j = 2; j < ntile; ++j) {
-      if (TPS == 1 || (j & 1)) sc_barrier();
-      asm volatile(SC_ASMTILE_TEXT
-                   : [c0] "+{v[0:15]}"(c0), [c1] "+{v[16:31]}"(c1), [c2] "+{v[32:47]}"(c2), [c3] "+{v[48:63]}"(c3),
-                     [q0] "+v"(q0), [q1] "+v"(q1), [q2] "+v"(q2), [q3] "+v"(q3), [q4] "+v"(q4), [q5] "+v"(q5),
-                     [f0] "+v"(f0), [f1] "+v"(f1), [f7] "+v"(f7), [i0] "+v"(i0)
-                   : [k0] "v"(k0), [k1] "v"(k1), [la] "v"(la), [fa0] "v"(fa[0]), [fa1] "v"(fa[1]), [fa2] "v"(fa[2]),
-                     [fa3] "v"(fa[3]), [fa4] "v"(fa[4]), [fa5] "v"(fa[5]), [fa6] "v"(fa[6]), [fa7] "v"(fa[7])
-                   : "memory");
-      {
-        const uint32_t dl = (uint32_t)step(j);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) fa[c] += dl;
-      }
-      SC_T(8)
-    }
-    rs += f0 + f1 + f7 + c0[0] + c1[1] + c2[2] + c3[3] + (float)(i0 + q0.x + q1.x + q2.x + q3.x + q4.x + q5.x);
-  }
-#else
   for (int j = 2; j + 1 < ntile; j += 2) {
     // tile j -> A with the hinge of tile j - 1 (B) and the word of tile j - 2; B re-initialised for tile j + 1
     SC_TILE(hiA, loA, hiB, loB, true, j - 2, tcl(j + 1), tcl(j + 2), step(j), TPS == 1)
     // tile j + 1 -> B with the hinge of tile j (A) and the word of tile j - 1; A re-initialised for tile j + 2
     SC_TILE(hiB, loB, hiA, loA, true, j - 1, tcl(j + 2), tcl(j + 3), step(j + 1), true)
   }
-#endif
   // tail: the word of tile ntile - 2 (h holds it), then the hinge and the word of the last tile (B)
   SC_WORD(h, ntile - 2)
 #pragma unroll
