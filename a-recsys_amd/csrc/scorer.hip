@@ -1002,8 +1002,19 @@ __global__ __launch_bounds__(256) void k_sc_db_steps(const float* __restrict__ d
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (q >= L * S) return;
   const int64_t t = q / S, s = q % S;
+  // (eight loads in flight, added in block order: one load per iteration was a chain of L2 round trips -- 12 us for
+  // 6.5 MB at the C4 shape)
+  const float* p = dbp + t * bps * S + s;
   float acc = 0.f;
-  for (int64_t b = 0; b < bps; ++b) acc += dbp[(t * bps + b) * S + s];
+  int64_t b = 0;
+  for (; b + 8 <= bps; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(b + u) * S];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; b < bps; ++b) acc += p[b * S];
   db_steps[q] = acc;
 }
 
