@@ -165,6 +165,7 @@ PROTOTYPES = {
                                   i64, f32p, vp, sz, vp, vp]),
     "arx_fill_f32": (cint, [f32p, i64, f32, vp]),
     "arx_fill_i32": (cint, [i32p, i64, i32, vp]),
+    "arx_take_i32": (cint, [i32p, i32p, i64, i32, i32p, vp]),
     "arx_fill_u8": (cint, [u8p, i64, cint, vp]),
     "arx_axpby": (cint, [f32, f32p, f32, f32p, i64, vp]),
     "arx_add_rows_bcast": (cint, [f32, f32p, i64, i64, f32, f32p, i64, i64, cint, vp]),

@@ -831,6 +831,10 @@ def dropout_fwd_step(x, keep_prob, seed, step_dev, y, keep_mask):
          _p(step_dev), _p(y), _p(keep_mask), _stream())
 
 
+def take_i32(table, idx, out, fill=-1):
+    call("arx_take_i32", _p(table), _p(idx), int(idx.shape[0]), int(fill), _p(out), _stream())
+
+
 def copy_words(pairs):
     """[(src, dst), ...] device tensors of 4-byte elements, equal sizes per pair; <= 8 per launch."""
     import ctypes as C

@@ -92,9 +92,11 @@ class DeviceSampler(object):
     def _cap_for(self, n):
         """Key threshold t of the capped race for draws of n items: an item survives the cap with
         probability 1 - exp(-w t), so t is chosen such that the EXPECTED number of survivors,
-        sum_i (1 - exp(-w_i t)), is 7.5 n (the count is a sum of independent indicators: fewer than n
-        of 7.5 n expected is out of reach; and no more than 8 n -- the power of two the survivors'
-        one-workgroup sort pads to -- at n = 1024: 7680 + 5 sigma < 8192).  `8 n / sum(w)` -- round 2 -- only equals that while
+        sum_i (1 - exp(-w_i t)), is 3 n (the count is a sum of independent indicators, standard deviation
+        <= sqrt(3 n): fewer than n of 3 n expected is ~37 sigma away at n = 1024; and no more than 4 n -- the
+        power of two the survivors' one-workgroup sort pads to: 3072 + 5 sigma < 4096.  Round 3 aimed at 7.5 n:
+        the sort of 8192 padded entries and the list appends were 150 of the redraw's 166 us at 1 M items).
+        `8 n / sum(w)` -- round 2 -- only equals that while
         w t << 1 for every item: with heavy-tailed weights (w ~ rank^-1.5, 1 M items, n = 1000) it
         let ~630 keys through, the draw came back short and the missing positions indexed
         items[-1].  0.0 = no cap (small populations, or too few positive weights for one to pay).
@@ -112,7 +114,7 @@ class DeviceSampler(object):
         if self._npos < n:
             raise ValueError("DeviceSampler.sample(%d): only %d items have a positive weight" % (n, self._npos))
         cap = 0.0
-        target = 7.5 * n
+        target = 3.0 * n
         if N > (1 << 16) and 16 * n < N and self._npos >= 2 * target:
             w = self.w.clamp(min=0)
 
@@ -166,8 +168,7 @@ class DeviceSampler(object):
         self.counter += 1
         # positions the capped race could not fill come back as -1: map them to id -1 (update_sampled_pool and
         # draw_global_pool reject negative ids) instead of letting -1 index items[-1] (advisor, round 3)
-        ids = torch.where(pos >= 0, self.items[pos.clamp(min=0).long()], torch.full_like(pos, -1))
-        if out is not None:
-            out.copy_(ids)
-            return out
-        return ids
+        if out is None:
+            out = torch.empty((n,), dtype=torch.int32, device=self.w.device)
+        self._ops.take_i32(self.items, pos, out, fill=-1)         # (one launch; the torch form was six)
+        return out

@@ -296,6 +296,16 @@ int arx_device_info(int* cu, int* wave, int* lds_bytes, char* arch, int arch_len
   return ARX_OK;
 }
 
+}  // extern "C"
+namespace {
+__global__ void k_take_i32(const int32_t* __restrict__ table, const int32_t* __restrict__ idx, int64_t n, int32_t fill,
+                           int32_t* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = idx[i] >= 0 ? table[idx[i]] : fill;
+}
+}  // namespace
+extern "C" {
+
 int arx_fill_f32(float* p, int64_t n, float v, void* stream) {
   ARX_CHECK_ARG(p || n == 0, "arx_fill_f32: null pointer");
   if (n <= 0) return ARX_OK;
@@ -308,6 +318,14 @@ int arx_fill_i32(int32_t* p, int64_t n, int32_t v, void* stream) {
   ARX_CHECK_ARG(p || n == 0, "arx_fill_i32: null pointer");
   if (n <= 0) return ARX_OK;
   k_fill<int32_t><<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(p, n, v);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_take_i32(const int32_t* table, const int32_t* idx, int64_t n, int32_t fill, int32_t* out, void* stream) {
+  ARX_CHECK_ARG(n == 0 || (table && idx && out), "arx_take_i32: null pointer");
+  if (n <= 0) return ARX_OK;
+  k_take_i32<<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(table, idx, n, fill, out);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

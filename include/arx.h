@@ -686,6 +686,9 @@ int arx_merged_sq_norm(const int32_t* keys, const int32_t* src, const float* coe
 /* ---- small device utilities ------------------------------------------------ */
 int arx_fill_f32(float* p, int64_t n, float v, void* stream);
 int arx_fill_i32(int32_t* p, int64_t n, int32_t v, void* stream);
+/* out[i] = idx[i] >= 0 ? table[idx[i]] : fill -- drawn positions -> item ids (utils/prepare_train.py:7-17: the
+ * population list the sampler draws from need not be 0..n-1); unfilled positions of a short draw stay `fill`. */
+int arx_take_i32(const int32_t* table, const int32_t* idx, int64_t n, int32_t fill, int32_t* out, void* stream);
 int arx_fill_u8(uint8_t* p, int64_t n, int v, void* stream);
 /* y = a*x + b*y  (n elements) */
 int arx_axpby(float a, const float* x, float b, float* y, int64_t n, void* stream);
