@@ -190,10 +190,6 @@ PROTOTYPES = {
     "arx_capture_begin": (cint, [vp]),
     "arx_capture_end": (cint, [vp, C.POINTER(vp)]),
     "arx_graph_launch": (cint, [vp, vp]),
-    "arx_capture_end_graph": (cint, [vp, C.POINTER(C.c_void_p)]),
-    "arx_graph_instantiate": (cint, [vp, C.POINTER(C.c_void_p)]),
-    "arx_graph_exec_update": (cint, [vp, vp]),
-    "arx_graph_free": (cint, [vp]),
     "arx_graph_destroy": (cint, [vp]),
 }
 

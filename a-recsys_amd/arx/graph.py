@@ -790,9 +790,7 @@ class Plan(object):
         self._ring = False             # inside a ring execution / capture
         self._ring_par = 0             # slot the coming step APPLIES from; its branch sorts into 1 - _ring_par
         self._ring_ready = False       # slot _ring_par holds the sorted lookups of the coming step
-        self._ring_graphs = {}         # parity -> captured graph (not instantiated)
-        self._ring_exec = None         # the one executable, re-pointed at the graph of the parity about to run
-        self._ring_loaded = None
+        self._ring_graphs = {}         # parity -> captured executable
         self._ring_warm = {}
         self.has_dropout = any(getattr(n, 'uses_dropout', False) for n in self.order)
         self.tables = []
@@ -1481,10 +1479,7 @@ class Plan(object):
         self._ring_ready = True
 
     def _ring_reset(self):
-        for g in self._ring_graphs.values():
-            ops.CapturedGraph.free_graph(g)
         self._ring_graphs, self._ring_warm, self._ring_ready = {}, {}, False
-        self._ring_exec, self._ring_loaded = None, None
 
     def _run_ring(self):
         rt = self.rt
@@ -1492,30 +1487,24 @@ class Plan(object):
         self._ring = True
         try:
             if self._ring_warm.get(par, 0) >= 1:
-                # ONE executable for both buffer sets: each parity is captured once as a graph, the executable is
-                # instantiated from the first and re-pointed (hipGraphExecUpdate: same topology, other kernel
-                # arguments) at the graph of the step about to run -- two executables launched in turn cost
-                # ~15 us more per launch than replaying one
+                # one captured executable per parity, launched in turn.  (Re-pointing ONE executable at the other
+                # parity's graph with hipGraphExecUpdate saved the ~15 us that alternating executables cost per
+                # launch, and segfaulted inside a later hipGraphLaunch of ANOTHER plan once in a full test run:
+                # not worth an opt-in mode that does not pay anyway.)
                 g = self._ring_graphs.get(par)
                 if g is None:
-                    cg = self._ring_exec if self._ring_exec is not None else ops.CapturedGraph()
+                    g = ops.CapturedGraph()
                     side = torch.cuda.Stream(device=rt.device)
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
-                        cg.begin()
+                        g.begin()
                         try:
                             self._execute()
                         finally:
-                            g = cg.end_graph()
+                            g.end()
                     torch.cuda.current_stream().wait_stream(side)
                     self._ring_graphs[par] = g
-                    if self._ring_exec is None:
-                        cg.instantiate(g)
-                        self._ring_exec, self._ring_loaded = cg, par
-                if self._ring_loaded != par:
-                    self._ring_exec.update(g)
-                    self._ring_loaded = par
-                self._ring_exec.launch()
+                g.launch()
             else:
                 self._execute()
                 self._ring_warm[par] = self._ring_warm.get(par, 0) + 1

@@ -911,26 +911,6 @@ class CapturedGraph(object):
     def launch(self):
         call("arx_graph_launch", self._exec, _stream())
 
-    # -- pieces (ring mode: ONE executable re-pointed at one of several captured graphs of equal topology)
-    def end_graph(self):
-        """End the capture without instantiating; returns the graph handle (free with free_graph)."""
-        import ctypes as C
-        g = C.c_void_p(0)
-        call("arx_capture_end_graph", _stream(), C.byref(g))
-        return g
-
-    def instantiate(self, g):
-        import ctypes as C
-        call("arx_graph_instantiate", g, C.byref(self._exec))
-
-    def update(self, g):
-        call("arx_graph_exec_update", self._exec, g)
-
-    @staticmethod
-    def free_graph(g):
-        if g:
-            _lib.lib.arx_graph_free(g)
-
     def __del__(self):
         try:
             if self._exec:

@@ -512,43 +512,6 @@ int arx_capture_end(void* stream, void** graph_exec_out) {
   return ARX_OK;
 }
 
-int arx_capture_end_graph(void* stream, void** graph_out) {
-  ARX_CHECK_ARG(graph_out, "arx_capture_end_graph: null out pointer");
-  hipGraph_t g = nullptr;
-  ARX_CHECK_HIP(hipStreamEndCapture(as_stream(stream), &g));
-  *graph_out = (void*)g;
-  return ARX_OK;
-}
-
-int arx_graph_instantiate(void* graph, void** graph_exec_out) {
-  ARX_CHECK_ARG(graph && graph_exec_out, "arx_graph_instantiate: null pointer");
-  hipGraphExec_t e = nullptr;
-  hipError_t err = hipGraphInstantiate(&e, (hipGraph_t)graph, nullptr, nullptr, 0);
-  if (err != hipSuccess) {
-    set_error("hipGraphInstantiate failed: %s", hipGetErrorString(err));
-    return ARX_EHIP;
-  }
-  *graph_exec_out = (void*)e;
-  return ARX_OK;
-}
-
-int arx_graph_exec_update(void* graph_exec, void* graph) {
-  ARX_CHECK_ARG(graph_exec && graph, "arx_graph_exec_update: null pointer");
-  hipGraphNode_t bad = nullptr;
-  hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
-  hipError_t err = hipGraphExecUpdate((hipGraphExec_t)graph_exec, (hipGraph_t)graph, &bad, &res);
-  if (err != hipSuccess || res != hipGraphExecUpdateSuccess) {
-    set_error("hipGraphExecUpdate failed: %s (result %d)", hipGetErrorString(err), (int)res);
-    return ARX_EHIP;
-  }
-  return ARX_OK;
-}
-
-int arx_graph_free(void* graph) {
-  if (graph) ARX_CHECK_HIP(hipGraphDestroy((hipGraph_t)graph));
-  return ARX_OK;
-}
-
 int arx_graph_launch(void* graph_exec, void* stream) {
   ARX_CHECK_ARG(graph_exec, "arx_graph_launch: null graph");
   ARX_CHECK_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, as_stream(stream)));

@@ -775,14 +775,6 @@ int arx_seq_weights(const float* w, int64_t L, int64_t B, float* out, void* stre
 int arx_capture_begin(void* stream);
 int arx_capture_end(void* stream, void** graph_exec_out);
 int arx_graph_launch(void* graph_exec, void* stream);
-/* The same in pieces, for steps that alternate between two buffer sets (Plan ring mode, LatentProductModel.
- * prepare_next): end a capture WITHOUT instantiating, instantiate one executable from the first graph and
- * re-point it at the graph of the step about to run (same topology, other kernel arguments:
- * hipGraphExecUpdate) -- two executables launched in turn cost ~15 us more per launch. */
-int arx_capture_end_graph(void* stream, void** graph_out);
-int arx_graph_instantiate(void* graph, void** graph_exec_out);
-int arx_graph_exec_update(void* graph_exec, void* graph);
-int arx_graph_free(void* graph);
 int arx_graph_destroy(void* graph_exec);
 
 #ifdef __cplusplus

@@ -19,3 +19,20 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _release_device_memory_between_modules():
+    """The full-size tests hold 100 GB tables; torch's caching allocator keeps them after the module is done.
+    Give the memory back to the driver before the next module runs (hipGraph instantiation / launch allocate
+    outside torch's pool)."""
+    yield
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    except Exception:
+        pass
