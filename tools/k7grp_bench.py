@@ -2,7 +2,7 @@
 table) with the item's multi-hot table riding on it (arx_sparse_adagrad_cat_multi_bags), phase 1
 (grouping / sorts: ids only) and phase 2 (apply) timed separately as hipGraph replays.
 
-usage: python tools/k7grp_bench.py [B ...]        ARX_K7_SORTED=1 selects the radix / window path
+usage: python tools/k7grp_bench.py [B ...]        K7_MODE=c2: the one-hot pass alone
 """
 import os
 import sys
@@ -68,7 +68,7 @@ def main():
         us_p1 = timed(lambda: run(1))
         # (phase 2 alone can only be replayed when every pass uses the run-centric apply: the window
         # apply appends to run lists that the sort's first launch resets)
-        if mode == 'c2' and not os.environ.get('ARX_K7_WINDOWS'):
+        if mode == 'c2':
             run(1)
             us_p2 = timed(lambda: run(2))
         else:
