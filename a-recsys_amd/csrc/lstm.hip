@@ -466,22 +466,33 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_r4(
     const int xr = threadIdx.x / DIN, xc = threadIdx.x % DIN;
     if (t + 1 < L) xn = x[((t + 1) * B + min(row0 + xr, B - 1)) * DIN + xc];
     f32x4 a0 = (f32x4){bv, bv, bv, bv}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+    // 32 operand groups (16 of x_t, 16 of h_{t-1}), four MFMAs each; the LDS read of group g + 4 is issued behind the
+    // MFMAs of group g (a ring of four registers).  Left to the compiler the read of group g + 1 sat under the 32
+    // cycles of group g -- less than an LDS round trip: 1 990 cycles for the 1 024 of the 128 MFMAs (cycle stamps,
+    // tools/lstm_trace.py).
+    constexpr int NG = (DIN + H) / 4;
+    float4 q[4];
 #pragma unroll
-    for (int ks = 0; ks < DIN / 4; ++ks) {
-      const float4 v = *reinterpret_cast<const float4*>(xb + 4 * ks);
-      a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.x, wreg[4 * ks + 0], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.y, wreg[4 * ks + 1], a1, 0, 0, 0);
-      a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.z, wreg[4 * ks + 2], a2, 0, 0, 0);
-      a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.w, wreg[4 * ks + 3], a3, 0, 0, 0);
-    }
+    for (int g = 0; g < 4; ++g) q[g] = *reinterpret_cast<const float4*>((g < DIN / 4 ? xb + 4 * g : hb + 4 * (g - DIN / 4)));
 #pragma unroll
-    for (int ks = 0; ks < H / 4; ++ks) {
-      const float4 v = *reinterpret_cast<const float4*>(hb + 4 * ks);
-      a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.x, wreg[DIN + 4 * ks + 0], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.y, wreg[DIN + 4 * ks + 1], a1, 0, 0, 0);
-      a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.z, wreg[DIN + 4 * ks + 2], a2, 0, 0, 0);
-      a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.w, wreg[DIN + 4 * ks + 3], a3, 0, 0, 0);
+    for (int g = 0; g < NG; ++g) {
+      const float4 v = q[g & 3];
+      a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.x, wreg[4 * g + 0], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.y, wreg[4 * g + 1], a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.z, wreg[4 * g + 2], a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.w, wreg[4 * g + 3], a3, 0, 0, 0);
+      if (g + 4 < NG) {
+        const int gn = g + 4;
+        q[g & 3] = *reinterpret_cast<const float4*>((gn < DIN / 4 ? xb + 4 * gn : hb + 4 * (gn - DIN / 4)));
+      }
     }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // z[i] = pre-activation of gate j, unit, row i.  Quad exchange: lane j takes row j's four gates.
     float zg[4];
 #pragma unroll
