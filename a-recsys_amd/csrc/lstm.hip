@@ -433,6 +433,17 @@ __global__ __launch_bounds__(256, 1) void k_lstm_bwd_wreg(
 //             in LDS and are added in wave order (fixed => deterministic).
 constexpr int kR4 = 4;
 
+// lane g of every quad to its four lanes: DPP quad_perm [g, g, g, g] (the control word is an immediate)
+__device__ __forceinline__ float quad_bcast(float x, int g) {
+  const int v = __float_as_int(x);
+  switch (g) {
+    case 0: return __int_as_float(__builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true));
+    case 1: return __int_as_float(__builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true));
+    case 2: return __int_as_float(__builtin_amdgcn_mov_dpp(v, 0xAA, 0xf, 0xf, true));
+    default: return __int_as_float(__builtin_amdgcn_mov_dpp(v, 0xFF, 0xf, 0xf, true));
+  }
+}
+
 template <int DIN>
 __global__ __launch_bounds__(256, 2) void k_lstm_fwd_r4(
     const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
@@ -501,7 +512,9 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_r4(
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float zi = (a0[i] + a1[i]) + (a2[i] + a3[i]);
-        const float got = __shfl(zi, g, 4);         // row i, gate g of this unit
+        // row i, gate g of this unit: lane g of the quad, as a DPP quad_perm broadcast (a VALU move; __shfl went
+        // through the LDS crossbar: 16 ds_bpermute round trips per step)
+        const float got = quad_bcast(zi, g);
         pick = (i == j) ? got : pick;
       }
       zg[g] = pick;
@@ -514,6 +527,9 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_r4(
     const float hh = go * tanhf_(c);
     cprev = c;
     hbuf[nxt][j * SH + unit] = hh;
+    // (x_{t+1} goes to LDS BEFORE the step's global stores are issued: loads and stores share the vmcnt counter, and
+    // behind the stores the wait for this one load was a wait for seven store acknowledgements per step)
+    if (t + 1 < L) xbuf[nxt][xr * SX + xc] = (row0 + xr < B) ? xn : 0.f;
     const int64_t gr = row0 + j;
     if (gr < B) {
       const int64_t o = t * B + gr;
@@ -525,7 +541,6 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_r4(
       gp[2 * H] = gf;
       gp[3 * H] = go;
     }
-    if (t + 1 < L) xbuf[nxt][xr * SX + xc] = (row0 + xr < B) ? xn : 0.f;
     __syncthreads();
   }
 }
