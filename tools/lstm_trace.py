@@ -13,6 +13,11 @@ hs, cs = torch.empty(L * B, h, device=dev), torch.empty(L * B, h, device=dev)
 gates = torch.empty(L * B, 4 * h, device=dev)
 for _ in range(3):
     ops.lstm_fwd(x, W, b, L, B, din, h, 1.0, hs, cs, gates)
+if os.environ.get('LT_BWD'):
+    dhs = torch.randn(L * B, h, device=dev) * 0.01
+    dz = torch.empty(L * B, 4 * h, device=dev)
+    for _ in range(3):
+        ops.lstm_bwd(W, hs, cs, gates, dhs, L, B, din, h, dz)
 torch.cuda.synchronize()
 buf = np.zeros(4096, dtype=np.uint64)
 lib = ctypes.CDLL(_lib.LIB_PATH)
