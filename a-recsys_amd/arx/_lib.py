@@ -64,6 +64,9 @@ PROTOTYPES = {
                             f32p, vp, sz, vp]),
     "arx_gemm_f32_rowsum": (cint, [cint, cint, i64, i64, i64, f32, f32p, i64, f32p, i64, f32, f32p,
                                    i64, f32p, f32p, vp, sz, vp]),
+    "arx_gemm_f32_tn_pair_workspace_bytes": (sz, [i64, i64, i64]),
+    "arx_gemm_f32_tn_pair": (cint, [i64, i64, i64, i64, f32p, i64, f32p, i64, f32p, i64, i64, f32p, i64, f32p,
+                                    vp, sz, vp]),
     "arx_gemm_f32_steps_tn": (cint, [i64, i64, i64, i64, f32p, i64, f32p, i64, f32p, f32p, f32, f32p,
                                      i64, f32p, vp]),
     "arx_dot_scaled": (cint, [f32p, f32p, i64, f32, f32p, vp]),
@@ -218,7 +221,8 @@ lib = _load()
 
 _NO_CHECK = ("arx_last_error", "arx_version", "arx_csr_expand_workspace_bytes",
              "arx_col_sum_workspace_bytes",
-             "arx_gemm_f32_workspace_bytes", "arx_sparse_adagrad_workspace_bytes",
+             "arx_gemm_f32_workspace_bytes", "arx_gemm_f32_tn_pair_workspace_bytes",
+             "arx_sparse_adagrad_workspace_bytes",
              "arx_sample_wor_workspace_bytes", "arx_sample_wor_keys_workspace_bytes",
              "arx_gemm_nt_bx6_workspace_bytes", "arx_reduce_scratch_bytes", "arx_mw_scorer_supported",
              "arx_mw_scorer_state_bytes", "arx_mw_scorer_bwd_di_workspace_bytes")

@@ -145,24 +145,27 @@ class LSTM(G.Node):
             self.dz = torch.empty((L * B, 4 * h), dtype=torch.float32, device=rt.device)
         dz = self.dz
         ops.lstm_bwd(self.W.w, self.value, self.cs, self.gates, self.grad, L, B, din, h, dz)
-        # All three products stream the [L*B, 4h] matrix dz once through the LDS-DMA GEMM, whose
-        # output tile is at most 128 columns wide: so dx uses W_x^T as a plain [4h, din] operand
-        # and the weight gradients are formed transposed (dW^T = dz^T . [x ; h_prev], 4h rows,
-        # din / h columns) and flipped afterwards by a 16 k-element transpose.  db = column sums
-        # of dz falls out of the first product as its row-sum side output.
+        # dx = dz . W_x^T streams dz through the LDS-DMA GEMM with W_x^T as a plain [4h, din] operand (its
+        # output tile is at most 128 columns wide).  The weight gradient, both halves, and db come from
+        # ONE more pass over dz: (dz^T . [x | h_prev])^T with h_prev = the cell outputs one step (B rows)
+        # up, written in W's own [din + h, 4h] layout by the split-K reduce (arx_gemm_f32_tn_pair) -- two
+        # TN products, two reduces and a transpose before.
         if self._wt is None:
-            dev = rt.device
-            self._wt = torch.empty((4 * h, din), dtype=torch.float32, device=dev)
-            self._dwt = torch.empty((4 * h, din + h), dtype=torch.float32, device=dev)     # [dW_x^T | dW_h^T]
+            self._wt = torch.empty((4 * h, din), dtype=torch.float32, device=rt.device)
         if x.requires_grad:
             ops.transpose(self.W.w[:din], self._wt)
             ops.gemm(dz, self._wt, x.alloc_grad(), rt.ws, beta=x.grad_beta())
-        ops.gemm(dz, x.value, self._dwt[:, :din], rt.ws, transA=True, a_rowsum=self.b.grad)
-        if L > 1:
-            ops.gemm(dz[B:], self.value[:(L - 1) * B], self._dwt[:, din:], rt.ws, transA=True)
+        if L > 1 and ops.gemm_tn_pair_supported(4 * h, din, h, L * B):
+            ops.gemm_tn_pair(dz, x.value, self.value, B, self.W.grad, rt.ws, a_rowsum=self.b.grad)
         else:
-            self._dwt[:, din:].zero_()                        # (strided view: torch fill)
-        ops.transpose(self._dwt, self.W.grad)                 # both halves flipped by one launch
+            if self._dwt is None:
+                self._dwt = torch.empty((4 * h, din + h), dtype=torch.float32, device=rt.device)   # [dW_x^T | dW_h^T]
+            ops.gemm(dz, x.value, self._dwt[:, :din], rt.ws, transA=True, a_rowsum=self.b.grad)
+            if L > 1:
+                ops.gemm(dz[B:], self.value[:(L - 1) * B], self._dwt[:, din:], rt.ws, transA=True)
+            else:
+                self._dwt[:, din:].zero_()                        # (strided view: torch fill)
+            ops.transpose(self._dwt, self.W.grad)                 # both halves flipped by one launch
         self.W.touched = self.b.touched = True
 
 

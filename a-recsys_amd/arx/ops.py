@@ -303,6 +303,23 @@ def gemm(A, B, C, ws, transA=False, transB=False, alpha=1.0, beta=0.0, col_bias=
     return C
 
 
+def gemm_tn_pair_supported(M, N1, N2, K):
+    """The shape class of gemm_tn_pair (include/arx.h: arx_gemm_f32_tn_pair)."""
+    return (N1 % 4 == 0 and N2 % 4 == 0 and 32 < N1 + N2 <= 128 and M >= 64 and M % 4 == 0 and
+            K >= 64 and K % 32 == 0)
+
+
+def gemm_tn_pair(A, B1, B2, shift, Ct, ws, a_rowsum=None):
+    """Ct [N1 + N2, M] = (A^T . [B1 | B2 shifted down by `shift` rows])^T in one pass over A [K, M]
+    (the LSTM cell's dW with A = dz, B1 = x, B2 = the cell outputs, shift = B), a_rowsum = A's column sums."""
+    K, M = int(A.shape[0]), int(A.shape[1])
+    N1, N2 = int(B1.shape[1]), int(B2.shape[1])
+    wsp, wsn = ws.get(_lib.lib.arx_gemm_f32_tn_pair_workspace_bytes(M, N1 + N2, K))
+    call("arx_gemm_f32_tn_pair", M, N1, N2, K, _p(A), _ld(A), _p(B1), _ld(B1), _p(B2), _ld(B2), int(shift),
+         _p(Ct), _ld(Ct), _p(a_rowsum), wsp, wsn, _stream())
+    return Ct
+
+
 def gemm_steps_tn(A, B, C_steps, rowsum_steps, steps, Kb, C_sum=None, beta=0.0, rowsum_sum=None):
     """C_steps[t] = A_t^T . B_t for every time step t (rows t*Kb..), plus the sums."""
     M, N = int(C_steps.shape[1]), int(C_steps.shape[2])

@@ -137,6 +137,10 @@ int gemm_dma_launch(int transA, int64_t M, int64_t N, int64_t K, float alpha, co
                     int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc,
                     const float* col_bias, float* partial, int bm, int splits, int64_t kchunk,
                     float* a_rowsum, float* rowsum_partial, hipStream_t s);
+int gemm_dma_launch_tn_pair(int64_t M, int64_t N, int n1, int64_t K, const float* A, int64_t lda,
+                            const float* B1, int64_t ldb1, const float* B2, int64_t ldb2,
+                            int64_t shift, float* partial, int bm, int splits, int64_t kchunk,
+                            float* a_rowsum, float* rowsum_partial, hipStream_t s);
 
 // topk.hip: radix-select top-k of every row (k <= 1024); indices are offset by idx_base.
 int topk_select_launch(const float* logits, int64_t ld, int64_t B, int64_t V, int k, int32_t idx_base,

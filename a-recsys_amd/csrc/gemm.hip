@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(
 __global__ __launch_bounds__(256) void k_splitk_reduce(
     const float* __restrict__ partial, int splits, int64_t M, int64_t N, float alpha, float beta,
     float* __restrict__ C, int64_t ldc, const float* __restrict__ col_bias,
-    const float* __restrict__ rowsum_partial, float* __restrict__ a_rowsum) {
+    const float* __restrict__ rowsum_partial, float* __restrict__ a_rowsum, int tr) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t total = M * N;
@@ -241,10 +241,11 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(
     float s = 0.f;
     for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * total + i];
     const int64_t r = i / N, c = i % N;
+    float* dst = tr ? C + c * ldc + r : C + r * ldc + c;      // tr: the result is stored as C^T [N, M]
     float v = alpha * s;
-    if (beta != 0.f) v += beta * C[r * ldc + c];
+    if (beta != 0.f) v += beta * *dst;
     if (col_bias) v += col_bias[c];
-    C[r * ldc + c] = v;
+    *dst = v;
   }
 }
 
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(
 __global__ __launch_bounds__(256) void k_splitk_reduce_lanes(
     const float* __restrict__ partial, int splits, int64_t M, int64_t N, float alpha, float beta,
     float* __restrict__ C, int64_t ldc, const float* __restrict__ col_bias,
-    const float* __restrict__ rowsum_partial, float* __restrict__ a_rowsum, int nb_main) {
+    const float* __restrict__ rowsum_partial, float* __restrict__ a_rowsum, int nb_main, int tr) {
   __shared__ float4 sh[16][17];
   const int cx = threadIdx.x & 15, sy = threadIdx.x >> 4;
   const int64_t total = M * N;
@@ -281,6 +282,11 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_lanes(
       }
       const int64_t e = i4 * 4, r = e / N, c = e % N;
       float4 o = make_float4(alpha * t.x, alpha * t.y, alpha * t.z, alpha * t.w);
+      if (tr) {               // C^T [N, M]: four rows of the transposed result (beta = 0, no bias: host)
+        float* d = C + c * ldc + r;
+        d[0] = o.x; d[ldc] = o.y; d[2 * ldc] = o.z; d[3 * ldc] = o.w;
+        return;
+      }
       float4* dst = reinterpret_cast<float4*>(C + r * ldc + c);
       if (beta != 0.f) {
         const float4 old = *dst;
@@ -313,9 +319,9 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_lanes(
 static inline void launch_splitk_reduce(const float* partial, int splits, int64_t M, int64_t N,
                                         float alpha, float beta, float* C, int64_t ldc,
                                         const float* col_bias, const float* rowsum_partial,
-                                        float* a_rowsum, hipStream_t s) {
+                                        float* a_rowsum, hipStream_t s, int tr = 0) {
   const int64_t total = M * N;
-  const bool v4 = (N % 4 == 0) && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+  const bool v4 = (N % 4 == 0) && (tr || ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(partial) & 15) == 0) &&
                   (!col_bias || (reinterpret_cast<uintptr_t>(col_bias) & 15) == 0) && splits >= 8 &&
                   total / 64 + M / 16 + 2 < 0x7fffffff;
@@ -323,14 +329,14 @@ static inline void launch_splitk_reduce(const float* partial, int splits, int64_
     const int nb_main = (int)ceil_div(total, (int64_t)64);
     const int nb_rs = a_rowsum ? (int)ceil_div(M, (int64_t)16) : 0;
     k_splitk_reduce_lanes<<<nb_main + nb_rs, 256, 0, s>>>(partial, splits, M, N, alpha, beta, C, ldc,
-                                                          col_bias, rowsum_partial, a_rowsum, nb_main);
+                                                          col_bias, rowsum_partial, a_rowsum, nb_main, tr);
     return;
   }
   int64_t g = ceil_div(total, 256);
   int64_t cap = (int64_t)cu_count() * 8;
   if (g > cap) g = cap;
   k_splitk_reduce<<<(int)g, 256, 0, s>>>(partial, splits, M, N, alpha, beta, C, ldc, col_bias,
-                                         rowsum_partial, a_rowsum);
+                                         rowsum_partial, a_rowsum, tr);
 }
 
 struct GemmPlan {
@@ -511,6 +517,48 @@ int arx_gemm_f32_steps_tn(int64_t steps, int64_t M, int64_t N, int64_t Kb, const
   return ARX_OK;
 }
 
+size_t arx_gemm_f32_tn_pair_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int bm, sp;
+  int64_t kc;
+  gemm_dma_plan(M, N, K, &bm, &sp, &kc);
+  return (size_t)sp * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
+}
+
+int arx_gemm_f32_tn_pair(int64_t M, int64_t N1, int64_t N2, int64_t K, const float* A, int64_t lda,
+                         const float* B1, int64_t ldb1, const float* B2, int64_t ldb2,
+                         int64_t shift, float* Ct, int64_t ldct, float* a_rowsum, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  const int64_t N = N1 + N2;
+  ARX_CHECK_ARG(M > 0 && N1 > 0 && N2 > 0 && K > 0 && shift >= 0, "arx_gemm_f32_tn_pair: bad size");
+  ARX_CHECK_ARG(A && B1 && B2 && Ct, "arx_gemm_f32_tn_pair: null pointer");
+  ARX_CHECK_ARG(lda >= M && ldb1 >= N1 && ldb2 >= N2 && ldct >= M,
+                "arx_gemm_f32_tn_pair: leading dimension too small");
+  // the LDS-DMA kernel's shape class, with 16-byte pieces that never straddle the two operands
+  if (!gemm_dma_supported(1, 0, M, N, K, A, lda, B1, ldb1) || (N1 % 4) || (N2 % 4) || (ldb2 % 4) ||
+      (reinterpret_cast<uintptr_t>(B2) & 15)) {
+    set_error("arx_gemm_f32_tn_pair: unsupported shape (M=%lld N=%lld+%lld K=%lld)", (long long)M,
+              (long long)N1, (long long)N2, (long long)K);
+    return ARX_EUNSUPPORTED;
+  }
+  int bm, sp;
+  int64_t kc;
+  gemm_dma_plan(M, N, K, &bm, &sp, &kc);
+  const size_t need = (size_t)sp * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    set_error("arx_gemm_f32_tn_pair: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return ARX_EWORKSPACE;
+  }
+  hipStream_t s = as_stream(stream);
+  float* part = reinterpret_cast<float*>(workspace);
+  float* rsp = a_rowsum ? part + (size_t)sp * (size_t)M * (size_t)N : nullptr;
+  const int rc = gemm_dma_launch_tn_pair(M, N, (int)N1, K, A, lda, B1, ldb1, B2, ldb2, shift, part, bm,
+                                         sp, kc, a_rowsum, rsp, s);
+  if (rc) return rc;
+  launch_splitk_reduce(part, sp, M, N, 1.f, 0.f, Ct, ldct, nullptr, rsp, a_rowsum, s, /*tr=*/1);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
 
 int arx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                  const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,

@@ -17,6 +17,8 @@
 // k_splitk_reduce in gemm.hip); optional row sums of op(A) (the bias gradient of dI).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace arx {
@@ -55,12 +57,23 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) 
   }
 }
 
-template <bool A_KC, int BM, int kBN>
+// Second B operand of the paired TN product (arx_gemm_f32_tn_pair): columns [n1, N) of op(B)
+// come from B2, whose row k - shift sits under row k of A (rows k < shift read zeros).
+struct PairB {
+  const float* B2;
+  int64_t ldb2, shift;
+  int n1;
+};
+struct NoPair {};
+__device__ __attribute__((aligned(16))) float g_zero4[4];      // what a row ahead of the shift reads
+
+template <bool A_KC, int BM, int kBN, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_dma(
     int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C, int64_t ldc,
     const float* __restrict__ col_bias, float* __restrict__ partial, int64_t kchunk,
-    float* __restrict__ a_rowsum, float* __restrict__ rowsum_partial) {
+    float* __restrict__ a_rowsum, float* __restrict__ rowsum_partial,
+    typename std::conditional<PAIR, PairB, NoPair>::type pair) {
   constexpr int FM = BM / 64;                 // A fragments per wave (wave covers BM/2 rows)
   constexpr int NPA = BM * kBK / 4 / 256;     // DMA pieces per thread, A tile
   constexpr int NPB = kBK * kBN / 4 / 256;    // 4 (BN=128) or 2 (BN=64)
@@ -118,7 +131,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dma(
     for (int i = 0; i < NPB; ++i) {
       const int f = threadIdx.x + i * 256;
       const int k = f / (kBN / 4), nq = f % (kBN / 4);
-      const float* src = B + (k0 + k) * ldb + min((int64_t)nq * 4, N - 4);
+      const int64_t col = min((int64_t)nq * 4, N - 4);
+      const float* src = B + (k0 + k) * ldb + col;
+      if constexpr (PAIR) {
+        if (col >= pair.n1) {
+          const int64_t r2 = k0 + k - pair.shift;
+          src = r2 >= 0 ? pair.B2 + r2 * pair.ldb2 + (col - pair.n1) : g_zero4;
+        }
+      }
       glds16(src, imgB + (f - lane) * 4);
     }
   };
@@ -320,7 +340,7 @@ int gemm_dma_launch(int transA, int64_t M, int64_t N, int64_t K, float alpha, co
   float* rsp = splits > 1 ? rowsum_partial : nullptr;
 #define ARX_DMA_GO(AKC, BM_, BN_)                                                              \
   k_gemm_dma<AKC, BM_, BN_><<<grid, 256, 0, s>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
-                                                 col_bias, part, kchunk, a_rowsum, rsp)
+                                                 col_bias, part, kchunk, a_rowsum, rsp, NoPair{})
   const bool narrow = N <= 64;                   // LSTM / d=64 shapes: 64-column tile
   if (!transA) {
     if (bm == 128) { if (narrow) ARX_DMA_GO(true, 128, 64); else ARX_DMA_GO(true, 128, 128); }
@@ -329,6 +349,25 @@ int gemm_dma_launch(int transA, int64_t M, int64_t N, int64_t K, float alpha, co
     if (bm == 128) { if (narrow) ARX_DMA_GO(false, 128, 64); else ARX_DMA_GO(false, 128, 128); }
     else { if (narrow) ARX_DMA_GO(false, 64, 64); else ARX_DMA_GO(false, 64, 128); }
   }
+#undef ARX_DMA_GO
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+// The paired TN product: always through partials (the reduce writes the transposed result).
+int gemm_dma_launch_tn_pair(int64_t M, int64_t N, int n1, int64_t K, const float* A, int64_t lda,
+                            const float* B1, int64_t ldb1, const float* B2, int64_t ldb2,
+                            int64_t shift, float* partial, int bm, int splits, int64_t kchunk,
+                            float* a_rowsum, float* rowsum_partial, hipStream_t s) {
+  dim3 grid((unsigned)ceil_div(M, (int64_t)bm), 1, (unsigned)splits);
+  const PairB pb{B2, ldb2, shift, n1};
+#define ARX_DMA_GO(BM_, BN_)                                                                   \
+  k_gemm_dma<false, BM_, BN_, true><<<grid, 256, 0, s>>>(M, N, K, 1.f, A, lda, B1, ldb1, 0.f,  \
+                                                         nullptr, 0, nullptr, partial, kchunk, \
+                                                         a_rowsum, rowsum_partial, pb)
+  const bool narrow = N <= 64;
+  if (bm == 128) { if (narrow) ARX_DMA_GO(128, 64); else ARX_DMA_GO(128, 128); }
+  else { if (narrow) ARX_DMA_GO(64, 64); else ARX_DMA_GO(64, 128); }
 #undef ARX_DMA_GO
   ARX_CHECK_LAUNCH();
   return ARX_OK;

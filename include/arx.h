@@ -218,6 +218,21 @@ int arx_gemm_f32_steps_tn(int64_t steps, int64_t M, int64_t N, int64_t Kb, const
                           float* rowsum_steps, float beta, float* C_sum, int64_t ldc,
                           float* rowsum_sum, void* stream);
 
+/* The LSTM cell's weight gradient in one pass over dz (seqModel.py:99-103: static_rnn of
+ * LSTMCell, whose kernel is one [din + h, 4h] matrix applied to concat(x_t, h_{t-1})):
+ *   Ct[0:N1, m]     = sum_k A[k, m] . B1[k, 0:N1]
+ *   Ct[N1:N1+N2, m] = sum_{k >= shift} A[k, m] . B2[k - shift, 0:N2]
+ * i.e. (A^T . [B1 | shifted B2])^T stored row-major [N1 + N2, M] (ldct >= M); a_rowsum[m]
+ * (optional) = sum_k A[k, m].  With A = dz [L*B, 4h], B1 = x, B2 = the cell outputs and
+ * shift = B this is dW (both halves) and db of tf's LSTMCell backward.  N1 + N2 <= 128,
+ * N1 % 4 == N2 % 4 == M % 4 == 0, K % 32 == 0, 16-byte aligned operands; anything else
+ * ARX_EUNSUPPORTED.  Deterministic (fixed-order split-K). */
+size_t arx_gemm_f32_tn_pair_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int arx_gemm_f32_tn_pair(int64_t M, int64_t N1, int64_t N2, int64_t K, const float* A, int64_t lda,
+                         const float* B1, int64_t ldb1, const float* B2, int64_t ldb2,
+                         int64_t shift, float* Ct, int64_t ldct, float* a_rowsum, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* ---- a14: positive mask ---------------------------------------------------
  * embed_attribute.py:651-672 (mask variable + scatter_update set/reset) and
  * :721-745 (host index list).  For each batch row r and each positive item v

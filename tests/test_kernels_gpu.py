@@ -763,6 +763,36 @@ def test_gemm_rowsum(dev, tA, M, N, K):
     np.testing.assert_allclose(C.cpu().numpy(), opA.astype(np.float64) @ Bm, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("M,N1,N2,K,shift", [(256, 64, 64, 51200, 1024), (256, 64, 64, 640, 128),
+                                             (128, 32, 64, 4096, 0), (512, 100, 28, 320, 320),
+                                             (64, 8, 40, 96, 5)])
+def test_gemm_tn_pair(dev, M, N1, N2, K, shift):
+    """The LSTM cell's dW and db in one pass over dz (arx_gemm_f32_tn_pair): (A^T . [B1 | B2 moved down by
+    `shift` rows])^T against a float64 product, the bound scaled by |A|^T |B| (f32 products, f32 sums)."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(M + N1 + K + shift)
+    A = rng.standard_normal((K, M)).astype(np.float32)
+    B1 = rng.standard_normal((K, N1)).astype(np.float32)
+    B2 = rng.standard_normal((K, N2)).astype(np.float32)       # rows [0, K - shift) are read
+    assert ops.gemm_tn_pair_supported(M, N1, N2, K)
+    Ct = torch.full((N1 + N2, M), 7.0, dtype=torch.float32, device=dev)
+    rs = torch.full((M,), 7.0, dtype=torch.float32, device=dev)
+    ops.gemm_tn_pair(_t(dev, A), _t(dev, B1), _t(dev, B2), shift, Ct, ops.Workspace(dev), a_rowsum=rs)
+    Bcat = np.zeros((K, N1 + N2))
+    Bcat[:, :N1] = B1
+    Bcat[shift:, N1:] = B2[:K - shift]
+    ref = (A.astype(np.float64).T @ Bcat).T
+    scale = (np.abs(A).astype(np.float64).T @ np.abs(Bcat)).T
+    err = np.abs(Ct.cpu().numpy() - ref)
+    assert np.all(err <= 2e-6 * scale + 1e-5), float((err / (scale + 1e-9)).max())
+    np.testing.assert_allclose(rs.cpu().numpy(), A.astype(np.float64).sum(0), rtol=1e-4, atol=2e-3)
+    # deterministic: a second launch gives the same bits
+    Ct2 = torch.empty_like(Ct)
+    ops.gemm_tn_pair(_t(dev, A), _t(dev, B1), _t(dev, B2), shift, Ct2, ops.Workspace(dev))
+    assert torch.equal(Ct, Ct2)
+
+
 @pytest.mark.parametrize("d,Vf,ns", [(128, 5000, (4096, 1024)), (32, 40, (300, 17, 64)), (64, 100000, (64,))])
 def test_sparse_adagrad_cat_fast_path(dev, d, Vf, ns):
     """Sort-free one-hot path == reference semantics (duplicates summed, one update per
