@@ -105,6 +105,11 @@ PROTOTYPES = {
     "arx_mw_scorer_fwd_phases": (cint, [f32p, i64, f32p, i64, f32p, f32p, i64, f32p, i64, cint, i32p, i32p, i32p, i32p,
                                         i64, f32, f32p, i64, i64, f32p, f32p, f32p, i64, f32p, i64, f32p, i64, vp, sz,
                                         cint, vp]),
+    "arx_mw_scorer_fwd_seqw": (cint, [f32p, i64, f32p, i64, f32p, f32p, i64, f32p, i64, cint, i32p, i32p, i32p, i32p,
+                                      i64, f32, f32p, f32p, i64, i64, i64, f32p, f32p, f32p, i64, f32p, i64, f32p, i64,
+                                      vp, sz, cint, vp]),
+    "arx_mw_scorer_bwd_di_loss": (cint, [i64, i64, cint, vp, i64, f32, f32p, i64, f32p, f32p, f32p, f32p, f32, f32p,
+                                         f32p, vp, sz, vp]),
     "arx_mw_scorer_bwd_du": (cint, [i64, i64, cint, vp, f32, f32p, i64, vp]),
     "arx_mw_scorer_bwd_di_workspace_bytes": (sz, [i64, i64, cint, i64]),
     "arx_mw_scorer_bwd_di": (cint, [i64, i64, cint, vp, i64, f32, f32p, i64, f32p, f32p, f32p, vp, sz, vp]),
@@ -189,6 +194,7 @@ PROTOTYPES = {
     "arx_topk_merge": (cint, [f32p, i32p, f32p, i32p, i64, cint, cint, cint, f32p, i32p, vp]),
     "arx_lstm_fwd": (cint, [f32p, f32p, f32p, i64, i64, cint, cint, f32, f32p, f32p, f32p, vp]),
     "arx_lstm_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, i64, i64, cint, cint, f32p, vp]),
+    "arx_lstm_bwd_wxt": (cint, [f32p, f32p, f32p, f32p, f32p, i64, i64, cint, cint, f32p, f32p, vp]),
     "arx_seq_weights": (cint, [f32p, i64, i64, f32p, vp]),
     "arx_capture_begin": (cint, [vp]),
     "arx_capture_end": (cint, [vp, C.POINTER(vp)]),

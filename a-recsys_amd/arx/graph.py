@@ -303,6 +303,7 @@ class Prediction(Node):
         # matrix as bits, the row factors g and g * U here for the two backward products
         self.fused_into_loss = False
         self.scorer = None            # ops.MwScorer (its state holds the act bits, g and the operand planes)
+        self.loss_out = None          # (batch_loss, gscale, row_w, out [1]): the step's scalar loss, left by the fused scorer's dI reduce
 
     def fusable(self, rows):
         """May BatchLoss('mw') take the scorer GEMM in (csrc/scorer.hip)?  Subclasses with their own backward say."""
@@ -327,7 +328,7 @@ class Prediction(Node):
             hook = getattr(self.rt, '_between_backward_gemms', None)
             if hook is not None:
                 hook()
-            self.scorer.bwd_dI(gp, db=pool.bias_grad, beta=beta)
+            self.scorer.bwd_dI(gp, db=pool.bias_grad, beta=beta, loss=self.loss_out)
             pool.bias_grad_used = True
 
     def backward(self):
@@ -547,6 +548,8 @@ class BatchLoss(Node):
         self.mask_rows = mask_rows
         self.gscale = 1.0
         self.row_w = None             # FloatInput-like node
+        self.loss_sink = None         # the node that reduces this loss to the step's scalar (MeanLoss / SeqLoss)
+        self.loss_in_scorer = False   # this execution: the fused scorer's backward leaves that scalar in the sink
         self.rank_value = None
         # 'mw' over <= 2048 sampled columns with the in-kernel positive mask: the wave that owns
         # a row also forms its target score and the two rank-one gradients (2 launches less)
@@ -571,6 +574,7 @@ class BatchLoss(Node):
     def forward(self, train):
         logits, target = self.inputs
         bl = self.alloc_value()
+        self.loss_in_scorer = False
         in_gemm = self.gemm_fused and train           # no [B, S] logits / dlogits at all
         dl = logits.alloc_grad() if (train and not in_gemm) else None
         if train and not in_gemm:
@@ -660,8 +664,20 @@ def _bl_forward_gemm_fused(self, bl, rw, uid, ptr, items, i2s):
         te.bias_grad_used = True
         if dt.data_ptr() != te.bias_grad.data_ptr():
             raise RuntimeError("target-score gradient is expected to alias the bias gradient rows")
+    # the scalar the step reports, gscale * sum_r row_w_r * loss_r, comes out of the backward's reduce launch
+    # (arx_mw_scorer_bwd_di_loss) whenever that launch exists, i.e. the pool trains
+    sink = self.loss_sink
+    self.loss_in_scorer = sink is not None and bool(pool.train_tables)
+    # the sequence model's example weights, normalised over time by the scorer's first launch (SeqWeights.forward
+    # left them to it: folded_into)
+    seq_w, seq_rows = None, 0
+    wn = self.row_w
+    if wn is not None and getattr(wn, 'folded_into', None) is self:
+        seq_w, seq_rows, rw = wn.inputs[0].value, wn.B, wn.alloc_value()
+    logits.loss_out = (bl, self.gscale, rw, sink.alloc_value()) if self.loss_in_scorer else None
     logits.scorer.fwd(lat.value, pool.value, pool.bias_value, te.value, te.bias_value, uid, ptr, items, i2s,
-                      bl, target.value, dt, dU, dT, self.gscale, row_w=rw, mask_rows=self.mask_rows)
+                      bl, target.value, dt, dU, dT, self.gscale, row_w=rw, mask_rows=self.mask_rows,
+                      seq_w=seq_w, seq_rows=seq_rows)
 
 
 BatchLoss._forward_gemm_fused = _bl_forward_gemm_fused
@@ -719,10 +735,19 @@ class MeanLoss(Node):
     def __init__(self, rt, batch_loss):
         super().__init__(rt, (1,), (batch_loss,))
         batch_loss.gscale = 1.0 / batch_loss.shape[0]
+        batch_loss.loss_sink = self
 
     lazy = False   # train plans set this: the scalar is reduced only when somebody reads it
 
+    def in_scorer(self):
+        """This execution's mean came out of the fused scorer's backward (BatchLoss.loss_in_scorer)."""
+        return bool(getattr(self.inputs[0], 'loss_in_scorer', False))
+
     def forward(self, train):
+        if train and self.in_scorer():
+            self.alloc_value()
+            self._stale = False
+            return
         if self.lazy and train:
             self.alloc_value()      # Plan.run marks it stale after every (replayed) step
             return
@@ -1527,7 +1552,7 @@ class Plan(object):
             self._run_ring()
             if self.train:
                 for n in self.fetch:
-                    if isinstance(n, MeanLoss) and n.lazy:
+                    if isinstance(n, MeanLoss) and n.lazy and not n.in_scorer():
                         n._stale = True
             return
         self._ring_ready = False
@@ -1550,7 +1575,7 @@ class Plan(object):
             self.warm += 1
         if self.train:
             for n in self.fetch:
-                if isinstance(n, MeanLoss) and n.lazy:
+                if isinstance(n, MeanLoss) and n.lazy and not n.in_scorer():
                     n._stale = True
 
 

@@ -144,16 +144,17 @@ class LSTM(G.Node):
         if self.dz is None:
             self.dz = torch.empty((L * B, 4 * h), dtype=torch.float32, device=rt.device)
         dz = self.dz
-        ops.lstm_bwd(self.W.w, self.value, self.cs, self.gates, self.grad, L, B, din, h, dz)
-        # dx = dz . W_x^T streams dz through the LDS-DMA GEMM with W_x^T as a plain [4h, din] operand (its
-        # output tile is at most 128 columns wide).  The weight gradient, both halves, and db come from
-        # ONE more pass over dz: (dz^T . [x | h_prev])^T with h_prev = the cell outputs one step (B rows)
-        # up, written in W's own [din + h, 4h] layout by the split-K reduce (arx_gemm_f32_tn_pair) -- two
-        # TN products, two reduces and a transpose before.
         if self._wt is None:
             self._wt = torch.empty((4 * h, din), dtype=torch.float32, device=rt.device)
+        ops.lstm_bwd(self.W.w, self.value, self.cs, self.gates, self.grad, L, B, din, h, dz,
+                     wxt=self._wt if x.requires_grad else None)
+        # dx = dz . W_x^T streams dz through the LDS-DMA GEMM with W_x^T as a plain [4h, din] operand (its
+        # output tile is at most 128 columns wide; the transpose rode along in the backward kernel).
+        # The weight gradient, both halves, and db come from ONE more pass over dz:
+        # (dz^T . [x | h_prev])^T with h_prev = the cell outputs one step (B rows) up, written in W's own
+        # [din + h, 4h] layout by the split-K reduce (arx_gemm_f32_tn_pair) -- two TN products, two
+        # reduces and a transpose before.
         if x.requires_grad:
-            ops.transpose(self.W.w[:din], self._wt)
             ops.gemm(dz, self._wt, x.alloc_grad(), rt.ws, beta=x.grad_beta())
         if L > 1 and ops.gemm_tn_pair_supported(4 * h, din, h, L * B):
             ops.gemm_tn_pair(dz, x.value, self.value, B, self.W.grad, rt.ws, a_rowsum=self.b.grad)
@@ -200,7 +201,7 @@ class SeqPrediction(G.Prediction):
             self._steps(S, d)
             gp = pool.alloc_grad()
             self.scorer.bwd_dI(gp, db=pool.bias_grad, beta=pool.grad_beta(), step_rows=self.B,
-                               dI_steps=self.C_steps, db_steps=self.rs_steps)
+                               dI_steps=self.C_steps, db_steps=self.rs_steps, loss=self.loss_out)
             pool.bias_grad_used = True
 
     def backward(self):
@@ -225,8 +226,12 @@ class SeqWeights(G.Node):
     def __init__(self, rt, w, L, B):
         super().__init__(rt, (L * B,), (w,))
         self.L, self.B = L, B
+        self.folded_into = None       # a BatchLoss whose fused scorer forms these weights in its first launch
 
     def forward(self, train):
+        if train and self.folded_into is not None:
+            self.alloc_value()        # written by arx_mw_scorer_fwd_seqw (graph._bl_forward_gemm_fused)
+            return
         ops.seq_weights(self.inputs[0].value, self.L, self.B, self.alloc_value())
 
 
@@ -240,9 +245,15 @@ class SeqLoss(G.Node):
         batch_loss.gscale = 1.0
         batch_loss.row_w = wn
         batch_loss.extra_inputs = (wn,)
+        batch_loss.loss_sink = self
+        if getattr(batch_loss, 'gemm_fused', False) and isinstance(wn, SeqWeights):
+            wn.folded_into = batch_loss
 
     def forward(self, train):
         bl, wn = self.inputs
+        if train and getattr(bl, 'loss_in_scorer', False):
+            self.alloc_value()        # sum_r wn_r * loss_r arrives with the scorer's backward (bwd_dI(loss_out=))
+            return
         ops.dot_scaled(bl.value, wn.value, 1.0, self.alloc_value())
 
     def read(self):

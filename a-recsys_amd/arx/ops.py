@@ -454,27 +454,31 @@ class MwScorer(object):
         self.ws = Workspace(device)
 
     def fwd(self, U, P, pbias, T, tbias, user_ids, pos_ptr, pos_items, item2slot, batch_loss, tscore_out, dtscore,
-            dU, dT, gscale, row_w=None, mask_rows=0, phases=7):
-        """phases: 1 pool planes + hit lists, 2 hinge GEMM, 4 row kernel (arx_mw_scorer_fwd_phases)"""
-        call("arx_mw_scorer_fwd_phases", _p(U), _ld(U), _p(P), _ld(P), _p(pbias), _p(T), _ld(T), _p(tbias),
+            dU, dT, gscale, row_w=None, mask_rows=0, phases=7, seq_w=None, seq_rows=0):
+        """phases: 1 pool planes + hit lists, 2 hinge GEMM, 4 row kernel (arx_mw_scorer_fwd_phases).  seq_w (the
+        sequence model's raw example weights, [L * seq_rows]): row_w is WRITTEN by phase 1 (normalised over time)."""
+        call("arx_mw_scorer_fwd_seqw", _p(U), _ld(U), _p(P), _ld(P), _p(pbias), _p(T), _ld(T), _p(tbias),
              int(tbias.stride(0)) if tbias is not None else 1, self.d, _p(user_ids), _p(pos_ptr), _p(pos_items),
-             _p(item2slot), int(mask_rows), float(gscale), _p(row_w), self.B, self.S, _p(batch_loss), _p(tscore_out),
-             _p(dtscore), int(dtscore.stride(0)) if dtscore is not None else 1, _p(dU),
-             _ld(dU) if dU is not None else 0, _p(dT), _ld(dT) if dT is not None else 0, _p(self.state),
+             _p(item2slot), int(mask_rows), float(gscale), _p(row_w), _p(seq_w), int(seq_rows), self.B, self.S,
+             _p(batch_loss), _p(tscore_out), _p(dtscore), int(dtscore.stride(0)) if dtscore is not None else 1,
+             _p(dU), _ld(dU) if dU is not None else 0, _p(dT), _ld(dT) if dT is not None else 0, _p(self.state),
              int(self.state.numel()), int(phases), _stream())
 
     def bwd_dU(self, dU, beta=1.0):
         """dU = beta dU + g * (act . P)"""
         call("arx_mw_scorer_bwd_du", self.B, self.S, self.d, _p(self.state), float(beta), _p(dU), _ld(dU), _stream())
 
-    def bwd_dI(self, dI, db=None, beta=0.0, step_rows=0, dI_steps=None, db_steps=None):
-        """dI = beta dI + act^T . (g U), db = act^T . g; step_rows > 0: the per-time-step products too."""
+    def bwd_dI(self, dI, db=None, beta=0.0, step_rows=0, dI_steps=None, db_steps=None, loss=None):
+        """dI = beta dI + act^T . (g U), db = act^T . g; step_rows > 0: the per-time-step products too; loss =
+        (batch_loss [B], gscale, row_w [B] or None, out [1]): out = gscale * sum_r row_w_r * batch_loss_r, the step's
+        scalar, out of the same reduce launch."""
         wsp, wsn = (None, 0)
         if dI_steps is None:
             wsp, wsn = self.ws.get(_lib.lib.arx_mw_scorer_bwd_di_workspace_bytes(self.B, self.S, self.d,
                                                                                  int(step_rows)))
-        call("arx_mw_scorer_bwd_di", self.B, self.S, self.d, _p(self.state), int(step_rows), float(beta), _p(dI),
-             _ld(dI), _p(db), _p(dI_steps), _p(db_steps), wsp, wsn, _stream())
+        bl, gs, rw, out = loss if loss is not None else (None, 0.0, None, None)
+        call("arx_mw_scorer_bwd_di_loss", self.B, self.S, self.d, _p(self.state), int(step_rows), float(beta), _p(dI),
+             _ld(dI), _p(db), _p(dI_steps), _p(db_steps), _p(bl), float(gs), _p(rw), _p(out), wsp, wsn, _stream())
 
 
 def loss_warp_pos(logits, target, user_ids, pos_ptr, pos_items, item2slot, batch_loss, dlogits,
@@ -902,9 +906,10 @@ def lstm_fwd(x, W, b, L, B, din, h, forget_bias, hs, cs, gates):
          _p(hs), _p(cs), _p(gates), _stream())
 
 
-def lstm_bwd(W, hs, cs, gates, dhs, L, B, din, h, dz):
-    call("arx_lstm_bwd", _p(W), _p(hs), _p(cs), _p(gates), _p(dhs), int(L), int(B), int(din),
-         int(h), _p(dz), _stream())
+def lstm_bwd(W, hs, cs, gates, dhs, L, B, din, h, dz, wxt=None):
+    """dz of the whole unrolled cell; wxt (optional, [4h, din]) receives W[:din]^T on the way."""
+    call("arx_lstm_bwd_wxt", _p(W), _p(hs), _p(cs), _p(gates), _p(dhs), int(L), int(B), int(din),
+         int(h), _p(dz), _p(wxt), _stream())
 
 
 def seq_weights(w, L, B, out):

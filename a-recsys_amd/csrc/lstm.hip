@@ -548,10 +548,16 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_r4(
 template <int DIN>
 __global__ __launch_bounds__(256, 2) void k_lstm_bwd_r4(
     const float* __restrict__ W, const float* __restrict__ cs, const float* __restrict__ gates,
-    const float* __restrict__ dhs, int64_t L, int64_t B, float* __restrict__ dz) {
+    const float* __restrict__ dhs, int64_t L, int64_t B, float* __restrict__ dz,
+    float* __restrict__ wxt) {
   constexpr int H = 64, H4 = 256, SZ = H4 + 4;
   __shared__ __attribute__((aligned(16))) float zbuf[kR4 * SZ];
   __shared__ __attribute__((aligned(16))) float part[4][kR4 * H];
+  // W_x^T [4h, din] for the caller's dx product rides along (a 16 k-element transpose that was a launch
+  // of its own on the step's serial chain): a few elements per workgroup, ahead of the recurrence
+  if (wxt)
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < DIN * H4; e += gridDim.x * 256)
+      wxt[(e % H4) * DIN + e / H4] = W[e];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = lane >> 2, j = lane & 3;
   const int64_t row0 = (int64_t)blockIdx.x * kR4;
@@ -737,15 +743,25 @@ int arx_lstm_fwd(const float* x, const float* W, const float* b, int64_t L, int6
 int arx_lstm_bwd(const float* W, const float* hs, const float* cs, const float* gates,
                  const float* dhs, int64_t L, int64_t B, int din, int h, float* dz,
                  void* stream) {
+  return arx_lstm_bwd_wxt(W, hs, cs, gates, dhs, L, B, din, h, dz, nullptr, stream);
+}
+
+int arx_lstm_bwd_wxt(const float* W, const float* hs, const float* cs, const float* gates,
+                     const float* dhs, int64_t L, int64_t B, int din, int h, float* dz, float* wxt,
+                     void* stream) {
   (void)hs;
   ARX_CHECK_ARG(W && cs && gates && dhs && dz, "arx_lstm_bwd: null pointer");
   ARX_CHECK_ARG(L >= 0 && B >= 0 && din > 0 && h > 0, "arx_lstm_bwd: bad size");
-  if (L == 0 || B == 0) return ARX_OK;
   hipStream_t s = as_stream(stream);
   const bool mfma_ok = (h % 64 == 0) && (h <= 128);
   const bool r4 = h == 64 && din == 64 && ceil_div(B, kRows) < 2 * (int64_t)cu_count();
+  if (wxt && !(r4 && L > 0 && B > 0)) {          // the other kernels leave the transpose to its own launch
+    const int rc = arx_transpose_f32(W, 4 * (int64_t)h, din, 4 * (int64_t)h, wxt, din, stream);
+    if (rc) return rc;
+  }
+  if (L == 0 || B == 0) return ARX_OK;
   if (r4) {
-    k_lstm_bwd_r4<64><<<(int)ceil_div(B, kR4), 256, 0, s>>>(W, cs, gates, dhs, L, B, dz);
+    k_lstm_bwd_r4<64><<<(int)ceil_div(B, kR4), 256, 0, s>>>(W, cs, gates, dhs, L, B, dz, wxt);
   } else if (h == 64 && din == 64) {
     k_lstm_bwd_wreg<64><<<(int)ceil_div(B, kRows), 256, 0, s>>>(W, cs, gates, dhs, L, B, dz);
   } else if (mfma_ok) {

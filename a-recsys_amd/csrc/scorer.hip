@@ -203,11 +203,33 @@ __global__ __launch_bounds__(256) void k_sc_prep(const float* __restrict__ P, in
                                                  uint16_t* __restrict__ PT, int64_t ldpt, float* __restrict__ pool_bad,
                                                  PosMask pm,
                                                  int64_t mask_rows, int64_t B, int32_t* __restrict__ hits,
-                                                 int32_t* __restrict__ nhit) {
+                                                 int32_t* __restrict__ nhit, const float* __restrict__ seq_w,
+                                                 int64_t seq_rows, float* __restrict__ row_w_out) {
   __shared__ float tile[32 * 129];
   __shared__ float sbad[4];
   const int tid = threadIdx.x;
   const int64_t pblocks = S / 32;
+  const int64_t hblocks = (B + 3) / 4;
+  if ((int64_t)blockIdx.x >= pblocks + hblocks) {
+    // the sequence model's example weights (seqModel.py:561-567): row_w[t * seq_rows + b] = w_t[b] / (sum_t w_t[b] +
+    // 1e-12) for the B = L * seq_rows time-major rows -- 32 sequences x 8 time lanes per workgroup, combined in
+    // lane order (the arithmetic of arx_seq_weights, which was a launch of its own in front of this kernel)
+    float* part = tile;                                      // [8][33]
+    const int cx = tid & 31, ty = tid >> 5;
+    const int64_t b = ((int64_t)blockIdx.x - pblocks - hblocks) * 32 + cx;
+    const int64_t L = B / seq_rows;
+    float sum = 0.f;
+    if (b < seq_rows)
+      for (int64_t t = ty; t < L; t += 8) sum += seq_w[t * seq_rows + b];
+    part[ty * 33 + cx] = sum;
+    __syncthreads();
+    float tot = 1e-12f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += part[k * 33 + cx];
+    if (b < seq_rows)
+      for (int64_t t = ty; t < L; t += 8) row_w_out[t * seq_rows + b] = seq_w[t * seq_rows + b] / tot;
+    return;
+  }
   if ((int64_t)blockIdx.x < pblocks) {
     const int64_t r0 = (int64_t)blockIdx.x * 32;
     const int ld = d + 1;
@@ -919,8 +941,41 @@ __global__ __launch_bounds__(512) void k_sc_bits(int64_t M, int N, int64_t kslic
 __global__ __launch_bounds__(256) void k_sc_tn_reduce(const float* __restrict__ part, int nsl, int64_t M, int N,
                                                       float beta, float* __restrict__ C, int64_t ldc,
                                                       const float* __restrict__ dbp, int64_t nblk,
-                                                      float* __restrict__ db, int dbblocks) {
-  const int nmain = (int)gridDim.x - dbblocks;
+                                                      float* __restrict__ db, int dbblocks,
+                                                      const float* __restrict__ lrow, const float* __restrict__ lw,
+                                                      int64_t lrows, float lscale, float* __restrict__ loss_out) {
+  const int nmain = (int)gridDim.x - dbblocks - (loss_out ? 1 : 0);
+  if (loss_out && blockIdx.x == gridDim.x - 1) {
+    // the step's scalar loss, gscale * sum_r row_w[r] * loss[r] over the row kernel's batch_loss, in a fixed order
+    // (thread t takes float4s t, t + 256, ..., eight pairs of loads in flight; the 256 sub-sums meet in a fixed
+    // tree) -- was a launch of its own (mean / weighted dot) between the forward and the backward kernels.
+    // (Block sums out of the row kernel would be less to read, but ANY code added to k_sc_rows -- one store --
+    // cost a register, 88 -> 89 = one allocation granule, and ~6 us of the C3 step: measured.)
+    __shared__ float sls[256];
+    const int64_t n4 = lrows >> 2;
+    float t = 0.f;
+    for (int64_t b0 = threadIdx.x; b0 < n4; b0 += 8 * 256) {
+      float4 v[8], w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t q = b0 + u * 256;
+        v[u] = q < n4 ? reinterpret_cast<const float4*>(lrow)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        w[u] = (q < n4 && lw) ? reinterpret_cast<const float4*>(lw)[q] : make_float4(1.f, 1.f, 1.f, 1.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += (v[u].x * w[u].x + v[u].y * w[u].y) + (v[u].z * w[u].z + v[u].w * w[u].w);
+    }
+    if (threadIdx.x == 0)
+      for (int64_t r = n4 * 4; r < lrows; ++r) t += lrow[r] * (lw ? lw[r] : 1.f);
+    sls[threadIdx.x] = t;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) sls[threadIdx.x] += sls[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss_out = lscale * sls[0];
+    return;
+  }
   if ((int)blockIdx.x >= nmain) {
     // 64 columns per workgroup: thread = (row group rg of 16, four columns cg); a thread adds up the partial rows
     // rg, rg + 16, ... with sixteen 16-byte loads in flight (four waves walking 128 rows each, four loads at a time,
@@ -1113,8 +1168,23 @@ int arx_mw_scorer_fwd_phases(const float* U, int64_t ldu, const float* P, int64_
                              int64_t S, float* batch_loss, float* tscore_out, float* dtscore, int64_t dtscore_stride,
                              float* dU, int64_t lddu, float* dT, int64_t lddt, void* state, size_t state_bytes,
                              int phases, void* stream) {
+  return arx_mw_scorer_fwd_seqw(U, ldu, P, ldp, pbias, T, ldt, tbias, tb_stride, d, user_ids, pos_ptr, pos_items,
+                                item2slot, mask_rows, gscale, const_cast<float*>(row_w), nullptr, 0, B, S, batch_loss,
+                                tscore_out, dtscore, dtscore_stride, dU, lddu, dT, lddt, state, state_bytes, phases,
+                                stream);
+}
+
+int arx_mw_scorer_fwd_seqw(const float* U, int64_t ldu, const float* P, int64_t ldp, const float* pbias,
+                           const float* T, int64_t ldt, const float* tbias, int64_t tb_stride, int d,
+                           const int32_t* user_ids, const int32_t* pos_ptr, const int32_t* pos_items,
+                           const int32_t* item2slot, int64_t mask_rows, float gscale, float* row_w,
+                           const float* seq_w, int64_t seq_rows, int64_t B, int64_t S, float* batch_loss,
+                           float* tscore_out, float* dtscore, int64_t dtscore_stride, float* dU, int64_t lddu,
+                           float* dT, int64_t lddt, void* state, size_t state_bytes, int phases, void* stream) {
   ARX_CHECK_ARG(U && P && T && user_ids && pos_ptr && pos_items && item2slot && state,
                 "arx_mw_scorer_fwd: null pointer");
+  ARX_CHECK_ARG(!seq_w || (row_w && seq_rows > 0 && B % seq_rows == 0),
+                "arx_mw_scorer_fwd_seqw: sequence weights need row_w [B] to write and seq_rows dividing B");
   ScLayout L;
   const bool ok = sc_layout(B, S, d, &L) && ldu % 4 == 0 && ldp % 4 == 0 && ldt % 4 == 0 && ldu >= d && ldp >= d &&
                   ldt >= d && (!dU || (lddu % 4 == 0 && lddu >= d)) && (!dT || (lddt % 4 == 0 && lddt >= d)) &&
@@ -1143,9 +1213,9 @@ int arx_mw_scorer_fwd_phases(const float* U, int64_t ldu, const float* P, int64_
   const PosMask pm = make_pos_mask(user_ids, pos_ptr, pos_items, item2slot);
   const int64_t mrows = mask_rows > 0 ? mask_rows : B;
   if (phases & 1) {
-    const int64_t grid = S / 32 + ceil_div(B, 4);
+    const int64_t grid = S / 32 + ceil_div(B, 4) + (seq_w ? ceil_div(seq_rows, 32) : 0);
     k_sc_prep<<<(int)grid, 256, 0, s>>>(P, ldp, S, d, pbias, Pp, PT, L.ldpt, reinterpret_cast<float*>(st + L.pbad), pm,
-                                        mrows, B, hits, nhit);
+                                        mrows, B, hits, nhit, seq_w, seq_rows, row_w);
     ARX_CHECK_LAUNCH();
   }
   if (phases & 2) {
@@ -1219,7 +1289,18 @@ size_t arx_mw_scorer_bwd_di_workspace_bytes(int64_t B, int64_t S, int d, int64_t
 int arx_mw_scorer_bwd_di(int64_t B, int64_t S, int d, const void* state, int64_t step_rows, float beta, float* dI,
                          int64_t lddi, float* db, float* dI_steps, float* db_steps, void* workspace,
                          size_t workspace_bytes, void* stream) {
+  return arx_mw_scorer_bwd_di_loss(B, S, d, state, step_rows, beta, dI, lddi, db, dI_steps, db_steps, nullptr, 0.f,
+                                   nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+int arx_mw_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, int64_t step_rows, float beta,
+                              float* dI, int64_t lddi, float* db, float* dI_steps, float* db_steps,
+                              const float* batch_loss, float gscale, const float* row_w, float* loss_out,
+                              void* workspace, size_t workspace_bytes, void* stream) {
   ScLayout L;
+  ARX_CHECK_ARG(!loss_out || (batch_loss && (reinterpret_cast<uintptr_t>(batch_loss) & 15) == 0 &&
+                              (reinterpret_cast<uintptr_t>(row_w) & 15) == 0),
+                "arx_mw_scorer_bwd_di_loss: loss_out needs batch_loss (and row_w) 16-byte aligned");
   ARX_CHECK_ARG(state && dI && sc_layout(B, S, d, &L), "arx_mw_scorer_bwd_di: bad argument / shape");
   ARX_CHECK_ARG(lddi % 4 == 0 && lddi >= d && (reinterpret_cast<uintptr_t>(dI) & 15) == 0,
                 "arx_mw_scorer_bwd_di: dI rows must be 16-byte aligned");
@@ -1251,8 +1332,8 @@ int arx_mw_scorer_bwd_di(int64_t B, int64_t S, int d, const void* state, int64_t
   ARX_CHECK_LAUNCH();
   const float* dbp = reinterpret_cast<const float*>(st + L.dbp);
   const int dbblocks = db ? (int)ceil_div(S, 64) : 0;
-  k_sc_tn_reduce<<<(int)ceil_div(S * (d / 4), 64) + dbblocks, 256, 0, s>>>(part, (int)nsl, S, d, beta, dI, lddi, dbp,
-                                                                           L.nblk, db, dbblocks);
+  k_sc_tn_reduce<<<(int)ceil_div(S * (d / 4), 64) + dbblocks + (loss_out ? 1 : 0), 256, 0, s>>>(
+      part, (int)nsl, S, d, beta, dI, lddi, dbp, L.nblk, db, dbblocks, batch_loss, row_w, B, gscale, loss_out);
   ARX_CHECK_LAUNCH();
   if (db_steps && step_rows > 0) {
     const int64_t Lsteps = B / step_rows, bps = step_rows / 32;

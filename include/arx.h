@@ -419,12 +419,31 @@ int arx_mw_scorer_fwd_phases(const float* U, int64_t ldu, const float* P, int64_
                              int64_t S, float* batch_loss, float* tscore_out, float* dtscore, int64_t dtscore_stride,
                              float* dU, int64_t lddu, float* dT, int64_t lddt, void* state, size_t state_bytes,
                              int phases, void* stream);
+/* arx_mw_scorer_fwd_phases for the sequence model (seqModel.py:561-567): with seq_w [B] (time-major, B = L *
+ * seq_rows) the row weights are formed on the way -- row_w[t * seq_rows + b] = seq_w[t * seq_rows + b] /
+ * (sum_t seq_w[t * seq_rows + b] + 1e-12) is WRITTEN to row_w by the launch of phase bit 0 and read by the row
+ * kernel (the arithmetic of arx_seq_weights).  seq_w == NULL: row_w is an input (nullable), as above. */
+int arx_mw_scorer_fwd_seqw(const float* U, int64_t ldu, const float* P, int64_t ldp, const float* pbias,
+                           const float* T, int64_t ldt, const float* tbias, int64_t tb_stride, int d,
+                           const int32_t* user_ids, const int32_t* pos_ptr, const int32_t* pos_items,
+                           const int32_t* item2slot, int64_t mask_rows, float gscale, float* row_w,
+                           const float* seq_w, int64_t seq_rows, int64_t B, int64_t S, float* batch_loss,
+                           float* tscore_out, float* dtscore, int64_t dtscore_stride, float* dU, int64_t lddu,
+                           float* dT, int64_t lddt, void* state, size_t state_bytes, int phases, void* stream);
 int arx_mw_scorer_bwd_du(int64_t B, int64_t S, int d, const void* state, float beta, float* dU, int64_t lddu,
                          void* stream);
 size_t arx_mw_scorer_bwd_di_workspace_bytes(int64_t B, int64_t S, int d, int64_t step_rows);
 int arx_mw_scorer_bwd_di(int64_t B, int64_t S, int d, const void* state, int64_t step_rows, float beta, float* dI,
                          int64_t lddi, float* db, float* dI_steps, float* db_steps, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* The same, and *loss_out = gscale * sum_r row_w[r] * batch_loss[r] over the B row losses the forward wrote (row_w
+ * NULL: ones) -- hmf_model.py:140 reduce_mean with gscale = 1 / B; seqModel.py:571-604 with row_w the normalised
+ * example weights -- added up in a fixed order by one more block of the reduce launch.  loss_out NULL:
+ * arx_mw_scorer_bwd_di. */
+int arx_mw_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, int64_t step_rows, float beta,
+                              float* dI, int64_t lddi, float* db, float* dI_steps, float* db_steps,
+                              const float* batch_loss, float gscale, const float* row_w, float* loss_out,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* Sampled softmax ('mce').  BUILD-DEFINED: the reference accepts loss 'mce'
  * (embed_attribute.py:527 assert, :717 feed guard, run_hmf.py:31,100, lstm/run.py:447) but its
@@ -771,6 +790,11 @@ int arx_lstm_fwd(const float* x, const float* W, const float* b, int64_t L, int6
 int arx_lstm_bwd(const float* W, const float* hs, const float* cs, const float* gates,
                  const float* dhs, int64_t L, int64_t B, int din, int h, float* dz,
                  void* stream);
+/* The same, and wxt [4h, din] = W[0:din, :]^T (the B operand of dx = dz . W_x^T) written on the way
+ * (wxt may be NULL). */
+int arx_lstm_bwd_wxt(const float* W, const float* hs, const float* cs, const float* gates,
+                     const float* dhs, int64_t L, int64_t B, int din, int h, float* dz, float* wxt,
+                     void* stream);
 
 /* *out = scale * sum_i x[i]*y[i] (single workgroup, fixed order): the weighted
  * sum of sequence_loss (seqModel.py:561-563,596). */

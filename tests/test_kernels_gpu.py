@@ -691,8 +691,10 @@ def test_lstm_fwd_bwd(dev, L, B, din, h):
     np.testing.assert_allclose(cs.cpu().numpy(), r_cs, rtol=RTOL, atol=2e-5)
     np.testing.assert_allclose(gates.cpu().numpy(), r_g, rtol=RTOL, atol=2e-5)
     dz = torch.empty((L, B, 4 * h), dtype=torch.float32, device=dev)
-    ops.lstm_bwd(tW, hs, cs, gates, _t(dev, dhs), L, B, din, h, dz)
+    wxt = torch.full((4 * h, din), 7.0, dtype=torch.float32, device=dev)
+    ops.lstm_bwd(tW, hs, cs, gates, _t(dev, dhs), L, B, din, h, dz, wxt=wxt)
     np.testing.assert_allclose(dz.cpu().numpy(), r_dz, rtol=1e-4, atol=5e-5)
+    assert np.array_equal(wxt.cpu().numpy(), W[:din].T)         # W_x^T rides along (a copy: exact)
     # dx / dW / db are GEMMs + a column sum over dz (what the model issues)
     ws = ops.Workspace(dev)
     dz2 = dz.view(L * B, 4 * h)
@@ -707,6 +709,12 @@ def test_lstm_fwd_bwd(dev, L, B, din, h):
     db = torch.empty(4 * h, dtype=torch.float32, device=dev)
     ops.col_sum(dz2, db, ws)
     np.testing.assert_allclose(db.cpu().numpy(), r_db, rtol=1e-4, atol=2e-4)
+    if L > 1 and ops.gemm_tn_pair_supported(4 * h, din, h, L * B):     # the model's one-pass form of dW, db
+        dW2 = torch.empty_like(dW)
+        db2 = torch.empty_like(db)
+        ops.gemm_tn_pair(dz2, _t(dev, x).view(L * B, din), hs.view(L * B, h), B, dW2, ws, a_rowsum=db2)
+        np.testing.assert_allclose(dW2.cpu().numpy(), r_dW, rtol=1e-4, atol=2e-4)
+        np.testing.assert_allclose(db2.cpu().numpy(), r_db, rtol=1e-4, atol=2e-4)
 
 
 def test_loss_pos_variants_equal_mask_array(dev):
@@ -1463,7 +1471,12 @@ def test_mw_scorer(dev, B, S, d, mask_rows):
     dI0 = rng.standard_normal((S, d)).astype(np.float32)
     dI = _t(dev, dI0)
     db = torch.empty(S, dtype=f32, device=dev)
-    sc.bwd_dI(dI, db=db, beta=0.5)                                               # dI = 0.5 dI + act^T . (g U)
+    lsum = torch.full((1,), 7.0, dtype=f32, device=dev)
+    sc.bwd_dI(dI, db=db, beta=0.5, loss=(out_bl, gscale, _t(dev, rw), lsum))     # dI = 0.5 dI + act^T . (g U)
+    # the step's scalar out of the same reduce launch: gscale * sum_r row_w_r * loss_r (f32 sums of <= B terms)
+    ref_sum = float((rw.astype(np.float64) * gscale * bl).sum())
+    bound = 4e-7 * float((rw.astype(np.float64) * gscale * np.abs(bl)).sum()) * (6 + np.log2(max(B, 2))) + 1e-12
+    assert abs(float(lsum.item()) - ref_sum) <= bound, (float(lsum.item()), ref_sum, bound)
     if exact:
         np.testing.assert_allclose(dI.cpu().numpy(), 0.5 * dI0 + dl.T @ U.astype(np.float64), rtol=RTOL, atol=2e-8)
         np.testing.assert_allclose(db.cpu().numpy(), dl.sum(0), rtol=RTOL, atol=2e-8)
@@ -1479,6 +1492,23 @@ def test_mw_scorer(dev, B, S, d, mask_rows):
                                        atol=2e-8)
             np.testing.assert_allclose(dbs[k].cpu().numpy(), dl[rows].sum(0), rtol=RTOL, atol=2e-8)
         np.testing.assert_allclose(dI2.cpu().numpy(), dl.T @ U.astype(np.float64), rtol=RTOL, atol=2e-8)
+    if mask_rows:
+        # the sequence model's example weights formed by the first launch (arx_mw_scorer_fwd_seqw): the arithmetic
+        # of arx_seq_weights bit for bit, and g / the scalar loss follow from them
+        L = B // mask_rows
+        w_raw = _t(dev, (rng.random(B) * (rng.random(B) > 0.2)).astype(np.float32))
+        wn_ref = torch.empty(B, dtype=f32, device=dev)
+        ops.seq_weights(w_raw, L, mask_rows, wn_ref)
+        wn = torch.full((B,), 7.0, dtype=f32, device=dev)
+        sc.fwd(tU, tP, _t(dev, pb), _t(dev, T), _t(dev, tb), _t(dev, users), _t(dev, ptr), _t(dev, pitems),
+               _t(dev, i2s), out_bl, out_t, dts, dU, dT, 1.0, row_w=wn, mask_rows=mask_rows, seq_w=w_raw,
+               seq_rows=mask_rows)
+        assert torch.equal(wn, wn_ref)
+        wn64 = wn.cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(sc.g[:B].cpu().numpy(), wn64 / (1.0 + cache['s']), rtol=RTOL, atol=1e-10)
+        sc.bwd_dI(dI, db=db, loss=(out_bl, 1.0, wn, lsum))
+        ref_sum = float((wn64 * bl).sum())
+        assert abs(float(lsum.item()) - ref_sum) <= 4e-7 * ref_sum * (6 + np.log2(B)) + 1e-12
 
 
 def test_mw_scorer_products_f32_exact(dev):
