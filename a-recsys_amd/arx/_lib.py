@@ -198,6 +198,10 @@ PROTOTYPES = {
     "arx_seq_weights": (cint, [f32p, i64, i64, f32p, vp]),
     "arx_capture_begin": (cint, [vp]),
     "arx_capture_end": (cint, [vp, C.POINTER(vp)]),
+    "arx_capture_end_feeds": (cint, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(cint)]),
+    "arx_graph_feed_dst0": (cint, [vp, cint, C.POINTER(vp)]),
+    "arx_graph_set_feed": (cint, [vp, vp, cint, cint, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]),
+    "arx_graph_feeds_destroy": (cint, [vp]),
     "arx_graph_launch": (cint, [vp, vp]),
     "arx_graph_destroy": (cint, [vp]),
 }

@@ -1540,13 +1540,16 @@ class Plan(object):
 
     def run(self):
         rt = self.rt
-        rt.flush_feeds()
         if self.train and self._kp != rt.keep_prob:
             # keep_prob is baked into the kernel sequence (identity vs masked): rebuild
             self._kp = rt.keep_prob
             self.graph = None
             self.warm = 0
             self._ring_reset()
+        ring_now = self.ring_req and self._ring_ready and self.ring_capable()
+        in_graph = rt.use_graph and self.warm >= 1 and rt.feeds_in_graph and not ring_now
+        if not in_graph:
+            rt.flush_feeds()
         ring, self.ring_req = self.ring_req, False
         if ring and self._ring_ready and self.ring_capable():
             self._run_ring()
@@ -1557,6 +1560,9 @@ class Plan(object):
             return
         self._ring_ready = False
         if rt.use_graph and self.warm >= 1:
+            # the step's placeholder feeds travel as the graph's first node(s): their sources are swapped in before
+            # the replay (CapturedGraph.set_feeds) -- one submission per step instead of an eager copy + the graph
+            pf = rt.take_feeds() if in_graph else []
             if self.graph is None:
                 g = ops.CapturedGraph()
                 side = torch.cuda.Stream(device=rt.device)
@@ -1564,11 +1570,21 @@ class Plan(object):
                 with torch.cuda.stream(side):
                     g.begin()
                     try:
+                        if pf:
+                            ops.copy_words(pf)
                         self._execute()
-                    finally:
+                    except BaseException:
                         g.end()
+                        raise
+                    g.end(feeds=pf)
                 torch.cuda.current_stream().wait_stream(side)
                 self.graph = g
+            elif pf and self.graph.feeds_match(pf):
+                self.graph.set_feeds(pf)
+            else:
+                if pf:
+                    ops.copy_words(pf)            # other placeholders than the captured ones: fed eagerly
+                self.graph.set_feeds(None)
             self.graph.launch()
         else:
             self._execute()
@@ -1604,6 +1620,7 @@ class Runtime(object):
         self.dropout_calls = 0
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)   # device step counter
         self.pending_feeds = []         # (src, placeholder buffer) device-to-device feeds not yet issued
+        self.feeds_in_graph = True      # captured plans take them in as graph nodes (False: an eager launch per step)
         # K7 pass selection overrides (attributes, not environment switches: set them on the runtime object to
         # force a pass shape that the sizes would not pick; all False / 0 in production)
         self.force_sort_path = False     # every table through arx_sparse_adagrad (explicit triples)
@@ -1626,6 +1643,11 @@ class Runtime(object):
         source tensor is referenced, not copied: it must stay unmodified until the plan runs."""
         self.drop_feed(dst)
         self.pending_feeds.append((src, dst))
+
+    def take_feeds(self):
+        """The queued placeholder feeds, for a caller that issues them itself (Plan.run: as graph nodes)."""
+        pf, self.pending_feeds = self.pending_feeds, []
+        return pf
 
     def flush_feeds(self):
         """Issue the queued placeholder feeds (one launch per eight buffers)."""

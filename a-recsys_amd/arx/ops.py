@@ -917,18 +917,63 @@ def seq_weights(w, L, B, out):
 
 
 class CapturedGraph(object):
-    """A hipGraph of one step (arx_capture_* in include/arx.h)."""
+    """A hipGraph of one step (arx_capture_* in include/arx.h).  end(feeds=...): the placeholder feeds issued inside
+    the capture (copy_words) stay addressable -- set_feeds() swaps their sources before a replay."""
 
     def __init__(self):
         import ctypes as C
         self._exec = C.c_void_p(0)
+        self._feeds = C.c_void_p(0)
+        self.feed_groups = None      # per captured copy node: the destination pointers of its (<= 8) feeds, in order
+        self._node_of = []           # group index -> node index
+        self._fed = False            # the nodes hold live sources (else: they copy nothing)
 
     def begin(self):
         call("arx_capture_begin", _stream())
 
-    def end(self):
+    def end(self, feeds=None):
+        """feeds: the [(src, dst), ...] list copy_words() was called with inside this capture (None: no feed nodes)."""
         import ctypes as C
-        call("arx_capture_end", _stream(), C.byref(self._exec))
+        if not feeds:
+            call("arx_capture_end", _stream(), C.byref(self._exec))
+            return
+        n = C.c_int(0)
+        call("arx_capture_end_feeds", _stream(), C.byref(self._exec), C.byref(self._feeds), C.byref(n))
+        groups = [feeds[k:k + 8] for k in range(0, len(feeds), 8)]
+        first = {}
+        for i in range(n.value):
+            d0 = C.c_void_p(0)
+            call("arx_graph_feed_dst0", self._feeds, i, C.byref(d0))
+            first[d0.value] = i
+        node_of = [first.get(g[0][1].data_ptr()) for g in groups]
+        if n.value != len(groups) or None in node_of or len(set(node_of)) != len(groups):
+            raise RuntimeError("captured step: %d feed node(s) found for %d feed group(s)" % (n.value, len(groups)))
+        self._node_of = node_of
+        self.feed_groups = [tuple((d.data_ptr(), d.numel()) for _, d in g) for g in groups]
+        self._fed = True
+
+    def feeds_match(self, feeds):
+        """Do these pending feeds address exactly the destinations the capture's feed nodes write?"""
+        if self.feed_groups is None:
+            return False
+        groups = [feeds[k:k + 8] for k in range(0, len(feeds), 8)]
+        return [tuple((d.data_ptr(), d.numel()) for _, d in g) for g in groups] == self.feed_groups
+
+    def set_feeds(self, feeds):
+        """The sources the feed nodes copy at the next launches; None / []: they copy nothing."""
+        import ctypes as C
+        if self.feed_groups is None or (not feeds and not self._fed):
+            return
+        for gi, ni in enumerate(self._node_of):
+            grp = feeds[gi * 8:(gi + 1) * 8] if feeds else []
+            n = len(grp)
+            src, dst, cnt = (C.c_void_p * max(n, 1))(), (C.c_void_p * max(n, 1))(), (C.c_int64 * max(n, 1))()
+            for a, (s_, d_) in enumerate(grp):
+                if s_.element_size() != 4 or d_.element_size() != 4 or s_.numel() != d_.numel():
+                    raise ValueError("set_feeds: 4-byte tensors of equal size expected")
+                src[a], dst[a], cnt[a] = s_.data_ptr(), d_.data_ptr(), s_.numel()
+            call("arx_graph_set_feed", self._exec, self._feeds, ni, n, src, dst, cnt)
+        self._fed = bool(feeds)
 
     def launch(self):
         call("arx_graph_launch", self._exec, _stream())
@@ -937,5 +982,7 @@ class CapturedGraph(object):
         try:
             if self._exec:
                 _lib.lib.arx_graph_destroy(self._exec)
+            if self._feeds:
+                _lib.lib.arx_graph_feeds_destroy(self._feeds)
         except Exception:
             pass

@@ -95,6 +95,27 @@ __global__ __launch_bounds__(kExtThreads) void k_runs_extract(const uint32_t* __
 #pragma unroll
     for (int u = 0; u < kExtPer; ++u) k[u + 1] = p0 + u < n ? sk[p0 + u] : 0xffffffffu;
   }
+  // (src, coef) of the tile's positions, wanted by the records of its run heads: loaded HERE, with the keys, as
+  // vector loads -- in the record loop below each pair was a load behind the previous record's stores (the
+  // compiler cannot move it across them: the record arrays are plain pointers), eight dependent round trips
+  int sv[kExtPer];
+  float cv[kExtPer];
+  if (rl.R != nullptr && p0 + kExtPer <= n) {
+#pragma unroll
+    for (int v = 0; v < kExtPer / 4; ++v) {
+      const int4 a = *reinterpret_cast<const int4*>(ssrc + p0 + 4 * v);
+      const float4 c4 = *reinterpret_cast<const float4*>(scoef + p0 + 4 * v);
+      sv[4 * v] = a.x; sv[4 * v + 1] = a.y; sv[4 * v + 2] = a.z; sv[4 * v + 3] = a.w;
+      cv[4 * v] = c4.x; cv[4 * v + 1] = c4.y; cv[4 * v + 2] = c4.z; cv[4 * v + 3] = c4.w;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < kExtPer; ++u) {
+      const bool in = rl.R != nullptr && p0 + u < n;
+      sv[u] = in ? ssrc[p0 + u] : 0;
+      cv[u] = in ? scoef[p0 + u] : 0.f;
+    }
+  }
   uint32_t hm = 0, mk = 0;                               // heads; heads or dead positions
   int llen[kExtPer];
   int lsum = 0;
@@ -251,7 +272,7 @@ __global__ __launch_bounds__(kExtThreads) void k_runs_extract(const uint32_t* __
     const int c = cnt[u];
     const int ur = u_run++;
     rl.R[ur] = make_int4((int)k[u + 1], (int)p, c, (int)p);
-    rl.R2[ur] = make_int2(ssrc[p], __float_as_int(scoef[p]));
+    rl.R2[ur] = make_int2(sv[u], __float_as_int(cv[u]));
     if (c > kshort) {
       const int nch = (c + kItem - 1) / kItem;
       const int pbu = nch > 1 ? pb : 0;

@@ -512,6 +512,100 @@ int arx_capture_end(void* stream, void** graph_exec_out) {
   return ARX_OK;
 }
 
+// ---- placeholder feeds as nodes of the step graph -------------------------------------------------------------
+// The feed of a step (arx_copy_words: the batch's id / weight arrays into the tensors the captured kernels read)
+// was an eager launch in front of every graph launch: two submissions per step, and the graph's first kernel
+// started ~7 us behind the copy.  Captured as the graph's first node(s), the copy's sources are swapped per step
+// with hipGraphExecKernelNodeSetParams: one submission per step.
+struct FeedNodes {
+  hipGraph_t g;
+  int n;
+  hipGraphNode_t node[16];
+};
+
+int arx_capture_end_feeds(void* stream, void** graph_exec_out, void** feeds_out, int* n_feed_nodes) {
+  ARX_CHECK_ARG(graph_exec_out && feeds_out && n_feed_nodes, "arx_capture_end_feeds: null out pointer");
+  hipGraph_t g = nullptr;
+  ARX_CHECK_HIP(hipStreamEndCapture(as_stream(stream), &g));
+  FeedNodes* fn = new FeedNodes();
+  fn->g = g;
+  fn->n = 0;
+  size_t nn = 0;
+  hipError_t err = hipGraphGetNodes(g, nullptr, &nn);
+  if (err == hipSuccess && nn > 0) {
+    hipGraphNode_t* all = new hipGraphNode_t[nn];
+    err = hipGraphGetNodes(g, all, &nn);
+    for (size_t i = 0; err == hipSuccess && i < nn; ++i) {
+      hipGraphNodeType ty;
+      if (hipGraphNodeGetType(all[i], &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
+      hipKernelNodeParams kp;
+      if (hipGraphKernelNodeGetParams(all[i], &kp) != hipSuccess) continue;
+      if (kp.func == reinterpret_cast<void*>(k_copy_words) && fn->n < 16) fn->node[fn->n++] = all[i];
+    }
+    delete[] all;
+  }
+  hipGraphExec_t e = nullptr;
+  if (err == hipSuccess) err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  if (err != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    delete fn;
+    set_error("arx_capture_end_feeds: %s", hipGetErrorString(err));
+    return ARX_EHIP;
+  }
+  *graph_exec_out = (void*)e;
+  *feeds_out = (void*)fn;
+  *n_feed_nodes = fn->n;
+  return ARX_OK;
+}
+
+/* first destination pointer of feed node idx as captured (the caller matches nodes to its feed groups by it) */
+int arx_graph_feed_dst0(void* feeds, int idx, void** dst0) {
+  FeedNodes* fn = reinterpret_cast<FeedNodes*>(feeds);
+  ARX_CHECK_ARG(fn && dst0 && idx >= 0 && idx < fn->n, "arx_graph_feed_dst0: bad argument");
+  hipKernelNodeParams kp;
+  ARX_CHECK_HIP(hipGraphKernelNodeGetParams(fn->node[idx], &kp));
+  ARX_CHECK_ARG(kp.kernelParams && kp.kernelParams[0], "arx_graph_feed_dst0: the node carries no argument block");
+  *dst0 = reinterpret_cast<const CopySet*>(kp.kernelParams[0])->dst[0];
+  return ARX_OK;
+}
+
+/* feed node idx of the instantiated graph copies these (count 0: nothing) at its next launches */
+int arx_graph_set_feed(void* graph_exec, void* feeds, int idx, int count, const void* const* src, void* const* dst,
+                       const int64_t* n_words) {
+  FeedNodes* fn = reinterpret_cast<FeedNodes*>(feeds);
+  ARX_CHECK_ARG(graph_exec && fn && idx >= 0 && idx < fn->n && count >= 0 && count <= 8,
+                "arx_graph_set_feed: bad argument");
+  ARX_CHECK_ARG(count == 0 || (src && dst && n_words), "arx_graph_set_feed: null pointer");
+  CopySet cs = {};
+  int64_t nmax = 1;
+  for (int a = 0; a < count; ++a) {
+    ARX_CHECK_ARG(n_words[a] >= 0 && (n_words[a] == 0 || (src[a] && dst[a])), "arx_graph_set_feed: bad entry");
+    cs.src[a] = reinterpret_cast<const uint32_t*>(src[a]);
+    cs.dst[a] = reinterpret_cast<uint32_t*>(dst[a]);
+    cs.n[a] = n_words[a];
+    if (n_words[a] > nmax) nmax = n_words[a];
+  }
+  cs.count = count;
+  hipKernelNodeParams kp;
+  ARX_CHECK_HIP(hipGraphKernelNodeGetParams(fn->node[idx], &kp));
+  void* args[1] = {&cs};
+  kp.kernelParams = args;
+  kp.extra = nullptr;
+  kp.gridDim = dim3((unsigned)grid_for(nmax, 256), 1, 1);
+  kp.blockDim = dim3(256, 1, 1);
+  ARX_CHECK_HIP(hipGraphExecKernelNodeSetParams((hipGraphExec_t)graph_exec, fn->node[idx], &kp));
+  return ARX_OK;
+}
+
+int arx_graph_feeds_destroy(void* feeds) {
+  FeedNodes* fn = reinterpret_cast<FeedNodes*>(feeds);
+  if (fn) {
+    (void)hipGraphDestroy(fn->g);
+    delete fn;
+  }
+  return ARX_OK;
+}
+
 int arx_graph_launch(void* graph_exec, void* stream) {
   ARX_CHECK_ARG(graph_exec, "arx_graph_launch: null graph");
   ARX_CHECK_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, as_stream(stream)));

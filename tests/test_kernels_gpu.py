@@ -1624,3 +1624,47 @@ def test_gemm_nt_bx6(dev, M, N, K):
     assert float(e1.max()) <= K * 2.0 ** -24
     assert float(e1.mean()) <= float(e0.mean()) * 1.05 and float(e1.max()) <= float(e0.max()) * 1.05
     assert bool((Lbuf[:, N:] == 7.0).all())                           # nothing written past the row
+
+
+def test_captured_graph_feed_nodes(dev):
+    """Placeholder feeds captured as graph nodes (arx_capture_end_feeds / arx_graph_set_feed): a replay copies
+    whatever sources were set last, nine feeds = two copy nodes told apart by their first destination, None = the
+    nodes copy nothing, and a feed list over other destinations is refused by feeds_match."""
+    from arx import ops
+    import torch
+    n_feeds = 9
+    dst = [torch.zeros(100 + 7 * k, dtype=torch.int32, device=dev) for k in range(n_feeds)]
+    out = torch.zeros(1, dtype=torch.float32, device=dev)
+    mk = lambda base: [torch.full((100 + 7 * k,), base + k, dtype=torch.int32, device=dev) for k in range(n_feeds)]
+    src0 = mk(10)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    g = ops.CapturedGraph()
+    feeds0 = list(zip(src0, dst))
+    with torch.cuda.stream(side):
+        g.begin()
+        ops.copy_words(feeds0)
+        ops.sum_scaled(dst[8].view(torch.float32), 1.0, out)       # a consumer behind the feed nodes
+        g.end(feeds=feeds0)
+    torch.cuda.current_stream().wait_stream(side)
+    g.launch()
+    torch.cuda.synchronize()
+    assert all(int(d[0]) == 10 + k and int(d[-1]) == 10 + k for k, d in enumerate(dst))
+    src1 = mk(50)
+    feeds1 = list(zip(src1, dst))
+    assert g.feeds_match(feeds1) and not g.feeds_match(feeds1[:8]) and not g.feeds_match(list(zip(src1, src0)))
+    g.set_feeds(feeds1)
+    g.launch()
+    torch.cuda.synchronize()
+    assert all(bool((d == 50 + k).all()) for k, d in enumerate(dst))
+    for d in dst:
+        d.zero_()
+    g.set_feeds(None)                     # nothing fed: the nodes must not re-copy the last sources
+    g.launch()
+    g.launch()
+    torch.cuda.synchronize()
+    assert all(not bool(d.any()) for d in dst)
+    g.set_feeds(feeds0)
+    g.launch()
+    torch.cuda.synchronize()
+    assert all(bool((d == 10 + k).all()) for k, d in enumerate(dst))
