@@ -935,6 +935,29 @@ __global__ __launch_bounds__(512) void k_sc_bits(int64_t M, int N, int64_t kslic
   }
 }
 
+// db_steps[t][s] = sum of the bps block partials of time step t (fixed order): a role of k_sc_tn_reduce's launch (blocks
+// of 256 outputs; a launch of its own, 5 us on the sequence model's serial chain, before)
+__device__ __forceinline__ void sc_db_steps_block(const float* __restrict__ dbp, int64_t bps, int64_t S, int64_t L,
+                                                  float* __restrict__ db_steps, int64_t blk) {
+  const int64_t q = blk * 256 + threadIdx.x;
+  if (q >= L * S) return;
+  const int64_t t = q / S, s = q % S;
+  // (eight loads in flight, added in block order: one load per iteration was a chain of L2 round trips -- 12 us for
+  // 6.5 MB at the C4 shape)
+  const float* p = dbp + t * bps * S + s;
+  float acc = 0.f;
+  int64_t b = 0;
+  for (; b + 8 <= bps; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(b + u) * S];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; b < bps; ++b) acc += p[b * S];
+  db_steps[q] = acc;
+}
+
 // dI[m, :] = beta dI[m, :] + sum_slices part[sl][m, :]   (fixed order); the LAST blocks of the grid (dbblocks of them, 64
 // columns each): db[m] = sum_blocks dbp[blk][m] -- four waves take a quarter of the partial rows each (coalesced
 // 256-byte rows, independent loads), combined in wave order
@@ -943,8 +966,14 @@ __global__ __launch_bounds__(256) void k_sc_tn_reduce(const float* __restrict__ 
                                                       const float* __restrict__ dbp, int64_t nblk,
                                                       float* __restrict__ db, int dbblocks,
                                                       const float* __restrict__ lrow, const float* __restrict__ lw,
-                                                      int64_t lrows, float lscale, float* __restrict__ loss_out) {
-  const int nmain = (int)gridDim.x - dbblocks - (loss_out ? 1 : 0);
+                                                      int64_t lrows, float lscale, float* __restrict__ loss_out,
+                                                      int stepblocks, int64_t bps, int64_t Lsteps,
+                                                      float* __restrict__ db_steps) {
+  const int nmain = (int)gridDim.x - dbblocks - stepblocks - (loss_out ? 1 : 0);
+  if (stepblocks && (int)blockIdx.x >= nmain + dbblocks && (int)blockIdx.x < nmain + dbblocks + stepblocks) {
+    sc_db_steps_block(dbp, bps, M, Lsteps, db_steps, (int)blockIdx.x - nmain - dbblocks);
+    return;
+  }
   if (loss_out && blockIdx.x == gridDim.x - 1) {
     // the step's scalar loss, gscale * sum_r row_w[r] * loss[r] over the row kernel's batch_loss, in a fixed order
     // (thread t takes float4s t, t + 256, ..., eight pairs of loads in flight; the 256 sub-sums meet in a fixed
@@ -1049,28 +1078,6 @@ __global__ __launch_bounds__(256) void k_sc_tn_reduce(const float* __restrict__ 
     }
     *cp = acc;
   }
-}
-
-// db_steps[t][s] = sum of the bps block partials of time step t (fixed order)
-__global__ __launch_bounds__(256) void k_sc_db_steps(const float* __restrict__ dbp, int64_t bps, int64_t S, int64_t L,
-                                                     float* __restrict__ db_steps) {
-  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (q >= L * S) return;
-  const int64_t t = q / S, s = q % S;
-  // (eight loads in flight, added in block order: one load per iteration was a chain of L2 round trips -- 12 us for
-  // 6.5 MB at the C4 shape)
-  const float* p = dbp + t * bps * S + s;
-  float acc = 0.f;
-  int64_t b = 0;
-  for (; b + 8 <= bps; b += 8) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[(b + u) * S];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc += v[u];
-  }
-  for (; b < bps; ++b) acc += p[b * S];
-  db_steps[q] = acc;
 }
 
 size_t al256(size_t v) { return (v + 255) / 256 * 256; }
@@ -1332,14 +1339,13 @@ int arx_mw_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, in
   ARX_CHECK_LAUNCH();
   const float* dbp = reinterpret_cast<const float*>(st + L.dbp);
   const int dbblocks = db ? (int)ceil_div(S, 64) : 0;
-  k_sc_tn_reduce<<<(int)ceil_div(S * (d / 4), 64) + dbblocks + (loss_out ? 1 : 0), 256, 0, s>>>(
-      part, (int)nsl, S, d, beta, dI, lddi, dbp, L.nblk, db, dbblocks, batch_loss, row_w, B, gscale, loss_out);
+  const bool steps = db_steps && step_rows > 0;
+  const int64_t Lsteps = steps ? B / step_rows : 0, bps = steps ? step_rows / 32 : 0;
+  const int stepblocks = steps ? (int)ceil_div(Lsteps * S, 256) : 0;
+  k_sc_tn_reduce<<<(int)ceil_div(S * (d / 4), 64) + dbblocks + stepblocks + (loss_out ? 1 : 0), 256, 0, s>>>(
+      part, (int)nsl, S, d, beta, dI, lddi, dbp, L.nblk, db, dbblocks, batch_loss, row_w, B, gscale, loss_out,
+      stepblocks, bps, Lsteps, db_steps);
   ARX_CHECK_LAUNCH();
-  if (db_steps && step_rows > 0) {
-    const int64_t Lsteps = B / step_rows, bps = step_rows / 32;
-    k_sc_db_steps<<<(int)ceil_div(Lsteps * S, 256), 256, 0, s>>>(dbp, bps, S, Lsteps, db_steps);
-    ARX_CHECK_LAUNCH();
-  }
   return ARX_OK;
 }
 
