@@ -475,22 +475,38 @@ class ShardedHMF(object):
         return self._stream
 
     # ------------------------------------------------------- step, hipGraph segments
-    def _segment(self, mode, name, fn):
+    def _segment(self, mode, name, fn, feeds=None):
         """eager: run; capture: record the launches of `fn` into a hipGraph, keep it, launch it;
-        replay: launch the kept graph."""
+        replay: launch the kept graph.  feeds ([(src, dst)], the step's first segment): the copy of the batch's
+        index vector is the graph's first node, its source replaced before every replay
+        (ops.CapturedGraph.set_feeds) -- it was an eager launch in front of the graph."""
+        ops_ = self.be.ops
         if mode == 'eager':
+            if feeds:
+                ops_.copy_words(feeds)
             fn()
         elif mode == 'capture':
-            g = self.be.ops.CapturedGraph()
+            g = ops_.CapturedGraph()
             g.begin()
             try:
+                if feeds:
+                    ops_.copy_words(feeds)
                 fn()
-            finally:
+            except BaseException:
                 g.end()
+                raise
+            g.end(feeds=feeds)
             self._graphs[name] = g
             g.launch()
         else:
-            self._graphs[name].launch()
+            g = self._graphs[name]
+            if feeds:
+                if g.feeds_match(feeds):
+                    g.set_feeds(feeds)
+                else:
+                    ops_.copy_words(feeds)
+                    g.set_feeds(None)
+            g.launch()
 
     def _step_static(self, route):
         """The step of step() with every buffer at a fixed address and a fixed size, so that the
@@ -519,7 +535,8 @@ class ShardedHMF(object):
             route['idx'] = idx
         if self.g_idx is None or self.g_idx.shape[0] != n_idx:
             self.g_idx = torch.empty(n_idx, dtype=torch.int32, device=dev)
-        be.ops.copy_words([(idx, self.g_idx)])         # (a kernel: a device-to-device hipMemcpyAsync costs more)
+        feed = [(idx, self.g_idx)]                     # (a kernel: a device-to-device hipMemcpyAsync costs more;
+        #                                                since round 4 the first node of the step's first graph)
         key = (cap, cap_r, self.g_idx.data_ptr(), self.arena.data_ptr(), self.pos_ptr.data_ptr(),
                self.pos_items.data_ptr())
         if os.environ.get("ARX_DIST_NO_CAPTURE"):        # (profiling: the static step, launched kernel by kernel)
@@ -631,9 +648,9 @@ class ShardedHMF(object):
             apply()
 
         if W == 1:
-            seg('step', whole_step)
+            self._segment(mode, 'step', whole_step, feeds=feed)
         else:
-            seg('fwd_gather', fwd_gather)
+            self._segment(mode, 'fwd_gather', fwd_gather, feeds=feed)
             sorted_ = k7_sorts(True)
             dist.all_gather_into_tensor(self.I_gath[:W * cap], self.I_pack[:cap], group=grp)
             w_rows = _all_to_all(self.T_pack, self.T_send[:R], send, recv, group=grp, async_op=True)
