@@ -520,7 +520,7 @@ int arx_capture_end(void* stream, void** graph_exec_out) {
 struct FeedNodes {
   hipGraph_t g;
   int n;
-  hipGraphNode_t node[16];
+  hipGraphNode_t* node;      // [n]
 };
 
 int arx_capture_end_feeds(void* stream, void** graph_exec_out, void** feeds_out, int* n_feed_nodes) {
@@ -530,17 +530,19 @@ int arx_capture_end_feeds(void* stream, void** graph_exec_out, void** feeds_out,
   FeedNodes* fn = new FeedNodes();
   fn->g = g;
   fn->n = 0;
+  fn->node = nullptr;
   size_t nn = 0;
   hipError_t err = hipGraphGetNodes(g, nullptr, &nn);
   if (err == hipSuccess && nn > 0) {
     hipGraphNode_t* all = new hipGraphNode_t[nn];
+    fn->node = new hipGraphNode_t[nn];
     err = hipGraphGetNodes(g, all, &nn);
     for (size_t i = 0; err == hipSuccess && i < nn; ++i) {
       hipGraphNodeType ty;
       if (hipGraphNodeGetType(all[i], &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
       hipKernelNodeParams kp;
       if (hipGraphKernelNodeGetParams(all[i], &kp) != hipSuccess) continue;
-      if (kp.func == reinterpret_cast<void*>(k_copy_words) && fn->n < 16) fn->node[fn->n++] = all[i];
+      if (kp.func == reinterpret_cast<void*>(k_copy_words)) fn->node[fn->n++] = all[i];
     }
     delete[] all;
   }
@@ -548,6 +550,7 @@ int arx_capture_end_feeds(void* stream, void** graph_exec_out, void** feeds_out,
   if (err == hipSuccess) err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
   if (err != hipSuccess) {
     (void)hipGraphDestroy(g);
+    delete[] fn->node;
     delete fn;
     set_error("arx_capture_end_feeds: %s", hipGetErrorString(err));
     return ARX_EHIP;
@@ -601,6 +604,7 @@ int arx_graph_feeds_destroy(void* feeds) {
   FeedNodes* fn = reinterpret_cast<FeedNodes*>(feeds);
   if (fn) {
     (void)hipGraphDestroy(fn->g);
+    delete[] fn->node;
     delete fn;
   }
   return ARX_OK;

@@ -818,7 +818,7 @@ int arx_graph_destroy(void* graph_exec);
 /* Placeholder feeds as nodes of the captured step: arx_copy_words launches issued INSIDE the capture become
  * graph nodes whose (source, destination, length) triples are replaced before a replay -- one submission per
  * step instead of an eager copy + the graph.  arx_capture_end_feeds: as arx_capture_end, and `feeds` = a handle
- * on the n_feed_nodes copy nodes found (<= 16; the captured graph stays alive with it); arx_graph_feed_dst0:
+ * on the n_feed_nodes copy nodes found (the captured graph stays alive with it); arx_graph_feed_dst0:
  * the first destination a node was captured with (to tell the nodes apart); arx_graph_set_feed: what node idx
  * copies at the following launches (count 0: nothing). */
 int arx_capture_end_feeds(void* stream, void** graph_exec_out, void** feeds_out, int* n_feed_nodes);
