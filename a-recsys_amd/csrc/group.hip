@@ -164,12 +164,14 @@ __global__ __launch_bounds__(kExtThreads) void k_runs_extract(const uint32_t* __
       int w = i1 >> 5;
       uint32_t word = bm[w] & (0xffffffffu << (i1 & 31));
       int c = 0;
-      for (int step = 0; step < 5 && c == 0; ++step) {
+      // (the whole bitmap, not its next 128 positions: a run that ends inside the tile costs LDS reads, the search
+      // below is two to four dependent rounds of global probes per long run)
+      for (int step = 0; step < kExtTile / 32 + 2 && c == 0; ++step) {
         if (word) c = (w << 5) + __builtin_ctz(word) - i;
         else if (++w > kExtTile / 32 + 1) break;
         else word = bm[w];
       }
-      if (c == 0) {                                      // > 128 positions, or it leaves the bitmap: 16-ary search
+      if (c == 0) {                                      // it leaves the bitmap: 16-ary search in the sorted keys
         const uint32_t key = k[u + 1];
         int64_t lo = p0 + u + 1, hi = n;                   // sk[lo - 1] == key; answer in [lo, hi]
         while (lo < hi) {
