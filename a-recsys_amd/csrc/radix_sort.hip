@@ -145,17 +145,32 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__
 }
 
 // Exclusive scan over the rows (waves, in sort order) of each histogram column, in place;
-// column totals to tot[].  One workgroup per 4 columns (int4), thread r <-> row r.
-__global__ __launch_bounds__(1024) void k_rs_scan(int32_t* __restrict__ hist, int nrows, int bins,
-                                                  int32_t* __restrict__ tot) {
-  __shared__ int4 wsum[16];
-  const int r = threadIdx.x;
-  const int lane = r & 63;
-  const int w = r >> 6;
-  int4* cell = reinterpret_cast<int4*>(hist + (int64_t)r * bins) + blockIdx.x;
-  int4 v = make_int4(0, 0, 0, 0);
-  if (r < nrows) v = *cell;
-  int4 incl = v;
+// column totals to tot[].  One workgroup per 4 columns (int4) of AT MOST 256 threads: thread t owns the kRows =
+// ceil(rows / threads) consecutive rows [t * kRows, ...) -- all its loads in flight together, a serial prefix over
+// them, one workgroup scan over the thread totals.  (One thread per row made the token list's scan, ~590 rows, a
+// 640-thread workgroup that waits for ten free wave slots on ONE CU beside the step's GEMMs: 7.6 us alone, 15-17 us
+// in the step, on the chain that ends it.)
+constexpr int kScanThreads = 256;
+constexpr int kScanRowsMax = (kRsMaxBlocks * (kRsThreads / 64) + kScanThreads - 1) / kScanThreads;   // 4
+__global__ __launch_bounds__(kScanThreads) void k_rs_scan(int32_t* __restrict__ hist, int nrows, int bins,
+                                                         int32_t* __restrict__ tot) {
+  __shared__ int4 wsum[kScanThreads / 64];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int w = t >> 6;
+  const int per = (nrows + (int)blockDim.x - 1) / (int)blockDim.x;        // <= kScanRowsMax
+  const int r0 = t * per;
+  int4 v[kScanRowsMax];
+#pragma unroll
+  for (int q = 0; q < kScanRowsMax; ++q) {
+    const int r = r0 + q;
+    v[q] = (q < per && r < nrows) ? *(reinterpret_cast<const int4*>(hist + (int64_t)r * bins) + blockIdx.x)
+                                  : make_int4(0, 0, 0, 0);
+  }
+  int4 sum = make_int4(0, 0, 0, 0);
+#pragma unroll
+  for (int q = 0; q < kScanRowsMax; ++q) { sum.x += v[q].x; sum.y += v[q].y; sum.z += v[q].z; sum.w += v[q].w; }
+  int4 incl = sum;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int tx = __shfl_up(incl.x, o, 64), ty = __shfl_up(incl.y, o, 64);
@@ -168,12 +183,17 @@ __global__ __launch_bounds__(1024) void k_rs_scan(int32_t* __restrict__ hist, in
   for (int ww = 0; ww < w; ++ww) {
     off.x += wsum[ww].x; off.y += wsum[ww].y; off.z += wsum[ww].z; off.w += wsum[ww].w;
   }
-  if (r < nrows)
-    *cell = make_int4(off.x + incl.x - v.x, off.y + incl.y - v.y, off.z + incl.z - v.z,
-                      off.w + incl.w - v.w);
-  if (r == nrows - 1)
-    reinterpret_cast<int4*>(tot)[blockIdx.x] =
-        make_int4(off.x + incl.x, off.y + incl.y, off.z + incl.z, off.w + incl.w);
+  int4 run = make_int4(off.x + incl.x - sum.x, off.y + incl.y - sum.y, off.z + incl.z - sum.z,
+                       off.w + incl.w - sum.w);                            // rows in front of this thread's
+#pragma unroll
+  for (int q = 0; q < kScanRowsMax; ++q) {
+    const int r = r0 + q;
+    if (q < per && r < nrows) {
+      *(reinterpret_cast<int4*>(hist + (int64_t)r * bins) + blockIdx.x) = run;
+      run.x += v[q].x; run.y += v[q].y; run.z += v[q].z; run.w += v[q].w;
+      if (r == nrows - 1) reinterpret_cast<int4*>(tot)[blockIdx.x] = run;
+    }
+  }
 }
 
 template <int RAW>
@@ -348,10 +368,11 @@ int launch_radix_sort(const int32_t* keys_raw, const int32_t* src_raw, const flo
                                                  p.ipb, hist, nullptr, nullptr, NoSites{});
     ARX_CHECK_LAUNCH();
     {
-      // thread r <-> row r: as many waves as there are rows (a 16-wave workgroup waits for a whole CU's worth of
-      // slots next to the step's GEMMs: measured 44 us for a 132-row scan)
+      // (at most 256 threads per workgroup: a 16-wave workgroup waits for a whole CU's worth of slots next to the
+      // step's GEMMs -- measured 44 us for a 132-row scan)
       const int rows = p.nblk * kRsWaves;
-      k_rs_scan<<<bins / 4, (rows + 63) / 64 * 64, 0, s>>>(hist, rows, bins, tot);
+      const int thr = rows < kScanThreads ? (rows + 63) / 64 * 64 : kScanThreads;
+      k_rs_scan<<<bins / 4, thr, 0, s>>>(hist, rows, bins, tot);
     }
     ARX_CHECK_LAUNCH();
     if (i == 0 && sites)
