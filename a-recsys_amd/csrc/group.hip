@@ -171,33 +171,34 @@ __global__ __launch_bounds__(kExtThreads) void k_runs_extract(const uint32_t* __
         else if (++w > kExtTile / 32 + 1) break;
         else word = bm[w];
       }
-      if (c == 0) {                                      // it leaves the bitmap: 16-ary search in the sorted keys
+      if (c == 0) {                                      // it leaves the bitmap: 9-ary search in the sorted keys
         const uint32_t key = k[u + 1];
         int64_t lo = p0 + u + 1, hi = n;                   // sk[lo - 1] == key; answer in [lo, hi]
         while (lo < hi) {
           const int64_t span = hi - lo;
-          bool same[16];
-          int64_t pos[16];
+          constexpr int NP = 8;                            // probes in flight (rare path since the whole-tile bitmap
+          bool same[NP];                                   // search: 16 of them were 40 of the kernel's 125 VGPRs)
+          int64_t pos[NP];
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            // 16 probes in flight: the whole rest when it is that short, else 1/17-th steps
-            pos[q] = span <= 16 ? lo + q : lo + (span * (q + 1)) / 17;
+          for (int q = 0; q < NP; ++q) {
+            // the whole rest when it is that short, else 1/(NP+1)-th steps
+            pos[q] = span <= NP ? lo + q : lo + (span * (q + 1)) / (NP + 1);
           }
-          uint32_t pv[16];
+          uint32_t pv[NP];
 #pragma unroll
-          for (int q = 0; q < 16; ++q) pv[q] = sk[min(pos[q], hi - 1)];   // (unconditional: all 16 loads fly together)
+          for (int q = 0; q < NP; ++q) pv[q] = sk[min(pos[q], hi - 1)];   // (unconditional: all loads fly together)
 #pragma unroll
-          for (int q = 0; q < 16; ++q) same[q] = pos[q] < hi && pv[q] == key;
+          for (int q = 0; q < NP; ++q) same[q] = pos[q] < hi && pv[q] == key;
           int64_t nlo = lo, nhi = hi;
           bool closed = false;
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
+          for (int q = 0; q < NP; ++q) {
             if (closed || pos[q] >= hi) continue;
             if (same[q]) nlo = pos[q] + 1;
             else { nhi = pos[q]; closed = true; }
           }
           lo = nlo;
-          hi = (span <= 16 && !closed) ? nlo : nhi;      // (all of a short rest equal: the run ends at hi)
+          hi = (span <= NP && !closed) ? nlo : nhi;      // (all of a short rest equal: the run ends at hi)
         }
         c = (int)(lo - (p0 + u));
       }
