@@ -73,6 +73,7 @@ __global__ __launch_bounds__(kExtThreads) void k_runs_extract(const uint32_t* __
                                                               const float* __restrict__ scoef, int64_t n_host,
                                                               const int32_t* __restrict__ n_dev, uint32_t sentinel,
                                                               RunLists rl, int kshort, HeadLens hl) {
+  __builtin_amdgcn_s_setprio(3);      // (sort-branch kernel: see radix_sort.hip, "wave priority")
   __shared__ uint32_t bm[kExtTile / 32 + 2];             // head (or dead) flags of the tile + 64 positions
   __shared__ int wtot[2][kExtThreads / 64];
   __shared__ int s_cnt[4], s_base[5];

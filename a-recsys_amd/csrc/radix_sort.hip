@@ -20,6 +20,12 @@
 // The first pass reads the caller's raw int32 keys (out-of-range ones become the
 // sentinel) and raw src/coef; the payload travels with the key (coalesced 12 B per item
 // per pass instead of two random 4-byte gathers -- 64 B sectors each -- at the end).
+//
+// Wave priority: the kernels of the step's sort branch (this file, k_runs_extract) raise their waves' issue
+// priority (s_setprio 3).  They are short, latency-bound launches next to the scorer's long MFMA kernels; with
+// priority they get through and free their slots sooner (same box, three alternating runs: C3 227.4 -> 226.0,
+// C2 163.8 -> 162.4, C3-MIX 247.7 -> 245.7 us).  The opposite -- priority for the scorer's kernels -- measured
+// slower (C3 228.2 -> 229.9).
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -93,6 +99,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const void* __restrict__
   // is sized for the host-side capacity: the live entries are dealt over ALL its blocks)
   // (first pass: n_in_dev, if given, is the number of input entries -- a compacted list whose length
   // is only known on the device)
+  __builtin_amdgcn_s_setprio(3);      // (sort-branch kernel: see radix_sort.hip, "wave priority")
   const int32_t* cnt = RAW ? n_in_dev : n_dev;
   const int64_t n = cnt ? min((int64_t)*cnt, n_host) : n_host;
   const int64_t ipb = cnt ? rs_ipb_dev(n, gridDim.x) : ipb_host;
@@ -154,6 +161,7 @@ constexpr int kScanThreads = 256;
 constexpr int kScanRowsMax = (kRsMaxBlocks * (kRsThreads / 64) + kScanThreads - 1) / kScanThreads;   // 4
 __global__ __launch_bounds__(kScanThreads) void k_rs_scan(int32_t* __restrict__ hist, int nrows, int bins,
                                                          int32_t* __restrict__ tot) {
+  __builtin_amdgcn_s_setprio(3);      // (sort-branch kernel: see radix_sort.hip, "wave priority")
   __shared__ int4 wsum[kScanThreads / 64];
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -203,6 +211,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(
     uint32_t sentinel, int shift, int bits, int64_t ipb_host, const int32_t* __restrict__ hist,
     const int32_t* __restrict__ tot, uint32_t* __restrict__ keys_out, int32_t* __restrict__ src_out,
     float* __restrict__ coef_out, const int32_t* __restrict__ n_in_dev, typename SitesArg<RAW>::type st) {
+  __builtin_amdgcn_s_setprio(3);      // (sort-branch kernel: see radix_sort.hip, "wave priority")
   const int32_t* cnt = RAW ? n_in_dev : n_live;
   const int64_t n = cnt ? min((int64_t)*cnt, n_host) : n_host;
   const int64_t ipb = cnt ? rs_ipb_dev(n, gridDim.x) : ipb_host;
