@@ -1138,6 +1138,7 @@ __global__ __launch_bounds__(256) void k_bag_expand_compact(
     int ent_kb, uint32_t ent_tag, const int32_t* __restrict__ vals, const int32_t* __restrict__ starts,
     const int32_t* __restrict__ lens, int max_len, int64_t table_rows, const int32_t* __restrict__ hoff,
     int32_t* __restrict__ tkeys, int32_t* __restrict__ tsrc) {
+  __builtin_amdgcn_s_setprio(3);      // (sort-branch kernel: radix_sort.hip, "wave priority")
   const int64_t n = n_dev ? min((int64_t)*n_dev, n_host) : n_host;
   const int64_t total = n * (int64_t)max_len;
   for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total;
