@@ -473,3 +473,34 @@ def test_hmf_prepare_next_ring_mode_bit_identical(dev, monkeypatch, cfg):
     plan = m_ring._plan('train')
     assert len(plan._ring_graphs) == 2                    # both parities were captured and replayed
     _compare_state(m_plain, ref)
+
+
+@pytest.mark.parametrize("cfg", [CFG_ID, CFG_HET])
+def test_hmf_feeds_as_graph_nodes_bit_identical(dev, cfg):
+    """The step's placeholder feeds as nodes of the captured graph (Runtime.feeds_in_graph, the default: sources
+    swapped with hipGraphExecKernelNodeSetParams) against the eager copy in front of every graph launch: the same
+    batches -- device tensors, a new one every step, a pool redraw in between -- leave bit-identical losses and
+    tables, and the graph of the default model carries feed nodes."""
+    import torch
+    B, S, d = 512, 128, 64
+    steps = 8
+    rng = np.random.default_rng(5)
+    syn0, m_nodes, _ = _build(cfg, 'mw', d, B, S, seed=11)
+    _, m_eager, _ = _build(cfg, 'mw', d, B, S, seed=11)
+    m_eager.rt.feeds_in_graph = False
+    dev_ = m_nodes.rt.device
+    batches = [syn0.sample_batch(B, rng) for _ in range(steps)]
+    pools = {0: syn0.sample_pool(S, rng), 5: syn0.sample_pool(S, rng)}
+    tb = [(torch.from_numpy(u.astype(np.int32)).to(dev_), torch.from_numpy(i.astype(np.int32)).to(dev_))
+          for u, i in batches]
+    tp = {k: torch.from_numpy(v.astype(np.int32)).to(dev_) for k, v in pools.items()}
+    for k in range(steps):
+        l_a = m_nodes.step(None, tb[k][0], tb[k][1], None, tp.get(k), None, loss='mw')
+        l_b = m_eager.step(None, tb[k][0], tb[k][1], None, tp.get(k), None, loss='mw')
+        assert l_a == l_b, (k, l_a, l_b)
+    pa, pb = m_nodes.att_emb.get_params(), m_eager.att_emb.get_params()
+    for name in pa:
+        assert np.array_equal(pa[name], pb[name]), name
+    g = m_nodes._plan('train').graph
+    assert g is not None and g.feed_groups, "the captured step carries no feed nodes"
+    assert m_eager._plan('train').graph.feed_groups is None
