@@ -339,9 +339,13 @@ class ShardedHMF(object):
         # block layout (redraw path, every n_resample steps): two launches of arx_pool_blocks around ONE host
         # read of the W owner counts (the block capacity is a host decision: it sizes the exchanges)
         if getattr(self, '_pool_counts', None) is None:
-            self._pool_counts = torch.zeros(W, dtype=torch.int32, device=self.device)
+            self._pool_counts = torch.zeros(W + 1, dtype=torch.int32, device=self.device)   # [W] = negative ids
         be.pool_blocks(self.pool_ids, W, r, self.zero_row, 0, self._pool_counts)
-        cap = (int(self._pool_counts.max().item()) + 3) // 4 * 4
+        cnts = self._pool_counts.cpu().tolist()
+        if cnts[W] != 0:
+            raise ValueError("set_pool: %d negative item id(s) in the pool (a short draw of the device sampler "
+                             "leaves -1: redraw or pass valid ids)" % cnts[W])
+        cap = (max(cnts[:W]) + 3) // 4 * 4
         if self.use_graphs:      # block capacity only grows (a new capacity = new graphs), with slack
             cap = self.cap if cap <= self.cap else min(S, (cap + cap // 8 + 15) // 16 * 16)
         self.cap = cap

@@ -166,8 +166,10 @@ class DeviceSampler(object):
         cap = self._cap_for(int(n))
         self._ops.sample_wor(self.w, n, self.seed, self.counter, pos, self.ws, key_cap=cap)
         self.counter += 1
-        # positions the capped race could not fill come back as -1: map them to id -1 (update_sampled_pool and
-        # draw_global_pool reject negative ids) instead of letting -1 index items[-1] (advisor, round 3)
+        # positions the capped race could not fill come back as -1: they become id -1 instead of letting -1 index
+        # items[-1] (advisor, round 3).  A negative id is an EMPTY slot downstream (advisor, round 4): the step's
+        # lookup launch writes a zero row for it, the slot map skips it and K7's key builders drop it -- no read of
+        # cat_map[-1] / E[-1]; the sharded pool (dist.set_pool, draw_global_pool) rejects it with a ValueError.
         if out is None:
             out = torch.empty((n,), dtype=torch.int32, device=self.w.device)
         self._ops.take_i32(self.items, pos, out, fill=-1)         # (one launch; the torch form was six)

@@ -313,34 +313,70 @@ __global__ void k_site_onehot(const int32_t* __restrict__ cat_map, const int32_t
 
 // row-sharded table routing (mod-N striping): owner = id % world, local row = id / world
 // Block layout of a pool whose items are striped over `world` owners (owner = id % world): the owner's
-// items, in slot order, are rows [0, count_g) of its block.  One workgroup: S <= 4096 slots in LDS; a slot's
-// position in its block = the number of earlier slots of the same owner (O(S^2 / 1024) LDS reads).
+// items, in slot order, are rows [0, count_g) of its block.  One workgroup, any S, world <= 256: the slots go
+// by in rounds of 1024; in a round every wave ranks its slots among the same-owner slots of the wave (one ballot
+// per owner bit, as the radix scatter does), the waves' counts meet in LDS and a per-owner running total carries
+// over the rounds.  (Round 4's form kept all owners in LDS and counted earlier slots one by one: S <= 4096,
+// world <= 64, O(S^2 / 1024).)  A negative id has no owner: it is counted in counts[world] (the caller rejects the
+// pool), gets gidx = -1 and takes no row of any block.
 __global__ __launch_bounds__(1024) void k_pool_blocks(const int32_t* __restrict__ ids, int S, int world, int rank,
                                                       int32_t zero_row, int cap, int32_t* __restrict__ counts,
                                                       int32_t* __restrict__ gidx, int32_t* __restrict__ my_slots,
                                                       int32_t* __restrict__ pool_rows) {
-  __shared__ int16_t own[4096];
-  __shared__ int cnt[64];
-  for (int i = threadIdx.x; i < 64; i += blockDim.x) cnt[i] = 0;
-  for (int i = threadIdx.x; i < S; i += blockDim.x) own[i] = (int16_t)(ids[i] % world);
-  __syncthreads();
-  for (int i = threadIdx.x; i < S; i += blockDim.x) {
-    const int o = own[i];
-    int pos = 0;
-    for (int j = 0; j < i; ++j) pos += own[j] == o;
-    atomicAdd(&cnt[o], 1);
-    if (cap > 0) {
-      gidx[i] = o * cap + pos;
-      if (o == rank) {
-        my_slots[pos] = i;
-        pool_rows[pos] = ids[i] / world;
+  __shared__ int wc[16][256];          // a round's per-wave counts, then the waves' starting positions
+  __shared__ int tot[256];             // slots of each owner in the rounds before
+  __shared__ int bad;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid < 256) tot[tid] = 0;
+  if (tid == 0) bad = 0;
+  int obits = 1;
+  while ((1 << obits) < world) ++obits;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int r0 = 0; r0 < S; r0 += 1024) {
+    for (int q = tid; q < 16 * 256; q += 1024) (&wc[0][0])[q] = 0;
+    __syncthreads();
+    const int i = r0 + tid;
+    const int id = i < S ? ids[i] : -1;
+    const bool live = i < S && id >= 0;
+    if (i < S && id < 0) atomicAdd(&bad, 1);
+    const int o = live ? id % world : 0;
+    unsigned long long peers = __ballot(live);
+    for (int bit = 0; bit < obits; ++bit) {
+      const bool one = (o >> bit) & 1;
+      const unsigned long long bb = __ballot(one);
+      peers &= one ? bb : ~bb;
+    }
+    const int rank_in = __popcll(peers & lt);
+    if (live && rank_in == 0) wc[w][o] = __popcll(peers);
+    __syncthreads();
+    if (tid < world) {                 // the waves' starting positions for owner tid, the running total
+      int run = tot[tid];
+      for (int q = 0; q < 16; ++q) {
+        const int c = wc[q][tid];
+        wc[q][tid] = run;
+        run += c;
+      }
+      tot[tid] = run;
+    }
+    __syncthreads();
+    if (i < S && cap > 0) {
+      if (live) {
+        const int pos = wc[w][o] + rank_in;
+        gidx[i] = o * cap + pos;
+        if (o == rank) {
+          my_slots[pos] = i;
+          pool_rows[pos] = id / world;
+        }
+      } else {
+        gidx[i] = -1;
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int g = threadIdx.x; g < world; g += blockDim.x) counts[g] = cnt[g];
+  for (int g = tid; g < world; g += 1024) counts[g] = tot[g];
+  if (tid == 0) counts[world] = bad;
   if (cap > 0)
-    for (int i = cnt[rank] + threadIdx.x; i < S; i += blockDim.x) {     // the tail of this rank's lists: padding
+    for (int i = tot[rank] + tid; i < S; i += 1024) {     // the tail of this rank's lists: padding
       my_slots[i] = S;
       pool_rows[i] = zero_row;
     }
@@ -449,6 +485,14 @@ __global__ __launch_bounds__(256) void k_lookup_multi(LookupSites ls, int d) {
     const int64_t r = base + u * (4 * GPW);
     if (r >= n) continue;
     const int id = ids[r];
+    if (id < 0) {
+      // an EMPTY pool slot: DeviceSampler.sample() leaves id -1 where a (37-sigma rare) short capped draw could not
+      // fill a position.  It looks nothing up -- a zero row, zero bias -- and K7's key builders drop it (site_key),
+      // instead of reading cat_map[-1] / E[-1] (advisor, round 4).  Sub-group-uniform branch.
+      if (colok) *reinterpret_cast<float4*>(out + r * ldo + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias_out && lig == 0) bias_out[r] = 0.f;
+      continue;
+    }
     float4 one = make_float4(0.f, 0.f, 0.f, 0.f);
     float one_b = 0.f;
     if (E1) {
@@ -893,8 +937,8 @@ int arx_sparse_site_onehot(const int32_t* cat_map, const int32_t* ids, int64_t n
 
 int arx_pool_blocks(const int32_t* ids, int64_t S, int world, int rank, int32_t zero_row, int64_t cap,
                     int32_t* counts, int32_t* gidx, int32_t* my_slots, int32_t* pool_rows, void* stream) {
-  ARX_CHECK_ARG(ids && counts && world > 0 && world <= 64 && rank >= 0 && rank < world, "arx_pool_blocks: bad argument");
-  ARX_CHECK_ARG(S > 0 && S <= 4096, "arx_pool_blocks: 1 <= S <= 4096");
+  ARX_CHECK_ARG(ids && counts && world > 0 && world <= 256 && rank >= 0 && rank < world, "arx_pool_blocks: bad argument (world <= 256)");
+  ARX_CHECK_ARG(S > 0 && S < (1ll << 31), "arx_pool_blocks: 1 <= S < 2^31");
   ARX_CHECK_ARG(cap == 0 || (gidx && my_slots && pool_rows), "arx_pool_blocks: cap > 0 needs the three outputs");
   k_pool_blocks<<<1, 1024, 0, as_stream(stream)>>>(ids, (int)S, world, rank, zero_row, (int)cap, counts, gidx,
                                                     my_slots, pool_rows);

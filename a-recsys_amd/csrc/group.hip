@@ -76,13 +76,14 @@ __global__ __launch_bounds__(kExtThreads) void k_runs_extract(const uint32_t* __
   __builtin_amdgcn_s_setprio(3);      // (sort-branch kernel: see radix_sort.hip, "wave priority")
   __shared__ uint32_t bm[kExtTile / 32 + 2];             // head (or dead) flags of the tile + 64 positions
   __shared__ int wtot[2][kExtThreads / 64];
-  __shared__ int s_cnt[4], s_base[5];
+  __shared__ int s_cnt[4], s_base[5], s_cnt4;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t n = n_dev ? min((int64_t)*n_dev, n_host) : n_host;
   const int64_t t0 = (int64_t)blockIdx.x * kExtTile;
   const bool dead_tile = t0 >= n;
   if (dead_tile && !hl.lens) return;                     // (whole workgroup; with a look-back chain it still publishes)
   if (tid < 4) s_cnt[tid] = 0;
+  if (tid == 4) s_cnt4 = 0;
   const int64_t p0 = t0 + (int64_t)tid * kExtPer;
   uint32_t k[kExtPer + 1];
   k[0] = (p0 > 0 && p0 <= n) ? sk[p0 - 1] : 0xffffffffu;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(kExtThreads) void k_runs_extract(const uint32_t* __
   }
   uint32_t hm = 0, mk = 0;                               // heads; heads or dead positions
   int llen[kExtPer];
-  int lsum = 0;
+  int lsum = 0, nh0 = 0;                                 // bag lengths / number of the thread's ENTITY heads
 #pragma unroll
   for (int u = 0; u < kExtPer; ++u) {
     const bool live = p0 + u < n && k[u + 1] < sentinel;
@@ -127,8 +128,10 @@ __global__ __launch_bounds__(kExtThreads) void k_runs_extract(const uint32_t* __
     hm |= head ? (1u << u) : 0u;
     mk |= (head || !live) ? (1u << u) : 0u;
     llen[u] = 0;
-    if (hl.lens && head && (k[u + 1] >> hl.ent_kb) == hl.ent_tag)
+    if (hl.lens && head && (k[u + 1] >> hl.ent_kb) == hl.ent_tag) {
       llen[u] = min(hl.lens[k[u + 1] & ((1u << hl.ent_kb) - 1u)], hl.max_len);
+      ++nh0;
+    }
   }
 #pragma unroll
   for (int u = 0; u < kExtPer; ++u) lsum += llen[u];
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(kExtThreads) void k_runs_extract(const uint32_t* __
     }
   }
   int li = 0, it = 0, pb = 0;
+  if (nh0) atomicAdd(&s_cnt4, nh0);
   if (nlong) {
     li = atomicAdd(&s_cnt[1], nlong);
     it = atomicAdd(&s_cnt[2], nitem);
@@ -235,6 +239,8 @@ __global__ __launch_bounds__(kExtThreads) void k_runs_extract(const uint32_t* __
   if (tid < 4) {                                         // the four list counters: one atomic each, in flight together
     const int v = s_cnt[tid];
     s_base[tid] = (rec && v > 0) ? atomicAdd(&rl.ctr[tid == 0 ? kNRuns : tid == 1 ? kNLong : tid == 2 ? kNItems : kNPart], v) : 0;
+  } else if (tid == 4 && rec && s_cnt4 > 0) {            // runs of the ENTITY table (they sort first: records [0, that))
+    atomicAdd(&rl.ctr[kNRuns0], s_cnt4);
   }
   __syncthreads();
   if (hl.lens && wv == 0) {
@@ -243,21 +249,29 @@ __global__ __launch_bounds__(kExtThreads) void k_runs_extract(const uint32_t* __
     // started before every block < b has been) -- which the hardware dispatcher gives -- not full co-residency: the
     // lowest unfinished block never waits for anything that has not started.  The caller bounds the grid
     // (runs_extract_blocks(n) <= 224, optim.hip) and otherwise takes the one-workgroup k_head_len_scan.
+    // (the word also carries the workgroup's number of runs: with it the run RECORDS are written in sorted order
+    // -- the entity table's runs first -- instead of in the order the counter atomics were served)
     if (lane == 0)
-      __hip_atomic_store(&hl.lookback[blockIdx.x], (1ull << 63) | (unsigned long long)s_base[4], __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    int part = 0;
+      __hip_atomic_store(&hl.lookback[blockIdx.x],
+                         (1ull << 63) | ((unsigned long long)s_cnt[0] << 31) | (unsigned long long)s_base[4],
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int part = 0, rpart = 0;
     for (int q = lane; q < (int)blockIdx.x; q += 64) {
       unsigned long long v;
       while (!((v = __hip_atomic_load(&hl.lookback[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 63))
         __builtin_amdgcn_s_sleep(2);
       part += (int)(v & 0x7fffffffull);
+      rpart += (int)((v >> 31) & 0x7fffffffull);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    for (int o = 32; o > 0; o >>= 1) {
+      part += __shfl_xor(part, o, 64);
+      rpart += __shfl_xor(rpart, o, 64);
+    }
     if (lane == 0) {
       if (blockIdx.x == gridDim.x - 1) *hl.total = part + s_base[4];
       s_base[4] = part;
+      s_base[0] = rpart;
     }
   }
   __syncthreads();
@@ -348,14 +362,40 @@ __device__ __forceinline__ void finish_row(const TabRow& T, const MergeOut& mo, 
 #define ARX_RUN_RU 4
 #endif
 
-// blocks [0, gshort): one sub-group per short run, NB runs in flight per sub-group;
-// blocks [gshort, ...): one workgroup per work item of a long run.
+// One run-centric apply inside a launch: a table set, the run lists of its sorted pass, the gradient rows.
+// rec_lo / rec_hi: indices into sg.ctr of the record range [lo, hi) taken (-1: 0 / all) -- with the records in
+// sorted order (k_runs_extract on the look-back path) the entity table's runs are records [0, ctr[kNRuns0]);
+// tsel: which LONG runs (they live in their own unordered list): -1 all, t >= 0 those of table t, t <= -2 those of
+// every table but -2 - t.
+struct ApplyJob {
+  TableSet ts;
+  RunLists sg;
+  const float* G;
+  int64_t ldg;
+  const float* Gb;
+  MergeOut mo;
+  int gshort, glong;
+  int rec_lo, rec_hi, tsel;
+};
+
+__device__ __forceinline__ bool job_takes(const ApplyJob& jb, uint32_t key) {
+  if (jb.tsel == -1) return true;
+  const int t = (int)(key >> jb.ts.kb);
+  return jb.tsel >= 0 ? t == jb.tsel : t != -2 - jb.tsel;
+}
+
+// blocks [0, glong) of the job: one workgroup per work item of a long run;
+// blocks [glong, glong + gshort): one sub-group per short run, NB runs in flight per sub-group.
 template <int LPR, bool MT, bool SGD>
-__global__ __launch_bounds__(256) void k_run_apply(TableSet ts, int d, RunLists sg, const float* __restrict__ G,
-                                                   int64_t ldg, const float* __restrict__ Gb,
-                                                   const float* __restrict__ lr_dev,
-                                                   const float* __restrict__ gscale_dev, MergeOut mo, int gshort,
-                                                   int kshort) {
+__device__ __forceinline__ void run_apply_job(const ApplyJob& jb, int d, const int bid, const float lr, const float gs,
+                                              int kshort) {
+  const TableSet& ts = jb.ts;
+  const RunLists& sg = jb.sg;
+  const float* __restrict__ G = jb.G;
+  const int64_t ldg = jb.ldg;
+  const float* __restrict__ Gb = jb.Gb;
+  const MergeOut& mo = jb.mo;
+  const int gshort = jb.gshort;
   constexpr int NSG = 64 / LPR;        // sub-groups per wave
   constexpr int NSGB = 256 / LPR;      // sub-groups per workgroup
   constexpr int NB = ARX_RUN_NB;
@@ -367,22 +407,21 @@ __global__ __launch_bounds__(256) void k_run_apply(TableSet ts, int d, RunLists 
   const int g = lane / LPR;
   const int col = lig * 4;
   const bool colok = col < d;
-  const float lr = *lr_dev;
-  const float gs = gscale_dev ? *gscale_dev : 1.f;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // the long runs' work items take the FIRST blocks of the grid: they are the long poles
-  const int glong = (int)gridDim.x - gshort;
-  if ((int)blockIdx.x >= glong) {
+  const int glong = jb.glong;
+  if (bid >= glong) {
     constexpr int KS = LPR < 32 ? LPR : 32;          // entries of a short run
     // entries 1.. of the sub-group's runs, in summation order (private to the sub-group: wave-synchronous)
     __shared__ int s_src[4 * NSG][NB][KS];
     __shared__ float s_coef[4 * NSG][NB][KS];
     __shared__ float s_gb[4 * NSG][NB][KS];
     const int sgl = wv * NSG + g;
-    const int nruns = sg.ctr[kNRuns];
+    const int nruns = sg.ctr[jb.rec_hi >= 0 ? jb.rec_hi : (int)kNRuns];
+    const int rlo = jb.rec_lo >= 0 ? sg.ctr[jb.rec_lo] : 0;
     const int64_t nsg_tot = (int64_t)gshort * 4 * NSG;
-    const int64_t sgid = (((int64_t)blockIdx.x - glong) * 4 + wv) * NSG + g;
-    for (int64_t base = 0; base < nruns; base += nsg_tot * NB) {
+    const int64_t sgid = (((int64_t)bid - glong) * 4 + wv) * NSG + g;
+    for (int64_t base = rlo; base < nruns; base += nsg_tot * NB) {
       // round trip 1: the run records -- key, segment, length AND the first entry
       int4 r[NB];
       int2 r2[NB];
@@ -393,7 +432,7 @@ __global__ __launch_bounds__(256) void k_run_apply(TableSet ts, int d, RunLists 
         act[j] = u < nruns;
         r[j] = act[j] ? sg.R[u] : make_int4(0, 0, 0, 0);
         r2[j] = act[j] ? sg.R2[u] : make_int2(0, 0);
-        act[j] = act[j] && r[j].z > 0 && r[j].z <= kshort;
+        act[j] = act[j] && r[j].z > 0 && r[j].z <= kshort && job_takes(jb, (uint32_t)r[j].x);
         if (!act[j]) r[j].z = 0;                            // (long runs: the work items below)
       }
       // round trip 2: table row, slot row, bias cells, the first gradient row, the other entries
@@ -477,10 +516,11 @@ __global__ __launch_bounds__(256) void k_run_apply(TableSet ts, int d, RunLists 
   __shared__ int s_last;
   const int sgb = threadIdx.x / LPR;
   const int nitems = min(sg.ctr[kNItems], (int)sg.cap_items);
-  for (int it = (int)blockIdx.x; it < nitems; it += glong) {
+  for (int it = bid; it < nitems; it += glong) {
     const int2 item = sg.items[it];
     const int4 lr4 = sg.LR[item.x];
     const int4 r = sg.R[lr4.x];
+    if (!job_takes(jb, (uint32_t)r.x)) continue;        // (block-uniform)
     const int nch = lr4.z;
     const int64_t off = r.y;
     const int cnt = r.z;
@@ -596,6 +636,27 @@ __global__ __launch_bounds__(256) void k_run_apply(TableSet ts, int d, RunLists 
   }
 }
 
+template <int LPR, bool MT, bool SGD>
+__global__ __launch_bounds__(256) void k_run_apply(ApplyJob jb, int d, const float* __restrict__ lr_dev,
+                                                   const float* __restrict__ gscale_dev, int kshort) {
+  const float lr = *lr_dev;
+  const float gs = gscale_dev ? *gscale_dev : 1.f;
+  run_apply_job<LPR, MT, SGD>(jb, d, (int)blockIdx.x, lr, gs, kshort);
+}
+
+// Two jobs in one launch (the tail of a step with a riding bag table: the token runs over the merged rows + the
+// one-hot runs of the tables that do not feed them).  Job B's blocks first: its long runs are the long poles.
+template <int LPR, bool MTA, bool SGD>
+__global__ __launch_bounds__(256) void k_run_apply2(ApplyJob ja, ApplyJob jbb, int d,
+                                                    const float* __restrict__ lr_dev,
+                                                    const float* __restrict__ gscale_dev, int kshort) {
+  const float lr = *lr_dev;
+  const float gs = gscale_dev ? *gscale_dev : 1.f;
+  const int nb = jbb.glong + jbb.gshort;
+  if ((int)blockIdx.x < nb) run_apply_job<LPR, false, SGD>(jbb, d, (int)blockIdx.x, lr, gs, kshort);
+  else run_apply_job<LPR, MTA, SGD>(ja, d, (int)blockIdx.x - nb, lr, gs, kshort);
+}
+
 #define ARX_GRP_LPR(lpr, CALL)                        \
   switch (lpr) {                                      \
     case 8: { constexpr int LPR = 8; CALL; } break;   \
@@ -604,10 +665,8 @@ __global__ __launch_bounds__(256) void k_run_apply(TableSet ts, int d, RunLists 
     default: { constexpr int LPR = 64; CALL; } break; \
   }
 
-template <bool MT>
-int launch_run_apply_t(const TableSet& ts, int d, const RunLists& sg, int64_t n, const float* G, int64_t ldg,
-                       const float* Gb, const float* lr_dev, const float* gscale_dev, const MergeOut& mo, bool sgd,
-                       hipStream_t s) {
+static ApplyJob make_job(const TableSet& ts, int d, const RunLists& sg, int64_t n, const float* G, int64_t ldg,
+                         const float* Gb, const MergeOut& mo, const ApplySel& sel) {
   const int lpr = lanes_per_row(d);
   const int kshort = lpr < 32 ? lpr : 32;
   const int nsg = 64 / lpr;
@@ -618,12 +677,48 @@ int launch_run_apply_t(const TableSet& ts, int d, const RunLists& sg, int64_t n,
   int64_t glong = n / (kshort + 1) + 1;       // upper bound of the work items is larger; the loop strides
   const int64_t capl = (int64_t)cu_count() * 4;
   if (glong > capl) glong = capl;
+  ApplyJob jb;
+  jb.ts = ts;
+  jb.sg = sg;
+  jb.G = G;
+  jb.ldg = ldg;
+  jb.Gb = Gb;
+  jb.mo = mo;
+  jb.gshort = (int)gshort;
+  jb.glong = (int)glong;
+  jb.rec_lo = sel.rec_lo;
+  jb.rec_hi = sel.rec_hi;
+  jb.tsel = sel.tsel;
+  return jb;
+}
+
+template <bool MT>
+int launch_run_apply_t(const TableSet& ts, int d, const RunLists& sg, int64_t n, const float* G, int64_t ldg,
+                       const float* Gb, const float* lr_dev, const float* gscale_dev, const MergeOut& mo, bool sgd,
+                       hipStream_t s, const ApplySel& sel) {
+  const int lpr = lanes_per_row(d);
+  const int kshort = lpr < 32 ? lpr : 32;
+  const ApplyJob jb = make_job(ts, d, sg, n, G, ldg, Gb, mo, sel);
+  const int grid = jb.gshort + jb.glong;
   if (sgd) {
-    ARX_GRP_LPR(lpr, (k_run_apply<LPR, MT, true><<<(int)(gshort + glong), 256, 0, s>>>(
-                         ts, d, sg, G, ldg, Gb, lr_dev, gscale_dev, mo, (int)gshort, kshort)));
+    ARX_GRP_LPR(lpr, (k_run_apply<LPR, MT, true><<<grid, 256, 0, s>>>(jb, d, lr_dev, gscale_dev, kshort)));
   } else {
-    ARX_GRP_LPR(lpr, (k_run_apply<LPR, MT, false><<<(int)(gshort + glong), 256, 0, s>>>(
-                         ts, d, sg, G, ldg, Gb, lr_dev, gscale_dev, mo, (int)gshort, kshort)));
+    ARX_GRP_LPR(lpr, (k_run_apply<LPR, MT, false><<<grid, 256, 0, s>>>(jb, d, lr_dev, gscale_dev, kshort)));
+  }
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+template <bool MTA>
+int launch_run_apply_pair_t(const ApplyJob& ja, const ApplyJob& jb, int d, const float* lr_dev,
+                            const float* gscale_dev, bool sgd, hipStream_t s) {
+  const int lpr = lanes_per_row(d);
+  const int kshort = lpr < 32 ? lpr : 32;
+  const int grid = ja.gshort + ja.glong + jb.gshort + jb.glong;
+  if (sgd) {
+    ARX_GRP_LPR(lpr, (k_run_apply2<LPR, MTA, true><<<grid, 256, 0, s>>>(ja, jb, d, lr_dev, gscale_dev, kshort)));
+  } else {
+    ARX_GRP_LPR(lpr, (k_run_apply2<LPR, MTA, false><<<grid, 256, 0, s>>>(ja, jb, d, lr_dev, gscale_dev, kshort)));
   }
   ARX_CHECK_LAUNCH();
   return ARX_OK;
@@ -684,9 +779,21 @@ int runs_extract_blocks(int64_t n) { return (int)ceil_div(n, kExtTile); }
 
 int launch_run_apply(const TableSet& ts, bool multi, int d, const RunLists& rl, int64_t n, const float* G,
                      int64_t ldg, const float* Gb, const float* lr_dev, const float* gscale_dev, const MergeOut& mo,
-                     bool sgd, hipStream_t s) {
-  if (multi) return launch_run_apply_t<true>(ts, d, rl, n, G, ldg, Gb, lr_dev, gscale_dev, mo, sgd, s);
-  return launch_run_apply_t<false>(ts, d, rl, n, G, ldg, Gb, lr_dev, gscale_dev, mo, sgd, s);
+                     bool sgd, hipStream_t s, const ApplySel& sel) {
+  if (multi) return launch_run_apply_t<true>(ts, d, rl, n, G, ldg, Gb, lr_dev, gscale_dev, mo, sgd, s, sel);
+  return launch_run_apply_t<false>(ts, d, rl, n, G, ldg, Gb, lr_dev, gscale_dev, mo, sgd, s, sel);
+}
+
+int launch_run_apply_pair(const TableSet& tsa, bool multi_a, const RunLists& rla, int64_t na, const float* Ga,
+                          int64_t ldga, const float* Gba, const MergeOut& moa, const ApplySel& sela,
+                          const TableSet& tsb, const RunLists& rlb, int64_t nb, const float* Gbm, int64_t ldgb,
+                          const float* Gbb, int d, const float* lr_dev, const float* gscale_dev, bool sgd,
+                          hipStream_t s) {
+  const ApplyJob ja = make_job(tsa, d, rla, na, Ga, ldga, Gba, moa, sela);
+  const MergeOut none = {nullptr, nullptr, nullptr, -1, 0};
+  const ApplyJob jb = make_job(tsb, d, rlb, nb, Gbm, ldgb, Gbb, none, ApplySel{-1, -1, -1});
+  if (multi_a) return launch_run_apply_pair_t<true>(ja, jb, d, lr_dev, gscale_dev, sgd, s);
+  return launch_run_apply_pair_t<false>(ja, jb, d, lr_dev, gscale_dev, sgd, s);
 }
 
 }  // namespace arx

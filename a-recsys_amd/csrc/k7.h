@@ -125,7 +125,7 @@ __device__ __forceinline__ void merge_row(const MergeOut& mo, int d, uint32_t ke
 }
 
 // group.hip: run records of a radix-sorted pass + the run-centric apply (d >= 32).
-enum { kNRuns = 0, kNLong = 2, kNItems = 3, kNPart = 4 };      // counters of a pass (ints, zeroed by the sort)
+enum { kNRuns = 0, kNLong = 2, kNItems = 3, kNPart = 4, kNRuns0 = 5 };   // counters of a pass (ints, zeroed by the sort)
 struct RunLists {
   int4* R;              // run records {key, offset, count, head position}
   int2* R2;             // first entry of every run {src, coef bits}
@@ -150,8 +150,20 @@ int launch_runs_extract(const uint32_t* sk, int64_t n, const int32_t* n_dev, uin
                         int32_t* total = nullptr,
                         void* lookback = nullptr);
 int runs_extract_blocks(int64_t n);
+// which runs of the lists one apply takes: the record range [ctr[rec_lo], ctr[rec_hi]) (-1: from 0 / to the end;
+// meaningful when the records are in sorted order: k_runs_extract on its look-back path) and, for the long runs
+// (their own unordered list), the table: -1 all, t >= 0 table t, t <= -2 every table but -2 - t
+struct ApplySel {
+  int rec_lo, rec_hi, tsel;
+};
 int launch_run_apply(const TableSet& ts, bool multi, int d, const RunLists& rl, int64_t n, const float* G,
                      int64_t ldg, const float* Gb, const float* lr_dev, const float* gscale_dev, const MergeOut& mo,
-                     bool sgd, hipStream_t s);
+                     bool sgd, hipStream_t s, const ApplySel& sel = ApplySel{-1, -1, -1});
+// two applies in ONE launch: job A (table set a, selection sela, side output moa) and job B (single table b, all runs)
+int launch_run_apply_pair(const TableSet& tsa, bool multi_a, const RunLists& rla, int64_t na, const float* Ga,
+                          int64_t ldga, const float* Gba, const MergeOut& moa, const ApplySel& sela,
+                          const TableSet& tsb, const RunLists& rlb, int64_t nb, const float* Gbm, int64_t ldgb,
+                          const float* Gbb, int d, const float* lr_dev, const float* gscale_dev, bool sgd,
+                          hipStream_t s);
 
 }  // namespace arx

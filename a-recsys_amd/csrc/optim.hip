@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_site_keys(CatSites st, int32_t* __restr
       if (q < st.nsites && i >= st.offs[q]) s = q;
     const int64_t j = i - st.offs[s];
     const int id = st.ids[s][j];
-    const int key = st.cat_map[s] ? st.cat_map[s][id] : id;
+    const int key = id < 0 ? -1 : (st.cat_map[s] ? st.cat_map[s][id] : id);   // (id < 0: an empty pool slot)
     const int tb = st.table[s];
     const int64_t rows = tb == 0 ? st.rows[0] : tb == 1 ? st.rows[1] : tb == 2 ? st.rows[2] : st.rows[3];
     keys[i] = (key < 0 || key >= rows) ? ARX_KEY_NONE : ((tb << st.kb) | key);
@@ -1423,6 +1423,20 @@ int bag_token_apply(const BagWs& w, char* base, int64_t n_i, int max_len, float*
 
 namespace arx {
 
+static bool rider_hoff_ok(int64_t n, int64_t n0, int max_len, int d) {
+  return runs_path(d) && bag_compact(n0, max_len) && runs_extract_blocks(n) <= 224;
+}
+
+// Round 5, opt-in (ARX_K7_RIDER_SPLIT=1): the rider's one-hot pass on run records too (they have to be in sorted
+// order: the extraction sweep's look-back path) and the apply cut by data flow -- see the apply phases below.  The
+// default stays the window + finish launches of rounds 3-4: the records lengthen the one-hot list's extraction sweep
+// by ~7 us on the step's sort branch and the two run-centric launches (23 + 34 us in the step) are no shorter than
+// window + finish + token apply (24 + 8 + 29): C3 230.5 / 231.5 against 227.8 / 227.9 us, same box, alternating runs.
+static bool rider_records(bool hoff_ok) {
+  static const bool split = [] { const char* e = getenv("ARX_K7_RIDER_SPLIT"); return e && e[0] == '1'; }();
+  return hoff_ok && split;
+}
+
 int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const CatSites& st,
                                 const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
                                 const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
@@ -1516,7 +1530,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
     }
     bbase = reinterpret_cast<char*>(bag->ws);
   }
-  const bool hoff_ok = bag && n_dev && runs_path(d) && bag_compact(n0, bag->max_len) && runs_extract_blocks(n) <= 224;
+  const bool hoff_ok = bag && n_dev && rider_hoff_ok(n, n0, bag->max_len, d);
   if (sorted_runs) {
     // run records of the one-hot list -- unless a bag table rides on it: then the sort branch of the step has
     // no room for them (measured at C3: the branch ends 40 us behind the backward GEMMs), the one-hot pass
@@ -1525,7 +1539,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
     const bool hoff = hoff_ok;
     int32_t* hp = hoff ? reinterpret_cast<int32_t*>(bbase + bw.off_hoff) : nullptr;
     RunLists rl = run_lists_of(base + w.off_runs, n, 256, ssrc, scoef, count + 8);
-    if (bag) rl.R = nullptr;
+    if (bag && !rider_records(hoff_ok)) rl.R = nullptr;
     if (!bag || hoff) {
       rc = launch_runs_extract(keys_out, n, count + 2, sentinel, rl, d, s, hoff ? bag->lens : nullptr, ts.kb, 0u,
                                bag ? bag->max_len : 0, hp, n0, hoff ? hp + n0 : nullptr, count + 32);
@@ -1548,6 +1562,38 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
                     bag->bias ? reinterpret_cast<float*>(bbase + bw.off_gub) : nullptr, bag->lens, 0, ts.kb};
   const RunLists rl_sites = run_lists_of(base + w.off_runs, n, 256, ssrc, scoef, count + 8);
   rc = ARX_OK;
+  bool sgd_sites = ts.acc[0] == nullptr;
+  if (!ts.E[0] && ts.E[1]) sgd_sites = ts.acc[1] == nullptr;
+  if (bag && n_dev && runs_path(d) && rider_records(hoff_ok) && n0 * (int64_t)bag->max_len > kRankSortMax &&
+      sgd_sites == (bag->acc == nullptr)) {
+    // Round 5: the rider's one-hot pass on run records too, cut where the data flow allows --
+    //   C  the ENTITY table's runs (records [0, ctr[kNRuns0]): the records are in sorted order, k_runs_extract's
+    //      look-back path): Adagrad on the id rows + the merged rows Gu the token stage reads;
+    //   D  ONE launch: the token runs over Gu + the runs of the other one-hot tables (users), which nothing waits for.
+    // (before: window + finish launches over the whole one-hot list, then the token apply: three launches in a row)
+    if (mask & 4)
+      rc = launch_run_apply(ts, ntables > 1, d, rl_sites, n0, G, ldg, gb_in, lr_dev, gscale_dev, side, sgd_sites, s,
+                            ApplySel{-1, kNRuns0, 0});
+    if (rc || !(mask & 8)) return rc;
+    char* bt = bbase + bw.off_wt;
+    const int64_t n_t = n0 * (int64_t)bag->max_len;
+    int32_t* count_t = reinterpret_cast<int32_t*>(bt + bw.wt.off_count);
+    int kbt = 1;
+    while ((1ll << kbt) < bag->rows && kbt < 30) ++kbt;
+    TableSet tt = {};
+    tt.E[0] = bag->E;
+    tt.acc[0] = bag->acc;
+    tt.bias[0] = bag->bias;
+    tt.bias_acc[0] = bag->bias_acc;
+    tt.kb = kbt;
+    const RunLists rl_t = run_lists_of(bt + bw.wt.off_runs, n_t, 256, reinterpret_cast<int32_t*>(bt + bw.wt.off_ssrc),
+                                       reinterpret_cast<float*>(bt + bw.wt.off_scoef), count_t + 8);
+    const MergeOut none = {nullptr, nullptr, nullptr, -1, 0};
+    return launch_run_apply_pair(ts, ntables > 1, rl_sites, n - n0 > 0 ? n - n0 : 1, G, ldg, gb_in, none,
+                                 ApplySel{kNRuns0, -1, -2}, tt, rl_t, n_t, reinterpret_cast<float*>(bbase + bw.off_gu),
+                                 d, bag->bias ? reinterpret_cast<float*>(bbase + bw.off_gub) : nullptr, d, lr_dev,
+                                 gscale_dev, sgd_sites, s);
+  }
   if (mask & 4)
     rc = launch_apply(ts, d, keys_out, spos_arg, src_arg, coef_arg, n, sentinel, G, ldg, gb_in, lr_dev,
                     gscale_dev, scratch, scratch_b, scratch_h, scratch_hb, list, count,

@@ -17,6 +17,14 @@
 //                 (block < wave < round < lane).
 // (An inline scan in the scatter kernel was measured first: 16 dependent batches of loads
 // per block at 256 blocks, ~16 us per pass -- the extra launch is cheaper.)
+// (Round 5: a ONE-SWEEP form of the two-pass sort -- both digits' histograms from one read of the keys, pass 1 with
+// the column prefix formed inside the scatter kernel, pass 2 with a decoupled look-back over published tile
+// histograms: 3 launches instead of 6 -- was built, passed every K7 test bit for bit, and measured SLOWER in the step:
+// C3 291 against 231 us.  Beside the scorer's streaming kernels a small kernel pays ~3 us per DEPENDENT global round
+// trip in its CU's memory queue whatever the bytes; the all-to-all prefix over tile histograms is either a scan
+// launch (2 round trips spread over bins / 4 workgroups) or, inlined, tiles x bins loads per workgroup = many
+// round trips in a row (k_rs1_scat 68 us in the step), and few fat tiles turn a wave's four-round batch into a
+// serial chain of them.  Removed again)
 // The first pass reads the caller's raw int32 keys (out-of-range ones become the
 // sentinel) and raw src/coef; the payload travels with the key (coalesced 12 B per item
 // per pass instead of two random 4-byte gathers -- 64 B sectors each -- at the end).
@@ -56,7 +64,8 @@ __device__ __forceinline__ uint32_t site_key(const CatSites& st, int64_t i, uint
     if (q < st.nsites && i >= st.offs[q]) s = q;
   const int64_t j = i - st.offs[s];
   const int id = st.ids[s][j];
-  const int key = st.cat_map[s] ? st.cat_map[s][id] : id;
+  // (id < 0: an empty pool slot -- a short device draw leaves -1 -- looks nothing up: no map read, no contribution)
+  const int key = id < 0 ? -1 : (st.cat_map[s] ? st.cat_map[s][id] : id);
   const int tb = st.table[s];
   const int64_t rows = tb == 0 ? st.rows[0] : tb == 1 ? st.rows[1] : tb == 2 ? st.rows[2] : st.rows[3];
   if (src) {
@@ -319,6 +328,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(
   }
 }
 
+
 struct RsPlan {
   int nblk, passes, bits[4], shift[4];
   int64_t ipb;
@@ -348,6 +358,8 @@ RsPlan rs_plan(int64_t n, int total_bits) {
 size_t radix_sort_hist_bytes() {   // per-wave rows + the column totals
   return (size_t)(kRsMaxBlocks * kRsWaves + 1) * kRsMaxBins * sizeof(int32_t);
 }
+
+
 
 int launch_radix_sort(const int32_t* keys_raw, const int32_t* src_raw, const float* coef_raw, int64_t n,
                       uint32_t sentinel, int total_bits, uint32_t* keys_tmp, uint32_t* keys_out,

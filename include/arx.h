@@ -80,10 +80,12 @@ int arx_shard_route(const int32_t* ids, int64_t n, int world, int rank, int32_t 
                     int32_t* rows_out, int32_t* keys_out, void* stream);
 /* Block layout of the shared negative pool on a row-sharded item table (the pool itself:
  * embed_attribute.py:320-348 update_sampled).  Owner g's pool items, in slot order, are rows
- * [0, counts[g]) of its block; blocks travel padded to `cap` rows.  cap == 0: only counts[world] is
- * written (the caller reads it to choose cap).  cap > 0: gidx[s] = owner * cap + position (row of slot s
- * in the gathered [world * cap] blocks), my_slots[0 .. counts[rank]) = this rank's slots (rest = S),
- * pool_rows[...] = their local rows (rest = zero_row).  1 <= S <= 4096, world <= 64; one launch. */
+ * [0, counts[g]) of its block; blocks travel padded to `cap` rows.  counts has world + 1 cells:
+ * counts[0 .. world) the owners' slot counts (the caller reads them to choose cap), counts[world] the number
+ * of NEGATIVE ids (no owner: gidx = -1, no row of any block -- the caller rejects such a pool).  cap == 0:
+ * only counts is written.  cap > 0: gidx[s] = owner * cap + position (row of slot s in the gathered
+ * [world * cap] blocks), my_slots[0 .. counts[rank]) = this rank's slots (rest = S), pool_rows[...] = their
+ * local rows (rest = zero_row).  Any S, world <= 256; one launch. */
 int arx_pool_blocks(const int32_t* ids, int64_t S, int world, int rank, int32_t zero_row, int64_t cap,
                     int32_t* counts, int32_t* gidx, int32_t* my_slots, int32_t* pool_rows, void* stream);
 /* strided 2-D copy (packs / unpacks the all-to-all blocks of the sharded scorer) */
@@ -605,6 +607,10 @@ int arx_sparse_adagrad_cat_multi_phase(int phase, int ntables, float* const* E, 
  *   phase 5 = the one-hot keys + sort (+ the bag offsets), phase 6 = the token chain (needs 5),
  *   phase 7 = the one-hot apply with its side output (needs 5 and G), phase 8 = the token apply
  *   (needs 6 and 7) -- so the tail of the token chain can run under the one-hot apply.
+ * Round 5, opt-in (ARX_K7_RIDER_SPLIT=1; measured 3 us/step slower than the default at C3): the
+ * one-hot list gets run records in sorted order as well and the two apply phases cut the work by data flow:
+ *   phase 7 = the runs of table 0 alone (Adagrad on its rows + the merged rows),
+ *   phase 8 = ONE launch: the token runs over the merged rows + the runs of the other one-hot tables.
  * bag_workspace >= arx_sparse_adagrad_bags_workspace_bytes(lookups of table 0, max_len, d). */
 int arx_sparse_adagrad_cat_multi_bags(int phase, int ntables, float* const* E, float* const* acc,
                                       float* const* bias, float* const* bias_acc,
@@ -620,6 +626,7 @@ int arx_sparse_adagrad_cat_multi_bags(int phase, int ntables, float* const* E, f
                                       int64_t bag_rows, const int32_t* vals, const int32_t* starts,
                                       const int32_t* lens, int max_len, int32_t* bag_aux_cnt,
                                       void* bag_workspace, size_t bag_workspace_bytes, void* stream);
+
 
 /* Multi-hot lookups of ONE table (embed_attribute.py:397-406: embedding_lookup of the bag
  * tokens + unsorted_segment_sum / length; hmf_model.py:146-151 one Adagrad apply per variable),

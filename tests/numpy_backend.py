@@ -98,17 +98,21 @@ class NumpyBackend(object):
             _n(keys_out)[...] = np.where(own, i // world, KEY_NONE).astype(np.int32)
 
     def pool_blocks(self, ids, world, rank, zero_row, cap, counts, gidx=None, my_slots=None, pool_rows=None):
+        # counts: world + 1 cells, [world] = negative ids (no owner: gidx -1, no row of any block) -- include/arx.h
         i = _n(ids).astype(np.int64)
         S = i.shape[0]
-        owner = i % world
-        _n(counts)[...] = np.bincount(owner, minlength=world).astype(np.int32)
+        live = i >= 0
+        owner = np.where(live, i % world, -1)
+        c = _n(counts)
+        c[:world] = np.bincount(owner[live], minlength=world).astype(np.int32)
+        c[world] = int((~live).sum())
         if cap == 0:
             return
         pos = np.zeros(S, np.int64)
         for g in range(world):
             sel = np.nonzero(owner == g)[0]
             pos[sel] = np.arange(len(sel))
-        _n(gidx)[...] = (owner * cap + pos).astype(np.int32)
+        _n(gidx)[...] = np.where(live, owner * cap + pos, -1).astype(np.int32)
         mine = np.nonzero(owner == rank)[0]
         ms, pr = _n(my_slots), _n(pool_rows)
         ms[...] = S

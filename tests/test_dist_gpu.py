@@ -281,11 +281,13 @@ def test_sharded_hip_backend_two_ranks_one_gpu(dev, tmp_path, graphs):
     assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(2))
 
 
-@pytest.mark.parametrize("S,world", [(1024, 8), (1000, 3), (128, 2), (4096, 64), (7, 4)])
-def test_pool_blocks_match_numpy_double(dev, S, world):
+@pytest.mark.parametrize("S,world,neg", [(1024, 8, 0), (1000, 3, 0), (128, 2, 0), (4096, 64, 0), (7, 4, 0),
+                                         (8192, 8, 0), (20000, 200, 0), (3000, 8, 5)])
+def test_pool_blocks_match_numpy_double(dev, S, world, neg):
     """arx_pool_blocks (the block layout of a pool striped over the owners; dist.ShardedHMF.set_pool) == the
     numpy restatement the gloo tests run on, for every rank: counts, slot -> gathered row, the rank's slots and
-    local rows with their padding; incl. an owner without pool items."""
+    local rows with their padding; incl. an owner without pool items, pools past round 4's 4096-slot / 64-owner
+    limits (advisor, round 4) and negative ids (a short device draw leaves -1): counted in counts[world], no row."""
     import torch
     from arx import ops
     from numpy_backend import NumpyBackend
@@ -294,17 +296,20 @@ def test_pool_blocks_match_numpy_double(dev, S, world):
     if world > 2:
         ids = ids[ids % world != 1]                      # owner 1 owns nothing
         ids = np.concatenate([ids, (ids[:S - len(ids)] // world) * world * 7 + 0]).astype(np.int32)[:S]
+    if neg:
+        ids[rng.choice(len(ids), size=neg, replace=False)] = -1
     S = len(ids)
     nb = NumpyBackend()
     t_ids = torch.from_numpy(ids).to(dev)
     c_ids = torch.from_numpy(ids)
     for rank in range(min(world, 4)):
-        cnt_ref = torch.zeros(world, dtype=torch.int32)
+        cnt_ref = torch.zeros(world + 1, dtype=torch.int32)
         nb.pool_blocks(c_ids, world, rank, 777, 0, cnt_ref)
-        cap = (int(cnt_ref.max()) + 3) // 4 * 4
+        assert int(cnt_ref[world]) == neg
+        cap = (int(cnt_ref[:world].max()) + 3) // 4 * 4
         g_ref, ms_ref, pr_ref = (torch.zeros(S, dtype=torch.int32) for _ in range(3))
         nb.pool_blocks(c_ids, world, rank, 777, cap, cnt_ref, g_ref, ms_ref, pr_ref)
-        cnt = torch.zeros(world, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(world + 1, dtype=torch.int32, device=dev)
         ops.pool_blocks(t_ids, world, rank, 777, 0, cnt)
         assert torch.equal(cnt.cpu(), cnt_ref)
         g, ms, pr = (torch.full((S,), -5, dtype=torch.int32, device=dev) for _ in range(3))

@@ -100,7 +100,8 @@ CFG_MIX = dict(n_users=400, n_items=600, logit_size=600, item_mulhot=True, user_
 @pytest.mark.parametrize("cfg,loss,d,B,S", [
     (CFG_ID, 'mw', 128, 64, 256),
     (CFG_HET, 'mw', 128, 64, 256),
-    (CFG_MIX, 'mw', 32, 48, 128),
+    (CFG_MIX, 'mw', 32, 48, 128),            # d = 32: not a shape of the fused scorer family -> K4 + K6
+    (CFG_MIX, 'mw', 64, 48, 128),            # ... and the same layout on it
     (CFG_ID, 'mce', 128, 64, 256),           # build-defined sampled softmax (fused target score)
     (CFG_HET, 'mce', 64, 32, 128),
     (CFG_ID, 'ce', 32, 64, None),
@@ -129,6 +130,9 @@ def test_hmf_steps_match_oracle(dev, cfg, loss, d, B, S, use_graph):
         l_got = model.step(None, list(users), list(items), None, pool, id2idx, loss=loss)
         np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='step %d' % step)
         _compare_state(model, ref)
+    if loss == 'mw':
+        from conftest import assert_mw_scorer_path
+        assert_mw_scorer_path(model._plan('train'), B, S, d)
     if loss == 'mce':                            # evaluates with the full softmax
         e_ref = ref.step(list(users), list(items), forward_only=True, loss=loss)
         e_got = model.step(None, list(users), list(items), forward_only=True, loss=loss)
@@ -404,8 +408,8 @@ def test_hmf_mw_scorer_gemm_with_hinge_epilogue(dev, cfg, d):
         l_got = model.step(None, list(users), list(items), None, pool, id2idx, loss='mw')
         np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='step %d' % step)
         _compare_state(model, ref)
-    plan = model._plan('train')
-    assert ops.SCORER_F32 or any(isinstance(n, G.BatchLoss) and n.gemm_fused for n in plan.order)   # the path under test ran
+    from conftest import assert_mw_scorer_path
+    assert assert_mw_scorer_path(model._plan('train'), B, S, d) or ops.SCORER_F32    # the path under test ran
 
 
 @pytest.mark.parametrize("cfg,loss", [(CFG_ID, 'mw'), (CFG_HET, 'mw'), (CFG_HET, 'mce')])
@@ -504,3 +508,87 @@ def test_hmf_feeds_as_graph_nodes_bit_identical(dev, cfg):
     g = m_nodes._plan('train').graph
     assert g is not None and g.feed_groups, "the captured step carries no feed nodes"
     assert m_eager._plan('train').graph.feed_groups is None
+
+
+@pytest.mark.parametrize("cfg", [CFG_ID, CFG_HET])
+def test_hmf_feed_nodes_unsynchronised_run(dev, cfg):
+    """The same comparison over a LONG run without any host synchronisation between the steps (step_async: the host
+    enqueues ~0.1 ms per step and runs ahead of the device, so the feed nodes of step t + k are re-pointed while
+    step t is still executing -- advisor, round 4): per-step losses and final tables of the feed-node plan equal the
+    eager-feed plan's bit for bit."""
+    import torch
+    B, S, d = 2048, 256, 64
+    steps = 40
+    rng = np.random.default_rng(6)
+    syn0, m_nodes, _ = _build(cfg, 'mw', d, B, S, seed=12)
+    _, m_eager, _ = _build(cfg, 'mw', d, B, S, seed=12)
+    m_eager.rt.feeds_in_graph = False
+    dev_ = m_nodes.rt.device
+    batches = [syn0.sample_batch(B, rng) for _ in range(steps)]
+    pool = torch.from_numpy(syn0.sample_pool(S, rng).astype(np.int32)).to(dev_)
+    tb = [(torch.from_numpy(u.astype(np.int32)).to(dev_), torch.from_numpy(i.astype(np.int32)).to(dev_))
+          for u, i in batches]
+    out = {}
+    for name, m in (('nodes', m_nodes), ('eager', m_eager)):
+        losses = torch.zeros(steps, dtype=torch.float32, device=dev_)
+        torch.cuda.synchronize()
+        for k in range(steps):
+            node = m.step_async(None, tb[k][0], tb[k][1], None, pool if k == 0 else None, None, loss='mw')
+            losses[k:k + 1].copy_(node.read().reshape(1), non_blocking=True)
+        torch.cuda.synchronize()
+        out[name] = (losses.cpu().numpy(), m.att_emb.get_params())
+    assert np.array_equal(out['nodes'][0], out['eager'][0]), (out['nodes'][0], out['eager'][0])
+    for name in out['nodes'][1]:
+        assert np.array_equal(out['nodes'][1][name], out['eager'][1][name]), name
+    assert m_nodes._plan('train').graph.feed_groups
+
+
+def test_hmf_empty_pool_slot_is_a_zero_row(dev):
+    """A negative id in the sampled pool (what DeviceSampler.sample leaves where a short capped draw could not fill a
+    position) is an EMPTY slot: it scores like an item whose rows are zero and receives no update -- no read of
+    cat_map[-1] / E[-1] (advisor, round 4).  Against a twin model whose pool holds, in that slot, a real item X with
+    zeroed id row and bias: same losses bit for bit, same tables except X's own rows."""
+    import torch
+    from arx.utils.synthetic import SyntheticHMF
+    from arx.hmf.hmf_model import LatentProductModel
+    d, B, S = 64, 256, 128
+    syn = SyntheticHMF(seed=21, **CFG_ID)
+    params = syn.glorot_params(d, seed=22, scale=0.5)
+    rng = np.random.default_rng(23)
+    batches = [syn.sample_batch(B, rng) for _ in range(3)]
+    used = set(int(i) for _, it in batches for i in it)
+    pool = syn.sample_pool(S, rng).astype(np.int32)
+    X = next(int(i) for i in syn.item_population if int(i) not in used and int(i) not in set(pool.tolist()))
+    xrow = int(np.asarray(syn.i_attr.features_cat[0])[X])
+    params['itemembed_cat_0'][xrow] = 0
+    params['item_bias_cat_0'][xrow] = 0
+    i2l, l2i = syn.item_ind2logit_ind_dict(), syn.logit_ind2item_ind
+    models = []
+    for _ in range(2):
+        m = LatentProductModel(syn.n_users, syn.n_items, d, 1, B, 0.5, 1.0, syn.u_attr, syn.i_attr, i2l, l2i,
+                               loss_function='mw', n_sampled=S, params=params)
+        m.prepare_warp(None, None)      # no positives: X in the twin's pool would be masked for the users who know it
+        models.append(m)
+    dev_ = models[0].rt.device
+    pa, pb = pool.copy(), pool.copy()
+    pa[5] = -1
+    pb[5] = X
+    for k, (u, it) in enumerate(batches):
+        tu = torch.from_numpy(u.astype(np.int32)).to(dev_)
+        ti = torch.from_numpy(it.astype(np.int32)).to(dev_)
+        la = models[0].step(None, tu, ti, None, torch.from_numpy(pa).to(dev_) if k == 0 else None, None, loss='mw')
+        assert np.isfinite(la)
+        if k > 0:
+            continue                                 # (later steps, eager -> captured: the empty slot stays harmless)
+        lb = models[1].step(None, tu, ti, None, torch.from_numpy(pb).to(dev_), None, loss='mw')
+        assert la == lb, (la, lb)
+        ga, gb = models[0].att_emb.get_params(), models[1].att_emb.get_params()
+        keep = np.ones(ga['itemembed_cat_0'].shape[0], dtype=bool)
+        keep[xrow] = False
+        assert not ga['itemembed_cat_0'][xrow].any() and not ga['item_bias_cat_0'][xrow].any()   # nothing written
+        assert gb['itemembed_cat_0'][xrow].any()                                                 # the twin's X moved
+        assert np.array_equal(ga['userembed_cat_0'], gb['userembed_cat_0'])
+        assert np.array_equal(ga['itemembed_cat_0'][keep], gb['itemembed_cat_0'][keep])
+        assert np.array_equal(ga['item_bias_cat_0'][keep], gb['item_bias_cat_0'][keep])
+    ga = models[0].att_emb.get_params()
+    assert not ga['itemembed_cat_0'][xrow].any() and all(np.isfinite(v).all() for v in ga.values())

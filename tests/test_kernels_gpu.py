@@ -1462,12 +1462,20 @@ def test_mw_scorer(dev, B, S, d, mask_rows):
     np.testing.assert_allclose(dT.cpu().numpy()[same], (dt[:, None] * U)[same], rtol=RTOL, atol=1e-9)
     assert not np.any(act & ~mask)                                  # masked positives carry no bit
     # ---- the backward products read the bits ----
-    exact = not diff.any()
+    # Expected values from the DEVICE's own bits: a borderline hinge (|x - t + 1| < 1e-5, fp32 vs f64) flips a bit
+    # and the products legitimately follow the bit -- with the oracle's act matrix the check had to be skipped
+    # whenever ONE of the B * S bits differed, which at the C3 shape (16.8 M logits) is the expected case.  g moves by
+    # < 1e-5 relative with such a flip (the hinge sum by |v| < 1e-5), inside the tolerance.
+    dl_dev = g[:, None] * act                                       # d loss / d logits as the device sees it
+    dt_dev = -dl_dev.sum(1)
     dUx = dU.clone()
     sc.bwd_dU(dUx, beta=1.0)                                                     # dU += g * (act . P)
-    if exact:
-        np.testing.assert_allclose(dUx.cpu().numpy(), dt[:, None] * T + (dl @ P.astype(np.float64)), rtol=RTOL,
-                                   atol=2e-8)
+    np.testing.assert_allclose(dUx.cpu().numpy(), dt_dev[:, None] * T + (dl_dev @ P.astype(np.float64)), rtol=RTOL,
+                               atol=3e-8)
+    # ... and against the oracle's own backward on every row without a flipped bit: almost all of them
+    assert same.mean() >= 0.99, same.mean()
+    np.testing.assert_allclose(dUx.cpu().numpy()[same], (dt[:, None] * T + (dl @ P.astype(np.float64)))[same],
+                               rtol=RTOL, atol=2e-8)
     dI0 = rng.standard_normal((S, d)).astype(np.float32)
     dI = _t(dev, dI0)
     db = torch.empty(S, dtype=f32, device=dev)
@@ -1477,10 +1485,14 @@ def test_mw_scorer(dev, B, S, d, mask_rows):
     ref_sum = float((rw.astype(np.float64) * gscale * bl).sum())
     bound = 4e-7 * float((rw.astype(np.float64) * gscale * np.abs(bl)).sum()) * (6 + np.log2(max(B, 2))) + 1e-12
     assert abs(float(lsum.item()) - ref_sum) <= bound, (float(lsum.item()), ref_sum, bound)
-    if exact:
-        np.testing.assert_allclose(dI.cpu().numpy(), 0.5 * dI0 + dl.T @ U.astype(np.float64), rtol=RTOL, atol=2e-8)
-        np.testing.assert_allclose(db.cpu().numpy(), dl.sum(0), rtol=RTOL, atol=2e-8)
-    if mask_rows and exact:            # per-time-step products (TF-1.0's clip norm squares them one by one)
+    np.testing.assert_allclose(dI.cpu().numpy(), 0.5 * dI0 + dl_dev.T @ U.astype(np.float64), rtol=RTOL, atol=3e-8)
+    np.testing.assert_allclose(db.cpu().numpy(), dl_dev.sum(0), rtol=RTOL, atol=3e-8)
+    same_c = ~diff.any(axis=0)         # pool columns without a flipped bit: the oracle's own dI rows / db cells
+    assert same_c.mean() >= 0.99, same_c.mean()
+    np.testing.assert_allclose(dI.cpu().numpy()[same_c], (0.5 * dI0 + dl.T @ U.astype(np.float64))[same_c],
+                               rtol=RTOL, atol=2e-8)
+    np.testing.assert_allclose(db.cpu().numpy()[same_c], dl.sum(0)[same_c], rtol=RTOL, atol=2e-8)
+    if mask_rows:                      # per-time-step products (TF-1.0's clip norm squares them one by one)
         L = B // mask_rows
         dIs = torch.empty((L, S, d), dtype=f32, device=dev)
         dbs = torch.empty((L, S), dtype=f32, device=dev)
@@ -1488,10 +1500,10 @@ def test_mw_scorer(dev, B, S, d, mask_rows):
         sc.bwd_dI(dI2, db=db, step_rows=mask_rows, dI_steps=dIs, db_steps=dbs)
         for k in range(L):
             rows = slice(k * mask_rows, (k + 1) * mask_rows)
-            np.testing.assert_allclose(dIs[k].cpu().numpy(), dl[rows].T @ U[rows].astype(np.float64), rtol=RTOL,
-                                       atol=2e-8)
-            np.testing.assert_allclose(dbs[k].cpu().numpy(), dl[rows].sum(0), rtol=RTOL, atol=2e-8)
-        np.testing.assert_allclose(dI2.cpu().numpy(), dl.T @ U.astype(np.float64), rtol=RTOL, atol=2e-8)
+            np.testing.assert_allclose(dIs[k].cpu().numpy(), dl_dev[rows].T @ U[rows].astype(np.float64), rtol=RTOL,
+                                       atol=3e-8)
+            np.testing.assert_allclose(dbs[k].cpu().numpy(), dl_dev[rows].sum(0), rtol=RTOL, atol=3e-8)
+        np.testing.assert_allclose(dI2.cpu().numpy(), dl_dev.T @ U.astype(np.float64), rtol=RTOL, atol=3e-8)
     if mask_rows:
         # the sequence model's example weights formed by the first launch (arx_mw_scorer_fwd_seqw): the arithmetic
         # of arx_seq_weights bit for bit, and g / the scalar loss follow from them
@@ -1668,3 +1680,47 @@ def test_captured_graph_feed_nodes(dev):
     g.launch()
     torch.cuda.synchronize()
     assert all(bool((d == 10 + k).all()) for k, d in enumerate(dst))
+
+
+def test_captured_graph_feed_nodes_in_flight(dev):
+    """Feed nodes re-pointed while EARLIER launches of the same executable are still in flight (advisor, round 4):
+    hipGraphExecKernelNodeSetParams must only affect launches issued after it.  The graph is made long (a few passes
+    over 64 MB behind the consumer) so that the host runs ahead: 48 set_feeds + launch pairs with distinct sources
+    and no synchronisation in between; each launch's consumer result is copied out by an eager copy ordered behind
+    it.  Validated on ROCm 7.2 / gfx950 (the step's default path relies on it: Runtime.feeds_in_graph)."""
+    from arx import ops
+    import torch
+    n, K = 4096, 48
+    f32, i32 = torch.float32, torch.int32
+    dst = torch.zeros(n, dtype=i32, device=dev)
+    out = torch.zeros(1, dtype=f32, device=dev)
+    sink = torch.zeros(1, dtype=f32, device=dev)
+    big = torch.ones(1 << 24, dtype=f32, device=dev)
+    srcs = [torch.full((n,), float(k + 1), dtype=f32, device=dev).view(i32) for k in range(K)]
+    res = torch.zeros(K, dtype=f32, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    g = ops.CapturedGraph()
+    feeds0 = [(srcs[0], dst)]
+    with torch.cuda.stream(side):
+        g.begin()
+        ops.copy_words(feeds0)
+        ops.sum_scaled(dst.view(f32), 1.0, out)                   # the consumer behind the feed node
+        for _ in range(6):
+            ops.sum_scaled(big, 1.0, sink)                        # ... and ~100 us of other work: launches queue up
+        g.end(feeds=feeds0)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for k in range(K):
+        g.set_feeds([(srcs[k], dst)])
+        g.launch()
+        res[k:k + 1].copy_(out, non_blocking=True)
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    got = res.cpu().numpy()
+    assert np.array_equal(got, np.arange(1, K + 1, dtype=np.float32) * n), got
+    # (informational: the host was ahead of the device for most of the run when t_host << t_all)
+    print("feed nodes in flight: host %.2f ms, device %.2f ms" % (1e3 * t_host, 1e3 * t_all))

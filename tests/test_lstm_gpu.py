@@ -96,9 +96,6 @@ CFG_HET = dict(n_users=300, n_items=500, logit_size=500, item_mulhot=True, mulho
 ])
 def test_seq_mw_steps_match_oracle(dev, cfg, size, B, L, S, clip):
     syn, emb, model, remb, ref = _build(cfg, 'mw', size, B, L, S, clip, seed=4)
-    if B % 128 == 0:
-        from arx import graph as G, ops
-        plan_fused = lambda: any(isinstance(n, G.BatchLoss) and n.gemm_fused for n in model._plan(0, 'train').order)
     rng = np.random.default_rng(7)
     pool = syn.sample_pool(S, rng)
     id2idx = {int(v): i for i, v in enumerate(pool)}
@@ -117,8 +114,11 @@ def test_seq_mw_steps_match_oracle(dev, cfg, size, B, L, S, clip):
             np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL,
                                        err_msg='global norm step %d' % step)
         _compare(emb, model, remb, ref)
+    from conftest import assert_mw_scorer_path
+    from arx import ops
+    fused = assert_mw_scorer_path(model._plan(0, 'train'), L * B, S, size)   # every case that qualifies ran on it
     if B % 128 == 0:
-        assert ops.SCORER_F32 or plan_fused()                     # the path under test ran
+        assert ops.SCORER_F32 or fused                            # the path under test ran
 
 
 @pytest.mark.parametrize("cfg", [CFG_ID, CFG_HET])
