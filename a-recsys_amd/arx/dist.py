@@ -186,6 +186,23 @@ class HipBackend(object):
                                              torch.empty(ent.total, dtype=torch.float32, device=G.device))
         ops.sparse_adagrad_cat_multi(ent, G, Gb, lr, kb, sb, cb, self.ws_k7, phase=phase)
 
+    def bags_grad_dense(self, D, Db, vals, starts, lens, sites, G, Gb):
+        """D[t] += sum of the gradient rows of the bags that hold token t (coefficient coef / len), Db likewise: the
+        two-stage multi-hot pass in its gradient-descent form (no slots) with a step of -1 onto a gradient table --
+        0 - (-1) g = g, the merged sums themselves, bit for bit.  Tokens >= D.shape[0] are dropped."""
+        if getattr(self, '_neg_one', None) is None:
+            self._neg_one = torch.tensor([-1.0], dtype=torch.float32, device=D.device)
+        self.bags_adagrad(D, None, Db, None, vals, starts, lens, sites, G, Gb, self._neg_one)
+
+    def adagrad_dense(self, w, acc, g, lr):
+        self.ops.adagrad_dense(w, acc, g, lr)
+
+    def fill_zero(self, t):
+        self.ops.fill_f32(t, 0.0)
+
+    def take_i32(self, table, idx, out, fill):
+        self.ops.take_i32(table, idx, out, fill=fill)
+
     def slot_map_set(self, m, ids, clear):
         self.ops.slot_map_set(m, ids, clear=clear)
 
@@ -850,6 +867,162 @@ class ShardedHMFBags(ShardedHMF):
         return out
 
 
+class ShardedHMFRepTokens(ShardedHMF):
+    """HET items (comb_attribute.py:151-176: item = mean(id row, bag mean)) with the id table striped by item and
+    the TOKEN table REPLICATED on every rank -- round 5, the redesign of ShardedHMFBags for token tables that fit
+    beside the id shard (C3: 100 k x 128 x 4 B = 51 MB; past ~64 MB stripe by token: ShardedHMFBags).
+
+    With every token on every rank a bag mean is LOCAL to the owner of the item's id row, so the step is
+    ShardedHMF's -- the owner forms the whole item embedding, pool blocks are all-gathered, target rows and their
+    gradients travel in two all-to-alls sized by B_loc, the pool gradient in one small all-reduce -- plus ONE
+    all-reduce for the token table: every rank merges the token gradients of the lookups it owns (pool block +
+    received targets, coefficient 1/2 . 1/len) into a dense gradient table D [n_tokens, d] (the two-stage bag pass
+    in its gradient-descent form with a step of -1 onto a zeroed table: the sums themselves), D is summed over the
+    ranks, and every replica applies the same dense Adagrad step (rows without gradient: acc += 0, w -= 0 -- the
+    sparse update of embed_attribute.py:383-400 / hmf_model.py:146-151).  Volume per rank and step on top of
+    ShardedHMF: 2 x n_tokens x (d + 1) x 4 B x (N-1)/N through the ring, independent of the batch, issued under the
+    id shard's own K7 pass; the token-striped step moves 2 x B x (d + 4) x 4 B with B the GLOBAL batch
+    (predicted comm / compute 0.35 against 0.57 at N = 8, B_loc = 16384)."""
+
+    def __init__(self, n_users, n_items, d, B_loc, S, learning_rate, rank, world, device, bags, n_tokens,
+                 backend=None, group=None, tables=None, seed=0, acc0=0.1):
+        super().__init__(n_users, n_items, d, B_loc, S, learning_rate, rank, world, device, backend=backend,
+                         group=group, tables=tables, seed=seed, acc0=acc0, graphs=False)
+        dev, f32, i32 = self.device, torch.float32, torch.int32
+        vals, starts, lens = [np.asarray(a) for a in bags]
+        nt = int(n_tokens)
+        self.n_tokens = nt
+        if tables is not None:
+            self.E_tok = torch.zeros((nt + 1, d), dtype=f32, device=dev)
+            self.E_tok[:nt].copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(tables['token'], dtype=np.float32))))
+            self.b_tok = torch.zeros((nt + 1,), dtype=f32, device=dev)
+            self.b_tok[:nt].copy_(torch.from_numpy(np.ascontiguousarray(
+                np.asarray(tables['token_bias'], dtype=np.float32).reshape(-1))))
+        else:
+            g = torch.Generator(device=dev)
+            g.manual_seed(seed * 2003)                      # (the SAME table on every rank)
+            lim = float(np.sqrt(6.0 / (nt + d)))
+            self.E_tok = torch.empty((nt + 1, d), dtype=f32, device=dev).uniform_(-lim, lim, generator=g)
+            self.b_tok = torch.empty((nt + 1,), dtype=f32, device=dev).uniform_(-lim, lim, generator=g)
+            self.E_tok[nt].zero_()
+            self.b_tok[nt] = 0.0
+        self.A_tok = torch.full_like(self.E_tok, acc0)
+        self.Ab_tok = torch.full_like(self.b_tok, acc0)
+        # bag index by GLOBAL item id + one padding entity (index n_items): a bag of one padding token (row nt:
+        # zeros, dropped by the gradient pass) -- what the padding rows of a pool block / of the receive buffer look up
+        n_ent = int(lens.shape[0])
+        if n_ent < n_items:
+            raise ValueError("bag index shorter than the item table")
+        v = np.concatenate([vals.astype(np.int32)[:int(starts[n_ent - 1] + lens[n_ent - 1])], [nt]]).astype(np.int32)
+        st = np.concatenate([starts.astype(np.int32)[:n_ent], [len(v) - 1]]).astype(np.int32)
+        ln = np.concatenate([lens.astype(np.int32)[:n_ent], [1]]).astype(np.int32)
+        self.pad_item = n_ent
+        self.bag_vals = torch.from_numpy(v).to(dev)
+        self.bag_starts = torch.from_numpy(st).to(dev)
+        self.bag_lens = torch.from_numpy(ln).to(dev)
+        self.D_tok = torch.zeros((nt, d), dtype=f32, device=dev)      # merged token gradients, summed over the ranks
+        self.Db_tok = torch.zeros((nt,), dtype=f32, device=dev)
+        self.pool_ext = torch.zeros(S + 1, dtype=i32, device=dev)     # pool ids + the padding entity
+        self.block_ids = torch.zeros(S, dtype=i32, device=dev)        # global item id of every row of the owned block
+
+    def set_pool(self, pool_ids):
+        super().set_pool(pool_ids)
+        be, S = self.be, self.S
+        be.copy_i32(self.pool_ids, self.pool_ext[:S])
+        be.copy_i32(torch.full((1,), self.pad_item, dtype=torch.int32, device=self.device), self.pool_ext[S:])
+        if self.world == 1:
+            be.copy_i32(self.pool_ids, self.block_ids)
+        else:          # block row -> pool slot (S: padding) -> item id (padding entity)
+            be.take_i32(self.pool_ext, self.my_slots, self.block_ids, self.pad_item)
+
+    def _het_rows(self, rows, ids, out, bias_tmp):
+        """out[:, :d] = (id row + bag mean) / 2, out[:, d] = (id bias + mean token bias) / 2 for the owned items
+        `ids` (global) whose id-shard rows are `rows`."""
+        be, d = self.be, self.d
+        bag = (self.bag_vals, self.bag_starts, self.bag_lens)
+        be.gather_rows(self.E_item, self.b_item, rows, out[:, :d], bias_tmp, scale=0.5)
+        be.gather_bags(self.E_tok, self.b_tok, *bag, ids, out[:, :d], bias_tmp, scale=0.5, accumulate=True)
+        be.copy_strided(bias_tmp, out[:, d])
+
+    def step(self, users, items=None):
+        if self.world > 1 and self.cap <= 0:
+            raise RuntimeError("ShardedHMFRepTokens.step before set_pool()")
+        route = users if isinstance(users, dict) else self.prepare_route(users, items)
+        be, W = self.be, self.world
+        B, B_loc, S, Sg, d = self.B, self.B_loc, self.S, self.Sg, self.d
+        grp = self.group
+        send, recv, R = route['send'], route['recv'], route['R']
+        arena, arena_b = self.arena, self.arena_b
+        urows, recv_rows, recv_ids = route['urows'], route['recv_rows'], route['recv_ids']
+        self.urows = urows
+        cap = self.cap
+        # ---- forward: the owner forms the whole HET embedding of its pool block and of the requested targets ----
+        be.gather_rows(self.E_user, None, urows, self.U_loc, None)
+        if W == 1:
+            self._het_rows(self.pool_rows, self.block_ids, self.I_all, self.b_all)
+        else:
+            self._het_rows(self.pool_rows[:cap], self.block_ids[:cap], self.I_pack[:cap], self.b_g[:cap])
+            dist.all_gather_into_tensor(self.I_gath[:W * cap], self.I_pack[:cap], group=grp)
+            be.gather_rows(self.I_gath, None, self.gidx, self.I_all, None)    # blocks -> pool (slot) order
+            be.copy_strided(self.I_all[:, d], self.b_all)
+        T_send = self.T_send[:R]
+        if R > 0:
+            self._het_rows(recv_rows, recv_ids, T_send, self.tb_send[:R])
+        w_rows = _all_to_all(self.T_pack, T_send, send, recv, group=grp, async_op=True)
+        be.gemm(self.U_loc, self.I_all[:, :d], self.logits, transB=True, col_bias=self.b_all)
+        w_rows.wait()
+        dU = arena[:B_loc, :d]
+        be.loss_mw_fused_pos(self.logits, self.U_loc, self.T_pack[:, :d], self.T_pack[:, d], self.urows,
+                             self.pos_ptr, self.pos_items, self.item2slot, self.bl, self.dlogits,
+                             self.t_loc, self.dT_pack[:, d], dU, self.dT_pack[:, :d], 1.0 / B)
+        # ---- backward ----
+        w_dt = _all_to_all(arena[B_loc + Sg:B_loc + Sg + R], self.dT_pack, recv, send, group=grp, async_op=True)
+        be.gemm(self.dlogits, self.I_all[:, :d], dU, beta=1.0)
+        be.gemm(self.dlogits, self.U_loc, self.dI_all[:S, :d], transA=True, a_rowsum=self.gb_all)
+        be.copy_strided(self.gb_all, self.dI_all[:S, d])
+        if W == 1:
+            be.copy_2d(self.dI_all[:S], arena[B_loc:B_loc + S])
+        else:
+            dist.all_reduce(self.dI_all[:S], op=dist.ReduceOp.SUM, group=grp)
+            be.gather_rows(self.dI_all, None, self.my_slots[:cap], arena[B_loc:B_loc + cap], None)
+        w_dt.wait()
+        be.copy_strided(arena[B_loc:B_loc + Sg + R, d], arena_b[B_loc:B_loc + Sg + R])
+        # token table: this rank's merged token gradients -> D, summed over the ranks under the id shard's pass
+        nt = self.n_tokens
+        bag = (self.bag_vals, self.bag_starts, self.bag_lens)
+        be.fill_zero(self.D_tok)
+        be.fill_zero(self.Db_tok)
+        bsites = [(self.block_ids[:cap], B_loc, 0.5)]
+        if R > 0:
+            bsites.append((recv_ids[:R], B_loc + Sg, 0.5))
+        be.bags_grad_dense(self.D_tok, self.Db_tok, *bag, bsites, arena[:, :d], arena_b)
+        w_tok = w_tokb = None
+        if W > 1:
+            w_tok = dist.all_reduce(self.D_tok, op=dist.ReduceOp.SUM, group=grp, async_op=True)
+            w_tokb = dist.all_reduce(self.Db_tok, op=dist.ReduceOp.SUM, group=grp, async_op=True)
+        # id shard + user shard: one fused one-hot pass (the item rows' share of the embedding is 1/2)
+        sites = [(0, self.urows, 0, 1.0), (1, self.pool_rows[:cap], B_loc, 0.5)]
+        if R > 0:
+            sites.append((1, recv_rows, B_loc + Sg, 0.5))
+        ni = self.ni_loc
+        be.sparse_adagrad_multi([(self.E_user, self.A_user, None, None),
+                                 (self.E_item[:ni], self.A_item[:ni], self.b_item[:ni], self.Ab_item[:ni])],
+                                sites, arena[:, :d], arena_b, self.lr)
+        if w_tok is not None:
+            w_tok.wait()
+            w_tokb.wait()
+        be.adagrad_dense(self.E_tok[:nt], self.A_tok[:nt], self.D_tok, self.lr)
+        be.adagrad_dense(self.b_tok[:nt], self.Ab_tok[:nt], self.Db_tok, self.lr)
+        self.steps += 1
+
+    def gather_global_tables(self):
+        out = super().gather_global_tables()
+        nt = self.n_tokens
+        out['token'] = self.E_tok[:nt].cpu().numpy()
+        out['token_bias'] = self.b_tok[:nt].cpu().numpy()
+        return out
+
+
 # --------------------------------------------------------------------------
 # bench entry for N > 1 (driver: python -m torch.distributed.run ... bench.py --gpus N)
 # --------------------------------------------------------------------------
@@ -926,13 +1099,30 @@ class SeqDataParallel(object):
         its per-link latency at these sizes, not by bytes)."""
         if self.world == 1 or not tensors:
             return
-        flat = torch.cat([t.reshape(-1) for t in tensors])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        off = 0
+        if not all(t.is_cuda and t.is_contiguous() and t.element_size() == 4 for t in tensors):
+            # (the gloo / CPU rig of the tests, strided views)
+            flat = torch.cat([t.reshape(-1) for t in tensors])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            off = 0
+            for t in tensors:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view(t.shape))
+                off += n
+            return
+        # round 5: the bucket is a persistent flat buffer, packed and unpacked by arx_copy_words (8 tensors per
+        # launch) instead of torch.cat + one copy_ per tensor
+        from . import ops
+        n_all = sum(t.numel() for t in tensors)
+        flat = getattr(self, '_bucket', None)
+        if flat is None or flat.numel() < n_all or flat.device != tensors[0].device:
+            flat = self._bucket = torch.empty(n_all, dtype=torch.float32, device=tensors[0].device)
+        views, off = [], 0
         for t in tensors:
-            n = t.numel()
-            t.copy_(flat[off:off + n].view(t.shape))
-            off += n
+            views.append(flat[off:off + t.numel()])
+            off += t.numel()
+        ops.copy_words([(t.view(-1), v) for t, v in zip(tensors, views)])
+        dist.all_reduce(flat[:n_all], op=dist.ReduceOp.SUM, group=self.group)
+        ops.copy_words([(v, t.view(-1)) for t, v in zip(tensors, views)])
 
     def _all_gather(self, src, dst):
         """dst[w * n : (w + 1) * n] = src of replica w."""
@@ -1064,7 +1254,14 @@ def draw_global_pool(sampler, S, group=None):
         alli = torch.empty(world * S, dtype=ids.dtype, device=ids.device)
         dist.all_gather_into_tensor(allk, keys.contiguous(), group=group)
         dist.all_gather_into_tensor(alli, ids.contiguous(), group=group)
-        ids = alli[torch.argsort(allk, stable=True)[:S]]
+        if allk.is_cuda and world * S <= 16384:
+            # (round 5: one rank-selection launch over the 64-bit (key, position) words instead of torch's sort +
+            # index kernels -- SURVEY section 7: no torch arithmetic on the path)
+            from . import ops
+            ids = torch.empty(S, dtype=alli.dtype, device=alli.device)
+            ops.merge_keyed_take(allk, alli, S, ids)
+        else:          # (the gloo / CPU rig of the tests, or more pairs than the kernel's LDS list holds)
+            ids = alli[torch.argsort(allk, stable=True)[:S]]
     if int(ids.min().item()) < 0:
         raise ValueError("draw_global_pool(%d): fewer items with a positive weight in all shards together" % S)
     return ids
@@ -1137,7 +1334,8 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
             dist.init_process_group(backend)
     B_loc, S, d = args.batch, args.n_sampled, args.dim
     t_setup = time.time()
-    with_bags = bool(getattr(args, 'sharded_bags', False))
+    rep_tokens = bool(getattr(args, 'sharded_rep_tokens', False))
+    with_bags = bool(getattr(args, 'sharded_bags', False)) or rep_tokens
     if with_bags:
         # HET items: a multi-hot attribute of 20 tokens over a 100 k-token table striped by token
         n_tok, L_bag = 100000, 20
@@ -1146,8 +1344,8 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
         vals = rng.choice(n_tok, size=(args.n_items + 1) * L_bag, p=p_tok / p_tok.sum()).astype(np.int32)
         lens = np.full(args.n_items + 1, L_bag, dtype=np.int32)
         starts = (np.arange(args.n_items + 1, dtype=np.int64) * L_bag).astype(np.int32)
-        model = ShardedHMFBags(args.n_users, args.n_items, d, B_loc, S, 0.1, rank, world, dev,
-                               (vals, starts, lens), n_tok, seed=0)
+        cls = ShardedHMFRepTokens if rep_tokens else ShardedHMFBags
+        model = cls(args.n_users, args.n_items, d, B_loc, S, 0.1, rank, world, dev, (vals, starts, lens), n_tok, seed=0)
     else:
         model = ShardedHMF(args.n_users, args.n_items, d, B_loc, S, 0.1, rank, world, dev, seed=0)
     gen = torch.Generator(device=dev)
@@ -1228,9 +1426,23 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
     out = None
     if rank == 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        pool_mat = model.P_part if with_bags else model.I_all
-        run_gemm = lambda: model.be.gemm(model.U_loc, pool_mat[:, :d], model.logits, transB=True,
-                                         col_bias=model.b_all)
+        pool_mat = model.P_part if (with_bags and not rep_tokens) else model.I_all
+        # the kernel the timed step RUNS (round 4 verdict, weak #6): with the fused scorer that is k_sc_hinge of
+        # MwScorer.fwd (phase 2: target score + scorer GEMM + hinge epilogue, no logits), launched here with the step's
+        # own buffers; only where the step itself takes the materialising GEMM (shapes the family does not cover,
+        # ARX_SCORER_F32, the bag variants) is that GEMM the one timed
+        fused = (not with_bags) and getattr(model, 'scorer', None) is not None and model._fused_scorer()
+        if fused:
+            Sg_, arena, arena_b = model.Sg, model.arena, model.arena_b
+            dT_ = arena[B_loc + Sg_:B_loc + Sg_ + B_loc] if world == 1 else model.dT_pack
+            dt_ = arena_b[B_loc + Sg_:B_loc + Sg_ + B_loc] if world == 1 else dT_[:, d]
+            run_gemm = lambda: model.scorer.fwd(model.U_loc, model.I_all[:, :d], model.b_all, model.T_pack[:, :d],
+                                                model.T_pack[:, d], model.urows, model.pos_ptr, model.pos_items,
+                                                model.item2slot, model.bl, model.t_loc, dt_, arena[:B_loc, :d],
+                                                dT_[:, :d], 1.0 / (B_loc * world), phases=2)
+        else:
+            run_gemm = lambda: model.be.gemm(model.U_loc, pool_mat[:, :d], model.logits, transB=True,
+                                             col_bias=model.b_all)
         for _ in range(5):
             run_gemm()
         e0.record()
@@ -1240,9 +1452,11 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 50
         flops = 2.0 * B_loc * S * d
-        bx6 = (not _ops.SCORER_F32) and d in (64, 128) and S % 128 == 0 and B_loc >= 4096
+        bx6 = fused or ((not _ops.SCORER_F32) and d in (64, 128) and S % 128 == 0 and B_loc >= 4096)
         peak = 2500.0 / 6.0 if bx6 else 157.3
-        roofline = {"kernel": ("logits GEMM on the bf16 pipe, 6 exact bf16 terms per f32 product term (k_nt_bx6; per rank)"
+        roofline = {"kernel": ("k_sc_hinge (MwScorer.fwd phase 2: target score + scorer GEMM + hinge epilogue, 6 exact bf16 terms "
+                               "per f32 product term; the kernel the sharded step runs; per rank)" if fused else
+                               "logits GEMM on the bf16 pipe, 6 exact bf16 terms per f32 product term (k_nt_bx6; per rank)"
                                if bx6 else "gemm_logits_nt (f32-input MFMA; per rank)"),
                     "bound": "mfma", "achieved": flops / ms / 1e9,
                     "peak": peak, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / peak, "traffic": None,
@@ -1255,7 +1469,10 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ("C3 sharded: HET items (id + 20-token bag over a 100 k-token table striped by TOKEN; "
+            "config": {"workload": ("C3 sharded: HET items (id + 20-token bag over a 100 k-token table REPLICATED on every rank; "
+                                    "per step the id-only exchanges + ONE all_reduce of the merged token gradient [n_tokens, d], "
+                                    "arx.dist.ShardedHMFRepTokens) -- " if rep_tokens else
+                                    "C3 sharded: HET items (id + 20-token bag over a 100 k-token table striped by TOKEN; "
                                     "per step all_reduce(pool partials, pool grads) + reduce_scatter(target partials) + "
                                     "all_gather(target grads), arx.dist.ShardedHMFBags) -- " if with_bags else "") +
                                    "C5 (BASELINE configs[4]): synthetic %d-item/%d-user HMF, dim %d, id-only, WMRB 'mw', "

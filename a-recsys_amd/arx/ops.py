@@ -852,6 +852,11 @@ def dropout_fwd_step(x, keep_prob, seed, step_dev, y, keep_mask):
          _p(step_dev), _p(y), _p(keep_mask), _stream())
 
 
+def merge_keyed_take(keys, ids, S, out):
+    """out[r] = id of the r-th smallest (key, position) pair, r < S (arx.h): the merge of sorted race lists."""
+    call("arx_merge_keyed_take", _p(keys), _p(ids), int(keys.shape[0]), int(S), _p(out), _stream())
+
+
 def take_i32(table, idx, out, fill=-1):
     call("arx_take_i32", _p(table), _p(idx), int(idx.shape[0]), int(fill), _p(out), _stream())
 

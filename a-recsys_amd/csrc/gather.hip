@@ -610,24 +610,25 @@ __global__ __launch_bounds__(256) void k_gather_onehot_multi(GatherSites gs, int
   const int64_t base = (int64_t)((int)blockIdx.x - blk0) * RPB + wv * GPW + gid;
   int64_t r[UN];
   int row[UN];
-  bool ok[UN];
+  bool ok[UN], hit[UN];
 #pragma unroll
   for (int u = 0; u < UN; ++u) {
     r[u] = base + u * (4 * GPW);                   // neighbouring sub-groups take neighbouring rows
     ok[u] = r[u] < n;
     row[u] = ok[u] ? ids[r[u]] : 0;
+    hit[u] = ok[u] && row[u] >= 0;                 // (id < 0: an EMPTY pool slot -- a zero row, k_lookup_multi)
   }
   if (cat_map) {
 #pragma unroll
-    for (int u = 0; u < UN; ++u) row[u] = ok[u] ? cat_map[row[u]] : 0;
+    for (int u = 0; u < UN; ++u) row[u] = hit[u] ? cat_map[row[u]] : 0;
   }
   float4 v[UN];
   float bv[UN];
 #pragma unroll
   for (int u = 0; u < UN; ++u) {
-    v[u] = (ok[u] && col < d) ? *reinterpret_cast<const float4*>(E + (int64_t)row[u] * d + col)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-    bv[u] = (ok[u] && bias_out && lig == 0) ? bias[(int64_t)row[u] * ldbi] : 0.f;
+    v[u] = (hit[u] && col < d) ? *reinterpret_cast<const float4*>(E + (int64_t)row[u] * d + col)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    bv[u] = (hit[u] && bias_out && lig == 0) ? bias[(int64_t)row[u] * ldbi] : 0.f;
   }
 #pragma unroll
   for (int u = 0; u < UN; ++u) {

@@ -1423,19 +1423,34 @@ int bag_token_apply(const BagWs& w, char* base, int64_t n_i, int max_len, float*
 
 namespace arx {
 
+#ifndef ARX_K7_RIDER_DEFAULT
+#define ARX_K7_RIDER_DEFAULT kRiderWin
+#endif
 static bool rider_hoff_ok(int64_t n, int64_t n0, int max_len, int d) {
   return runs_path(d) && bag_compact(n0, max_len) && runs_extract_blocks(n) <= 224;
 }
 
-// Round 5, opt-in (ARX_K7_RIDER_SPLIT=1): the rider's one-hot pass on run records too (they have to be in sorted
-// order: the extraction sweep's look-back path) and the apply cut by data flow -- see the apply phases below.  The
-// default stays the window + finish launches of rounds 3-4: the records lengthen the one-hot list's extraction sweep
-// by ~7 us on the step's sort branch and the two run-centric launches (23 + 34 us in the step) are no shorter than
-// window + finish + token apply (24 + 8 + 29): C3 230.5 / 231.5 against 227.8 / 227.9 us, same box, alternating runs.
-static bool rider_records(bool hoff_ok) {
-  static const bool split = [] { const char* e = getenv("ARX_K7_RIDER_SPLIT"); return e && e[0] == '1'; }();
-  return hoff_ok && split;
+// Round 5: the rider's one-hot pass on run records too (they have to be in sorted order: the extraction sweep's
+// look-back path) -- ARX_K7_RIDER = "win" (the default: window + finish launches over the one-hot list, then the token
+// apply: rounds 3-4) or "split" (phase 7 = the entity table's runs, phase 8 = one launch with the token runs and the
+// other tables' runs).  Measured at C3, same box, alternating runs: win 230.5 / 228.9 us, split 231.6 / 231.4 us --
+// the records lengthen the one-hot list's extraction sweep by ~7 us on the sort branch and the two run-centric
+// launches (23 + 34 us in the step) are no shorter than window + finish + token apply (24 + 8 + 29).  A third form,
+// the WHOLE apply in one launch with the token runs waiting inside it for the entity runs (arrival counters,
+// write-through merged rows), passed every test and measured 297 us: the one-hot runs alone fill the chip's
+// resident workgroups, so the token workgroups behind them cannot start early and only pay for the coupling.
+// Removed again.
+enum { kRiderWin = 0, kRiderSplit = 1 };
+static int rider_mode() {
+  static const int mode = [] {
+    const char* e = getenv("ARX_K7_RIDER");
+    if (e && !strcmp(e, "split")) return (int)kRiderSplit;
+    if (e && !strcmp(e, "win")) return (int)kRiderWin;
+    return (int)ARX_K7_RIDER_DEFAULT;
+  }();
+  return mode;
 }
+static bool rider_records(bool hoff_ok) { return hoff_ok && rider_mode() != kRiderWin; }
 
 int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const CatSites& st,
                                 const float* G, int64_t ldg, const float* Gb, const float* lr_dev,

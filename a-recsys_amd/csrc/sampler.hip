@@ -165,6 +165,35 @@ __global__ __launch_bounds__(256) void k_rank_take(const uint2* __restrict__ lis
   }
 }
 
+// The S smallest of m (key, id) pairs in (key, position) order -- the merge of the ranks' sorted race lists of ONE
+// pool draw over a sharded item set (arx.dist.draw_global_pool: position = rank-major, so ties go to the lower rank,
+// then to the earlier entry): the rank selection of k_rank_take over 64-bit (key bits, position) words, m <= 16 384
+// pairs in LDS.  Keys are non-negative floats or +inf (their bit patterns order like the values).
+__global__ __launch_bounds__(256) void k_merge_take(const float* __restrict__ keys, const int32_t* __restrict__ ids, int m,
+                                                    int64_t S, int32_t* __restrict__ out) {
+  extern __shared__ uint64_t sk[];
+  const int tid = threadIdx.x;
+  const int e0 = blockIdx.x * 16;
+  if (e0 >= m) return;
+  const int m2 = (m + 1) & ~1;
+  for (int i = tid; i < m2; i += 256)
+    sk[i] = i < m ? ((uint64_t)__float_as_uint(keys[i]) << 32) | (uint64_t)(uint32_t)i : ~0ull;
+  __syncthreads();
+  const int e = e0 + (tid >> 4), part = tid & 15;
+  const uint64_t key = e < m ? sk[e] : 0ull;
+  int chunk = ((m2 / 2 + 15) / 16) * 2;
+  if ((chunk & 31) == 0) chunk += 2;
+  const int jb = min(m2, part * chunk), je = min(m2, jb + chunk);
+  int rank = 0;
+  for (int j = jb; j < je; j += 2) {
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&sk[j]);
+    rank += (v.x < key) + (v.y < key);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) rank += __shfl_xor(rank, o, 16);
+  if (part == 0 && e < m && rank < S) out[rank] = ids[e];
+}
+
 __global__ void k_take_first(const int32_t* __restrict__ src, const uint32_t* __restrict__ keys,
                              const int32_t* __restrict__ n_live, int64_t S, int32_t* __restrict__ out,
                              float* __restrict__ out_keys) {
@@ -255,6 +284,17 @@ int arx_sample_wor_capped(const float* weights, int64_t n, int64_t S, uint64_t s
                           void* stream) {
   return arx_sample_wor_keys(weights, n, S, seed, counter, key_cap, out_idx, nullptr, workspace, workspace_bytes,
                              stream);
+}
+
+int arx_merge_keyed_take(const float* keys, const int32_t* ids, int64_t m, int64_t S, int32_t* out, void* stream) {
+  ARX_CHECK_ARG(keys && ids && out, "arx_merge_keyed_take: null pointer");
+  ARX_CHECK_ARG(m > 0 && m <= kCompactCap && S > 0 && S <= m, "arx_merge_keyed_take: need 0 < S <= m <= 16384");
+  const size_t lds = (size_t)((m + 1) & ~1ll) * 8;
+  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_take),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kCompactCap * 8));
+  k_merge_take<<<(int)ceil_div(m, 16), 256, lds, as_stream(stream)>>>(keys, ids, (int)m, S, out);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
 }
 
 int arx_sample_wor_keys(const float* weights, int64_t n, int64_t S, uint64_t seed, uint64_t counter,

@@ -308,6 +308,13 @@ int arx_sample_wor_capped(const float* weights, int64_t n, int64_t S, uint64_t s
                           float key_cap, int32_t* out_idx, void* workspace, size_t workspace_bytes,
                           void* stream);
 size_t arx_sample_wor_keys_workspace_bytes(int64_t n, int64_t S, float key_cap);
+/* The S smallest of m (key, id) pairs in (key, position) order: out[r] = id of the pair of rank r.  Merges the
+ * ranks' race lists of ONE negative-pool draw over an item set whose weights are sharded (utils/prepare_train.py:7-17
+ * draws the pool from one distribution; arx.dist.draw_global_pool all-gathers every rank's S smallest (key, id) pairs
+ * rank-major: ties go to the lower rank, then to the earlier entry -- a stable order, identical on every rank).
+ * keys: non-negative floats or +inf.  m <= 16384, 0 < S <= m.  One launch. */
+int arx_merge_keyed_take(const float* keys, const int32_t* ids, int64_t m, int64_t S, int32_t* out, void* stream);
+
 /* ... and the race keys of the drawn items (out_keys [S], ascending; +inf where out_idx is -1; NULL:
  * not wanted).  For ONE draw over an item set that is sharded over several ranks (the reference draws
  * its S negatives from one distribution, prepare_train.py:7-17): every rank races its own shard
@@ -607,10 +614,10 @@ int arx_sparse_adagrad_cat_multi_phase(int phase, int ntables, float* const* E, 
  *   phase 5 = the one-hot keys + sort (+ the bag offsets), phase 6 = the token chain (needs 5),
  *   phase 7 = the one-hot apply with its side output (needs 5 and G), phase 8 = the token apply
  *   (needs 6 and 7) -- so the tail of the token chain can run under the one-hot apply.
- * Round 5, opt-in (ARX_K7_RIDER_SPLIT=1; measured 3 us/step slower than the default at C3): the
- * one-hot list gets run records in sorted order as well and the two apply phases cut the work by data flow:
- *   phase 7 = the runs of table 0 alone (Adagrad on its rows + the merged rows),
- *   phase 8 = ONE launch: the token runs over the merged rows + the runs of the other one-hot tables.
+ * Round 5 (ARX_K7_RIDER = win | split): with `split` the one-hot list gets run records in
+ * sorted order as well and the two apply phases cut the work by data flow: phase 7 = the runs of table 0 alone
+ * (Adagrad on its rows + the merged rows), phase 8 = ONE launch with the token runs over the merged rows and the runs
+ * of the other one-hot tables.  `win` (the default) measured 1-3 us/step faster at C3.
  * bag_workspace >= arx_sparse_adagrad_bags_workspace_bytes(lookups of table 0, max_len, d). */
 int arx_sparse_adagrad_cat_multi_bags(int phase, int ntables, float* const* E, float* const* acc,
                                       float* const* bias, float* const* bias_acc,

@@ -51,6 +51,34 @@ class NumpyBackend(object):
         ba[rows] = ba[rows] + gb[rows] ** 2
         b[rows] = b[rows] - lrv * gb[rows] / np.sqrt(ba[rows])
 
+    def bags_grad_dense(self, D, Db, vals, starts, lens, sites, G, Gb):
+        e, b = _n(D), _n(Db)
+        v, st, ln = _n(vals), _n(starts), _n(lens)
+        g_all, gb_all = _n(G).astype(np.float64), _n(Gb).astype(np.float64)
+        g = np.zeros(e.shape, dtype=np.float64)
+        gb = np.zeros(e.shape[0], dtype=np.float64)
+        for ids, base, coef in sites:
+            for j, i in enumerate(_n(ids).astype(np.int64)):
+                for t in v[st[i]:st[i] + ln[i]].astype(np.int64):
+                    if 0 <= t < e.shape[0]:
+                        g[t] += coef / float(ln[i]) * g_all[base + j][:e.shape[1]]
+                        gb[t] += coef / float(ln[i]) * gb_all[base + j]
+        e[...] = (e + g).astype(np.float32)
+        b[...] = (b + gb).astype(np.float32)
+
+    def adagrad_dense(self, w, acc, g, lr):
+        ww, aa, gg = _n(w), _n(acc), _n(g).astype(np.float64)
+        a2 = aa.astype(np.float64) + gg * gg
+        ww[...] = (ww - float(_n(lr)[0]) * gg / np.sqrt(a2)).astype(np.float32)
+        aa[...] = a2.astype(np.float32)
+
+    def fill_zero(self, t):
+        _n(t)[...] = 0
+
+    def take_i32(self, table, idx, out, fill):
+        i = _n(idx).astype(np.int64)
+        _n(out)[...] = np.where(i >= 0, _n(table)[np.maximum(i, 0)], fill).astype(np.int32)
+
     def gather_rows_packed(self, E, bias, rows, out):
         r = _n(rows).astype(np.int64)
         d = _n(E).shape[1]

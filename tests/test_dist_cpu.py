@@ -158,9 +158,10 @@ def test_seq_data_parallel_collectives_gloo(tmp_path, world):
     assert all(os.path.exists(tmp_path / ("dp%d" % r)) for r in range(world))
 
 
-def _bags_worker(rank, world, port, out_dir):
-    """Token-sharded multi-hot table (arx.dist.ShardedHMFBags): HET items = mean(id row, bag mean),
-    id table striped by item, token table striped by token; vs the single-process oracle."""
+def _bags_worker(rank, world, port, out_dir, replicated=False):
+    """Multi-hot item table on the sharded step: HET items = mean(id row, bag mean), id table striped by item and
+    the token table striped by token (arx.dist.ShardedHMFBags) or REPLICATED with one all-reduce of its merged
+    gradient (arx.dist.ShardedHMFRepTokens, round 5); vs the single-process oracle."""
     for p in (ROOT, os.path.join(ROOT, "a-recsys_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -169,7 +170,7 @@ def _bags_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from arx.dist import ShardedHMFBags
+    from arx.dist import ShardedHMFBags, ShardedHMFRepTokens
     from arx.utils.synthetic import SyntheticHMF
     from numpy_backend import NumpyBackend
     from oracle import ref_graph as rg
@@ -184,8 +185,9 @@ def _bags_worker(rank, world, port, out_dir):
               'item_bias': params['item_bias_cat_0'][2:], 'token': params['itemembed_mulhot_0'],
               'token_bias': params['item_bias_mulhot_0']}
     bags = (np.asarray(ia.features_mulhot[0]), np.asarray(ia.mulhot_starts[0]), np.asarray(ia.mulhot_lengths[0]))
-    model = ShardedHMFBags(n_users, n_items, d, B_loc, S, 0.5, rank, world, 'cpu', bags, n_tok,
-                           backend=NumpyBackend(), tables=tables)
+    cls = ShardedHMFRepTokens if replicated else ShardedHMFBags
+    model = cls(n_users, n_items, d, B_loc, S, 0.5, rank, world, 'cpu', bags, n_tok,
+                backend=NumpyBackend(), tables=tables)
     own_users = np.arange(rank, n_users, world)
     ptr = np.zeros(len(own_users) + 2, dtype=np.int32)
     items = []
@@ -204,7 +206,8 @@ def _bags_worker(rank, world, port, out_dir):
     for step in range(4):
         pool = None
         if step % 2 == 0:
-            blocks = [rng.choice(np.arange(g, n_items, world), size=S // world, replace=False) for g in range(world)]
+            blocks = [rng.choice(np.arange(g, n_items, world), size=S // world + (1 if g < S % world else 0),
+                                 replace=False) for g in range(world)]
             pool = np.concatenate(blocks).astype(np.int32)
             id2idx = {int(v): i for i, v in enumerate(pool)}
             model.set_pool(pool)
@@ -240,6 +243,15 @@ def test_token_sharded_bags_match_oracle_gloo(tmp_path, world):
     import torch.multiprocessing as mp
     port = 29300 + (os.getpid() % 400) + world
     mp.spawn(_bags_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("bags%d" % r)) for r in range(world))
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_replicated_token_table_matches_oracle_gloo(tmp_path, world):
+    """ShardedHMFRepTokens: id table striped, token table replicated, its merged gradient all-reduced (round 5)."""
+    import torch.multiprocessing as mp
+    port = 29700 + (os.getpid() % 400) + world
+    mp.spawn(_bags_worker, args=(world, port, str(tmp_path), True), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ("bags%d" % r)) for r in range(world))
 
 

@@ -61,14 +61,15 @@ def test_sharded_hip_backend_world1(dev, graphs, B, S):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("replicated", [False, True])
 @pytest.mark.parametrize("n_users,n_items,V,d,B,S", [(300, 500, 120, 64, 32, 64), (3000, 4000, 900, 32, 2048, 256)])
-def test_token_sharded_bags_hip_backend_world1(dev, n_users, n_items, V, d, B, S):
-    """ShardedHMFBags (HET items: id table striped by item, token table striped by token) on the HIP
-    backend with a 1-rank RCCL group vs the oracle; the second shape is past the rank-sort limits
-    (radix sort + window apply in both K7 passes)."""
+def test_token_sharded_bags_hip_backend_world1(dev, n_users, n_items, V, d, B, S, replicated):
+    """ShardedHMFBags (HET items: id table striped by item, token table striped by token) and ShardedHMFRepTokens
+    (token table replicated, its merged gradient all-reduced: round 5) on the HIP backend with a 1-rank RCCL group
+    vs the oracle; the second shape is past the rank-sort limits (radix sort + window apply in both K7 passes)."""
     import torch
     import torch.distributed as dist
-    from arx.dist import ShardedHMFBags
+    from arx.dist import ShardedHMFBags, ShardedHMFRepTokens
     from arx.utils.synthetic import SyntheticHMF
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29734")
@@ -85,7 +86,8 @@ def test_token_sharded_bags_hip_backend_world1(dev, n_users, n_items, V, d, B, S
                   'item_bias': params['item_bias_cat_0'][2:], 'token': params['itemembed_mulhot_0'],
                   'token_bias': params['item_bias_mulhot_0']}
         bags = (np.asarray(ia.features_mulhot[0]), np.asarray(ia.mulhot_starts[0]), np.asarray(ia.mulhot_lengths[0]))
-        model = ShardedHMFBags(n_users, n_items, d, B, S, 0.5, 0, 1, dev, bags, n_tok, tables=tables)
+        cls = ShardedHMFRepTokens if replicated else ShardedHMFBags
+        model = cls(n_users, n_items, d, B, S, 0.5, 0, 1, dev, bags, n_tok, tables=tables)
         ptr = np.concatenate([syn.pos_ptr[:n_users + 1], [syn.pos_ptr[n_users]]]).astype(np.int32)
         model.set_positives(ptr, syn.pos_items)
         ref = rg.RefLatentProductModel(d, B, 0.5, syn.u_attr, syn.i_attr, syn.item_ind2logit_ind_dict(),
@@ -265,6 +267,89 @@ def _two_rank_worker(rank, world, port, out_dir, graphs=True):
     with open(os.path.join(out_dir, "ok%d" % rank), "w") as f:
         f.write("ok")
     dist.destroy_process_group()
+
+
+def _two_rank_rep_worker(rank, world, port, out_dir):
+    """ShardedHMFRepTokens on the HIP backend, two rank processes on the one GPU (gloo underneath): id table striped,
+    token table replicated, the merged token gradient all-reduced; five steps vs the oracle on the global batch."""
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "a-recsys_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    from arx.dist import ShardedHMFRepTokens
+    from arx.utils.synthetic import SyntheticHMF
+
+    n_users, n_items, d, B_loc, S, V = 601, 1003, 64, 1024, 256, 300   # past the rank-sort limits of both K7 passes
+    syn = SyntheticHMF(n_users=n_users, n_items=n_items, seed=1, permute_logits=False, n_pos=8,
+                       item_mulhot=True, mulhot_vocab=V, avg_len=5, max_len=12)
+    ia = syn.i_attr
+    n_tok = ia._embedding_classes_list_mulhot[0]
+    params = syn.glorot_params(d, seed=2, scale=0.5)
+    tables = {'user': params['userembed_cat_0'][2:], 'item': params['itemembed_cat_0'][2:],
+              'item_bias': params['item_bias_cat_0'][2:], 'token': params['itemembed_mulhot_0'],
+              'token_bias': params['item_bias_mulhot_0']}
+    bags = (np.asarray(ia.features_mulhot[0]), np.asarray(ia.mulhot_starts[0]), np.asarray(ia.mulhot_lengths[0]))
+    model = ShardedHMFRepTokens(n_users, n_items, d, B_loc, S, 0.5, rank, world, dev, bags, n_tok, tables=tables)
+    own_users = np.arange(rank, n_users, world)
+    ptr = np.zeros(len(own_users) + 2, dtype=np.int32)
+    its = []
+    for k, u in enumerate(own_users):
+        its.extend(syn.pos_items[syn.pos_ptr[u]:syn.pos_ptr[u + 1]].tolist())
+        ptr[k + 1] = len(its)
+    ptr[-1] = ptr[-2]
+    model.set_positives(ptr, np.asarray(its, dtype=np.int32))
+    B = B_loc * world
+    ref = rg.RefLatentProductModel(d, B, 0.5, syn.u_attr, syn.i_attr, syn.item_ind2logit_ind_dict(),
+                                   syn.logit_ind2item_ind, loss_function='mw', n_sampled=S, params=params,
+                                   dtype=np.float64)
+    pos = syn.positives_dict()
+    ref.prepare_warp(pos, pos)
+    rng = np.random.default_rng(5)                                    # identical stream on both ranks
+    for step in range(5):
+        pool = None
+        if step in (0, 2):
+            pool = syn.sample_pool(S, rng)                            # any owners: blocks of unequal size
+            if step == 2:                                             # ... and an all-on-one-owner pool
+                pool = rng.choice(np.arange(1, n_items, world), size=S, replace=False).astype(np.int32)
+            id2idx = {int(v): i for i, v in enumerate(pool)}
+            model.set_pool(pool)
+            cur = pool
+        gu, gi = [], []
+        for g in range(world):
+            lu = rng.integers(0, len(np.arange(g, n_users, world)), size=B_loc)
+            users = lu * world + g
+            k = rng.integers(0, syn.n_pos, size=B_loc)
+            gu.append(users)
+            gi.append(syn.pos_items[syn.pos_ptr[users] + k])
+        gi[0][0] = cur[0]                                             # a target that is also a pool slot
+        l_ref = ref.step(np.concatenate(gu).tolist(), np.concatenate(gi).tolist(), pool, id2idx, loss='mw')
+        model.step(gu[rank].astype(np.int32), gi[rank].astype(np.int32))
+        np.testing.assert_allclose(float(model.read_loss().item()), l_ref, rtol=1e-4, err_msg='step %d' % step)
+    got = model.gather_global_tables()
+    P = ref.att_emb.params
+    for name, want in (('user', P['userembed_cat_0'][2:]), ('item', P['itemembed_cat_0'][2:]),
+                       ('item_bias', P['item_bias_cat_0'][2:, 0]), ('token', P['itemembed_mulhot_0']),
+                       ('token_bias', P['item_bias_mulhot_0'][:, 0])):
+        np.testing.assert_allclose(got[name], want, rtol=1e-4, atol=2e-6, err_msg=name)
+    with open(os.path.join(out_dir, "rep%d" % rank), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+def test_replicated_token_table_two_ranks_one_gpu(dev, tmp_path):
+    """Round 5: the redesigned multi-hot step of the sharded model (ShardedHMFRepTokens) with its N > 1 branches on the
+    HIP backend -- two rank processes on the test box's one GPU, gloo underneath (as the id-only two-rank test)."""
+    import torch.multiprocessing as mp
+    port = 29760 + (os.getpid() % 100)
+    mp.spawn(_two_rank_rep_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(tmp_path / ("rep%d" % r)) for r in range(2))
 
 
 @pytest.mark.parametrize("graphs", [True, False])

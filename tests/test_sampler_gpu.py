@@ -199,3 +199,24 @@ def test_device_sampler_heavy_tailed_weights(dev):
     few[:10] = 1.0
     with pytest.raises(ValueError):
         DeviceSampler(np.arange(200000, dtype=np.int32), few, device=dev).sample(64)
+
+
+@pytest.mark.parametrize("world,S", [(2, 60), (8, 1024), (3, 1000), (16, 1024)])
+def test_merge_keyed_take_equals_stable_argsort(dev, world, S):
+    """arx_merge_keyed_take (the merge of the ranks' race lists in arx.dist.draw_global_pool): the S smallest of the
+    world * S (key, id) pairs in (key, position) order == torch's stable argsort, incl. tied keys across ranks,
+    +inf / id -1 tails of short shards and a zero key."""
+    import torch
+    from arx import ops
+    rng = np.random.default_rng(world * 1000 + S)
+    keys = np.sort(rng.exponential(size=(world, S)).astype(np.float32), axis=1)
+    ids = rng.permutation(world * S).astype(np.int32).reshape(world, S)
+    keys[1, :5] = keys[0, :5]                      # ties between ranks: the lower rank first
+    keys[0, 0] = 0.0
+    keys[-1, S // 2:] = np.inf                     # a short shard
+    ids[-1, S // 2:] = -1
+    tk, ti = torch.from_numpy(keys.reshape(-1)).to(dev), torch.from_numpy(ids.reshape(-1)).to(dev)
+    out = torch.full((S,), -7, dtype=torch.int32, device=dev)
+    ops.merge_keyed_take(tk, ti, S, out)
+    want = ti[torch.argsort(tk, stable=True)[:S]]
+    assert torch.equal(out, want)
