@@ -305,7 +305,7 @@ __global__ void k_site_onehot(const int32_t* __restrict__ cat_map, const int32_t
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     const int id = ids[i];
-    keys_out[i] = cat_map ? cat_map[id] : id;
+    keys_out[i] = id < 0 ? ARX_KEY_NONE : (cat_map ? cat_map[id] : id);     // (id < 0: an empty pool slot, no update)
     if (src_out) src_out[i] = row_base + (int32_t)i;
     if (coef_out) coef_out[i] = coef;
   }

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_cat_keys(CatSites st, int32_t* __restri
       if (k < st.nsites && i >= st.offs[k]) s = k;
     const int64_t j = i - st.offs[s];
     const int id = st.ids[s][j];
-    int key = st.cat_map[s] ? st.cat_map[s][id] : id;
+    int key = id < 0 ? -1 : (st.cat_map[s] ? st.cat_map[s][id] : id);     // (id < 0: an empty pool slot, no update)
     if (key < 0 || key >= table_rows) key = ARX_KEY_NONE;
     keys[i] = key;
     src[i] = st.row_base[s] + (int32_t)j;

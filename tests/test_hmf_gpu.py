@@ -588,7 +588,9 @@ def test_hmf_empty_pool_slot_is_a_zero_row(dev):
         assert not ga['itemembed_cat_0'][xrow].any() and not ga['item_bias_cat_0'][xrow].any()   # nothing written
         assert gb['itemembed_cat_0'][xrow].any()                                                 # the twin's X moved
         assert np.array_equal(ga['userembed_cat_0'], gb['userembed_cat_0'])
-        assert np.array_equal(ga['itemembed_cat_0'][keep], gb['itemembed_cat_0'][keep])
-        assert np.array_equal(ga['item_bias_cat_0'][keep], gb['item_bias_cat_0'][keep])
+        # (the item table's pass sorts one contribution more in the twin: runs of duplicate targets may be cut into
+        # sub-sums at other positions -- the same sums in another association, not bit for bit)
+        np.testing.assert_allclose(ga['itemembed_cat_0'][keep], gb['itemembed_cat_0'][keep], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(ga['item_bias_cat_0'][keep], gb['item_bias_cat_0'][keep], rtol=1e-5, atol=1e-7)
     ga = models[0].att_emb.get_params()
     assert not ga['itemembed_cat_0'][xrow].any() and all(np.isfinite(v).all() for v in ga.values())
