@@ -1574,9 +1574,23 @@ class Plan(object):
                             ops.copy_words(pf)
                         self._execute()
                     except BaseException:
-                        g.end()
+                        # (the capture may already be invalidated: ending it raises again -- the ORIGINAL error is the
+                        # one that has to surface; advisor, round 4)
+                        try:
+                            g.end()
+                        except BaseException:
+                            pass
+                        if pf:
+                            rt.pending_feeds = list(pf) + list(getattr(rt, 'pending_feeds', []))
                         raise
-                    g.end(feeds=pf)
+                    try:
+                        g.end(feeds=pf)
+                    except BaseException:
+                        # feed nodes not found as captured (node count mismatch): the feeds taken out of the queue
+                        # go back in front of it, so that an eager retry of the step still feeds its placeholders
+                        if pf:
+                            rt.pending_feeds = list(pf) + list(getattr(rt, 'pending_feeds', []))
+                        raise
                 torch.cuda.current_stream().wait_stream(side)
                 self.graph = g
             elif pf and self.graph.feeds_match(pf):

@@ -358,7 +358,21 @@ class LatentProductModel(object):
         the run records (K7, hmf_model.py:146-151) -- then runs for step t + 1 as a side branch of step t's graph,
         off the critical path.  item_sampled: the pool step t + 1 will be given, if it is a new one.  Optional:
         step() without it (or with other ids than announced) computes the same numbers, bit for bit."""
-        self._next_batch = (user_input, item_input, item_sampled)
+        # (advisor, round 4) identity alone does not see a loader that refills the announced buffers in place: torch
+        # tensors are remembered with their version counters, anything else (numpy arrays, lists) is COPIED here
+        self._next_batch = tuple(self._announce(x) for x in (user_input, item_input, item_sampled))
+
+    @staticmethod
+    def _announce(x):
+        import torch
+        if x is None or isinstance(x, torch.Tensor):
+            return x
+        return np.array(x, dtype=np.int32, copy=True)
+
+    @staticmethod
+    def _versions(t):
+        import torch
+        return tuple((x._version if isinstance(x, torch.Tensor) else None) for x in t)
 
     def _ring_feed(self, plan, item_sampled):
         """step t: queue the announced ids of step t + 1 into the next-step placeholders; True if the plan may run
@@ -375,9 +389,12 @@ class LatentProductModel(object):
             return False                      # a lookup this method does not know how to announce
         # what step t - 1 sorted ahead is only valid for the ids it was told (tensor identity; a pool given now
         # must be the one announced)
-        if ann is None or ann[0] is not self._cur[0] or ann[1] is not self._cur[1] or \
-                (item_sampled is not None and ann[2] is not item_sampled):
-            plan._ring_ready = False
+        same = lambda a, b: a is b or (isinstance(a, np.ndarray) and not hasattr(b, '_version')
+                                       and np.array_equal(a, np.asarray(b)))
+        if ann is None or not same(ann[0], self._cur[0]) or not same(ann[1], self._cur[1]) or \
+                (item_sampled is not None and not same(ann[2], item_sampled)) or \
+                self._versions(ann) != getattr(self, '_announced_versions', None):
+            plan._ring_ready = False        # other ids than announced (or announced buffers refilled since): sort now
         if not plan._ring_ready:
             plan.ring_bootstrap()
         for n in plan.ring_ids():
@@ -388,6 +405,7 @@ class LatentProductModel(object):
             else:
                 n.feed_next(item_sampled if item_sampled is not None else n.value)   # same pool as this step
         self._announced = nxt
+        self._announced_versions = self._versions(nxt)
         plan.ring_req = True
         return True
 

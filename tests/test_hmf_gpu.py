@@ -442,8 +442,8 @@ def test_hmf_streaming_eval_loss(dev, monkeypatch, cfg, loss):
 def test_hmf_prepare_next_ring_mode_bit_identical(dev, monkeypatch, cfg):
     """prepare_next (ring mode: the K7 sort half of step t + 1 runs as a side branch of step t): the same steps with
     and without the announcement leave bit-identical tables and losses -- through graph capture of both parities, a
-    pool redraw that is announced, one that is NOT, and a step without announcement in the middle -- and match the
-    oracle."""
+    pool redraw that is announced, one that is NOT, a step without announcement in the middle and an announced
+    buffer that is refilled in place before its step -- and match the oracle."""
     import torch
     monkeypatch.setenv('ARX_K7_EARLY_MIN', '0')           # (the sort branch exists at this small size too)
     B, S, d = 512, 128, 64
@@ -468,6 +468,12 @@ def test_hmf_prepare_next_ring_mode_bit_identical(dev, monkeypatch, cfg):
         if k + 1 < steps and k != 4:                      # (step 4 announces nothing: step 5 sorts for itself)
             nxt_pool = tp.get(k + 1) if k + 1 != 9 else None      # the redraw of step 9 is NOT announced
             m_ring.prepare_next(tb[k + 1][0], tb[k + 1][1], nxt_pool)
+            if k == 7:
+                # (advisor, round 4) a loader refills the ANNOUNCED buffer in place before step 8 runs: same tensor
+                # object, other ids -- the sort done ahead is stale and step 8 has to sort for itself
+                u8 = np.roll(batches[8][0], 3)
+                batches[8] = (u8, batches[8][1])
+                tb[8][0].copy_(torch.from_numpy(u8.astype(np.int32)).to(dev_))
         l_b = m_ring.step(None, tb[k][0], tb[k][1], None, tp.get(k), None, loss='mw')
         assert l_a == l_b, (k, l_a, l_b)
         np.testing.assert_allclose(l_a, l_ref, rtol=RTOL, err_msg='step %d' % k)
