@@ -78,9 +78,10 @@ class HipBackend(object):
         self.ops.gather_mulhot_mean(E, bias, vals, starts, lens, ids, out, scale=scale, accumulate=accumulate,
                                     bias_out=bias_out)
 
-    def bags_adagrad(self, E, acc, bias, bias_acc, vals, starts, lens, sites, G, Gb, lr):
+    def bags_adagrad(self, E, acc, bias, bias_acc, vals, starts, lens, sites, G, Gb, lr, phase=3):
         """Two-stage multi-hot pass (arx_sparse_adagrad_bags); sites: [(entity ids, row_base, coef)].
-        Tokens >= E.shape[0] (rows of other shards, mapped to the padding row) are dropped."""
+        Tokens >= E.shape[0] (rows of other shards, mapped to the padding row) are dropped.
+        phase 1: both sorts (ids only), 2: merge + apply, 3: both."""
         ops = self.ops
         # one workspace per SHAPE of the pass (counts, row bases, coefficients); the id tensors may be
         # fresh every step (prepare_route): only the pointer arrays are rebuilt then
@@ -95,7 +96,20 @@ class HipBackend(object):
             ent = cache[key] = [None, None, ops.Workspace(G.device)]
         if ent[0] != ptrs:
             ent[0], ent[1] = ptrs, ops.BagSiteArgs(sites, mx[lens.data_ptr()][1])
-        ops.sparse_adagrad_bags(E, acc, bias, bias_acc, vals, starts, lens, ent[1], G, Gb, lr, ent[2])
+        ops.sparse_adagrad_bags(E, acc, bias, bias_acc, vals, starts, lens, ent[1], G, Gb, lr, ent[2], phase=phase)
+
+    def lookup_het_multi(self, sites):
+        """The step's lookups in ONE launch (arx_lookup_multi) where items are HET (id row + bag mean, both halved):
+        sites = LookupSet tuples (E_id, bias_id, cat_map, E_tok, bias_tok, vals, starts, lens, ids, out, scale,
+        bias_out); static buffers: the descriptor is built once per set of addresses."""
+        key = tuple((x[8].data_ptr(), int(x[8].shape[0]), x[9].data_ptr()) for x in sites)
+        cache = self.__dict__.setdefault('_lsets', {})
+        ls = cache.get(key)
+        if ls is None:
+            if len(cache) > 16:
+                cache.clear()
+            ls = cache[key] = self.ops.LookupSet(sites)
+        self.ops.lookup_multi(ls)
 
     def gather_rows_packed(self, E, bias, rows, out):
         self.ops.gather_onehot_packed(E, bias, None, rows, out)
@@ -186,13 +200,13 @@ class HipBackend(object):
                                              torch.empty(ent.total, dtype=torch.float32, device=G.device))
         ops.sparse_adagrad_cat_multi(ent, G, Gb, lr, kb, sb, cb, self.ws_k7, phase=phase)
 
-    def bags_grad_dense(self, D, Db, vals, starts, lens, sites, G, Gb):
+    def bags_grad_dense(self, D, Db, vals, starts, lens, sites, G, Gb, phase=3):
         """D[t] += sum of the gradient rows of the bags that hold token t (coefficient coef / len), Db likewise: the
         two-stage multi-hot pass in its gradient-descent form (no slots) with a step of -1 onto a gradient table --
         0 - (-1) g = g, the merged sums themselves, bit for bit.  Tokens >= D.shape[0] are dropped."""
         if getattr(self, '_neg_one', None) is None:
             self._neg_one = torch.tensor([-1.0], dtype=torch.float32, device=D.device)
-        self.bags_adagrad(D, None, Db, None, vals, starts, lens, sites, G, Gb, self._neg_one)
+        self.bags_adagrad(D, None, Db, None, vals, starts, lens, sites, G, Gb, self._neg_one, phase=phase)
 
     def adagrad_dense(self, w, acc, g, lr):
         self.ops.adagrad_dense(w, acc, g, lr)
@@ -234,8 +248,8 @@ class ShardedHMF(object):
         # hipGraph segments (_step_static): the product backend on a GPU, unless switched off
         if graphs is None:
             graphs = not os.environ.get("ARX_DIST_EAGER")
-        self.use_graphs = bool(graphs) and type(self) is ShardedHMF and isinstance(self.be, HipBackend) \
-            and self.device.type == 'cuda'
+        self.use_graphs = bool(graphs) and getattr(self, '_static_step_ok', type(self) is ShardedHMF) \
+            and isinstance(self.be, HipBackend) and self.device.type == 'cuda'
         self._graphs, self._graph_key, self._warm_key, self.g_idx = {}, None, None, None
         self.n_captures, self.n_replays = 0, 0
         # (the legacy default stream cannot be captured: the step runs on a stream of its own, joined with
@@ -558,6 +572,7 @@ class ShardedHMF(object):
             self.g_idx = torch.empty(n_idx, dtype=torch.int32, device=dev)
         feed = [(idx, self.g_idx)]                     # (a kernel: a device-to-device hipMemcpyAsync costs more;
         #                                                since round 4 the first node of the step's first graph)
+        feed += self._static_feeds(route, cap_r)       # (subclasses: more per-batch index vectors)
         key = (cap, cap_r, self.g_idx.data_ptr(), self.arena.data_ptr(), self.pos_ptr.data_ptr(),
                self.pos_items.data_ptr())
         if os.environ.get("ARX_DIST_NO_CAPTURE"):        # (profiling: the static step, launched kernel by kernel)
@@ -579,7 +594,11 @@ class ShardedHMF(object):
 
         # world 1: nothing travels, so nothing is packed twice -- the pool bias goes straight to b_all, the pool
         # gradient and its row sums straight into the K7 arena, the target-bias gradient straight into arena_b
+        het = getattr(self, '_het', False)             # ShardedHMFRepTokens: the owner forms HET rows, token table replicated
+
         def fwd_gather():      # the step's three lookups, one launch
+            if het:
+                return self._het_gather(urows, T_in, cap, cap_r)
             if W == 1:
                 be.gather_rows_multi([(self.E_user, None, urows, self.U_loc, None),
                                       (self.E_item, self.b_item, self.pool_rows, self.I_all, self.b_all),
@@ -628,6 +647,8 @@ class ShardedHMF(object):
             be.copy_strided(self.gb_all, self.dI_all[:S, d])
 
         def k7(phase):
+            if het:
+                return self._het_k7(phase, urows, rrows[:B_loc] if W == 1 else rrows, cap, cap_r)
             be.sparse_adagrad_multi([(self.E_user, self.A_user, None, None),
                                      (self.E_item[:ni], self.A_item[:ni], self.b_item[:ni], self.Ab_item[:ni])],
                                     [(0, urows, 0), (1, self.pool_rows[:cap], B_loc),
@@ -641,6 +662,8 @@ class ShardedHMF(object):
                                        arena_b[B_loc:B_loc + cap])])
                 be.copy_strided(arena[B_loc + Sg:B_loc + Sg + cap_r, d], arena_b[B_loc + Sg:B_loc + Sg + cap_r])
             k7(2)
+            if het and W == 1:
+                self._het_tok_apply()                  # (one rank: nothing to sum, the dense step follows at once)
 
         def k7_sorts(own_graph):
             # K7's keys, sorts and run records need the ids only: on a second stream, under the forward
@@ -685,6 +708,10 @@ class ShardedHMF(object):
             w_dt.wait()
             torch.cuda.current_stream(dev).wait_event(sorted_)
             seg('apply', apply)
+            if het:            # the merged token gradients of all ranks, then the same dense Adagrad step everywhere
+                dist.all_reduce(self.D_tok, op=dist.ReduceOp.SUM, group=grp)
+                dist.all_reduce(self.Db_tok, op=dist.ReduceOp.SUM, group=grp)
+                seg('tok_apply', self._het_tok_apply)
         if mode == 'eager':
             self._warm_key = key
         elif mode == 'capture':
@@ -693,6 +720,9 @@ class ShardedHMF(object):
         else:
             self.n_replays += 1
         self.steps += 1
+
+    def _static_feeds(self, route, cap_r):
+        return []
 
     def read_loss(self):
         """Global mean loss of the last step (device scalar; one tiny all-reduce)."""
@@ -884,14 +914,18 @@ class ShardedHMFRepTokens(ShardedHMF):
     id shard's own K7 pass; the token-striped step moves 2 x B x (d + 4) x 4 B with B the GLOBAL batch
     (predicted comm / compute 0.35 against 0.57 at N = 8, B_loc = 16384)."""
 
+    _static_step_ok = True          # (ShardedHMF.__init__: the hipGraph-segment step serves this class too)
+    _het = True
+
     def __init__(self, n_users, n_items, d, B_loc, S, learning_rate, rank, world, device, bags, n_tokens,
-                 backend=None, group=None, tables=None, seed=0, acc0=0.1):
+                 backend=None, group=None, tables=None, seed=0, acc0=0.1, graphs=None):
         super().__init__(n_users, n_items, d, B_loc, S, learning_rate, rank, world, device, backend=backend,
-                         group=group, tables=tables, seed=seed, acc0=acc0, graphs=False)
+                         group=group, tables=tables, seed=seed, acc0=acc0, graphs=graphs)
         dev, f32, i32 = self.device, torch.float32, torch.int32
         vals, starts, lens = [np.asarray(a) for a in bags]
         nt = int(n_tokens)
         self.n_tokens = nt
+        self.g_gid = None               # received target ids (global), padded with the padding entity: fed per step
         if tables is not None:
             self.E_tok = torch.zeros((nt + 1, d), dtype=f32, device=dev)
             self.E_tok[:nt].copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(tables['token'], dtype=np.float32))))
@@ -924,6 +958,11 @@ class ShardedHMFRepTokens(ShardedHMF):
         self.Db_tok = torch.zeros((nt,), dtype=f32, device=dev)
         self.pool_ext = torch.zeros(S + 1, dtype=i32, device=dev)     # pool ids + the padding entity
         self.block_ids = torch.zeros(S, dtype=i32, device=dev)        # global item id of every row of the owned block
+        # global item id (or the padding entity) -> row of the id shard (the shard's zero row where not owned): the
+        # map the one-launch HET lookup of the static step takes beside the bag index (both indexed by global id)
+        g = np.arange(n_ent + 1, dtype=np.int64)
+        lm = np.where((g < n_items) & (g % world == rank), g // world, self.zero_row).astype(np.int32)
+        self.lmap = torch.from_numpy(lm).to(dev)
 
     def set_pool(self, pool_ids):
         super().set_pool(pool_ids)
@@ -934,6 +973,58 @@ class ShardedHMFRepTokens(ShardedHMF):
             be.copy_i32(self.pool_ids, self.block_ids)
         else:          # block row -> pool slot (S: padding) -> item id (padding entity)
             be.take_i32(self.pool_ext, self.my_slots, self.block_ids, self.pad_item)
+
+    # ---- the hipGraph-segment step (ShardedHMF._step_static) with HET rows and the replicated token table ----
+    def _static_feeds(self, route, cap_r):
+        gid = route.get('gid')
+        if gid is None or gid.shape[0] != cap_r:
+            gid = torch.full((cap_r,), self.pad_item, dtype=torch.int32, device=self.device)
+            R = route['R']
+            if R > 0:
+                gid[:R] = route['recv_ids'][:R]
+            route['gid'] = gid
+        if self.g_gid is None or self.g_gid.shape[0] != cap_r:
+            self.g_gid = torch.empty(cap_r, dtype=torch.int32, device=self.device)
+        return [(gid, self.g_gid)]
+
+    def _het_gather(self, urows, T_in, cap, cap_r):
+        """users, the owned pool block and the requested target rows in ONE launch (arx_lookup_multi): item rows =
+        (id row + bag mean) / 2 with their biases, then the two bias columns of the packed rows."""
+        be, d, W = self.be, self.d, self.world
+        bag = (self.bag_vals, self.bag_starts, self.bag_lens)
+        item = (self.E_item, self.b_item, self.lmap, self.E_tok, self.b_tok) + bag
+        nt_rows = self.B_loc if W == 1 else cap_r
+        if W == 1:
+            pool_out, pool_b = self.I_all[:, :d], self.b_all
+        else:
+            pool_out, pool_b = self.I_pack[:cap, :d], self.b_g[:cap]
+        be.lookup_het_multi([(self.E_user, None, None, None, None, None, None, None, urows, self.U_loc, 1.0, None),
+                             item + (self.block_ids[:self.S if W == 1 else cap], pool_out, 0.5, pool_b),
+                             item + (self.g_gid[:nt_rows], T_in[:nt_rows, :d], 0.5, self.tb_send[:nt_rows])])
+        if W > 1:
+            be.copy_strided(pool_b, self.I_pack[:cap, d])
+        be.copy_strided(self.tb_send[:nt_rows], T_in[:nt_rows, d])
+
+    def _het_k7(self, phase, urows, rrows, cap, cap_r):
+        be, d, B_loc, Sg, ni, W = self.be, self.d, self.B_loc, self.Sg, self.ni_loc, self.world
+        arena, arena_b = self.arena, self.arena_b
+        nb = self.S if W == 1 else cap
+        nt_rows = B_loc if W == 1 else cap_r
+        be.sparse_adagrad_multi([(self.E_user, self.A_user, None, None),
+                                 (self.E_item[:ni], self.A_item[:ni], self.b_item[:ni], self.Ab_item[:ni])],
+                                [(0, urows, 0, 1.0), (1, self.pool_rows[:nb], B_loc, 0.5), (1, rrows, B_loc + Sg, 0.5)],
+                                arena[:, :d], arena_b, self.lr, phase=phase)
+        if phase & 2:
+            be.fill_zero(self.D_tok)
+            be.fill_zero(self.Db_tok)
+        be.bags_grad_dense(self.D_tok, self.Db_tok, self.bag_vals, self.bag_starts, self.bag_lens,
+                           [(self.block_ids[:nb], B_loc, 0.5), (self.g_gid[:nt_rows], B_loc + Sg, 0.5)],
+                           arena[:, :d], arena_b, phase=phase)
+
+    def _het_tok_apply(self):
+        nt = self.n_tokens
+        self.be.adagrad_dense(self.E_tok[:nt], self.A_tok[:nt], self.D_tok, self.lr)
+        self.be.adagrad_dense(self.b_tok[:nt], self.Ab_tok[:nt], self.Db_tok, self.lr)
 
     def _het_rows(self, rows, ids, out, bias_tmp):
         """out[:, :d] = (id row + bag mean) / 2, out[:, d] = (id bias + mean token bias) / 2 for the owned items
@@ -947,6 +1038,8 @@ class ShardedHMFRepTokens(ShardedHMF):
     def step(self, users, items=None):
         if self.world > 1 and self.cap <= 0:
             raise RuntimeError("ShardedHMFRepTokens.step before set_pool()")
+        if self.use_graphs:            # HIP backend: the hipGraph-segment step with the hooks above
+            return ShardedHMF.step(self, users, items)
         route = users if isinstance(users, dict) else self.prepare_route(users, items)
         be, W = self.be, self.world
         B, B_loc, S, Sg, d = self.B, self.B_loc, self.S, self.Sg, self.d
@@ -1314,6 +1407,36 @@ def comm_roofline(model, world, grp=None):
     return out
 
 
+def comm_prediction(mode, world, B_loc, S, d, n_tokens=0):
+    """What the step's collectives cost at link rate for a world of `world` ranks -- ARITHMETIC, not a measurement
+    (the bench line carries it as `roofline_comm_predicted`): a rank moves (N-1)/N of a payload
+    over N-1 links of XGMI_LINK_GBS each in an all_gather / all_to_all / reduce_scatter, twice that in an
+    all_reduce; collectives below ~1 MB are latency-bound (tens of us under RCCL) whatever this floor says."""
+    N = max(int(world), 1)
+    dp = d + 4
+    link = XGMI_LINK_GBS * 1e9
+    f = (N - 1) / N if N > 1 else 0.0
+
+    def row(name, kind, payload):
+        wire = payload * (2.0 if kind == 'all_reduce' else 1.0) * f
+        us = wire / max(N - 1, 1) / link * 1e6 if N > 1 else 0.0
+        return {"collective": name, "kind": kind, "payload_bytes": int(payload), "wire_bytes_per_rank": int(wire),
+                "us_at_link_rate": us}
+    if mode == 'id':
+        rows = [row("pool blocks", 'all_gather', S * dp * 4), row("target rows", 'all_to_all', B_loc * dp * 4),
+                row("target-row gradients", 'all_to_all', B_loc * dp * 4), row("pool gradients", 'all_reduce', S * dp * 4)]
+    elif mode == 'rep_tokens':
+        rows = [row("pool blocks", 'all_gather', S * dp * 4), row("target rows", 'all_to_all', B_loc * dp * 4),
+                row("target-row gradients", 'all_to_all', B_loc * dp * 4), row("pool gradients", 'all_reduce', S * dp * 4),
+                row("merged token gradient + bias", 'all_reduce', n_tokens * (d + 1) * 4)]
+    else:           # token-striped bags: partials of the GLOBAL batch
+        B = B_loc * N
+        rows = [row("pool partials", 'all_reduce', S * dp * 4), row("target partials", 'reduce_scatter', B * dp * 4),
+                row("pool-gradient partials", 'all_reduce', S * dp * 4), row("target-row gradients", 'all_gather', B * dp * 4)]
+    return {"model": "%d ranks, %d xGMI links x %.0f GB/s per direction each; arithmetic, not measured" % (N, max(N - 1, 1), XGMI_LINK_GBS),
+            "exchanges": rows, "us_total_at_link_rate": sum(r["us_at_link_rate"] for r in rows)}
+
+
 def bench_run(args, world, rank, local_rank, init_pg=True):
     """The N-rank bench body (every rank calls it); returns the JSON dict on rank 0, None elsewhere.
     world == 1 runs the very same sharded step on one GPU (all "exchanges" local): the anchor of
@@ -1431,7 +1554,7 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
         # MwScorer.fwd (phase 2: target score + scorer GEMM + hinge epilogue, no logits), launched here with the step's
         # own buffers; only where the step itself takes the materialising GEMM (shapes the family does not cover,
         # ARX_SCORER_F32, the bag variants) is that GEMM the one timed
-        fused = (not with_bags) and getattr(model, 'scorer', None) is not None and model._fused_scorer()
+        fused = (rep_tokens or not with_bags) and getattr(model, 'scorer', None) is not None and model._fused_scorer()
         if fused:
             Sg_, arena, arena_b = model.Sg, model.arena, model.arena_b
             dT_ = arena[B_loc + Sg_:B_loc + Sg_ + B_loc] if world == 1 else model.dT_pack
@@ -1488,10 +1611,18 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
                        "parallelism": "row-sharded tables x dp%d" % world,
                        "routing_in_timed_region": False, "pool_redraws_timed": redraws[0],
                        "hipgraph_segments": (sorted(model._graphs) if model.use_graphs else None),
+                       "step_form": ("hipGraph segments between the collectives" if model.use_graphs else "eager launches"),
                        "hipgraph_captures": model.n_captures, "hipgraph_replays": model.n_replays,
                        "sampled_negative_logits_per_s": B * S * args.steps / wall,
                        "final_loss": loss, "setup_s": setup_s},
             "roofline": roofline, "roofline_comm": comm,
+            # the same exchanges priced at link rate for the world of this run and for the 8-GPU node of BASELINE
+            # configs[4] (arithmetic: no multi-GPU box was in reach of the builder)
+            "roofline_comm_predicted": {
+                "this_run": comm_prediction('rep_tokens' if rep_tokens else ('bags' if with_bags else 'id'), world,
+                                            B_loc, S, d, n_tokens=100000 if with_bags else 0),
+                "at_8_ranks": comm_prediction('rep_tokens' if rep_tokens else ('bags' if with_bags else 'id'), 8,
+                                              B_loc, S, d, n_tokens=100000 if with_bags else 0)},
             "cpu_baseline": {"value": None, "unit": "interactions/s", "cores": None, "kind": "port",
                              "sample": None,
                              "why": "timed on rank 0 at N = 1 only (bench contract): the N = 1 line of the same run "

@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--no-anchor", action="store_true",
                     help="N > 1: do not run the world-1 anchor of the same workload after the N-rank run")
     ap.add_argument("--mulhot", action="store_true", help="(compat) same as --workload c3")
-    ap.add_argument("--subs", default="c2,c3mix,c4,c4mce,k1,c5w1,c3_f32mfma,c2_f32mfma",
+    ap.add_argument("--subs", default="c2,c3mix,c4,c4mce,k1,c5w1,c3repw1,c3_f32mfma,c2_f32mfma",
                     help="comma list of sub-results besides the headline ('' = none)")
     ap.add_argument("--sub-steps", type=int, default=50)
     ap.add_argument("--repeats", type=int, default=5,
@@ -616,7 +616,7 @@ def run_lstm(args, loss, steps, warmup):
     return out
 
 
-def run_sharded_world1(args):
+def run_sharded_world1(args, rep_tokens=False):
     """The N > 1 code path (arx.dist.ShardedHMF, BASELINE configs[4]: 100 M-item table) on ONE rank:
     every exchange is a local copy.  This -- not the hipGraph single-process headline above, which
     is another workload (C3, 1 M items) -- is the N = 1 point of the weak-scaling curve that
@@ -626,6 +626,10 @@ def run_sharded_world1(args):
     from arx import dist as arx_dist
     a = copy.copy(args)
     a.n_items = 100000000
+    if rep_tokens:
+        # the HET variant of the sharded step (arx.dist.ShardedHMFRepTokens, round 5): C3's items (1 M, id + 20-token
+        # bag over a 100 k-token table) with the id table striped and the token table replicated
+        a.n_items, a.sharded_rep_tokens = 1000000, True
     a.steps, a.warmup = args.sub_steps, min(args.warmup, 10)
     for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(_free_port())),
                  ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
@@ -826,6 +830,8 @@ def main():
                     out["roofline_gather"]["past_llc"] = r
             elif s == "c5w1":
                 r = run_sharded_world1(args)
+            elif s == "c3repw1":
+                r = run_sharded_world1(args, rep_tokens=True)
             elif s.endswith("_f32mfma") and (s[:-8] in WORKLOADS or s[:-8] == "c5w1"):
                 r = run_f32mfma(args, s[:-8])
             else:

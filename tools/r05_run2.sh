@@ -1,9 +1,10 @@
 set -u
 mkdir -p gpurun_out/r05
-timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -30 > gpurun_out/r05/pytest2.txt
-cat gpurun_out/r05/pytest2.txt
-timeout 600 python bench.py --no-cpu-baseline --subs c2,c3mix,c4 --repeats 3 --no-rooflines 2>/dev/null | python -c "
+timeout 1500 python -m pytest tests/test_dist_gpu.py tests/test_bench_gpu.py tests/test_sampler_gpu.py -q -x 2>&1 | tail -25 > gpurun_out/r05/pytest4.txt
+cat gpurun_out/r05/pytest4.txt
+for f in "--sharded-rep-tokens" "--sharded-bags"; do
+  timeout 600 python bench.py --gpus 1 --workload c5 $f --subs "" --no-cpu-baseline --steps 60 --warmup 10 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('C3 %.1f us' % (1e3*j['ms_per_step']), {k: round(1e3*v['ms_per_step'],1) for k,v in j['sub'].items() if isinstance(v,dict) and 'ms_per_step' in v})"
-timeout 300 python tools/lstm_bench.py --batch 1024 2>&1 | tail -3
+print('c5 world-1 [$f]', '%.1f us/step' % (1e3*j['ms_per_step']), '%.1f M/s' % (j['value']/1e6), j['config'].get('step_form'), 'roofline', j['roofline']['kernel'][:40], round(j['roofline']['frac'],3), round(1e3*j['roofline']['ms_per_launch'],1),'us')" | tee -a gpurun_out/r05/c5_world1.txt
+done
