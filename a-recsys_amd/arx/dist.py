@@ -665,13 +665,14 @@ class ShardedHMF(object):
             if het and W == 1:
                 self._het_tok_apply()                  # (one rank: nothing to sum, the dense step follows at once)
 
-        def k7_sorts(own_graph):
+        def k7_sorts(own_graph, ev=None):
             # K7's keys, sorts and run records need the ids only: on a second stream, under the forward
             # kernels (the ~70 us chain leaves the critical path) -- a graph of its own between the
             # segments, a branch of the one graph at world 1
             main, side = torch.cuda.current_stream(dev), self._side
-            ev = torch.cuda.Event()
-            ev.record(main)
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(main)
             side.wait_event(ev)
             with torch.cuda.stream(side):
                 if own_graph:
@@ -684,6 +685,9 @@ class ShardedHMF(object):
 
         def whole_step():
             fwd_gather()
+            # (round 5: with the branch's kernels captured BEHIND the scorer's forward launches -- the order arx/graph.py
+            # uses -- the two chains overlap from the start, and the HET step got slower: 436 against 412-427 us.
+            # Captured first, the sorts run ahead of the scorer and only their tail overlaps it: kept)
             sorted_ = k7_sorts(False)
             fwd_score()
             loss()
