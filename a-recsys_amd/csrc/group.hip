@@ -671,7 +671,10 @@ static ApplyJob make_job(const TableSet& ts, int d, const RunLists& sg, int64_t 
   const int kshort = lpr < 32 ? lpr : 32;
   const int nsg = 64 / lpr;
   int64_t gshort = ceil_div(n, (int64_t)4 * nsg * ARX_RUN_NB);
-  const int64_t cap = (int64_t)cu_count() * 8;
+#ifndef ARX_RUN_CAP_PER_CU
+#define ARX_RUN_CAP_PER_CU 16       // (round 5, same box: 8 -> 12 / 24: C3 229.0 -> 227.1..227.9, C2 160 -> 157..159 us)
+#endif
+  const int64_t cap = (int64_t)cu_count() * ARX_RUN_CAP_PER_CU;
   if (gshort > cap) gshort = cap;
   if (gshort < 1) gshort = 1;
   int64_t glong = n / (kshort + 1) + 1;       // upper bound of the work items is larger; the loop strides

@@ -1,7 +1,6 @@
 #!/bin/bash
-# Round-5 A/B on one box, alternating, N rounds: the C3 / C2 / C3-MIX step with the rider's K7 apply as
-#   win (rounds 3-4: window + finish launches over the one-hot list, then the token apply) | split | flow
-# usage: tools/r05_ab.sh [rounds] [variant libs ...]
+# Round-5 A/B on one box, alternating, N rounds: the C3 / C2 / C3-MIX step with variant libraries (tools/build_variant.sh)
+# and / or ARX_K7_RIDER modes.  usage: tools/r05_ab.sh [rounds] [variant libs ...]
 set -u
 N=${1:-2}; shift || true
 OUT=gpurun_out/r05ab; mkdir -p $OUT
@@ -14,7 +13,5 @@ print('$tag', 'C3 %.1f us' % (1e3*j['ms_per_step']), 'C2 %.1f us' % (1e3*j['sub'
 }
 for i in $(seq $N); do
   run win ARX_K7_RIDER=win
-  run split ARX_K7_RIDER=split
-  run flow ARX_K7_RIDER=flow
   for v in "$@"; do run $v ARX_LIB=$PWD/a-recsys_amd/arx/lib/exp/$v.so; done
 done
