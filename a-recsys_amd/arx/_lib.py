@@ -99,6 +99,7 @@ PROTOTYPES = {
     "arx_eval_finish": (cint, [cint, f32p, f32p, f32p, i64, f32p, vp]),
     "arx_mw_scorer_supported": (cint, [i64, i64, cint]),
     "arx_merge_keyed_take": (cint, [f32p, i32p, i64, i64, i32p, vp]),
+    "arx_adagrad_rows_nonzero": (cint, [f32p, f32p, f32p, f32p, f32p, f32p, i64, cint, f32p, vp]),
     "arx_mw_scorer_state_bytes": (sz, [i64, i64, cint]),
     "arx_mw_scorer_state_layout": (cint, [i64, i64, cint, C.POINTER(i64)]),
     "arx_mw_scorer_fwd": (cint, [f32p, i64, f32p, i64, f32p, f32p, i64, f32p, i64, cint, i32p, i32p, i32p, i32p,

@@ -211,6 +211,10 @@ class HipBackend(object):
     def adagrad_dense(self, w, acc, g, lr):
         self.ops.adagrad_dense(w, acc, g, lr)
 
+    def adagrad_rows_nonzero(self, W, acc, bias, bias_acc, G, Gb, lr):
+        """Adagrad on the rows whose dense gradient row is not all zero; the consumed gradient is zeroed (arx.h)."""
+        self.ops.adagrad_rows_nonzero(W, acc, bias, bias_acc, G, Gb, lr)
+
     def fill_zero(self, t):
         self.ops.fill_f32(t, 0.0)
 
@@ -912,8 +916,9 @@ class ShardedHMFRepTokens(ShardedHMF):
     all-reduce for the token table: every rank merges the token gradients of the lookups it owns (pool block +
     received targets, coefficient 1/2 . 1/len) into a dense gradient table D [n_tokens, d] (the two-stage bag pass
     in its gradient-descent form with a step of -1 onto a zeroed table: the sums themselves), D is summed over the
-    ranks, and every replica applies the same dense Adagrad step (rows without gradient: acc += 0, w -= 0 -- the
-    sparse update of embed_attribute.py:383-400 / hmf_model.py:146-151).  Volume per rank and step on top of
+    ranks, and every replica applies the same Adagrad step to the rows of D that are not all zero (rows without gradient
+    would not move: the sparse update of embed_attribute.py:383-400 / hmf_model.py:146-151; arx_adagrad_rows_nonzero,
+    which also zeroes D for the next step).  Volume per rank and step on top of
     ShardedHMF: 2 x n_tokens x (d + 1) x 4 B x (N-1)/N through the ring, independent of the batch, issued under the
     id shard's own K7 pass; the token-striped step moves 2 x B x (d + 4) x 4 B with B the GLOBAL batch
     (predicted comm / compute 0.35 against 0.57 at N = 8, B_loc = 16384)."""
@@ -1018,17 +1023,17 @@ class ShardedHMFRepTokens(ShardedHMF):
                                  (self.E_item[:ni], self.A_item[:ni], self.b_item[:ni], self.Ab_item[:ni])],
                                 [(0, urows, 0, 1.0), (1, self.pool_rows[:nb], B_loc, 0.5), (1, rrows, B_loc + Sg, 0.5)],
                                 arena[:, :d], arena_b, self.lr, phase=phase)
-        if phase & 2:
-            be.fill_zero(self.D_tok)
-            be.fill_zero(self.Db_tok)
+        # (D_tok / Db_tok are all zero here: allocated so, and the token apply zeroes every row it consumes)
         be.bags_grad_dense(self.D_tok, self.Db_tok, self.bag_vals, self.bag_starts, self.bag_lens,
                            [(self.block_ids[:nb], B_loc, 0.5), (self.g_gid[:nt_rows], B_loc + Sg, 0.5)],
                            arena[:, :d], arena_b, phase=phase)
 
     def _het_tok_apply(self):
+        """The same Adagrad step on every replica: rows of the summed gradient table that are not all zero (the rest
+        would not move), the table zeroed on the way for the next step's accumulation (arx_adagrad_rows_nonzero)."""
         nt = self.n_tokens
-        self.be.adagrad_dense(self.E_tok[:nt], self.A_tok[:nt], self.D_tok, self.lr)
-        self.be.adagrad_dense(self.b_tok[:nt], self.Ab_tok[:nt], self.Db_tok, self.lr)
+        self.be.adagrad_rows_nonzero(self.E_tok[:nt], self.A_tok[:nt], self.b_tok[:nt], self.Ab_tok[:nt], self.D_tok,
+                                     self.Db_tok, self.lr)
 
     def _het_rows(self, rows, ids, out, bias_tmp):
         """out[:, :d] = (id row + bag mean) / 2, out[:, d] = (id bias + mean token bias) / 2 for the owned items
@@ -1087,9 +1092,7 @@ class ShardedHMFRepTokens(ShardedHMF):
         # token table: this rank's merged token gradients -> D, summed over the ranks under the id shard's pass
         nt = self.n_tokens
         bag = (self.bag_vals, self.bag_starts, self.bag_lens)
-        be.fill_zero(self.D_tok)
-        be.fill_zero(self.Db_tok)
-        bsites = [(self.block_ids[:cap], B_loc, 0.5)]
+        bsites = [(self.block_ids[:cap], B_loc, 0.5)]       # (D_tok / Db_tok are all zero: _het_tok_apply leaves them so)
         if R > 0:
             bsites.append((recv_ids[:R], B_loc + Sg, 0.5))
         be.bags_grad_dense(self.D_tok, self.Db_tok, *bag, bsites, arena[:, :d], arena_b)
@@ -1108,8 +1111,7 @@ class ShardedHMFRepTokens(ShardedHMF):
         if w_tok is not None:
             w_tok.wait()
             w_tokb.wait()
-        be.adagrad_dense(self.E_tok[:nt], self.A_tok[:nt], self.D_tok, self.lr)
-        be.adagrad_dense(self.b_tok[:nt], self.Ab_tok[:nt], self.Db_tok, self.lr)
+        self._het_tok_apply()
         self.steps += 1
 
     def gather_global_tables(self):

@@ -730,6 +730,13 @@ def adagrad_dense(w, acc, g, lr_dev, gscale_dev=None):
          _stream())
 
 
+def adagrad_rows_nonzero(W, acc, bias, bias_acc, G, Gb, lr_dev):
+    """Adagrad over the rows of W whose dense gradient row in G is not all zero; consumed rows of G / cells of Gb are
+    zeroed (arx.h)."""
+    call("arx_adagrad_rows_nonzero", _p(W), _p(acc), _p(bias), _p(bias_acc), _p(G), _p(Gb), int(W.shape[0]),
+         int(W.shape[1]), _p(lr_dev), _stream())
+
+
 def adagrad_dense_multi(params, lr_dev, gscale_dev=None):
     """params: [(w, acc|None, g)]: one launch per 8 parameters (arx_adagrad_dense_multi)."""
     import ctypes as C

@@ -758,6 +758,67 @@ __global__ void k_adagrad_dense(float* __restrict__ w, float* __restrict__ acc,
   }
 }
 
+// Adagrad over the rows of a table whose dense gradient rows are mostly zero (arx.dist.ShardedHMFRepTokens: the merged,
+// all-reduced gradient of a replicated token table -- ~30 % of 100 k rows touched per step): a sub-group reads its
+// gradient row, skips the row when every element is zero (what the dense step would do to it: acc += 0, w -= 0), else
+// applies arx_adagrad_dense's arithmetic and ZEROES the gradient row it consumed -- the table is left all zero for the
+// next step's accumulation, no fill pass.  bias / bias_acc / Gb (nullable): the same per row.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_adagrad_rows_nonzero(float* __restrict__ W, float* __restrict__ acc,
+                                                              float* __restrict__ bias, float* __restrict__ bias_acc,
+                                                              float* __restrict__ G, float* __restrict__ Gb,
+                                                              int64_t rows, int d, const float* __restrict__ lr_dev) {
+  constexpr int NSG = 256 / LPR;
+  const int lig = threadIdx.x % LPR;
+  const int col = lig * 4;
+  const bool colok = col < d;
+  const float lr = *lr_dev;
+  const int64_t stride = (int64_t)gridDim.x * NSG;
+  for (int64_t r0 = (int64_t)blockIdx.x * NSG + threadIdx.x / LPR; r0 < rows; r0 += 4 * stride) {
+    float4 g[4];
+    float gb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {          // four rows in flight per sub-group
+      const int64_t r = r0 + u * stride;
+      g[u] = (r < rows && colok) ? *reinterpret_cast<const float4*>(G + r * d + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gb[u] = (r < rows && Gb && lig == 0) ? Gb[r] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = r0 + u * stride;
+      // (x != 0 is true for NaN: a poisoned gradient row is applied, not skipped)
+      bool nz = (g[u].x != 0.f) | (g[u].y != 0.f) | (g[u].z != 0.f) | (g[u].w != 0.f) | (gb[u] != 0.f);
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) nz = nz | (bool)__shfl_xor((int)nz, o, LPR);
+      if (r >= rows || !nz) continue;
+      if (colok) {
+        float4 w = *reinterpret_cast<const float4*>(W + r * d + col);
+        if (acc) {
+          float4 a = *reinterpret_cast<const float4*>(acc + r * d + col);
+          a.x += g[u].x * g[u].x; a.y += g[u].y * g[u].y; a.z += g[u].z * g[u].z; a.w += g[u].w * g[u].w;
+          *reinterpret_cast<float4*>(acc + r * d + col) = a;
+          w.x -= lr * g[u].x / sqrtf(a.x); w.y -= lr * g[u].y / sqrtf(a.y);
+          w.z -= lr * g[u].z / sqrtf(a.z); w.w -= lr * g[u].w / sqrtf(a.w);
+        } else {
+          w.x -= lr * g[u].x; w.y -= lr * g[u].y; w.z -= lr * g[u].z; w.w -= lr * g[u].w;
+        }
+        *reinterpret_cast<float4*>(W + r * d + col) = w;
+        *reinterpret_cast<float4*>(G + r * d + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (bias && lig == 0) {
+        if (bias_acc) {
+          const float a = bias_acc[r] + gb[u] * gb[u];
+          bias_acc[r] = a;
+          bias[r] -= lr * gb[u] / sqrtf(a);
+        } else {
+          bias[r] -= lr * gb[u];
+        }
+        Gb[r] = 0.f;
+      }
+    }
+  }
+}
+
 // Up to 8 dense parameters in one launch (the LSTM weights / biases / input projections of a step:
 // 2-6 tensors of 256 B - 128 KB, each a launch of its own otherwise).  Blocks [blk_end[t-1], blk_end[t])
 // own tensor t.
@@ -1901,6 +1962,22 @@ int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const flo
   int64_t cap = (int64_t)cu_count() * 8;
   if (gr > cap) gr = cap;
   k_adagrad_dense<<<(int)gr, 256, 0, as_stream(stream)>>>(w, acc, g, n, lr_dev, gscale_dev);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_adagrad_rows_nonzero(float* W, float* acc, float* bias, float* bias_acc, float* G, float* Gb, int64_t rows,
+                             int d, const float* lr_dev, void* stream) {
+  ARX_CHECK_ARG(W && G && lr_dev && rows >= 0, "arx_adagrad_rows_nonzero: null pointer");
+  ARX_CHECK_ARG(d > 0 && d % 4 == 0 && d <= 256, "arx_adagrad_rows_nonzero: d %% 4 == 0, d <= 256");
+  ARX_CHECK_ARG(!(bias && !Gb) && !(bias_acc && !bias), "arx_adagrad_rows_nonzero: bias needs Gb, bias_acc needs bias");
+  if (rows == 0) return ARX_OK;
+  const int lpr = lanes_per_row(d);
+  int64_t g = ceil_div(rows, (int64_t)(256 / lpr) * 4);
+  const int64_t cap = (int64_t)cu_count() * 16;
+  if (g > cap) g = cap;
+  ARX_DISPATCH_LPR(lpr, (k_adagrad_rows_nonzero<LPR><<<(int)g, 256, 0, as_stream(stream)>>>(W, acc, bias, bias_acc, G, Gb,
+                                                                                              rows, d, lr_dev)));
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

@@ -694,6 +694,13 @@ int arx_gmax_residual_bwd(const float* resid_dev, const int32_t* idx_dev, const 
  * (seqModel.py:180): coef = max_norm / max(sqrt(sq), max_norm). */
 int arx_adagrad_dense(float* w, float* acc, const float* g, int64_t n, const float* lr_dev,
                       const float* gscale_dev, void* stream);
+/* Adagrad over the rows of W [rows, d] whose DENSE gradient row in G is not all zero, with arx_adagrad_dense's
+ * arithmetic (a row of zeros would not move: acc += 0, w -= 0 -- the sparse update of hmf_model.py:146-151 on a dense
+ * gradient table), and every consumed gradient row / bias-gradient cell is ZEROED: G and Gb are left all zero for the
+ * next accumulation.  The replicated token table of the sharded HET step (arx.dist.ShardedHMFRepTokens: G = the merged
+ * token gradients summed over the ranks).  acc == NULL: gradient descent.  bias / bias_acc / Gb nullable. */
+int arx_adagrad_rows_nonzero(float* W, float* acc, float* bias, float* bias_acc, float* G, float* Gb, int64_t rows,
+                             int d, const float* lr_dev, void* stream);
 /* The same update for up to 8 dense parameters in one launch (the LSTM weights, biases and input
  * projections of a step: seqModel.py:173-182 applies one op per variable).  acc[t] NULL: gradient descent. */
 int arx_adagrad_dense_multi(int count, float* const* w, float* const* acc, const float* const* g,

@@ -72,6 +72,22 @@ class NumpyBackend(object):
         ww[...] = (ww - float(_n(lr)[0]) * gg / np.sqrt(a2)).astype(np.float32)
         aa[...] = a2.astype(np.float32)
 
+    def adagrad_rows_nonzero(self, W, acc, bias, bias_acc, G, Gb, lr):
+        g, gb = _n(G), _n(Gb)
+        nz = (g != 0).any(axis=1) | (gb != 0)
+        rows = np.nonzero(nz)[0]
+        lrv = float(_n(lr)[0])
+        w, a, b, ba = _n(W), _n(acc), _n(bias), _n(bias_acc)
+        g64, gb64 = g[rows].astype(np.float64), gb[rows].astype(np.float64)
+        a2 = a[rows].astype(np.float64) + g64 * g64
+        w[rows] = (w[rows] - lrv * g64 / np.sqrt(a2)).astype(np.float32)
+        a[rows] = a2.astype(np.float32)
+        b2 = ba[rows].astype(np.float64) + gb64 * gb64
+        b[rows] = (b[rows] - lrv * gb64 / np.sqrt(b2)).astype(np.float32)
+        ba[rows] = b2.astype(np.float32)
+        g[rows] = 0
+        gb[rows] = 0
+
     def fill_zero(self, t):
         _n(t)[...] = 0
 

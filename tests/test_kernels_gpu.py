@@ -1724,3 +1724,33 @@ def test_captured_graph_feed_nodes_in_flight(dev):
     assert np.array_equal(got, np.arange(1, K + 1, dtype=np.float32) * n), got
     # (informational: the host was ahead of the device for most of the run when t_host << t_all)
     print("feed nodes in flight: host %.2f ms, device %.2f ms" % (1e3 * t_host, 1e3 * t_all))
+
+
+@pytest.mark.parametrize("rows,d,frac", [(100000, 128, 0.3), (777, 64, 0.5), (5, 32, 1.0), (4096, 128, 0.0)])
+def test_adagrad_rows_nonzero_equals_dense_step(dev, rows, d, frac):
+    """arx_adagrad_rows_nonzero (the replicated token table of the sharded HET step): the rows whose gradient row is
+    not all zero move exactly as under arx_adagrad_dense, the others not at all (bit for bit: the dense step on a zero
+    gradient is the identity), the bias vector alike, and the gradient table comes back all zero."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(rows + d)
+    W = rng.standard_normal((rows, d)).astype(np.float32)
+    A = (0.1 + rng.random((rows, d))).astype(np.float32)
+    b = rng.standard_normal(rows).astype(np.float32)
+    Ab = (0.1 + rng.random(rows)).astype(np.float32)
+    touched = rng.random(rows) < frac
+    G = np.where(touched[:, None], rng.standard_normal((rows, d)), 0.0).astype(np.float32)
+    G[touched, ::3] = 0.0                                  # zeros inside a live row are fine
+    Gb = np.where(touched, rng.standard_normal(rows), 0.0).astype(np.float32)
+    if rows > 10:
+        Gb[1] = 0.5                                        # a row whose only gradient is its bias cell
+        G[1] = 0.0
+    lr = torch.tensor([0.37], dtype=torch.float32, device=dev)
+    w1, a1, b1, ab1 = _t(dev, W), _t(dev, A), _t(dev, b), _t(dev, Ab)
+    ops.adagrad_dense(w1, a1, _t(dev, G), lr)
+    ops.adagrad_dense(b1, ab1, _t(dev, Gb), lr)
+    w2, a2, b2, ab2, g2, gb2 = _t(dev, W), _t(dev, A), _t(dev, b), _t(dev, Ab), _t(dev, G), _t(dev, Gb)
+    ops.adagrad_rows_nonzero(w2, a2, b2, ab2, g2, gb2, lr)
+    torch.cuda.synchronize()
+    assert torch.equal(w1, w2) and torch.equal(a1, a2) and torch.equal(b1, b2) and torch.equal(ab1, ab2)
+    assert not bool(g2.any()) and not bool(gb2.any())
