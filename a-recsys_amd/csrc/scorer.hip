@@ -14,9 +14,20 @@
 // L2 -> LDS traffic per launch, and the loaders prefetched ONE stage ahead of a ~2 600-cycle L2 round trip.
 // This file: 128 x 512 (forward) and 256 x 32 (backward) workgroup tiles -- 2x / 4x less plane traffic --, LDS-DMA
 // loader waves (global_load_lds_dwordx4: no staging registers) three stages ahead in a four-slot ring, the hinge
-// epilogue of tile j - 1 interleaved with the MFMAs of tile j, the target score formed in the forward kernel's
-// prologue, and every operand plane produced by the kernel that has the data in registers anyway (k_sc_prep: pool
-// rows in both layouts; k_sc_rows: g U transposed) -- no split launches.
+// epilogue of tile j - 1 interleaved with the MFMAs of tile j, the target score formed by the half waves of k_sc_prep
+// that list a row's positives (round 4: in the forward kernel's prologue), and every operand plane produced by the
+// kernel that has the data in registers anyway (k_sc_prep: pool rows in both layouts; k_sc_rows: g U transposed) --
+// no split launches.
+//
+// Round 5, k_sc_hinge 28.2 -> 24.4 us (0.38 -> 0.42 of 2500 / 6; the C4 shape 56.4 -> 49.9): its start is bound by the
+// bytes 256 workgroups ask for at once.  The T rows and the dot moved to k_sc_prep (+1.7 us there at the C3 shape, 0
+// at C4's), the pieces of U are made chunk by chunk between the MFMAs of tile 0 instead of in front of them, loads are
+// issued in cache-line order, and the two column splits of a row block run on ONE XCD (blockIdx mapping).  Measured
+// on the way, with UNTRACED builds timed by rocprofv3 (tools/r05_sc_ab.sh) -- the cycle stamps of tools/sc_trace.py
+// slow the stamped kernel by 8 us and mis-attribute it (a traced build made the bias re-reads look like a third of the
+// loop): no MFMA 9.6 us, no LDS-DMA -2.3, no barriers -0.8, no re-initialising writes +-0, the bias through
+// v_readlane instead of LDS +0.6, U pre-split by k_sc_prep 24.3 but +3 us in k_sc_prep.  The part runs this kernel at
+// 1.85 - 1.95 GHz (s_memtime against s_memrealtime), not the 2.4 the guide's peak assumes.
 //
 // Launches of a step:  k_sc_prep -> k_sc_hinge -> k_sc_rows          (arx_mw_scorer_fwd)
 //                      k_sc_bits (dU += g (act . P))                 (arx_mw_scorer_bwd_du)
@@ -48,7 +59,11 @@ __device__ unsigned long long g_sc_trace[4096];
   if (blockIdx.x == (gridDim.x > 5 ? 5 : 0) && threadIdx.x == 0 && tcount < 4096)                        \
     g_sc_trace[tcount++] = ((unsigned long long)(ev_) << 56) | (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFFFull);
 #define SC_TDECL int tcount = 0;
+#define SC_TREAL(ev_)                 /* the constant 100 MHz counter: shader clock = cycle stamps / these */ \
+  if (blockIdx.x == (gridDim.x > 5 ? 5 : 0) && threadIdx.x == 0 && tcount < 4096)                        \
+    g_sc_trace[tcount++] = ((unsigned long long)(ev_) << 56) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFFFFFFFull);
 #else
+#define SC_TREAL(ev_)
 #define SC_T(ev_)
 #define SC_TDECL
 #endif
@@ -149,6 +164,10 @@ struct ScLoader {
 //          so the first fragments of stage st + 1 are requested under the last MFMAs of stage st, never behind a
 //          barrier.
 // EXTRA: a seventh piece per stage and loader wave lands at ldsx + slot * 4096 + lw * 1024.
+// (Round 5, measured and not kept: k_sc_hinge's loaders requesting only stage 0 in front of B0 and stages 1 / 2 behind
+// it -- the start of that kernel is bound by what all 256 workgroups ask of the memory system at once, ~7 TB/s -- 24.3
+// against 24.4 us; the loaders forming the target scores from whole-row loads of their own under the first stages:
+// the second copy of U's bytes cost more than the compute waves' strided T loads had.)
 template <int ROWB, bool EXTRA = false>
 __device__ __forceinline__ void sc_loader_loop(const ScLoader<ROWB>& ld, char* lds, int nstage, char* ldsx = nullptr,
                                                int lw = 0) {
@@ -192,6 +211,13 @@ __device__ __forceinline__ float sc_wsum(float v) {
   return v;
 }
 
+struct ScTScore {                     // target scores t_r = U_r . T_r + tb_r, formed by the hit-list half waves of k_sc_prep
+  const float* U; int64_t ldu;
+  const float* T; int64_t ldt;
+  const float* tb; int64_t tb_stride;
+  float* tscore; float* tscore2;      // [B] (tscore2 nullable)
+};
+
 // ------------------------------------------------------------------------------------------------------------
 // k_sc_prep: blocks [0, S / 32): 32 pool rows -> planes Pp [3][S][d] (forward operand, k contiguous) and
 // PT [3][d][S] (dU operand, pool index contiguous); the other blocks: one wave per batch row walks the user's
@@ -204,12 +230,12 @@ __global__ __launch_bounds__(256) void k_sc_prep(const float* __restrict__ P, in
                                                  PosMask pm,
                                                  int64_t mask_rows, int64_t B, int32_t* __restrict__ hits,
                                                  int32_t* __restrict__ nhit, const float* __restrict__ seq_w,
-                                                 int64_t seq_rows, float* __restrict__ row_w_out) {
+                                                 int64_t seq_rows, float* __restrict__ row_w_out, ScTScore ts) {
   __shared__ float tile[32 * 129];
   __shared__ float sbad[4];
   const int tid = threadIdx.x;
   const int64_t pblocks = S / 32;
-  const int64_t hblocks = (B + 3) / 4;
+  const int64_t hblocks = (B + 7) / 8;
   if ((int64_t)blockIdx.x >= pblocks + hblocks) {
     // the sequence model's example weights (seqModel.py:561-567): row_w[t * seq_rows + b] = w_t[b] / (sum_t w_t[b] +
     // 1e-12) for the B = L * seq_rows time-major rows -- 32 sequences x 8 time lanes per workgroup, combined in
@@ -231,6 +257,9 @@ __global__ __launch_bounds__(256) void k_sc_prep(const float* __restrict__ P, in
     return;
   }
   if ((int64_t)blockIdx.x < pblocks) {
+#if defined(SC_PREP_SKIP) && (SC_PREP_SKIP & 1)          // timing builds: a role's blocks return at once
+    return;
+#endif
     const int64_t r0 = (int64_t)blockIdx.x * 32;
     const int ld = d + 1;
     const int c4n = d / 4;
@@ -255,43 +284,69 @@ __global__ __launch_bounds__(256) void k_sc_prep(const float* __restrict__ P, in
     sc_emit_planes_t(tile, ld, 32, d, PT, (int64_t)d * ldpt, ldpt, r0, tid, 256);
     return;
   }
-  const int lane = tid & 63;
-  const int64_t r = (((int64_t)blockIdx.x - pblocks) * 256 + tid) >> 6;
-  if (r >= B) return;
-  const int usr = pm.user_ids[r % mask_rows];
-  const int beg = pm.pos_ptr[usr], end = pm.pos_ptr[usr + 1];
+  // HALF a wave per batch row (round 5: one wave per row was 16 384 waves of a four-deep load chain, two rounds of the
+  // chip's wave slots, for lists of ~20 entries).  The half wave also forms the row's target score: 32 lanes x 16 bytes
+  // are a whole row of U and of T at d = 128 (at d = 64 the upper 16 lanes idle) -- two coalesced loads that ride under
+  // the chain's latency.  k_sc_hinge formed t_r itself in round 4, per COLUMN split, with 16 strided loads per lane.
+#if defined(SC_PREP_SKIP) && (SC_PREP_SKIP & 2)
+  return;
+#endif
+  const int lane = tid & 63, hl = lane & 31;
+  const int64_t r = (((int64_t)blockIdx.x - pblocks) * 256 + tid) >> 5;
+  const bool valid = r < B;
+  float4 u4 = make_float4(0.f, 0.f, 0.f, 0.f), t4 = u4;
+  if (valid && 4 * hl < d) {
+    u4 = *reinterpret_cast<const float4*>(ts.U + r * ts.ldu + 4 * hl);
+    t4 = *reinterpret_cast<const float4*>(ts.T + r * ts.ldt + 4 * hl);
+  }
+  const float tbv = (valid && ts.tb) ? ts.tb[r * ts.tb_stride] : 0.f;
+  const int usr = valid ? pm.user_ids[r % mask_rows] : 0;
+  const int beg = valid ? pm.pos_ptr[usr] : 0, end = valid ? pm.pos_ptr[usr + 1] : 0;
   int n = 0;
-  for (int p0 = beg; p0 < end && n >= 0; p0 += 64) {
-    const int p = p0 + lane;
+  for (int p0 = beg;; p0 += 32) {
+    const bool active = p0 < end && n >= 0;
+    if (!__any(active)) break;
+    const int p = p0 + hl;
     int j = -1;
-    if (p < end) {
+    if (active && p < end) {
       j = pos_slot(pm, pm.pos_items[p]);
       if (j < 0 || j >= S) j = -1;
     }
-    const unsigned long long hm = __ballot(j >= 0);
-    const int k = __popcll(hm);
-    if (n + k > kScHits) { n = -1; break; }
-    if (j >= 0) hits[r * kScHits + n + __popcll(hm & ((1ull << lane) - 1ull))] = j;
-    n += k;
+    const unsigned long long hm64 = __ballot(j >= 0);
+    const uint32_t hm = (lane >> 5) ? (uint32_t)(hm64 >> 32) : (uint32_t)hm64;
+    const int k = __popc(hm);
+    if (active) {
+      if (n + k > kScHits) n = -1;
+      else {
+        if (j >= 0) hits[r * kScHits + n + __popc(hm & ((1u << hl) - 1u))] = j;
+        n += k;
+      }
+    }
   }
-  if (lane == 0) nhit[r] = n;
+  float dot = u4.x * t4.x + u4.y * t4.y + u4.z * t4.z + u4.w * t4.w;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+  if (hl == 0 && valid) {
+    nhit[r] = n;
+    const float t = dot + tbv;
+    ts.tscore[r] = t;
+    if (ts.tscore2) ts.tscore2[r] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // k_sc_hinge<KD>: workgroup = 128 batch rows x CW pool columns (CW = S / nsplit).  Waves 0..3 compute: wave w
 // keeps rows [32 w, 32 w + 32) of U as bf16 pieces in registers for the whole kernel (lane = row l % 32, k = 8 (l / 32)
-// .. + 8 of each 16-chunk) and forms t_r = U_r . T_r + tb_r on the way; per 32-column tile 6 KD / 16 MFMAs out of
+// .. + 8 of each 16-chunk; t_r = U_r . T_r + tb_r comes from k_sc_prep); per 32-column tile 6 KD / 16 MFMAs out of
 // the pool planes in LDS (pool tile = FIRST operand: D[pool column][row], a lane's 16 accumulator values are columns
 // 8 g + 4 (l / 32) + e of its row).  The hinge of tile j - 1 (v = x - t + 1: one act bit per logit, running
 // sum act * v and count) is written between the MFMAs of tile j (two accumulator sets).  Waves 4..7: LDS-DMA loaders.
-// Outputs: bits[tile * ldbits + row] (bit c = column 32 tile + c), rs_part / cnt_part [nsplit][B], tscore [B].
+// Outputs: bits[tile * ldbits + row] (bit c = column 32 tile + c), rs_part / cnt_part [nsplit][B].
 // ------------------------------------------------------------------------------------------------------------
 template <int KD>
 __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, const float* __restrict__ U, int64_t ldu,
-                                                  const float* __restrict__ T, int64_t ldt,
-                                                  const float* __restrict__ tb, int64_t tb_stride,
+                                                  const float* __restrict__ tscore,
                                                   const uint16_t* __restrict__ Pp, const float* __restrict__ bias,
-                                                  float* __restrict__ tscore, float* __restrict__ tscore2,
                                                   uint32_t* __restrict__ bits, int64_t ldbits, float* __restrict__ rs_part,
                                                   float* __restrict__ cnt_part) {
   constexpr int NCH = KD / 16;
@@ -308,12 +363,24 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
   const int lane = tid & 63;
   const int wv = tid >> 6;
   const int nsplit = (int)(S / CW);
-  const int64_t rb = (int64_t)blockIdx.x / nsplit;
-  const int ch = (int)((int64_t)blockIdx.x % nsplit);
+  // workgroup -> (row block, column split).  Workgroups are dealt to the 8 XCDs round-robin: the nsplit workgroups
+  // that read the SAME 128 rows of U / T are 8 apart, i.e. on one XCD (its L2 then serves the second reader); with
+  // plain division they sat on neighbouring XCDs and every row came over the fabric nsplit times
+  int64_t rb;
+  int ch;
+  {
+    const int64_t bid = blockIdx.x, grp = (int64_t)8 * nsplit, full = (int64_t)gridDim.x / grp * grp;
+    if (bid < full) {
+      rb = bid / grp * 8 + bid % 8;
+      ch = (int)(bid % grp / 8);
+    } else {
+      rb = full / nsplit + (bid - full) / nsplit;
+      ch = (int)((bid - full) % nsplit);
+    }
+  }
   const int64_t col0 = (int64_t)ch * CW;
   const int ntile = CW / 32;
   const int nstage = ntile / TPS;
-  for (int i = tid; i < CW; i += 512) sbias[i] = bias ? bias[col0 + i] : 0.f;
 
   if (wv >= 4) {
     // ================================== loaders ==================================
@@ -325,42 +392,58 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
   }
 
   // ================================== compute waves ==================================
+#ifdef SC_SETPRIO
+  __builtin_amdgcn_s_setprio(SC_SETPRIO);
+#endif
   const int lr = lane & 31, kg = lane >> 5;
   const int64_t row = rb * 128 + wv * 32 + lr;
   const bool ok = row < B;
+  SC_TDECL
+  SC_TREAL(120)
+  SC_T(99)
+  // Prologue (round 5).  Round 4 staged the bias (a global round trip in front of everything), then loaded the rows of
+  // U and T (32 strided 16-byte loads per lane), formed t_r and split ALL of U into bf16 pieces (~1 000 VALU per lane)
+  // before the first MFMA: 12 000 of the kernel's 54 000 cycles with the matrix pipe idle (tools/sc_trace.py), and most
+  // of that the loads -- 256 workgroups x (128 KB of rows + 72 KB of pool stages) at the ~7 TB/s the memory system
+  // gives a cold start.  Now: t_r comes from k_sc_prep (its hit-list waves have the lanes to spare), every load is
+  // issued at once (the bias first: its LDS stores need only that one back), chunk 0 is split as soon as ITS lines are
+  // there -- and the pieces of chunk c + 1 are made between the MFMAs of chunk c of tile 0, whose gaps have no hinge to
+  // hold yet.  The raw rows occupy the registers the pieces grow into (8 raw / 12 piece registers per chunk: never
+  // more than the 96 of the steady state).
   bf16x8 a1[NCH], a2[NCH], a3[NCH];
+  float4 ru[NCH][2];
   float tm1;
   {
+    float bv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) bv[k] = (bias && tid + 256 * k < CW) ? bias[col0 + tid + 256 * k] : 0.f;
+    tm1 = (ok ? tscore[row] : 0.f) - 1.f;                    // v = x - (t - 1); t_r from k_sc_prep
+    // rows past B read row 0 (their results are never stored).  Load order = line order: the four 16-byte loads that
+    // touch one 128-byte line of a row (chunks 2 p, 2 p + 1) are adjacent, U before T -- issued chunk by chunk for both
+    // arrays, the 4 waves' working set (2 x 32 lines each) overflowed the L1 and every line came from L2 four times
     const float* up = U + (ok ? row : 0) * ldu + 8 * kg;
-    const float* tp = T + (ok ? row : 0) * ldt + 8 * kg;
-    float dot = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, t0 = v0, t1 = v0;
-      if (ok) {
-        v0 = *reinterpret_cast<const float4*>(up + 16 * c);
-        v1 = *reinterpret_cast<const float4*>(up + 16 * c + 4);
-        t0 = *reinterpret_cast<const float4*>(tp + 16 * c);
-        t1 = *reinterpret_cast<const float4*>(tp + 16 * c + 4);
-      }
-      dot += v0.x * t0.x + v0.y * t0.y + v0.z * t0.z + v0.w * t0.w + v1.x * t1.x + v1.y * t1.y + v1.z * t1.z + v1.w * t1.w;
-      uint32_t p1[4], p2[4], p3[4];
-      split3x2(v0.x, v0.y, p1[0], p2[0], p3[0]);
-      split3x2(v0.z, v0.w, p1[1], p2[1], p3[1]);
-      split3x2(v1.x, v1.y, p1[2], p2[2], p3[2]);
-      split3x2(v1.z, v1.w, p1[3], p2[3], p3[3]);
-      a1[c] = __builtin_bit_cast(bf16x8, make_uint4(p1[0], p1[1], p1[2], p1[3]));
-      a2[c] = __builtin_bit_cast(bf16x8, make_uint4(p2[0], p2[1], p2[2], p2[3]));
-      a3[c] = __builtin_bit_cast(bf16x8, make_uint4(p3[0], p3[1], p3[2], p3[3]));
+      ru[c][0] = *reinterpret_cast<const float4*>(up + 16 * c);
+      ru[c][1] = *reinterpret_cast<const float4*>(up + 16 * c + 4);
+      if (c & 1) __builtin_amdgcn_sched_barrier(0);
     }
-    dot += __shfl_xor(dot, 32, 64);
-    const float t = dot + ((ok && tb) ? tb[row * tb_stride] : 0.f);
-    if (ch == 0 && kg == 0 && ok) {
-      tscore[row] = t;
-      if (tscore2) tscore2[row] = t;
-    }
-    tm1 = t - 1.f;                                            // v = x - (t - 1)
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tid + 256 * k < CW) sbias[tid + 256 * k] = bv[k];
   }
+#define SC_SPLIT(c_)                                                                                     \
+  {                                                                                                      \
+    uint32_t p1[4], p2[4], p3[4];                                                                        \
+    split3x2(ru[c_][0].x, ru[c_][0].y, p1[0], p2[0], p3[0]);                                             \
+    split3x2(ru[c_][0].z, ru[c_][0].w, p1[1], p2[1], p3[1]);                                             \
+    split3x2(ru[c_][1].x, ru[c_][1].y, p1[2], p2[2], p3[2]);                                             \
+    split3x2(ru[c_][1].z, ru[c_][1].w, p1[3], p2[3], p3[3]);                                             \
+    a1[c_] = __builtin_bit_cast(bf16x8, make_uint4(p1[0], p1[1], p1[2], p1[3]));                         \
+    a2[c_] = __builtin_bit_cast(bf16x8, make_uint4(p2[0], p2[1], p2[2], p2[3]));                         \
+    a3[c_] = __builtin_bit_cast(bf16x8, make_uint4(p3[0], p3[1], p3[2], p3[3]));                         \
+  }
+  SC_SPLIT(0)
   float rs = 0.f;
   int cnt = 0;
   // LDS byte address of this lane's fragment of chunk c in the CURRENT tile's image (plane pl: + pl * 32 * ROWB).
@@ -479,11 +562,17 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
     else __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);                                            \
   }
 #endif
+  // tile 0: the split of the next chunk's rows (~70 VALU) spread over the chunk's six MFMA gaps
+#define SC_CHUNK_SCHED_PRO                                                                               \
+  _Pragma("unroll") for (int m = 0; m < 6; ++m) {                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                                   \
+  }
   // one tile: MFMAs into (hi_, lo_).  EPI_: the previous tile's accumulators (hy_, ly_) are turned into hinge bits /
   // sums and re-initialised from bvn; jw_ >= 0: the word of tile jw_ (finished one tile ago) is assembled and stored in
   // chunk 0; jb0_ / jb_: the tiles whose bias quad 0 (chunk 0) / quads 1..3 (later chunks) are re-read -- see below;
   // dl_: byte step to the next tile's image; BAR_: the stage barrier E in the middle of this tile
-#define SC_TILE(hi_, lo_, hy_, ly_, EPI_, jw_, jb0_, jb_, dl_, BAR_)                                     \
+#define SC_TILE(hi_, lo_, hy_, ly_, EPI_, PRO_, jw_, jb0_, jb_, dl_, BAR_)                               \
   {                                                                                                      \
     const uint32_t dl = (uint32_t)(dl_);                                                                 \
     _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                    \
@@ -518,7 +607,8 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
           SC_EPI_WRITE({ float z_; asm volatile("v_mov_b32 %0, 0" : "=v"(z_)); ly_[i] = z_; })          \
         }                                                                                                \
       }                                                                                                  \
-      SC_CHUNK_SCHED(c)                                                                                  \
+      if ((PRO_) && c + 1 < NCH) { SC_SPLIT(c + 1) }                                                     \
+      if (PRO_) { SC_CHUNK_SCHED_PRO } else { SC_CHUNK_SCHED(c) }                                        \
       __builtin_amdgcn_sched_barrier(0);                                                                 \
       if (SC_TRACE_CHUNKS || c == NCH - 1) { SC_T(1 + c) }                                               \
     }                                                                                                    \
@@ -535,7 +625,6 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
   // byte offset of tile j's image in the ring, and the step from tile j to tile j + 1 (wave-uniform)
   auto img = [&](int j) -> int { return ((j / TPS) % kScSlots) * kScStageBytes + (j % TPS) * TILEB; };
   auto step = [&](int j) -> int { return img(j + 1) - img(j); };
-  SC_TDECL
   SC_T(100)
   sc_barrier();                                               // B0: stage 0 and the bias are in LDS
   SC_T(101)
@@ -545,14 +634,14 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
   for (int c = 0; c < SC_PF; ++c) SC_LD3(c, c)
   // tile 0 -> A (no hinge to do yet); the stage barrier: in every tile at K = 128, in the odd ones at K = 64
   auto tcl = [&](int j) -> int { return j < ntile ? j : ntile - 1; };
-  SC_TILE(hiA, loA, hiB, loB, false, -1, tcl(1), tcl(2), step(0), TPS == 1)
+  SC_TILE(hiA, loA, hiB, loB, false, true, -1, tcl(1), tcl(2), step(0), TPS == 1)
   // tile 1 -> B with the hinge of tile 0 (A), A re-initialised for tile 2
-  SC_TILE(hiB, loB, hiA, loA, true, -1, tcl(2), tcl(3), step(1), true)
+  SC_TILE(hiB, loB, hiA, loA, true, false, -1, tcl(2), tcl(3), step(1), true)
   for (int j = 2; j + 1 < ntile; j += 2) {
     // tile j -> A with the hinge of tile j - 1 (B) and the word of tile j - 2; B re-initialised for tile j + 1
-    SC_TILE(hiA, loA, hiB, loB, true, j - 2, tcl(j + 1), tcl(j + 2), step(j), TPS == 1)
+    SC_TILE(hiA, loA, hiB, loB, true, false, j - 2, tcl(j + 1), tcl(j + 2), step(j), TPS == 1)
     // tile j + 1 -> B with the hinge of tile j (A) and the word of tile j - 1; A re-initialised for tile j + 2
-    SC_TILE(hiB, loB, hiA, loA, true, j - 1, tcl(j + 2), tcl(j + 3), step(j + 1), true)
+    SC_TILE(hiB, loB, hiA, loA, true, false, j - 1, tcl(j + 2), tcl(j + 3), step(j + 1), true)
   }
   // tail: the word of tile ntile - 2 (h holds it), then the hinge and the word of the last tile (B)
   SC_WORD(h, ntile - 2)
@@ -563,12 +652,16 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
     rs += fmaxf(-nv, 0.f);
   }
   SC_WORD(h, ntile - 1)
+  SC_T(110)
   // the wave's words leave: lane (lr, kg) stores the tiles of parity kg (its own LDS writes: no barrier needed)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (ok) {
     for (int j = kg; j < ntile; j += 2) bits[(col0 / 32 + j) * ldbits + row] = swords[j * 128 + wv * 32 + lr];
   }
+  SC_T(111)
+  SC_TREAL(121)
 #undef SC_LD3
+#undef SC_SPLIT
 #undef SC_MFMA6
 #undef SC_TILE
 #undef SC_WORD
@@ -1220,20 +1313,19 @@ int arx_mw_scorer_fwd_seqw(const float* U, int64_t ldu, const float* P, int64_t 
   const PosMask pm = make_pos_mask(user_ids, pos_ptr, pos_items, item2slot);
   const int64_t mrows = mask_rows > 0 ? mask_rows : B;
   if (phases & 1) {
-    const int64_t grid = S / 32 + ceil_div(B, 4) + (seq_w ? ceil_div(seq_rows, 32) : 0);
+    const int64_t grid = S / 32 + ceil_div(B, 8) + (seq_w ? ceil_div(seq_rows, 32) : 0);
+    const ScTScore ts{U, ldu, T, ldt, tbias, tb_stride > 0 ? tb_stride : 1, t, tscore_out};
     k_sc_prep<<<(int)grid, 256, 0, s>>>(P, ldp, S, d, pbias, Pp, PT, L.ldpt, reinterpret_cast<float*>(st + L.pbad), pm,
-                                        mrows, B, hits, nhit, seq_w, seq_rows, row_w);
+                                        mrows, B, hits, nhit, seq_w, seq_rows, row_w, ts);
     ARX_CHECK_LAUNCH();
   }
   if (phases & 2) {
     const int64_t grid = ceil_div(B, 128) * L.nsplit;
     const size_t lds = (size_t)kScSlots * kScStageBytes + (size_t)L.CW * 4 + (size_t)(L.CW / 32) * 128 * 4;
     if (d == 128)
-      k_sc_hinge<128><<<(int)grid, 512, lds, s>>>(B, S, L.CW, U, ldu, T, ldt, tbias, tb_stride > 0 ? tb_stride : 1, Pp,
-                                                  pbias, t, tscore_out, bits, L.ldbits, rs_part, cnt_part);
+      k_sc_hinge<128><<<(int)grid, 512, lds, s>>>(B, S, L.CW, U, ldu, t, Pp, pbias, bits, L.ldbits, rs_part, cnt_part);
     else
-      k_sc_hinge<64><<<(int)grid, 512, lds, s>>>(B, S, L.CW, U, ldu, T, ldt, tbias, tb_stride > 0 ? tb_stride : 1, Pp,
-                                                 pbias, t, tscore_out, bits, L.ldbits, rs_part, cnt_part);
+      k_sc_hinge<64><<<(int)grid, 512, lds, s>>>(B, S, L.CW, U, ldu, t, Pp, pbias, bits, L.ldbits, rs_part, cnt_part);
     ARX_CHECK_LAUNCH();
   }
   if (phases & 4) {

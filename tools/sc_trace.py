@@ -35,6 +35,13 @@ ev = (buf >> np.uint64(56)).astype(np.int64)
 t = (buf & np.uint64((1 << 56) - 1)).astype(np.int64)
 n = int((buf != 0).sum())
 print("events", n)
+real = {int(ev[k]): int(t[k]) for k in range(n) if ev[k] >= 120}
+keep = [k for k in range(n) if ev[k] < 120]
+if len(real) == 2:
+    dt_us = (real[121] - real[120]) / 100.0
+    cyc = int(t[keep[-1]] - t[keep[0]])
+    print("wave lifetime %.2f us by the 100 MHz counter, %d cycle stamps -> %.2f GHz" % (dt_us, cyc, cyc / dt_us / 1e3))
+ev, t, n = ev[keep], t[keep], len(keep)
 prev = t[0]
 line = []
 for k in range(n):
