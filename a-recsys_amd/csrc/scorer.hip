@@ -27,7 +27,9 @@
 // slow the stamped kernel by 8 us and mis-attribute it (a traced build made the bias re-reads look like a third of the
 // loop): no MFMA 9.6 us, no LDS-DMA -2.3, no barriers -0.8, no re-initialising writes +-0, the bias through
 // v_readlane instead of LDS +0.6, U pre-split by k_sc_prep 24.3 but +3 us in k_sc_prep.  The part runs this kernel at
-// 1.85 - 1.95 GHz (s_memtime against s_memrealtime), not the 2.4 the guide's peak assumes.
+// 1.85 - 1.95 GHz (s_memtime against s_memrealtime), not the 2.4 the guide's peak assumes.  s_setprio 3 in the compute
+// waves: +-0.  k_sc_prep by role (blocks of the others returning at once): pool planes 5.0 us, hit lists + target scores
+// 8.7 (a chain of four dependent loads per row), together 10.1.
 //
 // Launches of a step:  k_sc_prep -> k_sc_hinge -> k_sc_rows          (arx_mw_scorer_fwd)
 //                      k_sc_bits (dU += g (act . P))                 (arx_mw_scorer_bwd_du)
@@ -257,9 +259,6 @@ __global__ __launch_bounds__(256) void k_sc_prep(const float* __restrict__ P, in
     return;
   }
   if ((int64_t)blockIdx.x < pblocks) {
-#if defined(SC_PREP_SKIP) && (SC_PREP_SKIP & 1)          // timing builds: a role's blocks return at once
-    return;
-#endif
     const int64_t r0 = (int64_t)blockIdx.x * 32;
     const int ld = d + 1;
     const int c4n = d / 4;
@@ -288,9 +287,6 @@ __global__ __launch_bounds__(256) void k_sc_prep(const float* __restrict__ P, in
   // chip's wave slots, for lists of ~20 entries).  The half wave also forms the row's target score: 32 lanes x 16 bytes
   // are a whole row of U and of T at d = 128 (at d = 64 the upper 16 lanes idle) -- two coalesced loads that ride under
   // the chain's latency.  k_sc_hinge formed t_r itself in round 4, per COLUMN split, with 16 strided loads per lane.
-#if defined(SC_PREP_SKIP) && (SC_PREP_SKIP & 2)
-  return;
-#endif
   const int lane = tid & 63, hl = lane & 31;
   const int64_t r = (((int64_t)blockIdx.x - pblocks) * 256 + tid) >> 5;
   const bool valid = r < B;
@@ -392,9 +388,6 @@ __global__ __launch_bounds__(512) void k_sc_hinge(int64_t B, int64_t S, int CW, 
   }
 
   // ================================== compute waves ==================================
-#ifdef SC_SETPRIO
-  __builtin_amdgcn_s_setprio(SC_SETPRIO);
-#endif
   const int lr = lane & 31, kg = lane >> 5;
   const int64_t row = rb * 128 + wv * 32 + lr;
   const bool ok = row < B;
