@@ -163,6 +163,8 @@ PROTOTYPES = {
     "arx_max_argmax": (cint, [f32p, i64, i64, i64, i64, cint, f32p, i32p, vp, vp]),
     "arx_reduce_scratch_bytes": (sz, []),
     "arx_gmax_residual_bwd": (cint, [f32p, i32p, f32p, i64, f32p, cint, f32p, f32p, f32p, i64, vp]),
+    "arx_gmax_norm_corr": (cint, [i32p, i32p, f32p, i64, f32p, i64, cint, cint, i64, f32p, cint, i64, i32p, f32p, i64,
+                                  f32p, cint, f32p, vp]),
     "arx_adagrad_dense": (cint, [f32p, f32p, f32p, i64, f32p, f32p, vp]),
     "arx_adagrad_dense_multi": (cint, [cint, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), f32p, f32p, vp]),
     "arx_sq_norm_accum": (cint, [f32p, i64, cint, f32p, f32p, vp, vp]),

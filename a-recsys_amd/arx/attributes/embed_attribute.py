@@ -385,21 +385,23 @@ class EmbeddingAttribute(object):
         self._pool_nodes[key] = node
         return node
 
-    def get_prediction(self, latent, pool='full', device='/gpu:0', output_feat=1, pred_cls=None):
+    def get_prediction(self, latent, pool='full', device='/gpu:0', output_feat=1, pred_cls=None, steps=None):
         """embed_attribute.py:148-206 -> logits [rows(latent), V or n_sampled].
         output_feat 0 / 1: embedding-space scorer (pool rows averaged first, one GEMM);
         2 / 3: the multi-hot features pool their per-token SCORES (max / log-sum-exp, :194-200).
-        pred_cls: scorer node class (SeqModel passes its per-time-step variant)."""
+        pred_cls: scorer node class (SeqModel passes its per-time-step variant); steps = (L, mb): the
+        latent's rows are L unrolled steps -- the reference calls get_prediction once per step
+        (seqModel.py:480-493), so output_feat 3 takes ONE reduce_max per step (:197)."""
         mk = pred_cls or (lambda lat, pe: G.Prediction(self.rt, lat, pe))
         if isinstance(latent, list):          # one latent per output feature (:169, :178)
             if output_feat not in (1, 2, 3):
                 raise NotImplementedError('Error: Attribute combination not implemented!')
-            return self._pooled_prediction(latent, pool, output_feat, mk)
+            return self._pooled_prediction(latent, pool, output_feat, mk, steps)
         if output_feat in (0, 1):
             return mk(latent, self._pool_embed(pool, output_feat))
         if output_feat not in (2, 3):
             raise NotImplementedError('Error: Attribute combination not implemented!')    # :202
-        return self._pooled_prediction(latent, pool, output_feat, mk)
+        return self._pooled_prediction(latent, pool, output_feat, mk, steps)
 
     def _pool_ids_and_maps(self, pool):
         """(ids node, per-feature maps in pool order, W): the sampled placeholder with the item
@@ -419,7 +421,7 @@ class EmbeddingAttribute(object):
         self._pool_nodes[key] = res
         return res
 
-    def _pooled_prediction(self, latent, pool, output_feat, mk):
+    def _pooled_prediction(self, latent, pool, output_feat, mk, steps=None):
         """logits = mean over output features of: the plain score for a categorical feature, the
         pooled token scores of a multi-hot one."""
         rt = self.rt
@@ -446,14 +448,16 @@ class EmbeddingAttribute(object):
             scores = mk(latent, te)
             gmax = None
             if output_feat == 3:
-                if mk is not None and type(scores) is not G.Prediction:
-                    raise NotImplementedError("output_feat 3 under a per-time-step scorer (one reduce_max per "
-                                              "unrolled step) is not implemented")
-                gmax = G.GlobalMax(rt, latent, table)
+                if type(scores) is not G.Prediction and steps is None:
+                    raise ValueError("output_feat 3 under a per-time-step scorer needs steps = (L, mb)")
+                gmax = G.GlobalMax(rt, latent, table, steps=steps)
                 vf = G.Feature('cat', table, (None,))
-                vf._inj = True
-                gmax.vstar = G.EntityEmbed(rt, G._IdsOf(rt, gmax, gmax.best_idx[1:2], 'gmax_row'), [vf],
-                                           with_bias=True)
+                vf._inj = gmax.L == 1           # (the steps' arg-max rows may coincide)
+                gmax.vstar = G.EntityEmbed(rt, G._IdsOf(rt, gmax, gmax.vrows, 'gmax_row'), [vf], with_bias=True)
+                # clip_by_global_norm (seqModel.py:180): the residual rows are part of the steps' dense matmul
+                # gradients of `table`, not a lookup of their own (SeqModel._clip_hook)
+                gmax.vstar._is_gmax_vstar = True
+                te._gmax = gmax
                 for pnode in parts + [scores]:          # its backward must follow every scorer's
                     pnode.extra_inputs = tuple(getattr(pnode, 'extra_inputs', ())) + (gmax,)
             parts.append(G.SegmentPool(rt, scores, bag, W, output_feat, gmax))

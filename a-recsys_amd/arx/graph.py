@@ -402,32 +402,43 @@ class GlobalMax(Node):
     """score_max = tf.reduce_max(innerp) over the WHOLE feature table's score matrix
     (embed_attribute.py:197): chunked scorer GEMM + running arg-max; nothing of size [B, Vf] is
     kept.  backward: the gradient that flows through the max (collected by SegmentPool) goes to
-    its arg-max element -- table row v*, batch row r* -- through `vstar` (a one-row lookup)."""
+    its arg-max element -- table row v*, batch row r* -- through `vstar` (a one-row lookup).
+    steps = (L, B): the latent holds L unrolled steps of B rows and get_prediction ran once per
+    step (lstm/seqModel.py:480-493): one maximum, arg-max and residual PER STEP."""
 
     requires_grad = True
 
-    def __init__(self, rt, latent, table, chunk=65536):
+    def __init__(self, rt, latent, table, chunk=65536, steps=None):
         super().__init__(rt, (1,), (latent,))
         self.table = table
+        self.steps = steps
         dev = rt.device
-        self.best = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.best_idx = torch.zeros(2, dtype=torch.int32, device=dev)      # (batch row, table row)
-        self.resid = torch.zeros(1, dtype=torch.float32, device=dev)
+        L, B = steps if steps else (1, latent.shape[0])
+        if L * B != latent.shape[0]:
+            raise ValueError("GlobalMax: steps do not cover the latent's rows")
+        self.L, self.B = L, B
+        self.best = torch.zeros(L, dtype=torch.float32, device=dev)
+        self.best_idx = torch.zeros((L, 2), dtype=torch.int32, device=dev)      # (row inside the step, table row)
+        self.resid = torch.zeros(L, dtype=torch.float32, device=dev)
+        self.vrows = torch.zeros(L, dtype=torch.int32, device=dev)              # table rows, contiguous (vstar's ids)
         V = int(table.E.shape[0])
         self.chunk = min(V, int(chunk))
-        self._tmp = torch.empty((latent.shape[0], self.chunk), dtype=torch.float32, device=dev)
-        self.vstar = None            # EntityEmbed over the arg-max row, set by the builder
+        self._tmp = torch.empty((B, self.chunk), dtype=torch.float32, device=dev)
+        self.vstar = None            # EntityEmbed over the arg-max rows, set by the builder
 
     def forward(self, train):
         lat = self.inputs[0]
         E, b = self.table.E, self.table.bias
         V = int(E.shape[0])
-        for c0 in range(0, V, self.chunk):
-            n = min(self.chunk, V - c0)
-            tmp = self._tmp[:, :n]
-            ops.gemm(lat.value, E[c0:c0 + n], tmp, self.rt.ws, transB=True,
-                     col_bias=b[c0:c0 + n] if b is not None else None)
-            ops.max_argmax(tmp, c0, c0 == 0, self.best, self.best_idx, scratch=self.rt.scratch)
+        for t in range(self.L):
+            rows = lat.value[t * self.B:(t + 1) * self.B]
+            for c0 in range(0, V, self.chunk):
+                n = min(self.chunk, V - c0)
+                tmp = self._tmp[:, :n]
+                ops.gemm(rows, E[c0:c0 + n], tmp, self.rt.ws, transB=True,
+                         col_bias=b[c0:c0 + n] if b is not None else None)
+                ops.max_argmax(tmp, c0, c0 == 0, self.best[t:t + 1], self.best_idx[t], scratch=self.rt.scratch)
+        self.vrows.copy_(self.best_idx[:, 1])
 
     def backward(self):
         lat, vs = self.inputs[0], self.vstar
@@ -439,7 +450,10 @@ class GlobalMax(Node):
         rg = vs.alloc_grad()
         vs.grad_beta()
         vs.bias_grad_used = True
-        ops.gmax_residual_bwd(self.resid, self.best_idx, lat.value, vs.value, rg, vs.bias_grad, dU)
+        for t in range(self.L):
+            sl = slice(t * self.B, (t + 1) * self.B)
+            ops.gmax_residual_bwd(self.resid[t:t + 1], self.best_idx[t], lat.value[sl], vs.value[t:t + 1], rg[t:t + 1],
+                                  vs.bias_grad[t:t + 1], dU[sl] if dU is not None else None)
 
 
 class _IdsOf(Node):
@@ -466,10 +480,18 @@ class SegmentPool(Node):
         self.extra_inputs = (gmax.vstar,) if gmax is not None else ()
         self._resid_rows = None
 
+    def _step_rows(self):
+        g = self.gmax
+        if g is None or g.L == 1:
+            return [(slice(0, self.shape[0]), 0)]
+        return [(slice(t * g.B, (t + 1) * g.B), t) for t in range(g.L)]
+
     def forward(self, train):
         scores, bag = self.inputs[0], self.inputs[1]
-        ops.segment_pool_fwd(scores.value, bag.offs, self.W, self.mode, self.alloc_value(),
-                             gmax=self.gmax.best if self.gmax is not None else None)
+        out = self.alloc_value()
+        for sl, t in self._step_rows():
+            ops.segment_pool_fwd(scores.value[sl], bag.offs, self.W, self.mode, out[sl],
+                                 gmax=self.gmax.best[t:t + 1] if self.gmax is not None else None)
 
     def backward(self):
         scores, bag = self.inputs[0], self.inputs[1]
@@ -481,10 +503,13 @@ class SegmentPool(Node):
             if self._resid_rows is None:
                 self._resid_rows = torch.empty(self.shape[0], dtype=torch.float32, device=self.rt.device)
             rr = self._resid_rows
-        ops.segment_pool_bwd(scores.value, bag.offs, self.W, self.mode, self.value, self.grad, ds,
-                             gmax=self.gmax.best if self.gmax is not None else None, resid_rows=rr)
+        for sl, t in self._step_rows():
+            ops.segment_pool_bwd(scores.value[sl], bag.offs, self.W, self.mode, self.value[sl], self.grad[sl], ds[sl],
+                                 gmax=self.gmax.best[t:t + 1] if self.gmax is not None else None,
+                                 resid_rows=rr[sl] if rr is not None else None)
+            if self.mode == 3:
+                ops.sum_scaled(rr[sl], 1.0, self.gmax.resid[t:t + 1])
         if self.mode == 3:
-            ops.sum_scaled(rr, 1.0, self.gmax.resid)
             self.gmax._grad_written = True            # its backward applies the residual (runs later)
 
 

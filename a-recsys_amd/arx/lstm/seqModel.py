@@ -443,18 +443,18 @@ class SeqModel(SeqBatching):
         bk = {'L': L, 'dropouts': bk_drop}
         seq_pred = lambda lat, pe: SeqPrediction(rt, lat, pe, L, B)     # scorer of all L time steps at once
         if self.loss in ('mw', 'mce'):       # ('mce': build-defined sampled softmax, see arx.h)
-            logits = m.get_prediction(hs, 'sampled', output_feat=self.output_feat, pred_cls=seq_pred)  # :492
+            logits = m.get_prediction(hs, 'sampled', output_feat=self.output_feat, pred_cls=seq_pred, steps=(L, B))  # :492
             tscore = m.get_target_score(hs, tid)                                            # :493
             bl = m.compute_loss(logits, tscore, self.loss)
         else:
-            logits = m.get_prediction(hs, 'full', output_feat=self.output_feat, pred_cls=seq_pred)   # :484
+            logits = m.get_prediction(hs, 'full', output_feat=self.output_feat, pred_cls=seq_pred, steps=(L, B))   # :484
             bl = m.compute_loss(logits, tgt, self.loss)
         bk['train'] = SeqLoss(rt, bl, wn)
         bk['train_logits'] = logits
         # losses_full (:510): full-vocabulary loss for evaluation
         if self.loss in ('mw', 'mce'):
             wn2 = SeqWeights(rt, wn.inputs[0], L, B)
-            full = m.get_prediction(hs, 'full', output_feat=self.output_feat)
+            full = m.get_prediction(hs, 'full', output_feat=self.output_feat, steps=(L, B))
             kind_full = 'warp' if self.loss == 'mw' else 'ce'
             import os as _os
             big = n * m.logit_size * 4 > int(_os.environ.get('ARX_STREAM_TOPK_BYTES', str(1 << 30)))
@@ -553,7 +553,8 @@ class SeqModel(SeqBatching):
             ops.csr_expand(f.maps[0], f.maps[1], f.maps[2], ids, ks.shape[0], rt.ws, pad_token=G.KEY_NONE,
                            pad_seg=0, seg_base=0, coef_scale=1.0 / F, want_coef=True,
                            out=(ks, ss, offs, tot, cs))
-        others = [s for s in sites_of.get(id(f.table), []) if s.node is not n]
+        others = [s for s in sites_of.get(id(f.table), [])
+                  if s.node is not n and not getattr(s.node, '_is_gmax_vstar', False)]
         others_b = [s for s in others if s.node.with_bias]
         # any IndexedSlices contribution to the variable -> every step's dense gradient is kept
         # apart (un-merged concat); otherwise the steps are add_n'ed first
@@ -561,6 +562,21 @@ class SeqModel(SeqBatching):
         Xb, Lb = (sp.rs_steps, L) if others_b else (n.bias_grad, 1)
         ops.merged_sq_norm(ks, ss, cs, f.table.E.shape[0], sq, rt.ws, scratch=rt.scratch, X=X, d=d, L=Lx, step_stride=S * d,
                            Xb=Xb, Lb=Lb, stepb_stride=S)
+        gmax = getattr(n, '_gmax', None)
+        if gmax is not None and gmax.vstar._grad_written:
+            # output_feat 3: each step's reduce_max sends its residual to ONE element of that step's dense matmul
+            # gradient (embed_attribute.py:197) -- a rank-one row on table row v*_t that the merged norm above has not
+            # seen (it travels as the gradient of the `vstar` lookup): arx_gmax_norm_corr adds what it changes
+            vs = gmax.vstar
+            ckey = ('gmaxcorr', id(n))
+            if ckey not in cache:
+                cache[ckey] = (torch.zeros(gmax.L, dtype=torch.float32, device=rt.device),
+                               torch.zeros(1, dtype=torch.float32, device=rt.device))
+            corr, tot = cache[ckey]
+            ops.gmax_norm_corr(ks, ss, cs, ks.shape[0], X, d, bool(others), S * d, Xb, bool(others_b), S, gmax.vrows,
+                               vs.grad, vs.bias_grad if vs.bias_grad_used else None, corr)
+            ops.sum_scaled(corr, 1.0, tot)
+            ops.axpby(1.0, tot, 1.0, sq)
 
     def _tiled(self, rs, L, tag, static=False):
         """rs repeated for each of the L unrolled steps; static: rs never changes (one-hot features
@@ -610,6 +626,8 @@ class SeqModel(SeqBatching):
         for n in plan.order:
             if not (isinstance(n, G.EntityEmbed) and n.train_tables and n._grad_written):
                 continue
+            if getattr(n, '_is_gmax_vstar', False):
+                continue                  # (counted with the pool feature it belongs to: _shared_rows_norm)
             if id(n) in seq_pools:
                 sp = seq_pools[id(n)]
                 L, S, d = sp.C_steps.shape
@@ -625,7 +643,8 @@ class SeqModel(SeqBatching):
                     for f in n.feats:
                         if f in shared:
                             continue
-                        others = [s for s in sites_of.get(id(f.table), []) if s.node is not n]
+                        others = [s for s in sites_of.get(id(f.table), [])
+                                  if s.node is not n and not getattr(s.node, '_is_gmax_vstar', False)]
                         if for_bias:
                             others = [s for s in others if s.node.with_bias]
                         (per_step if others else merged).append(f)

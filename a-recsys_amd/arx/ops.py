@@ -725,6 +725,13 @@ def gmax_residual_bwd(resid, idx, U, E_row, row_grad, bias_grad, dU):
          _p(bias_grad), _p(dU), _ld(dU) if dU is not None else 0, _stream())
 
 
+def gmax_norm_corr(keys, src, coef, n, X, d, per_step, step_stride, Xb, per_step_b, stepb_stride, vrows, RG, RGb, corr):
+    """corr[t] = change of a merged table gradient's squared norm from the arg-max residual rows (arx.h)."""
+    call("arx_gmax_norm_corr", _p(keys), _p(src), _p(coef), int(n), _p(X), int(X.stride(-2)) if X is not None else 0,
+         int(d), int(bool(per_step)), int(step_stride), _p(Xb), int(bool(per_step_b)), int(stepb_stride), _p(vrows),
+         _p(RG), int(RG.stride(-2)) if RG is not None else 0, _p(RGb), int(vrows.shape[0]), _p(corr), _stream())
+
+
 def adagrad_dense(w, acc, g, lr_dev, gscale_dev=None):
     call("arx_adagrad_dense", _p(w), _p(acc), _p(g), int(w.numel()), _p(lr_dev), _p(gscale_dev),
          _stream())

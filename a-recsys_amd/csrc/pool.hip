@@ -159,6 +159,71 @@ __global__ void k_gmax_residual(const float* __restrict__ resid, const int32_t* 
   if (c == 0 && bias_grad) bias_grad[0] = g;
 }
 
+// arx_gmax_norm_corr: workgroup t, 256 threads.  M = the merged gradient row of table row v = vrows[t] (sum over the key
+// list's entries naming v, in list order within a thread group, groups combined in fixed order), R = the rank-one rows
+// that land on v (per_step: RG[t] alone; summed: every RG[t'] with vrows[t'] == v, and only the FIRST such t does the
+// work).  corr[t] = 2 <M, R> + |R|^2 (+ the d = 1 analogue on the bias gradients).
+__global__ __launch_bounds__(256) void k_gmax_norm_corr(const int32_t* __restrict__ keys, const int32_t* __restrict__ src,
+                                                        const float* __restrict__ coef, int64_t n,
+                                                        const float* __restrict__ X, int64_t ldx, int d, int per_step,
+                                                        int64_t step_stride, const float* __restrict__ Xb,
+                                                        int per_step_b, int64_t stepb_stride,
+                                                        const int32_t* __restrict__ vrows, const float* __restrict__ RG,
+                                                        int64_t ldrg, const float* __restrict__ RGb, int L,
+                                                        float* __restrict__ corr) {
+  __shared__ float sm[256];
+  __shared__ float sr[256];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int v = vrows[t];
+  float total = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {              // 0: the embedding rows (width d), 1: the bias cells (width 1)
+    const float* Xp = pass == 0 ? X : Xb;
+    const float* Rp = pass == 0 ? RG : RGb;
+    if (!Xp || !Rp) continue;
+    const int w = pass == 0 ? d : 1;
+    const bool steps = pass == 0 ? per_step != 0 : per_step_b != 0;
+    const int64_t xstep = pass == 0 ? step_stride : stepb_stride;
+    const int64_t xld = pass == 0 ? ldx : 1, rld = pass == 0 ? ldrg : 1;
+    bool first = true;                                // summed form: only the first step naming v works
+    if (!steps)
+      for (int t2 = 0; t2 < t; ++t2) first = first && vrows[t2] != v;
+    float acc = 0.f;
+    if (first) {
+      const float* Xt = Xp + (steps ? (int64_t)t * xstep : 0);
+      for (int c0 = 0; c0 < w; c0 += 256) {           // column block (d <= 1024)
+        const int ng = w - c0 >= 256 ? 1 : 256 / (w - c0 < 1 ? 1 : (w - c0));   // thread groups over the key list
+        const int wc = w - c0 >= 256 ? 256 : w - c0;
+        const int col = tid % wc, g = tid / wc;
+        float m = 0.f;
+        if (g < ng)
+          for (int64_t k = g; k < n; k += ng)
+            if (keys[k] == v) m += coef[k] * Xt[(int64_t)src[k] * xld + c0 + col];
+        sm[tid] = g < ng ? m : 0.f;
+        float r = 0.f;
+        if (g == 0) {
+          if (steps) r = Rp[(int64_t)t * rld + c0 + col];
+          else
+            for (int t2 = t; t2 < L; ++t2)
+              if (vrows[t2] == v) r += Rp[(int64_t)t2 * rld + c0 + col];
+        }
+        sr[tid] = r;
+        __syncthreads();
+        if (g == 0) {
+          float mm = 0.f;
+          for (int gg = 0; gg < ng; ++gg) mm += sm[gg * wc + col];
+          sm[tid] = 2.f * mm * r + r * r;
+        }
+        __syncthreads();
+        if (tid == 0)
+          for (int cc = 0; cc < wc; ++cc) acc += sm[cc];
+        __syncthreads();
+      }
+    }
+    total += acc;
+  }
+  if (tid == 0) corr[t] = total;
+}
+
 }  // namespace
 
 }  // namespace arx
@@ -215,6 +280,19 @@ int arx_gmax_residual_bwd(const float* resid_dev, const int32_t* idx_dev, const 
                 "arx_gmax_residual_bwd: bad argument");
   k_gmax_residual<<<1, 1024, 0, as_stream(stream)>>>(resid_dev, idx_dev, U, ldu, E_row, d, row_grad, bias_grad,
                                                       dU, lddu);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_gmax_norm_corr(const int32_t* keys, const int32_t* src, const float* coef, int64_t n, const float* X,
+                       int64_t ldx, int d, int per_step, int64_t step_stride, const float* Xb, int per_step_b,
+                       int64_t stepb_stride, const int32_t* vrows, const float* RG, int64_t ldrg, const float* RGb,
+                       int L, float* corr, void* stream) {
+  ARX_CHECK_ARG(keys && src && coef && vrows && corr && n >= 0 && L > 0, "arx_gmax_norm_corr: bad argument");
+  ARX_CHECK_ARG((X && RG && d > 0 && d <= 1024 && ldx >= d && ldrg >= d) || (Xb && RGb),
+                "arx_gmax_norm_corr: neither the embedding nor the bias gradients given");
+  k_gmax_norm_corr<<<L, 256, 0, as_stream(stream)>>>(keys, src, coef, n, X, ldx, d, per_step, step_stride, Xb,
+                                                      per_step_b, stepb_stride, vrows, RG, ldrg, RGb, L, corr);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

@@ -688,6 +688,21 @@ int arx_max_argmax(const float* x, int64_t rows, int64_t cols, int64_t ld, int64
 int arx_gmax_residual_bwd(const float* resid_dev, const int32_t* idx_dev, const float* U, int64_t ldu,
                           const float* E_row, int d, float* row_grad, float* bias_grad, float* dU,
                           int64_t lddu, void* stream);
+/* output_feat 3 under a per-time-step scorer (lstm/seqModel.py:492 -> embed_attribute.py:197-200: one reduce_max
+ * per unrolled step): step t's residual is the rank-one row RG[t] = resid_t * U[r*_t] on table row vrows[t] (+ RGb[t]
+ * on its bias cell) -- in TF part of that step's DENSE matmul gradient, so clip_by_global_norm (seqModel.py:180) squares
+ * it together with the merged token contributions of the same row.  corr[t] = what adding it changes of the squared
+ * norm arx_merged_sq_norm computed without it:
+ *   per_step != 0 (the steps' gradients X[t] stay apart: an IndexedSlices contribution to the variable exists)
+ *       2 <M_t[v_t], RG_t> + |RG_t|^2,  M_t[v] = sum_{k: keys[k] == v} coef[k] X[t][src[k]]
+ *   per_step == 0 (one summed gradient X): rows naming the same table row add up first, R_v = sum_{t: v_t = v} RG_t;
+ *       corr[t] = 2 <M[v_t], R_v> + |R_v|^2 for the FIRST t naming v, 0 for the others
+ * and the d = 1 analogue on (Xb, RGb) with its own per_step flag.  The caller adds sum_t corr[t] (fixed order) to the
+ * squared norm.  keys / src / coef: the pool's token list as given to arx_merged_sq_norm. */
+int arx_gmax_norm_corr(const int32_t* keys, const int32_t* src, const float* coef, int64_t n, const float* X,
+                       int64_t ldx, int d, int per_step, int64_t step_stride, const float* Xb, int per_step_b,
+                       int64_t stepb_stride, const int32_t* vrows, const float* RG, int64_t ldrg, const float* RGb,
+                       int L, float* corr, void* stream);
 
 /* ---- a16/a19: dense Adagrad, norms, clip ---------------------------------
  * tf.train.AdagradOptimizer dense apply; tf.clip_by_global_norm

@@ -13,7 +13,7 @@ RTOL = 1e-4
 
 
 def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False, use_concat=False, num_layers=1,
-           keep=1.0, adagrad=True, buckets=None, output_feat=1):
+           keep=1.0, adagrad=True, buckets=None, output_feat=1, no_input_item_feature=False):
     from arx.attributes.embed_attribute import EmbeddingAttribute
     from arx.lstm.seqModel import SeqModel
     from arx.utils.synthetic import SyntheticHMF
@@ -41,13 +41,14 @@ def _build(cfg, loss, size, B, L, S, clip, seed, no_user_id=False, use_concat=Fa
     emb = EmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i, params=params)
     model = SeqModel(buckets or [L], size, num_layers, clip, B, 0.5, 0.83, emb, loss=loss, use_concat=use_concat,
                      no_user_id=no_user_id, START_ID=START, params=params, dropoutRate=keep,
-                     withAdagrad=adagrad, output_feat=output_feat)
+                     withAdagrad=adagrad, output_feat=output_feat, no_input_item_feature=no_input_item_feature)
     remb = rg.RefEmbeddingAttribute(syn.u_attr, syn.i_attr, B, n_s, L, False, i2l, l2i,
                                     params={k: v for k, v in params.items() if not k.startswith('lstm')},
                                     dtype=np.float64)
     ref = ref_lstm.RefSeqModel(L, size, clip, B, 0.5, remb, loss=loss, no_user_id=no_user_id,
                                params=params, use_concat=use_concat, num_layers=num_layers,
-                               withAdagrad=adagrad, output_feat=output_feat)
+                               withAdagrad=adagrad, output_feat=output_feat,
+                               no_input_item_feature=no_input_item_feature)
     pos = syn.positives_dict()
     emb.prepare_warp(pos, pos)
     remb.prepare_warp(pos, pos)
@@ -152,6 +153,39 @@ def test_seq_output_feat_2_max_pooled_scores(dev, loss, S, clip):
     size, B, L = 64, 16, 4
     syn, emb, model, remb, ref = _build(CFG_HET, loss, size, B, L, S, clip, seed=21, output_feat=2)
     rng = np.random.default_rng(23)
+    pool = id2idx = None
+    if loss == 'mw':
+        pool = syn.sample_pool(S, rng)
+        id2idx = {int(v): i for i, v in enumerate(pool)}
+    for step in range(3):
+        users, inp, tg, w = _batch(syn, rng, L, B)
+        ps = pool if step == 0 else None
+        l_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), ps, id2idx)
+        l_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, ps, id2idx)
+        np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='loss step %d' % step)
+        np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL,
+                                   err_msg='global norm step %d' % step)
+        _compare(emb, model, remb, ref)
+    e_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), None, id2idx, forward_only=True)
+    e_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, None, id2idx,
+                       forward_only=True)
+    np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
+
+
+@pytest.mark.parametrize("loss,S,clip,no_in", [('mw', 64, 0.5, False), ('ce', None, 5.0, False), ('ce', None, 0.5, True)])
+def test_seq_output_feat_3_log_sum_exp_pooled_scores(dev, loss, S, clip, no_in):
+    """output_feat = 3 (lstm/run.py:80; embed_attribute.py:197-200): score_max + log(1 + segment_sum(exp(score -
+    score_max))) with score_max = reduce_max over the WHOLE table's score matrix -- and get_prediction runs once per
+    unrolled step (seqModel.py:480-493), so every step has its own maximum, arg-max element and residual gradient
+    (round 5: GlobalMax(steps=(L, mb)); rounds 2-4 raised NotImplementedError here).  clip_by_global_norm sees the
+    residual inside the step's dense matmul gradient of the table (arx_gmax_norm_corr): the global norm is compared
+    with an ACTIVE clip (0.5) and with an inactive one; no_in = no_input_item_feature with 'ce': no lookup touches the
+    token table, so TF add_n's the steps' dense gradients and the norm runs over their SUM (the other form of the
+    correction: residual rows of different steps on one table row add up first)."""
+    size, B, L = 64, 16, 4
+    syn, emb, model, remb, ref = _build(CFG_HET, loss, size, B, L, S, clip, seed=31, output_feat=3,
+                                        no_input_item_feature=no_in)
+    rng = np.random.default_rng(29)
     pool = id2idx = None
     if loss == 'mw':
         pool = syn.sample_pool(S, rng)
