@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--len", type=int, default=50)
     ap.add_argument("--n-sampled", type=int, default=1024)
+    ap.add_argument("--loss", default="mw", choices=["mw", "mce"])
     args = ap.parse_args()
     torch.cuda.set_device(0)
     from arx.attributes.embed_attribute import EmbeddingAttribute
@@ -48,7 +49,7 @@ def main():
     i2l = syn.item2logit[:args.n_items]
     START = args.n_items
     emb = EmbeddingAttribute(syn.u_attr, syn.i_attr, B, S, L, False, None, syn.logit_ind2item_ind)
-    model = SeqModel([L], size, 1, 5.0, B, 0.5, 0.99, emb, loss='mw', use_concat=False,
+    model = SeqModel([L], size, 1, 5.0, B, 0.5, 0.99, emb, loss=args.loss, use_concat=False,
                      START_ID=START)
     emb.prepare_warp(syn.positives_csr(), syn.positives_csr())
     dev = model.rt.device
