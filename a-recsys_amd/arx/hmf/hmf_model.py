@@ -139,9 +139,15 @@ class TopK(G.Node):
 
 
 class StreamTopK(G.Node):
-    """top_k over the FULL vocabulary without the [mb, V] logits: the scorer GEMM
-    runs over chunks of the pool rows, every chunk keeps its k best per row (radix select) and a
-    merge folds them into the running result -- same indices/values as TopK(Prediction)."""
+    """top_k over the FULL vocabulary without the [mb, V] logits -- same indices / values as
+    TopK(Prediction), tf.nn.top_k's tie rule included.
+    fused (round 5, the default where the scorer GEMM's small-K kernel applies): the first chunk of the pool gives
+    every row its k best (GEMM -> radix select); the scorer GEMM over ALL the other columns then writes no logits --
+    arx_gemm_nt_topk_filter keeps only what beats the row's k-th best so far, as short candidate lists in column order;
+    one select over the lists and one merge finish.  A candidate list that overflows (scores rising along the
+    vocabulary) sets a flag: overflowed() -- LatentProductModel.step re-runs the request on the chunked path.
+    chunked: the GEMM runs over chunks of the pool rows, every chunk keeps its k best per row (radix select) and a
+    merge folds them into the running result."""
 
     def __init__(self, rt, latent, pool, k, chunk=65536):
         super().__init__(rt, (latent.shape[0], k), (latent, pool))
@@ -155,12 +161,58 @@ class StreamTopK(G.Node):
         tail = V % self.chunk                       # a last chunk narrower than k keeps only `tail` entries
         kt = tail if 0 < tail < k else k
         self._tv, self._ti = torch.empty((B, kt), dtype=f32, device=dev), torch.empty((B, kt), dtype=i32, device=dev)
+        self.fused = (os.environ.get('ARX_TOPK_FUSED', '1') != '0' and latent.shape[1] in (32, 64, 128)
+                      and pool.shape[1] == latent.shape[1])
+        self.overflow = torch.zeros(1, dtype=i32, device=dev)
+        self.slack, self.min_capp = 4.0, 32          # candidate segment = slack x the expected survivors, >= min_capp
+        self._cand = None
+
+    def _cand_bufs(self, n0, V):
+        """Candidate rows [B, parts * capp]: a column range's expected survivors are k (V - n0) / n0 / parts (scores in
+        no particular order along the vocabulary); four times that, at least 32."""
+        key = (n0, V, self.slack, self.min_capp)
+        if self._cand is None or self._cand[0] != key:
+            B, k, dev = self.shape[0], self.k, self.rt.device
+            parts = ops.gemm_nt_topk_parts(B, V - n0)
+            expect = k * (V - n0) / float(n0) / parts
+            capp = self.min_capp
+            while capp < self.slack * expect + self.min_capp:
+                capp *= 2
+            while parts * capp < k:
+                capp *= 2
+            cap = parts * capp
+            self._cand = (key, capp, torch.empty((B, cap), dtype=torch.float32, device=dev),
+                          torch.zeros((B, cap), dtype=torch.int32, device=dev),
+                          torch.empty((B, k), dtype=torch.int32, device=dev))
+        return self._cand[1:]
+
+    def overflowed(self):
+        """True when the last fused run dropped candidates (device -> host read)."""
+        return bool(self.fused and int(self.overflow.item()) != 0)
 
     def forward(self, train):
         latent, pool = self.inputs
         V, k = pool.shape[0], self.k
         run_v, run_i = self.alloc_value(), self.indices
         out_v, out_i = self._ov, self._oi
+        if self.fused and V > self.chunk and pool.value.stride(0) % 4 == 0 and latent.value.stride(0) % 4 == 0:
+            n0 = self.chunk
+            lg = self._buf[:, :n0]
+            bias = pool.bias_value
+            ops.gemm(latent.value, pool.value[:n0], lg, self.rt.ws, transB=True,
+                     col_bias=bias[:n0] if bias is not None else None)
+            ops.topk_chunk(lg, k, 0, run_v, run_i)
+            capp, cand_v, cand_i, cpos = self._cand_bufs(n0, V)
+            ops.fill_f32(cand_v.view(-1), float('-inf'))
+            ops.fill_i32(self.overflow, 0)
+            ops.gemm_nt_topk_filter(latent.value, pool.value[n0:], bias[n0:] if bias is not None else None,
+                                    run_v[:, k - 1], n0, cand_v, cand_i, capp, self.overflow)
+            ops.topk_chunk(cand_v, k, 0, self._cv, cpos)
+            ops.take_rows_i32(cand_i, cpos, self._ci)
+            ops.topk_merge(run_v, run_i, self._cv, self._ci, k, out_v, out_i)
+            self.value.copy_(out_v)
+            self.indices.copy_(out_i)
+            return
         for c0 in range(0, V, self.chunk):
             c1 = min(V, c0 + self.chunk)
             kc = min(k, c1 - c0)
@@ -446,6 +498,18 @@ class LatentProductModel(object):
                               item_sampled_id2idx, forward_only, recommend, recommend_new, loss,
                               run_op, run_meta)
         if recommend:
+            if isinstance(self.topk, StreamTopK) and self.topk.overflowed():
+                # a candidate list of the fused top-k was too short for this batch: once more on the chunked path
+                self.topk.fused = False
+                self._plans.pop('recommend', None)
+                try:
+                    out = self.step_async(session, user_input, item_input, neg_item_input, item_sampled,
+                                          item_sampled_id2idx, forward_only, recommend, recommend_new, loss, run_op,
+                                          run_meta)
+                    return out.cpu().numpy()
+                finally:
+                    self.topk.fused = True
+                    self._plans.pop('recommend', None)
             return out.cpu().numpy()
         if isinstance(out, list):
             return [o.cpu().numpy() for o in out]

@@ -915,6 +915,26 @@ def topk_merge(va, ia, vb, ib, k, vo, io):
          int(vb.shape[1]), int(k), _p(vo), _p(io), _stream())
 
 
+def gemm_nt_topk_parts(M, N):
+    """Column ranges arx_gemm_nt_topk_filter splits N columns into for M rows (sizes the candidate rows)."""
+    import ctypes as C
+    n = C.c_int(0)
+    call("arx_gemm_nt_topk_parts", int(M), int(N), C.byref(n))
+    return int(n.value)
+
+
+def gemm_nt_topk_filter(A, Bm, col_bias, thr, col_base, cand_v, cand_i, capp, overflow):
+    """Scorer GEMM A . Bm^T + col_bias that keeps only the logits above thr[row] (arx.h)."""
+    call("arx_gemm_nt_topk_filter", _p(A), _ld(A), int(A.shape[0]), _p(Bm), _ld(Bm), int(Bm.shape[0]), int(A.shape[1]),
+         _p(col_bias), _p(thr), int(thr.stride(0)), int(col_base), _p(cand_v), _p(cand_i), int(cand_v.stride(0)),
+         int(capp), _p(overflow), _stream())
+
+
+def take_rows_i32(table, pos, out):
+    call("arx_take_rows_i32", _p(table), int(table.stride(0)), _p(pos), int(pos.stride(0)), int(pos.shape[0]),
+         int(pos.shape[1]), _p(out), int(out.stride(0)), _stream())
+
+
 def topk(logits, k, values, indices):
     call("arx_topk", _p(logits), _ld(logits), int(logits.shape[0]), int(logits.shape[1]), int(k),
          _p(values), _p(indices), _stream())

@@ -37,11 +37,24 @@ __device__ __forceinline__ int nt_swz(int r) {
   return (KT >= 64) ? (r & 15) : ((r >> 1) & 7);
 }
 
-template <int KT>
+// FILTER (round 5, the recommend path: hmf_model.py:154 tf.nn.top_k over the FULL vocabulary): no C.  A logit leaves
+// the kernel only if it beats its row's threshold thr[row] (the k-th best of the columns scored so far): it is appended
+// to the row's candidate segment of this workgroup's column range, cand[row][part * capp ..), in ascending column
+// order -- a wave owns its 32 rows, keeps their 16 + 16 counters in registers and places a tile's survivors by ballot
+// + prefix count, so the lists are deterministic, need no atomics, and POSITION order is COLUMN order (what
+// arx_topk_chunk's tie rule needs).  A full segment raises *overflow (the caller falls back to the chunked path).
+struct NtFilter {
+  const float* thr; int64_t ldthr;
+  float* cand_v; int32_t* cand_i; int64_t ldcand;
+  int capp; int32_t col_base;
+  int* overflow;
+};
+
+template <int KT, bool FILTER = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
     int64_t M, int64_t N, const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
     int64_t ldb, float alpha, float* __restrict__ C, int64_t ldc,
-    const float* __restrict__ col_bias, int tiles_per_block, int nsplit) {
+    const float* __restrict__ col_bias, int tiles_per_block, int nsplit, NtFilter flt) {
   constexpr int NS = KT / 8;                  // steps of 4 MFMAs
   constexpr int CPR = KT / 4;                 // 16-B chunks per pool row
   constexpr int NLB = kNtBN * CPR / 256;      // DMA pieces per thread per tile
@@ -98,6 +111,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
     if (!ok) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) a[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // FILTER: thresholds and list lengths of the lane's 16 rows (row = rbase + (e & 3) + 8 (e >> 2))
+  float th[FILTER ? 16 : 1];
+  int cnt[FILTER ? 16 : 1];
+  bool ovf = false;
+  if (FILTER) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = m0 + wave * 32 + 4 * lhi + (e & 3) + 8 * (e >> 2);
+      th[e] = row < M ? flt.thr[row * flt.ldthr] : __builtin_inff();
+      cnt[e] = 0;
     }
   }
   // bias of the first tile (later ones are fetched one tile ahead, behind the DMA issue)
@@ -158,6 +183,32 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
     const int64_t n0 = t * kNtBN;
     const int64_t rbase = m0 + wave * 32 + 4 * lhi;
+    if (FILTER) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t col = n0 + j * 32 + l31;
+        const float bias = (j == 0) ? bias0 : bias1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = alpha * (j == 0 ? acc0[e] : acc1[e]) + bias;
+          const bool pred = col < N && v > th[e];
+          const unsigned long long m = __ballot(pred);
+          if (m == 0ull) continue;                                  // (the common case by far)
+          const uint32_t mh = lhi ? (uint32_t)(m >> 32) : (uint32_t)m;
+          const int pos = cnt[e] + __popc(mh & ((1u << l31) - 1u));
+          if (pred) {
+            if (pos < flt.capp) {
+              const int64_t at = (rbase + (e & 3) + 8 * (e >> 2)) * flt.ldcand + (int64_t)part * flt.capp + pos;
+              flt.cand_v[at] = v;
+              flt.cand_i[at] = flt.col_base + (int32_t)col;
+            } else {
+              ovf = true;
+            }
+          }
+          cnt[e] += __popc(mh);
+        }
+      }
+    } else
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int64_t col = n0 + j * 32 + l31;
@@ -180,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
     tile(t, sB0, sB1);
     if (t + 1 < t_end) tile(t + 1, sB1, sB0);
   }
+  if (FILTER && ovf) *flt.overflow = 1;
 }
 
 }  // namespace
@@ -205,15 +257,68 @@ int gemm_nt_smallk(int64_t M, int64_t N, int64_t K, float alpha, const float* A,
   if (grid > 0x7fffffff) return ARX_EUNSUPPORTED;
   if (K == 128)
     k_gemm_nt_areg<128><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, alpha, C, ldc, col_bias,
-                                                   (int)tpb, (int)nsplit);
+                                                   (int)tpb, (int)nsplit, NtFilter{});
   else if (K == 64)
     k_gemm_nt_areg<64><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, alpha, C, ldc, col_bias,
-                                                  (int)tpb, (int)nsplit);
+                                                  (int)tpb, (int)nsplit, NtFilter{});
   else
     k_gemm_nt_areg<32><<<(int)grid, 256, 0, s>>>(M, N, A, lda, B, ldb, alpha, C, ldc, col_bias,
-                                                  (int)tpb, (int)nsplit);
+                                                  (int)tpb, (int)nsplit, NtFilter{});
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
 
+static void nt_split(int64_t M, int64_t N, int64_t* tpb, int64_t* nsplit) {
+  const int64_t panels = ceil_div(M, (int64_t)kNtBM);
+  const int64_t tiles_n = ceil_div(N, (int64_t)kNtBN);
+  int64_t ns = ceil_div((int64_t)cu_count() * 2, panels);
+  if (ns > tiles_n) ns = tiles_n;
+  if (ns < 1) ns = 1;
+  *tpb = ceil_div(tiles_n, ns);
+  *nsplit = ceil_div(tiles_n, *tpb);
+}
+
 }  // namespace arx
+
+using namespace arx;
+
+extern "C" {
+
+int arx_gemm_nt_topk_parts(int64_t M, int64_t N, int* parts) {
+  ARX_CHECK_ARG(M > 0 && N > 0 && parts, "arx_gemm_nt_topk_parts: bad argument");
+  int64_t tpb, ns;
+  nt_split(M, N, &tpb, &ns);
+  *parts = (int)ns;
+  return ARX_OK;
+}
+
+int arx_gemm_nt_topk_filter(const float* A, int64_t lda, int64_t M, const float* Bm, int64_t ldb, int64_t N, int64_t K,
+                            const float* col_bias, const float* thr, int64_t ldthr, int32_t col_base, float* cand_v,
+                            int32_t* cand_i, int64_t ldcand, int capp, int* overflow, void* stream) {
+  ARX_CHECK_ARG(A && Bm && thr && cand_v && cand_i && overflow && M > 0 && N > 0 && capp > 0,
+                "arx_gemm_nt_topk_filter: bad argument");
+  ARX_CHECK_ARG(K == 32 || K == 64 || K == 128, "arx_gemm_nt_topk_filter: K must be 32, 64 or 128");
+  ARX_CHECK_ARG(!((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bm)) & 15) && lda % 4 == 0 &&
+                    ldb % 4 == 0,
+                "arx_gemm_nt_topk_filter: operands must be 16-byte aligned");
+  int64_t tpb, ns;
+  nt_split(M, N, &tpb, &ns);
+  ARX_CHECK_ARG(ns * capp <= ldcand, "arx_gemm_nt_topk_filter: candidate rows too short (parts * capp > ldcand)");
+  const int64_t grid = ceil_div(M, (int64_t)kNtBM) * ns;
+  ARX_CHECK_ARG(grid <= 0x7fffffff, "arx_gemm_nt_topk_filter: grid too large");
+  const NtFilter f{thr, ldthr, cand_v, cand_i, ldcand, capp, col_base, overflow};
+  hipStream_t s = as_stream(stream);
+  if (K == 128)
+    k_gemm_nt_areg<128, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, (int)tpb,
+                                                         (int)ns, f);
+  else if (K == 64)
+    k_gemm_nt_areg<64, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, (int)tpb,
+                                                        (int)ns, f);
+  else
+    k_gemm_nt_areg<32, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, (int)tpb,
+                                                        (int)ns, f);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+}  // extern "C"

@@ -193,6 +193,16 @@ __global__ void k_topk_merge(const float* __restrict__ va, const int32_t* __rest
   }
 }
 
+// out[r][j] = table[r][pos[r][j]]: positions inside a row's candidate list -> the candidates' column indices
+__global__ void k_take_rows_i32(const int32_t* __restrict__ table, int64_t ld, const int32_t* __restrict__ pos,
+                                int64_t ldp, int64_t B, int k, int32_t* __restrict__ out, int64_t ldo) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * k) return;
+  const int64_t r = i / k;
+  const int j = (int)(i % k);
+  out[r * ldo + j] = table[r * ld + pos[r * ldp + j]];
+}
+
 }  // namespace
 
 int topk_select_launch(const float* logits, int64_t ld, int64_t B, int64_t V, int k, int32_t idx_base,
@@ -222,6 +232,15 @@ int arx_topk_merge(const float* va, const int32_t* ia, const float* vb, const in
   ARX_CHECK_ARG(ka >= 0 && kb >= 0 && k > 0 && k <= ka + kb, "arx_topk_merge: need 0 < k <= ka + kb");
   if (B <= 0) return ARX_OK;
   k_topk_merge<<<(int)ceil_div(B, 64), 64, 0, as_stream(stream)>>>(va, ia, vb, ib, B, ka, kb, k, vo, io);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_take_rows_i32(const int32_t* table, int64_t ld, const int32_t* pos, int64_t ldp, int64_t B, int k,
+                      int32_t* out, int64_t ldo, void* stream) {
+  ARX_CHECK_ARG(table && pos && out && k > 0, "arx_take_rows_i32: bad argument");
+  if (B <= 0) return ARX_OK;
+  k_take_rows_i32<<<(int)ceil_div(B * k, 256), 256, 0, as_stream(stream)>>>(table, ld, pos, ldp, B, k, out, ldo);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

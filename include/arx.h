@@ -810,6 +810,23 @@ int arx_topk_chunk(const float* logits, int64_t ld, int64_t B, int64_t V, int k,
 int arx_topk_merge(const float* va, const int32_t* ia, const float* vb, const int32_t* ib, int64_t B,
                    int ka, int kb, int k, float* vo, int32_t* io, void* stream);
 
+/* The fused form of that streaming scorer (round 5): after the first chunk gave every row its k best (arx_topk_chunk),
+ * the scorer GEMM over the REST of the vocabulary writes no logits -- arx_gemm_nt_topk_filter keeps, per row, only the
+ * logits above thr[row * ldthr] (the row's k-th best so far; strictly above: an equal one further right loses the tie)
+ * as (value, global column = col_base + column) in cand_v / cand_i [M, ldcand]: the kernel splits the columns into
+ * `parts` ranges (arx_gemm_nt_topk_parts; one workgroup per 128 rows and range) and range p fills
+ * cand[row][p * capp ..) in ascending column order, deterministically.  Pre-fill cand_v with -inf: then
+ * arx_topk_chunk over the candidate rows (positions are in column order, so its tie rule holds), arx_take_rows_i32
+ * (positions -> columns) and arx_topk_merge finish the top-k.  *overflow is set when a range's segment was too short
+ * (results incomplete: fall back to the chunked path).  K in {32, 64, 128}; values bit-identical to arx_gemm_f32's. */
+int arx_gemm_nt_topk_parts(int64_t M, int64_t N, int* parts);
+int arx_gemm_nt_topk_filter(const float* A, int64_t lda, int64_t M, const float* Bm, int64_t ldb, int64_t N, int64_t K,
+                            const float* col_bias, const float* thr, int64_t ldthr, int32_t col_base, float* cand_v,
+                            int32_t* cand_i, int64_t ldcand, int capp, int* overflow, void* stream);
+/* out[r][j] = table[r * ld + pos[r * ldp + j]], r < B, j < k */
+int arx_take_rows_i32(const int32_t* table, int64_t ld, const int32_t* pos, int64_t ldp, int64_t B, int k,
+                      int32_t* out, int64_t ldo, void* stream);
+
 /* ---- a19-a20: LSTM encoder (K9) ---------------------------------------------
  * lstm/seqModel.py:99-103,477 -- tf.contrib.rnn LSTMCell(h), no peepholes,
  * forget_bias=1, gate order i,j,f,o, zero initial state, static_rnn over L

@@ -249,9 +249,15 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     assert l2 == l2b     # deterministic kernels: same state + same batch -> same loss bits
 
 
-def test_recommend_streaming_topk_equals_materialised(dev, monkeypatch):
-    """chunked scorer + running top-k (StreamTopK) returns exactly the
-    recommendation of the materialised [mb, V] path (index-exact, same tie rule)."""
+@pytest.mark.parametrize("mode", ['fused', 'chunked', 'fused-overflow', 'fused-ties'])
+def test_recommend_streaming_topk_equals_materialised(dev, monkeypatch, mode):
+    """the streaming full-vocabulary top-k (StreamTopK) returns exactly the recommendation of the
+    materialised [mb, V] path (index-exact, same tie rule).  fused (round 5): first chunk -> thresholds, then the
+    scorer GEMM over the rest of the vocabulary keeps only the logits above them (arx_gemm_nt_topk_filter), select,
+    merge; chunked: GEMM + select + merge per chunk; fused-overflow: item biases RISING along the vocabulary -- every
+    later column beats the first chunk's thresholds, the candidate lists overflow, the flag sends the request to the
+    chunked path; fused-ties: blocks of items with IDENTICAL rows and biases across the chunk boundary (equal logits:
+    the lower index has to win, inside the candidate lists and against the first chunk's)."""
     from arx.hmf import hmf_model as hm
     cfg = dict(n_users=200, n_items=5000, logit_size=5000)
     syn, model_a, ref = _build(cfg, 'ce', 32, 32, None, seed=4)
@@ -260,6 +266,28 @@ def test_recommend_streaming_topk_equals_materialised(dev, monkeypatch):
     assert isinstance(model_b.topk, hm.StreamTopK) and isinstance(model_a.topk, hm.TopK)
     model_b.topk.chunk = 1536                                     # several chunks + a ragged tail
     model_b.topk._buf = model_b.topk._buf[:, :1536].contiguous()
+    assert model_b.topk.fused
+    if mode == 'chunked':
+        model_b.topk.fused = False
+    if mode == 'fused-overflow':
+        model_b.topk.slack, model_b.topk.min_capp = 0.0, 8        # segments of 8 for tiles that yield 64
+    if mode in ('fused-overflow', 'fused-ties'):
+        import torch
+        for m in (model_a, model_b):
+            t = m.att_emb.item_feats[0].table
+            if mode == 'fused-overflow':
+                rows = m.att_emb._pool_embed('full', 1).feats[0].maps[0].long()      # table row of logit column j
+                t.bias[rows] = torch.arange(rows.numel(), device=t.bias.device, dtype=torch.float32)
+            else:
+                for lo in (100, 1500, 1530, 3000, 4990):          # (1530 .. 1546 straddles the first chunk's end)
+                    t.E[lo + 1:lo + 17] = t.E[lo:lo + 1]
+                    t.bias[lo + 1:lo + 17] = t.bias[lo:lo + 1]
+                t.bias[1500:1517] += 3.0                           # ... and make two of the blocks winners
+                t.bias[1530:1547] += 3.0
+        P = ref.att_emb.params
+        te = model_a.att_emb.item_feats[0].table
+        P['itemembed_cat_0'][...] = te.E.cpu().numpy()
+        P['item_bias_cat_0'][:, 0] = te.bias.cpu().numpy()
     rng = np.random.default_rng(0)
     users, items = syn.sample_batch(32, rng)
     ra = model_a.step(None, list(users), list(items), recommend=True)
@@ -267,6 +295,12 @@ def test_recommend_streaming_topk_equals_materialised(dev, monkeypatch):
     rr = ref.step(list(users), list(items), recommend=True)
     np.testing.assert_array_equal(ra, rr)
     np.testing.assert_array_equal(rb, rr)
+    if mode == 'fused-overflow':
+        assert int(model_b.topk.overflow.item()) != 0            # (the fused run of this request did overflow)
+    elif mode.startswith('fused'):
+        assert int(model_b.topk.overflow.item()) == 0 and model_b.topk.fused
+    rb2 = model_b.step(None, list(users), list(items), recommend=True)      # the captured plan, replayed
+    np.testing.assert_array_equal(rb2, rr)
 
 
 @pytest.mark.parametrize("use_graph", [True, False])
