@@ -1391,15 +1391,20 @@ def _unpack_bits(words, n):
     return ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(w.shape[0], -1)[:, :n].astype(bool)
 
 
-@pytest.mark.parametrize("B,S,d,mask_rows", [(16384, 1024, 128, 0), (320, 256, 64, 0), (1024, 2048, 128, 0),
-                                              (77, 128, 64, 0), (1, 128, 128, 0), (4096, 512, 64, 1024),
-                                              (200, 384, 128, 0)])
-def test_mw_scorer(dev, B, S, d, mask_rows):
+@pytest.mark.parametrize("B,S,d,mask_rows,maxpos", [(16384, 1024, 128, 0, 30), (320, 256, 64, 0, 30),
+                                                     (1024, 2048, 128, 0, 30), (77, 128, 64, 0, 30),
+                                                     (1, 128, 128, 0, 30), (4096, 512, 64, 1024, 30),
+                                                     (200, 384, 128, 0, 30), (515, 256, 128, 0, 100),
+                                                     (515, 256, 64, 0, 100)])
+def test_mw_scorer(dev, B, S, d, mask_rows, maxpos):
     """The fused 'mw' scorer (csrc/scorer.hip: arx_mw_scorer_fwd / _bwd_du / _bwd_di): target score, loss, g, dt, the
     rank-one terms and the act BITS (both orientations) against the oracle's logits -> compute_loss('mw') ->
     compute_loss_bwd chain (embed_attribute.py:148-206, 208-220, 641-649), positives of the row's user masked
     (user of row r = users[r % mask_rows]: the sequence model's time-major rows); then the two backward products
-    and the bias gradient out of the bits, incl. the per-time-step products (step_rows)."""
+    and the bias gradient out of the bits, incl. the per-time-step products (step_rows).  maxpos = 100: positives
+    lists longer than the 32 entries a half wave of k_sc_prep lists per round (round 5), most of them past the
+    kScHits = 8 pool slots a hit list holds (those rows walk their lists in k_sc_rows); B = 515: a ragged last
+    8-row hit-list block and 128-row tile."""
     from arx import ops
     import torch
     rng = np.random.default_rng(B + S)
@@ -1412,7 +1417,7 @@ def test_mw_scorer(dev, B, S, d, mask_rows):
     pool = rng.permutation(n_items)[:S].astype(np.int32)
     i2s = np.full(n_items + 1, -1, dtype=np.int32)
     i2s[pool] = np.arange(S, dtype=np.int32)
-    npos = rng.integers(0, 30, size=n_users)
+    npos = rng.integers(0, maxpos, size=n_users)
     ptr = np.concatenate([[0], np.cumsum(npos)]).astype(np.int32)
     pitems = rng.integers(0, n_items, size=int(ptr[-1])).astype(np.int32)     # duplicates happen
     mrows = mask_rows or B
