@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--no-anchor", action="store_true",
                     help="N > 1: do not run the world-1 anchor of the same workload after the N-rank run")
     ap.add_argument("--mulhot", action="store_true", help="(compat) same as --workload c3")
-    ap.add_argument("--subs", default="c2,c3mix,c4,c4mce,k1,c5w1,c3repw1,c3_f32mfma,c2_f32mfma",
+    ap.add_argument("--subs", default="c2,c3mix,c4,c4mce,k1,c5w1,c3repw1,topk,c3_f32mfma,c2_f32mfma",
                     help="comma list of sub-results besides the headline ('' = none)")
     ap.add_argument("--sub-steps", type=int, default=50)
     ap.add_argument("--repeats", type=int, default=5,
@@ -199,6 +199,48 @@ def k7_in_situ(model, d):
         res['ms_sorts'] = t_sort
         res['ms_apply'] = t_full - t_sort
         res['gbs_apply'] = by / max(t_full - t_sort, 1e-6) / 1e6
+    return res
+
+
+def run_topk(args, B=4096, k=100):
+    """SURVEY 8(f) #3, the other side of training: tf.nn.top_k over the FULL vocabulary for B users (hmf_model.py:154)
+    without the [B, V] logits -- arx.hmf.hmf_model.StreamTopK on random rows of the C2 shape, fused (threshold-filter
+    epilogue of the scorer GEMM) against chunked (GEMM + radix select + merge per 65 536 columns)."""
+    from arx import graph as G
+    from arx.hmf.hmf_model import StreamTopK
+    dev = torch.device('cuda', 0)
+    rt = G.Runtime(dev)
+    V, d = int(args.n_items), int(args.dim)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+
+    class Leaf(G.Node):
+        def __init__(self, shape):
+            super().__init__(rt, shape)
+            self.value = torch.randn(shape, device=dev, generator=g) * 0.3
+            self.bias_value = None
+
+    lat, pool = Leaf((B, d)), Leaf((V, d))
+    pool.bias_value = torch.randn(V, device=dev, generator=g) * 0.1
+    res = {"config": {"workload": "full-vocabulary top-%d, %d users x %d items, d=%d, f32" % (k, B, V, d)}}
+    for mode in ("fused", "chunked"):
+        tk = StreamTopK(rt, lat, pool, k)
+        tk.fused = mode == "fused"
+        for _ in range(2):
+            tk.forward(False)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        n = 3
+        for _ in range(n):
+            tk.forward(False)
+        torch.cuda.synchronize()
+        ms = (time.time() - t0) / n * 1e3
+        res[mode] = {"ms": ms, "user_item_scores_per_s": B * V / ms * 1e3, "tflops_f32": 2.0 * B * V * d / ms / 1e9,
+                     "overflow": int(tk.overflow.item())}
+        del tk
+    res["value"] = res["fused"]["user_item_scores_per_s"]
+    res["unit"] = "user x item scores ranked /s"
+    res["speedup_vs_chunked"] = res["chunked"]["ms"] / res["fused"]["ms"]
     return res
 
 
@@ -832,6 +874,8 @@ def main():
                 r = run_sharded_world1(args)
             elif s == "c3repw1":
                 r = run_sharded_world1(args, rep_tokens=True)
+            elif s == "topk":
+                r = run_topk(args)
             elif s.endswith("_f32mfma") and (s[:-8] in WORKLOADS or s[:-8] == "c5w1"):
                 r = run_f32mfma(args, s[:-8])
             else:
