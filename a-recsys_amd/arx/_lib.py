@@ -198,7 +198,7 @@ PROTOTYPES = {
     "arx_topk_merge": (cint, [f32p, i32p, f32p, i32p, i64, cint, cint, cint, f32p, i32p, vp]),
     "arx_gemm_nt_topk_parts": (cint, [i64, i64, C.POINTER(C.c_int)]),
     "arx_gemm_nt_topk_filter": (cint, [f32p, i64, i64, f32p, i64, i64, i64, f32p, f32p, i64, i32, f32p, i32p, i64, cint,
-                                       i32p, vp]),
+                                       i32p, f32p, i64, vp]),
     "arx_take_rows_i32": (cint, [i32p, i64, i32p, i64, i64, cint, i32p, i64, vp]),
     "arx_lstm_fwd": (cint, [f32p, f32p, f32p, i64, i64, cint, cint, f32, f32p, f32p, f32p, vp]),
     "arx_lstm_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, i64, i64, cint, cint, f32p, vp]),

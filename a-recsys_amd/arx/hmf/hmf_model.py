@@ -149,9 +149,14 @@ class StreamTopK(G.Node):
     chunked: the GEMM runs over chunks of the pool rows, every chunk keeps its k best per row (radix select) and a
     merge folds them into the running result."""
 
-    def __init__(self, rt, latent, pool, k, chunk=65536):
+    def __init__(self, rt, latent, pool, k, chunk=65536, want_lse=False):
         super().__init__(rt, (latent.shape[0], k), (latent, pool))
         self.k, self.chunk = k, max(int(chunk), k)
+        # want_lse: also self.lse [B] = log sum exp over ALL the row's logits (seqModel.py:514-517 reports the winners'
+        # softmax values exp(v - lse)): per column range out of the fused GEMM / per chunk, combined at the end
+        self.want_lse = bool(want_lse)
+        self.lse = torch.empty(latent.shape[0], dtype=torch.float32, device=rt.device) if want_lse else None
+        self._lse_parts = None
         B, V, dev = latent.shape[0], pool.shape[0], rt.device
         f32, i32 = torch.float32, torch.int32
         self.indices = torch.empty((B, k), dtype=i32, device=dev)
@@ -183,8 +188,15 @@ class StreamTopK(G.Node):
             cap = parts * capp
             self._cand = (key, capp, torch.empty((B, cap), dtype=torch.float32, device=dev),
                           torch.zeros((B, cap), dtype=torch.int32, device=dev),
-                          torch.empty((B, k), dtype=torch.int32, device=dev))
+                          torch.empty((B, k), dtype=torch.int32, device=dev), parts)
         return self._cand[1:]
+
+    def _lse_buf(self, ncols):
+        if self._lse_parts is None or self._lse_parts.shape[1] != ncols:
+            B, dev = self.shape[0], self.rt.device
+            self._lse_parts = torch.empty((B, ncols), dtype=torch.float32, device=dev)
+            self._lse0 = torch.empty(B, dtype=torch.float32, device=dev)
+        return self._lse_parts
 
     def overflowed(self):
         """True when the last fused run dropped candidates (device -> host read)."""
@@ -202,23 +214,35 @@ class StreamTopK(G.Node):
             ops.gemm(latent.value, pool.value[:n0], lg, self.rt.ws, transB=True,
                      col_bias=bias[:n0] if bias is not None else None)
             ops.topk_chunk(lg, k, 0, run_v, run_i)
-            capp, cand_v, cand_i, cpos = self._cand_bufs(n0, V)
+            capp, cand_v, cand_i, cpos, parts = self._cand_bufs(n0, V)
+            lp = None
+            if self.want_lse:
+                lp = self._lse_buf(parts + 1)
+                ops.row_logsumexp(lg, self._lse0)
+                lp[:, parts].copy_(self._lse0)
             ops.fill_f32(cand_v.view(-1), float('-inf'))
             ops.fill_i32(self.overflow, 0)
             ops.gemm_nt_topk_filter(latent.value, pool.value[n0:], bias[n0:] if bias is not None else None,
-                                    run_v[:, k - 1], n0, cand_v, cand_i, capp, self.overflow)
+                                    run_v[:, k - 1], n0, cand_v, cand_i, capp, self.overflow, lse_part=lp)
+            if self.want_lse:
+                ops.row_logsumexp(lp, self.lse)
             ops.topk_chunk(cand_v, k, 0, self._cv, cpos)
             ops.take_rows_i32(cand_i, cpos, self._ci)
             ops.topk_merge(run_v, run_i, self._cv, self._ci, k, out_v, out_i)
             self.value.copy_(out_v)
             self.indices.copy_(out_i)
             return
+        nch = (V + self.chunk - 1) // self.chunk
+        lp = self._lse_buf(nch) if self.want_lse else None
         for c0 in range(0, V, self.chunk):
             c1 = min(V, c0 + self.chunk)
             kc = min(k, c1 - c0)
             lg = self._buf[:, :c1 - c0]
             bias = pool.bias_value[c0:c1] if pool.bias_value is not None else None
             ops.gemm(latent.value, pool.value[c0:c1], lg, self.rt.ws, transB=True, col_bias=bias)
+            if self.want_lse:
+                ops.row_logsumexp(lg, self._lse0)
+                lp[:, c0 // self.chunk].copy_(self._lse0)
             if c0 == 0:                              # chunk >= k and V >= k: the first chunk fills all k
                 ops.topk_chunk(lg, k, 0, run_v, run_i)
                 continue
@@ -230,6 +254,8 @@ class StreamTopK(G.Node):
         if run_v.data_ptr() != self.value.data_ptr():
             self.value.copy_(run_v)
             self.indices.copy_(run_i)
+        if self.want_lse:
+            ops.row_logsumexp(lp, self.lse)
 
 
 class LatentProductModel(object):

@@ -277,6 +277,17 @@ class TopKSoftmax(G.Node):
         ops.row_logsumexp(x, self.lse)
 
 
+class RowsAt(G.Node):
+    """value[i] = x[rows[i]]: the LSTM outputs at one time position per sequence (step_recommend)."""
+
+    def __init__(self, rt, x, rows):
+        super().__init__(rt, (rows.shape[0], x.shape[1]), (x, rows))
+
+    def forward(self, train):
+        x, rows = self.inputs
+        ops.gather_onehot(x.value, None, None, rows.value, self.alloc_value())
+
+
 class _KeepProb(object):
     """model.dropoutRate: .eval() reads, .assign(v) returns an op that sets the keep probability."""
 
@@ -470,6 +481,16 @@ class SeqModel(SeqBatching):
             bk['eval'] = bk['train']
             full = logits
         bk['recommend'] = TopKSoftmax(rt, full, min(self.topk_n, full.shape[1]))      # :514-517
+        import os as _os2
+        if self.output_feat in (0, 1) and n * m.logit_size * 4 > int(_os2.environ.get('ARX_STREAM_TOPK_BYTES',
+                                                                                      str(1 << 30))):
+            # [L*mb, V] logits are not worth materialising for ONE position per sequence: the rows asked for are
+            # gathered first, then the fused full-vocabulary top-k (+ the softmax normaliser) runs on [mb, d]
+            from ..hmf.hmf_model import StreamTopK
+            bk['rec_rows'] = G.IdsInput(rt, B, 'recommend_rows_%d' % L)
+            sel = RowsAt(rt, hs, bk['rec_rows'])
+            bk['recommend_stream'] = StreamTopK(rt, sel, m._pool_embed('full', self.output_feat),
+                                                min(self.topk_n, m.logit_size), want_lse=True)
         bk['plans'] = {}
         self._bk[bucket_id] = bk
         return bk
@@ -482,7 +503,7 @@ class SeqModel(SeqBatching):
                 masks = [m.mask[self.loss]] if self.loss in m.mask else []
                 bk['plans'][key] = G.Plan(self.rt, [bk['train']], True, masks)
             elif key == 'recommend':
-                bk['plans'][key] = G.Plan(self.rt, [bk['recommend']], False, [])
+                bk['plans'][key] = G.Plan(self.rt, [bk.get('recommend_stream', bk['recommend'])], False, [])
             else:
                 l = 'warp' if self.loss == 'mw' else ('ce' if self.loss == 'mce' else self.loss)
                 masks = [m.mask[l]] if (l in m.mask and not bk.get('eval_streamed')) else []
@@ -743,8 +764,9 @@ class SeqModel(SeqBatching):
 
     def step_recommend(self, session, user_input, item_inputs, positions, bucket_id):
         """seqModel.py:326-353 -> [(uid, values[topk_n], indexes[topk_n])]: the top-k softmax
-        values / logit indexes at time position positions[i] of sequence i.  The full
-        [L*mb, V] logits are materialised (the streaming scorer + running top-k is SURVEY 8f #3)."""
+        values / logit indexes at time position positions[i] of sequence i.  Small vocabularies: the full
+        [L*mb, V] logits are materialised; past ARX_STREAM_TOPK_BYTES (1 GB) the mb rows asked for are gathered
+        and the fused full-vocabulary top-k + log-sum-exp of hmf_model.StreamTopK runs on them (round 5)."""
         L = self.buckets[bucket_id]
         m, B = self.att_emb, self.batch_size
         it = item_inputs
@@ -752,12 +774,27 @@ class SeqModel(SeqBatching):
             it = torch.from_numpy(np.ascontiguousarray(np.asarray(it, dtype=np.int32)[:L].reshape(-1)))
         m.input_all.value[:L * B].copy_(it.reshape(-1), non_blocking=True)
         m.add_input({}, user_input, None, forward_only=True, recommend=True, loss=self.loss)
+        bk = self._bucket(bucket_id)
+        users = user_input.cpu().numpy() if isinstance(user_input, torch.Tensor) else user_input
+        if 'recommend_stream' in bk:
+            node = bk['recommend_stream']
+            bk['rec_rows'].feed(np.asarray([int(pos) * B + i for i, pos in enumerate(positions)], dtype=np.int32))
+            self._plan(bucket_id, 'recommend').run()
+            if node.overflowed():             # a candidate list of the fused top-k was too short: the chunked path
+                node.fused = False
+                bk['plans'].pop('recommend', None)
+                try:
+                    self._plan(bucket_id, 'recommend').run()
+                finally:
+                    node.fused = True
+                    bk['plans'].pop('recommend', None)
+            vals, idx, lse = node.value.cpu().numpy(), node.indices.cpu().numpy(), node.lse.cpu().numpy()
+            return [(users[i], np.exp(vals[i] - lse[i]), idx[i]) for i in range(len(positions))]
         self._plan(bucket_id, 'recommend').run()
-        node = self._bucket(bucket_id)['recommend']
+        node = bk['recommend']
         vals = node.value.cpu().numpy()
         idx = node.indices.cpu().numpy()
         lse = node.lse.cpu().numpy()
-        users = user_input.cpu().numpy() if isinstance(user_input, torch.Tensor) else user_input
         results = []
         for i, pos in enumerate(positions):
             r = int(pos) * B + i

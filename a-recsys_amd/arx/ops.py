@@ -923,11 +923,12 @@ def gemm_nt_topk_parts(M, N):
     return int(n.value)
 
 
-def gemm_nt_topk_filter(A, Bm, col_bias, thr, col_base, cand_v, cand_i, capp, overflow):
-    """Scorer GEMM A . Bm^T + col_bias that keeps only the logits above thr[row] (arx.h)."""
+def gemm_nt_topk_filter(A, Bm, col_bias, thr, col_base, cand_v, cand_i, capp, overflow, lse_part=None):
+    """Scorer GEMM A . Bm^T + col_bias that keeps only the logits above thr[row]; lse_part [M, >= parts]: also the
+    per-column-range log-sum-exp of every row (arx.h)."""
     call("arx_gemm_nt_topk_filter", _p(A), _ld(A), int(A.shape[0]), _p(Bm), _ld(Bm), int(Bm.shape[0]), int(A.shape[1]),
          _p(col_bias), _p(thr), int(thr.stride(0)), int(col_base), _p(cand_v), _p(cand_i), int(cand_v.stride(0)),
-         int(capp), _p(overflow), _stream())
+         int(capp), _p(overflow), _p(lse_part), int(lse_part.stride(0)) if lse_part is not None else 0, _stream())
 
 
 def take_rows_i32(table, pos, out):

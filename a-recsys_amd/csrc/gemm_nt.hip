@@ -43,11 +43,15 @@ __device__ __forceinline__ int nt_swz(int r) {
 // order -- a wave owns its 32 rows, keeps their 16 + 16 counters in registers and places a tile's survivors by ballot
 // + prefix count, so the lists are deterministic, need no atomics, and POSITION order is COLUMN order (what
 // arx_topk_chunk's tie rule needs).  A full segment raises *overflow (the caller falls back to the chunked path).
+// lse_part (nullable): also the log-sum-exp of the row's logits over the workgroup's column range, lse_part[row * ldl +
+// part] -- the softmax normaliser of seqModel.py:514-517 top_k(softmax(logits)) without the logits: every lane keeps a
+// running (max, sum exp(v - max)) per row over ITS columns, the 32 lanes of a row meet once at the end.
 struct NtFilter {
   const float* thr; int64_t ldthr;
   float* cand_v; int32_t* cand_i; int64_t ldcand;
   int capp; int32_t col_base;
   int* overflow;
+  float* lse_part; int64_t ldl;
 };
 
 template <int KT, bool FILTER = false>
@@ -116,13 +120,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
   // FILTER: thresholds and list lengths of the lane's 16 rows (row = rbase + (e & 3) + 8 (e >> 2))
   float th[FILTER ? 16 : 1];
   int cnt[FILTER ? 16 : 1];
+  float lm[FILTER ? 16 : 1], ls[FILTER ? 16 : 1];
   bool ovf = false;
+  const bool want_lse = FILTER && flt.lse_part != nullptr;
   if (FILTER) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int64_t row = m0 + wave * 32 + 4 * lhi + (e & 3) + 8 * (e >> 2);
       th[e] = row < M ? flt.thr[row * flt.ldthr] : __builtin_inff();
       cnt[e] = 0;
+      lm[e] = -__builtin_inff();
+      ls[e] = 0.f;
     }
   }
   // bias of the first tile (later ones are fetched one tile ahead, behind the DMA issue)
@@ -191,6 +199,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const float v = alpha * (j == 0 ? acc0[e] : acc1[e]) + bias;
+          if (want_lse && col < N) {                                // online (max, sum): one exp per logit
+            const float mx = fmaxf(lm[e], v);
+            ls[e] = ls[e] * __expf(lm[e] - mx) + __expf(v - mx);
+            lm[e] = mx;
+          }
           const bool pred = col < N && v > th[e];
           const unsigned long long m = __ballot(pred);
           if (m == 0ull) continue;                                  // (the common case by far)
@@ -232,6 +245,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
     if (t + 1 < t_end) tile(t + 1, sB1, sB0);
   }
   if (FILTER && ovf) *flt.overflow = 1;
+  if (want_lse) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float mx = lm[e], sm = ls[e];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {                            // the row's 32 lanes (one half wave)
+        const float m2 = __shfl_xor(mx, o, 64), s2 = __shfl_xor(sm, o, 64);
+        const float mn = fmaxf(mx, m2);
+        sm = (mx == -__builtin_inff() ? 0.f : sm * __expf(mx - mn)) + (m2 == -__builtin_inff() ? 0.f : s2 * __expf(m2 - mn));
+        mx = mn;
+      }
+      const int64_t row = m0 + wave * 32 + 4 * lhi + (e & 3) + 8 * (e >> 2);
+      if (l31 == 0 && row < M) flt.lse_part[row * flt.ldl + part] = mx + __logf(sm);
+    }
+  }
 }
 
 }  // namespace
@@ -294,7 +322,8 @@ int arx_gemm_nt_topk_parts(int64_t M, int64_t N, int* parts) {
 
 int arx_gemm_nt_topk_filter(const float* A, int64_t lda, int64_t M, const float* Bm, int64_t ldb, int64_t N, int64_t K,
                             const float* col_bias, const float* thr, int64_t ldthr, int32_t col_base, float* cand_v,
-                            int32_t* cand_i, int64_t ldcand, int capp, int* overflow, void* stream) {
+                            int32_t* cand_i, int64_t ldcand, int capp, int* overflow, float* lse_part, int64_t ldl,
+                            void* stream) {
   ARX_CHECK_ARG(A && Bm && thr && cand_v && cand_i && overflow && M > 0 && N > 0 && capp > 0,
                 "arx_gemm_nt_topk_filter: bad argument");
   ARX_CHECK_ARG(K == 32 || K == 64 || K == 128, "arx_gemm_nt_topk_filter: K must be 32, 64 or 128");
@@ -306,7 +335,8 @@ int arx_gemm_nt_topk_filter(const float* A, int64_t lda, int64_t M, const float*
   ARX_CHECK_ARG(ns * capp <= ldcand, "arx_gemm_nt_topk_filter: candidate rows too short (parts * capp > ldcand)");
   const int64_t grid = ceil_div(M, (int64_t)kNtBM) * ns;
   ARX_CHECK_ARG(grid <= 0x7fffffff, "arx_gemm_nt_topk_filter: grid too large");
-  const NtFilter f{thr, ldthr, cand_v, cand_i, ldcand, capp, col_base, overflow};
+  ARX_CHECK_ARG(!lse_part || ldl >= ns, "arx_gemm_nt_topk_filter: lse_part rows too short (ldl < parts)");
+  const NtFilter f{thr, ldthr, cand_v, cand_i, ldcand, capp, col_base, overflow, lse_part, ldl};
   hipStream_t s = as_stream(stream);
   if (K == 128)
     k_gemm_nt_areg<128, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, (int)tpb,

@@ -818,11 +818,14 @@ int arx_topk_merge(const float* va, const int32_t* ia, const float* vb, const in
  * cand[row][p * capp ..) in ascending column order, deterministically.  Pre-fill cand_v with -inf: then
  * arx_topk_chunk over the candidate rows (positions are in column order, so its tie rule holds), arx_take_rows_i32
  * (positions -> columns) and arx_topk_merge finish the top-k.  *overflow is set when a range's segment was too short
- * (results incomplete: fall back to the chunked path).  K in {32, 64, 128}; values bit-identical to arx_gemm_f32's. */
+ * (results incomplete: fall back to the chunked path).  K in {32, 64, 128}; values bit-identical to arx_gemm_f32's.
+ * lse_part (nullable) [M, ldl >= parts]: lse_part[row][p] = log sum exp of the row's logits over column range p -- with
+ * the first chunk's row log-sum-exp this is the softmax normaliser of seqModel.py:514-517 top_k(softmax(logits)). */
 int arx_gemm_nt_topk_parts(int64_t M, int64_t N, int* parts);
 int arx_gemm_nt_topk_filter(const float* A, int64_t lda, int64_t M, const float* Bm, int64_t ldb, int64_t N, int64_t K,
                             const float* col_bias, const float* thr, int64_t ldthr, int32_t col_base, float* cand_v,
-                            int32_t* cand_i, int64_t ldcand, int capp, int* overflow, void* stream);
+                            int32_t* cand_i, int64_t ldcand, int capp, int* overflow, float* lse_part, int64_t ldl,
+                            void* stream);
 /* out[r][j] = table[r * ld + pos[r * ldp + j]], r < B, j < k */
 int arx_take_rows_i32(const int32_t* table, int64_t ld, const int32_t* pos, int64_t ldp, int64_t B, int k,
                       int32_t* out, int64_t ldo, void* stream);

@@ -236,12 +236,22 @@ def test_seq_no_user_id_and_mw_eval(dev):
     np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)
 
 
-@pytest.mark.parametrize("loss,S", [('ce', None), ('mw', 64)])
-def test_seq_step_recommend(dev, loss, S):
+@pytest.mark.parametrize("loss,S,stream", [('ce', None, False), ('mw', 64, False), ('ce', None, True),
+                                            ('mw', 64, True)])
+def test_seq_step_recommend(dev, monkeypatch, loss, S, stream):
     """seqModel.py:326-353,514-517: top_k(softmax(full logits)) at one position per sequence,
-    indexes exact, softmax values to rtol 1e-4, after a training step (tables have moved)."""
+    indexes exact, softmax values to rtol 1e-4, after a training step (tables have moved).
+    stream (round 5): the rows asked for are gathered and the fused full-vocabulary top-k of hmf_model.StreamTopK
+    runs on them, with the softmax normaliser out of the same GEMM (no [L*mb, V] logits)."""
+    if stream:
+        monkeypatch.setenv('ARX_STREAM_TOPK_BYTES', '0')
     syn, emb, model, remb, ref = _build(CFG_ID, loss, 64, 16, 4, S, 5.0, seed=11)
     model.topk_n = 7
+    if stream:
+        bk = model._bucket(0)
+        assert 'recommend_stream' in bk
+        bk['recommend_stream'].chunk = 128                        # 500 logits: a first chunk + a fused rest
+        bk['recommend_stream']._buf = bk['recommend_stream']._buf[:, :128].contiguous()
     rng = np.random.default_rng(2)
     users, inp, tg, w = _batch(syn, rng, 4, 16)
     if loss == 'mw':
