@@ -200,6 +200,7 @@ PROTOTYPES = {
     "arx_gemm_nt_topk_filter": (cint, [f32p, i64, i64, f32p, i64, i64, i64, f32p, f32p, i64, i32, f32p, i32p, i64, cint,
                                        i32p, f32p, i64, vp]),
     "arx_take_rows_i32": (cint, [i32p, i64, i32p, i64, i64, cint, i32p, i64, vp]),
+    "arx_gemm_nt_eval_parts": (cint, [f32p, i64, i64, f32p, i64, i64, i64, f32p, f32p, f32p, f32p, i64, vp]),
     "arx_lstm_fwd": (cint, [f32p, f32p, f32p, i64, i64, cint, cint, f32, f32p, f32p, f32p, vp]),
     "arx_lstm_bwd": (cint, [f32p, f32p, f32p, f32p, f32p, i64, i64, cint, cint, f32p, vp]),
     "arx_lstm_bwd_wxt": (cint, [f32p, f32p, f32p, f32p, f32p, i64, i64, cint, cint, f32p, f32p, vp]),

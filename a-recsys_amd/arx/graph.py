@@ -728,6 +728,8 @@ class StreamEvalLoss(Node):
         self._T = torch.empty((B, pool.shape[1]), dtype=f32, device=dev)
         self._tb = torch.empty((B,), dtype=f32, device=dev)
         self._a0, self._a1 = torch.empty((B,), dtype=f32, device=dev), torch.empty((B,), dtype=f32, device=dev)
+        self.fused = os.environ.get('ARX_EVAL_FUSED', '1') != '0'
+        self._parts = None
 
     def forward(self, train):
         if train:
@@ -738,12 +740,27 @@ class StreamEvalLoss(Node):
         # target logit = latent . pool_row(target) + bias (the target is a logit index = a pool row)
         ops.gather_onehot(pool.value, pool.bias_value, None, target.value, self._T, bias_out=self._tb)
         ops.dot_score(latent.value, self._T, self._tb, self._t)
-        for c0 in range(0, V, self.chunk):
-            c1 = min(V, c0 + self.chunk)
-            lg = self._buf[:, :c1 - c0]
-            bias = pool.bias_value[c0:c1] if pool.bias_value is not None else None
-            ops.gemm(latent.value, pool.value[c0:c1], lg, rt.ws, transB=True, col_bias=bias)
-            ops.eval_chunk_accum(lg, self._t, mode, c0 == 0, self._a0, self._a1)
+        if (self.fused and latent.shape[1] in (32, 64, 128) and pool.shape[1] == latent.shape[1]
+                and latent.value.stride(0) % 4 == 0 and pool.value.stride(0) % 4 == 0):
+            # round 5: ONE pass of the scorer GEMM whose epilogue keeps the per-row sums (arx_gemm_nt_eval_parts)
+            # instead of chunks of [rows, 65536] logits and an accumulate launch per chunk
+            if self._parts is None:
+                npart = ops.gemm_nt_topk_parts(latent.shape[0], V)
+                self._parts = torch.empty((latent.shape[0], npart), dtype=torch.float32, device=rt.device)
+            if mode == 0:
+                ops.gemm_nt_eval_parts(latent.value, pool.value, pool.bias_value, None, self._parts, None)
+                ops.row_logsumexp(self._parts, self._a0)
+                ops.fill_f32(self._a1, 1.0)                    # (eval_finish: a0 + log(a1) - t)
+            else:
+                ops.gemm_nt_eval_parts(latent.value, pool.value, pool.bias_value, self._t, None, self._parts)
+                ops.row_sum(self._parts, self._a0)
+        else:
+            for c0 in range(0, V, self.chunk):
+                c1 = min(V, c0 + self.chunk)
+                lg = self._buf[:, :c1 - c0]
+                bias = pool.bias_value[c0:c1] if pool.bias_value is not None else None
+                ops.gemm(latent.value, pool.value[c0:c1], lg, rt.ws, transB=True, col_bias=bias)
+                ops.eval_chunk_accum(lg, self._t, mode, c0 == 0, self._a0, self._a1)
         ms = self.mask
         if mode == 1 and ms is not None:
             ptr, items = ms.pos_getter()

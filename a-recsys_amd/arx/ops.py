@@ -931,6 +931,13 @@ def gemm_nt_topk_filter(A, Bm, col_bias, thr, col_base, cand_v, cand_i, capp, ov
          int(capp), _p(overflow), _p(lse_part), int(lse_part.stride(0)) if lse_part is not None else 0, _stream())
 
 
+def gemm_nt_eval_parts(A, Bm, col_bias, tscore, lse_part, relu_part):
+    """Full-vocabulary evaluation sums out of the scorer GEMM, no logits (arx.h)."""
+    ref = lse_part if lse_part is not None else relu_part
+    call("arx_gemm_nt_eval_parts", _p(A), _ld(A), int(A.shape[0]), _p(Bm), _ld(Bm), int(Bm.shape[0]), int(A.shape[1]),
+         _p(col_bias), _p(tscore), _p(lse_part), _p(relu_part), int(ref.stride(0)), _stream())
+
+
 def take_rows_i32(table, pos, out):
     call("arx_take_rows_i32", _p(table), int(table.stride(0)), _p(pos), int(pos.stride(0)), int(pos.shape[0]),
          int(pos.shape[1]), _p(out), int(out.stride(0)), _stream())

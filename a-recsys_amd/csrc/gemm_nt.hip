@@ -52,6 +52,10 @@ struct NtFilter {
   int capp; int32_t col_base;
   int* overflow;
   float* lse_part; int64_t ldl;
+  // the evaluation losses of a sampled-loss model over the FULL vocabulary (hmf_model.py:130,144, seqModel.py:510)
+  // without the logits: relu_part[row * ldl + part] = sum over the range of relu(v - tsc[row] + 1) (WMRB, :605-618);
+  // thr == nullptr: no candidate lists at all (arx_gemm_nt_eval_parts)
+  const float* tsc; float* relu_part;
 };
 
 template <int KT, bool FILTER = false>
@@ -120,17 +124,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
   // FILTER: thresholds and list lengths of the lane's 16 rows (row = rbase + (e & 3) + 8 (e >> 2))
   float th[FILTER ? 16 : 1];
   int cnt[FILTER ? 16 : 1];
-  float lm[FILTER ? 16 : 1], ls[FILTER ? 16 : 1];
+  float lm[FILTER ? 16 : 1], ls[FILTER ? 16 : 1], tq[FILTER ? 16 : 1], rsum[FILTER ? 16 : 1];
   bool ovf = false;
   const bool want_lse = FILTER && flt.lse_part != nullptr;
+  const bool want_relu = FILTER && flt.relu_part != nullptr;
   if (FILTER) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int64_t row = m0 + wave * 32 + 4 * lhi + (e & 3) + 8 * (e >> 2);
-      th[e] = row < M ? flt.thr[row * flt.ldthr] : __builtin_inff();
+      th[e] = (row < M && flt.thr) ? flt.thr[row * flt.ldthr] : __builtin_inff();
       cnt[e] = 0;
       lm[e] = -__builtin_inff();
       ls[e] = 0.f;
+      tq[e] = (want_relu && row < M) ? flt.tsc[row] - 1.f : 0.f;
+      rsum[e] = 0.f;
     }
   }
   // bias of the first tile (later ones are fetched one tile ahead, behind the DMA issue)
@@ -199,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const float v = alpha * (j == 0 ? acc0[e] : acc1[e]) + bias;
+          if (want_relu && col < N) rsum[e] += fmaxf(v - tq[e], 0.f);
           if (want_lse && col < N) {                                // online (max, sum): one exp per logit
             const float mx = fmaxf(lm[e], v);
             ls[e] = ls[e] * __expf(lm[e] - mx) + __expf(v - mx);
@@ -258,6 +266,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
       }
       const int64_t row = m0 + wave * 32 + 4 * lhi + (e & 3) + 8 * (e >> 2);
       if (l31 == 0 && row < M) flt.lse_part[row * flt.ldl + part] = mx + __logf(sm);
+    }
+  }
+  if (want_relu) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float sm = rsum[e];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+      const int64_t row = m0 + wave * 32 + 4 * lhi + (e & 3) + 8 * (e >> 2);
+      if (l31 == 0 && row < M) flt.relu_part[row * flt.ldl + part] = sm;
     }
   }
 }
@@ -336,7 +354,36 @@ int arx_gemm_nt_topk_filter(const float* A, int64_t lda, int64_t M, const float*
   const int64_t grid = ceil_div(M, (int64_t)kNtBM) * ns;
   ARX_CHECK_ARG(grid <= 0x7fffffff, "arx_gemm_nt_topk_filter: grid too large");
   ARX_CHECK_ARG(!lse_part || ldl >= ns, "arx_gemm_nt_topk_filter: lse_part rows too short (ldl < parts)");
-  const NtFilter f{thr, ldthr, cand_v, cand_i, ldcand, capp, col_base, overflow, lse_part, ldl};
+  const NtFilter f{thr, ldthr, cand_v, cand_i, ldcand, capp, col_base, overflow, lse_part, ldl, nullptr, nullptr};
+  hipStream_t s = as_stream(stream);
+  if (K == 128)
+    k_gemm_nt_areg<128, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, (int)tpb,
+                                                         (int)ns, f);
+  else if (K == 64)
+    k_gemm_nt_areg<64, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, (int)tpb,
+                                                        (int)ns, f);
+  else
+    k_gemm_nt_areg<32, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, (int)tpb,
+                                                        (int)ns, f);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_gemm_nt_eval_parts(const float* A, int64_t lda, int64_t M, const float* Bm, int64_t ldb, int64_t N, int64_t K,
+                           const float* col_bias, const float* tscore, float* lse_part, float* relu_part, int64_t ldl,
+                           void* stream) {
+  ARX_CHECK_ARG(A && Bm && M > 0 && N > 0 && (lse_part || relu_part), "arx_gemm_nt_eval_parts: bad argument");
+  ARX_CHECK_ARG(!relu_part || tscore, "arx_gemm_nt_eval_parts: the margin sums need the target scores");
+  ARX_CHECK_ARG(K == 32 || K == 64 || K == 128, "arx_gemm_nt_eval_parts: K must be 32, 64 or 128");
+  ARX_CHECK_ARG(!((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bm)) & 15) && lda % 4 == 0 &&
+                    ldb % 4 == 0,
+                "arx_gemm_nt_eval_parts: operands must be 16-byte aligned");
+  int64_t tpb, ns;
+  nt_split(M, N, &tpb, &ns);
+  ARX_CHECK_ARG(ldl >= ns, "arx_gemm_nt_eval_parts: part rows too short (ldl < parts)");
+  const int64_t grid = ceil_div(M, (int64_t)kNtBM) * ns;
+  ARX_CHECK_ARG(grid <= 0x7fffffff, "arx_gemm_nt_eval_parts: grid too large");
+  const NtFilter f{nullptr, 0, nullptr, nullptr, 0, 0, 0, nullptr, lse_part, ldl, tscore, relu_part};
   hipStream_t s = as_stream(stream);
   if (K == 128)
     k_gemm_nt_areg<128, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, (int)tpb,

@@ -826,6 +826,14 @@ int arx_gemm_nt_topk_filter(const float* A, int64_t lda, int64_t M, const float*
                             const float* col_bias, const float* thr, int64_t ldthr, int32_t col_base, float* cand_v,
                             int32_t* cand_i, int64_t ldcand, int capp, int* overflow, float* lse_part, int64_t ldl,
                             void* stream);
+/* The evaluation losses over the full vocabulary (hmf_model.py:130,144; seqModel.py:510: the full-softmax / full-WMRB
+ * loss a sampled-loss model is selected on) in ONE pass of the same GEMM, no logits: per row and column range p
+ * (arx_gemm_nt_topk_parts) lse_part[row][p] = log sum exp of the logits ('ce': loss = logsumexp_p(lse_part) - t) and /
+ * or relu_part[row][p] = sum relu(logit - tscore[row] + 1) ('warp', embed_attribute.py:605-618: loss = log(1 + sum_p
+ * relu_part), positives taken out by arx_eval_warp_unmask as for the chunked form).  Either output may be NULL. */
+int arx_gemm_nt_eval_parts(const float* A, int64_t lda, int64_t M, const float* Bm, int64_t ldb, int64_t N, int64_t K,
+                           const float* col_bias, const float* tscore, float* lse_part, float* relu_part, int64_t ldl,
+                           void* stream);
 /* out[r][j] = table[r * ld + pos[r * ldp + j]], r < B, j < k */
 int arx_take_rows_i32(const int32_t* table, int64_t ld, const int32_t* pos, int64_t ldp, int64_t B, int k,
                       int32_t* out, int64_t ldo, void* stream);

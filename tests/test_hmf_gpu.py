@@ -446,17 +446,21 @@ def test_hmf_mw_scorer_gemm_with_hinge_epilogue(dev, cfg, d):
     assert assert_mw_scorer_path(model._plan('train'), B, S, d) or ops.SCORER_F32    # the path under test ran
 
 
+@pytest.mark.parametrize("fused", ['1', '0'])
 @pytest.mark.parametrize("cfg,loss", [(CFG_ID, 'mw'), (CFG_HET, 'mw'), (CFG_HET, 'mce')])
-def test_hmf_streaming_eval_loss(dev, monkeypatch, cfg, loss):
+def test_hmf_streaming_eval_loss(dev, monkeypatch, cfg, loss, fused):
     """Evaluation loss of a sampled-loss model over the FULL vocabulary without [mb, V] logits
-    (StreamEvalLoss: chunked scorer GEMM + running per-row reductions + positives taken out):
-    equal to the oracle's forward_only loss and to the materialising path."""
+    (StreamEvalLoss; fused = 1, round 5: ONE pass of the scorer GEMM whose epilogue keeps the per-row sums,
+    arx_gemm_nt_eval_parts; fused = 0: chunked scorer GEMM + running per-row reductions; both: positives taken out
+    afterwards): equal to the oracle's forward_only loss and to the materialising path."""
     monkeypatch.setenv('ARX_STREAM_TOPK_BYTES', '1')          # force streaming at this size
     monkeypatch.setenv('ARX_STREAM_EVAL_CHUNK', '96')         # several ragged chunks of the pool
+    monkeypatch.setenv('ARX_EVAL_FUSED', fused)
     from arx import graph as G
     d, B, S = 32, 48, 128
     syn, model, ref = _build(cfg, loss, d, B, S, seed=6)
     assert isinstance(model.loss_eval.inputs[0], G.StreamEvalLoss)
+    assert model.loss_eval.inputs[0].fused == (fused == '1')
     rng = np.random.default_rng(2)
     pool = syn.sample_pool(S, rng)
     id2idx = {int(v): i for i, v in enumerate(pool)}

@@ -60,3 +60,28 @@ if os.environ.get("TOPK_CHECK"):
     r = int(d_.nonzero()[0]) if d_.any() else 0
     print("row", r, "fused  ", res['fused'][1][r, :8].tolist(), res['fused'][2][r, :4].tolist())
     print("row", r, "chunked", res['chunked'][1][r, :8].tolist(), res['chunked'][2][r, :4].tolist())
+if os.environ.get("EVAL_BENCH"):
+    # the full-vocabulary evaluation loss (graph.StreamEvalLoss): fused GEMM epilogue against chunks
+    class Ids(G.Node):
+        def __init__(self, n):
+            super().__init__(rt, (n,))
+            self.value = torch.randint(0, V, (n,), device=dev, dtype=torch.int32, generator=g)
+    tgt = Ids(B)
+    for kind in ('ce', 'warp'):
+        out = {}
+        for mode in ('fused', 'chunked'):
+            ev = G.StreamEvalLoss(rt, kind, lat, pool, tgt)
+            ev.fused = mode == 'fused'
+            for _ in range(2):
+                ev.forward(False)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(3):
+                ev.forward(False)
+            torch.cuda.synchronize()
+            ms = (time.time() - t0) / 3 * 1e3
+            out[mode] = (ms, ev.value.clone())
+            del ev
+        rel = ((out['fused'][1] - out['chunked'][1]).abs() / out['chunked'][1].abs().clamp_min(1e-6)).max().item()
+        print("eval %-4s fused %8.2f ms  chunked %8.2f ms  (%.1fx)  max rel diff %.2e" % (
+            kind, out['fused'][0], out['chunked'][0], out['chunked'][0] / out['fused'][0], rel))
