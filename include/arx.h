@@ -418,9 +418,10 @@ int arx_mw_scorer_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp, 
                       float gscale, const float* row_w, int64_t B, int64_t S, float* batch_loss, float* tscore_out,
                       float* dtscore, int64_t dtscore_stride, float* dU, int64_t lddu, float* dT, int64_t lddt,
                       void* state, size_t state_bytes, void* stream);
-/* the same in parts -- phases: bit 0 the pool planes + the positives' hit lists (needs P and the ids only: may run
- * ahead), bit 1 the hinge GEMM (target score, act bits, partial sums), bit 2 the row kernel (loss, g, rank-one
- * terms, the g U planes); in this order on one stream.  arx_mw_scorer_fwd == phases 7. */
+/* the same in parts -- phases: bit 0 the pool planes, the positives' hit lists and (since round 5) the target scores
+ * t_r = U_r . T_r + tb_r, written to the state and to tscore_out (needs U and T: no longer ahead of the lookups),
+ * bit 1 the hinge GEMM (act bits, partial sums; reads the target scores bit 0 left), bit 2 the row kernel (loss, g,
+ * rank-one terms, the g U planes); in this order on one stream.  arx_mw_scorer_fwd == phases 7. */
 int arx_mw_scorer_fwd_phases(const float* U, int64_t ldu, const float* P, int64_t ldp, const float* pbias,
                              const float* T, int64_t ldt, const float* tbias, int64_t tb_stride, int d,
                              const int32_t* user_ids, const int32_t* pos_ptr, const int32_t* pos_items,
