@@ -58,11 +58,17 @@ struct NtFilter {
   const float* tsc; float* relu_part;
 };
 
-template <int KT, bool FILTER = false>
+// MODE (FILTER kernels): bit 0 candidate lists (thr), bit 1 lse_part, bit 2 relu_part -- a template parameter, not a
+// run-time switch: every feature is 32 registers of per-row state and the plain kernel already holds 246
+constexpr int kNtTopk = 1, kNtLse = 2, kNtRelu = 4;
+
+template <int KT, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
     int64_t M, int64_t N, const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
     int64_t ldb, float alpha, float* __restrict__ C, int64_t ldc,
     const float* __restrict__ col_bias, int tiles_per_block, int nsplit, NtFilter flt) {
+  constexpr bool FILTER = MODE != 0;
+  constexpr bool want_topk = (MODE & kNtTopk) != 0, want_lse = (MODE & kNtLse) != 0, want_relu = (MODE & kNtRelu) != 0;
   constexpr int NS = KT / 8;                  // steps of 4 MFMAs
   constexpr int CPR = KT / 4;                 // 16-B chunks per pool row
   constexpr int NLB = kNtBN * CPR / 256;      // DMA pieces per thread per tile
@@ -122,22 +128,30 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
     }
   }
   // FILTER: thresholds and list lengths of the lane's 16 rows (row = rbase + (e & 3) + 8 (e >> 2))
-  float th[FILTER ? 16 : 1];
-  int cnt[FILTER ? 16 : 1];
-  float lm[FILTER ? 16 : 1], ls[FILTER ? 16 : 1], tq[FILTER ? 16 : 1], rsum[FILTER ? 16 : 1];
+  // per-row CONSTANTS (thresholds, target scores) and the list lengths live in LDS -- read four rows at a time per
+  // tile, the lengths only when a tile has a survivor; only the running sums are registers (the plain kernel holds
+  // 246 VGPRs: with everything in registers the top-k form spilled 476 bytes per lane)
+  __shared__ float s_th[want_topk ? kNtBM : 1];
+  __shared__ float s_tq[want_relu ? kNtBM : 1];
+  __shared__ int s_cnt[want_topk ? kNtBM : 1];
+  float lm[want_lse ? 16 : 1], ls[want_lse ? 16 : 1], rsum[want_relu ? 16 : 1];
   bool ovf = false;
-  const bool want_lse = FILTER && flt.lse_part != nullptr;
-  const bool want_relu = FILTER && flt.relu_part != nullptr;
   if (FILTER) {
+    if (threadIdx.x < kNtBM) {
+      const int64_t row = m0 + threadIdx.x;
+      if (want_topk) {
+        s_th[threadIdx.x] = row < M ? flt.thr[row * flt.ldthr] : __builtin_inff();
+        s_cnt[threadIdx.x] = 0;
+      }
+      if (want_relu) s_tq[threadIdx.x] = row < M ? flt.tsc[row] - 1.f : 0.f;
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int64_t row = m0 + wave * 32 + 4 * lhi + (e & 3) + 8 * (e >> 2);
-      th[e] = (row < M && flt.thr) ? flt.thr[row * flt.ldthr] : __builtin_inff();
-      cnt[e] = 0;
-      lm[e] = -__builtin_inff();
-      ls[e] = 0.f;
-      tq[e] = (want_relu && row < M) ? flt.tsc[row] - 1.f : 0.f;
-      rsum[e] = 0.f;
+      if (want_lse) {
+        lm[e] = -__builtin_inff();
+        ls[e] = 0.f;
+      }
+      if (want_relu) rsum[e] = 0.f;
     }
   }
   // bias of the first tile (later ones are fetched one tile ahead, behind the DMA issue)
@@ -199,6 +213,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
     const int64_t n0 = t * kNtBN;
     const int64_t rbase = m0 + wave * 32 + 4 * lhi;
     if (FILTER) {
+      const int rl0 = wave * 32 + 4 * lhi;                          // the lane's rows: rl0 + (e & 3) + 8 (e >> 2)
+      float th[want_topk ? 16 : 1], tq[want_relu ? 16 : 1];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        if (want_topk) {
+          const float4 t4 = *reinterpret_cast<const float4*>(&s_th[rl0 + 8 * g4]);
+          th[4 * g4] = t4.x; th[4 * g4 + 1] = t4.y; th[4 * g4 + 2] = t4.z; th[4 * g4 + 3] = t4.w;
+        }
+        if (want_relu) {
+          const float4 t4 = *reinterpret_cast<const float4*>(&s_tq[rl0 + 8 * g4]);
+          tq[4 * g4] = t4.x; tq[4 * g4 + 1] = t4.y; tq[4 * g4 + 2] = t4.z; tq[4 * g4 + 3] = t4.w;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int64_t col = n0 + j * 32 + l31;
@@ -207,16 +234,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
         for (int e = 0; e < 16; ++e) {
           const float v = alpha * (j == 0 ? acc0[e] : acc1[e]) + bias;
           if (want_relu && col < N) rsum[e] += fmaxf(v - tq[e], 0.f);
-          if (want_lse && col < N) {                                // online (max, sum): one exp per logit
-            const float mx = fmaxf(lm[e], v);
-            ls[e] = ls[e] * __expf(lm[e] - mx) + __expf(v - mx);
-            lm[e] = mx;
+          if (want_lse && col < N) {                                // online (max, sum): ONE exp per logit
+            const float dd = v - lm[e];
+            const float ex = __expf(-fabsf(dd));                    // (first logit: dd = +inf, ex = 0: ls = 0 * 0 + 1)
+            ls[e] = dd > 0.f ? ls[e] * ex + 1.f : ls[e] + ex;
+            lm[e] = fmaxf(lm[e], v);
           }
+          if (!want_topk) continue;
           const bool pred = col < N && v > th[e];
           const unsigned long long m = __ballot(pred);
           if (m == 0ull) continue;                                  // (the common case by far)
           const uint32_t mh = lhi ? (uint32_t)(m >> 32) : (uint32_t)m;
-          const int pos = cnt[e] + __popc(mh & ((1u << l31) - 1u));
+          const int rl = rl0 + (e & 3) + 8 * (e >> 2);
+          const int c0 = s_cnt[rl];                                 // (the wave owns its rows: no other writer)
+          const int pos = c0 + __popc(mh & ((1u << l31) - 1u));
           if (pred) {
             if (pos < flt.capp) {
               const int64_t at = (rbase + (e & 3) + 8 * (e >> 2)) * flt.ldcand + (int64_t)part * flt.capp + pos;
@@ -226,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
               ovf = true;
             }
           }
-          cnt[e] += __popc(mh);
+          if (l31 == 0 && mh) s_cnt[rl] = c0 + __popc(mh);
         }
       }
     } else
@@ -252,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
     tile(t, sB0, sB1);
     if (t + 1 < t_end) tile(t + 1, sB1, sB0);
   }
-  if (FILTER && ovf) *flt.overflow = 1;
+  if (want_topk && ovf) *flt.overflow = 1;
   if (want_lse) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -324,6 +355,17 @@ static void nt_split(int64_t M, int64_t N, int64_t* tpb, int64_t* nsplit) {
   *nsplit = ceil_div(tiles_n, *tpb);
 }
 
+template <int MODE>
+static void nt_launch_mode(int64_t K, int64_t grid, hipStream_t s, int64_t M, int64_t N, const float* A, int64_t lda,
+                           const float* Bm, int64_t ldb, const float* col_bias, int tpb, int ns, const NtFilter& f) {
+  if (K == 128)
+    k_gemm_nt_areg<128, MODE><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, tpb, ns, f);
+  else if (K == 64)
+    k_gemm_nt_areg<64, MODE><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, tpb, ns, f);
+  else
+    k_gemm_nt_areg<32, MODE><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, tpb, ns, f);
+}
+
 }  // namespace arx
 
 using namespace arx;
@@ -356,15 +398,10 @@ int arx_gemm_nt_topk_filter(const float* A, int64_t lda, int64_t M, const float*
   ARX_CHECK_ARG(!lse_part || ldl >= ns, "arx_gemm_nt_topk_filter: lse_part rows too short (ldl < parts)");
   const NtFilter f{thr, ldthr, cand_v, cand_i, ldcand, capp, col_base, overflow, lse_part, ldl, nullptr, nullptr};
   hipStream_t s = as_stream(stream);
-  if (K == 128)
-    k_gemm_nt_areg<128, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, (int)tpb,
-                                                         (int)ns, f);
-  else if (K == 64)
-    k_gemm_nt_areg<64, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, (int)tpb,
-                                                        (int)ns, f);
+  if (lse_part)
+    nt_launch_mode<kNtTopk | kNtLse>(K, grid, s, M, N, A, lda, Bm, ldb, col_bias, (int)tpb, (int)ns, f);
   else
-    k_gemm_nt_areg<32, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, (int)tpb,
-                                                        (int)ns, f);
+    nt_launch_mode<kNtTopk>(K, grid, s, M, N, A, lda, Bm, ldb, col_bias, (int)tpb, (int)ns, f);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
@@ -385,15 +422,12 @@ int arx_gemm_nt_eval_parts(const float* A, int64_t lda, int64_t M, const float* 
   ARX_CHECK_ARG(grid <= 0x7fffffff, "arx_gemm_nt_eval_parts: grid too large");
   const NtFilter f{nullptr, 0, nullptr, nullptr, 0, 0, 0, nullptr, lse_part, ldl, tscore, relu_part};
   hipStream_t s = as_stream(stream);
-  if (K == 128)
-    k_gemm_nt_areg<128, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, (int)tpb,
-                                                         (int)ns, f);
-  else if (K == 64)
-    k_gemm_nt_areg<64, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, (int)tpb,
-                                                        (int)ns, f);
+  if (lse_part && relu_part)
+    nt_launch_mode<kNtLse | kNtRelu>(K, grid, s, M, N, A, lda, Bm, ldb, col_bias, (int)tpb, (int)ns, f);
+  else if (lse_part)
+    nt_launch_mode<kNtLse>(K, grid, s, M, N, A, lda, Bm, ldb, col_bias, (int)tpb, (int)ns, f);
   else
-    k_gemm_nt_areg<32, true><<<(int)grid, 256, 0, s>>>(M, N, A, lda, Bm, ldb, 1.f, nullptr, 0, col_bias, (int)tpb,
-                                                        (int)ns, f);
+    nt_launch_mode<kNtRelu>(K, grid, s, M, N, A, lda, Bm, ldb, col_bias, (int)tpb, (int)ns, f);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
