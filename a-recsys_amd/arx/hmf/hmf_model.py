@@ -491,7 +491,9 @@ class LatentProductModel(object):
                    item_sampled_id2idx=None, forward_only=False, recommend=False,
                    recommend_new=False, loss=None, run_op=None, run_meta=None):
         """step() without the device->host read of the result: returns the MeanLoss
-        node (call .read() for the device scalar) / the top-k index tensor."""
+        node (call .read() for the device scalar) / the top-k index tensor.  recommend with the streaming top-k
+        (StreamTopK, fused form): the result is complete only if `self.topk.overflowed()` is False afterwards
+        (one device -> host read; step() checks it and re-runs the request on the chunked path)."""
         if loss is None:
             loss = self.loss_function
         self._cur = (user_input, item_input)
