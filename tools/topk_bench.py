@@ -85,3 +85,19 @@ if os.environ.get("EVAL_BENCH"):
         rel = ((out['fused'][1] - out['chunked'][1]).abs() / out['chunked'][1].abs().clamp_min(1e-6)).max().item()
         print("eval %-4s fused %8.2f ms  chunked %8.2f ms  (%.1fx)  max rel diff %.2e" % (
             kind, out['fused'][0], out['chunked'][0], out['chunked'][0] / out['fused'][0], rel))
+if os.environ.get("TOPK_MATERIALISED"):
+    # the materialising form (hmf_model.TopK over Prediction): one [B, V] GEMM + arx_topk
+    from arx import ops
+    lg = torch.empty((B, V), dtype=torch.float32, device=dev)
+    tv, ti = torch.empty((B, k), dtype=torch.float32, device=dev), torch.empty((B, k), dtype=torch.int32, device=dev)
+    def mat():
+        ops.gemm(lat.value, pool.value, lg, rt.ws, transB=True, col_bias=pool.bias_value)
+        ops.topk(lg, k, tv, ti)
+    for _ in range(2):
+        mat()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(3):
+        mat()
+    torch.cuda.synchronize()
+    print("materialised %8.2f ms   same indices as fused: %s" % ((time.time() - t0) / 3 * 1e3, bool(torch.equal(ti, res['fused'][1]))))
