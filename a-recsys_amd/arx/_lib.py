@@ -115,6 +115,14 @@ PROTOTYPES = {
     "arx_mw_scorer_bwd_du": (cint, [i64, i64, cint, vp, f32, f32p, i64, vp]),
     "arx_mw_scorer_bwd_di_workspace_bytes": (sz, [i64, i64, cint, i64]),
     "arx_mw_scorer_bwd_di": (cint, [i64, i64, cint, vp, i64, f32, f32p, i64, f32p, f32p, f32p, vp, sz, vp]),
+    "arx_mce_scorer_supported": (cint, [i64, i64, cint]),
+    "arx_mce_scorer_state_bytes": (sz, [i64, i64, cint]),
+    "arx_mce_scorer_fwd": (cint, [f32p, i64, f32p, i64, f32p, f32p, i64, f32p, i64, cint, i32p, i32p, i32p, i32p,
+                                  i64, f32, f32p, f32p, i64, i64, i64, f32p, f32p, f32p, i64, f32p, i64, f32p, i64,
+                                  vp, sz, cint, vp]),
+    "arx_mce_scorer_bwd_di_workspace_bytes": (sz, [i64, i64, cint, i64]),
+    "arx_mce_scorer_bwd_di_loss": (cint, [i64, i64, cint, vp, f32p, i64, f32, f32p, i64, f32p, f32p, f32p, f32p, f32,
+                                          f32p, f32p, vp, sz, vp]),
     "arx_sample_wor_workspace_bytes": (sz, [i64]),
     "arx_sample_wor_keys_workspace_bytes": (sz, [i64, i64, f32]),
     "arx_sample_wor": (cint, [f32p, i64, i64, u64, u64, i32p, vp, sz, vp]),
@@ -244,7 +252,8 @@ _NO_CHECK = ("arx_last_error", "arx_version", "arx_csr_expand_workspace_bytes",
              "arx_sparse_adagrad_workspace_bytes",
              "arx_sample_wor_workspace_bytes", "arx_sample_wor_keys_workspace_bytes",
              "arx_gemm_nt_bx6_workspace_bytes", "arx_reduce_scratch_bytes", "arx_mw_scorer_supported",
-             "arx_mw_scorer_state_bytes", "arx_mw_scorer_bwd_di_workspace_bytes")
+             "arx_mw_scorer_state_bytes", "arx_mw_scorer_bwd_di_workspace_bytes", "arx_mce_scorer_supported",
+             "arx_mce_scorer_state_bytes", "arx_mce_scorer_bwd_di_workspace_bytes")
 
 
 def call(name, *args):

@@ -588,11 +588,13 @@ class BatchLoss(Node):
                 target.fused_into_loss = True
                 # ... and, for the plain pool scorer, the GEMM itself moves in (hinge epilogue)
                 B_ = logits.shape[0]
-                if (kind == 'mw' and isinstance(logits, Prediction) and logits.fusable(B_)
-                        and logits.inputs[0] is lat and ops.mw_scorer_supported(B_, W, d)):
+                if (isinstance(logits, Prediction) and logits.fusable(B_) and logits.inputs[0] is lat
+                        and (ops.mw_scorer_supported(B_, W, d) if kind == 'mw' else ops.mce_scorer_supported(B_, W, d))):
                     # DEFAULT since round 4 (ARX_SCORER_F32=1: logits GEMM + loss kernel + two f32 GEMMs): no
                     # [B, S] logits / dlogits in HBM, 2 MB of activity bits instead, and all three products on
                     # the bf16 matrix pipe, f32-exact (csrc/gemm_bx6.hip; C3 312 -> 260 us/step in round 3)
+                    # 'mce' (round 5): the same move with exp in the epilogue and the weight tiles recomputed in the
+                    # backward (ops.MceScorer, d == 64)
                     self.gemm_fused = True
                     logits.fused_into_loss = True
 
@@ -674,7 +676,7 @@ def _bl_forward_gemm_fused(self, bl, rw, uid, ptr, items, i2s):
     rt = self.rt
     B, S, d = logits.shape[0], logits.shape[1], lat.shape[1]
     if logits.scorer is None:
-        logits.scorer = ops.MwScorer(B, S, d, rt.device)
+        logits.scorer = (ops.MwScorer if self.kind == 'mw' else ops.MceScorer)(B, S, d, rt.device)
     dt = target.alloc_grad()
     target.grad_beta()
     logits._grad_written = True                    # its backward consumes the bits

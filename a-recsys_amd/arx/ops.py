@@ -481,6 +481,53 @@ class MwScorer(object):
              _ld(dI), _p(db), _p(dI_steps), _p(db_steps), _p(bl), float(gs), _p(rw), _p(out), wsp, wsn, _stream())
 
 
+def mce_scorer_supported(B, S, d):
+    """True when the fused 'mce' family (csrc/scorer.hip, k_mc_flow) takes this shape: d == 64, S % 128 == 0,
+    128 <= S <= 2048 -- and the process has not asked for the materialising reference (ARX_SCORER_F32 /
+    ARX_MCE_FUSED=0)."""
+    if SCORER_F32 or os.environ.get('ARX_MCE_FUSED', '1') == '0':
+        return False
+    return bool(_lib.lib.arx_mce_scorer_supported(int(B), int(S), int(d)))
+
+
+class MceScorer(object):
+    """The build-defined sampled softmax 'mce' without [B, S] logits or weights in HBM (include/arx.h, "'mce' on the
+    fused family"): fwd() leaves loss, target-score terms and the COMPLETE latent gradient (one pass forms s_r and
+    O_r = sum_s e_rs P_s); bwd_dI() recomputes the weight tiles for the pool-side product.  Same surface as MwScorer
+    (bwd_dU is a no-op kept for the graph nodes that drive both)."""
+
+    def __init__(self, B, S, d, device):
+        self.B, self.S, self.d = int(B), int(S), int(d)
+        n = int(_lib.lib.arx_mce_scorer_state_bytes(self.B, self.S, self.d))
+        if n == 0:
+            raise ValueError("MceScorer: shape not supported (B=%d, S=%d, d=%d)" % (B, S, d))
+        self.state = torch.zeros(n, dtype=torch.uint8, device=device)
+        self.ws = Workspace(device)
+        self._pbias = None
+
+    def fwd(self, U, P, pbias, T, tbias, user_ids, pos_ptr, pos_items, item2slot, batch_loss, tscore_out, dtscore,
+            dU, dT, gscale, row_w=None, mask_rows=0, phases=7, seq_w=None, seq_rows=0):
+        self._pbias = pbias
+        call("arx_mce_scorer_fwd", _p(U), _ld(U), _p(P), _ld(P), _p(pbias), _p(T), _ld(T), _p(tbias),
+             int(tbias.stride(0)) if tbias is not None else 1, self.d, _p(user_ids), _p(pos_ptr), _p(pos_items),
+             _p(item2slot), int(mask_rows), float(gscale), _p(row_w), _p(seq_w), int(seq_rows), self.B, self.S,
+             _p(batch_loss), _p(tscore_out), _p(dtscore), int(dtscore.stride(0)) if dtscore is not None else 1,
+             _p(dU), _ld(dU) if dU is not None else 0, _p(dT), _ld(dT) if dT is not None else 0, _p(self.state),
+             int(self.state.numel()), int(phases), _stream())
+
+    def bwd_dU(self, dU, beta=1.0):
+        """(the forward wrote dU = coef O + dt T: nothing left to add)"""
+        if beta != 1.0:
+            raise RuntimeError("MceScorer: the latent gradient is written by fwd(); bwd_dU(beta != 1) would drop it")
+
+    def bwd_dI(self, dI, db=None, beta=0.0, step_rows=0, dI_steps=None, db_steps=None, loss=None):
+        wsp, wsn = self.ws.get(_lib.lib.arx_mce_scorer_bwd_di_workspace_bytes(self.B, self.S, self.d, int(step_rows)))
+        bl, gs, rw, out = loss if loss is not None else (None, 0.0, None, None)
+        call("arx_mce_scorer_bwd_di_loss", self.B, self.S, self.d, _p(self.state), _p(self._pbias), int(step_rows),
+             float(beta), _p(dI), _ld(dI), _p(db), _p(dI_steps), _p(db_steps), _p(bl), float(gs), _p(rw), _p(out),
+             wsp, wsn, _stream())
+
+
 def loss_warp_pos(logits, target, user_ids, pos_ptr, pos_items, item2slot, batch_loss, dlogits,
                   gscale, row_w=None, mask_rows=0):
     B, V = int(logits.shape[0]), int(logits.shape[1])

@@ -1168,6 +1168,345 @@ __global__ __launch_bounds__(256) void k_sc_tn_reduce(const float* __restrict__ 
 
 size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
+// ============================================================================================================
+// The 'mce' family (round 5): sampled softmax in the shape of 'mw' (build-defined, arx.h), loss_r = log(1 + sum_s
+// m_rs exp(x_rs - t_r)), WITHOUT [B, S] logits or weights in HBM.  The backward weight of a logit is dense,
+// w_rs = coef_r e_rs with e_rs = m_rs exp(x_rs - t_r) and coef_r = g_r / (1 + s_r), not a bit -- so the weight tile is
+// recomputed where it is used and consumed out of the accumulator registers:
+//
+//   k_mc_flow: a wave keeps 32 STATIONARY rows as bf16 pieces in registers and streams 32-index tiles of the other
+//   side through LDS (LDS-DMA, double buffered): six-term x tile = D[stream index][stationary] as in k_sc_hinge, e =
+//   exp(x + c_stream + c_stat) in the accumulator layout -- which IS the second-operand layout of the next product
+//   if the k slots of a 32x32x16 MFMA are dealt as  slot (kg, i) <-> stream index 16 q + 8 (i / 4) + 4 kg + i % 4:
+//   the lane's values 8 q .. 8 q + 7, split into three exact bf16 pieces, are operand fragments as they stand, and
+//   the first operand (the streamed side's TRANSPOSED planes) is read from LDS as two 8-byte halves in the same
+//   order.  O[stationary][:] += sum_stream e . X[stream][:] with six terms again; rsum[stationary] += sum e (. cw).
+//     role dU (DI = false): stationary = batch rows (U split in the prologue), stream = pool columns (Pp / PT of
+//       k_sc_prep), c_stat = -t_r, c_stream = bias: O_r = sum_s e_rs P_s, s_r = sum_s e_rs -- the loss and BOTH
+//       the forward and the latent-side backward product in one pass (the row factor coef_r commutes with it).
+//     role dI (DI = true): stationary = pool columns (pieces from Pp), stream = batch rows (Up: U as planes,
+//       UgT: coef_r U_r transposed, both by k_mc_rows), c_stream = -t_r (-inf in the padding), cw = coef:
+//       part[slice][s][:] = sum_r e_rs coef_r U_r, dbpart[slice][s] = sum_r e_rs coef_r; slices = time steps for
+//       the sequence model (its per-step clip norm), summed by k_sc_tn_reduce.
+//   The positives of a row that sit in the pool are MASKED (m_rs = 0) from two bit tables, word-major per stream
+//   tile, set by k_mc_mask from the positives chain: a word is non-zero once in thousands of tiles, one wave-wide
+//   test per tile.
+//   k_mc_rows (between the two): s_r, loss_r = log1p(s_r), coef_r, dt_r = -coef_r s_r, dU_r = coef_r O_r + dt_r T_r,
+//   dT_r = dt_r U_r, the planes Up / UgT, -t_r.
+// Two workgroups of four waves per CU (two MFMA-issuing waves per SIMD: one's exp / split VALU under the other's
+// MFMAs); d = 64 (x accumulators 32 + O accumulators 64 + stationary pieces 48 registers; d = 128 would need 352).
+// ============================================================================================================
+constexpr int kMcStage = 25 * 1024;          // K part 12 KB + T part 12 KB + 1 KB: the tile's 32 + 32 constants
+
+struct McFlow {
+  int64_t nstat;                             // stationary extent
+  int64_t span;                              // streamed indices per slice (multiple of 32)
+  int64_t nstream;                           // streamed extent (multiple of 32; planes hold that many rows)
+  const float* statF; int64_t ldstat;        // dU role: U [nstat][ldstat] f32
+  const uint16_t* statP; int64_t statP_plane;   // dI role: planes [3][nstat][64]
+  const uint16_t* XK; int64_t xk_plane;      // streamed planes, k contiguous [3][nstream][64] (elements per plane)
+  const uint16_t* XT; int64_t ldx;           // streamed planes, transposed [3][64][ldx]
+  const float* cstat; float sgn_stat;        // exponent constant of a stationary index (nullable), times sgn
+  const float* cstream;                      // ... of a streamed index (nullable: 0)
+  const float* cw;                           // dI role: weight of a streamed index in rsum
+  const uint32_t* mask; int64_t ldmask;      // [nstream / 32][ldmask]: bit i of mask[t][stat] <-> pair (stat, 32 t + i) masked
+  const float* zeros;                        // >= 16 bytes of zeros (what an absent constant array reads)
+  float* O; int64_t o_rows;                  // [slices][o_rows][64]
+  float* rsum; int64_t rs_rows;              // [slices][rs_rows]
+};
+
+template <bool DI>
+__global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
+  constexpr int NCH = 4;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];      // [2][kMcStage]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 31, kg = lane >> 5;
+  const int64_t nsb = (a.nstat + 127) / 128;
+  const int64_t sb = (int64_t)blockIdx.x % nsb, sl = (int64_t)blockIdx.x / nsb;
+  const int64_t n_begin = sl * a.span;
+  const int64_t n_end = n_begin + a.span < a.nstream ? n_begin + a.span : a.nstream;
+  const int ntile = (int)((n_end - n_begin) / 32);
+  const int64_t stat = sb * 128 + wv * 32 + lr;
+  const bool ok = stat < a.nstat;
+  const int64_t stat_c = ok ? stat : 0;
+
+  // ---- the LDS-DMA pieces of a stage: waves 0 / 1 the K part (pieces 0 .. 11), waves 2 / 3 the T part ----
+  // Issued through inline asm: the compiler orders every LDS read behind an outstanding __builtin_amdgcn_global_load_lds
+  // (s_waitcnt vmcnt(0) at the top of the loop: the prefetch of tile t + 1 was waited for in front of tile t, 107 us
+  // per launch at the C4 shape) -- k_sc_hinge avoids that with loader waves of their own, here the four compute waves
+  // are all a CU's register file holds.  The waits are the explicit ones in front of the stage barriers.
+  const char* src[6];
+  int64_t adv;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int p = (wv & 1) * 6 + i, pl = p >> 2, rg = p & 3;
+    if (wv < 2) {
+      const int row = rg * 8 + (lane >> 3), pos = lane & 7, q = pos ^ ((row >> 1) & 7);
+      src[i] = reinterpret_cast<const char*>(a.XK) + ((int64_t)pl * a.xk_plane + (n_begin + row) * 64) * 2 + q * 16;
+    } else {
+      const int row = rg * 16 + (lane >> 2), pos = lane & 3, q = pos ^ ((row >> 2) & 3);
+      src[i] = reinterpret_cast<const char*>(a.XT) + ((int64_t)pl * 64 * a.ldx + (int64_t)row * a.ldx + n_begin) * 2 + q * 16;
+    }
+  }
+  adv = wv < 2 ? 32 * 128 : 64;
+  // the tile's constants and mask words (wave 0's seventh piece): lanes 0..7 c_stream[32 t ..], lanes 8..15 cw[32 t ..],
+  // lanes 16..47 the mask words of the workgroup's 128 stationary indices, the others re-fetch `zeros`
+  const char* srcx = reinterpret_cast<const char*>(a.zeros);
+  int64_t advx = 0;
+  if (lane < 8) {
+    if (a.cstream) { srcx = reinterpret_cast<const char*>(a.cstream + n_begin + 4 * lane); advx = 128; }
+  } else if (lane < 16) {
+    if (DI) { srcx = reinterpret_cast<const char*>(a.cw + n_begin + 4 * (lane - 8)); advx = 128; }
+  } else if (lane < 48) {
+    srcx = reinterpret_cast<const char*>(a.mask + (n_begin / 32) * a.ldmask + sb * 128 + 4 * (lane - 16));
+    advx = a.ldmask * 4;
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+  auto dma = [&](uint32_t dst, const char* p) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                 :: "s"(__builtin_amdgcn_readfirstlane(dst)), "v"(p) : "memory");
+  };
+  auto issue = [&](int t) {                        // (tiles are issued in order: the sources step along)
+    const uint32_t stage = lds0 + (uint32_t)((t & 1) * kMcStage + wv * 6 * 1024);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      dma(stage + i * 1024, src[i]);
+      src[i] += adv;
+    }
+    if (wv == 0) {
+      dma(lds0 + (uint32_t)((t & 1) * kMcStage + 24 * 1024), srcx);
+      srcx += advx;
+    }
+  };
+  if (ntile > 0) issue(0);
+
+  // ---- the stationary rows as bf16 pieces (second MFMA operand: lane = row lr, k = 16 c + 8 kg ..) ----
+  bf16x8 a1[NCH], a2[NCH], a3[NCH];
+  if (!DI) {
+    const float* up = a.statF + stat_c * a.ldstat + 8 * kg;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float4 r0 = *reinterpret_cast<const float4*>(up + 16 * c);
+      const float4 r1 = *reinterpret_cast<const float4*>(up + 16 * c + 4);
+      uint32_t p1[4], p2[4], p3[4];
+      split3x2(r0.x, r0.y, p1[0], p2[0], p3[0]);
+      split3x2(r0.z, r0.w, p1[1], p2[1], p3[1]);
+      split3x2(r1.x, r1.y, p1[2], p2[2], p3[2]);
+      split3x2(r1.z, r1.w, p1[3], p2[3], p3[3]);
+      a1[c] = __builtin_bit_cast(bf16x8, make_uint4(p1[0], p1[1], p1[2], p1[3]));
+      a2[c] = __builtin_bit_cast(bf16x8, make_uint4(p2[0], p2[1], p2[2], p2[3]));
+      a3[c] = __builtin_bit_cast(bf16x8, make_uint4(p3[0], p3[1], p3[2], p3[3]));
+    }
+  } else {
+    const uint16_t* pp = a.statP + stat_c * 64 + 8 * kg;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      a1[c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pp + 16 * c));
+      a2[c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pp + a.statP_plane + 16 * c));
+      a3[c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pp + 2 * a.statP_plane + 16 * c));
+    }
+  }
+  const float cst = (a.cstat && ok) ? a.sgn_stat * a.cstat[stat] : 0.f;
+
+  f32x16 hiO0 = {0}, loO0 = {0}, hiO1 = {0}, loO1 = {0};
+  float rs = 0.f;
+  // LDS byte offsets of this lane's fragments inside a stage
+  const uint32_t fk = (uint32_t)(lr * 128);                          // K part row
+  const int swk = (lr >> 1) & 7;
+  const uint32_t ft = (uint32_t)(12288 + lr * 64 + 8 * kg);           // T part row of dd block 0 (block 1: + 2048)
+  const int swt = (lr >> 2) & 3;                                      // ((32 + lr) >> 2) & 3 is the same
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < ntile; ++t) {
+    const char* st = lds + (t & 1) * kMcStage;
+    if (t + 1 < ntile) issue(t + 1);
+    const uint32_t mw = reinterpret_cast<const uint32_t*>(st + 24 * 1024 + 256)[wv * 32 + lr];
+    // ---- x tile: D[stream index][stationary], hi starts at c_stream + c_stat ----
+    f32x16 hi, lo;
+    const float* cs = reinterpret_cast<const float*>(st + 24 * 1024) + 4 * kg;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 cv = *reinterpret_cast<const float4*>(cs + 8 * g);
+      hi[4 * g] = cv.x + cst; hi[4 * g + 1] = cv.y + cst; hi[4 * g + 2] = cv.z + cst; hi[4 * g + 3] = cv.w + cst;
+      lo[4 * g] = 0.f; lo[4 * g + 1] = 0.f; lo[4 * g + 2] = 0.f; lo[4 * g + 3] = 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const uint32_t fa = fk + 16 * ((2 * c + kg) ^ swk);
+      const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + fa));
+      const bf16x8 b2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + fa + 4096));
+      const bf16x8 b3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + fa + 8192));
+      lo = SC_MFMA(b3, a1[c], lo);
+      hi = SC_MFMA(b1, a1[c], hi);
+      lo = SC_MFMA(b1, a3[c], lo);
+      lo = SC_MFMA(b2, a2[c], lo);
+      lo = SC_MFMA(b2, a1[c], lo);
+      lo = SC_MFMA(b1, a2[c], lo);
+    }
+    // ---- e = exp(x) in the accumulator layout (value 4 g + e <-> stream index 8 g + 4 kg + e), masked ----
+    float w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = __expf(hi[i] + lo[i]);
+    if (__any(mw != 0u)) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if ((mw >> (8 * (i >> 2) + 4 * kg + (i & 3))) & 1u) w[i] = 0.f;
+    }
+    if (DI) {
+      const float* cwp = reinterpret_cast<const float*>(st + 24 * 1024 + 128) + 4 * kg;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 cv = *reinterpret_cast<const float4*>(cwp + 8 * g);
+        rs += w[4 * g] * cv.x; rs += w[4 * g + 1] * cv.y; rs += w[4 * g + 2] * cv.z; rs += w[4 * g + 3] * cv.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) rs += w[i];
+    }
+    // ---- O[dd][stationary] += X^T[dd][stream] . e[stream][stationary], six terms ----
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      uint32_t p1[4], p2[4], p3[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split3x2(w[8 * q + 2 * j], w[8 * q + 2 * j + 1], p1[j], p2[j], p3[j]);
+      const bf16x8 w1 = __builtin_bit_cast(bf16x8, make_uint4(p1[0], p1[1], p1[2], p1[3]));
+      const bf16x8 w2 = __builtin_bit_cast(bf16x8, make_uint4(p2[0], p2[1], p2[2], p2[3]));
+      const bf16x8 w3 = __builtin_bit_cast(bf16x8, make_uint4(p3[0], p3[1], p3[2], p3[3]));
+      const uint32_t o0 = ft + 16 * ((2 * q) ^ swt), o1 = ft + 16 * ((2 * q + 1) ^ swt);
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        bf16x8 tp[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const uint2 h0 = *reinterpret_cast<const uint2*>(st + o0 + blk * 2048 + pl * 4096);
+          const uint2 h1 = *reinterpret_cast<const uint2*>(st + o1 + blk * 2048 + pl * 4096);
+          tp[pl] = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+        }
+        f32x16& hO = blk ? hiO1 : hiO0;
+        f32x16& lO = blk ? loO1 : loO0;
+        lO = SC_MFMA(tp[2], w1, lO);
+        hO = SC_MFMA(tp[0], w1, hO);
+        lO = SC_MFMA(tp[0], w3, lO);
+        lO = SC_MFMA(tp[1], w2, lO);
+        lO = SC_MFMA(tp[1], w1, lO);
+        lO = SC_MFMA(tp[0], w2, lO);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  rs += __shfl_xor(rs, 32, 64);
+  if (!ok) return;
+  if (kg == 0) a.rsum[sl * a.rs_rows + stat] = rs;
+  float* orow = a.O + (sl * a.o_rows + stat) * 64 + 4 * kg;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    *reinterpret_cast<float4*>(orow + 8 * g) =
+        make_float4(hiO0[4 * g] + loO0[4 * g], hiO0[4 * g + 1] + loO0[4 * g + 1], hiO0[4 * g + 2] + loO0[4 * g + 2],
+                    hiO0[4 * g + 3] + loO0[4 * g + 3]);
+    *reinterpret_cast<float4*>(orow + 32 + 8 * g) =
+        make_float4(hiO1[4 * g] + loO1[4 * g], hiO1[4 * g + 1] + loO1[4 * g + 1], hiO1[4 * g + 2] + loO1[4 * g + 2],
+                    hiO1[4 * g + 3] + loO1[4 * g + 3]);
+  }
+}
+
+// bit tables of the masked pairs: maskR[s / 32][ldr] bit (s % 32) of row r (read by the dU role: stationary = rows)
+// and maskC[r / 32][ldc] bit (r % 32) of column s (dI role).  Half a wave per batch row walks the user's positives
+// (embed_attribute.py:729-741).  Both tables are zeroed by the caller in front of this launch.
+__global__ __launch_bounds__(256) void k_mc_mask(PosMask pm, int64_t mask_rows, int64_t B, int64_t S,
+                                                 uint32_t* __restrict__ maskR, int64_t ldr,
+                                                 uint32_t* __restrict__ maskC, int64_t ldc) {
+  const int hl = threadIdx.x & 31;
+  const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
+  if (r >= B) return;
+  const int usr = pm.user_ids[r % mask_rows];
+  const int beg = pm.pos_ptr[usr], end = pm.pos_ptr[usr + 1];
+  for (int p = beg + hl; p < end; p += 32) {
+    const int j = pos_slot(pm, pm.pos_items[p]);
+    if (j >= 0 && j < S) {
+      atomicOr(&maskR[(int64_t)(j >> 5) * ldr + r], 1u << (j & 31));
+      atomicOr(&maskC[(r >> 5) * ldc + j], 1u << (int)(r & 31));
+    }
+  }
+}
+
+struct McRows {
+  const float* rs_part; const float* O_part; int nsplit; int64_t Bp;   // [nsplit][B], [nsplit][Bp][64]
+  const float* tscore;
+  const float* U; int64_t ldu;
+  const float* T; int64_t ldt;
+  float gscale; const float* row_w;
+  float* batch_loss; float* coef_out; float* tneg;                     // [B], [Bp], [Bp]
+  float* dtscore; int64_t dts_stride;
+  float* dU; int64_t lddu;
+  float* dT; int64_t lddt;
+  uint16_t* Up;                                                        // [3][Bp][64]
+  uint16_t* UgT; int64_t ldug;                                         // [3][64][ldug]
+  const float* pool_bad; int nbad;
+};
+
+// 32 batch rows per workgroup, 16 lanes x float4 per row (d = 64), 4 waves x 2 rounds x 4 rows
+__global__ __launch_bounds__(256) void k_mc_rows(McRows a, int64_t B) {
+  __shared__ float tile[32 * 65];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * 32;
+  const int c4 = (lane & 15) * 4;
+  const float pbad = sc_wsum(lane < a.nbad ? a.pool_bad[lane] : 0.f);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int rl = wv * 8 + it * 4 + (lane >> 4);
+    const int64_t r = r0 + rl;
+    const bool live = r < B;
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f), tt = u, o = u;
+    float s = 0.f, t = 0.f;
+    if (live) {
+      u = *reinterpret_cast<const float4*>(a.U + r * a.ldu + c4);
+      tt = *reinterpret_cast<const float4*>(a.T + r * a.ldt + c4);
+      for (int p = 0; p < a.nsplit; ++p) {                    // fixed order
+        s += a.rs_part[(int64_t)p * B + r];
+        const float4 v = *reinterpret_cast<const float4*>(a.O_part + ((int64_t)p * a.Bp + r) * 64 + c4);
+        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+      }
+      t = a.tscore[r];
+    }
+    // non-finite inputs poison the row's loss like an f32 chain would
+    float poison = ((u.x + u.y) + (u.z + u.w) + (tt.x + tt.y) + (tt.z + tt.w)) * 0.f;
+#pragma unroll
+    for (int m = 8; m > 0; m >>= 1) poison += __shfl_xor(poison, m, 64);
+    s += pbad + poison + t * 0.f;
+    const float gw = live ? a.gscale * (a.row_w ? a.row_w[r] : 1.f) : 0.f;
+    const float coef = gw / (1.f + s);
+    const float dt = -coef * s;
+    if ((lane & 15) == 0) {
+      if (live) {
+        if (a.batch_loss) a.batch_loss[r] = log1pf(s);
+        if (a.dtscore) a.dtscore[r * a.dts_stride] = dt;
+      }
+      a.coef_out[r] = live ? coef : 0.f;
+      a.tneg[r] = live ? -t : -__builtin_inff();
+    }
+    if (live) {
+      if (a.dT) *reinterpret_cast<float4*>(a.dT + r * a.lddt + c4) = make_float4(dt * u.x, dt * u.y, dt * u.z, dt * u.w);
+      if (a.dU)
+        *reinterpret_cast<float4*>(a.dU + r * a.lddu + c4) =
+            make_float4(coef * o.x + dt * tt.x, coef * o.y + dt * tt.y, coef * o.z + dt * tt.z, coef * o.w + dt * tt.w);
+    }
+    uint32_t pa[3], pb[3];
+    split3x2(u.x, u.y, pa[0], pa[1], pa[2]);
+    split3x2(u.z, u.w, pb[0], pb[1], pb[2]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      *reinterpret_cast<uint2*>(a.Up + ((int64_t)p * a.Bp + r) * 64 + c4) = make_uint2(pa[p], pb[p]);
+    float* tp = tile + rl * 65 + c4;
+    const float cu = live ? coef : 0.f;
+    tp[0] = cu * u.x; tp[1] = cu * u.y; tp[2] = cu * u.z; tp[3] = cu * u.w;
+  }
+  __syncthreads();
+  sc_emit_planes_t(tile, 65, 32, 64, a.UgT, (int64_t)64 * a.ldug, a.ldug, r0, tid, 256);
+}
+
+
 }  // namespace
 
 // Layout of the caller's scorer state (one buffer): everything the three launches of the forward leave for the two
@@ -1430,6 +1769,227 @@ int arx_mw_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, in
   k_sc_tn_reduce<<<(int)ceil_div(S * (d / 4), 64) + dbblocks + stepblocks + (loss_out ? 1 : 0), 256, 0, s>>>(
       part, (int)nsl, S, d, beta, dI, lddi, dbp, L.nblk, db, dbblocks, batch_loss, row_w, B, gscale, loss_out,
       stepblocks, bps, Lsteps, db_steps);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+}  // extern "C"
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 'mce' (build-defined sampled softmax, see arx_loss_mce_fwdbwd) on the fused family: no [B, S] logits or weights.
+ * ------------------------------------------------------------------------------------------------------------- */
+namespace arx {
+namespace {
+
+struct McLayout {
+  int64_t Bp, ldpt, ldug, ldr, ldc;
+  int nsplit;
+  int64_t CW;
+  size_t maskR, maskC, mask_bytes, t, tneg, coef, rs, O, hits, nhit, Pp, PT, Up, UgT, pbad, zeros, total;
+};
+
+bool mc_layout(int64_t B, int64_t S, int d, McLayout* L) {
+  if (d != 64 || S % 128 != 0 || S < 128 || S > 2048 || B < 1) return false;
+  L->Bp = (B + 127) / 128 * 128;
+  L->ldpt = S + 128;                     // (not a power of two: see ScLayout)
+  L->ldug = L->Bp + 128;
+  L->ldr = L->Bp;
+  L->ldc = S;
+  // column splits of the dU role: enough workgroups for two rounds of the chip's 2 x 256 slots
+  int ns = 1;
+  while (ns < 4 && (L->Bp / 128) * ns < 4 * (int64_t)cu_count() && S / (2 * ns) >= 128 && (S / (2 * ns)) % 32 == 0) ns *= 2;
+  L->nsplit = ns;
+  L->CW = S / ns;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += al256(bytes); return at; };
+  L->maskR = take((size_t)(S / 32) * L->ldr * 4);
+  L->maskC = take((size_t)(L->Bp / 32) * L->ldc * 4);
+  L->mask_bytes = o;
+  L->t = take((size_t)B * 4);
+  L->tneg = take((size_t)L->Bp * 4);
+  L->coef = take((size_t)L->Bp * 4);
+  L->rs = take((size_t)ns * B * 4);
+  L->O = take((size_t)ns * L->Bp * 64 * 4);
+  L->hits = take((size_t)B * kScHits * 4);
+  L->nhit = take((size_t)B * 4);
+  L->Pp = take((size_t)3 * S * 64 * 2);
+  L->PT = take((size_t)3 * 64 * L->ldpt * 2);
+  L->Up = take((size_t)3 * L->Bp * 64 * 2);
+  L->UgT = take((size_t)3 * 64 * L->ldug * 2);
+  L->pbad = take(64 * 4);
+  L->zeros = take(256);                  // (never written: the caller zeroed the state once)
+  L->total = o;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_mc_zero(uint4* __restrict__ p, int64_t n16) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+int mc_raise_lds() {
+  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mc_flow<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mc_flow<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  return ARX_OK;
+}
+
+// slices of the dI role: time steps for the sequence model, else enough of them for four workgroups per CU
+int64_t mc_di_slice(const McLayout& L, int64_t S, int64_t step_rows) {
+  if (step_rows > 0) return step_rows;
+  const int64_t wg = S / 128;
+  const int64_t nsl0 = ceil_div((int64_t)4 * cu_count(), wg);
+  return ceil_div(ceil_div(L.Bp, nsl0), 128) * 128;
+}
+
+}  // namespace
+}  // namespace arx
+
+extern "C" {
+
+int arx_mce_scorer_supported(int64_t B, int64_t S, int d) {
+  McLayout L;
+  return mc_layout(B, S, d, &L) ? 1 : 0;
+}
+
+size_t arx_mce_scorer_state_bytes(int64_t B, int64_t S, int d) {
+  McLayout L;
+  return mc_layout(B, S, d, &L) ? L.total : 0;
+}
+
+int arx_mce_scorer_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp, const float* pbias, const float* T,
+                       int64_t ldt, const float* tbias, int64_t tb_stride, int d, const int32_t* user_ids,
+                       const int32_t* pos_ptr, const int32_t* pos_items, const int32_t* item2slot, int64_t mask_rows,
+                       float gscale, float* row_w, const float* seq_w, int64_t seq_rows, int64_t B, int64_t S,
+                       float* batch_loss, float* tscore_out, float* dtscore, int64_t dtscore_stride, float* dU,
+                       int64_t lddu, float* dT, int64_t lddt, void* state, size_t state_bytes, int phases,
+                       void* stream) {
+  ARX_CHECK_ARG(U && P && T && user_ids && pos_ptr && pos_items && item2slot && state,
+                "arx_mce_scorer_fwd: null pointer");
+  ARX_CHECK_ARG(!seq_w || (row_w && seq_rows > 0 && B % seq_rows == 0),
+                "arx_mce_scorer_fwd: sequence weights need row_w [B] to write and seq_rows dividing B");
+  McLayout L;
+  const bool ok = mc_layout(B, S, d, &L) && ldu % 4 == 0 && ldp % 4 == 0 && ldt % 4 == 0 && ldu >= d && ldp >= d &&
+                  ldt >= d && (!dU || (lddu % 4 == 0 && lddu >= d)) && (!dT || (lddt % 4 == 0 && lddt >= d)) &&
+                  ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(T) |
+                    reinterpret_cast<uintptr_t>(dU) | reinterpret_cast<uintptr_t>(dT) |
+                    reinterpret_cast<uintptr_t>(state)) & 15) == 0;
+  if (!ok) {
+    set_error("arx_mce_scorer_fwd: shape not supported (d == 64, S %% 128 == 0, 128 <= S <= 2048, 16-byte rows)");
+    return ARX_EUNSUPPORTED;
+  }
+  if (state_bytes < L.total) {
+    set_error("arx_mce_scorer_fwd: state too small (%zu < %zu)", state_bytes, L.total);
+    return ARX_EWORKSPACE;
+  }
+  if (int rc = mc_raise_lds()) return rc;
+  hipStream_t s = as_stream(stream);
+  char* st = reinterpret_cast<char*>(state);
+  float* t = reinterpret_cast<float*>(st + L.t);
+  uint16_t* Pp = reinterpret_cast<uint16_t*>(st + L.Pp);
+  uint16_t* PT = reinterpret_cast<uint16_t*>(st + L.PT);
+  uint32_t* maskR = reinterpret_cast<uint32_t*>(st + L.maskR);
+  uint32_t* maskC = reinterpret_cast<uint32_t*>(st + L.maskC);
+  float* rs_part = reinterpret_cast<float*>(st + L.rs);
+  float* O_part = reinterpret_cast<float*>(st + L.O);
+  const PosMask pm = make_pos_mask(user_ids, pos_ptr, pos_items, item2slot);
+  const int64_t mrows = mask_rows > 0 ? mask_rows : B;
+  if (phases & 1) {
+    const int64_t n16 = (int64_t)(L.mask_bytes / 16);
+    k_mc_zero<<<(int)ceil_div(n16, 256), 256, 0, s>>>(reinterpret_cast<uint4*>(st + L.maskR), n16);
+    ARX_CHECK_LAUNCH();
+    const int64_t grid = S / 32 + ceil_div(B, 8) + (seq_w ? ceil_div(seq_rows, 32) : 0);
+    const ScTScore ts{U, ldu, T, ldt, tbias, tb_stride > 0 ? tb_stride : 1, t, tscore_out};
+    k_sc_prep<<<(int)grid, 256, 0, s>>>(P, ldp, S, d, pbias, Pp, PT, L.ldpt, reinterpret_cast<float*>(st + L.pbad), pm,
+                                        mrows, B, reinterpret_cast<int32_t*>(st + L.hits),
+                                        reinterpret_cast<int32_t*>(st + L.nhit), seq_w, seq_rows, row_w, ts);
+    ARX_CHECK_LAUNCH();
+    k_mc_mask<<<(int)ceil_div(B, 8), 256, 0, s>>>(pm, mrows, B, S, maskR, L.ldr, maskC, L.ldc);
+    ARX_CHECK_LAUNCH();
+  }
+  if (phases & 2) {
+    McFlow a{};
+    a.nstat = B; a.span = L.CW; a.nstream = S;
+    a.statF = U; a.ldstat = ldu;
+    a.XK = Pp; a.xk_plane = S * 64;
+    a.XT = PT; a.ldx = L.ldpt;
+    a.cstat = t; a.sgn_stat = -1.f;
+    a.cstream = pbias; a.cw = nullptr;
+    a.mask = maskR; a.ldmask = L.ldr;
+    a.zeros = reinterpret_cast<const float*>(st + L.zeros);
+    a.O = O_part; a.o_rows = L.Bp;
+    a.rsum = rs_part; a.rs_rows = B;
+    k_mc_flow<false><<<(int)(ceil_div(B, 128) * L.nsplit), 256, 2 * kMcStage, s>>>(a);
+    ARX_CHECK_LAUNCH();
+  }
+  if (phases & 4) {
+    McRows a{rs_part, O_part, L.nsplit, L.Bp, t, U, ldu, T, ldt, gscale, row_w, batch_loss,
+             reinterpret_cast<float*>(st + L.coef), reinterpret_cast<float*>(st + L.tneg), dtscore,
+             dtscore_stride > 0 ? dtscore_stride : 1, dU, lddu, dT, lddt, reinterpret_cast<uint16_t*>(st + L.Up),
+             reinterpret_cast<uint16_t*>(st + L.UgT), L.ldug, reinterpret_cast<const float*>(st + L.pbad),
+             (int)(S / 32)};
+    k_mc_rows<<<(int)(L.Bp / 32), 256, 0, s>>>(a, B);
+    ARX_CHECK_LAUNCH();
+  }
+  return ARX_OK;
+}
+
+size_t arx_mce_scorer_bwd_di_workspace_bytes(int64_t B, int64_t S, int d, int64_t step_rows) {
+  McLayout L;
+  if (!mc_layout(B, S, d, &L)) return 0;
+  const int64_t nsl = ceil_div(L.Bp, mc_di_slice(L, S, step_rows));
+  return (size_t)nsl * S * 64 * 4 + (size_t)nsl * S * 4 + 512;
+}
+
+/* dI[s, :] = beta dI[s, :] + sum_r w_rs U[r, :], db[s] = sum_r w_rs with w_rs = coef_r m_rs exp(x_rs - t_r), recomputed
+ * tile by tile; arguments as arx_mw_scorer_bwd_di_loss (step_rows > 0: B % step_rows == 0, step_rows % 128 == 0). */
+int arx_mce_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, const float* pbias, int64_t step_rows,
+                               float beta, float* dI, int64_t lddi, float* db, float* dI_steps, float* db_steps,
+                               const float* batch_loss, float gscale, const float* row_w, float* loss_out,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  McLayout L;
+  ARX_CHECK_ARG(!loss_out || (batch_loss && (reinterpret_cast<uintptr_t>(batch_loss) & 15) == 0 &&
+                              (reinterpret_cast<uintptr_t>(row_w) & 15) == 0),
+                "arx_mce_scorer_bwd_di_loss: loss_out needs batch_loss (and row_w) 16-byte aligned");
+  ARX_CHECK_ARG(state && dI && mc_layout(B, S, d, &L), "arx_mce_scorer_bwd_di: bad argument / shape");
+  ARX_CHECK_ARG(lddi % 4 == 0 && lddi >= d && (reinterpret_cast<uintptr_t>(dI) & 15) == 0,
+                "arx_mce_scorer_bwd_di: dI rows must be 16-byte aligned");
+  ARX_CHECK_ARG(step_rows == 0 || (step_rows % 128 == 0 && B % step_rows == 0),
+                "arx_mce_scorer_bwd_di: step_rows must divide B and be a multiple of 128");
+  if (int rc = mc_raise_lds()) return rc;
+  const int64_t ks = mc_di_slice(L, S, step_rows);
+  const int64_t nsl = ceil_div(L.Bp, ks);
+  const size_t part_bytes = (size_t)nsl * S * 64 * 4;
+  const size_t need = (dI_steps ? 0 : part_bytes) + (size_t)nsl * S * 4 + 256;
+  if (!workspace || workspace_bytes < need) {
+    set_error("arx_mce_scorer_bwd_di: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return ARX_EWORKSPACE;
+  }
+  char* wsb = reinterpret_cast<char*>(workspace);
+  float* part = dI_steps ? dI_steps : reinterpret_cast<float*>(wsb);
+  float* dbpart = reinterpret_cast<float*>(wsb + (dI_steps ? 0 : al256(part_bytes)));
+  hipStream_t s = as_stream(stream);
+  const char* st = reinterpret_cast<const char*>(state);
+  McFlow a{};
+  a.nstat = S; a.span = ks; a.nstream = L.Bp;
+  a.statP = reinterpret_cast<const uint16_t*>(st + L.Pp); a.statP_plane = S * 64;
+  a.XK = reinterpret_cast<const uint16_t*>(st + L.Up); a.xk_plane = L.Bp * 64;
+  a.XT = reinterpret_cast<const uint16_t*>(st + L.UgT); a.ldx = L.ldug;
+  a.cstat = pbias; a.sgn_stat = 1.f;
+  a.cstream = reinterpret_cast<const float*>(st + L.tneg);
+  a.cw = reinterpret_cast<const float*>(st + L.coef);
+  a.mask = reinterpret_cast<const uint32_t*>(st + L.maskC); a.ldmask = L.ldc;
+  a.zeros = reinterpret_cast<const float*>(st + L.zeros);
+  a.O = part; a.o_rows = S;
+  a.rsum = dbpart; a.rs_rows = S;
+  k_mc_flow<true><<<(int)((S / 128) * nsl), 256, 2 * kMcStage, s>>>(a);
+  ARX_CHECK_LAUNCH();
+  const int dbblocks = db ? (int)ceil_div(S, 64) : 0;
+  const bool steps = db_steps && step_rows > 0;
+  const int64_t Lsteps = steps ? B / step_rows : 0;
+  const int stepblocks = steps ? (int)ceil_div(Lsteps * S, 256) : 0;
+  k_sc_tn_reduce<<<(int)ceil_div(S * (64 / 4), 64) + dbblocks + stepblocks + (loss_out ? 1 : 0), 256, 0, s>>>(
+      part, (int)nsl, S, 64, beta, dI, lddi, dbpart, nsl, db, dbblocks, batch_loss, row_w, B, gscale, loss_out,
+      stepblocks, 1, Lsteps, db_steps);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

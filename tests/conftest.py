@@ -42,10 +42,15 @@ def assert_mw_scorer_path(plan, rows, S, d):
     """Every 'mw' train plan whose shape the fused scorer family takes (csrc/scorer.hip: arx_mw_scorer_supported)
     must have run on it, and a plan whose shape it does not take must not claim it: a whole-step test that passes on
     the K4 + K6 path says nothing about the default one (round-4 verdict, weak #1 ii)."""
+    return assert_scorer_path(plan, rows, S, d, 'mw')
+
+
+def assert_scorer_path(plan, rows, S, d, kind):
+    """... for 'mw' or the build-defined 'mce' (ops.mce_scorer_supported: the k_mc_flow family, d == 64)."""
     from arx import graph as G, ops
-    bls = [n for n in plan.order if isinstance(n, G.BatchLoss) and n.kind == 'mw']
-    assert bls, "no 'mw' loss node in the plan"
-    want = ops.mw_scorer_supported(rows, S, d)
+    bls = [n for n in plan.order if isinstance(n, G.BatchLoss) and n.kind == kind]
+    assert bls, "no %r loss node in the plan" % kind
+    want = (ops.mw_scorer_supported if kind == 'mw' else ops.mce_scorer_supported)(rows, S, d)
     for n in bls:
         logits = n.inputs[0]
         if isinstance(logits, G.Prediction) and logits.fusable(rows):

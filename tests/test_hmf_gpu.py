@@ -103,7 +103,8 @@ CFG_MIX = dict(n_users=400, n_items=600, logit_size=600, item_mulhot=True, user_
     (CFG_MIX, 'mw', 32, 48, 128),            # d = 32: not a shape of the fused scorer family -> K4 + K6
     (CFG_MIX, 'mw', 64, 48, 128),            # ... and the same layout on it
     (CFG_ID, 'mce', 128, 64, 256),           # build-defined sampled softmax (fused target score)
-    (CFG_HET, 'mce', 64, 32, 128),
+    (CFG_HET, 'mce', 64, 32, 128),           # ... on the fused 'mce' family (d = 64)
+    (CFG_ID, 'mce', 64, 200, 256),
     (CFG_ID, 'ce', 32, 64, None),
     (CFG_HET, 'ce', 32, 64, None),
     (CFG_HET, 'warp', 64, 32, None),
@@ -134,6 +135,8 @@ def test_hmf_steps_match_oracle(dev, cfg, loss, d, B, S, use_graph):
         from conftest import assert_mw_scorer_path
         assert_mw_scorer_path(model._plan('train'), B, S, d)
     if loss == 'mce':                            # evaluates with the full softmax
+        from conftest import assert_scorer_path
+        assert assert_scorer_path(model._plan('train'), B, S, d, 'mce') == (d == 64)   # d = 64: the fused family ran
         e_ref = ref.step(list(users), list(items), forward_only=True, loss=loss)
         e_got = model.step(None, list(users), list(items), forward_only=True, loss=loss)
         np.testing.assert_allclose(e_got, e_ref, rtol=RTOL)

@@ -1528,6 +1528,108 @@ def test_mw_scorer(dev, B, S, d, mask_rows, maxpos):
         assert abs(float(lsum.item()) - ref_sum) <= 4e-7 * ref_sum * (6 + np.log2(B)) + 1e-12
 
 
+@pytest.mark.parametrize("B,S,mask_rows,maxpos,bias", [(320, 256, 0, 30, True), (77, 128, 0, 30, True),
+                                                        (1, 128, 0, 30, False), (4096, 512, 1024, 30, True),
+                                                        (515, 2048, 0, 100, True), (2048, 1024, 0, 400, True),
+                                                        (5120, 1024, 1024, 30, False)])
+def test_mce_scorer(dev, B, S, mask_rows, maxpos, bias):
+    """The build-defined sampled softmax 'mce' on the fused family (csrc/scorer.hip k_mc_flow / k_mc_rows:
+    arx_mce_scorer_fwd / _bwd_di_loss, d = 64) against the oracle's logits -> compute_loss('mce') ->
+    compute_loss_bwd chain in f64: loss, target score, dt, dT = dt U, the COMPLETE latent gradient dU = dl . P + dt T
+    out of the forward, then dI = beta dI + dl^T . U, db, the step's scalar loss and the per-time-step products.  No
+    [B, S] array exists on the device; the positives of the row's user are masked pairs (maxpos = 400: rows with
+    dozens of them in the pool); B = 515 / 77 / 1: ragged stationary and stream tiles; S = 2048: four column splits."""
+    from arx import ops
+    import torch
+    d = 64
+    assert ops.mce_scorer_supported(B, S, d)
+    rng = np.random.default_rng(B + S + 1)
+    U = (rng.standard_normal((B, d)) * 0.4).astype(np.float32)
+    P = (rng.standard_normal((S, d)) * 0.4).astype(np.float32)
+    pb = (rng.standard_normal(S) * 0.2).astype(np.float32) if bias else None
+    T = (rng.standard_normal((B, d)) * 0.4).astype(np.float32)
+    tb = (rng.standard_normal(B) * 0.1).astype(np.float32)
+    n_items, n_users = 5 * S, 50
+    pool = rng.permutation(n_items)[:S].astype(np.int32)
+    i2s = np.full(n_items + 1, -1, dtype=np.int32)
+    i2s[pool] = np.arange(S, dtype=np.int32)
+    npos = rng.integers(0, maxpos, size=n_users)
+    ptr = np.concatenate([[0], np.cumsum(npos)]).astype(np.int32)
+    pitems = rng.integers(0, n_items, size=int(ptr[-1])).astype(np.int32)
+    mrows = mask_rows or B
+    users = rng.integers(0, n_users, size=mrows).astype(np.int32)
+    rw = rng.random(B).astype(np.float32)
+    gscale = 1.0 / B
+    logits = U.astype(np.float64) @ P.astype(np.float64).T + (pb if bias else 0.0)
+    t = (U.astype(np.float64) * T).sum(1) + tb
+    mask = np.ones((B, S), dtype=bool)
+    for r in range(B):
+        u = users[r % mrows]
+        sl = i2s[pitems[ptr[u]:ptr[u + 1]]]
+        mask[r, sl[sl >= 0]] = False
+    assert (~mask).sum() > 0 or B == 1
+    e = rg.RefEmbeddingAttribute.__new__(rg.RefEmbeddingAttribute)
+    e.dt = np.dtype(np.float64)
+    bl, cache = e.compute_loss(logits, t, 'mce', mask)
+    dl, dt = e.compute_loss_bwd(cache, rw.astype(np.float64) * gscale)
+    U64, P64 = U.astype(np.float64), P.astype(np.float64)
+    f32 = torch.float32
+    sc = ops.MceScorer(B, S, d, dev)
+    out_bl, out_t = (torch.empty(B, dtype=f32, device=dev) for _ in range(2))
+    dU, dT = (torch.full((B, d), 9.0, dtype=f32, device=dev) for _ in range(2))
+    dts = torch.empty(B, dtype=f32, device=dev)
+    tU, tP, tpb = _t(dev, U), _t(dev, P), (_t(dev, pb) if bias else None)
+    args = (_t(dev, T), _t(dev, tb), _t(dev, users), _t(dev, ptr), _t(dev, pitems), _t(dev, i2s))
+    for rep in range(2):               # twice: the state (mask tables included) is reusable
+        sc.fwd(tU, tP, tpb, *args, out_bl, out_t, dts, dU, dT, gscale, row_w=_t(dev, rw), mask_rows=mask_rows)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out_t.cpu().numpy(), t, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out_bl.cpu().numpy(), bl, rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(dts.cpu().numpy(), dt, rtol=RTOL, atol=1e-10)
+    np.testing.assert_allclose(dT.cpu().numpy(), dt[:, None] * U64, rtol=RTOL, atol=1e-9)
+    scale_u = np.abs(dl) @ np.abs(P64) + np.abs(dt[:, None] * T)           # term scale of a gradient entry
+    errU = np.abs(dU.cpu().numpy() - (dl @ P64 + dt[:, None] * T))
+    assert np.all(errU <= 2e-6 * scale_u + 1e-12), float((errU / (scale_u + 1e-30)).max())
+    sc.bwd_dU(dU, beta=1.0)            # (no-op: the forward wrote the whole latent gradient)
+    dI0 = rng.standard_normal((S, d)).astype(np.float32)
+    dI = _t(dev, dI0)
+    db = torch.empty(S, dtype=f32, device=dev)
+    lsum = torch.full((1,), 7.0, dtype=f32, device=dev)
+    sc.bwd_dI(dI, db=db, beta=0.5, loss=(out_bl, gscale, _t(dev, rw), lsum))
+    ref_sum = float((rw.astype(np.float64) * gscale * bl).sum())
+    bound = 4e-7 * float((rw.astype(np.float64) * gscale * np.abs(bl)).sum()) * (6 + np.log2(max(B, 2))) + 1e-12
+    assert abs(float(lsum.item()) - ref_sum) <= bound, (float(lsum.item()), ref_sum, bound)
+    scale_i = np.abs(dl).T @ np.abs(U64)
+    errI = np.abs(dI.cpu().numpy() - (0.5 * dI0 + dl.T @ U64))
+    assert np.all(errI <= 2e-6 * scale_i + 1e-7 * np.abs(dI0) + 1e-12), float((errI / (scale_i + 1e-30)).max())
+    np.testing.assert_allclose(db.cpu().numpy(), dl.sum(0), rtol=2e-5, atol=1e-12)
+    if mask_rows:
+        L = B // mask_rows
+        dIs = torch.empty((L, S, d), dtype=f32, device=dev)
+        dbs = torch.empty((L, S), dtype=f32, device=dev)
+        dI2 = torch.empty((S, d), dtype=f32, device=dev)
+        sc.bwd_dI(dI2, db=db, step_rows=mask_rows, dI_steps=dIs, db_steps=dbs)
+        for k in range(L):
+            rows = slice(k * mask_rows, (k + 1) * mask_rows)
+            ref = dl[rows].T @ U64[rows]
+            err = np.abs(dIs[k].cpu().numpy() - ref)
+            assert np.all(err <= 2e-6 * (np.abs(dl[rows]).T @ np.abs(U64[rows])) + 1e-12)
+            np.testing.assert_allclose(dbs[k].cpu().numpy(), dl[rows].sum(0), rtol=2e-5, atol=1e-12)
+        err = np.abs(dI2.cpu().numpy() - dl.T @ U64)
+        assert np.all(err <= 2e-6 * scale_i + 1e-12)
+        # the sequence model's example weights formed by the first launch, as in arx_mw_scorer_fwd_seqw
+        w_raw = _t(dev, (rng.random(B) * (rng.random(B) > 0.2)).astype(np.float32))
+        wn_ref = torch.empty(B, dtype=f32, device=dev)
+        ops.seq_weights(w_raw, L, mask_rows, wn_ref)
+        wn = torch.full((B,), 7.0, dtype=f32, device=dev)
+        sc.fwd(tU, tP, tpb, *args, out_bl, out_t, dts, dU, dT, 1.0, row_w=wn, mask_rows=mask_rows, seq_w=w_raw,
+               seq_rows=mask_rows)
+        assert torch.equal(wn, wn_ref)
+        wn64 = wn.cpu().numpy().astype(np.float64)
+        _, dt2 = e.compute_loss_bwd(cache, wn64)
+        np.testing.assert_allclose(dts.cpu().numpy(), dt2, rtol=RTOL, atol=1e-10)
+
+
 def test_mw_scorer_products_f32_exact(dev):
     """The piece arithmetic of the scorer at its edges (the round-3 ruling's condition ii).  Stated input domain:
     finite f32 operands whose products and sums stay inside the f32 normal range -- what an f32 FMA chain needs as

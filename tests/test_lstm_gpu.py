@@ -122,11 +122,12 @@ def test_seq_mw_steps_match_oracle(dev, cfg, size, B, L, S, clip):
         assert ops.SCORER_F32 or fused                            # the path under test ran
 
 
-@pytest.mark.parametrize("cfg", [CFG_ID, CFG_HET])
-def test_seq_mce_steps_match_oracle(dev, cfg):
+@pytest.mark.parametrize("cfg,B", [(CFG_ID, 16), (CFG_HET, 16), (CFG_ID, 128), (CFG_HET, 128)])
+def test_seq_mce_steps_match_oracle(dev, cfg, B):
     """Build-defined sampled softmax ('mce', arx.h) through the sequence model: train steps with
-    active clipping and the full-softmax evaluation, vs the oracle's definition of the same."""
-    size, B, L, S = 64, 16, 5, 128
+    active clipping and the full-softmax evaluation, vs the oracle's definition of the same.  B = 128: a time
+    step's rows are whole tiles -- the fused 'mce' family (k_mc_flow) with its per-step pool gradients."""
+    size, L, S = 64, 5, 128
     syn, emb, model, remb, ref = _build(cfg, 'mce', size, B, L, S, 5.0, seed=14)
     rng = np.random.default_rng(17)
     pool = syn.sample_pool(S, rng)
@@ -139,6 +140,11 @@ def test_seq_mce_steps_match_oracle(dev, cfg):
         np.testing.assert_allclose(l_got, l_ref, rtol=RTOL, err_msg='loss step %d' % step)
         np.testing.assert_allclose(float(model._gnorm.item()), ref.last['gnorm'], rtol=RTOL)
         _compare(emb, model, remb, ref)
+    from conftest import assert_scorer_path
+    from arx import ops
+    fused = assert_scorer_path(model._plan(0, 'train'), L * B, S, size, 'mce')
+    if B % 128 == 0:
+        assert ops.SCORER_F32 or fused                            # the path under test ran
     e_ref = ref.step(list(users), inp.tolist(), tg.tolist(), w.tolist(), None, id2idx, forward_only=True)
     e_got = model.step(None, list(users), inp.tolist(), tg.tolist(), w.tolist(), 0, None, id2idx,
                        forward_only=True)
