@@ -226,13 +226,18 @@ struct ScTScore {                     // target scores t_r = U_r . T_r + tb_r, f
 // positives (user -> pos_ptr -> pos_items -> item2slot, embed_attribute.py:729-741) and lists the ones that are
 // pool slots: hits[r][0 .. nhit) (more than kScHits: nhit = -1, the row kernel walks the chain itself).
 // ------------------------------------------------------------------------------------------------------------
+// MASKS (the 'mce' family, k_mc_flow): the same walk also sets the masked pairs' bits, maskR[(s >> 5) * ldr + r] bit
+// (s & 31), for EVERY positive of the row that sits in the pool (no stop at kScHits; the table was zeroed in front
+// of this launch) -- a walk of its own (k_mc_mask) took 18 us in the C4 step, as long as this whole kernel.
+template <bool MASKS>
 __global__ __launch_bounds__(256) void k_sc_prep(const float* __restrict__ P, int64_t ldp, int64_t S, int d,
                                                  const float* __restrict__ pbias, uint16_t* __restrict__ Pp,
                                                  uint16_t* __restrict__ PT, int64_t ldpt, float* __restrict__ pool_bad,
                                                  PosMask pm,
                                                  int64_t mask_rows, int64_t B, int32_t* __restrict__ hits,
                                                  int32_t* __restrict__ nhit, const float* __restrict__ seq_w,
-                                                 int64_t seq_rows, float* __restrict__ row_w_out, ScTScore ts) {
+                                                 int64_t seq_rows, float* __restrict__ row_w_out, ScTScore ts,
+                                                 uint32_t* __restrict__ maskR, int64_t ldr) {
   __shared__ float tile[32 * 129];
   __shared__ float sbad[4];
   const int tid = threadIdx.x;
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256) void k_sc_prep(const float* __restrict__ P, in
   const int beg = valid ? pm.pos_ptr[usr] : 0, end = valid ? pm.pos_ptr[usr + 1] : 0;
   int n = 0;
   for (int p0 = beg;; p0 += 32) {
-    const bool active = p0 < end && n >= 0;
+    const bool active = p0 < end && (MASKS || n >= 0);
     if (!__any(active)) break;
     const int p = p0 + hl;
     int j = -1;
@@ -308,10 +313,11 @@ __global__ __launch_bounds__(256) void k_sc_prep(const float* __restrict__ P, in
       j = pos_slot(pm, pm.pos_items[p]);
       if (j < 0 || j >= S) j = -1;
     }
+    if (MASKS && j >= 0) atomicOr(&maskR[(int64_t)(j >> 5) * ldr + r], 1u << (j & 31));
     const unsigned long long hm64 = __ballot(j >= 0);
     const uint32_t hm = (lane >> 5) ? (uint32_t)(hm64 >> 32) : (uint32_t)hm64;
     const int k = __popc(hm);
-    if (active) {
+    if (active && n >= 0) {
       if (n + k > kScHits) n = -1;
       else {
         if (j >= 0) hits[r * kScHits + n + __popc(hm & ((1u << hl) - 1u))] = j;
@@ -1188,14 +1194,19 @@ size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 //       UgT: coef_r U_r transposed, both by k_mc_rows), c_stream = -t_r (-inf in the padding), cw = coef:
 //       part[slice][s][:] = sum_r e_rs coef_r U_r, dbpart[slice][s] = sum_r e_rs coef_r; slices = time steps for
 //       the sequence model (its per-step clip norm), summed by k_sc_tn_reduce.
-//   The positives of a row that sit in the pool are MASKED (m_rs = 0) from two bit tables, word-major per stream
-//   tile, set by k_mc_mask from the positives chain: a word is non-zero once in thousands of tiles, one wave-wide
-//   test per tile.
+//   The positives of a row that sit in the pool are MASKED (m_rs = 0) from one bit table, maskR[s / 32][r], set by
+//   k_sc_prep<true>'s walk of the positives chain (zeroed in front of it by k_mc_zero): the dU role's lane reads its
+//   row's word of the tile, the dI role reads the same words across (a tile's 32 rows x the wave's 32 columns are the
+//   32 words of one word row) -- a word is non-zero once in thousands of tiles, one wave-wide test per tile.
 //   k_mc_rows (between the two): s_r, loss_r = log1p(s_r), coef_r, dt_r = -coef_r s_r, dU_r = coef_r O_r + dt_r T_r,
 //   dT_r = dt_r U_r, the planes Up / UgT, -t_r.
 // Two workgroups of four waves per CU (two MFMA-issuing waves per SIMD: one's exp / split VALU under the other's
 // MFMAs); d = 64 (x accumulators 32 + O accumulators 64 + stationary pieces 48 registers; d = 128 would need 352).
 // ============================================================================================================
+#ifndef MC_SLOTS
+#define MC_SLOTS 2
+#endif
+constexpr int kMcSlots = MC_SLOTS;           // LDS ring: the stage being read + kMcSlots - 1 in flight
 constexpr int kMcStage = 25 * 1024;          // K part 12 KB + T part 12 KB + 1 KB: the tile's 32 + 32 constants
 
 struct McFlow {
@@ -1209,7 +1220,7 @@ struct McFlow {
   const float* cstat; float sgn_stat;        // exponent constant of a stationary index (nullable), times sgn
   const float* cstream;                      // ... of a streamed index (nullable: 0)
   const float* cw;                           // dI role: weight of a streamed index in rsum
-  const uint32_t* mask; int64_t ldmask;      // [nstream / 32][ldmask]: bit i of mask[t][stat] <-> pair (stat, 32 t + i) masked
+  const uint32_t* mask; int64_t ldmask;      // maskR [S / 32][ldmask]: bit (s & 31) of word [(s >> 5) * ldmask + r] <-> pair (r, s) masked
   const float* zeros;                        // >= 16 bytes of zeros (what an absent constant array reads)
   float* O; int64_t o_rows;                  // [slices][o_rows][64]
   float* rsum; int64_t rs_rows;              // [slices][rs_rows]
@@ -1218,11 +1229,27 @@ struct McFlow {
 template <bool DI>
 __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
   constexpr int NCH = 4;
-  extern __shared__ __attribute__((aligned(1024))) char lds[];      // [2][kMcStage]
+  extern __shared__ __attribute__((aligned(1024))) char lds[];      // [kMcSlots][kMcStage]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 31, kg = lane >> 5;
   const int64_t nsb = (a.nstat + 127) / 128;
-  const int64_t sb = (int64_t)blockIdx.x % nsb, sl = (int64_t)blockIdx.x / nsb;
+  // workgroup -> (stationary block sb, slice sl).  Workgroups are dealt to the 8 XCDs round-robin; the dI role's nsb
+  // workgroups of a slice stream the SAME rows of the batch: they sit 8 apart, i.e. on one XCD, whose L2 then fetches
+  // the slice once (with plain division every slice came over the fabric nsb times)
+  int64_t sb, sl;
+  if (DI) {
+    const int64_t bid = blockIdx.x, grp = 8 * nsb, full = (int64_t)gridDim.x / grp * grp;
+    if (bid < full) {
+      sl = bid / grp * 8 + bid % 8;
+      sb = bid % grp / 8;
+    } else {
+      sl = full / nsb + (bid - full) / nsb;
+      sb = (bid - full) % nsb;
+    }
+  } else {
+    sb = (int64_t)blockIdx.x % nsb;
+    sl = (int64_t)blockIdx.x / nsb;
+  }
   const int64_t n_begin = sl * a.span;
   const int64_t n_end = n_begin + a.span < a.nstream ? n_begin + a.span : a.nstream;
   const int ntile = (int)((n_end - n_begin) / 32);
@@ -1258,27 +1285,37 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
   } else if (lane < 16) {
     if (DI) { srcx = reinterpret_cast<const char*>(a.cw + n_begin + 4 * (lane - 8)); advx = 128; }
   } else if (lane < 48) {
-    srcx = reinterpret_cast<const char*>(a.mask + (n_begin / 32) * a.ldmask + sb * 128 + 4 * (lane - 16));
-    advx = a.ldmask * 4;
+    if (!DI) {       // word (tile, row) of the workgroup's 128 rows: bit i <-> column 32 tile + i
+      srcx = reinterpret_cast<const char*>(a.mask + (n_begin / 32) * a.ldmask + sb * 128 + 4 * (lane - 16));
+      advx = a.ldmask * 4;
+    } else {         // the SAME table read across: wave w's 32 columns are word row 4 sb + w, the tile's 32 rows its words
+      srcx = reinterpret_cast<const char*>(a.mask + (sb * 4 + ((lane - 16) >> 3)) * a.ldmask + n_begin + 4 * ((lane - 16) & 7));
+      advx = 128;
+    }
   }
   const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
   auto dma = [&](uint32_t dst, const char* p) {
+#ifdef MC_ABL_NODMA
+    return;
+#endif
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                  :: "s"(__builtin_amdgcn_readfirstlane(dst)), "v"(p) : "memory");
   };
-  auto issue = [&](int t) {                        // (tiles are issued in order: the sources step along)
-    const uint32_t stage = lds0 + (uint32_t)((t & 1) * kMcStage + wv * 6 * 1024);
+  auto issue = [&](int slot) {                     // (tiles are issued in order: the sources step along)
+    const uint32_t stage = lds0 + (uint32_t)(slot * kMcStage + wv * 6 * 1024);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       dma(stage + i * 1024, src[i]);
       src[i] += adv;
     }
     if (wv == 0) {
-      dma(lds0 + (uint32_t)((t & 1) * kMcStage + 24 * 1024), srcx);
+      dma(lds0 + (uint32_t)(slot * kMcStage + 24 * 1024), srcx);
       srcx += advx;
     }
   };
-  if (ntile > 0) issue(0);
+#pragma unroll
+  for (int q = 0; q < kMcSlots - 1; ++q)
+    if (q < ntile) issue(q);
 
   // ---- the stationary rows as bf16 pieces (second MFMA operand: lane = row lr, k = 16 c + 8 kg ..) ----
   bf16x8 a1[NCH], a2[NCH], a3[NCH];
@@ -1318,83 +1355,147 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  int slot = 0, slot_in = kMcSlots - 1;            // the slot being read / the slot the next request goes to
   for (int t = 0; t < ntile; ++t) {
-    const char* st = lds + (t & 1) * kMcStage;
-    if (t + 1 < ntile) issue(t + 1);
+    const char* st = lds + slot * kMcStage;
+    if (t + kMcSlots - 1 < ntile) issue(slot_in);  // (read last in tile t - 1: every wave is past that barrier)
+    slot = slot + 1 == kMcSlots ? 0 : slot + 1;
+    slot_in = slot_in + 1 == kMcSlots ? 0 : slot_in + 1;
     const uint32_t mw = reinterpret_cast<const uint32_t*>(st + 24 * 1024 + 256)[wv * 32 + lr];
+    // The instruction stream of a tile is pinned group by group (sched_barrier): the fragments of group g + 1 are
+    // requested in front of the six MFMAs of group g -- left alone the scheduler emits read / wait / MFMA triples and
+    // the matrix pipe idles for an LDS round trip per fragment.  Groups: four k-chunks of the x tile, then four
+    // (q, dd block) products; the first product's fragments are requested under the last chunk, exp / split sit between.
+    uint4 fr[2][3];
+#define MC_LDK(set_, c_)                                                                                 \
+  {                                                                                                      \
+    const uint32_t fa = fk + 16 * ((2 * (c_) + kg) ^ swk);                                               \
+    fr[set_][0] = *reinterpret_cast<const uint4*>(st + fa);                                              \
+    fr[set_][1] = *reinterpret_cast<const uint4*>(st + fa + 4096);                                       \
+    fr[set_][2] = *reinterpret_cast<const uint4*>(st + fa + 8192);                                       \
+  }
+#define MC_LDT(set_, g_)                                                                                 \
+  {                                                                                                      \
+    const uint32_t o0 = ft + 16 * ((2 * ((g_) >> 1)) ^ swt) + ((g_) & 1) * 2048;                         \
+    const uint32_t o1 = ft + 16 * ((2 * ((g_) >> 1) + 1) ^ swt) + ((g_) & 1) * 2048;                     \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                   \
+      const uint2 h0 = *reinterpret_cast<const uint2*>(st + o0 + pl * 4096);                             \
+      const uint2 h1 = *reinterpret_cast<const uint2*>(st + o1 + pl * 4096);                             \
+      fr[set_][pl] = make_uint4(h0.x, h0.y, h1.x, h1.y);                                                 \
+    }                                                                                                    \
+  }
     // ---- x tile: D[stream index][stationary], hi starts at c_stream + c_stat ----
     f32x16 hi, lo;
     const float* cs = reinterpret_cast<const float*>(st + 24 * 1024) + 4 * kg;
+    MC_LDK(0, 0)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float4 cv = *reinterpret_cast<const float4*>(cs + 8 * g);
       hi[4 * g] = cv.x + cst; hi[4 * g + 1] = cv.y + cst; hi[4 * g + 2] = cv.z + cst; hi[4 * g + 3] = cv.w + cst;
       lo[4 * g] = 0.f; lo[4 * g + 1] = 0.f; lo[4 * g + 2] = 0.f; lo[4 * g + 3] = 0.f;
     }
+    float4 cwv[4];
+    if (DI) {
+      const float* cwp = reinterpret_cast<const float*>(st + 24 * 1024 + 128) + 4 * kg;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) cwv[g] = *reinterpret_cast<const float4*>(cwp + 8 * g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const uint32_t fa = fk + 16 * ((2 * c + kg) ^ swk);
-      const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + fa));
-      const bf16x8 b2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + fa + 4096));
-      const bf16x8 b3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + fa + 8192));
+      const bf16x8 b1 = __builtin_bit_cast(bf16x8, fr[c & 1][0]), b2 = __builtin_bit_cast(bf16x8, fr[c & 1][1]),
+                   b3 = __builtin_bit_cast(bf16x8, fr[c & 1][2]);
+      if (c + 1 < NCH) MC_LDK((c + 1) & 1, c + 1)
+      else MC_LDT(0, 0)
+      __builtin_amdgcn_sched_barrier(0);
       lo = SC_MFMA(b3, a1[c], lo);
       hi = SC_MFMA(b1, a1[c], hi);
       lo = SC_MFMA(b1, a3[c], lo);
       lo = SC_MFMA(b2, a2[c], lo);
       lo = SC_MFMA(b2, a1[c], lo);
       lo = SC_MFMA(b1, a2[c], lo);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---- e = exp(x) in the accumulator layout (value 4 g + e <-> stream index 8 g + 4 kg + e), masked ----
     float w[16];
 #pragma unroll
+#ifdef MC_ABL_NOEXP
+    for (int i = 0; i < 16; ++i) w[i] = hi[i] + lo[i];
+#else
     for (int i = 0; i < 16; ++i) w[i] = __expf(hi[i] + lo[i]);
+#endif
     if (__any(mw != 0u)) {
+      // dU role: the lane's word holds its row's bits for the tile's columns; dI role: lane lr holds the word of the
+      // tile's ROW lr (bits = the wave's 32 columns): value i belongs to row 8 (i / 4) + 4 kg + i % 4, column lr
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
-        if ((mw >> (8 * (i >> 2) + 4 * kg + (i & 3))) & 1u) w[i] = 0.f;
+      for (int i = 0; i < 16; ++i) {
+        const int m = 8 * (i >> 2) + 4 * kg + (i & 3);
+        const uint32_t bit = DI ? (__shfl(mw, m, 64) >> lr) & 1u : (mw >> m) & 1u;
+        if (bit) w[i] = 0.f;
+      }
     }
     if (DI) {
-      const float* cwp = reinterpret_cast<const float*>(st + 24 * 1024 + 128) + 4 * kg;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 cv = *reinterpret_cast<const float4*>(cwp + 8 * g);
-        rs += w[4 * g] * cv.x; rs += w[4 * g + 1] * cv.y; rs += w[4 * g + 2] * cv.z; rs += w[4 * g + 3] * cv.w;
+        rs += w[4 * g] * cwv[g].x; rs += w[4 * g + 1] * cwv[g].y; rs += w[4 * g + 2] * cwv[g].z; rs += w[4 * g + 3] * cwv[g].w;
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) rs += w[i];
     }
     // ---- O[dd][stationary] += X^T[dd][stream] . e[stream][stationary], six terms ----
+    bf16x8 w1[2], w2[2], w3[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       uint32_t p1[4], p2[4], p3[4];
 #pragma unroll
+#ifdef MC_ABL_NOSPLIT
+      for (int j = 0; j < 4; ++j) p1[j] = p2[j] = p3[j] = __float_as_uint(w[8 * q + 2 * j]) ^ __float_as_uint(w[8 * q + 2 * j + 1]);
+#else
       for (int j = 0; j < 4; ++j) split3x2(w[8 * q + 2 * j], w[8 * q + 2 * j + 1], p1[j], p2[j], p3[j]);
-      const bf16x8 w1 = __builtin_bit_cast(bf16x8, make_uint4(p1[0], p1[1], p1[2], p1[3]));
-      const bf16x8 w2 = __builtin_bit_cast(bf16x8, make_uint4(p2[0], p2[1], p2[2], p2[3]));
-      const bf16x8 w3 = __builtin_bit_cast(bf16x8, make_uint4(p3[0], p3[1], p3[2], p3[3]));
-      const uint32_t o0 = ft + 16 * ((2 * q) ^ swt), o1 = ft + 16 * ((2 * q + 1) ^ swt);
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        bf16x8 tp[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          const uint2 h0 = *reinterpret_cast<const uint2*>(st + o0 + blk * 2048 + pl * 4096);
-          const uint2 h1 = *reinterpret_cast<const uint2*>(st + o1 + blk * 2048 + pl * 4096);
-          tp[pl] = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
-        }
-        f32x16& hO = blk ? hiO1 : hiO0;
-        f32x16& lO = blk ? loO1 : loO0;
-        lO = SC_MFMA(tp[2], w1, lO);
-        hO = SC_MFMA(tp[0], w1, hO);
-        lO = SC_MFMA(tp[0], w3, lO);
-        lO = SC_MFMA(tp[1], w2, lO);
-        lO = SC_MFMA(tp[1], w1, lO);
-        lO = SC_MFMA(tp[0], w2, lO);
-      }
+#endif
+      w1[q] = __builtin_bit_cast(bf16x8, make_uint4(p1[0], p1[1], p1[2], p1[3]));
+      w2[q] = __builtin_bit_cast(bf16x8, make_uint4(p2[0], p2[1], p2[2], p2[3]));
+      w3[q] = __builtin_bit_cast(bf16x8, make_uint4(p3[0], p3[1], p3[2], p3[3]));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int q = g >> 1;
+      const bf16x8 t1 = __builtin_bit_cast(bf16x8, fr[g & 1][0]), t2 = __builtin_bit_cast(bf16x8, fr[g & 1][1]),
+                   t3 = __builtin_bit_cast(bf16x8, fr[g & 1][2]);
+      if (g + 1 < 4) MC_LDT((g + 1) & 1, g + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16& hO = (g & 1) ? hiO1 : hiO0;
+      f32x16& lO = (g & 1) ? loO1 : loO0;
+#ifdef MC_ABL_NOPROD
+      lO[0] += __uint_as_float(__builtin_bit_cast(uint4, t3).x ^ __builtin_bit_cast(uint4, w1[q]).x ^ __builtin_bit_cast(uint4, w2[q]).y ^ __builtin_bit_cast(uint4, w3[q]).z);
+      hO[0] += __uint_as_float(__builtin_bit_cast(uint4, t1).x ^ __builtin_bit_cast(uint4, t2).x);
+#else
+      lO = SC_MFMA(t3, w1[q], lO);
+      hO = SC_MFMA(t1, w1[q], hO);
+      lO = SC_MFMA(t1, w3[q], lO);
+      lO = SC_MFMA(t2, w2[q], lO);
+      lO = SC_MFMA(t2, w1[q], lO);
+      lO = SC_MFMA(t1, w2[q], lO);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef MC_LDK
+#undef MC_LDT
+#ifdef MC_ABL_NOBAR
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    // tile t + 1 has landed; with three slots the requests of tile t + 2 (seven by wave 0, six by the others) stay
+    // in flight
+    if (kMcSlots == 3 && t + 2 < ntile) {
+      if (wv == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
+#endif
   }
   rs += __shfl_xor(rs, 32, 64);
   if (!ok) return;
@@ -1408,26 +1509,6 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
     *reinterpret_cast<float4*>(orow + 32 + 8 * g) =
         make_float4(hiO1[4 * g] + loO1[4 * g], hiO1[4 * g + 1] + loO1[4 * g + 1], hiO1[4 * g + 2] + loO1[4 * g + 2],
                     hiO1[4 * g + 3] + loO1[4 * g + 3]);
-  }
-}
-
-// bit tables of the masked pairs: maskR[s / 32][ldr] bit (s % 32) of row r (read by the dU role: stationary = rows)
-// and maskC[r / 32][ldc] bit (r % 32) of column s (dI role).  Half a wave per batch row walks the user's positives
-// (embed_attribute.py:729-741).  Both tables are zeroed by the caller in front of this launch.
-__global__ __launch_bounds__(256) void k_mc_mask(PosMask pm, int64_t mask_rows, int64_t B, int64_t S,
-                                                 uint32_t* __restrict__ maskR, int64_t ldr,
-                                                 uint32_t* __restrict__ maskC, int64_t ldc) {
-  const int hl = threadIdx.x & 31;
-  const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
-  if (r >= B) return;
-  const int usr = pm.user_ids[r % mask_rows];
-  const int beg = pm.pos_ptr[usr], end = pm.pos_ptr[usr + 1];
-  for (int p = beg + hl; p < end; p += 32) {
-    const int j = pos_slot(pm, pm.pos_items[p]);
-    if (j >= 0 && j < S) {
-      atomicOr(&maskR[(int64_t)(j >> 5) * ldr + r], 1u << (j & 31));
-      atomicOr(&maskC[(r >> 5) * ldc + j], 1u << (int)(r & 31));
-    }
   }
 }
 
@@ -1647,8 +1728,8 @@ int arx_mw_scorer_fwd_seqw(const float* U, int64_t ldu, const float* P, int64_t 
   if (phases & 1) {
     const int64_t grid = S / 32 + ceil_div(B, 8) + (seq_w ? ceil_div(seq_rows, 32) : 0);
     const ScTScore ts{U, ldu, T, ldt, tbias, tb_stride > 0 ? tb_stride : 1, t, tscore_out};
-    k_sc_prep<<<(int)grid, 256, 0, s>>>(P, ldp, S, d, pbias, Pp, PT, L.ldpt, reinterpret_cast<float*>(st + L.pbad), pm,
-                                        mrows, B, hits, nhit, seq_w, seq_rows, row_w, ts);
+    k_sc_prep<false><<<(int)grid, 256, 0, s>>>(P, ldp, S, d, pbias, Pp, PT, L.ldpt, reinterpret_cast<float*>(st + L.pbad),
+                                               pm, mrows, B, hits, nhit, seq_w, seq_rows, row_w, ts, nullptr, 0);
     ARX_CHECK_LAUNCH();
   }
   if (phases & 2) {
@@ -1782,10 +1863,10 @@ namespace arx {
 namespace {
 
 struct McLayout {
-  int64_t Bp, ldpt, ldug, ldr, ldc;
+  int64_t Bp, ldpt, ldug, ldr;
   int nsplit;
   int64_t CW;
-  size_t maskR, maskC, mask_bytes, t, tneg, coef, rs, O, hits, nhit, Pp, PT, Up, UgT, pbad, zeros, total;
+  size_t maskR, mask_bytes, t, tneg, coef, rs, O, hits, nhit, Pp, PT, Up, UgT, pbad, zeros, total;
 };
 
 bool mc_layout(int64_t B, int64_t S, int d, McLayout* L) {
@@ -1794,16 +1875,15 @@ bool mc_layout(int64_t B, int64_t S, int d, McLayout* L) {
   L->ldpt = S + 128;                     // (not a power of two: see ScLayout)
   L->ldug = L->Bp + 128;
   L->ldr = L->Bp;
-  L->ldc = S;
-  // column splits of the dU role: enough workgroups for two rounds of the chip's 2 x 256 slots
+  // column splits of the dU role: >= 3 workgroups per CU (two are resident: 400 row blocks x 2 splits run 25 tile
+  // rounds per CU where 400 x 1 run 32), no more -- every split writes its own O partial ([Bp][64] f32)
   int ns = 1;
-  while (ns < 4 && (L->Bp / 128) * ns < 4 * (int64_t)cu_count() && S / (2 * ns) >= 128 && (S / (2 * ns)) % 32 == 0) ns *= 2;
+  while (ns < 4 && (L->Bp / 128) * ns < 3 * (int64_t)cu_count() && S / (2 * ns) >= 128 && (S / (2 * ns)) % 32 == 0) ns *= 2;
   L->nsplit = ns;
   L->CW = S / ns;
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += al256(bytes); return at; };
   L->maskR = take((size_t)(S / 32) * L->ldr * 4);
-  L->maskC = take((size_t)(L->Bp / 32) * L->ldc * 4);
   L->mask_bytes = o;
   L->t = take((size_t)B * 4);
   L->tneg = take((size_t)L->Bp * 4);
@@ -1823,13 +1903,15 @@ bool mc_layout(int64_t B, int64_t S, int d, McLayout* L) {
 }
 
 __global__ __launch_bounds__(256) void k_mc_zero(uint4* __restrict__ p, int64_t n16) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+  const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (i0 + 256 * k < n16) p[i0 + 256 * k] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 int mc_raise_lds() {
-  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mc_flow<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mc_flow<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mc_flow<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mc_flow<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   return ARX_OK;
 }
 
@@ -1888,22 +1970,20 @@ int arx_mce_scorer_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp,
   uint16_t* Pp = reinterpret_cast<uint16_t*>(st + L.Pp);
   uint16_t* PT = reinterpret_cast<uint16_t*>(st + L.PT);
   uint32_t* maskR = reinterpret_cast<uint32_t*>(st + L.maskR);
-  uint32_t* maskC = reinterpret_cast<uint32_t*>(st + L.maskC);
   float* rs_part = reinterpret_cast<float*>(st + L.rs);
   float* O_part = reinterpret_cast<float*>(st + L.O);
   const PosMask pm = make_pos_mask(user_ids, pos_ptr, pos_items, item2slot);
   const int64_t mrows = mask_rows > 0 ? mask_rows : B;
   if (phases & 1) {
     const int64_t n16 = (int64_t)(L.mask_bytes / 16);
-    k_mc_zero<<<(int)ceil_div(n16, 256), 256, 0, s>>>(reinterpret_cast<uint4*>(st + L.maskR), n16);
+    k_mc_zero<<<(int)ceil_div(n16, 1024), 256, 0, s>>>(reinterpret_cast<uint4*>(st + L.maskR), n16);
     ARX_CHECK_LAUNCH();
     const int64_t grid = S / 32 + ceil_div(B, 8) + (seq_w ? ceil_div(seq_rows, 32) : 0);
     const ScTScore ts{U, ldu, T, ldt, tbias, tb_stride > 0 ? tb_stride : 1, t, tscore_out};
-    k_sc_prep<<<(int)grid, 256, 0, s>>>(P, ldp, S, d, pbias, Pp, PT, L.ldpt, reinterpret_cast<float*>(st + L.pbad), pm,
-                                        mrows, B, reinterpret_cast<int32_t*>(st + L.hits),
-                                        reinterpret_cast<int32_t*>(st + L.nhit), seq_w, seq_rows, row_w, ts);
-    ARX_CHECK_LAUNCH();
-    k_mc_mask<<<(int)ceil_div(B, 8), 256, 0, s>>>(pm, mrows, B, S, maskR, L.ldr, maskC, L.ldc);
+    k_sc_prep<true><<<(int)grid, 256, 0, s>>>(P, ldp, S, d, pbias, Pp, PT, L.ldpt, reinterpret_cast<float*>(st + L.pbad),
+                                              pm, mrows, B, reinterpret_cast<int32_t*>(st + L.hits),
+                                              reinterpret_cast<int32_t*>(st + L.nhit), seq_w, seq_rows, row_w, ts,
+                                              maskR, L.ldr);
     ARX_CHECK_LAUNCH();
   }
   if (phases & 2) {
@@ -1918,7 +1998,7 @@ int arx_mce_scorer_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp,
     a.zeros = reinterpret_cast<const float*>(st + L.zeros);
     a.O = O_part; a.o_rows = L.Bp;
     a.rsum = rs_part; a.rs_rows = B;
-    k_mc_flow<false><<<(int)(ceil_div(B, 128) * L.nsplit), 256, 2 * kMcStage, s>>>(a);
+    k_mc_flow<false><<<(int)(ceil_div(B, 128) * L.nsplit), 256, kMcSlots * kMcStage, s>>>(a);
     ARX_CHECK_LAUNCH();
   }
   if (phases & 4) {
@@ -1977,11 +2057,11 @@ int arx_mce_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, c
   a.cstat = pbias; a.sgn_stat = 1.f;
   a.cstream = reinterpret_cast<const float*>(st + L.tneg);
   a.cw = reinterpret_cast<const float*>(st + L.coef);
-  a.mask = reinterpret_cast<const uint32_t*>(st + L.maskC); a.ldmask = L.ldc;
+  a.mask = reinterpret_cast<const uint32_t*>(st + L.maskR); a.ldmask = L.ldr;
   a.zeros = reinterpret_cast<const float*>(st + L.zeros);
   a.O = part; a.o_rows = S;
   a.rsum = dbpart; a.rs_rows = S;
-  k_mc_flow<true><<<(int)((S / 128) * nsl), 256, 2 * kMcStage, s>>>(a);
+  k_mc_flow<true><<<(int)((S / 128) * nsl), 256, kMcSlots * kMcStage, s>>>(a);
   ARX_CHECK_LAUNCH();
   const int dbblocks = db ? (int)ceil_div(S, 64) : 0;
   const bool steps = db_steps && step_rows > 0;
