@@ -52,6 +52,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   SC_ABL_NOBAR   no per-stage barriers (loaders and compute waves run free)
 //   SC_ABL_NOMFMA  the MFMAs are compiled out (reads, epilogue and barriers stay)
 //   SC_TRACE       cycle stamps (s_memtime) of one compute wave of workgroup 5: arx_sc_trace_read (tools/sc_trace.py)
+//   MC_ABL_NODMA / MC_ABL_NOEXP / MC_ABL_NOBAR   the same for k_mc_flow (SC_ABL_NOMFMA applies to it too); MC_SLOTS=3: a
+//                  three-slot LDS ring (measured +-0)
 #ifndef SC_TRACE_CHUNKS
 #define SC_TRACE_CHUNKS 0            // 1: a stamp after every chunk (perturbs: each stamp drains the LDS counter)
 #endif
@@ -1200,8 +1202,15 @@ size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 //   32 words of one word row) -- a word is non-zero once in thousands of tiles, one wave-wide test per tile.
 //   k_mc_rows (between the two): s_r, loss_r = log1p(s_r), coef_r, dt_r = -coef_r s_r, dU_r = coef_r O_r + dt_r T_r,
 //   dT_r = dt_r U_r, the planes Up / UgT, -t_r.
-// Two workgroups of four waves per CU (two MFMA-issuing waves per SIMD: one's exp / split VALU under the other's
-// MFMAs); d = 64 (x accumulators 32 + O accumulators 64 + stationary pieces 48 registers; d = 128 would need 352).
+// Two workgroups of four waves per CU (two MFMA-issuing waves per SIMD); d = 64 (x accumulators 32 + O accumulators
+// 64 + stationary pieces 48 registers; d = 128 would need 352).
+// Measured at the C4 shape (51 200 rows x 1 024 columns, tools/mcebench.py; ablation builds give WRONG results, the
+// clock is what counts): a flow launch 96 - 100 us = 0.33 of the bf16 peak for its 12 terms (k_sc_hinge<64>: 0.28);
+// no MFMA 30 us, no product MFMAs 66, no exp -2, no split -8, no barrier -4, one workgroup per CU 122 (the second
+// wave per SIMD gives 1.22x), three LDS slots +-0, s_setprio on every other workgroup +-0, the q = 1 split between
+// the MFMAs of the q = 0 products (kept) +-0, fragments requested one group ahead -3; "no LDS-DMA" -23 is the
+// matrix pipe multiplying zeros at a higher clock, not the DMA.  The walk of the positives in a launch of its own
+// took 18 us in the step (now k_sc_prep<true>), slices on one XCD -8 us for the dI role.
 // ============================================================================================================
 #ifndef MC_SLOTS
 #define MC_SLOTS 2
@@ -1444,20 +1453,18 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
       for (int i = 0; i < 16; ++i) rs += w[i];
     }
     // ---- O[dd][stationary] += X^T[dd][stream] . e[stream][stationary], six terms ----
+    // the split of values 8..15 (q = 1) sits in the MFMA gaps of the q = 0 products
     bf16x8 w1[2], w2[2], w3[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      uint32_t p1[4], p2[4], p3[4];
-#pragma unroll
-#ifdef MC_ABL_NOSPLIT
-      for (int j = 0; j < 4; ++j) p1[j] = p2[j] = p3[j] = __float_as_uint(w[8 * q + 2 * j]) ^ __float_as_uint(w[8 * q + 2 * j + 1]);
-#else
-      for (int j = 0; j < 4; ++j) split3x2(w[8 * q + 2 * j], w[8 * q + 2 * j + 1], p1[j], p2[j], p3[j]);
-#endif
-      w1[q] = __builtin_bit_cast(bf16x8, make_uint4(p1[0], p1[1], p1[2], p1[3]));
-      w2[q] = __builtin_bit_cast(bf16x8, make_uint4(p2[0], p2[1], p2[2], p2[3]));
-      w3[q] = __builtin_bit_cast(bf16x8, make_uint4(p3[0], p3[1], p3[2], p3[3]));
-    }
+#define MC_SPLITQ(q_)                                                                                    \
+  {                                                                                                      \
+    uint32_t p1[4], p2[4], p3[4];                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+      split3x2(w[8 * (q_) + 2 * j], w[8 * (q_) + 2 * j + 1], p1[j], p2[j], p3[j]);                       \
+    w1[q_] = __builtin_bit_cast(bf16x8, make_uint4(p1[0], p1[1], p1[2], p1[3]));                         \
+    w2[q_] = __builtin_bit_cast(bf16x8, make_uint4(p2[0], p2[1], p2[2], p2[3]));                         \
+    w3[q_] = __builtin_bit_cast(bf16x8, make_uint4(p3[0], p3[1], p3[2], p3[3]));                         \
+  }
+    MC_SPLITQ(0)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1468,19 +1475,23 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
       __builtin_amdgcn_sched_barrier(0);
       f32x16& hO = (g & 1) ? hiO1 : hiO0;
       f32x16& lO = (g & 1) ? loO1 : loO0;
-#ifdef MC_ABL_NOPROD
-      lO[0] += __uint_as_float(__builtin_bit_cast(uint4, t3).x ^ __builtin_bit_cast(uint4, w1[q]).x ^ __builtin_bit_cast(uint4, w2[q]).y ^ __builtin_bit_cast(uint4, w3[q]).z);
-      hO[0] += __uint_as_float(__builtin_bit_cast(uint4, t1).x ^ __builtin_bit_cast(uint4, t2).x);
-#else
       lO = SC_MFMA(t3, w1[q], lO);
       hO = SC_MFMA(t1, w1[q], hO);
       lO = SC_MFMA(t1, w3[q], lO);
       lO = SC_MFMA(t2, w2[q], lO);
       lO = SC_MFMA(t2, w1[q], lO);
       lO = SC_MFMA(t1, w2[q], lO);
-#endif
+      if (g == 0) {
+        MC_SPLITQ(1)
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
+#undef MC_SPLITQ
 #undef MC_LDK
 #undef MC_LDT
 #ifdef MC_ABL_NOBAR

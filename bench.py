@@ -653,6 +653,36 @@ def run_lstm(args, loss, steps, warmup):
                            "ms_per_launch": t_f, "traffic": None,
                            "bwd": {"ms_per_launch": t_b, "flops_per_launch": fl_b,
                                    "achieved": fl_b / t_b / 1e9, "frac": fl_b / t_b / 1e9 / FP32_MFMA_PEAK_TF}}
+        from arx import graph as G
+        pred = [n for n in plan.order if isinstance(n, G.Prediction)][0]
+        if loss == 'mce' and pred.fused_into_loss and isinstance(pred.scorer, ops.MceScorer):
+            # the 'mce' family (csrc/scorer.hip k_mc_flow): the pass that leaves s_r and O_r (loss + latent-side
+            # product) and the pool-side pass, each 12 bf16 MFMA terms of 2 (L B) S d (six for the recomputed logit
+            # tile, six for the product out of the accumulators); no [L B, S] array exists
+            bl = [n for n in plan.order if isinstance(n, G.BatchLoss) and n.gemm_fused][0]
+            ms = bl.mask
+            ptr, items = ms.pos_getter()
+            uid, i2s = ms.user_ids.value, ms.slot_map_getter()
+            tgt = bl.inputs[1]
+            lat_, te = tgt.inputs
+            pool_ = pred.inputs[1]
+            sc = pred.scorer
+            rw = bl.row_w.value if bl.row_w is not None else None
+            t_u = _evt_time_ms(lambda: sc.fwd(lat_.value, pool_.value, pool_.bias_value, te.value, te.bias_value, uid,
+                                              ptr, items, i2s, bl.value, tgt.value, tgt.grad, lat_.grad, te.grad,
+                                              bl.gscale, row_w=rw, mask_rows=bl.mask_rows, phases=2), 20)
+            t_i = _evt_time_ms(lambda: sc.bwd_dI(pool_.grad, db=pool_.bias_grad, step_rows=B, dI_steps=pred.C_steps,
+                                                 db_steps=pred.rs_steps), 20)
+            fl12 = 12 * 2.0 * L * B * S * size
+            out["roofline_scorer"] = {
+                "kernel": "k_mc_flow<dU role> (x tile six terms + e . P six terms out of the accumulators)",
+                "bound": "mfma", "achieved": fl12 / t_u / 1e9, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": fl12 / t_u / 1e9 / BF16_MFMA_PEAK_TF, "flops_per_launch": fl12, "ms_per_launch": t_u,
+                "traffic": None,
+                "dI": {"kernel": "k_mc_flow<dI role> + k_sc_tn_reduce", "ms_per_launch": t_i,
+                       "achieved": fl12 / t_i / 1e9, "frac": fl12 / t_i / 1e9 / BF16_MFMA_PEAK_TF},
+                "note": "no [L*B, S] logits / weights in HBM; the materialising path (ARX_MCE_FUSED=0) runs the "
+                        "same step ~125 us slower"}
     del model, emb, syn, batches
     torch.cuda.empty_cache()
     return out
