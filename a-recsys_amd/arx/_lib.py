@@ -121,7 +121,7 @@ PROTOTYPES = {
                                   i64, f32, f32p, f32p, i64, i64, i64, f32p, f32p, f32p, i64, f32p, i64, f32p, i64,
                                   vp, sz, cint, vp]),
     "arx_mce_scorer_bwd_di_workspace_bytes": (sz, [i64, i64, cint, i64]),
-    "arx_mce_scorer_bwd_di_loss": (cint, [i64, i64, cint, vp, f32p, i64, f32, f32p, i64, f32p, f32p, f32p, f32p, f32,
+    "arx_mce_scorer_bwd_di_loss": (cint, [i64, i64, cint, vp, f32p, i64, i64, f32, f32p, i64, f32p, f32p, f32p, f32p, f32,
                                           f32p, f32p, vp, sz, vp]),
     "arx_sample_wor_workspace_bytes": (sz, [i64]),
     "arx_sample_wor_keys_workspace_bytes": (sz, [i64, i64, f32]),

@@ -503,11 +503,11 @@ class MceScorer(object):
             raise ValueError("MceScorer: shape not supported (B=%d, S=%d, d=%d)" % (B, S, d))
         self.state = torch.zeros(n, dtype=torch.uint8, device=device)
         self.ws = Workspace(device)
-        self._pbias = None
+        self._pbias, self._mask_rows = None, 0
 
     def fwd(self, U, P, pbias, T, tbias, user_ids, pos_ptr, pos_items, item2slot, batch_loss, tscore_out, dtscore,
             dU, dT, gscale, row_w=None, mask_rows=0, phases=7, seq_w=None, seq_rows=0):
-        self._pbias = pbias
+        self._pbias, self._mask_rows = pbias, int(mask_rows)
         call("arx_mce_scorer_fwd", _p(U), _ld(U), _p(P), _ld(P), _p(pbias), _p(T), _ld(T), _p(tbias),
              int(tbias.stride(0)) if tbias is not None else 1, self.d, _p(user_ids), _p(pos_ptr), _p(pos_items),
              _p(item2slot), int(mask_rows), float(gscale), _p(row_w), _p(seq_w), int(seq_rows), self.B, self.S,
@@ -523,7 +523,8 @@ class MceScorer(object):
     def bwd_dI(self, dI, db=None, beta=0.0, step_rows=0, dI_steps=None, db_steps=None, loss=None):
         wsp, wsn = self.ws.get(_lib.lib.arx_mce_scorer_bwd_di_workspace_bytes(self.B, self.S, self.d, int(step_rows)))
         bl, gs, rw, out = loss if loss is not None else (None, 0.0, None, None)
-        call("arx_mce_scorer_bwd_di_loss", self.B, self.S, self.d, _p(self.state), _p(self._pbias), int(step_rows),
+        call("arx_mce_scorer_bwd_di_loss", self.B, self.S, self.d, _p(self.state), _p(self._pbias), self._mask_rows,
+             int(step_rows),
              float(beta), _p(dI), _ld(dI), _p(db), _p(dI_steps), _p(db_steps), _p(bl), float(gs), _p(rw), _p(out),
              wsp, wsn, _stream())
 

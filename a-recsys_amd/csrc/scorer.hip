@@ -228,9 +228,9 @@ struct ScTScore {                     // target scores t_r = U_r . T_r + tb_r, f
 // positives (user -> pos_ptr -> pos_items -> item2slot, embed_attribute.py:729-741) and lists the ones that are
 // pool slots: hits[r][0 .. nhit) (more than kScHits: nhit = -1, the row kernel walks the chain itself).
 // ------------------------------------------------------------------------------------------------------------
-// MASKS (the 'mce' family, k_mc_flow): the same walk also sets the masked pairs' bits, maskR[(s >> 5) * ldr + r] bit
-// (s & 31), for EVERY positive of the row that sits in the pool (no stop at kScHits; the table was zeroed in front
-// of this launch) -- a walk of its own (k_mc_mask) took 18 us in the C4 step, as long as this whole kernel.
+// MASKS (the 'mce' family, k_mc_flow): the walk leaves the masked pairs as bits instead of hit lists, maskR[(s >> 5) *
+// ldr + u] bit (s & 31) for EVERY positive of user row u = r % mask_rows that sits in the pool (no stop at kScHits) --
+// a walk of its own (k_mc_mask) took 18 us in the C4 step, as long as this whole kernel.
 template <bool MASKS>
 __global__ __launch_bounds__(256) void k_sc_prep(const float* __restrict__ P, int64_t ldp, int64_t S, int d,
                                                  const float* __restrict__ pbias, uint16_t* __restrict__ Pp,
@@ -303,9 +303,18 @@ __global__ __launch_bounds__(256) void k_sc_prep(const float* __restrict__ P, in
     t4 = *reinterpret_cast<const float4*>(ts.T + r * ts.ldt + 4 * hl);
   }
   const float tbv = (valid && ts.tb) ? ts.tb[r * ts.tb_stride] : 0.f;
-  const int usr = valid ? pm.user_ids[r % mask_rows] : 0;
-  const int beg = valid ? pm.pos_ptr[usr] : 0, end = valid ? pm.pos_ptr[usr + 1] : 0;
+  // MASKS: the masked pairs of row r are those of its user, r % mask_rows -- the sequence model's L * mask_rows
+  // time-major rows repeat every user L times: only the rows r < mask_rows walk (1 024 walks instead of 51 200 at the
+  // C4 shape) and leave the user's word row maskR[0 .. S / 32)[r], WRITTEN whole (lane hl keeps words hl and hl + 32 in
+  // registers: no zeroing launch, no atomics); the flow kernels index the table with r % mask_rows.
+  // (hit lists, !MASKS: the same once-per-user walk since round 5 -- the walker leaves nhit / hits for every row of
+  // its user, r + t * mask_rows; k_sc_prep took 16 us of the C4 'mw' step for 51 200 walks of 1 024 distinct lists)
+  const bool walker = valid && r < mask_rows;
+  const int64_t reps = walker ? (B - r + mask_rows - 1) / mask_rows : 0;
+  const int usr = walker ? pm.user_ids[r % mask_rows] : 0;
+  const int beg = walker ? pm.pos_ptr[usr] : 0, end = walker ? pm.pos_ptr[usr + 1] : 0;
   int n = 0;
+  uint32_t mw0 = 0u, mw1 = 0u;
   for (int p0 = beg;; p0 += 32) {
     const bool active = p0 < end && (MASKS || n >= 0);
     if (!__any(active)) break;
@@ -315,23 +324,46 @@ __global__ __launch_bounds__(256) void k_sc_prep(const float* __restrict__ P, in
       j = pos_slot(pm, pm.pos_items[p]);
       if (j < 0 || j >= S) j = -1;
     }
-    if (MASKS && j >= 0) atomicOr(&maskR[(int64_t)(j >> 5) * ldr + r], 1u << (j & 31));
     const unsigned long long hm64 = __ballot(j >= 0);
-    const uint32_t hm = (lane >> 5) ? (uint32_t)(hm64 >> 32) : (uint32_t)hm64;
-    const int k = __popc(hm);
-    if (active && n >= 0) {
-      if (n + k > kScHits) n = -1;
-      else {
-        if (j >= 0) hits[r * kScHits + n + __popc(hm & ((1u << hl) - 1u))] = j;
-        n += k;
+    uint32_t hm = (lane >> 5) ? (uint32_t)(hm64 >> 32) : (uint32_t)hm64;
+    if (MASKS) {
+      // every slot found by a lane of the half wave goes to the lane that keeps its word (wave-uniform loop: the
+      // two half waves of a wave take their own lists in step)
+      while (__any(hm != 0u)) {
+        const bool some = hm != 0u;
+        const int srcl = some ? __builtin_ctz(hm) : 0;
+        hm &= hm - 1u;
+        const int jj = __shfl(j, (lane & 32) + srcl, 64);
+        if (some && hl == ((jj >> 5) & 31)) {
+          if (jj < 1024) mw0 |= 1u << (jj & 31);
+          else mw1 |= 1u << (jj & 31);
+        }
+      }
+    } else {
+      const int k = __popc(hm);
+      if (active && n >= 0) {
+        if (n + k > kScHits) n = -1;
+        else {
+          if (j >= 0) {
+            const int at = n + __popc(hm & ((1u << hl) - 1u));
+            for (int64_t t = 0; t < reps; ++t) hits[(r + t * mask_rows) * kScHits + at] = j;
+          }
+          n += k;
+        }
       }
     }
+  }
+  if (MASKS && walker) {
+    const int nwords = (int)(S >> 5);
+    if (hl < nwords) maskR[(int64_t)hl * ldr + r] = mw0;
+    if (hl + 32 < nwords) maskR[(int64_t)(hl + 32) * ldr + r] = mw1;
   }
   float dot = u4.x * t4.x + u4.y * t4.y + u4.z * t4.z + u4.w * t4.w;
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+  if (!MASKS && hl == 0)
+    for (int64_t t = 0; t < reps; ++t) nhit[r + t * mask_rows] = n;
   if (hl == 0 && valid) {
-    nhit[r] = n;
     const float t = dot + tbv;
     ts.tscore[r] = t;
     if (ts.tscore2) ts.tscore2[r] = t;
@@ -1196,10 +1228,11 @@ size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 //       UgT: coef_r U_r transposed, both by k_mc_rows), c_stream = -t_r (-inf in the padding), cw = coef:
 //       part[slice][s][:] = sum_r e_rs coef_r U_r, dbpart[slice][s] = sum_r e_rs coef_r; slices = time steps for
 //       the sequence model (its per-step clip norm), summed by k_sc_tn_reduce.
-//   The positives of a row that sit in the pool are MASKED (m_rs = 0) from one bit table, maskR[s / 32][r], set by
-//   k_sc_prep<true>'s walk of the positives chain (zeroed in front of it by k_mc_zero): the dU role's lane reads its
-//   row's word of the tile, the dI role reads the same words across (a tile's 32 rows x the wave's 32 columns are the
-//   32 words of one word row) -- a word is non-zero once in thousands of tiles, one wave-wide test per tile.
+//   The positives of a row that sit in the pool are MASKED (m_rs = 0) from one bit table, maskR[s / 32][user row],
+//   WRITTEN by k_sc_prep<true>'s walk of the positives chain, one walk per user row (the sequence model's time-major
+//   rows repeat theirs L times): the dU role's lane reads its row's word of the tile, the dI role reads the same
+//   words across (a tile's 32 rows x the wave's 32 columns are the 32 words of one word row) -- a word is non-zero
+//   once in thousands of tiles, one wave-wide test per tile.
 //   k_mc_rows (between the two): s_r, loss_r = log1p(s_r), coef_r, dt_r = -coef_r s_r, dU_r = coef_r O_r + dt_r T_r,
 //   dT_r = dt_r U_r, the planes Up / UgT, -t_r.
 // Two workgroups of four waves per CU (two MFMA-issuing waves per SIMD); d = 64 (x accumulators 32 + O accumulators
@@ -1231,6 +1264,7 @@ struct McFlow {
   const float* cw;                           // dI role: weight of a streamed index in rsum
   const uint32_t* mask; int64_t ldmask;      // maskR [S / 32][ldmask]: bit (s & 31) of word [(s >> 5) * ldmask + r] <-> pair (r, s) masked
   const float* zeros;                        // >= 16 bytes of zeros (what an absent constant array reads)
+  int64_t mask_mod;                          // the table's columns are USER rows: batch row r reads column r % mask_mod
   float* O; int64_t o_rows;                  // [slices][o_rows][64]
   float* rsum; int64_t rs_rows;              // [slices][rs_rows]
 };
@@ -1295,10 +1329,11 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
     if (DI) { srcx = reinterpret_cast<const char*>(a.cw + n_begin + 4 * (lane - 8)); advx = 128; }
   } else if (lane < 48) {
     if (!DI) {       // word (tile, row) of the workgroup's 128 rows: bit i <-> column 32 tile + i
-      srcx = reinterpret_cast<const char*>(a.mask + (n_begin / 32) * a.ldmask + sb * 128 + 4 * (lane - 16));
+      srcx = reinterpret_cast<const char*>(a.mask + (n_begin / 32) * a.ldmask + (sb * 128) % a.mask_mod + 4 * (lane - 16));
       advx = a.ldmask * 4;
     } else {         // the SAME table read across: wave w's 32 columns are word row 4 sb + w, the tile's 32 rows its words
-      srcx = reinterpret_cast<const char*>(a.mask + (sb * 4 + ((lane - 16) >> 3)) * a.ldmask + n_begin + 4 * ((lane - 16) & 7));
+      srcx = reinterpret_cast<const char*>(a.mask + (sb * 4 + ((lane - 16) >> 3)) * a.ldmask + n_begin % a.mask_mod +
+                                           4 * ((lane - 16) & 7));
       advx = 128;
     }
   }
@@ -1913,13 +1948,6 @@ bool mc_layout(int64_t B, int64_t S, int d, McLayout* L) {
   return true;
 }
 
-__global__ __launch_bounds__(256) void k_mc_zero(uint4* __restrict__ p, int64_t n16) {
-  const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (i0 + 256 * k < n16) p[i0 + 256 * k] = make_uint4(0u, 0u, 0u, 0u);
-}
-
 int mc_raise_lds() {
   ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mc_flow<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mc_flow<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -1974,6 +2002,8 @@ int arx_mce_scorer_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp,
     set_error("arx_mce_scorer_fwd: state too small (%zu < %zu)", state_bytes, L.total);
     return ARX_EWORKSPACE;
   }
+  ARX_CHECK_ARG(mask_rows <= 0 || mask_rows == B || (mask_rows % 128 == 0 && B % mask_rows == 0),
+                "arx_mce_scorer_fwd: mask_rows must be B or a multiple of 128 that divides B");
   if (int rc = mc_raise_lds()) return rc;
   hipStream_t s = as_stream(stream);
   char* st = reinterpret_cast<char*>(state);
@@ -1986,9 +2016,6 @@ int arx_mce_scorer_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp,
   const PosMask pm = make_pos_mask(user_ids, pos_ptr, pos_items, item2slot);
   const int64_t mrows = mask_rows > 0 ? mask_rows : B;
   if (phases & 1) {
-    const int64_t n16 = (int64_t)(L.mask_bytes / 16);
-    k_mc_zero<<<(int)ceil_div(n16, 1024), 256, 0, s>>>(reinterpret_cast<uint4*>(st + L.maskR), n16);
-    ARX_CHECK_LAUNCH();
     const int64_t grid = S / 32 + ceil_div(B, 8) + (seq_w ? ceil_div(seq_rows, 32) : 0);
     const ScTScore ts{U, ldu, T, ldt, tbias, tb_stride > 0 ? tb_stride : 1, t, tscore_out};
     k_sc_prep<true><<<(int)grid, 256, 0, s>>>(P, ldp, S, d, pbias, Pp, PT, L.ldpt, reinterpret_cast<float*>(st + L.pbad),
@@ -2006,6 +2033,7 @@ int arx_mce_scorer_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp,
     a.cstat = t; a.sgn_stat = -1.f;
     a.cstream = pbias; a.cw = nullptr;
     a.mask = maskR; a.ldmask = L.ldr;
+    a.mask_mod = mrows;
     a.zeros = reinterpret_cast<const float*>(st + L.zeros);
     a.O = O_part; a.o_rows = L.Bp;
     a.rsum = rs_part; a.rs_rows = B;
@@ -2033,8 +2061,8 @@ size_t arx_mce_scorer_bwd_di_workspace_bytes(int64_t B, int64_t S, int d, int64_
 
 /* dI[s, :] = beta dI[s, :] + sum_r w_rs U[r, :], db[s] = sum_r w_rs with w_rs = coef_r m_rs exp(x_rs - t_r), recomputed
  * tile by tile; arguments as arx_mw_scorer_bwd_di_loss (step_rows > 0: B % step_rows == 0, step_rows % 128 == 0). */
-int arx_mce_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, const float* pbias, int64_t step_rows,
-                               float beta, float* dI, int64_t lddi, float* db, float* dI_steps, float* db_steps,
+int arx_mce_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, const float* pbias, int64_t mask_rows,
+                               int64_t step_rows, float beta, float* dI, int64_t lddi, float* db, float* dI_steps, float* db_steps,
                                const float* batch_loss, float gscale, const float* row_w, float* loss_out,
                                void* workspace, size_t workspace_bytes, void* stream) {
   McLayout L;
@@ -2046,8 +2074,11 @@ int arx_mce_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, c
                 "arx_mce_scorer_bwd_di: dI rows must be 16-byte aligned");
   ARX_CHECK_ARG(step_rows == 0 || (step_rows % 128 == 0 && B % step_rows == 0),
                 "arx_mce_scorer_bwd_di: step_rows must divide B and be a multiple of 128");
+  const int64_t mrows = mask_rows > 0 ? mask_rows : B;
   if (int rc = mc_raise_lds()) return rc;
   const int64_t ks = mc_di_slice(L, S, step_rows);
+  ARX_CHECK_ARG(mrows == B || (mrows % 128 == 0 && mrows % ks == 0),
+                "arx_mce_scorer_bwd_di: mask_rows as given to the forward; a slice of rows must not wrap the user rows");
   const int64_t nsl = ceil_div(L.Bp, ks);
   const size_t part_bytes = (size_t)nsl * S * 64 * 4;
   const size_t need = (dI_steps ? 0 : part_bytes) + (size_t)nsl * S * 4 + 256;
@@ -2069,6 +2100,7 @@ int arx_mce_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, c
   a.cstream = reinterpret_cast<const float*>(st + L.tneg);
   a.cw = reinterpret_cast<const float*>(st + L.coef);
   a.mask = reinterpret_cast<const uint32_t*>(st + L.maskR); a.ldmask = L.ldr;
+  a.mask_mod = mrows;
   a.zeros = reinterpret_cast<const float*>(st + L.zeros);
   a.O = part; a.o_rows = S;
   a.rsum = dbpart; a.rs_rows = S;

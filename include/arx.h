@@ -488,12 +488,13 @@ int arx_loss_mce_fused_pos(const float* logits, int64_t ldl, const float* U, int
  * materialising entry point's max shift does not), backward weight w_rs = coef_r m_rs e_rs, coef_r = gscale row_w_r /
  * (1 + s_r), dt_r = -coef_r s_r.  The weight tile is recomputed where it is used and consumed out of the MFMA
  * accumulators (six-term f32-exact x, e split into three exact bf16 pieces, six-term products):
- *   arx_mce_scorer_fwd (phases bit 0: mask tables zeroed, k_sc_prep as in arx_mw_scorer_fwd_seqw, the masked pairs
- *     from the positives chain; bit 1: one pass over U . P^T that leaves s_r AND O_r = sum_s m e_rs P_s; bit 2: the
+ *   arx_mce_scorer_fwd (phases bit 0: k_sc_prep as in arx_mw_scorer_fwd_seqw, whose walk of the positives chain
+ *     leaves the masked pairs as one bit row per USER row -- mask_rows must be B (or 0) or a multiple of 128 that
+ *     divides B; bit 1: one pass over U . P^T that leaves s_r AND O_r = sum_s m e_rs P_s; bit 2: the
  *     row kernel): batch_loss, tscore_out, dtscore = dt, dT = dt U, dU = coef O + dt T (WRITTEN: the latent-side
  *     product is complete, there is no bwd_du), and in `state` the planes of U and coef U, coef, -t.
  *   arx_mce_scorer_bwd_di_loss: dI[s, :] = beta dI[s, :] + sum_r w_rs U[r, :], db[s] = sum_r w_rs; pbias = the pool
- *     bias the forward was given; step_rows / dI_steps / db_steps / loss_out as in arx_mw_scorer_bwd_di_loss.
+ *     bias and mask_rows the mask_rows the forward was given; step_rows / dI_steps / db_steps / loss_out as in arx_mw_scorer_bwd_di_loss.
  * Shapes: d == 64, S % 128 == 0, 128 <= S <= 2048, B >= 1, rows 16-byte aligned; arx_mce_scorer_supported tells,
  * callers take arx_gemm_f32 + arx_loss_mce_fused_pos otherwise.  `state`: arx_mce_scorer_state_bytes bytes, 256-byte
  * aligned, zeroed once, private to one (model, stream). */
@@ -507,8 +508,8 @@ int arx_mce_scorer_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp,
                        int64_t lddu, float* dT, int64_t lddt, void* state, size_t state_bytes, int phases,
                        void* stream);
 size_t arx_mce_scorer_bwd_di_workspace_bytes(int64_t B, int64_t S, int d, int64_t step_rows);
-int arx_mce_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, const float* pbias, int64_t step_rows,
-                               float beta, float* dI, int64_t lddi, float* db, float* dI_steps, float* db_steps,
+int arx_mce_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, const float* pbias, int64_t mask_rows,
+                               int64_t step_rows, float beta, float* dI, int64_t lddi, float* db, float* dI_steps, float* db_steps,
                                const float* batch_loss, float gscale, const float* row_w, float* loss_out,
                                void* workspace, size_t workspace_bytes, void* stream);
 
