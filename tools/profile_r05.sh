@@ -23,6 +23,17 @@ cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/c4
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c4 -o ks -- python $REPO/tools/lstm_bench.py --batch 1024 > $OUT/r05_c4_lstm_b1024.json 2>/dev/null
 f=$(find /tmp/c4 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/r05_c4_lstm_b1024_kernel_stats.csv
+# C4 with the sampled softmax 'mce' (the k_mc_flow family): kernel stats in step, its launches stand-alone beside the
+# materialising path's, the fused and the materialising step loss by loss, the step's timeline
+rm -rf /tmp/c4mce
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c4mce -o ks -- python $REPO/tools/lstm_bench.py --batch 1024 --loss mce > $OUT/r05_c4mce_lstm_b1024.json 2>/dev/null
+f=$(find /tmp/c4mce -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/r05_c4mce_lstm_b1024_kernel_stats.csv
+rm -rf /tmp/tr_c4mce
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_c4mce -- python $REPO/tools/lstm_bench.py --batch 1024 --steps 40 --warmup 10 --loss mce > /dev/null 2>&1
+f=$(find /tmp/tr_c4mce -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $REPO/tools/trace_gaps.py $f k_copy_words 15 > $OUT/r05_c4mce_step_timeline.txt
+python $REPO/tools/mcebench.py 51200 1024 1024 2>&1 | grep -v amdgpu.ids > $OUT/r05_mcebench_c4.txt
+python $REPO/tools/mcebench.py 16384 1024 2>&1 | grep -v amdgpu.ids > $OUT/r05_mcebench_b16384.txt
+python $REPO/tools/mce_ab_steps.py 2>&1 | grep "^step" > $OUT/r05_mce_ab_steps.txt
 # K7 of the C3 / C2 step alone (phase split)
 rm -rf /tmp/k7g
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k7g -o ks -- python $REPO/tools/k7grp_bench.py 16384 65536 > $OUT/r05_k7grp_bench.txt 2>/dev/null
