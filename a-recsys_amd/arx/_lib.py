@@ -115,6 +115,8 @@ PROTOTYPES = {
     "arx_mw_scorer_bwd_du": (cint, [i64, i64, cint, vp, f32, f32p, i64, vp]),
     "arx_mw_scorer_bwd_di_workspace_bytes": (sz, [i64, i64, cint, i64]),
     "arx_mw_scorer_bwd_di": (cint, [i64, i64, cint, vp, i64, f32, f32p, i64, f32p, f32p, f32p, vp, sz, vp]),
+    "arx_gemm_bt_bx6_supported": (cint, [i64, i64, i64]),
+    "arx_gemm_bt_bx6": (cint, [i64, i64, i64, f32p, i64, f32p, i64, f32, f32p, i64, vp]),
     "arx_mce_scorer_supported": (cint, [i64, i64, cint]),
     "arx_mce_scorer_state_bytes": (sz, [i64, i64, cint]),
     "arx_mce_scorer_fwd": (cint, [f32p, i64, f32p, i64, f32p, f32p, i64, f32p, i64, cint, i32p, i32p, i32p, i32p,
@@ -253,7 +255,7 @@ _NO_CHECK = ("arx_last_error", "arx_version", "arx_csr_expand_workspace_bytes",
              "arx_sample_wor_workspace_bytes", "arx_sample_wor_keys_workspace_bytes",
              "arx_gemm_nt_bx6_workspace_bytes", "arx_reduce_scratch_bytes", "arx_mw_scorer_supported",
              "arx_mw_scorer_state_bytes", "arx_mw_scorer_bwd_di_workspace_bytes", "arx_mce_scorer_supported",
-             "arx_mce_scorer_state_bytes", "arx_mce_scorer_bwd_di_workspace_bytes")
+             "arx_mce_scorer_state_bytes", "arx_mce_scorer_bwd_di_workspace_bytes", "arx_gemm_bt_bx6_supported")
 
 
 def call(name, *args):

@@ -146,15 +146,19 @@ class LSTM(G.Node):
         dz = self.dz
         if self._wt is None:
             self._wt = torch.empty((4 * h, din), dtype=torch.float32, device=rt.device)
+        # round 5: dx on the six-term bf16 tiles with W_x read as it lies (arx_gemm_bt_bx6; no W_x^T needed)
+        dx_bx6 = x.requires_grad and ops.gemm_bt_bx6_supported(L * B, din, 4 * h)
         ops.lstm_bwd(self.W.w, self.value, self.cs, self.gates, self.grad, L, B, din, h, dz,
-                     wxt=self._wt if x.requires_grad else None)
+                     wxt=self._wt if (x.requires_grad and not dx_bx6) else None)
         # dx = dz . W_x^T streams dz through the LDS-DMA GEMM with W_x^T as a plain [4h, din] operand (its
         # output tile is at most 128 columns wide; the transpose rode along in the backward kernel).
         # The weight gradient, both halves, and db come from ONE more pass over dz:
         # (dz^T . [x | h_prev])^T with h_prev = the cell outputs one step (B rows) up, written in W's own
         # [din + h, 4h] layout by the split-K reduce (arx_gemm_f32_tn_pair) -- two TN products, two
         # reduces and a transpose before.
-        if x.requires_grad:
+        if dx_bx6:
+            ops.gemm_bt_bx6(dz, self.W.w[:din], x.alloc_grad(), beta=x.grad_beta())
+        elif x.requires_grad:
             ops.gemm(dz, self._wt, x.alloc_grad(), rt.ws, beta=x.grad_beta())
         if L > 1 and ops.gemm_tn_pair_supported(4 * h, din, h, L * B):
             ops.gemm_tn_pair(dz, x.value, self.value, B, self.W.grad, rt.ws, a_rowsum=self.b.grad)

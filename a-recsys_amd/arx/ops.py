@@ -481,6 +481,18 @@ class MwScorer(object):
              _ld(dI), _p(db), _p(dI_steps), _p(db_steps), _p(bl), float(gs), _p(rw), _p(out), wsp, wsn, _stream())
 
 
+def gemm_bt_bx6_supported(M, N, K):
+    """arx_gemm_bt_bx6 takes this shape (N % 32 == 0, N <= 128, K in {64, 128, 256}) and the six-term family is on."""
+    return (not SCORER_F32) and bool(_lib.lib.arx_gemm_bt_bx6_supported(int(M), int(N), int(K)))
+
+
+def gemm_bt_bx6(A, Bt, C, beta=0.0):
+    """C = beta C + A . Bt^T, six-term f32-exact, Bt [N, K] k-contiguous (the LSTM's dx = dz . W_x^T with Bt = W_x)."""
+    M, K = int(A.shape[0]), int(A.shape[1])
+    N = int(Bt.shape[0])
+    call("arx_gemm_bt_bx6", M, N, K, _p(A), _ld(A), _p(Bt), _ld(Bt), float(beta), _p(C), _ld(C), _stream())
+
+
 def mce_scorer_supported(B, S, d):
     """True when the fused 'mce' family (csrc/scorer.hip, k_mc_flow) takes this shape: d == 64, S % 128 == 0,
     128 <= S <= 2048 -- and the process has not asked for the materialising reference (ARX_SCORER_F32 /

@@ -204,6 +204,16 @@ size_t arx_gemm_nt_bx6_workspace_bytes(int64_t N, int64_t K);
 int arx_gemm_nt_bx6(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                     const float* col_bias, float* C, int64_t ldc, void* workspace, size_t workspace_bytes,
                     void* stream);
+
+/* C[M, N] = beta C + A[M, K] . Bt[N, K]^T, six-term (f32-exact on the bf16 matrix pipe), for a SMALL second operand
+ * given k-contiguous: the LSTM cell's input gradient dx = dz . W_x^T (seqModel.py:99-103 static_rnn backward; tf's
+ * MatMul gradient) with Bt = W_x = rows [0, din) of the cell's [din + h, 4h] weight matrix as they lie.  The rows of
+ * A stream through LDS in coalesced segments and are split into bf16 pieces on the fly, the planes of Bt are made in
+ * LDS per workgroup: no operand planes in HBM, no workspace.  N % 32 == 0, N <= 128, K in {64, 128, 256}, rows
+ * 16-byte aligned (arx_gemm_bt_bx6_supported); other shapes: arx_gemm_f32. */
+int arx_gemm_bt_bx6_supported(int64_t M, int64_t N, int64_t K);
+int arx_gemm_bt_bx6(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* Bt, int64_t ldb,
+                    float beta, float* C, int64_t ldc, void* stream);
 int arx_gemm_f32_rowsum(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
                         const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
                         float* C, int64_t ldc, const float* col_bias, float* a_rowsum,

@@ -1630,6 +1630,28 @@ def test_mce_scorer(dev, B, S, mask_rows, maxpos, bias):
         np.testing.assert_allclose(dts.cpu().numpy(), dt2, rtol=RTOL, atol=1e-10)
 
 
+@pytest.mark.parametrize("M,N,K,beta", [(51200, 64, 256, 0.0), (777, 64, 256, 1.0), (130, 128, 128, 0.5),
+                                          (1, 32, 64, 0.0), (4096, 96, 64, 0.0)])
+def test_gemm_bt_bx6(dev, M, N, K, beta):
+    """arx_gemm_bt_bx6 (the LSTM's dx = dz . W_x^T on the six-term bf16 tiles, W_x read as it lies, the rows of dz
+    streamed through LDS and split on the fly): against an f64 product at 1e-6 of the term scale -- an f32 FMA chain's
+    own error -- incl. ragged row blocks and a strided second operand (rows of a wider matrix)."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(M + N + K)
+    A = (rng.standard_normal((M, K)) * (2.0 ** rng.integers(-8, 9, size=(M, 1)))).astype(np.float32)
+    W = rng.standard_normal((N + 5, K + 8)).astype(np.float32)          # Bt = rows [0, N), columns [0, K) of it
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    tA, tW, tC = _t(dev, A), _t(dev, W), _t(dev, C0)
+    assert ops.gemm_bt_bx6_supported(M, N, K)
+    ops.gemm_bt_bx6(tA, tW[:N, :K], tC, beta=beta)
+    Bt = W[:N, :K].astype(np.float64)
+    ref = beta * C0 + A.astype(np.float64) @ Bt.T
+    scale = np.abs(A).astype(np.float64) @ np.abs(Bt).T + np.abs(beta * C0)
+    err = np.abs(tC.cpu().numpy() - ref)
+    assert np.all(err <= 1e-6 * scale + 1e-30), float((err / (scale + 1e-30)).max())
+
+
 def test_mw_scorer_products_f32_exact(dev):
     """The piece arithmetic of the scorer at its edges (the round-3 ruling's condition ii).  Stated input domain:
     finite f32 operands whose products and sums stay inside the f32 normal range -- what an f32 FMA chain needs as
