@@ -266,8 +266,9 @@ size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 // ------------------------------------------------------------------------------------------------------------
 // k_bt_bx6: C[M, 32 nb .. + 32) = beta C + A[M, K] . Bt[n, K]^T, six terms, for a SMALL second operand held
 // k-contiguous (Bt [N][K]): the LSTM's dx = dz . W_x^T with Bt = W_x itself, the first din rows of the cell's
-// weight matrix as they lie.  Workgroup = 128 rows of A x 32 columns; the 32 rows of Bt become bf16 planes in LDS in
-// the prologue (48 KB at K = 256).  A streams in units of 32 rows x 64 k per wave: COALESCED loads (16 lanes x 16 B
+// weight matrix as they lie.  Workgroup = 128 rows of A x 64 columns (A is read ONCE: with one 32-column block per
+// workgroup every block streamed dz from HBM again, 24 us); Bt follows A unit by unit (64 k: 24 KB of planes made by
+// the workgroup, double buffered, one barrier per unit).  A streams in units of 32 rows x 64 k per wave: COALESCED loads (16 lanes x 16 B
 // = a row's 256-byte segment; eight loads per unit stay in flight in registers), a private LDS image per wave
 // (written and read by the same wave: no barrier in the loop), read back in operand layout (lane = row, k = 16 c +
 // 8 kg ..), split on the fly, six MFMAs per 16-chunk.  A first form loaded the operand layout directly -- every lane
@@ -285,61 +286,57 @@ __device__ __forceinline__ void bx_split3x2(float x, float y, uint32_t& p1, uint
 }
 
 typedef float bx_f4 __attribute__((ext_vector_type(4)));
-template <int K>
-__global__ __launch_bounds__(256) void k_bt_bx6(int64_t M, const float* __restrict__ A, int64_t lda,
+template <int K, int NBW>
+__global__ __launch_bounds__(256) void k_bt_bx6(int64_t M, int N, const float* __restrict__ A, int64_t lda,
                                                 const float* __restrict__ Bt, int64_t ldb, float beta,
                                                 float* __restrict__ C, int64_t ldc) {
   constexpr int NU = K / 64;                       // units of 64 k
-  constexpr int CPR = K / 8;                       // 16-byte bf16 chunks per plane row
-  constexpr int SWM = (CPR < 16 ? CPR : 16) - 1;
-  constexpr int ROWB = K * 2;
+  constexpr int BUF = 3 * NBW * 32 * 128;          // one unit of Bt as planes: [3][NBW * 32 rows][64 k bf16 = 128 B]
   extern __shared__ __attribute__((aligned(16))) uint16_t lds_raw[];
-  char* lds = reinterpret_cast<char*>(lds_raw);                     // planes [3][32][ROWB], staging [4 waves][32][256 B]
+  char* lds = reinterpret_cast<char*>(lds_raw);    // Bt units [2][BUF], staging [4 waves][32][256 B]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 31, kg = lane >> 5;
-  // workgroup -> (row block mb, column block nb): the column blocks of a row block sit 8 apart = on one XCD, whose L2
-  // serves the later readers of the same rows of A
-  int64_t mb;
-  int nb;
-  {
-    const int nnb = (int)gridDim.y;
-    const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x, total = (int64_t)gridDim.x * nnb;
-    const int64_t grp = (int64_t)8 * nnb, full = total / grp * grp;
-    if (bid < full) {
-      mb = bid / grp * 8 + bid % 8;
-      nb = (int)(bid % grp / 8);
-    } else {
-      mb = full / nnb + (bid - full) / nnb;
-      nb = (int)((bid - full) % nnb);
-    }
-  }
-  const int64_t row0 = mb * 128 + wv * 32;
-  // loads of a unit: instruction i takes rows 4 i + lane / 16, the lane's 16 bytes of the row's 256-byte segment
-  const int lrow = lane >> 4, lch = lane & 15;
+  const int n0 = blockIdx.y * (NBW * 32);
+  const int64_t row0 = (int64_t)blockIdx.x * 128 + wv * 32;
+  // loads of a unit of A: instruction i takes rows 4 i + lane / 16, the lane's 16 bytes of the row's 256-byte segment
   // (rows past M read row M - 1: their results are not stored)
+  const int lrow = lane >> 4, lch = lane & 15;
 #define BT_APTR(i_, u_)                                                                                  \
   reinterpret_cast<const bx_f4*>(A + ((row0 + 4 * (i_) + lrow) < M ? (row0 + 4 * (i_) + lrow) : M - 1) * lda + 4 * lch + 64 * (u_))
   bx_f4 ra[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) ra[i] = *BT_APTR(i, 0);
-  for (int q = tid; q < 32 * CPR; q += 256) {
-    const int r = q / CPR, ch = q % CPR;
-    const float* bp = Bt + (int64_t)(32 * nb + r) * ldb + 8 * ch;
-    const float4 v0 = *reinterpret_cast<const float4*>(bp), v1 = *reinterpret_cast<const float4*>(bp + 4);
-    uint32_t p1[4], p2[4], p3[4];
-    bx_split3x2(v0.x, v0.y, p1[0], p2[0], p3[0]);
-    bx_split3x2(v0.z, v0.w, p1[1], p2[1], p3[1]);
-    bx_split3x2(v1.x, v1.y, p1[2], p2[2], p3[2]);
-    bx_split3x2(v1.z, v1.w, p1[3], p2[3], p3[3]);
-    char* dst = lds + r * ROWB + ((ch ^ (r & SWM)) * 16);
-    *reinterpret_cast<uint4*>(dst) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
-    *reinterpret_cast<uint4*>(dst + 32 * ROWB) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
-    *reinterpret_cast<uint4*>(dst + 64 * ROWB) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+  // a unit of Bt: NBW * 32 rows x 8 chunks of 8 k, NBW chunks per thread (rows past N read row N - 1)
+  bx_f4 rb[NBW][2];
+#define BT_BLOAD(u_)                                                                                     \
+  _Pragma("unroll") for (int j = 0; j < NBW; ++j) {                                                      \
+    const int q = tid + 256 * j, r = q >> 3, ch = q & 7;                                                 \
+    const float* bp = Bt + (int64_t)(n0 + r < N ? n0 + r : N - 1) * ldb + 64 * (u_) + 8 * ch;           \
+    rb[j][0] = *reinterpret_cast<const bx_f4*>(bp);                                                      \
+    rb[j][1] = *reinterpret_cast<const bx_f4*>(bp + 4);                                                  \
   }
+#define BT_BSTORE(buf_)                                                                                  \
+  _Pragma("unroll") for (int j = 0; j < NBW; ++j) {                                                      \
+    const int q = tid + 256 * j, r = q >> 3, ch = q & 7;                                                 \
+    uint32_t p1[4], p2[4], p3[4];                                                                        \
+    bx_split3x2(rb[j][0].x, rb[j][0].y, p1[0], p2[0], p3[0]);                                            \
+    bx_split3x2(rb[j][0].z, rb[j][0].w, p1[1], p2[1], p3[1]);                                            \
+    bx_split3x2(rb[j][1].x, rb[j][1].y, p1[2], p2[2], p3[2]);                                            \
+    bx_split3x2(rb[j][1].z, rb[j][1].w, p1[3], p2[3], p3[3]);                                            \
+    char* dst = lds + (buf_) * BUF + r * 128 + ((ch ^ ((r >> 1) & 7)) * 16);                             \
+    *reinterpret_cast<uint4*>(dst) = make_uint4(p1[0], p1[1], p1[2], p1[3]);                             \
+    *reinterpret_cast<uint4*>(dst + NBW * 32 * 128) = make_uint4(p2[0], p2[1], p2[2], p2[3]);            \
+    *reinterpret_cast<uint4*>(dst + 2 * NBW * 32 * 128) = make_uint4(p3[0], p3[1], p3[2], p3[3]);        \
+  }
+  BT_BLOAD(0)
+  BT_BSTORE(0)
   __syncthreads();
-  char* stg = lds + 3 * 32 * ROWB + wv * (32 * 256);
-  f32x16 hi = {0}, lo = {0};
-  const char* frow = lds + lr * ROWB;
+  char* stg = lds + 2 * BUF + wv * (32 * 256);
+  f32x16 hi[NBW], lo[NBW];
+#pragma unroll
+  for (int b = 0; b < NBW; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { hi[b][e] = 0.f; lo[b][e] = 0.f; }
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     // registers -> the wave's image, 16-byte chunk q of row r at position q ^ (r & 15) (conflict-free operand reads)
@@ -351,7 +348,9 @@ __global__ __launch_bounds__(256) void k_bt_bx6(int64_t M, const float* __restri
     if (u + 1 < NU) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) ra[i] = *BT_APTR(i, u + 1);
+      BT_BLOAD(u + 1)
     }
+    const char* bt = lds + (u & 1) * BUF + lr * 128;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int q0 = 4 * c + 2 * kg;
@@ -365,32 +364,47 @@ __global__ __launch_bounds__(256) void k_bt_bx6(int64_t M, const float* __restri
       const bf16x8 a1 = __builtin_bit_cast(bf16x8, make_uint4(p1[0], p1[1], p1[2], p1[3]));
       const bf16x8 a2 = __builtin_bit_cast(bf16x8, make_uint4(p2[0], p2[1], p2[2], p2[3]));
       const bf16x8 a3 = __builtin_bit_cast(bf16x8, make_uint4(p3[0], p3[1], p3[2], p3[3]));
-      const int pos = ((2 * (4 * u + c) + kg) ^ (lr & SWM)) * 16;
-      const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(frow + pos));
-      const bf16x8 b2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(frow + pos + 32 * ROWB));
-      const bf16x8 b3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(frow + pos + 64 * ROWB));
-      // D[n][row]: first operand = the Bt tile (n = lane % 32), second = the rows of A
-      lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, a1, lo, 0, 0, 0);
-      hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, hi, 0, 0, 0);
-      lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a3, lo, 0, 0, 0);
-      lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a2, lo, 0, 0, 0);
-      lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a1, lo, 0, 0, 0);
-      lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a2, lo, 0, 0, 0);
+      const int pos = ((2 * c + kg) ^ ((lr >> 1) & 7)) * 16;
+#pragma unroll
+      for (int b = 0; b < NBW; ++b) {
+        const char* fp = bt + b * (32 * 128) + pos;
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fp));
+        const bf16x8 b2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fp + NBW * 32 * 128));
+        const bf16x8 b3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fp + 2 * NBW * 32 * 128));
+        // D[n][row]: first operand = the Bt tile (n = lane % 32), second = the rows of A
+        lo[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, a1, lo[b], 0, 0, 0);
+        hi[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, hi[b], 0, 0, 0);
+        lo[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a3, lo[b], 0, 0, 0);
+        lo[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a2, lo[b], 0, 0, 0);
+        lo[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a1, lo[b], 0, 0, 0);
+        lo[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a2, lo[b], 0, 0, 0);
+      }
+    }
+    if (u + 1 < NU) {
+      BT_BSTORE((u + 1) & 1)                        // (read last in unit u - 1: every wave is past that barrier)
+      __syncthreads();
     }
   }
+#undef BT_APTR
+#undef BT_BLOAD
+#undef BT_BSTORE
   const int64_t row = row0 + lr;
   if (row >= M) return;
-  float* crow = C + row * ldc + 32 * nb + 4 * kg;     // the lane's values 4 g + e are columns 8 g + 4 kg + e
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    float4* cp4 = reinterpret_cast<float4*>(crow + 8 * g);
-    float4 o = make_float4(hi[4 * g] + lo[4 * g], hi[4 * g + 1] + lo[4 * g + 1], hi[4 * g + 2] + lo[4 * g + 2],
-                           hi[4 * g + 3] + lo[4 * g + 3]);
-    if (beta != 0.f) {
-      const float4 old = *cp4;
-      o.x += beta * old.x; o.y += beta * old.y; o.z += beta * old.z; o.w += beta * old.w;
+  for (int b = 0; b < NBW; ++b) {
+    if (n0 + 32 * b >= N) break;
+    float* crow = C + row * ldc + n0 + 32 * b + 4 * kg;   // the lane's values 4 g + e are columns 8 g + 4 kg + e
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4* cp4 = reinterpret_cast<float4*>(crow + 8 * g);
+      float4 o = make_float4(hi[b][4 * g] + lo[b][4 * g], hi[b][4 * g + 1] + lo[b][4 * g + 1],
+                             hi[b][4 * g + 2] + lo[b][4 * g + 2], hi[b][4 * g + 3] + lo[b][4 * g + 3]);
+      if (beta != 0.f) {
+        const float4 old = *cp4;
+        o.x += beta * old.x; o.y += beta * old.y; o.z += beta * old.z; o.w += beta * old.w;
+      }
+      *cp4 = o;
     }
-    *cp4 = o;
   }
 }
 
@@ -466,17 +480,28 @@ int arx_gemm_bt_bx6(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
   ARX_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && lda >= K && ldb >= K && ldc >= N &&
                     ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bt) | reinterpret_cast<uintptr_t>(C)) & 15) == 0,
                 "arx_gemm_bt_bx6: rows must be 16-byte aligned");
-  const dim3 grid((unsigned)ceil_div(M, 128), (unsigned)(N / 32));
-  const size_t lds = (size_t)3 * 32 * K * 2 + (size_t)4 * 32 * 256;
   hipStream_t s = as_stream(stream);
   static bool raised = false;
   if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_bx6<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_bx6<256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_bx6<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_bx6<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     raised = true;
   }
-  if (K == 256) k_bt_bx6<256><<<grid, 256, lds, s>>>(M, A, lda, Bt, ldb, beta, C, ldc);
-  else if (K == 128) k_bt_bx6<128><<<grid, 256, lds, s>>>(M, A, lda, Bt, ldb, beta, C, ldc);
-  else k_bt_bx6<64><<<grid, 256, lds, s>>>(M, A, lda, Bt, ldb, beta, C, ldc);
+  const int nbw = N > 32 ? 2 : 1;
+  const dim3 grid((unsigned)ceil_div(M, 128), (unsigned)ceil_div(N, 32 * nbw));
+  const size_t lds = (size_t)2 * 3 * nbw * 32 * 128 + (size_t)4 * 32 * 256;
+#define BT_LAUNCH(K_, W_) k_bt_bx6<K_, W_><<<grid, 256, lds, s>>>(M, (int)N, A, lda, Bt, ldb, beta, C, ldc)
+  if (nbw == 2) {
+    if (K == 256) BT_LAUNCH(256, 2);
+    else if (K == 128) BT_LAUNCH(128, 2);
+    else BT_LAUNCH(64, 2);
+  } else {
+    if (K == 256) BT_LAUNCH(256, 1);
+    else if (K == 128) BT_LAUNCH(128, 1);
+    else BT_LAUNCH(64, 1);
+  }
+#undef BT_LAUNCH
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
