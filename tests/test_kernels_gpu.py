@@ -1643,7 +1643,8 @@ def test_gemm_bt_bx6(dev, M, N, K, beta):
     W = rng.standard_normal((N + 5, K + 8)).astype(np.float32)          # Bt = rows [0, N), columns [0, K) of it
     C0 = rng.standard_normal((M, N)).astype(np.float32)
     tA, tW, tC = _t(dev, A), _t(dev, W), _t(dev, C0)
-    assert ops.gemm_bt_bx6_supported(M, N, K)
+    from arx import _lib
+    assert _lib.lib.arx_gemm_bt_bx6_supported(M, N, K)      # (ops.gemm_bt_bx6_supported also reads ARX_SCORER_F32)
     ops.gemm_bt_bx6(tA, tW[:N, :K], tC, beta=beta)
     Bt = W[:N, :K].astype(np.float64)
     ref = beta * C0 + A.astype(np.float64) @ Bt.T

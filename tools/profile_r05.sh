@@ -34,6 +34,7 @@ f=$(find /tmp/tr_c4mce -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && pyth
 python $REPO/tools/mcebench.py 51200 1024 1024 2>&1 | grep -v amdgpu.ids > $OUT/r05_mcebench_c4.txt
 python $REPO/tools/mcebench.py 16384 1024 2>&1 | grep -v amdgpu.ids > $OUT/r05_mcebench_b16384.txt
 python $REPO/tools/mce_ab_steps.py 2>&1 | grep "^step" > $OUT/r05_mce_ab_steps.txt
+python $REPO/tools/dxbench.py 2>&1 | grep -v amdgpu.ids > $OUT/r05_dxbench.txt
 # K7 of the C3 / C2 step alone (phase split)
 rm -rf /tmp/k7g
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k7g -o ks -- python $REPO/tools/k7grp_bench.py 16384 65536 > $OUT/r05_k7grp_bench.txt 2>/dev/null
