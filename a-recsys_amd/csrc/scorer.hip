@@ -1954,11 +1954,12 @@ int mc_raise_lds() {
   return ARX_OK;
 }
 
-// slices of the dI role: time steps for the sequence model, else enough of them for four workgroups per CU
+// slices of the dI role: time steps for the sequence model, else enough of them for two workgroups per CU (four: 128-row
+// slices of four tiles, 46 us at B = 16 384; two: 41; one: 42)
 int64_t mc_di_slice(const McLayout& L, int64_t S, int64_t step_rows) {
   if (step_rows > 0) return step_rows;
   const int64_t wg = S / 128;
-  const int64_t nsl0 = ceil_div((int64_t)4 * cu_count(), wg);
+  const int64_t nsl0 = ceil_div((int64_t)2 * cu_count(), wg);
   return ceil_div(ceil_div(L.Bp, nsl0), 128) * 128;
 }
 
