@@ -51,7 +51,7 @@ def main():
         sc.fwd(U, P, pb, T, tb, users, ptr, items, i2s, bl, ts, dts, dU, dT, 1.0 / B, mask_rows=mrows, phases=ph)
     fwd(7)
     print("B=%d S=%d d=%d  (2BSd = %.2f GFLOP f32-equivalent; a flow launch = 12 bf16 terms of it)" % (B, S, d, fl / 1e9))
-    for name, ph in (("zero+prep+mask", 1), ("flow dU", 2), ("rows", 4), ("fwd (all)", 7)):
+    for name, ph in (("prep (+ masks)", 1), ("flow dU", 2), ("rows", 4), ("fwd (all)", 7)):
         t = t_us(lambda: fwd(ph))
         extra = "  %.0f TF bf16 = %.2f of 2500" % (12 * fl / t / 1e6, 12 * fl / t / 1e6 / 2500) if ph == 2 else ""
         print("  %-18s %7.1f us%s" % (name, t, extra))
