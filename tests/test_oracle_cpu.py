@@ -319,6 +319,27 @@ def test_library_exports_every_symbol_of_arx_h():
     assert _lib.lib.arx_version() >= 100
 
 
+def test_scorer_family_shape_predicates_and_state_sizes():
+    """Host logic of the fused scorer families (no compute, no GPU): which shapes they take and what state they ask
+    of the caller -- arx_mw_scorer_* (d in {64, 128}), arx_mce_scorer_* (d == 64), arx_gemm_bt_bx6 (the LSTM's dx)."""
+    from arx import _lib
+    L = _lib.lib
+    assert L.arx_mw_scorer_supported(16384, 1024, 128) and L.arx_mw_scorer_supported(51200, 1024, 64)
+    assert not L.arx_mw_scorer_supported(64, 1000, 128) and not L.arx_mw_scorer_supported(64, 1024, 32)
+    assert L.arx_mce_scorer_supported(51200, 1024, 64) and L.arx_mce_scorer_supported(1, 128, 64)
+    for B, S, d in ((64, 1024, 128), (64, 1000, 64), (64, 4096, 64), (0, 1024, 64)):
+        assert not L.arx_mce_scorer_supported(B, S, d)
+        assert L.arx_mce_scorer_state_bytes(B, S, d) == 0
+    # the state holds the O partials ([splits][Bp][64] f32) and four plane sets but NOTHING of size B x S x 4
+    n = L.arx_mce_scorer_state_bytes(51200, 1024, 64)
+    assert 0 < n < 51200 * 1024 * 4 // 2 and n % 256 == 0
+    assert L.arx_mce_scorer_state_bytes(51201, 1024, 64) >= n
+    ws = L.arx_mce_scorer_bwd_di_workspace_bytes(51200, 1024, 64, 1024)
+    assert ws >= 50 * 1024 * 64 * 4 + 50 * 1024 * 4               # per-step partial products + bias partials
+    assert L.arx_gemm_bt_bx6_supported(51200, 64, 256) and L.arx_gemm_bt_bx6_supported(7, 128, 64)
+    assert not L.arx_gemm_bt_bx6_supported(100, 160, 256) and not L.arx_gemm_bt_bx6_supported(100, 64, 192)
+
+
 def test_product_path_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
