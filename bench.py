@@ -363,12 +363,16 @@ def k1_past_llc(dev, d=128, bags=65536, L=20, V=4194304):
         k[0] += 1
     t = _evt_time_ms(launch, 30)
     by = bags * L * (4 * d + 4) + bags * (4 * d + 8)
+    # HBM bytes by the PMC counters (FETCH_SIZE x2 + WRITE_SIZE) of the builder's own rocprofv3 --pmc passes over
+    # tools/k1_physical.py (the same launch), per launch
+    pmc, src = _load_pmc("k1_past_llc")
+    tr = ((pmc or {}).get("gather_mulhot") or {}).get("traffic_bytes")
     return {"kernel": "k_gather_mulhot (K1), %d bags x %d tokens over a %d-row table (%.0f MB = %.0fx the 256 MB "
                       "LLC); tokens of a launch = a permutation slice (no repeated row), %d disjoint slices "
                       "rotated between launches" % (bags, L, V, V * d * 4 / 1e6, V * d * 4 / (256 << 20), n_sets),
             "bound": "hbm", "achieved": by / t / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": by / t / 1e6 / HBM_PEAK_GBS, "bytes_per_launch": by, "distinct_bytes_per_launch": by,
-            "ms_per_launch": t, "traffic": None}
+            "ms_per_launch": t, "traffic": tr, "traffic_source": src}
 
 
 def cpu_baseline(args, syn, label):
@@ -532,6 +536,13 @@ def run_hmf(args, name, steps, warmup, with_cpu=False):
                                          "f32-input MFMA peak"),
                            "traffic": ((pmc or {}).get(dom) or {}).get("traffic_bytes"),
                            "flops_per_launch": kr[dom]['flops'], "ms_per_launch": kr[dom]['ms']}
+        ns, src = _instep_ns("%s_b%d" % (name, B), "k_sc_hinge" if "hinge" in dom else "\0")
+        if ns:
+            # the duration the kernel has INSIDE the step (rocprofv3 --kernel-trace --stats of this very command,
+            # builder's committed summary): what the step pays, quoted next to the stand-alone HIP-event figure
+            out["roofline"]["ms_in_step_rocprof"] = ns / 1e6
+            out["roofline"]["frac_in_step"] = kr[dom]['flops'] / (ns / 1e9) / 1e12 / peak
+            out["roofline"]["in_step_source"] = src
         k7 = kr['k7_step_fused']
         out["roofline_hbm"] = {
             "kernel": "K7 scatter + sparse Adagrad, the step's fused passes over ALL tables (%s): sorts + run "
@@ -554,16 +565,15 @@ def run_hmf(args, name, steps, warmup, with_cpu=False):
                    "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS, "bytes_per_launch": kr[g]['bytes'],
                    "ms_per_launch": kr[g]['ms'], "traffic": tr, "table_bytes": kr[g]['table_bytes']}
             if alg_gbs > HBM_PEAK_GBS or kr[g]['table_bytes'] < (256 << 20):
-                # the table sits in L2 / the 256 MB Infinity Cache (Zipf-hot rows): algorithmic
-                # bytes over time is a cache figure, not an HBM fraction -- the HBM-side figure is
-                # the PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, profiles/) over the same time
-                ent["note"] = ("table is LLC-resident: 'achieved' is algorithmic bytes/time (cache-served); "
-                               "frac is taken from the PMC traffic when present")
-                if tr:
-                    ent["achieved_counter"] = tr / kr[g]['ms'] / 1e6
-                    ent["frac"] = ent["achieved_counter"] / HBM_PEAK_GBS
-                else:
-                    ent["frac"] = None
+                # the table sits in L2 / the 256 MB Infinity Cache (Zipf-hot rows): algorithmic bytes over time is a
+                # cache figure, not an HBM rate, and is NOT reported as `achieved` (round-5 verdict, weak #10): the
+                # HBM-side figure is the PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, profiles/) over the same time; the
+                # gather's headline is the physical past-LLC K1 measurement (sub `k1`, promoted in main())
+                ent["note"] = ("table is LLC-resident: algorithmic bytes/time would be a cache-served rate and is "
+                               "not reported; achieved/frac are PMC traffic over time when a profile is present")
+                ent["algorithmic_bytes_over_time_cache_served"] = alg_gbs
+                ent["achieved"] = (tr / kr[g]['ms'] / 1e6) if tr else None
+                ent["frac"] = (ent["achieved"] / HBM_PEAK_GBS) if tr else None
             out["roofline_gather"] = ent
         if pmc_src:
             # the `traffic` fields are NOT measured by this run: they are read from the committed PMC summary of
@@ -723,7 +733,7 @@ def run_f32mfma(args, workload):
     f32-input MFMA kernels (logits GEMM, wave-per-row loss kernel over [B, S] logits, two f32 backward GEMMs) --
     the default path of rounds 1-3.  The switch is read once per process: a child process runs the workload."""
     import subprocess
-    env = dict(os.environ, ARX_SCORER_F32="1")
+    env = dict(os.environ, ARX_SCORER_F32="1", ARX_BENCH_CHILD="1")
     sharded = workload == "c5w1"            # the world-1 sharded step: a sub-result of a (short) child run
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "c2" if sharded else workload,
            "--subs", "c5w1" if sharded else "", "--no-rooflines",
@@ -733,8 +743,7 @@ def run_f32mfma(args, workload):
     if args.n_items:
         cmd += ["--n-items", str(args.n_items)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
-    line = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")][-1]
-    j = json.loads(line)
+    j = _child_detail(r.stdout)
     if sharded:
         j = j["sub"]["c5w1"]
         j.setdefault("steps", args.sub_steps)
@@ -779,6 +788,7 @@ def scaling_anchor(args):
                         "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE",
                         "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE",
                         "TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCHELASTIC_ERROR_FILE")}
+    env["ARX_BENCH_CHILD"] = "1"
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", "c5", "--subs", "",
            "--no-rooflines", "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--batch", str(args.batch), "--n-sampled", str(args.n_sampled), "--dim", str(args.dim),
@@ -792,12 +802,114 @@ def scaling_anchor(args):
     else:
         cmd += ["--cpu-seconds", str(args.cpu_seconds)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900)
-    line = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")][-1]
-    j = json.loads(line)
+    j = _child_detail(r.stdout)
     return {"value": j["value"], "unit": j["unit"], "n_gpus": 1, "ms_per_step": j["ms_per_step"],
             "steps": j["steps"], "warmup": j["warmup"], "cpu_baseline": j.get("cpu_baseline"),
             "what": "the same sharded step (arx.dist), table and per-GPU batch on ONE rank -- `python bench.py --gpus 1 "
                     "--workload c5` -- run by rank 0 after the N-rank job; efficiency = value / (N * anchor value)"}
+
+
+LINE_LIMIT = 8000            # the driver keeps an 8 KB tail of stdout: the final line must fit in it whole
+DETAIL_FILE = "bench_detail.json"
+
+
+def _short(s, n=200):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _instep_ns(tag_part, needle):
+    """Average in-step duration (ns) of the kernel whose name holds `needle`, from the newest committed
+    rocprofv3 --kernel-trace --stats summary of this workload (profiles/rNN_<tag>_kernel_stats.csv)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_kernel_stats.csv" % tag_part)))
+    if not files:
+        return None, None
+    try:
+        for row in csv.DictReader(open(files[-1])):
+            if needle in row["Name"]:
+                return float(row["AverageNs"]), "profiles/" + os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None, None
+
+
+def _child_detail(stdout):
+    """The full result of a child bench process: its BENCH_DETAIL line (the final '{' line is the compact one)."""
+    lines = stdout.decode(errors="replace").splitlines()
+    det = [l for l in lines if l.startswith("BENCH_DETAIL ")]
+    if det:
+        return json.loads(det[-1][len("BENCH_DETAIL "):])
+    return json.loads([l for l in lines if l.startswith("{")][-1])
+
+
+def compact_line(out):
+    """The FINAL stdout line: every field of the bench contract + `roofline` of the step's DOMINANT pass (by time)
+    + `cpu_baseline`, small enough for the driver's 8 KB tail (round-5 verdict: a 20 KB line left the driver's record
+    unparsed).  Everything else (sub-results, per-kernel table, long workload prose) goes to bench_detail.json and
+    to an EARLIER stdout line."""
+    c = out.get("config", {})
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                       "scaling", "dtype", "data", "value_per_gpu", "scaling_efficiency_vs_anchor"))
+    line["vs_baseline"] = out.get("vs_baseline")
+    line["dtype_detail"] = _short(out.get("dtype_detail", ""), 220)
+    line["config"] = _pick(c, ("batch", "n_sampled", "dim", "n_items", "n_users", "hipgraph", "pool_redraws_timed",
+                               "hip_event_ms_per_step", "ms_per_step_min", "ms_per_step_max", "timed_regions",
+                               "sampled_negative_logits_per_s", "final_loss", "parallelism", "world", "batch_per_gpu",
+                               "global_batch", "exchange", "routing_in_timed_region"))
+    line["config"]["workload"] = _short(c.get("workload", ""), 260)
+    # dominant pass of the step by time: K7 (HBM) / the hinge GEMM (MFMA) / the step's lookups (HBM)
+    cands = [(k, out[k]) for k in ("roofline_hbm", "roofline", "roofline_gather")
+             if isinstance(out.get(k), dict) and out[k].get("ms_per_launch")]
+    if cands:
+        dk, dom = max(cands, key=lambda kv: kv[1]["ms_per_launch"])
+        rf = _pick(dom, ("bound", "achieved", "peak", "unit", "frac", "bytes_per_launch", "flops_per_launch",
+                         "ms_per_launch", "ms_sorts", "ms_apply_finish", "frac_apply_finish_only", "unique_rows",
+                         "contributions", "ms_in_step_rocprof", "frac_in_step", "in_step_source"))
+        rf["traffic"] = dom.get("traffic")
+        rf["kernel"] = _short(dom.get("kernel", ""), 160)
+        if out.get("ms_per_step"):
+            rf["share_of_step"] = dom["ms_per_launch"] / out["ms_per_step"]
+        if out.get("traffic_source"):
+            rf["traffic_source"] = out["traffic_source"]
+        for k, short in (("roofline", "mfma"), ("roofline_hbm", "scatter"), ("roofline_gather", "gather")):
+            if k != dk and isinstance(out.get(k), dict):
+                e = _pick(out[k], ("bound", "achieved", "peak", "unit", "frac", "ms_per_launch", "bytes_per_launch",
+                                   "flops_per_launch", "ms_in_step_rocprof", "frac_in_step", "in_step_source"))
+                e["traffic"] = out[k].get("traffic")
+                e["kernel"] = _short(out[k].get("kernel", ""), 120)
+                rf[short] = e
+        line["roofline"] = rf
+    elif isinstance(out.get("roofline"), dict):
+        line["roofline"] = out["roofline"]
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "ms_per_step", "timed_in"))
+        line["cpu_baseline"]["sample"] = _short(cb.get("sample", ""), 320)
+    sub = out.get("sub")
+    if isinstance(sub, dict):
+        line["sub_ms_per_step"] = {k: (round(v["ms_per_step"], 5) if isinstance(v, dict) and "ms_per_step" in v
+                                       else None) for k, v in sub.items()}
+    if isinstance(out.get("scaling_anchor"), dict):
+        line["scaling_anchor"] = _pick(out["scaling_anchor"], ("value", "unit", "n_gpus", "ms_per_step", "error"))
+    if isinstance(out.get("roofline_comm_predicted"), dict):
+        line["roofline_comm_predicted"] = {k: (_short(v, 120) if isinstance(v, str) else v)
+                                           for k, v in out["roofline_comm_predicted"].items()}
+    line["detail"] = DETAIL_FILE
+    txt = json.dumps(line)
+    if len(txt) >= LINE_LIMIT:         # never let prose take the record down: drop the optional objects first
+        for k in ("roofline_comm_predicted", "sub_ms_per_step", "scaling_anchor", "dtype_detail"):
+            line.pop(k, None)
+            txt = json.dumps(line)
+            if len(txt) < LINE_LIMIT:
+                break
+    assert len(txt) < LINE_LIMIT, "bench line is %d bytes" % len(txt)
+    return txt
 
 
 def _print_line(out):
@@ -809,7 +921,18 @@ def _print_line(out):
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
-    print(json.dumps(out), flush=True)
+    detail = json.dumps(out)
+    for path in (os.path.join(ROOT, DETAIL_FILE), os.path.join(ROOT, "gpurun_out", DETAIL_FILE)):
+        if os.environ.get("ARX_BENCH_CHILD"):
+            break
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    f.write(detail + "\n")
+        except OSError:
+            pass
+    print("BENCH_DETAIL " + detail, flush=True)        # the earlier line: everything; not a '{' line on purpose
+    print(compact_line(out), flush=True)
 
 
 def main_sharded(args, world, rank, local_rank):
@@ -898,8 +1021,13 @@ def main():
                 r = run_lstm(args, 'mce' if s == "c4mce" else 'mw', min(args.sub_steps, 30), 5)
             elif s == "k1":
                 r = k1_past_llc(torch.device('cuda', 0), args.dim)
-                if "roofline_gather" in out:
-                    out["roofline_gather"]["past_llc"] = r
+                # the gather's headline is this PHYSICAL measurement (2 GB table, 8x the LLC); the step's own
+                # LLC-resident lookup launch stays beside it as `in_step`
+                if "error" not in r:
+                    ent = dict(r)
+                    if "roofline_gather" in out:
+                        ent["in_step"] = out["roofline_gather"]
+                    out["roofline_gather"] = ent
             elif s == "c5w1":
                 r = run_sharded_world1(args)
             elif s == "c3repw1":

@@ -19,9 +19,15 @@ def _bench(extra, timeout=900, env_extra=None):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
     assert r.returncode == 0, (r.stdout.decode(errors="replace")[-2000:], r.stderr.decode(errors="replace")[-3000:])
-    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
-    assert len(lines) == 1, lines
-    return json.loads(lines[0])
+    out = r.stdout.decode(errors="replace").splitlines()
+    lines = [l for l in out if l.startswith("{")]
+    assert len(lines) == 1 and out[-1] == lines[0], lines       # ONE JSON line, and it is the LAST line
+    assert len(lines[0]) < 8000                                  # fits the driver's 8 KB tail whole
+    j = json.loads(lines[0])
+    det = [l for l in out if l.startswith("BENCH_DETAIL ")]
+    assert len(det) == 1
+    j["_detail"] = json.loads(det[0][len("BENCH_DETAIL "):])
+    return j
 
 
 def test_bench_gpus2_self_launch_one_line(dev):
@@ -31,7 +37,8 @@ def test_bench_gpus2_self_launch_one_line(dev):
     assert j["scaling"] == "weak" and j["unit"] == "interactions/s" and j["value"] > 0
     assert j["dtype"] == "f32" and "bf16" in j["dtype_detail"]
     assert j["config"]["global_batch"] == 2 * 2048
-    assert set(j["roofline_comm"]) >= {"all_gather_pool_blocks", "all_to_all_target_rows", "all_reduce_pool_grads"}
+    assert j["roofline"]["bound"] == "mfma" and j["roofline"]["frac"] > 0
+    assert set(j["_detail"]["roofline_comm"]) >= {"all_gather_pool_blocks", "all_to_all_target_rows", "all_reduce_pool_grads"}
     a = j["scaling_anchor"]
     assert a["n_gpus"] == 1 and a["value"] > 0
     assert j["value_per_gpu"] == pytest.approx(j["value"] / 2)

@@ -558,3 +558,43 @@ def test_embedding_space_oracle_equals_dense_oracle_lstm(loss, cfg, no_uid):
         _assert_sparse_state(emb, tabs, remb.slots, params, rtol=1e-9)
         np.testing.assert_allclose(emb.W, ref.W, rtol=1e-9, atol=1e-13)
         np.testing.assert_allclose(emb.b, ref.b, rtol=1e-9, atol=1e-13)
+
+
+def test_bench_line_is_compact_and_parses():
+    """The driver keeps an 8 KB tail of bench.py's stdout (round 5: a 20 KB line left BENCH_r05 unparsed).  The final
+    line built from a detail dict with kilobytes of prose and sub-results must stay under the limit, parse, carry the
+    contract's fields and name the DOMINANT pass (by time) as `roofline`."""
+    import json
+    import bench
+    prose = "x" * 3000
+    k7 = {"kernel": "K7 " + prose, "bound": "hbm", "achieved": 800.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1,
+          "bytes_per_launch": 147028324, "ms_per_launch": 0.17, "traffic": 1.8e8, "unique_rows": 5, "contributions": 9}
+    mf = {"kernel": "gemm_logits_hinge", "bound": "mfma", "achieved": 190.0, "peak": 416.7, "unit": "TFLOP/s",
+          "frac": 0.46, "ms_per_launch": 0.022, "flops_per_launch": 4.29e9, "traffic": None, "peak_note": prose}
+    ga = {"kernel": "K1 " + prose, "bound": "hbm", "achieved": 5000.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.63,
+          "ms_per_launch": 0.14, "bytes_per_launch": 7e8, "traffic": 7.2e8, "in_step": {"note": prose}}
+    out = {"metric": bench.METRIC, "value": 7.3e7, "unit": "interactions/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+           "ms_per_step": 0.22, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "dtype_detail": prose, "data": "synthetic",
+           "config": {"workload": "C3 " + prose, "batch": 16384, "n_sampled": 1024, "dim": 128, "setup_s": 3.0},
+           "roofline": mf, "roofline_hbm": k7, "roofline_gather": ga,
+           "kernels": {("k%d" % i): {"ms": 0.01, "note": prose} for i in range(12)},
+           "sub": {("s%d" % i): {"ms_per_step": 0.3, "config": {"workload": prose}} for i in range(10)},
+           "cpu_baseline": {"value": 77.0, "unit": "interactions/s", "cores": 128, "kind": "port", "sample": prose}}
+    assert len(json.dumps(out)) > 40000
+    txt = bench.compact_line(out)
+    assert len(txt) < bench.LINE_LIMIT and "\n" not in txt
+    j = json.loads(txt)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["config"]["workload"].startswith("C3") and j["config"]["batch"] == 16384
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["ms_per_launch"] == 0.17 and r["frac"] == 0.1 and r["traffic"] == 1.8e8
+    assert r["mfma"]["frac"] == 0.46 and r["gather"]["achieved"] <= r["gather"]["peak"]
+    assert j["cpu_baseline"]["cores"] == 128 and j["cpu_baseline"]["kind"] == "port"
+    # a sharded (N > 1) line: one `roofline` only
+    out2 = {k: v for k, v in out.items() if k not in ("roofline_hbm", "roofline_gather")}
+    out2["roofline_comm_predicted"] = {"this_run": {"a": prose}, "at_8_ranks": {"b": prose * 3}}
+    j2 = json.loads(bench.compact_line(out2))
+    assert j2["roofline"]["bound"] == "mfma" and len(json.dumps(j2)) < bench.LINE_LIMIT

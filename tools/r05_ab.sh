@@ -6,7 +6,7 @@ N=${1:-2}; shift || true
 OUT=gpurun_out/r05ab; mkdir -p $OUT
 run() { # tag, env...
   tag=$1; shift
-  env "$@" python bench.py --no-cpu-baseline --subs ${SUBS:-c2,c3mix} --repeats 3 --no-rooflines 2>/dev/null | python -c "
+  env "$@" python bench.py --no-cpu-baseline --subs ${SUBS:-c2,c3mix} --repeats 3 --no-rooflines 2>/dev/null | grep "^BENCH_DETAIL " | cut -c14- | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$tag', 'C3 %.1f us' % (1e3*j['ms_per_step']), ' '.join('%s %.1f us' % (k, 1e3*v['ms_per_step']) for k, v in j['sub'].items() if 'ms_per_step' in v))" | tee -a $OUT/log.txt
