@@ -598,3 +598,109 @@ def test_bench_line_is_compact_and_parses():
     out2["roofline_comm_predicted"] = {"this_run": {"a": prose}, "at_8_ranks": {"b": prose * 3}}
     j2 = json.loads(bench.compact_line(out2))
     assert j2["roofline"]["bound"] == "mfma" and len(json.dumps(j2)) < bench.LINE_LIMIT
+
+
+# ------------------------------------------------------------ 5. third-party witnesses (round-5 verdict, missing #6)
+def test_oracle_lstm_equals_torch_nn_lstmcell():
+    """oracle.ref_lstm (TF-1.0 LSTMCell: gate order i, j, f, o, forget_bias 1.0 added inside the sigmoid;
+    lstm/seqModel.py:99-103) against a THIRD-PARTY cell, torch.nn.LSTMCell (gate order i, f, g, o, no forget bias):
+    TF's columns permuted into torch's row blocks and forget_bias folded into the f bias must give the same
+    hidden states, cell states and BPTT gradients in fp64."""
+    rng = np.random.default_rng(7)
+    L, B, din, h = 6, 5, 7, 9
+    x = rng.standard_normal((L, B, din))
+    W = rng.standard_normal((din + h, 4 * h)) * 0.3
+    b = rng.standard_normal(4 * h) * 0.1
+    dhs = rng.standard_normal((L, B, h))
+    fb = 1.0
+    hs, cs, gates = ref_lstm.lstm_fwd(x, W, b, fb)
+    dz, dx, dW, db = ref_lstm.lstm_bwd(x, W, hs, cs, gates, dhs)
+    cell = torch.nn.LSTMCell(din, h, bias=True).double()
+    blk = lambda M, g: M[..., g * h:(g + 1) * h]
+    tf2torch = (0, 2, 1, 3)            # torch block order (i, f, g, o) <- TF column blocks (i, j, f, o)
+    with torch.no_grad():
+        cell.weight_ih.copy_(torch.tensor(np.concatenate([blk(W[:din], g).T for g in tf2torch], 0)))
+        cell.weight_hh.copy_(torch.tensor(np.concatenate([blk(W[din:], g).T for g in tf2torch], 0)))
+        bt = np.concatenate([blk(b, g) for g in tf2torch]).copy()
+        bt[h:2 * h] += fb
+        cell.bias_ih.copy_(torch.tensor(bt))
+        cell.bias_hh.zero_()
+    tx = torch.tensor(x, requires_grad=True)
+    hp = torch.zeros(B, h, dtype=torch.float64)
+    cp = torch.zeros(B, h, dtype=torch.float64)
+    Hs, Cs = [], []
+    for t in range(L):
+        hp, cp = cell(tx[t], (hp, cp))
+        Hs.append(hp)
+        Cs.append(cp)
+    H = torch.stack(Hs)
+    np.testing.assert_allclose(H.detach().numpy(), hs, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(torch.stack(Cs).detach().numpy(), cs, rtol=1e-12, atol=1e-14)
+    (H * torch.tensor(dhs)).sum().backward()
+    np.testing.assert_allclose(tx.grad.numpy(), dx, rtol=1e-10, atol=1e-13)
+    gWi, gWh = cell.weight_ih.grad.numpy(), cell.weight_hh.grad.numpy()
+    gb = cell.bias_ih.grad.numpy()
+    for k, g in enumerate(tf2torch):   # torch block k holds TF block g
+        np.testing.assert_allclose(gWi[k * h:(k + 1) * h].T, blk(dW[:din], g), rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(gWh[k * h:(k + 1) * h].T, blk(dW[din:], g), rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(gb[k * h:(k + 1) * h], blk(db, g), rtol=1e-10, atol=1e-13)
+
+
+def test_oracle_adagrad_equals_torch_optim_adagrad_dense_and_sparse_duplicates():
+    """oracle.ref_graph.adagrad_apply / RefEmbeddingAttribute.apply_gradients (tf.train.AdagradOptimizer,
+    hmf/hmf_model.py:147: accumulators start at 0.1, no epsilon, duplicate IndexedSlices rows summed BEFORE the
+    single application) against torch.optim.Adagrad(initial_accumulator_value=0.1, eps=0): dense gradients over
+    three steps, and sparse gradients with duplicate indices (torch coalesces an uncoalesced sparse gradient,
+    i.e. sums duplicates first -- the same rule)."""
+    rng = np.random.default_rng(11)
+    V, d, lr = 13, 4, 0.7
+    p0 = rng.standard_normal((V, d))
+    # dense
+    p, acc = p0.copy(), np.full((V, d), 0.1)
+    tp = torch.nn.Parameter(torch.tensor(p0.copy()))
+    opt = torch.optim.Adagrad([tp], lr=lr, initial_accumulator_value=0.1, eps=0.0)
+    for _ in range(3):
+        g = rng.standard_normal((V, d))
+        rg.adagrad_apply(p, acc, g, lr)
+        tp.grad = torch.tensor(g)
+        opt.step()
+        np.testing.assert_allclose(p, tp.detach().numpy(), rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(acc, opt.state[tp]['sum'].numpy(), rtol=1e-13)
+    # sparse with duplicates, through the oracle's own optimiser entry (two lookup sites of one table)
+    class _Holder(rg.RefEmbeddingAttribute):
+        def __init__(self, params):          # only what apply_gradients touches
+            self.params = params
+            self.slots = {k: np.full(v.shape, 0.1) for k, v in params.items()}
+            self.dt = np.dtype(np.float64)
+    hold = _Holder({'E': p0.copy()})
+    tp = torch.nn.Parameter(torch.tensor(p0.copy()))
+    opt = torch.optim.Adagrad([tp], lr=lr, initial_accumulator_value=0.1, eps=0.0)
+    for _ in range(3):
+        i1 = np.array([3, 3, 5, 0, 3]); v1 = rng.standard_normal((5, d))
+        i2 = np.array([5, 12, 0]); v2 = rng.standard_normal((3, d))
+        grads = rg.Grads()
+        grads.add_sparse('E', i1, v1)
+        grads.add_sparse('E', i2, v2)
+        hold.apply_gradients(grads, lr)
+        idx = torch.tensor(np.concatenate([i1, i2]))[None]
+        tp.grad = torch.sparse_coo_tensor(idx, torch.tensor(np.concatenate([v1, v2], 0)), (V, d))
+        assert not tp.grad.is_coalesced()
+        opt.step()
+        np.testing.assert_allclose(hold.params['E'], tp.detach().numpy(), rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(hold.slots['E'], opt.state[tp]['sum'].numpy(), rtol=1e-13)
+    # untouched rows: exactly unchanged (a dense Adagrad over the summed gradient would also leave them)
+    untouched = np.setdiff1d(np.arange(V), [0, 3, 5, 12])
+    assert np.array_equal(hold.params['E'][untouched], p0[untouched])
+
+
+def test_tf1_witness_hook():
+    """"auto-upgrade to real TF if importable".  oracle.tf1_witness.available() probes for
+    tensorflow.compat.v1; absent here (and on the GPU box), the hook reports so and nothing else changes.  When
+    present, the real TF-1 graph ops (LSTMCell / AdagradOptimizer / clip_by_global_norm) run as a further witness."""
+    from oracle import tf1_witness
+    if not tf1_witness.available():
+        assert tf1_witness.kind() == "port"
+        pytest.skip("tensorflow not importable: parity stays 'unpinned' (third-party torch witnesses above)")
+    assert tf1_witness.kind() == "tf1"
+    tf1_witness.check_lstm(ref_lstm)
+    tf1_witness.check_adagrad(rg)
