@@ -433,11 +433,11 @@ class ShardedHMF(object):
         if self.use_graphs:
             outer = torch.cuda.current_stream(self.device)
             if outer == self._stream:          # the caller already works on the model's stream (model.stream)
-                self._step_static(route)
+                self._step_guard(route)
                 return
             self._stream.wait_stream(outer)
             with torch.cuda.stream(self._stream):
-                self._step_static(route)
+                self._step_guard(route)
             outer.wait_stream(self._stream)
             return
         be, W, r = self.be, self.world, self.rank
@@ -547,6 +547,15 @@ class ShardedHMF(object):
                     g.set_feeds(None)
             g.launch()
 
+    def _step_guard(self, route):
+        """_step_static; a step that raises leaves no captured graph behind: the next one runs eagerly again (and, for
+        the replicated-token class, from a cleared token-gradient table -- see _step_static)."""
+        try:
+            self._step_static(route)
+        except BaseException:
+            self._graphs, self._graph_key, self._warm_key = {}, None, None
+            raise
+
     def _step_static(self, route):
         """The step of step() with every buffer at a fixed address and a fixed size, so that the
         kernels between two collectives are ONE hipGraph launch each (5 segments + K7's sort half as a
@@ -588,6 +597,14 @@ class ShardedHMF(object):
         else:
             mode, self._graphs, self._graph_key = 'eager', {}, None
         seg = lambda name, fn: self._segment(mode, name, fn)
+        if mode != 'replay' and getattr(self, 'D_tok', None) is not None:
+            # ShardedHMFRepTokens: the dense token-gradient table must be all zero at step entry (the token apply zeroes
+            # the rows it consumes).  A step that died between the gradient pass and that apply would leave sums behind
+            # that the next step counts twice: every step that is NOT a replay (the first eager one, a re-capture,
+            # the step after an exception -- _step_guard below drops the graphs) starts from a cleared table
+            # (advisor, round 5).
+            self.D_tok.zero_()
+            self.Db_tok.zero_()
         arena, arena_b = self.arena, self.arena_b
         urows, rrows = self.g_idx[:B_loc], self.g_idx[B_loc:]
         self.urows = urows
@@ -919,8 +936,11 @@ class ShardedHMFRepTokens(ShardedHMF):
     ranks, and every replica applies the same Adagrad step to the rows of D that are not all zero (rows without gradient
     would not move: the sparse update of embed_attribute.py:383-400 / hmf_model.py:146-151; arx_adagrad_rows_nonzero,
     which also zeroes D for the next step).  Volume per rank and step on top of
-    ShardedHMF: 2 x n_tokens x (d + 1) x 4 B x (N-1)/N through the ring, independent of the batch, issued under the
-    id shard's own K7 pass; the token-striped step moves 2 x B x (d + 4) x 4 B with B the GLOBAL batch
+    ShardedHMF: 2 x n_tokens x (d + 1) x 4 B x (N-1)/N through the ring, independent of the batch.  In the EAGER
+    step the two all-reduces are issued asynchronously under the id shard's own K7 pass; in the hipGraph-segment step
+    (the default) they run on the main stream between the 'apply' and 'tok_apply' segments -- NOT overlapped, and
+    priced so in roofline_comm_predicted (comm_prediction 'rep_tokens').  The token-striped step moves
+    2 x B x (d + 4) x 4 B with B the GLOBAL batch
     (predicted comm / compute 0.35 against 0.57 at N = 8, B_loc = 16384)."""
 
     _static_step_ok = True          # (ShardedHMF.__init__: the hipGraph-segment step serves this class too)
@@ -1198,7 +1218,9 @@ class SeqDataParallel(object):
         its per-link latency at these sizes, not by bytes)."""
         if self.world == 1 or not tensors:
             return
-        if not all(t.is_cuda and t.is_contiguous() and t.element_size() == 4 for t in tensors):
+        if not all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 for t in tensors):
+            # (advisor, round 5: a 4-byte INTEGER tensor packed into the float32 bucket would be summed as float bit
+            # patterns -- the word-copy path is for float32 only)
             # (the gloo / CPU rig of the tests, strided views)
             flat = torch.cat([t.reshape(-1) for t in tensors])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
@@ -1353,7 +1375,7 @@ def draw_global_pool(sampler, S, group=None):
         alli = torch.empty(world * S, dtype=ids.dtype, device=ids.device)
         dist.all_gather_into_tensor(allk, keys.contiguous(), group=group)
         dist.all_gather_into_tensor(alli, ids.contiguous(), group=group)
-        if allk.is_cuda and world * S <= 16384:
+        if allk.is_cuda and world * S <= 16384 and allk.dtype == torch.float32 and alli.dtype == torch.int32:
             # (round 5: one rank-selection launch over the 64-bit (key, position) words instead of torch's sort +
             # index kernels -- SURVEY section 7: no torch arithmetic on the path)
             from . import ops

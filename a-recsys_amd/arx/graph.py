@@ -25,6 +25,9 @@ KEY_NONE = ops.KEY_NONE
 # --------------------------------------------------------------------------
 # parameters
 # --------------------------------------------------------------------------
+_ABL_SKIP_SORT = bool(os.environ.get('ARX_ABL_SKIP_SORT'))
+_ABL_SKIP_APPLY = bool(os.environ.get('ARX_ABL_SKIP_APPLY'))
+
 class Table(object):
     """One attribute embedding table [Vf,d] (+ optional bias [Vf]) with its
     Adagrad accumulators (TF initial_accumulator_value = 0.1)."""
@@ -1294,6 +1297,12 @@ class Plan(object):
                        ws=ops.Workspace(dev))       # own workspace: the sorted arrays live in it
             cache[ck] = ent                         # between the two phases
         args = ent['args']
+        # timing-only ablations (WRONG results; tools/r06_abl.sh): ARX_ABL_SKIP_SORT leaves the ids-only half out once it
+        # ran eagerly (the applies then walk the first batch's lists), ARX_ABL_SKIP_APPLY leaves the apply half out
+        if _ABL_SKIP_SORT and phase in (1, 5, 6) and self.warm >= 1:
+            return
+        if _ABL_SKIP_APPLY and phase in (2, 7, 8) and self.warm >= 1:
+            return
         if phase & 1:
             for x, off in zip(ent['xsites'], args.extra_off):   # multi-hot lookups: padded slots, the sort drops the pads
                 ops.bag_expand_padded(x.maps[0], x.maps[1], x.maps[2], ids_of(x), x.max_len,

@@ -927,7 +927,13 @@ def dropout_fwd_step(x, keep_prob, seed, step_dev, y, keep_mask):
 
 
 def merge_keyed_take(keys, ids, S, out):
-    """out[r] = id of the r-th smallest (key, position) pair, r < S (arx.h): the merge of sorted race lists."""
+    """out[r] = id of the r-th smallest (key, position) pair, r < S (arx.h): the merge of sorted race lists.
+    keys: float32 >= 0 (race keys: the kernel orders their bit patterns), ids / out: int32."""
+    if keys.dtype != torch.float32 or ids.dtype != torch.int32 or out.dtype != torch.int32:
+        raise TypeError("merge_keyed_take: keys float32, ids / out int32 expected (got %s, %s, %s)"
+                        % (keys.dtype, ids.dtype, out.dtype))
+    if ids.shape[0] != keys.shape[0] or out.shape[0] < int(S):
+        raise ValueError("merge_keyed_take: ids must match keys, out must hold S entries")
     call("arx_merge_keyed_take", _p(keys), _p(ids), int(keys.shape[0]), int(S), _p(out), _stream())
 
 

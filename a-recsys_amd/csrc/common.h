@@ -79,6 +79,18 @@ struct CatSites {
   int32_t xtable[kMaxSites];
 };
 
+// Build-defined sampled softmax 'mce' (arx.h): loss_r = log(1 + sum_s m_rs e_rs), backward weight w_rs = g_r e_rs /
+// (1 + s_r), with e_rs = exp(min(x_rs - t_r, kMceSat)).  Below the cap this is the plain sampled softmax; the cap keeps
+// every path finite whatever the logits (e^64 * 65 536 columns < FLT_MAX) -- round-5 advisor: the fused family anchors
+// its exponent at t_r and overflowed at x - t > 88.7, poisoning the tables with NaN.  (NaN inputs stay NaN.)
+constexpr float kEmptySlotBias = -1e30f;     // bias of an EMPTY (-1) pool slot in a lookup's bias output (gather.hip)
+constexpr float kMceSat = 64.f;
+__device__ __forceinline__ float mce_sat(float x, float t) {
+  const float hi = t + kMceSat;
+  return x > hi ? hi : x;
+}
+
+
 // Tables updated by ONE sparse-Adagrad pass.  Several tables of equal width share a sort and
 // an apply launch (the per-table kernel chains are launch-bound: 12 launches of ~5 us per
 // table at B=16384): the sort key carries the table index above the row bits.

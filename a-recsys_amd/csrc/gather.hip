@@ -389,7 +389,7 @@ __global__ void k_shard_route(const int32_t* __restrict__ ids, int64_t n, int wo
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     const int id = ids[i];
-    const bool own = (id % world) == rank;
+    const bool own = id >= 0 && (id % world) == rank;     // (id < 0: an EMPTY slot -- the zero row, no update; advisor r5)
     if (rows_out) rows_out[i] = own ? id / world : zero_row;
     if (keys_out) keys_out[i] = own ? id / world : ARX_KEY_NONE;
   }
@@ -487,10 +487,14 @@ __global__ __launch_bounds__(256) void k_lookup_multi(LookupSites ls, int d) {
     const int id = ids[r];
     if (id < 0) {
       // an EMPTY pool slot: DeviceSampler.sample() leaves id -1 where a (37-sigma rare) short capped draw could not
-      // fill a position.  It looks nothing up -- a zero row, zero bias -- and K7's key builders drop it (site_key),
-      // instead of reading cat_map[-1] / E[-1] (advisor, round 4).  Sub-group-uniform branch.
+      // fill a position.  It looks nothing up -- a zero row -- and K7's key builders drop it (site_key), instead of
+      // reading cat_map[-1] / E[-1] (advisor, round 4).  Round 6 (advisor, round 5): where the lookup has a bias
+      // output the slot's bias is kEmptySlotBias = -1e30, so its logit lies 1e30 below every target score: no hinge
+      // activity, exp() = 0 -- the slot is OUT of the sampled losses ('mw' rank weighting, 'mce' sum) and of their
+      // gradients instead of scoring as a real negative with logit 0.  (Finite on purpose: -inf would read as a
+      // poisoned pool row in k_sc_prep's non-finite check.)  Sub-group-uniform branch.
       if (colok) *reinterpret_cast<float4*>(out + r * ldo + col) = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bias_out && lig == 0) bias_out[r] = 0.f;
+      if (bias_out && lig == 0) bias_out[r] = kEmptySlotBias;
       continue;
     }
     float4 one = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -629,6 +633,7 @@ __global__ __launch_bounds__(256) void k_gather_onehot_multi(GatherSites gs, int
     v[u] = (hit[u] && col < d) ? *reinterpret_cast<const float4*>(E + (int64_t)row[u] * d + col)
                                : make_float4(0.f, 0.f, 0.f, 0.f);
     bv[u] = (hit[u] && bias_out && lig == 0) ? bias[(int64_t)row[u] * ldbi] : 0.f;
+    if (ok[u] && !hit[u] && sc > 0.f) bv[u] = kEmptySlotBias / sc;     // an EMPTY slot is out of the sampled losses (k_lookup_multi)
   }
 #pragma unroll
   for (int u = 0; u < UN; ++u) {

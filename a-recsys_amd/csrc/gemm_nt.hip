@@ -246,7 +246,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
           if (m == 0ull) continue;                                  // (the common case by far)
           const uint32_t mh = lhi ? (uint32_t)(m >> 32) : (uint32_t)m;
           const int rl = rl0 + (e & 3) + 8 * (e >> 2);
-          const int c0 = s_cnt[rl];                                 // (the wave owns its rows: no other writer)
+          // (the wave owns its rows: no other writer.  volatile: lane l31 == 0 stores the new length, the other lanes of
+          // the half read it in the next (j, e) iteration -- a plain access would let the compiler carry a lane's
+          // earlier load across a store that lane did not execute; advisor, round 5)
+          const int c0 = *const_cast<volatile int*>(&s_cnt[rl]);
           const int pos = c0 + __popc(mh & ((1u << l31) - 1u));
           if (pred) {
             if (pos < flt.capp) {
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_areg(
               ovf = true;
             }
           }
-          if (l31 == 0 && mh) s_cnt[rl] = c0 + __popc(mh);
+          if (l31 == 0 && mh) *const_cast<volatile int*>(&s_cnt[rl]) = c0 + __popc(mh);
         }
       }
     } else

@@ -84,8 +84,11 @@ __device__ __forceinline__ void build_pos_bits(uint32_t* bits, int64_t W, const 
 }
 
 // SOFT (build-defined 'mce', sampled softmax; !WARP only): the hinge sum becomes
-//   loss = log(1 + sum_s keep_s * exp(x_s - t)),  dx_s = g * keep_s * exp(x_s - t) / (1 + sum),
-// evaluated around M = max(t, max kept x) for range safety.
+//   loss = log(1 + sum_s keep_s * e_s),  dx_s = g * keep_s * e_s / (1 + sum),  e_s = exp(min(x_s - t, kMceSat)),
+// evaluated around M = max(t, max kept x) for range safety.  The saturation at kMceSat (common.h) is part of the
+// build-defined loss: a pair whose logit leads the target score by more than 64 has a softmax weight of 1 - 1e-28
+// already; capping its exponent keeps the FUSED family (scorer.hip: k_mc_flow anchors at t, no running maximum)
+// finite, and both paths, and the oracle, share ONE definition.
 template <bool WARP, bool POS, bool SOFT = false>
 __global__ __launch_bounds__(256) void k_loss_margin(
     const float* __restrict__ logits, int64_t ldl, const float* __restrict__ tscore,
@@ -108,13 +111,13 @@ __global__ __launch_bounds__(256) void k_loss_margin(
     float mx = t;
     for (int64_t c = threadIdx.x; c < W; c += 256) {
       const bool keep = POS ? !((bits[c >> 5] >> (c & 31)) & 1u) : (m ? (m[c] != 0) : true);
-      if (keep) mx = fmaxf(mx, x[c]);
+      if (keep) mx = fmaxf(mx, mce_sat(x[c], t));
     }
     mx = block_max(mx, sh);
     float se = 0.f;
     for (int64_t c = threadIdx.x; c < W; c += 256) {
       const bool keep = POS ? !((bits[c >> 5] >> (c & 31)) & 1u) : (m ? (m[c] != 0) : true);
-      se += keep ? expf(x[c] - mx) : 0.f;
+      se += keep ? expf(mce_sat(x[c], t) - mx) : 0.f;
     }
     se = block_sum(se, sh);
     const float z = expf(t - mx) + se;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void k_loss_margin(
     float* dxs = dlogits + r * lddl;
     for (int64_t c = threadIdx.x; c < W; c += 256) {
       const bool keep = POS ? !((bits[c >> 5] >> (c & 31)) & 1u) : (m ? (m[c] != 0) : true);
-      dxs[c] = keep ? gz * expf(x[c] - mx) : 0.f;
+      dxs[c] = keep ? gz * expf(mce_sat(x[c], t) - mx) : 0.f;
     }
     if (threadIdx.x == 0 && dtscore) dtscore[r] = -gz * se;
     return;
@@ -244,6 +247,9 @@ __global__ __launch_bounds__(256) void k_loss_margin_wave(
   float dt_soft = 0.f;
   if constexpr (SOFT) {                                  // sampled softmax ('mce'), see k_loss_margin
     float mx = t;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)             // saturation of the build-defined loss (k_loss_margin, common.h)
+      v[i] = make_float4(mce_sat(v[i].x, t), mce_sat(v[i].y, t), mce_sat(v[i].z, t), mce_sat(v[i].w, t));
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int64_t c = (int64_t)i * 256 + lane * 4;

@@ -1466,7 +1466,10 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
 #ifdef MC_ABL_NOEXP
     for (int i = 0; i < 16; ++i) w[i] = hi[i] + lo[i];
 #else
-    for (int i = 0; i < 16; ++i) w[i] = __expf(hi[i] + lo[i]);
+    for (int i = 0; i < 16; ++i) {           // saturating exponent (common.h kMceSat): finite whatever the logits; NaN stays
+      const float xa = hi[i] + lo[i];
+      w[i] = __expf(xa > kMceSat ? kMceSat : xa);
+    }
 #endif
     if (__any(mw != 0u)) {
       // dU role: the lane's word holds its row's bits for the tile's columns; dI role: lane lr holds the word of the
@@ -1603,8 +1606,11 @@ __global__ __launch_bounds__(256) void k_mc_rows(McRows a, int64_t B) {
     for (int m = 8; m > 0; m >>= 1) poison += __shfl_xor(poison, m, 64);
     s += pbad + poison + t * 0.f;
     const float gw = live ? a.gscale * (a.row_w ? a.row_w[r] : 1.f) : 0.f;
-    const float coef = gw / (1.f + s);
-    const float dt = -coef * s;
+    // (s is finite for finite inputs since the exponent saturates; the limits keep an overflowed sum -- more than
+    // 2^20 saturated pairs in a row -- from turning 0 * inf into NaN: coef -> 0, dt -> -g)
+    const bool sinf = s == __builtin_inff();
+    const float coef = sinf ? 0.f : gw / (1.f + s);
+    const float dt = sinf ? -gw : -coef * s;
     if ((lane & 15) == 0) {
       if (live) {
         if (a.batch_loss) a.batch_loss[r] = log1pf(s);

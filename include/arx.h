@@ -471,6 +471,9 @@ int arx_mw_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, in
  *   loss_r = log(1 + sum_s m_rs * exp(x_rs - t_r))      (softmax cross-entropy over
  *            [target score || the sampled logits the positive mask keeps]; no log-Q term)
  *   dx_rs  = g_r * m_rs * exp(x_rs - t_r) / (1 + sum),  dt_r = -sum_s dx_rs.
+ * Round 6: the exponent SATURATES, exp(min(x_rs - t_r, 64)) in the loss and in the weight: the plain sampled softmax
+ * while no kept logit leads the target score by more than 64 (a softmax weight of 1 - 1e-28 there), finite beyond --
+ * the same definition on every path (these entries, the fused arx_mce_scorer_* family, the oracle).
  * Same three forms, arguments and restrictions as the arx_loss_mw_* entries above. */
 int arx_loss_mce_fwdbwd(const float* logits, int64_t ldl, const float* tscore,
                        const uint8_t* mask, int64_t ldm, int64_t mask_rows, float gscale,

@@ -189,6 +189,7 @@ class _Model(object):
             bl = np.log1p(s)
             d = act / (1.0 + s)[:, None]
         else:
+            logits = np.minimum(logits, t[:, None] + 64.0)       # ref_graph.MCE_SAT: the build-defined saturation
             mx = np.maximum(np.where(mask, logits, -np.inf).max(1), t)
             ex = np.where(mask, np.exp(logits - mx[:, None]), 0.0)
             z = np.exp(t - mx) + ex.sum(1)

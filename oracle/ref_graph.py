@@ -60,6 +60,9 @@ def unsorted_segment_sum(data, segids, n):
     return out
 
 
+MCE_SAT = 64.0      # saturation of the build-defined 'mce' exponent (csrc/common.h kMceSat)
+
+
 def _sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
 
@@ -498,7 +501,11 @@ class RefEmbeddingAttribute(object):
             # (:641-649): softmax cross-entropy over [target score || the sampled logits the mask
             # keeps], i.e.  log(1 + sum_s m_rs * exp(x_rs - t_r)); no log-Q correction, like 'mw'
             # has no |Y|/|Z| rescale.  SURVEY.md section 8(a) footnote.
+            # Round 6: the exponent saturates at MCE_SAT = 64 (e_rs = exp(min(x_rs - t_r, 64))): identical to the
+            # plain sampled softmax while no kept logit leads the target score by more than 64 (softmax weight
+            # 1 - 1e-28 there), finite beyond -- one definition for every device path (csrc/common.h kMceSat).
             tl = np.asarray(item_target, dtype=self.dt).reshape(mb, 1)
+            logits = np.minimum(logits, tl + MCE_SAT)
             mx = np.maximum(np.where(mask, logits, -np.inf).max(1, keepdims=True), tl)
             ex = np.where(mask, np.exp(logits - mx), 0)
             z = np.exp(tl - mx)[:, 0] + ex.sum(1)

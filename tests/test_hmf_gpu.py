@@ -592,11 +592,13 @@ def test_hmf_feed_nodes_unsynchronised_run(dev, cfg):
     assert m_nodes._plan('train').graph.feed_groups
 
 
-def test_hmf_empty_pool_slot_is_a_zero_row(dev):
+def test_hmf_empty_pool_slot_is_out_of_the_loss(dev):
     """A negative id in the sampled pool (what DeviceSampler.sample leaves where a short capped draw could not fill a
-    position) is an EMPTY slot: it scores like an item whose rows are zero and receives no update -- no read of
-    cat_map[-1] / E[-1] (advisor, round 4).  Against a twin model whose pool holds, in that slot, a real item X with
-    zeroed id row and bias: same losses bit for bit, same tables except X's own rows."""
+    position) is an EMPTY slot: it looks nothing up -- no read of cat_map[-1] / E[-1] (advisor, round 4) --, receives
+    no update, and (advisor, round 5) is OUT of the sampled loss: its bias output is -1e30 (gather.hip
+    kEmptySlotBias), so it is never hinge-active and does not enter the rank weighting.  Against a twin model whose
+    pool holds, in that slot, a real item X with a zeroed id row and bias -1e30: same losses bit for bit, same
+    tables except X's own rows -- and against the oracle over the S - 1 real slots."""
     import torch
     from arx.utils.synthetic import SyntheticHMF
     from arx.hmf.hmf_model import LatentProductModel
@@ -610,7 +612,7 @@ def test_hmf_empty_pool_slot_is_a_zero_row(dev):
     X = next(int(i) for i in syn.item_population if int(i) not in used and int(i) not in set(pool.tolist()))
     xrow = int(np.asarray(syn.i_attr.features_cat[0])[X])
     params['itemembed_cat_0'][xrow] = 0
-    params['item_bias_cat_0'][xrow] = 0
+    params['item_bias_cat_0'][xrow] = -1e30
     i2l, l2i = syn.item_ind2logit_ind_dict(), syn.logit_ind2item_ind
     models = []
     for _ in range(2):
@@ -634,8 +636,15 @@ def test_hmf_empty_pool_slot_is_a_zero_row(dev):
         ga, gb = models[0].att_emb.get_params(), models[1].att_emb.get_params()
         keep = np.ones(ga['itemembed_cat_0'].shape[0], dtype=bool)
         keep[xrow] = False
-        assert not ga['itemembed_cat_0'][xrow].any() and not ga['item_bias_cat_0'][xrow].any()   # nothing written
-        assert gb['itemembed_cat_0'][xrow].any()                                                 # the twin's X moved
+        assert not ga['itemembed_cat_0'][xrow].any() and ga['item_bias_cat_0'][xrow] == np.float32(-1e30)   # nothing written
+        assert not gb['itemembed_cat_0'][xrow].any()                  # the twin's X has no active pair: zero gradient
+        # the oracle over the S - 1 REAL slots (the reference's np.random.choice never leaves a hole: "not there")
+        ref = rg.RefLatentProductModel(d, B, 0.5, syn.u_attr, syn.i_attr, i2l, l2i, loss_function='mw',
+                                       n_sampled=S - 1, params=params, dtype=np.float64)
+        ref.prepare_warp({}, {})
+        real = np.delete(pa, 5)
+        l_ref = ref.step(list(u), list(it), real, {int(v): i for i, v in enumerate(real)}, loss='mw')
+        assert abs(la - l_ref) <= 1e-4 * abs(l_ref), (la, l_ref)
         assert np.array_equal(ga['userembed_cat_0'], gb['userembed_cat_0'])
         # (the item table's pass sorts one contribution more in the twin: runs of duplicate targets may be cut into
         # sub-sums at other positions -- the same sums in another association, not bit for bit)

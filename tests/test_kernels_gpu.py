@@ -336,6 +336,36 @@ def test_loss_mw(dev, B, S, kind):
     np.testing.assert_allclose(out_dt.cpu().numpy(), dt2, rtol=RTOL, atol=1e-7)
 
 
+@pytest.mark.parametrize("B,S", [(64, 1024), (33, 3100)])
+def test_loss_mce_large_logits_saturate(dev, B, S):
+    """Round-5 advisor (medium): logits that lead the target score by more than 88.7 overflowed the fused 'mce'
+    family.  The build-defined loss saturates its exponent at 64 on EVERY path (csrc/common.h kMceSat, the oracle's
+    MCE_SAT): the materialising kernels (wave-per-row and workgroup-per-row) against the oracle on logits up to
+    +-300 -- finite everywhere, rows far beyond the cap included."""
+    from arx import ops
+    import torch
+    rng = np.random.default_rng(7 * B + S)
+    logits = (rng.standard_normal((B, S)) * 60.0).astype(np.float32)
+    t = (rng.standard_normal((B,)) * 20.0).astype(np.float32)
+    logits[0] = -150.0                                        # a row far BELOW its target score
+    t[0] = 100.0
+    mask = _mask(rng, B, S)
+    assert ((logits - t[:, None]) * mask > 88.7).any()
+    e = rg.RefEmbeddingAttribute.__new__(rg.RefEmbeddingAttribute)
+    e.dt = np.dtype(np.float64)
+    bl, cache = e.compute_loss(logits.astype(np.float64), t.astype(np.float64), 'mce', mask)
+    dl, dt = e.compute_loss_bwd(cache, np.full(B, 1.0 / B))
+    assert np.isfinite(bl).all() and np.isfinite(dl).all()
+    out_l = torch.empty(B, dtype=torch.float32, device=dev)
+    out_dt = torch.empty(B, dtype=torch.float32, device=dev)
+    dlog = torch.empty((B, S), dtype=torch.float32, device=dev)
+    ops.loss_mw(_t(dev, logits), _t(dev, t), _t(dev, mask.astype(np.uint8)), out_l, dlog, out_dt, 1.0 / B, kind='mce')
+    assert bool(torch.isfinite(out_l).all()) and bool(torch.isfinite(dlog).all()) and bool(torch.isfinite(out_dt).all())
+    np.testing.assert_allclose(out_l.cpu().numpy(), bl, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(dlog.cpu().numpy(), dl, rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(out_dt.cpu().numpy(), dt, rtol=RTOL, atol=1e-7)
+
+
 @pytest.mark.parametrize("B,V", [(64, 3100), (7, 50)])
 def test_loss_warp_and_ce(dev, B, V):
     from arx import ops
@@ -1628,6 +1658,70 @@ def test_mce_scorer(dev, B, S, mask_rows, maxpos, bias):
         wn64 = wn.cpu().numpy().astype(np.float64)
         _, dt2 = e.compute_loss_bwd(cache, wn64)
         np.testing.assert_allclose(dts.cpu().numpy(), dt2, rtol=RTOL, atol=1e-10)
+
+
+@pytest.mark.parametrize("B,S,scale", [(320, 256, 2.0), (515, 1024, 3.0)])
+def test_mce_scorer_large_logits_stay_finite(dev, B, S, scale):
+    """Round-5 advisor (medium, scorer.hip k_mc_flow): the fused 'mce' family anchors exp() at the target score; a
+    pair with x_rs - t_r > 88.7 made s = inf, coef = 0, dt = NaN and poisoned dU / dT / the tables for good.  The
+    build-defined loss now saturates its exponent at 64 (one definition: csrc/common.h kMceSat, oracle MCE_SAT):
+    operands scaled until hundreds of pairs pass 88.7 -- every output finite, and equal to the oracle's (saturating)
+    f64 chain: loss, dt, dT, dU, dI, db.  Gradient tolerance 3e-4 of the term scale: |x| ~ 100 carries an f32 product
+    chain's ~2e-5 absolute error into the exponent."""
+    from arx import ops
+    import torch
+    d = 64
+    rng = np.random.default_rng(B + S)
+    U = (rng.standard_normal((B, d)) * scale).astype(np.float32)
+    P = (rng.standard_normal((S, d)) * scale).astype(np.float32)
+    pb = (rng.standard_normal(S) * 0.2).astype(np.float32)
+    T = (rng.standard_normal((B, d)) * 0.4).astype(np.float32)
+    tb = (rng.standard_normal(B) * 0.1).astype(np.float32)
+    n_items, n_users = 5 * S, 50
+    pool = rng.permutation(n_items)[:S].astype(np.int32)
+    i2s = np.full(n_items + 1, -1, dtype=np.int32)
+    i2s[pool] = np.arange(S, dtype=np.int32)
+    npos = rng.integers(0, 30, size=n_users)
+    ptr = np.concatenate([[0], np.cumsum(npos)]).astype(np.int32)
+    pitems = rng.integers(0, n_items, size=int(ptr[-1])).astype(np.int32)
+    users = rng.integers(0, n_users, size=B).astype(np.int32)
+    rw = rng.random(B).astype(np.float32)
+    gscale = 1.0 / B
+    U64, P64 = U.astype(np.float64), P.astype(np.float64)
+    logits = U64 @ P64.T + pb
+    t = (U64 * T).sum(1) + tb
+    mask = np.ones((B, S), dtype=bool)
+    for r in range(B):
+        sl = i2s[pitems[ptr[users[r]]:ptr[users[r] + 1]]]
+        mask[r, sl[sl >= 0]] = False
+    lead = np.where(mask, logits - t[:, None], -np.inf)
+    assert (lead > 88.7).sum() > 100 and (lead.max(1) < 64).sum() > 10      # overflowing rows AND plain ones
+    e = rg.RefEmbeddingAttribute.__new__(rg.RefEmbeddingAttribute)
+    e.dt = np.dtype(np.float64)
+    bl, cache = e.compute_loss(logits, t, 'mce', mask)
+    dl, dt = e.compute_loss_bwd(cache, rw.astype(np.float64) * gscale)
+    f32 = torch.float32
+    sc = ops.MceScorer(B, S, d, dev)
+    out_bl, out_t, dts = (torch.empty(B, dtype=f32, device=dev) for _ in range(3))
+    dU, dT = (torch.full((B, d), 9.0, dtype=f32, device=dev) for _ in range(2))
+    sc.fwd(_t(dev, U), _t(dev, P), _t(dev, pb), _t(dev, T), _t(dev, tb), _t(dev, users), _t(dev, ptr), _t(dev, pitems),
+           _t(dev, i2s), out_bl, out_t, dts, dU, dT, gscale, row_w=_t(dev, rw))
+    dI = torch.zeros((S, d), dtype=f32, device=dev)
+    db = torch.empty(S, dtype=f32, device=dev)
+    sc.bwd_dI(dI, db=db, beta=0.0)
+    torch.cuda.synchronize()
+    for x in (out_bl, out_t, dts, dU, dT, dI, db):
+        assert bool(torch.isfinite(x).all())
+    np.testing.assert_allclose(out_bl.cpu().numpy(), bl, rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(dts.cpu().numpy(), dt, rtol=3e-4, atol=1e-10)
+    np.testing.assert_allclose(dT.cpu().numpy(), dt[:, None] * U64, rtol=3e-4, atol=1e-9)
+    scale_u = np.abs(dl) @ np.abs(P64) + np.abs(dt[:, None] * T)
+    errU = np.abs(dU.cpu().numpy() - (dl @ P64 + dt[:, None] * T))
+    assert np.all(errU <= 3e-4 * scale_u + 1e-12), float((errU / (scale_u + 1e-30)).max())
+    scale_i = np.abs(dl).T @ np.abs(U64)
+    errI = np.abs(dI.cpu().numpy() - dl.T @ U64)
+    assert np.all(errI <= 3e-4 * scale_i + 1e-12), float((errI / (scale_i + 1e-30)).max())
+    np.testing.assert_allclose(db.cpu().numpy(), dl.sum(0), rtol=3e-4, atol=1e-12)
 
 
 @pytest.mark.parametrize("M,N,K,beta", [(51200, 64, 256, 0.0), (777, 64, 256, 1.0), (130, 128, 128, 0.5),
