@@ -1347,6 +1347,391 @@ class SeqDataParallel(object):
         return [(table, [g for _, g, _ in gs], gbufs, rows) for table, gs, gbufs, rows in self._state(plan)['tables']]
 
 
+
+# ---------------------------------------------------------------------------------------------
+# Hybrid sequence model (round 6): embedding tables striped by row, LSTM weights data-parallel.
+# north_star: "partition the item-embedding table row-wise ... all-reduce for the dense LSTM weights";
+# the reference's only device split is a TF tower list (lstm/run.py:87,221-229, lstm/seqModel.py:87-126).
+# ---------------------------------------------------------------------------------------------
+class _ShardView(object):
+    """A striped table WITHOUT its padding row, as K7 sees it: keys that name the padding row (lookups this rank
+    does not own, padded receive slots) are out of range and dropped by the key builders."""
+
+    def __init__(self, t, rows):
+        self.name, self.bias_name = t.name, t.bias_name
+        self.E, self.acc = t.E[:rows], t.acc[:rows]
+        self.bias = None if t.bias is None else t.bias[:rows]
+        self.bias_acc = None if t.bias_acc is None else t.bias_acc[:rows]
+        self.sites = []
+
+
+class SeqHybridParallel(SeqDataParallel):
+    """SeqModel on `world` ranks with every embedding table striped by ROW (owner = row % world, local row =
+    row // world -- ShardedHMF's rule) and the dense parameters (lstm_w / lstm_b of every layer, w_input_*)
+    replicated and all-reduced.  One step of the group == the single-process step on the global batch, like
+    SeqDataParallel -- but no rank holds a whole table, no rank sorts the GLOBAL lookups, and the lookup traffic is
+    all-to-all (rows travel once, to the rank that asked / owns) instead of an all-gather of every replica's rows:
+
+      forward   per batch lookup (inputs, targets, users) and feature: ids -> owners (all_to_all, 4 B per lookup),
+                the owner gathers its rows (K2 on its shard), rows + bias -> back (all_to_all, 4 (d + 1) B per
+                lookup); the sampled pool: every rank gathers the pool rows it owns (zeros elsewhere), one
+                all_reduce of [S, d + 1] makes the pool whole everywhere (S = 1024: 266 KB)
+      backward  gradient rows of the batch lookups -> owners (all_to_all); the owner runs K7 over what it RECEIVED
+                (keys = local rows) -- every row is updated once, on one rank, duplicates across ranks merged by
+                that rank's pass; pool gradient [S, d] (+ bias): all_reduce, every owner applies ITS pool rows;
+                per-unrolled-step pool gradients [L, S, d] (+ [L, S]): reduce_scatter -- they are only SQUARED
+                (tf.clip_by_global_norm over the un-merged per-step matmul gradients, lstm/seqModel.py:178-182,
+                SURVEY A.7): each rank squares its 1/world slice, the squares join the scalar all_reduce that the
+                batch lookups' un-merged IndexedSlices norms already need
+      dense     lstm_w / lstm_b / w_input_*: one packed all_reduce (128 KB at C4)
+
+    Per rank and step at C4 (L = 50, B_loc = 1024, d = 64, S = 1024): 2 x 2 x 51 200 lookups x 260 B = 53 MB of
+    all-to-all + 13.3 MB x (N - 1) / N of reduce_scatter + < 1 MB of small all-reduces -- against SeqDataParallel's
+    all_gather of N x 26 MB of rows and a 13.3 MB all_reduce.  Routing (owner of every
+    lookup, permutation, split sizes) is host work per batch on the ids the step is fed with: one D2H read of the
+    ids per lookup node (data-loader work in a production loop, like ShardedHMF.prepare_route).
+
+    Scope: training steps (step(..., forward_only=False)) of models whose trained lookups are one-hot,
+    mean-combined features (the restriction SeqDataParallel has; C4); full-vocabulary evaluation over striped
+    tables is not built -- global_params() reassembles the tables for a single-process model.  Steps run eagerly
+    (collectives between the kernels).  No multi-GPU box was in reach of the builder: verified with gloo ranks
+    sharing one GPU (tests/test_seq_hybrid_gpu.py) and on CPU for the routing (tests/test_dist_cpu.py)."""
+
+    def __init__(self, model, group=None):
+        super().__init__(model, group)
+        self._feat = {}            # id(Feature) -> dict(full_h, route)
+        self._fetch = {}           # (id(node), k) -> this step's exchange record
+        self._hstate = {}
+        self._shard_tables()
+
+    # ---- striping -----------------------------------------------------------------------------
+    def _shard_tables(self):
+        W, r = self.world, self.rank
+        for t in self.model.att_emb.tables.values():
+            if getattr(t, 'shard', None) is not None:
+                continue
+            V, d = int(t.E.shape[0]), int(t.E.shape[1])
+            rows = (V + W - 1) // W
+            E = torch.zeros((rows + 1, d), dtype=torch.float32, device=t.E.device)
+            mine = t.E[r::W]
+            E[:mine.shape[0]].copy_(mine)
+            acc = torch.full_like(E, float(t.acc.flatten()[0].item()) if t.acc.numel() else 0.1)
+            acc[:mine.shape[0]].copy_(t.acc[r::W])
+            bias = bias_acc = None
+            if t.bias is not None:
+                bias = torch.zeros((rows + 1,), dtype=torch.float32, device=t.E.device)
+                bias[:mine.shape[0]].copy_(t.bias[r::W])
+                bias_acc = torch.full_like(bias, 0.1)
+                bias_acc[:mine.shape[0]].copy_(t.bias_acc[r::W])
+            t.E, t.acc, t.bias, t.bias_acc = E, acc, bias, bias_acc
+            t.shard = dict(V=V, rows=rows, zero_row=rows, count=int(mine.shape[0]))
+            t.view = _ShardView(t, rows)
+            for a in ('aux_cnt', 'aux_first'):
+                if hasattr(t, a):
+                    delattr(t, a)
+
+    @staticmethod
+    def route_rows(full_rows, world):
+        """Host side of one lookup exchange: (order, send_rows, send_counts) for global table rows `full_rows` --
+        lookups grouped by owner (stable: the order inside a group is the order of the lookups), rows as LOCAL rows
+        of their owner."""
+        full_rows = np.asarray(full_rows, dtype=np.int64)
+        owner = full_rows % world
+        order = np.argsort(owner, kind='stable')
+        return (order.astype(np.int32), (full_rows[order] // world).astype(np.int32),
+                np.bincount(owner, minlength=world).astype(np.int64))
+
+    def _feature(self, f):
+        """The map of a feature re-expressed for a striped table: kept on the host (entity -> global row) for the
+        routing, and on the device as entity -> LOCAL row or the padding row (pool-like lookups: every rank looks the
+        same ids up and contributes the rows it owns)."""
+        st = self._feat.get(id(f))
+        if st is None:
+            t = f.table
+            V = t.shard['V']
+            full = f.maps[0]
+            full_h = np.arange(V, dtype=np.int64) if full is None else full.cpu().numpy().astype(np.int64)
+            if full_h.size and (full_h.min() < 0 or full_h.max() >= V):
+                raise ValueError("SeqHybridParallel: feature map of %s leaves the table" % t.name)
+            route = np.where(full_h % self.world == self.rank, full_h // self.world, t.shard['zero_row'])
+            st = dict(full_h=full_h, route=torch.from_numpy(route.astype(np.int32)).to(t.E.device), f=f)
+            self._feat[id(f)] = st
+        return st
+
+    def _exchange_counts(self, send_counts):
+        W = self.world
+        sc = torch.as_tensor(send_counts, dtype=torch.int64)
+        rc = torch.empty(W, dtype=torch.int64)
+        if W > 1:
+            be = dist.get_backend(self.group)
+            if be == 'nccl':
+                scd, rcd = sc.to(self.rt.device), rc.to(self.rt.device)
+                dist.all_to_all_single(rcd, scd, group=self.group)
+                rc = rcd.cpu()
+            else:
+                dist.all_to_all_single(rc, sc, group=self.group)
+        else:
+            rc.copy_(sc)
+        return [int(x) for x in sc.tolist()], [int(x) for x in rc.tolist()]
+
+    def _a2a(self, out, inp, out_splits, in_splits):
+        if self.world == 1:
+            out.copy_(inp)
+            return
+        if out.is_cuda and dist.get_backend(self.group) != 'nccl':      # (the gloo rig of the tests: host-staged)
+            o, i = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+            dist.all_to_all_single(o, i, out_splits, in_splits, group=self.group)
+            out.copy_(o)
+            return
+        dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=self.group)
+
+    def _reduce_host_staged(self, t):
+        if self.world > 1:
+            if t.is_cuda and dist.get_backend(self.group) != 'nccl':
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    # ---- forward: the lookups ---------------------------------------------------------------------
+    def _pool_nodes(self, plan):
+        from . import graph as G
+        pools = set()
+        for n in plan.order:
+            if isinstance(n, G.Prediction):
+                pools.add(id(n.inputs[1]))
+        return pools
+
+    def fetch(self, plan):
+        """Plan._execute, in front of the lookups: every EntityEmbed node of the plan is served here."""
+        from . import graph as G, ops
+        if not plan.train:
+            raise NotImplementedError("SeqHybridParallel: training steps only (evaluate a single-process model built "
+                                      "from global_params())")
+        pools = self._pool_nodes(plan)
+        dev = self.rt.device
+        done = set()
+        for n in plan.order:
+            if not isinstance(n, G.EntityEmbed):
+                continue
+            if n.concat or any(f.kind != 'cat' for f in n.feats):
+                raise NotImplementedError("SeqHybridParallel: one-hot, mean-combined features only")
+            n.alloc_value()
+            F = len(n.feats)
+            if id(n) in pools:
+                # every rank: the pool rows it owns (the padding row elsewhere), summed over the ranks
+                for k, f in enumerate(n.feats):
+                    fs = self._feature(f)
+                    t = f.table
+                    ops.gather_onehot(t.E, t.bias if n.with_bias else None, fs['route'], n.inputs[0].value, n.value,
+                                      scale=n.out_scale / F, accumulate=k > 0,
+                                      bias_out=n.bias_value if n.with_bias else None)
+                self._reduce_host_staged(n.value)
+                if n.with_bias:
+                    self._reduce_host_staged(n.bias_value)
+                done.add(id(n))
+                continue
+            ids_h = n.inputs[0].value.cpu().numpy()
+            for k, f in enumerate(n.feats):
+                fs = self._feature(f)
+                t = f.table
+                d = int(t.E.shape[1])
+                order, send_rows, sc = self.route_rows(fs['full_h'][ids_h], self.world)
+                sc, rc = self._exchange_counts(sc)
+                R = sum(rc)
+                nloc = int(ids_h.shape[0])
+                rec = self._fetch.get((id(n), k))
+                if rec is None or rec['cap'] < R:
+                    cap = max(R, nloc + nloc // 2 + 64) if self.world > 1 else nloc
+                    rec = dict(cap=cap, recv_rows=torch.empty(cap, dtype=torch.int32, device=dev),
+                               rows=torch.empty((cap, d), dtype=torch.float32, device=dev),
+                               rows_b=torch.empty((cap,), dtype=torch.float32, device=dev),
+                               got=torch.empty((nloc, d), dtype=torch.float32, device=dev),
+                               got_b=torch.empty((nloc,), dtype=torch.float32, device=dev),
+                               send=torch.empty((nloc, d), dtype=torch.float32, device=dev),
+                               send_b=torch.empty((nloc,), dtype=torch.float32, device=dev),
+                               garena=torch.zeros((cap, d), dtype=torch.float32, device=dev),
+                               garena_b=torch.zeros((cap,), dtype=torch.float32, device=dev), gen=0)
+                    rec['gen'] = (self._fetch[(id(n), k)]['gen'] + 1) if (id(n), k) in self._fetch else 0
+                    self._fetch[(id(n), k)] = rec
+                    self._hstate.pop(id(plan), None)          # (new buffers: the K7 proxies are rebuilt)
+                inv = np.empty_like(order)
+                inv[order] = np.arange(order.shape[0], dtype=np.int32)
+                rec.update(sc=sc, rc=rc, R=R, order=torch.from_numpy(order).to(dev), inv=torch.from_numpy(inv).to(dev))
+                rec['recv_rows'].fill_(t.shard['zero_row'])
+                self._a2a(rec['recv_rows'][:R], torch.from_numpy(send_rows).to(dev), rc, sc)      # ids -> owners
+                wb = n.with_bias and t.bias is not None
+                if R:
+                    ops.gather_onehot(t.E, t.bias if wb else None, None, rec['recv_rows'][:R], rec['rows'][:R],
+                                      bias_out=rec['rows_b'][:R] if wb else None)
+                self._a2a(rec['got'], rec['rows'][:R], sc, rc)                                    # rows -> back
+                if wb:
+                    self._a2a(rec['got_b'], rec['rows_b'][:R], sc, rc)
+                # got is in owner order: lookup i sits at got[inv[i]]
+                ops.gather_onehot(rec['got'], rec['got_b'] if wb else None, None, rec['inv'], n.value,
+                                  scale=n.out_scale / F, accumulate=k > 0,
+                                  bias_out=n.bias_value if n.with_bias else None)
+            done.add(id(n))
+        return done
+
+    # ---- backward: gradients to the owners ----------------------------------------------------------
+    def _state(self, plan):
+        from . import graph as G
+        st = self._hstate.get(id(plan))
+        if st is not None:
+            return st
+        rt = self.rt
+        dev = rt.device
+        pools, preds = set(), []
+        for n in plan.order:
+            if isinstance(n, G.Prediction) and n.inputs[1].train_tables:
+                pools.add(id(n.inputs[1]))
+                preds.append(n)
+        tables = []
+        for table, sites, bufs, total in plan.tables:
+            if any(s.kind != 'cat' or s.col_off != 0 for s in sites):
+                raise NotImplementedError("SeqHybridParallel: one-hot, mean-combined features only")
+            width = sites[0].node.shape[1]
+            gs, rows = [], 0
+            for s in sites:
+                k = next(i for i, f in enumerate(s.node.feats) if f.table is s.table)
+                if id(s.node) in pools:
+                    n_ = s.n
+                    route = self._feature(s.node.feats[k])['route']
+                    gs.append((s, n_, 'pool', route, None))
+                else:
+                    rec = self._fetch[(id(s.node), k)]
+                    gs.append((s, rec['cap'], 'batch', None, rec))
+                rows += gs[-1][1]
+            arena = torch.zeros((rows, width), dtype=torch.float32, device=dev)
+            arena_b = torch.zeros((rows,), dtype=torch.float32, device=dev)
+            out, r0 = [], 0
+            for s, n_, kind, route, rec in gs:
+                if kind == 'pool':
+                    g = _GSite(s, s.ids_node.value, _GNode(r0, arena, arena_b, s.node), n_)
+                    g.maps = (route,)
+                else:
+                    g = _GSite(s, rec['recv_rows'], _GNode(r0, arena, arena_b, s.node), n_)
+                    g.maps = (None,)
+                g.table = table.view
+                out.append((s, g, kind, rec))
+                r0 += n_
+            gbufs = {'keys': torch.full((rows,), G.KEY_NONE, dtype=torch.int32, device=dev),
+                     'src': torch.zeros((rows,), dtype=torch.int32, device=dev),
+                     'coef': torch.zeros((rows,), dtype=torch.float32, device=dev),
+                     'hot': torch.zeros((rows // 16 + 4,), dtype=torch.int32, device=dev)}
+            off = 0
+            for _, g, _, _ in out:
+                g.key_off = off
+                off += g.cap
+            tables.append((table.view, out, gbufs, rows))
+        # per-step pool gradients: only their squares are needed -> reduce_scatter (see the class docstring)
+        steps = []
+        for n in preds:
+            if getattr(n, 'C_steps', None) is not None:
+                for buf in (n.C_steps, n.rs_steps):
+                    tot = buf.numel()
+                    dd = int(buf.shape[-1]) if buf.dim() == 3 else 1
+                    per = (tot + self.world - 1) // self.world
+                    per = (per + dd - 1) // dd * dd            # slices start on a row (the norm's row scales)
+                    steps.append(dict(buf=buf, per=per,
+                                      pad=torch.zeros(per * self.world, dtype=torch.float32, device=dev),
+                                      mine=torch.zeros(per, dtype=torch.float32, device=dev)))
+        st = dict(preds=preds, tables=tables, steps=steps)
+        self._hstate[id(plan)] = st
+        return st
+
+    def step_slices(self, buf):
+        """(this rank's summed slice of a per-step pool-gradient buffer, first element, count) after exchange()."""
+        for st in self._hstate.values():
+            for e in st['steps']:
+                if e['buf'] is buf:
+                    lo = self.rank * e['per']
+                    cnt = max(0, min(e['per'], buf.numel() - lo))
+                    return e['mine'], lo, cnt
+        return None
+
+    def exchange(self, plan):
+        from . import ops
+        rt = self.rt
+        st = self._state(plan)
+        # dense gradients + the pool gradient and its bias (small): one packed all_reduce
+        pack = [p.grad for p in rt.dense.values() if getattr(p, 'touched', False)]
+        for n in st['preds']:
+            if not n._grad_written:
+                continue
+            pool = n.inputs[1]
+            pack.append(pool.grad)
+            if pool.bias_grad_used:
+                pack.append(pool.bias_grad)
+        self._all_reduce_packed([t for t in pack])
+        # per-step pool gradients: summed slices
+        for e in st['steps']:
+            flat = e['buf'].reshape(-1)
+            if self.world == 1:
+                e['mine'][:flat.numel()].copy_(flat)
+                continue
+            e['pad'][:flat.numel()].copy_(flat)
+            if e['pad'].is_cuda and dist.get_backend(self.group) != 'nccl':
+                h = e['pad'].cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)       # (gloo has no reduce_scatter)
+                e['mine'].copy_(h[self.rank * e['per']:(self.rank + 1) * e['per']])
+            else:
+                dist.reduce_scatter_tensor(e['mine'], e['pad'], op=dist.ReduceOp.SUM, group=self.group)
+        # lookups: gradient rows to the owners of the rows
+        for table, gs, gbufs, rows in st['tables']:
+            for s, g, kind, rec in gs:
+                node = s.node
+                g.node._grad_written = node._grad_written
+                g.node.bias_grad_used = node.bias_grad_used
+                if not node._grad_written:
+                    continue
+                a = g.node.arena[g.node.row0:g.node.row0 + g.n]
+                ab = g.node.arena_b[g.node.row0:g.node.row0 + g.n]
+                src = node.arena[node.row0:node.row0 + s.n]
+                src_b = node.arena_b[node.row0:node.row0 + s.n]
+                if kind == 'pool':
+                    a.copy_(src)                      # (all-reduced above: the pool gradient of the global batch)
+                    if node.bias_grad_used:
+                        ab.copy_(src_b)
+                    continue
+                R, sc, rc = rec['R'], rec['sc'], rec['rc']
+                ops.gather_onehot(src, src_b if node.bias_grad_used else None, None, rec['order'], rec['send'],
+                                  bias_out=rec['send_b'] if node.bias_grad_used else None)       # owner order
+                a.zero_()
+                self._a2a(a[:R], rec['send'], rc, sc)
+                if node.bias_grad_used:
+                    ab.zero_()
+                    self._a2a(ab[:R], rec['send_b'], rc, sc)
+
+    def gathered_tables(self, plan):
+        return [(view, [g for _, g, _, _ in gs], gbufs, rows) for view, gs, gbufs, rows in self._state(plan)['tables']]
+
+    # ---- tables back together (tests, checkpoints) ----------------------------------------------------
+    def global_params(self, slots=False):
+        """{reference variable name: numpy array} of the WHOLE tables (att_emb.get_params() of a single-process
+        model): the shards of all ranks, interleaved.  O(table) traffic -- not a step-path call."""
+        W = self.world
+        out = {}
+        for t in self.model.att_emb.tables.values():
+            sh = t.shard
+            for name, loc in ((t.name, t.acc if slots else t.E), (t.bias_name, None if t.bias is None else
+                                                                   (t.bias_acc if slots else t.bias))):
+                if loc is None or name is None:
+                    continue
+                x = loc[:sh['rows']].detach().cpu().contiguous()
+                parts = [torch.empty_like(x) for _ in range(W)]
+                if W > 1:
+                    dist.all_gather(parts, x, group=self.group)
+                else:
+                    parts = [x]
+                full = torch.stack(parts, 1).reshape((sh['rows'] * W,) + tuple(x.shape[1:]))[:sh['V']]
+                a = full.numpy()
+                out[name] = a.reshape(-1, 1) if a.ndim == 1 else a
+        return out
+
 def _hash_u32(x, salt):
     x = (x.to(torch.int64) * 2654435761 + salt) & 0xFFFFFFFF
     x = ((x ^ (x >> 15)) * 2246822519) & 0xFFFFFFFF

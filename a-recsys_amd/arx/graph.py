@@ -934,12 +934,17 @@ class Plan(object):
             n._grad_written = False
             if isinstance(n, EntityEmbed):
                 n.bias_grad_used = False
+        # Row-striped tables (arx.dist.SeqHybridParallel): the lookups of this step are exchanges -- ids to the owners
+        # of the rows, rows back -- done by the wrapper; the nodes it served are skipped below
+        fetched = rt.dp.fetch(self) if (rt.dp is not None and hasattr(rt.dp, 'fetch')) else ()
         # single one-hot lookups are independent leaves: all of them leave in one launch
         if self._pregather is None:
             self._pregather = []
             groups = {}
             for n in self.order:
                 kinds = tuple(f.kind for f in n.feats) if isinstance(n, EntityEmbed) else ()
+                if id(n) in fetched:
+                    continue
                 if (kinds in (('cat',), ('mulhot',), ('cat', 'mulhot')) and not n.concat
                         and all(f.d == n.feats[0].d for f in n.feats)
                         and type(n.inputs[0]).__name__ in ('IdsInput', 'IdsSlice')
@@ -991,6 +996,7 @@ class Plan(object):
         if early_after == 0:
             self._early_launch()
         k_fwd = 0
+        pre.update(fetched)
         for n in self.order:
             if id(n) in pre:
                 continue

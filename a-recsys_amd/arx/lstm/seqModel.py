@@ -661,6 +661,9 @@ class SeqModel(SeqBatching):
                     if dp is None:
                         zero_sq()
                         self._shared_rows_norm(n, sp, f, sites_of, sq)
+                    elif hasattr(dp, 'step_slices'):
+                        raise NotImplementedError("striped tables: pool features that share rows between slots "
+                                                  "(attribute features) are not served; one-hot id features only")
                     else:
                         deferred.append((n, sp, f))
                 for for_bias in (False, True):
@@ -678,8 +681,19 @@ class SeqModel(SeqBatching):
                     dd = 1 if for_bias else d
                     if per_step:
                         rs = self._row_scale(n, True, per_step, 'ps%d' % for_bias)
-                        norms.append((steps_buf, dd, self._tiled(rs, L, (id(n), for_bias),
-                                                                 static=all(f.kind == 'cat' for f in per_step)), None))
+                        tiled = self._tiled(rs, L, (id(n), for_bias), static=all(f.kind == 'cat' for f in per_step))
+                        sl = dp.step_slices(steps_buf) if (dp is not None and hasattr(dp, 'step_slices')) else None
+                        if sl is not None:
+                            # striped tables (arx.dist.SeqHybridParallel): the per-step gradients were
+                            # reduce-scattered -- this rank squares ITS slice of the global sums; the squares add
+                            # over the ranks with the batch lookups' (the slice starts on a row: a multiple of dd)
+                            mine, lo, cnt = sl
+                            if cnt > 0:
+                                local.append(len(norms))
+                                norms.append((mine[:cnt].view(-1, dd) if dd > 1 else mine[:cnt], dd,
+                                              tiled[lo // dd:(lo + cnt) // dd], None))
+                        else:
+                            norms.append((steps_buf, dd, tiled, None))
                     if merged:
                         rs = self._row_scale(n, True, merged, 'mg%d' % for_bias)
                         norms.append((sum_buf, dd, rs, S * dd))

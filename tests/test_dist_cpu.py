@@ -310,3 +310,89 @@ def test_global_pool_draw_equals_single_process_draw_gloo(tmp_path, world):
     port = 29950 + (os.getpid() % 40) + world
     mp.spawn(_pool_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SeqHybridParallel (round 6): the routing and the two lookup exchanges of the striped-table sequence model, on CPU
+# tensors over gloo -- ids to the owners, rows back, gradient rows to the owners -- against plain indexing of the whole
+# table (the kernels on either side of the collectives are the HIP gathers, covered by tests/test_seq_hybrid_gpu.py).
+# ---------------------------------------------------------------------------------------------------------------------
+def test_hybrid_route_rows_groups_by_owner_stably():
+    from arx.dist import SeqHybridParallel
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 3, 8):
+        rows = rng.integers(0, 1000, size=257)
+        order, send_rows, counts = SeqHybridParallel.route_rows(rows, world)
+        assert counts.sum() == len(rows) and len(counts) == world
+        owner = rows[order] % world
+        assert np.all(np.diff(owner) >= 0)                             # grouped by owner, owners ascending
+        for g in range(world):                                         # stable inside a group
+            idx = order[owner == g]
+            assert np.all(np.diff(idx) > 0)
+        np.testing.assert_array_equal(send_rows.astype(np.int64) * world + owner, rows[order])
+    order, send_rows, counts = SeqHybridParallel.route_rows(np.zeros(0, dtype=np.int64), 4)
+    assert len(order) == 0 and counts.tolist() == [0, 0, 0, 0]
+
+
+def _hybrid_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "a-recsys_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arx.dist import SeqHybridParallel
+
+    class _Rt(object):
+        device = torch.device('cpu')
+    h = SeqHybridParallel.__new__(SeqHybridParallel)                    # the exchange helpers only: no model, no GPU
+    h.world, h.rank, h.group, h.rt = world, rank, None, _Rt()
+    V, d = 101, 6
+    rng = np.random.default_rng(3)                                     # the same table on every rank
+    table = rng.standard_normal((V, d)).astype(np.float32)
+    rows_loc = (V + world - 1) // world
+    shard = np.zeros((rows_loc + 1, d), dtype=np.float32)
+    shard[:len(table[rank::world])] = table[rank::world]
+    for step in range(4):
+        r2 = np.random.default_rng(100 * step + rank)                  # every rank looks other rows up
+        n = [0, 17, 64, 5][(step + rank) % 4]                          # ... ragged, incl. NO lookup at all on a rank
+        full = r2.integers(0, V, size=n)
+        if step == 2:
+            full[:] = 7                                                # every lookup of every rank on ONE owner
+        order, send_rows, sc = h.route_rows(full, world)
+        sc, rc = h._exchange_counts(sc)
+        R = sum(rc)
+        recv_rows = torch.empty(R, dtype=torch.int32)
+        h._a2a(recv_rows, torch.from_numpy(send_rows), rc, sc)         # ids -> owners
+        assert R == 0 or int(recv_rows.max()) < rows_loc
+        rows = torch.from_numpy(shard)[recv_rows.long()]               # the owner's gather
+        got = torch.empty((n, d), dtype=torch.float32)
+        h._a2a(got, rows, sc, rc)                                      # rows -> back
+        inv = np.empty_like(order)
+        inv[order] = np.arange(n, dtype=np.int32)
+        np.testing.assert_array_equal(got.numpy()[inv], table[full])   # == a lookup in the whole table
+        # backward: gradient rows to the owners; the owners' scatter-adds together == the global one
+        G = r2.standard_normal((n, d)).astype(np.float32)
+        recv_g = torch.zeros((R, d), dtype=torch.float32)
+        h._a2a(recv_g, torch.from_numpy(G[order]), rc, sc)
+        mine = np.zeros((rows_loc, d), dtype=np.float64)
+        np.add.at(mine, recv_rows.numpy(), recv_g.numpy().astype(np.float64))
+        objs = [None] * world
+        dist.all_gather_object(objs, (full, G))
+        ref = np.zeros((V, d), dtype=np.float64)
+        for f_, g_ in objs:
+            np.add.at(ref, f_, g_.astype(np.float64))
+        np.testing.assert_allclose(mine[:len(ref[rank::world])], ref[rank::world], rtol=1e-6, atol=1e-6)
+    with open(os.path.join(out_dir, "ok%d" % rank), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_hybrid_lookup_exchanges_equal_whole_table_lookup(tmp_path, world):
+    import torch.multiprocessing as mp
+    port = 29100 + (os.getpid() % 400) + 7 * world
+    mp.spawn(_hybrid_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
