@@ -858,8 +858,162 @@ class ShardedHMFBags(ShardedHMF):
         self.be.shard_route(u, W, self.rank, 0, urows, None)
         return {'users': u, 'items': it, 'urows': urows, 'tgt_all': tgt_all, 'tgt_fwd': fwd, 'tgt_bwd': bwd}
 
+    _static_step_ok = True          # (round 6: the kernels between the collectives as hipGraph segments, below)
+
+    def _step_bags_static(self, route):
+        """The step of step() as hipGraph segments between its four collectives (round 6; round-5 verdict, missing #3:
+        the eager step cost 583 us at world 1 against 187 us for ShardedHMF).  Every buffer is static; what varies from
+        batch to batch are four index vectors (user rows, the global batch's target ids and their id-shard rows /
+        keys), fed by the first node of the first segment.  K7's ids-only half (both one-hot sorts, the entity and
+        token sorts of the bag pass) runs on a second stream under the forward kernels -- a graph of its own between
+        the segments, a branch of the ONE graph at world 1 -- and the scorer is the fused bf16-pipe family where its
+        shapes allow (no [B_loc, S] logits), as in ShardedHMF._step_static."""
+        be, grp, W = self.be, self.group, self.world
+        B, B_loc, S, d = self.B, self.B_loc, self.S, self.d
+        dev = self.device
+        arena, arena_b = self.arena, self.arena_b
+        if getattr(self, 'g_urows', None) is None:
+            i32 = torch.int32
+            self.g_urows = torch.zeros(B_loc, dtype=i32, device=dev)
+            self.g_fwd, self.g_all, self.g_bwd = (torch.zeros(B, dtype=i32, device=dev) for _ in range(3))
+        urows, t_fwd, t_all, t_bwd = self.g_urows, self.g_fwd, self.g_all, self.g_bwd
+        self.urows = urows
+        feed = [(route['urows'], urows), (route['tgt_fwd'], t_fwd), (route['tgt_all'], t_all), (route['tgt_bwd'], t_bwd)]
+        key = (arena.data_ptr(), self.pos_ptr.data_ptr(), self.pos_items.data_ptr(), urows.data_ptr())
+        if os.environ.get("ARX_DIST_NO_CAPTURE"):
+            mode = 'eager'
+        elif self._graph_key == key:
+            mode = 'replay'
+        elif self._warm_key == key:
+            mode, self._graphs = 'capture', {}
+        else:
+            mode, self._graphs, self._graph_key = 'eager', {}, None
+        seg = lambda name, fn: self._segment(mode, name, fn)
+        bag = (self.bag_vals, self.bag_starts, self.bag_lens)
+        dU = arena[:B_loc, :d]
+        gP = arena[B_loc:B_loc + S]
+        nt = self.nt_loc
+        fused = self._fused_scorer()
+
+        def fwd_pool():
+            be.gather_rows(self.E_user, None, urows, self.U_loc, None)
+            be.gather_rows(self.E_item, self.b_item, self.pool_fwd, self.P_part[:, :d], self.Pb, scale=0.5)
+            be.gather_bags(self.E_tok, self.b_tok, *bag, self.pool_ids, self.P_part[:, :d], self.Pb, scale=0.5,
+                           accumulate=True)
+            be.copy_strided(self.Pb, self.P_part[:, d])
+
+        def fwd_tgt():
+            be.gather_rows(self.E_item, self.b_item, t_fwd, self.T_part[:, :d], self.Tb, scale=0.5)
+            be.gather_bags(self.E_tok, self.b_tok, *bag, t_all, self.T_part[:, :d], self.Tb, scale=0.5, accumulate=True)
+            be.copy_strided(self.Tb, self.T_part[:, d])
+
+        def score():
+            be.copy_strided(self.P_part[:, d], self.b_all)
+            if not fused:
+                be.gemm(self.U_loc, self.P_part[:, :d], self.logits, transB=True, col_bias=self.b_all)
+
+        def loss():
+            if fused:
+                self.scorer.fwd(self.U_loc, self.P_part[:, :d], self.b_all, self.T_pack[:, :d], self.T_pack[:, d],
+                                urows, self.pos_ptr, self.pos_items, self.item2slot, self.bl, self.t_loc,
+                                self.dT_pack[:, d], dU, self.dT_pack[:, :d], 1.0 / B)
+                return
+            be.loss_mw_fused_pos(self.logits, self.U_loc, self.T_pack[:, :d], self.T_pack[:, d], urows,
+                                 self.pos_ptr, self.pos_items, self.item2slot, self.bl, self.dlogits,
+                                 self.t_loc, self.dT_pack[:, d], dU, self.dT_pack[:, :d], 1.0 / B)
+
+        def bwd():
+            if fused:
+                self.scorer.bwd_dU(dU, beta=1.0)
+                self.scorer.bwd_dI(gP[:, :d], db=self.gb_all)
+            else:
+                be.gemm(self.dlogits, self.P_part[:, :d], dU, beta=1.0)                    # dU += dL . pool
+                be.gemm(self.dlogits, self.U_loc, gP[:, :d], transA=True, a_rowsum=self.gb_all)
+            be.copy_strided(self.gb_all, gP[:, d])
+
+        def k7(phase):
+            be.sparse_adagrad_multi([(self.E_user, self.A_user, None, None),
+                                     (self.E_item, self.A_item, self.b_item, self.Ab_item)],
+                                    [(0, urows, 0, 1.0), (1, self.pool_bwd, B_loc, 0.5), (1, t_bwd, B_loc + S, 0.5)],
+                                    arena[:, :d], arena_b, self.lr, phase=phase)
+            be.bags_adagrad(self.E_tok[:nt], self.A_tok[:nt], self.b_tok[:nt], self.Ab_tok[:nt], *bag,
+                            [(self.pool_ids, B_loc, 0.5), (t_all, B_loc + S, 0.5)], arena[:, :d], arena_b, self.lr,
+                            phase=phase)
+
+        def apply():
+            be.copy_strided(arena[B_loc:, d], arena_b[B_loc:])
+            k7(2)
+
+        def k7_sorts(own_graph):
+            main, side = torch.cuda.current_stream(dev), self._side
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                if own_graph:
+                    seg('k7_sorts', lambda: k7(1))
+                else:
+                    k7(1)
+                done = torch.cuda.Event()
+                done.record(side)
+            return done
+
+        if W == 1:
+            def whole_step():
+                fwd_pool()
+                sorted_ = k7_sorts(False)
+                fwd_tgt()
+                be.copy_2d(self.T_part, self.T_pack)          # (one rank: the partials ARE the embeddings)
+                score()
+                loss()
+                be.copy_2d(self.dT_pack, arena[B_loc + S:])
+                bwd()
+                torch.cuda.current_stream(dev).wait_event(sorted_)
+                apply()
+            self._segment(mode, 'step', whole_step, feeds=feed)
+        else:
+            self._segment(mode, 'fwd_pool', fwd_pool, feeds=feed)
+            sorted_ = k7_sorts(True)
+            w_pool = dist.all_reduce(self.P_part, op=dist.ReduceOp.SUM, group=grp, async_op=True)
+            seg('fwd_tgt', fwd_tgt)                               # target partials under the pool all-reduce
+            w_pool.wait()
+            w_tgt = dist.reduce_scatter_tensor(self.T_pack, self.T_part, op=dist.ReduceOp.SUM, group=grp, async_op=True)
+            seg('score', score)                                   # (unfused scorer: its GEMM under the reduce-scatter)
+            w_tgt.wait()
+            seg('loss', loss)
+            w_dt = dist.all_gather_into_tensor(arena[B_loc + S:], self.dT_pack, group=grp, async_op=True)
+            seg('bwd', bwd)                                       # dU, pool gradient under the all-gather
+            dist.all_reduce(gP, op=dist.ReduceOp.SUM, group=grp)
+            w_dt.wait()
+            torch.cuda.current_stream(dev).wait_event(sorted_)
+            seg('apply', apply)
+        if mode == 'eager':
+            self._warm_key = key
+        elif mode == 'capture':
+            self._graph_key = key
+            self.n_captures += 1
+        else:
+            self.n_replays += 1
+        self.steps += 1
+
     def step(self, users, items=None):
         route = users if isinstance(users, dict) else self.prepare_route(users, items)
+        if self.use_graphs:
+            def guarded():
+                try:
+                    self._step_bags_static(route)
+                except BaseException:
+                    self._graphs, self._graph_key, self._warm_key = {}, None, None
+                    raise
+            outer = torch.cuda.current_stream(self.device)
+            if outer == self._stream:
+                guarded()
+                return
+            self._stream.wait_stream(outer)
+            with torch.cuda.stream(self._stream):
+                guarded()
+            outer.wait_stream(self._stream)
+            return
         be, grp = self.be, self.group
         B, B_loc, S, d = self.B, self.B_loc, self.S, self.d
         arena, arena_b = self.arena, self.arena_b
@@ -1820,7 +1974,7 @@ def comm_roofline(model, world, grp=None):
     return out
 
 
-def comm_prediction(mode, world, B_loc, S, d, n_tokens=0):
+def comm_prediction(mode, world, B_loc, S, d, n_tokens=0, L=0, dense_bytes=0):
     """What the step's collectives cost at link rate for a world of `world` ranks -- ARITHMETIC, not a measurement
     (the bench line carries it as `roofline_comm_predicted`): a rank moves (N-1)/N of a payload
     over N-1 links of XGMI_LINK_GBS each in an all_gather / all_to_all / reduce_scatter, twice that in an
@@ -1842,6 +1996,21 @@ def comm_prediction(mode, world, B_loc, S, d, n_tokens=0):
         rows = [row("pool blocks", 'all_gather', S * dp * 4), row("target rows", 'all_to_all', B_loc * dp * 4),
                 row("target-row gradients", 'all_to_all', B_loc * dp * 4), row("pool gradients", 'all_reduce', S * dp * 4),
                 row("merged token gradient + bias", 'all_reduce', n_tokens * (d + 1) * 4)]
+    elif mode in ('seq_hybrid', 'seq_dp'):
+        # the sequence model (C4: L unrolled steps, B_loc sequences per rank, d = 64): lookups per rank and step =
+        # 2 L B_loc (inputs + targets), rows of (d + 1) floats; per-step pool gradients [L, S, d + 1]
+        n_look = 2 * L * B_loc
+        if mode == 'seq_hybrid':        # SeqHybridParallel: tables striped by row
+            rows = [row("lookup ids to the owners", 'all_to_all', n_look * 4),
+                    row("lookup rows back", 'all_to_all', n_look * (d + 1) * 4),
+                    row("pool rows", 'all_reduce', S * (d + 1) * 4),
+                    row("lookup-gradient rows to the owners", 'all_to_all', n_look * (d + 1) * 4),
+                    row("per-step pool gradients (squared only)", 'reduce_scatter', L * S * (d + 1) * 4),
+                    row("dense gradients + pool gradient", 'all_reduce', dense_bytes + S * (d + 1) * 4)]
+        else:                           # SeqDataParallel: every table on every rank
+            rows = [row("dense + per-step pool gradients", 'all_reduce', dense_bytes + (L + 1) * S * (d + 1) * 4),
+                    row("lookup ids of all replicas", 'all_gather', N * n_look * 4),
+                    row("lookup-gradient rows of all replicas", 'all_gather', N * n_look * (d + 1) * 4)]
     else:           # token-striped bags: partials of the GLOBAL batch
         B = B_loc * N
         rows = [row("pool partials", 'all_reduce', S * dp * 4), row("target partials", 'reduce_scatter', B * dp * 4),

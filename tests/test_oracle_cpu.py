@@ -704,3 +704,46 @@ def test_tf1_witness_hook():
     assert tf1_witness.kind() == "tf1"
     tf1_witness.check_lstm(ref_lstm)
     tf1_witness.check_adagrad(rg)
+
+
+# ------------------------------------------------------------ 6. the C ABI without a GPU: behaviour, not only names
+def test_abi_argument_validation_without_gpu():
+    """SURVEY 8(b) asked for a host build (libarx_host.so) so that the ABI can be exercised on a GPU-less box.  It is
+    not needed: libarx.so itself loads without a device (hipcc's host half links against the HIP runtime only), and
+    every entry point validates its arguments BEFORE its first HIP call -- so the error half of the contract (arx.h:
+    "returns 0 or a negative ARX_E* code; the message through arx_last_error") is testable here: null pointers, bad
+    sizes, unsupported shapes and short workspaces come back as codes + messages, no launch is attempted, nothing
+    crashes.  (The compute half needs the GPU: tests/*_gpu.py.)"""
+    from arx import _lib
+    lib = _lib.lib
+    EINVAL, EWS, EUNS = -1, -3, -4
+
+    def err():
+        m = lib.arx_last_error()
+        return m.decode() if m else ""
+    assert lib.arx_version() > 0
+    # null pointers / negative sizes
+    assert lib.arx_gather_onehot_fwd(None, None, None, None, 8, 64, 1.0, 0, None, 64, None, None) == EINVAL
+    assert "arx_gather_onehot" in err()
+    assert lib.arx_loss_mce_fwdbwd(None, 0, None, None, 0, 0, 1.0, None, 4, 8, None, None, 0, None, None) == EINVAL
+    assert "arx_loss_mce_fwdbwd" in err()
+    assert lib.arx_shard_route(None, 4, 2, 0, 0, None, None, None) == EINVAL
+    assert lib.arx_shard_route(1, 4, 2, 5, 0, None, None, None) == EINVAL          # rank >= world
+    assert "arx_shard_route" in err()
+    # an empty problem is NOT an error (ragged / empty inputs are legal)
+    assert lib.arx_shard_route(1, 0, 2, 0, 0, None, None, None) == 0
+    # size queries and shape predicates are pure host functions
+    assert lib.arx_sparse_adagrad_workspace_bytes(0) > 0
+    assert lib.arx_sparse_adagrad_workspace_bytes(1 << 20) > lib.arx_sparse_adagrad_workspace_bytes(1 << 10)
+    assert lib.arx_mw_scorer_supported(16384, 1024, 128) == 1 and lib.arx_mw_scorer_supported(16384, 1000, 128) == 0
+    assert lib.arx_mce_scorer_supported(51200, 1024, 64) == 1 and lib.arx_mce_scorer_supported(51200, 1024, 128) == 0
+    assert lib.arx_mw_scorer_state_bytes(16384, 1024, 128) > 16384 * 1024 // 8       # at least the activity bits
+    # a workspace that is too small is refused before any launch
+    need = lib.arx_sparse_adagrad_workspace_bytes(4096)
+    # (pointers are only compared with NULL before the workspace check: small integers stand in for them)
+    rc = lib.arx_sparse_adagrad(1, 1, None, None, 64, 1, 1, 1, 4096, 1, 64, None, 1, None, 12, 1, need - 1, None)
+    assert rc == EWS, (rc, err())
+    assert "workspace" in err()
+    assert lib.arx_sparse_adagrad(1, 1, None, None, 62, 1, 1, 1, 4096, 1, 64, None, 1, None, 12, 1, need, None) == EUNS
+    assert "d=62" in err()
+    assert lib.arx_sparse_adagrad(1, 1, None, None, 64, 1, 1, 1, 0, 1, 64, None, 1, None, 12, None, 0, None) == 0   # n = 0: nothing to do
