@@ -1349,7 +1349,9 @@ class Plan(object):
             return                            # (data-parallel: the apply sorts the GATHERED lookups)
         rt = self.rt
         if self._k7_stream is None:
-            self._k7_stream = torch.cuda.Stream(device=rt.device)
+            # (ARX_K7_STREAM_PRIO=1, experiment: the sort branch captured from a high-priority stream)
+            self._k7_stream = torch.cuda.Stream(device=rt.device,
+                                                priority=-1 if os.environ.get('ARX_K7_STREAM_PRIO') else 0)
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(main)

@@ -746,6 +746,11 @@ __global__ __launch_bounds__(512) void k_sc_rows(ScRows a, PosMask pm, int64_t m
   __shared__ float tile[32 * 129];              // g U of the block's rows, f32 [32][d + 1]
   __shared__ uint32_t sbits[32 * 64];           // final act words of the rows [32][S / 32]
   __shared__ float sg[32];
+#ifdef SC_TRACE_ROWS
+  SC_TDECL
+  SC_TREAL(120)
+#endif
+  SC_TR(10)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = tid >> 6;
@@ -783,6 +788,7 @@ __global__ __launch_bounds__(512) void k_sc_rows(ScRows a, PosMask pm, int64_t m
       if (lane < nwords) w0[q] = a.bits[(int64_t)lane * a.ldbits + r];
     }
   }
+  SC_TR(16)
 #pragma unroll
   for (int q = 0; q < RPW; ++q) {
     const int rl = wv * RPW + q;
@@ -849,7 +855,9 @@ __global__ __launch_bounds__(512) void k_sc_rows(ScRows a, PosMask pm, int64_t m
       tp[0] = g * uq.x; tp[1] = g * uq.y; tp[2] = g * uq.z; tp[3] = g * uq.w;
     }
   }
+  SC_TR(11)
   __syncthreads();
+  SC_TR(15)
   // g U -> transposed planes, 32 consecutive k (= batch rows) per column n
   sc_emit_planes_t(tile, ld, 32, a.d, a.UgT, (int64_t)a.d * a.ldug, a.ldug, r0, tid, 512);
   SC_TR(12)
@@ -893,6 +901,9 @@ __global__ __launch_bounds__(512) void k_sc_rows(ScRows a, PosMask pm, int64_t m
     a.dbp[(int64_t)blockIdx.x * S + col] = db;
   }
   SC_TR(13)
+#ifdef SC_TRACE_ROWS
+  SC_TREAL(121)
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------

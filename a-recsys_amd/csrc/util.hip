@@ -497,10 +497,56 @@ int arx_capture_begin(void* stream) {
   return ARX_OK;
 }
 
+// ARX_GRAPH_PRIO=1 (experiment, round 6): the kernel nodes of the step's ids-only sort branch (names matching
+// ARX_GRAPH_PRIO_MATCH, default the radix / extraction / expansion kernels) get the device's greatest stream priority
+// as their hipKernelNodeAttributePriority before the graph is instantiated -- the branch is C3's critical path (190 us
+// under contention with the scorer against 109 us alone) and its kernels wait for wave slots.
+static void prio_nodes(hipGraph_t g, hipStream_t s) {
+  static const char* on = getenv("ARX_GRAPH_PRIO");
+  if (!on || !*on || *on == '0') return;
+  const char* match = getenv("ARX_GRAPH_PRIO_MATCH");
+  if (!match || !*match) match = "k_rs_,k_runs_extract,k_bag_expand,k_head_len,k_site_keys";
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return;
+  size_t nn = 0;
+  if (hipGraphGetNodes(g, nullptr, &nn) != hipSuccess || nn == 0) return;
+  hipGraphNode_t* all = new hipGraphNode_t[nn];
+  int hit = 0;
+  if (hipGraphGetNodes(g, all, &nn) == hipSuccess) {
+    for (size_t i = 0; i < nn; ++i) {
+      hipGraphNodeType ty;
+      if (hipGraphNodeGetType(all[i], &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
+      hipKernelNodeParams kp;
+      if (hipGraphKernelNodeGetParams(all[i], &kp) != hipSuccess || !kp.func) continue;
+      const char* name = hipKernelNameRefByPtr(kp.func, s);
+      if (!name) continue;
+      bool m = false;
+      for (const char* p = match; *p && !m;) {
+        const char* q = strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : strlen(p);
+        if (len > 0 && len < 128) {
+          char tok[128];
+          memcpy(tok, p, len);
+          tok[len] = 0;
+          m = strstr(name, tok) != nullptr;
+        }
+        p = q ? q + 1 : p + len;
+      }
+      if (!m) continue;
+      hipKernelNodeAttrValue v = {};
+      v.priority = greatest;
+      if (hipGraphKernelNodeSetAttribute(all[i], hipKernelNodeAttributePriority, &v) == hipSuccess) ++hit;
+    }
+  }
+  delete[] all;
+  if (getenv("ARX_GRAPH_PRIO_VERBOSE")) fprintf(stderr, "arx: %d of %zu graph nodes at priority %d\n", hit, nn, greatest);
+}
+
 int arx_capture_end(void* stream, void** graph_exec_out) {
   ARX_CHECK_ARG(graph_exec_out, "arx_capture_end: null out pointer");
   hipGraph_t g = nullptr;
   ARX_CHECK_HIP(hipStreamEndCapture(as_stream(stream), &g));
+  prio_nodes(g, as_stream(stream));
   hipGraphExec_t e = nullptr;
   hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);
@@ -546,6 +592,7 @@ int arx_capture_end_feeds(void* stream, void** graph_exec_out, void** feeds_out,
     }
     delete[] all;
   }
+  prio_nodes(g, as_stream(stream));
   hipGraphExec_t e = nullptr;
   if (err == hipSuccess) err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
   if (err != hipSuccess) {

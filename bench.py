@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16384,
                     help="interactions per step per GPU (SURVEY 8(d) throughput batches: 4096, 16384)")
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3mix", "c5"],
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3mix", "c5", "c4h"],
                     help="headline workload (default c3 = BASELINE configs[2], HET layout; c5 = configs[4] on ONE "
                          "rank: the N = 1 anchor of the --gpus N curve)")
     ap.add_argument("--no-anchor", action="store_true",
@@ -935,6 +935,107 @@ def _print_line(out):
     print(compact_line(out), flush=True)
 
 
+def main_seq_hybrid(args, world, rank, local_rank):
+    """`--workload c4h`: BASELINE configs[3] (C4: LSTM d = h = 64, L = 50, S = 1024) on `world` ranks with
+    arx.dist.SeqHybridParallel -- every embedding table striped by row (all-to-all lookups, owner-side sparse
+    updates), the LSTM weights data-parallel (one packed all-reduce), per-step pool gradients reduce-scattered for the
+    clip norm.  args.lstm_batch sequences PER RANK (weak scaling).  One JSON line from rank 0: targets/s over all
+    ranks, the max-over-ranks wall time, and the exchanges priced at link rate (roofline_comm_predicted: arithmetic --
+    no multi-GPU box was in reach of the builder; N = 1 runs the same code path with every exchange a local copy)."""
+    import torch.distributed as dist
+    from arx import dist as arx_dist
+    from arx.attributes.embed_attribute import EmbeddingAttribute
+    from arx.lstm.seqModel import SeqModel
+    from arx.utils.synthetic import SyntheticHMF
+    one_gpu = bool(os.environ.get("ARX_DIST_ONE_GPU"))
+    if one_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world == 1:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(_free_port())), ("RANK", "0"),
+                     ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+            os.environ.setdefault(k, v)
+    backend = os.environ.get("ARX_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    B, L, S, size = args.lstm_batch, 50, args.n_sampled, 64
+    t0 = time.time()
+    syn = SyntheticHMF(n_users=args.n_users, n_items=args.n_items, permute_logits=False, seed=0)   # the same on every rank
+    syn.u_attr.set_model_size(size)
+    syn.i_attr.set_model_size(size)
+    START = args.n_items
+    emb = EmbeddingAttribute(syn.u_attr, syn.i_attr, B, S, L, False, None, syn.logit_ind2item_ind)
+    model = SeqModel([L], size, 1, 5.0, B, 0.5, 0.99, emb, loss='mw', use_concat=False, START_ID=START)
+    emb.prepare_warp(syn.positives_csr(), syn.positives_csr())
+    dp = arx_dist.SeqHybridParallel(model)
+    rng = np.random.default_rng(1 + rank)                    # every rank its own sequences
+    total = args.steps + args.warmup
+    nb = min(total, 8)
+    batches = []
+    for _ in range(nb):
+        users = rng.integers(0, args.n_users, size=B).astype(np.int32)
+        tg = np.stack([syn.sample_batch(B, rng)[1] for _ in range(L)], 0).astype(np.int32)
+        inp = np.concatenate([np.full((1, B), START, dtype=np.int32), tg[:-1]], 0)
+        lens = rng.integers(10, L + 1, size=B)
+        w = (np.arange(L)[:, None] < lens[None, :]).astype(np.float32)
+        batches.append((torch.from_numpy(users).to(dev), torch.from_numpy(inp).to(dev),
+                        torch.from_numpy(tg).to(dev), torch.from_numpy(w).to(dev), float(w.sum())))
+    pool = torch.from_numpy(syn.sample_pool(S, np.random.default_rng(5))).to(dev)      # the same pool on every rank
+    setup_s = time.time() - t0
+
+    def run(k0, k1):
+        tot = 0.0
+        for k in range(k0, k1):
+            u, i, t, w, ws = batches[k % nb]
+            model.step_async(None, u, i, t, w, 0, pool if (k == 0 or k == args.warmup) else None, None)
+            tot += ws
+        return tot
+    run(0, args.warmup)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.time()
+    tot_w = run(args.warmup, total)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.time() - t1
+    red = torch.tensor([wall, -wall, tot_w], dtype=torch.float64, device=dev)
+    mx = red[:2].clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    sm = red[2:].clone()
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    wall, targets = float(mx[0].item()), float(sm[0].item())
+    dense_bytes = sum(p.w.numel() * 4 for p in model.rt.dense.values())
+    dist.destroy_process_group()
+    if rank != 0:
+        return 0
+    pred = arx_dist.comm_prediction('seq_hybrid', world, B, S, size, L=L, dense_bytes=dense_bytes)
+    pred8 = arx_dist.comm_prediction('seq_hybrid', 8, B, S, size, L=L, dense_bytes=dense_bytes)
+    dp8 = arx_dist.comm_prediction('seq_dp', 8, B, S, size, L=L, dense_bytes=dense_bytes)
+    out = {"metric": METRIC, "value": targets / wall, "unit": "targets/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "dtype_detail": DTYPE_DETAIL, "data": "synthetic",
+           "value_per_gpu": targets / wall / world,
+           "config": {"workload": "C4 hybrid (BASELINE configs[3] on %d rank(s)): LSTM d=h=%d, L=%d, %d sequences per "
+                                  "rank, %d items, S=%d, 'mw', clip 5.0, Adagrad; tables striped by row "
+                                  "(arx.dist.SeqHybridParallel: all-to-all lookups, owner-side K7), LSTM weights "
+                                  "all-reduced; eager step, routing on the host per batch (inside the timed region)"
+                                  % (world, size, L, B, args.n_items, S),
+                      "batch_per_gpu": B, "global_batch": B * world, "n_sampled": S, "dim": size,
+                      "parallelism": "row-striped tables x dp%d" % world, "routing_in_timed_region": True,
+                      "timestep_rows_per_s": L * B * world * args.steps / wall, "setup_s": setup_s},
+           "roofline_comm_predicted": {"this_run": pred, "at_8_ranks": pred8, "seq_data_parallel_at_8_ranks": dp8},
+           "cpu_baseline": {"value": None, "unit": "targets/s", "cores": None, "kind": "port", "sample": None,
+                            "why": "the sequence model's CPU baseline is not timed (the headline line's is the HMF step)"}}
+    _print_line(out)
+    return 0
+
+
 def main_sharded(args, world, rank, local_rank):
     """BASELINE configs[4] (C5) on `world` ranks: one JSON line from rank 0, with the N = 1 anchor beside it."""
     import torch.distributed as dist
@@ -989,6 +1090,10 @@ def main():
     world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.workload == "c4h":
+        if args.n_items is None:
+            args.n_items = 1000000
+        return main_seq_hybrid(args, world, rank, local_rank)
     if world > 1 or args.workload == "c5":
         if args.n_items is None:
             # configs[4]: 100 M-item dim-128 table, row-sharded (with --sharded-bags: 1 M items, 20 tokens each)

@@ -49,3 +49,16 @@ def test_bench_c5_anchor_is_a_headline(dev):
                 "--n-users", "200000", "--batch", "2048", "--no-cpu-baseline"])
     assert j["n_gpus"] == 1 and j["value"] > 0 and "C5" in j["config"]["workload"]
     assert j["scaling_anchor"]["value"] == j["value"]
+
+
+def test_bench_c4_hybrid_two_ranks_one_line(dev):
+    """`bench.py --workload c4h --gpus 2`: the hybrid sequence model (tables striped by row, LSTM weights
+    data-parallel) through the self-launcher, two ranks on the one GPU over gloo: ONE compact line with the predicted
+    exchange costs beside it."""
+    j = _bench(["--workload", "c4h", "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-items", "20000", "--n-users",
+                "2000", "--lstm-batch", "128", "--n-sampled", "128"],
+               env_extra={"ARX_DIST_ONE_GPU": "1", "ARX_DIST_BACKEND": "gloo"})
+    assert j["n_gpus"] == 2 and j["unit"] == "targets/s" and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["config"]["global_batch"] == 256 and j["config"]["routing_in_timed_region"] is True
+    pred = j["_detail"]["roofline_comm_predicted"]
+    assert pred["at_8_ranks"]["us_total_at_link_rate"] < pred["seq_data_parallel_at_8_ranks"]["us_total_at_link_rate"]
