@@ -907,6 +907,180 @@ __global__ __launch_bounds__(512) void k_sc_rows(ScRows a, PosMask pm, int64_t m
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_sc_rows_g (round 6): k_sc_rows with the row phase laid out for the width the scorer family has -- d = 64 / 128 is
+// LPR = 16 / 32 lanes of 16 bytes, so a wave serves 64 / LPR rows AT ONCE (one sub-group per row) instead of four
+// rows one after the other with 48 / 32 idle lanes: one load instruction per operand for all of the wave's rows, 16-
+// / 32-lane reductions (the upper steps of the 64-lane xor tree added exact zeros: same bits), the row's S / 32
+// activity words spread over the sub-group's lanes (word w in lane w % LPR, slot w / LPR).  Measured on the C4 shape
+// (51 200 rows, d = 64; cycle stamps of one wave, tools/sc_trace.py): the four-rows-in-a-row phase was 6 300 of the
+// workgroup's 23 200 cycles behind an 8 900-cycle first load; k_sc_rows was the largest kernel of the C4 step (71.8 us).
+// Results bit-identical to k_sc_rows (ARX_SC_ROWS_OLD=1 selects it: the A/B of DESIGN.md section 6).
+// ------------------------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(512) void k_sc_rows_g(ScRows a, PosMask pm, int64_t mask_rows, int64_t B, int64_t S) {
+  constexpr int G = 64 / LPR;                    // rows a wave serves at once
+  constexpr int WPL = 64 / LPR;                  // activity words per lane (S <= 2048: 64 words per row)
+  constexpr int ROUNDS = 4 / G;                  // 32 rows per workgroup of 8 waves = 4 rows per wave
+  static_assert(G == 2 || G == 4, "d = 128 or d = 64");
+  __shared__ float tile[32 * 129];               // g U of the block's rows, f32 [32][d + 1]
+  __shared__ uint32_t sbits[32 * 64];            // final act words of the rows [32][S / 32]
+  __shared__ float sg[32];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int j = lane % LPR, grp = lane / LPR, gbase = grp * LPR;
+  const int64_t r0 = (int64_t)blockIdx.x * 32;
+  const int nwords = (int)(S >> 5);
+  const int ld = a.d + 1;
+  const float pbad = sc_wsum(lane < nwords ? a.pool_bad[lane] : 0.f);
+  auto gsum = [](float v) {                      // sum over the sub-group's LPR lanes (xor tree, offsets LPR / 2 .. 1)
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+#pragma unroll
+  for (int it = 0; it < ROUNDS; ++it) {
+    const int rl = wv * 4 + it * G + grp;
+    const int64_t r = r0 + rl;
+    const bool live = r < B;
+    float4 uq = make_float4(0.f, 0.f, 0.f, 0.f), tq = uq;
+    float sq = 0.f, cq = 0.f, t = 0.f;
+    int nh = 0;
+    uint32_t w[WPL], w0[WPL];
+#pragma unroll
+    for (int k = 0; k < WPL; ++k) w[k] = 0u;
+    if (live) {
+      for (int p = 0; p < a.nsplit; ++p) {                    // fixed order: bit-reproducible
+        sq += a.rs_part[(int64_t)p * B + r];
+        cq += a.cnt_part[(int64_t)p * B + r];
+      }
+      t = a.tscore[r];
+      uq = *reinterpret_cast<const float4*>(a.U + r * a.ldu + j * 4);
+      tq = *reinterpret_cast<const float4*>(a.T + r * a.ldt + j * 4);
+      nh = a.nhit[r];
+#pragma unroll
+      for (int k = 0; k < WPL; ++k)
+        if (k * LPR + j < nwords) w[k] = a.bits[(int64_t)(k * LPR + j) * a.ldbits + r];
+    }
+#pragma unroll
+    for (int k = 0; k < WPL; ++k) w0[k] = w[k];
+    if (__any(live && nh != 0)) {
+      // a slot the positives name twice is taken out once; jj / act are uniform over the sub-group
+      auto take_out = [&](int jj, bool act) {
+        const int wi = jj >> 5, own = wi % LPR, slot = wi / LPR;
+        uint32_t mine = w[0];
+#pragma unroll
+        for (int k = 1; k < WPL; ++k) mine = slot == k ? w[k] : mine;
+        const uint32_t word = __shfl(mine, gbase + own, 64);
+        const bool on = act && ((word >> (jj & 31)) & 1u);          // hinge active there (and not yet taken out)
+        float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) pr = *reinterpret_cast<const float4*>(a.P + (int64_t)jj * a.ldp + j * 4);
+        const float x = gsum(uq.x * pr.x + uq.y * pr.y + uq.z * pr.z + uq.w * pr.w) + ((on && a.pb) ? a.pb[jj] : 0.f);
+        const float v = x - t + 1.f;
+        if (on) {
+          sq -= v > 0.f ? v : 0.f;
+          cq -= 1.f;
+          if (j == own) {
+#pragma unroll
+            for (int k = 0; k < WPL; ++k)
+              if (slot == k) w[k] &= ~(1u << (jj & 31));
+          }
+        }
+      };
+      const bool listed = live && nh > 0;
+      const int myhit = (listed && j < nh) ? a.hits[r * kScHits + j] : 0;
+      for (int k = 0; k < kScHits; ++k) {
+        const bool act = listed && k < nh;
+        if (!__any(act)) break;
+        take_out(__shfl(myhit, gbase + k, 64), act);
+      }
+      const bool walk = live && nh < 0;                     // long list: walk the positives here
+      if (__any(walk)) {
+        const int usr = walk ? pm.user_ids[r % mask_rows] : 0;
+        const int beg = walk ? pm.pos_ptr[usr] : 0, end = walk ? pm.pos_ptr[usr + 1] : 0;
+        for (int p0 = beg;; p0 += LPR) {
+          const bool more = walk && p0 < end;
+          if (!__any(more)) break;
+          const int p = p0 + j;
+          int js = -1;
+          if (more && p < end) {
+            js = pos_slot(pm, pm.pos_items[p]);
+            if (js < 0 || js >= S) js = -1;
+          }
+          const unsigned long long bal = __ballot(js >= 0);
+          uint32_t hm = (uint32_t)((bal >> gbase) & ((LPR == 32) ? 0xffffffffull : 0xffffull));
+          while (__any(hm != 0u)) {                         // sub-groups drain their hit masks side by side
+            const bool act = hm != 0u;
+            const int src = act ? __builtin_ctz(hm) : 0;
+            hm &= hm - 1u;
+            take_out(__shfl(js, gbase + src, 64), act);
+          }
+        }
+      }
+      if (live && nh != 0) {
+#pragma unroll
+        for (int k = 0; k < WPL; ++k)
+          if (k * LPR + j < nwords && w[k] != w0[k]) a.bits[(int64_t)(k * LPR + j) * a.ldbits + r] = w[k];
+      }
+    }
+    // non-finite inputs poison the loss like an f32 chain would (the hinge itself drops a NaN logit: v > 0 is false)
+    sq = fmaxf(sq, 0.f) + (pbad + gsum(((uq.x + uq.y) + (uq.z + uq.w) + (tq.x + tq.y) + (tq.z + tq.w)) * 0.f) + t * 0.f);
+    const float g = live ? a.gscale * (a.row_w ? a.row_w[r] : 1.f) / (1.f + sq) : 0.f;
+    const float dt = -g * cq;
+    if (j == 0) {
+      sg[rl] = g;
+      if (live) {
+        if (a.batch_loss) a.batch_loss[r] = logf(1.f + sq);
+        if (a.dtscore) a.dtscore[r * a.dts_stride] = dt;
+      }
+      a.g_out[r] = g;                                 // (rows past B inside the padded length: 0)
+    }
+#pragma unroll
+    for (int k = 0; k < WPL; ++k)
+      if (k * LPR + j < nwords) sbits[rl * 64 + k * LPR + j] = w[k];
+    if (live) {
+      if (a.dT) *reinterpret_cast<float4*>(a.dT + r * a.lddt + j * 4) = make_float4(dt * uq.x, dt * uq.y, dt * uq.z, dt * uq.w);
+      if (a.dU) *reinterpret_cast<float4*>(a.dU + r * a.lddu + j * 4) = make_float4(dt * tq.x, dt * tq.y, dt * tq.z, dt * tq.w);
+    }
+    float* tp = tile + rl * ld + j * 4;
+    tp[0] = g * uq.x; tp[1] = g * uq.y; tp[2] = g * uq.z; tp[3] = g * uq.w;
+  }
+  __syncthreads();
+  // g U -> transposed planes, 32 consecutive k (= batch rows) per column n
+  sc_emit_planes_t(tile, ld, 32, a.d, a.UgT, (int64_t)a.d * a.ldug, a.ldug, r0, tid, 512);
+  // act bits transposed + the block's bias-gradient partials: as in k_sc_rows
+  uint32_t* tw = reinterpret_cast<uint32_t*>(tile);            // (the f32 tile is dead: planes emitted above)
+  __syncthreads();
+  for (int c0 = wv * 2; c0 < nwords; c0 += 16) {
+    const int c = c0 + (lane >> 5);
+    const uint32_t w = c < nwords ? sbits[(lane & 31) * 64 + c] : 0u;
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const unsigned long long bal = __ballot((w >> k) & 1u);
+      asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
+                   : "+v"(mine) : "s"((uint32_t)bal), "s"((uint32_t)(bal >> 32)), "n"(k), "n"(32 + k));
+    }
+    if (c < nwords) tw[c * 32 + (lane & 31)] = mine;
+  }
+  __syncthreads();
+  for (int col = tid; col < S; col += 512) {
+    const uint32_t word = tw[col];
+    float db = 0.f;
+#pragma unroll 1
+    for (int r4 = 0; r4 < 32; r4 += 4) {
+      const float4 g4 = *reinterpret_cast<const float4*>(&sg[r4]);
+      db += ((word >> r4) & 1u) ? g4.x : 0.f;
+      db += ((word >> (r4 + 1)) & 1u) ? g4.y : 0.f;
+      db += ((word >> (r4 + 2)) & 1u) ? g4.z : 0.f;
+      db += ((word >> (r4 + 3)) & 1u) ? g4.w : 0.f;
+    }
+    a.bitsT[(int64_t)blockIdx.x * a.ldbt + col] = word;
+    a.dbp[(int64_t)blockIdx.x * S + col] = db;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // k_sc_bits: C[m, n] (+)= sum_k act[m][k] X[k][n] with act a 0/1 matrix given as bits, word-major:
 // act[m][k] = bit (k & 31) of bits[(k >> 5) * ldw + m], and X as TRANSPOSED bf16 planes XT [3][N][ldx].
 // Workgroup = 256 m x 32 n x one K slice; compute wave = 64 m (two m-tiles) x the n-tile: per 16-chunk three plane
@@ -1809,7 +1983,10 @@ int arx_mw_scorer_fwd_seqw(const float* U, int64_t ldu, const float* P, int64_t 
              P, ldp, pbias, d, gscale, row_w, batch_loss, reinterpret_cast<float*>(st + L.g), dtscore,
              dtscore_stride > 0 ? dtscore_stride : 1, dU, lddu, dT, lddt, reinterpret_cast<uint16_t*>(st + L.UgT), L.ldug,
              reinterpret_cast<float*>(st + L.dbp), hits, nhit, reinterpret_cast<const float*>(st + L.pbad)};
-    k_sc_rows<<<(int)L.nblk, 512, 0, s>>>(a, pm, mrows, B, S);
+    static const bool rows_old = getenv("ARX_SC_ROWS_OLD") != nullptr;     // (A/B: the four-rows-in-a-row kernel)
+    if (!rows_old && d == 64) k_sc_rows_g<16><<<(int)L.nblk, 512, 0, s>>>(a, pm, mrows, B, S);
+    else if (!rows_old && d == 128) k_sc_rows_g<32><<<(int)L.nblk, 512, 0, s>>>(a, pm, mrows, B, S);
+    else k_sc_rows<<<(int)L.nblk, 512, 0, s>>>(a, pm, mrows, B, S);
     ARX_CHECK_LAUNCH();
   }
   return ARX_OK;
