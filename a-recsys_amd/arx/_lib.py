@@ -163,6 +163,13 @@ PROTOTYPES = {
                                                  f32p, f32p, f32p, i32p, i32p, f32p, vp, sz,
                                                  f32p, f32p, f32p, f32p, i64, i32p, i32p, i32p, cint, i32p,
                                                  vp, sz, vp]),
+    "arx_sparse_adagrad_cat_multi_bags_csc": (cint, [cint, cint, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                                     C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), cint, cint,
+                                                     C.POINTER(i32), C.POINTER(vp), C.POINTER(vp),
+                                                     C.POINTER(i64), C.POINTER(i32), C.POINTER(f32), f32p, i64,
+                                                     f32p, f32p, f32p, i32p, i32p, f32p, vp, sz,
+                                                     f32p, f32p, f32p, f32p, i64, i32p, i32p, i32p, cint, i32p,
+                                                     vp, sz, i32p, i32p, vp, i32p, i64, vp]),
     "arx_sparse_adagrad_bags_workspace_bytes": (sz, [i64, cint, cint]),
     "arx_sparse_adagrad_bags": (cint, [cint, f32p, f32p, f32p, f32p, i64, cint, i32p, i32p, i32p, i64, cint,
                                        cint, C.POINTER(vp), C.POINTER(i64), C.POINTER(i32), C.POINTER(f32),

@@ -1326,12 +1326,24 @@ class Plan(object):
             else:
                 starts_r, lens_r = self._rider_csr(group[0][1][0].maps[0], s0.maps[1], s0.maps[2],
                                                    int(group[0][0][0].E.shape[0]))
+            max_len = max(x.max_len for x in bag_live)
+            if 'csc' not in ent:
+                # static token order of the bags (ops.BagCSC: built once per bag index), flags / slots per pass
+                ent['csc'] = None
+                if rt.csc_mode == '1' or (rt.csc_mode != '0' and bag_virtual):
+                    cache = self.__dict__.setdefault('_csc_cache', {})
+                    ck2 = (s0.maps[0].data_ptr(), starts_r.data_ptr(), lens_r.data_ptr(), max_len, int(bt.E.shape[0]))
+                    if ck2 not in cache:
+                        cache[ck2] = ops.BagCSC(s0.maps[0], starts_r, lens_r, max_len, int(bt.E.shape[0]))
+                    if cache[ck2].ok:
+                        ent['csc'] = (cache[ck2],) + cache[ck2].scratch()
             ops.sparse_adagrad_cat_multi_bags(
                 args, node0.arena, node0.arena_b if (ent['any_bias'] or bag_bias) else None, rt.lr,
                 ent['keys'], ent['src'], ent['coef'], ent['ws'], bt.E, None if sgd else bt.acc,
                 bt.bias if bag_bias else None, bt.bias_acc if (bag_bias and not sgd) else None,
-                s0.maps[0], starts_r, lens_r, max(x.max_len for x in bag_live), ent['bag_ws'],
-                gscale_dev=rt.clip_coef_dev, phase=phase, bag_aux_cnt=self._aux_cnt(bt))
+                s0.maps[0], starts_r, lens_r, max_len, ent['bag_ws'],
+                gscale_dev=rt.clip_coef_dev, phase=phase, bag_aux_cnt=self._aux_cnt(bt), csc=ent['csc'],
+                split=rt.rider_split(ent['csc'] is not None, bool(bag_virtual)))
             return
         ops.sparse_adagrad_cat_multi(args, node0.arena, node0.arena_b if ent['any_bias'] else None,
                                      rt.lr, ent['keys'], ent['src'], ent['coef'], ent['ws'],
@@ -1704,7 +1716,21 @@ class Runtime(object):
         self.no_bags = False             # contribution-level multi-hot pass
         self.no_rider = False            # the bag table keeps its own two-stage pass
         self.no_virtual = False          # ... unless an id table shares its lookups
+        # round 6: the riding bag table's tokens in their STATIC order (csrc/csc.hip) instead of a sort per step.
+        # Measured (profiles/r06_csc_ab.txt, alternating runs on one box): MIX layout (virtual entity table) 250 ->
+        # 236 us per step, HET 231 -> 235..239 -- so: ARX_K7_CSC unset = where the entity table is virtual, 1 = every
+        # riding bag table, 0 = the per-step expansion + radix sort of rounds 2-6 everywhere
+        self.csc_mode = os.environ.get('ARX_K7_CSC', 'auto')
         self.dp = None                  # arx.dist.SeqDataParallel: gradient exchange between replicas
+
+    def rider_split(self, csc, virtual):
+        """The apply form of a pass with a riding bag table (arx.h, ARX_K7_RIDER): the environment's choice if it
+        makes one; else `split` (entity runs, then ONE launch with the token runs and the other tables' runs) where the
+        step's sort branch has room for the one-hot list's run records -- with the static token order -- and `win`
+        (window + finish + token apply) otherwise.  Measured: profiles/r06_csc_ab.txt."""
+        if os.environ.get('ARX_K7_RIDER') in ('win', 'split'):
+            return None
+        return bool(csc)
 
     def drop_feed(self, dst):
         """Forget queued feeds whose destination is `dst` (same start address: placeholders and

@@ -698,7 +698,7 @@ def sparse_adagrad_cat_multi(args, G, Gb, lr_dev, keys_buf, src_buf, coef_buf, w
 
 def sparse_adagrad_cat_multi_bags(args, G, Gb, lr_dev, keys_buf, src_buf, coef_buf, ws, bag_E, bag_acc,
                                   bag_bias, bag_bias_acc, vals, starts, lens, max_len, bag_ws,
-                                  gscale_dev=None, phase=3, bag_aux_cnt=None):
+                                  gscale_dev=None, phase=3, bag_aux_cnt=None, csc=None, split=None):
     """arx_sparse_adagrad_cat_multi with a multi-hot table riding on it: the lookups of one-hot
     table 0 are also the lookups of the bags of table bag_E -- an item's id row and its multi-hot
     attribute (HET layout); starts / lens are indexed by the ROW of table 0 (arx.h).  Same phases as
@@ -707,12 +707,66 @@ def sparse_adagrad_cat_multi_bags(args, G, Gb, lr_dev, keys_buf, src_buf, coef_b
     n0 = sum(int(args.count[q]) for q in range(args.ns) if int(args.site_table[q]) == 0)
     wsp, wsn = ws.get(_lib.lib.arx_sparse_adagrad_workspace_bytes(args.total))
     bwp, bwn = bag_ws.get(_lib.lib.arx_sparse_adagrad_bags_workspace_bytes(max(n0, 1), int(max_len), args.d))
-    call("arx_sparse_adagrad_cat_multi_bags", int(phase), args.nt, args.E, args.acc, args.bias,
+    # csc: (BagCSC, flags, slot_of) -- the table's static token order (no expansion, no token sort in the step)
+    cs, flags, slot_of = csc if csc is not None else (None, None, None)
+    # split: this pass's apply form (True `split`, False `win`, None: the process default ARX_K7_RIDER) -- arx.h
+    form = 0 if split is None else (0x100 if split else 0x200)
+    call("arx_sparse_adagrad_cat_multi_bags_csc", int(phase) | form, args.nt, args.E, args.acc, args.bias,
          args.bias_acc, args.rows, args.cnt, args.d, args.ns, args.site_table, args.cat_map, args.ids,
          args.count, args.row_base, args.coef, _p(G), _ld(G), _p(Gb), _p(lr_dev), _p(gscale_dev),
          _p(keys_buf), _p(src_buf), _p(coef_buf), wsp, wsn, _p(bag_E), _p(bag_acc), _p(bag_bias),
          _p(bag_bias_acc), int(bag_E.shape[0]), _p(vals), _p(starts), _p(lens), int(max_len),
-         _p(bag_aux_cnt), bwp, bwn, _stream())
+         _p(bag_aux_cnt), bwp, bwn, _p(cs.qpos) if cs is not None else None,
+         _p(cs.qte) if cs is not None else None, _p(flags), _p(slot_of), cs.nq if cs is not None else 0,
+         _stream())
+
+
+class BagCSC(object):
+    """The STATIC token-major order of a multi-hot table's bags (csrc/csc.hip; arx.h,
+    arx_sparse_adagrad_cat_multi_bags_csc): built once per (bag index, max_len) on the host from the
+    feature CSR of attributes/attribute.py (embed_attribute.py:265-318 uploads it once and never
+    changes it).  Pairs are enumerated by (entity, position in bag) and ordered by token with a stable
+    sort -- the order the per-step stable radix sort of the expanded bags produced, so the token
+    sums keep their bits.  ok == False: a CSR position belongs to two bags (no place of its own)."""
+
+    def __init__(self, vals, starts, lens, max_len, table_rows):
+        import numpy as np
+        dev = vals.device
+        v = vals.detach().cpu().numpy()
+        st = starts.detach().cpu().numpy().astype(np.int64)
+        ln = np.clip(lens.detach().cpu().numpy().astype(np.int64), 0, int(max_len))
+        n_ent, nv = int(ln.shape[0]), int(v.shape[0])
+        st = st[:n_ent]
+        tot = int(ln.sum())
+        ent = np.repeat(np.arange(n_ent, dtype=np.int32), ln)
+        pos = np.repeat(st - (np.cumsum(ln) - ln), ln) + np.arange(tot, dtype=np.int64)   # CSR position of every pair
+        keep = (pos >= 0) & (pos < nv)
+        tok = np.full(tot, -1, dtype=np.int64)
+        tok[keep] = v[pos[keep]]
+        keep &= (tok >= 0) & (tok < int(table_rows))
+        pos, ent, tok = pos[keep], ent[keep], tok[keep].astype(np.int32)
+        # stable order by token: LSD passes over 16-bit digits (numpy's stable sort is a radix sort for those)
+        order = np.argsort((tok & 0xffff).astype(np.uint16), kind='stable')
+        if int(table_rows) > (1 << 16):
+            order = order[np.argsort((tok[order] >> 16).astype(np.uint16), kind='stable')]
+        nq = int(order.shape[0])
+        qpos = np.full(max(nv, 1), -1, dtype=np.int32)
+        ps = pos[order]
+        qpos[ps] = np.arange(nq, dtype=np.int32)
+        self.ok = bool(nq < (1 << 31) and np.array_equal(qpos[ps], np.arange(nq, dtype=np.int32)))
+        self.nq, self.n_ent = nq, n_ent
+        qte = np.empty((max(nq, 1), 2), dtype=np.int32)
+        qte[:nq, 0] = tok[order]
+        qte[:nq, 1] = ent[order]
+        self.qpos = torch.from_numpy(qpos).to(dev)
+        self.qte = torch.from_numpy(qte).to(dev)
+
+    def scratch(self):
+        """Per-pass device state: the flag bytes (zero between steps) and the entity -> merged-row map."""
+        dev = self.qpos.device
+        fb = (self.nq + 255) // 256 * 256          # flag bytes + one coarse byte per 16 of them (arx.h)
+        return (torch.zeros(fb + fb // 16, dtype=torch.uint8, device=dev),
+                torch.zeros(max(self.n_ent, 1), dtype=torch.int32, device=dev))
 
 
 class BagSiteArgs(object):

@@ -114,6 +114,7 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
 
 // A multi-hot table riding on a one-hot pass (arx_sparse_adagrad_cat_multi_bags): the lookups of
 // one-hot table 0 of the pass are also the entity lookups of this table's bags.
+struct BagCsc;
 struct BagStage {
   float* E;
   float* acc;
@@ -127,6 +128,8 @@ struct BagStage {
   int32_t* aux_cnt;                // per-token-row ticket counters (may be null)
   void* ws;                        // arx_sparse_adagrad_bags_workspace_bytes(lookups of table 0, max_len, d)
   size_t ws_bytes;
+  const BagCsc* csc;               // static token order of the bags (csc.hip), or null: sort the tokens every step
+  int rider;                       // form of the apply: -1 the process default (ARX_K7_RIDER), 0 win, 1 split
 };
 
 // gemm_nt.hip: logits GEMM with the A operand register-resident (K in {32,64,128});

@@ -109,6 +109,9 @@ struct MergeOut {
   // the bag's token stage needs no entity sort and no merge pass of its own.
   int table;
   int kb;                  // row bits of the key (side output: key = (table << kb) | entity)
+  // csc.hip: the row of Gu an entity's merged gradient goes to (null: the head's sorted position) -- the
+  // static token order addresses Gu through this map, written by k_csc_mark from the step's lookups
+  const int32_t* slot_of;
 };
 
 __device__ __forceinline__ bool merge_side(const MergeOut& mo, uint32_t key) {
@@ -118,11 +121,34 @@ __device__ __forceinline__ bool merge_side(const MergeOut& mo, uint32_t key) {
 __device__ __forceinline__ void merge_row(const MergeOut& mo, int d, uint32_t key, int64_t head_pos, int col,
                                           bool colok, int lig, float4 g, float gb) {
   const float inv = 1.f / (float)mo.lens[key];
+  if (mo.slot_of) head_pos = mo.slot_of[key];
   if (colok)
     *reinterpret_cast<float4*>(mo.Gu + head_pos * (int64_t)d + col) =
         make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
   if (mo.Gub && lig == 0) mo.Gub[head_pos] = gb * inv;
 }
+
+// csc.hip: the static token-major order of a multi-hot table's bags (built once per table: arx/ops.py BagCSC)
+struct BagCsc {
+  const int32_t* qpos;     // [len(vals)] CSR position -> place in the token-major order (-1: token out of range)
+  const int2* qte;         // [nq] {token row, entity} of every place
+  uint8_t* flags;          // [nq rounded up to 256] live pairs of the step; zero between steps
+  uint8_t* cflags;         // [flags bytes / 16] one coarse byte per 16 places (a 16-byte flag word); zero between steps
+  int32_t* slot_of;        // [entities] row of the merged gradients Gu of an entity of the step
+  int64_t nq;
+};
+struct MarkSites {         // the entity lookups of the step (the sites of table 0 of the one-hot pass)
+  int n;
+  const int32_t* ids[kMaxSites];
+  const int32_t* cat_map[kMaxSites];
+  int64_t offs[kMaxSites + 1];
+  int64_t rows;            // entities (rows of table 0)
+};
+int launch_csc_mark(const MarkSites& ms, const BagCsc& csc, const int32_t* starts, const int32_t* lens,
+                    int max_len, int32_t* zero_i, int n_zero_i, void* zero_l, int n_zero_l, hipStream_t s);
+int csc_compact_blocks(int64_t nq);
+int launch_csc_compact(const BagCsc& csc, uint32_t* sk, int32_t* ssrc, float* scoef, int64_t cap,
+                       int32_t* n_out, void* lookback, hipStream_t s);
 
 // group.hip: run records of a radix-sorted pass + the run-centric apply (d >= 32).
 enum { kNRuns = 0, kNLong = 2, kNItems = 3, kNPart = 4, kNRuns0 = 5 };   // counters of a pass (ints, zeroed by the sort)

@@ -1370,7 +1370,7 @@ static int launch_apply(const TableSet& ts, int d, const uint32_t* sk, const uin
 namespace {
 struct BagWs {
   SparseWs wi, wt;                        // sort / apply workspaces of the two stages
-  size_t off_wi, off_wt, off_ikeys, off_isrc, off_icoef, off_tkeys, off_tsrc, off_gu, off_gub, off_hoff, total;
+  size_t off_wi, off_wt, off_ikeys, off_isrc, off_icoef, off_tkeys, off_tsrc, off_gu, off_gub, off_hoff, off_csc_lb, total;
 };
 int bag_ws_layout(int64_t n_i, int max_len, int d, BagWs* w) {
   const int64_t n_t = n_i * (int64_t)max_len;
@@ -1387,6 +1387,7 @@ int bag_ws_layout(int64_t n_i, int max_len, int d, BagWs* w) {
   w->off_gu = o; o += align_up((size_t)n_i * (size_t)d * 4, 256);
   w->off_gub = o; o += align_up((size_t)n_i * 4, 256);
   w->off_hoff = o; o += align_up((size_t)(n_i + 64) * 4, 256);       // head offsets of the compacted expansion + its total
+  w->off_csc_lb = o; o += 1024 * 8;                                  // look-back cells of the static-order sweep (csc.hip)
   w->total = o;
   return ARX_OK;
 }
@@ -1446,6 +1447,52 @@ int bag_token_sort(const BagWs& w, char* base, const uint32_t* sk_ent, int64_t n
   if (rc || !runs_path(d)) return rc;
   const RunLists rl = run_lists_of(bt + w.wt.off_runs, n_t, 256, ssrc_t, scoef_t, count_t + 8);
   return launch_runs_extract(sk_t, n_t, count_t + 2, sent_t, rl, d, s);
+}
+
+// Stage 1b with the table's STATIC token order (csc.hip): no expansion, no sort -- mark the live pairs from the
+// step's entity lookups, sweep them out in place order, extract the run records.  Depends on the lookup ids only
+// (not on the one-hot sort of the pass).
+bool csc_path(const BagStage* bag, int64_t n_i, int d) {
+  return bag && bag->csc && runs_path(d) && n_i * (int64_t)bag->max_len > kRankSortMax;
+}
+// part 0: the marks (phase A of the pass: the one-hot apply reads slot_of, and it only waits for phase A);
+// part 1: the sweep + the run records (phase B)
+int csc_token_sort(const BagWs& w, char* base, const CatSites& st, int64_t n_i, const BagStage& bag, int d,
+                   hipStream_t s, int part) {
+  const int64_t n_t = n_i * (int64_t)bag.max_len;
+  char* bt = base + w.off_wt;
+  uint32_t* sk_t = reinterpret_cast<uint32_t*>(bt + w.wt.off_keys_out);
+  int32_t* ssrc_t = reinterpret_cast<int32_t*>(bt + w.wt.off_ssrc);
+  float* scoef_t = reinterpret_cast<float*>(bt + w.wt.off_scoef);
+  int32_t* count_t = reinterpret_cast<int32_t*>(bt + w.wt.off_count);
+  void* lb = base + w.off_csc_lb;
+  // timing-only ablation (WRONG results): ARX_ABL_CSC_SKIP=1 -- after the first call only the marks go out (the token
+  // apply walks the first batch's list): what the step would cost if the apply read the flags itself
+  static const bool abl_skip = getenv("ARX_ABL_CSC_SKIP") != nullptr;
+  static int abl_calls = 0;
+  if (part == 0) {
+    MarkSites ms = {};
+    ms.rows = st.rows[0];
+    ms.offs[0] = 0;
+    for (int q = 0; q < st.nsites; ++q) {
+      if (st.table[q] != 0) continue;
+      ms.ids[ms.n] = st.ids[q];
+      ms.cat_map[ms.n] = st.cat_map[q];
+      ms.offs[ms.n + 1] = ms.offs[ms.n] + (st.offs[q + 1] - st.offs[q]);
+      ++ms.n;
+    }
+    for (int q = ms.n; q < kMaxSites; ++q) ms.offs[q + 1] = ms.offs[ms.n];
+    const bool skip = abl_skip && abl_calls++ >= 1;
+    return launch_csc_mark(ms, *bag.csc, bag.starts, bag.lens, bag.max_len, count_t, skip ? 0 : 512, lb,
+                           skip ? 0 : 1024, s);
+  }
+  if (abl_skip && abl_calls > 1) return ARX_OK;
+  int kbt = 1;
+  while ((1ll << kbt) < bag.rows && kbt < 30) ++kbt;
+  int rc = launch_csc_compact(*bag.csc, sk_t, ssrc_t, scoef_t, n_t, count_t + 2, lb, s);
+  if (rc) return rc;
+  const RunLists rl = run_lists_of(bt + w.wt.off_runs, n_t, 256, ssrc_t, scoef_t, count_t + 8);
+  return launch_runs_extract(sk_t, n_t, count_t + 2, 1u << kbt, rl, d, s);
 }
 
 // Stage 2b: token runs over the merged rows Gu (every coefficient is 1) -> Adagrad.
@@ -1511,7 +1558,11 @@ static int rider_mode() {
   }();
   return mode;
 }
-static bool rider_records(bool hoff_ok) { return hoff_ok && rider_mode() != kRiderWin; }
+// (bag->rider >= 0: the caller's choice for this pass -- bit 0x100 of the entry point's phase argument)
+static bool rider_records(bool hoff_ok, const BagStage* bag) {
+  const int mode = (bag && bag->rider >= 0) ? bag->rider : rider_mode();
+  return hoff_ok && mode != kRiderWin;
+}
 
 int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const CatSites& st,
                                 const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
@@ -1606,6 +1657,11 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
     }
     bbase = reinterpret_cast<char*>(bag->ws);
   }
+  const bool csc = n_dev && csc_path(bag, n0, d);      // static token order: no bag offsets, no token sort
+  if (csc && (mask & 1)) {        // the marks: part of the first quarter (the one-hot apply reads slot_of)
+    rc = csc_token_sort(bw, bbase, st, n0, *bag, d, s, 0);
+    if (rc) return rc;
+  }
   const bool hoff_ok = bag && n_dev && rider_hoff_ok(n, n0, bag->max_len, d);
   if (sorted_runs) {
     // run records of the one-hot list -- unless a bag table rides on it: then the sort branch of the step has
@@ -1615,8 +1671,8 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
     const bool hoff = hoff_ok;
     int32_t* hp = hoff ? reinterpret_cast<int32_t*>(bbase + bw.off_hoff) : nullptr;
     RunLists rl = run_lists_of(base + w.off_runs, n, 256, ssrc, scoef, count + 8);
-    if (bag && !rider_records(hoff_ok)) rl.R = nullptr;
-    if (!bag || hoff) {
+    if (bag && !rider_records(hoff_ok, bag)) rl.R = nullptr;
+    if (!bag || (hoff && (!csc || rl.R))) {      // (static token order: the sweep is only wanted for the records)
       rc = launch_runs_extract(keys_out, n, count + 2, sentinel, rl, d, s, hoff ? bag->lens : nullptr, ts.kb, 0u,
                                bag ? bag->max_len : 0, hp, n0, hoff ? hp + n0 : nullptr, count + 32);
       if (rc) return rc;
@@ -1624,8 +1680,9 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   }
   have_hoff = hoff_ok;
   if (bag && (mask & 2)) {
-    rc = bag_token_sort(bw, bbase, keys_out, n0, n_dev, sentinel, ts.kb, 0u, bag->vals, bag->starts,
-                        bag->lens, bag->max_len, bag->rows, d, s, have_hoff);
+    rc = csc ? csc_token_sort(bw, bbase, st, n0, *bag, d, s, 1)
+             : bag_token_sort(bw, bbase, keys_out, n0, n_dev, sentinel, ts.kb, 0u, bag->vals, bag->starts,
+                              bag->lens, bag->max_len, bag->rows, d, s, have_hoff);
     if (rc) return rc;
   }
   if (!(mask & 12)) return ARX_OK;
@@ -1633,14 +1690,15 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
   for (int t = 0; t < ntables; ++t) any_bias = any_bias || ts.bias[t] != nullptr;
   const float* gb_in = any_bias ? Gb : nullptr;
   MergeOut side = {nullptr, nullptr, nullptr, -1, 0};
-  if (bag)
-    side = MergeOut{reinterpret_cast<float*>(bbase + bw.off_gu),
-                    bag->bias ? reinterpret_cast<float*>(bbase + bw.off_gub) : nullptr, bag->lens, 0, ts.kb};
+  float* gu = bag ? reinterpret_cast<float*>(bbase + bw.off_gu) : nullptr;
+  float* gub = bag ? reinterpret_cast<float*>(bbase + bw.off_gub) : nullptr;
+  if (bag)      // (static token order: the rows of Gu are addressed through slot_of, not by sorted head position)
+    side = MergeOut{gu, bag->bias ? gub : nullptr, bag->lens, 0, ts.kb, csc ? bag->csc->slot_of : nullptr};
   const RunLists rl_sites = run_lists_of(base + w.off_runs, n, 256, ssrc, scoef, count + 8);
   rc = ARX_OK;
   bool sgd_sites = ts.acc[0] == nullptr;
   if (!ts.E[0] && ts.E[1]) sgd_sites = ts.acc[1] == nullptr;
-  if (bag && n_dev && runs_path(d) && rider_records(hoff_ok) && n0 * (int64_t)bag->max_len > kRankSortMax &&
+  if (bag && n_dev && runs_path(d) && rider_records(hoff_ok, bag) && n0 * (int64_t)bag->max_len > kRankSortMax &&
       sgd_sites == (bag->acc == nullptr)) {
     // Round 5: the rider's one-hot pass on run records too, cut where the data flow allows --
     //   C  the ENTITY table's runs (records [0, ctr[kNRuns0]): the records are in sorted order, k_runs_extract's
@@ -1666,8 +1724,8 @@ int sparse_adagrad_sites_sorted(const TableSet& ts, int ntables, int d, const Ca
                                        reinterpret_cast<float*>(bt + bw.wt.off_scoef), count_t + 8);
     const MergeOut none = {nullptr, nullptr, nullptr, -1, 0};
     return launch_run_apply_pair(ts, ntables > 1, rl_sites, n - n0 > 0 ? n - n0 : 1, G, ldg, gb_in, none,
-                                 ApplySel{kNRuns0, -1, -2}, tt, rl_t, n_t, reinterpret_cast<float*>(bbase + bw.off_gu),
-                                 d, bag->bias ? reinterpret_cast<float*>(bbase + bw.off_gub) : nullptr, d, lr_dev,
+                                 ApplySel{kNRuns0, -1, -2}, tt, rl_t, n_t, gu,
+                                 d, bag->bias ? gub : nullptr, d, lr_dev,
                                  gscale_dev, sgd_sites, s);
   }
   if (mask & 4)

@@ -17,6 +17,7 @@
 #include <limits.h>
 
 #include "common.h"
+#include "k7.h"
 
 namespace arx {
 
@@ -478,6 +479,45 @@ int arx_sparse_adagrad_cat_multi_phase(int phase, int ntables, float* const* E, 
                         workspace_bytes, stream);
 }
 
+int arx_sparse_adagrad_cat_multi_bags_csc(int phase, int ntables, float* const* E, float* const* acc,
+                                      float* const* bias, float* const* bias_acc,
+                                      const int64_t* table_rows, int32_t* const* aux_cnt, int d,
+                                      int nsites, const int32_t* site_table,
+                                      const int32_t* const* site_cat_map,
+                                      const int32_t* const* site_ids, const int64_t* site_n,
+                                      const int32_t* site_row_base, const float* site_coef,
+                                      const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
+                                      const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
+                                      float* coef_buf, void* workspace, size_t workspace_bytes,
+                                      float* bag_E, float* bag_acc, float* bag_bias, float* bag_bias_acc,
+                                      int64_t bag_rows, const int32_t* vals, const int32_t* starts,
+                                      const int32_t* lens, int max_len, int32_t* bag_aux_cnt,
+                                      void* bag_workspace, size_t bag_workspace_bytes,
+                                          const int32_t* csc_qpos, const int32_t* csc_qte, uint8_t* csc_flags,
+                                          int32_t* csc_slot_of, int64_t csc_nq, void* stream) {
+  const int rider = (phase & 0x100) ? 1 : (phase & 0x200) ? 0 : -1;     // this pass's apply form (arx.h)
+  phase &= 0xff;
+  ARX_CHECK_ARG((phase >= 1 && phase <= 3) || (phase >= 5 && phase <= 8),
+                "arx_sparse_adagrad_cat_multi_bags_csc: phase 1, 2, 3 or the quarter phases 5 .. 8");
+  ARX_CHECK_ARG(bag_E && vals && starts && lens && bag_rows > 0 && max_len > 0 && bag_workspace,
+                "arx_sparse_adagrad_cat_multi_bags_csc: null pointer / bad sizes");
+  ARX_CHECK_ARG(bag_acc ? (bag_bias == nullptr) == (bag_bias_acc == nullptr) : bag_bias_acc == nullptr,
+                "arx_sparse_adagrad_cat_multi_bags_csc: bag bias and bias_acc go together");
+  ARX_CHECK_ARG(!(bag_bias && !Gb), "arx_sparse_adagrad_cat_multi_bags_csc: bag bias given without Gb");
+  ARX_CHECK_ARG(!csc_qpos || (csc_qte && csc_flags && csc_slot_of && csc_nq >= 0 && csc_nq < (1ll << 31)),
+                "arx_sparse_adagrad_cat_multi_bags_csc: incomplete static token order");
+  const int64_t csc_fb = (csc_nq + 255) / 256 * 256;     // flag bytes, then their coarse bytes (one per 16)
+  BagCsc csc = {csc_qpos, reinterpret_cast<const int2*>(csc_qte), csc_flags, csc_flags ? csc_flags + csc_fb : nullptr,
+                csc_slot_of, csc_nq};
+  BagStage bag = {bag_E, bag_acc, bag_bias, bag_bias_acc, bag_rows, vals, starts, lens, max_len, bag_aux_cnt,
+                  bag_workspace, bag_workspace_bytes, csc_qpos ? &csc : nullptr, rider};
+  return cat_multi_impl(phase, ntables, E, acc, bias, bias_acc, table_rows, aux_cnt, d, nsites, site_table,
+                        site_cat_map, site_ids, site_n, site_row_base, site_coef, G, ldg, Gb, lr_dev,
+                        gscale_dev, keys_buf, src_buf, coef_buf, 0, nullptr, nullptr, workspace,
+                        workspace_bytes, stream, &bag);
+}
+
+
 int arx_sparse_adagrad_cat_multi_bags(int phase, int ntables, float* const* E, float* const* acc,
                                       float* const* bias, float* const* bias_acc,
                                       const int64_t* table_rows, int32_t* const* aux_cnt, int d,
@@ -492,19 +532,12 @@ int arx_sparse_adagrad_cat_multi_bags(int phase, int ntables, float* const* E, f
                                       int64_t bag_rows, const int32_t* vals, const int32_t* starts,
                                       const int32_t* lens, int max_len, int32_t* bag_aux_cnt,
                                       void* bag_workspace, size_t bag_workspace_bytes, void* stream) {
-  ARX_CHECK_ARG((phase >= 1 && phase <= 3) || (phase >= 5 && phase <= 8),
-                "arx_sparse_adagrad_cat_multi_bags: phase 1, 2, 3 or the quarter phases 5 .. 8");
-  ARX_CHECK_ARG(bag_E && vals && starts && lens && bag_rows > 0 && max_len > 0 && bag_workspace,
-                "arx_sparse_adagrad_cat_multi_bags: null pointer / bad sizes");
-  ARX_CHECK_ARG(bag_acc ? (bag_bias == nullptr) == (bag_bias_acc == nullptr) : bag_bias_acc == nullptr,
-                "arx_sparse_adagrad_cat_multi_bags: bag bias and bias_acc go together");
-  ARX_CHECK_ARG(!(bag_bias && !Gb), "arx_sparse_adagrad_cat_multi_bags: bag bias given without Gb");
-  BagStage bag = {bag_E, bag_acc, bag_bias, bag_bias_acc, bag_rows, vals, starts, lens, max_len, bag_aux_cnt,
-                  bag_workspace, bag_workspace_bytes};
-  return cat_multi_impl(phase, ntables, E, acc, bias, bias_acc, table_rows, aux_cnt, d, nsites, site_table,
-                        site_cat_map, site_ids, site_n, site_row_base, site_coef, G, ldg, Gb, lr_dev,
-                        gscale_dev, keys_buf, src_buf, coef_buf, 0, nullptr, nullptr, workspace,
-                        workspace_bytes, stream, &bag);
+  return arx_sparse_adagrad_cat_multi_bags_csc(phase, ntables, E, acc, bias, bias_acc, table_rows, aux_cnt, d, nsites,
+                                               site_table, site_cat_map, site_ids, site_n, site_row_base, site_coef,
+                                               G, ldg, Gb, lr_dev, gscale_dev, keys_buf, src_buf, coef_buf, workspace,
+                                               workspace_bytes, bag_E, bag_acc, bag_bias, bag_bias_acc, bag_rows, vals,
+                                               starts, lens, max_len, bag_aux_cnt, bag_workspace, bag_workspace_bytes,
+                                               nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -681,6 +681,39 @@ int arx_sparse_adagrad_cat_multi_bags(int phase, int ntables, float* const* E, f
                                       void* bag_workspace, size_t bag_workspace_bytes, void* stream);
 
 
+/* arx_sparse_adagrad_cat_multi_bags with the riding table's STATIC token order (csc.hip).  The bag index
+ * (attributes/attribute.py: the feature CSR built once by _init_attributes, embed_attribute.py:265-318) never
+ * changes, so the token-major order of its (token, entity) pairs is built ONCE per table by the caller:
+ *   csc_qpos  int32[len(vals)]  CSR position p = starts[r] + j -> place q of the pair in the order sorted by
+ *                               (token, p); -1 for tokens outside [0, bag_rows) and for positions past max_len;
+ *   csc_qte   int32[2 * csc_nq] {token row, row of table 0} of every place;
+ *   csc_flags uint8[F + F / 16], F = csc_nq rounded up to 256: one flag byte per place, then one coarse byte per
+ *             16 places; ZERO on entry of phase 5 and zero again on return of phase 6 (1 and 3 hold both);
+ *   csc_slot_of int32[table_rows[0]] scratch (row of the merged gradients of an entity of the step).
+ * The step then neither expands nor sorts: phase 5 also marks the live pairs from the lookups of table 0, phase 6
+ * sweeps the flags out in place order (= the token-sorted list, entries of a token in (entity, position) order --
+ * for a standard CSR the order the stable sort produced: same bits) and extracts the run records -- 3 launches for
+ * 8 (the marks belong to phase 5 because phase 7 reads csc_slot_of and only waits for phase 5).  Used when csc_qpos != NULL, d >= 32 and lookups * max_len > 8192; otherwise
+ * (and with csc_qpos == NULL) identical to arx_sparse_adagrad_cat_multi_bags.
+ * phase: the phase number, optionally | 0x100 (this pass applies in the `split` form) or | 0x200 (`win`), whatever
+ * ARX_K7_RIDER says -- the same bits in every phase of a pass. */
+int arx_sparse_adagrad_cat_multi_bags_csc(int phase, int ntables, float* const* E, float* const* acc,
+                                          float* const* bias, float* const* bias_acc,
+                                          const int64_t* table_rows, int32_t* const* aux_cnt, int d,
+                                          int nsites, const int32_t* site_table,
+                                          const int32_t* const* site_cat_map,
+                                          const int32_t* const* site_ids, const int64_t* site_n,
+                                          const int32_t* site_row_base, const float* site_coef,
+                                          const float* G, int64_t ldg, const float* Gb, const float* lr_dev,
+                                          const float* gscale_dev, int32_t* keys_buf, int32_t* src_buf,
+                                          float* coef_buf, void* workspace, size_t workspace_bytes,
+                                          float* bag_E, float* bag_acc, float* bag_bias, float* bag_bias_acc,
+                                          int64_t bag_rows, const int32_t* vals, const int32_t* starts,
+                                          const int32_t* lens, int max_len, int32_t* bag_aux_cnt,
+                                          void* bag_workspace, size_t bag_workspace_bytes,
+                                          const int32_t* csc_qpos, const int32_t* csc_qte, uint8_t* csc_flags,
+                                          int32_t* csc_slot_of, int64_t csc_nq, void* stream);
+
 /* Multi-hot lookups of ONE table (embed_attribute.py:397-406: embedding_lookup of the bag
  * tokens + unsorted_segment_sum / length; hmf_model.py:146-151 one Adagrad apply per variable),
  * in two merge stages so that an entity that occurs k times in a step (Zipf-popular target

@@ -1289,7 +1289,12 @@ def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, p
     tmap = _t(dev, map_pad)
     tG, tGb = _t(dev, G), _t(dev, Gb)
     outs = []
-    for rep in range(2):
+    # rep 2 (round 6): the bag table's STATIC token order (ops.BagCSC, csrc/csc.hip) instead of expansion + sort --
+    # same lists, same bits; its flag bytes are zero again after every pass
+    cs = ops.BagCSC(tv, tst, tl, max_len, Vf)
+    assert cs.ok
+    csc = (cs,) + cs.scratch()
+    for rep in range(3):
         D_it, D_us, D_bag = [[_t(dev, x) for x in tab] for tab in (T_it, T_us, T_bag)]
         cnts = [torch.zeros(n_rows0, dtype=torch.int32, device=dev), torch.zeros(n_user, dtype=torch.int32, device=dev)]
         if sgd:
@@ -1314,8 +1319,10 @@ def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, p
         for ph in phases:
             ops.sparse_adagrad_cat_multi_bags(args, tG, tGb, lr_dev, kb_, sb_, cb_, ws, D_bag[0], D_bag[1],
                                               D_bag[2], D_bag[3], tv, tst, tl, max_len, bws,
-                                              gscale_dev=gs_dev, phase=ph, bag_aux_cnt=bcnt if maps else None)
+                                              gscale_dev=gs_dev, phase=ph, bag_aux_cnt=bcnt if maps else None,
+                                              csc=csc if rep == 2 else None)
         torch.cuda.synchronize()
+        assert int(csc[1].sum().item()) == 0
         assert int(bcnt.abs().sum().item()) == 0 and all(int(c.abs().sum().item()) == 0 for c in cnts)
         assert int(vcnt.abs().sum().item()) == 0
         outs.append(D_it + D_us + D_bag)
@@ -1323,8 +1330,8 @@ def test_sparse_adagrad_cat_multi_bags(dev, d, n_ent, n_user, Vf, max_len, ns, p
     for got, want in zip(outs[0], want_it + list(R_us) + list(R_bag)):
         if got is not None:
             np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=2e-5)
-    for a, b in zip(outs[0], outs[1]):                 # bit-reproducible
-        assert a is None or torch.equal(a, b)
+    for a, b, c in zip(*outs):                         # bit-reproducible; the static token order: same bits
+        assert a is None or (torch.equal(a, b) and torch.equal(a, c))
 
 
 @pytest.mark.parametrize("d,sizes", [(128, (16384, 16384, 1024)), (32, (5, 0, 300)), (64, (7, 1, 2048))])
