@@ -61,6 +61,19 @@ def _all_to_all(out, inp, out_splits=None, in_splits=None, group=None, async_op=
     return w if async_op else _Done()
 
 
+def _reduce_scatter(out, inp, group=None):
+    """dist.reduce_scatter_tensor (sum) -- RCCL in production; device tensors over gloo (several ranks on ONE GPU:
+    the test rigs) are summed through the host and every rank keeps its block."""
+    if inp.is_cuda and dist.get_backend(group) == 'gloo':
+        t = inp.cpu().contiguous()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        n = out.shape[0]
+        r = dist.get_rank(group)
+        out.copy_(t[r * n:(r + 1) * n])
+        return
+    dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
+
+
 class HipBackend(object):
     """Compute stages on libarx.so (include/arx.h)."""
 
@@ -144,6 +157,13 @@ class HipBackend(object):
 
     def copy_strided(self, src, dst):
         self.ops.copy_strided(src, dst)
+
+    def transpose(self, src, dst):
+        self.ops.transpose(src, dst)
+
+    def add_2d(self, src, dst):
+        """dst += src (2-D, any row strides)."""
+        self.ops.add_rows_bcast(1.0, src, 1.0, dst)
 
     def shard_route(self, ids, world, rank, zero_row, rows_out, keys_out):
         self.ops.shard_route(ids, world, rank, zero_row, rows_out, keys_out)
@@ -236,9 +256,19 @@ class ShardedHMF(object):
     the API; `users` passed to step() must all be owned by this rank."""
 
     def __init__(self, n_users, n_items, d, B_loc, S, learning_rate, rank, world, device,
-                 backend=None, group=None, tables=None, seed=0, acc0=0.1, graphs=None):
+                 backend=None, group=None, tables=None, seed=0, acc0=0.1, graphs=None, exchange='rows'):
         if S % 4 != 0 or d % 4 != 0:
             raise ValueError("n_sampled and d must be multiples of 4")
+        if exchange not in ('rows', 'logits'):
+            raise ValueError("exchange: 'rows' (gather the pool rows) or 'logits' (all-to-all of the logits)")
+        if exchange == 'logits' and type(self) is not ShardedHMF:
+            raise ValueError("exchange='logits' is the id-only step's alternative (ShardedHMF)")
+        # 'logits' (SURVEY 8e steps 1-5, the exchange north_star words): the latents are all-gathered, every owner
+        # scores the WHOLE batch against its pool block, the [B, S_g] partial logits cross by all_to_all, and their
+        # gradients cross back -- _step_logits.  Eager launches (no graph segments).
+        self.exchange = exchange
+        if exchange == 'logits':
+            graphs = False
         self.n_users, self.n_items, self.d = n_users, n_items, d
         # The shared pool is ONE draw over all items (prepare_train.py:7-17), so the number of pool items
         # a rank owns varies from draw to draw: the owned blocks travel padded to `cap` rows (the largest
@@ -370,6 +400,8 @@ class ShardedHMF(object):
         W, r, S = self.world, self.rank, self.S
         if W == 1:
             be.shard_route(self.pool_ids, W, r, self.zero_row, self.pool_rows, None)
+            if self.exchange == 'logits':
+                self._logits_layout(np.arange(S, dtype=np.int32))
             return
         # block layout (redraw path, every n_resample steps): two launches of arx_pool_blocks around ONE host
         # read of the W owner counts (the block capacity is a host decision: it sizes the exchanges)
@@ -386,6 +418,31 @@ class ShardedHMF(object):
         self.cap = cap
         be.pool_blocks(self.pool_ids, W, r, self.zero_row, cap, self._pool_counts, self.gidx, self.my_slots,
                        self.pool_rows)
+        if self.exchange == 'logits':
+            self._logits_layout(self.gidx.cpu().numpy())
+
+    def _logits_layout(self, gidx):
+        """Buffers and the inverse block map of the logits exchange, per pool draw (host; the redraw path):
+        blk2slot[g * cap + j] = pool slot of row j of owner g's block (S = padding: a zero row), the order
+        in which the gradient rows of the transposed logits are sent back to the owners."""
+        W, S, cap, B_loc, dp = self.world, self.S, self.cap, self.B_loc, self.dp
+        inv = np.full(W * cap, S, dtype=np.int32)
+        inv[np.asarray(gidx, dtype=np.int64)] = np.arange(S, dtype=np.int32)
+        self.blk2slot = torch.from_numpy(inv).to(self.device)
+        if W == 1:
+            self.gidx = torch.arange(S, dtype=torch.int32, device=self.device)
+        if getattr(self, '_lg_cap', -1) != cap:
+            z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=self.device)
+            self._lg_cap = cap
+            self.U_aug = z(B_loc, dp)                  # [U | 1 | 0 0 0]: the bias column of the packed pool rows
+            self.U_aug[:, self.d] = 1.0                # rides through the scorer GEMM
+            self.U_all = z(W * B_loc, dp)
+            self.Pt_send, self.Pt_recv = z(W * cap, B_loc), z(W * cap, B_loc)    # [owner | dest][block row][batch row]
+            self.logitsT, self.dlogitsT = z(S, B_loc), z(S + 1, B_loc)           # (+ a zero row for the padding)
+            self.dPt_send, self.dPt_recv = z(W * cap, B_loc), z(W * cap, B_loc)
+            self.dI_blk = z(cap, dp)
+            self.dU_part = z(W * B_loc, self.d)
+            self.dU_red = z(B_loc, self.d)
 
     # ------------------------------------------------------------------ route
     def prepare_route(self, users, items):
@@ -430,6 +487,8 @@ class ShardedHMF(object):
         if self.world > 1 and self.cap <= 0:
             raise RuntimeError("ShardedHMF.step before set_pool(): the pool's block layout sizes the exchanges")
         route = users if isinstance(users, dict) else self.prepare_route(users, items)
+        if self.exchange == 'logits':
+            return self._step_logits(route)
         if self.use_graphs:
             outer = torch.cuda.current_stream(self.device)
             if outer == self._stream:          # the caller already works on the model's stream (model.stream)
@@ -496,6 +555,88 @@ class ShardedHMF(object):
                                 sites, arena[:, :d], arena_b, self.lr)
         self.steps += 1
 
+
+    def _step_logits(self, route):
+        """The step with the exchange north_star words (hmf_model.py:52-99 on the global
+        batch, embed_attribute.py:148-206 scorer, :641-649 'mw'): the [B, S] logits are computed WHERE THE POOL
+        ROWS LIVE and cross xGMI, instead of the pool rows travelling to the batch rows.
+
+          all_gather      latents [B_loc, d+4] -> [B, d+4]                      (column d = 1: carries the pool bias)
+          (local)         Pt[h] = I_g . U_h^T  [cap, B_loc] for every destination h (owned pool block, padded to cap)
+          all_to_all      Pt blocks -> rank h holds [W . cap, B_loc] = its rows against every owner's block
+          (local)         block rows -> pool slots (gather), transpose -> logits [B_loc, S]; target rows as in step();
+                          WMRB loss, dlogits; transpose, slots -> block rows (gather; padding reads a zero row)
+          all_to_all      dlogits^T blocks back -> owner g holds dP^T [W][cap, B_loc]
+          (local)         dI_g = sum_h dP_h^T-blocks . U_h  (column d: the bias gradient), dU partials for ALL B rows
+          reduce_scatter  dU partials [B, d] -> [B_loc, d]
+          (local)         the same fused scatter + Adagrad pass as step()
+
+        Bytes per rank and step: 2 . (W-1)/W . B_loc . W . cap . 4 for the logits (cap ~ S / W: ~2 . B_loc . S . 4)
+        + 2 . B . (d+4) . 4 for the latents, against 2 . B_loc . (d+4) . 4 + ~2 . S . (d+4) . 4 for the 'rows'
+        exchange: it pays when S . (d+4) > B_loc . S, i.e. B_loc < d + 4 -- small batches against huge pools.  The
+        product default stays 'rows'; this form is kept measured and tested (tests/test_dist_cpu.py, test_dist_gpu.py)."""
+        be, W = self.be, self.world
+        B, B_loc, S, Sg, d, dp, cap = self.B, self.B_loc, self.S, self.Sg, self.d, self.dp, self.cap
+        grp = self.group
+        send, recv, R = route['send'], route['recv'], route['R']
+        arena, arena_b = self.arena, self.arena_b
+        urows, recv_rows = route['urows'], route['recv_rows']
+        self.urows = urows
+        # ---- forward ----
+        be.gather_rows(self.E_user, None, urows, self.U_aug[:, :d], None)
+        be.copy_2d(self.U_aug[:, :d], self.U_loc)
+        if W == 1:
+            be.copy_2d(self.U_aug, self.U_all)
+        else:
+            dist.all_gather_into_tensor(self.U_all, self.U_aug, group=grp)
+        be.gather_rows_packed(self.E_item, self.b_item, self.pool_rows[:cap], self.I_pack[:cap])
+        T_send = self.T_send[:R]
+        if R > 0:
+            be.gather_rows_packed(self.E_item, self.b_item, recv_rows, T_send)
+        w_rows = _all_to_all(self.T_pack, T_send, send, recv, group=grp, async_op=True)   # target rows back ...
+        for h in range(W):                                                                 # ... under the scorer
+            be.gemm(self.I_pack[:cap], self.U_all[h * B_loc:(h + 1) * B_loc], self.Pt_send[h * cap:(h + 1) * cap],
+                    transB=True)
+        if W == 1:
+            Pt = self.Pt_send
+        else:
+            _all_to_all(self.Pt_recv, self.Pt_send, group=grp)
+            Pt = self.Pt_recv
+        be.gather_rows(Pt, None, self.gidx, self.logitsT, None)          # block rows -> pool slots
+        be.transpose(self.logitsT, self.logits)
+        w_rows.wait()
+        dU = arena[:B_loc, :d]
+        be.loss_mw_fused_pos(self.logits, self.U_loc, self.T_pack[:, :d], self.T_pack[:, d], self.urows,
+                             self.pos_ptr, self.pos_items, self.item2slot, self.bl, self.dlogits,
+                             self.t_loc, self.dT_pack[:, d], dU, self.dT_pack[:, :d], 1.0 / B)
+        # ---- backward ----
+        w_dt = _all_to_all(arena[B_loc + Sg:B_loc + Sg + R], self.dT_pack, recv, send, group=grp, async_op=True)
+        be.transpose(self.dlogits, self.dlogitsT[:S])
+        be.gather_rows(self.dlogitsT, None, self.blk2slot, self.dPt_send, None)    # slots -> block rows of every owner
+        if W == 1:
+            dPt = self.dPt_send
+        else:
+            _all_to_all(self.dPt_recv, self.dPt_send, group=grp)
+            dPt = self.dPt_recv
+        for h in range(W):
+            blk, Uh = dPt[h * cap:(h + 1) * cap], self.U_all[h * B_loc:(h + 1) * B_loc]
+            be.gemm(blk, Uh, self.dI_blk, beta=0.0 if h == 0 else 1.0)           # [cap, d+4]: column d = bias gradient
+            be.gemm(blk, self.I_pack[:cap, :d], self.dU_part[h * B_loc:(h + 1) * B_loc], transA=True)
+        if W == 1:
+            be.copy_2d(self.dU_part, self.dU_red)
+        else:
+            _reduce_scatter(self.dU_red, self.dU_part, group=grp)
+        be.add_2d(self.dU_red, dU)                                                # dU = dt . T (loss kernel) + dL . pool
+        be.copy_2d(self.dI_blk, arena[B_loc:B_loc + cap])
+        w_dt.wait()
+        be.copy_strided(arena[B_loc:B_loc + Sg + R, d], arena_b[B_loc:B_loc + Sg + R])
+        sites = [(0, self.urows, 0), (1, self.pool_rows[:cap], B_loc)]
+        if R > 0:
+            sites.append((1, recv_rows, B_loc + Sg))
+        be.sparse_adagrad_multi([(self.E_user, self.A_user, None, None),
+                                 (self.E_item, self.A_item, self.b_item, self.Ab_item)],
+                                sites, arena[:, :d], arena_b, self.lr)
+        self.steps += 1
 
     def _fused_scorer(self):
         """True when the step takes the bf16-pipe scorer (switches on, shapes it supports); allocates its buffers."""
@@ -1992,6 +2133,14 @@ def comm_prediction(mode, world, B_loc, S, d, n_tokens=0, L=0, dense_bytes=0):
     if mode == 'id':
         rows = [row("pool blocks", 'all_gather', S * dp * 4), row("target rows", 'all_to_all', B_loc * dp * 4),
                 row("target-row gradients", 'all_to_all', B_loc * dp * 4), row("pool gradients", 'all_reduce', S * dp * 4)]
+    elif mode == 'id_logits':        # ShardedHMF(exchange='logits'): the logits cross, not the pool rows
+        B = B_loc * N
+        rows = [row("latents of the global batch", 'all_gather', B * dp * 4),
+                row("target rows", 'all_to_all', B_loc * dp * 4),
+                row("partial logits [B, S / N] -> [B_loc, S]", 'all_to_all', B_loc * S * 4),
+                row("logit gradients back", 'all_to_all', B_loc * S * 4),
+                row("target-row gradients", 'all_to_all', B_loc * dp * 4),
+                row("latent-gradient partials", 'reduce_scatter', B * d * 4)]
     elif mode == 'rep_tokens':
         rows = [row("pool blocks", 'all_gather', S * dp * 4), row("target rows", 'all_to_all', B_loc * dp * 4),
                 row("target-row gradients", 'all_to_all', B_loc * dp * 4), row("pool gradients", 'all_reduce', S * dp * 4),
@@ -2052,7 +2201,10 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
         cls = ShardedHMFRepTokens if rep_tokens else ShardedHMFBags
         model = cls(args.n_users, args.n_items, d, B_loc, S, 0.1, rank, world, dev, (vals, starts, lens), n_tok, seed=0)
     else:
-        model = ShardedHMF(args.n_users, args.n_items, d, B_loc, S, 0.1, rank, world, dev, seed=0)
+        model = ShardedHMF(args.n_users, args.n_items, d, B_loc, S, 0.1, rank, world, dev, seed=0,
+                           exchange=getattr(args, 'exchange', 'rows'))
+    pred_mode = 'rep_tokens' if rep_tokens else ('bags' if with_bags else
+                                                 ('id_logits' if getattr(model, 'exchange', 'rows') == 'logits' else 'id'))
     gen = torch.Generator(device=dev)
     gen.manual_seed(77 + rank)
     n_pos = 20
@@ -2191,6 +2343,7 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
                                    % (args.n_items, args.n_users, d, world, S, args.n_resample, redraws[0], B_loc, nb),
                        "batch_per_gpu": B_loc, "global_batch": B, "n_sampled": S, "dim": d,
                        "parallelism": "row-sharded tables x dp%d" % world,
+                       "exchange": getattr(model, 'exchange', 'rows'),
                        "routing_in_timed_region": False, "pool_redraws_timed": redraws[0],
                        "hipgraph_segments": (sorted(model._graphs) if model.use_graphs else None),
                        "step_form": ("hipGraph segments between the collectives" if model.use_graphs else "eager launches"),
@@ -2201,10 +2354,8 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
             # the same exchanges priced at link rate for the world of this run and for the 8-GPU node of BASELINE
             # configs[4] (arithmetic: no multi-GPU box was in reach of the builder)
             "roofline_comm_predicted": {
-                "this_run": comm_prediction('rep_tokens' if rep_tokens else ('bags' if with_bags else 'id'), world,
-                                            B_loc, S, d, n_tokens=100000 if with_bags else 0),
-                "at_8_ranks": comm_prediction('rep_tokens' if rep_tokens else ('bags' if with_bags else 'id'), 8,
-                                              B_loc, S, d, n_tokens=100000 if with_bags else 0)},
+                "this_run": comm_prediction(pred_mode, world, B_loc, S, d, n_tokens=100000 if with_bags else 0),
+                "at_8_ranks": comm_prediction(pred_mode, 8, B_loc, S, d, n_tokens=100000 if with_bags else 0)},
             "cpu_baseline": {"value": None, "unit": "interactions/s", "cores": None, "kind": "port",
                              "sample": None,
                              "why": "timed on rank 0 at N = 1 only (bench contract): the N = 1 line of the same run "

@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--sharded-rep-tokens", action="store_true",
                     help="N > 1 (or WORLD_SIZE set): HET items on the sharded step with the 100 k-token table REPLICATED "
                          "and its merged gradient all-reduced (arx.dist.ShardedHMFRepTokens, round 5); 1 M items")
+    ap.add_argument("--exchange", choices=["rows", "logits"], default="rows",
+                    help="the sharded id-only step's exchange (--workload c5 / --gpus N): 'rows' = gather the pool rows "
+                         "(default), 'logits' = all-to-all of the negative-sample logits (SURVEY 8e steps 1-5; eager launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ring", action="store_true",
@@ -797,6 +800,8 @@ def scaling_anchor(args):
         cmd.append("--sharded-bags")
     if args.sharded_rep_tokens:
         cmd.append("--sharded-rep-tokens")
+    if getattr(args, 'exchange', 'rows') != 'rows':
+        cmd += ["--exchange", args.exchange]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     else:

@@ -133,6 +133,12 @@ class NumpyBackend(object):
     def copy_2d(self, src, dst):
         dst.copy_(src)
 
+    def transpose(self, src, dst):
+        _n(dst)[...] = _n(src).T
+
+    def add_2d(self, src, dst):
+        _n(dst)[...] += _n(src)
+
     def shard_route(self, ids, world, rank, zero_row, rows_out, keys_out):
         i = _n(ids).astype(np.int64)
         own = (i % world) == rank

@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, exchange='rows'):
     for p in (ROOT, os.path.join(ROOT, "a-recsys_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -32,7 +32,7 @@ def _worker(rank, world, port, out_dir):
     tables = {'user': params['userembed_cat_0'][2:], 'item': params['itemembed_cat_0'][2:],
               'item_bias': params['item_bias_cat_0'][2:]}
     model = ShardedHMF(n_users, n_items, d, B_loc, S, 0.5, rank, world, 'cpu',
-                       backend=NumpyBackend(), tables=tables)
+                       backend=NumpyBackend(), tables=tables, exchange=exchange)
     # positives CSR over this rank's local user rows (global item ids)
     own_users = np.arange(rank, n_users, world)
     ptr = np.zeros(len(own_users) + 2, dtype=np.int32)
@@ -106,6 +106,16 @@ def test_sharded_step_matches_oracle_gloo(tmp_path, world):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() % 400) + world
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_step_logits_exchange_matches_oracle_gloo(tmp_path, world):
+    """exchange='logits' (north_star's all-to-all of the negative-sample logits): the same
+    five steps -- mixed / one-owner / skewed pools, R = 0 ranks, duplicate rows -- against the same oracle."""
+    import torch.multiprocessing as mp
+    port = 29950 + (os.getpid() % 400) + world
+    mp.spawn(_worker, args=(world, port, str(tmp_path), 'logits'), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
 
 

@@ -11,10 +11,13 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("B,S", [(32, 64), (128, 128)])     # (the second shape is one the bf16-pipe scorer takes)
-@pytest.mark.parametrize("graphs", [True, False])
+@pytest.mark.parametrize("graphs", [True, False, 'logits'])
 def test_sharded_hip_backend_world1(dev, graphs, B, S):
     """graphs=True: the step is ONE hipGraph (ShardedHMF._step_static: eager on step 0, captured on step
-    1, replayed from step 2 on -- through two pool redraws and fresh batches)."""
+    1, replayed from step 2 on -- through two pool redraws and fresh batches).  'logits': the step with the
+    all-to-all-of-logits exchange (_step_logits; at world 1 its transposes, block gathers and per-owner GEMMs)."""
+    exchange = 'logits' if graphs == 'logits' else 'rows'
+    graphs = graphs is True
     import torch
     import torch.distributed as dist
     from arx.dist import ShardedHMF
@@ -30,7 +33,7 @@ def test_sharded_hip_backend_world1(dev, graphs, B, S):
         params = syn.glorot_params(d, seed=2, scale=0.5)
         tables = {'user': params['userembed_cat_0'][2:], 'item': params['itemembed_cat_0'][2:],
                   'item_bias': params['item_bias_cat_0'][2:]}
-        model = ShardedHMF(n_users, n_items, d, B, S, 0.5, 0, 1, dev, tables=tables, graphs=graphs)
+        model = ShardedHMF(n_users, n_items, d, B, S, 0.5, 0, 1, dev, tables=tables, graphs=graphs, exchange=exchange)
         assert model.use_graphs == graphs
         ptr = np.concatenate([syn.pos_ptr[:n_users + 1], [syn.pos_ptr[n_users]]]).astype(np.int32)
         model.set_positives(ptr, syn.pos_items)
@@ -189,7 +192,7 @@ def test_sharded_c5_shape_world1(dev):
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _two_rank_worker(rank, world, port, out_dir, graphs=True):
+def _two_rank_worker(rank, world, port, out_dir, graphs=True, exchange='rows'):
     import sys
     for p in (ROOT, os.path.join(ROOT, "a-recsys_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
@@ -210,7 +213,8 @@ def _two_rank_worker(rank, world, port, out_dir, graphs=True):
     params = syn.glorot_params(d, seed=2, scale=0.5)
     tables = {'user': params['userembed_cat_0'][2:], 'item': params['itemembed_cat_0'][2:],
               'item_bias': params['item_bias_cat_0'][2:]}
-    model = ShardedHMF(n_users, n_items, d, B_loc, S, 0.5, rank, world, dev, tables=tables, graphs=graphs)
+    model = ShardedHMF(n_users, n_items, d, B_loc, S, 0.5, rank, world, dev, tables=tables, graphs=graphs,
+                       exchange=exchange)
     own_users = np.arange(rank, n_users, world)
     ptr = np.zeros(len(own_users) + 2, dtype=np.int32)
     its = []
@@ -350,6 +354,16 @@ def test_replicated_token_table_two_ranks_one_gpu(dev, tmp_path):
     port = 29760 + (os.getpid() % 100)
     mp.spawn(_two_rank_rep_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert all(os.path.exists(tmp_path / ("rep%d" % r)) for r in range(2))
+
+
+def test_sharded_logits_exchange_two_ranks_one_gpu(dev, tmp_path):
+    """exchange='logits' on the HIP backend, two rank processes on the one GPU (gloo underneath): latents
+    all-gathered, per-owner partial logits crossing by all_to_all and their gradients back, dU reduce-scattered --
+    the same seven steps (uneven blocks, an all-on-one-owner pool, S not divisible by the world size) vs the oracle."""
+    import torch.multiprocessing as mp
+    port = 29640 + (os.getpid() % 100)
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), False, 'logits'), nprocs=2, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(2))
 
 
 @pytest.mark.parametrize("graphs", [True, False])
