@@ -40,6 +40,7 @@ PROTOTYPES = {
     "arx_pool_blocks": (cint, [i32p, i64, cint, cint, i32, i64, i32p, i32p, i32p, i32p, vp]),
     "arx_copy_2d": (cint, [f32p, i64, f32p, i64, i64, i64, vp]),
     "arx_transpose_f32": (cint, [f32p, i64, i64, i64, f32p, i64, vp]),
+    "arx_gather_rows_wide": (cint, [f32p, i64, i64, i32p, i64, i64, f32p, i64, vp]),
     "arx_gather_onehot_fwd": (cint, [f32p, f32p, i32p, i32p, i64, cint, f32, cint, f32p, i64, f32p, vp]),
     "arx_copy_strided_f32": (cint, [f32p, i64, f32p, i64, i64, vp]),
     "arx_gather_onehot_packed_fwd": (cint, [f32p, f32p, i32p, i32p, i64, cint, f32, f32p, i64, vp]),

@@ -161,6 +161,9 @@ class HipBackend(object):
     def transpose(self, src, dst):
         self.ops.transpose(src, dst)
 
+    def gather_rows_wide(self, src, rows, dst):
+        self.ops.gather_rows_wide(src, rows, dst)
+
     def add_2d(self, src, dst):
         """dst += src (2-D, any row strides)."""
         self.ops.add_rows_bcast(1.0, src, 1.0, dst)
@@ -602,7 +605,7 @@ class ShardedHMF(object):
         else:
             _all_to_all(self.Pt_recv, self.Pt_send, group=grp)
             Pt = self.Pt_recv
-        be.gather_rows(Pt, None, self.gidx, self.logitsT, None)          # block rows -> pool slots
+        be.gather_rows_wide(Pt, self.gidx, self.logitsT)                 # block rows -> pool slots
         be.transpose(self.logitsT, self.logits)
         w_rows.wait()
         dU = arena[:B_loc, :d]
@@ -612,7 +615,7 @@ class ShardedHMF(object):
         # ---- backward ----
         w_dt = _all_to_all(arena[B_loc + Sg:B_loc + Sg + R], self.dT_pack, recv, send, group=grp, async_op=True)
         be.transpose(self.dlogits, self.dlogitsT[:S])
-        be.gather_rows(self.dlogitsT, None, self.blk2slot, self.dPt_send, None)    # slots -> block rows of every owner
+        be.gather_rows_wide(self.dlogitsT, self.blk2slot, self.dPt_send)  # slots -> block rows of every owner
         if W == 1:
             dPt = self.dPt_send
         else:

@@ -156,6 +156,12 @@ def transpose(src, dst):
          _stream())
 
 
+def gather_rows_wide(src, rows, dst):
+    """dst[r, :] = src[rows[r], :] for 2-D fp32 views of any width (zeros for row indices out of range)."""
+    call("arx_gather_rows_wide", _p(src), _ld(src), int(src.shape[0]), _p(rows), int(rows.shape[0]),
+         int(dst.shape[1]), _p(dst), _ld(dst), _stream())
+
+
 def gather_onehot(E, bias, cat_map, ids, out, scale=1.0, accumulate=False, bias_out=None):
     _chk(E, torch.float32, 'E'); _chk(ids, torch.int32, 'ids'); _chk(out, torch.float32, 'out')
     call("arx_gather_onehot_fwd", _p(E), _p(bias), _p(cat_map), _p(ids), int(ids.shape[0]),

@@ -275,6 +275,31 @@ __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ src
 
 using namespace arx;
 
+namespace arx {
+namespace {
+// dst[r, 0:width] = src[rows[r], 0:width] (0 for a row index outside [0, src_rows)): whole rows of any width --
+// the block rows <-> pool slots permutations of the sharded step's logits exchange (arx/dist.py _step_logits),
+// whose rows are B_loc floats wide (arx_gather_onehot_fwd stops at d = 1024)
+__global__ __launch_bounds__(256) void k_gather_rows_wide(const float* __restrict__ src, int64_t lds, int64_t src_rows,
+                                                          const int32_t* __restrict__ rows, int64_t n, int64_t width,
+                                                          float* __restrict__ dst, int64_t ldd) {
+  const int64_t c0 = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+  for (int64_t r = blockIdx.y; r < n; r += gridDim.y) {
+    const int64_t sr = rows[r];
+    const bool ok = sr >= 0 && sr < src_rows;
+    const float* sp = src + (ok ? sr : 0) * lds;
+    float* dp = dst + r * ldd;
+    if (c0 + 4 <= width && ((lds | ldd) & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+      const float4 v = ok ? *reinterpret_cast<const float4*>(sp + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(dp + c0) = v;
+    } else {
+      for (int64_t c = c0; c < width && c < c0 + 4; ++c) dp[c] = ok ? sp[c] : 0.f;
+    }
+  }
+}
+}  // namespace
+}  // namespace arx
+
 extern "C" {
 
 const char* arx_last_error(void) { return g_err; }
@@ -385,6 +410,18 @@ int arx_col_sum(const float* x, int64_t ld, int64_t rows, int64_t cols, float* o
   k_col_sum_partial<<<grid, 256, 0, as_stream(stream)>>>(x, ld, rows, cols, rpc, partial);
   ARX_CHECK_LAUNCH();
   k_col_sum_final<<<(int)ceil_div(cols, 64), 256, 0, as_stream(stream)>>>(partial, nchunk, cols, out);
+  ARX_CHECK_LAUNCH();
+  return ARX_OK;
+}
+
+int arx_gather_rows_wide(const float* src, int64_t lds, int64_t src_rows, const int32_t* rows, int64_t n,
+                         int64_t width, float* dst, int64_t ldd, void* stream) {
+  ARX_CHECK_ARG(src && rows && dst, "arx_gather_rows_wide: null pointer");
+  ARX_CHECK_ARG(lds >= width && ldd >= width && width > 0, "arx_gather_rows_wide: leading dimension too small");
+  if (n <= 0) return ARX_OK;
+  // one workgroup per 1024-float piece of a row
+  dim3 grid((unsigned)ceil_div(width, 1024), (unsigned)(n < 65535 ? n : 65535));
+  k_gather_rows_wide<<<grid, 256, 0, as_stream(stream)>>>(src, lds, src_rows, rows, n, width, dst, ldd);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }

@@ -99,6 +99,11 @@ int arx_copy_strided_f32(const float* src, int64_t src_stride, float* dst, int64
  * into the layouts the streaming GEMMs take (seqModel.py:477 backward) */
 int arx_transpose_f32(const float* src, int64_t lds, int64_t rows, int64_t cols, float* dst,
                       int64_t ldd, void* stream);
+/* dst[r, 0:width] = src[rows[r], 0:width], r < n (zeros for a row index outside [0, src_rows)): rows of ANY width --
+ * the block-row <-> pool-slot permutations of the sharded step's all-to-all-of-logits exchange,
+ * whose rows are one batch shard (B_loc floats) wide */
+int arx_gather_rows_wide(const float* src, int64_t lds, int64_t src_rows, const int32_t* rows, int64_t n,
+                         int64_t width, float* dst, int64_t ldd, void* stream);
 
 /* ---- a5: one-hot attribute gather --------------------------------------
  * embed_attribute.py:371-381: rows = cat_map[ids]; E[rows] (+ bias[rows]).

@@ -136,6 +136,13 @@ class NumpyBackend(object):
     def transpose(self, src, dst):
         _n(dst)[...] = _n(src).T
 
+    def gather_rows_wide(self, src, rows, dst):
+        r = _n(rows).astype(np.int64)
+        ok = (r >= 0) & (r < _n(src).shape[0])
+        out = np.zeros(_n(dst).shape, dtype=np.float32)
+        out[ok] = _n(src)[r[ok]]
+        _n(dst)[...] = out
+
     def add_2d(self, src, dst):
         _n(dst)[...] += _n(src)
 
