@@ -2218,12 +2218,17 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
     total = args.steps + args.warmup
     nb = min(total, 32)
     batches = []
+    route_ms = []      # host cost of routing one batch (prepare_route: D2H of the ids, argsort by owner, counts, ids to the owners)
     for _ in range(nb):
         lu = torch.randint(0, nu, (B_loc,), device=dev, generator=gen)
         k = torch.randint(0, n_pos, (B_loc,), device=dev, generator=gen)
         users = (lu * world + rank).to(torch.int32)
         items = pos_items[(lu * n_pos + k)]
+        torch.cuda.synchronize()
+        t_r = time.time()
         batches.append(model.prepare_route(users, items))      # data-loader side: order by owner
+        torch.cuda.synchronize()
+        route_ms.append((time.time() - t_r) * 1e3)
     # Shared negative pool: ONE draw of S items without replacement with p ~ count^0.5 over ALL items
     # (prepare_train.py:7-35 sample_items over item_frequency, run_hmf.py:62 power = 0.5): every rank
     # races its own shard on device (arx_sample_wor_keys), the ranks exchange their S best (key, id)
@@ -2347,7 +2352,11 @@ def bench_run(args, world, rank, local_rank, init_pg=True):
                        "batch_per_gpu": B_loc, "global_batch": B, "n_sampled": S, "dim": d,
                        "parallelism": "row-sharded tables x dp%d" % world,
                        "exchange": getattr(model, 'exchange', 'rows'),
-                       "routing_in_timed_region": False, "pool_redraws_timed": redraws[0],
+                       "routing_in_timed_region": False,
+                       # the data loader's share, stated next to it: host milliseconds per batch of B_loc interactions
+                       # (median over the ring's batches; one host thread, includes the tiny count exchange)
+                       "routing_host_ms_per_batch": float(np.median(route_ms)) if route_ms else None,
+                       "pool_redraws_timed": redraws[0],
                        "hipgraph_segments": (sorted(model._graphs) if model.use_graphs else None),
                        "step_form": ("hipGraph segments between the collectives" if model.use_graphs else "eager launches"),
                        "hipgraph_captures": model.n_captures, "hipgraph_replays": model.n_replays,

@@ -1337,6 +1337,16 @@ class Plan(object):
                         cache[ck2] = ops.BagCSC(s0.maps[0], starts_r, lens_r, max_len, int(bt.E.shape[0]))
                     if cache[ck2].ok:
                         ent['csc'] = (cache[ck2],) + cache[ck2].scratch()
+            if ent['csc'] is not None:
+                # the flag bytes are zero between steps because every sort half that marks (phase 1 / 5) is followed
+                # by the sweep that clears (1 / 6); an eager step that raised in between leaves marks behind, which
+                # the next sweep would take for live pairs -- cleared here (never on the replay path: no Python there)
+                if phase in (1, 3, 5):
+                    if ent.get('csc_marked'):
+                        ent['csc'][1].zero_()
+                    ent['csc_marked'] = phase == 5
+                elif phase == 6:
+                    ent['csc_marked'] = False
             ops.sparse_adagrad_cat_multi_bags(
                 args, node0.arena, node0.arena_b if (ent['any_bias'] or bag_bias) else None, rt.lr,
                 ent['keys'], ent['src'], ent['coef'], ent['ws'], bt.E, None if sgd else bt.acc,
