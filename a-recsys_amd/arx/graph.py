@@ -597,7 +597,7 @@ class BatchLoss(Node):
                     # [B, S] logits / dlogits in HBM, 2 MB of activity bits instead, and all three products on
                     # the bf16 matrix pipe, f32-exact (csrc/gemm_bx6.hip; C3 312 -> 260 us/step in round 3)
                     # 'mce' (round 5): the same move with exp in the epilogue and the weight tiles recomputed in the
-                    # backward (ops.MceScorer, d == 64)
+                    # backward (ops.MceScorer, d in {64, 128})
                     self.gemm_fused = True
                     logits.fused_into_loss = True
 

@@ -500,7 +500,7 @@ def gemm_bt_bx6(A, Bt, C, beta=0.0):
 
 
 def mce_scorer_supported(B, S, d):
-    """True when the fused 'mce' family (csrc/scorer.hip, k_mc_flow) takes this shape: d == 64, S % 128 == 0,
+    """True when the fused 'mce' family (csrc/scorer.hip, k_mc_flow) takes this shape: d in {64, 128}, S % 128 == 0,
     128 <= S <= 2048 -- and the process has not asked for the materialising reference (ARX_SCORER_F32 /
     ARX_MCE_FUSED=0)."""
     if SCORER_F32 or os.environ.get('ARX_MCE_FUSED', '1') == '0':

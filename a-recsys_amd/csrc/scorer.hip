@@ -1434,7 +1434,10 @@ size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 #define MC_SLOTS 2
 #endif
 constexpr int kMcSlots = MC_SLOTS;           // LDS ring: the stage being read + kMcSlots - 1 in flight
-constexpr int kMcStage = 25 * 1024;          // K part 12 KB + T part 12 KB + 1 KB: the tile's 32 + 32 constants
+// a stage: K part (3 planes x 32 rows x KD k) + T part (3 planes x KD rows x 32 indices) + 1 KB: the tile's 32 + 32
+// constants -- 12 + 12 + 1 KB at KD = 64, 24 + 24 + 1 KB at KD = 128
+constexpr int mc_part(int KD) { return 192 * KD; }
+constexpr int mc_stage(int KD) { return 2 * mc_part(KD) + 1024; }
 
 struct McFlow {
   int64_t nstat;                             // stationary extent
@@ -1454,9 +1457,15 @@ struct McFlow {
   float* rsum; int64_t rs_rows;              // [slices][rs_rows]
 };
 
-template <bool DI>
-__global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
-  constexpr int NCH = 4;
+template <bool DI, int KD>
+__global__ __launch_bounds__(256, KD == 64 ? 2 : 1) void k_mc_flow(McFlow a) {
+  constexpr int NCH = KD / 16;                 // k-chunks of the x tile
+  constexpr int NB = KD / 32;                  // 32-wide blocks of the product's second index
+  constexpr int PART = mc_part(KD), kMcStage = mc_stage(KD);
+  constexpr int NPC = PART / 2048;             // LDS-DMA pieces (1 KB) per loader wave and stage: 6 / 12
+  constexpr int ROWB = 2 * KD;                 // bytes of a K-part row
+  constexpr int PK = 32 * ROWB;                // plane stride of the K part
+  constexpr int PTS = KD * 64;                 // plane stride of the T part
   extern __shared__ __attribute__((aligned(1024))) char lds[];      // [kMcSlots][kMcStage]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 31, kg = lane >> 5;
@@ -1490,20 +1499,24 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
   // (s_waitcnt vmcnt(0) at the top of the loop: the prefetch of tile t + 1 was waited for in front of tile t, 107 us
   // per launch at the C4 shape) -- k_sc_hinge avoids that with loader waves of their own, here the four compute waves
   // are all a CU's register file holds.  The waits are the explicit ones in front of the stage barriers.
-  const char* src[6];
+  const char* src[NPC];
   int64_t adv;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int p = (wv & 1) * 6 + i, pl = p >> 2, rg = p & 3;
-    if (wv < 2) {
-      const int row = rg * 8 + (lane >> 3), pos = lane & 7, q = pos ^ ((row >> 1) & 7);
-      src[i] = reinterpret_cast<const char*>(a.XK) + ((int64_t)pl * a.xk_plane + (n_begin + row) * 64) * 2 + q * 16;
-    } else {
+  for (int i = 0; i < NPC; ++i) {
+    const int p = (wv & 1) * NPC + i;
+    if (wv < 2) {      // K part: pieces of 1024 / ROWB rows, a row = ROWB / 16 chunks, chunk position swizzled by the row
+      constexpr int RPP = 1024 / ROWB, CPR = ROWB / 16, PPP = 32 / RPP;
+      const int pl = p / PPP, rg = p % PPP;
+      const int row = rg * RPP + lane / CPR, pos = lane % CPR, q = pos ^ sc_swz<ROWB>(row);
+      src[i] = reinterpret_cast<const char*>(a.XK) + ((int64_t)pl * a.xk_plane + (n_begin + row) * KD) * 2 + q * 16;
+    } else {           // T part: pieces of 16 rows of 64 bytes
+      constexpr int PPP = KD / 16;
+      const int pl = p / PPP, rg = p % PPP;
       const int row = rg * 16 + (lane >> 2), pos = lane & 3, q = pos ^ ((row >> 2) & 3);
-      src[i] = reinterpret_cast<const char*>(a.XT) + ((int64_t)pl * 64 * a.ldx + (int64_t)row * a.ldx + n_begin) * 2 + q * 16;
+      src[i] = reinterpret_cast<const char*>(a.XT) + ((int64_t)pl * KD * a.ldx + (int64_t)row * a.ldx + n_begin) * 2 + q * 16;
     }
   }
-  adv = wv < 2 ? 32 * 128 : 64;
+  adv = wv < 2 ? 32 * ROWB : 64;
   // the tile's constants and mask words (wave 0's seventh piece): lanes 0..7 c_stream[32 t ..], lanes 8..15 cw[32 t ..],
   // lanes 16..47 the mask words of the workgroup's 128 stationary indices, the others re-fetch `zeros`
   const char* srcx = reinterpret_cast<const char*>(a.zeros);
@@ -1531,14 +1544,14 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
                  :: "s"(__builtin_amdgcn_readfirstlane(dst)), "v"(p) : "memory");
   };
   auto issue = [&](int slot) {                     // (tiles are issued in order: the sources step along)
-    const uint32_t stage = lds0 + (uint32_t)(slot * kMcStage + wv * 6 * 1024);
+    const uint32_t stage = lds0 + (uint32_t)(slot * kMcStage + wv * NPC * 1024);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < NPC; ++i) {
       dma(stage + i * 1024, src[i]);
       src[i] += adv;
     }
     if (wv == 0) {
-      dma(lds0 + (uint32_t)(slot * kMcStage + 24 * 1024), srcx);
+      dma(lds0 + (uint32_t)(slot * kMcStage + 2 * PART), srcx);
       srcx += advx;
     }
   };
@@ -1564,7 +1577,7 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
       a3[c] = __builtin_bit_cast(bf16x8, make_uint4(p3[0], p3[1], p3[2], p3[3]));
     }
   } else {
-    const uint16_t* pp = a.statP + stat_c * 64 + 8 * kg;
+    const uint16_t* pp = a.statP + stat_c * KD + 8 * kg;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       a1[c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pp + 16 * c));
@@ -1574,13 +1587,17 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
   }
   const float cst = (a.cstat && ok) ? a.sgn_stat * a.cstat[stat] : 0.f;
 
-  f32x16 hiO0 = {0}, loO0 = {0}, hiO1 = {0}, loO1 = {0};
+  f32x16 hiO[NB], loO[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) hiO[q][e] = loO[q][e] = 0.f;
   float rs = 0.f;
   // LDS byte offsets of this lane's fragments inside a stage
-  const uint32_t fk = (uint32_t)(lr * 128);                          // K part row
-  const int swk = (lr >> 1) & 7;
-  const uint32_t ft = (uint32_t)(12288 + lr * 64 + 8 * kg);           // T part row of dd block 0 (block 1: + 2048)
-  const int swt = (lr >> 2) & 3;                                      // ((32 + lr) >> 2) & 3 is the same
+  const uint32_t fk = (uint32_t)(lr * ROWB);                         // K part row
+  const int swk = sc_swz<ROWB>(lr);
+  const uint32_t ft = (uint32_t)(PART + lr * 64 + 8 * kg);            // T part row of dd block 0 (block b: + 2048 b)
+  const int swt = (lr >> 2) & 3;                                      // ((32 b + lr) >> 2) & 3 is the same
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -1590,7 +1607,7 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
     if (t + kMcSlots - 1 < ntile) issue(slot_in);  // (read last in tile t - 1: every wave is past that barrier)
     slot = slot + 1 == kMcSlots ? 0 : slot + 1;
     slot_in = slot_in + 1 == kMcSlots ? 0 : slot_in + 1;
-    const uint32_t mw = reinterpret_cast<const uint32_t*>(st + 24 * 1024 + 256)[wv * 32 + lr];
+    const uint32_t mw = reinterpret_cast<const uint32_t*>(st + 2 * PART + 256)[wv * 32 + lr];
     // The instruction stream of a tile is pinned group by group (sched_barrier): the fragments of group g + 1 are
     // requested in front of the six MFMAs of group g -- left alone the scheduler emits read / wait / MFMA triples and
     // the matrix pipe idles for an LDS round trip per fragment.  Groups: four k-chunks of the x tile, then four
@@ -1600,22 +1617,22 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
   {                                                                                                      \
     const uint32_t fa = fk + 16 * ((2 * (c_) + kg) ^ swk);                                               \
     fr[set_][0] = *reinterpret_cast<const uint4*>(st + fa);                                              \
-    fr[set_][1] = *reinterpret_cast<const uint4*>(st + fa + 4096);                                       \
-    fr[set_][2] = *reinterpret_cast<const uint4*>(st + fa + 8192);                                       \
+    fr[set_][1] = *reinterpret_cast<const uint4*>(st + fa + PK);                                         \
+    fr[set_][2] = *reinterpret_cast<const uint4*>(st + fa + 2 * PK);                                     \
   }
 #define MC_LDT(set_, g_)                                                                                 \
   {                                                                                                      \
-    const uint32_t o0 = ft + 16 * ((2 * ((g_) >> 1)) ^ swt) + ((g_) & 1) * 2048;                         \
-    const uint32_t o1 = ft + 16 * ((2 * ((g_) >> 1) + 1) ^ swt) + ((g_) & 1) * 2048;                     \
+    const uint32_t o0 = ft + 16 * ((2 * ((g_) / NB)) ^ swt) + ((g_) % NB) * 2048;                        \
+    const uint32_t o1 = ft + 16 * ((2 * ((g_) / NB) + 1) ^ swt) + ((g_) % NB) * 2048;                    \
     _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                   \
-      const uint2 h0 = *reinterpret_cast<const uint2*>(st + o0 + pl * 4096);                             \
-      const uint2 h1 = *reinterpret_cast<const uint2*>(st + o1 + pl * 4096);                             \
+      const uint2 h0 = *reinterpret_cast<const uint2*>(st + o0 + pl * PTS);                              \
+      const uint2 h1 = *reinterpret_cast<const uint2*>(st + o1 + pl * PTS);                              \
       fr[set_][pl] = make_uint4(h0.x, h0.y, h1.x, h1.y);                                                 \
     }                                                                                                    \
   }
     // ---- x tile: D[stream index][stationary], hi starts at c_stream + c_stat ----
     f32x16 hi, lo;
-    const float* cs = reinterpret_cast<const float*>(st + 24 * 1024) + 4 * kg;
+    const float* cs = reinterpret_cast<const float*>(st + 2 * PART) + 4 * kg;
     MC_LDK(0, 0)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1625,7 +1642,7 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
     }
     float4 cwv[4];
     if (DI) {
-      const float* cwp = reinterpret_cast<const float*>(st + 24 * 1024 + 128) + 4 * kg;
+      const float* cwp = reinterpret_cast<const float*>(st + 2 * PART + 128) + 4 * kg;
 #pragma unroll
       for (int g = 0; g < 4; ++g) cwv[g] = *reinterpret_cast<const float4*>(cwp + 8 * g);
     }
@@ -1690,14 +1707,14 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
     MC_SPLITQ(0)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int q = g >> 1;
+    for (int g = 0; g < 2 * NB; ++g) {
+      const int q = g / NB;
       const bf16x8 t1 = __builtin_bit_cast(bf16x8, fr[g & 1][0]), t2 = __builtin_bit_cast(bf16x8, fr[g & 1][1]),
                    t3 = __builtin_bit_cast(bf16x8, fr[g & 1][2]);
-      if (g + 1 < 4) MC_LDT((g + 1) & 1, g + 1)
+      if (g + 1 < 2 * NB) MC_LDT((g + 1) & 1, g + 1)
       __builtin_amdgcn_sched_barrier(0);
-      f32x16& hO = (g & 1) ? hiO1 : hiO0;
-      f32x16& lO = (g & 1) ? loO1 : loO0;
+      f32x16& hO = hiO[g % NB];
+      f32x16& lO = loO[g % NB];
       lO = SC_MFMA(t3, w1[q], lO);
       hO = SC_MFMA(t1, w1[q], hO);
       lO = SC_MFMA(t1, w3[q], lO);
@@ -1722,7 +1739,7 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
 #else
     // tile t + 1 has landed; with three slots the requests of tile t + 2 (seven by wave 0, six by the others) stay
     // in flight
-    if (kMcSlots == 3 && t + 2 < ntile) {
+    if (kMcSlots == 3 && KD == 64 && t + 2 < ntile) {
       if (wv == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
@@ -1734,16 +1751,14 @@ __global__ __launch_bounds__(256, 2) void k_mc_flow(McFlow a) {
   rs += __shfl_xor(rs, 32, 64);
   if (!ok) return;
   if (kg == 0) a.rsum[sl * a.rs_rows + stat] = rs;
-  float* orow = a.O + (sl * a.o_rows + stat) * 64 + 4 * kg;
+  float* orow = a.O + (sl * a.o_rows + stat) * KD + 4 * kg;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    *reinterpret_cast<float4*>(orow + 8 * g) =
-        make_float4(hiO0[4 * g] + loO0[4 * g], hiO0[4 * g + 1] + loO0[4 * g + 1], hiO0[4 * g + 2] + loO0[4 * g + 2],
-                    hiO0[4 * g + 3] + loO0[4 * g + 3]);
-    *reinterpret_cast<float4*>(orow + 32 + 8 * g) =
-        make_float4(hiO1[4 * g] + loO1[4 * g], hiO1[4 * g + 1] + loO1[4 * g + 1], hiO1[4 * g + 2] + loO1[4 * g + 2],
-                    hiO1[4 * g + 3] + loO1[4 * g + 3]);
-  }
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(orow + 32 * b + 8 * g) =
+          make_float4(hiO[b][4 * g] + loO[b][4 * g], hiO[b][4 * g + 1] + loO[b][4 * g + 1],
+                      hiO[b][4 * g + 2] + loO[b][4 * g + 2], hiO[b][4 * g + 3] + loO[b][4 * g + 3]);
 }
 
 struct McRows {
@@ -1761,16 +1776,19 @@ struct McRows {
   const float* pool_bad; int nbad;
 };
 
-// 32 batch rows per workgroup, 16 lanes x float4 per row (d = 64), 4 waves x 2 rounds x 4 rows
+// 32 batch rows per workgroup, LPR = d / 4 lanes x float4 per row: 4 waves x (2 rounds x 4 rows at d = 64, 4 rounds x 2
+// rows at d = 128)
+template <int LPR>
 __global__ __launch_bounds__(256) void k_mc_rows(McRows a, int64_t B) {
-  __shared__ float tile[32 * 65];
+  constexpr int D = 4 * LPR, RPW = 64 / LPR, NIT = 8 / RPW;
+  __shared__ float tile[32 * (D + 1)];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t r0 = (int64_t)blockIdx.x * 32;
-  const int c4 = (lane & 15) * 4;
+  const int c4 = (lane & (LPR - 1)) * 4;
   const float pbad = sc_wsum(lane < a.nbad ? a.pool_bad[lane] : 0.f);
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int rl = wv * 8 + it * 4 + (lane >> 4);
+  for (int it = 0; it < NIT; ++it) {
+    const int rl = wv * 8 + it * RPW + lane / LPR;
     const int64_t r = r0 + rl;
     const bool live = r < B;
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f), tt = u, o = u;
@@ -1780,7 +1798,7 @@ __global__ __launch_bounds__(256) void k_mc_rows(McRows a, int64_t B) {
       tt = *reinterpret_cast<const float4*>(a.T + r * a.ldt + c4);
       for (int p = 0; p < a.nsplit; ++p) {                    // fixed order
         s += a.rs_part[(int64_t)p * B + r];
-        const float4 v = *reinterpret_cast<const float4*>(a.O_part + ((int64_t)p * a.Bp + r) * 64 + c4);
+        const float4 v = *reinterpret_cast<const float4*>(a.O_part + ((int64_t)p * a.Bp + r) * D + c4);
         o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
       }
       t = a.tscore[r];
@@ -1788,7 +1806,7 @@ __global__ __launch_bounds__(256) void k_mc_rows(McRows a, int64_t B) {
     // non-finite inputs poison the row's loss like an f32 chain would
     float poison = ((u.x + u.y) + (u.z + u.w) + (tt.x + tt.y) + (tt.z + tt.w)) * 0.f;
 #pragma unroll
-    for (int m = 8; m > 0; m >>= 1) poison += __shfl_xor(poison, m, 64);
+    for (int m = LPR / 2; m > 0; m >>= 1) poison += __shfl_xor(poison, m, 64);
     s += pbad + poison + t * 0.f;
     const float gw = live ? a.gscale * (a.row_w ? a.row_w[r] : 1.f) : 0.f;
     // (s is finite for finite inputs since the exponent saturates; the limits keep an overflowed sum -- more than
@@ -1796,7 +1814,7 @@ __global__ __launch_bounds__(256) void k_mc_rows(McRows a, int64_t B) {
     const bool sinf = s == __builtin_inff();
     const float coef = sinf ? 0.f : gw / (1.f + s);
     const float dt = sinf ? -gw : -coef * s;
-    if ((lane & 15) == 0) {
+    if ((lane & (LPR - 1)) == 0) {
       if (live) {
         if (a.batch_loss) a.batch_loss[r] = log1pf(s);
         if (a.dtscore) a.dtscore[r * a.dts_stride] = dt;
@@ -1815,13 +1833,13 @@ __global__ __launch_bounds__(256) void k_mc_rows(McRows a, int64_t B) {
     split3x2(u.z, u.w, pb[0], pb[1], pb[2]);
 #pragma unroll
     for (int p = 0; p < 3; ++p)
-      *reinterpret_cast<uint2*>(a.Up + ((int64_t)p * a.Bp + r) * 64 + c4) = make_uint2(pa[p], pb[p]);
-    float* tp = tile + rl * 65 + c4;
+      *reinterpret_cast<uint2*>(a.Up + ((int64_t)p * a.Bp + r) * D + c4) = make_uint2(pa[p], pb[p]);
+    float* tp = tile + rl * (D + 1) + c4;
     const float cu = live ? coef : 0.f;
     tp[0] = cu * u.x; tp[1] = cu * u.y; tp[2] = cu * u.z; tp[3] = cu * u.w;
   }
   __syncthreads();
-  sc_emit_planes_t(tile, 65, 32, 64, a.UgT, (int64_t)64 * a.ldug, a.ldug, r0, tid, 256);
+  sc_emit_planes_t(tile, D + 1, 32, D, a.UgT, (int64_t)D * a.ldug, a.ldug, r0, tid, 256);
 }
 
 
@@ -2110,7 +2128,7 @@ struct McLayout {
 };
 
 bool mc_layout(int64_t B, int64_t S, int d, McLayout* L) {
-  if (d != 64 || S % 128 != 0 || S < 128 || S > 2048 || B < 1) return false;
+  if (!(d == 64 || d == 128) || S % 128 != 0 || S < 128 || S > 2048 || B < 1) return false;
   L->Bp = (B + 127) / 128 * 128;
   L->ldpt = S + 128;                     // (not a power of two: see ScLayout)
   L->ldug = L->Bp + 128;
@@ -2129,13 +2147,13 @@ bool mc_layout(int64_t B, int64_t S, int d, McLayout* L) {
   L->tneg = take((size_t)L->Bp * 4);
   L->coef = take((size_t)L->Bp * 4);
   L->rs = take((size_t)ns * B * 4);
-  L->O = take((size_t)ns * L->Bp * 64 * 4);
+  L->O = take((size_t)ns * L->Bp * d * 4);
   L->hits = take((size_t)B * kScHits * 4);
   L->nhit = take((size_t)B * 4);
-  L->Pp = take((size_t)3 * S * 64 * 2);
-  L->PT = take((size_t)3 * 64 * L->ldpt * 2);
-  L->Up = take((size_t)3 * L->Bp * 64 * 2);
-  L->UgT = take((size_t)3 * 64 * L->ldug * 2);
+  L->Pp = take((size_t)3 * S * d * 2);
+  L->PT = take((size_t)3 * d * L->ldpt * 2);
+  L->Up = take((size_t)3 * L->Bp * d * 2);
+  L->UgT = take((size_t)3 * d * L->ldug * 2);
   L->pbad = take(64 * 4);
   L->zeros = take(256);                  // (never written: the caller zeroed the state once)
   L->total = o;
@@ -2143,8 +2161,10 @@ bool mc_layout(int64_t B, int64_t S, int d, McLayout* L) {
 }
 
 int mc_raise_lds() {
-  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mc_flow<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mc_flow<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mc_flow<false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mc_flow<true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mc_flow<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+  ARX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mc_flow<true, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
   return ARX_OK;
 }
 
@@ -2190,7 +2210,7 @@ int arx_mce_scorer_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp,
                     reinterpret_cast<uintptr_t>(dU) | reinterpret_cast<uintptr_t>(dT) |
                     reinterpret_cast<uintptr_t>(state)) & 15) == 0;
   if (!ok) {
-    set_error("arx_mce_scorer_fwd: shape not supported (d == 64, S %% 128 == 0, 128 <= S <= 2048, 16-byte rows)");
+    set_error("arx_mce_scorer_fwd: shape not supported (d in {64, 128}, S %% 128 == 0, 128 <= S <= 2048, 16-byte rows)");
     return ARX_EUNSUPPORTED;
   }
   if (state_bytes < L.total) {
@@ -2223,7 +2243,7 @@ int arx_mce_scorer_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp,
     McFlow a{};
     a.nstat = B; a.span = L.CW; a.nstream = S;
     a.statF = U; a.ldstat = ldu;
-    a.XK = Pp; a.xk_plane = S * 64;
+    a.XK = Pp; a.xk_plane = S * d;
     a.XT = PT; a.ldx = L.ldpt;
     a.cstat = t; a.sgn_stat = -1.f;
     a.cstream = pbias; a.cw = nullptr;
@@ -2232,7 +2252,8 @@ int arx_mce_scorer_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp,
     a.zeros = reinterpret_cast<const float*>(st + L.zeros);
     a.O = O_part; a.o_rows = L.Bp;
     a.rsum = rs_part; a.rs_rows = B;
-    k_mc_flow<false><<<(int)(ceil_div(B, 128) * L.nsplit), 256, kMcSlots * kMcStage, s>>>(a);
+    if (d == 64) k_mc_flow<false, 64><<<(int)(ceil_div(B, 128) * L.nsplit), 256, kMcSlots * mc_stage(64), s>>>(a);
+    else k_mc_flow<false, 128><<<(int)(ceil_div(B, 128) * L.nsplit), 256, kMcSlots * mc_stage(128), s>>>(a);
     ARX_CHECK_LAUNCH();
   }
   if (phases & 4) {
@@ -2241,7 +2262,8 @@ int arx_mce_scorer_fwd(const float* U, int64_t ldu, const float* P, int64_t ldp,
              dtscore_stride > 0 ? dtscore_stride : 1, dU, lddu, dT, lddt, reinterpret_cast<uint16_t*>(st + L.Up),
              reinterpret_cast<uint16_t*>(st + L.UgT), L.ldug, reinterpret_cast<const float*>(st + L.pbad),
              (int)(S / 32)};
-    k_mc_rows<<<(int)(L.Bp / 32), 256, 0, s>>>(a, B);
+    if (d == 64) k_mc_rows<16><<<(int)(L.Bp / 32), 256, 0, s>>>(a, B);
+    else k_mc_rows<32><<<(int)(L.Bp / 32), 256, 0, s>>>(a, B);
     ARX_CHECK_LAUNCH();
   }
   return ARX_OK;
@@ -2251,7 +2273,7 @@ size_t arx_mce_scorer_bwd_di_workspace_bytes(int64_t B, int64_t S, int d, int64_
   McLayout L;
   if (!mc_layout(B, S, d, &L)) return 0;
   const int64_t nsl = ceil_div(L.Bp, mc_di_slice(L, S, step_rows));
-  return (size_t)nsl * S * 64 * 4 + (size_t)nsl * S * 4 + 512;
+  return (size_t)nsl * S * d * 4 + (size_t)nsl * S * 4 + 512;
 }
 
 /* dI[s, :] = beta dI[s, :] + sum_r w_rs U[r, :], db[s] = sum_r w_rs with w_rs = coef_r m_rs exp(x_rs - t_r), recomputed
@@ -2275,7 +2297,7 @@ int arx_mce_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, c
   ARX_CHECK_ARG(mrows == B || (mrows % 128 == 0 && mrows % ks == 0),
                 "arx_mce_scorer_bwd_di: mask_rows as given to the forward; a slice of rows must not wrap the user rows");
   const int64_t nsl = ceil_div(L.Bp, ks);
-  const size_t part_bytes = (size_t)nsl * S * 64 * 4;
+  const size_t part_bytes = (size_t)nsl * S * d * 4;
   const size_t need = (dI_steps ? 0 : part_bytes) + (size_t)nsl * S * 4 + 256;
   if (!workspace || workspace_bytes < need) {
     set_error("arx_mce_scorer_bwd_di: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -2288,8 +2310,8 @@ int arx_mce_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, c
   const char* st = reinterpret_cast<const char*>(state);
   McFlow a{};
   a.nstat = S; a.span = ks; a.nstream = L.Bp;
-  a.statP = reinterpret_cast<const uint16_t*>(st + L.Pp); a.statP_plane = S * 64;
-  a.XK = reinterpret_cast<const uint16_t*>(st + L.Up); a.xk_plane = L.Bp * 64;
+  a.statP = reinterpret_cast<const uint16_t*>(st + L.Pp); a.statP_plane = S * d;
+  a.XK = reinterpret_cast<const uint16_t*>(st + L.Up); a.xk_plane = L.Bp * d;
   a.XT = reinterpret_cast<const uint16_t*>(st + L.UgT); a.ldx = L.ldug;
   a.cstat = pbias; a.sgn_stat = 1.f;
   a.cstream = reinterpret_cast<const float*>(st + L.tneg);
@@ -2299,14 +2321,15 @@ int arx_mce_scorer_bwd_di_loss(int64_t B, int64_t S, int d, const void* state, c
   a.zeros = reinterpret_cast<const float*>(st + L.zeros);
   a.O = part; a.o_rows = S;
   a.rsum = dbpart; a.rs_rows = S;
-  k_mc_flow<true><<<(int)((S / 128) * nsl), 256, kMcSlots * kMcStage, s>>>(a);
+  if (d == 64) k_mc_flow<true, 64><<<(int)((S / 128) * nsl), 256, kMcSlots * mc_stage(64), s>>>(a);
+  else k_mc_flow<true, 128><<<(int)((S / 128) * nsl), 256, kMcSlots * mc_stage(128), s>>>(a);
   ARX_CHECK_LAUNCH();
   const int dbblocks = db ? (int)ceil_div(S, 64) : 0;
   const bool steps = db_steps && step_rows > 0;
   const int64_t Lsteps = steps ? B / step_rows : 0;
   const int stepblocks = steps ? (int)ceil_div(Lsteps * S, 256) : 0;
-  k_sc_tn_reduce<<<(int)ceil_div(S * (64 / 4), 64) + dbblocks + stepblocks + (loss_out ? 1 : 0), 256, 0, s>>>(
-      part, (int)nsl, S, 64, beta, dI, lddi, dbpart, nsl, db, dbblocks, batch_loss, row_w, B, gscale, loss_out,
+  k_sc_tn_reduce<<<(int)ceil_div(S * (d / 4), 64) + dbblocks + stepblocks + (loss_out ? 1 : 0), 256, 0, s>>>(
+      part, (int)nsl, S, d, beta, dI, lddi, dbpart, nsl, db, dbblocks, batch_loss, row_w, B, gscale, loss_out,
       stepblocks, 1, Lsteps, db_steps);
   ARX_CHECK_LAUNCH();
   return ARX_OK;

@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--no-anchor", action="store_true",
                     help="N > 1: do not run the world-1 anchor of the same workload after the N-rank run")
     ap.add_argument("--mulhot", action="store_true", help="(compat) same as --workload c3")
-    ap.add_argument("--subs", default="c2,c3mix,c4,c4mce,k1,c5w1,c3repw1,topk,c3_f32mfma,c2_f32mfma",
+    ap.add_argument("--subs", default="c2,c3mix,c3mce,c4,c4mce,k1,c5w1,c3repw1,topk,c3_f32mfma,c2_f32mfma",
                     help="comma list of sub-results besides the headline ('' = none)")
     ap.add_argument("--sub-steps", type=int, default=50)
     ap.add_argument("--repeats", type=int, default=5,
@@ -437,7 +437,7 @@ WORKLOADS = {
 }
 
 
-def run_hmf(args, name, steps, warmup, with_cpu=False):
+def run_hmf(args, name, steps, warmup, with_cpu=False, loss='mw'):
     from arx.hmf.hmf_model import LatentProductModel
     from arx.utils.synthetic import SyntheticHMF
     from arx.utils.prepare_train import DeviceSampler
@@ -448,7 +448,7 @@ def run_hmf(args, name, steps, warmup, with_cpu=False):
                        zipf_items=args.zipf_items, **kw)
     model = LatentProductModel(args.n_users, args.n_items, d, 1, B, 0.1, 1.0, syn.u_attr, syn.i_attr,
                                syn.item2logit[:args.n_items], syn.logit_ind2item_ind,
-                               loss_function='mw', n_sampled=S, use_graph=not args.no_graph)
+                               loss_function=loss, n_sampled=S, use_graph=not args.no_graph)
     model.prepare_warp(syn.positives_csr(), syn.positives_csr())
     dev = model.rt.device
     total = steps + warmup
@@ -484,7 +484,7 @@ def run_hmf(args, name, steps, warmup, with_cpu=False):
             if args.ring and k + 1 < k1:
                 un, in_ = batches[(k + 1) % nb]
                 model.prepare_next(un, in_, pool_of(k + 1))
-            model.step_async(None, u, i, None, pool, None, loss='mw')
+            model.step_async(None, u, i, None, pool, None, loss=loss)
             drawn.pop(k, None)
 
     run(0, warmup)
@@ -513,10 +513,14 @@ def run_hmf(args, name, steps, warmup, with_cpu=False):
     out = {
         "value": B * steps / wall, "unit": "interactions/s", "steps": steps, "warmup": warmup,
         "ms_per_step": 1e3 * wall / steps,
-        "config": {"workload": "%s; synthetic %d-item/%d-user HMF, dim %d, WMRB 'mw' loss, %d shared "
+        "config": {"workload": "%s; synthetic %d-item/%d-user HMF, dim %d, %s, %d shared "
                                "negatives/step (pool redrawn on device every %d steps, %d redraw(s) inside the "
                                "timed region), Adagrad, B=%d interactions/step"
-                               % (label, args.n_items, args.n_users, d, S, args.n_resample, redraws[0], B),
+                               % (label, args.n_items, args.n_users, d,
+                                  "WMRB 'mw' loss" if loss == 'mw' else
+                                  "sampled softmax 'mce' (build-defined: the reference accepts the name and holds no "
+                                  "arithmetic for it) on its fused family, no [B, S] array",
+                                  S, args.n_resample, redraws[0], B),
                    "batch": B, "n_sampled": S, "dim": d, "n_items": args.n_items, "n_users": args.n_users,
                    "hipgraph": not args.no_graph, "pool_redraws_timed": redraws[0],
                    "next_batch_announced": bool(args.ring),
@@ -1126,6 +1130,9 @@ def main():
         try:
             if s in WORKLOADS:
                 r = run_hmf(args, s, args.sub_steps, min(args.warmup, 10))
+                r.pop("kernels", None)
+            elif s.endswith("mce") and s[:-3] in WORKLOADS:      # C2 / C3 with the sampled softmax (round 6: fused at d = 128)
+                r = run_hmf(args, s[:-3], args.sub_steps, min(args.warmup, 10), loss='mce')
                 r.pop("kernels", None)
             elif s in ("c4", "c4mce"):
                 r = run_lstm(args, 'mce' if s == "c4mce" else 'mw', min(args.sub_steps, 30), 5)

@@ -513,7 +513,7 @@ int arx_loss_mce_fused_pos(const float* logits, int64_t ldl, const float* U, int
  *     product is complete, there is no bwd_du), and in `state` the planes of U and coef U, coef, -t.
  *   arx_mce_scorer_bwd_di_loss: dI[s, :] = beta dI[s, :] + sum_r w_rs U[r, :], db[s] = sum_r w_rs; pbias = the pool
  *     bias and mask_rows the mask_rows the forward was given; step_rows / dI_steps / db_steps / loss_out as in arx_mw_scorer_bwd_di_loss.
- * Shapes: d == 64, S % 128 == 0, 128 <= S <= 2048, B >= 1, rows 16-byte aligned; arx_mce_scorer_supported tells,
+ * Shapes: d in {64, 128} (128: round 6), S % 128 == 0, 128 <= S <= 2048, B >= 1, rows 16-byte aligned; arx_mce_scorer_supported tells,
  * callers take arx_gemm_f32 + arx_loss_mce_fused_pos otherwise.  `state`: arx_mce_scorer_state_bytes bytes, 256-byte
  * aligned, zeroed once, private to one (model, stream). */
 int arx_mce_scorer_supported(int64_t B, int64_t S, int d);

@@ -46,7 +46,7 @@ def assert_mw_scorer_path(plan, rows, S, d):
 
 
 def assert_scorer_path(plan, rows, S, d, kind):
-    """... for 'mw' or the build-defined 'mce' (ops.mce_scorer_supported: the k_mc_flow family, d == 64)."""
+    """... for 'mw' or the build-defined 'mce' (ops.mce_scorer_supported: the k_mc_flow family, d in {64, 128})."""
     from arx import graph as G, ops
     bls = [n for n in plan.order if isinstance(n, G.BatchLoss) and n.kind == kind]
     assert bls, "no %r loss node in the plan" % kind

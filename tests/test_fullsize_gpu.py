@@ -241,10 +241,11 @@ def _check_tables(model, oracle):
             _cmp_rows(t.bias_name, oracle.t[t.bias_name], t.bias, t.bias_acc)
 
 
-@pytest.mark.parametrize("layout", ['id', 'het', 'mix'])
-def test_fullsize_hmf_matches_embedding_space_oracle(dev, layout):
+@pytest.mark.parametrize("layout,loss", [('id', 'mw'), ('het', 'mw'), ('mix', 'mw'), ('id', 'mce'), ('het', 'mce')])
+def test_fullsize_hmf_matches_embedding_space_oracle(dev, layout, loss):
     """C2 / C3 (HET and MIX layouts) at 1 M x 1 M, d = 128, B = 16384, S = 1024: three consecutive
-    'mw' steps (pool drawn at step 0, fresh batch every step) against oracle/ref_embed.py.
+    'mw' steps (pool drawn at step 0, fresh batch every step) against oracle/ref_embed.py; round 6: the same with
+    the build-defined sampled softmax 'mce' on its fused family at d = 128 (no [B, S] array on the device).
     Checked after step 1 and after step 3: the loss of every step (rtol 1e-4), every touched row
     of every table and bias with its Adagrad slot (rtol 1e-4); rows the oracle did not touch are
     covered by the locality test above."""
@@ -254,10 +255,10 @@ def test_fullsize_hmf_matches_embedding_space_oracle(dev, layout):
     kw = {'id': {}, 'het': dict(item_mulhot=True), 'mix': dict(item_mix=True)}[layout]
     syn = SyntheticHMF(n_users=N, n_items=N, permute_logits=False, seed=0, **kw)
     model = LatentProductModel(N, N, D, 1, B, 0.1, 1.0, syn.u_attr, syn.i_attr, syn.item2logit[:N],
-                               syn.logit_ind2item_ind, loss_function='mw', n_sampled=S, seed=0)
+                               syn.logit_ind2item_ind, loss_function=loss, n_sampled=S, seed=0)
     model.prepare_warp(syn.positives_csr(), syn.positives_csr())
     params0 = model.att_emb.get_params()
-    oracle = ref_embed.EmbedSpaceHMF(syn.u_attr, syn.i_attr, params0, 0.1, loss='mw')
+    oracle = ref_embed.EmbedSpaceHMF(syn.u_attr, syn.i_attr, params0, 0.1, loss=loss)
     ptr, pit = syn.positives_csr()
     d_ = model.rt.device
     rng = np.random.default_rng(1)
@@ -271,10 +272,12 @@ def test_fullsize_hmf_matches_embedding_space_oracle(dev, layout):
         ps = pool if step == 0 else None
         l_ref = oracle.step(u, i, ps, ptr, pit)
         l_got = model.step(None, torch.from_numpy(u).to(d_), torch.from_numpy(i).to(d_), None,
-                           torch.from_numpy(ps).to(d_) if ps is not None else None, None, loss='mw')
+                           torch.from_numpy(ps).to(d_) if ps is not None else None, None, loss=loss)
         np.testing.assert_allclose(l_got, l_ref, rtol=1e-4, err_msg='loss, step %d' % step)
         if step in (0, 2):
             _check_tables(model, oracle)
+    from conftest import assert_scorer_path
+    assert_scorer_path(model._plan('train'), B, S, D, loss)             # the fused family of the loss ran (unless switched off)
 
 
 @pytest.mark.parametrize("loss", ['mw', 'mce'])

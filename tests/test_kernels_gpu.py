@@ -1569,16 +1569,16 @@ def test_mw_scorer(dev, B, S, d, mask_rows, maxpos):
                                                         (1, 128, 0, 30, False), (4096, 512, 1024, 30, True),
                                                         (515, 2048, 0, 100, True), (2048, 1024, 0, 400, True),
                                                         (5120, 1024, 1024, 30, False)])
-def test_mce_scorer(dev, B, S, mask_rows, maxpos, bias):
+@pytest.mark.parametrize("d", [64, 128])
+def test_mce_scorer(dev, B, S, mask_rows, maxpos, bias, d):
     """The build-defined sampled softmax 'mce' on the fused family (csrc/scorer.hip k_mc_flow / k_mc_rows:
-    arx_mce_scorer_fwd / _bwd_di_loss, d = 64) against the oracle's logits -> compute_loss('mce') ->
+    arx_mce_scorer_fwd / _bwd_di_loss, d = 64 and -- round 6 -- d = 128) against the oracle's logits -> compute_loss('mce') ->
     compute_loss_bwd chain in f64: loss, target score, dt, dT = dt U, the COMPLETE latent gradient dU = dl . P + dt T
     out of the forward, then dI = beta dI + dl^T . U, db, the step's scalar loss and the per-time-step products.  No
     [B, S] array exists on the device; the positives of the row's user are masked pairs (maxpos = 400: rows with
     dozens of them in the pool); B = 515 / 77 / 1: ragged stationary and stream tiles; S = 2048: four column splits."""
     from arx import ops
     import torch
-    d = 64
     assert ops.mce_scorer_supported(B, S, d)
     rng = np.random.default_rng(B + S + 1)
     U = (rng.standard_normal((B, d)) * 0.4).astype(np.float32)

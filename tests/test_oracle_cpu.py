@@ -321,13 +321,16 @@ def test_library_exports_every_symbol_of_arx_h():
 
 def test_scorer_family_shape_predicates_and_state_sizes():
     """Host logic of the fused scorer families (no compute, no GPU): which shapes they take and what state they ask
-    of the caller -- arx_mw_scorer_* (d in {64, 128}), arx_mce_scorer_* (d == 64), arx_gemm_bt_bx6 (the LSTM's dx)."""
+    of the caller -- arx_mw_scorer_* and arx_mce_scorer_* (d in {64, 128}; 'mce' at 128 since round 6), arx_gemm_bt_bx6
+    (the LSTM's dx)."""
     from arx import _lib
     L = _lib.lib
     assert L.arx_mw_scorer_supported(16384, 1024, 128) and L.arx_mw_scorer_supported(51200, 1024, 64)
     assert not L.arx_mw_scorer_supported(64, 1000, 128) and not L.arx_mw_scorer_supported(64, 1024, 32)
     assert L.arx_mce_scorer_supported(51200, 1024, 64) and L.arx_mce_scorer_supported(1, 128, 64)
-    for B, S, d in ((64, 1024, 128), (64, 1000, 64), (64, 4096, 64), (0, 1024, 64)):
+    assert L.arx_mce_scorer_supported(16384, 1024, 128)
+    assert L.arx_mce_scorer_state_bytes(16384, 1024, 128) > L.arx_mce_scorer_state_bytes(16384, 1024, 64)
+    for B, S, d in ((64, 1024, 32), (64, 1024, 256), (64, 1000, 64), (64, 4096, 64), (0, 1024, 64)):
         assert not L.arx_mce_scorer_supported(B, S, d)
         assert L.arx_mce_scorer_state_bytes(B, S, d) == 0
     # the state holds the O partials ([splits][Bp][64] f32) and four plane sets but NOTHING of size B x S x 4
@@ -736,7 +739,7 @@ def test_abi_argument_validation_without_gpu():
     assert lib.arx_sparse_adagrad_workspace_bytes(0) > 0
     assert lib.arx_sparse_adagrad_workspace_bytes(1 << 20) > lib.arx_sparse_adagrad_workspace_bytes(1 << 10)
     assert lib.arx_mw_scorer_supported(16384, 1024, 128) == 1 and lib.arx_mw_scorer_supported(16384, 1000, 128) == 0
-    assert lib.arx_mce_scorer_supported(51200, 1024, 64) == 1 and lib.arx_mce_scorer_supported(51200, 1024, 128) == 0
+    assert lib.arx_mce_scorer_supported(51200, 1024, 64) == 1 and lib.arx_mce_scorer_supported(51200, 1024, 96) == 0
     assert lib.arx_mw_scorer_state_bytes(16384, 1024, 128) > 16384 * 1024 // 8       # at least the activity bits
     # a workspace that is too small is refused before any launch
     need = lib.arx_sparse_adagrad_workspace_bytes(4096)

@@ -1,6 +1,6 @@
 """Micro-benchmark of the fused 'mce' family (csrc/scorer.hip k_mc_flow): every launch group of the forward alone and
 the pool-side backward, against the materialising path (logits GEMM + loss kernel + two GEMMs).
-usage: python tools/mcebench.py [B S [mask_rows]]   (d = 64)"""
+usage: python tools/mcebench.py [B S [mask_rows [d]]]   (d = 64 or 128)"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,7 +25,7 @@ def main():
     a = [int(x) for x in sys.argv[1:]]
     B, S = (a + [51200, 1024])[:2] if len(a) < 2 else a[:2]
     mrows = a[2] if len(a) > 2 else 0
-    d = 64
+    d = a[3] if len(a) > 3 else 64
     dev = torch.device('cuda', 0)
     g = torch.Generator(device=dev)
     g.manual_seed(0)
