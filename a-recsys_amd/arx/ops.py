@@ -739,28 +739,36 @@ class BagCSC(object):
         import numpy as np
         dev = vals.device
         v = vals.detach().cpu().numpy()
-        st = starts.detach().cpu().numpy().astype(np.int64)
         ln = np.clip(lens.detach().cpu().numpy().astype(np.int64), 0, int(max_len))
         n_ent, nv = int(ln.shape[0]), int(v.shape[0])
-        st = st[:n_ent]
+        st = starts.detach().cpu().numpy().astype(np.int64)[:n_ent]
         tot = int(ln.sum())
+        assert nv < (1 << 31) and tot < (1 << 31)
+        # every CSR position may belong to ONE bag only (it gets one place): ranges of non-empty bags, in start order,
+        # must not overlap and must lie inside vals
+        live = np.nonzero(ln > 0)[0]
+        o_ = live[np.argsort(st[live], kind='stable')]
+        inside = bool(live.size == 0 or (st[o_[0]] >= 0 and st[o_[-1]] + ln[o_[-1]] <= nv))
+        self.ok = inside and bool(np.all(st[o_[:-1]] + ln[o_[:-1]] <= st[o_[1:]]))
+        self.nq, self.n_ent = 0, n_ent
+        if not self.ok:
+            self.qpos = self.qte = None
+            return
         ent = np.repeat(np.arange(n_ent, dtype=np.int32), ln)
-        pos = np.repeat(st - (np.cumsum(ln) - ln), ln) + np.arange(tot, dtype=np.int64)   # CSR position of every pair
-        keep = (pos >= 0) & (pos < nv)
-        tok = np.full(tot, -1, dtype=np.int64)
-        tok[keep] = v[pos[keep]]
-        keep &= (tok >= 0) & (tok < int(table_rows))
-        pos, ent, tok = pos[keep], ent[keep], tok[keep].astype(np.int32)
+        pos = np.repeat((st - (np.cumsum(ln) - ln)).astype(np.int32), ln) + np.arange(tot, dtype=np.int32)
+        tok = v[pos]                                   # CSR position and token of every pair, (entity, position) order
+        bad = (tok < 0) | (tok >= int(table_rows))
+        if bad.any():                                  # tokens outside the table are dropped (as the step's sort does)
+            keep = ~bad
+            pos, ent, tok = pos[keep], ent[keep], tok[keep]
         # stable order by token: LSD passes over 16-bit digits (numpy's stable sort is a radix sort for those)
         order = np.argsort((tok & 0xffff).astype(np.uint16), kind='stable')
         if int(table_rows) > (1 << 16):
             order = order[np.argsort((tok[order] >> 16).astype(np.uint16), kind='stable')]
         nq = int(order.shape[0])
         qpos = np.full(max(nv, 1), -1, dtype=np.int32)
-        ps = pos[order]
-        qpos[ps] = np.arange(nq, dtype=np.int32)
-        self.ok = bool(nq < (1 << 31) and np.array_equal(qpos[ps], np.arange(nq, dtype=np.int32)))
-        self.nq, self.n_ent = nq, n_ent
+        qpos[pos[order]] = np.arange(nq, dtype=np.int32)
+        self.nq = nq
         qte = np.empty((max(nq, 1), 2), dtype=np.int32)
         qte[:nq, 0] = tok[order]
         qte[:nq, 1] = ent[order]

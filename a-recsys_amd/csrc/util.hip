@@ -687,6 +687,7 @@ int arx_graph_set_feed(void* graph_exec, void* feeds, int idx, int count, const 
 int arx_graph_feeds_destroy(void* feeds) {
   FeedNodes* fn = reinterpret_cast<FeedNodes*>(feeds);
   if (fn) {
+    (void)hipDeviceSynchronize();            // (see arx_graph_destroy)
     (void)hipGraphDestroy(fn->g);
     delete[] fn->node;
     delete fn;
@@ -701,7 +702,14 @@ int arx_graph_launch(void* graph_exec, void* stream) {
 }
 
 int arx_graph_destroy(void* graph_exec) {
-  if (graph_exec) ARX_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  // Destroyed at a QUIET device: an executable graph destroyed while launches of ANOTHER executable graph were still in
+  // flight made that graph's next hipGraphLaunch segfault inside the runtime (round 6, ROCm 7.0: bench.py's last
+  // workload, whenever Python's cyclic collector freed an earlier workload's plan in the middle of its replay loop).
+  // Destruction is rare (a plan dies with its model); the synchronisation costs one pipeline bubble.
+  if (graph_exec) {
+    (void)hipDeviceSynchronize();
+    ARX_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  }
   return ARX_OK;
 }
 

@@ -437,6 +437,18 @@ WORKLOADS = {
 }
 
 
+def _quiesce():
+    """Between two workloads of one process: the finished workload's models (plans, captured hipGraphs) sit in reference
+    cycles, so they are destroyed whenever the cyclic collector next runs -- if that is in the middle of the NEXT
+    workload's replay loop, hipGraphExecDestroy runs beside its hipGraphLaunch calls, and the launch segfaulted in the
+    HIP runtime (round 6: 2 of 3 default runs, always in the last graph workload, never with fewer workloads in front of
+    it).  Collect and synchronise at the quiet point instead."""
+    import gc
+    torch.cuda.synchronize()
+    gc.collect()
+    torch.cuda.synchronize()
+
+
 def run_hmf(args, name, steps, warmup, with_cpu=False, loss='mw'):
     from arx.hmf.hmf_model import LatentProductModel
     from arx.utils.synthetic import SyntheticHMF
@@ -1126,6 +1138,7 @@ def main():
             out[k] = head[k]
     subs = [s for s in args.subs.split(",") if s and s != args.workload]
     sub = {}
+    _quiesce()
     for s in subs:
         try:
             if s in WORKLOADS:
@@ -1158,6 +1171,7 @@ def main():
             sub[s] = r
         except Exception as e:      # a sub-result must never take the headline line down
             sub[s] = {"error": "%s: %s" % (type(e).__name__, e)}
+        _quiesce()
     if sub:
         out["sub"] = sub
     if not args.no_cpu_baseline:

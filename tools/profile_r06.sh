@@ -15,6 +15,7 @@ done
 cd $REPO
 bash tools/profile.sh r06_c3_b16384
 bash tools/profile.sh r06_c2_b16384 --workload c2
+bash tools/profile.sh r06_c3mix_b16384 --workload c3mix      # (the layout whose token list is never sorted: csc.hip)
 # K1 past the LLC: the launch bench.py's `k1` sub-result times, under the two PMC passes + kernel stats
 cd /tmp
 rm -rf /tmp/k1ks
@@ -48,6 +49,9 @@ bash tools/trace_cmd.sh r06_c3 k_sc_prep --subs "" --no-rooflines --repeats 1 > 
 mv gpurun_out/tr_r06_c3.txt $OUT/r06_c3_step_timeline.txt 2>/dev/null
 bash tools/r06_abl.sh 2 > /dev/null 2>&1
 cp gpurun_out/r06abl/log.txt $OUT/r06_k7_halves_ablation.txt 2>/dev/null
+# the C3-MIX step timeline (static token order + split apply), the sampled softmax at d = 128
+bash tools/trace_cmd.sh r06_c3mix k_sc_prep --workload c3mix --subs "" --no-rooflines --repeats 1 > /dev/null 2>&1
+mv gpurun_out/tr_r06_c3mix.txt $OUT/r06_c3mix_step_timeline_csc.txt 2>/dev/null
 # the bench lines as the driver runs them
 timeout 900 python bench.py > $OUT/r06_bench_default.json 2> $OUT/r06_bench_default.err
 cp bench_detail.json $OUT/r06_bench_default_detail.json 2>/dev/null
