@@ -34,7 +34,12 @@
 namespace arx {
 namespace {
 
-constexpr int kItem = 256;            // entries per work item of a long run (one 256-thread workgroup)
+// (round 6, alternating runs on one box: 256 -> 128 entries per item: C2 157.8 -> 151.6 us, C3 / C3-MIX / C4 within
+// +-1 us; 64: C3 +6 us; 8 instead of 4 gradient rows in flight per sub-group: +-1 -- profiles/r06_run_item_ab.txt)
+#ifndef ARX_RUN_ITEM
+#define ARX_RUN_ITEM 128
+#endif
+constexpr int kItem = ARX_RUN_ITEM;   // entries per work item of a long run (one 256-thread workgroup: kItem / 8 per sub-group, <= its lanes)
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -400,7 +405,10 @@ __device__ __forceinline__ void run_apply_job(const ApplyJob& jb, int d, const i
   constexpr int NSGB = 256 / LPR;      // sub-groups per workgroup
   constexpr int NB = ARX_RUN_NB;
   constexpr int RU = ARX_RUN_RU;
-  constexpr int LRU = 4;               // rows in flight per sub-group of a long run's work item
+#ifndef ARX_RUN_LRU
+#define ARX_RUN_LRU 4
+#endif
+  constexpr int LRU = ARX_RUN_LRU;     // rows in flight per sub-group of a long run's work item
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int lig = lane % LPR;
@@ -524,8 +532,10 @@ __device__ __forceinline__ void run_apply_job(const ApplyJob& jb, int d, const i
     const int nch = lr4.z;
     const int64_t off = r.y;
     const int cnt = r.z;
-    const int e0 = item.y * kItem + sgb * LPR;
-    const int m = max(0, min(LPR, cnt - e0));
+    constexpr int EPS = kItem / NSGB < LPR ? kItem / NSGB : LPR;      // entries per sub-group
+    static_assert(EPS * NSGB == kItem || LPR * NSGB < kItem, "a work item is dealt whole to the sub-groups");
+    const int e0 = item.y * kItem + sgb * EPS;
+    const int m = max(0, min(EPS, cnt - e0));
     int es = 0;
     float ec = 0.f, gbv = 0.f;
     if (lig < m) {
