@@ -16,9 +16,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _bench(extra, timeout=900, env_extra=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra or {})
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
-    assert r.returncode == 0, (r.stdout.decode(errors="replace")[-2000:], r.stderr.decode(errors="replace")[-3000:])
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    if r.returncode != 0:
+        # one retry: inside the full suite (never alone: 18 of 18) a launch failed about once in four suite runs --
+        # the rendezvous of a self-launched job next to the leftovers of the suite's other multi-process tests; the
+        # first failure is shown, a second one fails the test with both outputs
+        first = (r.returncode, r.stdout.decode(errors="replace")[-1500:], r.stderr.decode(errors="replace")[-3000:])
+        print("bench.py failed once (rc %d), retrying; its stderr tail:\n%s" % (first[0], first[2]), file=sys.stderr)
+        import time
+        time.sleep(5)
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+        assert r.returncode == 0, (first, r.stdout.decode(errors="replace")[-2000:], r.stderr.decode(errors="replace")[-3000:])
     out = r.stdout.decode(errors="replace").splitlines()
     lines = [l for l in out if l.startswith("{")]
     assert len(lines) == 1 and out[-1] == lines[0], lines       # ONE JSON line, and it is the LAST line
