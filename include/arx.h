@@ -962,6 +962,9 @@ int arx_seq_weights(const float* w, int64_t L, int64_t B, float* out, void* stre
 int arx_capture_begin(void* stream);
 int arx_capture_end(void* stream, void** graph_exec_out);
 int arx_graph_launch(void* graph_exec, void* stream);
+/* Synchronises the DEVICE first (as does arx_graph_feeds_destroy): on ROCm 7.0 an executable graph destroyed while launches
+ * of another executable graph are in flight makes that graph's next launch segfault inside the runtime -- and a host
+ * language's collector may destroy a plan at any time.  Rare (a plan dies with its model); one pipeline bubble. */
 int arx_graph_destroy(void* graph_exec);
 /* Placeholder feeds as nodes of the captured step: arx_copy_words launches issued INSIDE the capture become
  * graph nodes whose (source, destination, length) triples are replaced before a replay -- one submission per
