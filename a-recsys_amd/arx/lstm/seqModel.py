@@ -736,12 +736,14 @@ class SeqModel(SeqBatching):
 
         def put(dst, src, dtype):
             """device tensors are queued (all feeds of the step leave as one copy launch when the
-            plan runs); host data goes up with one H2D copy"""
+            plan runs); host data is packed into the step's pinned slab and goes up with ONE H2D copy"""
             if isinstance(src, torch.Tensor) and src.is_cuda and src.dtype == dtype and src.is_contiguous():
                 rt.queue_feed(src, dst)
             else:
                 if not isinstance(src, torch.Tensor):
                     src = torch.from_numpy(np.ascontiguousarray(src))
+                if not src.is_cuda and src.dtype == dtype and rt.host_feed(dst, src.numpy()):
+                    return                        # host arrays: the step's pinned slab (Runtime.host_feed)
                 rt.drop_feed(dst)
                 dst.copy_(src.reshape(-1), non_blocking=True)
 

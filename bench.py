@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--no-anchor", action="store_true",
                     help="N > 1: do not run the world-1 anchor of the same workload after the N-rank run")
     ap.add_argument("--mulhot", action="store_true", help="(compat) same as --workload c3")
-    ap.add_argument("--subs", default="c2,c3mix,c3mce,c4,c4mce,k1,c5w1,c3repw1,topk,c3_f32mfma,c2_f32mfma",
+    ap.add_argument("--subs", default="c2,c3mix,c3mce,c3host,c4,c4mce,c4host,k1,c5w1,c3repw1,topk,c3_f32mfma,c2_f32mfma",
                     help="comma list of sub-results besides the headline ('' = none)")
     ap.add_argument("--sub-steps", type=int, default=50)
     ap.add_argument("--repeats", type=int, default=5,
@@ -449,7 +449,7 @@ def _quiesce():
     torch.cuda.synchronize()
 
 
-def run_hmf(args, name, steps, warmup, with_cpu=False, loss='mw'):
+def run_hmf(args, name, steps, warmup, with_cpu=False, loss='mw', host_feed=False):
     from arx.hmf.hmf_model import LatentProductModel
     from arx.utils.synthetic import SyntheticHMF
     from arx.utils.prepare_train import DeviceSampler
@@ -473,7 +473,13 @@ def run_hmf(args, name, steps, warmup, with_cpu=False, loss='mw'):
     batches = []
     for _ in range(nb):
         u, i = syn.sample_batch(B, rng)
-        batches.append((torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev)))
+        if host_feed:
+            # the reference's own hand-over (hmf_model.py:162-175 step(): python lists into feed_dict): the ids of a
+            # step arrive as pageable host arrays and cross PCIe inside the timed region -- reported as a sub-result
+            # (`c3host`), never as `value`
+            batches.append((np.ascontiguousarray(u, dtype=np.int32), np.ascontiguousarray(i, dtype=np.int32)))
+        else:
+            batches.append((torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev)))
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
     redraws = [0]
@@ -536,6 +542,8 @@ def run_hmf(args, name, steps, warmup, with_cpu=False, loss='mw'):
                    "batch": B, "n_sampled": S, "dim": d, "n_items": args.n_items, "n_users": args.n_users,
                    "hipgraph": not args.no_graph, "pool_redraws_timed": redraws[0],
                    "next_batch_announced": bool(args.ring),
+                   "ids_fed_from": ("host (pageable numpy int32, 2 x %d B per step over PCIe inside the timed region)"
+                                    % (4 * B)) if host_feed else "HBM (device-resident ring of batches)",
                    "host_enqueue_ms_per_step": 1e3 * hosts[med] / steps,
                    "sampled_negative_logits_per_s": B * S * steps / wall,
                    "pool_rows_per_s": S * steps / wall, "hip_event_ms_per_step": ev_ms / steps,
@@ -610,7 +618,7 @@ def run_hmf(args, name, steps, warmup, with_cpu=False, loss='mw'):
     return out
 
 
-def run_lstm(args, loss, steps, warmup):
+def run_lstm(args, loss, steps, warmup, host_feed=False):
     """C4 (BASELINE configs[3]): LSTM seqModel d = h = 64, L = 50, 1 M items, S = 1024 sampled
     negatives, use_concat=False, clip 5.0, Adagrad lr 0.5; targets/s = sum(weights)/wall
     (lstm/run.py:466-470).  loss 'mw' (reference arithmetic) or 'mce' (build-defined sampled
@@ -640,8 +648,13 @@ def run_lstm(args, loss, steps, warmup):
         inp = np.concatenate([np.full((1, B), START, dtype=np.int32), tg[:-1]], 0)
         lens = rng.integers(10, L + 1, size=B)
         w = (np.arange(L)[:, None] < lens[None, :]).astype(np.float32)
-        batches.append((torch.from_numpy(users).to(dev), torch.from_numpy(inp).to(dev),
-                        torch.from_numpy(tg).to(dev), torch.from_numpy(w).to(dev), float(w.sum())))
+        if host_feed:
+            # the reference's hand-over (seqModel.py:289-404 get_batch -> step(): host arrays into feed_dict): ids and
+            # weights cross PCIe inside the timed region -- the `c4host` sub-result, never `value`
+            batches.append((users, np.ascontiguousarray(inp), np.ascontiguousarray(tg), w, float(w.sum())))
+        else:
+            batches.append((torch.from_numpy(users).to(dev), torch.from_numpy(inp).to(dev),
+                            torch.from_numpy(tg).to(dev), torch.from_numpy(w).to(dev), float(w.sum())))
     pool = torch.from_numpy(syn.sample_pool(S, rng)).to(dev)
     setup_s = time.time() - t0
 
@@ -668,6 +681,9 @@ def run_lstm(args, loss, steps, warmup):
                                      " (build-defined sampled softmax: no reference arithmetic, no parity claim)"
                                      if loss == 'mce' else ""),
                       "timestep_rows_per_s": L * B * steps / wall, "final_loss_per_target": per_target,
+                      "ids_fed_from": ("host (pageable numpy: users, inputs, targets, weights = %d B per step over "
+                                       "PCIe inside the timed region)" % (4 * B + 12 * L * B)) if host_feed
+                      else "HBM (device-resident ring of batches)",
                       "setup_s": setup_s}}
     if not args.no_rooflines:
         plan = model._plan(0, 'train')
@@ -1003,8 +1019,13 @@ def main_seq_hybrid(args, world, rank, local_rank):
         inp = np.concatenate([np.full((1, B), START, dtype=np.int32), tg[:-1]], 0)
         lens = rng.integers(10, L + 1, size=B)
         w = (np.arange(L)[:, None] < lens[None, :]).astype(np.float32)
-        batches.append((torch.from_numpy(users).to(dev), torch.from_numpy(inp).to(dev),
-                        torch.from_numpy(tg).to(dev), torch.from_numpy(w).to(dev), float(w.sum())))
+        if host_feed:
+            # the reference's hand-over (seqModel.py:289-404 get_batch -> step(): host arrays into feed_dict): ids and
+            # weights cross PCIe inside the timed region -- the `c4host` sub-result, never `value`
+            batches.append((users, np.ascontiguousarray(inp), np.ascontiguousarray(tg), w, float(w.sum())))
+        else:
+            batches.append((torch.from_numpy(users).to(dev), torch.from_numpy(inp).to(dev),
+                            torch.from_numpy(tg).to(dev), torch.from_numpy(w).to(dev), float(w.sum())))
     pool = torch.from_numpy(syn.sample_pool(S, np.random.default_rng(5))).to(dev)      # the same pool on every rank
     setup_s = time.time() - t0
 
@@ -1147,8 +1168,14 @@ def main():
             elif s.endswith("mce") and s[:-3] in WORKLOADS:      # C2 / C3 with the sampled softmax (round 6: fused at d = 128)
                 r = run_hmf(args, s[:-3], args.sub_steps, min(args.warmup, 10), loss='mce')
                 r.pop("kernels", None)
+            elif s.endswith("host") and s[:-4] in WORKLOADS:     # the step with its ids handed over as host arrays
+                r = run_hmf(args, s[:-4], args.sub_steps, min(args.warmup, 10), host_feed=True)
+                r.pop("kernels", None)
             elif s in ("c4", "c4mce"):
                 r = run_lstm(args, 'mce' if s == "c4mce" else 'mw', min(args.sub_steps, 30), 5)
+            elif s == "c4host":
+                r = run_lstm(args, 'mw', min(args.sub_steps, 30), 5, host_feed=True)
+                r.pop("roofline", None)
             elif s == "k1":
                 r = k1_past_llc(torch.device('cuda', 0), args.dim)
                 # the gather's headline is this PHYSICAL measurement (2 GB table, 8x the LLC); the step's own

@@ -592,6 +592,49 @@ def test_hmf_feed_nodes_unsynchronised_run(dev, cfg):
     assert m_nodes._plan('train').graph.feed_groups
 
 
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_hmf_host_fed_steps_staged_slab_bit_identical(dev, use_graph):
+    """The reference's own hand-over: the ids of a step as HOST arrays (hmf_model.py:162-175 step() puts python lists
+    into feed_dict).  Runtime.host_feed packs them into a pinned slab, one asynchronous copy on a side stream, then the
+    device feeds' route; four slabs in turn.  40 steps enqueued without a host synchronisation (the slabs are reused
+    ten times while earlier steps are still running), a new batch every step, lists and numpy arrays mixed: losses
+    and tables equal, bit for bit, the direct pageable copies (ARX_STAGE_FEEDS=0's form) and the device-resident
+    batches."""
+    import torch
+    B, S, d = 2048, 256, 64
+    steps = 40
+    rng = np.random.default_rng(7)
+    syn0, m_stage, _ = _build(CFG_HET, 'mw', d, B, S, seed=13, use_graph=use_graph)
+    _, m_direct, _ = _build(CFG_HET, 'mw', d, B, S, seed=13, use_graph=use_graph)
+    _, m_dev, _ = _build(CFG_HET, 'mw', d, B, S, seed=13, use_graph=use_graph)
+    assert m_stage.rt.stage_host_feeds
+    m_direct.rt.stage_host_feeds = False
+    dev_ = m_stage.rt.device
+    batches = [syn0.sample_batch(B, rng) for _ in range(steps)]
+    pools = {0: syn0.sample_pool(S, rng), 17: syn0.sample_pool(S, rng)}
+    out = {}
+    for name, m in (('stage', m_stage), ('direct', m_direct), ('dev', m_dev)):
+        losses = torch.zeros(steps, dtype=torch.float32, device=dev_)
+        torch.cuda.synchronize()
+        for k in range(steps):
+            u, i = batches[k]
+            p = pools.get(k)
+            if name == 'dev':
+                u, i = torch.from_numpy(u.astype(np.int32)).to(dev_), torch.from_numpy(i.astype(np.int32)).to(dev_)
+                p = None if p is None else torch.from_numpy(p.astype(np.int32)).to(dev_)
+            elif k % 2:
+                u, i = u.tolist(), i.tolist()            # (python lists, as run.py hands them over)
+            node = m.step_async(None, u, i, None, p, None, loss='mw')
+            losses[k:k + 1].copy_(node.read().reshape(1), non_blocking=True)
+        torch.cuda.synchronize()
+        out[name] = (losses.cpu().numpy(), m.att_emb.get_params())
+    assert m_stage.rt._stage is not None and m_direct.rt._stage is None and m_dev.rt._stage is None
+    for other in ('direct', 'dev'):
+        assert np.array_equal(out['stage'][0], out[other][0]), (other, out['stage'][0], out[other][0])
+        for pn in out['stage'][1]:
+            assert np.array_equal(out['stage'][1][pn], out[other][1][pn]), (other, pn)
+
+
 def test_hmf_empty_pool_slot_is_out_of_the_loss(dev):
     """A negative id in the sampled pool (what DeviceSampler.sample leaves where a short capped draw could not fill a
     position) is an EMPTY slot: it looks nothing up -- no read of cat_map[-1] / E[-1] (advisor, round 4) --, receives
