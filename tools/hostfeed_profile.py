@@ -29,4 +29,26 @@ for k in range(300):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("tottime").print_stats(14)
+# the synchronous step() of the reference API (a float back per step): no back-pressure, the host costs are the true ones
+import time
+for mode in ("host", "dev"):
+    if mode == "dev":
+        bs = [tuple(torch.from_numpy(x).to(model.rt.device) for x in b) for b in bs]
+    for k in range(10):
+        model.step(None, bs[k % 16][0], bs[k % 16][1], None, None, None, loss='mw')
+    t0 = time.time()
+    for k in range(300):
+        model.step(None, bs[k % 16][0], bs[k % 16][1], None, None, None, loss='mw')
+    print("synchronous step(), ids from %s: %.1f us per step" % (mode, (time.time() - t0) / 300 * 1e6))
+    t0 = time.time()
+    for k in range(300):
+        model.step_async(None, bs[k % 16][0], bs[k % 16][1], None, None, None, loss='mw')
+    torch.cuda.synchronize()
+    print("step_async, ids from %s: %.1f us per step" % (mode, (time.time() - t0) / 300 * 1e6))
+pr = cProfile.Profile()
+pr.enable()
+for k in range(300):
+    model.step(None, bs[k % 16][0], bs[k % 16][1], None, None, None, loss='mw')
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(16)
