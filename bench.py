@@ -1019,13 +1019,8 @@ def main_seq_hybrid(args, world, rank, local_rank):
         inp = np.concatenate([np.full((1, B), START, dtype=np.int32), tg[:-1]], 0)
         lens = rng.integers(10, L + 1, size=B)
         w = (np.arange(L)[:, None] < lens[None, :]).astype(np.float32)
-        if host_feed:
-            # the reference's hand-over (seqModel.py:289-404 get_batch -> step(): host arrays into feed_dict): ids and
-            # weights cross PCIe inside the timed region -- the `c4host` sub-result, never `value`
-            batches.append((users, np.ascontiguousarray(inp), np.ascontiguousarray(tg), w, float(w.sum())))
-        else:
-            batches.append((torch.from_numpy(users).to(dev), torch.from_numpy(inp).to(dev),
-                            torch.from_numpy(tg).to(dev), torch.from_numpy(w).to(dev), float(w.sum())))
+        batches.append((torch.from_numpy(users).to(dev), torch.from_numpy(inp).to(dev),
+                        torch.from_numpy(tg).to(dev), torch.from_numpy(w).to(dev), float(w.sum())))
     pool = torch.from_numpy(syn.sample_pool(S, np.random.default_rng(5))).to(dev)      # the same pool on every rank
     setup_s = time.time() - t0
 
