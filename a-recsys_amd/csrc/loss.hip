@@ -564,6 +564,53 @@ __global__ __launch_bounds__(256) void k_loss_ce(
   }
 }
 
+// k_loss_ce for V <= 4096 (the C1 shape: V = 3100): the row is read ONCE into 16 registers per thread instead of three
+// dependent passes over it (9.5 us measured at 64 x 3100 -- three L2 round trips and two block reductions per row).
+// Same per-thread accumulation order (c = tid, tid + 256, ...) and the same block reductions: bit-identical results.
+__global__ __launch_bounds__(256) void k_loss_ce_regs(
+    const float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ target,
+    float gscale, const float* __restrict__ row_w, int64_t V, float* __restrict__ batch_loss,
+    float* dlogits, int64_t lddl) {
+  __shared__ float sh[4];
+  const int64_t r = blockIdx.x;
+  const float* x = logits + r * ldl;
+  const int tcol = target[r];
+  const bool bad = tcol < 0 || tcol >= V;               // see k_loss_margin
+  const float xt = bad ? NAN : x[tcol];
+  const float rw = row_w ? row_w[r] : 1.f;
+  float v[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int64_t c = threadIdx.x + u * 256;
+    v[u] = c < V ? x[c] : -INFINITY;
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) mx = fmaxf(mx, v[u]);
+  mx = block_max(mx, sh);
+  float se = 0.f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int64_t c = threadIdx.x + u * 256;
+    v[u] = expf(v[u] - mx);
+    if (c < V) se += v[u];
+  }
+  se = block_sum(se, sh);
+  if (threadIdx.x == 0 && batch_loss) batch_loss[r] = logf(se) + mx - xt;
+  if (!dlogits) return;
+  const float g = bad ? 0.f : gscale * rw;
+  const float inv = g / se;
+  float* dx = dlogits + r * lddl;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int64_t c = threadIdx.x + u * 256;
+    if (c < V) {
+      const float p = v[u] * inv;
+      dx[c] = (c == tcol) ? p - g : p;
+    }
+  }
+}
+
 // per-row logsumexp (softmax normaliser of the recommend path, seqModel.py:514-517)
 __global__ __launch_bounds__(256) void k_row_lse(const float* __restrict__ logits, int64_t ldl,
                                                  int64_t V, float* __restrict__ out) {
@@ -1011,8 +1058,12 @@ int arx_loss_ce_fwdbwd(const float* logits, int64_t ldl, const int32_t* target, 
   ARX_CHECK_ARG(logits && target, "arx_loss_ce_fwdbwd: null pointer");
   ARX_CHECK_ARG(B >= 0 && V > 0, "arx_loss_ce_fwdbwd: bad size");
   if (B == 0) return ARX_OK;
-  k_loss_ce<<<(int)B, 256, 0, as_stream(stream)>>>(logits, ldl, target, gscale, row_w, V,
-                                                   batch_loss, dlogits, lddl);
+  if (V <= 4096)
+    k_loss_ce_regs<<<(int)B, 256, 0, as_stream(stream)>>>(logits, ldl, target, gscale, row_w, V,
+                                                          batch_loss, dlogits, lddl);
+  else
+    k_loss_ce<<<(int)B, 256, 0, as_stream(stream)>>>(logits, ldl, target, gscale, row_w, V,
+                                                     batch_loss, dlogits, lddl);
   ARX_CHECK_LAUNCH();
   return ARX_OK;
 }
