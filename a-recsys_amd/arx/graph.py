@@ -13,6 +13,7 @@ raises NotImplementedError.  torch tensors are device-memory holders only.
 from __future__ import annotations
 
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -1699,6 +1700,17 @@ class Plan(object):
                     n._stale = True
 
 
+_STAGE_POOL = []     # pinned slab sets of collected runtimes (Runtime.host_feed)
+
+
+def _stage_release(pin):
+    try:
+        torch.cuda.synchronize()
+    except Exception:
+        pass
+    _STAGE_POOL.append(pin)
+
+
 class Runtime(object):
     def __init__(self, device=None, learning_rate=0.1, use_graph=True):
         if device is None:
@@ -1787,8 +1799,13 @@ class Runtime(object):
         st = self._stage
         if st is None:
             S, W = self._STAGE_SLOTS, self._STAGE_WORDS
-            st = self._stage = {'pin': [torch.empty(W, dtype=torch.int32).pin_memory() for _ in range(S)],
-                                'done': [None, None], 'k': 0, 'used': 0}
+            # the slabs outlive this runtime's last submitted step: a collected runtime hands them back to a module
+            # pool after a device synchronisation (the feed launch reads them in place -- the pinned allocator does
+            # not know about that reader and would recycle the block under it)
+            pin = _STAGE_POOL.pop() if _STAGE_POOL else [torch.empty(W, dtype=torch.int32).pin_memory()
+                                                         for _ in range(S)]
+            weakref.finalize(self, _stage_release, pin)
+            st = self._stage = {'pin': pin, 'done': [None, None], 'k': 0, 'used': 0}
             st['np'] = [b.numpy() for b in st['pin']]
         k = st['k']
         if st['used'] + n > self._STAGE_WORDS:

@@ -356,10 +356,6 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ceil_div(M, 64) * ceil_div(N, 64);
     int64_t want = ceil_div((int64_t)cus * 2, tiles);
     int64_t maxs = K / 128;  // keep >= 128 of K per split
-    // a handful of output tiles over a long K (the C1 shape's dU: 64 x 32 out of K = 3100): the kernel is a chain of
-    // K / 16 dependent load -> LDS -> multiply rounds per workgroup (~1 us each: 12 rounds = 14.5 us measured), so the
-    // splits go down to 64 of K (4 rounds; round 6)
-    if (tiles <= 4) maxs = K / 64;
     if (maxs < 1) maxs = 1;
     int64_t s = want < maxs ? want : maxs;
     if (s < 1) s = 1;
