@@ -898,7 +898,7 @@ def compact_line(out):
     line["config"] = _pick(c, ("batch", "n_sampled", "dim", "n_items", "n_users", "hipgraph", "pool_redraws_timed",
                                "hip_event_ms_per_step", "ms_per_step_min", "ms_per_step_max", "timed_regions",
                                "sampled_negative_logits_per_s", "final_loss", "parallelism", "world", "batch_per_gpu",
-                               "global_batch", "exchange", "routing_in_timed_region"))
+                               "global_batch", "exchange", "routing_in_timed_region", "ids_fed_from"))
     line["config"]["workload"] = _short(c.get("workload", ""), 260)
     # dominant pass of the step by time: K7 (HBM) / the hinge GEMM (MFMA) / the step's lookups (HBM)
     cands = [(k, out[k]) for k in ("roofline_hbm", "roofline", "roofline_gather")

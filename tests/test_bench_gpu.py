@@ -71,3 +71,17 @@ def test_bench_c4_hybrid_two_ranks_one_line(dev):
     assert j["config"]["global_batch"] == 256 and j["config"]["routing_in_timed_region"] is True
     pred = j["_detail"]["roofline_comm_predicted"]
     assert pred["at_8_ranks"]["us_total_at_link_rate"] < pred["seq_data_parallel_at_8_ranks"]["us_total_at_link_rate"]
+
+
+def test_bench_host_fed_subs(dev):
+    """`c3host` / `c4host`: the step with its ids handed over as host arrays (the reference's feed_dict boundary), the
+    transfer inside the timed region -- sub-results beside the HBM-resident headline, never `value`."""
+    j = _bench(["--gpus", "1", "--steps", "3", "--warmup", "2", "--sub-steps", "4", "--repeats", "1", "--n-items", "20000",
+                "--n-users", "2000", "--batch", "1024", "--lstm-batch", "64", "--n-sampled", "128", "--subs",
+                "c3host,c4host", "--no-rooflines", "--no-cpu-baseline"])
+    sub = j["_detail"]["sub"]
+    for k in ("c3host", "c4host"):
+        assert "error" not in sub[k], sub[k]
+        assert sub[k]["value"] > 0 and sub[k]["config"]["ids_fed_from"].startswith("host")
+    assert j["config"]["ids_fed_from"].startswith("HBM")
+    assert set(j["sub_ms_per_step"]) == {"c3host", "c4host"}
