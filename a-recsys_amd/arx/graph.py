@@ -1793,8 +1793,10 @@ class Runtime(object):
         """Feed the placeholder buffer `dst` (contiguous, 4-byte elements) from the host array `arr` (same element
         count, already of dst's dtype).  Returns False when the staged route is not available (caller copies directly)."""
         n = dst.numel()
-        if not (self.stage_host_feeds and dst.is_cuda and dst.is_contiguous() and dst.element_size() == 4
-                and arr.dtype.itemsize == 4 and arr.size == n and n <= self._STAGE_WORDS):
+        same = ((dst.dtype == torch.int32 and arr.dtype == np.int32)
+                or (dst.dtype == torch.float32 and arr.dtype == np.float32))
+        if not (self.stage_host_feeds and dst.is_cuda and dst.is_contiguous() and same and arr.size == n
+                and n <= self._STAGE_WORDS):
             return False
         st = self._stage
         if st is None:
